@@ -1,0 +1,697 @@
+/*
+ * obb_oracle.c -- CPU ORACLE for the oriented-bounding-box hot path.
+ *
+ * THIS FILE IS TEST INFRASTRUCTURE.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load it.  The product (aidet_amd/) never
+ * imports, links or executes anything in oracle/.
+ *
+ * PARITY STATUS: "parity unpinned" for the rotated arithmetic itself -- the
+ * reference (jwwangchn/aidet) ships no rotated IoU / rotated NMS / rotated
+ * RoI-Align; its polygon NMS lives in the un-vendored, un-pinned package
+ * `wwtool` (mmdet/datasets/dota.py:21-23,334-336).  What IS pinned, through
+ * tests/golden/ fixtures generated from the reference itself:
+ *   - greedy-NMS control flow, `>=` threshold, ascending keep order
+ *       mmdet/ops/nms/src/nms_cpu.cpp:5-60      (obbo_rnms_f32 below)
+ *   - HBB IoU values / +1 pixel convention at theta = 0
+ *       mmdet/core/bbox/geometry.py:47-88       (obbo_rbbox_overlaps_f32)
+ *   - RoIAlign sampling + bilinear rules at theta = 0
+ *       mmdet/ops/roi_align/src/roi_align_kernel_v2.cu:15-128 (V2)
+ *       mmdet/ops/roi_align/src/roi_align_kernel.cu:17-117    (V1)
+ *   - theta-OBB corner convention (cv2.boxPoints)
+ *       mmdet/core/rbbox/transforms.py:45-55
+ *
+ * ARITHMETIC SPEC ("OBB-GEOM v1").  Every fp32 routine below uses only
+ * + - * / comparisons and floorf, in a FIXED operation order, compiled with
+ * -ffp-contract=off.  The HIP kernels implement the same sequence, so integer
+ * results (keep indices) are bit-exact and float results agree to the last bit
+ * in practice (tests allow 1e-4 as BASELINE.json states).
+ *
+ * Plain C99.  Build: see oracle/Makefile.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define OBBO_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------ */
+/* deterministic sin/cos (no libm: glibc and ROCm OCML differ in ulps) */
+/* ------------------------------------------------------------------ */
+/* Cody-Waite reduction by pi/2 (3 constants), cephes-style minimax
+ * polynomials on [-pi/4, pi/4]; quadrant from k mod 4 in float arithmetic. */
+OBBO_API void obbo_sincos_f32(float x, float *s_out, float *c_out) {
+  float q = x * 0.636619772f;
+  float kf = floorf(q + 0.5f);
+  float r = x - kf * 1.5703125f;
+  r = r - kf * 4.837512969970703125e-4f;
+  r = r - kf * 7.54978995489188e-8f;
+  float z = r * r;
+  float sp = -1.9515295891e-4f * z;
+  sp = sp + 8.3321608736e-3f;
+  sp = sp * z;
+  sp = sp - 1.6666654611e-1f;
+  sp = sp * z;
+  sp = sp * r;
+  sp = sp + r;
+  float cp = 2.443315711809948e-5f * z;
+  cp = cp - 1.388731625493765e-3f;
+  cp = cp * z;
+  cp = cp + 4.166664568298827e-2f;
+  cp = cp * z;
+  cp = cp * z;
+  float hz = 0.5f * z;
+  cp = cp - hz;
+  cp = cp + 1.0f;
+  /* quadrant = kf mod 4, computed exactly in float */
+  float k4 = floorf(kf * 0.25f);
+  float kq = kf - 4.0f * k4; /* 0,1,2,3 */
+  float s, c;
+  if (kq == 0.0f) { s = sp; c = cp; }
+  else if (kq == 1.0f) { s = cp; c = -sp; }
+  else if (kq == 2.0f) { s = -sp; c = -cp; }
+  else { s = -cp; c = sp; }
+  *s_out = s;
+  *c_out = c;
+}
+
+/* ------------------------------------------------------------------ */
+/* box records                                                         */
+/* ------------------------------------------------------------------ */
+/* A "quad record" is what the pair routine consumes:
+ *   ox, oy            origin (box centre, or vertex 0 of a polygon)
+ *   rx[4], ry[4]      the 4 vertices RELATIVE to (ox,oy), positive orientation
+ *                     (shoelace sum > 0 in image coordinates)
+ *   ex, ey            AABB half extents measured from (ox,oy):  |rx|,|ry| max
+ *   area              w*h for a theta-OBB; |shoelace|/2 for a polygon
+ * theta-OBB meaning follows cv2.boxPoints (transforms.py:45-55):
+ *   x = cx + lx*cos(t) - ly*sin(t),  y = cy + lx*sin(t) + ly*cos(t).       */
+typedef struct {
+  float ox, oy;
+  float rx[4], ry[4];
+  float ex, ey;
+  float area;
+} obbo_quad;
+
+static inline float fabs_sel(float a) { return a < 0.0f ? -a : a; }
+static inline float max_sel(float a, float b) { return a < b ? b : a; }
+static inline float min_sel(float a, float b) { return b < a ? b : a; }
+
+OBBO_API void obbo_quad_from_rbox_f32(const float *b, obbo_quad *q) {
+  float cx = b[0], cy = b[1], w = b[2], h = b[3], th = b[4];
+  float s, c;
+  obbo_sincos_f32(th, &s, &c);
+  float hw = 0.5f * w, hh = 0.5f * h;
+  float ux = hw * c, uy = hw * s;
+  float t = hh * s;
+  float vx = -t, vy = hh * c;
+  q->ox = cx; q->oy = cy;
+  float mx = -ux, my = -uy; /* -u */
+  q->rx[0] = mx - vx; q->ry[0] = my - vy; /* -u - v */
+  q->rx[1] = ux - vx; q->ry[1] = uy - vy; /* +u - v */
+  q->rx[2] = ux + vx; q->ry[2] = uy + vy; /* +u + v */
+  q->rx[3] = mx + vx; q->ry[3] = my + vy; /* -u + v */
+  q->ex = fabs_sel(ux) + fabs_sel(vx);
+  q->ey = fabs_sel(uy) + fabs_sel(vy);
+  q->area = w * h;
+}
+
+/* polygon (x1,y1,...,x4,y4): origin = vertex 0; orientation normalised by the
+ * sign of the shoelace sum (negative -> vertices 1 and 3 swapped).          */
+OBBO_API void obbo_quad_from_poly_f32(const float *p, obbo_quad *q) {
+  float ox = p[0], oy = p[1];
+  float x1 = p[2] - ox, y1 = p[3] - oy;
+  float x2 = p[4] - ox, y2 = p[5] - oy;
+  float x3 = p[6] - ox, y3 = p[7] - oy;
+  /* shoelace with vertex 0 at the origin: terms 0->1 and 3->0 vanish */
+  float a = x1 * y2 - x2 * y1;
+  float b2 = x2 * y3 - x3 * y2;
+  float sh = a + b2;
+  q->ox = ox; q->oy = oy;
+  q->rx[0] = 0.0f; q->ry[0] = 0.0f;
+  q->rx[2] = x2; q->ry[2] = y2;
+  if (sh < 0.0f) {
+    q->rx[1] = x3; q->ry[1] = y3;
+    q->rx[3] = x1; q->ry[3] = y1;
+    sh = -sh;
+  } else {
+    q->rx[1] = x1; q->ry[1] = y1;
+    q->rx[3] = x3; q->ry[3] = y3;
+  }
+  float ex = max_sel(max_sel(fabs_sel(x1), fabs_sel(x2)), fabs_sel(x3));
+  float ey = max_sel(max_sel(fabs_sel(y1), fabs_sel(y2)), fabs_sel(y3));
+  q->ex = ex; q->ey = ey;
+  q->area = 0.5f * sh;
+}
+
+/* ------------------------------------------------------------------ */
+/* convex quad  x  convex quad  intersection area ("segment soup" S-H) */
+/* ------------------------------------------------------------------ */
+/* The subject A is held as up to 8 boundary SEGMENTS (ax,ay)->(bx,by), one
+ * per supporting line (4 of A, 4 of B).  Clipping by a half-plane of B trims
+ * every live segment and adds one new segment on the clip line that runs
+ * from the (unique) leaving crossing to the (unique) entering crossing; both
+ * end points are the very same floats stored into the trimmed segments, so the
+ * boundary stays closed.  No vertex list, no data-dependent indexing.
+ * Everything is relative to A's origin; (dx,dy) = B.origin - A.origin.      */
+static float quad_inter_f32(const obbo_quad *A, const obbo_quad *B,
+                            float dx, float dy) {
+  float sax[8], say[8], sbx[8], sby[8];
+  int valid[8];
+  int k, m;
+  for (k = 0; k < 4; ++k) {
+    int k1 = (k + 1) & 3;
+    sax[k] = A->rx[k]; say[k] = A->ry[k];
+    sbx[k] = A->rx[k1]; sby[k] = A->ry[k1];
+    valid[k] = 1;
+  }
+  for (k = 4; k < 8; ++k) {
+    sax[k] = say[k] = sbx[k] = sby[k] = 0.0f;
+    valid[k] = 0;
+  }
+  float qx[4], qy[4];
+  for (k = 0; k < 4; ++k) {
+    qx[k] = dx + B->rx[k];
+    qy[k] = dy + B->ry[k];
+  }
+  for (m = 0; m < 4; ++m) {
+    int m1 = (m + 1) & 3;
+    float px = qx[m], py = qy[m];
+    float ex = qx[m1] - px, ey = qy[m1] - py;
+    float nsx = 0.0f, nsy = 0.0f, nex = 0.0f, ney = 0.0f;
+    int has_leave = 0, has_enter = 0;
+    for (k = 0; k < 4 + m; ++k) {
+      if (!valid[k]) continue;
+      float ta = say[k] - py, tb = sax[k] - px;
+      float sa = ex * ta - ey * tb;
+      float tc = sby[k] - py, td = sbx[k] - px;
+      float sb = ex * tc - ey * td;
+      int ina = sa >= 0.0f, inb = sb >= 0.0f;
+      if (ina && inb) continue;
+      if (!ina && !inb) { valid[k] = 0; continue; }
+      float den = sa - sb;
+      float t = sa / den;
+      float ddx = sbx[k] - sax[k], ddy = sby[k] - say[k];
+      float X = sax[k] + t * ddx;
+      float Y = say[k] + t * ddy;
+      if (ina) { /* leaving: keep a, end moves to the crossing */
+        sbx[k] = X; sby[k] = Y;
+        nsx = X; nsy = Y; has_leave = 1;
+      } else {   /* entering: start moves to the crossing */
+        sax[k] = X; say[k] = Y;
+        nex = X; ney = Y; has_enter = 1;
+      }
+    }
+    sax[4 + m] = nsx; say[4 + m] = nsy;
+    sbx[4 + m] = nex; sby[4 + m] = ney;
+    valid[4 + m] = has_leave && has_enter;
+  }
+  float acc = 0.0f;
+  for (k = 0; k < 8; ++k) {
+    float c1 = sax[k] * sby[k];
+    float c2 = sbx[k] * say[k];
+    float cr = c1 - c2;
+    acc = acc + (valid[k] ? cr : 0.0f);
+  }
+  return 0.5f * acc;
+}
+
+/* overlap of two quad records.  mode 0 = iou, 1 = iof (inter / area(A)). */
+static float quad_overlap_f32(const obbo_quad *A, const obbo_quad *B, int mode) {
+  float dx = B->ox - A->ox, dy = B->oy - A->oy;
+  /* AABB prefilter -- part of the spec (decides exact zeros) */
+  float lox = A->ex + B->ex, loy = A->ey + B->ey;
+  /* polygons measure extents from vertex 0, boxes from the centre; in both
+   * cases |d| > eA + eB on an axis proves the quads are disjoint.          */
+  if (fabs_sel(dx) > lox) return 0.0f;
+  if (fabs_sel(dy) > loy) return 0.0f;
+  float inter = quad_inter_f32(A, B, dx, dy);
+  float lim = min_sel(A->area, B->area);
+  inter = min_sel(inter, lim);
+  inter = max_sel(inter, 0.0f);
+  float den;
+  if (mode == 0) {
+    float su = A->area + B->area;
+    den = su - inter;
+  } else {
+    den = A->area;
+  }
+  if (!(den > 0.0f)) return 0.0f;
+  return inter / den;
+}
+
+OBBO_API float obbo_rbox_iou_f32(const float *a5, const float *b5, int mode) {
+  obbo_quad A, B;
+  obbo_quad_from_rbox_f32(a5, &A);
+  obbo_quad_from_rbox_f32(b5, &B);
+  return quad_overlap_f32(&A, &B, mode);
+}
+
+OBBO_API float obbo_poly_iou_f32(const float *a8, const float *b8, int mode) {
+  obbo_quad A, B;
+  obbo_quad_from_poly_f32(a8, &A);
+  obbo_quad_from_poly_f32(b8, &B);
+  return quad_overlap_f32(&A, &B, mode);
+}
+
+/* ------------------------------------------------------------------ */
+/* rbbox_overlaps  (signature mirrors geometry.py:4 bbox_overlaps)      */
+/* ------------------------------------------------------------------ */
+/* kind: 0 = theta-OBB rows of 5 floats, 1 = polygon rows of 8 floats.
+ * aligned=0: out is (m,n) row-major; aligned=1: m==n, out is (m,).       */
+OBBO_API int obbo_overlaps_f32(const float *a, long m, const float *b, long n,
+                               int kind, int mode, int aligned, float *out) {
+  long i, j;
+  int stride = kind ? 8 : 5;
+  if (m < 0 || n < 0) return -1;
+  if (aligned && m != n) return -1;
+  obbo_quad *QB = (obbo_quad *)malloc(sizeof(obbo_quad) * (size_t)(n > 0 ? n : 1));
+  if (!QB) return -2;
+  for (j = 0; j < n; ++j) {
+    if (kind) obbo_quad_from_poly_f32(b + j * stride, &QB[j]);
+    else obbo_quad_from_rbox_f32(b + j * stride, &QB[j]);
+  }
+  for (i = 0; i < m; ++i) {
+    obbo_quad A;
+    if (kind) obbo_quad_from_poly_f32(a + i * stride, &A);
+    else obbo_quad_from_rbox_f32(a + i * stride, &A);
+    if (aligned) {
+      out[i] = quad_overlap_f32(&A, &QB[i], mode);
+    } else {
+      for (j = 0; j < n; ++j) out[i * n + j] = quad_overlap_f32(&A, &QB[j], mode);
+    }
+  }
+  free(QB);
+  return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* fp64 "truth" (libm trig, no prefilter, classic vertex-list S-H)     */
+/* ------------------------------------------------------------------ */
+/* A deliberately DIFFERENT algorithm from the fp32 spec above, used to bound
+ * the fp32 error (tests: |f32 - f64| <= 1e-4).                           */
+static double poly_area_d(const double *px, const double *py, int n) {
+  double s = 0.0;
+  int i;
+  for (i = 0; i < n; ++i) {
+    int j = (i + 1) % n;
+    s += px[i] * py[j] - px[j] * py[i];
+  }
+  return 0.5 * s;
+}
+
+static double convex_inter_d(const double *ax, const double *ay, int na,
+                             const double *bx, const double *by, int nb) {
+  double px[16], py[16], qx[16], qy[16];
+  int n = na, i, m;
+  for (i = 0; i < na; ++i) { px[i] = ax[i]; py[i] = ay[i]; }
+  for (m = 0; m < nb && n > 0; ++m) {
+    int m1 = (m + 1) % nb;
+    double ex = bx[m1] - bx[m], ey = by[m1] - by[m];
+    int cnt = 0;
+    for (i = 0; i < n; ++i) {
+      int j = (i + 1) % n;
+      double si = ex * (py[i] - by[m]) - ey * (px[i] - bx[m]);
+      double sj = ex * (py[j] - by[m]) - ey * (px[j] - bx[m]);
+      if (si >= 0) {
+        qx[cnt] = px[i]; qy[cnt] = py[i]; ++cnt;
+        if (sj < 0) {
+          double t = si / (si - sj);
+          qx[cnt] = px[i] + t * (px[j] - px[i]);
+          qy[cnt] = py[i] + t * (py[j] - py[i]); ++cnt;
+        }
+      } else if (sj >= 0) {
+        double t = si / (si - sj);
+        qx[cnt] = px[i] + t * (px[j] - px[i]);
+        qy[cnt] = py[i] + t * (py[j] - py[i]); ++cnt;
+      }
+    }
+    n = cnt;
+    for (i = 0; i < n; ++i) { px[i] = qx[i]; py[i] = qy[i]; }
+  }
+  if (n < 3) return 0.0;
+  double a = poly_area_d(px, py, n);
+  return a < 0 ? 0.0 : a;
+}
+
+static void rbox_corners_d(const double *b, double *x, double *y) {
+  double c = cos(b[4]), s = sin(b[4]);
+  double ux = 0.5 * b[2] * c, uy = 0.5 * b[2] * s;
+  double vx = -0.5 * b[3] * s, vy = 0.5 * b[3] * c;
+  x[0] = b[0] - ux - vx; y[0] = b[1] - uy - vy;
+  x[1] = b[0] + ux - vx; y[1] = b[1] + uy - vy;
+  x[2] = b[0] + ux + vx; y[2] = b[1] + uy + vy;
+  x[3] = b[0] - ux + vx; y[3] = b[1] - uy + vy;
+}
+
+static void poly_corners_d(const double *p, double *x, double *y) {
+  int i;
+  for (i = 0; i < 4; ++i) { x[i] = p[2 * i]; y[i] = p[2 * i + 1]; }
+  if (poly_area_d(x, y, 4) < 0) {
+    double t;
+    t = x[1]; x[1] = x[3]; x[3] = t;
+    t = y[1]; y[1] = y[3]; y[3] = t;
+  }
+}
+
+OBBO_API int obbo_overlaps_f64(const double *a, long m, const double *b, long n,
+                               int kind, int mode, int aligned, double *out) {
+  long i, j;
+  int stride = kind ? 8 : 5;
+  if (aligned && m != n) return -1;
+  for (i = 0; i < m; ++i) {
+    double ax[4], ay[4];
+    if (kind) poly_corners_d(a + i * stride, ax, ay);
+    else rbox_corners_d(a + i * stride, ax, ay);
+    double aa = kind ? poly_area_d(ax, ay, 4) : a[i * stride + 2] * a[i * stride + 3];
+    long j0 = aligned ? i : 0, j1 = aligned ? i + 1 : n;
+    for (j = j0; j < j1; ++j) {
+      double bx[4], by[4];
+      if (kind) poly_corners_d(b + j * stride, bx, by);
+      else rbox_corners_d(b + j * stride, bx, by);
+      double ab = kind ? poly_area_d(bx, by, 4) : b[j * stride + 2] * b[j * stride + 3];
+      double inter = convex_inter_d(ax, ay, 4, bx, by, 4);
+      double den = mode == 0 ? aa + ab - inter : aa;
+      double v = den > 0 ? inter / den : 0.0;
+      if (aligned) out[i] = v; else out[i * n + j] = v;
+    }
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* score ordering                                                      */
+/* ------------------------------------------------------------------ */
+/* descending score, ties -> lower original index (stable).  The key is the
+ * usual order-preserving map float -> uint32 (after -0 -> +0), inverted so an
+ * ASCENDING stable sort of keys is a DESCENDING stable sort of scores.  The
+ * HIP path radix-sorts the same keys.  (nms_cpu.cpp:21 uses an unstable
+ * descending sort; distinct scores make both agree.)                       */
+OBBO_API uint32_t obbo_score_key(float s) {
+  union { float f; uint32_t u; } v;
+  v.f = s + 0.0f;
+  uint32_t u = v.u;
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  return ~u;
+}
+
+typedef struct { uint32_t key; int64_t idx; } key_idx;
+
+static int cmp_key_idx(const void *a, const void *b) {
+  const key_idx *x = (const key_idx *)a, *y = (const key_idx *)b;
+  if (x->key < y->key) return -1;
+  if (x->key > y->key) return 1;
+  return x->idx < y->idx ? -1 : (x->idx > y->idx ? 1 : 0);
+}
+
+/* ------------------------------------------------------------------ */
+/* rotated / polygon NMS -- control flow of nms_cpu.cpp:21-59           */
+/* ------------------------------------------------------------------ */
+/* kind 0: dets (n,6) = cx,cy,w,h,theta,score.  kind 1: dets (n,9) = 8 coords,
+ * score.  keep receives ASCENDING original indices (nms_cpu.cpp:59).
+ * Returns the number kept, or <0 on error.                                */
+OBBO_API long obbo_nms_f32(const float *dets, long n, int kind, float thr,
+                           int64_t *keep) {
+  long i, j;
+  int stride = kind ? 9 : 6;
+  if (n < 0) return -1;
+  if (n == 0) return 0;
+  key_idx *ord = (key_idx *)malloc(sizeof(key_idx) * (size_t)n);
+  obbo_quad *Q = (obbo_quad *)malloc(sizeof(obbo_quad) * (size_t)n);
+  uint8_t *sup = (uint8_t *)calloc((size_t)n, 1);
+  /* SoA copies of the prefilter fields in SORTED order: keeps the O(n^2)
+   * inner loop streaming                                                    */
+  float *sx = (float *)malloc(sizeof(float) * (size_t)n * 4);
+  if (!ord || !Q || !sup || !sx) { free(ord); free(Q); free(sup); free(sx); return -2; }
+  float *sy = sx + n, *sex = sx + 2 * n, *sey = sx + 3 * n;
+  for (i = 0; i < n; ++i) {
+    ord[i].key = obbo_score_key(dets[i * stride + stride - 1]);
+    ord[i].idx = i;
+  }
+  qsort(ord, (size_t)n, sizeof(key_idx), cmp_key_idx);
+  for (i = 0; i < n; ++i) {
+    const float *d = dets + ord[i].idx * stride;
+    if (kind) obbo_quad_from_poly_f32(d, &Q[i]);
+    else obbo_quad_from_rbox_f32(d, &Q[i]);
+    sx[i] = Q[i].ox; sy[i] = Q[i].oy; sex[i] = Q[i].ex; sey[i] = Q[i].ey;
+  }
+  for (i = 0; i < n; ++i) {
+    if (sup[i]) continue;
+    const obbo_quad *A = &Q[i];
+    float ax = A->ox, ay = A->oy, aex = A->ex, aey = A->ey;
+    for (j = i + 1; j < n; ++j) {
+      if (sup[j]) continue;
+      /* same prefilter as quad_overlap_f32, hoisted */
+      float dx = sx[j] - ax;
+      if (fabs_sel(dx) > aex + sex[j]) continue;
+      float dy = sy[j] - ay;
+      if (fabs_sel(dy) > aey + sey[j]) continue;
+      float ovr = quad_overlap_f32(A, &Q[j], 0);
+      if (ovr >= thr) sup[j] = 1;
+    }
+  }
+  /* ascending ORIGINAL index */
+  uint8_t *kept = (uint8_t *)calloc((size_t)n, 1);
+  if (!kept) { free(ord); free(Q); free(sup); free(sx); return -2; }
+  for (i = 0; i < n; ++i) if (!sup[i]) kept[ord[i].idx] = 1;
+  long k = 0;
+  for (i = 0; i < n; ++i) if (kept[i]) keep[k++] = i;
+  free(kept); free(ord); free(Q); free(sup); free(sx);
+  return k;
+}
+
+/* the sorted order itself (tests compare it with the device radix sort) */
+OBBO_API int obbo_score_order(const float *scores, long n, long stride, int64_t *order) {
+  long i;
+  key_idx *ord = (key_idx *)malloc(sizeof(key_idx) * (size_t)(n > 0 ? n : 1));
+  if (!ord) return -2;
+  for (i = 0; i < n; ++i) { ord[i].key = obbo_score_key(scores[i * stride]); ord[i].idx = i; }
+  qsort(ord, (size_t)n, sizeof(key_idx), cmp_key_idx);
+  for (i = 0; i < n; ++i) order[i] = ord[i].idx;
+  free(ord);
+  return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* Rotated RoI-Align forward / backward                                */
+/* ------------------------------------------------------------------ */
+/* bilinear tap rules = roi_align_kernel_v2.cu:15-60 (identical in
+ * roi_align_kernel.cu:17-62).  Returns the 4 tap offsets and weights;
+ * weights are all zero for an out-of-map sample.                          */
+static inline void bilinear_taps_f32(int height, int width, float y, float x,
+                                     int *o1, int *o2, int *o3, int *o4,
+                                     float *w1, float *w2, float *w3, float *w4) {
+  if (y < -1.0f || y > (float)height || x < -1.0f || x > (float)width) {
+    *o1 = *o2 = *o3 = *o4 = 0;
+    *w1 = *w2 = *w3 = *w4 = 0.0f;
+    return;
+  }
+  if (y <= 0.0f) y = 0.0f;
+  if (x <= 0.0f) x = 0.0f;
+  int y_low = (int)y, x_low = (int)x, y_high, x_high;
+  if (y_low >= height - 1) { y_high = y_low = height - 1; y = (float)y_low; }
+  else y_high = y_low + 1;
+  if (x_low >= width - 1) { x_high = x_low = width - 1; x = (float)x_low; }
+  else x_high = x_low + 1;
+  float ly = y - (float)y_low, lx = x - (float)x_low;
+  float hy = 1.0f - ly, hx = 1.0f - lx;
+  *o1 = y_low * width + x_low;  *o2 = y_low * width + x_high;
+  *o3 = y_high * width + x_low; *o4 = y_high * width + x_high;
+  *w1 = hy * hx; *w2 = hy * lx; *w3 = ly * hx; *w4 = ly * lx;
+}
+
+/* per-RoI sampling frame (Appendix B of SURVEY.md; theta = 0 reduces to
+ * RoIAlignForwardV2 aligned=False, roi_align_kernel_v2.cu:79-102).        */
+typedef struct {
+  int b, gh, gw;
+  float cx, cy, c, s, rw, rh, bin_w, bin_h, x0, y0;
+} rroi_frame;
+
+static void rroi_make_frame(const float *roi, float scale, int ph, int pw,
+                            int sample_num, float min_size, rroi_frame *f) {
+  f->b = (int)roi[0];
+  f->cx = roi[1] * scale; f->cy = roi[2] * scale;
+  float rw = roi[3] * scale, rh = roi[4] * scale;
+  rw = max_sel(rw, min_size); rh = max_sel(rh, min_size);
+  f->rw = rw; f->rh = rh;
+  obbo_sincos_f32(roi[5], &f->s, &f->c);
+  f->bin_h = rh / (float)ph; f->bin_w = rw / (float)pw;
+  f->gh = sample_num > 0 ? sample_num : (int)ceilf(rh / (float)ph);
+  f->gw = sample_num > 0 ? sample_num : (int)ceilf(rw / (float)pw);
+  f->x0 = -0.5f * rw; f->y0 = -0.5f * rh;
+}
+
+static inline void rroi_sample_xy(const rroi_frame *f, int ph_i, int pw_i, int iy, int ix,
+                                  float *x, float *y) {
+  /* local offsets from the RoI centre, V2's expression order */
+  float ly = f->y0 + (float)ph_i * f->bin_h;
+  float t1 = ((float)iy + 0.5f) * f->bin_h;
+  ly = ly + t1 / (float)f->gh;
+  float lx = f->x0 + (float)pw_i * f->bin_w;
+  float t2 = ((float)ix + 0.5f) * f->bin_w;
+  lx = lx + t2 / (float)f->gw;
+  float xc = lx * f->c, ys = ly * f->s;
+  float xs = lx * f->s, yc = ly * f->c;
+  float rx = xc - ys, ry = xs + yc;
+  *x = f->cx + rx;
+  *y = f->cy + ry;
+}
+
+OBBO_API int obbo_rroi_align_forward_f32(const float *feat, int B, int C, int H, int W,
+                                         const float *rois, long K, int ph, int pw,
+                                         float scale, int sample_num, float min_size,
+                                         float *out) {
+  long k;
+  int c, i, j, iy, ix;
+  for (k = 0; k < K; ++k) {
+    rroi_frame f;
+    rroi_make_frame(rois + k * 6, scale, ph, pw, sample_num, min_size, &f);
+    if (f.b < 0 || f.b >= B) return -1;
+    int cnt_i = f.gh * f.gw; if (cnt_i < 1) cnt_i = 1;
+    float cnt = (float)cnt_i;
+    for (c = 0; c < C; ++c) {
+      const float *plane = feat + ((long)f.b * C + c) * H * W;
+      for (i = 0; i < ph; ++i) for (j = 0; j < pw; ++j) {
+        float acc = 0.0f;
+        for (iy = 0; iy < f.gh; ++iy) for (ix = 0; ix < f.gw; ++ix) {
+          float x, y, w1, w2, w3, w4; int o1, o2, o3, o4;
+          rroi_sample_xy(&f, i, j, iy, ix, &x, &y);
+          bilinear_taps_f32(H, W, y, x, &o1, &o2, &o3, &o4, &w1, &w2, &w3, &w4);
+          float v = w1 * plane[o1];
+          v = v + w2 * plane[o2];
+          v = v + w3 * plane[o3];
+          v = v + w4 * plane[o4];
+          acc = acc + v;
+        }
+        out[((k * C + c) * ph + i) * pw + j] = acc / cnt;
+      }
+    }
+  }
+  return 0;
+}
+
+/* backward w.r.t. features: scatter of grad*w/count (mirrors
+ * roi_align_kernel_v2.cu:179-263); grad_in must be pre-zeroed. */
+OBBO_API int obbo_rroi_align_backward_f32(const float *grad_out, int B, int C, int H, int W,
+                                          const float *rois, long K, int ph, int pw,
+                                          float scale, int sample_num, float min_size,
+                                          float *grad_in) {
+  long k;
+  int c, i, j, iy, ix;
+  for (k = 0; k < K; ++k) {
+    rroi_frame f;
+    rroi_make_frame(rois + k * 6, scale, ph, pw, sample_num, min_size, &f);
+    if (f.b < 0 || f.b >= B) return -1;
+    int cnt_i = f.gh * f.gw; if (cnt_i < 1) cnt_i = 1;
+    float cnt = (float)cnt_i;
+    for (c = 0; c < C; ++c) {
+      float *plane = grad_in + ((long)f.b * C + c) * H * W;
+      for (i = 0; i < ph; ++i) for (j = 0; j < pw; ++j) {
+        float g = grad_out[((k * C + c) * ph + i) * pw + j];
+        for (iy = 0; iy < f.gh; ++iy) for (ix = 0; ix < f.gw; ++ix) {
+          float x, y, w1, w2, w3, w4; int o1, o2, o3, o4;
+          rroi_sample_xy(&f, i, j, iy, ix, &x, &y);
+          bilinear_taps_f32(H, W, y, x, &o1, &o2, &o3, &o4, &w1, &w2, &w3, &w4);
+          plane[o1] += g * w1 / cnt;
+          plane[o2] += g * w2 / cnt;
+          plane[o3] += g * w3 / cnt;
+          plane[o4] += g * w4 / cnt;
+        }
+      }
+    }
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* horizontal RoIAlign V1 / V2 restatement (anchor A4 of SURVEY 8c)     */
+/* ------------------------------------------------------------------ */
+/* version 1: roi_align_kernel.cu:64-117 ( +1 on the far edge, clamp >= 0 )
+ * version 2: roi_align_kernel_v2.cu:62-128 (aligned flag)                  */
+OBBO_API int obbo_roi_align_forward_f32(const float *feat, int B, int C, int H, int W,
+                                        const float *rois, long K, int ph, int pw,
+                                        float scale, int sample_num, int version,
+                                        int aligned, float *out) {
+  long k;
+  int c, i, j, iy, ix;
+  for (k = 0; k < K; ++k) {
+    const float *r = rois + k * 5;
+    int b = (int)r[0];
+    if (b < 0 || b >= B) return -1;
+    float sw, sh, rw, rh;
+    if (version == 1) {
+      sw = r[1] * scale; sh = r[2] * scale;
+      float ew = (r[3] + 1.0f) * scale, eh = (r[4] + 1.0f) * scale;
+      rw = max_sel(ew - sw, 0.0f); rh = max_sel(eh - sh, 0.0f);
+    } else {
+      float off = aligned ? 0.5f : 0.0f;
+      sw = r[1] * scale - off; sh = r[2] * scale - off;
+      float ew = r[3] * scale - off, eh = r[4] * scale - off;
+      rw = ew - sw; rh = eh - sh;
+      if (!aligned) { rw = max_sel(rw, 1.0f); rh = max_sel(rh, 1.0f); }
+    }
+    float bin_h = rh / (float)ph, bin_w = rw / (float)pw;
+    int gh = sample_num > 0 ? sample_num : (int)ceilf(rh / (float)ph);
+    int gw = sample_num > 0 ? sample_num : (int)ceilf(rw / (float)pw);
+    float cnt;
+    if (version == 1) cnt = (float)(gh * gw);
+    else { int ci = gh * gw; if (ci < 1) ci = 1; cnt = (float)ci; }
+    for (c = 0; c < C; ++c) {
+      const float *plane = feat + ((long)b * C + c) * H * W;
+      for (i = 0; i < ph; ++i) for (j = 0; j < pw; ++j) {
+        float acc = 0.0f;
+        for (iy = 0; iy < gh; ++iy) {
+          float y = sh + (float)i * bin_h + ((float)iy + 0.5f) * bin_h / (float)gh;
+          for (ix = 0; ix < gw; ++ix) {
+            float x = sw + (float)j * bin_w + ((float)ix + 0.5f) * bin_w / (float)gw;
+            float w1, w2, w3, w4; int o1, o2, o3, o4;
+            bilinear_taps_f32(H, W, y, x, &o1, &o2, &o3, &o4, &w1, &w2, &w3, &w4);
+            acc += w1 * plane[o1] + w2 * plane[o2] + w3 * plane[o3] + w4 * plane[o4];
+          }
+        }
+        out[((k * C + c) * ph + i) * pw + j] = acc / cnt;
+      }
+    }
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* horizontal greedy NMS restatement of nms_cpu.cpp:5-60 (anchor A2)    */
+/* ------------------------------------------------------------------ */
+OBBO_API long obbo_hbb_nms_f32(const float *dets, long n, float thr, int64_t *keep) {
+  long i, j;
+  if (n <= 0) return 0;
+  key_idx *ord = (key_idx *)malloc(sizeof(key_idx) * (size_t)n);
+  float *areas = (float *)malloc(sizeof(float) * (size_t)n);
+  uint8_t *sup = (uint8_t *)calloc((size_t)n, 1);
+  if (!ord || !areas || !sup) { free(ord); free(areas); free(sup); return -2; }
+  for (i = 0; i < n; ++i) {
+    const float *d = dets + i * 5;
+    areas[i] = (d[2] - d[0] + 1.0f) * (d[3] - d[1] + 1.0f);
+    ord[i].key = obbo_score_key(d[4]); ord[i].idx = i;
+  }
+  qsort(ord, (size_t)n, sizeof(key_idx), cmp_key_idx);
+  for (i = 0; i < n; ++i) {
+    long a = ord[i].idx;
+    if (sup[a]) continue;
+    const float *da = dets + a * 5;
+    for (j = i + 1; j < n; ++j) {
+      long b = ord[j].idx;
+      if (sup[b]) continue;
+      const float *db = dets + b * 5;
+      float xx1 = max_sel(da[0], db[0]), yy1 = max_sel(da[1], db[1]);
+      float xx2 = min_sel(da[2], db[2]), yy2 = min_sel(da[3], db[3]);
+      float w = max_sel(0.0f, xx2 - xx1 + 1.0f), h = max_sel(0.0f, yy2 - yy1 + 1.0f);
+      float inter = w * h;
+      float ovr = inter / (areas[a] + areas[b] - inter);
+      if (ovr >= thr) sup[b] = 1;
+    }
+  }
+  long k = 0;
+  for (i = 0; i < n; ++i) if (!sup[i]) keep[k++] = i;
+  free(ord); free(areas); free(sup);
+  return k;
+}
+
+OBBO_API const char *obbo_version(void) { return "obb-oracle 1 (OBB-GEOM v1)"; }

@@ -1,0 +1,197 @@
+"""Generate tests/golden/*.npz by RUNNING the reference (jwwangchn/aidet).
+
+Runs only in the build container: needs /root/reference and oracle/_ref/nms_cpu.so
+(python oracle/build_ref.py).  The fixtures are DATA (inputs + the reference's
+outputs); no reference source is stored.  Re-run:  python tests/golden/make_golden.py
+
+What is captured (SURVEY.md 8c anchors):
+  hbb_iou.npz        A1  mmdet/core/bbox/geometry.py:4-88   bbox_overlaps
+  hbb_nms.npz        A2  mmdet/ops/nms/src/nms_cpu.cpp:5-68 via nms_wrapper.py:7-60
+  multiclass.npz     A3  core/post_processing/bbox_nms.py:6-76, rbbox_nms.py:6-119
+  thetaobb_codec.npz A5  core/rbbox/transforms.py:191-203,280-293,321-395
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = '/root/reference'
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+
+def _load(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def load_reference():
+    from oracle import build_ref
+    build_ref.build()
+    nms_cpu = build_ref.load_ref()
+    assert nms_cpu is not None
+    for pkg in ('mmdet', 'mmdet.ops', 'mmdet.ops.nms'):
+        m = types.ModuleType(pkg)
+        m.__path__ = []
+        sys.modules[pkg] = m
+    sys.modules['mmdet.ops.nms.nms_cpu'] = nms_cpu
+    sys.modules['mmdet.ops.nms'].nms_cpu = nms_cpu
+    cuda_stub = types.ModuleType('mmdet.ops.nms.nms_cuda')
+    sys.modules['mmdet.ops.nms.nms_cuda'] = cuda_stub
+    sys.modules['mmdet.ops.nms'].nms_cuda = cuda_stub
+    nms_wrapper = _load('mmdet.ops.nms.nms_wrapper', REF + '/mmdet/ops/nms/nms_wrapper.py')
+    sys.modules['mmdet.ops.nms'].nms_wrapper = nms_wrapper
+    geometry = _load('ref_geometry', REF + '/mmdet/core/bbox/geometry.py')
+    bbox_nms = _load('ref_bbox_nms', REF + '/mmdet/core/post_processing/bbox_nms.py')
+    rbbox_nms = _load('ref_rbbox_nms', REF + '/mmdet/core/post_processing/rbbox_nms.py')
+    # transforms.py imports cv2 / pycocotools at module level; the functions
+    # captured here never call them.
+    for stub in ('cv2', 'pycocotools', 'pycocotools.mask', 'mmcv'):
+        if stub not in sys.modules:
+            sys.modules[stub] = types.ModuleType(stub)
+    transforms = _load('ref_rbbox_transforms', REF + '/mmdet/core/rbbox/transforms.py')
+    return nms_wrapper, geometry, bbox_nms, rbbox_nms, transforms
+
+
+def rand_hbb(rng, n, canvas, smin=8, smax=128, integer=False):
+    x1 = rng.uniform(0, canvas, n)
+    y1 = rng.uniform(0, canvas, n)
+    w = np.exp(rng.uniform(np.log(smin), np.log(smax), n))
+    h = np.exp(rng.uniform(np.log(smin), np.log(smax), n))
+    b = np.stack([x1, y1, x1 + w, y1 + h], 1)
+    if integer:
+        b = np.round(b)
+    return b.astype(np.float32)
+
+
+def main():
+    nms_wrapper, geometry, bbox_nms, rbbox_nms, transforms = load_reference()
+    rng = np.random.default_rng(20261003)
+
+    # ---- A1: HBB IoU ---------------------------------------------------
+    out = {}
+    b1 = torch.FloatTensor([[0, 0, 10, 10], [10, 10, 20, 20], [32, 32, 38, 42]])
+    b2 = torch.FloatTensor([[0, 0, 10, 20], [0, 10, 10, 19], [10, 10, 20, 20]])
+    out['doc_b1'] = b1.numpy()
+    out['doc_b2'] = b2.numpy()
+    out['doc_iou'] = geometry.bbox_overlaps(b1, b2).numpy()
+    r1 = torch.from_numpy(rand_hbb(rng, 200, 512))
+    r2 = torch.from_numpy(rand_hbb(rng, 300, 512))
+    out['rand_b1'] = r1.numpy()
+    out['rand_b2'] = r2.numpy()
+    out['rand_iou'] = geometry.bbox_overlaps(r1, r2).numpy()
+    out['rand_iof'] = geometry.bbox_overlaps(r1, r2, mode='iof').numpy()
+    out['rand_iou_aligned'] = geometry.bbox_overlaps(r1, r2[:200], is_aligned=True).numpy()
+    out['rand_iof_aligned'] = geometry.bbox_overlaps(r1, r2[:200], mode='iof', is_aligned=True).numpy()
+    i1 = torch.from_numpy(rand_hbb(rng, 64, 96, integer=True))
+    i2 = torch.from_numpy(rand_hbb(rng, 64, 96, integer=True))
+    out['int_b1'] = i1.numpy()
+    out['int_b2'] = i2.numpy()
+    out['int_iou'] = geometry.bbox_overlaps(i1, i2).numpy()
+    empty = torch.FloatTensor([])
+    nonempty = torch.FloatTensor([[0, 0, 10, 9]])
+    out['empty_shapes'] = np.array([
+        tuple(geometry.bbox_overlaps(empty, nonempty).shape),
+        tuple(geometry.bbox_overlaps(nonempty, empty).shape),
+        tuple(geometry.bbox_overlaps(empty, empty).shape)], dtype=np.int64)
+    np.savez_compressed(os.path.join(HERE, 'hbb_iou.npz'), **out)
+
+    # ---- A2: HBB NMS (reference nms_cpu.cpp through nms_wrapper.nms) -----
+    out = {}
+    t4 = np.array([[49.1, 32.4, 51.0, 35.9, 0.9], [49.3, 32.9, 51.0, 35.3, 0.9],
+                   [35.3, 11.5, 39.9, 14.5, 0.4], [35.2, 11.7, 39.7, 15.7, 0.3]], dtype=np.float32)
+    d7 = np.array([[49.1, 32.4, 51.0, 35.9, 0.9], [49.3, 32.9, 51.0, 35.3, 0.9],
+                   [49.2, 31.8, 51.0, 35.4, 0.5], [35.1, 11.5, 39.1, 15.7, 0.5],
+                   [35.6, 11.8, 39.3, 14.2, 0.5], [35.3, 11.5, 39.9, 14.5, 0.4],
+                   [35.2, 11.7, 39.7, 15.7, 0.3]], dtype=np.float32)
+    out['test4_dets'] = t4
+    out['test4_keep'] = nms_wrapper.nms(t4, 0.7)[1]
+    out['doc7_dets'] = d7
+    out['doc7_keep'] = nms_wrapper.nms(d7, 0.7)[1]
+    # witness of `>=` (nms_cpu.cpp:56): identical boxes at thr 1.0
+    two = np.array([[0, 0, 9, 9, 0.9], [0, 0, 9, 9, 0.8]], dtype=np.float32)
+    out['ge_dets'] = two
+    out['ge_keep'] = nms_wrapper.nms(two, 1.0)[1]
+    for tag, n, canvas, thr in (('a', 1000, 256, 0.5), ('b', 3000, 512, 0.3),
+                                ('c', 3000, 512, 0.7), ('d', 5000, 2048, 0.5)):
+        boxes = rand_hbb(rng, n, canvas)
+        score = ((rng.permutation(n) + 0.5) / n).astype(np.float32)
+        dets = np.concatenate([boxes, score[:, None]], 1)
+        keep = nms_wrapper.nms(dets, thr)[1]
+        out['rand_%s_dets' % tag] = dets
+        out['rand_%s_thr' % tag] = np.float32(thr)
+        out['rand_%s_keep' % tag] = keep
+    np.savez_compressed(os.path.join(HERE, 'hbb_nms.npz'), **out)
+
+    # ---- A3: class-wise orchestration ------------------------------------
+    out = {}
+    torch.manual_seed(0)
+    n, ncls = 200, 4
+    hb = torch.from_numpy(rand_hbb(rng, n, 128, 16, 64))
+    multi_bboxes = (hb[:, None, :] + torch.randn(n, ncls, 4) * 2).reshape(n, ncls * 4)
+    multi_scores = torch.softmax(torch.randn(n, ncls) * 2, dim=1)
+    nms_cfg = dict(type='nms', iou_thr=0.5)
+    bboxes, labels, cls_inds, keep_inds = rbbox_nms.multiclass_nms_with_index(
+        multi_bboxes, multi_scores, 0.05, nms_cfg, 100)
+    cx = (hb[:, 0] + hb[:, 2]) * 0.5
+    cy = (hb[:, 1] + hb[:, 3]) * 0.5
+    w = hb[:, 2] - hb[:, 0]
+    h = hb[:, 3] - hb[:, 1]
+    th = -torch.rand(n) * np.pi / 2
+    multi_rb = torch.stack([cx, cy, w, h, th], 1)[:, None, :].repeat(1, ncls, 1)
+    multi_rb = (multi_rb + torch.randn(n, ncls, 5) * torch.tensor([2., 2., 2., 2., .1])).reshape(n, ncls * 5)
+    keep_copy = [k.clone() for k in keep_inds]
+    rb, rl = rbbox_nms.thetaobb_nms_by_bbox_nms(multi_rb, multi_scores, cls_inds, keep_copy, 100, 5)
+    out['multi_bboxes'] = multi_bboxes.numpy()
+    out['multi_scores'] = multi_scores.numpy()
+    out['multi_rbboxes'] = multi_rb.numpy()
+    out['score_thr'] = np.float32(0.05)
+    out['iou_thr'] = np.float32(0.5)
+    out['max_num'] = np.int64(100)
+    out['idx_bboxes'] = bboxes.numpy()
+    out['idx_labels'] = labels.numpy()
+    out['idx_keep_lens'] = np.array([len(k) for k in keep_inds], dtype=np.int64)
+    for i, k in enumerate(keep_inds):
+        out['idx_keep_%d' % i] = k.numpy()
+    out['rb_bboxes'] = rb.numpy()
+    out['rb_labels'] = rl.numpy()
+    mb, ml = bbox_nms.multiclass_nms(multi_bboxes, multi_scores, 0.05, nms_cfg, 100)
+    out['mc_bboxes'] = mb.numpy()
+    out['mc_labels'] = ml.numpy()
+    np.savez_compressed(os.path.join(HERE, 'multiclass.npz'), **out)
+
+    # ---- A5: theta-OBB codec ----------------------------------------------
+    out = {}
+    rois = torch.tensor([[0., 0., 9., 19.], [5., 5., 24., 14.]])
+    deltas = torch.tensor([[.1, .2, .3, -.1, .05], [0., 0., 0., 0., 0.]])
+    out['small_rois'] = rois.numpy()
+    out['small_deltas'] = deltas.numpy()
+    out['small_thetaobb'] = transforms.delta2thetaobb(rois, deltas).numpy()
+    R = torch.from_numpy(rand_hbb(rng, 64, 512))
+    D = torch.randn(64, 15) * 0.5
+    stds = [.1, .1, .2, .2, .1]
+    out['rois'] = R.numpy()
+    out['deltas'] = D.numpy()
+    out['stds'] = np.array(stds, dtype=np.float32)
+    dec = transforms.delta2thetaobb(R, D, [0, 0, 0, 0, 0], stds)
+    out['thetaobb'] = dec.numpy()
+    gt = dec[:, 5:10].clone()
+    out['gt'] = gt.numpy()
+    out['enc'] = transforms.thetaobb2delta(R, gt, [0, 0, 0, 0, 0], stds).numpy()
+    out['flip_in'] = dec.numpy()
+    out['flip_out'] = transforms.thetaobb_flip(dec.numpy(), (600, 800, 3))
+    out['rescale_out'] = transforms.thetaobb_rescale(dec.clone(), 1.7).numpy()
+    out['rescale_rev_out'] = transforms.thetaobb_rescale(dec.clone(), 1.7, reverse_flag=True).numpy()
+    np.savez_compressed(os.path.join(HERE, 'thetaobb_codec.npz'), **out)
+    print('wrote', sorted(f for f in os.listdir(HERE) if f.endswith('.npz')))
+
+
+if __name__ == '__main__':
+    main()
