@@ -1,0 +1,93 @@
+"""ctypes binding of the C ABI in include/obbops.h (libobbops.so).
+
+This is the stub INTEGRATION.md describes: the reference imports its pybind
+modules next to the wrappers (mmdet/ops/nms/nms_wrapper.py:4); here the flat C
+ABI is loaded once and called with raw device pointers + the current HIP stream.
+PyTorch is only the owner of device memory and streams.
+
+No fallback of any kind: a missing library or GPU raises.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libobbops.so')
+
+OBB_OK = 0
+OBB_EINVAL = -1
+OBB_EWORKSPACE = -2
+OBB_EHIP = -3
+
+KIND_RBOX = 0
+KIND_POLY = 1
+MODE = {'iou': 0, 'iof': 1}
+
+_lib = None
+
+
+class ObbOpsError(RuntimeError):
+    """A libobbops call failed (mirrors the RuntimeError raised by AT_CHECK in the
+    reference's C++ ops, mmdet/ops/nms/src/nms_cpu.cpp:7)."""
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                'aidet_amd: %s not found. Build it with `python -c "import __graft_entry__ as g; '
+                'g.build()"` or `make -C aidet_amd/csrc` (hipcc, gfx950). There is no CPU '
+                'fallback.' % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        vp, i64, i32, f32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
+        L.obb_version.restype = i32
+        L.obb_build_info.restype = ctypes.c_char_p
+        L.obb_last_error.restype = ctypes.c_char_p
+        L.obb_overlaps_f32.argtypes = [vp, i64, vp, i64, i32, i32, i32, vp, vp]
+        L.obb_overlaps_f32.restype = i32
+        L.obb_nms_workspace_bytes.argtypes = [i64, i32, i64]
+        L.obb_nms_workspace_bytes.restype = ctypes.c_size_t
+        L.obb_nms_f32.argtypes = [vp, i64, i32, f32, vp, ctypes.POINTER(i64), vp,
+                                  ctypes.c_size_t, vp]
+        L.obb_nms_f32.restype = i32
+        rroi = [vp, i32, i32, i32, i32, vp, i64, i32, i32, f32, i32, f32, vp, vp]
+        L.obb_rroi_align_forward_f32.argtypes = rroi
+        L.obb_rroi_align_forward_f32.restype = i32
+        L.obb_rroi_align_backward_f32.argtypes = rroi
+        L.obb_rroi_align_backward_f32.restype = i32
+        L.obb_nms_profile_enable.argtypes = [i32]
+        L.obb_nms_profile_enable.restype = i32
+        L.obb_nms_profile_last.argtypes = [ctypes.POINTER(f32)]
+        L.obb_nms_profile_last.restype = i32
+        L.obb_rbox_to_poly_f32.argtypes = [vp, i64, vp, vp]
+        L.obb_rbox_to_poly_f32.restype = i32
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != OBB_OK:
+        raise ObbOpsError('libobbops error %d: %s' % (rc, lib().obb_last_error().decode()))
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError('aidet_amd ops run on a HIP device only (no CPU path); '
+                           'torch.cuda.is_available() is False')
+
+
+def stream_ptr(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def to_device_f32(t, device_id=None):
+    """Contiguous fp32 copy of `t` on a HIP device (the input's own device for a
+    HIP tensor, else cuda:{device_id or current})."""
+    require_gpu()
+    if t.is_cuda:
+        dev = t.device
+    else:
+        dev = torch.device('cuda', torch.cuda.current_device() if device_id is None else device_id)
+    return t.detach().to(device=dev, dtype=torch.float32).contiguous()

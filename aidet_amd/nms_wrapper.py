@@ -1,0 +1,138 @@
+"""Rotated / polygon NMS with the calling conventions of the reference's
+``mmdet/ops/nms/nms_wrapper.py`` (``nms`` at :7-60), so that
+``getattr(nms_wrapper, nms_cfg['type'])(cls_dets, **cfg)`` -- the selection the
+reference does in mmdet/core/post_processing/bbox_nms.py:60-64 and
+rbbox_nms.py:25-27 -- works with ``type='rnms'`` / ``'poly_nms'`` /
+``'thetaobb_nms'`` (the name the reference's disabled call expects,
+rbbox_nms.py:97).
+
+All compute is the HIP path ``obb_nms_f32`` (include/obbops.h); there is no CPU
+implementation.  CPU tensors / numpy arrays are moved to the GPU and the result
+is returned in the caller's container type and device, as the reference does
+for ``device_id`` (nms_wrapper.py:41-43).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _run_nms(dets_dev, kind, iou_thr):
+    """dets_dev: contiguous fp32 HIP tensor (n, 6|9). Returns int64 keep (K,)."""
+    n = dets_dev.size(0)
+    dev = dets_dev.device
+    L = _lib.lib()
+    keep = torch.empty(n, dtype=torch.int64, device=dev)
+    info = (ctypes.c_int64 * 4)()
+    capacity = 0  # library default
+    with torch.cuda.device(dev):
+        for _ in range(3):
+            nbytes = L.obb_nms_workspace_bytes(n, kind, capacity)
+            if nbytes == 0:
+                raise _lib.ObbOpsError('obb_nms_workspace_bytes failed: %s' %
+                                       L.obb_last_error().decode())
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            rc = L.obb_nms_f32(ctypes.c_void_p(dets_dev.data_ptr()), n, kind,
+                               ctypes.c_float(iou_thr), ctypes.c_void_p(keep.data_ptr()), info,
+                               ctypes.c_void_p(ws.data_ptr()), nbytes, _lib.stream_ptr(dev))
+            if rc != _lib.OBB_EWORKSPACE:
+                break
+            capacity = int(info[1]) + 1024  # exact number of overlap edges found
+    _lib.check(rc)
+    return keep[:int(info[0])], (int(info[1]), int(info[2]))
+
+
+def _nms_generic(dets, iou_thr, device_id, cols, kind, name):
+    # container handling mirrors nms_wrapper.py:36-47
+    if isinstance(dets, torch.Tensor):
+        is_numpy = False
+        dets_th = dets
+    elif isinstance(dets, np.ndarray):
+        is_numpy = True
+        dets_th = torch.from_numpy(dets)
+    else:
+        raise TypeError('dets must be either a Tensor or numpy array, but got {}'.format(
+            type(dets)))
+    if dets_th.dim() != 2 or dets_th.size(1) != cols:
+        raise ValueError('{} expects dets of shape (n, {}), got {}'.format(
+            name, cols, tuple(dets_th.shape)))
+
+    if dets_th.shape[0] == 0:  # nms_wrapper.py:50-51
+        inds = dets_th.new_zeros(0, dtype=torch.long)
+    else:
+        d = _lib.to_device_f32(dets_th, device_id)
+        inds, _ = _run_nms(d, kind, float(iou_thr))
+        if not is_numpy:
+            inds = inds.to(dets_th.device)  # keep lives where the input lives
+    if is_numpy:
+        inds = inds.cpu().numpy()
+    return dets[inds, :], inds
+
+
+def rnms(dets, iou_thr, device_id=None):
+    """Greedy NMS on theta-OBBs.
+
+    Arguments:
+        dets (torch.Tensor or np.ndarray): (n, 6) <cx, cy, w, h, theta, score>.
+        iou_thr (float): a box is suppressed by a higher-scored kept box when
+            their rotated IoU is >= iou_thr (the CPU reference's comparison,
+            mmdet/ops/nms/src/nms_cpu.cpp:56).
+        device_id (int, optional): HIP device for numpy / CPU input.
+
+    Returns:
+        tuple: kept dets and int64 indices (ascending, nms_cpu.cpp:59), same
+        container type as the input.
+
+    Example:
+        >>> dets = np.array([[50., 34., 2., 3.5, 0., 0.9],
+        >>>                  [50.1, 34.1, 1.8, 2.5, 0., 0.9],
+        >>>                  [37.6, 13., 4.6, 3., 0., 0.4],
+        >>>                  [37.4, 13.7, 4.5, 4., 0., 0.3]], dtype=np.float32)
+        >>> kept, inds = rnms(dets, 0.7)
+        >>> assert len(inds) == len(kept) == 4
+    """
+    return _nms_generic(dets, iou_thr, device_id, 6, _lib.KIND_RBOX, 'rnms')
+
+
+def poly_nms(dets, iou_thr, device_id=None):
+    """Greedy NMS on convex quadrilaterals: dets (n, 9) <x1,y1,..,x4,y4,score>
+    (the 8-point polygons the reference writes for the DOTA merge,
+    mmdet/datasets/dota.py:197-235, merged by the external mergebypoly)."""
+    return _nms_generic(dets, iou_thr, device_id, 9, _lib.KIND_POLY, 'poly_nms')
+
+
+# the names the reference's own (disabled) call sites use
+thetaobb_nms = rnms      # mmdet/core/post_processing/rbbox_nms.py:97
+pointobb_nms = poly_nms
+
+
+def nms(dets, iou_thr, device_id=None):
+    """Horizontal-box NMS with the reference's exact signature
+    (nms_wrapper.py:7), served by the rotated kernel through the theta = 0
+    mapping  w = x2-x1+1, h = y2-y1+1, centre = box centre  (the continuous box
+    [x1-.5, x2+.5] x [y1-.5, y2+.5] has the reference's +1 intersection widths,
+    nms_cpu.cpp:19,52-55).  dets: (n, 5) <x1, y1, x2, y2, score>."""
+    if isinstance(dets, torch.Tensor):
+        is_numpy = False
+        dets_th = dets
+    elif isinstance(dets, np.ndarray):
+        is_numpy = True
+        dets_th = torch.from_numpy(dets)
+    else:
+        raise TypeError('dets must be either a Tensor or numpy array, but got {}'.format(
+            type(dets)))
+    if dets_th.shape[0] == 0:
+        inds = dets_th.new_zeros(0, dtype=torch.long)
+    else:
+        d = _lib.to_device_f32(dets_th, device_id)
+        rb = torch.stack([(d[:, 0] + d[:, 2]) * 0.5, (d[:, 1] + d[:, 3]) * 0.5,
+                          d[:, 2] - d[:, 0] + 1.0, d[:, 3] - d[:, 1] + 1.0,
+                          torch.zeros_like(d[:, 0]), d[:, 4]], dim=1).contiguous()
+        inds, _ = _run_nms(rb, _lib.KIND_RBOX, float(iou_thr))
+        if not is_numpy:
+            inds = inds.to(dets_th.device)
+    if is_numpy:
+        inds = inds.cpu().numpy()
+    return dets[inds, :], inds

@@ -1,0 +1,45 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a HIP device (run on the MI355X box)')
+
+
+def pytest_collection_modifyitems(config, items):
+    # a `-m gpu` run on a machine without a GPU must fail loudly, not skip:
+    # the product has no CPU path.  (`-m "not gpu"` deselects them instead.)
+    pass
+
+
+@pytest.fixture(scope='session')
+def golden():
+    def load(name):
+        return np.load(os.path.join(GOLDEN, name))
+    return load
+
+
+def hbb_to_rbox(b, rot=False):
+    """xyxy(+score) -> theta-OBB with the +1 pixel convention.
+    rot=True describes the same rectangle with theta = -pi/2 and w,h swapped."""
+    b = np.asarray(b, dtype=np.float64)
+    w = b[:, 2] - b[:, 0] + 1
+    h = b[:, 3] - b[:, 1] + 1
+    cx = (b[:, 0] + b[:, 2]) / 2
+    cy = (b[:, 1] + b[:, 3]) / 2
+    if rot:
+        cols = [cx, cy, h, w, np.full(len(b), -np.pi / 2)]
+    else:
+        cols = [cx, cy, w, h, np.zeros(len(b))]
+    if b.shape[1] > 4:
+        cols.append(b[:, 4])
+    return np.stack(cols, 1).astype(np.float32)

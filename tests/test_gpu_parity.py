@@ -1,0 +1,336 @@
+"""GPU parity tests (run on the MI355X box: `pytest -m gpu`).
+
+Every test calls the product through its Python surface, which goes through the
+C ABI (include/obbops.h) into the HIP kernels, and compares with the CPU oracle
+(oracle/obb_oracle.c) on the same seeded inputs, or with the golden fixtures
+generated from the reference itself (tests/golden/).
+
+Bars (BASELINE.json north_star): NMS keep indices BIT-EXACT; IoU and RoI-Align
+within 1e-4.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from conftest import hbb_to_rbox
+
+pytestmark = pytest.mark.gpu
+
+IOU_TOL = 1e-4  # BASELINE.json: "within 1e-4 on IoU/RoI-Align floats"
+
+
+def dev():
+    assert torch.cuda.is_available(), 'GPU tests need a HIP device (no CPU path exists)'
+    return torch.device('cuda:0')
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev())
+
+
+# --------------------------------------------------------------------------
+# rbbox_overlaps
+# --------------------------------------------------------------------------
+@pytest.mark.parametrize('m,n', [(1, 1), (3, 5), (64, 64), (100, 257), (1000, 1000), (37, 4099)])
+@pytest.mark.parametrize('mode', ['iou', 'iof'])
+def test_overlaps_matches_oracle(m, n, mode):
+    from aidet_amd import rbbox_overlaps
+    a = oracle.synth_boxes(m, 512, 1 + m)[:, :5]
+    b = oracle.synth_boxes(n, 512, 2 + n)[:, :5]
+    got = rbbox_overlaps(t(a), t(b), mode=mode).cpu().numpy()
+    ref = oracle.overlaps(a, b, mode=mode)
+    assert got.shape == (m, n)
+    assert np.abs(got - ref).max() <= IOU_TOL
+    # same arithmetic spec on both sides: in practice bit-identical
+    assert np.array_equal(got, ref)
+    # and close to the independent fp64 truth
+    assert np.abs(got - oracle.overlaps_f64(a, b, mode=mode)).max() <= IOU_TOL
+
+
+def test_overlaps_cfg1_1k_x_1k():
+    """BASELINE.json configs[0]: 1k x 1k synthetic (cx,cy,w,h,theta) fp32 boxes."""
+    from aidet_amd import rbbox_overlaps
+    a = oracle.synth_boxes(1000, 1024, 1)[:, :5]
+    b = oracle.synth_boxes(1000, 1024, 2)[:, :5]
+    got = rbbox_overlaps(t(a), t(b)).cpu().numpy()
+    assert np.abs(got - oracle.overlaps(a, b)).max() <= IOU_TOL
+    assert np.abs(got - oracle.overlaps_f64(a, b)).max() <= IOU_TOL
+    assert (got > 0).sum() > 1000
+
+
+@pytest.mark.parametrize('mode', ['iou', 'iof'])
+def test_overlaps_aligned(mode):
+    from aidet_amd import rbbox_overlaps
+    a = oracle.synth_boxes(5000, 256, 5)[:, :5]
+    b = oracle.synth_boxes(5000, 256, 6)[:, :5]
+    got = rbbox_overlaps(t(a), t(b), mode=mode, is_aligned=True).cpu().numpy()
+    ref = oracle.overlaps(a, b, mode=mode, is_aligned=True)
+    assert got.shape == (5000,)
+    assert np.abs(got - ref).max() <= IOU_TOL
+
+
+def test_overlaps_polygons():
+    from aidet_amd.rbbox_geometry import pointobb_overlaps
+    a = oracle.synth_boxes(300, 256, 7)
+    b = oracle.synth_boxes(500, 256, 8)
+    pa = oracle.rbox_to_poly(a).astype(np.float32)
+    pb = oracle.rbox_to_poly(b).astype(np.float32)
+    pb[::2] = pb[::2].reshape(-1, 4, 2)[:, ::-1].reshape(-1, 8)  # mixed orientation
+    got = pointobb_overlaps(t(pa), t(pb)).cpu().numpy()
+    ref = oracle.overlaps(pa, pb, kind='poly')
+    assert np.abs(got - ref).max() <= IOU_TOL
+    # polygons of the same rectangles: close to the rbox answer
+    assert np.abs(got - oracle.overlaps_f64(a[:, :5], b[:, :5])).max() <= 1e-3
+
+
+def test_overlaps_reference_doctest(golden):
+    """Anchor A1: the numeric table of geometry.py:21-35 through theta=0 and
+    theta=-pi/2 mappings."""
+    from aidet_amd import rbbox_overlaps
+    g = golden('hbb_iou.npz')
+    for rot in (False, True):
+        got = rbbox_overlaps(t(hbb_to_rbox(g['doc_b1'], rot)), t(hbb_to_rbox(g['doc_b2'], rot)))
+        assert np.abs(got.cpu().numpy() - g['doc_iou']).max() <= 1e-6
+        got = rbbox_overlaps(t(hbb_to_rbox(g['rand_b1'], rot)), t(hbb_to_rbox(g['rand_b2'], rot)))
+        assert np.abs(got.cpu().numpy() - g['rand_iou']).max() <= IOU_TOL
+        got = rbbox_overlaps(t(hbb_to_rbox(g['rand_b1'], rot)), t(hbb_to_rbox(g['rand_b2'], rot)), mode='iof')
+        assert np.abs(got.cpu().numpy() - g['rand_iof']).max() <= IOU_TOL
+
+
+def test_overlaps_analytic_and_degenerate():
+    from aidet_amd import rbbox_overlaps
+    unit = np.array([[0, 0, 1, 1, 0]], np.float32)
+    cases = np.array([
+        [0, 0, 1, 1, np.pi / 4],   # octagon: sqrt(2)/2
+        [0, 0, 1, 1, 0],           # identical: 1
+        [5, 5, 1, 1, 0.3],         # disjoint: 0
+        [1, 0, 1, 1, 0],           # shared edge: 0
+        [0, 0, 0, 1, 0],           # zero area: 0, never NaN
+        [0, 0, 0.5, 0.5, 0.2],     # contained: 0.25
+    ], np.float32)
+    got = rbbox_overlaps(t(unit), t(cases)).cpu().numpy()[0]
+    want = [np.sqrt(2) / 2, 1, 0, 0, 0, 0.25]
+    assert np.isfinite(got).all()
+    assert np.abs(got - np.array(want)).max() <= 1e-5
+
+
+def test_overlaps_empty_shapes():
+    """geometry.py:51-55 empty-input shapes."""
+    from aidet_amd import rbbox_overlaps
+    e = torch.zeros((0, 5), device=dev())
+    ne = torch.tensor([[0., 0., 10., 9., 0.]], device=dev())
+    assert tuple(rbbox_overlaps(e, ne).shape) == (0, 1)
+    assert tuple(rbbox_overlaps(ne, e).shape) == (1, 0)
+    assert tuple(rbbox_overlaps(e, e).shape) == (0, 0)
+    assert tuple(rbbox_overlaps(e, e, is_aligned=True).shape) == (0, 1)
+
+
+def test_overlaps_cpu_tensor_roundtrip():
+    """CPU tensors are computed on the GPU and come back on the CPU."""
+    from aidet_amd import rbbox_overlaps
+    a = torch.from_numpy(oracle.synth_boxes(10, 64, 1)[:, :5])
+    out = rbbox_overlaps(a, a)
+    assert out.device.type == 'cpu' and out.shape == (10, 10)
+
+
+# --------------------------------------------------------------------------
+# rotated NMS: keep indices bit-exact
+# --------------------------------------------------------------------------
+@pytest.mark.parametrize('n,canvas', [(1, 10), (2, 10), (63, 64), (64, 64), (65, 64), (257, 128),
+                                      (1000, 256), (1025, 256), (5000, 512), (5000, 2048),
+                                      (20000, 2048), (20000, 8000)])
+@pytest.mark.parametrize('thr', [0.3, 0.5])
+def test_rnms_bit_exact(n, canvas, thr):
+    from aidet_amd import rnms
+    d = oracle.synth_boxes(n, canvas, 100 + n)
+    kept, inds = rnms(t(d), thr)
+    ref = oracle.rnms(d, thr)
+    got = inds.cpu().numpy()
+    assert got.dtype == np.int64
+    assert np.array_equal(got, ref)
+    assert np.array_equal(kept.cpu().numpy(), d[ref])
+
+
+def test_rnms_cfg2_100k_sparse_and_dense():
+    """BASELINE.json configs[1]: 100k synthetic OBBs, thr 0.5, keep bit-exact."""
+    from aidet_amd import rnms
+    for canvas, seed in ((20000, 3), (4096, 4)):
+        d = oracle.synth_boxes(100000, canvas, seed)
+        _, inds = rnms(t(d), 0.5)
+        got = inds.cpu().numpy()
+        ref = oracle.rnms(d, 0.5)
+        assert np.array_equal(got, ref), 'canvas %d' % canvas
+        # idempotence: NMS of the survivors keeps them all
+        _, again = rnms(t(d[got]), 0.5)
+        assert again.numel() == len(got)
+
+
+def test_rnms_score_ties_lower_index_first():
+    from aidet_amd import rnms
+    d = oracle.synth_boxes(3000, 256, 11)
+    d[:, 5] = np.round(d[:, 5] * 8) / 8  # 9 distinct scores -> massive ties
+    _, inds = rnms(t(d), 0.4)
+    assert np.array_equal(inds.cpu().numpy(), oracle.rnms(d, 0.4))
+
+
+def test_rnms_all_identical_boxes():
+    """Pathological: every pair overlaps (n^2/2 edges); forces the workspace retry."""
+    from aidet_amd import rnms
+    n = 3000
+    d = np.tile(np.array([[50, 50, 20, 10, 0.3, 0]], np.float32), (n, 1))
+    d[:, 5] = (np.random.default_rng(0).permutation(n) + 0.5) / n
+    _, inds = rnms(t(d), 0.5)
+    ref = oracle.rnms(d, 0.5)
+    assert len(ref) == 1
+    assert np.array_equal(inds.cpu().numpy(), ref)
+
+
+def test_rnms_chain_dependency():
+    """A long suppress/keep chain: box k overlaps only k-1 and k+1 (many resolve rounds)."""
+    from aidet_amd import rnms
+    n = 2000
+    d = np.zeros((n, 6), np.float32)
+    d[:, 0] = np.arange(n) * 4.0   # 10-wide boxes every 4 px: IoU(k,k+1) = 6/14 = 0.43
+    d[:, 1] = 5
+    d[:, 2] = 10
+    d[:, 3] = 10
+    d[:, 5] = 1.0 - np.arange(n) / n
+    _, inds = rnms(t(d), 0.4)
+    ref = oracle.rnms(d, 0.4)
+    assert np.array_equal(inds.cpu().numpy(), ref)
+    assert len(ref) == n // 2
+
+
+def test_rnms_threshold_is_greater_equal():
+    """nms_cpu.cpp:56 suppresses on `>=`: identical boxes at thr = 1.0 -> one kept."""
+    from aidet_amd import rnms, nms
+    d = np.array([[5, 5, 10, 10, 0, 0.9], [5, 5, 10, 10, 0, 0.8]], np.float32)
+    _, inds = rnms(t(d), 1.0)
+    assert inds.cpu().tolist() == [0]
+
+
+def test_poly_nms_bit_exact():
+    from aidet_amd import poly_nms
+    d = oracle.synth_boxes(6000, 512, 21)
+    p = np.concatenate([oracle.rbox_to_poly(d).astype(np.float32), d[:, 5:6]], 1)
+    p[::3, :8] = p[::3, :8].reshape(-1, 4, 2)[:, ::-1].reshape(-1, 8)
+    _, inds = poly_nms(t(p), 0.5)
+    assert np.array_equal(inds.cpu().numpy(), oracle.poly_nms(p, 0.5))
+
+
+def test_nms_wrapper_containers_and_dtypes():
+    """Mirror of the reference's tests/test_nms.py:11-70 for the rotated op."""
+    from aidet_amd import rnms
+    base = np.array([[50.05, 34.15, 2.9, 4.5, 0., 0.9], [50.15, 34.1, 2.7, 3.4, 0., 0.9],
+                     [37.6, 13.0, 5.6, 4.0, 0., 0.4], [37.45, 13.7, 5.5, 5.0, 0., 0.3]])
+    for dets in (base.astype(np.float32), base.astype(np.float64)):
+        sup, inds = rnms(dets, 0.7)
+        assert isinstance(sup, np.ndarray) and dets.dtype == sup.dtype
+        assert len(inds) == len(sup) == 3
+        sup, inds = rnms(dets, 0.7, device_id=0)
+        assert len(inds) == len(sup) == 3
+    for tt in (torch.FloatTensor(base), torch.DoubleTensor(base), torch.FloatTensor(base).to(dev())):
+        sup, inds = rnms(tt, 0.7)
+        assert tt.dtype == sup.dtype and sup.device == tt.device and inds.device == tt.device
+        assert inds.dtype == torch.int64 and len(inds) == len(sup) == 3
+    sup, inds = rnms(np.zeros((0, 6), np.float32), 0.5)
+    assert inds.shape == (0,) and inds.dtype == np.int64
+    with pytest.raises(TypeError):
+        rnms([[0, 0, 1, 1, 0, 1]], 0.5)
+
+
+def test_hbb_nms_matches_reference_golden(golden):
+    """Anchor A2: `nms` (theta=0 mapping onto the rotated kernel) against keep
+    indices produced by the reference's own nms_cpu.cpp."""
+    from aidet_amd import nms
+    g = golden('hbb_nms.npz')
+    for tag, thr in (('test4', 0.7), ('doc7', 0.7), ('ge', 1.0)):
+        _, inds = nms(g[tag + '_dets'], thr)
+        assert np.array_equal(inds, g[tag + '_keep'])
+    for tag in 'abcd':
+        dets, thr = g['rand_%s_dets' % tag], float(g['rand_%s_thr' % tag])
+        _, inds = nms(t(dets), thr)
+        assert np.array_equal(inds.cpu().numpy(), g['rand_%s_keep' % tag])
+
+
+# --------------------------------------------------------------------------
+# rotated RoI-Align
+# --------------------------------------------------------------------------
+def _rois(k, canvas, seed, batch=1):
+    r = oracle.synth_boxes(k, canvas, seed)[:, :5]
+    b = (np.arange(k) % batch).astype(np.float32)[:, None]
+    return np.concatenate([b, r], 1).astype(np.float32)
+
+
+@pytest.mark.parametrize('C,H,W,K,out,sn', [(16, 64, 64, 40, 7, 2), (3, 33, 47, 25, (5, 9), 0),
+                                            (40, 32, 32, 10, 14, 1), (256, 64, 64, 64, 7, 2)])
+def test_rroi_align_forward(C, H, W, K, out, sn):
+    from aidet_amd import RRoIAlign
+    rng = np.random.default_rng(C + K)
+    feat = rng.standard_normal((2, C, H, W)).astype(np.float32)
+    rois = _rois(K, 4 * W, 5, batch=2)
+    layer = RRoIAlign(out, 0.25, sample_num=sn)
+    got = layer(t(feat), t(rois)).cpu().numpy()
+    ref = oracle.rroi_align_forward(feat, rois, out, 0.25, sn)
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() <= IOU_TOL
+
+
+def test_rroi_align_cfg3():
+    """BASELINE.json configs[2]: 512 rotated RoIs, 256 x H x W fp32 map, 7x7."""
+    from aidet_amd import RRoIAlign
+    rng = np.random.default_rng(5)
+    feat = rng.standard_normal((1, 256, 256, 256)).astype(np.float32)
+    rois = _rois(512, 1024, 5)
+    got = RRoIAlign(7, 0.25, sample_num=2)(t(feat), t(rois)).cpu().numpy()
+    ref = oracle.rroi_align_forward(feat, rois, 7, 0.25, 2)
+    assert np.abs(got - ref).max() <= IOU_TOL
+
+
+def test_rroi_align_theta0_equals_roi_align_v2():
+    """Anchor A4: theta=0 reproduces RoIAlignForwardV2(aligned=False)
+    (roi_align_kernel_v2.cu:62-128) on the equivalent xyxy RoI."""
+    from aidet_amd import RRoIAlign
+    rng = np.random.default_rng(1)
+    feat = rng.standard_normal((1, 8, 50, 60)).astype(np.float32)
+    x1 = rng.uniform(0, 150, 30); y1 = rng.uniform(0, 120, 30)
+    w = rng.uniform(4, 90, 30); h = rng.uniform(4, 90, 30)
+    xyxy = np.stack([np.zeros(30), x1, y1, x1 + w, y1 + h], 1).astype(np.float32)
+    rr = np.stack([np.zeros(30), x1 + w / 2, y1 + h / 2, w, h, np.zeros(30)], 1).astype(np.float32)
+    got = RRoIAlign(7, 0.25, sample_num=2)(t(feat), t(rr)).cpu().numpy()
+    ref = oracle.roi_align_forward(feat, xyxy, 7, 0.25, 2, version=2, aligned=False)
+    assert np.abs(got - ref).max() <= IOU_TOL
+
+
+def test_rroi_align_backward():
+    from aidet_amd import RRoIAlign
+    rng = np.random.default_rng(2)
+    feat = rng.standard_normal((2, 24, 40, 40)).astype(np.float32)
+    rois = _rois(50, 160, 9, batch=2)
+    ft = t(feat).requires_grad_(True)
+    out = RRoIAlign(7, 0.25, sample_num=2)(ft, t(rois))
+    g = rng.standard_normal(out.shape).astype(np.float32)
+    out.backward(t(g))
+    ref = oracle.rroi_align_backward(g, rois, feat.shape, 0.25, 2)
+    got = ft.grad.cpu().numpy()
+    # float atomics: summation order differs -> relative tolerance
+    assert np.abs(got - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
+
+
+def test_rroi_align_errors():
+    from aidet_amd import RRoIAlign
+    layer = RRoIAlign(7, 0.25, 2)
+    with pytest.raises(NotImplementedError):  # CPU features, like roi_align.py:41-42
+        layer(torch.zeros(1, 2, 8, 8), torch.zeros(1, 6))
+    with pytest.raises(AssertionError):       # rois must be (K, 6), cf. roi_align.py:136
+        layer(torch.zeros(1, 2, 8, 8, device=dev()), torch.zeros(1, 5, device=dev()))
+    out = layer(torch.zeros(1, 2, 8, 8, device=dev()), torch.zeros(0, 6, device=dev()))
+    assert tuple(out.shape) == (0, 2, 7, 7)
+
+
+def test_thetaobb2pointobb():
+    from aidet_amd import thetaobb2pointobb
+    d = oracle.synth_boxes(100, 512, 3)[:, :5]
+    got = thetaobb2pointobb(t(d)).cpu().numpy()
+    assert np.abs(got - oracle.rbox_to_poly(d)).max() <= 1e-3
