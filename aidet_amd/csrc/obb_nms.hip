@@ -247,9 +247,12 @@ __global__ __launch_bounds__(1024) void nms_resolve_kernel(uint2 *__restrict__ e
                                                            NmsCounters *__restrict__ ctr) {
   __shared__ int wsum[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  unsigned long long found = ctr->edges;
-  long long live = (long long)(found < cap ? found : cap);
+  const unsigned long long found = ctr->edges;
+  // an overflowed edge list is incomplete (cnt[] counts edges that were not
+  // stored): nothing to resolve, the host reports OBB_EWORKSPACE
+  long long live = found <= cap ? (long long)found : 0;
   long long rounds = 0;
+  int stalled = 0;
   while (live > 0) {
     long long w = 0;
     for (long long base = 0; base < live; base += 1024) {
@@ -284,10 +287,15 @@ __global__ __launch_bounds__(1024) void nms_resolve_kernel(uint2 *__restrict__ e
       w += tot;
       __syncthreads();
     }
+    // every round retires at least the live edge with the smallest source (its
+    // source is decided); two rounds without progress can only mean corrupted
+    // input state -- stop instead of spinning
+    stalled = (w == live) ? stalled + 1 : 0;
     live = w;
     ++rounds;
     __threadfence();
     __syncthreads();
+    if (stalled >= 2) break;
   }
   if (tid == 0) ctr->rounds = rounds;
 }
