@@ -1,0 +1,111 @@
+"""CPU tests: the C-ABI library loads and exports every symbol include/obbops.h
+declares; argument validation; host-side wrapper behaviour that needs no GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, 'include', 'obbops.h')).read()
+    return re.findall(r'OBB_API\s+[\w\s\*]+?\b(obb_\w+)\s*\(', text)
+
+
+def test_library_exports_every_declared_symbol():
+    from aidet_amd import _lib
+    L = _lib.lib()
+    names = declared_symbols()
+    assert len(names) >= 10
+    for n in names:
+        assert hasattr(L, n), 'libobbops.so does not export ' + n
+    assert L.obb_version() >= 100
+    assert b'gfx950' in L.obb_build_info()
+
+
+def test_header_cites_reference_for_each_entry_point():
+    text = open(os.path.join(ROOT, 'include', 'obbops.h')).read()
+    for cite in ('geometry.py:4-88', 'nms_cuda.cpp:8-17', 'nms_cpu.cpp', 'roi_align_cuda.cpp',
+                 'transforms.py:45-55'):
+        assert cite in text
+
+
+def test_argument_validation_without_gpu():
+    """Validation happens before any device work, so it is testable here."""
+    from aidet_amd import _lib
+    L = _lib.lib()
+    null = ctypes.c_void_p(0)
+    assert L.obb_overlaps_f32(null, -1, null, 3, 0, 0, 0, null, null) == _lib.OBB_EINVAL
+    assert b'negative' in L.obb_last_error()
+    assert L.obb_overlaps_f32(null, 2, null, 3, 7, 0, 0, null, null) == _lib.OBB_EINVAL
+    assert L.obb_overlaps_f32(null, 2, null, 3, 0, 9, 0, null, null) == _lib.OBB_EINVAL
+    assert L.obb_overlaps_f32(null, 2, null, 3, 0, 0, 1, null, null) == _lib.OBB_EINVAL   # aligned, m != n
+    assert L.obb_overlaps_f32(null, 0, null, 3, 0, 0, 0, null, null) == _lib.OBB_OK       # empty: no-op
+    assert L.obb_overlaps_f32(null, 2, null, 3, 0, 0, 0, null, null) == _lib.OBB_EINVAL   # null pointers
+    info = (ctypes.c_int64 * 4)()
+    assert L.obb_nms_f32(null, -5, 0, 0.5, null, info, null, 0, null) == _lib.OBB_EINVAL
+    assert L.obb_nms_f32(null, 0, 0, 0.5, null, info, null, 0, null) == _lib.OBB_OK
+    assert L.obb_nms_f32(null, 5, 3, 0.5, null, info, null, 0, null) == _lib.OBB_EINVAL
+    assert L.obb_rroi_align_forward_f32(null, 1, 1, 4, 4, null, 1, 0, 7, 1.0, 2, 1.0, null, null) == _lib.OBB_EINVAL
+    assert L.obb_rroi_align_forward_f32(null, 1, 1, 4, 4, null, 0, 7, 7, 1.0, 2, 1.0, null, null) == _lib.OBB_OK
+    assert L.obb_rbox_to_poly_f32(null, 0, null, null) == _lib.OBB_OK
+    buf = (ctypes.c_float * 6)()
+    assert L.obb_nms_profile_last(buf) == _lib.OBB_EINVAL   # nothing profiled yet
+
+
+def test_wrapper_type_errors_match_reference():
+    """nms_wrapper.py:44-47 raises TypeError for anything but Tensor / ndarray."""
+    from aidet_amd import nms, poly_nms, rnms
+    for fn in (rnms, poly_nms, nms):
+        with pytest.raises(TypeError):
+            fn([[0, 0, 1, 1, 0, 1]], 0.5)
+    with pytest.raises(ValueError):
+        rnms(np.zeros((3, 5), np.float32), 0.5)
+
+
+def test_empty_inputs_need_no_device():
+    """N == 0 returns before any device work (nms_wrapper.py:50-51)."""
+    from aidet_amd import rbbox_overlaps, rnms
+    kept, inds = rnms(np.zeros((0, 6), np.float32), 0.5)
+    assert kept.shape == (0, 6) and inds.dtype == np.int64 and inds.shape == (0,)
+    kept, inds = rnms(torch.zeros((0, 6)), 0.5)
+    assert inds.dtype == torch.int64 and inds.numel() == 0
+    assert tuple(rbbox_overlaps(torch.zeros(0, 5), torch.zeros(3, 5)).shape) == (0, 3)
+    assert tuple(rbbox_overlaps(torch.zeros(0, 5), torch.zeros(0, 5), is_aligned=True).shape) == (0, 1)
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason='checks the no-GPU failure mode')
+def test_product_fails_loudly_without_gpu():
+    """No CPU fallback exists: compute calls raise instead of silently degrading."""
+    from aidet_amd import RRoIAlign, rbbox_overlaps, rnms
+    with pytest.raises(RuntimeError):
+        rnms(np.ones((4, 6), np.float32), 0.5)
+    with pytest.raises(RuntimeError):
+        rbbox_overlaps(torch.ones(2, 5), torch.ones(2, 5))
+    with pytest.raises(NotImplementedError):
+        RRoIAlign(7, 1.0)(torch.zeros(1, 1, 8, 8), torch.zeros(1, 6))
+
+
+def test_product_never_imports_oracle():
+    """oracle/ is test infrastructure: nothing under aidet_amd/ may reference it."""
+    pkg = os.path.join(ROOT, 'aidet_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.cuh', '.h')):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r'^\s*(import|from)\s+oracle', src, re.M), f
+                assert 'libobb_oracle' not in src, f
+
+
+def test_module_construction_mirrors_roi_align():
+    """RRoIAlign is built like RoIAlign: layer_cls(spatial_scale=1/s, **cfg)
+    (single_level.py:45-52) and exposes .out_size (single_level.py:94)."""
+    from aidet_amd import RRoIAlign
+    cfg = dict(out_size=7, sample_num=2)
+    layers = [RRoIAlign(spatial_scale=1 / s, **cfg) for s in (4, 8, 16, 32)]
+    assert layers[0].out_size == (7, 7)
+    assert 'RRoIAlign(out_size=(7, 7), spatial_scale=0.25, sample_num=2' in repr(layers[0])
