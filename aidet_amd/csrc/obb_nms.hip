@@ -1,26 +1,42 @@
 // obb_nms.hip -- greedy rotated / polygon NMS on gfx950, entirely on the GPU.
 //
-// Replaces nms_cuda (mmdet/ops/nms/src/nms_kernel.cu:71-139: sort, 64x64
-// bitmask kernel, 1.25 GB mask D2H copy at n = 100k, serial host reduce) with
-// the semantics of the CPU reference (mmdet/ops/nms/src/nms_cpu.cpp:21-59).
+// Replaces nms_cuda (mmdet/ops/nms/src/nms_kernel.cu:71-139: score sort, dense
+// 64x64 bit-mask kernel over all n^2 pairs, 1.25 GB mask D2H copy at n = 100k,
+// serial host reduce) with the semantics of the CPU reference
+// (mmdet/ops/nms/src/nms_cpu.cpp:21-59).
 //
-// Pipeline (one stream, no host round trip until the final count read-back):
-//   1 key      score -> order-preserving uint32 key, value = original index
-//   2 sort     stable LSD radix sort (rocPRIM) -> order[]
-//   3 gather   boxes in sorted order -> 64-byte quad records + conservative
-//              AABB intervals (float4), both coalesced for the pair kernel
-//   4 pair     upper-triangular tiles; 4-compare interval scan per pair, LDS
-//              ballot-compacted candidate queue, full-wave polygon clip; pairs
-//              with overlap >= thr are appended to a sparse EDGE list (i -> j,
-//              i before j in score order) and counted per target (cnt[j]).
-//              The n x n/64 bit matrix of the reference is never materialised.
-//   5 resolve  the greedy scan is the unique fixpoint of
-//                 kept(j)  <=>  no kept i with an edge i -> j
-//              evaluated by rounds over the live edges only: an edge whose
-//              source is kept suppresses its target; an edge whose source is
-//              suppressed decrements cnt[target], which becomes kept at zero.
-//   6 compact  keep flags scattered to original index order, block scan ->
-//              ascending int64 indices (nms_cpu.cpp:59).
+// Greedy NMS is the unique fixpoint of
+//     kept(j)  <=>  no kept i that PRECEDES j with overlap(i,j) >= thr
+// where "precedes" = higher score, ties -> lower index.  Nothing in that
+// definition needs the boxes to be physically sorted by score, so the single
+// sort of this pipeline is spent on SPACE instead: boxes are ordered along a
+// Morton curve, tiles of 256 consecutive boxes get a bounding box, and only
+// tile pairs whose boxes meet are scanned (about 1/30 of all pairs at n = 100k,
+// for any distribution -- big boxes just make big tiles).
+//
+//   1 prep     per box: 64-byte quad record, conservative AABB interval, score
+//              key; per-block min/max of the scene
+//   2 quant    intervals -> 15-bit grid over the scene, x|y packed in a dword
+//              with guard bits; Morton key of the centre
+//   3 sort     LSD radix sort of (Morton key, box id)              [rocPRIM]
+//   4 permute  packed intervals in spatial order + one bounding box per tile
+//   5 cull     all tile pairs (A <= B): keep those whose bounding boxes meet
+//   6 scan     per surviving tile pair 256 x 256 interval tests, 3 full-rate
+//              VALU ops per pair (a wave holds 64 rows in one VGPR pair and
+//              broadcasts them with v_readlane; 4 columns per lane), one wave
+//              vote per 256 pairs; survivors are compacted through a per-wave
+//              LDS queue (ballot/popcount) into sharded global CANDIDATE lists
+//   7 clip     one candidate pair per lane, perfectly balanced: the polygon
+//              clip (~1100 VALU) runs with every lane busy; pairs with overlap
+//              >= thr become directed EDGES (preceding box -> other box) and
+//              bump cnt[target].  The n x n/64 bit matrix of the reference is
+//              never materialised.
+//   8 resolve  rounds over the live edges only: an edge whose source is kept
+//              suppresses its target; an edge whose source is suppressed
+//              decrements cnt[target], which becomes kept at zero.
+//   9 compact  block scan over the flags (already in original index order) ->
+//              ascending int64 indices (nms_cpu.cpp:59) + count.
+#include <cstdlib>
 #include <cstring>
 
 #include <hip/hip_runtime.h>
@@ -31,204 +47,447 @@
 
 namespace obb {
 
-constexpr int kNmsWaves = 4;
-constexpr int kNmsColsPerLane = 4;
-constexpr int kNmsColsPerWave = 64 * kNmsColsPerLane;           // 256
-constexpr int kNmsColsPerBlock = kNmsWaves * kNmsColsPerWave;   // 1024
-constexpr int kNmsMaxRows = 256;
-constexpr int kNmsQueue = 64 + kNmsColsPerWave;
+constexpr int kTile = 256;            // boxes per spatial tile
+constexpr int kNmsWaves = 8;          // waves per scan block (one block = one tile pair)
+constexpr int kNmsColsPerLane = 4;    // 64 lanes x 4 = one tile of columns per wave
+constexpr int kRowsPerWave = kTile / kNmsWaves;  // 32 rows of the row tile per wave
+constexpr int kRowChunk = 8;
+constexpr int kNmsQueue = 64 + kTile;  // carry (<= 63) + one row's worst case
+constexpr int kShards = 64;            // candidate lists / counters (atomic rate)
+constexpr int kPrepBlocks = 1024;     // upper bound on blocks of the prep kernel
+constexpr int kPairBlocks = 4096;     // grid of the scan kernel (blocks loop over tile pairs)
+constexpr int kClipBlocksPerShard = 32;
 
 constexpr uint8_t kUndecided = 0, kKept = 1, kSuppressed = 2;
+constexpr uint32_t kGuard = 0x80008000u;   // guard bits of the packed intervals
+constexpr uint32_t kQMax = 32766u;         // finite boxes quantise to 0..32766
+constexpr uint32_t kSentLo = 0x7FFF7FFFu;  // "never a candidate": lo = max, hi = 0
+constexpr uint32_t kSentHi = kGuard;
 
 struct alignas(16) QuadRec {  // 64 bytes: four float4 loads
   float ox, oy, ex, ey;
   float rx[4];
   float ry[4];
-  float area, pad0, pad1, pad2;
+  float area;
+  uint32_t skey;  // score key: smaller = visited earlier by the greedy scan
+  float pad1, pad2;
 };
 
 struct NmsCounters {
   unsigned long long edges;   // overlap edges found (may exceed capacity)
   long long kept;             // K
   long long rounds;           // resolve rounds
-  long long pad;
+  unsigned int tile_pairs;    // surviving tile pairs (heavy + light)
+  unsigned int heavy_pairs;   // of which heavy (stored from the front of the list)
+  unsigned long long cand[kShards];  // candidate pairs per shard (may exceed the segment)
 };
 
 __device__ __forceinline__ void nms_interval(float o, float e, float &lo, float &hi) {
+  // margin 2^-21 (|o| + e): covers every rounding of the spec's prefilter
   float mg = (fabs_sel(o) + e) * 4.76837158203125e-7f;
   lo = (o - e) - mg;
   hi = (o + e) + mg;
 }
 
-// ---- 1: keys ---------------------------------------------------------------
-__global__ __launch_bounds__(256) void nms_key_kernel(const float *__restrict__ dets, int64_t n,
-                                                      int stride, uint32_t *__restrict__ keys,
-                                                      uint32_t *__restrict__ vals) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    keys[i] = score_key(dets[i * stride + stride - 1]);
-    vals[i] = (uint32_t)i;
-  }
+// order-preserving float <-> uint map (min/max of floats as integers)
+__device__ __forceinline__ uint32_t fkey(float f) {
+  uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float fkey_inv(uint32_t k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
 }
 
-// ---- 3: gather into sorted order --------------------------------------------
+__device__ __forceinline__ uint32_t shfl_xor_u(uint32_t v, int o) {
+  return (uint32_t)__shfl_xor((int)v, o);
+}
+
+// ---- 1: prep -------------------------------------------------------------------
+// part[block] = { max key(xhi), max ~key(xlo), max key(yhi), max ~key(ylo) }
 template <int KIND>
-__global__ __launch_bounds__(256) void nms_gather_kernel(const float *__restrict__ dets, int64_t n,
-                                                         const uint32_t *__restrict__ order,
-                                                         QuadRec *__restrict__ rec,
-                                                         float4 *__restrict__ iv) {
+__global__ __launch_bounds__(256) void nms_prep_kernel(const float *__restrict__ dets, int64_t n,
+                                                       QuadRec *__restrict__ rec,
+                                                       float4 *__restrict__ iv,
+                                                       uint4 *__restrict__ part) {
   constexpr int S = KIND ? 9 : 6;
-  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n;
-       p += (int64_t)gridDim.x * blockDim.x) {
+  __shared__ uint4 wred[4];
+  uint32_t mxh = 0, mxl = 0, myh = 0, myl = 0;
+  for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n;
+       b += (int64_t)gridDim.x * blockDim.x) {
+    const float *row = dets + b * S;
     Quad q;
-    load_quad<KIND>(dets + (int64_t)order[p] * S, q);
+    load_quad<KIND>(row, q);
     QuadRec r;
     r.ox = q.ox; r.oy = q.oy; r.ex = q.ex; r.ey = q.ey;
 #pragma unroll
     for (int k = 0; k < 4; ++k) { r.rx[k] = q.rx[k]; r.ry[k] = q.ry[k]; }
-    r.area = q.area; r.pad0 = 0.f; r.pad1 = 0.f; r.pad2 = 0.f;
-    rec[p] = r;
+    r.area = q.area; r.skey = score_key(row[S - 1]); r.pad1 = 0.f; r.pad2 = 0.f;
+    rec[b] = r;
     float4 v;
     nms_interval(q.ox, q.ex, v.x, v.y);
     nms_interval(q.oy, q.ey, v.z, v.w);
-    iv[p] = v;
+    // a box with a non-finite interval can never reach overlap >= thr in the spec
+    // (its prefilter / area guards fail): isolate it from the scan
+    const float big = 3.0e38f;
+    const bool fin = (fabs_sel(v.x) < big) && (fabs_sel(v.y) < big) && (fabs_sel(v.z) < big) &&
+                     (fabs_sel(v.w) < big);
+    if (!fin) { v.x = 1.0f; v.y = -1.0f; v.z = 1.0f; v.w = -1.0f; }  // lo > hi = "isolated"
+    iv[b] = v;
+    if (fin) {
+      mxh = max(mxh, fkey(v.y)); mxl = max(mxl, ~fkey(v.x));
+      myh = max(myh, fkey(v.w)); myl = max(myl, ~fkey(v.z));
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    mxh = max(mxh, shfl_xor_u(mxh, o)); mxl = max(mxl, shfl_xor_u(mxl, o));
+    myh = max(myh, shfl_xor_u(myh, o)); myl = max(myl, shfl_xor_u(myl, o));
+  }
+  if ((threadIdx.x & 63) == 0) wred[threadIdx.x >> 6] = make_uint4(mxh, mxl, myh, myl);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint4 a = wred[0];
+    for (int k = 1; k < 4; ++k) {
+      a.x = max(a.x, wred[k].x); a.y = max(a.y, wred[k].y);
+      a.z = max(a.z, wred[k].z); a.w = max(a.w, wred[k].w);
+    }
+    part[blockIdx.x] = a;
   }
 }
 
-__device__ __forceinline__ void load_rec(const QuadRec *__restrict__ rec, uint32_t p, Quad &q) {
+// ---- 2: quantise + Morton key ----------------------------------------------------
+__device__ __forceinline__ uint32_t spread15(uint32_t v) {  // 15 bits -> even bit positions
+  v &= 0x7FFFu;
+  v = (v | (v << 8)) & 0x00FF00FFu;
+  v = (v | (v << 4)) & 0x0F0F0F0Fu;
+  v = (v | (v << 2)) & 0x33333333u;
+  v = (v | (v << 1)) & 0x55555555u;
+  return v;
+}
+
+// floor() of a monotone map is monotone, so lo_a <= hi_b ==> q(lo_a) <= q(hi_b):
+// the quantised test never loses a real overlap.
+__global__ __launch_bounds__(256) void nms_quant_kernel(const float4 *__restrict__ iv, int64_t n,
+                                                        const uint4 *__restrict__ part, int nparts,
+                                                        uint2 *__restrict__ qb,
+                                                        uint32_t *__restrict__ mkey,
+                                                        uint32_t *__restrict__ vals) {
+  __shared__ uint4 wred[4];
+  __shared__ float sb[4];
+  uint4 a = make_uint4(0u, 0u, 0u, 0u);
+  for (int k = threadIdx.x; k < nparts; k += 256) {
+    const uint4 p = part[k];
+    a.x = max(a.x, p.x); a.y = max(a.y, p.y); a.z = max(a.z, p.z); a.w = max(a.w, p.w);
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    a.x = max(a.x, shfl_xor_u(a.x, o)); a.y = max(a.y, shfl_xor_u(a.y, o));
+    a.z = max(a.z, shfl_xor_u(a.z, o)); a.w = max(a.w, shfl_xor_u(a.w, o));
+  }
+  if ((threadIdx.x & 63) == 0) wred[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint4 m = wred[0];
+    for (int k = 1; k < 4; ++k) {
+      m.x = max(m.x, wred[k].x); m.y = max(m.y, wred[k].y);
+      m.z = max(m.z, wred[k].z); m.w = max(m.w, wred[k].w);
+    }
+    const bool any = m.x != 0u;  // at least one finite box
+    const float bx = any ? fkey_inv(~m.y) : 0.0f, by = any ? fkey_inv(~m.w) : 0.0f;
+    const float rx = any ? fkey_inv(m.x) - bx : 0.0f, ry = any ? fkey_inv(m.z) - by : 0.0f;
+    sb[0] = bx; sb[1] = by;
+    sb[2] = rx > 0.0f ? (float)kQMax / rx : 0.0f;
+    sb[3] = ry > 0.0f ? (float)kQMax / ry : 0.0f;
+  }
+  __syncthreads();
+  const float bx = sb[0], by = sb[1], sx = sb[2], sy = sb[3];
+  auto qz = [](float x, float b, float s) {
+    float u = floorf((x - b) * s);
+    u = u < 0.0f ? 0.0f : (u > (float)kQMax ? (float)kQMax : u);
+    return (uint32_t)u;
+  };
+  for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n;
+       b += (int64_t)gridDim.x * blockDim.x) {
+    const float4 v = iv[b];
+    uint2 o = make_uint2(kSentLo, kSentHi);
+    uint32_t mk = 0x3FFFFFFFu;  // isolated boxes sort to the end
+    if (v.x <= v.y) {
+      const uint32_t xl = qz(v.x, bx, sx), xh = qz(v.y, bx, sx);
+      const uint32_t yl = qz(v.z, by, sy), yh = qz(v.w, by, sy);
+      o.x = xl | (yl << 16);
+      o.y = (xh | (yh << 16)) | kGuard;
+      mk = spread15((xl + xh) >> 1) | (spread15((yl + yh) >> 1) << 1);
+    }
+    qb[b] = o;
+    mkey[b] = mk;
+    vals[b] = (uint32_t)b;
+  }
+}
+
+// ---- 4: permute into spatial order + tile bounding boxes ---------------------------
+// one block = one tile of 256 spatial positions
+__global__ __launch_bounds__(256) void nms_permute_kernel(const uint2 *__restrict__ qb,
+                                                          const uint32_t *__restrict__ sid,
+                                                          int64_t n, uint2 *__restrict__ qs,
+                                                          uint2 *__restrict__ tbox) {
+  __shared__ uint4 wred[4];
+  const int64_t s = (int64_t)blockIdx.x * kTile + threadIdx.x;
+  uint2 o = make_uint2(kSentLo, kSentHi);
+  if (s < n) o = qb[sid[s]];
+  qs[s] = o;
+  uint32_t xl = o.x & 0x7FFFu, yl = (o.x >> 16) & 0x7FFFu;
+  uint32_t xh = o.y & 0x7FFFu, yh = (o.y >> 16) & 0x7FFFu;
+  for (int k = 32; k > 0; k >>= 1) {
+    xl = min(xl, shfl_xor_u(xl, k)); yl = min(yl, shfl_xor_u(yl, k));
+    xh = max(xh, shfl_xor_u(xh, k)); yh = max(yh, shfl_xor_u(yh, k));
+  }
+  if ((threadIdx.x & 63) == 0) wred[threadIdx.x >> 6] = make_uint4(xl, yl, xh, yh);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint4 m = wred[0];
+    for (int k = 1; k < 4; ++k) {
+      m.x = min(m.x, wred[k].x); m.y = min(m.y, wred[k].y);
+      m.z = max(m.z, wred[k].z); m.w = max(m.w, wred[k].w);
+    }
+    // a tile of sentinels only keeps lo = max, hi = 0: it meets nothing
+    tbox[blockIdx.x] = make_uint2(m.x | (m.y << 16), (m.z | (m.w << 16)) | kGuard);
+  }
+}
+
+// packed interval test: every guard bit of (b.hi|G - a.lo) and (a.hi|G - b.lo)
+// survives  <=>  the intervals meet on both axes.  Returns 0 for "meet".
+__device__ __forceinline__ uint32_t qdisjoint(uint32_t alo, uint32_t ahiG, uint32_t blo, uint32_t bhiG) {
+  const uint32_t d1 = bhiG - alo, d2 = ahiG - blo;
+  return (~d1 | ~d2) & kGuard;  // one v_bitop3_b32
+}
+
+// ---- 5: tile-pair culling ------------------------------------------------------------
+// thread per (A, B >= A); survivors are stored as (A << 16 | B)  [ntiles < 65536].
+// Candidate density differs by an order of magnitude between tile pairs (a tile
+// against itself or its Morton neighbour vs. two tiles that merely touch), and the
+// scan kernel's duration is set by its slowest block -- so pairs that overlap
+// substantially ("heavy") are listed from the FRONT of tpairs and start first,
+// the others from the BACK (longest-processing-time-first scheduling).
+__global__ __launch_bounds__(256) void nms_cull_kernel(const uint2 *__restrict__ tbox, int nt,
+                                                       uint32_t *__restrict__ tpairs,
+                                                       unsigned int tp_capacity,
+                                                       NmsCounters *__restrict__ ctr) {
+  const int A = blockIdx.y;
+  const int B = A + blockIdx.x * 256 + threadIdx.x;
+  bool ok = false, heavy = false;
+  if (B < nt) {
+    const uint2 a = tbox[A], b = tbox[B];
+    ok = qdisjoint(a.x, a.y, b.x, b.y) == 0u;
+    if (ok) {
+      const int axl = a.x & 0x7FFF, ayl = (a.x >> 16) & 0x7FFF, axh = a.y & 0x7FFF, ayh = (a.y >> 16) & 0x7FFF;
+      const int bxl = b.x & 0x7FFF, byl = (b.x >> 16) & 0x7FFF, bxh = b.y & 0x7FFF, byh = (b.y >> 16) & 0x7FFF;
+      const float ow = (float)(min(axh, bxh) - max(axl, bxl) + 1), oh = (float)(min(ayh, byh) - max(ayl, byl) + 1);
+      const float aa = (float)(axh - axl + 1) * (float)(ayh - ayl + 1);
+      const float ab = (float)(bxh - bxl + 1) * (float)(byh - byl + 1);
+      heavy = (A == B) || (ow * oh * 8.0f >= fminf(aa, ab));
+    }
+  }
+  const int lane = threadIdx.x & 63;
+  const uint64_t mh = __ballot(ok && heavy), ml = __ballot(ok && !heavy);
+  if (mh) {
+    const int leader = __ffsll((long long)mh) - 1;
+    unsigned int base = 0;
+    if (lane == leader) base = atomicAdd(&ctr->heavy_pairs, (unsigned int)__popcll(mh));
+    base = (unsigned int)__shfl((int)base, leader);
+    if (ok && heavy) tpairs[base + __popcll(mh & ((1ull << lane) - 1ull))] = ((uint32_t)A << 16) | (uint32_t)B;
+  }
+  if (ml) {
+    const int leader = __ffsll((long long)ml) - 1;
+    unsigned int base = 0;
+    if (lane == leader) base = atomicAdd(&ctr->tile_pairs, (unsigned int)__popcll(ml));  // light count for now
+    base = (unsigned int)__shfl((int)base, leader);
+    if (ok && !heavy) tpairs[tp_capacity - 1u - (base + __popcll(ml & ((1ull << lane) - 1ull)))] = ((uint32_t)A << 16) | (uint32_t)B;
+  }
+}
+
+// ---- 6: scan kernel --------------------------------------------------------------------
+// One wave: 64 rows of tile A (lane l holds row l; broadcast with v_readlane) x
+// 256 columns of tile B (4 per lane).  15 full-rate VALU + 2 v_readlane per row.
+// Rows with a candidate are only RECORDED in `hit` and pushed out of line.
+template <bool DIAG>
+__device__ __forceinline__ void nms_scan_rows(uint2 rv, uint32_t rid, uint32_t sa0, uint32_t sb0,
+                                              const uint2 (&col)[4], const uint32_t (&cid)[4],
+                                              uint2 *q, int &qn, uint2 *__restrict__ cand,
+                                              unsigned long long segcap,
+                                              unsigned long long *__restrict__ ccnt, int lane) {
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+  const uint32_t sbl = sb0 + lane * kNmsColsPerLane;
+  for (int ib = 0; ib < kRowsPerWave; ib += kRowChunk) {
+    uint32_t hit = 0;
+#pragma unroll
+    for (int u = 0; u < kRowChunk; ++u) {
+      const uint32_t rlo = (uint32_t)__builtin_amdgcn_readlane((int)rv.x, ib + u);
+      const uint32_t rhi = (uint32_t)__builtin_amdgcn_readlane((int)rv.y, ib + u);
+      uint32_t t0 = qdisjoint(rlo, rhi, col[0].x, col[0].y);
+      uint32_t t1 = qdisjoint(rlo, rhi, col[1].x, col[1].y);
+      uint32_t t2 = qdisjoint(rlo, rhi, col[2].x, col[2].y);
+      uint32_t t3 = qdisjoint(rlo, rhi, col[3].x, col[3].y);
+      if (DIAG) {  // only pairs (row, col) with col > row exist in a diagonal tile
+        const uint32_t sa = sa0 + ib + u;
+        t0 |= (sbl + 0 > sa) ? 0u : 1u; t1 |= (sbl + 1 > sa) ? 0u : 1u;
+        t2 |= (sbl + 2 > sa) ? 0u : 1u; t3 |= (sbl + 3 > sa) ? 0u : 1u;
+      }
+      const uint32_t m = min(min(t0, t1), min(t2, t3));
+      hit |= __any(m == 0u) ? (1u << u) : 0u;
+    }
+    while (hit) {  // some lane has a candidate in row ib+u
+      const int u = __builtin_ctz(hit);
+      hit &= hit - 1u;
+      const uint32_t rlo = (uint32_t)__builtin_amdgcn_readlane((int)rv.x, ib + u);
+      const uint32_t rhi = (uint32_t)__builtin_amdgcn_readlane((int)rv.y, ib + u);
+      const uint32_t ida = (uint32_t)__builtin_amdgcn_readlane((int)rid, ib + u);
+      const uint32_t sa = sa0 + ib + u;
+#pragma unroll
+      for (int c = 0; c < kNmsColsPerLane; ++c) {
+        bool cnd = qdisjoint(rlo, rhi, col[c].x, col[c].y) == 0u;
+        if (DIAG) cnd = cnd && (sbl + c > sa);
+        const uint64_t mk = __ballot(cnd);
+        if (mk) {
+          if (cnd) q[qn + __popcll(mk & lt_mask)] = make_uint2(ida, cid[c]);
+          qn += __popcll(mk);
+        }
+      }
+      while (qn >= 64) {  // flush a full batch: one global atomic per 64 candidates
+        qn -= 64;
+        __builtin_amdgcn_wave_barrier();
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(ccnt, 64ull);
+        base = __shfl(base, 0);
+        const uint2 e = q[qn + lane];
+        if (base + lane < segcap) cand[base + lane] = e;
+      }
+    }
+  }
+}
+
+// block k handles tile pairs k, k + gridDim.x, ... of the list [heavy ..., light ...];
+// wave w owns rows [32 w, 32 w + 32) of the row tile.
+__global__ __launch_bounds__(512) void nms_scan_kernel(const uint2 *__restrict__ qs,
+                                                       const uint32_t *__restrict__ sid,
+                                                       const uint32_t *__restrict__ tpairs,
+                                                       unsigned int tp_capacity,
+                                                       uint2 *__restrict__ cands,
+                                                       unsigned long long segcap,
+                                                       NmsCounters *__restrict__ ctr) {
+  __shared__ uint2 queue[kNmsWaves][kNmsQueue];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  uint2 *q = queue[wave];
+  int qn = 0;
+  const uint32_t gw = blockIdx.x * kNmsWaves + wave;       // global wave id
+  const int shard = (int)(gw & (kShards - 1));
+  uint2 *cand = cands + (size_t)shard * segcap;
+  unsigned long long *ccnt = &ctr->cand[shard];
+  const unsigned int nheavy = ctr->heavy_pairs, nlight = ctr->tile_pairs;
+  const unsigned int ntp = nheavy + nlight;
+  for (unsigned int k = blockIdx.x; k < ntp; k += gridDim.x) {
+    const uint32_t tp = (k < nheavy) ? tpairs[k] : tpairs[tp_capacity - 1u - (k - nheavy)];
+    const uint32_t A = tp >> 16, B = tp & 0xFFFFu;
+    const uint32_t sa0 = A * kTile + wave * kRowsPerWave;   // this wave's 32 rows
+    const uint32_t sb0 = B * kTile;                          // 256 columns
+    // qs / sid are padded to whole tiles (sentinel intervals never match);
+    // lanes >= 32 mirror lanes < 32 (only rows 0..31 are ever broadcast)
+    const uint2 rv = qs[sa0 + (lane & (kRowsPerWave - 1))];
+    const uint32_t rid = sid[sa0 + (lane & (kRowsPerWave - 1))];
+    uint2 col[4];
+    uint32_t cid[4];
+    {
+      const uint4 *cp = reinterpret_cast<const uint4 *>(qs + sb0 + lane * kNmsColsPerLane);
+      const uint4 a = cp[0], b = cp[1];
+      const uint4 c = *reinterpret_cast<const uint4 *>(sid + sb0 + lane * kNmsColsPerLane);
+      col[0] = make_uint2(a.x, a.y); col[1] = make_uint2(a.z, a.w);
+      col[2] = make_uint2(b.x, b.y); col[3] = make_uint2(b.z, b.w);
+      cid[0] = c.x; cid[1] = c.y; cid[2] = c.z; cid[3] = c.w;
+    }
+    if (A == B) nms_scan_rows<true>(rv, rid, sa0, sb0, col, cid, q, qn, cand, segcap, ccnt, lane);
+    else nms_scan_rows<false>(rv, rid, sa0, sb0, col, cid, q, qn, cand, segcap, ccnt, lane);
+  }
+  if (qn > 0) {  // final partial flush, once per wave
+    __builtin_amdgcn_wave_barrier();
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(ccnt, (unsigned long long)qn);
+    base = __shfl(base, 0);
+    if (lane < qn && base + lane < segcap) cand[base + lane] = q[lane];
+  }
+}
+
+// ---- 7: clip kernel -----------------------------------------------------------------------
+__device__ __forceinline__ void load_rec(const QuadRec *__restrict__ rec, uint32_t p, Quad &q,
+                                         uint32_t &key) {
   const float4 *r = reinterpret_cast<const float4 *>(rec + p);
   float4 a = r[0], b = r[1], c = r[2], d = r[3];
   q.ox = a.x; q.oy = a.y; q.ex = a.z; q.ey = a.w;
   q.rx[0] = b.x; q.rx[1] = b.y; q.rx[2] = b.z; q.rx[3] = b.w;
   q.ry[0] = c.x; q.ry[1] = c.y; q.ry[2] = c.z; q.ry[3] = c.w;
   q.area = d.x;
+  key = __float_as_uint(d.y);
 }
 
-// clip one candidate pair per lane; append overlap edges (wave-aggregated)
-__device__ __forceinline__ void nms_clip_emit(const QuadRec *__restrict__ rec, bool active,
-                                              uint32_t i, uint32_t j, float thr,
-                                              uint2 *__restrict__ edges, unsigned long long cap,
-                                              NmsCounters *__restrict__ ctr, int *__restrict__ cnt,
-                                              int lane) {
-  bool hit = false;
-  if (active) {
-    Quad A, B;
-    load_rec(rec, i, A);
-    load_rec(rec, j, B);
-    float ov = quad_overlap(A, B, 0);
-    hit = ov >= thr;
-  }
-  const uint64_t mk = __ballot(hit);
-  if (mk) {
-    const int leader = __ffsll((long long)mk) - 1;
-    unsigned long long base = 0;
-    if (lane == leader) base = atomicAdd(&ctr->edges, (unsigned long long)__popcll(mk));
-    base = __shfl(base, leader);
-    if (hit) {
-      const unsigned long long pos = base + __popcll(mk & ((1ull << lane) - 1ull));
-      if (pos < cap) edges[pos] = make_uint2(i, j);
-      atomicAdd(&cnt[j], 1);
-    }
-  }
+__device__ __forceinline__ void swap_if(bool c, float &a, float &b) {
+  const float t = c ? b : a;
+  b = c ? a : b;
+  a = t;
 }
 
-// ---- 4: pair kernel -----------------------------------------------------------
-// Block = 4 waves x 256 columns; rows_per_block rows.  Blocks enumerate only
-// the tiles that intersect the strict upper triangle (j > i).
-template <bool DIAG>
-__device__ __forceinline__ void nms_scan_rows(const float4 *arow, int ti, uint32_t i0, uint32_t jw,
-                                              uint32_t j0, const float (&bxlo)[4],
-                                              const float (&bxhi)[4], const float (&bylo)[4],
-                                              const float (&byhi)[4], uint32_t *q,
-                                              const QuadRec *__restrict__ rec, float thr,
-                                              uint2 *__restrict__ edges, unsigned long long cap,
-                                              NmsCounters *__restrict__ ctr, int *__restrict__ cnt,
-                                              int lane) {
-  int qn = 0;
-  const uint64_t lt_mask = (1ull << lane) - 1ull;
-  for (int ii = 0; ii < ti; ++ii) {
-    const float4 r = arow[ii];
-#pragma unroll
-    for (int c = 0; c < kNmsColsPerLane; ++c) {
-      bool cand = (r.x <= bxhi[c]) && (bxlo[c] <= r.y) && (r.z <= byhi[c]) && (bylo[c] <= r.w);
-      if (DIAG) cand = cand && (j0 + c > i0 + ii);
-      const uint64_t mk = __ballot(cand);
-      if (mk) {
-        if (cand) q[qn + __popcll(mk & lt_mask)] = ((uint32_t)ii << 10) | (uint32_t)(lane * kNmsColsPerLane + c);
-        qn += __popcll(mk);
-      }
-    }
-    while (qn >= 64) {
-      qn -= 64;
-      __builtin_amdgcn_wave_barrier();
-      const uint32_t e = q[qn + lane];
-      nms_clip_emit(rec, true, i0 + (e >> 10), jw + (e & 1023u), thr, edges, cap, ctr, cnt, lane);
-    }
-  }
-  if (qn > 0) {
-    __builtin_amdgcn_wave_barrier();
-    const bool act = lane < qn;
-    const uint32_t e = act ? q[lane] : 0u;
-    nms_clip_emit(rec, act, i0 + (e >> 10), jw + (e & 1023u), thr, edges, cap, ctr, cnt, lane);
-  }
-}
-
-__global__ __launch_bounds__(256) void nms_pair_kernel(const float4 *__restrict__ iv,
-                                                       const QuadRec *__restrict__ rec, uint32_t n,
-                                                       float thr, int rows_per_block, int nj,
+// One candidate pair per lane.  The edge points from the box that PRECEDES in the
+// greedy order (smaller score key, then smaller index) to the other one; the clip
+// always takes the preceding box as the subject A, exactly like the i-before-j
+// loop of nms_cpu.cpp:35-58.  grid = (blocks per shard, shards).
+__global__ __launch_bounds__(256) void nms_clip_kernel(const uint2 *__restrict__ cands,
+                                                       unsigned long long segcap,
+                                                       const QuadRec *__restrict__ rec, float thr,
                                                        uint2 *__restrict__ edges,
                                                        unsigned long long cap,
                                                        NmsCounters *__restrict__ ctr,
                                                        int *__restrict__ cnt) {
-  __shared__ float4 arow[kNmsMaxRows];
-  __shared__ uint32_t queue[kNmsWaves][kNmsQueue];
-
-  // block id -> (row tile bi, col tile bj).  G = 1024/rows row tiles share the
-  // same first column tile g; blocks before group g: G*(g*nj - g(g-1)/2).
-  const int G = kNmsColsPerBlock / rows_per_block;
-  const long long id = blockIdx.x;
-  const double twoNj1 = 2.0 * nj + 1.0;
-  long long g = (long long)((twoNj1 - sqrt(twoNj1 * twoNj1 - 8.0 * (double)id / G)) * 0.5);
-  if (g < 0) g = 0;
-  if (g > nj - 1) g = nj - 1;
-  auto before = [&](long long gg) { return (long long)G * (gg * nj - gg * (gg - 1) / 2); };
-  while (g > 0 && before(g) > id) --g;
-  while (g + 1 < nj && before(g + 1) <= id) ++g;
-  const long long rem = id - before(g);
-  const int width = nj - (int)g;            // col tiles per row tile in this group
-  const uint32_t bi = (uint32_t)(g * G + rem / width);
-  const uint32_t bj = (uint32_t)(g + rem % width);
-
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  const uint32_t i0 = bi * (uint32_t)rows_per_block;
-  if (i0 >= n) return;  // (partial last group)
-  const int ti = (int)min((uint32_t)rows_per_block, n - i0);
-  const uint32_t jw = bj * kNmsColsPerBlock + wave * kNmsColsPerWave;
-  const uint32_t j0 = jw + lane * kNmsColsPerLane;
-
-  for (int t = threadIdx.x; t < ti; t += 256) arow[t] = iv[i0 + t];
-  float bxlo[4], bxhi[4], bylo[4], byhi[4];
+  const int shard = blockIdx.y;
+  const uint2 *cand = cands + (size_t)shard * segcap;
+  unsigned long long total = ctr->cand[shard];
+  if (total > segcap) total = segcap;  // overflow is reported by the host
+  // whole waves iterate together so that the ballot below sees all 64 lanes
+  const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+  for (unsigned long long base = (unsigned long long)blockIdx.x * blockDim.x + (threadIdx.x & ~63);
+       base < total; base += stride) {
+    const unsigned long long e = base + lane;
+    bool hit = false;
+    uint32_t src = 0, dst = 0;
+    if (e < total) {
+      const uint2 pr = cand[e];
+      Quad A, B;
+      uint32_t ka, kb;
+      load_rec(rec, pr.x, A, ka);
+      load_rec(rec, pr.y, B, kb);
+      const bool b_first = (kb < ka) || (kb == ka && pr.y < pr.x);
+      src = b_first ? pr.y : pr.x;
+      dst = b_first ? pr.x : pr.y;
+      swap_if(b_first, A.ox, B.ox); swap_if(b_first, A.oy, B.oy);
+      swap_if(b_first, A.ex, B.ex); swap_if(b_first, A.ey, B.ey);
+      swap_if(b_first, A.area, B.area);
 #pragma unroll
-  for (int c = 0; c < kNmsColsPerLane; ++c) {
-    if (j0 + c < n) {
-      const float4 v = iv[j0 + c];
-      bxlo[c] = v.x; bxhi[c] = v.y; bylo[c] = v.z; byhi[c] = v.w;
-    } else {
-      bxlo[c] = 3.0e38f; bxhi[c] = -3.0e38f; bylo[c] = 3.0e38f; byhi[c] = -3.0e38f;
+      for (int k = 0; k < 4; ++k) { swap_if(b_first, A.rx[k], B.rx[k]); swap_if(b_first, A.ry[k], B.ry[k]); }
+      const float ov = quad_overlap(A, B, 0);
+      hit = ov >= thr;
+    }
+    const uint64_t mk = __ballot(hit);
+    if (mk) {
+      const int leader = __ffsll((long long)mk) - 1;
+      unsigned long long pos0 = 0;
+      if (lane == leader) pos0 = atomicAdd(&ctr->edges, (unsigned long long)__popcll(mk));
+      pos0 = __shfl(pos0, leader);
+      if (hit) {
+        const unsigned long long pos = pos0 + __popcll(mk & ((1ull << lane) - 1ull));
+        if (pos < cap) edges[pos] = make_uint2(src, dst);
+        atomicAdd(&cnt[dst], 1);
+      }
     }
   }
-  __syncthreads();
-  if (jw >= n) return;
-  if (jw + kNmsColsPerWave - 1 <= i0) return;  // every column <= every row: no pair j > i
-
-  if (jw <= i0 + (uint32_t)ti - 1)
-    nms_scan_rows<true>(arow, ti, i0, jw, j0, bxlo, bxhi, bylo, byhi, queue[wave], rec, thr, edges, cap, ctr, cnt, lane);
-  else
-    nms_scan_rows<false>(arow, ti, i0, jw, j0, bxlo, bxhi, bylo, byhi, queue[wave], rec, thr, edges, cap, ctr, cnt, lane);
 }
 
-// ---- 5: resolve ---------------------------------------------------------------
+// ---- 8: resolve ---------------------------------------------------------------
 // agent-scope loads (L2): cnt is updated by atomics, which bypass this CU's L1
 __device__ __forceinline__ uint8_t ld_state(uint8_t *p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -287,9 +546,9 @@ __global__ __launch_bounds__(1024) void nms_resolve_kernel(uint2 *__restrict__ e
       w += tot;
       __syncthreads();
     }
-    // every round retires at least the live edge with the smallest source (its
-    // source is decided); two rounds without progress can only mean corrupted
-    // input state -- stop instead of spinning
+    // every round retires at least the live edge whose source precedes all other
+    // live sources (that source is decided); two rounds without progress can only
+    // mean corrupted state -- stop instead of spinning
     stalled = (w == live) ? stalled + 1 : 0;
     live = w;
     ++rounds;
@@ -300,23 +559,19 @@ __global__ __launch_bounds__(1024) void nms_resolve_kernel(uint2 *__restrict__ e
   if (tid == 0) ctr->rounds = rounds;
 }
 
-// ---- 6: compaction --------------------------------------------------------------
-__global__ __launch_bounds__(256) void nms_flag_kernel(const uint32_t *__restrict__ order,
-                                                       const uint8_t *__restrict__ state,
-                                                       const int *__restrict__ cnt, int64_t n,
-                                                       uint8_t *__restrict__ keepflag) {
-  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n;
-       p += (int64_t)gridDim.x * blockDim.x) {
-    const uint8_t s = state[p];
-    keepflag[order[p]] = (s == kKept) || (s == kUndecided && cnt[p] == 0);
-  }
+// ---- 9: compaction --------------------------------------------------------------
+__device__ __forceinline__ bool kept_flag(const uint8_t *__restrict__ state,
+                                          const int *__restrict__ cnt, int64_t i) {
+  const uint8_t s = state[i];
+  return (s == kKept) || (s == kUndecided && cnt[i] == 0);
 }
 
-__global__ __launch_bounds__(1024) void nms_count_kernel(const uint8_t *__restrict__ keepflag,
-                                                         int64_t n, int *__restrict__ blockcnt) {
+__global__ __launch_bounds__(1024) void nms_count_kernel(const uint8_t *__restrict__ state,
+                                                         const int *__restrict__ cnt, int64_t n,
+                                                         int *__restrict__ blockcnt) {
   __shared__ int wsum[16];
   const int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x;
-  const bool f = (i < n) && keepflag[i];
+  const bool f = (i < n) && kept_flag(state, cnt, i);
   const uint64_t mk = __ballot(f);
   if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = __popcll(mk);
   __syncthreads();
@@ -327,8 +582,9 @@ __global__ __launch_bounds__(1024) void nms_count_kernel(const uint8_t *__restri
   }
 }
 
-__global__ __launch_bounds__(1024) void nms_write_kernel(const uint8_t *__restrict__ keepflag,
-                                                         int64_t n, const int *__restrict__ blockcnt,
+__global__ __launch_bounds__(1024) void nms_write_kernel(const uint8_t *__restrict__ state,
+                                                         const int *__restrict__ cnt, int64_t n,
+                                                         const int *__restrict__ blockcnt,
                                                          int64_t *__restrict__ keep,
                                                          NmsCounters *__restrict__ ctr) {
   __shared__ int wsum[16];
@@ -341,7 +597,7 @@ __global__ __launch_bounds__(1024) void nms_write_kernel(const uint8_t *__restri
   for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o);
   if (lane == 0) red[wave] = part;
   const int64_t i = (int64_t)blockIdx.x * 1024 + tid;
-  const bool f = (i < n) && keepflag[i];
+  const bool f = (i < n) && kept_flag(state, cnt, i);
   const uint64_t mk = __ballot(f);
   if (lane == 0) wsum[wave] = __popcll(mk);
   __syncthreads();
@@ -375,41 +631,51 @@ static thread_local NmsProfile g_prof;
 
 // ---- workspace layout ------------------------------------------------------------
 struct NmsLayout {
-  size_t keys_in, keys_out, vals_in, order, iv, rec, zero_begin, state, cnt, ctr, zero_end,
-      keepflag, blockcnt, sort_temp, edges, total;
+  size_t rec, iv, part, qb, mkey_in, mkey_out, vals_in, sid, qs, tbox, tpairs, zero_begin,
+      state, cnt, ctr, zero_end, blockcnt, sort_temp, cands, edges, total;
   size_t sort_temp_bytes;
   unsigned long long cap;
+  int64_t ntiles;
 };
 
 static int nms_layout(int64_t n, int64_t edge_capacity, NmsLayout &L) {
   if (edge_capacity <= 0) {
-    edge_capacity = 32 * n;
+    edge_capacity = 64 * n;
     if (edge_capacity < (1 << 18)) edge_capacity = 1 << 18;
   }
   L.cap = (unsigned long long)edge_capacity;
   size_t tmp = 0;
   uint32_t *nul = nullptr;
-  hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp, nul, nul, nul, nul, (size_t)(n > 0 ? n : 1), 0u, 32u, (hipStream_t)0, false);
+  hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp, nul, nul, nul, nul, (size_t)(n > 0 ? n : 1), 0u, 30u, (hipStream_t)0, false);
   if (e != hipSuccess) return set_err(OBB_EHIP, "rocprim::radix_sort_pairs size query failed: %s", hipGetErrorString(e));
   L.sort_temp_bytes = tmp;
   const size_t nn = (size_t)(n > 0 ? n : 1);
+  const size_t nt = (nn + kTile - 1) / kTile;
+  L.ntiles = (int64_t)nt;
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
-  L.keys_in = take(nn * 4);
-  L.keys_out = take(nn * 4);
-  L.vals_in = take(nn * 4);
-  L.order = take(nn * 4);
-  L.iv = take(nn * sizeof(float4));
   L.rec = take(nn * sizeof(QuadRec));
+  L.iv = take(nn * sizeof(float4));
+  L.part = take(kPrepBlocks * sizeof(uint4));
+  L.qb = take(nn * sizeof(uint2));
+  L.mkey_in = take(nn * 4);
+  L.mkey_out = take(nn * 4);
+  L.vals_in = take(nn * 4);
+  L.sid = take((nt * kTile) * 4);
+  L.qs = take((nt * kTile + kRowChunk) * sizeof(uint2));
+  L.tbox = take(nt * sizeof(uint2));
+  L.tpairs = take((nt * (nt + 1) / 2) * 4);
   L.zero_begin = off;
   L.state = take(nn);
   L.cnt = take(nn * 4);
   L.ctr = take(sizeof(NmsCounters));
   L.zero_end = off;
-  L.keepflag = take(nn);
   L.blockcnt = take(((nn + 1023) / 1024) * 4);
   L.sort_temp = take(tmp > 0 ? tmp : 1);
-  L.edges = take((size_t)L.cap * sizeof(uint2));
+  // candidates and edges share one capacity: [cands | edges], cap entries each
+  L.cands = off;
+  L.edges = off;  // resolved at run time from the actual workspace size
+  off += 2 * (size_t)L.cap * sizeof(uint2);
   L.total = off;
   return OBB_OK;
 }
@@ -432,38 +698,46 @@ extern "C" int obb_nms_f32(const float *dets_dev, int64_t n, int kind, float iou
   if (n < 0) return set_err(OBB_EINVAL, "obb_nms_f32: negative n");
   if (kind != OBB_KIND_RBOX && kind != OBB_KIND_POLY) return set_err(OBB_EINVAL, "obb_nms_f32: bad kind %d", kind);
   if (n == 0) return OBB_OK;
-  if (n >= (1ll << 31)) return set_err(OBB_EINVAL, "obb_nms_f32: n = %lld exceeds 2^31-1", (long long)n);
+  if (n > (int64_t)kTile * 65535) return set_err(OBB_EINVAL, "obb_nms_f32: n = %lld exceeds %lld", (long long)n, (long long)kTile * 65535);
   if (!dets_dev || !keep_dev || !workspace_dev) return set_err(OBB_EINVAL, "obb_nms_f32: null pointer");
   if (reinterpret_cast<uintptr_t>(workspace_dev) & 255u) return set_err(OBB_EINVAL, "obb_nms_f32: workspace must be 256-byte aligned");
 
-  // capacity = whatever the caller's workspace holds beyond the fixed part
+  // pair capacity = whatever the caller's workspace holds beyond the fixed part,
+  // split evenly between the candidate lists and the edge list
   NmsLayout L;
   int rc = nms_layout(n, 1, L);
   if (rc != OBB_OK) return rc;
-  const size_t fixed = L.edges;
-  if (workspace_bytes < fixed + sizeof(uint2))
-    return set_err(OBB_EWORKSPACE, "obb_nms_f32: workspace %zu bytes < minimum %zu", workspace_bytes, fixed + sizeof(uint2));
-  const unsigned long long cap = (workspace_bytes - fixed) / sizeof(uint2);
+  const size_t fixed = L.cands;
+  if (workspace_bytes < fixed + 2 * kShards * sizeof(uint2))
+    return set_err(OBB_EWORKSPACE, "obb_nms_f32: workspace %zu bytes < minimum %zu", workspace_bytes, fixed + 2 * kShards * sizeof(uint2));
+  const unsigned long long segcap = (workspace_bytes - fixed) / (2 * sizeof(uint2)) / kShards;
+  const unsigned long long cap = segcap * kShards;
 
   char *ws = static_cast<char *>(workspace_dev);
-  uint32_t *keys_in = reinterpret_cast<uint32_t *>(ws + L.keys_in);
-  uint32_t *keys_out = reinterpret_cast<uint32_t *>(ws + L.keys_out);
-  uint32_t *vals_in = reinterpret_cast<uint32_t *>(ws + L.vals_in);
-  uint32_t *order = reinterpret_cast<uint32_t *>(ws + L.order);
-  float4 *iv = reinterpret_cast<float4 *>(ws + L.iv);
   QuadRec *rec = reinterpret_cast<QuadRec *>(ws + L.rec);
+  float4 *iv = reinterpret_cast<float4 *>(ws + L.iv);
+  uint4 *part = reinterpret_cast<uint4 *>(ws + L.part);
+  uint2 *qb = reinterpret_cast<uint2 *>(ws + L.qb);
+  uint32_t *mkey_in = reinterpret_cast<uint32_t *>(ws + L.mkey_in);
+  uint32_t *mkey_out = reinterpret_cast<uint32_t *>(ws + L.mkey_out);
+  uint32_t *vals_in = reinterpret_cast<uint32_t *>(ws + L.vals_in);
+  uint32_t *sid = reinterpret_cast<uint32_t *>(ws + L.sid);
+  uint2 *qs = reinterpret_cast<uint2 *>(ws + L.qs);
+  uint2 *tbox = reinterpret_cast<uint2 *>(ws + L.tbox);
+  uint32_t *tpairs = reinterpret_cast<uint32_t *>(ws + L.tpairs);
   uint8_t *state = reinterpret_cast<uint8_t *>(ws + L.state);
   int *cnt = reinterpret_cast<int *>(ws + L.cnt);
   NmsCounters *ctr = reinterpret_cast<NmsCounters *>(ws + L.ctr);
-  uint8_t *keepflag = reinterpret_cast<uint8_t *>(ws + L.keepflag);
   int *blockcnt = reinterpret_cast<int *>(ws + L.blockcnt);
   void *sort_temp = ws + L.sort_temp;
-  uint2 *edges = reinterpret_cast<uint2 *>(ws + L.edges);
+  uint2 *cands = reinterpret_cast<uint2 *>(ws + L.cands);
+  uint2 *edges = cands + cap;
   hipStream_t st = (hipStream_t)stream;
+  const int nt = (int)L.ntiles;
+  const unsigned int tp_capacity = (unsigned int)((size_t)nt * (nt + 1) / 2);
 
-  const int stride = kind == OBB_KIND_POLY ? 9 : 6;
-  unsigned gblocks = (unsigned)((n + 255) / 256);
-  if (gblocks > 4096) gblocks = 4096;
+  unsigned pblocks = (unsigned)((n + 255) / 256);
+  if (pblocks > (unsigned)kPrepBlocks) pblocks = kPrepBlocks;
 
   NmsProfile &prof = g_prof;
   const bool timed = prof.on;
@@ -472,47 +746,52 @@ extern "C" int obb_nms_f32(const float *dets_dev, int64_t n, int kind, float iou
     prof.created = true;
   }
 #define OBB_PHASE(k) do { if (timed) OBB_HIP_TRY(hipEventRecord(prof.ev[k], st)); } while (0)
+  // phase 0: clear + prep + quantise
   OBB_PHASE(0);
   OBB_HIP_TRY(hipMemsetAsync(ws + L.zero_begin, 0, L.zero_end - L.zero_begin, st));
-  hipLaunchKernelGGL(nms_key_kernel, dim3(gblocks), dim3(256), 0, st, dets_dev, n, stride, keys_in, vals_in);
+  if (kind == OBB_KIND_RBOX)
+    hipLaunchKernelGGL(nms_prep_kernel<0>, dim3(pblocks), dim3(256), 0, st, dets_dev, n, rec, iv, part);
+  else
+    hipLaunchKernelGGL(nms_prep_kernel<1>, dim3(pblocks), dim3(256), 0, st, dets_dev, n, rec, iv, part);
   OBB_LAUNCH_CHECK();
+  hipLaunchKernelGGL(nms_quant_kernel, dim3(pblocks), dim3(256), 0, st, iv, n, part, (int)pblocks, qb, mkey_in, vals_in);
+  OBB_LAUNCH_CHECK();
+  // phase 1: spatial sort
   OBB_PHASE(1);
   size_t tmp = L.sort_temp_bytes;
-  OBB_HIP_TRY(rocprim::radix_sort_pairs(sort_temp, tmp, keys_in, keys_out, vals_in, order, (size_t)n, 0u, 32u, st, false));
+  OBB_HIP_TRY(rocprim::radix_sort_pairs(sort_temp, tmp, mkey_in, mkey_out, vals_in, sid, (size_t)n, 0u, 30u, st, false));
+  // phase 2: permute + tile boxes + tile-pair culling
   OBB_PHASE(2);
-  if (kind == OBB_KIND_RBOX)
-    hipLaunchKernelGGL(nms_gather_kernel<0>, dim3(gblocks), dim3(256), 0, st, dets_dev, n, order, rec, iv);
-  else
-    hipLaunchKernelGGL(nms_gather_kernel<1>, dim3(gblocks), dim3(256), 0, st, dets_dev, n, order, rec, iv);
+  hipLaunchKernelGGL(nms_permute_kernel, dim3((unsigned)nt), dim3(kTile), 0, st, qb, sid, n, qs, tbox);
   OBB_LAUNCH_CHECK();
-
-  // pair kernel geometry
-  const int nj = (int)((n + kNmsColsPerBlock - 1) / kNmsColsPerBlock);
-  int rows = kNmsMaxRows;
-  auto tiles = [&](int r) {
-    const long long G = kNmsColsPerBlock / r;
-    return G * ((long long)nj * nj - (long long)nj * (nj - 1) / 2);  // upper bound incl. partial group
-  };
-  while (rows > 64 && tiles(rows) < 4096) rows >>= 1;
-  const long long nblocks = tiles(rows);
-  if (nblocks > 2147483647LL) return set_err(OBB_EINVAL, "obb_nms_f32: n = %lld needs too many tiles", (long long)n);
+  hipLaunchKernelGGL(nms_cull_kernel, dim3((unsigned)((nt + 255) / 256), (unsigned)nt), dim3(256), 0, st, tbox, nt, tpairs, tp_capacity, ctr);
+  OBB_LAUNCH_CHECK();
+  // phase 3: scan (broad phase)
   OBB_PHASE(3);
-  hipLaunchKernelGGL(nms_pair_kernel, dim3((unsigned)nblocks), dim3(256), 0, st, iv, rec, (uint32_t)n,
-                     iou_thr, rows, nj, edges, cap, ctr, cnt);
-  OBB_LAUNCH_CHECK();
+  {
+    const long long maxpairs = (long long)nt * (nt + 1) / 2;
+    long long pb = kPairBlocks;
+    if (const char *e = getenv("OBB_NMS_SCAN_BLOCKS")) pb = atoll(e) > 0 ? atoll(e) : pb;  // tuning knob
+    const unsigned gb = (unsigned)(maxpairs < pb ? maxpairs : pb);
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(gb), dim3(64 * kNmsWaves), 0, st, qs, sid, tpairs, tp_capacity, cands, segcap, ctr);
+    OBB_LAUNCH_CHECK();
+  }
+  // phase 4: clip (narrow phase)
   OBB_PHASE(4);
+  hipLaunchKernelGGL(nms_clip_kernel, dim3(kClipBlocksPerShard, kShards), dim3(256), 0, st, cands, segcap, rec, iou_thr, edges, cap, ctr, cnt);
+  OBB_LAUNCH_CHECK();
+  // phase 5: resolve
+  OBB_PHASE(5);
   hipLaunchKernelGGL(nms_resolve_kernel, dim3(1), dim3(1024), 0, st, edges, cap, state, cnt, ctr);
   OBB_LAUNCH_CHECK();
-  OBB_PHASE(5);
-  hipLaunchKernelGGL(nms_flag_kernel, dim3(gblocks), dim3(256), 0, st, order, state, cnt, n, keepflag);
-  OBB_LAUNCH_CHECK();
-  const unsigned cblocks = (unsigned)((n + 1023) / 1024);
-  hipLaunchKernelGGL(nms_count_kernel, dim3(cblocks), dim3(1024), 0, st, keepflag, n, blockcnt);
-  OBB_LAUNCH_CHECK();
-  hipLaunchKernelGGL(nms_write_kernel, dim3(cblocks), dim3(1024), 0, st, keepflag, n, blockcnt, keep_dev, ctr);
-  OBB_LAUNCH_CHECK();
-
+  // phase 6: compaction
   OBB_PHASE(6);
+  const unsigned cblocks = (unsigned)((n + 1023) / 1024);
+  hipLaunchKernelGGL(nms_count_kernel, dim3(cblocks), dim3(1024), 0, st, state, cnt, n, blockcnt);
+  OBB_LAUNCH_CHECK();
+  hipLaunchKernelGGL(nms_write_kernel, dim3(cblocks), dim3(1024), 0, st, state, cnt, n, blockcnt, keep_dev, ctr);
+  OBB_LAUNCH_CHECK();
+  OBB_PHASE(7);
 #undef OBB_PHASE
   NmsCounters h;
   OBB_HIP_TRY(hipMemcpyAsync(&h, ctr, sizeof(h), hipMemcpyDeviceToHost, st));
@@ -521,16 +800,26 @@ extern "C" int obb_nms_f32(const float *dets_dev, int64_t n, int kind, float iou
     for (int k = 0; k < kPhases; ++k) OBB_HIP_TRY(hipEventElapsedTime(&prof.ms[k], prof.ev[k], prof.ev[k + 1]));
     prof.have = true;
   }
+  unsigned long long ncand = 0, worst = 0;
+  for (int k = 0; k < kShards; ++k) {
+    ncand += h.cand[k];
+    if (h.cand[k] > worst) worst = h.cand[k];
+  }
   if (info_host) {
     info_host[0] = h.kept;
     info_host[1] = (int64_t)h.edges;
     info_host[2] = h.rounds;
-    info_host[3] = (int64_t)cap;
+    info_host[3] = (int64_t)ncand;
   }
-  if (h.edges > cap) {
-    if (info_host) info_host[0] = 0;
-    return set_err(OBB_EWORKSPACE, "obb_nms_f32: %llu overlap edges exceed the workspace capacity %llu; retry with edge_capacity >= %llu",
-                   h.edges, cap, h.edges);
+  if (worst > segcap || h.edges > cap) {
+    // capacity that fits every shard (and the edge list) on a retry, with 25 % slack:
+    // the tile-pair -> shard assignment varies slightly from run to run
+    unsigned long long need = worst * kShards;
+    if (h.edges > need) need = h.edges;
+    need += need / 4 + 1024;
+    if (info_host) { info_host[0] = 0; info_host[3] = (int64_t)need; }
+    return set_err(OBB_EWORKSPACE, "obb_nms_f32: %llu candidate pairs / %llu overlap edges exceed the pair capacity %llu; retry with edge_capacity >= %llu",
+                   ncand, h.edges, cap, need);
   }
   return OBB_OK;
 }

@@ -39,9 +39,9 @@ def _run_nms(dets_dev, kind, iou_thr):
                                ctypes.c_void_p(ws.data_ptr()), nbytes, _lib.stream_ptr(dev))
             if rc != _lib.OBB_EWORKSPACE:
                 break
-            capacity = int(info[1]) + 1024  # exact number of overlap edges found
+            capacity = int(info[3])  # a pair capacity the library says suffices
     _lib.check(rc)
-    return keep[:int(info[0])], (int(info[1]), int(info[2]))
+    return keep[:int(info[0])], (int(info[1]), int(info[2]), int(info[3]))
 
 
 def _nms_generic(dets, iou_thr, device_id, cols, kind, name):

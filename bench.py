@@ -12,7 +12,7 @@ rnms call (key, sort, gather, pair kernel, resolve, compaction, count read-back)
 own 100k-box scene, seed = 3 + rank): weak scaling, no data-path collective.
 
 Extra objects on the same line:
-  roofline      dominant kernel (nms_pair_kernel): algorithmic bytes of the
+  roofline      dominant kernel (nms_scan_kernel): algorithmic bytes of the
                 reference's bit-mask model / its HIP-event
                 duration measured inside the timed region.
   cpu_baseline  the C oracle (single thread, restatement of nms_cpu.cpp's loop)
@@ -89,8 +89,8 @@ def main():
 
     # ---- timed region: exactly K steps, barrier + sync on both sides ----------
     L.obb_nms_profile_enable(1)
-    phases = np.zeros(6, dtype=np.float64)
-    buf = (ctypes.c_float * 6)()
+    phases = np.zeros(7, dtype=np.float64)
+    buf = (ctypes.c_float * 7)()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -113,11 +113,11 @@ def main():
     ms_per_step = elapsed * 1e3 / args.steps
     value = n * world * args.steps / elapsed
 
-    pair_ms = float(phases[3])
+    pair_ms = float(phases[3])  # scan kernel
     alg = nms_algorithmic_bytes(n, kept)
     achieved = alg / (pair_ms * 1e-3) / 1e9 if pair_ms > 0 else 0.0
     roofline = {
-        'bound': 'hbm', 'kernel': 'nms_pair_kernel', 'achieved': round(achieved, 1),
+        'bound': 'hbm', 'kernel': 'nms_scan_kernel', 'achieved': round(achieved, 1),
         'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
         'traffic': None,
         'algorithmic_bytes': alg, 'kernel_ms': round(pair_ms, 4),
@@ -133,10 +133,10 @@ def main():
         'config': {'workload': 'rnms: %d theta-OBBs per GPU, canvas %g, w,h~logU(8,128), '
                                'theta~U(-pi/2,0), IoU thr 0.5 (BASELINE configs[1])' % (n, args.canvas),
                    'boxes_per_gpu': n, 'kept': kept, 'overlap_edges': info[0],
-                   'resolve_rounds': info[1], 'parallelism': 'image-sharded x%d' % world},
+                   'resolve_rounds': info[1], 'candidate_pairs': info[2], 'parallelism': 'image-sharded x%d' % world},
         'roofline': roofline,
         'phase_ms': {k: round(float(v), 4) for k, v in zip(
-            ['clear_keys', 'radix_sort', 'gather', 'pair', 'resolve', 'compact'], phases)},
+            ['prep_quant', 'radix_sort', 'permute_cull', 'scan', 'clip', 'resolve', 'compact'], phases)},
     }
 
     if rank == 0 and world == 1 and not args.no_extras:

@@ -89,25 +89,26 @@ OBB_API int obb_overlaps_f32(const float *a_dev, int64_t m, const float *b_dev, 
  *   dets_dev   (n, 6) for OBB_KIND_RBOX, (n, 9) for OBB_KIND_POLY
  *   keep_dev   int64[n]; the first K entries are valid on return
  *   info_host  int64[4] (may be NULL): [0] K, [1] overlap edges found,
- *              [2] resolve rounds, [3] edge capacity that was available
- *   workspace  >= obb_nms_workspace_bytes(n, kind, edge_capacity) bytes.
- *              edge_capacity = number of (i,j) pairs with overlap >= thr the
- *              workspace can hold; pass 0 for the default (max(256K, 32 n)).
- *              If more edges exist the call returns OBB_EWORKSPACE with
- *              info_host[1] = the number needed; call again with a larger
- *              capacity.  n*(n-1)/2 always suffices.
+ *              [2] resolve rounds, [3] candidate pairs clipped
+ *   workspace  >= obb_nms_workspace_bytes(n, kind, pair_capacity) bytes.
+ *              pair_capacity = number of candidate pairs (boxes whose AABBs
+ *              meet) the workspace can hold; pass 0 for the default
+ *              (max(256K, 64 n)).  If more exist the call returns
+ *              OBB_EWORKSPACE with info_host[3] = a capacity that suffices;
+ *              call again with it.  n*(n-1)/2 * 1.25 always suffices.
  * Synchronises `stream` before returning.
  * ------------------------------------------------------------------------- */
-OBB_API size_t obb_nms_workspace_bytes(int64_t n, int kind, int64_t edge_capacity);
+OBB_API size_t obb_nms_workspace_bytes(int64_t n, int kind, int64_t pair_capacity);
 OBB_API int obb_nms_f32(const float *dets_dev, int64_t n, int kind, float iou_thr,
                 int64_t *keep_dev, int64_t *info_host, void *workspace_dev,
                 size_t workspace_bytes, void *stream);
 
 /* Optional per-phase device timing of obb_nms_f32 (HIP events recorded on the
- * caller's stream; thread-local).  Phases: 0 clear+keys, 1 radix sort,
- * 2 gather records, 3 pair kernel, 4 resolve, 5 compaction.  No reference
- * counterpart (the reference has no kernel-level profiling).    */
-#define OBB_NMS_PHASES 6
+ * caller's stream; thread-local).  Phases: 0 clear + prep + quantise, 1 spatial
+ * radix sort, 2 permute + tile culling, 3 scan (broad phase), 4 clip (narrow
+ * phase), 5 resolve, 6 compaction.  No reference counterpart (the reference has
+ * no kernel-level profiling).                                    */
+#define OBB_NMS_PHASES 7
 OBB_API int obb_nms_profile_enable(int on);
 OBB_API int obb_nms_profile_last(float *phase_ms_host /* [OBB_NMS_PHASES] */);
 

@@ -53,7 +53,7 @@ def test_argument_validation_without_gpu():
     assert L.obb_rroi_align_forward_f32(null, 1, 1, 4, 4, null, 1, 0, 7, 1.0, 2, 1.0, null, null) == _lib.OBB_EINVAL
     assert L.obb_rroi_align_forward_f32(null, 1, 1, 4, 4, null, 0, 7, 7, 1.0, 2, 1.0, null, null) == _lib.OBB_OK
     assert L.obb_rbox_to_poly_f32(null, 0, null, null) == _lib.OBB_OK
-    buf = (ctypes.c_float * 6)()
+    buf = (ctypes.c_float * 7)()
     assert L.obb_nms_profile_last(buf) == _lib.OBB_EINVAL   # nothing profiled yet
 
 
