@@ -11,11 +11,14 @@ operator surface:
 There is no CPU fallback: every op raises if the HIP library or a GPU is missing.
 """
 from .nms_wrapper import nms, poly_nms, rnms, thetaobb_nms
+from .post_processing import (multiclass_nms_with_index, multiclass_rnms,
+                              thetaobb_nms_by_bbox_nms)
 from .rbbox_geometry import rbbox_overlaps, thetaobb2pointobb
 from .rroi_align import RRoIAlign, rroi_align
 
 __all__ = [
     'rnms', 'poly_nms', 'thetaobb_nms', 'nms', 'rbbox_overlaps', 'thetaobb2pointobb',
-    'RRoIAlign', 'rroi_align'
+    'RRoIAlign', 'rroi_align', 'multiclass_rnms', 'multiclass_nms_with_index',
+    'thetaobb_nms_by_bbox_nms'
 ]
 __version__ = '0.1.0'

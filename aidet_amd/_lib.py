@@ -52,6 +52,9 @@ def lib():
         L.obb_nms_f32.argtypes = [vp, i64, i32, f32, vp, ctypes.POINTER(i64), vp,
                                   ctypes.c_size_t, vp]
         L.obb_nms_f32.restype = i32
+        L.obb_nms_grouped_f32.argtypes = [vp, i64, i32, f32, vp, vp, vp, ctypes.POINTER(i64), vp,
+                                          ctypes.c_size_t, vp]
+        L.obb_nms_grouped_f32.restype = i32
         rroi = [vp, i32, i32, i32, i32, vp, i64, i32, i32, f32, i32, f32, vp, vp]
         L.obb_rroi_align_forward_f32.argtypes = rroi
         L.obb_rroi_align_forward_f32.restype = i32

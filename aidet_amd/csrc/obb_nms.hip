@@ -70,7 +70,8 @@ struct alignas(16) QuadRec {  // 64 bytes: four float4 loads
   float ry[4];
   float area;
   uint32_t skey;  // score key: smaller = visited earlier by the greedy scan
-  float pad1, pad2;
+  int32_t group;  // boxes of different groups never interact (class / image)
+  float thr;      // overlap threshold that applies when this box is the earlier one
 };
 
 struct NmsCounters {
@@ -108,7 +109,10 @@ template <int KIND>
 __global__ __launch_bounds__(256) void nms_prep_kernel(const float *__restrict__ dets, int64_t n,
                                                        QuadRec *__restrict__ rec,
                                                        float4 *__restrict__ iv,
-                                                       uint4 *__restrict__ part) {
+                                                       uint4 *__restrict__ part,
+                                                       const int32_t *__restrict__ group,
+                                                       const float *__restrict__ thrs,
+                                                       float thr) {
   constexpr int S = KIND ? 9 : 6;
   __shared__ uint4 wred[4];
   uint32_t mxh = 0, mxl = 0, myh = 0, myl = 0;
@@ -121,7 +125,9 @@ __global__ __launch_bounds__(256) void nms_prep_kernel(const float *__restrict__
     r.ox = q.ox; r.oy = q.oy; r.ex = q.ex; r.ey = q.ey;
 #pragma unroll
     for (int k = 0; k < 4; ++k) { r.rx[k] = q.rx[k]; r.ry[k] = q.ry[k]; }
-    r.area = q.area; r.skey = score_key(row[S - 1]); r.pad1 = 0.f; r.pad2 = 0.f;
+    r.area = q.area; r.skey = score_key(row[S - 1]);
+    r.group = group ? group[b] : 0;
+    r.thr = thrs ? thrs[b] : thr;
     rec[b] = r;
     float4 v;
     nms_interval(q.ox, q.ex, v.x, v.y);
@@ -416,7 +422,7 @@ __global__ __launch_bounds__(512) void nms_scan_kernel(const uint2 *__restrict__
 
 // ---- 7: clip kernel -----------------------------------------------------------------------
 __device__ __forceinline__ void load_rec(const QuadRec *__restrict__ rec, uint32_t p, Quad &q,
-                                         uint32_t &key) {
+                                         uint32_t &key, int &grp, float &thr) {
   const float4 *r = reinterpret_cast<const float4 *>(rec + p);
   float4 a = r[0], b = r[1], c = r[2], d = r[3];
   q.ox = a.x; q.oy = a.y; q.ex = a.z; q.ey = a.w;
@@ -424,6 +430,8 @@ __device__ __forceinline__ void load_rec(const QuadRec *__restrict__ rec, uint32
   q.ry[0] = c.x; q.ry[1] = c.y; q.ry[2] = c.z; q.ry[3] = c.w;
   q.area = d.x;
   key = __float_as_uint(d.y);
+  grp = __float_as_int(d.z);
+  thr = d.w;
 }
 
 __device__ __forceinline__ void swap_if(bool c, float &a, float &b) {
@@ -438,7 +446,7 @@ __device__ __forceinline__ void swap_if(bool c, float &a, float &b) {
 // loop of nms_cpu.cpp:35-58.  grid = (blocks per shard, shards).
 __global__ __launch_bounds__(256) void nms_clip_kernel(const uint2 *__restrict__ cands,
                                                        unsigned long long segcap,
-                                                       const QuadRec *__restrict__ rec, float thr,
+                                                       const QuadRec *__restrict__ rec,
                                                        uint2 *__restrict__ edges,
                                                        unsigned long long cap,
                                                        NmsCounters *__restrict__ ctr,
@@ -459,9 +467,12 @@ __global__ __launch_bounds__(256) void nms_clip_kernel(const uint2 *__restrict__
       const uint2 pr = cand[e];
       Quad A, B;
       uint32_t ka, kb;
-      load_rec(rec, pr.x, A, ka);
-      load_rec(rec, pr.y, B, kb);
+      int ga, gb;
+      float ta, tb;
+      load_rec(rec, pr.x, A, ka, ga, ta);
+      load_rec(rec, pr.y, B, kb, gb, tb);
       const bool b_first = (kb < ka) || (kb == ka && pr.y < pr.x);
+      const float thr = b_first ? tb : ta;  // the earlier box's threshold
       src = b_first ? pr.y : pr.x;
       dst = b_first ? pr.x : pr.y;
       swap_if(b_first, A.ox, B.ox); swap_if(b_first, A.oy, B.oy);
@@ -470,7 +481,7 @@ __global__ __launch_bounds__(256) void nms_clip_kernel(const uint2 *__restrict__
 #pragma unroll
       for (int k = 0; k < 4; ++k) { swap_if(b_first, A.rx[k], B.rx[k]); swap_if(b_first, A.ry[k], B.ry[k]); }
       const float ov = quad_overlap(A, B, 0);
-      hit = ov >= thr;
+      hit = (ga == gb) && (ov >= thr);
     }
     const uint64_t mk = __ballot(hit);
     if (mk) {
@@ -693,6 +704,14 @@ extern "C" size_t obb_nms_workspace_bytes(int64_t n, int kind, int64_t edge_capa
 extern "C" int obb_nms_f32(const float *dets_dev, int64_t n, int kind, float iou_thr,
                            int64_t *keep_dev, int64_t *info_host, void *workspace_dev,
                            size_t workspace_bytes, void *stream) {
+  return obb_nms_grouped_f32(dets_dev, n, kind, iou_thr, nullptr, nullptr, keep_dev, info_host,
+                             workspace_dev, workspace_bytes, stream);
+}
+
+extern "C" int obb_nms_grouped_f32(const float *dets_dev, int64_t n, int kind, float iou_thr,
+                                   const int32_t *group_dev, const float *thr_dev,
+                                   int64_t *keep_dev, int64_t *info_host, void *workspace_dev,
+                                   size_t workspace_bytes, void *stream) {
   using namespace obb;
   if (info_host) { info_host[0] = 0; info_host[1] = 0; info_host[2] = 0; info_host[3] = 0; }
   if (n < 0) return set_err(OBB_EINVAL, "obb_nms_f32: negative n");
@@ -750,9 +769,9 @@ extern "C" int obb_nms_f32(const float *dets_dev, int64_t n, int kind, float iou
   OBB_PHASE(0);
   OBB_HIP_TRY(hipMemsetAsync(ws + L.zero_begin, 0, L.zero_end - L.zero_begin, st));
   if (kind == OBB_KIND_RBOX)
-    hipLaunchKernelGGL(nms_prep_kernel<0>, dim3(pblocks), dim3(256), 0, st, dets_dev, n, rec, iv, part);
+    hipLaunchKernelGGL(nms_prep_kernel<0>, dim3(pblocks), dim3(256), 0, st, dets_dev, n, rec, iv, part, group_dev, thr_dev, iou_thr);
   else
-    hipLaunchKernelGGL(nms_prep_kernel<1>, dim3(pblocks), dim3(256), 0, st, dets_dev, n, rec, iv, part);
+    hipLaunchKernelGGL(nms_prep_kernel<1>, dim3(pblocks), dim3(256), 0, st, dets_dev, n, rec, iv, part, group_dev, thr_dev, iou_thr);
   OBB_LAUNCH_CHECK();
   hipLaunchKernelGGL(nms_quant_kernel, dim3(pblocks), dim3(256), 0, st, iv, n, part, (int)pblocks, qb, mkey_in, vals_in);
   OBB_LAUNCH_CHECK();
@@ -778,7 +797,7 @@ extern "C" int obb_nms_f32(const float *dets_dev, int64_t n, int kind, float iou
   }
   // phase 4: clip (narrow phase)
   OBB_PHASE(4);
-  hipLaunchKernelGGL(nms_clip_kernel, dim3(kClipBlocksPerShard, kShards), dim3(256), 0, st, cands, segcap, rec, iou_thr, edges, cap, ctr, cnt);
+  hipLaunchKernelGGL(nms_clip_kernel, dim3(kClipBlocksPerShard, kShards), dim3(256), 0, st, cands, segcap, rec, edges, cap, ctr, cnt);
   OBB_LAUNCH_CHECK();
   // phase 5: resolve
   OBB_PHASE(5);

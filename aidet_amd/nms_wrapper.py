@@ -19,14 +19,27 @@ import torch
 from . import _lib
 
 
-def _run_nms(dets_dev, kind, iou_thr):
-    """dets_dev: contiguous fp32 HIP tensor (n, 6|9). Returns int64 keep (K,)."""
+def _run_nms(dets_dev, kind, iou_thr, groups=None, thrs=None):
+    """dets_dev: contiguous fp32 HIP tensor (n, 6|9). Returns int64 keep (K,).
+
+    groups: optional int tensor (n,) -- only boxes of equal group interact.
+    thrs: optional float tensor (n,) -- per-box threshold (the earlier box's applies).
+    """
     n = dets_dev.size(0)
     dev = dets_dev.device
     L = _lib.lib()
     keep = torch.empty(n, dtype=torch.int64, device=dev)
     info = (ctypes.c_int64 * 4)()
     capacity = 0  # library default
+    gptr = tptr = ctypes.c_void_p(0)
+    if groups is not None:
+        groups = groups.detach().to(device=dev, dtype=torch.int32).contiguous()
+        assert groups.numel() == n
+        gptr = ctypes.c_void_p(groups.data_ptr())
+    if thrs is not None:
+        thrs = thrs.detach().to(device=dev, dtype=torch.float32).contiguous()
+        assert thrs.numel() == n
+        tptr = ctypes.c_void_p(thrs.data_ptr())
     with torch.cuda.device(dev):
         for _ in range(3):
             nbytes = L.obb_nms_workspace_bytes(n, kind, capacity)
@@ -34,9 +47,11 @@ def _run_nms(dets_dev, kind, iou_thr):
                 raise _lib.ObbOpsError('obb_nms_workspace_bytes failed: %s' %
                                        L.obb_last_error().decode())
             ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            rc = L.obb_nms_f32(ctypes.c_void_p(dets_dev.data_ptr()), n, kind,
-                               ctypes.c_float(iou_thr), ctypes.c_void_p(keep.data_ptr()), info,
-                               ctypes.c_void_p(ws.data_ptr()), nbytes, _lib.stream_ptr(dev))
+            rc = L.obb_nms_grouped_f32(ctypes.c_void_p(dets_dev.data_ptr()), n, kind,
+                                       ctypes.c_float(iou_thr), gptr, tptr,
+                                       ctypes.c_void_p(keep.data_ptr()), info,
+                                       ctypes.c_void_p(ws.data_ptr()), nbytes,
+                                       _lib.stream_ptr(dev))
             if rc != _lib.OBB_EWORKSPACE:
                 break
             capacity = int(info[3])  # a pair capacity the library says suffices
@@ -44,7 +59,13 @@ def _run_nms(dets_dev, kind, iou_thr):
     return keep[:int(info[0])], (int(info[1]), int(info[2]), int(info[3]))
 
 
-def _nms_generic(dets, iou_thr, device_id, cols, kind, name):
+def _as_tensor(x):
+    if x is None or isinstance(x, torch.Tensor):
+        return x
+    return torch.as_tensor(np.asarray(x))
+
+
+def _nms_generic(dets, iou_thr, device_id, cols, kind, name, groups=None, thrs=None):
     # container handling mirrors nms_wrapper.py:36-47
     if isinstance(dets, torch.Tensor):
         is_numpy = False
@@ -63,7 +84,7 @@ def _nms_generic(dets, iou_thr, device_id, cols, kind, name):
         inds = dets_th.new_zeros(0, dtype=torch.long)
     else:
         d = _lib.to_device_f32(dets_th, device_id)
-        inds, _ = _run_nms(d, kind, float(iou_thr))
+        inds, _ = _run_nms(d, kind, float(iou_thr), _as_tensor(groups), _as_tensor(thrs))
         if not is_numpy:
             inds = inds.to(dets_th.device)  # keep lives where the input lives
     if is_numpy:
@@ -71,7 +92,7 @@ def _nms_generic(dets, iou_thr, device_id, cols, kind, name):
     return dets[inds, :], inds
 
 
-def rnms(dets, iou_thr, device_id=None):
+def rnms(dets, iou_thr, device_id=None, groups=None, thrs=None):
     """Greedy NMS on theta-OBBs.
 
     Arguments:
@@ -80,6 +101,11 @@ def rnms(dets, iou_thr, device_id=None):
             their rotated IoU is >= iou_thr (the CPU reference's comparison,
             mmdet/ops/nms/src/nms_cpu.cpp:56).
         device_id (int, optional): HIP device for numpy / CPU input.
+        groups (int array, optional): (n,) group id per box; boxes of different
+            groups never suppress each other (per-class / per-image NMS in one
+            call -- what bbox_nms.py:56-63 does with coordinate offsets).
+        thrs (float array, optional): (n,) per-box threshold replacing iou_thr
+            (per-class thresholds of the DOTA merge, dota.py:321-331).
 
     Returns:
         tuple: kept dets and int64 indices (ascending, nms_cpu.cpp:59), same
@@ -93,14 +119,14 @@ def rnms(dets, iou_thr, device_id=None):
         >>> kept, inds = rnms(dets, 0.7)
         >>> assert len(inds) == len(kept) == 4
     """
-    return _nms_generic(dets, iou_thr, device_id, 6, _lib.KIND_RBOX, 'rnms')
+    return _nms_generic(dets, iou_thr, device_id, 6, _lib.KIND_RBOX, 'rnms', groups, thrs)
 
 
-def poly_nms(dets, iou_thr, device_id=None):
+def poly_nms(dets, iou_thr, device_id=None, groups=None, thrs=None):
     """Greedy NMS on convex quadrilaterals: dets (n, 9) <x1,y1,..,x4,y4,score>
     (the 8-point polygons the reference writes for the DOTA merge,
     mmdet/datasets/dota.py:197-235, merged by the external mergebypoly)."""
-    return _nms_generic(dets, iou_thr, device_id, 9, _lib.KIND_POLY, 'poly_nms')
+    return _nms_generic(dets, iou_thr, device_id, 9, _lib.KIND_POLY, 'poly_nms', groups, thrs)
 
 
 # the names the reference's own (disabled) call sites use
@@ -108,7 +134,7 @@ thetaobb_nms = rnms      # mmdet/core/post_processing/rbbox_nms.py:97
 pointobb_nms = poly_nms
 
 
-def nms(dets, iou_thr, device_id=None):
+def nms(dets, iou_thr, device_id=None, groups=None):
     """Horizontal-box NMS with the reference's exact signature
     (nms_wrapper.py:7), served by the rotated kernel through the theta = 0
     mapping  w = x2-x1+1, h = y2-y1+1, centre = box centre  (the continuous box
@@ -130,7 +156,7 @@ def nms(dets, iou_thr, device_id=None):
         rb = torch.stack([(d[:, 0] + d[:, 2]) * 0.5, (d[:, 1] + d[:, 3]) * 0.5,
                           d[:, 2] - d[:, 0] + 1.0, d[:, 3] - d[:, 1] + 1.0,
                           torch.zeros_like(d[:, 0]), d[:, 4]], dim=1).contiguous()
-        inds, _ = _run_nms(rb, _lib.KIND_RBOX, float(iou_thr))
+        inds, _ = _run_nms(rb, _lib.KIND_RBOX, float(iou_thr), _as_tensor(groups))
         if not is_numpy:
             inds = inds.to(dets_th.device)
     if is_numpy:

@@ -103,6 +103,19 @@ OBB_API int obb_nms_f32(const float *dets_dev, int64_t n, int kind, float iou_th
                 int64_t *keep_dev, int64_t *info_host, void *workspace_dev,
                 size_t workspace_bytes, void *stream);
 
+/* Grouped variant: boxes with different group_dev[i] never suppress each other
+ * (per-class / per-image NMS in ONE call).  Replaces the coordinate-offset trick
+ * of multiclass_nms (mmdet/core/post_processing/bbox_nms.py:56-63), the Python
+ * loop over classes of rbbox_nms.py:29-49 and the per-class-file merge of
+ * mmdet/datasets/dota.py:310-336.  group_dev int32[n] or NULL; thr_dev float[n]
+ * or NULL gives one threshold per box -- the threshold of the EARLIER box of a
+ * pair applies (per-class thresholds, dota.py:321-331; boxes of one group are
+ * expected to share it).  Otherwise identical to obb_nms_f32.                  */
+OBB_API int obb_nms_grouped_f32(const float *dets_dev, int64_t n, int kind, float iou_thr,
+                                const int32_t *group_dev, const float *thr_dev,
+                                int64_t *keep_dev, int64_t *info_host, void *workspace_dev,
+                                size_t workspace_bytes, void *stream);
+
 /* Optional per-phase device timing of obb_nms_f32 (HIP events recorded on the
  * caller's stream; thread-local).  Phases: 0 clear + prep + quantise, 1 spatial
  * radix sort, 2 permute + tile culling, 3 scan (broad phase), 4 clip (narrow

@@ -55,6 +55,9 @@ def lib():
         L.obbo_score_order.restype = ctypes.c_int
         L.obbo_nms_f32.argtypes = [_f32p, ctypes.c_long, ctypes.c_int, ctypes.c_float, _i64p]
         L.obbo_nms_f32.restype = ctypes.c_long
+        L.obbo_nms_grouped_f32.argtypes = [_f32p, ctypes.c_long, ctypes.c_int, ctypes.c_float,
+                                           ctypes.POINTER(ctypes.c_int32), _f32p, _i64p]
+        L.obbo_nms_grouped_f32.restype = ctypes.c_long
         L.obbo_hbb_nms_f32.argtypes = [_f32p, ctypes.c_long, ctypes.c_float, _i64p]
         L.obbo_hbb_nms_f32.restype = ctypes.c_long
         rroi = [_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
@@ -138,22 +141,32 @@ def score_order(scores):
     return order
 
 
-def rnms(dets, iou_thr):
-    """dets (n,6) cx,cy,w,h,theta,score -> ascending int64 keep indices."""
-    d = _f32(dets).reshape(-1, 6)
-    keep = np.zeros(d.shape[0], dtype=np.int64)
-    k = lib().obbo_nms_f32(_p(d), d.shape[0], 0, ctypes.c_float(iou_thr), _p(keep, _i64p))
+def _nms(d, kind, iou_thr, groups, thrs):
+    n = d.shape[0]
+    keep = np.zeros(n, dtype=np.int64)
+    g = t = None
+    gp = ctypes.POINTER(ctypes.c_int32)()
+    tp = _f32p()
+    if groups is not None:
+        g = np.ascontiguousarray(groups, dtype=np.int32).reshape(n)
+        gp = g.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+    if thrs is not None:
+        t = _f32(thrs).reshape(n)
+        tp = _p(t)
+    k = lib().obbo_nms_grouped_f32(_p(d), n, kind, ctypes.c_float(iou_thr), gp, tp, _p(keep, _i64p))
     assert k >= 0
     return keep[:k].copy()
 
 
-def poly_nms(dets, iou_thr):
+def rnms(dets, iou_thr, groups=None, thrs=None):
+    """dets (n,6) cx,cy,w,h,theta,score -> ascending int64 keep indices.
+    groups (n,) int: only boxes of the same group interact; thrs (n,) per-box thr."""
+    return _nms(_f32(dets).reshape(-1, 6), 0, iou_thr, groups, thrs)
+
+
+def poly_nms(dets, iou_thr, groups=None, thrs=None):
     """dets (n,9) x1,y1..x4,y4,score -> ascending int64 keep indices."""
-    d = _f32(dets).reshape(-1, 9)
-    keep = np.zeros(d.shape[0], dtype=np.int64)
-    k = lib().obbo_nms_f32(_p(d), d.shape[0], 1, ctypes.c_float(iou_thr), _p(keep, _i64p))
-    assert k >= 0
-    return keep[:k].copy()
+    return _nms(_f32(dets).reshape(-1, 9), 1, iou_thr, groups, thrs)
 
 
 def hbb_nms(dets, iou_thr):

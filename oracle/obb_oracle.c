@@ -410,8 +410,22 @@ static int cmp_key_idx(const void *a, const void *b) {
 /* kind 0: dets (n,6) = cx,cy,w,h,theta,score.  kind 1: dets (n,9) = 8 coords,
  * score.  keep receives ASCENDING original indices (nms_cpu.cpp:59).
  * Returns the number kept, or <0 on error.                                */
+/* grouped variant: boxes of different groups never suppress each other (the
+ * per-class / per-image NMS that bbox_nms.py:56-63 obtains by shifting boxes of
+ * class c by c*(max_coordinate+1), and that the DOTA merge applies per class
+ * file, dota.py:310-336).  group may be NULL (one group); thrs may be NULL
+ * (use thr) or give a threshold per box (the threshold of the EARLIER box of a
+ * pair is used; boxes of one group share it: per-class thresholds, dota.py:324). */
+OBBO_API long obbo_nms_grouped_f32(const float *dets, long n, int kind, float thr,
+                                   const int32_t *group, const float *thrs, int64_t *keep);
+
 OBBO_API long obbo_nms_f32(const float *dets, long n, int kind, float thr,
                            int64_t *keep) {
+  return obbo_nms_grouped_f32(dets, n, kind, thr, NULL, NULL, keep);
+}
+
+OBBO_API long obbo_nms_grouped_f32(const float *dets, long n, int kind, float thr,
+                                   const int32_t *group, const float *thrs, int64_t *keep) {
   long i, j;
   int stride = kind ? 9 : 6;
   if (n < 0) return -1;
@@ -439,15 +453,18 @@ OBBO_API long obbo_nms_f32(const float *dets, long n, int kind, float thr,
     if (sup[i]) continue;
     const obbo_quad *A = &Q[i];
     float ax = A->ox, ay = A->oy, aex = A->ex, aey = A->ey;
+    int32_t gi = group ? group[ord[i].idx] : 0;
+    float ti = thrs ? thrs[ord[i].idx] : thr;
     for (j = i + 1; j < n; ++j) {
       if (sup[j]) continue;
+      if (group && group[ord[j].idx] != gi) continue;
       /* same prefilter as quad_overlap_f32, hoisted */
       float dx = sx[j] - ax;
       if (fabs_sel(dx) > aex + sex[j]) continue;
       float dy = sy[j] - ay;
       if (fabs_sel(dy) > aey + sey[j]) continue;
       float ovr = quad_overlap_f32(A, &Q[j], 0);
-      if (ovr >= thr) sup[j] = 1;
+      if (ovr >= ti) sup[j] = 1;
     }
   }
   /* ascending ORIGINAL index */
