@@ -17,8 +17,10 @@
 //   1 prep     per box: 64-byte quad record, conservative AABB interval, score
 //              key; per-block min/max of the scene
 //   2 quant    intervals -> 15-bit grid over the scene, x|y packed in a dword
-//              with guard bits; Morton key of the centre
-//   3 sort     LSD radix sort of (Morton key, box id)              [rocPRIM]
+//              with guard bits; Morton cell of the centre + cell histogram
+//   3 sort     counting sort by the 16-bit Morton CELL of the centre (histogram
+//              fused into 2, one scan block, one scatter): only tile locality
+//              matters, the order inside a cell is irrelevant for the result
 //   4 permute  packed intervals in spatial order + one bounding box per tile
 //   5 cull     all tile pairs (A <= B): keep those whose bounding boxes meet
 //   6 scan     per surviving tile pair 256 x 256 interval tests, 3 full-rate
@@ -40,7 +42,6 @@
 #include <cstring>
 
 #include <hip/hip_runtime.h>
-#include <rocprim/device/device_radix_sort.hpp>
 
 #include "obb_common.h"
 #include "obb_geom.cuh"
@@ -53,6 +54,7 @@ constexpr int kNmsColsPerLane = 4;    // 64 lanes x 4 = one tile of columns per 
 constexpr int kRowsPerWave = kTile / kNmsWaves;  // 32 rows of the row tile per wave
 constexpr int kRowChunk = 8;
 constexpr int kNmsQueue = 64 + kTile;  // carry (<= 63) + one row's worst case
+constexpr int kCells = 65536;           // Morton cells of the counting sort (8 + 8 bits)
 constexpr int kShards = 64;            // candidate lists / counters (atomic rate)
 constexpr int kPrepBlocks = 1024;     // upper bound on blocks of the prep kernel
 constexpr int kPairBlocks = 4096;     // grid of the scan kernel (blocks loop over tile pairs)
@@ -175,8 +177,8 @@ __device__ __forceinline__ uint32_t spread15(uint32_t v) {  // 15 bits -> even b
 __global__ __launch_bounds__(256) void nms_quant_kernel(const float4 *__restrict__ iv, int64_t n,
                                                         const uint4 *__restrict__ part, int nparts,
                                                         uint2 *__restrict__ qb,
-                                                        uint32_t *__restrict__ mkey,
-                                                        uint32_t *__restrict__ vals) {
+                                                        uint32_t *__restrict__ ckey,
+                                                        uint32_t *__restrict__ hist) {
   __shared__ uint4 wred[4];
   __shared__ float sb[4];
   uint4 a = make_uint4(0u, 0u, 0u, 0u);
@@ -214,17 +216,62 @@ __global__ __launch_bounds__(256) void nms_quant_kernel(const float4 *__restrict
        b += (int64_t)gridDim.x * blockDim.x) {
     const float4 v = iv[b];
     uint2 o = make_uint2(kSentLo, kSentHi);
-    uint32_t mk = 0x3FFFFFFFu;  // isolated boxes sort to the end
+    uint32_t mk = kCells - 1;  // isolated boxes go to the last cell
     if (v.x <= v.y) {
       const uint32_t xl = qz(v.x, bx, sx), xh = qz(v.y, bx, sx);
       const uint32_t yl = qz(v.z, by, sy), yh = qz(v.w, by, sy);
       o.x = xl | (yl << 16);
       o.y = (xh | (yh << 16)) | kGuard;
-      mk = spread15((xl + xh) >> 1) | (spread15((yl + yh) >> 1) << 1);
+      mk = spread15((xl + xh) >> 8) | (spread15((yl + yh) >> 8) << 1);  // top 8 bits of each centre
     }
     qb[b] = o;
-    mkey[b] = mk;
-    vals[b] = (uint32_t)b;
+    ckey[b] = mk;
+    atomicAdd(&hist[mk], 1u);
+  }
+}
+
+// exclusive scan of the 65536 cell counts, in place (one block, 64 cells per thread)
+__global__ __launch_bounds__(1024) void nms_cellscan_kernel(uint32_t *__restrict__ hist) {
+  __shared__ uint32_t wsum[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int per = kCells / 1024;
+  uint32_t v[per];
+  uint32_t tot = 0;
+  uint4 *h4 = reinterpret_cast<uint4 *>(hist + tid * per);
+#pragma unroll
+  for (int k = 0; k < per / 4; ++k) {
+    const uint4 a = h4[k];
+    v[4 * k] = a.x; v[4 * k + 1] = a.y; v[4 * k + 2] = a.z; v[4 * k + 3] = a.w;
+    tot += a.x + a.y + a.z + a.w;
+  }
+  uint32_t inc = tot;  // inclusive scan across the wave
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t t = (uint32_t)__shfl_up((int)inc, o);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  uint32_t base = inc - tot;
+  for (int k = 0; k < wave; ++k) base += wsum[k];
+#pragma unroll
+  for (int k = 0; k < per / 4; ++k) {
+    uint4 o;
+    o.x = base; base += v[4 * k];
+    o.y = base; base += v[4 * k + 1];
+    o.z = base; base += v[4 * k + 2];
+    o.w = base; base += v[4 * k + 3];
+    h4[k] = o;
+  }
+}
+
+// sid[position] = box id; positions inside a cell are handed out atomically
+__global__ __launch_bounds__(256) void nms_scatter_kernel(const uint32_t *__restrict__ ckey,
+                                                          int64_t n, uint32_t *__restrict__ offs,
+                                                          uint32_t *__restrict__ sid) {
+  for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n;
+       b += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t pos = atomicAdd(&offs[ckey[b]], 1u);
+    sid[pos] = (uint32_t)b;
   }
 }
 
@@ -642,9 +689,8 @@ static thread_local NmsProfile g_prof;
 
 // ---- workspace layout ------------------------------------------------------------
 struct NmsLayout {
-  size_t rec, iv, part, qb, mkey_in, mkey_out, vals_in, sid, qs, tbox, tpairs, zero_begin,
-      state, cnt, ctr, zero_end, blockcnt, sort_temp, cands, edges, total;
-  size_t sort_temp_bytes;
+  size_t rec, iv, part, qb, ckey, sid, qs, tbox, tpairs, zero_begin, state, cnt, ctr, hist,
+      zero_end, blockcnt, cands, edges, total;
   unsigned long long cap;
   int64_t ntiles;
 };
@@ -655,11 +701,6 @@ static int nms_layout(int64_t n, int64_t edge_capacity, NmsLayout &L) {
     if (edge_capacity < (1 << 18)) edge_capacity = 1 << 18;
   }
   L.cap = (unsigned long long)edge_capacity;
-  size_t tmp = 0;
-  uint32_t *nul = nullptr;
-  hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp, nul, nul, nul, nul, (size_t)(n > 0 ? n : 1), 0u, 30u, (hipStream_t)0, false);
-  if (e != hipSuccess) return set_err(OBB_EHIP, "rocprim::radix_sort_pairs size query failed: %s", hipGetErrorString(e));
-  L.sort_temp_bytes = tmp;
   const size_t nn = (size_t)(n > 0 ? n : 1);
   const size_t nt = (nn + kTile - 1) / kTile;
   L.ntiles = (int64_t)nt;
@@ -669,9 +710,7 @@ static int nms_layout(int64_t n, int64_t edge_capacity, NmsLayout &L) {
   L.iv = take(nn * sizeof(float4));
   L.part = take(kPrepBlocks * sizeof(uint4));
   L.qb = take(nn * sizeof(uint2));
-  L.mkey_in = take(nn * 4);
-  L.mkey_out = take(nn * 4);
-  L.vals_in = take(nn * 4);
+  L.ckey = take(nn * 4);
   L.sid = take((nt * kTile) * 4);
   L.qs = take((nt * kTile + kRowChunk) * sizeof(uint2));
   L.tbox = take(nt * sizeof(uint2));
@@ -680,9 +719,9 @@ static int nms_layout(int64_t n, int64_t edge_capacity, NmsLayout &L) {
   L.state = take(nn);
   L.cnt = take(nn * 4);
   L.ctr = take(sizeof(NmsCounters));
+  L.hist = take(kCells * 4);
   L.zero_end = off;
   L.blockcnt = take(((nn + 1023) / 1024) * 4);
-  L.sort_temp = take(tmp > 0 ? tmp : 1);
   // candidates and edges share one capacity: [cands | edges], cap entries each
   L.cands = off;
   L.edges = off;  // resolved at run time from the actual workspace size
@@ -737,9 +776,8 @@ extern "C" int obb_nms_grouped_f32(const float *dets_dev, int64_t n, int kind, f
   float4 *iv = reinterpret_cast<float4 *>(ws + L.iv);
   uint4 *part = reinterpret_cast<uint4 *>(ws + L.part);
   uint2 *qb = reinterpret_cast<uint2 *>(ws + L.qb);
-  uint32_t *mkey_in = reinterpret_cast<uint32_t *>(ws + L.mkey_in);
-  uint32_t *mkey_out = reinterpret_cast<uint32_t *>(ws + L.mkey_out);
-  uint32_t *vals_in = reinterpret_cast<uint32_t *>(ws + L.vals_in);
+  uint32_t *ckey = reinterpret_cast<uint32_t *>(ws + L.ckey);
+  uint32_t *hist = reinterpret_cast<uint32_t *>(ws + L.hist);
   uint32_t *sid = reinterpret_cast<uint32_t *>(ws + L.sid);
   uint2 *qs = reinterpret_cast<uint2 *>(ws + L.qs);
   uint2 *tbox = reinterpret_cast<uint2 *>(ws + L.tbox);
@@ -748,7 +786,6 @@ extern "C" int obb_nms_grouped_f32(const float *dets_dev, int64_t n, int kind, f
   int *cnt = reinterpret_cast<int *>(ws + L.cnt);
   NmsCounters *ctr = reinterpret_cast<NmsCounters *>(ws + L.ctr);
   int *blockcnt = reinterpret_cast<int *>(ws + L.blockcnt);
-  void *sort_temp = ws + L.sort_temp;
   uint2 *cands = reinterpret_cast<uint2 *>(ws + L.cands);
   uint2 *edges = cands + cap;
   hipStream_t st = (hipStream_t)stream;
@@ -773,12 +810,14 @@ extern "C" int obb_nms_grouped_f32(const float *dets_dev, int64_t n, int kind, f
   else
     hipLaunchKernelGGL(nms_prep_kernel<1>, dim3(pblocks), dim3(256), 0, st, dets_dev, n, rec, iv, part, group_dev, thr_dev, iou_thr);
   OBB_LAUNCH_CHECK();
-  hipLaunchKernelGGL(nms_quant_kernel, dim3(pblocks), dim3(256), 0, st, iv, n, part, (int)pblocks, qb, mkey_in, vals_in);
+  hipLaunchKernelGGL(nms_quant_kernel, dim3(pblocks), dim3(256), 0, st, iv, n, part, (int)pblocks, qb, ckey, hist);
   OBB_LAUNCH_CHECK();
   // phase 1: spatial sort
   OBB_PHASE(1);
-  size_t tmp = L.sort_temp_bytes;
-  OBB_HIP_TRY(rocprim::radix_sort_pairs(sort_temp, tmp, mkey_in, mkey_out, vals_in, sid, (size_t)n, 0u, 30u, st, false));
+  hipLaunchKernelGGL(nms_cellscan_kernel, dim3(1), dim3(1024), 0, st, hist);
+  OBB_LAUNCH_CHECK();
+  hipLaunchKernelGGL(nms_scatter_kernel, dim3(pblocks), dim3(256), 0, st, ckey, n, hist, sid);
+  OBB_LAUNCH_CHECK();
   // phase 2: permute + tile boxes + tile-pair culling
   OBB_PHASE(2);
   hipLaunchKernelGGL(nms_permute_kernel, dim3((unsigned)nt), dim3(kTile), 0, st, qb, sid, n, qs, tbox);

@@ -136,7 +136,7 @@ def main():
                    'resolve_rounds': info[1], 'candidate_pairs': info[2], 'parallelism': 'image-sharded x%d' % world},
         'roofline': roofline,
         'phase_ms': {k: round(float(v), 4) for k, v in zip(
-            ['prep_quant', 'radix_sort', 'permute_cull', 'scan', 'clip', 'resolve', 'compact'], phases)},
+            ['prep_quant', 'cell_sort', 'permute_cull', 'scan', 'clip', 'resolve', 'compact'], phases)},
     }
 
     if rank == 0 and world == 1 and not args.no_extras:

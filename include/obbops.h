@@ -118,7 +118,7 @@ OBB_API int obb_nms_grouped_f32(const float *dets_dev, int64_t n, int kind, floa
 
 /* Optional per-phase device timing of obb_nms_f32 (HIP events recorded on the
  * caller's stream; thread-local).  Phases: 0 clear + prep + quantise, 1 spatial
- * radix sort, 2 permute + tile culling, 3 scan (broad phase), 4 clip (narrow
+ * counting sort, 2 permute + tile culling, 3 scan (broad phase), 4 clip (narrow
  * phase), 5 resolve, 6 compaction.  No reference counterpart (the reference has
  * no kernel-level profiling).                                    */
 #define OBB_NMS_PHASES 7
