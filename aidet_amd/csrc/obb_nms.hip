@@ -54,7 +54,8 @@ constexpr int kNmsColsPerLane = 4;    // 64 lanes x 4 = one tile of columns per 
 constexpr int kRowsPerWave = kTile / kNmsWaves;  // 32 rows of the row tile per wave
 constexpr int kRowChunk = 8;
 constexpr int kNmsQueue = 64 + kTile;  // carry (<= 63) + one row's worst case
-constexpr int kCells = 65536;           // Morton cells of the counting sort (8 + 8 bits)
+constexpr int kCullChunk = 4096;        // column tiles per cull block (LDS list size)
+constexpr int kCells = 65536;           // max Morton cells of the counting sort (8 + 8 bits)
 constexpr int kShards = 64;            // candidate lists / counters (atomic rate)
 constexpr int kPrepBlocks = 1024;     // upper bound on blocks of the prep kernel
 constexpr int kPairBlocks = 4096;     // grid of the scan kernel (blocks loop over tile pairs)
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(256) void nms_quant_kernel(const float4 *__restrict
                                                         const uint4 *__restrict__ part, int nparts,
                                                         uint2 *__restrict__ qb,
                                                         uint32_t *__restrict__ ckey,
-                                                        uint32_t *__restrict__ hist) {
+                                                        uint32_t *__restrict__ hist, int cell_hbits) {
   __shared__ uint4 wred[4];
   __shared__ float sb[4];
   uint4 a = make_uint4(0u, 0u, 0u, 0u);
@@ -216,13 +217,14 @@ __global__ __launch_bounds__(256) void nms_quant_kernel(const float4 *__restrict
        b += (int64_t)gridDim.x * blockDim.x) {
     const float4 v = iv[b];
     uint2 o = make_uint2(kSentLo, kSentHi);
-    uint32_t mk = kCells - 1;  // isolated boxes go to the last cell
+    uint32_t mk = (1u << (2 * cell_hbits)) - 1u;  // isolated boxes go to the last cell
     if (v.x <= v.y) {
       const uint32_t xl = qz(v.x, bx, sx), xh = qz(v.y, bx, sx);
       const uint32_t yl = qz(v.z, by, sy), yh = qz(v.w, by, sy);
       o.x = xl | (yl << 16);
       o.y = (xh | (yh << 16)) | kGuard;
-      mk = spread15((xl + xh) >> 8) | (spread15((yl + yh) >> 8) << 1);  // top 8 bits of each centre
+      const int sh = 16 - cell_hbits;  // (lo + hi) is a 16-bit centre*2: keep its top bits
+      mk = spread15((xl + xh) >> sh) | (spread15((yl + yh) >> sh) << 1);
     }
     qb[b] = o;
     ckey[b] = mk;
@@ -230,16 +232,17 @@ __global__ __launch_bounds__(256) void nms_quant_kernel(const float4 *__restrict
   }
 }
 
-// exclusive scan of the 65536 cell counts, in place (one block, 64 cells per thread)
+// exclusive scan of the cell counts, in place (one block, PER cells per thread;
+// the cell count adapts to n so that this stays a few microseconds)
+template <int PER>
 __global__ __launch_bounds__(1024) void nms_cellscan_kernel(uint32_t *__restrict__ hist) {
   __shared__ uint32_t wsum[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  constexpr int per = kCells / 1024;
-  uint32_t v[per];
+  uint32_t v[PER];
   uint32_t tot = 0;
-  uint4 *h4 = reinterpret_cast<uint4 *>(hist + tid * per);
+  uint4 *h4 = reinterpret_cast<uint4 *>(hist + tid * PER);
 #pragma unroll
-  for (int k = 0; k < per / 4; ++k) {
+  for (int k = 0; k < PER / 4; ++k) {
     const uint4 a = h4[k];
     v[4 * k] = a.x; v[4 * k + 1] = a.y; v[4 * k + 2] = a.z; v[4 * k + 3] = a.w;
     tot += a.x + a.y + a.z + a.w;
@@ -254,7 +257,7 @@ __global__ __launch_bounds__(1024) void nms_cellscan_kernel(uint32_t *__restrict
   uint32_t base = inc - tot;
   for (int k = 0; k < wave; ++k) base += wsum[k];
 #pragma unroll
-  for (int k = 0; k < per / 4; ++k) {
+  for (int k = 0; k < PER / 4; ++k) {
     uint4 o;
     o.x = base; base += v[4 * k];
     o.y = base; base += v[4 * k + 1];
@@ -313,7 +316,8 @@ __device__ __forceinline__ uint32_t qdisjoint(uint32_t alo, uint32_t ahiG, uint3
 }
 
 // ---- 5: tile-pair culling ------------------------------------------------------------
-// thread per (A, B >= A); survivors are stored as (A << 16 | B)  [ntiles < 65536].
+// block per row tile A, threads over B >= A; survivors are stored as
+// (A << 16 | B)  [ntiles < 65536].
 // Candidate density differs by an order of magnitude between tile pairs (a tile
 // against itself or its Morton neighbour vs. two tiles that merely touch), and the
 // scan kernel's duration is set by its slowest block -- so pairs that overlap
@@ -323,37 +327,41 @@ __global__ __launch_bounds__(256) void nms_cull_kernel(const uint2 *__restrict__
                                                        uint32_t *__restrict__ tpairs,
                                                        unsigned int tp_capacity,
                                                        NmsCounters *__restrict__ ctr) {
-  const int A = blockIdx.y;
-  const int B = A + blockIdx.x * 256 + threadIdx.x;
-  bool ok = false, heavy = false;
-  if (B < nt) {
-    const uint2 a = tbox[A], b = tbox[B];
-    ok = qdisjoint(a.x, a.y, b.x, b.y) == 0u;
-    if (ok) {
-      const int axl = a.x & 0x7FFF, ayl = (a.x >> 16) & 0x7FFF, axh = a.y & 0x7FFF, ayh = (a.y >> 16) & 0x7FFF;
+  // one block per row tile A; survivors are collected in LDS and published with
+  // two global atomics per block (a returning atomic on one address sustains only
+  // ~90 per microsecond)
+  __shared__ uint32_t lists[kCullChunk];   // heavy from the front, light from the back
+  __shared__ unsigned int nh, nl, gbase_h, gbase_l;
+  const int A = blockIdx.x;
+  const int b0 = A + (int)blockIdx.y * kCullChunk;   // this block's column tiles [b0, b1)
+  if (b0 >= nt) return;
+  const int b1 = min(nt, b0 + kCullChunk);
+  const int span = b1 - b0;
+  if (threadIdx.x == 0) { nh = 0; nl = 0; }
+  __syncthreads();
+  const uint2 a = tbox[A];
+  const int axl = a.x & 0x7FFF, ayl = (a.x >> 16) & 0x7FFF, axh = a.y & 0x7FFF, ayh = (a.y >> 16) & 0x7FFF;
+  const float aa = (float)(axh - axl + 1) * (float)(ayh - ayl + 1);
+  for (int B = b0 + threadIdx.x; B < b1; B += 256) {
+    const uint2 b = tbox[B];
+    if (qdisjoint(a.x, a.y, b.x, b.y) == 0u) {
       const int bxl = b.x & 0x7FFF, byl = (b.x >> 16) & 0x7FFF, bxh = b.y & 0x7FFF, byh = (b.y >> 16) & 0x7FFF;
       const float ow = (float)(min(axh, bxh) - max(axl, bxl) + 1), oh = (float)(min(ayh, byh) - max(ayl, byl) + 1);
-      const float aa = (float)(axh - axl + 1) * (float)(ayh - ayl + 1);
       const float ab = (float)(bxh - bxl + 1) * (float)(byh - byl + 1);
-      heavy = (A == B) || (ow * oh * 8.0f >= fminf(aa, ab));
+      const bool heavy = (A == B) || (ow * oh * 8.0f >= fminf(aa, ab));
+      const uint32_t v = ((uint32_t)A << 16) | (uint32_t)B;
+      if (heavy) lists[atomicAdd(&nh, 1u)] = v;
+      else lists[span - 1 - atomicAdd(&nl, 1u)] = v;
     }
   }
-  const int lane = threadIdx.x & 63;
-  const uint64_t mh = __ballot(ok && heavy), ml = __ballot(ok && !heavy);
-  if (mh) {
-    const int leader = __ffsll((long long)mh) - 1;
-    unsigned int base = 0;
-    if (lane == leader) base = atomicAdd(&ctr->heavy_pairs, (unsigned int)__popcll(mh));
-    base = (unsigned int)__shfl((int)base, leader);
-    if (ok && heavy) tpairs[base + __popcll(mh & ((1ull << lane) - 1ull))] = ((uint32_t)A << 16) | (uint32_t)B;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    gbase_h = nh ? atomicAdd(&ctr->heavy_pairs, nh) : 0u;
+    gbase_l = nl ? atomicAdd(&ctr->tile_pairs, nl) : 0u;   // light count
   }
-  if (ml) {
-    const int leader = __ffsll((long long)ml) - 1;
-    unsigned int base = 0;
-    if (lane == leader) base = atomicAdd(&ctr->tile_pairs, (unsigned int)__popcll(ml));  // light count for now
-    base = (unsigned int)__shfl((int)base, leader);
-    if (ok && !heavy) tpairs[tp_capacity - 1u - (base + __popcll(ml & ((1ull << lane) - 1ull)))] = ((uint32_t)A << 16) | (uint32_t)B;
-  }
+  __syncthreads();
+  for (unsigned int k = threadIdx.x; k < nh; k += 256) tpairs[gbase_h + k] = lists[k];
+  for (unsigned int k = threadIdx.x; k < nl; k += 256) tpairs[tp_capacity - 1u - (gbase_l + k)] = lists[span - 1 - k];
 }
 
 // ---- 6: scan kernel --------------------------------------------------------------------
@@ -679,6 +687,7 @@ __global__ __launch_bounds__(1024) void nms_write_kernel(const uint8_t *__restri
 // ---- optional per-phase timing (HIP events on the caller's stream) ----------------
 constexpr int kPhases = OBB_NMS_PHASES;
 struct NmsProfile {
+  int level = 0;  // 0 off, 1 scan kernel only (two events), 2 every phase
   bool on = false;
   bool have = false;
   hipEvent_t ev[kPhases + 1] = {};
@@ -801,7 +810,7 @@ extern "C" int obb_nms_grouped_f32(const float *dets_dev, int64_t n, int kind, f
     for (int k = 0; k <= kPhases; ++k) OBB_HIP_TRY(hipEventCreate(&prof.ev[k]));
     prof.created = true;
   }
-#define OBB_PHASE(k) do { if (timed) OBB_HIP_TRY(hipEventRecord(prof.ev[k], st)); } while (0)
+#define OBB_PHASE(k) do { if (timed && (prof.level >= 2 || (k) == 3 || (k) == 4)) OBB_HIP_TRY(hipEventRecord(prof.ev[k], st)); } while (0)
   // phase 0: clear + prep + quantise
   OBB_PHASE(0);
   OBB_HIP_TRY(hipMemsetAsync(ws + L.zero_begin, 0, L.zero_end - L.zero_begin, st));
@@ -810,11 +819,16 @@ extern "C" int obb_nms_grouped_f32(const float *dets_dev, int64_t n, int kind, f
   else
     hipLaunchKernelGGL(nms_prep_kernel<1>, dim3(pblocks), dim3(256), 0, st, dets_dev, n, rec, iv, part, group_dev, thr_dev, iou_thr);
   OBB_LAUNCH_CHECK();
-  hipLaunchKernelGGL(nms_quant_kernel, dim3(pblocks), dim3(256), 0, st, iv, n, part, (int)pblocks, qb, ckey, hist);
+  // cells ~ n/16 .. n/4, a power of 4 in [4096, 65536]
+  int hbits = 6;
+  while (hbits < 8 && (1ll << (2 * hbits)) * 16 < n) ++hbits;
+  hipLaunchKernelGGL(nms_quant_kernel, dim3(pblocks), dim3(256), 0, st, iv, n, part, (int)pblocks, qb, ckey, hist, hbits);
   OBB_LAUNCH_CHECK();
   // phase 1: spatial sort
   OBB_PHASE(1);
-  hipLaunchKernelGGL(nms_cellscan_kernel, dim3(1), dim3(1024), 0, st, hist);
+  if (hbits == 6) hipLaunchKernelGGL(nms_cellscan_kernel<4>, dim3(1), dim3(1024), 0, st, hist);
+  else if (hbits == 7) hipLaunchKernelGGL(nms_cellscan_kernel<16>, dim3(1), dim3(1024), 0, st, hist);
+  else hipLaunchKernelGGL(nms_cellscan_kernel<64>, dim3(1), dim3(1024), 0, st, hist);
   OBB_LAUNCH_CHECK();
   hipLaunchKernelGGL(nms_scatter_kernel, dim3(pblocks), dim3(256), 0, st, ckey, n, hist, sid);
   OBB_LAUNCH_CHECK();
@@ -822,7 +836,7 @@ extern "C" int obb_nms_grouped_f32(const float *dets_dev, int64_t n, int kind, f
   OBB_PHASE(2);
   hipLaunchKernelGGL(nms_permute_kernel, dim3((unsigned)nt), dim3(kTile), 0, st, qb, sid, n, qs, tbox);
   OBB_LAUNCH_CHECK();
-  hipLaunchKernelGGL(nms_cull_kernel, dim3((unsigned)((nt + 255) / 256), (unsigned)nt), dim3(256), 0, st, tbox, nt, tpairs, tp_capacity, ctr);
+  hipLaunchKernelGGL(nms_cull_kernel, dim3((unsigned)nt, (unsigned)((nt + kCullChunk - 1) / kCullChunk)), dim3(256), 0, st, tbox, nt, tpairs, tp_capacity, ctr);
   OBB_LAUNCH_CHECK();
   // phase 3: scan (broad phase)
   OBB_PHASE(3);
@@ -855,7 +869,10 @@ extern "C" int obb_nms_grouped_f32(const float *dets_dev, int64_t n, int kind, f
   OBB_HIP_TRY(hipMemcpyAsync(&h, ctr, sizeof(h), hipMemcpyDeviceToHost, st));
   OBB_HIP_TRY(hipStreamSynchronize(st));
   if (timed) {
-    for (int k = 0; k < kPhases; ++k) OBB_HIP_TRY(hipEventElapsedTime(&prof.ms[k], prof.ev[k], prof.ev[k + 1]));
+    for (int k = 0; k < kPhases; ++k) {
+      prof.ms[k] = 0.0f;
+      if (prof.level >= 2 || k == 3) OBB_HIP_TRY(hipEventElapsedTime(&prof.ms[k], prof.ev[k], prof.ev[k + 1]));
+    }
     prof.have = true;
   }
   unsigned long long ncand = 0, worst = 0;
@@ -884,6 +901,7 @@ extern "C" int obb_nms_grouped_f32(const float *dets_dev, int64_t n, int kind, f
 
 extern "C" int obb_nms_profile_enable(int on) {
   obb::g_prof.on = on != 0;
+  obb::g_prof.level = on;
   obb::g_prof.have = false;
   return OBB_OK;
 }

@@ -87,6 +87,17 @@ def main():
         keep, info = step()
     kept = int(keep.numel())
 
+    # per-phase table from a separate, untimed pass (an event between two kernels
+    # costs a ~5 us bubble; the timed region only brackets the dominant kernel)
+    L.obb_nms_profile_enable(2)
+    phase_tab = np.zeros(7, dtype=np.float64)
+    pbuf = (ctypes.c_float * 7)()
+    for _ in range(5):
+        step()
+        L.obb_nms_profile_last(pbuf)
+        phase_tab += np.frombuffer(pbuf, dtype=np.float32)
+    phase_tab /= 5
+
     # ---- timed region: exactly K steps, barrier + sync on both sides ----------
     L.obb_nms_profile_enable(1)
     phases = np.zeros(7, dtype=np.float64)
@@ -136,7 +147,7 @@ def main():
                    'resolve_rounds': info[1], 'candidate_pairs': info[2], 'parallelism': 'image-sharded x%d' % world},
         'roofline': roofline,
         'phase_ms': {k: round(float(v), 4) for k, v in zip(
-            ['prep_quant', 'cell_sort', 'permute_cull', 'scan', 'clip', 'resolve', 'compact'], phases)},
+            ['prep_quant', 'cell_sort', 'permute_cull', 'scan', 'clip', 'resolve', 'compact'], phase_tab)},
     }
 
     if rank == 0 and world == 1 and not args.no_extras:

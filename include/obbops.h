@@ -122,7 +122,7 @@ OBB_API int obb_nms_grouped_f32(const float *dets_dev, int64_t n, int kind, floa
  * phase), 5 resolve, 6 compaction.  No reference counterpart (the reference has
  * no kernel-level profiling).                                    */
 #define OBB_NMS_PHASES 7
-OBB_API int obb_nms_profile_enable(int on);
+OBB_API int obb_nms_profile_enable(int level); /* 0 off, 1 scan kernel only, 2 all phases */
 OBB_API int obb_nms_profile_last(float *phase_ms_host /* [OBB_NMS_PHASES] */);
 
 /* ---------------------------------------------------------------------------
