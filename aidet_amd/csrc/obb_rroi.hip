@@ -13,6 +13,8 @@
 // the same channel group, so output stores are contiguous runs of ph*pw floats
 // and the feature gathers of a wave stay inside a few rows of a few planes
 // (L1/L2 resident) -- NCHW is kept because the op must be a drop-in.
+#include <cstdlib>
+
 #include "obb_common.h"
 #include "obb_geom.cuh"
 
@@ -81,53 +83,211 @@ __device__ __forceinline__ void bilinear_taps(int height, int width, float y, fl
   }
 }
 
-// grid: (K, channel chunks); block: 256 threads; item = (channel group, bin)
-__global__ __launch_bounds__(256) void rroi_forward_kernel(
-    const float *__restrict__ feat, int B, int C, int H, int W, const float *__restrict__ rois,
-    int ph, int pw, float scale, int sample_num, float min_size, int groups_per_block,
-    float *__restrict__ out) {
-  const int64_t k = blockIdx.x;
-  RoiFrame f;
-  make_frame(rois + k * 6, scale, ph, pw, sample_num, min_size, f);
+// same rules, but returning the tap coordinates (no division to recover them)
+__device__ __forceinline__ bool bilinear_taps_xy(int height, int width, float y, float x, int &yl,
+                                                 int &xl, int &yh, int &xh, float (&w)[4]) {
+  const bool outside = (y < -1.0f) || (y > (float)height) || (x < -1.0f) || (x > (float)width);
+  if (y <= 0.0f) y = 0.0f;
+  if (x <= 0.0f) x = 0.0f;
+  int y_low = (int)y, x_low = (int)x, y_high, x_high;
+  if (y_low >= height - 1) { y_high = y_low = height - 1; y = (float)y_low; }
+  else y_high = y_low + 1;
+  if (x_low >= width - 1) { x_high = x_low = width - 1; x = (float)x_low; }
+  else x_high = x_low + 1;
+  float ly = y - (float)y_low, lx = x - (float)x_low;
+  float hy = 1.0f - ly, hx = 1.0f - lx;
+  yl = y_low; xl = x_low; yh = y_high; xh = x_high;
+  w[0] = hy * hx; w[1] = hy * lx; w[2] = ly * hx; w[3] = ly * lx;
+  if (outside) { w[0] = w[1] = w[2] = w[3] = 0.0f; }
+  return !outside;
+}
+
+// ---- forward, direct gathers (any footprint size) ---------------------------------------
+// item = (channel group, bin); used for RoIs whose footprint does not fit the LDS tile
+__device__ __forceinline__ void rroi_forward_direct(const float *__restrict__ feat, int C, int H,
+                                                    int W, const RoiFrame &f, int64_t k, int ph,
+                                                    int pw, int c_block, int c_end,
+                                                    float *__restrict__ out) {
   const int nb = ph * pw;
-  const int items = groups_per_block * nb;
-  const int c_block = blockIdx.y * groups_per_block * kChanPerThread;
-  const bool bad = f.b < 0 || f.b >= B;
   const int64_t plane = (int64_t)H * W;
-  for (int it = threadIdx.x; it < items; it += 256) {
+  const int groups = (c_end - c_block + kChanPerThread - 1) / kChanPerThread;
+  for (int it = threadIdx.x; it < groups * nb; it += 256) {
     const int grp = it / nb, bin = it - grp * nb;
     const int c0 = c_block + grp * kChanPerThread;
-    if (c0 >= C) continue;
     const int bi = bin / pw, bj = bin - bi * pw;
     float acc[kChanPerThread];
 #pragma unroll
     for (int c = 0; c < kChanPerThread; ++c) acc[c] = 0.0f;
-    if (!bad) {
-      const float *base = feat + ((int64_t)f.b * C + c0) * plane;
-      for (int iy = 0; iy < f.gh; ++iy) {
-        for (int ix = 0; ix < f.gw; ++ix) {
-          float x, y;
-          sample_xy(f, bi, bj, iy, ix, x, y);
-          int o[4];
-          float w[4];
-          bilinear_taps(H, W, y, x, o, w);
+    const float *base = feat + ((int64_t)f.b * C + c0) * plane;
+    for (int iy = 0; iy < f.gh; ++iy) {
+      for (int ix = 0; ix < f.gw; ++ix) {
+        float x, y;
+        sample_xy(f, bi, bj, iy, ix, x, y);
+        int o[4];
+        float w[4];
+        bilinear_taps(H, W, y, x, o, w);
 #pragma unroll
-          for (int c = 0; c < kChanPerThread; ++c) {
-            if (c0 + c < C) {
-              const float *p = base + (int64_t)c * plane;
-              float v = w[0] * p[o[0]];
-              v = v + w[1] * p[o[1]];
-              v = v + w[2] * p[o[2]];
-              v = v + w[3] * p[o[3]];
-              acc[c] = acc[c] + v;
-            }
+        for (int c = 0; c < kChanPerThread; ++c) {
+          if (c0 + c < c_end) {
+            const float *p = base + (int64_t)c * plane;
+            float v = w[0] * p[o[0]];
+            v = v + w[1] * p[o[1]];
+            v = v + w[2] * p[o[2]];
+            v = v + w[3] * p[o[3]];
+            acc[c] = acc[c] + v;
           }
         }
       }
     }
 #pragma unroll
     for (int c = 0; c < kChanPerThread; ++c)
-      if (c0 + c < C) out[((k * C + c0 + c) * (int64_t)nb) + bin] = acc[c] / f.cnt;
+      if (c0 + c < c_end) out[((k * C + c0 + c) * (int64_t)nb) + bin] = acc[c] / f.cnt;
+  }
+}
+
+// ---- forward, staged ---------------------------------------------------------------
+// grid: (K, channel chunks); block: 256 threads; item = (channel group, bin).
+// The RoI's footprint (the axis-aligned pixel box that contains every bilinear tap
+// of every sample) of each channel plane is first copied into LDS with coalesced row
+// loads; the ~4 x samples x channels taps are then LDS gathers instead of scattered
+// 4-byte global loads.  Values and operation order are unchanged.
+#ifndef OBB_STAGE_FLOATS
+#define OBB_STAGE_FLOATS 6144
+#endif
+constexpr int kStageFloats = OBB_STAGE_FLOATS;  // LDS tile per block (24 KiB)
+constexpr int kMaxTabSamples = 256;   // sample table (8 KiB); 7x7 bins x 2x2 samples = 196
+
+struct Footprint { int x0, y0, w, h; };
+
+__device__ __forceinline__ Footprint roi_footprint(const RoiFrame &f, int ph, int pw, int H, int W) {
+  const float rw = f.bin_w * (float)pw, rh = f.bin_h * (float)ph;
+  const float hx = 0.5f * (fabs_sel(f.c) * rw + fabs_sel(f.s) * rh);
+  const float hy = 0.5f * (fabs_sel(f.s) * rw + fabs_sel(f.c) * rh);
+  // one pixel of slack on each side covers the high tap and any rounding
+  float fx0 = floorf(f.cx - hx) - 1.0f, fx1 = floorf(f.cx + hx) + 2.0f;
+  float fy0 = floorf(f.cy - hy) - 1.0f, fy1 = floorf(f.cy + hy) + 2.0f;
+  fx0 = min_sel(max_sel(fx0, 0.0f), (float)(W - 1)); fx1 = min_sel(max_sel(fx1, 0.0f), (float)(W - 1));
+  fy0 = min_sel(max_sel(fy0, 0.0f), (float)(H - 1)); fy1 = min_sel(max_sel(fy1, 0.0f), (float)(H - 1));
+  Footprint p;
+  p.x0 = (int)fx0; p.y0 = (int)fy0;
+  p.w = (int)fx1 - p.x0 + 1; p.h = (int)fy1 - p.y0 + 1;
+  return p;
+}
+
+template <bool X4>
+__global__ __launch_bounds__(256) void rroi_forward_kernel(
+    const float *__restrict__ feat, int B, int C, int H, int W, const float *__restrict__ rois,
+    int ph, int pw, float scale, int sample_num, float min_size, int groups_per_block,
+    float *__restrict__ out) {
+  __shared__ __attribute__((aligned(16))) float tile[kStageFloats + 256];  // + pad for the last wave-instruction
+  __shared__ int4 s_off[kMaxTabSamples];      // per sample: 4 footprint-local tap offsets
+  __shared__ float4 s_wgt[kMaxTabSamples];    // per sample: 4 bilinear weights
+  const int64_t k = blockIdx.x;
+  RoiFrame f;
+  make_frame(rois + k * 6, scale, ph, pw, sample_num, min_size, f);
+  const int nb = ph * pw;
+  const int c_block = blockIdx.y * groups_per_block * kChanPerThread;
+  const int c_end = min(C, c_block + groups_per_block * kChanPerThread);
+  const bool bad = f.b < 0 || f.b >= B;
+  const int64_t plane = (int64_t)H * W;
+  if (bad) {  // zeros for an invalid batch index
+    for (int it = threadIdx.x; it < (c_end - c_block) * nb; it += 256)
+      out[(k * C + c_block) * (int64_t)nb + it] = 0.0f;
+    return;
+  }
+  Footprint fp = roi_footprint(f, ph, pw, H, W);
+  if (X4) {  // 16-byte LDS-DMA: rows start and end on multiples of 4 floats (W % 4 == 0)
+    const int x1 = (fp.x0 + fp.w - 1) | 3;
+    fp.x0 &= ~3;
+    fp.w = x1 - fp.x0 + 1;
+  }
+  const int fsz = fp.w * fp.h;                       // floats per channel plane
+  const int spb = f.gh * f.gw;                       // samples per bin
+  const int nsamp = nb * spb;
+  // block-uniform: huge RoI / huge sampling grid / >2^31-element tensors gather directly
+  if (fsz > kStageFloats || nsamp > kMaxTabSamples || (int64_t)B * C * plane >= (1ll << 31)) {
+    rroi_forward_direct(feat, C, H, W, f, k, ph, pw, c_block, c_end, out);
+    return;
+  }
+  // sample table: coordinates, taps and weights are computed ONCE per RoI and block
+  // (the reference recomputes them for every output element, roi_align_kernel.cu:70-113)
+  for (int sidx = threadIdx.x; sidx < nsamp; sidx += 256) {
+    const int bin = sidx / spb, q = sidx - bin * spb;
+    const int bi = bin / pw, bj = bin - bi * pw;
+    const int iy = q / f.gw, ix = q - iy * f.gw;
+    float x, y, w[4];
+    int yl, xl, yh, xh;
+    sample_xy(f, bi, bj, iy, ix, x, y);
+    const bool live = bilinear_taps_xy(H, W, y, x, yl, xl, yh, xh, w);
+    // tap coordinates -> footprint-local offsets (clamped: never out of the tile)
+    auto cl = [](int v, int n) { return v < 0 ? 0 : (v >= n ? n - 1 : v); };
+    const int ly0 = cl(yl - fp.y0, fp.h) * fp.w, ly1 = cl(yh - fp.y0, fp.h) * fp.w;
+    const int lx0 = cl(xl - fp.x0, fp.w), lx1 = cl(xh - fp.x0, fp.w);
+    s_off[sidx] = live ? make_int4(ly0 + lx0, ly0 + lx1, ly1 + lx0, ly1 + lx1) : make_int4(0, 0, 0, 0);
+    s_wgt[sidx] = make_float4(w[0], w[1], w[2], w[3]);
+  }
+  const int cpp = kStageFloats / fsz;                // channels per pass (>= 1)
+  const uint32_t m_nb = nb > 1 ? 0xFFFFFFFFu / (uint32_t)nb + 1u : 0u;  // it / nb for it < 2^16
+  const uint32_t m_fsz = fsz > 1 ? 0xFFFFFFFFu / (uint32_t)fsz + 1u : 0u;
+  const uint32_t m_w = fp.w > 1 ? 0xFFFFFFFFu / (uint32_t)fp.w + 1u : 0u;
+  const uint32_t plane32 = (uint32_t)plane;
+  for (int cp = c_block; cp < c_end; cp += cpp) {
+    const int nch = min(cpp, c_end - cp);
+    // stage nch footprints with LDS-DMA (global_load_lds_dword): every lane supplies
+    // its own source address, a wave-instruction lands 64 consecutive floats in the
+    // tile, nothing passes through VGPRs and all loads are in flight together.
+    // flat index -> (channel, y, x) by exact multiply-high division (idx < 2^14);
+    // 32-bit element offsets from a uniform base.
+    const float *src = feat + ((int64_t)f.b * C + cp) * plane + (int64_t)fp.y0 * W + fp.x0;
+    {
+      const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+      const int total = nch * fsz;
+      if (X4) {
+        // 16 bytes per lane: one wave-instruction lands 1 KiB (64 chunks of 4 floats)
+        const int q4 = fsz >> 2, rw4 = fp.w >> 2, total4 = total >> 2;   // chunks per plane / row / pass
+        const uint32_t m_q4 = q4 > 1 ? 0xFFFFFFFFu / (uint32_t)q4 + 1u : 0u;
+        const uint32_t m_r4 = rw4 > 1 ? 0xFFFFFFFFu / (uint32_t)rw4 + 1u : 0u;
+        for (int base = wave * 64; base < total4; base += 256) {
+          const uint32_t idx = (uint32_t)min(base + lane, total4 - 1);
+          const uint32_t c = q4 > 1 ? __umulhi(idx, m_q4) : idx;
+          const uint32_t r = idx - c * (uint32_t)q4;
+          const uint32_t y = rw4 > 1 ? __umulhi(r, m_r4) : r;
+          const uint32_t x = (r - y * (uint32_t)rw4) << 2;
+          const uint32_t off = c * plane32 + y * (uint32_t)W + x;
+          __builtin_amdgcn_global_load_lds(src + off, (__attribute__((address_space(3))) void *)(tile + base * 4), 16, 0, 0);
+        }
+      } else {
+        for (int base = wave * 64; base < total; base += 256) {
+          const uint32_t idx = (uint32_t)min(base + lane, total - 1);  // tail lanes re-load the last float into the pad
+          const uint32_t c = fsz > 1 ? __umulhi(idx, m_fsz) : idx;
+          const uint32_t r = idx - c * (uint32_t)fsz;
+          const uint32_t y = fp.w > 1 ? __umulhi(r, m_w) : r;
+          const uint32_t x = r - y * (uint32_t)fp.w;
+          const uint32_t off = c * plane32 + y * (uint32_t)W + x;
+          __builtin_amdgcn_global_load_lds(src + off, (__attribute__((address_space(3))) void *)(tile + base), 4, 0, 0);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    // one output element per item: consecutive threads = consecutive bins of a channel
+    // (coalesced stores); tap offsets / weights come from the block's sample table
+    for (int it = threadIdx.x; it < nch * nb; it += 256) {
+      const int c = nb > 1 ? (int)__umulhi((uint32_t)it, m_nb) : it, bin = it - c * nb;
+      const float *p = tile + c * fsz;
+      float acc = 0.0f;
+      for (int q = 0; q < spb; ++q) {
+        const int4 l = s_off[bin * spb + q];
+        const float4 w = s_wgt[bin * spb + q];
+        float v = w.x * p[l.x];
+        v = v + w.y * p[l.y];
+        v = v + w.z * p[l.z];
+        v = v + w.w * p[l.w];
+        acc = acc + v;
+      }
+      out[((k * C + cp + c) * (int64_t)nb) + bin] = acc / f.cnt;
+    }
+    __syncthreads();
   }
 }
 
@@ -212,9 +372,21 @@ extern "C" int obb_rroi_align_forward_f32(const float *feat_dev, int B, int C, i
   if (H == 0 || W == 0 || B == 0) return set_err(OBB_EINVAL, "obb_rroi_align_forward_f32: empty feature map with %lld RoIs", (long long)K);
   int gpb; unsigned chunks;
   rroi_geometry(C, ph, pw, gpb, chunks);
+  // forward: 24 channels per block (gpb = 3, measured best of 1..8): a big rotated RoI
+  // needs several staging passes per channel group, and the kernel ends with its
+  // slowest block
+  gpb = 3;
+  if (const char *e = getenv("OBB_RROI_GPB")) gpb = atoi(e) > 0 ? atoi(e) : gpb;  // tuning knob
+  chunks = (unsigned)(((C + kChanPerThread - 1) / kChanPerThread + gpb - 1) / gpb);
   if (chunks > 65535u) return set_err(OBB_EINVAL, "obb_rroi_align_forward_f32: too many channels (%d)", C);
-  hipLaunchKernelGGL(rroi_forward_kernel, dim3((unsigned)K, chunks), dim3(256), 0, (hipStream_t)stream,
-                     feat_dev, B, C, H, W, rois_dev, ph, pw, spatial_scale, sample_num, min_size, gpb, out_dev);
+  // 16-byte LDS-DMA needs 16-byte aligned rows: W % 4 == 0 and an aligned base
+  const bool x4 = (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(feat_dev) & 15u) == 0);
+  if (x4)
+    hipLaunchKernelGGL(rroi_forward_kernel<true>, dim3((unsigned)K, chunks), dim3(256), 0, (hipStream_t)stream,
+                       feat_dev, B, C, H, W, rois_dev, ph, pw, spatial_scale, sample_num, min_size, gpb, out_dev);
+  else
+    hipLaunchKernelGGL(rroi_forward_kernel<false>, dim3((unsigned)K, chunks), dim3(256), 0, (hipStream_t)stream,
+                       feat_dev, B, C, H, W, rois_dev, ph, pw, spatial_scale, sample_num, min_size, gpb, out_dev);
   OBB_LAUNCH_CHECK();
   return OBB_OK;
 }

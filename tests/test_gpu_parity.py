@@ -407,3 +407,30 @@ def test_distributed_merge_on_gpu_single_process():
     _, ref = dota_merge.merge_detections(torch.from_numpy(rows), 0.3, NUM_CLASSES, CLASS_THRS,
                                          nms_fn=oracle_nms)
     assert np.array_equal(keep.cpu().numpy(), ref.numpy())
+
+
+def test_rroi_align_large_and_offmap_rois():
+    """RoIs whose footprint exceeds the LDS tile (direct-gather path), RoIs staged in
+    several channel passes, RoIs partly / wholly outside the map, bad batch index."""
+    from aidet_amd import RRoIAlign
+    rng = np.random.default_rng(11)
+    feat = rng.standard_normal((2, 20, 180, 200)).astype(np.float32)
+    rois = np.array([
+        [0, 400, 360, 700, 640, 0.4],      # ~175 x 160 px footprint: direct path
+        [1, 300, 300, 240, 200, -1.0],     # ~70 x 70: several channel passes
+        [0, 100, 90, 40, 30, 0.2],         # small: one pass
+        [1, -50, -40, 60, 60, 0.7],        # mostly off the map
+        [0, 5000, 5000, 30, 30, 0.0],      # entirely off the map -> zeros
+        [1, 790, 700, 90, 120, 2.5],       # bottom-right corner
+        [0, 400, 360, 1.0, 1.0, 0.3],      # tiny (min_size clamp)
+    ], np.float32)
+    for sn in (2, 0):
+        got = RRoIAlign(7, 0.25, sample_num=sn)(t(feat), t(rois)).cpu().numpy()
+        ref = oracle.rroi_align_forward(feat, rois, 7, 0.25, sn)
+        assert np.abs(got - ref).max() <= IOU_TOL
+        assert np.all(got[4] == 0)
+    bad = rois.copy()
+    bad[2, 0] = 7  # batch index out of range -> zeros for that RoI (header contract)
+    got = RRoIAlign(7, 0.25, sample_num=2)(t(feat), t(bad)).cpu().numpy()
+    ref = oracle.rroi_align_forward(feat, rois, 7, 0.25, 2)
+    assert np.all(got[2] == 0) and np.abs(got[[0, 1, 3, 4, 5, 6]] - ref[[0, 1, 3, 4, 5, 6]]).max() <= IOU_TOL
