@@ -22,7 +22,9 @@ constexpr int kColsPerLane = 4;
 constexpr int kColsPerWave = 64 * kColsPerLane;      // 256
 constexpr int kColsPerBlock = kWaves * kColsPerWave;  // 1024
 constexpr int kMaxRows = 256;        // rows per block (TI upper bound)
-constexpr int kQueue = 64 + kColsPerWave;  // worst case pending + one row's pushes
+constexpr int kQueue = 64 + kColsPerWave;  // carry (<= 63) + one row's worst case
+constexpr uint32_t kGuard = 0x80008000u;
+constexpr uint32_t kQMax = 32766u;
 
 // conservative closed interval of a record along one axis (see DESIGN.md:
 // margin 2^-21 * (|o| + e) dominates every rounding in the spec's prefilter)
@@ -30,6 +32,13 @@ __device__ __forceinline__ void interval(float o, float e, float &lo, float &hi)
   float mg = (fabs_sel(o) + e) * 4.76837158203125e-7f;
   lo = (o - e) - mg;
   hi = (o + e) + mg;
+}
+
+// packed x|y 15-bit interval test with guard bits, 3 full-rate VALU per pair
+// (same construction as the NMS scan kernel): 0 <=> the intervals meet on both axes
+__device__ __forceinline__ uint32_t qdisjoint(uint32_t alo, uint32_t ahiG, uint32_t blo, uint32_t bhiG) {
+  const uint32_t d1 = bhiG - alo, d2 = ahiG - blo;
+  return (~d1 | ~d2) & kGuard;
 }
 
 template <int KIND>
@@ -44,92 +53,181 @@ __device__ __forceinline__ void clip_and_store(const float *__restrict__ a,
   out[i * n + j] = quad_overlap(A, B, mode);
 }
 
+// Block = 4 waves x 256 columns (4 per lane) x up to 256 rows.
+//  1 every thread builds the float AABB interval of one row and of its 4 columns;
+//    a block reduction gives the frame (bounding box of the block's rows + columns);
+//    intervals are quantised to 15 bits in that frame -- floor of a monotone map is
+//    monotone, so the integer test never loses a real overlap
+//  2 per row: broadcast (v_readlane), 12 VALU for 4 columns + vote; every lane
+//    stores 16 bytes of exact zeros (1 KiB per wave-instruction, the HBM-bound part)
+//  3 rows with a candidate are handled out of line: ballot-compacted (row, col)
+//    pairs go to a per-wave LDS queue; 64 at a time are clipped with all lanes busy
+//    and overwrite their zeros (release fence + wave barrier order the two stores)
 template <int KIND, bool VEC>
 __global__ __launch_bounds__(256) void overlaps_tile_kernel(
     const float *__restrict__ a, int64_t m, const float *__restrict__ b, int64_t n,
     int mode, int rows_per_block, float *__restrict__ out) {
   constexpr int S = KIND ? 8 : 5;
-  __shared__ float4 arow[kMaxRows];              // xlo, xhi, ylo, yhi per row
+  __shared__ uint2 qrow[kMaxRows];                // packed (lo, hi|G) per row
   __shared__ uint32_t queue[kWaves][kQueue];
+  __shared__ float red[kWaves][4];
+  __shared__ float frame[4];                      // base x, base y, scale x, scale y
 
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t i0 = (int64_t)blockIdx.y * rows_per_block;
   const int ti = (int)min((int64_t)rows_per_block, m - i0);
   const int64_t jw = (int64_t)blockIdx.x * kColsPerBlock + wave * kColsPerWave;  // wave's first col
   const int64_t j0 = jw + lane * kColsPerLane;
 
-  // row intervals -> LDS
-  if (threadIdx.x < ti) {
+  // ---- 1a: float intervals (non-finite boxes become "isolated": lo > hi)
+  const float big = 3.0e38f;
+  float rxl = big, rxh = -big, ryl = big, ryh = -big;   // this thread's row
+  bool rfin = false;
+  if ((int)threadIdx.x < ti) {
     Quad A;
     load_quad<KIND>(a + (i0 + threadIdx.x) * S, A);
-    float4 r;
-    interval(A.ox, A.ex, r.x, r.y);
-    interval(A.oy, A.ey, r.z, r.w);
-    arow[threadIdx.x] = r;
+    interval(A.ox, A.ex, rxl, rxh);
+    interval(A.oy, A.ey, ryl, ryh);
+    rfin = (fabs_sel(rxl) < big) && (fabs_sel(rxh) < big) && (fabs_sel(ryl) < big) && (fabs_sel(ryh) < big);
   }
-  // this lane's 4 column intervals -> registers
-  float bxlo[kColsPerLane], bxhi[kColsPerLane], bylo[kColsPerLane], byhi[kColsPerLane];
+  float cxl[kColsPerLane], cxh[kColsPerLane], cyl[kColsPerLane], cyh[kColsPerLane];
+  bool cfin[kColsPerLane];
 #pragma unroll
   for (int c = 0; c < kColsPerLane; ++c) {
+    cfin[c] = false;
+    cxl[c] = big; cxh[c] = -big; cyl[c] = big; cyh[c] = -big;
     if (j0 + c < n) {
       Quad B;
       load_quad<KIND>(b + (j0 + c) * S, B);
-      interval(B.ox, B.ex, bxlo[c], bxhi[c]);
-      interval(B.oy, B.ey, bylo[c], byhi[c]);
-    } else {  // beyond the last column: an interval no row can meet
-      bxlo[c] = 3.0e38f; bxhi[c] = -3.0e38f; bylo[c] = 3.0e38f; byhi[c] = -3.0e38f;
+      interval(B.ox, B.ex, cxl[c], cxh[c]);
+      interval(B.oy, B.ey, cyl[c], cyh[c]);
+      cfin[c] = (fabs_sel(cxl[c]) < big) && (fabs_sel(cxh[c]) < big) && (fabs_sel(cyl[c]) < big) && (fabs_sel(cyh[c]) < big);
+    }
+  }
+  // ---- 1b: frame = bounding box of all finite intervals of the block
+  float mnx = big, mxx = -big, mny = big, mxy = -big;
+  if (rfin) { mnx = rxl; mxx = rxh; mny = ryl; mxy = ryh; }
+#pragma unroll
+  for (int c = 0; c < kColsPerLane; ++c)
+    if (cfin[c]) {
+      mnx = min_sel(mnx, cxl[c]); mxx = max_sel(mxx, cxh[c]);
+      mny = min_sel(mny, cyl[c]); mxy = max_sel(mxy, cyh[c]);
+    }
+  for (int o = 32; o > 0; o >>= 1) {
+    mnx = min_sel(mnx, __shfl_xor(mnx, o)); mxx = max_sel(mxx, __shfl_xor(mxx, o));
+    mny = min_sel(mny, __shfl_xor(mny, o)); mxy = max_sel(mxy, __shfl_xor(mxy, o));
+  }
+  if (lane == 0) { red[wave][0] = mnx; red[wave][1] = mxx; red[wave][2] = mny; red[wave][3] = mxy; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float x0 = red[0][0], x1 = red[0][1], y0 = red[0][2], y1 = red[0][3];
+    for (int k = 1; k < kWaves; ++k) {
+      x0 = min_sel(x0, red[k][0]); x1 = max_sel(x1, red[k][1]);
+      y0 = min_sel(y0, red[k][2]); y1 = max_sel(y1, red[k][3]);
+    }
+    const float rx = x1 - x0, ry = y1 - y0;
+    frame[0] = x0; frame[1] = y0;
+    frame[2] = rx > 0.0f ? (float)kQMax / rx : 0.0f;
+    frame[3] = ry > 0.0f ? (float)kQMax / ry : 0.0f;
+  }
+  __syncthreads();
+  const float bx = frame[0], by = frame[1], sx = frame[2], sy = frame[3];
+  auto qz = [](float x, float base, float s) {
+    float u = floorf((x - base) * s);
+    u = u < 0.0f ? 0.0f : (u > (float)kQMax ? (float)kQMax : u);
+    return (uint32_t)u;
+  };
+  // ---- 1c: quantise (isolated / absent boxes: lo = max, hi = 0 -> never a candidate)
+  if ((int)threadIdx.x < kMaxRows) {
+    uint2 o = make_uint2(0x7FFF7FFFu, kGuard);
+    if (rfin) {
+      o.x = qz(rxl, bx, sx) | (qz(ryl, by, sy) << 16);
+      o.y = (qz(rxh, bx, sx) | (qz(ryh, by, sy) << 16)) | kGuard;
+    }
+    qrow[threadIdx.x] = o;
+  }
+  uint2 col[kColsPerLane];
+#pragma unroll
+  for (int c = 0; c < kColsPerLane; ++c) {
+    col[c] = make_uint2(0x7FFF7FFFu, kGuard);
+    if (cfin[c]) {
+      col[c].x = qz(cxl[c], bx, sx) | (qz(cyl[c], by, sy) << 16);
+      col[c].y = (qz(cxh[c], bx, sx) | (qz(cyh[c], by, sy) << 16)) | kGuard;
     }
   }
   __syncthreads();
-  if (jw >= n) return;  // whole wave beyond the matrix (after the barrier)
+  if (jw >= n) return;  // whole wave beyond the matrix (after the last barrier)
 
   uint32_t *q = queue[wave];
   int qn = 0;  // wave-uniform
   const uint64_t lt_mask = (1ull << lane) - 1ull;
-
-  for (int ii = 0; ii < ti; ++ii) {
-    const float4 r = arow[ii];
-    bool cand[kColsPerLane];
-#pragma unroll
-    for (int c = 0; c < kColsPerLane; ++c)
-      cand[c] = (r.x <= bxhi[c]) && (bxlo[c] <= r.y) && (r.z <= byhi[c]) && (bylo[c] <= r.w);
-
-    // disjoint pairs are exact zeros; candidates are overwritten by the clip
-    float *orow = out + (i0 + ii) * n + j0;
-    if (VEC) {
-      if (j0 < n) *reinterpret_cast<float4 *>(orow) = make_float4(0.f, 0.f, 0.f, 0.f);
-    } else {
-#pragma unroll
-      for (int c = 0; c < kColsPerLane; ++c)
-        if (j0 + c < n) orow[c] = 0.0f;
-    }
-
-#pragma unroll
-    for (int c = 0; c < kColsPerLane; ++c) {
-      const uint64_t mk = __ballot(cand[c]);
-      if (mk) {
-        if (cand[c]) q[qn + __popcll(mk & lt_mask)] = ((uint32_t)ii << 10) | (uint32_t)(lane * kColsPerLane + c);
-        qn += __popcll(mk);
-      }
-    }
-    while (qn >= 64) {
-      qn -= 64;
+  auto drain = [&](bool flush) {
+    while (qn >= 64 || (flush && qn > 0)) {
+      const int take = qn < 64 ? qn : 64;
+      qn -= take;
       // order this wave's zero stores before the clip's stores to the same words
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __builtin_amdgcn_wave_barrier();
-      const uint32_t e = q[qn + lane];
-      clip_and_store<KIND>(a, b, i0 + (e >> 10), jw + (e & 1023u), n, mode, out);
+#ifndef OBB_OV_NOCLIP
+      if (lane < take) {
+        const uint32_t e = q[qn + lane];
+        clip_and_store<KIND>(a, b, i0 + (e >> 10), jw + (e & 1023u), n, mode, out);
+      }
+#endif
+    }
+  };
+
+  for (int g = 0; g < ti; g += 64) {          // 64 rows per VGPR pair
+    const uint2 rv = qrow[g + lane];
+    const int rows = min(64, ti - g);
+    for (int ib = 0; ib < rows; ib += 8) {
+      uint32_t hit = 0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int ii = ib + u;                 // rows beyond ti are sentinels
+        const uint32_t rlo = (uint32_t)__builtin_amdgcn_readlane((int)rv.x, ii);
+        const uint32_t rhi = (uint32_t)__builtin_amdgcn_readlane((int)rv.y, ii);
+        const uint32_t t0 = qdisjoint(rlo, rhi, col[0].x, col[0].y);
+        const uint32_t t1 = qdisjoint(rlo, rhi, col[1].x, col[1].y);
+        const uint32_t t2 = qdisjoint(rlo, rhi, col[2].x, col[2].y);
+        const uint32_t t3 = qdisjoint(rlo, rhi, col[3].x, col[3].y);
+        const uint32_t mn = min(min(t0, t1), min(t2, t3));
+        hit |= __any(mn == 0u) ? (1u << u) : 0u;
+        // disjoint pairs are exact zeros; candidates are overwritten by the clip
+#ifndef OBB_OV_NOSTORE
+        if (g + ii < ti) {
+          float *orow = out + (i0 + g + ii) * n + j0;
+          if (VEC) {
+            if (j0 < n) *reinterpret_cast<float4 *>(orow) = make_float4(0.f, 0.f, 0.f, 0.f);
+          } else {
+#pragma unroll
+            for (int c = 0; c < kColsPerLane; ++c)
+              if (j0 + c < n) orow[c] = 0.0f;
+          }
+        }
+#endif
+      }
+      while (hit) {  // some lane has a candidate in row g+ib+u
+        const int u = __builtin_ctz(hit);
+        hit &= hit - 1u;
+        const int ii = ib + u;
+        const uint32_t rlo = (uint32_t)__builtin_amdgcn_readlane((int)rv.x, ii);
+        const uint32_t rhi = (uint32_t)__builtin_amdgcn_readlane((int)rv.y, ii);
+#pragma unroll
+        for (int c = 0; c < kColsPerLane; ++c) {
+          const bool cand = qdisjoint(rlo, rhi, col[c].x, col[c].y) == 0u;
+          const uint64_t mk = __ballot(cand);
+          if (mk) {
+            if (cand) q[qn + __popcll(mk & lt_mask)] = ((uint32_t)(g + ii) << 10) | (uint32_t)(lane * kColsPerLane + c);
+            qn += __popcll(mk);
+          }
+        }
+        drain(false);
+      }
     }
   }
-  if (qn > 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    if (lane < qn) {
-      const uint32_t e = q[lane];
-      clip_and_store<KIND>(a, b, i0 + (e >> 10), jw + (e & 1023u), n, mode, out);
-    }
-  }
+  drain(true);
 }
 
 // aligned (pair i with pair i): one lane per pair

@@ -1,0 +1,18 @@
+"""Stand-alone timing of rbbox_overlaps 16k x 16k for profiling runs."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import oracle
+from aidet_amd import rbbox_overlaps
+dev = torch.device('cuda:0')
+m = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+a = torch.from_numpy(oracle.synth_boxes(m, 1024, 1)[:, :5]).to(dev)
+b = torch.from_numpy(oracle.synth_boxes(m, 1024, 2)[:, :5]).to(dev)
+for _ in range(3): rbbox_overlaps(a, b)
+torch.cuda.synchronize()
+s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+s.record()
+for _ in range(10): rbbox_overlaps(a, b)
+e.record(); torch.cuda.synchronize()
+ms = s.elapsed_time(e) / 10
+print('iou %dx%d ms %.4f  -> %.0f GB/s' % (m, m, ms, 4.0 * m * m / ms / 1e6))
