@@ -124,16 +124,19 @@ def main():
     ms_per_step = elapsed * 1e3 / args.steps
     value = n * world * args.steps / elapsed
 
-    pair_ms = float(phases[3])  # scan kernel
+    pair_ms = float(phases[3])  # scan kernel, HIP events inside the timed region
     alg = nms_algorithmic_bytes(n, kept)
     achieved = alg / (pair_ms * 1e-3) / 1e9 if pair_ms > 0 else 0.0
+    traffic, traffic_src = pmc_traffic('nms_scan_kernel', n, args.canvas)
     roofline = {
         'bound': 'hbm', 'kernel': 'nms_scan_kernel', 'achieved': round(achieved, 1),
         'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
-        'traffic': None,
+        'traffic': traffic, 'traffic_source': traffic_src,
         'algorithmic_bytes': alg, 'kernel_ms': round(pair_ms, 4),
-        'note': 'bytes = reference bit-mask model (SURVEY 8d); the mask is never materialised: '
-                'the kernel is VALU-bound on 4-compare AABB tests, see DESIGN.md',
+        'note': 'algorithmic_bytes = the reference bit-mask model of SURVEY 8d (1.25 GB at n=100k); '
+                'this pipeline never materialises that mask (spatial sort + tile culling), so '
+                'achieved exceeds the HBM peak by construction and traffic (PMC) is ~100x smaller. '
+                'The scan kernel is VALU-bound (3 ops per tested pair), see DESIGN.md section 5.',
     }
 
     out = {
@@ -161,6 +164,25 @@ def main():
         dist.destroy_process_group()
 
 
+def pmc_traffic(kernel, n, canvas):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes
+    (profiles/r01_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this
+    bench, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  PMC
+    collection needs rocprofv3 around the process, so the number cannot be taken
+    live; it is only reported for the workload it was measured on."""
+    path = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        w = t['workload']
+        if w['boxes'] == n and abs(w['canvas'] - canvas) < 1e-6 and kernel in t['kernels']:
+            k = t['kernels'][kernel]
+            return int(2 * k['FETCH_SIZE_KB'] * 1024 + k['WRITE_SIZE_KB'] * 1024), 'profiles/r01_traffic.json'
+    except (OSError, KeyError, ValueError):
+        pass
+    return None, None
+
+
 def _time_gpu(fn, iters):
     fn()
     torch.cuda.synchronize()
@@ -178,10 +200,13 @@ def extras(dev, oracle):
     """Side metrics outside the timed region (same process, current stream)."""
     from aidet_amd import RRoIAlign, rbbox_overlaps
     res = {}
-    # rotated IoU, configs[0] shape (1k x 1k, latency bound) and its 16k x 16k scale-up
-    for m, tag, iters in ((1000, 'iou_1k_x_1k', 200), (16384, 'iou_16k_x_16k', 10)):
-        a = torch.from_numpy(oracle.synth_boxes(m, 1024, 1)[:, :5]).to(dev)
-        b = torch.from_numpy(oracle.synth_boxes(m, 1024, 2)[:, :5]).to(dev)
+    # rotated IoU, configs[0] shape (1k x 1k on a 1024 canvas, latency bound), its
+    # 16k x 16k scale-up (1.2 % of the pairs are clipped: VALU-bound) and a sparse
+    # 16k x 16k (canvas 8192, 0.02 % clipped: the HBM-write-bound regime)
+    for m, canvas, tag, iters in ((1000, 1024, 'iou_1k_x_1k', 200), (16384, 1024, 'iou_16k_x_16k', 10),
+                                  (16384, 8192, 'iou_16k_x_16k_sparse', 10)):
+        a = torch.from_numpy(oracle.synth_boxes(m, canvas, 1)[:, :5]).to(dev)
+        b = torch.from_numpy(oracle.synth_boxes(m, canvas, 2)[:, :5]).to(dev)
         ms = _time_gpu(lambda: rbbox_overlaps(a, b), iters)
         alg = 20 * (2 * m) + 4 * m * m  # SURVEY 8d
         res[tag] = {'ms': round(ms, 4), 'pairs_per_s': round(m * m / (ms * 1e-3), 1),
