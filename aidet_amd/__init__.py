@@ -14,11 +14,12 @@ from .nms_wrapper import nms, poly_nms, rnms, thetaobb_nms
 from .post_processing import (multiclass_nms_with_index, multiclass_rnms,
                               thetaobb_nms_by_bbox_nms)
 from .rbbox_geometry import rbbox_overlaps, thetaobb2pointobb
+from .roi_layers import RoIAlign, RotatedSingleRoIExtractor
 from .rroi_align import RRoIAlign, rroi_align
 
 __all__ = [
     'rnms', 'poly_nms', 'thetaobb_nms', 'nms', 'rbbox_overlaps', 'thetaobb2pointobb',
-    'RRoIAlign', 'rroi_align', 'multiclass_rnms', 'multiclass_nms_with_index',
+    'RRoIAlign', 'rroi_align', 'RoIAlign', 'RotatedSingleRoIExtractor', 'multiclass_rnms', 'multiclass_nms_with_index',
     'thetaobb_nms_by_bbox_nms'
 ]
 __version__ = '0.1.0'

@@ -434,3 +434,41 @@ def test_rroi_align_large_and_offmap_rois():
     got = RRoIAlign(7, 0.25, sample_num=2)(t(feat), t(bad)).cpu().numpy()
     ref = oracle.rroi_align_forward(feat, rois, 7, 0.25, 2)
     assert np.all(got[2] == 0) and np.abs(got[[0, 1, 3, 4, 5, 6]] - ref[[0, 1, 3, 4, 5, 6]]).max() <= IOU_TOL
+
+
+def test_hbb_roi_align_dropin_v1_v2():
+    """RoIAlign (reference signature) over the rotated kernel vs the restated
+    ROIAlignForwardV1 (roi_align_kernel.cu:64-117) and RoIAlignForwardV2 aligned
+    (roi_align_kernel_v2.cu:62-128)."""
+    from aidet_amd import RoIAlign
+    rng = np.random.default_rng(4)
+    feat = rng.standard_normal((2, 12, 48, 64)).astype(np.float32)
+    k = 60
+    x1 = rng.uniform(0, 200, k); y1 = rng.uniform(0, 150, k)
+    w = rng.uniform(2, 120, k); h = rng.uniform(2, 100, k)
+    rois = np.stack([(np.arange(k) % 2), x1, y1, x1 + w, y1 + h], 1).astype(np.float32)
+    for sn in (2, 0):
+        got = RoIAlign(7, 0.25, sample_num=sn, aligned=False)(t(feat), t(rois)).cpu().numpy()
+        ref = oracle.roi_align_forward(feat, rois, 7, 0.25, sn, version=1)
+        assert np.abs(got - ref).max() <= IOU_TOL
+        got = RoIAlign(7, 0.25, sample_num=sn, aligned=True)(t(feat), t(rois)).cpu().numpy()
+        ref = oracle.roi_align_forward(feat, rois, 7, 0.25, sn, version=2, aligned=True)
+        assert np.abs(got - ref).max() <= IOU_TOL
+
+
+def test_rotated_extractor_forward():
+    from aidet_amd import RotatedSingleRoIExtractor
+    rng = np.random.default_rng(6)
+    feats = [rng.standard_normal((1, 8, 256 // s, 256 // s)).astype(np.float32) for s in (1, 2, 4, 8)]
+    ex = RotatedSingleRoIExtractor(dict(type='RRoIAlign', out_size=7, sample_num=2), 8, [4, 8, 16, 32])
+    r = oracle.synth_boxes(40, 1000, 2)[:, :5]
+    r[:, 2:4] *= rng.uniform(1, 6, (40, 1)).astype(np.float32)
+    rois = np.concatenate([np.zeros((40, 1), np.float32), r], 1)
+    out = ex([t(f) for f in feats], t(rois)).cpu().numpy()
+    lv = ex.map_roi_levels(torch.from_numpy(rois), 4).numpy()
+    assert len(set(lv.tolist())) >= 3
+    for i, s in enumerate((4, 8, 16, 32)):
+        m = lv == i
+        if m.any():
+            ref = oracle.rroi_align_forward(feats[i], rois[m], 7, 1.0 / s, 2)
+            assert np.abs(out[m] - ref).max() <= IOU_TOL
