@@ -77,14 +77,21 @@ struct alignas(16) QuadRec {  // 64 bytes: four float4 loads
   float thr;      // overlap threshold that applies when this box is the earlier one
 };
 
+// Hot counters live in separate 256-byte slots: returning atomics on words that
+// share a cache line serialise at the memory side.
 struct NmsCounters {
-  unsigned long long edges;   // overlap edges found (may exceed capacity)
-  long long kept;             // K
-  long long rounds;           // resolve rounds
-  unsigned int tile_pairs;    // surviving tile pairs (heavy + light)
-  unsigned int heavy_pairs;   // of which heavy (stored from the front of the list)
-  unsigned long long cand[kShards];  // candidate pairs per shard (may exceed the segment)
+  alignas(256) unsigned long long edges;   // overlap edges found (may exceed capacity)
+  alignas(256) unsigned int tile_pairs;    // light tile pairs (stored from the back of the list)
+  alignas(256) unsigned int heavy_pairs;   // heavy tile pairs (stored from the front)
+  alignas(256) long long kept;             // K
+  long long rounds;                        // resolve rounds
+  unsigned long long cand_total;           // candidate pairs over all shards
+  unsigned long long cand_worst;           // fullest shard
 };
+
+// candidate counters: one per shard, each alone in a 256-byte slot (returning
+// atomics on words that share a cache line serialise at the memory side)
+constexpr int kCandStride = 32;  // in unsigned long long
 
 __device__ __forceinline__ void nms_interval(float o, float e, float &lo, float &hi) {
   // margin 2^-21 (|o| + e): covers every rounding of the spec's prefilter
@@ -394,6 +401,9 @@ __device__ __forceinline__ void nms_scan_rows(uint2 rv, uint32_t rid, uint32_t s
       const uint32_t m = min(min(t0, t1), min(t2, t3));
       hit |= __any(m == 0u) ? (1u << u) : 0u;
     }
+#ifdef OBB_SCAN_NOSLOW
+    hit = 0;
+#endif
     while (hit) {  // some lane has a candidate in row ib+u
       const int u = __builtin_ctz(hit);
       hit &= hit - 1u;
@@ -413,12 +423,23 @@ __device__ __forceinline__ void nms_scan_rows(uint2 rv, uint32_t rid, uint32_t s
       }
       while (qn >= 64) {  // flush a full batch: one global atomic per 64 candidates
         qn -= 64;
+#ifdef OBB_SCAN_NOFLUSH
+        continue;
+#endif
         __builtin_amdgcn_wave_barrier();
         unsigned long long base = 0;
+#ifdef OBB_SCAN_NOATOMIC
+        base = (unsigned long long)(qn & 1023);
+#else
         if (lane == 0) base = atomicAdd(ccnt, 64ull);
         base = __shfl(base, 0);
+#endif
         const uint2 e = q[qn + lane];
+#ifndef OBB_SCAN_NOSTORE
         if (base + lane < segcap) cand[base + lane] = e;
+#else
+        if (e.x == 0xFFFFFFF0u) cand[base + lane] = e;
+#endif
       }
     }
   }
@@ -432,7 +453,8 @@ __global__ __launch_bounds__(512) void nms_scan_kernel(const uint2 *__restrict__
                                                        unsigned int tp_capacity,
                                                        uint2 *__restrict__ cands,
                                                        unsigned long long segcap,
-                                                       NmsCounters *__restrict__ ctr) {
+                                                       NmsCounters *__restrict__ ctr,
+                                                       unsigned long long *__restrict__ ccnts) {
   __shared__ uint2 queue[kNmsWaves][kNmsQueue];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -441,7 +463,7 @@ __global__ __launch_bounds__(512) void nms_scan_kernel(const uint2 *__restrict__
   const uint32_t gw = blockIdx.x * kNmsWaves + wave;       // global wave id
   const int shard = (int)(gw & (kShards - 1));
   uint2 *cand = cands + (size_t)shard * segcap;
-  unsigned long long *ccnt = &ctr->cand[shard];
+  unsigned long long *ccnt = ccnts + (size_t)shard * kCandStride;
   const unsigned int nheavy = ctr->heavy_pairs, nlight = ctr->tile_pairs;
   const unsigned int ntp = nheavy + nlight;
   for (unsigned int k = blockIdx.x; k < ntp; k += gridDim.x) {
@@ -505,11 +527,12 @@ __global__ __launch_bounds__(256) void nms_clip_kernel(const uint2 *__restrict__
                                                        uint2 *__restrict__ edges,
                                                        unsigned long long cap,
                                                        NmsCounters *__restrict__ ctr,
+                                                       const unsigned long long *__restrict__ ccnts,
                                                        int *__restrict__ cnt) {
   const int lane = threadIdx.x & 63;
   const int shard = blockIdx.y;
   const uint2 *cand = cands + (size_t)shard * segcap;
-  unsigned long long total = ctr->cand[shard];
+  unsigned long long total = ccnts[(size_t)shard * kCandStride];
   if (total > segcap) total = segcap;  // overflow is reported by the host
   // whole waves iterate together so that the ballot below sees all 64 lanes
   const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
@@ -652,7 +675,8 @@ __global__ __launch_bounds__(1024) void nms_write_kernel(const uint8_t *__restri
                                                          const int *__restrict__ cnt, int64_t n,
                                                          const int *__restrict__ blockcnt,
                                                          int64_t *__restrict__ keep,
-                                                         NmsCounters *__restrict__ ctr) {
+                                                         NmsCounters *__restrict__ ctr,
+                                                         const unsigned long long *__restrict__ ccnts) {
   __shared__ int wsum[16];
   __shared__ long long sbase;
   __shared__ long long red[16];
@@ -682,6 +706,15 @@ __global__ __launch_bounds__(1024) void nms_write_kernel(const uint8_t *__restri
   }
   if (f) keep[sbase + off + __popcll(mk & ((1ull << lane) - 1ull))] = i;
   if (blockIdx.x == gridDim.x - 1 && tid == 0) ctr->kept = sbase + tot;
+  if (blockIdx.x == 0 && wave == 0) {  // fold the padded shard counters for the host
+    unsigned long long v = ccnts[(size_t)lane * kCandStride], mx = v;
+    for (int o = 32; o > 0; o >>= 1) {
+      v += __shfl_xor(v, o);
+      const unsigned long long t = __shfl_xor(mx, o);
+      mx = t > mx ? t : mx;
+    }
+    if (lane == 0) { ctr->cand_total = v; ctr->cand_worst = mx; }
+  }
 }
 
 // ---- optional per-phase timing (HIP events on the caller's stream) ----------------
@@ -698,7 +731,7 @@ static thread_local NmsProfile g_prof;
 
 // ---- workspace layout ------------------------------------------------------------
 struct NmsLayout {
-  size_t rec, iv, part, qb, ckey, sid, qs, tbox, tpairs, zero_begin, state, cnt, ctr, hist,
+  size_t rec, iv, part, qb, ckey, sid, qs, tbox, tpairs, zero_begin, state, cnt, ctr, ccnts, hist,
       zero_end, blockcnt, cands, edges, total;
   unsigned long long cap;
   int64_t ntiles;
@@ -728,6 +761,7 @@ static int nms_layout(int64_t n, int64_t edge_capacity, NmsLayout &L) {
   L.state = take(nn);
   L.cnt = take(nn * 4);
   L.ctr = take(sizeof(NmsCounters));
+  L.ccnts = take((size_t)kShards * kCandStride * sizeof(unsigned long long));
   L.hist = take(kCells * 4);
   L.zero_end = off;
   L.blockcnt = take(((nn + 1023) / 1024) * 4);
@@ -794,6 +828,7 @@ extern "C" int obb_nms_grouped_f32(const float *dets_dev, int64_t n, int kind, f
   uint8_t *state = reinterpret_cast<uint8_t *>(ws + L.state);
   int *cnt = reinterpret_cast<int *>(ws + L.cnt);
   NmsCounters *ctr = reinterpret_cast<NmsCounters *>(ws + L.ctr);
+  unsigned long long *ccnts = reinterpret_cast<unsigned long long *>(ws + L.ccnts);
   int *blockcnt = reinterpret_cast<int *>(ws + L.blockcnt);
   uint2 *cands = reinterpret_cast<uint2 *>(ws + L.cands);
   uint2 *edges = cands + cap;
@@ -845,12 +880,12 @@ extern "C" int obb_nms_grouped_f32(const float *dets_dev, int64_t n, int kind, f
     long long pb = kPairBlocks;
     if (const char *e = getenv("OBB_NMS_SCAN_BLOCKS")) pb = atoll(e) > 0 ? atoll(e) : pb;  // tuning knob
     const unsigned gb = (unsigned)(maxpairs < pb ? maxpairs : pb);
-    hipLaunchKernelGGL(nms_scan_kernel, dim3(gb), dim3(64 * kNmsWaves), 0, st, qs, sid, tpairs, tp_capacity, cands, segcap, ctr);
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(gb), dim3(64 * kNmsWaves), 0, st, qs, sid, tpairs, tp_capacity, cands, segcap, ctr, ccnts);
     OBB_LAUNCH_CHECK();
   }
   // phase 4: clip (narrow phase)
   OBB_PHASE(4);
-  hipLaunchKernelGGL(nms_clip_kernel, dim3(kClipBlocksPerShard, kShards), dim3(256), 0, st, cands, segcap, rec, edges, cap, ctr, cnt);
+  hipLaunchKernelGGL(nms_clip_kernel, dim3(kClipBlocksPerShard, kShards), dim3(256), 0, st, cands, segcap, rec, edges, cap, ctr, ccnts, cnt);
   OBB_LAUNCH_CHECK();
   // phase 5: resolve
   OBB_PHASE(5);
@@ -861,7 +896,7 @@ extern "C" int obb_nms_grouped_f32(const float *dets_dev, int64_t n, int kind, f
   const unsigned cblocks = (unsigned)((n + 1023) / 1024);
   hipLaunchKernelGGL(nms_count_kernel, dim3(cblocks), dim3(1024), 0, st, state, cnt, n, blockcnt);
   OBB_LAUNCH_CHECK();
-  hipLaunchKernelGGL(nms_write_kernel, dim3(cblocks), dim3(1024), 0, st, state, cnt, n, blockcnt, keep_dev, ctr);
+  hipLaunchKernelGGL(nms_write_kernel, dim3(cblocks), dim3(1024), 0, st, state, cnt, n, blockcnt, keep_dev, ctr, ccnts);
   OBB_LAUNCH_CHECK();
   OBB_PHASE(7);
 #undef OBB_PHASE
@@ -875,11 +910,8 @@ extern "C" int obb_nms_grouped_f32(const float *dets_dev, int64_t n, int kind, f
     }
     prof.have = true;
   }
-  unsigned long long ncand = 0, worst = 0;
-  for (int k = 0; k < kShards; ++k) {
-    ncand += h.cand[k];
-    if (h.cand[k] > worst) worst = h.cand[k];
-  }
+  static_assert(kShards == 64, "the fold in nms_write_kernel uses one wave");
+  const unsigned long long ncand = h.cand_total, worst = h.cand_worst;
   if (info_host) {
     info_host[0] = h.kept;
     info_host[1] = (int64_t)h.edges;

@@ -472,3 +472,66 @@ def test_rotated_extractor_forward():
         if m.any():
             ref = oracle.rroi_align_forward(feats[i], rois[m], 7, 1.0 / s, 2)
             assert np.abs(out[m] - ref).max() <= IOU_TOL
+
+
+def test_rnms_non_finite_boxes_are_inert():
+    """NaN / inf boxes never suppress and are never suppressed (their overlap is 0 or
+    NaN on the spec path); the GPU isolates them before the scan."""
+    from aidet_amd import rnms
+    d = oracle.synth_boxes(4000, 300, 77)
+    bad = [5, 100, 101, 2500, 3999]
+    d[5, 0] = np.nan
+    d[100, 2] = np.inf
+    d[101, 1] = -np.inf
+    d[2500, 4] = np.nan
+    d[3999, 3] = np.nan
+    _, inds = rnms(t(d), 0.3)
+    ref = oracle.rnms(d, 0.3)
+    got = inds.cpu().numpy()
+    assert np.array_equal(got, ref)
+    assert set(bad) <= set(got.tolist())
+    # all boxes non-finite
+    z = np.full((10, 6), np.nan, np.float32)
+    z[:, 5] = np.linspace(0, 1, 10)
+    _, inds = rnms(t(z), 0.5)
+    assert inds.cpu().tolist() == list(range(10))
+
+
+def test_rnms_degenerate_and_huge_coordinates():
+    from aidet_amd import rnms
+    rng = np.random.default_rng(8)
+    d = oracle.synth_boxes(3000, 200, 9)
+    d[::7, 2] = 0.0                       # zero width
+    d[::11, 3] = 0.0                      # zero height
+    d[::13, :2] += 1.0e6                  # far away cluster
+    d[::17, 4] += 100 * np.pi             # many turns
+    d[1500:1600] = d[1400:1500]           # exact duplicates (different scores)
+    d[1500:1600, 5] = rng.permutation(100) / 1e4
+    _, inds = rnms(t(d), 0.5)
+    assert np.array_equal(inds.cpu().numpy(), oracle.rnms(d, 0.5))
+
+
+def test_rnms_one_million_boxes_properties():
+    """Size-independent checks at n = 1e6 (the O(n^2) oracle is out of reach):
+    idempotence, agreement of the grouped entry point, and an exact oracle check on
+    a spatial window (NMS is local: a window plus a margin decides its interior)."""
+    from aidet_amd import rnms
+    n, canvas = 1000000, 60000.0
+    d = oracle.synth_boxes(n, canvas, 12)
+    _, inds = rnms(t(d), 0.5)
+    keep = inds.cpu().numpy()
+    assert np.all(np.diff(keep) > 0) and 0.9 * n < len(keep) < n
+    _, again = rnms(t(d[keep]), 0.5)
+    assert again.numel() == len(keep)
+    _, g = rnms(t(d), 0.5, groups=np.zeros(n, np.int32))
+    assert np.array_equal(g.cpu().numpy(), keep)
+    # exact check in a window: every box within 400 px of a window box is included, chains
+    # longer than the 2000 px margin do not occur at this density
+    cx, cy = d[:, 0], d[:, 1]
+    sel = np.nonzero((cx > 28000) & (cx < 34000) & (cy > 28000) & (cy < 34000))[0]
+    inner = (cx[sel] > 30000) & (cx[sel] < 32000) & (cy[sel] > 30000) & (cy[sel] < 32000)
+    ref = sel[oracle.rnms(d[sel], 0.5)]
+    kept_mask = np.zeros(n, bool); kept_mask[keep] = True
+    ref_mask = np.zeros(n, bool); ref_mask[ref] = True
+    assert np.array_equal(kept_mask[sel[inner]], ref_mask[sel[inner]])
+    assert inner.sum() > 500
