@@ -186,7 +186,8 @@ __global__ __launch_bounds__(256) void nms_quant_kernel(const float4 *__restrict
                                                         const uint4 *__restrict__ part, int nparts,
                                                         uint2 *__restrict__ qb,
                                                         uint32_t *__restrict__ ckey,
-                                                        uint32_t *__restrict__ hist, int cell_hbits) {
+                                                        uint32_t *__restrict__ hist, int cell_hbits,
+                                                        float *__restrict__ cellpx) {
   __shared__ uint4 wred[4];
   __shared__ float sb[4];
   uint4 a = make_uint4(0u, 0u, 0u, 0u);
@@ -212,6 +213,11 @@ __global__ __launch_bounds__(256) void nms_quant_kernel(const float4 *__restrict
     sb[0] = bx; sb[1] = by;
     sb[2] = rx > 0.0f ? (float)kQMax / rx : 0.0f;
     sb[3] = ry > 0.0f ? (float)kQMax / ry : 0.0f;
+    if (blockIdx.x == 0) {
+      // pixels per cell, rounded UP (used for an upper bound of AABB overlaps)
+      cellpx[0] = rx > 0.0f ? (rx / (float)kQMax) * 1.000001f : 0.0f;
+      cellpx[1] = ry > 0.0f ? (ry / (float)kQMax) * 1.000001f : 0.0f;
+    }
   }
   __syncthreads();
   const float bx = sb[0], by = sb[1], sx = sb[2], sy = sb[3];
@@ -289,13 +295,21 @@ __global__ __launch_bounds__(256) void nms_scatter_kernel(const uint32_t *__rest
 // one block = one tile of 256 spatial positions
 __global__ __launch_bounds__(256) void nms_permute_kernel(const uint2 *__restrict__ qb,
                                                           const uint32_t *__restrict__ sid,
+                                                          const QuadRec *__restrict__ rec,
                                                           int64_t n, uint2 *__restrict__ qs,
+                                                          float *__restrict__ as,
                                                           uint2 *__restrict__ tbox) {
   __shared__ uint4 wred[4];
   const int64_t s = (int64_t)blockIdx.x * kTile + threadIdx.x;
   uint2 o = make_uint2(kSentLo, kSentHi);
-  if (s < n) o = qb[sid[s]];
+  float ar = 0.0f;
+  if (s < n) {
+    const uint32_t id = sid[s];
+    o = qb[id];
+    ar = rec[id].area;
+  }
   qs[s] = o;
+  as[s] = ar;
   uint32_t xl = o.x & 0x7FFFu, yl = (o.x >> 16) & 0x7FFFu;
   uint32_t xh = o.y & 0x7FFFu, yh = (o.y >> 16) & 0x7FFFu;
   for (int k = 32; k > 0; k >>= 1) {
@@ -375,11 +389,43 @@ __global__ __launch_bounds__(256) void nms_cull_kernel(const uint2 *__restrict__
 // One wave: 64 rows of tile A (lane l holds row l; broadcast with v_readlane) x
 // 256 columns of tile B (4 per lane).  15 full-rate VALU + 2 v_readlane per row.
 // Rows with a candidate are only RECORDED in `hit` and pushed out of line.
+// Threshold-aware pruning of a candidate (never changes the result: a pair is
+// dropped only when its overlap provably stays below thr in the fp32 spec):
+//   * inter <= min(aA, aB)            =>  iou <= min/max
+//   * inter <= area(AABB_A n AABB_B)  =>  iou <= I/(aA + aB - I),  I = that area, bounded
+//     from above through the quantised intervals (cells shared + 1) * cell size
+// both with a 1e-6 relative margin (the spec's roundings are a few 2^-24).
+struct Prune {
+  float thr;       // <= 0: pruning off
+  float cpx, cpy;  // pixels per quantisation cell (rounded up)
+};
+
+// first (cheap) bound: iou <= min(area)/max(area)
+__device__ __forceinline__ bool prune_area(const Prune &pr, float ra, float ca) {
+  const float mn = min_sel(ra, ca), mx = max_sel(ra, ca);
+  return !(mn < (pr.thr * mx) * 0.999999f);
+}
+
+// second bound: inter <= area of the AABB overlap, bounded through the shared cells
+__device__ __forceinline__ bool prune_aabb(const Prune &pr, uint32_t rlo, uint32_t rhiG, float ra,
+                                           uint32_t clo, uint32_t chiG, float ca) {
+  // shared cells per axis: min(b.hi - a.lo, a.hi - b.lo, own widths) + 1
+  const uint32_t d1 = chiG - rlo, d2 = rhiG - clo;          // guard bits set (candidate)
+  const uint32_t wr = rhiG - rlo, wc = chiG - clo;
+  const int sx = (int)min(min(d1 & 0x7FFFu, d2 & 0x7FFFu), min(wr & 0x7FFFu, wc & 0x7FFFu)) + 1;
+  const int sy = (int)min(min((d1 >> 16) & 0x7FFFu, (d2 >> 16) & 0x7FFFu),
+                          min((wr >> 16) & 0x7FFFu, (wc >> 16) & 0x7FFFu)) + 1;
+  const float I = ((float)sx * pr.cpx) * ((float)sy * pr.cpy) * 1.000001f;   // >= true AABB overlap
+  // possible hit only if I / (ra + ca - I) >= thr  <=>  I (1 + thr) >= thr (ra + ca)
+  return I * (1.0f + pr.thr) >= (pr.thr * (ra + ca)) * 0.999999f;
+}
+
 template <bool DIAG>
-__device__ __forceinline__ void nms_scan_rows(uint2 rv, uint32_t rid, uint32_t sa0, uint32_t sb0,
-                                              const uint2 (&col)[4], const uint32_t (&cid)[4],
-                                              uint2 *q, int &qn, uint2 *__restrict__ cand,
-                                              unsigned long long segcap,
+__device__ __forceinline__ void nms_scan_rows(uint2 rv, uint32_t rid, float rarea, uint32_t sa0,
+                                              uint32_t sb0, const uint2 (&col)[4],
+                                              const uint32_t (&cid)[4], const float (&car)[4],
+                                              const Prune &pr, uint2 *q, int &qn,
+                                              uint2 *__restrict__ cand, unsigned long long segcap,
                                               unsigned long long *__restrict__ ccnt, int lane) {
   const uint64_t lt_mask = (1ull << lane) - 1ull;
   const uint32_t sbl = sb0 + lane * kNmsColsPerLane;
@@ -410,11 +456,16 @@ __device__ __forceinline__ void nms_scan_rows(uint2 rv, uint32_t rid, uint32_t s
       const uint32_t rlo = (uint32_t)__builtin_amdgcn_readlane((int)rv.x, ib + u);
       const uint32_t rhi = (uint32_t)__builtin_amdgcn_readlane((int)rv.y, ib + u);
       const uint32_t ida = (uint32_t)__builtin_amdgcn_readlane((int)rid, ib + u);
+      const float ra = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rarea), ib + u));
       const uint32_t sa = sa0 + ib + u;
 #pragma unroll
       for (int c = 0; c < kNmsColsPerLane; ++c) {
         bool cnd = qdisjoint(rlo, rhi, col[c].x, col[c].y) == 0u;
         if (DIAG) cnd = cnd && (sbl + c > sa);
+        if (pr.thr > 0.0f && __any(cnd)) {
+          cnd = cnd && prune_area(pr, ra, car[c]);
+          if (__any(cnd)) cnd = cnd && prune_aabb(pr, rlo, rhi, ra, col[c].x, col[c].y, car[c]);
+        }
         const uint64_t mk = __ballot(cnd);
         if (mk) {
           if (cnd) q[qn + __popcll(mk & lt_mask)] = make_uint2(ida, cid[c]);
@@ -448,6 +499,8 @@ __device__ __forceinline__ void nms_scan_rows(uint2 rv, uint32_t rid, uint32_t s
 // block k handles tile pairs k, k + gridDim.x, ... of the list [heavy ..., light ...];
 // wave w owns rows [32 w, 32 w + 32) of the row tile.
 __global__ __launch_bounds__(512) void nms_scan_kernel(const uint2 *__restrict__ qs,
+                                                       const float *__restrict__ as,
+                                                       const float *__restrict__ cellpx, float thr,
                                                        const uint32_t *__restrict__ sid,
                                                        const uint32_t *__restrict__ tpairs,
                                                        unsigned int tp_capacity,
@@ -466,6 +519,8 @@ __global__ __launch_bounds__(512) void nms_scan_kernel(const uint2 *__restrict__
   unsigned long long *ccnt = ccnts + (size_t)shard * kCandStride;
   const unsigned int nheavy = ctr->heavy_pairs, nlight = ctr->tile_pairs;
   const unsigned int ntp = nheavy + nlight;
+  Prune pr;
+  pr.thr = thr; pr.cpx = cellpx[0]; pr.cpy = cellpx[1];
   for (unsigned int k = blockIdx.x; k < ntp; k += gridDim.x) {
     const uint32_t tp = (k < nheavy) ? tpairs[k] : tpairs[tp_capacity - 1u - (k - nheavy)];
     const uint32_t A = tp >> 16, B = tp & 0xFFFFu;
@@ -475,9 +530,13 @@ __global__ __launch_bounds__(512) void nms_scan_kernel(const uint2 *__restrict__
     // lanes >= 32 mirror lanes < 32 (only rows 0..31 are ever broadcast)
     const uint2 rv = qs[sa0 + (lane & (kRowsPerWave - 1))];
     const uint32_t rid = sid[sa0 + (lane & (kRowsPerWave - 1))];
+    const float rarea = as[sa0 + (lane & (kRowsPerWave - 1))];
     uint2 col[4];
     uint32_t cid[4];
+    float car[4];
     {
+      const float4 ar = *reinterpret_cast<const float4 *>(as + sb0 + lane * kNmsColsPerLane);
+      car[0] = ar.x; car[1] = ar.y; car[2] = ar.z; car[3] = ar.w;
       const uint4 *cp = reinterpret_cast<const uint4 *>(qs + sb0 + lane * kNmsColsPerLane);
       const uint4 a = cp[0], b = cp[1];
       const uint4 c = *reinterpret_cast<const uint4 *>(sid + sb0 + lane * kNmsColsPerLane);
@@ -485,8 +544,8 @@ __global__ __launch_bounds__(512) void nms_scan_kernel(const uint2 *__restrict__
       col[2] = make_uint2(b.x, b.y); col[3] = make_uint2(b.z, b.w);
       cid[0] = c.x; cid[1] = c.y; cid[2] = c.z; cid[3] = c.w;
     }
-    if (A == B) nms_scan_rows<true>(rv, rid, sa0, sb0, col, cid, q, qn, cand, segcap, ccnt, lane);
-    else nms_scan_rows<false>(rv, rid, sa0, sb0, col, cid, q, qn, cand, segcap, ccnt, lane);
+    if (A == B) nms_scan_rows<true>(rv, rid, rarea, sa0, sb0, col, cid, car, pr, q, qn, cand, segcap, ccnt, lane);
+    else nms_scan_rows<false>(rv, rid, rarea, sa0, sb0, col, cid, car, pr, q, qn, cand, segcap, ccnt, lane);
   }
   if (qn > 0) {  // final partial flush, once per wave
     __builtin_amdgcn_wave_barrier();
@@ -525,13 +584,14 @@ __global__ __launch_bounds__(256) void nms_clip_kernel(const uint2 *__restrict__
                                                        unsigned long long segcap,
                                                        const QuadRec *__restrict__ rec,
                                                        uint2 *__restrict__ edges,
-                                                       unsigned long long cap,
                                                        NmsCounters *__restrict__ ctr,
-                                                       const unsigned long long *__restrict__ ccnts,
+                                                       unsigned long long *__restrict__ ccnts,
                                                        int *__restrict__ cnt) {
   const int lane = threadIdx.x & 63;
   const int shard = blockIdx.y;
   const uint2 *cand = cands + (size_t)shard * segcap;
+  uint2 *eseg = edges + (size_t)shard * segcap;                       // this shard's edge segment
+  unsigned long long *ecnt = ccnts + (size_t)(kShards + shard) * kCandStride;
   unsigned long long total = ccnts[(size_t)shard * kCandStride];
   if (total > segcap) total = segcap;  // overflow is reported by the host
   // whole waves iterate together so that the ballot below sees all 64 lanes
@@ -565,11 +625,11 @@ __global__ __launch_bounds__(256) void nms_clip_kernel(const uint2 *__restrict__
     if (mk) {
       const int leader = __ffsll((long long)mk) - 1;
       unsigned long long pos0 = 0;
-      if (lane == leader) pos0 = atomicAdd(&ctr->edges, (unsigned long long)__popcll(mk));
+      if (lane == leader) pos0 = atomicAdd(ecnt, (unsigned long long)__popcll(mk));
       pos0 = __shfl(pos0, leader);
       if (hit) {
         const unsigned long long pos = pos0 + __popcll(mk & ((1ull << lane) - 1ull));
-        if (pos < cap) edges[pos] = make_uint2(src, dst);
+        if (pos < segcap) eseg[pos] = make_uint2(src, dst);
         atomicAdd(&cnt[dst], 1);
       }
     }
@@ -589,18 +649,38 @@ __device__ __forceinline__ int ld_cnt(int *p) {
 // place each round (reads of a 1024-edge chunk complete before its writes, and
 // the write cursor never passes the chunk being read).
 __global__ __launch_bounds__(1024) void nms_resolve_kernel(uint2 *__restrict__ edges,
-                                                           unsigned long long cap,
+                                                           unsigned long long segcap,
                                                            uint8_t *__restrict__ state,
                                                            int *__restrict__ cnt,
-                                                           NmsCounters *__restrict__ ctr) {
+                                                           NmsCounters *__restrict__ ctr,
+                                                           const unsigned long long *__restrict__ ccnts) {
   __shared__ int wsum[16];
+  __shared__ long long pre[kShards + 1];   // virtual start of every edge segment
+  __shared__ int overflow;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const unsigned long long found = ctr->edges;
-  // an overflowed edge list is incomplete (cnt[] counts edges that were not
-  // stored): nothing to resolve, the host reports OBB_EWORKSPACE
-  long long live = found <= cap ? (long long)found : 0;
+  if (wave == 0) {  // 64 lanes = 64 shards: coalesced-ish loads + one wave scan
+    const unsigned long long c = ccnts[(size_t)(kShards + lane) * kCandStride];
+    const unsigned long long cc = ccnts[(size_t)lane * kCandStride];
+    long long inc = (long long)c;
+    for (int o = 1; o < 64; o <<= 1) {
+      const long long t = __shfl_up(inc, o);
+      if (lane >= o) inc += t;
+    }
+    pre[lane] = inc - (long long)c;
+    const uint64_t ovm = __ballot((c > segcap) || (cc > segcap));
+    if (lane == 63) {
+      pre[kShards] = inc;
+      overflow = ovm != 0;
+      ctr->edges = (unsigned long long)inc;
+    }
+  }
+  __syncthreads();
+  // an overflowed candidate / edge list is incomplete (cnt[] counts edges that were
+  // not stored): nothing to resolve, the host reports OBB_EWORKSPACE
+  long long live = overflow ? 0 : pre[kShards];
   long long rounds = 0;
   int stalled = 0;
+  bool segmented = true;   // round 1 reads the 64 segments, later rounds the compacted front
   while (live > 0) {
     long long w = 0;
     for (long long base = 0; base < live; base += 1024) {
@@ -608,7 +688,17 @@ __global__ __launch_bounds__(1024) void nms_resolve_kernel(uint2 *__restrict__ e
       bool keep = false;
       uint2 ed = make_uint2(0u, 0u);
       if (e < live) {
-        ed = edges[e];
+        long long phys = e;
+        if (segmented) {  // virtual index -> (segment, offset); physical >= virtual, so the
+                          // in-place compaction below never overwrites an unread edge
+          int lo = 0, hi = kShards - 1;
+          while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (pre[mid] <= e) lo = mid; else hi = mid - 1;
+          }
+          phys = (long long)lo * (long long)segcap + (e - pre[lo]);
+        }
+        ed = edges[phys];
         if (ld_state(state + ed.y) == kUndecided) {
           uint8_t si = ld_state(state + ed.x);
           if (si == kUndecided && ld_cnt(cnt + ed.x) == 0) si = kKept;
@@ -640,6 +730,7 @@ __global__ __launch_bounds__(1024) void nms_resolve_kernel(uint2 *__restrict__ e
     // mean corrupted state -- stop instead of spinning
     stalled = (w == live) ? stalled + 1 : 0;
     live = w;
+    segmented = false;
     ++rounds;
     __threadfence();
     __syncthreads();
@@ -708,6 +799,8 @@ __global__ __launch_bounds__(1024) void nms_write_kernel(const uint8_t *__restri
   if (blockIdx.x == gridDim.x - 1 && tid == 0) ctr->kept = sbase + tot;
   if (blockIdx.x == 0 && wave == 0) {  // fold the padded shard counters for the host
     unsigned long long v = ccnts[(size_t)lane * kCandStride], mx = v;
+    const unsigned long long ev = ccnts[(size_t)(kShards + lane) * kCandStride];
+    mx = ev > mx ? ev : mx;   // fullest segment of either kind
     for (int o = 32; o > 0; o >>= 1) {
       v += __shfl_xor(v, o);
       const unsigned long long t = __shfl_xor(mx, o);
@@ -731,7 +824,7 @@ static thread_local NmsProfile g_prof;
 
 // ---- workspace layout ------------------------------------------------------------
 struct NmsLayout {
-  size_t rec, iv, part, qb, ckey, sid, qs, tbox, tpairs, zero_begin, state, cnt, ctr, ccnts, hist,
+  size_t rec, iv, part, qb, ckey, sid, qs, as, cellpx, tbox, tpairs, zero_begin, state, cnt, ctr, ccnts, hist,
       zero_end, blockcnt, cands, edges, total;
   unsigned long long cap;
   int64_t ntiles;
@@ -755,13 +848,15 @@ static int nms_layout(int64_t n, int64_t edge_capacity, NmsLayout &L) {
   L.ckey = take(nn * 4);
   L.sid = take((nt * kTile) * 4);
   L.qs = take((nt * kTile + kRowChunk) * sizeof(uint2));
+  L.as = take((nt * kTile) * sizeof(float));
+  L.cellpx = take(2 * sizeof(float));
   L.tbox = take(nt * sizeof(uint2));
   L.tpairs = take((nt * (nt + 1) / 2) * 4);
   L.zero_begin = off;
   L.state = take(nn);
   L.cnt = take(nn * 4);
   L.ctr = take(sizeof(NmsCounters));
-  L.ccnts = take((size_t)kShards * kCandStride * sizeof(unsigned long long));
+  L.ccnts = take((size_t)2 * kShards * kCandStride * sizeof(unsigned long long));  // candidates | edges
   L.hist = take(kCells * 4);
   L.zero_end = off;
   L.blockcnt = take(((nn + 1023) / 1024) * 4);
@@ -823,6 +918,8 @@ extern "C" int obb_nms_grouped_f32(const float *dets_dev, int64_t n, int kind, f
   uint32_t *hist = reinterpret_cast<uint32_t *>(ws + L.hist);
   uint32_t *sid = reinterpret_cast<uint32_t *>(ws + L.sid);
   uint2 *qs = reinterpret_cast<uint2 *>(ws + L.qs);
+  float *as = reinterpret_cast<float *>(ws + L.as);
+  float *cellpx = reinterpret_cast<float *>(ws + L.cellpx);
   uint2 *tbox = reinterpret_cast<uint2 *>(ws + L.tbox);
   uint32_t *tpairs = reinterpret_cast<uint32_t *>(ws + L.tpairs);
   uint8_t *state = reinterpret_cast<uint8_t *>(ws + L.state);
@@ -857,7 +954,7 @@ extern "C" int obb_nms_grouped_f32(const float *dets_dev, int64_t n, int kind, f
   // cells ~ n/16 .. n/4, a power of 4 in [4096, 65536]
   int hbits = 6;
   while (hbits < 8 && (1ll << (2 * hbits)) * 16 < n) ++hbits;
-  hipLaunchKernelGGL(nms_quant_kernel, dim3(pblocks), dim3(256), 0, st, iv, n, part, (int)pblocks, qb, ckey, hist, hbits);
+  hipLaunchKernelGGL(nms_quant_kernel, dim3(pblocks), dim3(256), 0, st, iv, n, part, (int)pblocks, qb, ckey, hist, hbits, cellpx);
   OBB_LAUNCH_CHECK();
   // phase 1: spatial sort
   OBB_PHASE(1);
@@ -869,7 +966,7 @@ extern "C" int obb_nms_grouped_f32(const float *dets_dev, int64_t n, int kind, f
   OBB_LAUNCH_CHECK();
   // phase 2: permute + tile boxes + tile-pair culling
   OBB_PHASE(2);
-  hipLaunchKernelGGL(nms_permute_kernel, dim3((unsigned)nt), dim3(kTile), 0, st, qb, sid, n, qs, tbox);
+  hipLaunchKernelGGL(nms_permute_kernel, dim3((unsigned)nt), dim3(kTile), 0, st, qb, sid, rec, n, qs, as, tbox);
   OBB_LAUNCH_CHECK();
   hipLaunchKernelGGL(nms_cull_kernel, dim3((unsigned)nt, (unsigned)((nt + kCullChunk - 1) / kCullChunk)), dim3(256), 0, st, tbox, nt, tpairs, tp_capacity, ctr);
   OBB_LAUNCH_CHECK();
@@ -880,16 +977,18 @@ extern "C" int obb_nms_grouped_f32(const float *dets_dev, int64_t n, int kind, f
     long long pb = kPairBlocks;
     if (const char *e = getenv("OBB_NMS_SCAN_BLOCKS")) pb = atoll(e) > 0 ? atoll(e) : pb;  // tuning knob
     const unsigned gb = (unsigned)(maxpairs < pb ? maxpairs : pb);
-    hipLaunchKernelGGL(nms_scan_kernel, dim3(gb), dim3(64 * kNmsWaves), 0, st, qs, sid, tpairs, tp_capacity, cands, segcap, ctr, ccnts);
+    // threshold-aware pruning needs ONE threshold: off when per-box thresholds are given
+    const float prune_thr = thr_dev ? 0.0f : iou_thr;
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(gb), dim3(64 * kNmsWaves), 0, st, qs, as, cellpx, prune_thr, sid, tpairs, tp_capacity, cands, segcap, ctr, ccnts);
     OBB_LAUNCH_CHECK();
   }
   // phase 4: clip (narrow phase)
   OBB_PHASE(4);
-  hipLaunchKernelGGL(nms_clip_kernel, dim3(kClipBlocksPerShard, kShards), dim3(256), 0, st, cands, segcap, rec, edges, cap, ctr, ccnts, cnt);
+  hipLaunchKernelGGL(nms_clip_kernel, dim3(kClipBlocksPerShard, kShards), dim3(256), 0, st, cands, segcap, rec, edges, ctr, ccnts, cnt);
   OBB_LAUNCH_CHECK();
   // phase 5: resolve
   OBB_PHASE(5);
-  hipLaunchKernelGGL(nms_resolve_kernel, dim3(1), dim3(1024), 0, st, edges, cap, state, cnt, ctr);
+  hipLaunchKernelGGL(nms_resolve_kernel, dim3(1), dim3(1024), 0, st, edges, segcap, state, cnt, ctr, ccnts);
   OBB_LAUNCH_CHECK();
   // phase 6: compaction
   OBB_PHASE(6);
@@ -918,11 +1017,10 @@ extern "C" int obb_nms_grouped_f32(const float *dets_dev, int64_t n, int kind, f
     info_host[2] = h.rounds;
     info_host[3] = (int64_t)ncand;
   }
-  if (worst > segcap || h.edges > cap) {
-    // capacity that fits every shard (and the edge list) on a retry, with 25 % slack:
-    // the tile-pair -> shard assignment varies slightly from run to run
+  if (worst > segcap) {
+    // capacity that fits the fullest candidate / edge segment on a retry, with 25 %
+    // slack: the tile-pair -> shard assignment varies slightly from run to run
     unsigned long long need = worst * kShards;
-    if (h.edges > need) need = h.edges;
     need += need / 4 + 1024;
     if (info_host) { info_host[0] = 0; info_host[3] = (int64_t)need; }
     return set_err(OBB_EWORKSPACE, "obb_nms_f32: %llu candidate pairs / %llu overlap edges exceed the pair capacity %llu; retry with edge_capacity >= %llu",
