@@ -654,7 +654,6 @@ __global__ __launch_bounds__(1024) void nms_resolve_kernel(uint2 *__restrict__ e
                                                            int *__restrict__ cnt,
                                                            NmsCounters *__restrict__ ctr,
                                                            const unsigned long long *__restrict__ ccnts) {
-  __shared__ int wsum[16];
   __shared__ long long pre[kShards + 1];   // virtual start of every edge segment
   __shared__ int overflow;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -681,48 +680,83 @@ __global__ __launch_bounds__(1024) void nms_resolve_kernel(uint2 *__restrict__ e
   long long rounds = 0;
   int stalled = 0;
   bool segmented = true;   // round 1 reads the 64 segments, later rounds the compacted front
+  constexpr int kPer = 4;  // edges per thread and chunk: their dependent loads overlap
+  __shared__ int wsum4[kPer][16];
   while (live > 0) {
     long long w = 0;
-    for (long long base = 0; base < live; base += 1024) {
-      const long long e = base + tid;
-      bool keep = false;
-      uint2 ed = make_uint2(0u, 0u);
-      if (e < live) {
-        long long phys = e;
-        if (segmented) {  // virtual index -> (segment, offset); physical >= virtual, so the
-                          // in-place compaction below never overwrites an unread edge
-          int lo = 0, hi = kShards - 1;
-          while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (pre[mid] <= e) lo = mid; else hi = mid - 1;
-          }
-          phys = (long long)lo * (long long)segcap + (e - pre[lo]);
-        }
-        ed = edges[phys];
-        if (ld_state(state + ed.y) == kUndecided) {
-          uint8_t si = ld_state(state + ed.x);
-          if (si == kUndecided && ld_cnt(cnt + ed.x) == 0) si = kKept;
-          if (si == kKept) {
-            state[ed.y] = kSuppressed;
-          } else if (si == kSuppressed) {
-            if (atomicSub(&cnt[ed.y], 1) == 1) state[ed.y] = kKept;
-          } else {
-            keep = true;
-          }
-        }
-      }
-      const uint64_t mk = __ballot(keep);
-      if (lane == 0) wsum[wave] = __popcll(mk);
-      __syncthreads();
-      int off = 0, tot = 0;
+    for (long long base = 0; base < live; base += 1024 * kPer) {
+      uint2 ed[kPer];
+      bool have[kPer], keep[kPer];
+      uint8_t sd[kPer], ss[kPer];
+      int cs[kPer];
+      // 1: edges (independent loads)
 #pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        const int v = wsum[k];
-        off += (k < wave) ? v : 0;
-        tot += v;
+      for (int k = 0; k < kPer; ++k) {
+        const long long e = base + (long long)k * 1024 + tid;
+        have[k] = e < live;
+        keep[k] = false;
+        ed[k] = make_uint2(0u, 0u);
+        if (have[k]) {
+          long long phys = e;
+          if (segmented) {  // virtual index -> (segment, offset); physical >= virtual, so the
+                            // in-place compaction below never overwrites an unread edge
+            int lo = 0, hi = kShards - 1;
+            while (lo < hi) {
+              const int mid = (lo + hi + 1) >> 1;
+              if (pre[mid] <= e) lo = mid; else hi = mid - 1;
+            }
+            phys = (long long)lo * (long long)segcap + (e - pre[lo]);
+          }
+          ed[k] = edges[phys];
+        }
       }
-      if (keep) edges[w + off + __popcll(mk & ((1ull << lane) - 1ull))] = ed;
-      w += tot;
+      // 2: both states and the source's count, speculatively (independent loads)
+#pragma unroll
+      for (int k = 0; k < kPer; ++k) {
+        sd[k] = kKept; ss[k] = kKept; cs[k] = 0;
+        if (have[k]) {
+          sd[k] = ld_state(state + ed[k].y);
+          ss[k] = ld_state(state + ed[k].x);
+          cs[k] = ld_cnt(cnt + ed[k].x);
+        }
+      }
+      // 3: decide
+#pragma unroll
+      for (int k = 0; k < kPer; ++k) {
+        if (have[k] && sd[k] == kUndecided) {
+          uint8_t si = ss[k];
+          if (si == kUndecided && cs[k] == 0) si = kKept;
+          if (si == kKept) {
+            state[ed[k].y] = kSuppressed;
+          } else if (si == kSuppressed) {
+            if (atomicSub(&cnt[ed[k].y], 1) == 1) state[ed[k].y] = kKept;
+          } else {
+            keep[k] = true;
+          }
+        }
+      }
+      // 4: compact the survivors to the front (any order is fine)
+      uint64_t mk[kPer];
+#pragma unroll
+      for (int k = 0; k < kPer; ++k) {
+        mk[k] = __ballot(keep[k]);
+        if (lane == 0) wsum4[k][wave] = __popcll(mk[k]);
+      }
+      __syncthreads();
+      int run = 0;
+#pragma unroll
+      for (int k = 0; k < kPer; ++k) {
+        int off = 0, tot = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int v = wsum4[k][j];
+          off += (j < wave) ? v : 0;
+          tot += v;
+        }
+        if (keep[k]) edges[w + run + off + __popcll(mk[k] & ((1ull << lane) - 1ull))] = ed[k];
+        run += tot;
+      }
+      w += run;
       __syncthreads();
     }
     // every round retires at least the live edge whose source precedes all other
@@ -732,7 +766,9 @@ __global__ __launch_bounds__(1024) void nms_resolve_kernel(uint2 *__restrict__ e
     live = w;
     segmented = false;
     ++rounds;
-    __threadfence();
+    // one workgroup = one CU: the barrier (workgroup-scope release/acquire, stores
+    // drained to L2) is all the ordering the agent-scope loads above need.  A
+    // device-scope __threadfence() by 1024 threads costs ~10 us per round here.
     __syncthreads();
     if (stalled >= 2) break;
   }

@@ -12,11 +12,41 @@ is returned in the caller's container type and device, as the reference does
 for ``device_id`` (nms_wrapper.py:41-43).
 """
 import ctypes
+import threading
 
 import numpy as np
 import torch
 
 from . import _lib
+
+
+# Workspace cache: the call is synchronous on its stream (it returns the keep count),
+# so one buffer per (thread, device, stream) can be reused by the next call there.
+# (ctypes releases the GIL during the call, hence per thread.)
+_tls = threading.local()
+_ws_bytes = {}
+
+
+def _workspace(L, dev, stream, n, kind, capacity):
+    key = (n, kind, capacity)
+    nbytes = _ws_bytes.get(key)
+    if nbytes is None:
+        nbytes = L.obb_nms_workspace_bytes(n, kind, capacity)
+        if nbytes == 0:
+            raise _lib.ObbOpsError('obb_nms_workspace_bytes failed: %s' %
+                                   L.obb_last_error().decode())
+        if len(_ws_bytes) > 4096:
+            _ws_bytes.clear()
+        _ws_bytes[key] = nbytes
+    cache = getattr(_tls, 'ws', None)
+    if cache is None:
+        cache = _tls.ws = {}
+    ckey = (dev.index, stream)
+    ws = cache.get(ckey)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        cache[ckey] = ws
+    return ws, nbytes
 
 
 def _run_nms(dets_dev, kind, iou_thr, groups=None, thrs=None):
@@ -30,7 +60,6 @@ def _run_nms(dets_dev, kind, iou_thr, groups=None, thrs=None):
     L = _lib.lib()
     keep = torch.empty(n, dtype=torch.int64, device=dev)
     info = (ctypes.c_int64 * 4)()
-    capacity = 0  # library default
     gptr = tptr = ctypes.c_void_p(0)
     if groups is not None:
         groups = groups.detach().to(device=dev, dtype=torch.int32).contiguous()
@@ -40,21 +69,26 @@ def _run_nms(dets_dev, kind, iou_thr, groups=None, thrs=None):
         thrs = thrs.detach().to(device=dev, dtype=torch.float32).contiguous()
         assert thrs.numel() == n
         tptr = ctypes.c_void_p(thrs.data_ptr())
-    with torch.cuda.device(dev):
+    same_dev = torch.cuda.current_device() == dev.index
+    if not same_dev:
+        prev = torch.cuda.current_device()
+        torch.cuda.set_device(dev)
+    try:
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        capacity = 0  # library default
         for _ in range(3):
-            nbytes = L.obb_nms_workspace_bytes(n, kind, capacity)
-            if nbytes == 0:
-                raise _lib.ObbOpsError('obb_nms_workspace_bytes failed: %s' %
-                                       L.obb_last_error().decode())
-            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            ws, nbytes = _workspace(L, dev, stream, n, kind, capacity)
             rc = L.obb_nms_grouped_f32(ctypes.c_void_p(dets_dev.data_ptr()), n, kind,
                                        ctypes.c_float(iou_thr), gptr, tptr,
                                        ctypes.c_void_p(keep.data_ptr()), info,
                                        ctypes.c_void_p(ws.data_ptr()), nbytes,
-                                       _lib.stream_ptr(dev))
+                                       ctypes.c_void_p(stream))
             if rc != _lib.OBB_EWORKSPACE:
                 break
             capacity = int(info[3])  # a pair capacity the library says suffices
+    finally:
+        if not same_dev:
+            torch.cuda.set_device(prev)
     _lib.check(rc)
     return keep[:int(info[0])], (int(info[1]), int(info[2]), int(info[3]))
 
