@@ -59,7 +59,8 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     dist = None
-    if world > 1:
+    # OBB_BENCH_FORCE_DIST=1 exercises the collective path with a single rank
+    if world > 1 or os.environ.get('OBB_BENCH_FORCE_DIST') == '1':
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
@@ -111,9 +112,9 @@ def main():
         L.obb_nms_profile_last(buf)
         phases += np.frombuffer(buf, dtype=np.float32)
     torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0   # per rank; the MAX over ranks is taken below
     if dist is not None:
         dist.barrier()
-    elapsed = time.perf_counter() - t0
     L.obb_nms_profile_enable(0)
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
