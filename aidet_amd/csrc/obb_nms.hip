@@ -447,9 +447,6 @@ __device__ __forceinline__ void nms_scan_rows(uint2 rv, uint32_t rid, float rare
       const uint32_t m = min(min(t0, t1), min(t2, t3));
       hit |= __any(m == 0u) ? (1u << u) : 0u;
     }
-#ifdef OBB_SCAN_NOSLOW
-    hit = 0;
-#endif
     while (hit) {  // some lane has a candidate in row ib+u
       const int u = __builtin_ctz(hit);
       hit &= hit - 1u;
@@ -474,23 +471,12 @@ __device__ __forceinline__ void nms_scan_rows(uint2 rv, uint32_t rid, float rare
       }
       while (qn >= 64) {  // flush a full batch: one global atomic per 64 candidates
         qn -= 64;
-#ifdef OBB_SCAN_NOFLUSH
-        continue;
-#endif
         __builtin_amdgcn_wave_barrier();
         unsigned long long base = 0;
-#ifdef OBB_SCAN_NOATOMIC
-        base = (unsigned long long)(qn & 1023);
-#else
         if (lane == 0) base = atomicAdd(ccnt, 64ull);
         base = __shfl(base, 0);
-#endif
         const uint2 e = q[qn + lane];
-#ifndef OBB_SCAN_NOSTORE
         if (base + lane < segcap) cand[base + lane] = e;
-#else
-        if (e.x == 0xFFFFFFF0u) cand[base + lane] = e;
-#endif
       }
     }
   }
