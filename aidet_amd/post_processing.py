@@ -143,3 +143,47 @@ def thetaobb_nms_by_bbox_nms(multi_bboxes, multi_scores, bbox_cls_inds, bbox_kee
         bboxes = multi_bboxes.new_zeros((0, out_dim_reg + 1))
         labels = multi_bboxes.new_zeros((0, ), dtype=torch.long)
     return bboxes, labels
+
+
+def get_det_rbboxes(rois, cls_score, rbbox_pred, img_shape, scale_factor, rescale=False, cfg=None,
+                    target_means=(0., 0., 0., 0., 0.), target_stds=(0.1, 0.1, 0.2, 0.2, 0.1),
+                    bbox_cls_inds=None, bbox_keep_inds=None, rotated_nms=True):
+    """theta-OBB detections of one image from the rbbox head's outputs.
+
+    Counterpart of ``RBBoxHead.get_det_rbboxes_parallel``
+    (mmdet/models/bbox_heads/rbbox_head.py:253-296, encode='thetaobb'): softmax,
+    ``delta2thetaobb`` with the head's means/stds, optional rescale, then NMS.
+
+    ``rotated_nms=True`` runs the call the reference left commented out (:294-295):
+    ``multiclass_rnms(thetaobbs, scores, cfg.score_thr, polygon_nms_iou_thr,
+    max_per_img)``.  ``rotated_nms=False`` reproduces the reference's behaviour, i.e.
+    re-applies the horizontal keep indices (:287-293) -- then ``bbox_cls_inds`` /
+    ``bbox_keep_inds`` from ``multiclass_nms_with_index`` are required.
+
+    ``cfg`` needs ``score_thr``, ``max_per_img`` and ``polygon_nms_iou_thr`` (attribute or
+    key access), as test_cfg.rcnn of configs/dota/dota_v002_theta_obb_r50_v1_train.py:125-132.
+    """
+    import torch.nn.functional as F
+
+    from .rbbox_transforms import delta2thetaobb, thetaobb_rescale
+
+    def get(name):
+        return cfg[name] if isinstance(cfg, dict) else getattr(cfg, name)
+
+    if isinstance(cls_score, list):
+        cls_score = sum(cls_score) / float(len(cls_score))
+    scores = F.softmax(cls_score, dim=1) if cls_score is not None else None
+    if rbbox_pred is not None:
+        rbboxes = delta2thetaobb(rois[:, 1:], rbbox_pred, target_means, target_stds, img_shape)
+    else:
+        rbboxes = rois[:, 1:]
+    if rescale:
+        rbboxes = thetaobb_rescale(rbboxes, scale_factor, reverse_flag=True)
+    if cfg is None:
+        return rbboxes, scores
+    if rotated_nms:
+        return multiclass_rnms(rbboxes, scores, get('score_thr'),
+                               dict(type='rnms', iou_thr=get('polygon_nms_iou_thr')),
+                               get('max_per_img'))
+    return thetaobb_nms_by_bbox_nms(rbboxes, scores, bbox_cls_inds, bbox_keep_inds,
+                                    get('max_per_img'), out_dim_reg=5)

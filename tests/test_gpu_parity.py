@@ -535,3 +535,38 @@ def test_rnms_one_million_boxes_properties():
     ref_mask = np.zeros(n, bool); ref_mask[ref] = True
     assert np.array_equal(kept_mask[sel[inner]], ref_mask[sel[inner]])
     assert inner.sum() > 500
+
+
+def test_get_det_rbboxes_both_modes(golden):
+    """rbbox_head.py:253-296 counterpart: reference behaviour (horizontal keep re-applied)
+    and the true rotated NMS the reference left commented out."""
+    from aidet_amd.post_processing import get_det_rbboxes, multiclass_nms_with_index
+    from aidet_amd.rbbox_transforms import delta2thetaobb
+    rng = np.random.default_rng(3)
+    n, ncls = 300, 6
+    x1 = rng.uniform(0, 400, n); y1 = rng.uniform(0, 400, n)
+    rois = np.stack([np.zeros(n), x1, y1, x1 + rng.uniform(10, 90, n), y1 + rng.uniform(10, 90, n)], 1).astype(np.float32)
+    cls_score = rng.standard_normal((n, ncls)).astype(np.float32) * 2
+    pred = (rng.standard_normal((n, ncls * 5)) * 0.5).astype(np.float32)
+    cfg = dict(score_thr=0.05, max_per_img=100, polygon_nms_iou_thr=0.4)
+    det, lab = get_det_rbboxes(t(rois), t(cls_score), t(pred), (512, 512, 3), 1.0, cfg=cfg)
+    det, lab = det.cpu().numpy(), lab.cpu().numpy()
+    assert det.shape[1] == 6 and len(det) == len(lab) <= 100
+    # oracle: decode on CPU, per-class rnms, top-100 by score
+    sc = torch.softmax(torch.from_numpy(cls_score), 1).numpy()
+    rb = delta2thetaobb(torch.from_numpy(rois[:, 1:]), torch.from_numpy(pred), (0,) * 5,
+                        (0.1, 0.1, 0.2, 0.2, 0.1)).numpy()
+    allk = []
+    for c in range(1, ncls):
+        m = sc[:, c] > 0.05
+        d = np.concatenate([rb[m, c * 5:(c + 1) * 5], sc[m, c:c + 1]], 1).astype(np.float32)
+        allk.append(d[oracle.rnms(d, 0.4)])
+    allk = np.concatenate(allk, 0)
+    top = allk[np.argsort(-allk[:, 5], kind='stable')[:100]]
+    assert np.allclose(np.sort(det[:, 5])[::-1], top[:, 5], atol=1e-6)
+    # reference mode needs the horizontal pass first
+    hb = torch.from_numpy(rois[:, 1:]).repeat(1, ncls)
+    _, _, cls_inds, keep_inds = multiclass_nms_with_index(t(hb.numpy()), t(sc), 0.05, dict(type='nms', iou_thr=0.5), 100)
+    det2, lab2 = get_det_rbboxes(t(rois), t(cls_score), t(pred), (512, 512, 3), 1.0, cfg=cfg,
+                                 bbox_cls_inds=cls_inds, bbox_keep_inds=keep_inds, rotated_nms=False)
+    assert det2.shape[1] == 6 and len(det2) <= 100
