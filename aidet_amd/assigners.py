@@ -1,0 +1,101 @@
+"""Max-IoU target assignment for rotated boxes.
+
+Restatement of the reference's ``MaxIoUAssigner``
+(mmdet/core/bbox/assigners/max_iou_assigner.py:8-202; result container
+assign_result.py) with the IoU supplied by the rotated kernel
+(``rbbox_overlaps`` instead of ``bbox_overlaps``, max_iou_assigner.py:99).
+The reference itself assigns with HORIZONTAL boxes even for its OBB models
+(rbbox_cnn.py:155-173); this is the "next" row 8f-3 of SURVEY.md.
+"""
+import torch
+
+from .rbbox_geometry import rbbox_overlaps
+
+
+class AssignResult(object):
+    """Same fields as mmdet/core/bbox/assigners/assign_result.py."""
+
+    def __init__(self, num_gts, gt_inds, max_overlaps, labels=None):
+        self.num_gts = num_gts
+        self.gt_inds = gt_inds
+        self.max_overlaps = max_overlaps
+        self.labels = labels
+
+    def add_gt_(self, gt_labels):
+        self_inds = torch.arange(1, len(gt_labels) + 1, dtype=torch.long, device=gt_labels.device)
+        self.gt_inds = torch.cat([self_inds, self.gt_inds])
+        self.max_overlaps = torch.cat([self.max_overlaps.new_ones(len(gt_labels)), self.max_overlaps])
+        if self.labels is not None:
+            self.labels = torch.cat([gt_labels, self.labels])
+
+
+def assign_wrt_overlaps(overlaps, gt_labels=None, pos_iou_thr=0.5, neg_iou_thr=0.5, min_pos_iou=.0,
+                        gt_max_assign_all=True):
+    """max_iou_assigner.py:114-202: overlaps (k gts, n boxes) -> AssignResult.
+    -1 = don't care, 0 = negative, i > 0 = 1-based index of the assigned gt."""
+    num_gts, num_bboxes = overlaps.size(0), overlaps.size(1)
+    assigned_gt_inds = overlaps.new_full((num_bboxes, ), -1, dtype=torch.long)
+    if num_gts == 0 or num_bboxes == 0:
+        max_overlaps = overlaps.new_zeros((num_bboxes, ))
+        if num_gts == 0:
+            assigned_gt_inds[:] = 0
+        labels = None if gt_labels is None else overlaps.new_zeros((num_bboxes, ), dtype=torch.long)
+        return AssignResult(num_gts, assigned_gt_inds, max_overlaps, labels=labels)
+
+    max_overlaps, argmax_overlaps = overlaps.max(dim=0)
+    gt_max_overlaps, gt_argmax_overlaps = overlaps.max(dim=1)
+    if isinstance(neg_iou_thr, float):
+        assigned_gt_inds[(max_overlaps >= 0) & (max_overlaps < neg_iou_thr)] = 0
+    elif isinstance(neg_iou_thr, tuple):
+        assert len(neg_iou_thr) == 2
+        assigned_gt_inds[(max_overlaps >= neg_iou_thr[0]) & (max_overlaps < neg_iou_thr[1])] = 0
+    pos_inds = max_overlaps >= pos_iou_thr
+    assigned_gt_inds[pos_inds] = argmax_overlaps[pos_inds] + 1
+    for i in range(num_gts):
+        if gt_max_overlaps[i] >= min_pos_iou:
+            if gt_max_assign_all:
+                assigned_gt_inds[overlaps[i, :] == gt_max_overlaps[i]] = i + 1
+            else:
+                assigned_gt_inds[gt_argmax_overlaps[i]] = i + 1
+    if gt_labels is not None:
+        assigned_labels = assigned_gt_inds.new_zeros((num_bboxes, ))
+        pos = torch.nonzero(assigned_gt_inds > 0).squeeze()
+        if pos.numel() > 0:
+            assigned_labels[pos] = gt_labels[assigned_gt_inds[pos] - 1]
+    else:
+        assigned_labels = None
+    return AssignResult(num_gts, assigned_gt_inds, max_overlaps, labels=assigned_labels)
+
+
+class MaxIoUAssignerRotated(object):
+    """MaxIoUAssigner over theta-OBBs (n, 5) with the rotated-IoU kernel.
+
+    Same constructor arguments as the reference (max_iou_assigner.py:36-51);
+    ``gpu_assign_thr`` is accepted and ignored (the overlaps always come from the
+    HIP kernel; there is no CPU path to fall back to).
+    """
+
+    def __init__(self, pos_iou_thr, neg_iou_thr, min_pos_iou=.0, gt_max_assign_all=True,
+                 ignore_iof_thr=-1, ignore_wrt_candidates=True, gpu_assign_thr=-1):
+        self.pos_iou_thr = pos_iou_thr
+        self.neg_iou_thr = neg_iou_thr
+        self.min_pos_iou = min_pos_iou
+        self.gt_max_assign_all = gt_max_assign_all
+        self.ignore_iof_thr = ignore_iof_thr
+        self.ignore_wrt_candidates = ignore_wrt_candidates
+        self.gpu_assign_thr = gpu_assign_thr
+
+    def assign(self, rbboxes, gt_rbboxes, gt_rbboxes_ignore=None, gt_labels=None):
+        rbboxes = rbboxes[:, :5]
+        overlaps = rbbox_overlaps(gt_rbboxes, rbboxes)
+        if (self.ignore_iof_thr > 0 and gt_rbboxes_ignore is not None
+                and gt_rbboxes_ignore.numel() > 0 and rbboxes.numel() > 0):
+            if self.ignore_wrt_candidates:
+                ignore_overlaps = rbbox_overlaps(rbboxes, gt_rbboxes_ignore, mode='iof')
+                ignore_max_overlaps, _ = ignore_overlaps.max(dim=1)
+            else:
+                ignore_overlaps = rbbox_overlaps(gt_rbboxes_ignore, rbboxes, mode='iof')
+                ignore_max_overlaps, _ = ignore_overlaps.max(dim=0)
+            overlaps[:, ignore_max_overlaps > self.ignore_iof_thr] = -1
+        return assign_wrt_overlaps(overlaps, gt_labels, self.pos_iou_thr, self.neg_iou_thr,
+                                   self.min_pos_iou, self.gt_max_assign_all)

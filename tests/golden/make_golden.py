@@ -9,6 +9,7 @@ What is captured (SURVEY.md 8c anchors):
   hbb_nms.npz        A2  mmdet/ops/nms/src/nms_cpu.cpp:5-68 via nms_wrapper.py:7-60
   multiclass.npz     A3  core/post_processing/bbox_nms.py:6-76, rbbox_nms.py:6-119
   thetaobb_codec.npz A5  core/rbbox/transforms.py:191-203,280-293,321-395
+  assigner.npz           core/bbox/assigners/max_iou_assigner.py:8-202 (MaxIoUAssigner)
 """
 import importlib.util
 import os
@@ -190,6 +191,35 @@ def main():
     out['rescale_out'] = transforms.thetaobb_rescale(dec.clone(), 1.7).numpy()
     out['rescale_rev_out'] = transforms.thetaobb_rescale(dec.clone(), 1.7, reverse_flag=True).numpy()
     np.savez_compressed(os.path.join(HERE, 'thetaobb_codec.npz'), **out)
+    # ---- MaxIoUAssigner (mmdet/core/bbox/assigners/max_iou_assigner.py:8-202) -------
+    out = {}
+    pk = types.ModuleType('refbbox'); pk.__path__ = []; sys.modules['refbbox'] = pk
+    sys.modules['refbbox.geometry'] = geometry
+    pa = types.ModuleType('refbbox.assigners'); pa.__path__ = []; sys.modules['refbbox.assigners'] = pa
+    adir = REF + '/mmdet/core/bbox/assigners/'
+    mu = types.ModuleType('mmdet.utils'); mu.__path__ = []; sys.modules['mmdet.utils'] = mu
+    mu.util_mixins = _load('mmdet.utils.util_mixins', REF + '/mmdet/utils/util_mixins.py')
+    _load('refbbox.assigners.assign_result', adir + 'assign_result.py')
+    _load('refbbox.assigners.base_assigner', adir + 'base_assigner.py')
+    mia = _load('refbbox.assigners.max_iou_assigner', adir + 'max_iou_assigner.py')
+    boxes = torch.from_numpy(rand_hbb(rng, 400, 300, 10, 80))
+    gts = torch.from_numpy(rand_hbb(rng, 14, 300, 20, 90))
+    ign = torch.from_numpy(rand_hbb(rng, 3, 300, 40, 120))
+    labels = torch.from_numpy(rng.integers(1, 16, 14))
+    for tag, kw, use_ign in (('a', dict(pos_iou_thr=0.5, neg_iou_thr=0.4, min_pos_iou=0.3), False),
+                             ('b', dict(pos_iou_thr=0.7, neg_iou_thr=(0.1, 0.3), min_pos_iou=0.0,
+                                        gt_max_assign_all=False), False),
+                             ('c', dict(pos_iou_thr=0.5, neg_iou_thr=0.5, min_pos_iou=0.5,
+                                        ignore_iof_thr=0.5), True)):
+        a = mia.MaxIoUAssigner(**kw)
+        r = a.assign(boxes, gts, ign if use_ign else None, labels)
+        out['assign_%s_gt_inds' % tag] = r.gt_inds.numpy()
+        out['assign_%s_max_overlaps' % tag] = r.max_overlaps.numpy()
+        out['assign_%s_labels' % tag] = r.labels.numpy()
+    out['boxes'] = boxes.numpy(); out['gts'] = gts.numpy(); out['ign'] = ign.numpy()
+    out['labels'] = labels.numpy()
+    out['overlaps'] = geometry.bbox_overlaps(gts, boxes).numpy()
+    np.savez_compressed(os.path.join(HERE, 'assigner.npz'), **out)
     print('wrote', sorted(f for f in os.listdir(HERE) if f.endswith('.npz')))
 
 

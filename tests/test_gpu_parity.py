@@ -570,3 +570,20 @@ def test_get_det_rbboxes_both_modes(golden):
     det2, lab2 = get_det_rbboxes(t(rois), t(cls_score), t(pred), (512, 512, 3), 1.0, cfg=cfg,
                                  bbox_cls_inds=cls_inds, bbox_keep_inds=keep_inds, rotated_nms=False)
     assert det2.shape[1] == 6 and len(det2) <= 100
+
+
+def test_rotated_max_iou_assigner_matches_reference_at_theta0(golden):
+    """MaxIoUAssignerRotated on theta=0 encodings of the reference's HBBs reproduces
+    the reference MaxIoUAssigner's gt_inds / labels (fixture from make_golden.py)."""
+    from aidet_amd.assigners import MaxIoUAssignerRotated
+    g = golden('assigner.npz')
+    boxes, gts, ign = (t(hbb_to_rbox(g[k])) for k in ('boxes', 'gts', 'ign'))
+    labels = t(g['labels'])
+    cases = (('a', dict(pos_iou_thr=0.5, neg_iou_thr=0.4, min_pos_iou=0.3), False),
+             ('b', dict(pos_iou_thr=0.7, neg_iou_thr=(0.1, 0.3), min_pos_iou=0.0, gt_max_assign_all=False), False),
+             ('c', dict(pos_iou_thr=0.5, neg_iou_thr=0.5, min_pos_iou=0.5, ignore_iof_thr=0.5), True))
+    for tag, kw, use_ign in cases:
+        r = MaxIoUAssignerRotated(**kw).assign(boxes, gts, ign if use_ign else None, labels)
+        assert np.array_equal(r.gt_inds.cpu().numpy(), g['assign_%s_gt_inds' % tag]), tag
+        assert np.array_equal(r.labels.cpu().numpy(), g['assign_%s_labels' % tag]), tag
+        assert np.abs(r.max_overlaps.cpu().numpy() - g['assign_%s_max_overlaps' % tag]).max() <= 1e-5

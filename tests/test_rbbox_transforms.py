@@ -58,3 +58,25 @@ def test_rotated_extractor_level_mapping_matches_reference_rule():
     r2 = ex.roi_rescale(rois, 1.5)
     assert torch.allclose(r2[:, 3], wh * 1.5) and torch.equal(r2[:, 1], rois[:, 1])
     assert ex.num_inputs == 4 and [l.spatial_scale for l in ex.roi_layers] == [0.25, 0.125, 0.0625, 0.03125]
+
+
+def test_assign_wrt_overlaps_matches_reference(golden):
+    """max_iou_assigner.py:114-202 on the reference's own overlap matrix."""
+    from aidet_amd.assigners import assign_wrt_overlaps
+    g = golden('assigner.npz')
+    ov = torch.from_numpy(g['overlaps'])
+    labels = torch.from_numpy(g['labels'])
+    r = assign_wrt_overlaps(ov.clone(), labels, 0.5, 0.4, 0.3, True)
+    assert np.array_equal(r.gt_inds.numpy(), g['assign_a_gt_inds'])
+    assert np.array_equal(r.labels.numpy(), g['assign_a_labels'])
+    assert np.array_equal(r.max_overlaps.numpy(), g['assign_a_max_overlaps'])
+    r = assign_wrt_overlaps(ov.clone(), labels, 0.7, (0.1, 0.3), 0.0, False)
+    assert np.array_equal(r.gt_inds.numpy(), g['assign_b_gt_inds'])
+    assert np.array_equal(r.labels.numpy(), g['assign_b_labels'])
+    # reference doctest (max_iou_assigner.py:81-87) and empty cases (:131-147)
+    r = assign_wrt_overlaps(torch.tensor([[0.9, 0.0]]), None, 0.5, 0.5)
+    assert r.gt_inds.tolist() == [1, 0]
+    r = assign_wrt_overlaps(torch.zeros((0, 3)), torch.zeros(0).long())
+    assert r.gt_inds.tolist() == [0, 0, 0] and r.labels.tolist() == [0, 0, 0]
+    r = assign_wrt_overlaps(torch.zeros((2, 0)))
+    assert r.gt_inds.numel() == 0
