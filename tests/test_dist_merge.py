@@ -3,6 +3,7 @@
 op is injected (the oracle) because the product has no CPU path; on the GPU box
 the same code runs with RCCL and the HIP rnms (tests/test_gpu_parity.py)."""
 import os
+import re as re_
 import socket
 
 import numpy as np
@@ -115,3 +116,26 @@ def test_shard_patches_is_rank_strided():
     assert dota_merge.shard_patches(10, 1, 4) == [1, 5, 9]
     got = sorted(sum((dota_merge.shard_patches(10, r, 4) for r in range(4)), []))
     assert got == list(range(10))
+
+
+def test_dota_io_names_rows_and_files(tmp_path):
+    """patch-name parsing, coordinate restoration and the Task1 line format
+    (mmdet/datasets/dota.py:304)."""
+    from aidet_amd import dota_io
+    assert dota_io.parse_patch_name('P0003__1__824___0') == ('P0003', 1.0, 824, 0)
+    assert dota_io.parse_patch_name('/a/b/P12__0.5__0___1648.png') == ('P12', 0.5, 0, 1648)
+    with pytest.raises(ValueError):
+        dota_io.parse_patch_name('P0003.png')
+    ids = {}
+    rb = torch.tensor([[10., 20., 8., 4., -0.3, 0.9], [100., 50., 30., 10., -1.0, 0.5]])
+    rows = dota_io.patch_rows_to_image(rb, torch.tensor([1, 3]), 'P7__0.5__100___200', ids)
+    assert ids == {'P7': 0}
+    assert torch.allclose(rows[0], torch.tensor([220., 440., 16., 8., -0.3, 0.9, 1., 0.]))
+    thr = dota_io.class_thresholds()
+    assert len(thr) == 15 and thr[1] == 0.05 and dota_io.class_thresholds(classwise=False)[3] == 0.3
+    polys = oracle.rbox_to_poly(rows.numpy())
+    counts = dota_io.write_task1(str(tmp_path), rows, polys, ['P7'])
+    assert counts['ship'] == 1 and counts['large-vehicle'] == 1 and sum(counts.values()) == 2
+    line = open(os.path.join(str(tmp_path), 'Task1_ship.txt')).read().split()
+    assert line[0] == 'P7' and line[1] == '0.900' and len(line) == 10
+    assert all(re_.match(r'^-?\d+\.\d$', v) for v in line[2:])
