@@ -832,6 +832,252 @@ __global__ __launch_bounds__(1024) void nms_write_kernel(const uint8_t *__restri
   }
 }
 
+// ---- fused path for small n: the whole NMS in ONE launch of ONE workgroup ------------
+// Detection heads call NMS thousands of times on a few hundred to ~2000 boxes
+// (RPN levels, per-image heads; rpn_head.py:92, bbox_nms.py:60-64): there the ten
+// launches of the general pipeline cost more than the work.  Same arithmetic, same
+// pruning, same edge/resolve formulation; state lives in LDS, records and edges in
+// the caller's workspace.
+constexpr int kSmallMax = 1024;          // one box per thread
+constexpr int kFusedDefault = 384;       // largest n routed to the fused kernel (measured crossover ~500)
+
+template <int KIND>
+__global__ __launch_bounds__(1024) void nms_small_kernel(const float *__restrict__ dets, int n,
+                                                         float thr_global,
+                                                         const int32_t *__restrict__ group,
+                                                         const float *__restrict__ thrs,
+                                                         QuadRec *__restrict__ rec,
+                                                         uint2 *__restrict__ edges,
+                                                         unsigned int ecap,
+                                                         int64_t *__restrict__ keep,
+                                                         NmsCounters *__restrict__ ctr) {
+  constexpr int S = KIND ? 9 : 6;
+  __shared__ uint2 qiv[kSmallMax];            // packed (lo, hi|G)
+  __shared__ float area[kSmallMax];
+  __shared__ uint32_t skey[kSmallMax];
+  __shared__ int cnt[kSmallMax];
+  __shared__ uint8_t state[kSmallMax];
+  __shared__ uint2 queue[16][kNmsQueue];
+  __shared__ float red[16][4];
+  __shared__ float frame[6];                  // base x,y, scale x,y, cell px x,y
+  __shared__ unsigned int n_edges;
+  __shared__ int wsum[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // ---- a: records, intervals, frame
+  const float big = 3.0e38f;
+  float xl = big, xh = -big, yl = big, yh = -big;
+  bool fin = false;
+  if (tid == 0) n_edges = 0;
+  if (tid < n) {
+    const float *row = dets + (int64_t)tid * S;
+    Quad q;
+    load_quad<KIND>(row, q);
+    QuadRec r;
+    r.ox = q.ox; r.oy = q.oy; r.ex = q.ex; r.ey = q.ey;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { r.rx[k] = q.rx[k]; r.ry[k] = q.ry[k]; }
+    r.area = q.area; r.skey = score_key(row[S - 1]);
+    r.group = group ? group[tid] : 0;
+    r.thr = thrs ? thrs[tid] : thr_global;
+    rec[tid] = r;
+    skey[tid] = r.skey;
+    area[tid] = q.area;
+    nms_interval(q.ox, q.ex, xl, xh);
+    nms_interval(q.oy, q.ey, yl, yh);
+    fin = (fabs_sel(xl) < big) && (fabs_sel(xh) < big) && (fabs_sel(yl) < big) && (fabs_sel(yh) < big);
+  }
+  cnt[tid] = 0;
+  state[tid] = kUndecided;
+  float mnx = fin ? xl : big, mxx = fin ? xh : -big, mny = fin ? yl : big, mxy = fin ? yh : -big;
+  for (int o = 32; o > 0; o >>= 1) {
+    mnx = min_sel(mnx, __shfl_xor(mnx, o)); mxx = max_sel(mxx, __shfl_xor(mxx, o));
+    mny = min_sel(mny, __shfl_xor(mny, o)); mxy = max_sel(mxy, __shfl_xor(mxy, o));
+  }
+  if (lane == 0) { red[wave][0] = mnx; red[wave][1] = mxx; red[wave][2] = mny; red[wave][3] = mxy; }
+  __syncthreads();
+  if (tid == 0) {
+    float x0 = red[0][0], x1 = red[0][1], y0 = red[0][2], y1 = red[0][3];
+    for (int k = 1; k < 16; ++k) {
+      x0 = min_sel(x0, red[k][0]); x1 = max_sel(x1, red[k][1]);
+      y0 = min_sel(y0, red[k][2]); y1 = max_sel(y1, red[k][3]);
+    }
+    const float rx = x1 - x0, ry = y1 - y0;
+    frame[0] = x0; frame[1] = y0;
+    frame[2] = rx > 0.0f ? (float)kQMax / rx : 0.0f;
+    frame[3] = ry > 0.0f ? (float)kQMax / ry : 0.0f;
+    frame[4] = rx > 0.0f ? (rx / (float)kQMax) * 1.000001f : 0.0f;
+    frame[5] = ry > 0.0f ? (ry / (float)kQMax) * 1.000001f : 0.0f;
+  }
+  __syncthreads();
+  {
+    auto qz = [](float x, float b, float s) {
+      float u = floorf((x - b) * s);
+      u = u < 0.0f ? 0.0f : (u > (float)kQMax ? (float)kQMax : u);
+      return (uint32_t)u;
+    };
+    uint2 o = make_uint2(kSentLo, kSentHi);
+    if (fin) {
+      o.x = qz(xl, frame[0], frame[2]) | (qz(yl, frame[1], frame[3]) << 16);
+      o.y = (qz(xh, frame[0], frame[2]) | (qz(yh, frame[1], frame[3]) << 16)) | kGuard;
+    }
+    qiv[tid] = o;   // threads >= n hold the sentinel
+  }
+  __syncthreads();
+
+  // ---- b: pair scan (rows r, columns c > r), candidates -> clip -> edges
+  Prune pr;
+  pr.thr = thrs ? 0.0f : thr_global; pr.cpx = frame[4]; pr.cpy = frame[5];
+  uint2 *q = queue[wave];
+  int qn = 0;
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+  auto drain = [&](bool flush) {
+    while (qn >= 64 || (flush && qn > 0)) {
+      const int take = qn < 64 ? qn : 64;
+      qn -= take;
+      __builtin_amdgcn_wave_barrier();
+      bool hit = false;
+      uint32_t src = 0, dst = 0;
+      if (lane < take) {
+        const uint2 prr = q[qn + lane];
+        Quad A, B;
+        uint32_t ka, kb;
+        int ga, gb;
+        float ta, tb;
+        load_rec(rec, prr.x, A, ka, ga, ta);
+        load_rec(rec, prr.y, B, kb, gb, tb);
+        const bool b_first = (kb < ka) || (kb == ka && prr.y < prr.x);
+        src = b_first ? prr.y : prr.x;
+        dst = b_first ? prr.x : prr.y;
+        swap_if(b_first, A.ox, B.ox); swap_if(b_first, A.oy, B.oy);
+        swap_if(b_first, A.ex, B.ex); swap_if(b_first, A.ey, B.ey);
+        swap_if(b_first, A.area, B.area);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { swap_if(b_first, A.rx[k], B.rx[k]); swap_if(b_first, A.ry[k], B.ry[k]); }
+        const float ov = quad_overlap(A, B, 0);
+        hit = (ga == gb) && (ov >= (b_first ? tb : ta));
+      }
+      const uint64_t mk = __ballot(hit);
+      if (mk) {
+        const int leader = __ffsll((long long)mk) - 1;
+        unsigned int pos0 = 0;
+        if (lane == leader) pos0 = atomicAdd(&n_edges, (unsigned int)__popcll(mk));
+        pos0 = (unsigned int)__shfl((int)pos0, leader);
+        if (hit) {
+          const unsigned int pos = pos0 + __popcll(mk & lt_mask);
+          if (pos < ecap) edges[pos] = make_uint2(src, dst);
+          atomicAdd(&cnt[dst], 1);
+        }
+      }
+    }
+  };
+  const int nchunks = (n + kTile - 1) / kTile;          // column chunks of 256
+  for (int cb = 0; cb < nchunks; ++cb) {
+    uint2 col[4];
+    float car[4];
+    const int c0 = cb * kTile + lane * kNmsColsPerLane;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { col[k] = qiv[c0 + k]; car[k] = area[c0 + k]; }
+    const int rend = min(n, cb * kTile + kTile - 1);    // rows that have a column > r in this chunk
+    for (int r = wave; r < rend; r += 16) {
+      const uint2 rv = qiv[r];                           // LDS broadcast
+      const uint32_t t0 = qdisjoint(rv.x, rv.y, col[0].x, col[0].y);
+      const uint32_t t1 = qdisjoint(rv.x, rv.y, col[1].x, col[1].y);
+      const uint32_t t2 = qdisjoint(rv.x, rv.y, col[2].x, col[2].y);
+      const uint32_t t3 = qdisjoint(rv.x, rv.y, col[3].x, col[3].y);
+      const uint32_t tt[4] = {t0, t1, t2, t3};
+      bool any_c = false;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) any_c = any_c || (tt[k] == 0u && c0 + k > r);
+      if (!__any(any_c)) continue;
+      const float ra = area[r];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        bool cnd = (tt[k] == 0u) && (c0 + k > r);
+        if (pr.thr > 0.0f && __any(cnd)) {
+          cnd = cnd && prune_area(pr, ra, car[k]);
+          if (__any(cnd)) cnd = cnd && prune_aabb(pr, rv.x, rv.y, ra, col[k].x, col[k].y, car[k]);
+        }
+        const uint64_t mk = __ballot(cnd);
+        if (mk) {
+          if (cnd) q[qn + __popcll(mk & lt_mask)] = make_uint2((uint32_t)r, (uint32_t)(c0 + k));
+          qn += __popcll(mk);
+        }
+      }
+      drain(false);
+    }
+  }
+  drain(true);
+  __syncthreads();
+
+  // ---- c: resolve (state / cnt in LDS, edges in the workspace)
+  const unsigned int found = n_edges;
+  long long live = found <= ecap ? (long long)found : 0;
+  long long rounds = 0;
+  int stalled = 0;
+  while (live > 0) {
+    long long w = 0;
+    for (long long base = 0; base < live; base += 1024) {
+      const long long e = base + tid;
+      bool kp = false;
+      uint2 ed = make_uint2(0u, 0u);
+      if (e < live) {
+        ed = edges[e];
+        if (state[ed.y] == kUndecided) {
+          uint8_t si = state[ed.x];
+          if (si == kUndecided && cnt[ed.x] == 0) si = kKept;
+          if (si == kKept) {
+            state[ed.y] = kSuppressed;
+          } else if (si == kSuppressed) {
+            if (atomicSub(&cnt[ed.y], 1) == 1) state[ed.y] = kKept;
+          } else {
+            kp = true;
+          }
+        }
+      }
+      const uint64_t mk = __ballot(kp);
+      if (lane == 0) wsum[wave] = __popcll(mk);
+      __syncthreads();
+      int off = 0, tot = 0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int v = wsum[k];
+        off += (k < wave) ? v : 0;
+        tot += v;
+      }
+      if (kp) edges[w + off + __popcll(mk & lt_mask)] = ed;
+      w += tot;
+      __syncthreads();
+    }
+    stalled = (w == live) ? stalled + 1 : 0;
+    live = w;
+    ++rounds;
+    __syncthreads();
+    if (stalled >= 2) break;
+  }
+
+  // ---- d: ascending keep indices + counters
+  const bool f = (tid < n) && ((state[tid] == kKept) || (state[tid] == kUndecided && cnt[tid] == 0));
+  const uint64_t mk = __ballot(f);
+  if (lane == 0) wsum[wave] = __popcll(mk);
+  __syncthreads();
+  int off = 0, tot = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int v = wsum[k];
+    off += (k < wave) ? v : 0;
+    tot += v;
+  }
+  if (f) keep[off + __popcll(mk & lt_mask)] = tid;
+  if (tid == 0) {
+    ctr->edges = found;
+    ctr->kept = tot;
+    ctr->rounds = rounds;
+    ctr->cand_total = found;
+    ctr->cand_worst = found > ecap ? (unsigned long long)found : 0ull;   // host: overflow if > segcap
+  }
+}
+
 // ---- optional per-phase timing (HIP events on the caller's stream) ----------------
 constexpr int kPhases = OBB_NMS_PHASES;
 struct NmsProfile {
@@ -965,6 +1211,36 @@ extern "C" int obb_nms_grouped_f32(const float *dets_dev, int64_t n, int kind, f
     prof.created = true;
   }
 #define OBB_PHASE(k) do { if (timed && (prof.level >= 2 || (k) == 3 || (k) == 4)) OBB_HIP_TRY(hipEventRecord(prof.ev[k], st)); } while (0)
+  int64_t fused_max = kFusedDefault;
+  if (const char *e = getenv("OBB_NMS_FUSED_MAX")) fused_max = atoll(e);   // tuning knob
+  if (fused_max > kSmallMax) fused_max = kSmallMax;
+  if (n <= fused_max && !getenv("OBB_NMS_NO_FUSED")) {
+    // fused single-launch path; the edge list may use the whole pair capacity
+    const unsigned long long ecap64 = 2ull * cap;
+    const unsigned int ecap = ecap64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned int)ecap64;
+    if (kind == OBB_KIND_RBOX)
+      hipLaunchKernelGGL(nms_small_kernel<0>, dim3(1), dim3(1024), 0, st, dets_dev, (int)n, iou_thr, group_dev, thr_dev, rec, cands, ecap, keep_dev, ctr);
+    else
+      hipLaunchKernelGGL(nms_small_kernel<1>, dim3(1), dim3(1024), 0, st, dets_dev, (int)n, iou_thr, group_dev, thr_dev, rec, cands, ecap, keep_dev, ctr);
+    OBB_LAUNCH_CHECK();
+    NmsCounters hs;
+    OBB_HIP_TRY(hipMemcpyAsync(&hs, ctr, sizeof(hs), hipMemcpyDeviceToHost, st));
+    OBB_HIP_TRY(hipStreamSynchronize(st));
+    if (timed) { for (int k = 0; k < kPhases; ++k) prof.ms[k] = 0.0f; prof.have = true; }
+    if (info_host) {
+      info_host[0] = hs.kept;
+      info_host[1] = (int64_t)hs.edges;
+      info_host[2] = hs.rounds;
+      info_host[3] = (int64_t)hs.cand_total;
+    }
+    if (hs.edges > ecap) {
+      const unsigned long long need = hs.edges / 2 + hs.edges / 8 + 1024;   // edges fit in 2 * capacity
+      if (info_host) { info_host[0] = 0; info_host[3] = (int64_t)need; }
+      return set_err(OBB_EWORKSPACE, "obb_nms_f32: %llu overlap edges exceed the pair capacity %llu; retry with edge_capacity >= %llu",
+                     hs.edges, cap, need);
+    }
+    return OBB_OK;
+  }
   // phase 0: clear + prep + quantise
   OBB_PHASE(0);
   OBB_HIP_TRY(hipMemsetAsync(ws + L.zero_begin, 0, L.zero_end - L.zero_begin, st));

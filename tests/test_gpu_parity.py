@@ -587,3 +587,43 @@ def test_rotated_max_iou_assigner_matches_reference_at_theta0(golden):
         assert np.array_equal(r.gt_inds.cpu().numpy(), g['assign_%s_gt_inds' % tag]), tag
         assert np.array_equal(r.labels.cpu().numpy(), g['assign_%s_labels' % tag]), tag
         assert np.abs(r.max_overlaps.cpu().numpy() - g['assign_%s_max_overlaps' % tag]).max() <= 1e-5
+
+
+@pytest.mark.parametrize('n,canvas', [(1, 10), (2, 10), (64, 64), (257, 100), (700, 150), (1024, 200),
+                                      (1024, 60)])
+def test_rnms_fused_and_general_paths_agree(n, canvas, monkeypatch):
+    """n <= 1024 takes the fused single-launch kernel; OBB_NMS_NO_FUSED=1 forces the
+    general pipeline.  Both must reproduce the oracle (dense canvas 60: ~1e5 edges)."""
+    from aidet_amd import poly_nms, rnms
+    d = oracle.synth_boxes(n, canvas, 300 + n)
+    g = np.random.default_rng(n).integers(0, 3, n)
+    ref = oracle.rnms(d, 0.45)
+    refg = oracle.rnms(d, 0.45, groups=g)
+    p = np.concatenate([oracle.rbox_to_poly(d).astype(np.float32), d[:, 5:6]], 1)
+    refp = oracle.poly_nms(p, 0.45)
+    monkeypatch.setenv('OBB_NMS_FUSED_MAX', '1024')   # route every case to the fused kernel
+    for no_fused in ('', '1'):
+        if no_fused:
+            monkeypatch.setenv('OBB_NMS_NO_FUSED', '1')
+        else:
+            monkeypatch.delenv('OBB_NMS_NO_FUSED', raising=False)
+        assert np.array_equal(rnms(t(d), 0.45)[1].cpu().numpy(), ref)
+        assert np.array_equal(rnms(t(d), 0.45, groups=g)[1].cpu().numpy(), refg)
+        assert np.array_equal(poly_nms(t(p), 0.45)[1].cpu().numpy(), refp)
+
+
+def test_small_nms_latency_smoke():
+    """not a benchmark: the fused path must not be slower than the general one"""
+    import time
+    from aidet_amd import rnms
+    d = t(oracle.synth_boxes(1000, 300, 5))
+    for _ in range(5):
+        rnms(d, 0.5)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(50):
+        rnms(d, 0.5)
+    torch.cuda.synchronize()
+    fused = (time.perf_counter() - t0) / 50
+    assert fused < 5e-3
+    print('rnms n=1000: %.1f us per call' % (fused * 1e6))
