@@ -249,3 +249,17 @@ def rbox_to_poly(boxes):
     cx, cy = b[:, 0], b[:, 1]
     return np.stack([cx - ux + vx, cy - uy + vy, cx - ux - vx, cy - uy - vy,
                      cx + ux - vx, cy + uy - vy, cx + ux + vx, cy + uy + vy], axis=1)
+
+
+def synth_quads(n, canvas, seed, jitter=0.25):
+    """(n,9) fp32 random CONVEX quadrilaterals + score: rectangles whose corners are
+    moved by up to `jitter` of the shorter side (stays convex for jitter < 0.3), in
+    random vertex order direction (CW / CCW)."""
+    b = synth_boxes(n, canvas, seed)
+    p = rbox_to_poly(b).reshape(n, 4, 2)
+    rng = np.random.default_rng(seed + 7919)
+    side = np.minimum(b[:, 2], b[:, 3])[:, None, None]
+    p = p + rng.uniform(-jitter, jitter, p.shape) * side
+    flip = rng.random(n) < 0.5
+    p[flip] = p[flip][:, ::-1]
+    return np.concatenate([p.reshape(n, 8), b[:, 5:6]], 1).astype(np.float32)

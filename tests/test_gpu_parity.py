@@ -627,3 +627,41 @@ def test_small_nms_latency_smoke():
     fused = (time.perf_counter() - t0) / 50
     assert fused < 5e-3
     print('rnms n=1000: %.1f us per call' % (fused * 1e6))
+
+
+def test_general_convex_quads_gpu():
+    """pointobb_overlaps / poly_nms on convex quads that are not rectangles"""
+    from aidet_amd import poly_nms
+    from aidet_amd.rbbox_geometry import pointobb_overlaps
+    a = oracle.synth_quads(700, 300, 31)
+    b = oracle.synth_quads(900, 300, 32)
+    for mode in ('iou', 'iof'):
+        got = pointobb_overlaps(t(a[:, :8]), t(b[:, :8]), mode=mode).cpu().numpy()
+        assert np.array_equal(got, oracle.overlaps(a[:, :8], b[:, :8], mode, kind='poly'))
+        assert np.abs(got - oracle.overlaps_f64(a[:, :8], b[:, :8], mode, kind='poly')).max() <= IOU_TOL
+    for n, canvas, thr in ((300, 100, 0.3), (5000, 600, 0.5), (30000, 3000, 0.4)):
+        d = oracle.synth_quads(n, canvas, 40 + n)
+        _, inds = poly_nms(t(d), thr)
+        assert np.array_equal(inds.cpu().numpy(), oracle.poly_nms(d, thr))
+
+
+@pytest.mark.parametrize('seed', range(6))
+def test_rnms_randomised_shapes_and_clusters(seed):
+    """clustered scenes, extreme aspect ratios, mixed scales, random thresholds"""
+    from aidet_amd import rnms
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(500, 12000))
+    k = int(rng.integers(3, 40))
+    centres = rng.uniform(0, 4000, (k, 2))
+    which = rng.integers(0, k, n)
+    d = np.zeros((n, 6), np.float32)
+    d[:, :2] = centres[which] + rng.normal(0, rng.uniform(5, 200), (n, 2))
+    d[:, 2] = np.exp(rng.uniform(np.log(2), np.log(400), n))
+    d[:, 3] = np.exp(rng.uniform(np.log(2), np.log(60), n))
+    d[:, 4] = rng.uniform(-np.pi, np.pi, n)
+    d[:, 5] = rng.random(n).astype(np.float32)
+    if seed % 2:
+        d[:, 5] = np.round(d[:, 5], 2)          # ties
+    thr = float(rng.uniform(0.1, 0.8))
+    _, inds = rnms(t(d), thr)
+    assert np.array_equal(inds.cpu().numpy(), oracle.rnms(d, thr))

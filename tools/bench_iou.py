@@ -6,8 +6,9 @@ import oracle
 from aidet_amd import rbbox_overlaps
 dev = torch.device('cuda:0')
 m = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
-a = torch.from_numpy(oracle.synth_boxes(m, 1024, 1)[:, :5]).to(dev)
-b = torch.from_numpy(oracle.synth_boxes(m, 1024, 2)[:, :5]).to(dev)
+canvas = float(sys.argv[2]) if len(sys.argv) > 2 else 1024.0
+a = torch.from_numpy(oracle.synth_boxes(m, canvas, 1)[:, :5]).to(dev)
+b = torch.from_numpy(oracle.synth_boxes(m, canvas, 2)[:, :5]).to(dev)
 for _ in range(3): rbbox_overlaps(a, b)
 torch.cuda.synchronize()
 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
