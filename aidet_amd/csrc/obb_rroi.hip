@@ -178,15 +178,23 @@ template <bool X4>
 __global__ __launch_bounds__(256) void rroi_forward_kernel(
     const float *__restrict__ feat, int B, int C, int H, int W, const float *__restrict__ rois,
     int ph, int pw, float scale, int sample_num, float min_size, int groups_per_block,
-    float *__restrict__ out) {
+    int K, int chunks, float *__restrict__ out) {
   __shared__ __attribute__((aligned(16))) float tile[kStageFloats + 256];  // + pad for the last wave-instruction
   __shared__ int4 s_off[kMaxTabSamples];      // per sample: 4 footprint-local tap offsets
   __shared__ float4 s_wgt[kMaxTabSamples];    // per sample: 4 bilinear weights
-  const int64_t k = blockIdx.x;
+  // XCD-aware block -> (RoI, channel chunk): workgroups are dealt round-robin over the 8
+  // XCDs (each with its own 4 MiB L2), so consecutive ids take the SAME RoI and 8
+  // DIFFERENT channel chunks: every XCD then sweeps all RoIs over its own chunk of
+  // planes, which stays L2 resident, instead of all 8 L2s thrashing on every plane.
+  const uint32_t lin = blockIdx.x;
+  const uint32_t c8 = lin & 7u, rest = lin >> 3;
+  const int64_t k = rest % (uint32_t)K;
+  const int chunk = (int)((rest / (uint32_t)K) * 8u + c8);
+  if (chunk >= chunks) return;
   RoiFrame f;
   make_frame(rois + k * 6, scale, ph, pw, sample_num, min_size, f);
   const int nb = ph * pw;
-  const int c_block = blockIdx.y * groups_per_block * kChanPerThread;
+  const int c_block = chunk * groups_per_block * kChanPerThread;
   const int c_end = min(C, c_block + groups_per_block * kChanPerThread);
   const bool bad = f.b < 0 || f.b >= B;
   const int64_t plane = (int64_t)H * W;
@@ -372,21 +380,26 @@ extern "C" int obb_rroi_align_forward_f32(const float *feat_dev, int B, int C, i
   if (H == 0 || W == 0 || B == 0) return set_err(OBB_EINVAL, "obb_rroi_align_forward_f32: empty feature map with %lld RoIs", (long long)K);
   int gpb; unsigned chunks;
   rroi_geometry(C, ph, pw, gpb, chunks);
-  // forward: 24 channels per block (gpb = 3, measured best of 1..8): a big rotated RoI
-  // needs several staging passes per channel group, and the kernel ends with its
-  // slowest block
-  gpb = 3;
+  // forward: 16-32 channels per block (a big rotated RoI needs several staging passes per
+  // channel group and the kernel ends with its slowest block), preferring a chunk
+  // count that is a multiple of 8 = one chunk per XCD and round (see the kernel)
+  {
+    const int groups = (C + kChanPerThread - 1) / kChanPerThread;
+    gpb = (groups % 32 == 0) ? 4 : ((groups % 16 == 0) ? 2 : 3);
+  }
   if (const char *e = getenv("OBB_RROI_GPB")) gpb = atoi(e) > 0 ? atoi(e) : gpb;  // tuning knob
   chunks = (unsigned)(((C + kChanPerThread - 1) / kChanPerThread + gpb - 1) / gpb);
   if (chunks > 65535u) return set_err(OBB_EINVAL, "obb_rroi_align_forward_f32: too many channels (%d)", C);
   // 16-byte LDS-DMA needs 16-byte aligned rows: W % 4 == 0 and an aligned base
   const bool x4 = (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(feat_dev) & 15u) == 0);
+  const unsigned long long nblk = (unsigned long long)((chunks + 7u) / 8u) * 8ull * (unsigned long long)K;
+  if (nblk > 2147483647ull) return set_err(OBB_EINVAL, "obb_rroi_align_forward_f32: too many blocks (K=%lld, C=%d)", (long long)K, C);
   if (x4)
-    hipLaunchKernelGGL(rroi_forward_kernel<true>, dim3((unsigned)K, chunks), dim3(256), 0, (hipStream_t)stream,
-                       feat_dev, B, C, H, W, rois_dev, ph, pw, spatial_scale, sample_num, min_size, gpb, out_dev);
+    hipLaunchKernelGGL(rroi_forward_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
+                       feat_dev, B, C, H, W, rois_dev, ph, pw, spatial_scale, sample_num, min_size, gpb, (int)K, (int)chunks, out_dev);
   else
-    hipLaunchKernelGGL(rroi_forward_kernel<false>, dim3((unsigned)K, chunks), dim3(256), 0, (hipStream_t)stream,
-                       feat_dev, B, C, H, W, rois_dev, ph, pw, spatial_scale, sample_num, min_size, gpb, out_dev);
+    hipLaunchKernelGGL(rroi_forward_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
+                       feat_dev, B, C, H, W, rois_dev, ph, pw, spatial_scale, sample_num, min_size, gpb, (int)K, (int)chunks, out_dev);
   OBB_LAUNCH_CHECK();
   return OBB_OK;
 }
