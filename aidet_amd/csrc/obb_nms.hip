@@ -49,16 +49,17 @@
 namespace obb {
 
 constexpr int kTile = 256;            // boxes per spatial tile
-constexpr int kNmsWaves = 8;          // waves per scan block (one block = one tile pair)
+constexpr int kNmsWaves = 4;          // waves per scan block (every wave works on its own units)
 constexpr int kNmsColsPerLane = 4;    // 64 lanes x 4 = one tile of columns per wave
-constexpr int kRowsPerWave = kTile / kNmsWaves;  // 32 rows of the row tile per wave
-constexpr int kRowChunk = 8;
+constexpr int kSub = 8;               // row sub-tiles per tile
+constexpr int kSubRows = kTile / kSub;  // 32 rows: one scan unit = (row sub-tile, column tile)
+constexpr int kRowChunk = 4;
 constexpr int kNmsQueue = 64 + kTile;  // carry (<= 63) + one row's worst case
-constexpr int kCullChunk = 4096;        // column tiles per cull block (LDS list size)
+constexpr int kCullChunk = 1024;        // column tiles per cull block (LDS list: kSub entries each)
 constexpr int kCells = 65536;           // max Morton cells of the counting sort (8 + 8 bits)
 constexpr int kShards = 64;            // candidate lists / counters (atomic rate)
 constexpr int kPrepBlocks = 1024;     // upper bound on blocks of the prep kernel
-constexpr int kPairBlocks = 4096;     // grid of the scan kernel (blocks loop over tile pairs)
+constexpr int kScanBlocks = 2048;     // grid of the scan kernel (waves loop over units)
 constexpr int kClipBlocksPerShard = 32;
 
 constexpr uint8_t kUndecided = 0, kKept = 1, kSuppressed = 2;
@@ -81,8 +82,8 @@ struct alignas(16) QuadRec {  // 64 bytes: four float4 loads
 // share a cache line serialise at the memory side.
 struct NmsCounters {
   alignas(256) unsigned long long edges;   // overlap edges found (may exceed capacity)
-  alignas(256) unsigned int tile_pairs;    // light tile pairs (stored from the back of the list)
-  alignas(256) unsigned int heavy_pairs;   // heavy tile pairs (stored from the front)
+  alignas(256) unsigned int light_units;   // light scan units (stored from the back of the list)
+  alignas(256) unsigned int heavy_units;   // heavy scan units (stored from the front)
   alignas(256) long long kept;             // K
   long long rounds;                        // resolve rounds
   unsigned long long cand_total;           // candidate pairs over all shards
@@ -298,7 +299,8 @@ __global__ __launch_bounds__(256) void nms_permute_kernel(const uint2 *__restric
                                                           const QuadRec *__restrict__ rec,
                                                           int64_t n, uint2 *__restrict__ qs,
                                                           float *__restrict__ as,
-                                                          uint2 *__restrict__ tbox) {
+                                                          uint2 *__restrict__ tbox,
+                                                          uint2 *__restrict__ sbox) {
   __shared__ uint4 wred[4];
   const int64_t s = (int64_t)blockIdx.x * kTile + threadIdx.x;
   uint2 o = make_uint2(kSentLo, kSentHi);
@@ -312,10 +314,17 @@ __global__ __launch_bounds__(256) void nms_permute_kernel(const uint2 *__restric
   as[s] = ar;
   uint32_t xl = o.x & 0x7FFFu, yl = (o.x >> 16) & 0x7FFFu;
   uint32_t xh = o.y & 0x7FFFu, yh = (o.y >> 16) & 0x7FFFu;
-  for (int k = 32; k > 0; k >>= 1) {
+  for (int k = kSubRows / 2; k > 0; k >>= 1) {
     xl = min(xl, shfl_xor_u(xl, k)); yl = min(yl, shfl_xor_u(yl, k));
     xh = max(xh, shfl_xor_u(xh, k)); yh = max(yh, shfl_xor_u(yh, k));
   }
+  // bounding box of each run of 32 consecutive positions (a sub-tile of sentinels
+  // keeps lo = max, hi = 0: it meets nothing)
+  if ((threadIdx.x & (kSubRows - 1)) == 0)
+    sbox[(size_t)blockIdx.x * kSub + (threadIdx.x / kSubRows)] = make_uint2(xl | (yl << 16), (xh | (yh << 16)) | kGuard);
+  static_assert(kSubRows == 32, "one more exchange joins the two sub-tiles of a wave");
+  xl = min(xl, shfl_xor_u(xl, 32)); yl = min(yl, shfl_xor_u(yl, 32));
+  xh = max(xh, shfl_xor_u(xh, 32)); yh = max(yh, shfl_xor_u(yh, 32));
   if ((threadIdx.x & 63) == 0) wred[threadIdx.x >> 6] = make_uint4(xl, yl, xh, yh);
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -336,58 +345,80 @@ __device__ __forceinline__ uint32_t qdisjoint(uint32_t alo, uint32_t ahiG, uint3
   return (~d1 | ~d2) & kGuard;  // one v_bitop3_b32
 }
 
-// ---- 5: tile-pair culling ------------------------------------------------------------
-// block per row tile A, threads over B >= A; survivors are stored as
-// (A << 16 | B)  [ntiles < 65536].
-// Candidate density differs by an order of magnitude between tile pairs (a tile
-// against itself or its Morton neighbour vs. two tiles that merely touch), and the
-// scan kernel's duration is set by its slowest block -- so pairs that overlap
-// substantially ("heavy") are listed from the FRONT of tpairs and start first,
-// the others from the BACK (longest-processing-time-first scheduling).
-__global__ __launch_bounds__(256) void nms_cull_kernel(const uint2 *__restrict__ tbox, int nt,
-                                                       uint32_t *__restrict__ tpairs,
-                                                       unsigned int tp_capacity,
+// ---- 5: unit culling --------------------------------------------------------------------
+// A scan UNIT is (row sub-tile = 32 consecutive positions of tile A, column tile B >= A):
+// one wave's worth of work in the scan kernel.  Block per row tile A, threads over B;
+// a tile pair whose boxes meet emits a unit for every sub-tile of A that meets B's box,
+// stored as { A << 16 | B, sub-tile }  [ntiles < 65536].
+// The scan kernel's duration is set by its slowest wave, and the work of a unit differs
+// by an order of magnitude (a sub-tile against its own tile vs. one that merely touches
+// the column tile) -- so units that overlap substantially ("heavy") are listed from the
+// FRONT of the list and start first, the others from the BACK (longest-processing-
+// time-first scheduling).
+__device__ __forceinline__ float qbox_area(uint32_t lo, uint32_t hiG) {
+  const uint32_t w = hiG - lo;   // per-axis width, guard bits survive (hi >= lo)
+  return (float)((w & 0x7FFFu) + 1u) * (float)(((w >> 16) & 0x7FFFu) + 1u);
+}
+
+__global__ __launch_bounds__(256) void nms_cull_kernel(const uint2 *__restrict__ tbox,
+                                                       const uint2 *__restrict__ sbox, int nt,
+                                                       uint2 *__restrict__ units,
+                                                       unsigned int ucap,
                                                        NmsCounters *__restrict__ ctr) {
-  // one block per row tile A; survivors are collected in LDS and published with
-  // two global atomics per block (a returning atomic on one address sustains only
-  // ~90 per microsecond)
-  __shared__ uint32_t lists[kCullChunk];   // heavy from the front, light from the back
+  // survivors are collected in LDS and published with two global atomics per block
+  // (a returning atomic on one address sustains only ~90 per microsecond)
+  __shared__ uint32_t lists[kCullChunk * kSub];   // sub << 16 | B; heavy from the front, light from the back
   __shared__ unsigned int nh, nl, gbase_h, gbase_l;
   const int A = blockIdx.x;
   const int b0 = A + (int)blockIdx.y * kCullChunk;   // this block's column tiles [b0, b1)
   if (b0 >= nt) return;
   const int b1 = min(nt, b0 + kCullChunk);
-  const int span = b1 - b0;
+  const int span = (b1 - b0) * kSub;
   if (threadIdx.x == 0) { nh = 0; nl = 0; }
   __syncthreads();
   const uint2 a = tbox[A];
-  const int axl = a.x & 0x7FFF, ayl = (a.x >> 16) & 0x7FFF, axh = a.y & 0x7FFF, ayh = (a.y >> 16) & 0x7FFF;
-  const float aa = (float)(axh - axl + 1) * (float)(ayh - ayl + 1);
+  uint2 sa[kSub];
+#pragma unroll
+  for (int w = 0; w < kSub; ++w) sa[w] = sbox[(size_t)A * kSub + w];
   for (int B = b0 + threadIdx.x; B < b1; B += 256) {
     const uint2 b = tbox[B];
-    if (qdisjoint(a.x, a.y, b.x, b.y) == 0u) {
-      const int bxl = b.x & 0x7FFF, byl = (b.x >> 16) & 0x7FFF, bxh = b.y & 0x7FFF, byh = (b.y >> 16) & 0x7FFF;
-      const float ow = (float)(min(axh, bxh) - max(axl, bxl) + 1), oh = (float)(min(ayh, byh) - max(ayl, byl) + 1);
-      const float ab = (float)(bxh - bxl + 1) * (float)(byh - byl + 1);
-      const bool heavy = (A == B) || (ow * oh * 8.0f >= fminf(aa, ab));
-      const uint32_t v = ((uint32_t)A << 16) | (uint32_t)B;
+    if (B == A || qdisjoint(a.x, a.y, b.x, b.y) != 0u) continue;   // diagonal units are implicit
+#pragma unroll
+    for (int w = 0; w < kSub; ++w) {
+      if (qdisjoint(sa[w].x, sa[w].y, b.x, b.y) != 0u) continue;
+      // shared part of the two boxes vs. the sub-tile's own box: most rows active?
+      const uint32_t ilo = __builtin_elementwise_max(sa[w].x & 0x7FFFu, b.x & 0x7FFFu) |
+                           (__builtin_elementwise_max(sa[w].x >> 16, b.x >> 16) << 16);
+      const uint32_t ihi = __builtin_elementwise_min(sa[w].y & 0x7FFFu, b.y & 0x7FFFu) |
+                           (__builtin_elementwise_min((sa[w].y >> 16) & 0x7FFFu, (b.y >> 16) & 0x7FFFu) << 16) | kGuard;
+      const bool heavy = qbox_area(ilo, ihi) * 4.0f >= qbox_area(sa[w].x, sa[w].y);
+      const uint32_t v = ((uint32_t)w << 16) | (uint32_t)B;
       if (heavy) lists[atomicAdd(&nh, 1u)] = v;
       else lists[span - 1 - atomicAdd(&nl, 1u)] = v;
     }
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    gbase_h = nh ? atomicAdd(&ctr->heavy_pairs, nh) : 0u;
-    gbase_l = nl ? atomicAdd(&ctr->tile_pairs, nl) : 0u;   // light count
+    gbase_h = nh ? atomicAdd(&ctr->heavy_units, nh) : 0u;
+    gbase_l = nl ? atomicAdd(&ctr->light_units, nl) : 0u;
   }
   __syncthreads();
-  for (unsigned int k = threadIdx.x; k < nh; k += 256) tpairs[gbase_h + k] = lists[k];
-  for (unsigned int k = threadIdx.x; k < nl; k += 256) tpairs[tp_capacity - 1u - (gbase_l + k)] = lists[span - 1 - k];
+  // a list that does not fit is reported by the host (heavy + light > ucap); never
+  // write outside it
+  for (unsigned int k = threadIdx.x; k < nh; k += 256) {
+    const uint32_t v = lists[k];
+    if (gbase_h + k < ucap) units[gbase_h + k] = make_uint2(((uint32_t)A << 16) | (v & 0xFFFFu), v >> 16);
+  }
+  for (unsigned int k = threadIdx.x; k < nl; k += 256) {
+    const uint32_t v = lists[span - 1 - k];
+    if (gbase_l + k < ucap) units[ucap - 1u - (gbase_l + k)] = make_uint2(((uint32_t)A << 16) | (v & 0xFFFFu), v >> 16);
+  }
 }
 
 // ---- 6: scan kernel --------------------------------------------------------------------
-// One wave: 64 rows of tile A (lane l holds row l; broadcast with v_readlane) x
-// 256 columns of tile B (4 per lane).  15 full-rate VALU + 2 v_readlane per row.
+// One wave = one unit: 32 rows of tile A (lane l holds row l; broadcast with
+// v_readlane) x 256 columns of tile B (4 per lane), and only the rows whose interval
+// meets B's bounding box are visited.  15 full-rate VALU + 2 v_readlane per row.
 // Rows with a candidate are only RECORDED in `hit` and pushed out of line.
 // Threshold-aware pruning of a candidate (never changes the result: a pair is
 // dropped only when its overlap provably stays below thr in the fp32 spec):
@@ -420,76 +451,118 @@ __device__ __forceinline__ bool prune_aabb(const Prune &pr, uint32_t rlo, uint32
   return I * (1.0f + pr.thr) >= (pr.thr * (ra + ca)) * 0.999999f;
 }
 
+// The per-wave LDS queue holds RAW candidates as spatial positions (row, column).  A
+// batch of 64 is pruned with one candidate per lane (the two bounds cost ~40 VALU: per
+// batch, not per candidate), and the survivors go to the wave's global candidate list
+// as (box id, box id) with one returning atomic per batch.
+__device__ __forceinline__ void nms_flush(const uint2 *q, int count, const Prune &pr,
+                                          const uint2 *__restrict__ qs, const float *__restrict__ as,
+                                          const uint32_t *__restrict__ sid,
+                                          uint2 *__restrict__ cand, unsigned long long segcap,
+                                          unsigned long long *__restrict__ ccnt, int lane) {
+  bool keep = lane < count;
+  uint2 ids = make_uint2(0u, 0u);
+  if (keep) {
+    const uint2 e = q[lane];
+    const uint2 a = qs[e.x], b = qs[e.y];
+    const float ra = as[e.x], ca = as[e.y];
+    ids = make_uint2(sid[e.x], sid[e.y]);
+    if (pr.thr > 0.0f) keep = prune_area(pr, ra, ca) && prune_aabb(pr, a.x, a.y, ra, b.x, b.y, ca);
+  }
+  const uint64_t mk = __ballot(keep);
+  if (mk == 0) return;
+  unsigned long long base = 0;
+  if (lane == 0) base = atomicAdd(ccnt, (unsigned long long)__popcll(mk));
+  base = __shfl(base, 0) + (unsigned long long)__popcll(mk & ((1ull << lane) - 1ull));
+  if (keep && base < segcap) cand[base] = ids;
+}
+
 template <bool DIAG>
-__device__ __forceinline__ void nms_scan_rows(uint2 rv, uint32_t rid, float rarea, uint32_t sa0,
-                                              uint32_t sb0, const uint2 (&col)[4],
-                                              const uint32_t (&cid)[4], const float (&car)[4],
-                                              const Prune &pr, uint2 *q, int &qn,
+__device__ __forceinline__ void nms_scan_rows(uint2 rv, uint32_t rows, uint32_t sa0, uint32_t sb0,
+                                              const uint2 (&col)[4], const Prune &pr,
+                                              const uint2 *__restrict__ qs, const float *__restrict__ as,
+                                              const uint32_t *__restrict__ sid, uint2 *q, int &qn,
                                               uint2 *__restrict__ cand, unsigned long long segcap,
                                               unsigned long long *__restrict__ ccnt, int lane) {
   const uint64_t lt_mask = (1ull << lane) - 1ull;
   const uint32_t sbl = sb0 + lane * kNmsColsPerLane;
-  for (int ib = 0; ib < kRowsPerWave; ib += kRowChunk) {
+  while (rows) {   // `rows`: the rows of this sub-tile that meet the column tile's box
     uint32_t hit = 0;
 #pragma unroll
     for (int u = 0; u < kRowChunk; ++u) {
-      const uint32_t rlo = (uint32_t)__builtin_amdgcn_readlane((int)rv.x, ib + u);
-      const uint32_t rhi = (uint32_t)__builtin_amdgcn_readlane((int)rv.y, ib + u);
+      // lane kSubRows holds a sentinel row (never a candidate): padding of the last chunk
+      const int r = rows ? __builtin_ctz(rows) : kSubRows;
+      rows &= rows - 1u;
+      const uint32_t rlo = (uint32_t)__builtin_amdgcn_readlane((int)rv.x, r);
+      const uint32_t rhi = (uint32_t)__builtin_amdgcn_readlane((int)rv.y, r);
       uint32_t t0 = qdisjoint(rlo, rhi, col[0].x, col[0].y);
       uint32_t t1 = qdisjoint(rlo, rhi, col[1].x, col[1].y);
       uint32_t t2 = qdisjoint(rlo, rhi, col[2].x, col[2].y);
       uint32_t t3 = qdisjoint(rlo, rhi, col[3].x, col[3].y);
       if (DIAG) {  // only pairs (row, col) with col > row exist in a diagonal tile
-        const uint32_t sa = sa0 + ib + u;
+        const uint32_t sa = sa0 + r;
         t0 |= (sbl + 0 > sa) ? 0u : 1u; t1 |= (sbl + 1 > sa) ? 0u : 1u;
         t2 |= (sbl + 2 > sa) ? 0u : 1u; t3 |= (sbl + 3 > sa) ? 0u : 1u;
       }
       const uint32_t m = min(min(t0, t1), min(t2, t3));
-      hit |= __any(m == 0u) ? (1u << u) : 0u;
+      hit |= __any(m == 0u) ? (1u << (r & (kSubRows - 1))) : 0u;
     }
-    while (hit) {  // some lane has a candidate in row ib+u
-      const int u = __builtin_ctz(hit);
+    while (hit) {  // some lane has a candidate in row r
+      const int r = __builtin_ctz(hit);
       hit &= hit - 1u;
-      const uint32_t rlo = (uint32_t)__builtin_amdgcn_readlane((int)rv.x, ib + u);
-      const uint32_t rhi = (uint32_t)__builtin_amdgcn_readlane((int)rv.y, ib + u);
-      const uint32_t ida = (uint32_t)__builtin_amdgcn_readlane((int)rid, ib + u);
-      const float ra = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rarea), ib + u));
-      const uint32_t sa = sa0 + ib + u;
+      const uint32_t rlo = (uint32_t)__builtin_amdgcn_readlane((int)rv.x, r);
+      const uint32_t rhi = (uint32_t)__builtin_amdgcn_readlane((int)rv.y, r);
+      const uint32_t sa = sa0 + r;
+      uint32_t m4 = 0;   // bit c: column c of this lane is a candidate
 #pragma unroll
       for (int c = 0; c < kNmsColsPerLane; ++c) {
         bool cnd = qdisjoint(rlo, rhi, col[c].x, col[c].y) == 0u;
         if (DIAG) cnd = cnd && (sbl + c > sa);
-        if (pr.thr > 0.0f && __any(cnd)) {
-          cnd = cnd && prune_area(pr, ra, car[c]);
-          if (__any(cnd)) cnd = cnd && prune_aabb(pr, rlo, rhi, ra, col[c].x, col[c].y, car[c]);
+        m4 |= cnd ? (1u << c) : 0u;
+      }
+      uint64_t mk = __ballot(m4 != 0u);
+      if (__popcll(mk) <= 2) {
+        // the common case, one or two lanes: push from scalar registers
+        while (mk) {
+          const int l = __builtin_ctzll(mk);
+          mk &= mk - 1ull;
+          uint32_t bits = (uint32_t)__builtin_amdgcn_readlane((int)m4, l);
+          const uint32_t sb = sb0 + (uint32_t)l * kNmsColsPerLane;
+          while (bits) {
+            const int c = __builtin_ctz(bits);
+            bits &= bits - 1u;
+            if (lane == 0) q[qn] = make_uint2(sa, sb + (uint32_t)c);
+            ++qn;
+          }
         }
-        const uint64_t mk = __ballot(cnd);
-        if (mk) {
-          if (cnd) q[qn + __popcll(mk & lt_mask)] = make_uint2(ida, cid[c]);
-          qn += __popcll(mk);
+      } else {
+#pragma unroll
+        for (int c = 0; c < kNmsColsPerLane; ++c) {
+          const bool cnd = (m4 >> c) & 1u;
+          const uint64_t mc = __ballot(cnd);
+          if (cnd) q[qn + __popcll(mc & lt_mask)] = make_uint2(sa, sbl + c);
+          qn += __popcll(mc);
         }
       }
-      while (qn >= 64) {  // flush a full batch: one global atomic per 64 candidates
+      while (qn >= 64) {  // prune + flush a full batch
         qn -= 64;
         __builtin_amdgcn_wave_barrier();
-        unsigned long long base = 0;
-        if (lane == 0) base = atomicAdd(ccnt, 64ull);
-        base = __shfl(base, 0);
-        const uint2 e = q[qn + lane];
-        if (base + lane < segcap) cand[base + lane] = e;
+        nms_flush(q + qn, 64, pr, qs, as, sid, cand, segcap, ccnt, lane);
       }
     }
   }
 }
 
-// block k handles tile pairs k, k + gridDim.x, ... of the list [heavy ..., light ...];
-// wave w owns rows [32 w, 32 w + 32) of the row tile.
-__global__ __launch_bounds__(512) void nms_scan_kernel(const uint2 *__restrict__ qs,
+// Wave g handles units g, g + (waves in the grid), ... of
+//   [ diagonal units (sub-tile vs. its own tile, implicit) | heavy ... | light ... ].
+// Consecutive blocks land on different CUs, so this deals the expensive units evenly.
+__global__ __launch_bounds__(64 * kNmsWaves) void nms_scan_kernel(const uint2 *__restrict__ qs,
                                                        const float *__restrict__ as,
                                                        const float *__restrict__ cellpx, float thr,
                                                        const uint32_t *__restrict__ sid,
-                                                       const uint32_t *__restrict__ tpairs,
-                                                       unsigned int tp_capacity,
+                                                       const uint2 *__restrict__ tbox, int nt,
+                                                       const uint2 *__restrict__ units,
+                                                       unsigned int ucap,
                                                        uint2 *__restrict__ cands,
                                                        unsigned long long segcap,
                                                        NmsCounters *__restrict__ ctr,
@@ -500,45 +573,48 @@ __global__ __launch_bounds__(512) void nms_scan_kernel(const uint2 *__restrict__
   uint2 *q = queue[wave];
   int qn = 0;
   const uint32_t gw = blockIdx.x * kNmsWaves + wave;       // global wave id
+  const uint32_t nw = gridDim.x * kNmsWaves;
   const int shard = (int)(gw & (kShards - 1));
   uint2 *cand = cands + (size_t)shard * segcap;
   unsigned long long *ccnt = ccnts + (size_t)shard * kCandStride;
-  const unsigned int nheavy = ctr->heavy_pairs, nlight = ctr->tile_pairs;
-  const unsigned int ntp = nheavy + nlight;
+  const unsigned int nheavy = ctr->heavy_units, nlight = ctr->light_units;
+  if (nheavy + nlight > ucap) return;   // unit list overflow: reported by the host, nothing valid to scan
+  const unsigned int ndiag = (unsigned int)nt * kSub;
+  const unsigned int nun = ndiag + nheavy + nlight;
   Prune pr;
   pr.thr = thr; pr.cpx = cellpx[0]; pr.cpy = cellpx[1];
-  for (unsigned int k = blockIdx.x; k < ntp; k += gridDim.x) {
-    const uint32_t tp = (k < nheavy) ? tpairs[k] : tpairs[tp_capacity - 1u - (k - nheavy)];
-    const uint32_t A = tp >> 16, B = tp & 0xFFFFu;
-    const uint32_t sa0 = A * kTile + wave * kRowsPerWave;   // this wave's 32 rows
+  for (unsigned int k = gw; k < nun; k += nw) {
+    uint32_t A, B, sub;
+    if (k < ndiag) {
+      A = B = k / kSub; sub = k % kSub;
+    } else {
+      const unsigned int j = k - ndiag;
+      const uint2 un = (j < nheavy) ? units[j] : units[ucap - 1u - (j - nheavy)];
+      A = un.x >> 16; B = un.x & 0xFFFFu; sub = un.y;
+    }
+    const uint32_t sa0 = A * kTile + sub * kSubRows;         // this unit's 32 rows
     const uint32_t sb0 = B * kTile;                          // 256 columns
-    // qs / sid are padded to whole tiles (sentinel intervals never match);
-    // lanes >= 32 mirror lanes < 32 (only rows 0..31 are ever broadcast)
-    const uint2 rv = qs[sa0 + (lane & (kRowsPerWave - 1))];
-    const uint32_t rid = sid[sa0 + (lane & (kRowsPerWave - 1))];
-    const float rarea = as[sa0 + (lane & (kRowsPerWave - 1))];
+    // qs is padded to whole tiles (sentinel intervals never match); lanes >= 32 hold a
+    // sentinel row
+    const bool rl = lane < kSubRows;
+    uint2 rv = make_uint2(kSentLo, kSentHi);
+    if (rl) rv = qs[sa0 + lane];
+    const uint2 tb = tbox[B];
     uint2 col[4];
-    uint32_t cid[4];
-    float car[4];
     {
-      const float4 ar = *reinterpret_cast<const float4 *>(as + sb0 + lane * kNmsColsPerLane);
-      car[0] = ar.x; car[1] = ar.y; car[2] = ar.z; car[3] = ar.w;
       const uint4 *cp = reinterpret_cast<const uint4 *>(qs + sb0 + lane * kNmsColsPerLane);
       const uint4 a = cp[0], b = cp[1];
-      const uint4 c = *reinterpret_cast<const uint4 *>(sid + sb0 + lane * kNmsColsPerLane);
       col[0] = make_uint2(a.x, a.y); col[1] = make_uint2(a.z, a.w);
       col[2] = make_uint2(b.x, b.y); col[3] = make_uint2(b.z, b.w);
-      cid[0] = c.x; cid[1] = c.y; cid[2] = c.z; cid[3] = c.w;
     }
-    if (A == B) nms_scan_rows<true>(rv, rid, rarea, sa0, sb0, col, cid, car, pr, q, qn, cand, segcap, ccnt, lane);
-    else nms_scan_rows<false>(rv, rid, rarea, sa0, sb0, col, cid, car, pr, q, qn, cand, segcap, ccnt, lane);
+    // only rows whose interval meets the column tile's box can have a candidate
+    const uint32_t rows = (uint32_t)__ballot(rl && qdisjoint(rv.x, rv.y, tb.x, tb.y) == 0u);
+    if (A == B) nms_scan_rows<true>(rv, rows, sa0, sb0, col, pr, qs, as, sid, q, qn, cand, segcap, ccnt, lane);
+    else nms_scan_rows<false>(rv, rows, sa0, sb0, col, pr, qs, as, sid, q, qn, cand, segcap, ccnt, lane);
   }
-  if (qn > 0) {  // final partial flush, once per wave
+  if (qn > 0) {  // final partial batch, once per wave
     __builtin_amdgcn_wave_barrier();
-    unsigned long long base = 0;
-    if (lane == 0) base = atomicAdd(ccnt, (unsigned long long)qn);
-    base = __shfl(base, 0);
-    if (lane < qn && base + lane < segcap) cand[base + lane] = q[lane];
+    nms_flush(q, qn, pr, qs, as, sid, cand, segcap, ccnt, lane);
   }
 }
 
@@ -1092,9 +1168,10 @@ static thread_local NmsProfile g_prof;
 
 // ---- workspace layout ------------------------------------------------------------
 struct NmsLayout {
-  size_t rec, iv, part, qb, ckey, sid, qs, as, cellpx, tbox, tpairs, zero_begin, state, cnt, ctr, ccnts, hist,
+  size_t rec, iv, part, qb, ckey, sid, qs, as, cellpx, tbox, sbox, zero_begin, state, cnt, ctr, ccnts, hist,
       zero_end, blockcnt, cands, edges, total;
-  unsigned long long cap;
+  unsigned long long cap;         // candidate pairs == overlap edges capacity
+  unsigned long long unit_worst;  // every (sub-tile, tile) unit there can be
   int64_t ntiles;
 };
 
@@ -1119,7 +1196,8 @@ static int nms_layout(int64_t n, int64_t edge_capacity, NmsLayout &L) {
   L.as = take((nt * kTile) * sizeof(float));
   L.cellpx = take(2 * sizeof(float));
   L.tbox = take(nt * sizeof(uint2));
-  L.tpairs = take((nt * (nt + 1) / 2) * 4);
+  L.sbox = take(nt * kSub * sizeof(uint2));
+  L.unit_worst = (unsigned long long)nt * (nt + 1) / 2 * kSub;   // (diagonal ones are not listed)
   L.zero_begin = off;
   L.state = take(nn);
   L.cnt = take(nn * 4);
@@ -1128,12 +1206,31 @@ static int nms_layout(int64_t n, int64_t edge_capacity, NmsLayout &L) {
   L.hist = take(kCells * 4);
   L.zero_end = off;
   L.blockcnt = take(((nn + 1023) / 1024) * 4);
-  // candidates and edges share one capacity: [cands | edges], cap entries each
+  // variable part, all 8-byte entries: [cands | edges | units]; candidates and edges
+  // share one capacity, the unit list gets 1/8 of it (never more than unit_worst).
+  // The split is re-derived from the actual workspace size at run time (nms_split).
   L.cands = off;
-  L.edges = off;  // resolved at run time from the actual workspace size
-  off += 2 * (size_t)L.cap * sizeof(uint2);
+  L.edges = off;
+  unsigned long long ucap = L.cap / 8 + 4096;
+  if (ucap > L.unit_worst) ucap = L.unit_worst;
+  off += (2 * (size_t)L.cap + (size_t)ucap) * sizeof(uint2);
   L.total = off;
   return OBB_OK;
+}
+
+// entries (8 bytes each) of the variable part -> per-shard pair capacity + unit capacity
+static void nms_split(unsigned long long entries, unsigned long long unit_worst,
+                      unsigned long long &segcap, unsigned long long &ucap) {
+  // inverse of nms_layout: entries = 2 cap + min(cap / 8 + 4096, unit_worst)
+  if (entries >= unit_worst && (entries - unit_worst) / 16 + 4096 >= unit_worst) {
+    ucap = unit_worst;
+  } else {
+    const unsigned long long cap = entries > 4096 ? (entries - 4096) * 8 / 17 : 0;
+    ucap = entries - 2 * cap;
+    if (ucap > unit_worst) ucap = unit_worst;
+  }
+  if (ucap > 0xFFFFFFFFull) ucap = 0xFFFFFFFFull;
+  segcap = (entries - ucap) / 2 / kShards;
 }
 
 }  // namespace obb
@@ -1172,10 +1269,12 @@ extern "C" int obb_nms_grouped_f32(const float *dets_dev, int64_t n, int kind, f
   int rc = nms_layout(n, 1, L);
   if (rc != OBB_OK) return rc;
   const size_t fixed = L.cands;
-  if (workspace_bytes < fixed + 2 * kShards * sizeof(uint2))
-    return set_err(OBB_EWORKSPACE, "obb_nms_f32: workspace %zu bytes < minimum %zu", workspace_bytes, fixed + 2 * kShards * sizeof(uint2));
-  const unsigned long long segcap = (workspace_bytes - fixed) / (2 * sizeof(uint2)) / kShards;
+  unsigned long long segcap = 0, ucap64 = 0;
+  if (workspace_bytes > fixed) nms_split((workspace_bytes - fixed) / sizeof(uint2), L.unit_worst, segcap, ucap64);
+  if (segcap == 0 || ucap64 == 0)
+    return set_err(OBB_EWORKSPACE, "obb_nms_f32: workspace %zu bytes < minimum %zu", workspace_bytes, L.total + 2 * kShards * sizeof(uint2));
   const unsigned long long cap = segcap * kShards;
+  const unsigned int ucap = (unsigned int)ucap64;
 
   char *ws = static_cast<char *>(workspace_dev);
   QuadRec *rec = reinterpret_cast<QuadRec *>(ws + L.rec);
@@ -1189,7 +1288,7 @@ extern "C" int obb_nms_grouped_f32(const float *dets_dev, int64_t n, int kind, f
   float *as = reinterpret_cast<float *>(ws + L.as);
   float *cellpx = reinterpret_cast<float *>(ws + L.cellpx);
   uint2 *tbox = reinterpret_cast<uint2 *>(ws + L.tbox);
-  uint32_t *tpairs = reinterpret_cast<uint32_t *>(ws + L.tpairs);
+  uint2 *sbox = reinterpret_cast<uint2 *>(ws + L.sbox);
   uint8_t *state = reinterpret_cast<uint8_t *>(ws + L.state);
   int *cnt = reinterpret_cast<int *>(ws + L.cnt);
   NmsCounters *ctr = reinterpret_cast<NmsCounters *>(ws + L.ctr);
@@ -1197,9 +1296,9 @@ extern "C" int obb_nms_grouped_f32(const float *dets_dev, int64_t n, int kind, f
   int *blockcnt = reinterpret_cast<int *>(ws + L.blockcnt);
   uint2 *cands = reinterpret_cast<uint2 *>(ws + L.cands);
   uint2 *edges = cands + cap;
+  uint2 *units = edges + cap;
   hipStream_t st = (hipStream_t)stream;
   const int nt = (int)L.ntiles;
-  const unsigned int tp_capacity = (unsigned int)((size_t)nt * (nt + 1) / 2);
 
   unsigned pblocks = (unsigned)((n + 255) / 256);
   if (pblocks > (unsigned)kPrepBlocks) pblocks = kPrepBlocks;
@@ -1264,20 +1363,20 @@ extern "C" int obb_nms_grouped_f32(const float *dets_dev, int64_t n, int kind, f
   OBB_LAUNCH_CHECK();
   // phase 2: permute + tile boxes + tile-pair culling
   OBB_PHASE(2);
-  hipLaunchKernelGGL(nms_permute_kernel, dim3((unsigned)nt), dim3(kTile), 0, st, qb, sid, rec, n, qs, as, tbox);
+  hipLaunchKernelGGL(nms_permute_kernel, dim3((unsigned)nt), dim3(kTile), 0, st, qb, sid, rec, n, qs, as, tbox, sbox);
   OBB_LAUNCH_CHECK();
-  hipLaunchKernelGGL(nms_cull_kernel, dim3((unsigned)nt, (unsigned)((nt + kCullChunk - 1) / kCullChunk)), dim3(256), 0, st, tbox, nt, tpairs, tp_capacity, ctr);
+  hipLaunchKernelGGL(nms_cull_kernel, dim3((unsigned)nt, (unsigned)((nt + kCullChunk - 1) / kCullChunk)), dim3(256), 0, st, tbox, sbox, nt, units, ucap, ctr);
   OBB_LAUNCH_CHECK();
   // phase 3: scan (broad phase)
   OBB_PHASE(3);
   {
-    const long long maxpairs = (long long)nt * (nt + 1) / 2;
-    long long pb = kPairBlocks;
+    const long long maxblocks = ((long long)L.unit_worst + kNmsWaves - 1) / kNmsWaves;
+    long long pb = kScanBlocks;
     if (const char *e = getenv("OBB_NMS_SCAN_BLOCKS")) pb = atoll(e) > 0 ? atoll(e) : pb;  // tuning knob
-    const unsigned gb = (unsigned)(maxpairs < pb ? maxpairs : pb);
+    const unsigned gb = (unsigned)(maxblocks < pb ? maxblocks : pb);
     // threshold-aware pruning needs ONE threshold: off when per-box thresholds are given
     const float prune_thr = thr_dev ? 0.0f : iou_thr;
-    hipLaunchKernelGGL(nms_scan_kernel, dim3(gb), dim3(64 * kNmsWaves), 0, st, qs, as, cellpx, prune_thr, sid, tpairs, tp_capacity, cands, segcap, ctr, ccnts);
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(gb), dim3(64 * kNmsWaves), 0, st, qs, as, cellpx, prune_thr, sid, tbox, nt, units, ucap, cands, segcap, ctr, ccnts);
     OBB_LAUNCH_CHECK();
   }
   // phase 4: clip (narrow phase)
@@ -1308,12 +1407,24 @@ extern "C" int obb_nms_grouped_f32(const float *dets_dev, int64_t n, int kind, f
     prof.have = true;
   }
   static_assert(kShards == 64, "the fold in nms_write_kernel uses one wave");
+  if (getenv("OBB_NMS_DEBUG"))
+    fprintf(stderr, "obb_nms: n=%lld tiles=%d heavy_units=%u light_units=%u (capacity %u) candidates=%llu edges=%llu\n",
+            (long long)n, nt, h.heavy_units, h.light_units, ucap, h.cand_total, h.edges);
   const unsigned long long ncand = h.cand_total, worst = h.cand_worst;
   if (info_host) {
     info_host[0] = h.kept;
     info_host[1] = (int64_t)h.edges;
     info_host[2] = h.rounds;
     info_host[3] = (int64_t)ncand;
+  }
+  if ((unsigned long long)h.heavy_units + h.light_units > ucap) {
+    // the unit list is 1/8 of the pair capacity: ask for a capacity that holds it
+    unsigned long long need = ((unsigned long long)h.heavy_units + h.light_units) * 8;
+    need += need / 4 + 1024;
+    if (need < cap * 2) need = cap * 2;
+    if (info_host) { info_host[0] = 0; info_host[3] = (int64_t)need; }
+    return set_err(OBB_EWORKSPACE, "obb_nms_f32: %u scan units exceed the unit capacity %u; retry with edge_capacity >= %llu",
+                   h.heavy_units + h.light_units, ucap, need);
   }
   if (worst > segcap) {
     // capacity that fits the fullest candidate / edge segment on a retry, with 25 %
