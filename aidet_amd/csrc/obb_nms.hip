@@ -90,6 +90,16 @@ struct NmsCounters {
   unsigned long long cand_worst;           // fullest shard
 };
 
+// what the host needs after a call: written by the LAST kernel straight into pinned
+// host memory (a device-to-host copy of the counters is one more ~5 us launch)
+struct NmsHostInfo {
+  long long kept;
+  unsigned long long edges;
+  long long rounds;
+  unsigned long long cand_total, cand_worst;
+  unsigned int heavy_units, light_units;
+};
+
 // candidate counters: one per shard, each alone in a 256-byte slot (returning
 // atomics on words that share a cache line serialise at the memory side)
 constexpr int kCandStride = 32;  // in unsigned long long
@@ -120,12 +130,19 @@ template <int KIND>
 __global__ __launch_bounds__(256) void nms_prep_kernel(const float *__restrict__ dets, int64_t n,
                                                        QuadRec *__restrict__ rec,
                                                        float4 *__restrict__ iv,
+                                                       float *__restrict__ ar,
                                                        uint4 *__restrict__ part,
                                                        const int32_t *__restrict__ group,
                                                        const float *__restrict__ thrs,
-                                                       float thr) {
+                                                       float thr, uint4 *__restrict__ zero,
+                                                       size_t zero_vecs) {
   constexpr int S = KIND ? 9 : 6;
   __shared__ uint4 wred[4];
+  // clear the counters / flags / histogram of this call (nothing reads them before the
+  // next kernel): saves the separate fill launch
+  for (size_t z = (size_t)blockIdx.x * blockDim.x + threadIdx.x; z < zero_vecs;
+       z += (size_t)gridDim.x * blockDim.x)
+    zero[z] = make_uint4(0u, 0u, 0u, 0u);
   uint32_t mxh = 0, mxl = 0, myh = 0, myl = 0;
   for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n;
        b += (int64_t)gridDim.x * blockDim.x) {
@@ -140,6 +157,7 @@ __global__ __launch_bounds__(256) void nms_prep_kernel(const float *__restrict__
     r.group = group ? group[b] : 0;
     r.thr = thrs ? thrs[b] : thr;
     rec[b] = r;
+    ar[b] = q.area;
     float4 v;
     nms_interval(q.ox, q.ex, v.x, v.y);
     nms_interval(q.oy, q.ey, v.z, v.w);
@@ -296,7 +314,7 @@ __global__ __launch_bounds__(256) void nms_scatter_kernel(const uint32_t *__rest
 // one block = one tile of 256 spatial positions
 __global__ __launch_bounds__(256) void nms_permute_kernel(const uint2 *__restrict__ qb,
                                                           const uint32_t *__restrict__ sid,
-                                                          const QuadRec *__restrict__ rec,
+                                                          const float *__restrict__ ar_in,
                                                           int64_t n, uint2 *__restrict__ qs,
                                                           float *__restrict__ as,
                                                           uint2 *__restrict__ tbox,
@@ -308,7 +326,7 @@ __global__ __launch_bounds__(256) void nms_permute_kernel(const uint2 *__restric
   if (s < n) {
     const uint32_t id = sid[s];
     o = qb[id];
-    ar = rec[id].area;
+    ar = ar_in[id];
   }
   qs[s] = o;
   as[s] = ar;
@@ -618,7 +636,7 @@ __global__ __launch_bounds__(64 * kNmsWaves) void nms_scan_kernel(const uint2 *_
   }
 }
 
-// ---- 7: clip kernel -----------------------------------------------------------------------
+// ---- narrow-phase helpers (clip kernel and the direct scan) ------------------------------
 __device__ __forceinline__ void load_rec(const QuadRec *__restrict__ rec, uint32_t p, Quad &q,
                                          uint32_t &key, int &grp, float &thr) {
   const float4 *r = reinterpret_cast<const float4 *>(rec + p);
@@ -638,6 +656,193 @@ __device__ __forceinline__ void swap_if(bool c, float &a, float &b) {
   a = t;
 }
 
+// One candidate pair: the edge points from the box that PRECEDES in the greedy order
+// (smaller score key, then smaller index) to the other one; the clip always takes the
+// preceding box as the subject A, exactly like the i-before-j loop of nms_cpu.cpp:35-58.
+__device__ __forceinline__ bool clip_pair(const QuadRec *__restrict__ rec, uint2 pr, uint32_t &src,
+                                          uint32_t &dst) {
+  Quad A, B;
+  uint32_t ka, kb;
+  int ga, gb;
+  float ta, tb;
+  load_rec(rec, pr.x, A, ka, ga, ta);
+  load_rec(rec, pr.y, B, kb, gb, tb);
+  const bool b_first = (kb < ka) || (kb == ka && pr.y < pr.x);
+  const float thr = b_first ? tb : ta;  // the earlier box's threshold
+  src = b_first ? pr.y : pr.x;
+  dst = b_first ? pr.x : pr.y;
+  swap_if(b_first, A.ox, B.ox); swap_if(b_first, A.oy, B.oy);
+  swap_if(b_first, A.ex, B.ex); swap_if(b_first, A.ey, B.ey);
+  swap_if(b_first, A.area, B.area);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { swap_if(b_first, A.rx[k], B.rx[k]); swap_if(b_first, A.ry[k], B.ry[k]); }
+  const float ov = quad_overlap(A, B, 0);
+  return (ga == gb) && (ov >= thr);
+}
+
+// hits of one wave -> its shard's edge segment (+ the in-degree of the targets)
+__device__ __forceinline__ void push_edges(bool hit, uint32_t src, uint32_t dst, uint2 *__restrict__ eseg,
+                                           unsigned long long segcap,
+                                           unsigned long long *__restrict__ ecnt, int *__restrict__ cnt,
+                                           int lane) {
+  const uint64_t mk = __ballot(hit);
+  if (mk) {
+    const int leader = __ffsll((long long)mk) - 1;
+    unsigned long long pos0 = 0;
+    if (lane == leader) pos0 = atomicAdd(ecnt, (unsigned long long)__popcll(mk));
+    pos0 = __shfl(pos0, leader);
+    if (hit) {
+      const unsigned long long pos = pos0 + __popcll(mk & ((1ull << lane) - 1ull));
+      if (pos < segcap) eseg[pos] = make_uint2(src, dst);
+      atomicAdd(&cnt[dst], 1);
+    }
+  }
+}
+
+// ---- 6b: direct scan + clip (medium n, no spatial sort) --------------------------------
+// Below a few ten thousand boxes the spatial sort costs more LAUNCHES (quantise, cell
+// scan, scatter, permute, cull: ~5 us each, latency-bound) than it saves work: all
+// nt (nt + 1) / 2 tile pairs are scanned on the float intervals of the prep kernel.
+// One wave = up to 32 rows x 256 columns (4 per lane); a row is four v_readlane, the
+// test is four v_cmp per pair whose lane masks are combined on the scalar unit -- the
+// masks ARE the ballots, so candidates are pushed without a second pass.  Positions
+// are box ids here.  A batch of 64 raw candidates is pruned AND clipped by the wave
+// that found it (the GPU is far from full at these sizes; a separate clip launch would
+// cost more than the idle lanes).  grid = (row parts, column tiles).
+__device__ __forceinline__ bool prune_aabb_f(const Prune &pr, float4 a, float ra, float4 b, float ca) {
+  const float w = max_sel(min_sel(a.y, b.y) - max_sel(a.x, b.x), 0.0f);
+  const float h = max_sel(min_sel(a.w, b.w) - max_sel(a.z, b.z), 0.0f);
+  const float I = (w * h) * 1.00001f;   // >= true AABB overlap (the intervals carry a margin)
+  return I * (1.0f + pr.thr) >= (pr.thr * (ra + ca)) * 0.999999f;
+}
+
+struct DirectOut {
+  const float4 *__restrict__ iv;
+  const float *__restrict__ ar;
+  const QuadRec *__restrict__ rec;
+  uint2 *__restrict__ eseg;                 // this wave's edge segment
+  unsigned long long segcap;
+  unsigned long long *__restrict__ ccnt;    // candidate statistics (not an index)
+  unsigned long long *__restrict__ ecnt;
+  int *__restrict__ cnt;
+};
+
+__device__ __forceinline__ void nms_flush_direct(const uint2 *q, int count, const Prune &pr,
+                                                 const DirectOut &o, int lane) {
+  bool keep = lane < count;
+  uint2 e = make_uint2(0u, 0u);
+  if (keep) {
+    e = q[lane];
+    if (pr.thr > 0.0f) {
+      const float4 a = o.iv[e.x], b = o.iv[e.y];
+      const float ra = o.ar[e.x], ca = o.ar[e.y];
+      keep = prune_area(pr, ra, ca) && prune_aabb_f(pr, a, ra, b, ca);
+    }
+  }
+  const uint64_t mk = __ballot(keep);
+  if (mk == 0) return;
+  if (lane == 0) atomicAdd(o.ccnt, (unsigned long long)__popcll(mk));
+  bool hit = false;
+  uint32_t src = 0, dst = 0;
+  if (keep) hit = clip_pair(o.rec, e, src, dst);
+  push_edges(hit, src, dst, o.eseg, o.segcap, o.ecnt, o.cnt, lane);
+}
+
+__device__ __forceinline__ float4 direct_interval(const float4 *__restrict__ iv, uint32_t i, uint32_t n) {
+  const float inf = __builtin_huge_valf();
+  float4 v = make_float4(inf, -inf, inf, -inf);   // meets nothing
+  if (i < n) {
+    const float4 t = iv[i];
+    if (t.x <= t.y) v = t;   // isolated (non-finite) boxes keep the sentinel
+  }
+  return v;
+}
+
+template <bool DIAG>
+__device__ __forceinline__ void nms_direct_rows(float4 rv, int nrows, uint32_t sa0, uint32_t sb0,
+                                                uint32_t rp0, const float4 (&cv)[4], const Prune &pr,
+                                                const DirectOut &o, uint2 *q, int &qn, int lane) {
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+  const uint32_t sbl = sb0 + lane * kNmsColsPerLane;
+  for (int r = 0; r < nrows; ++r) {
+    const float xlo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rv.x), r));
+    const float xhi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rv.y), r));
+    const float ylo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rv.z), r));
+    const float yhi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rv.w), r));
+    uint64_t m[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      m[c] = __ballot(xlo <= cv[c].y) & __ballot(cv[c].x <= xhi) & __ballot(ylo <= cv[c].w) & __ballot(cv[c].z <= yhi);
+    if (DIAG) {   // only pairs (row, col) with col > row exist in a diagonal tile
+      const uint32_t rp = rp0 + (uint32_t)r;   // row position inside the tile
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const uint32_t L = (rp >= (uint32_t)c) ? ((rp - (uint32_t)c) >> 2) + 1u : 0u;   // lanes with 4 lane + c <= rp
+        m[c] &= (L >= 64u) ? 0ull : (~0ull << L);
+      }
+    }
+    if ((m[0] | m[1]) | (m[2] | m[3])) {
+      const uint32_t sa = sa0 + (uint32_t)r;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (m[c]) {
+          if ((m[c] >> lane) & 1ull) q[qn + __popcll(m[c] & lt_mask)] = make_uint2(sa, sbl + (uint32_t)c);
+          qn += __popcll(m[c]);
+        }
+      }
+      while (qn >= 64) {
+        qn -= 64;
+        __builtin_amdgcn_wave_barrier();
+        nms_flush_direct(q + qn, 64, pr, o, lane);
+      }
+    }
+  }
+}
+
+// rows_per_wave (a power of two <= 32): fewer rows per wave = more waves, for the small
+// n where a few hundred 32-row waves would leave most of the chip idle
+__global__ __launch_bounds__(64 * kNmsWaves) void nms_scan_direct_kernel(const float4 *__restrict__ iv,
+                                                                const float *__restrict__ ar,
+                                                                const QuadRec *__restrict__ rec,
+                                                                uint32_t n, int rows_per_wave, float thr,
+                                                                uint2 *__restrict__ edges,
+                                                                unsigned long long segcap,
+                                                                unsigned long long *__restrict__ ccnts,
+                                                                int *__restrict__ cnt) {
+  __shared__ uint2 queue[kNmsWaves][kNmsQueue];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t B = blockIdx.y;
+  const uint32_t part = blockIdx.x * kNmsWaves + wave;     // rows [part * rpw, + rpw) of the whole array
+  const uint32_t sa0 = part * (uint32_t)rows_per_wave, sb0 = B * kTile;
+  const uint32_t A = sa0 / kTile;
+  if (A > B || sa0 >= n) return;   // (no block-wide barrier in this kernel)
+  uint2 *q = queue[wave];
+  int qn = 0;
+  const uint32_t gw = (blockIdx.y * gridDim.x + blockIdx.x) * kNmsWaves + wave;
+  const int shard = (int)(gw & (kShards - 1));
+  DirectOut o;
+  o.iv = iv; o.ar = ar; o.rec = rec;
+  o.eseg = edges + (size_t)shard * segcap;
+  o.segcap = segcap;
+  o.ccnt = ccnts + (size_t)shard * kCandStride;
+  o.ecnt = ccnts + (size_t)(kShards + shard) * kCandStride;
+  o.cnt = cnt;
+  Prune pr;
+  pr.thr = thr; pr.cpx = 0.0f; pr.cpy = 0.0f;
+  const float4 rv = direct_interval(iv, (lane < rows_per_wave) ? sa0 + lane : n, n);
+  float4 cv[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) cv[c] = direct_interval(iv, sb0 + lane * kNmsColsPerLane + c, n);
+  if (A == B) nms_direct_rows<true>(rv, rows_per_wave, sa0, sb0, sa0 - sb0, cv, pr, o, q, qn, lane);
+  else nms_direct_rows<false>(rv, rows_per_wave, sa0, sb0, 0u, cv, pr, o, q, qn, lane);
+  if (qn > 0) {
+    __builtin_amdgcn_wave_barrier();
+    nms_flush_direct(q, qn, pr, o, lane);
+  }
+}
+
+// ---- 7: clip kernel -----------------------------------------------------------------------
 // One candidate pair per lane.  The edge points from the box that PRECEDES in the
 // greedy order (smaller score key, then smaller index) to the other one; the clip
 // always takes the preceding box as the subject A, exactly like the i-before-j
@@ -663,38 +868,8 @@ __global__ __launch_bounds__(256) void nms_clip_kernel(const uint2 *__restrict__
     const unsigned long long e = base + lane;
     bool hit = false;
     uint32_t src = 0, dst = 0;
-    if (e < total) {
-      const uint2 pr = cand[e];
-      Quad A, B;
-      uint32_t ka, kb;
-      int ga, gb;
-      float ta, tb;
-      load_rec(rec, pr.x, A, ka, ga, ta);
-      load_rec(rec, pr.y, B, kb, gb, tb);
-      const bool b_first = (kb < ka) || (kb == ka && pr.y < pr.x);
-      const float thr = b_first ? tb : ta;  // the earlier box's threshold
-      src = b_first ? pr.y : pr.x;
-      dst = b_first ? pr.x : pr.y;
-      swap_if(b_first, A.ox, B.ox); swap_if(b_first, A.oy, B.oy);
-      swap_if(b_first, A.ex, B.ex); swap_if(b_first, A.ey, B.ey);
-      swap_if(b_first, A.area, B.area);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) { swap_if(b_first, A.rx[k], B.rx[k]); swap_if(b_first, A.ry[k], B.ry[k]); }
-      const float ov = quad_overlap(A, B, 0);
-      hit = (ga == gb) && (ov >= thr);
-    }
-    const uint64_t mk = __ballot(hit);
-    if (mk) {
-      const int leader = __ffsll((long long)mk) - 1;
-      unsigned long long pos0 = 0;
-      if (lane == leader) pos0 = atomicAdd(ecnt, (unsigned long long)__popcll(mk));
-      pos0 = __shfl(pos0, leader);
-      if (hit) {
-        const unsigned long long pos = pos0 + __popcll(mk & ((1ull << lane) - 1ull));
-        if (pos < segcap) eseg[pos] = make_uint2(src, dst);
-        atomicAdd(&cnt[dst], 1);
-      }
-    }
+    if (e < total) hit = clip_pair(rec, cand[e], src, dst);
+    push_edges(hit, src, dst, eseg, segcap, ecnt, cnt, lane);
   }
 }
 
@@ -710,12 +885,17 @@ __device__ __forceinline__ int ld_cnt(int *p) {
 // One workgroup walks the live edge list until it is empty, compacting it in
 // place each round (reads of a 1024-edge chunk complete before its writes, and
 // the write cursor never passes the chunk being read).
+// COMPACT: the same workgroup also writes the ascending keep indices and the host info
+// (medium n: two more launches would cost more than the serial compaction).
+template <bool COMPACT>
 __global__ __launch_bounds__(1024) void nms_resolve_kernel(uint2 *__restrict__ edges,
                                                            unsigned long long segcap,
                                                            uint8_t *__restrict__ state,
                                                            int *__restrict__ cnt,
                                                            NmsCounters *__restrict__ ctr,
-                                                           const unsigned long long *__restrict__ ccnts) {
+                                                           const unsigned long long *__restrict__ ccnts,
+                                                           int64_t n, int64_t *__restrict__ keep_out,
+                                                           NmsHostInfo *__restrict__ hinfo) {
   __shared__ long long pre[kShards + 1];   // virtual start of every edge segment
   __shared__ int overflow;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -835,6 +1015,46 @@ __global__ __launch_bounds__(1024) void nms_resolve_kernel(uint2 *__restrict__ e
     if (stalled >= 2) break;
   }
   if (tid == 0) ctr->rounds = rounds;
+  if (COMPACT) {
+    __shared__ int csum[16];
+    long long kbase = 0;
+    for (int64_t c0 = 0; c0 < n; c0 += 1024) {
+      const int64_t i = c0 + tid;
+      bool f = false;
+      if (i < n) {
+        const uint8_t st = ld_state(state + i);
+        f = (st == kKept) || (st == kUndecided && ld_cnt(cnt + i) == 0);
+      }
+      const uint64_t mk = __ballot(f);
+      if (lane == 0) csum[wave] = __popcll(mk);
+      __syncthreads();
+      int off = 0, tot = 0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int v = csum[k];
+        off += (k < wave) ? v : 0;
+        tot += v;
+      }
+      if (f) keep_out[kbase + off + __popcll(mk & ((1ull << lane) - 1ull))] = i;
+      kbase += tot;
+      __syncthreads();
+    }
+    if (wave == 0) {
+      unsigned long long v = ccnts[(size_t)lane * kCandStride], mx = v;
+      const unsigned long long ev = ccnts[(size_t)(kShards + lane) * kCandStride];
+      mx = ev > mx ? ev : mx;   // fullest segment of either kind
+      for (int o = 32; o > 0; o >>= 1) {
+        v += __shfl_xor(v, o);
+        const unsigned long long t = __shfl_xor(mx, o);
+        mx = t > mx ? t : mx;
+      }
+      if (lane == 0) {
+        hinfo->kept = kbase; hinfo->edges = (unsigned long long)pre[kShards]; hinfo->rounds = rounds;
+        hinfo->cand_total = v; hinfo->cand_worst = mx;
+        hinfo->heavy_units = 0u; hinfo->light_units = 0u;
+      }
+    }
+  }
 }
 
 // ---- 9: compaction --------------------------------------------------------------
@@ -865,7 +1085,8 @@ __global__ __launch_bounds__(1024) void nms_write_kernel(const uint8_t *__restri
                                                          const int *__restrict__ blockcnt,
                                                          int64_t *__restrict__ keep,
                                                          NmsCounters *__restrict__ ctr,
-                                                         const unsigned long long *__restrict__ ccnts) {
+                                                         const unsigned long long *__restrict__ ccnts,
+                                                         NmsHostInfo *__restrict__ hinfo) {
   __shared__ int wsum[16];
   __shared__ long long sbase;
   __shared__ long long red[16];
@@ -894,8 +1115,7 @@ __global__ __launch_bounds__(1024) void nms_write_kernel(const uint8_t *__restri
     tot += v;
   }
   if (f) keep[sbase + off + __popcll(mk & ((1ull << lane) - 1ull))] = i;
-  if (blockIdx.x == gridDim.x - 1 && tid == 0) ctr->kept = sbase + tot;
-  if (blockIdx.x == 0 && wave == 0) {  // fold the padded shard counters for the host
+  if (blockIdx.x == gridDim.x - 1 && wave == 0) {  // fold the padded shard counters for the host
     unsigned long long v = ccnts[(size_t)lane * kCandStride], mx = v;
     const unsigned long long ev = ccnts[(size_t)(kShards + lane) * kCandStride];
     mx = ev > mx ? ev : mx;   // fullest segment of either kind
@@ -904,7 +1124,11 @@ __global__ __launch_bounds__(1024) void nms_write_kernel(const uint8_t *__restri
       const unsigned long long t = __shfl_xor(mx, o);
       mx = t > mx ? t : mx;
     }
-    if (lane == 0) { ctr->cand_total = v; ctr->cand_worst = mx; }
+    if (lane == 0) {
+      hinfo->kept = sbase + tot; hinfo->edges = ctr->edges; hinfo->rounds = ctr->rounds;
+      hinfo->cand_total = v; hinfo->cand_worst = mx;
+      hinfo->heavy_units = ctr->heavy_units; hinfo->light_units = ctr->light_units;
+    }
   }
 }
 
@@ -915,7 +1139,9 @@ __global__ __launch_bounds__(1024) void nms_write_kernel(const uint8_t *__restri
 // pruning, same edge/resolve formulation; state lives in LDS, records and edges in
 // the caller's workspace.
 constexpr int kSmallMax = 1024;          // one box per thread
-constexpr int kFusedDefault = 384;       // largest n routed to the fused kernel (measured crossover ~500)
+constexpr int kFusedDefault = 128;       // largest n routed to the fused kernel (the direct path is faster above)
+constexpr int kDirectDefault = 16384;    // largest n routed to the direct (unsorted) scan
+constexpr int kDirectMax = 65536;
 
 template <int KIND>
 __global__ __launch_bounds__(1024) void nms_small_kernel(const float *__restrict__ dets, int n,
@@ -926,7 +1152,7 @@ __global__ __launch_bounds__(1024) void nms_small_kernel(const float *__restrict
                                                          uint2 *__restrict__ edges,
                                                          unsigned int ecap,
                                                          int64_t *__restrict__ keep,
-                                                         NmsCounters *__restrict__ ctr) {
+                                                         NmsHostInfo *__restrict__ hinfo) {
   constexpr int S = KIND ? 9 : 6;
   __shared__ uint2 qiv[kSmallMax];            // packed (lo, hi|G)
   __shared__ float area[kSmallMax];
@@ -1146,11 +1372,12 @@ __global__ __launch_bounds__(1024) void nms_small_kernel(const float *__restrict
   }
   if (f) keep[off + __popcll(mk & lt_mask)] = tid;
   if (tid == 0) {
-    ctr->edges = found;
-    ctr->kept = tot;
-    ctr->rounds = rounds;
-    ctr->cand_total = found;
-    ctr->cand_worst = found > ecap ? (unsigned long long)found : 0ull;   // host: overflow if > segcap
+    hinfo->edges = found;
+    hinfo->kept = tot;
+    hinfo->rounds = rounds;
+    hinfo->cand_total = found;
+    hinfo->cand_worst = 0ull;
+    hinfo->heavy_units = 0u; hinfo->light_units = 0u;
   }
 }
 
@@ -1168,7 +1395,7 @@ static thread_local NmsProfile g_prof;
 
 // ---- workspace layout ------------------------------------------------------------
 struct NmsLayout {
-  size_t rec, iv, part, qb, ckey, sid, qs, as, cellpx, tbox, sbox, zero_begin, state, cnt, ctr, ccnts, hist,
+  size_t rec, iv, ar, part, qb, ckey, sid, qs, as, cellpx, tbox, sbox, zero_begin, state, cnt, ctr, ccnts, hist,
       zero_end, blockcnt, cands, edges, total;
   unsigned long long cap;         // candidate pairs == overlap edges capacity
   unsigned long long unit_worst;  // every (sub-tile, tile) unit there can be
@@ -1188,6 +1415,7 @@ static int nms_layout(int64_t n, int64_t edge_capacity, NmsLayout &L) {
   auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
   L.rec = take(nn * sizeof(QuadRec));
   L.iv = take(nn * sizeof(float4));
+  L.ar = take(nn * sizeof(float));
   L.part = take(kPrepBlocks * sizeof(uint4));
   L.qb = take(nn * sizeof(uint2));
   L.ckey = take(nn * 4);
@@ -1279,6 +1507,7 @@ extern "C" int obb_nms_grouped_f32(const float *dets_dev, int64_t n, int kind, f
   char *ws = static_cast<char *>(workspace_dev);
   QuadRec *rec = reinterpret_cast<QuadRec *>(ws + L.rec);
   float4 *iv = reinterpret_cast<float4 *>(ws + L.iv);
+  float *ar = reinterpret_cast<float *>(ws + L.ar);
   uint4 *part = reinterpret_cast<uint4 *>(ws + L.part);
   uint2 *qb = reinterpret_cast<uint2 *>(ws + L.qb);
   uint32_t *ckey = reinterpret_cast<uint32_t *>(ws + L.ckey);
@@ -1303,6 +1532,16 @@ extern "C" int obb_nms_grouped_f32(const float *dets_dev, int64_t n, int kind, f
   unsigned pblocks = (unsigned)((n + 255) / 256);
   if (pblocks > (unsigned)kPrepBlocks) pblocks = kPrepBlocks;
 
+  // result counters arrive in pinned host memory written by the last kernel
+  static thread_local NmsHostInfo *hinfo = nullptr;
+  if (!hinfo) {
+    void *p = nullptr;
+    OBB_HIP_TRY(hipHostMalloc(&p, 256, hipHostMallocPortable | hipHostMallocMapped));
+    hinfo = static_cast<NmsHostInfo *>(p);
+  }
+  NmsHostInfo *hinfo_dev = nullptr;
+  OBB_HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&hinfo_dev), hinfo, 0));
+
   NmsProfile &prof = g_prof;
   const bool timed = prof.on;
   if (timed && !prof.created) {
@@ -1310,21 +1549,24 @@ extern "C" int obb_nms_grouped_f32(const float *dets_dev, int64_t n, int kind, f
     prof.created = true;
   }
 #define OBB_PHASE(k) do { if (timed && (prof.level >= 2 || (k) == 3 || (k) == 4)) OBB_HIP_TRY(hipEventRecord(prof.ev[k], st)); } while (0)
-  int64_t fused_max = kFusedDefault;
-  if (const char *e = getenv("OBB_NMS_FUSED_MAX")) fused_max = atoll(e);   // tuning knob
+  int64_t fused_max = kFusedDefault, direct_max = kDirectDefault;
+  if (const char *e = getenv("OBB_NMS_FUSED_MAX")) fused_max = atoll(e);     // tuning knobs
+  if (const char *e = getenv("OBB_NMS_DIRECT_MAX")) direct_max = atoll(e);
   if (fused_max > kSmallMax) fused_max = kSmallMax;
-  if (n <= fused_max && !getenv("OBB_NMS_NO_FUSED")) {
+  if (direct_max > kDirectMax) direct_max = kDirectMax;
+  const bool fused = n <= fused_max && !getenv("OBB_NMS_NO_FUSED");
+  const bool direct = !fused && n <= direct_max;
+  if (fused) {
     // fused single-launch path; the edge list may use the whole pair capacity
     const unsigned long long ecap64 = 2ull * cap;
     const unsigned int ecap = ecap64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned int)ecap64;
     if (kind == OBB_KIND_RBOX)
-      hipLaunchKernelGGL(nms_small_kernel<0>, dim3(1), dim3(1024), 0, st, dets_dev, (int)n, iou_thr, group_dev, thr_dev, rec, cands, ecap, keep_dev, ctr);
+      hipLaunchKernelGGL(nms_small_kernel<0>, dim3(1), dim3(1024), 0, st, dets_dev, (int)n, iou_thr, group_dev, thr_dev, rec, cands, ecap, keep_dev, hinfo_dev);
     else
-      hipLaunchKernelGGL(nms_small_kernel<1>, dim3(1), dim3(1024), 0, st, dets_dev, (int)n, iou_thr, group_dev, thr_dev, rec, cands, ecap, keep_dev, ctr);
+      hipLaunchKernelGGL(nms_small_kernel<1>, dim3(1), dim3(1024), 0, st, dets_dev, (int)n, iou_thr, group_dev, thr_dev, rec, cands, ecap, keep_dev, hinfo_dev);
     OBB_LAUNCH_CHECK();
-    NmsCounters hs;
-    OBB_HIP_TRY(hipMemcpyAsync(&hs, ctr, sizeof(hs), hipMemcpyDeviceToHost, st));
     OBB_HIP_TRY(hipStreamSynchronize(st));
+    const NmsHostInfo hs = *hinfo;
     if (timed) { for (int k = 0; k < kPhases; ++k) prof.ms[k] = 0.0f; prof.have = true; }
     if (info_host) {
       info_host[0] = hs.kept;
@@ -1340,65 +1582,86 @@ extern "C" int obb_nms_grouped_f32(const float *dets_dev, int64_t n, int kind, f
     }
     return OBB_OK;
   }
-  // phase 0: clear + prep + quantise
+  // threshold-aware pruning needs ONE threshold: off when per-box thresholds are given
+  const float prune_thr = thr_dev ? 0.0f : iou_thr;
+  // phase 0: prep (+ clears the counters) [+ quantise]
   OBB_PHASE(0);
-  OBB_HIP_TRY(hipMemsetAsync(ws + L.zero_begin, 0, L.zero_end - L.zero_begin, st));
-  if (kind == OBB_KIND_RBOX)
-    hipLaunchKernelGGL(nms_prep_kernel<0>, dim3(pblocks), dim3(256), 0, st, dets_dev, n, rec, iv, part, group_dev, thr_dev, iou_thr);
-  else
-    hipLaunchKernelGGL(nms_prep_kernel<1>, dim3(pblocks), dim3(256), 0, st, dets_dev, n, rec, iv, part, group_dev, thr_dev, iou_thr);
-  OBB_LAUNCH_CHECK();
-  // cells ~ n/16 .. n/4, a power of 4 in [4096, 65536]
-  int hbits = 6;
-  while (hbits < 8 && (1ll << (2 * hbits)) * 16 < n) ++hbits;
-  hipLaunchKernelGGL(nms_quant_kernel, dim3(pblocks), dim3(256), 0, st, iv, n, part, (int)pblocks, qb, ckey, hist, hbits, cellpx);
-  OBB_LAUNCH_CHECK();
-  // phase 1: spatial sort
-  OBB_PHASE(1);
-  if (hbits == 6) hipLaunchKernelGGL(nms_cellscan_kernel<4>, dim3(1), dim3(1024), 0, st, hist);
-  else if (hbits == 7) hipLaunchKernelGGL(nms_cellscan_kernel<16>, dim3(1), dim3(1024), 0, st, hist);
-  else hipLaunchKernelGGL(nms_cellscan_kernel<64>, dim3(1), dim3(1024), 0, st, hist);
-  OBB_LAUNCH_CHECK();
-  hipLaunchKernelGGL(nms_scatter_kernel, dim3(pblocks), dim3(256), 0, st, ckey, n, hist, sid);
-  OBB_LAUNCH_CHECK();
-  // phase 2: permute + tile boxes + tile-pair culling
-  OBB_PHASE(2);
-  hipLaunchKernelGGL(nms_permute_kernel, dim3((unsigned)nt), dim3(kTile), 0, st, qb, sid, rec, n, qs, as, tbox, sbox);
-  OBB_LAUNCH_CHECK();
-  hipLaunchKernelGGL(nms_cull_kernel, dim3((unsigned)nt, (unsigned)((nt + kCullChunk - 1) / kCullChunk)), dim3(256), 0, st, tbox, sbox, nt, units, ucap, ctr);
-  OBB_LAUNCH_CHECK();
-  // phase 3: scan (broad phase)
-  OBB_PHASE(3);
   {
-    const long long maxblocks = ((long long)L.unit_worst + kNmsWaves - 1) / kNmsWaves;
-    long long pb = kScanBlocks;
-    if (const char *e = getenv("OBB_NMS_SCAN_BLOCKS")) pb = atoll(e) > 0 ? atoll(e) : pb;  // tuning knob
-    const unsigned gb = (unsigned)(maxblocks < pb ? maxblocks : pb);
-    // threshold-aware pruning needs ONE threshold: off when per-box thresholds are given
-    const float prune_thr = thr_dev ? 0.0f : iou_thr;
-    hipLaunchKernelGGL(nms_scan_kernel, dim3(gb), dim3(64 * kNmsWaves), 0, st, qs, as, cellpx, prune_thr, sid, tbox, nt, units, ucap, cands, segcap, ctr, ccnts);
+    // the direct path never touches the cell histogram
+    const size_t zbytes = (direct ? L.hist : L.zero_end) - L.zero_begin;
+    uint4 *zero = reinterpret_cast<uint4 *>(ws + L.zero_begin);
+    if (kind == OBB_KIND_RBOX)
+      hipLaunchKernelGGL(nms_prep_kernel<0>, dim3(pblocks), dim3(256), 0, st, dets_dev, n, rec, iv, ar, part, group_dev, thr_dev, iou_thr, zero, zbytes / sizeof(uint4));
+    else
+      hipLaunchKernelGGL(nms_prep_kernel<1>, dim3(pblocks), dim3(256), 0, st, dets_dev, n, rec, iv, ar, part, group_dev, thr_dev, iou_thr, zero, zbytes / sizeof(uint4));
     OBB_LAUNCH_CHECK();
   }
-  // phase 4: clip (narrow phase)
-  OBB_PHASE(4);
-  hipLaunchKernelGGL(nms_clip_kernel, dim3(kClipBlocksPerShard, kShards), dim3(256), 0, st, cands, segcap, rec, edges, ctr, ccnts, cnt);
-  OBB_LAUNCH_CHECK();
-  // phase 5: resolve
-  OBB_PHASE(5);
-  hipLaunchKernelGGL(nms_resolve_kernel, dim3(1), dim3(1024), 0, st, edges, segcap, state, cnt, ctr, ccnts);
-  OBB_LAUNCH_CHECK();
-  // phase 6: compaction
-  OBB_PHASE(6);
-  const unsigned cblocks = (unsigned)((n + 1023) / 1024);
-  hipLaunchKernelGGL(nms_count_kernel, dim3(cblocks), dim3(1024), 0, st, state, cnt, n, blockcnt);
-  OBB_LAUNCH_CHECK();
-  hipLaunchKernelGGL(nms_write_kernel, dim3(cblocks), dim3(1024), 0, st, state, cnt, n, blockcnt, keep_dev, ctr, ccnts);
-  OBB_LAUNCH_CHECK();
-  OBB_PHASE(7);
+  if (direct) {
+    OBB_PHASE(1); OBB_PHASE(2);
+    OBB_PHASE(3);
+    // 32 rows per wave; fewer (more waves) while that leaves most SIMDs without one
+    int rpw = kSubRows;
+    while (rpw > 4 && ((n + rpw - 1) / rpw) * (long long)(nt + 1) / 2 < 2048) rpw >>= 1;
+    const unsigned nparts = (unsigned)((n + rpw - 1) / rpw);
+    hipLaunchKernelGGL(nms_scan_direct_kernel, dim3((nparts + kNmsWaves - 1) / kNmsWaves, (unsigned)nt), dim3(64 * kNmsWaves), 0, st,
+                       iv, ar, rec, (uint32_t)n, rpw, prune_thr, edges, segcap, ccnts, cnt);
+    OBB_LAUNCH_CHECK();
+    OBB_PHASE(4);
+    OBB_PHASE(5);
+    hipLaunchKernelGGL(nms_resolve_kernel<true>, dim3(1), dim3(1024), 0, st, edges, segcap, state, cnt, ctr, ccnts, n, keep_dev, hinfo_dev);
+    OBB_LAUNCH_CHECK();
+    OBB_PHASE(6);
+    OBB_PHASE(7);
+  } else {
+    // cells ~ n/16 .. n/4, a power of 4 in [4096, 65536]
+    int hbits = 6;
+    while (hbits < 8 && (1ll << (2 * hbits)) * 16 < n) ++hbits;
+    hipLaunchKernelGGL(nms_quant_kernel, dim3(pblocks), dim3(256), 0, st, iv, n, part, (int)pblocks, qb, ckey, hist, hbits, cellpx);
+    OBB_LAUNCH_CHECK();
+    // phase 1: spatial sort
+    OBB_PHASE(1);
+    if (hbits == 6) hipLaunchKernelGGL(nms_cellscan_kernel<4>, dim3(1), dim3(1024), 0, st, hist);
+    else if (hbits == 7) hipLaunchKernelGGL(nms_cellscan_kernel<16>, dim3(1), dim3(1024), 0, st, hist);
+    else hipLaunchKernelGGL(nms_cellscan_kernel<64>, dim3(1), dim3(1024), 0, st, hist);
+    OBB_LAUNCH_CHECK();
+    hipLaunchKernelGGL(nms_scatter_kernel, dim3(pblocks), dim3(256), 0, st, ckey, n, hist, sid);
+    OBB_LAUNCH_CHECK();
+    // phase 2: permute + tile boxes + unit culling
+    OBB_PHASE(2);
+    hipLaunchKernelGGL(nms_permute_kernel, dim3((unsigned)nt), dim3(kTile), 0, st, qb, sid, ar, n, qs, as, tbox, sbox);
+    OBB_LAUNCH_CHECK();
+    hipLaunchKernelGGL(nms_cull_kernel, dim3((unsigned)nt, (unsigned)((nt + kCullChunk - 1) / kCullChunk)), dim3(256), 0, st, tbox, sbox, nt, units, ucap, ctr);
+    OBB_LAUNCH_CHECK();
+    // phase 3: scan (broad phase)
+    OBB_PHASE(3);
+    {
+      const long long maxblocks = ((long long)L.unit_worst + kNmsWaves - 1) / kNmsWaves;
+      long long pb = kScanBlocks;
+      if (const char *e = getenv("OBB_NMS_SCAN_BLOCKS")) pb = atoll(e) > 0 ? atoll(e) : pb;  // tuning knob
+      const unsigned gb = (unsigned)(maxblocks < pb ? maxblocks : pb);
+      hipLaunchKernelGGL(nms_scan_kernel, dim3(gb), dim3(64 * kNmsWaves), 0, st, qs, as, cellpx, prune_thr, sid, tbox, nt, units, ucap, cands, segcap, ctr, ccnts);
+      OBB_LAUNCH_CHECK();
+    }
+    // phase 4: clip (narrow phase)
+    OBB_PHASE(4);
+    hipLaunchKernelGGL(nms_clip_kernel, dim3(kClipBlocksPerShard, kShards), dim3(256), 0, st, cands, segcap, rec, edges, ctr, ccnts, cnt);
+    OBB_LAUNCH_CHECK();
+    // phase 5: resolve
+    OBB_PHASE(5);
+    hipLaunchKernelGGL(nms_resolve_kernel<false>, dim3(1), dim3(1024), 0, st, edges, segcap, state, cnt, ctr, ccnts, n, keep_dev, hinfo_dev);
+    OBB_LAUNCH_CHECK();
+    // phase 6: compaction
+    OBB_PHASE(6);
+    const unsigned cblocks = (unsigned)((n + 1023) / 1024);
+    hipLaunchKernelGGL(nms_count_kernel, dim3(cblocks), dim3(1024), 0, st, state, cnt, n, blockcnt);
+    OBB_LAUNCH_CHECK();
+    hipLaunchKernelGGL(nms_write_kernel, dim3(cblocks), dim3(1024), 0, st, state, cnt, n, blockcnt, keep_dev, ctr, ccnts, hinfo_dev);
+    OBB_LAUNCH_CHECK();
+    OBB_PHASE(7);
+  }
 #undef OBB_PHASE
-  NmsCounters h;
-  OBB_HIP_TRY(hipMemcpyAsync(&h, ctr, sizeof(h), hipMemcpyDeviceToHost, st));
   OBB_HIP_TRY(hipStreamSynchronize(st));
+  const NmsHostInfo h = *hinfo;
   if (timed) {
     for (int k = 0; k < kPhases; ++k) {
       prof.ms[k] = 0.0f;
@@ -1406,10 +1669,10 @@ extern "C" int obb_nms_grouped_f32(const float *dets_dev, int64_t n, int kind, f
     }
     prof.have = true;
   }
-  static_assert(kShards == 64, "the fold in nms_write_kernel uses one wave");
+  static_assert(kShards == 64, "the counter folds use one wave");
   if (getenv("OBB_NMS_DEBUG"))
-    fprintf(stderr, "obb_nms: n=%lld tiles=%d heavy_units=%u light_units=%u (capacity %u) candidates=%llu edges=%llu\n",
-            (long long)n, nt, h.heavy_units, h.light_units, ucap, h.cand_total, h.edges);
+    fprintf(stderr, "obb_nms: n=%lld tiles=%d path=%s heavy_units=%u light_units=%u (capacity %u) candidates=%llu edges=%llu\n",
+            (long long)n, nt, direct ? "direct" : "sorted", h.heavy_units, h.light_units, ucap, h.cand_total, h.edges);
   const unsigned long long ncand = h.cand_total, worst = h.cand_worst;
   if (info_host) {
     info_host[0] = h.kept;
@@ -1428,7 +1691,7 @@ extern "C" int obb_nms_grouped_f32(const float *dets_dev, int64_t n, int kind, f
   }
   if (worst > segcap) {
     // capacity that fits the fullest candidate / edge segment on a retry, with 25 %
-    // slack: the tile-pair -> shard assignment varies slightly from run to run
+    // slack: the unit -> shard assignment varies slightly from run to run
     unsigned long long need = worst * kShards;
     need += need / 4 + 1024;
     if (info_host) { info_host[0] = 0; info_host[3] = (int64_t)need; }

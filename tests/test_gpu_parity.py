@@ -137,11 +137,21 @@ def test_overlaps_cpu_tensor_roundtrip():
 # --------------------------------------------------------------------------
 # rotated NMS: keep indices bit-exact
 # --------------------------------------------------------------------------
+@pytest.fixture(params=['auto', 'sorted'])
+def nms_path(request, monkeypatch):
+    """The library routes n <= 384 to the fused kernel, n <= 16384 to the direct
+    (unsorted) scan and the rest to the spatially sorted pipeline; 'sorted' forces the
+    last one for every n above the fused limit, so each test covers both."""
+    if request.param == 'sorted':
+        monkeypatch.setenv('OBB_NMS_DIRECT_MAX', '0')
+    return request.param
+
+
 @pytest.mark.parametrize('n,canvas', [(1, 10), (2, 10), (63, 64), (64, 64), (65, 64), (257, 128),
                                       (1000, 256), (1025, 256), (5000, 512), (5000, 2048),
                                       (20000, 2048), (20000, 8000)])
 @pytest.mark.parametrize('thr', [0.3, 0.5])
-def test_rnms_bit_exact(n, canvas, thr):
+def test_rnms_bit_exact(n, canvas, thr, nms_path):
     from aidet_amd import rnms
     d = oracle.synth_boxes(n, canvas, 100 + n)
     kept, inds = rnms(t(d), thr)
@@ -166,7 +176,7 @@ def test_rnms_cfg2_100k_sparse_and_dense():
         assert again.numel() == len(got)
 
 
-def test_rnms_score_ties_lower_index_first():
+def test_rnms_score_ties_lower_index_first(nms_path):
     from aidet_amd import rnms
     d = oracle.synth_boxes(3000, 256, 11)
     d[:, 5] = np.round(d[:, 5] * 8) / 8  # 9 distinct scores -> massive ties
@@ -174,7 +184,7 @@ def test_rnms_score_ties_lower_index_first():
     assert np.array_equal(inds.cpu().numpy(), oracle.rnms(d, 0.4))
 
 
-def test_rnms_all_identical_boxes():
+def test_rnms_all_identical_boxes(nms_path):
     """Pathological: every pair overlaps (n^2/2 edges); forces the workspace retry."""
     from aidet_amd import rnms
     n = 3000
@@ -186,7 +196,7 @@ def test_rnms_all_identical_boxes():
     assert np.array_equal(inds.cpu().numpy(), ref)
 
 
-def test_rnms_chain_dependency():
+def test_rnms_chain_dependency(nms_path):
     """A long suppress/keep chain: box k overlaps only k-1 and k+1 (many resolve rounds)."""
     from aidet_amd import rnms
     n = 2000
@@ -210,7 +220,7 @@ def test_rnms_threshold_is_greater_equal():
     assert inds.cpu().tolist() == [0]
 
 
-def test_poly_nms_bit_exact():
+def test_poly_nms_bit_exact(nms_path):
     from aidet_amd import poly_nms
     d = oracle.synth_boxes(6000, 512, 21)
     p = np.concatenate([oracle.rbox_to_poly(d).astype(np.float32), d[:, 5:6]], 1)
@@ -339,7 +349,7 @@ def test_thetaobb2pointobb():
 # --------------------------------------------------------------------------
 # grouped NMS, class-wise orchestration, merge
 # --------------------------------------------------------------------------
-def test_grouped_rnms_bit_exact():
+def test_grouped_rnms_bit_exact(nms_path):
     from aidet_amd import rnms
     d = oracle.synth_boxes(8000, 400, 31)
     rng = np.random.default_rng(1)
@@ -474,7 +484,7 @@ def test_rotated_extractor_forward():
             assert np.abs(out[m] - ref).max() <= IOU_TOL
 
 
-def test_rnms_non_finite_boxes_are_inert():
+def test_rnms_non_finite_boxes_are_inert(nms_path):
     """NaN / inf boxes never suppress and are never suppressed (their overlap is 0 or
     NaN on the spec path); the GPU isolates them before the scan."""
     from aidet_amd import rnms
@@ -497,7 +507,7 @@ def test_rnms_non_finite_boxes_are_inert():
     assert inds.cpu().tolist() == list(range(10))
 
 
-def test_rnms_degenerate_and_huge_coordinates():
+def test_rnms_degenerate_and_huge_coordinates(nms_path):
     from aidet_amd import rnms
     rng = np.random.default_rng(8)
     d = oracle.synth_boxes(3000, 200, 9)
@@ -592,8 +602,9 @@ def test_rotated_max_iou_assigner_matches_reference_at_theta0(golden):
 @pytest.mark.parametrize('n,canvas', [(1, 10), (2, 10), (64, 64), (257, 100), (700, 150), (1024, 200),
                                       (1024, 60)])
 def test_rnms_fused_and_general_paths_agree(n, canvas, monkeypatch):
-    """n <= 1024 takes the fused single-launch kernel; OBB_NMS_NO_FUSED=1 forces the
-    general pipeline.  Both must reproduce the oracle (dense canvas 60: ~1e5 edges)."""
+    """n <= 1024 can take the fused single-launch kernel; OBB_NMS_NO_FUSED=1 forces the
+    direct scan, OBB_NMS_DIRECT_MAX=0 on top of it the sorted pipeline.  All three must
+    reproduce the oracle (dense canvas 60: ~1e5 edges)."""
     from aidet_amd import poly_nms, rnms
     d = oracle.synth_boxes(n, canvas, 300 + n)
     g = np.random.default_rng(n).integers(0, 3, n)
@@ -602,14 +613,14 @@ def test_rnms_fused_and_general_paths_agree(n, canvas, monkeypatch):
     p = np.concatenate([oracle.rbox_to_poly(d).astype(np.float32), d[:, 5:6]], 1)
     refp = oracle.poly_nms(p, 0.45)
     monkeypatch.setenv('OBB_NMS_FUSED_MAX', '1024')   # route every case to the fused kernel
-    for no_fused in ('', '1'):
-        if no_fused:
+    for path in ('fused', 'direct', 'sorted'):
+        if path != 'fused':
             monkeypatch.setenv('OBB_NMS_NO_FUSED', '1')
-        else:
-            monkeypatch.delenv('OBB_NMS_NO_FUSED', raising=False)
-        assert np.array_equal(rnms(t(d), 0.45)[1].cpu().numpy(), ref)
-        assert np.array_equal(rnms(t(d), 0.45, groups=g)[1].cpu().numpy(), refg)
-        assert np.array_equal(poly_nms(t(p), 0.45)[1].cpu().numpy(), refp)
+        if path == 'sorted':
+            monkeypatch.setenv('OBB_NMS_DIRECT_MAX', '0')
+        assert np.array_equal(rnms(t(d), 0.45)[1].cpu().numpy(), ref), path
+        assert np.array_equal(rnms(t(d), 0.45, groups=g)[1].cpu().numpy(), refg), path
+        assert np.array_equal(poly_nms(t(p), 0.45)[1].cpu().numpy(), refp), path
 
 
 def test_small_nms_latency_smoke():
@@ -629,7 +640,7 @@ def test_small_nms_latency_smoke():
     print('rnms n=1000: %.1f us per call' % (fused * 1e6))
 
 
-def test_general_convex_quads_gpu():
+def test_general_convex_quads_gpu(nms_path):
     """pointobb_overlaps / poly_nms on convex quads that are not rectangles"""
     from aidet_amd import poly_nms
     from aidet_amd.rbbox_geometry import pointobb_overlaps
@@ -646,7 +657,7 @@ def test_general_convex_quads_gpu():
 
 
 @pytest.mark.parametrize('seed', range(6))
-def test_rnms_randomised_shapes_and_clusters(seed):
+def test_rnms_randomised_shapes_and_clusters(seed, nms_path):
     """clustered scenes, extreme aspect ratios, mixed scales, random thresholds"""
     from aidet_amd import rnms
     rng = np.random.default_rng(1000 + seed)
