@@ -473,35 +473,38 @@ __device__ __forceinline__ bool prune_aabb(const Prune &pr, uint32_t rlo, uint32
 // batch of 64 is pruned with one candidate per lane (the two bounds cost ~40 VALU: per
 // batch, not per candidate), and the survivors go to the wave's global candidate list
 // as (box id, box id) with one returning atomic per batch.
-__device__ __forceinline__ void nms_flush(const uint2 *q, int count, const Prune &pr,
-                                          const uint2 *__restrict__ qs, const float *__restrict__ as,
-                                          const uint32_t *__restrict__ sid,
-                                          uint2 *__restrict__ cand, unsigned long long segcap,
-                                          unsigned long long *__restrict__ ccnt, int lane) {
-  bool keep = lane < count;
-  uint2 ids = make_uint2(0u, 0u);
-  if (keep) {
-    const uint2 e = q[lane];
-    const uint2 a = qs[e.x], b = qs[e.y];
-    const float ra = as[e.x], ca = as[e.y];
-    ids = make_uint2(sid[e.x], sid[e.y]);
-    if (pr.thr > 0.0f) keep = prune_area(pr, ra, ca) && prune_aabb(pr, a.x, a.y, ra, b.x, b.y, ca);
-  }
-  const uint64_t mk = __ballot(keep);
-  if (mk == 0) return;
-  unsigned long long base = 0;
-  if (lane == 0) base = atomicAdd(ccnt, (unsigned long long)__popcll(mk));
-  base = __shfl(base, 0) + (unsigned long long)__popcll(mk & ((1ull << lane) - 1ull));
-  if (keep && base < segcap) cand[base] = ids;
-}
+struct SortedSink {
+  Prune pr;
+  const uint2 *__restrict__ qs;
+  const float *__restrict__ as;
+  const uint32_t *__restrict__ sid;
+  uint2 *__restrict__ cand;                 // this wave's candidate segment
+  unsigned long long segcap;
+  unsigned long long *__restrict__ ccnt;
 
-template <bool DIAG>
+  __device__ __forceinline__ void flush(const uint2 *q, int count, int lane) const {
+    bool keep = lane < count;
+    uint2 ids = make_uint2(0u, 0u);
+    if (keep) {
+      const uint2 e = q[lane];
+      const uint2 a = qs[e.x], b = qs[e.y];
+      const float ra = as[e.x], ca = as[e.y];
+      ids = make_uint2(sid[e.x], sid[e.y]);
+      if (pr.thr > 0.0f) keep = prune_area(pr, ra, ca) && prune_aabb(pr, a.x, a.y, ra, b.x, b.y, ca);
+    }
+    const uint64_t mk = __ballot(keep);
+    if (mk == 0) return;
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(ccnt, (unsigned long long)__popcll(mk));
+    base = __shfl(base, 0) + (unsigned long long)__popcll(mk & ((1ull << lane) - 1ull));
+    if (keep && base < segcap) cand[base] = ids;
+  }
+};
+
+template <bool DIAG, class Sink>
 __device__ __forceinline__ void nms_scan_rows(uint2 rv, uint32_t rows, uint32_t sa0, uint32_t sb0,
-                                              const uint2 (&col)[4], const Prune &pr,
-                                              const uint2 *__restrict__ qs, const float *__restrict__ as,
-                                              const uint32_t *__restrict__ sid, uint2 *q, int &qn,
-                                              uint2 *__restrict__ cand, unsigned long long segcap,
-                                              unsigned long long *__restrict__ ccnt, int lane) {
+                                              const uint2 (&col)[4], const Sink &sink, uint2 *q, int &qn,
+                                              int lane) {
   const uint64_t lt_mask = (1ull << lane) - 1ull;
   const uint32_t sbl = sb0 + lane * kNmsColsPerLane;
   while (rows) {   // `rows`: the rows of this sub-tile that meet the column tile's box
@@ -565,7 +568,7 @@ __device__ __forceinline__ void nms_scan_rows(uint2 rv, uint32_t rows, uint32_t 
       while (qn >= 64) {  // prune + flush a full batch
         qn -= 64;
         __builtin_amdgcn_wave_barrier();
-        nms_flush(q + qn, 64, pr, qs, as, sid, cand, segcap, ccnt, lane);
+        sink.flush(q + qn, 64, lane);
       }
     }
   }
@@ -593,14 +596,16 @@ __global__ __launch_bounds__(64 * kNmsWaves) void nms_scan_kernel(const uint2 *_
   const uint32_t gw = blockIdx.x * kNmsWaves + wave;       // global wave id
   const uint32_t nw = gridDim.x * kNmsWaves;
   const int shard = (int)(gw & (kShards - 1));
-  uint2 *cand = cands + (size_t)shard * segcap;
-  unsigned long long *ccnt = ccnts + (size_t)shard * kCandStride;
+  SortedSink sink;
+  sink.pr.thr = thr; sink.pr.cpx = cellpx[0]; sink.pr.cpy = cellpx[1];
+  sink.qs = qs; sink.as = as; sink.sid = sid;
+  sink.cand = cands + (size_t)shard * segcap;
+  sink.segcap = segcap;
+  sink.ccnt = ccnts + (size_t)shard * kCandStride;
   const unsigned int nheavy = ctr->heavy_units, nlight = ctr->light_units;
   if (nheavy + nlight > ucap) return;   // unit list overflow: reported by the host, nothing valid to scan
   const unsigned int ndiag = (unsigned int)nt * kSub;
   const unsigned int nun = ndiag + nheavy + nlight;
-  Prune pr;
-  pr.thr = thr; pr.cpx = cellpx[0]; pr.cpy = cellpx[1];
   for (unsigned int k = gw; k < nun; k += nw) {
     uint32_t A, B, sub;
     if (k < ndiag) {
@@ -627,12 +632,12 @@ __global__ __launch_bounds__(64 * kNmsWaves) void nms_scan_kernel(const uint2 *_
     }
     // only rows whose interval meets the column tile's box can have a candidate
     const uint32_t rows = (uint32_t)__ballot(rl && qdisjoint(rv.x, rv.y, tb.x, tb.y) == 0u);
-    if (A == B) nms_scan_rows<true>(rv, rows, sa0, sb0, col, pr, qs, as, sid, q, qn, cand, segcap, ccnt, lane);
-    else nms_scan_rows<false>(rv, rows, sa0, sb0, col, pr, qs, as, sid, q, qn, cand, segcap, ccnt, lane);
+    if (A == B) nms_scan_rows<true>(rv, rows, sa0, sb0, col, sink, q, qn, lane);
+    else nms_scan_rows<false>(rv, rows, sa0, sb0, col, sink, q, qn, lane);
   }
   if (qn > 0) {  // final partial batch, once per wave
     __builtin_amdgcn_wave_barrier();
-    nms_flush(q, qn, pr, qs, as, sid, cand, segcap, ccnt, lane);
+    sink.flush(q, qn, lane);
   }
 }
 
@@ -700,13 +705,13 @@ __device__ __forceinline__ void push_edges(bool hit, uint32_t src, uint32_t dst,
 }
 
 // ---- 6b: direct scan + clip (medium n, no spatial sort) --------------------------------
-// Below a few ten thousand boxes the spatial sort costs more LAUNCHES (quantise, cell
-// scan, scatter, permute, cull: ~5 us each, latency-bound) than it saves work: all
-// nt (nt + 1) / 2 tile pairs are scanned on the float intervals of the prep kernel.
-// One wave = up to 32 rows x 256 columns (4 per lane); a row is four v_readlane, the
-// test is four v_cmp per pair whose lane masks are combined on the scalar unit -- the
-// masks ARE the ballots, so candidates are pushed without a second pass.  Positions
-// are box ids here.  A batch of 64 raw candidates is pruned AND clipped by the wave
+// Below ~10^4 boxes the spatial sort costs more LAUNCHES (quantise, cell scan, scatter,
+// permute, cull: ~5 us each, latency-bound) than it saves work: all nt (nt + 1) / 2 tile
+// pairs are scanned.  One wave = up to 32 rows x 256 columns (positions are box ids);
+// it quantises its columns in the frame of THEIR bounding box (rows clamp into it --
+// floor of a clamped monotone map is monotone, so no real overlap is lost), skips the
+// rows that miss that box, and runs the same 3-op packed test as the sorted scan.  A
+// batch of 64 raw candidates is pruned on the float intervals AND clipped by the wave
 // that found it (the GPU is far from full at these sizes; a separate clip launch would
 // cost more than the idle lanes).  grid = (row parts, column tiles).
 __device__ __forceinline__ bool prune_aabb_f(const Prune &pr, float4 a, float ra, float4 b, float ca) {
@@ -716,7 +721,8 @@ __device__ __forceinline__ bool prune_aabb_f(const Prune &pr, float4 a, float ra
   return I * (1.0f + pr.thr) >= (pr.thr * (ra + ca)) * 0.999999f;
 }
 
-struct DirectOut {
+struct DirectSink {
+  Prune pr;
   const float4 *__restrict__ iv;
   const float *__restrict__ ar;
   const QuadRec *__restrict__ rec;
@@ -725,28 +731,29 @@ struct DirectOut {
   unsigned long long *__restrict__ ccnt;    // candidate statistics (not an index)
   unsigned long long *__restrict__ ecnt;
   int *__restrict__ cnt;
-};
 
-__device__ __forceinline__ void nms_flush_direct(const uint2 *q, int count, const Prune &pr,
-                                                 const DirectOut &o, int lane) {
-  bool keep = lane < count;
-  uint2 e = make_uint2(0u, 0u);
-  if (keep) {
-    e = q[lane];
-    if (pr.thr > 0.0f) {
-      const float4 a = o.iv[e.x], b = o.iv[e.y];
-      const float ra = o.ar[e.x], ca = o.ar[e.y];
-      keep = prune_area(pr, ra, ca) && prune_aabb_f(pr, a, ra, b, ca);
+  __device__ __forceinline__ void flush(const uint2 *q, int count, int lane) const {
+    bool keep = lane < count;
+    uint2 e = make_uint2(0u, 0u);
+    if (keep) {
+      e = q[lane];
+      const float4 a = iv[e.x], b = iv[e.y];
+      // (the quantised test is coarser than the float intervals: re-test them)
+      keep = (a.x <= b.y) && (b.x <= a.y) && (a.z <= b.w) && (b.z <= a.w);
+      if (keep && pr.thr > 0.0f) {
+        const float ra = ar[e.x], ca = ar[e.y];
+        keep = prune_area(pr, ra, ca) && prune_aabb_f(pr, a, ra, b, ca);
+      }
     }
+    const uint64_t mk = __ballot(keep);
+    if (mk == 0) return;
+    if (lane == 0) atomicAdd(ccnt, (unsigned long long)__popcll(mk));
+    bool hit = false;
+    uint32_t src = 0, dst = 0;
+    if (keep) hit = clip_pair(rec, e, src, dst);
+    push_edges(hit, src, dst, eseg, segcap, ecnt, cnt, lane);
   }
-  const uint64_t mk = __ballot(keep);
-  if (mk == 0) return;
-  if (lane == 0) atomicAdd(o.ccnt, (unsigned long long)__popcll(mk));
-  bool hit = false;
-  uint32_t src = 0, dst = 0;
-  if (keep) hit = clip_pair(o.rec, e, src, dst);
-  push_edges(hit, src, dst, o.eseg, o.segcap, o.ecnt, o.cnt, lane);
-}
+};
 
 __device__ __forceinline__ float4 direct_interval(const float4 *__restrict__ iv, uint32_t i, uint32_t n) {
   const float inf = __builtin_huge_valf();
@@ -758,45 +765,16 @@ __device__ __forceinline__ float4 direct_interval(const float4 *__restrict__ iv,
   return v;
 }
 
-template <bool DIAG>
-__device__ __forceinline__ void nms_direct_rows(float4 rv, int nrows, uint32_t sa0, uint32_t sb0,
-                                                uint32_t rp0, const float4 (&cv)[4], const Prune &pr,
-                                                const DirectOut &o, uint2 *q, int &qn, int lane) {
-  const uint64_t lt_mask = (1ull << lane) - 1ull;
-  const uint32_t sbl = sb0 + lane * kNmsColsPerLane;
-  for (int r = 0; r < nrows; ++r) {
-    const float xlo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rv.x), r));
-    const float xhi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rv.y), r));
-    const float ylo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rv.z), r));
-    const float yhi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rv.w), r));
-    uint64_t m[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-      m[c] = __ballot(xlo <= cv[c].y) & __ballot(cv[c].x <= xhi) & __ballot(ylo <= cv[c].w) & __ballot(cv[c].z <= yhi);
-    if (DIAG) {   // only pairs (row, col) with col > row exist in a diagonal tile
-      const uint32_t rp = rp0 + (uint32_t)r;   // row position inside the tile
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const uint32_t L = (rp >= (uint32_t)c) ? ((rp - (uint32_t)c) >> 2) + 1u : 0u;   // lanes with 4 lane + c <= rp
-        m[c] &= (L >= 64u) ? 0ull : (~0ull << L);
-      }
-    }
-    if ((m[0] | m[1]) | (m[2] | m[3])) {
-      const uint32_t sa = sa0 + (uint32_t)r;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        if (m[c]) {
-          if ((m[c] >> lane) & 1ull) q[qn + __popcll(m[c] & lt_mask)] = make_uint2(sa, sbl + (uint32_t)c);
-          qn += __popcll(m[c]);
-        }
-      }
-      while (qn >= 64) {
-        qn -= 64;
-        __builtin_amdgcn_wave_barrier();
-        nms_flush_direct(q + qn, 64, pr, o, lane);
-      }
-    }
-  }
+__device__ __forceinline__ uint32_t qclamp(float x, float b, float s) {
+  float u = floorf((x - b) * s);
+  u = u < 0.0f ? 0.0f : (u > (float)kQMax ? (float)kQMax : u);
+  return (uint32_t)u;
+}
+
+__device__ __forceinline__ uint2 direct_quant(float4 v, float bx, float by, float sx, float sy) {
+  if (!(v.x <= v.y)) return make_uint2(kSentLo, kSentHi);
+  return make_uint2(qclamp(v.x, bx, sx) | (qclamp(v.z, by, sy) << 16),
+                    (qclamp(v.y, bx, sx) | (qclamp(v.w, by, sy) << 16)) | kGuard);
 }
 
 // rows_per_wave (a power of two <= 32): fewer rows per wave = more waves, for the small
@@ -821,24 +799,43 @@ __global__ __launch_bounds__(64 * kNmsWaves) void nms_scan_direct_kernel(const f
   int qn = 0;
   const uint32_t gw = (blockIdx.y * gridDim.x + blockIdx.x) * kNmsWaves + wave;
   const int shard = (int)(gw & (kShards - 1));
-  DirectOut o;
-  o.iv = iv; o.ar = ar; o.rec = rec;
-  o.eseg = edges + (size_t)shard * segcap;
-  o.segcap = segcap;
-  o.ccnt = ccnts + (size_t)shard * kCandStride;
-  o.ecnt = ccnts + (size_t)(kShards + shard) * kCandStride;
-  o.cnt = cnt;
-  Prune pr;
-  pr.thr = thr; pr.cpx = 0.0f; pr.cpy = 0.0f;
-  const float4 rv = direct_interval(iv, (lane < rows_per_wave) ? sa0 + lane : n, n);
-  float4 cv[4];
+  DirectSink sink;
+  sink.pr.thr = thr; sink.pr.cpx = 0.0f; sink.pr.cpy = 0.0f;
+  sink.iv = iv; sink.ar = ar; sink.rec = rec;
+  sink.eseg = edges + (size_t)shard * segcap;
+  sink.segcap = segcap;
+  sink.ccnt = ccnts + (size_t)shard * kCandStride;
+  sink.ecnt = ccnts + (size_t)(kShards + shard) * kCandStride;
+  sink.cnt = cnt;
+  const float4 rvf = direct_interval(iv, (lane < rows_per_wave) ? sa0 + lane : n, n);
+  float4 cvf[4];
 #pragma unroll
-  for (int c = 0; c < 4; ++c) cv[c] = direct_interval(iv, sb0 + lane * kNmsColsPerLane + c, n);
-  if (A == B) nms_direct_rows<true>(rv, rows_per_wave, sa0, sb0, sa0 - sb0, cv, pr, o, q, qn, lane);
-  else nms_direct_rows<false>(rv, rows_per_wave, sa0, sb0, 0u, cv, pr, o, q, qn, lane);
+  for (int c = 0; c < 4; ++c) cvf[c] = direct_interval(iv, sb0 + lane * kNmsColsPerLane + c, n);
+  // frame = bounding box of the columns
+  float fxl = min_sel(min_sel(cvf[0].x, cvf[1].x), min_sel(cvf[2].x, cvf[3].x));
+  float fxh = max_sel(max_sel(cvf[0].y, cvf[1].y), max_sel(cvf[2].y, cvf[3].y));
+  float fyl = min_sel(min_sel(cvf[0].z, cvf[1].z), min_sel(cvf[2].z, cvf[3].z));
+  float fyh = max_sel(max_sel(cvf[0].w, cvf[1].w), max_sel(cvf[2].w, cvf[3].w));
+  for (int o = 32; o > 0; o >>= 1) {
+    fxl = min_sel(fxl, __shfl_xor(fxl, o)); fxh = max_sel(fxh, __shfl_xor(fxh, o));
+    fyl = min_sel(fyl, __shfl_xor(fyl, o)); fyh = max_sel(fyh, __shfl_xor(fyh, o));
+  }
+  if (!(fxl <= fxh)) return;   // no finite column
+  const float rx = fxh - fxl, ry = fyh - fyl;
+  const float sx = rx > 0.0f ? (float)kQMax / rx : 0.0f, sy = ry > 0.0f ? (float)kQMax / ry : 0.0f;
+  uint2 col[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) col[c] = direct_quant(cvf[c], fxl, fyl, sx, sy);
+  // rows that meet the columns' box (sentinel rows never do); lanes >= rows_per_wave hold a
+  // sentinel, which is also the padding row of nms_scan_rows
+  const bool meets = (rvf.x <= fxh) && (fxl <= rvf.y) && (rvf.z <= fyh) && (fyl <= rvf.w);
+  const uint2 rv = meets ? direct_quant(rvf, fxl, fyl, sx, sy) : make_uint2(kSentLo, kSentHi);
+  const uint32_t rows = (uint32_t)__ballot(meets);
+  if (A == B) nms_scan_rows<true>(rv, rows, sa0, sb0, col, sink, q, qn, lane);
+  else nms_scan_rows<false>(rv, rows, sa0, sb0, col, sink, q, qn, lane);
   if (qn > 0) {
     __builtin_amdgcn_wave_barrier();
-    nms_flush_direct(q, qn, pr, o, lane);
+    sink.flush(q, qn, lane);
   }
 }
 
@@ -1140,7 +1137,7 @@ __global__ __launch_bounds__(1024) void nms_write_kernel(const uint8_t *__restri
 // the caller's workspace.
 constexpr int kSmallMax = 1024;          // one box per thread
 constexpr int kFusedDefault = 128;       // largest n routed to the fused kernel (the direct path is faster above)
-constexpr int kDirectDefault = 16384;    // largest n routed to the direct (unsorted) scan
+constexpr int kDirectDefault = 10240;    // largest n routed to the direct (unsorted) scan (measured crossover 11-12k)
 constexpr int kDirectMax = 65536;
 
 template <int KIND>

@@ -139,7 +139,7 @@ def test_overlaps_cpu_tensor_roundtrip():
 # --------------------------------------------------------------------------
 @pytest.fixture(params=['auto', 'sorted'])
 def nms_path(request, monkeypatch):
-    """The library routes n <= 384 to the fused kernel, n <= 16384 to the direct
+    """The library routes n <= 128 to the fused kernel, n <= 10240 to the direct
     (unsorted) scan and the rest to the spatially sorted pipeline; 'sorted' forces the
     last one for every n above the fused limit, so each test covers both."""
     if request.param == 'sorted':
