@@ -214,6 +214,15 @@ def extras(dev, oracle):
         res[tag] = {'ms': round(ms, 4), 'pairs_per_s': round(m * m / (ms * 1e-3), 1),
                     'algorithmic_GBps': round(alg / (ms * 1e-3) / 1e9, 1),
                     'frac_of_8TBps': round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        if m == 1000:   # configs[0]: the CPU path on the same inputs (C oracle, 1 thread)
+            an, bn = a.cpu().numpy(), b.cpu().numpy()
+            t0 = time.perf_counter()
+            ref = oracle.overlaps(an, bn)
+            dt = time.perf_counter() - t0
+            got = rbbox_overlaps(a, b).cpu().numpy()
+            res[tag]['cpu_oracle_ms'] = round(dt * 1e3, 2)
+            res[tag]['cpu_oracle_pairs_per_s'] = round(m * m / dt, 1)
+            res[tag]['max_abs_diff_vs_oracle'] = float(np.abs(got - ref).max())
     # RRoIAlign, configs[2]
     rng = np.random.default_rng(5)
     feat = torch.from_numpy(rng.standard_normal((1, 256, 256, 256)).astype(np.float32)).to(dev)
@@ -224,6 +233,15 @@ def extras(dev, oracle):
     wr = 4 * 512 * 256 * 49
     res['rroi_align_512x256x7x7'] = {'ms': round(ms, 4), 'rois_per_s': round(512 / (ms * 1e-3), 1),
                                      'output_GBps': round(wr / (ms * 1e-3) / 1e9, 1)}
+    # CPU oracle on a bounded sample of the same workload: the first 32 RoIs
+    fn, rn = feat[0].cpu().numpy(), rois[:32].cpu().numpy()
+    t0 = time.perf_counter()
+    ref = oracle.rroi_align_forward(fn[None], rn, 7, 0.25, 2)
+    dt = time.perf_counter() - t0
+    got = layer(feat, rois[:32]).cpu().numpy()
+    res['rroi_align_512x256x7x7']['cpu_oracle_rois_per_s'] = round(32 / dt, 1)
+    res['rroi_align_512x256x7x7']['cpu_oracle_sample'] = 'first 32 RoIs, 1 thread, %.2f s' % dt
+    res['rroi_align_512x256x7x7']['max_abs_diff_vs_oracle'] = float(np.abs(got - ref).max())
     return res
 
 
