@@ -109,3 +109,23 @@ def test_module_construction_mirrors_roi_align():
     layers = [RRoIAlign(spatial_scale=1 / s, **cfg) for s in (4, 8, 16, 32)]
     assert layers[0].out_size == (7, 7)
     assert 'RRoIAlign(out_size=(7, 7), spatial_scale=0.25, sample_num=2' in repr(layers[0])
+
+
+def test_torch_extension_loads_and_validates():
+    """obbops_torch (the ATen-level binding, aidet_amd/csrc/obbops_torch.cpp): importable
+    without a GPU, same version as the C library, reference-style errors."""
+    import torch
+    from aidet_amd import _lib, torch_ext
+    e = torch_ext.ext()
+    assert e.version() == _lib.lib().obb_version()
+    for name in ('rnms', 'poly_nms', 'rnms_grouped', 'poly_nms_grouped', 'rbbox_overlaps',
+                 'rroi_align_forward', 'rroi_align_backward', 'thetaobb2pointobb'):
+        assert callable(getattr(e, name))
+    # empty input needs no device (nms_wrapper.py:50-51); anything else must live on the GPU
+    assert e.rnms(torch.zeros(0, 6), 0.5).dtype == torch.int64
+    with pytest.raises(RuntimeError):
+        e.rnms(torch.zeros(4, 6), 0.5)          # CPU tensor: C++ check -> RuntimeError
+    with pytest.raises(RuntimeError):
+        e.rnms(torch.zeros(4, 5), 0.5)          # wrong shape
+    with pytest.raises(RuntimeError):
+        e.rbbox_overlaps(torch.zeros(2, 5), torch.zeros(2, 5), 'giou', False)

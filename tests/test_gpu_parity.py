@@ -676,3 +676,29 @@ def test_rnms_randomised_shapes_and_clusters(seed, nms_path):
     thr = float(rng.uniform(0.1, 0.8))
     _, inds = rnms(t(d), thr)
     assert np.array_equal(inds.cpu().numpy(), oracle.rnms(d, thr))
+
+
+def test_torch_extension_matches_ctypes_path():
+    """the pybind11/ATen binding and the ctypes wrappers drive the same C ABI"""
+    from aidet_amd import poly_nms, rbbox_overlaps, rnms, rroi_align, torch_ext
+    e = torch_ext.ext()
+    d = oracle.synth_boxes(6000, 700, 91)
+    g = np.random.default_rng(2).integers(0, 4, len(d)).astype(np.int32)
+    dt = t(d)
+    assert np.array_equal(e.rnms(dt, 0.5).cpu().numpy(), oracle.rnms(d, 0.5))
+    assert torch.equal(e.rnms(dt, 0.5), rnms(dt, 0.5)[1])
+    assert np.array_equal(e.rnms_grouped(dt, 0.4, t(g), None).cpu().numpy(), oracle.rnms(d, 0.4, groups=g))
+    p = np.concatenate([oracle.rbox_to_poly(d).astype(np.float32), d[:, 5:6]], 1)
+    assert torch.equal(e.poly_nms(t(p), 0.5), poly_nms(t(p), 0.5)[1])
+    a, b = t(d[:300, :5]), t(d[300:1000, :5])
+    assert torch.equal(e.rbbox_overlaps(a, b, 'iou', False), rbbox_overlaps(a, b))
+    assert torch.equal(e.rbbox_overlaps(a, a, 'iof', True), rbbox_overlaps(a, a, mode='iof', is_aligned=True))
+    assert np.abs(e.thetaobb2pointobb(a).cpu().numpy() - oracle.rbox_to_poly(d[:300])).max() <= 1e-3
+    rng = np.random.default_rng(4)
+    feat = t(rng.standard_normal((2, 8, 40, 40)).astype(np.float32))
+    rois = np.concatenate([rng.integers(0, 2, (20, 1)).astype(np.float32), oracle.synth_boxes(20, 160, 3)[:, :5]], 1)
+    out = e.rroi_align_forward(feat, t(rois), 7, 7, 0.25, 2, 1.0)
+    assert torch.equal(out, rroi_align(feat, t(rois), 7, 0.25, 2))
+    gin = e.rroi_align_backward(torch.ones_like(out), t(rois), 2, 8, 40, 40, 0.25, 2, 1.0)
+    ref = oracle.rroi_align_backward(np.ones(out.shape, np.float32), rois, (2, 8, 40, 40), 0.25, 2)
+    assert np.abs(gin.cpu().numpy() - ref).max() <= 1e-3
