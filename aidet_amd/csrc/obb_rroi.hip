@@ -155,6 +155,8 @@ __device__ __forceinline__ void rroi_forward_direct(const float *__restrict__ fe
 #define OBB_STAGE_FLOATS 6144
 #endif
 constexpr int kStageFloats = OBB_STAGE_FLOATS;  // LDS tile per block (24 KiB)
+constexpr int kWaveFloats = kStageFloats / 4;   // private quarter of a wave (small footprints)
+constexpr int kWavePad = 256;                   // room for the tail lanes of a wave's last DMA instruction
 constexpr int kMaxTabSamples = 256;   // sample table (8 KiB); 7x7 bins x 2x2 samples = 196
 
 struct Footprint { int x0, y0, w, h; };
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(256) void rroi_forward_kernel(
     const float *__restrict__ feat, int B, int C, int H, int W, const float *__restrict__ rois,
     int ph, int pw, float scale, int sample_num, float min_size, int groups_per_block,
     int K, int chunks, float *__restrict__ out) {
-  __shared__ __attribute__((aligned(16))) float tile[kStageFloats + 256];  // + pad for the last wave-instruction
+  __shared__ __attribute__((aligned(16))) float tile[4 * (kWaveFloats + kWavePad)];  // block-wide: kStageFloats + pad
   __shared__ int4 s_off[kMaxTabSamples];      // per sample: 4 footprint-local tap offsets
   __shared__ float4 s_wgt[kMaxTabSamples];    // per sample: 4 bilinear weights
   // XCD-aware block -> (RoI, channel chunk): workgroups are dealt round-robin over the 8
@@ -233,6 +235,79 @@ __global__ __launch_bounds__(256) void rroi_forward_kernel(
     const int lx0 = cl(xl - fp.x0, fp.w), lx1 = cl(xh - fp.x0, fp.w);
     s_off[sidx] = live ? make_int4(ly0 + lx0, ly0 + lx1, ly1 + lx0, ly1 + lx1) : make_int4(0, 0, 0, 0);
     s_wgt[sidx] = make_float4(w[0], w[1], w[2], w[3]);
+  }
+  if (fsz <= kWaveFloats && nb <= 64 && spb <= 4) {
+    // ---- small footprint (the common case): every WAVE stages and reduces its own quarter of
+    // the block's channels in a private LDS region -- no block barriers after this one, so
+    // the four waves (and the other blocks of the CU) drift apart and one wave's DMA latency
+    // hides behind another's gathers.  A lane owns one bin: its <= 4 samples' tap offsets
+    // and weights are read from the table ONCE into registers and reused for every channel.
+    __syncthreads();   // table complete
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float *wt = tile + wave * (kWaveFloats + kWavePad);
+    const int per_wave = (c_end - c_block + 3) >> 2;
+    const int cw0 = c_block + wave * per_wave, cw1 = min(c_end, cw0 + per_wave);
+    int4 so[4];
+    float4 sw[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const bool on = lane < nb && q < spb;
+      so[q] = on ? s_off[lane * spb + q] : make_int4(0, 0, 0, 0);
+      sw[q] = on ? s_wgt[lane * spb + q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const int cpw = kWaveFloats / fsz;               // channels per pass (>= 1)
+    const uint32_t plane32w = (uint32_t)plane;
+    for (int cp = cw0; cp < cw1; cp += cpw) {
+      const int nch = min(cpw, cw1 - cp);
+      const float *src = feat + ((int64_t)f.b * C + cp) * plane + (int64_t)fp.y0 * W + fp.x0;
+      const int total = nch * fsz;
+      if (X4) {
+        const int q4 = fsz >> 2, rw4 = fp.w >> 2, total4 = total >> 2;
+        const uint32_t m_q4 = q4 > 1 ? 0xFFFFFFFFu / (uint32_t)q4 + 1u : 0u;
+        const uint32_t m_r4 = rw4 > 1 ? 0xFFFFFFFFu / (uint32_t)rw4 + 1u : 0u;
+        for (int base = 0; base < total4; base += 64) {
+          const uint32_t idx = (uint32_t)min(base + lane, total4 - 1);
+          const uint32_t c = q4 > 1 ? __umulhi(idx, m_q4) : idx;
+          const uint32_t r = idx - c * (uint32_t)q4;
+          const uint32_t y = rw4 > 1 ? __umulhi(r, m_r4) : r;
+          const uint32_t x = (r - y * (uint32_t)rw4) << 2;
+          const uint32_t off = c * plane32w + y * (uint32_t)W + x;
+          __builtin_amdgcn_global_load_lds(src + off, (__attribute__((address_space(3))) void *)(wt + base * 4), 16, 0, 0);
+        }
+      } else {
+        const uint32_t m_fszw = fsz > 1 ? 0xFFFFFFFFu / (uint32_t)fsz + 1u : 0u;
+        const uint32_t m_ww = fp.w > 1 ? 0xFFFFFFFFu / (uint32_t)fp.w + 1u : 0u;
+        for (int base = 0; base < total; base += 64) {
+          const uint32_t idx = (uint32_t)min(base + lane, total - 1);
+          const uint32_t c = fsz > 1 ? __umulhi(idx, m_fszw) : idx;
+          const uint32_t r = idx - c * (uint32_t)fsz;
+          const uint32_t y = fp.w > 1 ? __umulhi(r, m_ww) : r;
+          const uint32_t x = r - y * (uint32_t)fp.w;
+          const uint32_t off = c * plane32w + y * (uint32_t)W + x;
+          __builtin_amdgcn_global_load_lds(src + off, (__attribute__((address_space(3))) void *)(wt + base), 4, 0, 0);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      for (int c = 0; c < nch; ++c) {
+        const float *p = wt + c * fsz;
+        float acc = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (q < spb) {
+            float v = sw[q].x * p[so[q].x];
+            v = v + sw[q].y * p[so[q].y];
+            v = v + sw[q].z * p[so[q].z];
+            v = v + sw[q].w * p[so[q].w];
+            acc = acc + v;
+          }
+        }
+        if (lane < nb) out[((k * C + cp + c) * (int64_t)nb) + lane] = acc / f.cnt;
+      }
+      // the next pass overwrites this region: its gathers are done (their values were consumed)
+      __builtin_amdgcn_wave_barrier();
+    }
+    return;
   }
   const int cpp = kStageFloats / fsz;                // channels per pass (>= 1)
   const uint32_t m_nb = nb > 1 ? 0xFFFFFFFFu / (uint32_t)nb + 1u : 0u;  // it / nb for it < 2^16
