@@ -233,14 +233,14 @@ def extras(dev, oracle):
     wr = 4 * 512 * 256 * 49
     res['rroi_align_512x256x7x7'] = {'ms': round(ms, 4), 'rois_per_s': round(512 / (ms * 1e-3), 1),
                                      'output_GBps': round(wr / (ms * 1e-3) / 1e9, 1)}
-    # CPU oracle on a bounded sample of the same workload: the first 32 RoIs
-    fn, rn = feat[0].cpu().numpy(), rois[:32].cpu().numpy()
+    # CPU oracle on a bounded sample of the same workload: the first 128 RoIs
+    fn, rn = feat[0].cpu().numpy(), rois[:128].cpu().numpy()
     t0 = time.perf_counter()
     ref = oracle.rroi_align_forward(fn[None], rn, 7, 0.25, 2)
     dt = time.perf_counter() - t0
-    got = layer(feat, rois[:32]).cpu().numpy()
-    res['rroi_align_512x256x7x7']['cpu_oracle_rois_per_s'] = round(32 / dt, 1)
-    res['rroi_align_512x256x7x7']['cpu_oracle_sample'] = 'first 32 RoIs, 1 thread, %.2f s' % dt
+    got = layer(feat, rois[:128]).cpu().numpy()
+    res['rroi_align_512x256x7x7']['cpu_oracle_rois_per_s'] = round(128 / dt, 1)
+    res['rroi_align_512x256x7x7']['cpu_oracle_sample'] = 'first 128 RoIs, 1 thread, %.2f s' % dt
     res['rroi_align_512x256x7x7']['max_abs_diff_vs_oracle'] = float(np.abs(got - ref).max())
     return res
 
