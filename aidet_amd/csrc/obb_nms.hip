@@ -125,25 +125,30 @@ __device__ __forceinline__ uint32_t shfl_xor_u(uint32_t v, int o) {
 }
 
 // ---- 1: prep -------------------------------------------------------------------
-// part[block] = { max key(xhi), max ~key(xlo), max key(yhi), max ~key(ylo) }
+constexpr int kStat = 5;   // per-block statistics of the box centres (doubles)
+// part[block] = { max key(xhi), max ~key(xlo), max key(yhi), max ~key(ylo) } of the block's
+// boxes near its mean centre; pstat[block] = their count and centre sums
 template <int KIND>
 __global__ __launch_bounds__(256) void nms_prep_kernel(const float *__restrict__ dets, int64_t n,
                                                        QuadRec *__restrict__ rec,
                                                        float4 *__restrict__ iv,
                                                        float *__restrict__ ar,
                                                        uint4 *__restrict__ part,
+                                                       double *__restrict__ pstat,
                                                        const int32_t *__restrict__ group,
                                                        const float *__restrict__ thrs,
                                                        float thr, uint4 *__restrict__ zero,
                                                        size_t zero_vecs) {
   constexpr int S = KIND ? 9 : 6;
   __shared__ uint4 wred[4];
+  __shared__ double sred[4][kStat];
+  __shared__ double ssum[kStat];
+  double st[kStat] = {0.0, 0.0, 0.0, 0.0, 0.0};   // count, sum x, sum y, sum x^2, sum y^2 of the centres
   // clear the counters / flags / histogram of this call (nothing reads them before the
   // next kernel): saves the separate fill launch
   for (size_t z = (size_t)blockIdx.x * blockDim.x + threadIdx.x; z < zero_vecs;
        z += (size_t)gridDim.x * blockDim.x)
     zero[z] = make_uint4(0u, 0u, 0u, 0u);
-  uint32_t mxh = 0, mxl = 0, myh = 0, myl = 0;
   for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n;
        b += (int64_t)gridDim.x * blockDim.x) {
     const float *row = dets + b * S;
@@ -169,8 +174,44 @@ __global__ __launch_bounds__(256) void nms_prep_kernel(const float *__restrict__
     if (!fin) { v.x = 1.0f; v.y = -1.0f; v.z = 1.0f; v.w = -1.0f; }  // lo > hi = "isolated"
     iv[b] = v;
     if (fin) {
+      const double cx = 0.5 * ((double)v.x + (double)v.y), cy = 0.5 * ((double)v.z + (double)v.w);
+      st[0] += 1.0; st[1] += cx; st[2] += cy; st[3] += cx * cx; st[4] += cy * cy;
+    }
+  }
+  // Statistics for the ROBUST quantisation frame (nms_quant_kernel): the block's bounding
+  // box and centre sums are taken over its boxes within 3 sigma of the BLOCK's mean centre
+  // only (a uniform block spans 1.7 sigma: nothing is dropped; a stray box at 1e8 is).  Which
+  // boxes shape the frame never changes the result, only how well the grid fits the scene.
+  auto block_sum = [&](double (&v)[kStat]) {   // -> ssum[], valid after the barriers
+#pragma unroll
+    for (int k = 0; k < kStat; ++k)
+      for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o);
+    if ((threadIdx.x & 63) == 0)
+      for (int k = 0; k < kStat; ++k) sred[threadIdx.x >> 6][k] = v[k];
+    __syncthreads();
+    if (threadIdx.x < kStat) ssum[threadIdx.x] = (sred[0][threadIdx.x] + sred[1][threadIdx.x]) + (sred[2][threadIdx.x] + sred[3][threadIdx.x]);
+    __syncthreads();
+  };
+  block_sum(st);
+  double mx = 0.0, my = 0.0, rx = 0.0, ry = 0.0;
+  if (ssum[0] >= 1.0) {
+    mx = ssum[1] / ssum[0]; my = ssum[2] / ssum[0];
+    const double vx = ssum[3] / ssum[0] - mx * mx, vy = ssum[4] / ssum[0] - my * my;
+    rx = 3.0 * sqrt(vx > 0.0 ? vx : 0.0) * 1.000001 + 1e-30; ry = 3.0 * sqrt(vy > 0.0 ? vy : 0.0) * 1.000001 + 1e-30;
+  }
+  __syncthreads();   // ssum is rewritten below
+  uint32_t mxh = 0, mxl = 0, myh = 0, myl = 0;
+  double tr[kStat] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n;
+       b += (int64_t)gridDim.x * blockDim.x) {
+    const float4 v = iv[b];   // (this thread's own store)
+    if (!(v.x <= v.y)) continue;
+    const double cx = 0.5 * ((double)v.x + (double)v.y), cy = 0.5 * ((double)v.z + (double)v.w);
+    const double dx = cx - mx, dy = cy - my;
+    if ((dx < 0.0 ? -dx : dx) <= rx + 1e-9 * (mx < 0.0 ? -mx : mx) && (dy < 0.0 ? -dy : dy) <= ry + 1e-9 * (my < 0.0 ? -my : my)) {
       mxh = max(mxh, fkey(v.y)); mxl = max(mxl, ~fkey(v.x));
       myh = max(myh, fkey(v.w)); myl = max(myl, ~fkey(v.z));
+      tr[0] += 1.0; tr[1] += cx; tr[2] += cy; tr[3] += cx * cx; tr[4] += cy * cy;
     }
   }
   for (int o = 32; o > 0; o >>= 1) {
@@ -178,7 +219,7 @@ __global__ __launch_bounds__(256) void nms_prep_kernel(const float *__restrict__
     myh = max(myh, shfl_xor_u(myh, o)); myl = max(myl, shfl_xor_u(myl, o));
   }
   if ((threadIdx.x & 63) == 0) wred[threadIdx.x >> 6] = make_uint4(mxh, mxl, myh, myl);
-  __syncthreads();
+  block_sum(tr);   // (its barriers also publish wred)
   if (threadIdx.x == 0) {
     uint4 a = wred[0];
     for (int k = 1; k < 4; ++k) {
@@ -186,6 +227,7 @@ __global__ __launch_bounds__(256) void nms_prep_kernel(const float *__restrict__
       a.z = max(a.z, wred[k].z); a.w = max(a.w, wred[k].w);
     }
     part[blockIdx.x] = a;
+    for (int k = 0; k < kStat; ++k) pstat[(size_t)blockIdx.x * kStat + k] = ssum[k];
   }
 }
 
@@ -202,13 +244,19 @@ __device__ __forceinline__ uint32_t spread15(uint32_t v) {  // 15 bits -> even b
 // floor() of a monotone map is monotone, so lo_a <= hi_b ==> q(lo_a) <= q(hi_b):
 // the quantised test never loses a real overlap.
 __global__ __launch_bounds__(256) void nms_quant_kernel(const float4 *__restrict__ iv, int64_t n,
-                                                        const uint4 *__restrict__ part, int nparts,
+                                                        const uint4 *__restrict__ part,
+                                                        const double *__restrict__ pstat, int nparts,
                                                         uint2 *__restrict__ qb,
                                                         uint32_t *__restrict__ ckey,
                                                         uint32_t *__restrict__ hist, int cell_hbits,
                                                         float *__restrict__ cellpx) {
   __shared__ uint4 wred[4];
+  __shared__ double dred[4][kStat];
+  __shared__ double dsum[kStat];
   __shared__ float sb[4];
+  __shared__ float win[4];     // window of the robust frame: x lo, x hi, y lo, y hi
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  // (every block repeats this reduction of <= 1024 partials: cheaper than one more launch)
   uint4 a = make_uint4(0u, 0u, 0u, 0u);
   for (int k = threadIdx.x; k < nparts; k += 256) {
     const uint4 p = part[k];
@@ -218,18 +266,92 @@ __global__ __launch_bounds__(256) void nms_quant_kernel(const float4 *__restrict
     a.x = max(a.x, shfl_xor_u(a.x, o)); a.y = max(a.y, shfl_xor_u(a.y, o));
     a.z = max(a.z, shfl_xor_u(a.z, o)); a.w = max(a.w, shfl_xor_u(a.w, o));
   }
-  if ((threadIdx.x & 63) == 0) wred[threadIdx.x >> 6] = a;
-  __syncthreads();
-  if (threadIdx.x == 0) {
+  if (lane == 0) wred[wv] = a;
+  // ROBUST FRAME.  Any frame gives the same result (coordinates clamp into it, and a
+  // clamped monotone map is monotone), but one far-away box would stretch the bounding
+  // box of the scene until all other boxes share a handful of cells (measured: 0.13 ->
+  // 10 ms at n = 100k for ONE box at 1e8).  So: a first window = mean +- 8 sigma of the
+  // box centres; the frame = bounding box of the prep blocks that lie inside it.
+  auto block_sum = [&](double (&v)[kStat]) {   // -> dsum[], valid after the barrier
+#pragma unroll
+    for (int k = 0; k < kStat; ++k)
+      for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o);
+    if (lane == 0)
+      for (int k = 0; k < kStat; ++k) dred[wv][k] = v[k];
+    __syncthreads();
+    if (threadIdx.x < kStat) dsum[threadIdx.x] = (dred[0][threadIdx.x] + dred[1][threadIdx.x]) + (dred[2][threadIdx.x] + dred[3][threadIdx.x]);
+    __syncthreads();
+  };
+  auto window = [&](float x0, float x1, float y0, float y1) {   // thread 0: dsum -> win[], inside [x0,x1] x [y0,y1]
+    const double cnt = dsum[0];
+    float wx0 = x0, wx1 = x1, wy0 = y0, wy1 = y1;
+    if (cnt >= 1.0) {
+      const double mx = dsum[1] / cnt, my = dsum[2] / cnt;
+      double vx = dsum[3] / cnt - mx * mx, vy = dsum[4] / cnt - my * my;
+      vx = vx > 0.0 ? vx : 0.0; vy = vy > 0.0 ? vy : 0.0;
+      // + the largest box extent does not matter: intervals beyond the window clamp
+      const double rx = 8.0 * sqrt(vx), ry = 8.0 * sqrt(vy);
+      wx0 = max_sel(x0, (float)(mx - rx)); wx1 = min_sel(x1, (float)(mx + rx));
+      wy0 = max_sel(y0, (float)(my - ry)); wy1 = min_sel(y1, (float)(my + ry));
+      if (!(wx0 <= wx1)) { wx0 = x0; wx1 = x1; }
+      if (!(wy0 <= wy1)) { wy0 = y0; wy1 = y1; }
+    }
+    win[0] = wx0; win[1] = wx1; win[2] = wy0; win[3] = wy1;
+  };
+  double sv[kStat] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int k = threadIdx.x; k < nparts; k += 256)
+    for (int j = 0; j < kStat; ++j) sv[j] += pstat[(size_t)k * kStat + j];
+  block_sum(sv);   // (its barriers also publish wred)
+  float bx0 = 0.0f, bx1 = 0.0f, by0 = 0.0f, by1 = 0.0f;   // bounding box of the finite boxes
+  bool any;
+  {
     uint4 m = wred[0];
     for (int k = 1; k < 4; ++k) {
       m.x = max(m.x, wred[k].x); m.y = max(m.y, wred[k].y);
       m.z = max(m.z, wred[k].z); m.w = max(m.w, wred[k].w);
     }
-    const bool any = m.x != 0u;  // at least one finite box
-    const float bx = any ? fkey_inv(~m.y) : 0.0f, by = any ? fkey_inv(~m.w) : 0.0f;
-    const float rx = any ? fkey_inv(m.x) - bx : 0.0f, ry = any ? fkey_inv(m.z) - by : 0.0f;
-    sb[0] = bx; sb[1] = by;
+    any = m.x != 0u;  // at least one finite box
+    if (any) { bx0 = fkey_inv(~m.y); bx1 = fkey_inv(m.x); by0 = fkey_inv(~m.w); by1 = fkey_inv(m.z); }
+  }
+  if (threadIdx.x == 0) window(bx0, bx1, by0, by1);
+  __syncthreads();
+  {
+    // the frame = bounding box of the CLEAN blocks: those whose own bounding box lies inside
+    // the first window (a block with an outlier is dropped whole; without outliers every
+    // block is clean and this is the bounding box of the scene)
+    const float wx0 = win[0], wx1 = win[1], wy0 = win[2], wy1 = win[3];
+    uint4 c = make_uint4(0u, 0u, 0u, 0u);
+    double s2[kStat] = {0.0, 0.0, 0.0, 0.0, 0.0};   // [0]: boxes in clean blocks
+    for (int k = threadIdx.x; k < nparts; k += 256) {
+      const uint4 p = part[k];
+      if (p.x == 0u) continue;   // no finite box in that block
+      const bool inside = fkey_inv(~p.y) >= wx0 && fkey_inv(p.x) <= wx1 && fkey_inv(~p.w) >= wy0 && fkey_inv(p.z) <= wy1;
+      if (inside) {
+        c.x = max(c.x, p.x); c.y = max(c.y, p.y); c.z = max(c.z, p.z); c.w = max(c.w, p.w);
+        s2[0] += pstat[(size_t)k * kStat];
+      }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      c.x = max(c.x, shfl_xor_u(c.x, o)); c.y = max(c.y, shfl_xor_u(c.y, o));
+      c.z = max(c.z, shfl_xor_u(c.z, o)); c.w = max(c.w, shfl_xor_u(c.w, o));
+    }
+    if (lane == 0) wred[wv] = c;   // (the previous contents were consumed before the last barrier)
+    block_sum(s2);
+  }
+  if (threadIdx.x == 0) {
+    // enough clean blocks: their bounding box is the frame (otherwise outliers are everywhere
+    // -- a multi-modal scene -- and the first window stays)
+    if (dsum[0] * 8.0 >= (double)n || dsum[0] >= 4096.0) {
+      uint4 m = wred[0];
+      for (int k = 1; k < 4; ++k) {
+        m.x = max(m.x, wred[k].x); m.y = max(m.y, wred[k].y);
+        m.z = max(m.z, wred[k].z); m.w = max(m.w, wred[k].w);
+      }
+      win[0] = fkey_inv(~m.y); win[1] = fkey_inv(m.x); win[2] = fkey_inv(~m.w); win[3] = fkey_inv(m.z);
+    }
+    const float x0 = win[0], x1 = win[1], y0 = win[2], y1 = win[3];
+    const float rx = any ? x1 - x0 : 0.0f, ry = any ? y1 - y0 : 0.0f;
+    sb[0] = any ? x0 : 0.0f; sb[1] = any ? y0 : 0.0f;
     sb[2] = rx > 0.0f ? (float)kQMax / rx : 0.0f;
     sb[3] = ry > 0.0f ? (float)kQMax / ry : 0.0f;
     if (blockIdx.x == 0) {
@@ -449,6 +571,11 @@ struct Prune {
   float cpx, cpy;  // pixels per quantisation cell (rounded up)
 };
 
+// does a packed interval touch cell 0 or the last cell on either axis?
+__device__ __forceinline__ bool qedge(uint32_t lo, uint32_t hiG) {
+  return (lo & 0x7FFFu) == 0u || (lo & 0x7FFF0000u) == 0u || (hiG & 0x7FFFu) == kQMax || ((hiG >> 16) & 0x7FFFu) == kQMax;
+}
+
 // first (cheap) bound: iou <= min(area)/max(area)
 __device__ __forceinline__ bool prune_area(const Prune &pr, float ra, float ca) {
   const float mn = min_sel(ra, ca), mx = max_sel(ra, ca);
@@ -490,7 +617,12 @@ struct SortedSink {
       const uint2 a = qs[e.x], b = qs[e.y];
       const float ra = as[e.x], ca = as[e.y];
       ids = make_uint2(sid[e.x], sid[e.y]);
-      if (pr.thr > 0.0f) keep = prune_area(pr, ra, ca) && prune_aabb(pr, a.x, a.y, ra, b.x, b.y, ca);
+      if (pr.thr > 0.0f) {
+        // an interval that touches the first or last cell may have been CLAMPED into the frame
+        // (robust frame, nms_quant_kernel): its cells then say nothing about its extent
+        const bool edge = qedge(a.x, a.y) || qedge(b.x, b.y);
+        keep = prune_area(pr, ra, ca) && (edge || prune_aabb(pr, a.x, a.y, ra, b.x, b.y, ca));
+      }
     }
     const uint64_t mk = __ballot(keep);
     if (mk == 0) return;
@@ -1392,7 +1524,7 @@ static thread_local NmsProfile g_prof;
 
 // ---- workspace layout ------------------------------------------------------------
 struct NmsLayout {
-  size_t rec, iv, ar, part, qb, ckey, sid, qs, as, cellpx, tbox, sbox, zero_begin, state, cnt, ctr, ccnts, hist,
+  size_t rec, iv, ar, part, pstat, qb, ckey, sid, qs, as, cellpx, tbox, sbox, zero_begin, state, cnt, ctr, ccnts, hist,
       zero_end, blockcnt, cands, edges, total;
   unsigned long long cap;         // candidate pairs == overlap edges capacity
   unsigned long long unit_worst;  // every (sub-tile, tile) unit there can be
@@ -1414,6 +1546,7 @@ static int nms_layout(int64_t n, int64_t edge_capacity, NmsLayout &L) {
   L.iv = take(nn * sizeof(float4));
   L.ar = take(nn * sizeof(float));
   L.part = take(kPrepBlocks * sizeof(uint4));
+  L.pstat = take((size_t)kPrepBlocks * kStat * sizeof(double));
   L.qb = take(nn * sizeof(uint2));
   L.ckey = take(nn * 4);
   L.sid = take((nt * kTile) * 4);
@@ -1506,6 +1639,7 @@ extern "C" int obb_nms_grouped_f32(const float *dets_dev, int64_t n, int kind, f
   float4 *iv = reinterpret_cast<float4 *>(ws + L.iv);
   float *ar = reinterpret_cast<float *>(ws + L.ar);
   uint4 *part = reinterpret_cast<uint4 *>(ws + L.part);
+  double *pstat = reinterpret_cast<double *>(ws + L.pstat);
   uint2 *qb = reinterpret_cast<uint2 *>(ws + L.qb);
   uint32_t *ckey = reinterpret_cast<uint32_t *>(ws + L.ckey);
   uint32_t *hist = reinterpret_cast<uint32_t *>(ws + L.hist);
@@ -1588,9 +1722,9 @@ extern "C" int obb_nms_grouped_f32(const float *dets_dev, int64_t n, int kind, f
     const size_t zbytes = (direct ? L.hist : L.zero_end) - L.zero_begin;
     uint4 *zero = reinterpret_cast<uint4 *>(ws + L.zero_begin);
     if (kind == OBB_KIND_RBOX)
-      hipLaunchKernelGGL(nms_prep_kernel<0>, dim3(pblocks), dim3(256), 0, st, dets_dev, n, rec, iv, ar, part, group_dev, thr_dev, iou_thr, zero, zbytes / sizeof(uint4));
+      hipLaunchKernelGGL(nms_prep_kernel<0>, dim3(pblocks), dim3(256), 0, st, dets_dev, n, rec, iv, ar, part, pstat, group_dev, thr_dev, iou_thr, zero, zbytes / sizeof(uint4));
     else
-      hipLaunchKernelGGL(nms_prep_kernel<1>, dim3(pblocks), dim3(256), 0, st, dets_dev, n, rec, iv, ar, part, group_dev, thr_dev, iou_thr, zero, zbytes / sizeof(uint4));
+      hipLaunchKernelGGL(nms_prep_kernel<1>, dim3(pblocks), dim3(256), 0, st, dets_dev, n, rec, iv, ar, part, pstat, group_dev, thr_dev, iou_thr, zero, zbytes / sizeof(uint4));
     OBB_LAUNCH_CHECK();
   }
   if (direct) {
@@ -1613,7 +1747,7 @@ extern "C" int obb_nms_grouped_f32(const float *dets_dev, int64_t n, int kind, f
     // cells ~ n/16 .. n/4, a power of 4 in [4096, 65536]
     int hbits = 6;
     while (hbits < 8 && (1ll << (2 * hbits)) * 16 < n) ++hbits;
-    hipLaunchKernelGGL(nms_quant_kernel, dim3(pblocks), dim3(256), 0, st, iv, n, part, (int)pblocks, qb, ckey, hist, hbits, cellpx);
+    hipLaunchKernelGGL(nms_quant_kernel, dim3(pblocks), dim3(256), 0, st, iv, n, part, pstat, (int)pblocks, qb, ckey, hist, hbits, cellpx);
     OBB_LAUNCH_CHECK();
     // phase 1: spatial sort
     OBB_PHASE(1);

@@ -702,3 +702,28 @@ def test_torch_extension_matches_ctypes_path():
     gin = e.rroi_align_backward(torch.ones_like(out), t(rois), 2, 8, 40, 40, 0.25, 2, 1.0)
     ref = oracle.rroi_align_backward(np.ones(out.shape, np.float32), rois, (2, 8, 40, 40), 0.25, 2)
     assert np.abs(gin.cpu().numpy() - ref).max() <= 1e-3
+
+
+@pytest.mark.parametrize('case', ['one_far', 'far_cluster', 'edge_straddlers'])
+def test_rnms_outliers_clamp_into_the_robust_frame(case, nms_path):
+    """Boxes far outside the scene are left out of the quantisation frame of the sorted
+    route and CLAMP into its edge cells (nms_quant_kernel); the keep set must not notice."""
+    from aidet_amd import rnms
+    n = 15000
+    d = oracle.synth_boxes(n, 3000, 123)          # dense enough for a few thousand edges
+    if case == 'one_far':
+        d[7777, 0] = 1.0e8
+        d[7777, 1] = -3.0e7
+    elif case == 'far_cluster':                   # 1 % far away, overlapping each other there
+        idx = np.arange(150) * 100
+        d[idx, 0] = 1.0e6 + (np.arange(150) % 12) * 20.0
+        d[idx, 1] = -5.0e5 + (np.arange(150) // 12) * 20.0
+    else:                                         # huge boxes that cover the frame edge and beyond
+        idx = np.arange(40) * 300
+        d[idx, 2] = 5000.0
+        d[idx, 3] = 9000.0
+        d[idx[:10], 0] = -2000.0
+        d[idx[10:20], 1] = 6000.0
+    for thr in (0.3, 0.6):
+        _, inds = rnms(t(d), thr)
+        assert np.array_equal(inds.cpu().numpy(), oracle.rnms(d, thr)), (case, thr)
