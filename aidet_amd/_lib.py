@@ -13,7 +13,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libobbops.so')
+# OBBOPS_LIB: an alternative build of the library (A/B measurements)
+LIB_PATH = os.environ.get('OBBOPS_LIB') or os.path.join(_HERE, 'lib', 'libobbops.so')
 
 OBB_OK = 0
 OBB_EINVAL = -1

@@ -85,7 +85,8 @@ struct NmsCounters {
   alignas(256) unsigned int light_units;   // light scan units (stored from the back of the list)
   alignas(256) unsigned int heavy_units;   // heavy scan units (stored from the front)
   alignas(256) long long kept;             // K
-  long long rounds;                        // resolve rounds
+  long long rounds;                        // resolve sweeps (most of any shard)
+  unsigned int done;                       // resolve workgroups finished
   unsigned long long cand_total;           // candidate pairs over all shards
   unsigned long long cand_worst;           // fullest shard
 };
@@ -1003,32 +1004,47 @@ __global__ __launch_bounds__(256) void nms_clip_kernel(const uint2 *__restrict__
 }
 
 // ---- 8: resolve ---------------------------------------------------------------
-// agent-scope loads (L2): cnt is updated by atomics, which bypass this CU's L1
-__device__ __forceinline__ uint8_t ld_state(uint8_t *p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ int ld_cnt(int *p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
+// One word per box: the number of LIVE incoming edges (bits 0..29; set by the clip's
+// atomicAdd) and a SUPPRESSED flag (bit 30).  A box is KEPT iff its word is zero: no kept
+// predecessor can reach it any more.  Both transitions are fire-and-forget atomics:
+//   source kept       ->  atomicOr (word[target], SUPPRESSED)
+//   source suppressed ->  atomicSub(word[target], 1)
+// and each word only ever moves towards its final value, so the iteration may run
+// ASYNCHRONOUSLY: 64 workgroups, one per edge shard, each walking its own segment (compacted
+// in place) until it is empty, reading the others' progress through agent-scope loads.  A
+// stale read only postpones a decision to the next sweep.  No grid barrier: a workgroup
+// whose edges wait for other shards just sweeps again (every sweep retires at least the
+// edge with the globally earliest undecided source once that shard has run).
+// One workgroup = one CU sustains about one scattered memory request per clock -- the
+// single-workgroup version of this kernel needed 170 us for 3*10^4 edges.
+constexpr int kSuppressedBit = 1 << 30;
+constexpr int kResolveThreads = 256;          // sorted route: 64 workgroups share the edges
+constexpr int kResolveThreadsCompact = 1024;  // direct route: usually ONE workgroup does it all
+constexpr long long kSoloEdges = 2048;   // up to here one workgroup resolves alone (direct route)
 
-// One workgroup walks the live edge list until it is empty, compacting it in
-// place each round (reads of a 1024-edge chunk complete before its writes, and
-// the write cursor never passes the chunk being read).
-// COMPACT: the same workgroup also writes the ascending keep indices and the host info
-// (medium n: two more launches would cost more than the serial compaction).
+__device__ __forceinline__ int ld_word(const int *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool word_kept(int w) { return w == 0; }
+
+// COMPACT: the workgroup that finishes LAST also writes the ascending keep indices and the
+// host info (medium n: two more launches would cost more than the serial compaction).
 template <bool COMPACT>
-__global__ __launch_bounds__(1024) void nms_resolve_kernel(uint2 *__restrict__ edges,
+__global__ __launch_bounds__(COMPACT ? kResolveThreadsCompact : kResolveThreads) void nms_resolve_kernel(uint2 *__restrict__ edges,
                                                            unsigned long long segcap,
-                                                           uint8_t *__restrict__ state,
                                                            int *__restrict__ cnt,
                                                            NmsCounters *__restrict__ ctr,
                                                            const unsigned long long *__restrict__ ccnts,
                                                            int64_t n, int64_t *__restrict__ keep_out,
                                                            NmsHostInfo *__restrict__ hinfo) {
-  __shared__ long long pre[kShards + 1];   // virtual start of every edge segment
+  constexpr int kThreads = COMPACT ? kResolveThreadsCompact : kResolveThreads;
+  constexpr int kW = kThreads / 64;
   __shared__ int overflow;
+  __shared__ long long pre[kShards + 1];   // virtual start of every edge segment
+  __shared__ int is_last;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (wave == 0) {  // 64 lanes = 64 shards: coalesced-ish loads + one wave scan
+  const int shard = blockIdx.x;
+  if (wave == 0) {  // 64 lanes = 64 shards
     const unsigned long long c = ccnts[(size_t)(kShards + lane) * kCandStride];
     const unsigned long long cc = ccnts[(size_t)lane * kCandStride];
     long long inc = (long long)c;
@@ -1041,29 +1057,32 @@ __global__ __launch_bounds__(1024) void nms_resolve_kernel(uint2 *__restrict__ e
     if (lane == 63) {
       pre[kShards] = inc;
       overflow = ovm != 0;
-      ctr->edges = (unsigned long long)inc;
+      if (shard == 0) ctr->edges = (unsigned long long)inc;
     }
   }
   __syncthreads();
-  // an overflowed candidate / edge list is incomplete (cnt[] counts edges that were
+  const long long total_edges = pre[kShards];
+  // SOLO: with few edges (the usual case of the direct route) workgroup 0 walks all the
+  // segments itself and the other 63 leave at once -- no hand-over between workgroups
+  const bool solo = COMPACT && total_edges <= kSoloEdges;
+  if (solo && shard != 0) return;
+  // an overflowed candidate / edge list is incomplete (the words count edges that were
   // not stored): nothing to resolve, the host reports OBB_EWORKSPACE
-  long long live = overflow ? 0 : pre[kShards];
+  uint2 *seg = solo ? edges : edges + (size_t)shard * segcap;
+  long long live = overflow ? 0 : (solo ? total_edges : pre[shard + 1] - pre[shard]);
+  bool segmented = solo;   // sweep 1 of SOLO reads the 64 segments, later ones the compacted front
   long long rounds = 0;
-  int stalled = 0;
-  bool segmented = true;   // round 1 reads the 64 segments, later rounds the compacted front
   constexpr int kPer = 4;  // edges per thread and chunk: their dependent loads overlap
-  __shared__ int wsum4[kPer][16];
+  __shared__ int wsum4[kPer][kW];
   while (live > 0) {
     long long w = 0;
-    for (long long base = 0; base < live; base += 1024 * kPer) {
+    for (long long base = 0; base < live; base += kThreads * kPer) {
       uint2 ed[kPer];
       bool have[kPer], keep[kPer];
-      uint8_t sd[kPer], ss[kPer];
-      int cs[kPer];
-      // 1: edges (independent loads)
+      int ws[kPer], wd[kPer];
 #pragma unroll
       for (int k = 0; k < kPer; ++k) {
-        const long long e = base + (long long)k * 1024 + tid;
+        const long long e = base + (long long)k * kThreads + tid;
         have[k] = e < live;
         keep[k] = false;
         ed[k] = make_uint2(0u, 0u);
@@ -1078,35 +1097,24 @@ __global__ __launch_bounds__(1024) void nms_resolve_kernel(uint2 *__restrict__ e
             }
             phys = (long long)lo * (long long)segcap + (e - pre[lo]);
           }
-          ed[k] = edges[phys];
+          ed[k] = seg[phys];
         }
       }
-      // 2: both states and the source's count, speculatively (independent loads)
 #pragma unroll
       for (int k = 0; k < kPer; ++k) {
-        sd[k] = kKept; ss[k] = kKept; cs[k] = 0;
-        if (have[k]) {
-          sd[k] = ld_state(state + ed[k].y);
-          ss[k] = ld_state(state + ed[k].x);
-          cs[k] = ld_cnt(cnt + ed[k].x);
-        }
+        ws[k] = 0; wd[k] = kSuppressedBit;
+        if (have[k]) { wd[k] = ld_word(cnt + ed[k].y); ws[k] = ld_word(cnt + ed[k].x); }
       }
-      // 3: decide
 #pragma unroll
       for (int k = 0; k < kPer; ++k) {
-        if (have[k] && sd[k] == kUndecided) {
-          uint8_t si = ss[k];
-          if (si == kUndecided && cs[k] == 0) si = kKept;
-          if (si == kKept) {
-            state[ed[k].y] = kSuppressed;
-          } else if (si == kSuppressed) {
-            if (atomicSub(&cnt[ed[k].y], 1) == 1) state[ed[k].y] = kKept;
-          } else {
-            keep[k] = true;
-          }
+        if (have[k] && !(wd[k] & kSuppressedBit)) {   // (a suppressed target: the edge is moot)
+          if (ws[k] & kSuppressedBit) atomicSub(&cnt[ed[k].y], 1);
+          else if (word_kept(ws[k])) atomicOr(&cnt[ed[k].y], kSuppressedBit);
+          else keep[k] = true;
         }
       }
-      // 4: compact the survivors to the front (any order is fine)
+      // compact the survivors to the front of the segment (any order is fine; reads of a
+      // chunk complete before its writes and the write cursor never passes the chunk)
       uint64_t mk[kPer];
 #pragma unroll
       for (int k = 0; k < kPer; ++k) {
@@ -1119,53 +1127,66 @@ __global__ __launch_bounds__(1024) void nms_resolve_kernel(uint2 *__restrict__ e
       for (int k = 0; k < kPer; ++k) {
         int off = 0, tot = 0;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
+        for (int j = 0; j < kW; ++j) {
           const int v = wsum4[k][j];
           off += (j < wave) ? v : 0;
           tot += v;
         }
-        if (keep[k]) edges[w + run + off + __popcll(mk[k] & ((1ull << lane) - 1ull))] = ed[k];
+        if (keep[k]) seg[w + run + off + __popcll(mk[k] & ((1ull << lane) - 1ull))] = ed[k];
         run += tot;
       }
       w += run;
       __syncthreads();
     }
-    // every round retires at least the live edge whose source precedes all other
-    // live sources (that source is decided); two rounds without progress can only
-    // mean corrupted state -- stop instead of spinning
-    stalled = (w == live) ? stalled + 1 : 0;
     live = w;
     segmented = false;
     ++rounds;
-    // one workgroup = one CU: the barrier (workgroup-scope release/acquire, stores
-    // drained to L2) is all the ordering the agent-scope loads above need.  A
-    // device-scope __threadfence() by 1024 threads costs ~10 us per round here.
-    __syncthreads();
-    if (stalled >= 2) break;
+    if (rounds > (1ll << 22)) break;   // corrupted state: stop instead of spinning forever
   }
-  if (tid == 0) ctr->rounds = rounds;
+  if (tid == 0) atomicMax(reinterpret_cast<unsigned long long *>(&ctr->rounds), (unsigned long long)rounds);
   if (COMPACT) {
-    __shared__ int csum[16];
-    long long kbase = 0;
-    for (int64_t c0 = 0; c0 < n; c0 += 1024) {
-      const int64_t i = c0 + tid;
-      bool f = false;
-      if (i < n) {
-        const uint8_t st = ld_state(state + i);
-        f = (st == kKept) || (st == kUndecided && ld_cnt(cnt + i) == 0);
-      }
-      const uint64_t mk = __ballot(f);
-      if (lane == 0) csum[wave] = __popcll(mk);
+    if (!solo) {
+      // the last workgroup to get here sees every final word: each wave's atomics are
+      // acknowledged before it passes the barrier, then ONE thread publishes the count
       __syncthreads();
-      int off = 0, tot = 0;
-#pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        const int v = csum[k];
-        off += (k < wave) ? v : 0;
-        tot += v;
+      if (tid == 0) {
+        __threadfence();
+        is_last = atomicAdd(&ctr->done, 1u) == gridDim.x - 1;
       }
-      if (f) keep_out[kbase + off + __popcll(mk & ((1ull << lane) - 1ull))] = i;
-      kbase += tot;
+      __syncthreads();
+      if (!is_last) return;
+    }
+    constexpr int kC = 4;   // boxes per thread and sweep (independent loads in flight)
+    __shared__ int csum[kC][kW];
+    long long kbase = 0;
+    for (int64_t c0 = 0; c0 < n; c0 += kThreads * kC) {
+      bool f[kC];
+      uint64_t mk[kC];
+#pragma unroll
+      for (int k = 0; k < kC; ++k) {
+        const int64_t i = c0 + (int64_t)k * kThreads + tid;
+        f[k] = (i < n) && word_kept(ld_word(cnt + i));
+      }
+#pragma unroll
+      for (int k = 0; k < kC; ++k) {
+        mk[k] = __ballot(f[k]);
+        if (lane == 0) csum[k][wave] = __popcll(mk[k]);
+      }
+      __syncthreads();
+      int run = 0;
+#pragma unroll
+      for (int k = 0; k < kC; ++k) {
+        int off = 0, tot = 0;
+#pragma unroll
+        for (int j = 0; j < kW; ++j) {
+          const int v = csum[k][j];
+          off += (j < wave) ? v : 0;
+          tot += v;
+        }
+        if (f[k]) keep_out[kbase + run + off + __popcll(mk[k] & ((1ull << lane) - 1ull))] = c0 + (int64_t)k * kThreads + tid;
+        run += tot;
+      }
+      kbase += run;
       __syncthreads();
     }
     if (wave == 0) {
@@ -1178,7 +1199,8 @@ __global__ __launch_bounds__(1024) void nms_resolve_kernel(uint2 *__restrict__ e
         mx = t > mx ? t : mx;
       }
       if (lane == 0) {
-        hinfo->kept = kbase; hinfo->edges = (unsigned long long)pre[kShards]; hinfo->rounds = rounds;
+        hinfo->kept = kbase; hinfo->edges = (unsigned long long)total_edges;
+        hinfo->rounds = (long long)__hip_atomic_load(reinterpret_cast<unsigned long long *>(&ctr->rounds), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         hinfo->cand_total = v; hinfo->cand_worst = mx;
         hinfo->heavy_units = 0u; hinfo->light_units = 0u;
       }
@@ -1187,18 +1209,15 @@ __global__ __launch_bounds__(1024) void nms_resolve_kernel(uint2 *__restrict__ e
 }
 
 // ---- 9: compaction --------------------------------------------------------------
-__device__ __forceinline__ bool kept_flag(const uint8_t *__restrict__ state,
-                                          const int *__restrict__ cnt, int64_t i) {
-  const uint8_t s = state[i];
-  return (s == kKept) || (s == kUndecided && cnt[i] == 0);
+__device__ __forceinline__ bool kept_flag(const int *__restrict__ cnt, int64_t i) {
+  return word_kept(cnt[i]);
 }
 
-__global__ __launch_bounds__(1024) void nms_count_kernel(const uint8_t *__restrict__ state,
-                                                         const int *__restrict__ cnt, int64_t n,
+__global__ __launch_bounds__(1024) void nms_count_kernel(const int *__restrict__ cnt, int64_t n,
                                                          int *__restrict__ blockcnt) {
   __shared__ int wsum[16];
   const int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x;
-  const bool f = (i < n) && kept_flag(state, cnt, i);
+  const bool f = (i < n) && kept_flag(cnt, i);
   const uint64_t mk = __ballot(f);
   if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = __popcll(mk);
   __syncthreads();
@@ -1209,8 +1228,7 @@ __global__ __launch_bounds__(1024) void nms_count_kernel(const uint8_t *__restri
   }
 }
 
-__global__ __launch_bounds__(1024) void nms_write_kernel(const uint8_t *__restrict__ state,
-                                                         const int *__restrict__ cnt, int64_t n,
+__global__ __launch_bounds__(1024) void nms_write_kernel(const int *__restrict__ cnt, int64_t n,
                                                          const int *__restrict__ blockcnt,
                                                          int64_t *__restrict__ keep,
                                                          NmsCounters *__restrict__ ctr,
@@ -1226,7 +1244,7 @@ __global__ __launch_bounds__(1024) void nms_write_kernel(const uint8_t *__restri
   for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o);
   if (lane == 0) red[wave] = part;
   const int64_t i = (int64_t)blockIdx.x * 1024 + tid;
-  const bool f = (i < n) && kept_flag(state, cnt, i);
+  const bool f = (i < n) && kept_flag(cnt, i);
   const uint64_t mk = __ballot(f);
   if (lane == 0) wsum[wave] = __popcll(mk);
   __syncthreads();
@@ -1524,7 +1542,7 @@ static thread_local NmsProfile g_prof;
 
 // ---- workspace layout ------------------------------------------------------------
 struct NmsLayout {
-  size_t rec, iv, ar, part, pstat, qb, ckey, sid, qs, as, cellpx, tbox, sbox, zero_begin, state, cnt, ctr, ccnts, hist,
+  size_t rec, iv, ar, part, pstat, qb, ckey, sid, qs, as, cellpx, tbox, sbox, zero_begin, cnt, ctr, ccnts, hist,
       zero_end, blockcnt, cands, edges, total;
   unsigned long long cap;         // candidate pairs == overlap edges capacity
   unsigned long long unit_worst;  // every (sub-tile, tile) unit there can be
@@ -1557,7 +1575,6 @@ static int nms_layout(int64_t n, int64_t edge_capacity, NmsLayout &L) {
   L.sbox = take(nt * kSub * sizeof(uint2));
   L.unit_worst = (unsigned long long)nt * (nt + 1) / 2 * kSub;   // (diagonal ones are not listed)
   L.zero_begin = off;
-  L.state = take(nn);
   L.cnt = take(nn * 4);
   L.ctr = take(sizeof(NmsCounters));
   L.ccnts = take((size_t)2 * kShards * kCandStride * sizeof(unsigned long long));  // candidates | edges
@@ -1649,7 +1666,6 @@ extern "C" int obb_nms_grouped_f32(const float *dets_dev, int64_t n, int kind, f
   float *cellpx = reinterpret_cast<float *>(ws + L.cellpx);
   uint2 *tbox = reinterpret_cast<uint2 *>(ws + L.tbox);
   uint2 *sbox = reinterpret_cast<uint2 *>(ws + L.sbox);
-  uint8_t *state = reinterpret_cast<uint8_t *>(ws + L.state);
   int *cnt = reinterpret_cast<int *>(ws + L.cnt);
   NmsCounters *ctr = reinterpret_cast<NmsCounters *>(ws + L.ctr);
   unsigned long long *ccnts = reinterpret_cast<unsigned long long *>(ws + L.ccnts);
@@ -1739,7 +1755,7 @@ extern "C" int obb_nms_grouped_f32(const float *dets_dev, int64_t n, int kind, f
     OBB_LAUNCH_CHECK();
     OBB_PHASE(4);
     OBB_PHASE(5);
-    hipLaunchKernelGGL(nms_resolve_kernel<true>, dim3(1), dim3(1024), 0, st, edges, segcap, state, cnt, ctr, ccnts, n, keep_dev, hinfo_dev);
+    hipLaunchKernelGGL(nms_resolve_kernel<true>, dim3(kShards), dim3(kResolveThreadsCompact), 0, st, edges, segcap, cnt, ctr, ccnts, n, keep_dev, hinfo_dev);
     OBB_LAUNCH_CHECK();
     OBB_PHASE(6);
     OBB_PHASE(7);
@@ -1779,14 +1795,14 @@ extern "C" int obb_nms_grouped_f32(const float *dets_dev, int64_t n, int kind, f
     OBB_LAUNCH_CHECK();
     // phase 5: resolve
     OBB_PHASE(5);
-    hipLaunchKernelGGL(nms_resolve_kernel<false>, dim3(1), dim3(1024), 0, st, edges, segcap, state, cnt, ctr, ccnts, n, keep_dev, hinfo_dev);
+    hipLaunchKernelGGL(nms_resolve_kernel<false>, dim3(kShards), dim3(kResolveThreads), 0, st, edges, segcap, cnt, ctr, ccnts, n, keep_dev, hinfo_dev);
     OBB_LAUNCH_CHECK();
     // phase 6: compaction
     OBB_PHASE(6);
     const unsigned cblocks = (unsigned)((n + 1023) / 1024);
-    hipLaunchKernelGGL(nms_count_kernel, dim3(cblocks), dim3(1024), 0, st, state, cnt, n, blockcnt);
+    hipLaunchKernelGGL(nms_count_kernel, dim3(cblocks), dim3(1024), 0, st, cnt, n, blockcnt);
     OBB_LAUNCH_CHECK();
-    hipLaunchKernelGGL(nms_write_kernel, dim3(cblocks), dim3(1024), 0, st, state, cnt, n, blockcnt, keep_dev, ctr, ccnts, hinfo_dev);
+    hipLaunchKernelGGL(nms_write_kernel, dim3(cblocks), dim3(1024), 0, st, cnt, n, blockcnt, keep_dev, ctr, ccnts, hinfo_dev);
     OBB_LAUNCH_CHECK();
     OBB_PHASE(7);
   }
