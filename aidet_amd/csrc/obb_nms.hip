@@ -144,12 +144,17 @@ __global__ __launch_bounds__(256) void nms_prep_kernel(const float *__restrict__
   __shared__ uint4 wred[4];
   __shared__ double sred[4][kStat];
   __shared__ double ssum[kStat];
+  __shared__ uint4 cred[4];
   double st[kStat] = {0.0, 0.0, 0.0, 0.0, 0.0};   // count, sum x, sum y, sum x^2, sum y^2 of the centres
   // clear the counters / flags / histogram of this call (nothing reads them before the
   // next kernel): saves the separate fill launch
   for (size_t z = (size_t)blockIdx.x * blockDim.x + threadIdx.x; z < zero_vecs;
        z += (size_t)gridDim.x * blockDim.x)
     zero[z] = make_uint4(0u, 0u, 0u, 0u);
+  float4 mine = make_float4(1.0f, -1.0f, 1.0f, -1.0f);   // this thread's (last) interval
+  uint32_t axh = 0, axl = 0, ayh = 0, ayl = 0;   // bounding box of all finite intervals (keys)
+  uint32_t cxh = 0, cxl = 0, cyh = 0, cyl = 0;   // bounding box of their centres
+  const bool single = (int64_t)gridDim.x * blockDim.x >= n;   // one box per thread: no re-read below
   for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n;
        b += (int64_t)gridDim.x * blockDim.x) {
     const float *row = dets + b * S;
@@ -174,9 +179,15 @@ __global__ __launch_bounds__(256) void nms_prep_kernel(const float *__restrict__
                      (fabs_sel(v.w) < big);
     if (!fin) { v.x = 1.0f; v.y = -1.0f; v.z = 1.0f; v.w = -1.0f; }  // lo > hi = "isolated"
     iv[b] = v;
+    mine = v;
     if (fin) {
       const double cx = 0.5 * ((double)v.x + (double)v.y), cy = 0.5 * ((double)v.z + (double)v.w);
       st[0] += 1.0; st[1] += cx; st[2] += cy; st[3] += cx * cx; st[4] += cy * cy;
+      axh = max(axh, fkey(v.y)); axl = max(axl, ~fkey(v.x));
+      ayh = max(ayh, fkey(v.w)); ayl = max(ayl, ~fkey(v.z));
+      const float fx = (float)cx, fy = (float)cy;
+      cxh = max(cxh, fkey(fx)); cxl = max(cxl, ~fkey(fx));
+      cyh = max(cyh, fkey(fy)); cyl = max(cyl, ~fkey(fy));
     }
   }
   // Statistics for the ROBUST quantisation frame (nms_quant_kernel): the block's bounding
@@ -193,23 +204,55 @@ __global__ __launch_bounds__(256) void nms_prep_kernel(const float *__restrict__
     if (threadIdx.x < kStat) ssum[threadIdx.x] = (sred[0][threadIdx.x] + sred[1][threadIdx.x]) + (sred[2][threadIdx.x] + sred[3][threadIdx.x]);
     __syncthreads();
   };
-  block_sum(st);
+  for (int o = 32; o > 0; o >>= 1) {
+    axh = max(axh, shfl_xor_u(axh, o)); axl = max(axl, shfl_xor_u(axl, o));
+    ayh = max(ayh, shfl_xor_u(ayh, o)); ayl = max(ayl, shfl_xor_u(ayl, o));
+    cxh = max(cxh, shfl_xor_u(cxh, o)); cxl = max(cxl, shfl_xor_u(cxl, o));
+    cyh = max(cyh, shfl_xor_u(cyh, o)); cyl = max(cyl, shfl_xor_u(cyl, o));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    wred[threadIdx.x >> 6] = make_uint4(axh, axl, ayh, ayl);
+    cred[threadIdx.x >> 6] = make_uint4(cxh, cxl, cyh, cyl);
+  }
+  block_sum(st);   // (its barriers also publish wred / cred)
   double mx = 0.0, my = 0.0, rx = 0.0, ry = 0.0;
+  bool trim = false;
   if (ssum[0] >= 1.0) {
     mx = ssum[1] / ssum[0]; my = ssum[2] / ssum[0];
     const double vx = ssum[3] / ssum[0] - mx * mx, vy = ssum[4] / ssum[0] - my * my;
-    rx = 3.0 * sqrt(vx > 0.0 ? vx : 0.0) * 1.000001 + 1e-30; ry = 3.0 * sqrt(vy > 0.0 ? vy : 0.0) * 1.000001 + 1e-30;
+    rx = 3.0 * sqrt(vx > 0.0 ? vx : 0.0) * 1.000001 + 1e-30 + 1e-9 * (mx < 0.0 ? -mx : mx);
+    ry = 3.0 * sqrt(vy > 0.0 ? vy : 0.0) * 1.000001 + 1e-30 + 1e-9 * (my < 0.0 ? -my : my);
+    uint4 c = cred[0];
+    for (int k = 1; k < 4; ++k) {
+      c.x = max(c.x, cred[k].x); c.y = max(c.y, cred[k].y);
+      c.z = max(c.z, cred[k].z); c.w = max(c.w, cred[k].w);
+    }
+    // any centre further than 3 sigma from the block's mean?  (block-uniform)
+    trim = (double)fkey_inv(c.x) - mx > rx || mx - (double)fkey_inv(~c.y) > rx ||
+           (double)fkey_inv(c.z) - my > ry || my - (double)fkey_inv(~c.w) > ry;
   }
-  __syncthreads();   // ssum is rewritten below
+  if (!trim) {   // the usual case: the block's own bounding box and sums stand
+    if (threadIdx.x == 0) {
+      uint4 a = wred[0];
+      for (int k = 1; k < 4; ++k) {
+        a.x = max(a.x, wred[k].x); a.y = max(a.y, wred[k].y);
+        a.z = max(a.z, wred[k].z); a.w = max(a.w, wred[k].w);
+      }
+      part[blockIdx.x] = a;
+      for (int k = 0; k < kStat; ++k) pstat[(size_t)blockIdx.x * kStat + k] = ssum[k];
+    }
+    return;
+  }
+  __syncthreads();   // ssum / wred are rewritten below
   uint32_t mxh = 0, mxl = 0, myh = 0, myl = 0;
   double tr[kStat] = {0.0, 0.0, 0.0, 0.0, 0.0};
   for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n;
        b += (int64_t)gridDim.x * blockDim.x) {
-    const float4 v = iv[b];   // (this thread's own store)
+    const float4 v = single ? mine : iv[b];   // (this thread's own store)
     if (!(v.x <= v.y)) continue;
     const double cx = 0.5 * ((double)v.x + (double)v.y), cy = 0.5 * ((double)v.z + (double)v.w);
     const double dx = cx - mx, dy = cy - my;
-    if ((dx < 0.0 ? -dx : dx) <= rx + 1e-9 * (mx < 0.0 ? -mx : mx) && (dy < 0.0 ? -dy : dy) <= ry + 1e-9 * (my < 0.0 ? -my : my)) {
+    if ((dx < 0.0 ? -dx : dx) <= rx && (dy < 0.0 ? -dy : dy) <= ry) {
       mxh = max(mxh, fkey(v.y)); mxl = max(mxl, ~fkey(v.x));
       myh = max(myh, fkey(v.w)); myl = max(myl, ~fkey(v.z));
       tr[0] += 1.0; tr[1] += cx; tr[2] += cy; tr[3] += cx * cx; tr[4] += cy * cy;
@@ -316,7 +359,10 @@ __global__ __launch_bounds__(256) void nms_quant_kernel(const float4 *__restrict
   }
   if (threadIdx.x == 0) window(bx0, bx1, by0, by1);
   __syncthreads();
-  {
+  // (the usual case -- the window holds the whole bounding box, every block is clean -- needs
+  // no second pass: block-uniform)
+  const bool cut = win[0] > bx0 || win[1] < bx1 || win[2] > by0 || win[3] < by1;
+  if (cut) {
     // the frame = bounding box of the CLEAN blocks: those whose own bounding box lies inside
     // the first window (a block with an outlier is dropped whole; without outliers every
     // block is clean and this is the bounding box of the scene)
@@ -342,7 +388,7 @@ __global__ __launch_bounds__(256) void nms_quant_kernel(const float4 *__restrict
   if (threadIdx.x == 0) {
     // enough clean blocks: their bounding box is the frame (otherwise outliers are everywhere
     // -- a multi-modal scene -- and the first window stays)
-    if (dsum[0] * 8.0 >= (double)n || dsum[0] >= 4096.0) {
+    if (cut && (dsum[0] * 8.0 >= (double)n || dsum[0] >= 4096.0)) {
       uint4 m = wred[0];
       for (int k = 1; k < 4; ++k) {
         m.x = max(m.x, wred[k].x); m.y = max(m.y, wred[k].y);
@@ -1146,15 +1192,18 @@ __global__ __launch_bounds__(COMPACT ? kResolveThreadsCompact : kResolveThreads)
   if (tid == 0) atomicMax(reinterpret_cast<unsigned long long *>(&ctr->rounds), (unsigned long long)rounds);
   if (COMPACT) {
     if (!solo) {
-      // the last workgroup to get here sees every final word: each wave's atomics are
-      // acknowledged before it passes the barrier, then ONE thread publishes the count
+      // the last workgroup to get here sees every final word: the payload is atomics only
+      // (performed at the coherence point, nothing dirty in a cache), so every wave waits
+      // for its own to be acknowledged -- __syncthreads alone only waits for LDS -- and
+      // then ONE thread takes the ticket.  (An agent-scope release fence in every wave
+      // costs a cache write-back each: tens of microseconds.)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if (tid == 0) {
-        __threadfence();
-        is_last = atomicAdd(&ctr->done, 1u) == gridDim.x - 1;
-      }
+      if (tid == 0)
+        is_last = __hip_atomic_fetch_add(&ctr->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
       __syncthreads();
       if (!is_last) return;
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     constexpr int kC = 4;   // boxes per thread and sweep (independent loads in flight)
     __shared__ int csum[kC][kW];
