@@ -687,58 +687,52 @@ __device__ __forceinline__ void nms_scan_rows(uint2 rv, uint32_t rows, uint32_t 
   const uint64_t lt_mask = (1ull << lane) - 1ull;
   const uint32_t sbl = sb0 + lane * kNmsColsPerLane;
   while (rows) {   // `rows`: the rows of this sub-tile that meet the column tile's box
-    uint32_t hit = 0;
+    // a chunk of rows: the per-pair results stay in registers, the lanes with a candidate
+    // come out of the vote as a scalar mask
+    uint32_t t[kRowChunk][4];
+    uint64_t lm[kRowChunk];
+    int rr[kRowChunk];
 #pragma unroll
     for (int u = 0; u < kRowChunk; ++u) {
       // lane kSubRows holds a sentinel row (never a candidate): padding of the last chunk
       const int r = rows ? __builtin_ctz(rows) : kSubRows;
       rows &= rows - 1u;
+      rr[u] = r;
       const uint32_t rlo = (uint32_t)__builtin_amdgcn_readlane((int)rv.x, r);
       const uint32_t rhi = (uint32_t)__builtin_amdgcn_readlane((int)rv.y, r);
-      uint32_t t0 = qdisjoint(rlo, rhi, col[0].x, col[0].y);
-      uint32_t t1 = qdisjoint(rlo, rhi, col[1].x, col[1].y);
-      uint32_t t2 = qdisjoint(rlo, rhi, col[2].x, col[2].y);
-      uint32_t t3 = qdisjoint(rlo, rhi, col[3].x, col[3].y);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) t[u][c] = qdisjoint(rlo, rhi, col[c].x, col[c].y);
       if (DIAG) {  // only pairs (row, col) with col > row exist in a diagonal tile
         const uint32_t sa = sa0 + r;
-        t0 |= (sbl + 0 > sa) ? 0u : 1u; t1 |= (sbl + 1 > sa) ? 0u : 1u;
-        t2 |= (sbl + 2 > sa) ? 0u : 1u; t3 |= (sbl + 3 > sa) ? 0u : 1u;
-      }
-      const uint32_t m = min(min(t0, t1), min(t2, t3));
-      hit |= __any(m == 0u) ? (1u << (r & (kSubRows - 1))) : 0u;
-    }
-    while (hit) {  // some lane has a candidate in row r
-      const int r = __builtin_ctz(hit);
-      hit &= hit - 1u;
-      const uint32_t rlo = (uint32_t)__builtin_amdgcn_readlane((int)rv.x, r);
-      const uint32_t rhi = (uint32_t)__builtin_amdgcn_readlane((int)rv.y, r);
-      const uint32_t sa = sa0 + r;
-      uint32_t m4 = 0;   // bit c: column c of this lane is a candidate
 #pragma unroll
-      for (int c = 0; c < kNmsColsPerLane; ++c) {
-        bool cnd = qdisjoint(rlo, rhi, col[c].x, col[c].y) == 0u;
-        if (DIAG) cnd = cnd && (sbl + c > sa);
-        m4 |= cnd ? (1u << c) : 0u;
+        for (int c = 0; c < 4; ++c) t[u][c] |= (sbl + c > sa) ? 0u : 1u;
       }
-      uint64_t mk = __ballot(m4 != 0u);
+      const uint32_t m = min(min(t[u][0], t[u][1]), min(t[u][2], t[u][3]));
+      lm[u] = __ballot(m == 0u);
+    }
+#pragma unroll
+    for (int u = 0; u < kRowChunk; ++u) {
+      if (lm[u] == 0) continue;   // (wave-uniform) no candidate in this row: the usual case
+      const uint32_t sa = sa0 + (uint32_t)rr[u];
+      uint64_t mk = lm[u];
       if (__popcll(mk) <= 2) {
-        // the common case, one or two lanes: push from scalar registers
+        // one or two lanes: read their four results back and push from scalar registers
         while (mk) {
           const int l = __builtin_ctzll(mk);
           mk &= mk - 1ull;
-          uint32_t bits = (uint32_t)__builtin_amdgcn_readlane((int)m4, l);
           const uint32_t sb = sb0 + (uint32_t)l * kNmsColsPerLane;
-          while (bits) {
-            const int c = __builtin_ctz(bits);
-            bits &= bits - 1u;
-            if (lane == 0) q[qn] = make_uint2(sa, sb + (uint32_t)c);
-            ++qn;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            if (__builtin_amdgcn_readlane((int)t[u][c], l) == 0) {
+              if (lane == 0) q[qn] = make_uint2(sa, sb + (uint32_t)c);
+              ++qn;
+            }
           }
         }
       } else {
 #pragma unroll
         for (int c = 0; c < kNmsColsPerLane; ++c) {
-          const bool cnd = (m4 >> c) & 1u;
+          const bool cnd = t[u][c] == 0u;
           const uint64_t mc = __ballot(cnd);
           if (cnd) q[qn + __popcll(mc & lt_mask)] = make_uint2(sa, sbl + c);
           qn += __popcll(mc);
