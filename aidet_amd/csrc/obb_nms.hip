@@ -485,20 +485,22 @@ __global__ __launch_bounds__(256) void nms_permute_kernel(const uint2 *__restric
                                                           const uint32_t *__restrict__ sid,
                                                           const float *__restrict__ ar_in,
                                                           int64_t n, uint2 *__restrict__ qs,
-                                                          float *__restrict__ as,
+                                                          uint4 *__restrict__ pf,
                                                           uint2 *__restrict__ tbox,
                                                           uint2 *__restrict__ sbox) {
   __shared__ uint4 wred[4];
   const int64_t s = (int64_t)blockIdx.x * kTile + threadIdx.x;
   uint2 o = make_uint2(kSentLo, kSentHi);
   float ar = 0.0f;
+  uint32_t id = 0;
   if (s < n) {
-    const uint32_t id = sid[s];
+    id = sid[s];
     o = qb[id];
     ar = ar_in[id];
   }
   qs[s] = o;
-  as[s] = ar;
+  // one 16-byte record per position for the candidate batches (one gather instead of three)
+  pf[s] = make_uint4(o.x, o.y, __float_as_uint(ar), id);
   uint32_t xl = o.x & 0x7FFFu, yl = (o.x >> 16) & 0x7FFFu;
   uint32_t xh = o.y & 0x7FFFu, yh = (o.y >> 16) & 0x7FFFu;
   for (int k = kSubRows / 2; k > 0; k >>= 1) {
@@ -649,9 +651,7 @@ __device__ __forceinline__ bool prune_aabb(const Prune &pr, uint32_t rlo, uint32
 // as (box id, box id) with one returning atomic per batch.
 struct SortedSink {
   Prune pr;
-  const uint2 *__restrict__ qs;
-  const float *__restrict__ as;
-  const uint32_t *__restrict__ sid;
+  const uint4 *__restrict__ pf;             // per position: packed interval, area, box id
   uint2 *__restrict__ cand;                 // this wave's candidate segment
   unsigned long long segcap;
   unsigned long long *__restrict__ ccnt;
@@ -661,9 +661,9 @@ struct SortedSink {
     uint2 ids = make_uint2(0u, 0u);
     if (keep) {
       const uint2 e = q[lane];
-      const uint2 a = qs[e.x], b = qs[e.y];
-      const float ra = as[e.x], ca = as[e.y];
-      ids = make_uint2(sid[e.x], sid[e.y]);
+      const uint4 a = pf[e.x], b = pf[e.y];
+      const float ra = __uint_as_float(a.z), ca = __uint_as_float(b.z);
+      ids = make_uint2(a.w, b.w);
       if (pr.thr > 0.0f) {
         // an interval that touches the first or last cell may have been CLAMPED into the frame
         // (robust frame, nms_quant_kernel): its cells then say nothing about its extent
@@ -751,9 +751,8 @@ __device__ __forceinline__ void nms_scan_rows(uint2 rv, uint32_t rows, uint32_t 
 //   [ diagonal units (sub-tile vs. its own tile, implicit) | heavy ... | light ... ].
 // Consecutive blocks land on different CUs, so this deals the expensive units evenly.
 __global__ __launch_bounds__(64 * kNmsWaves) void nms_scan_kernel(const uint2 *__restrict__ qs,
-                                                       const float *__restrict__ as,
+                                                       const uint4 *__restrict__ pf,
                                                        const float *__restrict__ cellpx, float thr,
-                                                       const uint32_t *__restrict__ sid,
                                                        const uint2 *__restrict__ tbox, int nt,
                                                        const uint2 *__restrict__ units,
                                                        unsigned int ucap,
@@ -771,7 +770,7 @@ __global__ __launch_bounds__(64 * kNmsWaves) void nms_scan_kernel(const uint2 *_
   const int shard = (int)(gw & (kShards - 1));
   SortedSink sink;
   sink.pr.thr = thr; sink.pr.cpx = cellpx[0]; sink.pr.cpy = cellpx[1];
-  sink.qs = qs; sink.as = as; sink.sid = sid;
+  sink.pf = pf;
   sink.cand = cands + (size_t)shard * segcap;
   sink.segcap = segcap;
   sink.ccnt = ccnts + (size_t)shard * kCandStride;
@@ -1585,7 +1584,7 @@ static thread_local NmsProfile g_prof;
 
 // ---- workspace layout ------------------------------------------------------------
 struct NmsLayout {
-  size_t rec, iv, ar, part, pstat, qb, ckey, sid, qs, as, cellpx, tbox, sbox, zero_begin, cnt, ctr, ccnts, hist,
+  size_t rec, iv, ar, part, pstat, qb, ckey, sid, qs, pf, cellpx, tbox, sbox, zero_begin, cnt, ctr, ccnts, hist,
       zero_end, blockcnt, cands, edges, total;
   unsigned long long cap;         // candidate pairs == overlap edges capacity
   unsigned long long unit_worst;  // every (sub-tile, tile) unit there can be
@@ -1612,7 +1611,7 @@ static int nms_layout(int64_t n, int64_t edge_capacity, NmsLayout &L) {
   L.ckey = take(nn * 4);
   L.sid = take((nt * kTile) * 4);
   L.qs = take((nt * kTile + kRowChunk) * sizeof(uint2));
-  L.as = take((nt * kTile) * sizeof(float));
+  L.pf = take((nt * kTile) * sizeof(uint4));
   L.cellpx = take(2 * sizeof(float));
   L.tbox = take(nt * sizeof(uint2));
   L.sbox = take(nt * kSub * sizeof(uint2));
@@ -1705,7 +1704,7 @@ extern "C" int obb_nms_grouped_f32(const float *dets_dev, int64_t n, int kind, f
   uint32_t *hist = reinterpret_cast<uint32_t *>(ws + L.hist);
   uint32_t *sid = reinterpret_cast<uint32_t *>(ws + L.sid);
   uint2 *qs = reinterpret_cast<uint2 *>(ws + L.qs);
-  float *as = reinterpret_cast<float *>(ws + L.as);
+  uint4 *pf = reinterpret_cast<uint4 *>(ws + L.pf);
   float *cellpx = reinterpret_cast<float *>(ws + L.cellpx);
   uint2 *tbox = reinterpret_cast<uint2 *>(ws + L.tbox);
   uint2 *sbox = reinterpret_cast<uint2 *>(ws + L.sbox);
@@ -1818,7 +1817,7 @@ extern "C" int obb_nms_grouped_f32(const float *dets_dev, int64_t n, int kind, f
     OBB_LAUNCH_CHECK();
     // phase 2: permute + tile boxes + unit culling
     OBB_PHASE(2);
-    hipLaunchKernelGGL(nms_permute_kernel, dim3((unsigned)nt), dim3(kTile), 0, st, qb, sid, ar, n, qs, as, tbox, sbox);
+    hipLaunchKernelGGL(nms_permute_kernel, dim3((unsigned)nt), dim3(kTile), 0, st, qb, sid, ar, n, qs, pf, tbox, sbox);
     OBB_LAUNCH_CHECK();
     hipLaunchKernelGGL(nms_cull_kernel, dim3((unsigned)nt, (unsigned)((nt + kCullChunk - 1) / kCullChunk)), dim3(256), 0, st, tbox, sbox, nt, units, ucap, ctr);
     OBB_LAUNCH_CHECK();
@@ -1829,7 +1828,7 @@ extern "C" int obb_nms_grouped_f32(const float *dets_dev, int64_t n, int kind, f
       long long pb = kScanBlocks;
       if (const char *e = getenv("OBB_NMS_SCAN_BLOCKS")) pb = atoll(e) > 0 ? atoll(e) : pb;  // tuning knob
       const unsigned gb = (unsigned)(maxblocks < pb ? maxblocks : pb);
-      hipLaunchKernelGGL(nms_scan_kernel, dim3(gb), dim3(64 * kNmsWaves), 0, st, qs, as, cellpx, prune_thr, sid, tbox, nt, units, ucap, cands, segcap, ctr, ccnts);
+      hipLaunchKernelGGL(nms_scan_kernel, dim3(gb), dim3(64 * kNmsWaves), 0, st, qs, pf, cellpx, prune_thr, tbox, nt, units, ucap, cands, segcap, ctr, ccnts);
       OBB_LAUNCH_CHECK();
     }
     // phase 4: clip (narrow phase)
