@@ -836,14 +836,8 @@ __device__ __forceinline__ void swap_if(bool c, float &a, float &b) {
 // One candidate pair: the edge points from the box that PRECEDES in the greedy order
 // (smaller score key, then smaller index) to the other one; the clip always takes the
 // preceding box as the subject A, exactly like the i-before-j loop of nms_cpu.cpp:35-58.
-__device__ __forceinline__ bool clip_pair(const QuadRec *__restrict__ rec, uint2 pr, uint32_t &src,
-                                          uint32_t &dst) {
-  Quad A, B;
-  uint32_t ka, kb;
-  int ga, gb;
-  float ta, tb;
-  load_rec(rec, pr.x, A, ka, ga, ta);
-  load_rec(rec, pr.y, B, kb, gb, tb);
+__device__ __forceinline__ bool clip_loaded(Quad &A, Quad &B, uint32_t ka, uint32_t kb, int ga, int gb,
+                                            float ta, float tb, uint2 pr, uint32_t &src, uint32_t &dst) {
   const bool b_first = (kb < ka) || (kb == ka && pr.y < pr.x);
   const float thr = b_first ? tb : ta;  // the earlier box's threshold
   src = b_first ? pr.y : pr.x;
@@ -855,6 +849,17 @@ __device__ __forceinline__ bool clip_pair(const QuadRec *__restrict__ rec, uint2
   for (int k = 0; k < 4; ++k) { swap_if(b_first, A.rx[k], B.rx[k]); swap_if(b_first, A.ry[k], B.ry[k]); }
   const float ov = quad_overlap(A, B, 0);
   return (ga == gb) && (ov >= thr);
+}
+
+__device__ __forceinline__ bool clip_pair(const QuadRec *__restrict__ rec, uint2 pr, uint32_t &src,
+                                          uint32_t &dst) {
+  Quad A, B;
+  uint32_t ka, kb;
+  int ga, gb;
+  float ta, tb;
+  load_rec(rec, pr.x, A, ka, ga, ta);
+  load_rec(rec, pr.y, B, kb, gb, tb);
+  return clip_loaded(A, B, ka, kb, ga, gb, ta, tb, pr, src, dst);
 }
 
 // hits of one wave -> its shard's edge segment (+ the in-degree of the targets)
@@ -905,24 +910,35 @@ struct DirectSink {
   int *__restrict__ cnt;
 
   __device__ __forceinline__ void flush(const uint2 *q, int count, int lane) const {
+    // everything comes from the two 64-byte records (ONE round of loads): the float
+    // intervals are rebuilt exactly as the prep kernel built them
     bool keep = lane < count;
     uint2 e = make_uint2(0u, 0u);
+    Quad A, B;
+    uint32_t ka = 0, kb = 0;
+    int ga = 0, gb = 0;
+    float ta = 0.0f, tb = 0.0f;
     if (keep) {
       e = q[lane];
-      const float4 a = iv[e.x], b = iv[e.y];
-      // (the quantised test is coarser than the float intervals: re-test them)
-      keep = (a.x <= b.y) && (b.x <= a.y) && (a.z <= b.w) && (b.z <= a.w);
-      if (keep && pr.thr > 0.0f) {
-        const float ra = ar[e.x], ca = ar[e.y];
-        keep = prune_area(pr, ra, ca) && prune_aabb_f(pr, a, ra, b, ca);
-      }
+      load_rec(rec, e.x, A, ka, ga, ta);
+      load_rec(rec, e.y, B, kb, gb, tb);
+      float4 a, b;
+      nms_interval(A.ox, A.ex, a.x, a.y); nms_interval(A.oy, A.ey, a.z, a.w);
+      nms_interval(B.ox, B.ex, b.x, b.y); nms_interval(B.oy, B.ey, b.z, b.w);
+      const float big = 3.0e38f;   // (non-finite boxes are isolated, as in nms_prep_kernel)
+      const bool fin = (fabs_sel(a.x) < big) && (fabs_sel(a.y) < big) && (fabs_sel(a.z) < big) && (fabs_sel(a.w) < big) &&
+                       (fabs_sel(b.x) < big) && (fabs_sel(b.y) < big) && (fabs_sel(b.z) < big) && (fabs_sel(b.w) < big);
+      // (the quantised test is coarser than the float intervals: re-test them; boxes of
+      // different groups never interact)
+      keep = fin && (ga == gb) && (a.x <= b.y) && (b.x <= a.y) && (a.z <= b.w) && (b.z <= a.w);
+      if (keep && pr.thr > 0.0f) keep = prune_area(pr, A.area, B.area) && prune_aabb_f(pr, a, A.area, b, B.area);
     }
     const uint64_t mk = __ballot(keep);
     if (mk == 0) return;
     if (lane == 0) atomicAdd(ccnt, (unsigned long long)__popcll(mk));
     bool hit = false;
     uint32_t src = 0, dst = 0;
-    if (keep) hit = clip_pair(rec, e, src, dst);
+    if (keep) hit = clip_loaded(A, B, ka, kb, ga, gb, ta, tb, e, src, dst);
     push_edges(hit, src, dst, eseg, segcap, ecnt, cnt, lane);
   }
 };
