@@ -374,17 +374,13 @@ __global__ __launch_bounds__(256) void rroi_forward_kernel(
   }
 }
 
-__global__ __launch_bounds__(256) void rroi_backward_kernel(
-    const float *__restrict__ gout, int B, int C, int H, int W, const float *__restrict__ rois,
-    int ph, int pw, float scale, int sample_num, float min_size, int groups_per_block,
-    float *__restrict__ gfeat) {
-  const int64_t k = blockIdx.x;
-  RoiFrame f;
-  make_frame(rois + k * 6, scale, ph, pw, sample_num, min_size, f);
-  if (f.b < 0 || f.b >= B) return;
+// ---- backward, direct atomics (any footprint size) -----------------------------------------
+__device__ __forceinline__ void rroi_backward_direct(const float *__restrict__ gout, int C, int H, int W,
+                                                     const RoiFrame &f, int64_t k, int ph, int pw,
+                                                     int c_block, int groups_per_block,
+                                                     float *__restrict__ gfeat) {
   const int nb = ph * pw;
   const int items = groups_per_block * nb;
-  const int c_block = blockIdx.y * groups_per_block * kChanPerThread;
   const int64_t plane = (int64_t)H * W;
   for (int it = threadIdx.x; it < items; it += 256) {
     const int grp = it / nb, bin = it - grp * nb;
@@ -418,6 +414,105 @@ __global__ __launch_bounds__(256) void rroi_backward_kernel(
         }
       }
     }
+  }
+}
+
+// ---- backward, staged -----------------------------------------------------------------------
+// Mirror image of the forward kernel: a wave accumulates the gradient of its channels in a
+// private LDS copy of the RoI's footprint (ds_add_f32: the ~16 taps per output that neighbouring
+// bins share meet in LDS, not in L2), then adds the footprint to the gradient map -- one
+// global atomic per TOUCHED pixel and channel, in rows of consecutive addresses, instead of
+// one scattered atomic per tap (3.1 -> see DESIGN.md for the measured time).  Float atomics
+// commute only up to rounding: the tolerance of the op is 1e-4 * max|g| as before.
+__global__ __launch_bounds__(256) void rroi_backward_kernel(
+    const float *__restrict__ gout, int B, int C, int H, int W, const float *__restrict__ rois,
+    int ph, int pw, float scale, int sample_num, float min_size, int groups_per_block,
+    int K, int chunks, float *__restrict__ gfeat) {
+  __shared__ __attribute__((aligned(16))) float tile[4 * kWaveFloats];
+  __shared__ int4 s_off[kMaxTabSamples];
+  __shared__ float4 s_wgt[kMaxTabSamples];
+  const uint32_t lin = blockIdx.x;          // same XCD-aware numbering as the forward kernel
+  const uint32_t c8 = lin & 7u, rest = lin >> 3;
+  const int64_t k = rest % (uint32_t)K;
+  const int chunk = (int)((rest / (uint32_t)K) * 8u + c8);
+  if (chunk >= chunks) return;
+  RoiFrame f;
+  make_frame(rois + k * 6, scale, ph, pw, sample_num, min_size, f);
+  if (f.b < 0 || f.b >= B) return;
+  const int nb = ph * pw;
+  const int c_block = chunk * groups_per_block * kChanPerThread;
+  const int c_end = min(C, c_block + groups_per_block * kChanPerThread);
+  const int64_t plane = (int64_t)H * W;
+  const Footprint fp = roi_footprint(f, ph, pw, H, W);
+  const int fsz = fp.w * fp.h;
+  const int spb = f.gh * f.gw;
+  const int nsamp = nb * spb;
+  if (fsz > kWaveFloats || nb > 64 || spb > 4 || nsamp > kMaxTabSamples || (int64_t)B * C * plane >= (1ll << 31)) {
+    rroi_backward_direct(gout, C, H, W, f, k, ph, pw, c_block, groups_per_block, gfeat);
+    return;
+  }
+  for (int sidx = threadIdx.x; sidx < nsamp; sidx += 256) {
+    const int bin = sidx / spb, q = sidx - bin * spb;
+    const int bi = bin / pw, bj = bin - bi * pw;
+    const int iy = q / f.gw, ix = q - iy * f.gw;
+    float x, y, w[4];
+    int yl, xl, yh, xh;
+    sample_xy(f, bi, bj, iy, ix, x, y);
+    const bool live = bilinear_taps_xy(H, W, y, x, yl, xl, yh, xh, w);
+    auto cl = [](int v, int n) { return v < 0 ? 0 : (v >= n ? n - 1 : v); };
+    const int ly0 = cl(yl - fp.y0, fp.h) * fp.w, ly1 = cl(yh - fp.y0, fp.h) * fp.w;
+    const int lx0 = cl(xl - fp.x0, fp.w), lx1 = cl(xh - fp.x0, fp.w);
+    s_off[sidx] = live ? make_int4(ly0 + lx0, ly0 + lx1, ly1 + lx0, ly1 + lx1) : make_int4(0, 0, 0, 0);
+    s_wgt[sidx] = make_float4(w[0], w[1], w[2], w[3]);
+  }
+  __syncthreads();   // table complete; from here on the waves run independently
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float *wt = tile + wave * kWaveFloats;
+  const int per_wave = (c_end - c_block + 3) >> 2;
+  const int cw0 = c_block + wave * per_wave, cw1 = min(c_end, cw0 + per_wave);
+  int4 so[4];
+  float4 sw[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const bool on = lane < nb && q < spb;
+    so[q] = on ? s_off[lane * spb + q] : make_int4(0, 0, 0, 0);
+    sw[q] = on ? s_wgt[lane * spb + q] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const int cpw = kWaveFloats / fsz;               // channels per pass (>= 1)
+  const uint32_t m_fsz = fsz > 1 ? 0xFFFFFFFFu / (uint32_t)fsz + 1u : 0u;
+  const uint32_t m_w = fp.w > 1 ? 0xFFFFFFFFu / (uint32_t)fp.w + 1u : 0u;
+  for (int cp = cw0; cp < cw1; cp += cpw) {
+    const int nch = min(cpw, cw1 - cp);
+    const int total = nch * fsz;
+    for (int i = lane; i < total; i += 64) wt[i] = 0.0f;
+    __builtin_amdgcn_wave_barrier();
+    for (int c = 0; c < nch; ++c) {
+      float *p = wt + c * fsz;
+      const float g = (lane < nb) ? gout[((k * C + cp + c) * (int64_t)nb) + lane] : 0.0f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (q < spb && lane < nb) {
+          // same per-tap arithmetic as the direct kernel: (g * w) / count
+          atomicAdd(p + so[q].x, (g * sw[q].x) / f.cnt);
+          atomicAdd(p + so[q].y, (g * sw[q].y) / f.cnt);
+          atomicAdd(p + so[q].z, (g * sw[q].z) / f.cnt);
+          atomicAdd(p + so[q].w, (g * sw[q].w) / f.cnt);
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    float *dst = gfeat + ((int64_t)f.b * C + cp) * plane + (int64_t)fp.y0 * W + fp.x0;
+    for (int i = lane; i < total; i += 64) {
+      const float v = wt[i];
+      if (v != 0.0f) {
+        const uint32_t c = fsz > 1 ? __umulhi((uint32_t)i, m_fsz) : (uint32_t)i;
+        const uint32_t r = (uint32_t)i - c * (uint32_t)fsz;
+        const uint32_t y = fp.w > 1 ? __umulhi(r, m_w) : r;
+        const uint32_t x = r - y * (uint32_t)fp.w;
+        atomicAdd(dst + (int64_t)c * plane + (int64_t)y * W + x, v);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -488,11 +583,15 @@ extern "C" int obb_rroi_align_backward_f32(const float *grad_out_dev, int B, int
   if (rc != OBB_OK) return rc;
   if (K == 0 || C == 0 || H == 0 || W == 0 || B == 0) return OBB_OK;
   if (!grad_out_dev || !rois_dev || !grad_feat_dev) return set_err(OBB_EINVAL, "obb_rroi_align_backward_f32: null pointer");
-  int gpb; unsigned chunks;
-  rroi_geometry(C, ph, pw, gpb, chunks);
+  // same block geometry as the forward kernel (32 channels per block when C allows)
+  const int groups = (C + kChanPerThread - 1) / kChanPerThread;
+  const int gpb = (groups % 32 == 0) ? 4 : ((groups % 16 == 0) ? 2 : 3);
+  const unsigned chunks = (unsigned)((groups + gpb - 1) / gpb);
   if (chunks > 65535u) return set_err(OBB_EINVAL, "obb_rroi_align_backward_f32: too many channels (%d)", C);
-  hipLaunchKernelGGL(rroi_backward_kernel, dim3((unsigned)K, chunks), dim3(256), 0, (hipStream_t)stream,
-                     grad_out_dev, B, C, H, W, rois_dev, ph, pw, spatial_scale, sample_num, min_size, gpb, grad_feat_dev);
+  const unsigned long long nblk = (unsigned long long)((chunks + 7u) / 8u) * 8ull * (unsigned long long)K;
+  if (nblk > 2147483647ull) return set_err(OBB_EINVAL, "obb_rroi_align_backward_f32: too many blocks (K=%lld, C=%d)", (long long)K, C);
+  hipLaunchKernelGGL(rroi_backward_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
+                     grad_out_dev, B, C, H, W, rois_dev, ph, pw, spatial_scale, sample_num, min_size, gpb, (int)K, (int)chunks, grad_feat_dev);
   OBB_LAUNCH_CHECK();
   return OBB_OK;
 }

@@ -563,7 +563,7 @@ OBBO_API int obbo_rroi_align_forward_f32(const float *feat, int B, int C, int H,
   for (k = 0; k < K; ++k) {
     rroi_frame f;
     rroi_make_frame(rois + k * 6, scale, ph, pw, sample_num, min_size, &f);
-    if (f.b < 0 || f.b >= B) return -1;
+    if (f.b < 0 || f.b >= B) continue;   /* such a RoI reads / writes nothing: zeros (obbops.h); the caller pre-zeroes */
     int cnt_i = f.gh * f.gw; if (cnt_i < 1) cnt_i = 1;
     float cnt = (float)cnt_i;
     for (c = 0; c < C; ++c) {
@@ -598,7 +598,7 @@ OBBO_API int obbo_rroi_align_backward_f32(const float *grad_out, int B, int C, i
   for (k = 0; k < K; ++k) {
     rroi_frame f;
     rroi_make_frame(rois + k * 6, scale, ph, pw, sample_num, min_size, &f);
-    if (f.b < 0 || f.b >= B) return -1;
+    if (f.b < 0 || f.b >= B) continue;   /* such a RoI reads / writes nothing: zeros (obbops.h); the caller pre-zeroes */
     int cnt_i = f.gh * f.gw; if (cnt_i < 1) cnt_i = 1;
     float cnt = (float)cnt_i;
     for (c = 0; c < C; ++c) {

@@ -727,3 +727,36 @@ def test_rnms_outliers_clamp_into_the_robust_frame(case, nms_path):
     for thr in (0.3, 0.6):
         _, inds = rnms(t(d), thr)
         assert np.array_equal(inds.cpu().numpy(), oracle.rnms(d, thr)), (case, thr)
+
+
+@pytest.mark.parametrize('case', ['staged', 'big_rois', 'adaptive_grid', 'odd_shapes'])
+def test_rroi_align_backward_paths(case):
+    """backward: the staged path (per-wave LDS accumulation), the direct-atomics fallback (big
+    footprints, adaptive sampling grids) and RoIs that leave the map / name a bad batch index"""
+    from aidet_amd import rroi_align
+    rng = np.random.default_rng(11)
+    if case == 'staged':
+        B, C, H, W, K, out, sn, scale, canvas = 2, 40, 64, 64, 60, 7, 2, 0.25, 256
+    elif case == 'big_rois':
+        B, C, H, W, K, out, sn, scale, canvas = 1, 16, 96, 96, 12, 7, 2, 1.0, 96
+    elif case == 'adaptive_grid':
+        B, C, H, W, K, out, sn, scale, canvas = 1, 8, 48, 48, 20, 3, 0, 0.5, 96
+    else:
+        B, C, H, W, K, out, sn, scale, canvas = 3, 13, 37, 45, 33, (5, 9), 1, 0.25, 180
+    feat = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    rois = _rois(K, canvas, 70 + K, batch=B)
+    if case == 'big_rois':
+        rois[:, 3:5] *= 0.6          # up to ~77 px wide at scale 1: footprints beyond the LDS quarter
+    rois[0, 1:3] = [-30.0, 10.0]      # mostly off the map
+    rois[1, 1:3] = [canvas + 50.0, canvas + 50.0]   # entirely off the map
+    rois[2, 0] = B                     # invalid batch index: contributes nothing
+    ph, pw = (out, out) if isinstance(out, int) else out
+    g = rng.standard_normal((K, C, ph, pw)).astype(np.float32)
+    ft = t(feat).requires_grad_(True)
+    res = rroi_align(ft, t(rois), out, scale, sn)
+    res.backward(t(g))
+    ref = oracle.rroi_align_backward(g, rois, feat.shape, scale, sn)
+    got = ft.grad.cpu().numpy()
+    assert np.abs(got - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
+    # and the forward of the same call
+    assert np.abs(res.detach().cpu().numpy() - oracle.rroi_align_forward(feat, rois, out, scale, sn)).max() <= IOU_TOL
