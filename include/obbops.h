@@ -20,6 +20,8 @@
  *   - the library never allocates device memory: the caller passes outputs and
  *     a workspace sized by the *_workspace_bytes query (reference: scratch from
  *     the caching allocator, nms_kernel.cu:94,133).
+ *     (Host side: obb_nms_* keeps ONE 256-byte pinned host buffer per calling
+ *     thread, into which the last kernel writes the result counters.)
  *   - return value: OBB_OK or a negative OBB_E* code; obb_last_error() gives a
  *     thread-local message (reference: AT_ASSERTM/AT_CHECK -> RuntimeError,
  *     mmdet/ops/nms/src/nms_cpu.cpp:7, roi_align_cuda.cpp:37-42).
