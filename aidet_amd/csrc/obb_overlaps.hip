@@ -73,6 +73,8 @@ __global__ __launch_bounds__(256) void overlaps_tile_kernel(
   __shared__ uint32_t queue[kWaves][kQueue];
   __shared__ float red[kWaves][4];
   __shared__ float frame[4];                      // base x, base y, scale x, scale y
+  __shared__ uint32_t fin[kWaves * 64];           // the waves' leftover candidates, clipped together
+  __shared__ int fin_n;
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -158,7 +160,9 @@ __global__ __launch_bounds__(256) void overlaps_tile_kernel(
     }
   }
   __syncthreads();
-  if (jw >= n) return;  // whole wave beyond the matrix (after the last barrier)
+  if (threadIdx.x == 0) fin_n = 0;   // (published by the barrier at the end of the scan)
+  const bool wave_on = jw < n;        // a wave beyond the matrix only takes part in the barriers
+  const int64_t jb = (int64_t)blockIdx.x * kColsPerBlock;
 
   uint32_t *q = queue[wave];
   int qn = 0;  // wave-uniform
@@ -173,13 +177,13 @@ __global__ __launch_bounds__(256) void overlaps_tile_kernel(
 #ifndef OBB_OV_NOCLIP
       if (lane < take) {
         const uint32_t e = q[qn + lane];
-        clip_and_store<KIND>(a, b, i0 + (e >> 10), jw + (e & 1023u), n, mode, out);
+        clip_and_store<KIND>(a, b, i0 + (e >> 10), jb + (e & 1023u), n, mode, out);
       }
 #endif
     }
   };
 
-  for (int g = 0; g < ti; g += 64) {          // 64 rows per VGPR pair
+  for (int g = 0; wave_on && g < ti; g += 64) {          // 64 rows per VGPR pair
     const uint2 rv = qrow[g + lane];
     const int rows = min(64, ti - g);
     for (int ib = 0; ib < rows; ib += 8) {
@@ -221,7 +225,7 @@ __global__ __launch_bounds__(256) void overlaps_tile_kernel(
           const bool cand = qdisjoint(rlo, rhi, col[c].x, col[c].y) == 0u;
           const uint64_t mk = __ballot(cand);
           if (mk) {
-            if (cand) q[qn + __popcll(mk & lt_mask)] = ((uint32_t)(g + ii) << 10) | (uint32_t)(lane * kColsPerLane + c);
+            if (cand) q[qn + __popcll(mk & lt_mask)] = ((uint32_t)(g + ii) << 10) | (uint32_t)(wave * kColsPerWave + lane * kColsPerLane + c);
             qn += __popcll(mk);
           }
         }
@@ -229,7 +233,24 @@ __global__ __launch_bounds__(256) void overlaps_tile_kernel(
       }
     }
   }
-  drain(true);
+  // the < 64 candidates every wave has left are pooled and clipped 64 at a time by the whole
+  // block (four partial passes of ~1100 VALU each become one or two full ones)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's zero stores are out
+  __syncthreads();
+  int base = 0;
+  if (lane == 0 && qn > 0) base = atomicAdd(&fin_n, qn);
+  base = __shfl(base, 0);
+  if (lane < qn) fin[base + lane] = q[lane];
+  __syncthreads();
+  const int total = fin_n;
+#ifndef OBB_OV_NOCLIP
+  for (int start = wave * 64; start < total; start += kWaves * 64) {
+    if (start + lane < total) {
+      const uint32_t e = fin[start + lane];
+      clip_and_store<KIND>(a, b, i0 + (e >> 10), jb + (e & 1023u), n, mode, out);
+    }
+  }
+#endif
 }
 
 // aligned (pair i with pair i): one lane per pair
