@@ -11,33 +11,39 @@
 // definition needs the boxes to be physically sorted by score, so the single
 // sort of this pipeline is spent on SPACE instead: boxes are ordered along a
 // Morton curve, tiles of 256 consecutive boxes get a bounding box, and only
-// tile pairs whose boxes meet are scanned (about 1/30 of all pairs at n = 100k,
-// for any distribution -- big boxes just make big tiles).
+// (32-row sub-tile, tile) units whose boxes meet are scanned (about 1/70 of all
+// pairs at n = 100k, for any distribution -- big boxes just make big tiles).
 //
-//   1 prep     per box: 64-byte quad record, conservative AABB interval, score
-//              key; per-block min/max of the scene
-//   2 quant    intervals -> 15-bit grid over the scene, x|y packed in a dword
+// Three routes (same arithmetic, same edge / resolve formulation):
+//   n <= 128      nms_small_kernel: everything in ONE workgroup
+//   n <= 10240    direct: prep -> scan of all tile pairs + clip -> resolve + compaction
+//   larger        sorted:
+//   1 prep     per box: 64-byte quad record, conservative AABB interval, area, score
+//              key; per-block bounding box + centre statistics (robust frame);
+//              clears the counters of the call
+//   2 quant    robust frame, intervals -> 15-bit grid over it, x|y packed in a dword
 //              with guard bits; Morton cell of the centre + cell histogram
-//   3 sort     counting sort by the 16-bit Morton CELL of the centre (histogram
-//              fused into 2, one scan block, one scatter): only tile locality
-//              matters, the order inside a cell is irrelevant for the result
-//   4 permute  packed intervals in spatial order + one bounding box per tile
-//   5 cull     all tile pairs (A <= B): keep those whose bounding boxes meet
-//   6 scan     per surviving tile pair 256 x 256 interval tests, 3 full-rate
-//              VALU ops per pair (a wave holds 64 rows in one VGPR pair and
-//              broadcasts them with v_readlane; 4 columns per lane), one wave
-//              vote per 256 pairs; survivors are compacted through a per-wave
-//              LDS queue (ballot/popcount) into sharded global CANDIDATE lists
+//   3 sort     counting sort by the Morton CELL of the centre (one scan block, one
+//              scatter): only tile locality matters, the order inside a cell is
+//              irrelevant for the result
+//   4 permute  packed intervals (+ a 16-byte record) in spatial order; bounding box per
+//              tile of 256 and per sub-tile of 32
+//   5 cull     scan units = (sub-tile of A, tile B > A) whose boxes meet, heavy first
+//   6 scan     wave = one unit: only the rows that meet B's box, 3 full-rate VALU ops
+//              per pair (rows broadcast with v_readlane, 4 columns per lane), one wave
+//              vote per 256 pairs; candidate rows read their per-pair results back and
+//              push RAW candidates into a per-wave LDS queue; batches of 64 are pruned
+//              (threshold-aware) into sharded global CANDIDATE lists
 //   7 clip     one candidate pair per lane, perfectly balanced: the polygon
 //              clip (~1100 VALU) runs with every lane busy; pairs with overlap
 //              >= thr become directed EDGES (preceding box -> other box) and
-//              bump cnt[target].  The n x n/64 bit matrix of the reference is
-//              never materialised.
-//   8 resolve  rounds over the live edges only: an edge whose source is kept
-//              suppresses its target; an edge whose source is suppressed
-//              decrements cnt[target], which becomes kept at zero.
-//   9 compact  block scan over the flags (already in original index order) ->
-//              ascending int64 indices (nms_cpu.cpp:59) + count.
+//              bump the in-degree word of the target.  The n x n/64 bit matrix of the
+//              reference is never materialised.
+//   8 resolve  64 workgroups sweep their own edge shards asynchronously: an edge whose
+//              source is kept marks its target SUPPRESSED; an edge whose source is
+//              suppressed decrements the target's in-degree; a word of zero = kept.
+//   9 compact  block scan over the words (already in original index order) ->
+//              ascending int64 indices (nms_cpu.cpp:59); counters to pinned host memory.
 #include <cstdlib>
 #include <cstring>
 
