@@ -223,6 +223,22 @@ def extras(dev, oracle):
             res[tag]['cpu_oracle_ms'] = round(dt * 1e3, 2)
             res[tag]['cpu_oracle_pairs_per_s'] = round(m * m / dt, 1)
             res[tag]['max_abs_diff_vs_oracle'] = float(np.abs(got - ref).max())
+    # per-call latency of rnms at the sizes a detection head sees (one image / one class set):
+    # fused (n <= 128), direct (n <= 10240) and sorted routes; full call incl. the count read-back
+    from aidet_amd.nms_wrapper import _run_nms
+    from aidet_amd import _lib as _l
+    for nn in (100, 2048, 20000):
+        dd = torch.from_numpy(oracle.synth_boxes(nn, (nn ** 0.5) * 63.0, 7)).to(dev)
+        for _ in range(5):
+            _run_nms(dd, _l.KIND_RBOX, 0.5)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(100):
+            kk, _info = _run_nms(dd, _l.KIND_RBOX, 0.5)
+        torch.cuda.synchronize()
+        us = (time.perf_counter() - t0) / 100 * 1e6
+        res['rnms_latency_n%d' % nn] = {'us_per_call': round(us, 1), 'boxes_per_s': round(nn / us * 1e6, 1),
+                                        'kept': int(kk.numel())}
     # RRoIAlign, configs[2]
     rng = np.random.default_rng(5)
     feat = torch.from_numpy(rng.standard_normal((1, 256, 256, 256)).astype(np.float32)).to(dev)
