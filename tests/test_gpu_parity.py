@@ -760,3 +760,24 @@ def test_rroi_align_backward_paths(case):
     assert np.abs(got - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
     # and the forward of the same call
     assert np.abs(res.detach().cpu().numpy() - oracle.rroi_align_forward(feat, rois, out, scale, sn)).max() <= IOU_TOL
+
+
+@pytest.mark.parametrize('ngroups', [3, 40, 2500])
+def test_grouped_rnms_many_groups_share_one_coordinate_range(ngroups, nms_path):
+    """The merged NMS of tiled inference (config 5): thousands of (image, class) groups in ONE
+    coordinate range.  The sorted route orders by a hash bucket of the group first (arbitrary,
+    also negative, group ids); the keep set must equal the oracle's."""
+    from aidet_amd import rnms
+    n = 24000
+    d = oracle.synth_boxes(n, 1500, 900 + ngroups)         # dense: many cross-group overlaps
+    rng = np.random.default_rng(ngroups)
+    ids = rng.integers(-2**31, 2**31 - 1, ngroups, dtype=np.int64).astype(np.int32)
+    g = ids[rng.integers(0, ngroups, n)]
+    ref = oracle.rnms(d, 0.3, groups=g)
+    _, inds = rnms(t(d), 0.3, groups=t(g))
+    assert np.array_equal(inds.cpu().numpy(), ref)
+    # per-box thresholds on top (pruning off)
+    thr = rng.choice([0.1, 0.3, 0.5], n).astype(np.float32)
+    ref2 = oracle.rnms(d, 0.3, groups=g, thrs=thr)
+    _, inds2 = rnms(t(d), 0.3, groups=t(g), thrs=t(thr))
+    assert np.array_equal(inds2.cpu().numpy(), ref2)
