@@ -537,7 +537,9 @@ __global__ __launch_bounds__(256) void nms_permute_kernel(const uint2 *__restric
                                                           const int *__restrict__ ginfo,
                                                           int32_t *__restrict__ pg,
                                                           uint32_t *__restrict__ tgr,
-                                                          uint32_t *__restrict__ sgr) {
+                                                          uint32_t *__restrict__ sgr,
+                                                          const float *__restrict__ thrs,
+                                                          float *__restrict__ pt) {
   __shared__ uint4 wred[4];
   __shared__ uint2 gred[4];
   const int64_t s = (int64_t)blockIdx.x * kTile + threadIdx.x;
@@ -552,6 +554,7 @@ __global__ __launch_bounds__(256) void nms_permute_kernel(const uint2 *__restric
   qs[s] = o;
   // one 16-byte record per position for the candidate batches (one gather instead of three)
   pf[s] = make_uint4(o.x, o.y, __float_as_uint(ar), id);
+  if (thrs) pt[s] = (s < n) ? thrs[id] : 0.0f;
   // grouped calls: the group of every position and the bucket range (lo | hi << 16) of
   // every sub-tile / tile (empty: lo > hi)
   uint32_t glo = 0xFFFFu, ghi = 0u;
@@ -734,6 +737,7 @@ struct SortedSink {
   Prune pr;
   const uint4 *__restrict__ pf;             // per position: packed interval, area, box id
   const int32_t *__restrict__ pg;           // per position: group id (grouped calls, else null)
+  const float *__restrict__ pt;             // per position: threshold (per-box thresholds, else null)
   uint2 *__restrict__ cand;                 // this wave's candidate segment
   unsigned long long segcap;
   unsigned long long *__restrict__ ccnt;
@@ -747,11 +751,15 @@ struct SortedSink {
       const float ra = __uint_as_float(a.z), ca = __uint_as_float(b.z);
       ids = make_uint2(a.w, b.w);
       if (pg) keep = pg[e.x] == pg[e.y];   // boxes of different groups never interact
-      if (keep && pr.thr > 0.0f) {
+      // per-box thresholds: the one that applies is the earlier box's, i.e. one of the two --
+      // a pair that cannot reach the SMALLER one cannot reach it either
+      Prune p = pr;
+      if (pt) p.thr = min_sel(pt[e.x], pt[e.y]);
+      if (keep && p.thr > 0.0f) {
         // an interval that touches the first or last cell may have been CLAMPED into the frame
         // (robust frame, nms_quant_kernel): its cells then say nothing about its extent
         const bool edge = qedge(a.x, a.y) || qedge(b.x, b.y);
-        keep = prune_area(pr, ra, ca) && (edge || prune_aabb(pr, a.x, a.y, ra, b.x, b.y, ca));
+        keep = prune_area(p, ra, ca) && (edge || prune_aabb(p, a.x, a.y, ra, b.x, b.y, ca));
       }
     }
     const uint64_t mk = __ballot(keep);
@@ -836,6 +844,7 @@ __device__ __forceinline__ void nms_scan_rows(uint2 rv, uint32_t rows, uint32_t 
 __global__ __launch_bounds__(64 * kNmsWaves) void nms_scan_kernel(const uint2 *__restrict__ qs,
                                                        const uint4 *__restrict__ pf,
                                                        const int32_t *__restrict__ pg,
+                                                       const float *__restrict__ pt,
                                                        const float *__restrict__ cellpx, float thr,
                                                        const uint2 *__restrict__ tbox, int nt,
                                                        const uint2 *__restrict__ units,
@@ -854,7 +863,7 @@ __global__ __launch_bounds__(64 * kNmsWaves) void nms_scan_kernel(const uint2 *_
   const int shard = (int)(gw & (kShards - 1));
   SortedSink sink;
   sink.pr.thr = thr; sink.pr.cpx = cellpx[0]; sink.pr.cpy = cellpx[1];
-  sink.pf = pf; sink.pg = pg;
+  sink.pf = pf; sink.pg = pg; sink.pt = pt;
   sink.cand = cands + (size_t)shard * segcap;
   sink.segcap = segcap;
   sink.ccnt = ccnts + (size_t)shard * kCandStride;
@@ -984,6 +993,7 @@ __device__ __forceinline__ bool prune_aabb_f(const Prune &pr, float4 a, float ra
 
 struct DirectSink {
   Prune pr;
+  bool per_box_thr;                         // thresholds come from the records (pr.thr unused)
   const float4 *__restrict__ iv;
   const float *__restrict__ ar;
   const QuadRec *__restrict__ rec;
@@ -1015,7 +1025,9 @@ struct DirectSink {
       // (the quantised test is coarser than the float intervals: re-test them; boxes of
       // different groups never interact)
       keep = fin && (ga == gb) && (a.x <= b.y) && (b.x <= a.y) && (a.z <= b.w) && (b.z <= a.w);
-      if (keep && pr.thr > 0.0f) keep = prune_area(pr, A.area, B.area) && prune_aabb_f(pr, a, A.area, b, B.area);
+      Prune p = pr;
+      if (per_box_thr) p.thr = min_sel(ta, tb);   // the earlier box's applies: one of the two
+      if (keep && p.thr > 0.0f) keep = prune_area(p, A.area, B.area) && prune_aabb_f(p, a, A.area, b, B.area);
     }
     const uint64_t mk = __ballot(keep);
     if (mk == 0) return;
@@ -1055,6 +1067,7 @@ __global__ __launch_bounds__(64 * kNmsWaves) void nms_scan_direct_kernel(const f
                                                                 const float *__restrict__ ar,
                                                                 const QuadRec *__restrict__ rec,
                                                                 uint32_t n, int rows_per_wave, float thr,
+                                                                int per_box_thr,
                                                                 uint2 *__restrict__ edges,
                                                                 unsigned long long segcap,
                                                                 unsigned long long *__restrict__ ccnts,
@@ -1073,6 +1086,7 @@ __global__ __launch_bounds__(64 * kNmsWaves) void nms_scan_direct_kernel(const f
   const int shard = (int)(gw & (kShards - 1));
   DirectSink sink;
   sink.pr.thr = thr; sink.pr.cpx = 0.0f; sink.pr.cpy = 0.0f;
+  sink.per_box_thr = per_box_thr != 0;
   sink.iv = iv; sink.ar = ar; sink.rec = rec;
   sink.eseg = edges + (size_t)shard * segcap;
   sink.segcap = segcap;
@@ -1684,7 +1698,7 @@ static thread_local NmsProfile g_prof;
 
 // ---- workspace layout ------------------------------------------------------------
 struct NmsLayout {
-  size_t rec, iv, ar, part, pstat, qb, ckey, sid, qs, pf, pg, tgr, sgr, ginfo, cellpx, tbox, sbox, zero_begin, cnt, ctr, ccnts, hist,
+  size_t rec, iv, ar, part, pstat, qb, ckey, sid, qs, pf, pg, pt, tgr, sgr, ginfo, cellpx, tbox, sbox, zero_begin, cnt, ctr, ccnts, hist,
       zero_end, blockcnt, cands, edges, total;
   unsigned long long cap;         // candidate pairs == overlap edges capacity
   unsigned long long unit_worst;  // every (sub-tile, tile) unit there can be
@@ -1713,6 +1727,7 @@ static int nms_layout(int64_t n, int64_t edge_capacity, NmsLayout &L) {
   L.qs = take((nt * kTile + kRowChunk) * sizeof(uint2));
   L.pf = take((nt * kTile) * sizeof(uint4));
   L.pg = take((nt * kTile) * sizeof(int32_t));
+  L.pt = take((nt * kTile) * sizeof(float));
   L.tgr = take(nt * sizeof(uint32_t));
   L.sgr = take(nt * kSub * sizeof(uint32_t));
   L.ginfo = take(4 * sizeof(int));
@@ -1810,6 +1825,7 @@ extern "C" int obb_nms_grouped_f32(const float *dets_dev, int64_t n, int kind, f
   uint2 *qs = reinterpret_cast<uint2 *>(ws + L.qs);
   uint4 *pf = reinterpret_cast<uint4 *>(ws + L.pf);
   int32_t *pg = group_dev ? reinterpret_cast<int32_t *>(ws + L.pg) : nullptr;
+  float *pt = thr_dev ? reinterpret_cast<float *>(ws + L.pt) : nullptr;
   uint32_t *tgr = group_dev ? reinterpret_cast<uint32_t *>(ws + L.tgr) : nullptr;
   uint32_t *sgr = group_dev ? reinterpret_cast<uint32_t *>(ws + L.sgr) : nullptr;
   int *ginfo = reinterpret_cast<int *>(ws + L.ginfo);
@@ -1879,7 +1895,7 @@ extern "C" int obb_nms_grouped_f32(const float *dets_dev, int64_t n, int kind, f
     }
     return OBB_OK;
   }
-  // threshold-aware pruning needs ONE threshold: off when per-box thresholds are given
+  // threshold-aware pruning: the call's threshold, or per pair the smaller of the two boxes'
   const float prune_thr = thr_dev ? 0.0f : iou_thr;
   // phase 0: prep (+ clears the counters) [+ quantise]
   OBB_PHASE(0);
@@ -1901,7 +1917,7 @@ extern "C" int obb_nms_grouped_f32(const float *dets_dev, int64_t n, int kind, f
     while (rpw > 4 && ((n + rpw - 1) / rpw) * (long long)(nt + 1) / 2 < 2048) rpw >>= 1;
     const unsigned nparts = (unsigned)((n + rpw - 1) / rpw);
     hipLaunchKernelGGL(nms_scan_direct_kernel, dim3((nparts + kNmsWaves - 1) / kNmsWaves, (unsigned)nt), dim3(64 * kNmsWaves), 0, st,
-                       iv, ar, rec, (uint32_t)n, rpw, prune_thr, edges, segcap, ccnts, cnt);
+                       iv, ar, rec, (uint32_t)n, rpw, prune_thr, thr_dev ? 1 : 0, edges, segcap, ccnts, cnt);
     OBB_LAUNCH_CHECK();
     OBB_PHASE(4);
     OBB_PHASE(5);
@@ -1925,7 +1941,7 @@ extern "C" int obb_nms_grouped_f32(const float *dets_dev, int64_t n, int kind, f
     OBB_LAUNCH_CHECK();
     // phase 2: permute + tile boxes + unit culling
     OBB_PHASE(2);
-    hipLaunchKernelGGL(nms_permute_kernel, dim3((unsigned)nt), dim3(kTile), 0, st, qb, sid, ar, n, qs, pf, tbox, sbox, group_dev, ginfo, pg, tgr, sgr);
+    hipLaunchKernelGGL(nms_permute_kernel, dim3((unsigned)nt), dim3(kTile), 0, st, qb, sid, ar, n, qs, pf, tbox, sbox, group_dev, ginfo, pg, tgr, sgr, thr_dev, pt);
     OBB_LAUNCH_CHECK();
     hipLaunchKernelGGL(nms_cull_kernel, dim3((unsigned)nt, (unsigned)((nt + kCullChunk - 1) / kCullChunk)), dim3(256), 0, st, tbox, sbox, tgr, sgr, nt, units, ucap, ctr);
     OBB_LAUNCH_CHECK();
@@ -1936,7 +1952,7 @@ extern "C" int obb_nms_grouped_f32(const float *dets_dev, int64_t n, int kind, f
       long long pb = kScanBlocks;
       if (const char *e = getenv("OBB_NMS_SCAN_BLOCKS")) pb = atoll(e) > 0 ? atoll(e) : pb;  // tuning knob
       const unsigned gb = (unsigned)(maxblocks < pb ? maxblocks : pb);
-      hipLaunchKernelGGL(nms_scan_kernel, dim3(gb), dim3(64 * kNmsWaves), 0, st, qs, pf, pg, cellpx, prune_thr, tbox, nt, units, ucap, cands, segcap, ctr, ccnts);
+      hipLaunchKernelGGL(nms_scan_kernel, dim3(gb), dim3(64 * kNmsWaves), 0, st, qs, pf, pg, pt, cellpx, prune_thr, tbox, nt, units, ucap, cands, segcap, ctr, ccnts);
       OBB_LAUNCH_CHECK();
     }
     // phase 4: clip (narrow phase)
