@@ -76,14 +76,31 @@ def check(rc):
         raise ObbOpsError('libobbops error %d: %s' % (rc, lib().obb_last_error().decode()))
 
 
+_gpu_ok = False
+
+
 def require_gpu():
+    global _gpu_ok
+    if _gpu_ok:                      # (checked once: these ops are called thousands of times)
+        return
     if not torch.cuda.is_available():
         raise RuntimeError('aidet_amd ops run on a HIP device only (no CPU path); '
                            'torch.cuda.is_available() is False')
+    _gpu_ok = True
+
+
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
+def current_stream_handle(device):
+    """hipStream_t of torch's current stream on `device` as an int."""
+    if _raw_stream is not None:
+        return _raw_stream(device.index if device.index is not None else torch.cuda.current_device())
+    return torch.cuda.current_stream(device).cuda_stream
 
 
 def stream_ptr(device):
-    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    return ctypes.c_void_p(current_stream_handle(device))
 
 
 def to_device_f32(t, device_id=None):

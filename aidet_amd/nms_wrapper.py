@@ -74,7 +74,7 @@ def _run_nms(dets_dev, kind, iou_thr, groups=None, thrs=None):
         prev = torch.cuda.current_device()
         torch.cuda.set_device(dev)
     try:
-        stream = torch.cuda.current_stream(dev).cuda_stream
+        stream = _lib.current_stream_handle(dev)
         capacity = 0  # library default
         for _ in range(3):
             ws, nbytes = _workspace(L, dev, stream, n, kind, capacity)
