@@ -196,6 +196,7 @@ __global__ __launch_bounds__(256) void nms_prep_kernel(const float *__restrict__
       cyh = max(cyh, fkey(fy)); cyl = max(cyl, ~fkey(fy));
     }
   }
+  if (!part) return;   // direct route: no global frame, no statistics
   // Statistics for the ROBUST quantisation frame (nms_quant_kernel): the block's bounding
   // box and centre sums are taken over its boxes within 3 sigma of the BLOCK's mean centre
   // only (a uniform block spans 1.7 sigma: nothing is dropped; a stray box at 1e8 is).  Which
@@ -1904,9 +1905,9 @@ extern "C" int obb_nms_grouped_f32(const float *dets_dev, int64_t n, int kind, f
     const size_t zbytes = (direct ? L.hist : L.zero_end) - L.zero_begin;
     uint4 *zero = reinterpret_cast<uint4 *>(ws + L.zero_begin);
     if (kind == OBB_KIND_RBOX)
-      hipLaunchKernelGGL(nms_prep_kernel<0>, dim3(pblocks), dim3(256), 0, st, dets_dev, n, rec, iv, ar, part, pstat, group_dev, thr_dev, iou_thr, zero, zbytes / sizeof(uint4));
+      hipLaunchKernelGGL(nms_prep_kernel<0>, dim3(pblocks), dim3(256), 0, st, dets_dev, n, rec, iv, ar, direct ? nullptr : part, pstat, group_dev, thr_dev, iou_thr, zero, zbytes / sizeof(uint4));
     else
-      hipLaunchKernelGGL(nms_prep_kernel<1>, dim3(pblocks), dim3(256), 0, st, dets_dev, n, rec, iv, ar, part, pstat, group_dev, thr_dev, iou_thr, zero, zbytes / sizeof(uint4));
+      hipLaunchKernelGGL(nms_prep_kernel<1>, dim3(pblocks), dim3(256), 0, st, dets_dev, n, rec, iv, ar, direct ? nullptr : part, pstat, group_dev, thr_dev, iou_thr, zero, zbytes / sizeof(uint4));
     OBB_LAUNCH_CHECK();
   }
   if (direct) {
