@@ -28,14 +28,19 @@ for it in range(iters):
         d[n // 2:n // 2 + n // 10] = d[:n // 10]
         d[rng.integers(0, n), 0] += 1e7
     thr = float(rng.choice([0.05, 0.3, 0.5, 0.7, 0.95]))
-    groups = rng.integers(0, 3, n).astype(np.int32) if it % 4 == 0 else None
-    ref = oracle.rnms(d, thr, groups=groups)
+    groups = None
+    if it % 4 == 0:
+        ng = int(rng.choice([2, 3, 15, 400, 5000]))
+        ids = rng.integers(-2**31, 2**31 - 1, ng, dtype=np.int64).astype(np.int32)
+        groups = ids[rng.integers(0, ng, n)]
+    thrs = rng.choice([0.1, 0.3, 0.5, 0.7], n).astype(np.float32) if it % 6 == 0 else None
+    ref = oracle.rnms(d, thr, groups=groups, thrs=thrs)
     dt = torch.from_numpy(d).cuda()
     for route, env in (('auto', {}), ('sorted', {'OBB_NMS_DIRECT_MAX': '0', 'OBB_NMS_NO_FUSED': '1'}), ('direct', {'OBB_NMS_NO_FUSED': '1'}),
                        ('fused', {'OBB_NMS_FUSED_MAX': '1024'})):
         for kk in ('OBB_NMS_DIRECT_MAX', 'OBB_NMS_NO_FUSED', 'OBB_NMS_FUSED_MAX'): os.environ.pop(kk, None)
         os.environ.update(env)
-        got = rnms(dt, thr, groups=groups)[1].cpu().numpy()
+        got = rnms(dt, thr, groups=groups, thrs=thrs)[1].cpu().numpy()
         if not np.array_equal(got, ref):
             bad += 1
             print('MISMATCH it=%d route=%s n=%d thr=%.2f: %d vs %d kept' % (it, route, n, thr, len(got), len(ref)))
