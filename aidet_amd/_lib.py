@@ -23,6 +23,7 @@ OBB_EHIP = -3
 
 KIND_RBOX = 0
 KIND_POLY = 1
+KIND_HBB = 2   # NMS only: x1, y1, x2, y2 (+ score) with the reference's +1 convention
 MODE = {'iou': 0, 'iof': 1}
 
 _lib = None

@@ -102,11 +102,16 @@ __device__ __forceinline__ void quad_from_poly(const float p[8], Quad &q) {
   q.area = 0.5f * sh;
 }
 
-// Load one box row (rbox: 5 floats, poly: 8 floats; `stride` floats per row).
+// Load one box row (rbox: 5 floats, poly: 8 floats, hbb: 4 floats).
 template <int KIND>
 __device__ __forceinline__ void load_quad(const float *__restrict__ row, Quad &q) {
   if (KIND == 0) {
     quad_from_rbox(row[0], row[1], row[2], row[3], row[4], q);
+  } else if (KIND == 2) {
+    // horizontal box x1,y1,x2,y2 with the reference's +1 convention = the theta-0 OBB below
+    // (same fp32 operations, in the same order, as the torch expression it replaces)
+    const float x1 = row[0], y1 = row[1], x2 = row[2], y2 = row[3];
+    quad_from_rbox((x1 + x2) * 0.5f, (y1 + y2) * 0.5f, (x2 - x1) + 1.0f, (y2 - y1) + 1.0f, 0.0f, q);
   } else {
     float p[8];
 #pragma unroll

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void nms_prep_kernel(const float *__restrict__
                                                        const float *__restrict__ thrs,
                                                        float thr, uint4 *__restrict__ zero,
                                                        size_t zero_vecs) {
-  constexpr int S = KIND ? 9 : 6;
+  constexpr int S = KIND == 0 ? 6 : (KIND == 1 ? 9 : 5);
   __shared__ uint4 wred[4];
   __shared__ double sred[4][kStat];
   __shared__ double ssum[kStat];
@@ -1457,7 +1457,7 @@ __global__ __launch_bounds__(1024) void nms_small_kernel(const float *__restrict
                                                          unsigned int ecap,
                                                          int64_t *__restrict__ keep,
                                                          NmsHostInfo *__restrict__ hinfo) {
-  constexpr int S = KIND ? 9 : 6;
+  constexpr int S = KIND == 0 ? 6 : (KIND == 1 ? 9 : 5);
   __shared__ uint2 qiv[kSmallMax];            // packed (lo, hi|G)
   __shared__ float area[kSmallMax];
   __shared__ uint32_t skey[kSmallMax];
@@ -1794,7 +1794,7 @@ extern "C" int obb_nms_grouped_f32(const float *dets_dev, int64_t n, int kind, f
   using namespace obb;
   if (info_host) { info_host[0] = 0; info_host[1] = 0; info_host[2] = 0; info_host[3] = 0; }
   if (n < 0) return set_err(OBB_EINVAL, "obb_nms_f32: negative n");
-  if (kind != OBB_KIND_RBOX && kind != OBB_KIND_POLY) return set_err(OBB_EINVAL, "obb_nms_f32: bad kind %d", kind);
+  if (kind != OBB_KIND_RBOX && kind != OBB_KIND_POLY && kind != OBB_KIND_HBB) return set_err(OBB_EINVAL, "obb_nms_f32: bad kind %d", kind);
   if (n == 0) return OBB_OK;
   if (n > (int64_t)kTile * 65535) return set_err(OBB_EINVAL, "obb_nms_f32: n = %lld exceeds %lld", (long long)n, (long long)kTile * 65535);
   if (!dets_dev || !keep_dev || !workspace_dev) return set_err(OBB_EINVAL, "obb_nms_f32: null pointer");
@@ -1876,8 +1876,10 @@ extern "C" int obb_nms_grouped_f32(const float *dets_dev, int64_t n, int kind, f
     const unsigned int ecap = ecap64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned int)ecap64;
     if (kind == OBB_KIND_RBOX)
       hipLaunchKernelGGL(nms_small_kernel<0>, dim3(1), dim3(1024), 0, st, dets_dev, (int)n, iou_thr, group_dev, thr_dev, rec, cands, ecap, keep_dev, hinfo_dev);
-    else
+    else if (kind == OBB_KIND_POLY)
       hipLaunchKernelGGL(nms_small_kernel<1>, dim3(1), dim3(1024), 0, st, dets_dev, (int)n, iou_thr, group_dev, thr_dev, rec, cands, ecap, keep_dev, hinfo_dev);
+    else
+      hipLaunchKernelGGL(nms_small_kernel<2>, dim3(1), dim3(1024), 0, st, dets_dev, (int)n, iou_thr, group_dev, thr_dev, rec, cands, ecap, keep_dev, hinfo_dev);
     OBB_LAUNCH_CHECK();
     OBB_HIP_TRY(hipStreamSynchronize(st));
     const NmsHostInfo hs = *hinfo;
@@ -1906,8 +1908,10 @@ extern "C" int obb_nms_grouped_f32(const float *dets_dev, int64_t n, int kind, f
     uint4 *zero = reinterpret_cast<uint4 *>(ws + L.zero_begin);
     if (kind == OBB_KIND_RBOX)
       hipLaunchKernelGGL(nms_prep_kernel<0>, dim3(pblocks), dim3(256), 0, st, dets_dev, n, rec, iv, ar, direct ? nullptr : part, pstat, group_dev, thr_dev, iou_thr, zero, zbytes / sizeof(uint4));
-    else
+    else if (kind == OBB_KIND_POLY)
       hipLaunchKernelGGL(nms_prep_kernel<1>, dim3(pblocks), dim3(256), 0, st, dets_dev, n, rec, iv, ar, direct ? nullptr : part, pstat, group_dev, thr_dev, iou_thr, zero, zbytes / sizeof(uint4));
+    else
+      hipLaunchKernelGGL(nms_prep_kernel<2>, dim3(pblocks), dim3(256), 0, st, dets_dev, n, rec, iv, ar, direct ? nullptr : part, pstat, group_dev, thr_dev, iou_thr, zero, zbytes / sizeof(uint4));
     OBB_LAUNCH_CHECK();
   }
   if (direct) {

@@ -37,7 +37,7 @@ at::Tensor as_f32_dev(const at::Tensor &t, const char *name) {
 // keep indices (int64, ascending original order -- nms_cpu.cpp:59, nms_kernel.cu:135-138)
 at::Tensor nms_impl(const at::Tensor &dets_in, int kind, double thr, const c10::optional<at::Tensor> &groups,
                     const c10::optional<at::Tensor> &thrs) {
-  const int cols = kind == OBB_KIND_RBOX ? 6 : 9;
+  const int cols = kind == OBB_KIND_RBOX ? 6 : (kind == OBB_KIND_POLY ? 9 : 5);
   TORCH_CHECK(dets_in.dim() == 2 && dets_in.size(1) == cols, "dets must be (n, ", cols, ")");
   const int64_t n = dets_in.size(0);
   if (n == 0) return at::empty({0}, dets_in.options().dtype(at::kLong));   // nms_wrapper.py:50-51
@@ -75,6 +75,8 @@ at::Tensor nms_impl(const at::Tensor &dets_in, int kind, double thr, const c10::
 
 at::Tensor rnms(const at::Tensor &dets, double thr) { return nms_impl(dets, OBB_KIND_RBOX, thr, c10::nullopt, c10::nullopt); }
 at::Tensor poly_nms(const at::Tensor &dets, double thr) { return nms_impl(dets, OBB_KIND_POLY, thr, c10::nullopt, c10::nullopt); }
+// horizontal boxes (n, 5) x1, y1, x2, y2, score: the signature of nms_cuda.nms (nms_cuda.cpp:8)
+at::Tensor hbb_nms(const at::Tensor &dets, double thr) { return nms_impl(dets, OBB_KIND_HBB, thr, c10::nullopt, c10::nullopt); }
 at::Tensor rnms_grouped(const at::Tensor &dets, double thr, const c10::optional<at::Tensor> &groups,
                         const c10::optional<at::Tensor> &thrs) {
   return nms_impl(dets, OBB_KIND_RBOX, thr, groups, thrs);
@@ -155,6 +157,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("build_info", []() { return std::string(obb_build_info()); });
   m.def("rnms", &rnms, "rotated NMS: keep indices (int64, ascending)", py::arg("dets"), py::arg("threshold"));
   m.def("poly_nms", &poly_nms, "polygon NMS: keep indices", py::arg("dets"), py::arg("threshold"));
+  m.def("nms", &hbb_nms, "horizontal-box NMS (the reference's +1 convention): keep indices", py::arg("dets"), py::arg("threshold"));
   m.def("rnms_grouped", &rnms_grouped, py::arg("dets"), py::arg("threshold"), py::arg("groups") = py::none(),
         py::arg("thrs") = py::none());
   m.def("poly_nms_grouped", &poly_nms_grouped, py::arg("dets"), py::arg("threshold"), py::arg("groups") = py::none(),

@@ -170,7 +170,7 @@ pointobb_nms = poly_nms
 
 def nms(dets, iou_thr, device_id=None, groups=None):
     """Horizontal-box NMS with the reference's exact signature
-    (nms_wrapper.py:7), served by the rotated kernel through the theta = 0
+    (nms_wrapper.py:7), served by the rotated kernels through the theta = 0
     mapping  w = x2-x1+1, h = y2-y1+1, centre = box centre  (the continuous box
     [x1-.5, x2+.5] x [y1-.5, y2+.5] has the reference's +1 intersection widths,
     nms_cpu.cpp:19,52-55).  dets: (n, 5) <x1, y1, x2, y2, score>."""
@@ -183,14 +183,14 @@ def nms(dets, iou_thr, device_id=None, groups=None):
     else:
         raise TypeError('dets must be either a Tensor or numpy array, but got {}'.format(
             type(dets)))
+    if dets_th.dim() != 2 or dets_th.size(1) != 5:
+        raise ValueError('nms expects dets of shape (n, 5), got {}'.format(tuple(dets_th.shape)))
     if dets_th.shape[0] == 0:
         inds = dets_th.new_zeros(0, dtype=torch.long)
     else:
         d = _lib.to_device_f32(dets_th, device_id)
-        rb = torch.stack([(d[:, 0] + d[:, 2]) * 0.5, (d[:, 1] + d[:, 3]) * 0.5,
-                          d[:, 2] - d[:, 0] + 1.0, d[:, 3] - d[:, 1] + 1.0,
-                          torch.zeros_like(d[:, 0]), d[:, 4]], dim=1).contiguous()
-        inds, _ = _run_nms(rb, _lib.KIND_RBOX, float(iou_thr), _as_tensor(groups))
+        # the kernel reads x1, y1, x2, y2 and builds the theta = 0 OBB itself (OBB_KIND_HBB)
+        inds, _ = _run_nms(d, _lib.KIND_HBB, float(iou_thr), _as_tensor(groups))
         if not is_numpy:
             inds = inds.to(dets_th.device)
     if is_numpy:

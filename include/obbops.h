@@ -33,6 +33,10 @@
  *        cv2.boxPoints meaning used by mmdet/core/rbbox/transforms.py:45-55)
  *   kind OBB_KIND_POLY: row = x1,y1,x2,y2,x3,y3,x4,y4 (convex quad, any
  *        orientation; the pointobb of transforms.py:45-55)
+ *   kind OBB_KIND_HBB (obb_nms_* only): row = x1, y1, x2, y2 with the reference's +1 pixel
+ *        convention (nms_cpu.cpp:19,52-55): the box is the theta = 0 OBB with centre
+ *        ((x1+x2)/2, (y1+y2)/2), w = x2-x1+1, h = y2-y1+1 -- the continuous box
+ *        [x1-.5, x2+.5] x [y1-.5, y2+.5], whose intersection widths are the reference's.
  *   NMS rows carry one extra trailing float: the score.
  */
 #ifndef OBBOPS_H_
@@ -58,6 +62,7 @@ extern "C" {
 
 #define OBB_KIND_RBOX 0
 #define OBB_KIND_POLY 1
+#define OBB_KIND_HBB 2  /* NMS only: row = x1,y1,x2,y2 (+score), the reference's horizontal boxes */
 #define OBB_MODE_IOU 0
 #define OBB_MODE_IOF 1
 
@@ -88,7 +93,7 @@ OBB_API int obb_overlaps_f32(const float *a_dev, int64_t m, const float *b_dev, 
  * suppresses every later j with overlap(i,j) >= iou_thr; the result is the
  * ASCENDING list of original indices of unsuppressed boxes.
  *
- *   dets_dev   (n, 6) for OBB_KIND_RBOX, (n, 9) for OBB_KIND_POLY
+ *   dets_dev   (n, 6) for OBB_KIND_RBOX, (n, 9) for OBB_KIND_POLY, (n, 5) for OBB_KIND_HBB
  *   keep_dev   int64[n]; the first K entries are valid on return
  *   info_host  int64[4] (may be NULL): [0] K, [1] overlap edges found,
  *              [2] resolve rounds, [3] candidate pairs clipped

@@ -691,6 +691,8 @@ def test_torch_extension_matches_ctypes_path():
     p = np.concatenate([oracle.rbox_to_poly(d).astype(np.float32), d[:, 5:6]], 1)
     assert torch.equal(e.poly_nms(t(p), 0.5), poly_nms(t(p), 0.5)[1])
     a, b = t(d[:300, :5]), t(d[300:1000, :5])
+    hb = np.concatenate([hbb := np.sort(np.random.default_rng(9).uniform(0, 300, (800, 4)), axis=1)[:, [0, 2, 1, 3]], np.random.default_rng(10).random((800, 1))], 1).astype(np.float32)
+    assert np.array_equal(e.nms(t(hb), 0.5).cpu().numpy(), oracle.hbb_nms(hb, 0.5))
     assert torch.equal(e.rbbox_overlaps(a, b, 'iou', False), rbbox_overlaps(a, b))
     assert torch.equal(e.rbbox_overlaps(a, a, 'iof', True), rbbox_overlaps(a, a, mode='iof', is_aligned=True))
     assert np.abs(e.thetaobb2pointobb(a).cpu().numpy() - oracle.rbox_to_poly(d[:300])).max() <= 1e-3
