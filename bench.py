@@ -241,6 +241,25 @@ def extras(dev, oracle):
         res['rnms_latency_n%d' % nn] = {'us_per_call': round(us, 1), 'boxes_per_s': round(nn / us * 1e6, 1),
                                         'kept': int(kk.numel()), 'stat': 'median of 200 calls',
                                         'p99_us': round(float(np.percentile(ts, 99)) * 1e6, 1)}
+    # the headline workload through the bare C ABI (caller-owned keep + workspace, as a C host
+    # would call it): what the Python layer of `step()` costs on top
+    import ctypes as _ct
+    L = _l.lib()
+    nn = 100000
+    dd = torch.from_numpy(oracle.synth_boxes(nn, 20000.0, 3)).to(dev)
+    keepb = torch.empty(nn, dtype=torch.int64, device=dev)
+    wsb = torch.empty(L.obb_nms_workspace_bytes(nn, 0, 0), dtype=torch.uint8, device=dev)
+    infob = (_ct.c_int64 * 4)()
+    stp = _l.current_stream_handle(dev)
+    ts = []
+    for i in range(60):
+        t0 = time.perf_counter()
+        rc = L.obb_nms_f32(dd.data_ptr(), nn, 0, 0.5, keepb.data_ptr(), infob, wsb.data_ptr(), wsb.numel(), stp)
+        ts.append(time.perf_counter() - t0)
+        assert rc == 0
+    us = float(np.median(ts[10:])) * 1e6
+    res['rnms_100k_c_abi'] = {'us_per_call': round(us, 1), 'boxes_per_s': round(nn / us * 1e6, 1), 'kept': int(infob[0]),
+                              'stat': 'median of 50 calls of obb_nms_f32'}
     # RRoIAlign, configs[2]
     rng = np.random.default_rng(5)
     feat = torch.from_numpy(rng.standard_normal((1, 256, 256, 256)).astype(np.float32)).to(dev)
