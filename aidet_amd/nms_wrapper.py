@@ -59,38 +59,38 @@ def _run_nms(dets_dev, kind, iou_thr, groups=None, thrs=None):
     dev = dets_dev.device
     L = _lib.lib()
     keep = torch.empty(n, dtype=torch.int64, device=dev)
-    info = (ctypes.c_int64 * 4)()
-    gptr = tptr = ctypes.c_void_p(0)
+    info = getattr(_tls, 'info', None)      # (argtypes convert plain ints: no c_void_p objects per call)
+    if info is None:
+        info = _tls.info = (ctypes.c_int64 * 4)()
+    gptr = tptr = None
     if groups is not None:
         groups = groups.detach().to(device=dev, dtype=torch.int32).contiguous()
         assert groups.numel() == n
-        gptr = ctypes.c_void_p(groups.data_ptr())
+        gptr = groups.data_ptr()
     if thrs is not None:
         thrs = thrs.detach().to(device=dev, dtype=torch.float32).contiguous()
         assert thrs.numel() == n
-        tptr = ctypes.c_void_p(thrs.data_ptr())
-    same_dev = torch.cuda.current_device() == dev.index
+        tptr = thrs.data_ptr()
+    cur = torch.cuda.current_device()
+    same_dev = cur == dev.index
     if not same_dev:
-        prev = torch.cuda.current_device()
         torch.cuda.set_device(dev)
     try:
         stream = _lib.current_stream_handle(dev)
         capacity = 0  # library default
         for _ in range(3):
             ws, nbytes = _workspace(L, dev, stream, n, kind, capacity)
-            rc = L.obb_nms_grouped_f32(ctypes.c_void_p(dets_dev.data_ptr()), n, kind,
-                                       ctypes.c_float(iou_thr), gptr, tptr,
-                                       ctypes.c_void_p(keep.data_ptr()), info,
-                                       ctypes.c_void_p(ws.data_ptr()), nbytes,
-                                       ctypes.c_void_p(stream))
+            rc = L.obb_nms_grouped_f32(dets_dev.data_ptr(), n, kind, iou_thr, gptr, tptr,
+                                       keep.data_ptr(), info, ws.data_ptr(), nbytes, stream)
             if rc != _lib.OBB_EWORKSPACE:
                 break
             capacity = int(info[3])  # a pair capacity the library says suffices
     finally:
         if not same_dev:
-            torch.cuda.set_device(prev)
-    _lib.check(rc)
-    return keep[:int(info[0])], (int(info[1]), int(info[2]), int(info[3]))
+            torch.cuda.set_device(cur)
+    if rc != _lib.OBB_OK:
+        _lib.check(rc)
+    return keep[:info[0]], (info[1], info[2], info[3])
 
 
 def _as_tensor(x):
