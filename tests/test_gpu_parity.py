@@ -783,3 +783,25 @@ def test_grouped_rnms_many_groups_share_one_coordinate_range(ngroups, nms_path):
     ref2 = oracle.rnms(d, 0.3, groups=g, thrs=thr)
     _, inds2 = rnms(t(d), 0.3, groups=t(g), thrs=t(thr))
     assert np.array_equal(inds2.cpu().numpy(), ref2)
+
+
+def test_overlaps_16k_x_16k_properties():
+    """The scale-up of configs[0]: the full 16384 x 16384 matrix on the GPU; the
+    oracle checks a random sample of rows bit for bit, the rest through properties."""
+    from aidet_amd import rbbox_overlaps
+    m = 16384
+    a = oracle.synth_boxes(m, 2048, 1)[:, :5]
+    b = oracle.synth_boxes(m, 2048, 2)[:, :5]
+    ta, tb = t(a), t(b)
+    iou = rbbox_overlaps(ta, tb)
+    assert iou.shape == (m, m)
+    assert float(iou.min()) >= 0.0 and float(iou.max()) <= 1.0
+    rows = np.random.default_rng(0).choice(m, 96, replace=False)
+    assert np.array_equal(iou[torch.from_numpy(rows).cuda()].cpu().numpy(), oracle.overlaps(a[rows], b))
+    # symmetry against the transposed problem (the subject of a clip is the first box)
+    assert float((iou - rbbox_overlaps(tb, ta).t()).abs().max()) <= 2e-5
+    # disjoint pairs are exact zeros: the non-zeros are exactly the pairs the oracle's prefilter lets through
+    nz = int((iou > 0).sum())
+    assert 0 < nz < m * m // 20
+    # aligned mode = the diagonal
+    assert torch.equal(rbbox_overlaps(ta, tb, is_aligned=True), iou.diagonal())
