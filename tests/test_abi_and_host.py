@@ -129,3 +129,18 @@ def test_torch_extension_loads_and_validates():
         e.rnms(torch.zeros(4, 5), 0.5)          # wrong shape
     with pytest.raises(RuntimeError):
         e.rbbox_overlaps(torch.zeros(2, 5), torch.zeros(2, 5), 'giou', False)
+
+
+def test_header_is_c99_and_library_links_from_c(tmp_path):
+    """include/obbops.h compiles as strict C99 and a C host drives the library (argument
+    validation only: no GPU here)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, 'aidet_amd', 'lib')
+    exe = str(tmp_path / 'abi_smoke')
+    subprocess.check_call(['gcc', '-std=c99', '-pedantic', '-Wall', '-Werror', '-I', os.path.join(root, 'include'),
+                           os.path.join(root, 'tests', 'c', 'abi_smoke.c'), '-o', exe, '-L', libdir, '-lobbops',
+                           '-Wl,-rpath,' + libdir, '-Wl,-rpath,/opt/rocm/lib'])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
+    assert 'c abi ok' in out.stdout
