@@ -62,6 +62,11 @@ def lib():
         L.obb_rroi_align_forward_f32.restype = i32
         L.obb_rroi_align_backward_f32.argtypes = rroi
         L.obb_rroi_align_backward_f32.restype = i32
+        roi = [vp, i32, i32, i32, i32, vp, i64, i32, i32, f32, i32, i32, vp, vp]
+        L.obb_roi_align_forward_f32.argtypes = roi
+        L.obb_roi_align_forward_f32.restype = i32
+        L.obb_roi_align_backward_f32.argtypes = roi
+        L.obb_roi_align_backward_f32.restype = i32
         L.obb_nms_profile_enable.argtypes = [i32]
         L.obb_nms_profile_enable.restype = i32
         L.obb_nms_profile_last.argtypes = [ctypes.POINTER(f32)]

@@ -27,15 +27,40 @@ struct RoiFrame {
   float cx, cy, c, s, bin_w, bin_h, x0, y0, cnt;
 };
 
-__device__ __forceinline__ void make_frame(const float *__restrict__ roi, float scale, int ph,
+// RoI row layouts.  kind 0: [b, cx, cy, w, h, theta].  The horizontal RoIs of the reference's
+// RoIAlign, [b, x1, y1, x2, y2] (roi_align.py:136), are the theta = 0 special cases
+//   kind 1 (legacy V1, roi_align_kernel.cu:79-86): centre ((x1+x2+1)/2, (y1+y2+1)/2), size
+//          (x2-x1+1, y2-y1+1), no lower clamp
+//   kind 2 (V2 aligned=True, roi_align_kernel_v2.cu:79-86): centre ((x1+x2)/2 - off,
+//          (y1+y2)/2 - off) with off = 0.5 / spatial_scale, size (x2-x1, y2-y1), no clamp
+// evaluated here in the same fp32 operations the former torch-side mapping used.
+__device__ __forceinline__ int roi_stride(int kind) { return kind == 0 ? 6 : 5; }
+
+__device__ __forceinline__ void make_frame(const float *__restrict__ roi, int kind, float scale, int ph,
                                            int pw, int sample_num, float min_size, RoiFrame &f) {
   f.b = (int)roi[0];
-  f.cx = roi[1] * scale;
-  f.cy = roi[2] * scale;
-  float rw = roi[3] * scale, rh = roi[4] * scale;
+  float cx, cy, w, h, theta;
+  if (kind == 0) {
+    cx = roi[1]; cy = roi[2]; w = roi[3]; h = roi[4]; theta = roi[5];
+  } else {
+    const float x1 = roi[1], y1 = roi[2], x2 = roi[3], y2 = roi[4];
+    theta = 0.0f;
+    min_size = 0.0f;
+    if (kind == 1) {
+      cx = ((x1 + x2) + 1.0f) * 0.5f; cy = ((y1 + y2) + 1.0f) * 0.5f;
+      w = (x2 - x1) + 1.0f; h = (y2 - y1) + 1.0f;
+    } else {
+      const float off = 0.5f / scale;
+      cx = (x1 + x2) * 0.5f - off; cy = (y1 + y2) * 0.5f - off;
+      w = x2 - x1; h = y2 - y1;
+    }
+  }
+  f.cx = cx * scale;
+  f.cy = cy * scale;
+  float rw = w * scale, rh = h * scale;
   rw = max_sel(rw, min_size);
   rh = max_sel(rh, min_size);
-  sincos_det(roi[5], f.s, f.c);
+  sincos_det(theta, f.s, f.c);
   f.bin_h = rh / (float)ph;
   f.bin_w = rw / (float)pw;
   f.gh = sample_num > 0 ? sample_num : (int)ceilf(rh / (float)ph);
@@ -180,7 +205,7 @@ template <bool X4>
 __global__ __launch_bounds__(256) void rroi_forward_kernel(
     const float *__restrict__ feat, int B, int C, int H, int W, const float *__restrict__ rois,
     int ph, int pw, float scale, int sample_num, float min_size, int groups_per_block,
-    int K, int chunks, float *__restrict__ out) {
+    int K, int chunks, int roi_kind, float *__restrict__ out) {
   __shared__ __attribute__((aligned(16))) float tile[4 * (kWaveFloats + kWavePad)];  // block-wide: kStageFloats + pad
   __shared__ int4 s_off[kMaxTabSamples];      // per sample: 4 footprint-local tap offsets
   __shared__ float4 s_wgt[kMaxTabSamples];    // per sample: 4 bilinear weights
@@ -194,7 +219,7 @@ __global__ __launch_bounds__(256) void rroi_forward_kernel(
   const int chunk = (int)((rest / (uint32_t)K) * 8u + c8);
   if (chunk >= chunks) return;
   RoiFrame f;
-  make_frame(rois + k * 6, scale, ph, pw, sample_num, min_size, f);
+  make_frame(rois + k * roi_stride(roi_kind), roi_kind, scale, ph, pw, sample_num, min_size, f);
   const int nb = ph * pw;
   const int c_block = chunk * groups_per_block * kChanPerThread;
   const int c_end = min(C, c_block + groups_per_block * kChanPerThread);
@@ -427,7 +452,7 @@ __device__ __forceinline__ void rroi_backward_direct(const float *__restrict__ g
 __global__ __launch_bounds__(256) void rroi_backward_kernel(
     const float *__restrict__ gout, int B, int C, int H, int W, const float *__restrict__ rois,
     int ph, int pw, float scale, int sample_num, float min_size, int groups_per_block,
-    int K, int chunks, float *__restrict__ gfeat) {
+    int K, int chunks, int roi_kind, float *__restrict__ gfeat) {
   __shared__ __attribute__((aligned(16))) float tile[4 * kWaveFloats];
   __shared__ int4 s_off[kMaxTabSamples];
   __shared__ float4 s_wgt[kMaxTabSamples];
@@ -437,7 +462,7 @@ __global__ __launch_bounds__(256) void rroi_backward_kernel(
   const int chunk = (int)((rest / (uint32_t)K) * 8u + c8);
   if (chunk >= chunks) return;
   RoiFrame f;
-  make_frame(rois + k * 6, scale, ph, pw, sample_num, min_size, f);
+  make_frame(rois + k * roi_stride(roi_kind), roi_kind, scale, ph, pw, sample_num, min_size, f);
   if (f.b < 0 || f.b >= B) return;
   const int nb = ph * pw;
   const int c_block = chunk * groups_per_block * kChanPerThread;
@@ -525,15 +550,59 @@ static int rroi_check(const char *who, int B, int C, int H, int W, int64_t K, in
   return OBB_OK;
 }
 
-static void rroi_geometry(int C, int ph, int pw, int &groups_per_block, unsigned &chunks) {
-  const int nb = ph * pw;
-  int gpb = 256 / nb;
-  if (gpb < 1) gpb = 1;
-  if (gpb > 8) gpb = 8;
+}  // namespace obb
+
+namespace obb {
+
+static int rroi_forward_launch(const char *who, const float *feat_dev, int B, int C, int H, int W,
+                               const float *rois_dev, int64_t K, int ph, int pw, float spatial_scale,
+                               int sample_num, float min_size, int roi_kind, float *out_dev, void *stream) {
+  int rc = rroi_check(who, B, C, H, W, K, ph, pw);
+  if (rc != OBB_OK) return rc;
+  if (K == 0 || C == 0) return OBB_OK;
+  if (!feat_dev || !rois_dev || !out_dev) return set_err(OBB_EINVAL, "%s: null pointer", who);
+  if (H == 0 || W == 0 || B == 0) return set_err(OBB_EINVAL, "%s: empty feature map with %lld RoIs", who, (long long)K);
+  // 16-32 channels per block (a big rotated RoI needs several staging passes per channel
+  // group and the kernel ends with its slowest block), preferring a chunk count that is a
+  // multiple of 8 = one chunk per XCD and round (see the kernel)
   const int groups = (C + kChanPerThread - 1) / kChanPerThread;
-  if (gpb > groups) gpb = groups;
-  groups_per_block = gpb;
-  chunks = (unsigned)((groups + gpb - 1) / gpb);
+  int gpb = (groups % 32 == 0) ? 4 : ((groups % 16 == 0) ? 2 : 3);
+  if (const char *e = getenv("OBB_RROI_GPB")) gpb = atoi(e) > 0 ? atoi(e) : gpb;  // tuning knob
+  const unsigned chunks = (unsigned)((groups + gpb - 1) / gpb);
+  if (chunks > 65535u) return set_err(OBB_EINVAL, "%s: too many channels (%d)", who, C);
+  // 16-byte LDS-DMA needs 16-byte aligned rows: W % 4 == 0 and an aligned base
+  const bool x4 = (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(feat_dev) & 15u) == 0);
+  const unsigned long long nblk = (unsigned long long)((chunks + 7u) / 8u) * 8ull * (unsigned long long)K;
+  if (nblk > 2147483647ull) return set_err(OBB_EINVAL, "%s: too many blocks (K=%lld, C=%d)", who, (long long)K, C);
+  if (x4)
+    hipLaunchKernelGGL(rroi_forward_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
+                       feat_dev, B, C, H, W, rois_dev, ph, pw, spatial_scale, sample_num, min_size, gpb, (int)K, (int)chunks, roi_kind, out_dev);
+  else
+    hipLaunchKernelGGL(rroi_forward_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
+                       feat_dev, B, C, H, W, rois_dev, ph, pw, spatial_scale, sample_num, min_size, gpb, (int)K, (int)chunks, roi_kind, out_dev);
+  OBB_LAUNCH_CHECK();
+  return OBB_OK;
+}
+
+static int rroi_backward_launch(const char *who, const float *grad_out_dev, int B, int C, int H, int W,
+                                const float *rois_dev, int64_t K, int ph, int pw, float spatial_scale,
+                                int sample_num, float min_size, int roi_kind, float *grad_feat_dev,
+                                void *stream) {
+  int rc = rroi_check(who, B, C, H, W, K, ph, pw);
+  if (rc != OBB_OK) return rc;
+  if (K == 0 || C == 0 || H == 0 || W == 0 || B == 0) return OBB_OK;
+  if (!grad_out_dev || !rois_dev || !grad_feat_dev) return set_err(OBB_EINVAL, "%s: null pointer", who);
+  // same block geometry as the forward kernel (32 channels per block when C allows)
+  const int groups = (C + kChanPerThread - 1) / kChanPerThread;
+  const int gpb = (groups % 32 == 0) ? 4 : ((groups % 16 == 0) ? 2 : 3);
+  const unsigned chunks = (unsigned)((groups + gpb - 1) / gpb);
+  if (chunks > 65535u) return set_err(OBB_EINVAL, "%s: too many channels (%d)", who, C);
+  const unsigned long long nblk = (unsigned long long)((chunks + 7u) / 8u) * 8ull * (unsigned long long)K;
+  if (nblk > 2147483647ull) return set_err(OBB_EINVAL, "%s: too many blocks (K=%lld, C=%d)", who, (long long)K, C);
+  hipLaunchKernelGGL(rroi_backward_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
+                     grad_out_dev, B, C, H, W, rois_dev, ph, pw, spatial_scale, sample_num, min_size, gpb, (int)K, (int)chunks, roi_kind, grad_feat_dev);
+  OBB_LAUNCH_CHECK();
+  return OBB_OK;
 }
 
 }  // namespace obb
@@ -542,56 +611,30 @@ extern "C" int obb_rroi_align_forward_f32(const float *feat_dev, int B, int C, i
                                           const float *rois_dev, int64_t K, int ph, int pw,
                                           float spatial_scale, int sample_num, float min_size,
                                           float *out_dev, void *stream) {
-  using namespace obb;
-  int rc = rroi_check("obb_rroi_align_forward_f32", B, C, H, W, K, ph, pw);
-  if (rc != OBB_OK) return rc;
-  if (K == 0 || C == 0) return OBB_OK;
-  if (!feat_dev || !rois_dev || !out_dev) return set_err(OBB_EINVAL, "obb_rroi_align_forward_f32: null pointer");
-  if (H == 0 || W == 0 || B == 0) return set_err(OBB_EINVAL, "obb_rroi_align_forward_f32: empty feature map with %lld RoIs", (long long)K);
-  int gpb; unsigned chunks;
-  rroi_geometry(C, ph, pw, gpb, chunks);
-  // forward: 16-32 channels per block (a big rotated RoI needs several staging passes per
-  // channel group and the kernel ends with its slowest block), preferring a chunk
-  // count that is a multiple of 8 = one chunk per XCD and round (see the kernel)
-  {
-    const int groups = (C + kChanPerThread - 1) / kChanPerThread;
-    gpb = (groups % 32 == 0) ? 4 : ((groups % 16 == 0) ? 2 : 3);
-  }
-  if (const char *e = getenv("OBB_RROI_GPB")) gpb = atoi(e) > 0 ? atoi(e) : gpb;  // tuning knob
-  chunks = (unsigned)(((C + kChanPerThread - 1) / kChanPerThread + gpb - 1) / gpb);
-  if (chunks > 65535u) return set_err(OBB_EINVAL, "obb_rroi_align_forward_f32: too many channels (%d)", C);
-  // 16-byte LDS-DMA needs 16-byte aligned rows: W % 4 == 0 and an aligned base
-  const bool x4 = (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(feat_dev) & 15u) == 0);
-  const unsigned long long nblk = (unsigned long long)((chunks + 7u) / 8u) * 8ull * (unsigned long long)K;
-  if (nblk > 2147483647ull) return set_err(OBB_EINVAL, "obb_rroi_align_forward_f32: too many blocks (K=%lld, C=%d)", (long long)K, C);
-  if (x4)
-    hipLaunchKernelGGL(rroi_forward_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
-                       feat_dev, B, C, H, W, rois_dev, ph, pw, spatial_scale, sample_num, min_size, gpb, (int)K, (int)chunks, out_dev);
-  else
-    hipLaunchKernelGGL(rroi_forward_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
-                       feat_dev, B, C, H, W, rois_dev, ph, pw, spatial_scale, sample_num, min_size, gpb, (int)K, (int)chunks, out_dev);
-  OBB_LAUNCH_CHECK();
-  return OBB_OK;
+  return obb::rroi_forward_launch("obb_rroi_align_forward_f32", feat_dev, B, C, H, W, rois_dev, K, ph, pw,
+                                  spatial_scale, sample_num, min_size, 0, out_dev, stream);
 }
 
 extern "C" int obb_rroi_align_backward_f32(const float *grad_out_dev, int B, int C, int H, int W,
                                            const float *rois_dev, int64_t K, int ph, int pw,
                                            float spatial_scale, int sample_num, float min_size,
                                            float *grad_feat_dev, void *stream) {
-  using namespace obb;
-  int rc = rroi_check("obb_rroi_align_backward_f32", B, C, H, W, K, ph, pw);
-  if (rc != OBB_OK) return rc;
-  if (K == 0 || C == 0 || H == 0 || W == 0 || B == 0) return OBB_OK;
-  if (!grad_out_dev || !rois_dev || !grad_feat_dev) return set_err(OBB_EINVAL, "obb_rroi_align_backward_f32: null pointer");
-  // same block geometry as the forward kernel (32 channels per block when C allows)
-  const int groups = (C + kChanPerThread - 1) / kChanPerThread;
-  const int gpb = (groups % 32 == 0) ? 4 : ((groups % 16 == 0) ? 2 : 3);
-  const unsigned chunks = (unsigned)((groups + gpb - 1) / gpb);
-  if (chunks > 65535u) return set_err(OBB_EINVAL, "obb_rroi_align_backward_f32: too many channels (%d)", C);
-  const unsigned long long nblk = (unsigned long long)((chunks + 7u) / 8u) * 8ull * (unsigned long long)K;
-  if (nblk > 2147483647ull) return set_err(OBB_EINVAL, "obb_rroi_align_backward_f32: too many blocks (K=%lld, C=%d)", (long long)K, C);
-  hipLaunchKernelGGL(rroi_backward_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
-                     grad_out_dev, B, C, H, W, rois_dev, ph, pw, spatial_scale, sample_num, min_size, gpb, (int)K, (int)chunks, grad_feat_dev);
-  OBB_LAUNCH_CHECK();
-  return OBB_OK;
+  return obb::rroi_backward_launch("obb_rroi_align_backward_f32", grad_out_dev, B, C, H, W, rois_dev, K, ph, pw,
+                                   spatial_scale, sample_num, min_size, 0, grad_feat_dev, stream);
+}
+
+extern "C" int obb_roi_align_forward_f32(const float *feat_dev, int B, int C, int H, int W,
+                                         const float *rois_dev, int64_t K, int ph, int pw,
+                                         float spatial_scale, int sample_num, int aligned,
+                                         float *out_dev, void *stream) {
+  return obb::rroi_forward_launch("obb_roi_align_forward_f32", feat_dev, B, C, H, W, rois_dev, K, ph, pw,
+                                  spatial_scale, sample_num, 0.0f, aligned ? 2 : 1, out_dev, stream);
+}
+
+extern "C" int obb_roi_align_backward_f32(const float *grad_out_dev, int B, int C, int H, int W,
+                                          const float *rois_dev, int64_t K, int ph, int pw,
+                                          float spatial_scale, int sample_num, int aligned,
+                                          float *grad_feat_dev, void *stream) {
+  return obb::rroi_backward_launch("obb_roi_align_backward_f32", grad_out_dev, B, C, H, W, rois_dev, K, ph, pw,
+                                   spatial_scale, sample_num, 0.0f, aligned ? 2 : 1, grad_feat_dev, stream);
 }

@@ -4,8 +4,8 @@
 (mmdet/ops/roi_align/roi_align.py:79-152; its CUDA kernels need THC headers and
 cannot be built on ROCm): V1 (``aligned=False`` in the reference means the LEGACY
 kernel, roi_align.py:28-36 -> roi_align_kernel.cu:64-117) and V2
-(``aligned=True``, roi_align_kernel_v2.cu:62-128) are both served by
-``obb_rroi_align_*`` at theta = 0:
+(``aligned=True``, roi_align_kernel_v2.cu:62-128) are both served by the rotated
+kernels at theta = 0 (``obb_roi_align_*`` decodes the (K, 5) RoI row in the kernel):
 
   V1:  start = x1*s, end = (x2+1)*s, size clamped at 0
        == rotated RoI  centre ((x1+x2+1)/2, (y1+y2+1)/2), size (x2-x1+1, y2-y1+1), min_size 0
@@ -19,9 +19,63 @@ box's own extent), optional roi_rescale (:75-87) of w and h.
 """
 import torch
 from torch import nn
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
 from torch.nn.modules.utils import _pair
 
-from .rroi_align import RRoIAlign, rroi_align
+from . import _lib
+from .rroi_align import RRoIAlign, rroi_align  # noqa: F401  (rroi_align: the mapping the kernel now does itself)
+
+
+class RoIAlignFunction(Function):
+    """Horizontal RoIAlign (roi_align.py:9-73): features NCHW, rois (K, 5)
+    [batch, x1, y1, x2, y2]; gradient w.r.t. the features only."""
+
+    @staticmethod
+    def forward(ctx, features, rois, out_size, spatial_scale, sample_num=0, aligned=False):
+        out_h, out_w = _pair(out_size)
+        if not features.is_cuda:
+            raise NotImplementedError('RoIAlign runs on a HIP device only')   # roi_align.py:41-42
+        assert rois.dim() == 2 and rois.size(1) == 5
+        ctx.args = (out_h, out_w, float(spatial_scale), int(sample_num), 1 if aligned else 0)
+        ctx.feature_size = features.size()
+        ctx.in_dtype = features.dtype
+        feat = features.detach().to(torch.float32).contiguous()
+        r = rois.detach().to(device=feat.device, dtype=torch.float32).contiguous()
+        ctx.save_for_backward(r)
+        B, C, H, W = feat.shape
+        K = r.size(0)
+        out = torch.empty((K, C, out_h, out_w), dtype=torch.float32, device=feat.device)
+        if K > 0 and C > 0:
+            with torch.cuda.device(feat.device):
+                rc = _lib.lib().obb_roi_align_forward_f32(
+                    feat.data_ptr(), B, C, H, W, r.data_ptr(), K, out_h, out_w, ctx.args[2], ctx.args[3],
+                    ctx.args[4], out.data_ptr(), _lib.current_stream_handle(feat.device))
+            _lib.check(rc)
+        return out.to(features.dtype)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        (r,) = ctx.saved_tensors
+        B, C, H, W = ctx.feature_size
+        out_h, out_w, scale, sample_num, aligned = ctx.args
+        grad_input = None
+        if ctx.needs_input_grad[0]:
+            g = grad_output.detach().to(torch.float32).contiguous()
+            grad_input = torch.zeros((B, C, H, W), dtype=torch.float32, device=g.device)
+            K = r.size(0)
+            if K > 0 and C > 0:
+                with torch.cuda.device(g.device):
+                    rc = _lib.lib().obb_roi_align_backward_f32(
+                        g.data_ptr(), B, C, H, W, r.data_ptr(), K, out_h, out_w, scale, sample_num, aligned,
+                        grad_input.data_ptr(), _lib.current_stream_handle(g.device))
+                _lib.check(rc)
+            grad_input = grad_input.to(ctx.in_dtype)
+        return grad_input, None, None, None, None, None
+
+
+roi_align = RoIAlignFunction.apply
 
 
 class RoIAlign(nn.Module):
@@ -38,16 +92,7 @@ class RoIAlign(nn.Module):
     def forward(self, features, rois):
         """features: NCHW; rois: (K, 5) [batch_index, x1, y1, x2, y2]."""
         assert rois.dim() == 2 and rois.size(1) == 5
-        b, x1, y1, x2, y2 = rois.unbind(1)
-        zero = torch.zeros_like(x1)
-        if not self.aligned:   # legacy V1
-            rr = torch.stack([b, (x1 + x2 + 1) * 0.5, (y1 + y2 + 1) * 0.5, x2 - x1 + 1, y2 - y1 + 1,
-                              zero], 1)
-        else:                  # V2, aligned=True
-            off = 0.5 / self.spatial_scale
-            rr = torch.stack([b, (x1 + x2) * 0.5 - off, (y1 + y2) * 0.5 - off, x2 - x1, y2 - y1,
-                              zero], 1)
-        return rroi_align(features, rr, self.out_size, self.spatial_scale, self.sample_num, 0.0)
+        return roi_align(features, rois, self.out_size, self.spatial_scale, self.sample_num, self.aligned)
 
     def __repr__(self):
         return '{}(out_size={}, spatial_scale={}, sample_num={}, use_torchvision={}, aligned={})'.format(

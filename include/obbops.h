@@ -160,6 +160,26 @@ OBB_API int obb_rroi_align_backward_f32(const float *grad_out_dev, int B, int C,
                                 float *grad_feat_dev, void *stream);
 
 /* ---------------------------------------------------------------------------
+ * Horizontal RoI-Align on the same kernels (theta = 0; the RoI row is decoded in the kernel).
+ * Replaces: roi_align_cuda.forward / backward behind RoIAlignFunction,
+ *           mmdet/ops/roi_align/roi_align.py:9-73 (needs THC on CUDA: not buildable on ROCm)
+ *   rois_dev  (K, 5) batch index, x1, y1, x2, y2 (image scale, roi_align.py:136)
+ *   aligned   0: the legacy V1 kernel's geometry (roi_align_kernel.cu:79-86: +1 widths, the
+ *                module's default, roi_align.py:28-36)
+ *             1: V2 with aligned=True (roi_align_kernel_v2.cu:79-86: half-pixel shift, no
+ *                lower clamp of the size)
+ * Everything else as obb_rroi_align_*.
+ * ------------------------------------------------------------------------- */
+OBB_API int obb_roi_align_forward_f32(const float *feat_dev, int B, int C, int H, int W,
+                              const float *rois_dev, int64_t K, int ph, int pw,
+                              float spatial_scale, int sample_num, int aligned,
+                              float *out_dev, void *stream);
+OBB_API int obb_roi_align_backward_f32(const float *grad_out_dev, int B, int C, int H, int W,
+                               const float *rois_dev, int64_t K, int ph, int pw,
+                               float spatial_scale, int sample_num, int aligned,
+                               float *grad_feat_dev, void *stream);
+
+/* ---------------------------------------------------------------------------
  * theta-OBB -> 4 corner points in cv2.boxPoints order.
  * Replaces: thetaobb2pointobb, mmdet/core/rbbox/transforms.py:45-55 (per-box
  *           cv2 call on the host).  in (n,5) -> out (n,8).
