@@ -138,6 +138,39 @@ at::Tensor rroi_align_backward(const at::Tensor &grad_out, const at::Tensor &roi
   return grad_in;
 }
 
+// horizontal RoIAlign (roi_align_cuda.forward / backward, roi_align.py:9-73): rois (K, 5)
+// [batch, x1, y1, x2, y2]; aligned = false: legacy V1 geometry, true: V2 aligned
+at::Tensor roi_align_forward(const at::Tensor &features, const at::Tensor &rois, int64_t ph, int64_t pw,
+                             double spatial_scale, int64_t sample_num, bool aligned) {
+  TORCH_CHECK(features.dim() == 4, "features must be (B, C, H, W)");
+  TORCH_CHECK(rois.dim() == 2 && rois.size(1) == 5, "rois must be (K, 5) [batch, x1, y1, x2, y2]");
+  const at::Tensor f = as_f32_dev(features, "features"), r = as_f32_dev(rois, "rois");
+  HIPGuardMasqueradingAsCUDA guard(f.device());
+  const int64_t K = r.size(0), C = f.size(1);
+  at::Tensor out = at::empty({K, C, ph, pw}, f.options());
+  if (K == 0) return out;
+  check_rc(obb_roi_align_forward_f32(f.data_ptr<float>(), (int)f.size(0), (int)C, (int)f.size(2), (int)f.size(3),
+                                     r.data_ptr<float>(), K, (int)ph, (int)pw, (float)spatial_scale,
+                                     (int)sample_num, aligned ? 1 : 0, out.data_ptr<float>(), current_stream(f)),
+           "obb_roi_align_forward_f32");
+  return out;
+}
+
+at::Tensor roi_align_backward(const at::Tensor &grad_out, const at::Tensor &rois, int64_t B, int64_t C, int64_t H,
+                              int64_t W, double spatial_scale, int64_t sample_num, bool aligned) {
+  TORCH_CHECK(grad_out.dim() == 4 && grad_out.size(1) == C, "grad_output must be (K, C, ph, pw)");
+  TORCH_CHECK(rois.dim() == 2 && rois.size(1) == 5 && rois.size(0) == grad_out.size(0), "rois must be (K, 5)");
+  const at::Tensor g = as_f32_dev(grad_out, "grad_output"), r = as_f32_dev(rois, "rois");
+  HIPGuardMasqueradingAsCUDA guard(g.device());
+  at::Tensor grad_in = at::zeros({B, C, H, W}, g.options());
+  if (g.size(0) == 0) return grad_in;
+  check_rc(obb_roi_align_backward_f32(g.data_ptr<float>(), (int)B, (int)C, (int)H, (int)W, r.data_ptr<float>(),
+                                      g.size(0), (int)g.size(2), (int)g.size(3), (float)spatial_scale,
+                                      (int)sample_num, aligned ? 1 : 0, grad_in.data_ptr<float>(), current_stream(g)),
+           "obb_roi_align_backward_f32");
+  return grad_in;
+}
+
 at::Tensor rbox_to_poly(const at::Tensor &rboxes) {
   TORCH_CHECK(rboxes.dim() == 2 && rboxes.size(1) == 5, "rboxes must be (n, 5)");
   const at::Tensor r = as_f32_dev(rboxes, "rboxes");
@@ -169,5 +202,10 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("rroi_align_backward", &rroi_align_backward, py::arg("grad_output"), py::arg("rois"), py::arg("batch"),
         py::arg("channels"), py::arg("height"), py::arg("width"), py::arg("spatial_scale"),
         py::arg("sample_num") = 0, py::arg("min_size") = 1.0);
+  m.def("roi_align_forward", &roi_align_forward, py::arg("features"), py::arg("rois"), py::arg("pooled_height"),
+        py::arg("pooled_width"), py::arg("spatial_scale"), py::arg("sample_num") = 0, py::arg("aligned") = false);
+  m.def("roi_align_backward", &roi_align_backward, py::arg("grad_output"), py::arg("rois"), py::arg("batch"),
+        py::arg("channels"), py::arg("height"), py::arg("width"), py::arg("spatial_scale"),
+        py::arg("sample_num") = 0, py::arg("aligned") = false);
   m.def("thetaobb2pointobb", &rbox_to_poly, py::arg("rboxes"));
 }

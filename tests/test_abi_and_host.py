@@ -119,7 +119,8 @@ def test_torch_extension_loads_and_validates():
     e = torch_ext.ext()
     assert e.version() == _lib.lib().obb_version()
     for name in ('rnms', 'poly_nms', 'rnms_grouped', 'poly_nms_grouped', 'rbbox_overlaps',
-                 'rroi_align_forward', 'rroi_align_backward', 'thetaobb2pointobb'):
+                 'rroi_align_forward', 'rroi_align_backward', 'roi_align_forward', 'roi_align_backward', 'nms',
+                 'thetaobb2pointobb'):
         assert callable(getattr(e, name))
     # empty input needs no device (nms_wrapper.py:50-51); anything else must live on the GPU
     assert e.rnms(torch.zeros(0, 6), 0.5).dtype == torch.int64
