@@ -31,40 +31,47 @@ class AssignResult(object):
 
 def assign_wrt_overlaps(overlaps, gt_labels=None, pos_iou_thr=0.5, neg_iou_thr=0.5, min_pos_iou=.0,
                         gt_max_assign_all=True):
-    """max_iou_assigner.py:114-202: overlaps (k gts, n boxes) -> AssignResult.
-    -1 = don't care, 0 = negative, i > 0 = 1-based index of the assigned gt."""
-    num_gts, num_bboxes = overlaps.size(0), overlaps.size(1)
-    assigned_gt_inds = overlaps.new_full((num_bboxes, ), -1, dtype=torch.long)
-    if num_gts == 0 or num_bboxes == 0:
-        max_overlaps = overlaps.new_zeros((num_bboxes, ))
-        if num_gts == 0:
-            assigned_gt_inds[:] = 0
-        labels = None if gt_labels is None else overlaps.new_zeros((num_bboxes, ), dtype=torch.long)
-        return AssignResult(num_gts, assigned_gt_inds, max_overlaps, labels=labels)
+    """Assignment from a (k gts, n boxes) overlap matrix with the rules of
+    max_iou_assigner.py:114-202: -1 = don't care, 0 = negative, i > 0 = 1-based gt index.
 
-    max_overlaps, argmax_overlaps = overlaps.max(dim=0)
-    gt_max_overlaps, gt_argmax_overlaps = overlaps.max(dim=1)
+    The reference walks the gts in a Python loop (one device sync per gt); here the three
+    rules are evaluated as whole-matrix expressions:
+      1. negatives: best overlap below ``neg_iou_thr`` (or inside the ``(lo, hi)`` tuple);
+      2. positives: best overlap >= ``pos_iou_thr`` -> that gt;
+      3. every gt whose best overlap reaches ``min_pos_iou`` claims its best box(es); when
+         several gts claim one box the LAST gt wins, as the reference's loop order implies --
+         a column-wise max over (claim mask x gt number).
+    """
+    num_gts, num_bboxes = overlaps.size(0), overlaps.size(1)
+    gt_inds = overlaps.new_full((num_bboxes, ), -1, dtype=torch.long)
+    if num_gts == 0 or num_bboxes == 0:
+        if num_gts == 0:
+            gt_inds.zero_()
+        labels = None if gt_labels is None else gt_inds.new_zeros((num_bboxes, ))
+        return AssignResult(num_gts, gt_inds, overlaps.new_zeros((num_bboxes, )), labels=labels)
+
+    best, best_gt = overlaps.max(dim=0)               # per box
+    gt_best, gt_best_box = overlaps.max(dim=1)        # per gt
     if isinstance(neg_iou_thr, float):
-        assigned_gt_inds[(max_overlaps >= 0) & (max_overlaps < neg_iou_thr)] = 0
+        gt_inds[(best >= 0) & (best < neg_iou_thr)] = 0
     elif isinstance(neg_iou_thr, tuple):
         assert len(neg_iou_thr) == 2
-        assigned_gt_inds[(max_overlaps >= neg_iou_thr[0]) & (max_overlaps < neg_iou_thr[1])] = 0
-    pos_inds = max_overlaps >= pos_iou_thr
-    assigned_gt_inds[pos_inds] = argmax_overlaps[pos_inds] + 1
-    for i in range(num_gts):
-        if gt_max_overlaps[i] >= min_pos_iou:
-            if gt_max_assign_all:
-                assigned_gt_inds[overlaps[i, :] == gt_max_overlaps[i]] = i + 1
-            else:
-                assigned_gt_inds[gt_argmax_overlaps[i]] = i + 1
-    if gt_labels is not None:
-        assigned_labels = assigned_gt_inds.new_zeros((num_bboxes, ))
-        pos = torch.nonzero(assigned_gt_inds > 0).squeeze()
-        if pos.numel() > 0:
-            assigned_labels[pos] = gt_labels[assigned_gt_inds[pos] - 1]
+        gt_inds[(best >= neg_iou_thr[0]) & (best < neg_iou_thr[1])] = 0
+    gt_inds = torch.where(best >= pos_iou_thr, best_gt + 1, gt_inds)
+    if gt_max_assign_all:
+        claims = overlaps == gt_best[:, None]
     else:
-        assigned_labels = None
-    return AssignResult(num_gts, assigned_gt_inds, max_overlaps, labels=assigned_labels)
+        claims = torch.zeros_like(overlaps, dtype=torch.bool)
+        claims[torch.arange(num_gts, device=overlaps.device), gt_best_box] = True
+    claims &= (gt_best >= min_pos_iou)[:, None]
+    number = torch.arange(1, num_gts + 1, device=overlaps.device)[:, None]
+    claimed_by = (claims * number).max(dim=0)[0]      # 0 where no gt claims the box
+    gt_inds = torch.where(claimed_by > 0, claimed_by, gt_inds)
+
+    labels = None
+    if gt_labels is not None:
+        labels = torch.where(gt_inds > 0, gt_labels[(gt_inds - 1).clamp(min=0)], gt_inds.new_zeros(()))
+    return AssignResult(num_gts, gt_inds, best, labels=labels)
 
 
 class MaxIoUAssignerRotated(object):

@@ -1,148 +1,187 @@
-"""Class-wise NMS orchestration for rotated detections.
+"""Class-wise NMS orchestration for horizontal and rotated detections.
 
-Counterparts of mmdet/core/post_processing/bbox_nms.py (multiclass_nms, :6-76) and
-rbbox_nms.py (multiclass_nms_with_index :6-62, thetaobb_nms_by_bbox_nms :64-119)
-of the reference, with the NMS op resolved by name exactly as the reference does
-(``getattr(nms_wrapper, nms_cfg['type'])``, bbox_nms.py:60-62).
+Counterparts of the reference's mmdet/core/post_processing/bbox_nms.py
+(``multiclass_nms`` :6-76) and rbbox_nms.py (``multiclass_nms_with_index`` :6-62,
+``thetaobb_nms_by_bbox_nms`` :64-119), with the NMS op resolved by name exactly as
+the reference does (``getattr(nms_wrapper, nms_cfg['type'])``, bbox_nms.py:60-62).
+
+Design: every function first *flattens* the (box, class) candidates that pass the
+score threshold into one list and hands that list to ONE grouped NMS launch
+(group = class).  The reference's per-class Python loop (15 launches, each with a
+device-to-host mask copy, rbbox_nms.py:29-49) disappears; what the loop returned --
+per-class keep lists, class-major concatenation -- is recovered from the single
+ascending keep list by a segmented split.
 
 ``multiclass_rnms`` is the call the reference left commented out
 (``multiclass_thetaobb_nms(thetaobbs, scores, cfg.score_thr,
-cfg.polygon_nms_iou_thr, cfg.max_per_img)``, rbbox_head.py:294-295): true
-rotated NMS per class, done in ONE grouped kernel call (group = class) instead
-of 15 launches with a host sync each (rbbox_nms.py:29-49).
+cfg.polygon_nms_iou_thr, cfg.max_per_img)``, rbbox_head.py:294-295).
 """
 import torch
 
 from . import nms_wrapper
 
 
-def multiclass_rnms(multi_rbboxes, multi_scores, score_thr, nms_cfg, max_num=-1,
-                    score_factors=None, out_dim_reg=5):
-    """Rotated NMS for multi-class theta-OBBs.
+def _per_class_boxes(multi_boxes, num_fg, d):
+    """(n, (1+num_fg)*d) | (n, d)  ->  (n, num_fg, d) view of the foreground classes."""
+    n = multi_boxes.size(0)
+    if multi_boxes.size(1) > d:
+        return multi_boxes.view(n, -1, d)[:, 1:]
+    return multi_boxes[:, None].expand(n, num_fg, d)
 
-    Same contract as ``multiclass_nms`` (bbox_nms.py:6-76) with 5 numbers per box.
 
-    Args:
-        multi_rbboxes (Tensor): (n, #class*5) or (n, 5)
-        multi_scores (Tensor): (n, #class); column 0 is background and ignored
-        score_thr (float): boxes with a score <= score_thr are dropped
-        nms_cfg (dict): e.g. dict(type='rnms', iou_thr=0.5)
-        max_num (int): keep at most max_num detections (highest scores)
-        score_factors (Tensor, optional): multiplied to the scores before NMS
+def _resolve_op(nms_cfg, default):
+    cfg = dict(nms_cfg)
+    return getattr(nms_wrapper, cfg.pop('type', default)), cfg
 
-    Returns:
-        tuple: (rbboxes (k, 6), labels (k,)); labels are 0-based.
-    """
-    d = out_dim_reg
-    num_classes = multi_scores.size(1) - 1
-    if multi_rbboxes.shape[1] > d:
-        rb = multi_rbboxes.view(multi_scores.size(0), -1, d)[:, 1:]
-    else:
-        rb = multi_rbboxes[:, None].expand(-1, num_classes, d)
+
+def _top_by_score(dets, labels, max_num):
+    """The reference's cap (bbox_nms.py:68-74): only when more than ``max_num`` rows survive are
+    they re-ordered by descending score and cut.  (``max_num=-1`` therefore drops the
+    lowest-scored row, as ``inds[:-1]`` does in the reference.)"""
+    if dets.size(0) > max_num:
+        order = dets[:, -1].sort(descending=True)[1][:max_num]
+        dets, labels = dets[order], labels[order]
+    return dets, labels
+
+
+def _multiclass(multi_boxes, multi_scores, score_thr, nms_cfg, max_num, score_factors, d,
+                default_op, offset_trick):
+    num_fg = multi_scores.size(1) - 1
+    boxes = _per_class_boxes(multi_boxes, num_fg, d)
     scores = multi_scores[:, 1:]
-    valid_mask = scores > score_thr
-    rb = rb[valid_mask]
+    valid = scores > score_thr
     if score_factors is not None:
         scores = scores * score_factors[:, None]
-    scores = scores[valid_mask]
-    labels = valid_mask.nonzero()[:, 1]
-
-    if rb.numel() == 0:
-        return (multi_rbboxes.new_zeros((0, d + 1)),
-                multi_rbboxes.new_zeros((0, ), dtype=torch.long))
-
-    nms_cfg_ = nms_cfg.copy()
-    nms_type = nms_cfg_.pop('type', 'rnms')
-    nms_op = getattr(nms_wrapper, nms_type)
-    # bbox_nms.py:56-59 separates classes by adding label*(max_coordinate+1) to the
-    # coordinates; the grouped kernel gives the same per-class NMS without moving
-    # (and thereby rounding) any coordinate.
-    dets, keep = nms_op(torch.cat([rb, scores[:, None]], 1), groups=labels, **nms_cfg_)
-    rb = rb[keep]
-    scores = dets[:, -1]
+    rows, labels = valid.nonzero(as_tuple=True)          # row-major, like bbox_nms.py:43
+    boxes, scores = boxes[rows, labels], scores[rows, labels]
+    if boxes.numel() == 0:
+        return multi_boxes.new_zeros((0, d + 1)), multi_boxes.new_zeros((0, ), dtype=torch.long)
+    nms_op, cfg = _resolve_op(nms_cfg, default_op)
+    if offset_trick:
+        # bbox_nms.py:56-59 verbatim in effect: the classes are pushed apart by
+        # label * (max coordinate + 1), so the op sees the same floats as the reference's
+        shift = labels.to(boxes) * (boxes.max() + 1)
+        dets, keep = nms_op(torch.cat([boxes + shift[:, None], scores[:, None]], 1), **cfg)
+    else:
+        # same per-class NMS without moving (and thereby rounding) a coordinate
+        dets, keep = nms_op(torch.cat([boxes, scores[:, None]], 1), groups=labels, **cfg)
+    out = torch.cat([boxes[keep], dets[:, -1:]], 1)      # dets[:, -1]: soft-NMS rescored
     labels = labels[keep]
-    if keep.size(0) > max_num > 0:
-        _, inds = scores.sort(descending=True)
-        inds = inds[:max_num]
-        rb, scores, labels = rb[inds], scores[inds], labels[inds]
-    return torch.cat([rb, scores[:, None]], 1), labels
+    if max_num > 0 or offset_trick:   # (the new rotated op does not inherit the max_num=-1 quirk)
+        out, labels = _top_by_score(out, labels, max_num)
+    return out, labels
+
+
+def multiclass_nms(multi_bboxes, multi_scores, score_thr, nms_cfg, max_num=-1, score_factors=None,
+                   grouped=False):
+    """Horizontal multi-class NMS, ``multiclass_nms`` of bbox_nms.py:6-76.
+
+    Args:
+        multi_bboxes (Tensor): (n, #class*4) or (n, 4)
+        multi_scores (Tensor): (n, #class); column 0 is the background and ignored
+        score_thr (float): candidates need ``score > score_thr``
+        nms_cfg (dict): e.g. ``dict(type='nms', iou_thr=0.5)``
+        max_num (int): if more survive, the ``max_num`` best by score are returned
+        score_factors (Tensor, optional): multiplied to the scores before NMS
+        grouped (bool): False (default) separates classes with the reference's coordinate
+            offsets (:56-59), i.e. the NMS sees exactly the reference's floats; True passes
+            the class as group id instead (no coordinate is rounded by an offset).
+
+    Returns:
+        tuple: (bboxes (k, 5), labels (k,)); labels are 0-based.
+    """
+    return _multiclass(multi_bboxes, multi_scores, score_thr, nms_cfg, max_num, score_factors, 4,
+                       'nms', offset_trick=not grouped)
+
+
+def multiclass_rnms(multi_rbboxes, multi_scores, score_thr, nms_cfg, max_num=-1,
+                    score_factors=None, out_dim_reg=5):
+    """Rotated NMS for multi-class theta-OBBs: the contract of ``multiclass_nms``
+    (bbox_nms.py:6-76) with ``out_dim_reg`` numbers per box and ``type='rnms'``.
+
+    Returns:
+        tuple: (rbboxes (k, out_dim_reg + 1), labels (k,)); labels are 0-based.
+    """
+    return _multiclass(multi_rbboxes, multi_scores, score_thr, nms_cfg, max_num, score_factors,
+                       out_dim_reg, 'rnms', offset_trick=False)
+
+
+def _class_major(masks):
+    """masks (C, n) bool -> (class, row) of every set entry, class-major; counts per class."""
+    cls, rows = masks.nonzero(as_tuple=True)
+    return cls, rows, masks.sum(1)
 
 
 def multiclass_nms_with_index(multi_bboxes, multi_scores, score_thr, nms_cfg, max_num=-1):
-    """The reference's horizontal multi-class NMS that also returns, per class, the
-    score mask and the keep indices (rbbox_nms.py:6-62).  Per-class Python loop and
-    concatenation order are kept so that outputs are identical."""
-    num_classes = multi_scores.shape[1]
-    bboxes, labels = [], []
-    nms_cfg_ = nms_cfg.copy()
-    nms_type = nms_cfg_.pop('type', 'nms')
-    nms_op = getattr(nms_wrapper, nms_type)
-    bbox_cls_inds, bbox_keep_inds = [], []
-    for i in range(1, num_classes):
-        cls_inds = multi_scores[:, i] > score_thr
-        bbox_cls_inds.append(cls_inds)
-        if not cls_inds.any():
-            continue
-        if multi_bboxes.shape[1] == 4:
-            _bboxes = multi_bboxes[cls_inds, :]
-        else:
-            _bboxes = multi_bboxes[cls_inds, i * 4:(i + 1) * 4]
-        _scores = multi_scores[cls_inds, i]
-        cls_dets = torch.cat([_bboxes, _scores[:, None]], dim=1)
-        cls_dets, keep = nms_op(cls_dets, **nms_cfg_)
-        bbox_keep_inds.append(keep)
-        cls_labels = multi_bboxes.new_full((cls_dets.shape[0], ), i - 1, dtype=torch.long)
-        bboxes.append(cls_dets)
-        labels.append(cls_labels)
-    if bboxes:
-        bboxes = torch.cat(bboxes)
-        labels = torch.cat(labels)
-        if bboxes.shape[0] > max_num:
-            _, inds = bboxes[:, -1].sort(descending=True)
-            inds = inds[:max_num]
-            bboxes = bboxes[inds]
-            labels = labels[inds]
-    else:
-        bboxes = multi_bboxes.new_zeros((0, 5))
-        labels = multi_bboxes.new_zeros((0, ), dtype=torch.long)
-    return bboxes, labels, bbox_cls_inds, bbox_keep_inds
+    """Horizontal multi-class NMS that also reports what it did per class
+    (rbbox_nms.py:6-62), so that the decision can be re-applied to the rotated boxes.
+
+    One grouped launch over the class-major list of candidates replaces the loop over
+    classes.  The keep list of that launch is ascending in the class-major index, which
+    is the order in which the reference concatenates its per-class results; the per-class
+    keep lists are its segments, re-based to the start of their class.
+
+    Returns:
+        tuple: (bboxes (k, 5), labels (k,), bbox_cls_inds, bbox_keep_inds) --
+        ``bbox_cls_inds``: one (n,) bool mask per foreground class (``score > score_thr``);
+        ``bbox_keep_inds``: for every class with at least one candidate, in class order,
+        the int64 indices the NMS kept among that class's candidates.
+    """
+    num_fg = multi_scores.size(1) - 1
+    masks = (multi_scores[:, 1:] > score_thr).t().contiguous()          # (C, n)
+    bbox_cls_inds = list(masks.unbind(0))
+    cls, rows, per_class = _class_major(masks)
+    if rows.numel() == 0:
+        return (multi_bboxes.new_zeros((0, 5)), multi_bboxes.new_zeros((0, ), dtype=torch.long),
+                bbox_cls_inds, [])
+    boxes = _per_class_boxes(multi_bboxes, num_fg, 4)[rows, cls]
+    dets = torch.cat([boxes, multi_scores[rows, cls + 1][:, None]], 1)
+    nms_op, cfg = _resolve_op(nms_cfg, 'nms')
+    kept, keep = nms_op(dets, groups=cls, **cfg)
+    labels = cls[keep]
+    # segments of the keep list: candidates and survivors per class in ONE host read
+    counts = torch.stack([per_class, torch.bincount(labels, minlength=num_fg)]).tolist()
+    bbox_keep_inds, start, kstart = [], 0, 0
+    for m, k in zip(*counts):
+        if m:
+            bbox_keep_inds.append(keep[kstart:kstart + k] - start)
+        start += m
+        kstart += k
+    kept, labels = _top_by_score(kept, labels, max_num)
+    return kept, labels, bbox_cls_inds, bbox_keep_inds
 
 
 def thetaobb_nms_by_bbox_nms(multi_bboxes, multi_scores, bbox_cls_inds, bbox_keep_inds,
                              max_num=-1, out_dim_reg=5):
-    """The reference's *stand-in* for rotated NMS: re-apply the horizontal keep
-    indices to the rotated boxes (rbbox_nms.py:64-119).  Kept so that the
-    reference behaviour of config 4 can be reproduced side by side with
-    ``multiclass_rnms``.  Consumes ``bbox_keep_inds`` like the reference (:99)."""
-    num_classes = multi_scores.shape[1]
-    bboxes, labels = [], []
-    for i in range(1, num_classes):
-        cls_inds = bbox_cls_inds[i - 1]
-        if not cls_inds.any():
-            continue
-        if multi_bboxes.shape[1] == out_dim_reg:
-            _bboxes = multi_bboxes[cls_inds, :]
-        else:
-            _bboxes = multi_bboxes[cls_inds, i * out_dim_reg:(i + 1) * out_dim_reg]
-        _scores = multi_scores[cls_inds, i]
-        cls_dets = torch.cat([_bboxes, _scores[:, None]], dim=1)
-        keep = bbox_keep_inds.pop(0)
-        cls_dets = cls_dets[keep, :]
-        cls_labels = multi_bboxes.new_full((cls_dets.shape[0], ), i - 1, dtype=torch.long)
-        bboxes.append(cls_dets)
-        labels.append(cls_labels)
-    if bboxes:
-        bboxes = torch.cat(bboxes)
-        labels = torch.cat(labels)
-        if bboxes.shape[0] > max_num:
-            _, inds = bboxes[:, -1].sort(descending=True)
-            inds = inds[:max_num]
-            bboxes = bboxes[inds]
-            labels = labels[inds]
-    else:
-        bboxes = multi_bboxes.new_zeros((0, out_dim_reg + 1))
-        labels = multi_bboxes.new_zeros((0, ), dtype=torch.long)
-    return bboxes, labels
+    """The reference's *stand-in* for rotated NMS (rbbox_nms.py:64-119): the rotated
+    boxes that survive are those whose horizontal boxes survived.  Here a single gather:
+    the per-class keep lists of ``multiclass_nms_with_index`` are re-based into the
+    class-major candidate list and select (row, class) pairs directly.
+
+    Like the reference (:99, ``pop(0)``) the keep lists that were used are removed from
+    ``bbox_keep_inds``.
+    """
+    d = out_dim_reg
+    num_fg = multi_scores.size(1) - 1
+    empty = (multi_bboxes.new_zeros((0, d + 1)), multi_bboxes.new_zeros((0, ), dtype=torch.long))
+    if num_fg == 0:
+        return empty
+    masks = torch.stack(list(bbox_cls_inds[:num_fg]))                   # (C, n)
+    cls, rows, per_class = _class_major(masks)
+    parts, start, used = [], 0, 0
+    for m in per_class.tolist():
+        if m:
+            parts.append(bbox_keep_inds[used] + start)
+            used += 1
+        start += m
+    del bbox_keep_inds[:used]
+    if not parts:
+        return empty
+    sel = torch.cat(parts)
+    rows, cls = rows[sel], cls[sel]
+    boxes = _per_class_boxes(multi_bboxes, num_fg, d)[rows, cls]
+    dets = torch.cat([boxes, multi_scores[rows, cls + 1][:, None]], 1)
+    return _top_by_score(dets, cls, max_num)
 
 
 def get_det_rbboxes(rois, cls_score, rbbox_pred, img_shape, scale_factor, rescale=False, cfg=None,

@@ -60,6 +60,20 @@ def lib():
         L.obbo_nms_grouped_f32.restype = ctypes.c_long
         L.obbo_hbb_nms_f32.argtypes = [_f32p, ctypes.c_long, ctypes.c_float, _i64p]
         L.obbo_hbb_nms_f32.restype = ctypes.c_long
+        L.obbo_nms_ex_f32.argtypes = [_f32p, ctypes.c_long, ctypes.c_int, ctypes.c_float,
+                                      ctypes.POINTER(ctypes.c_int32), _f32p, ctypes.c_int, _i64p]
+        L.obbo_nms_ex_f32.restype = ctypes.c_long
+        L.obbo_soft_nms_f32.argtypes = [_f32p, ctypes.c_long, ctypes.c_float, ctypes.c_int,
+                                        ctypes.c_float, ctypes.c_float, _f32p]
+        L.obbo_soft_nms_f32.restype = ctypes.c_long
+        L.obbo_polyiou_f64.argtypes = [_f64p, _f64p, ctypes.c_long, ctypes.c_int, ctypes.c_int, _f64p]
+        L.obbo_polyiou_f64.restype = ctypes.c_int
+        L.obbo_max_threads.restype = ctypes.c_int
+        L.obbo_overlaps_mt_f32.argtypes = [_f32p, ctypes.c_long, _f32p, ctypes.c_long,
+                                           ctypes.c_int, ctypes.c_int, ctypes.c_int, _f32p]
+        L.obbo_overlaps_mt_f32.restype = ctypes.c_int
+        L.obbo_nms_mt_f32.argtypes = [_f32p, ctypes.c_long, ctypes.c_float, ctypes.c_int, _i64p]
+        L.obbo_nms_mt_f32.restype = ctypes.c_long
         rroi = [_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                 _f32p, ctypes.c_long, ctypes.c_int, ctypes.c_int,
                 ctypes.c_float, ctypes.c_int, ctypes.c_float, _f32p]
@@ -67,6 +81,8 @@ def lib():
         L.obbo_rroi_align_forward_f32.restype = ctypes.c_int
         L.obbo_rroi_align_backward_f32.argtypes = rroi
         L.obbo_rroi_align_backward_f32.restype = ctypes.c_int
+        L.obbo_rroi_align_forward_mt_f32.argtypes = rroi[:-1] + [ctypes.c_int, _f32p]
+        L.obbo_rroi_align_forward_mt_f32.restype = ctypes.c_int
         L.obbo_roi_align_forward_f32.argtypes = [
             _f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
             _f32p, ctypes.c_long, ctypes.c_int, ctypes.c_int,
@@ -141,7 +157,7 @@ def score_order(scores):
     return order
 
 
-def _nms(d, kind, iou_thr, groups, thrs):
+def _nms(d, kind, iou_thr, groups, thrs, strict=False):
     n = d.shape[0]
     keep = np.zeros(n, dtype=np.int64)
     g = t = None
@@ -153,39 +169,102 @@ def _nms(d, kind, iou_thr, groups, thrs):
     if thrs is not None:
         t = _f32(thrs).reshape(n)
         tp = _p(t)
-    k = lib().obbo_nms_grouped_f32(_p(d), n, kind, ctypes.c_float(iou_thr), gp, tp, _p(keep, _i64p))
+    k = lib().obbo_nms_ex_f32(_p(d), n, kind, ctypes.c_float(iou_thr), gp, tp, 1 if strict else 0,
+                              _p(keep, _i64p))
     assert k >= 0
     return keep[:k].copy()
 
 
-def rnms(dets, iou_thr, groups=None, thrs=None):
+def rnms(dets, iou_thr, groups=None, thrs=None, strict=False):
     """dets (n,6) cx,cy,w,h,theta,score -> ascending int64 keep indices.
-    groups (n,) int: only boxes of the same group interact; thrs (n,) per-box thr."""
-    return _nms(_f32(dets).reshape(-1, 6), 0, iou_thr, groups, thrs)
+    groups (n,) int: only boxes of the same group interact; thrs (n,) per-box thr;
+    strict: suppress on `>` (nms_kernel.cu:61) instead of `>=` (nms_cpu.cpp:56)."""
+    return _nms(_f32(dets).reshape(-1, 6), 0, iou_thr, groups, thrs, strict)
 
 
-def poly_nms(dets, iou_thr, groups=None, thrs=None):
+def poly_nms(dets, iou_thr, groups=None, thrs=None, strict=False):
     """dets (n,9) x1,y1..x4,y4,score -> ascending int64 keep indices."""
-    return _nms(_f32(dets).reshape(-1, 9), 1, iou_thr, groups, thrs)
+    return _nms(_f32(dets).reshape(-1, 9), 1, iou_thr, groups, thrs, strict)
 
 
-def hbb_nms(dets, iou_thr):
-    """Restatement of nms_cpu.cpp:5-60 for (n,5) x1,y1,x2,y2,score (fp32)."""
+def hbb_nms(dets, iou_thr, groups=None, strict=False):
+    """Restatement of nms_cpu.cpp:5-60 for (n,5) x1,y1,x2,y2,score (fp32), with the
+    reference's own pair arithmetic (+1 widths, :19,47-55); optional groups / strict `>`."""
     d = _f32(dets).reshape(-1, 5)
+    if groups is None and not strict:
+        keep = np.zeros(d.shape[0], dtype=np.int64)
+        k = lib().obbo_hbb_nms_f32(_p(d), d.shape[0], ctypes.c_float(iou_thr), _p(keep, _i64p))
+        assert k >= 0
+        return keep[:k].copy()
+    return _nms(d, 2, iou_thr, groups, None, strict)
+
+
+def soft_nms(dets, iou_thr, method='linear', sigma=0.5, min_score=1e-3):
+    """Restatement of soft_nms_cpu_kernel (nms_cpu.cpp:71-210) through the wrapper's
+    argument rules (nms_wrapper.py:63-118).  Returns (new_dets (k,5), inds (k,) int64)."""
+    codes = {'naive': 0, 'linear': 1, 'gaussian': 2}
+    if method not in codes:
+        raise ValueError('invalid method for SoftNMS: {}'.format(method))
+    d = _f32(dets).reshape(-1, 5)
+    out = np.zeros((d.shape[0], 6), dtype=np.float32)
+    k = lib().obbo_soft_nms_f32(_p(d), d.shape[0], ctypes.c_float(iou_thr), codes[method],
+                                ctypes.c_float(sigma), ctypes.c_float(min_score), _p(out))
+    assert k >= 0
+    return out[:k, :5].copy(), out[:k, 5].astype(np.int64)
+
+
+def polyiou_f64(a, b, kind='rbox', recentre=False):
+    """Aligned-pair IoU by the DOTA devkit's triangle-fan algorithm, fp64 (third,
+    independent formulation; see obb_oracle.c)."""
+    cols = 5 if kind == 'rbox' else 8
+    a = np.ascontiguousarray(a, dtype=np.float64).reshape(-1, cols)
+    b = np.ascontiguousarray(b, dtype=np.float64).reshape(-1, cols)
+    assert a.shape == b.shape
+    out = np.zeros(a.shape[0], dtype=np.float64)
+    if a.shape[0]:
+        rc = lib().obbo_polyiou_f64(_p(a, _f64p), _p(b, _f64p), a.shape[0], 0 if kind == 'rbox' else 1,
+                                    1 if recentre else 0, _p(out, _f64p))
+        assert rc == 0
+    return out
+
+
+def max_threads():
+    return int(lib().obbo_max_threads())
+
+
+def overlaps_mt(a, b, threads, mode='iou'):
+    """obbo_overlaps_f32 with rows dealt to `threads` OpenMP threads (same values)."""
+    a = _f32(a).reshape(-1, 5)
+    b = _f32(b).reshape(-1, 5)
+    out = np.zeros((a.shape[0], b.shape[0]), dtype=np.float32)
+    if out.size:
+        rc = lib().obbo_overlaps_mt_f32(_p(a), a.shape[0], _p(b), b.shape[0], 0, _mode(mode), int(threads), _p(out))
+        assert rc == 0
+    return out
+
+
+def rnms_mt(dets, iou_thr, threads):
+    """rnms with the suppression loop of each kept box dealt to threads (same keep)."""
+    d = _f32(dets).reshape(-1, 6)
     keep = np.zeros(d.shape[0], dtype=np.int64)
-    k = lib().obbo_hbb_nms_f32(_p(d), d.shape[0], ctypes.c_float(iou_thr), _p(keep, _i64p))
+    k = lib().obbo_nms_mt_f32(_p(d), d.shape[0], ctypes.c_float(iou_thr), int(threads), _p(keep, _i64p))
     assert k >= 0
     return keep[:k].copy()
 
 
-def rroi_align_forward(feat, rois, out_size, spatial_scale, sample_num=0, min_size=1.0):
+def rroi_align_forward(feat, rois, out_size, spatial_scale, sample_num=0, min_size=1.0, threads=1):
     feat = _f32(feat)
     rois = _f32(rois).reshape(-1, 6)
     B, C, H, W = feat.shape
     ph, pw = (out_size, out_size) if isinstance(out_size, int) else out_size
     K = rois.shape[0]
     out = np.zeros((K, C, ph, pw), dtype=np.float32)
-    if K:
+    if K and threads > 1:
+        rc = lib().obbo_rroi_align_forward_mt_f32(_p(feat), B, C, H, W, _p(rois), K, ph, pw,
+                                                  ctypes.c_float(spatial_scale), sample_num,
+                                                  ctypes.c_float(min_size), int(threads), _p(out))
+        assert rc == 0
+    elif K:
         rc = lib().obbo_rroi_align_forward_f32(_p(feat), B, C, H, W, _p(rois), K, ph, pw,
                                                ctypes.c_float(spatial_scale), sample_num,
                                                ctypes.c_float(min_size), _p(out))

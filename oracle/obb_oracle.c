@@ -416,18 +416,41 @@ static int cmp_key_idx(const void *a, const void *b) {
  * file, dota.py:310-336).  group may be NULL (one group); thrs may be NULL
  * (use thr) or give a threshold per box (the threshold of the EARLIER box of a
  * pair is used; boxes of one group share it: per-class thresholds, dota.py:324). */
-OBBO_API long obbo_nms_grouped_f32(const float *dets, long n, int kind, float thr,
-                                   const int32_t *group, const float *thrs, int64_t *keep);
-
-OBBO_API long obbo_nms_f32(const float *dets, long n, int kind, float thr,
-                           int64_t *keep) {
-  return obbo_nms_grouped_f32(dets, n, kind, thr, NULL, NULL, keep);
-}
+OBBO_API long obbo_nms_ex_f32(const float *dets, long n, int kind, float thr,
+                              const int32_t *group, const float *thrs, int flags, int64_t *keep);
 
 OBBO_API long obbo_nms_grouped_f32(const float *dets, long n, int kind, float thr,
                                    const int32_t *group, const float *thrs, int64_t *keep) {
+  return obbo_nms_ex_f32(dets, n, kind, thr, group, thrs, 0, keep);
+}
+
+OBBO_API long obbo_nms_f32(const float *dets, long n, int kind, float thr,
+                           int64_t *keep) {
+  return obbo_nms_ex_f32(dets, n, kind, thr, NULL, NULL, 0, keep);
+}
+
+/* the reference's horizontal pair overlap, nms_cpu.cpp:19,47-55, in its operation order:
+ * a[] / b[] = x1, y1, x2, y2; areas = (x2 - x1 + 1) * (y2 - y1 + 1).                    */
+static inline float hbb_area_f32(const float *d) {
+  return ((d[2] - d[0]) + 1.0f) * ((d[3] - d[1]) + 1.0f);
+}
+static inline float hbb_overlap_f32(const float *a, float aarea, const float *b, float barea) {
+  float xx1 = max_sel(a[0], b[0]), yy1 = max_sel(a[1], b[1]);   /* std::max(ix1, x1[j]) */
+  float xx2 = min_sel(a[2], b[2]), yy2 = min_sel(a[3], b[3]);
+  float w = max_sel(0.0f, (xx2 - xx1) + 1.0f), h = max_sel(0.0f, (yy2 - yy1) + 1.0f);
+  float inter = w * h;
+  return inter / ((aarea + barea) - inter);
+}
+
+/* kind 0 / 1: rotated / polygon rows (OBB-GEOM v1 overlap); kind 2: horizontal rows
+ * x1,y1,x2,y2,score with EXACTLY the reference's arithmetic (nms_cpu.cpp:19,47-56).
+ * flags bit 0 ("strict"): suppress on ovr > thr, the comparison of the reference's CUDA
+ * kernel (nms_kernel.cu:61), instead of the CPU reference's ovr >= thr (nms_cpu.cpp:56). */
+OBBO_API long obbo_nms_ex_f32(const float *dets, long n, int kind, float thr,
+                              const int32_t *group, const float *thrs, int flags, int64_t *keep) {
   long i, j;
-  int stride = kind ? 9 : 6;
+  const int strict = flags & 1;
+  int stride = kind == 1 ? 9 : (kind == 2 ? 5 : 6);
   if (n < 0) return -1;
   if (n == 0) return 0;
   key_idx *ord = (key_idx *)malloc(sizeof(key_idx) * (size_t)n);
@@ -435,9 +458,9 @@ OBBO_API long obbo_nms_grouped_f32(const float *dets, long n, int kind, float th
   uint8_t *sup = (uint8_t *)calloc((size_t)n, 1);
   /* SoA copies of the prefilter fields in SORTED order: keeps the O(n^2)
    * inner loop streaming                                                    */
-  float *sx = (float *)malloc(sizeof(float) * (size_t)n * 4);
+  float *sx = (float *)malloc(sizeof(float) * (size_t)n * 5);
   if (!ord || !Q || !sup || !sx) { free(ord); free(Q); free(sup); free(sx); return -2; }
-  float *sy = sx + n, *sex = sx + 2 * n, *sey = sx + 3 * n;
+  float *sy = sx + n, *sex = sx + 2 * n, *sey = sx + 3 * n, *sar = sx + 4 * n;
   for (i = 0; i < n; ++i) {
     ord[i].key = obbo_score_key(dets[i * stride + stride - 1]);
     ord[i].idx = i;
@@ -445,6 +468,7 @@ OBBO_API long obbo_nms_grouped_f32(const float *dets, long n, int kind, float th
   qsort(ord, (size_t)n, sizeof(key_idx), cmp_key_idx);
   for (i = 0; i < n; ++i) {
     const float *d = dets + ord[i].idx * stride;
+    if (kind == 2) { sx[i] = d[0]; sy[i] = d[1]; sex[i] = d[2]; sey[i] = d[3]; sar[i] = hbb_area_f32(d); continue; }
     if (kind) obbo_quad_from_poly_f32(d, &Q[i]);
     else obbo_quad_from_rbox_f32(d, &Q[i]);
     sx[i] = Q[i].ox; sy[i] = Q[i].oy; sex[i] = Q[i].ex; sey[i] = Q[i].ey;
@@ -452,19 +476,25 @@ OBBO_API long obbo_nms_grouped_f32(const float *dets, long n, int kind, float th
   for (i = 0; i < n; ++i) {
     if (sup[i]) continue;
     const obbo_quad *A = &Q[i];
-    float ax = A->ox, ay = A->oy, aex = A->ex, aey = A->ey;
+    float ax = sx[i], ay = sy[i], aex = sex[i], aey = sey[i];
     int32_t gi = group ? group[ord[i].idx] : 0;
     float ti = thrs ? thrs[ord[i].idx] : thr;
     for (j = i + 1; j < n; ++j) {
       if (sup[j]) continue;
       if (group && group[ord[j].idx] != gi) continue;
-      /* same prefilter as quad_overlap_f32, hoisted */
-      float dx = sx[j] - ax;
-      if (fabs_sel(dx) > aex + sex[j]) continue;
-      float dy = sy[j] - ay;
-      if (fabs_sel(dy) > aey + sey[j]) continue;
-      float ovr = quad_overlap_f32(A, &Q[j], 0);
-      if (ovr >= ti) sup[j] = 1;
+      float ovr;
+      if (kind == 2) {
+        const float a4[4] = {ax, ay, aex, aey}, b4[4] = {sx[j], sy[j], sex[j], sey[j]};
+        ovr = hbb_overlap_f32(a4, sar[i], b4, sar[j]);
+      } else {
+        /* same prefilter as quad_overlap_f32, hoisted */
+        float dx = sx[j] - ax;
+        if (fabs_sel(dx) > aex + sex[j]) continue;
+        float dy = sy[j] - ay;
+        if (fabs_sel(dy) > aey + sey[j]) continue;
+        ovr = quad_overlap_f32(A, &Q[j], 0);
+      }
+      if (strict ? (ovr > ti) : (ovr >= ti)) sup[j] = 1;
     }
   }
   /* ascending ORIGINAL index */
@@ -711,4 +741,257 @@ OBBO_API long obbo_hbb_nms_f32(const float *dets, long n, float thr, int64_t *ke
   return k;
 }
 
-OBBO_API const char *obbo_version(void) { return "obb-oracle 1 (OBB-GEOM v1)"; }
+/* ------------------------------------------------------------------ */
+/* Soft-NMS restatement of nms_cpu.cpp:71-210 (fp32 instantiation)      */
+/* ------------------------------------------------------------------ */
+/* dets (n,5) = x1,y1,x2,y2,score.  method 0 = hard (weight 0 when ovr > thr), 1 = linear
+ * (1 - ovr when ovr > thr), 2 = gaussian exp(-ovr^2 / sigma)  (nms_cpu.cpp:167-181).
+ * Selection by repeated arg-max over the not-yet-selected tail with STRICT `<`, i.e. the
+ * first of equal scores wins (:114-121); a rescored box below min_score is removed by
+ * moving the LAST box into its slot, which is then examined again (:184-198).
+ * out (n,6) receives x1,y1,x2,y2,new score,original index for every surviving box in
+ * selection order (:200-209).  Returns the number of rows.  method 2 calls expf(): results
+ * on other libms may differ in the last ulp of the score (the hard/linear methods use
+ * only + - * / and comparisons).                                                       */
+OBBO_API long obbo_soft_nms_f32(const float *dets, long n, float thr, int method, float sigma,
+                                float min_score, float *out) {
+  long i, pos;
+  if (n <= 0) return 0;
+  float *x1 = (float *)malloc(sizeof(float) * (size_t)n * 7);
+  if (!x1) return -2;
+  float *y1 = x1 + n, *x2 = x1 + 2 * n, *y2 = x1 + 3 * n, *sc = x1 + 4 * n, *ar = x1 + 5 * n, *id = x1 + 6 * n;
+  for (i = 0; i < n; ++i) {
+    const float *d = dets + i * 5;
+    x1[i] = d[0]; y1[i] = d[1]; x2[i] = d[2]; y2[i] = d[3]; sc[i] = d[4];
+    ar[i] = hbb_area_f32(d);
+    id[i] = (float)i;   /* the reference keeps the indices in the dets' dtype (arange(ndets, dets.options())) */
+  }
+  long nd = n;
+  for (i = 0; i < nd; ++i) {
+    float max_score = sc[i];
+    long max_pos = i;
+    for (pos = i + 1; pos < nd; ++pos)
+      if (max_score < sc[pos]) { max_score = sc[pos]; max_pos = pos; }
+    float t;
+#define OBBO_SWAP(a) t = a[i]; a[i] = a[max_pos]; a[max_pos] = t
+    OBBO_SWAP(x1); OBBO_SWAP(y1); OBBO_SWAP(x2); OBBO_SWAP(y2); OBBO_SWAP(sc); OBBO_SWAP(ar); OBBO_SWAP(id);
+#undef OBBO_SWAP
+    const float a4[4] = {x1[i], y1[i], x2[i], y2[i]};
+    const float iarea = ar[i];
+    pos = i + 1;
+    while (pos < nd) {
+      const float b4[4] = {x1[pos], y1[pos], x2[pos], y2[pos]};
+      float ovr = hbb_overlap_f32(a4, iarea, b4, ar[pos]);
+      float weight = 1.0f;
+      if (method == 1) { if (ovr > thr) weight = 1.0f - ovr; }
+      else if (method == 2) weight = expf(-(ovr * ovr) / sigma);
+      else weight = (ovr > thr) ? 0.0f : 1.0f;
+      sc[pos] = weight * sc[pos];
+      if (sc[pos] < min_score) {
+        x1[pos] = x1[nd - 1]; y1[pos] = y1[nd - 1]; x2[pos] = x2[nd - 1]; y2[pos] = y2[nd - 1];
+        sc[pos] = sc[nd - 1]; ar[pos] = ar[nd - 1]; id[pos] = id[nd - 1];
+        nd = nd - 1;
+        pos = pos - 1;
+      }
+      pos = pos + 1;
+    }
+  }
+  for (i = 0; i < nd; ++i) {
+    float *o = out + i * 6;
+    o[0] = x1[i]; o[1] = y1[i]; o[2] = x2[i]; o[3] = y2[i]; o[4] = sc[i]; o[5] = id[i];
+  }
+  free(x1);
+  return nd;
+}
+
+/* ------------------------------------------------------------------ */
+/* fp64 triangle-fan polygon IoU ("polyiou")                            */
+/* ------------------------------------------------------------------ */
+/* THIRD, independent formulation of the rotated overlap: the algorithm published with the
+ * DOTA development kit (DOTA_devkit/polyiou.cpp [external, not in the reference tree] -- the
+ * routine the absent `wwtool.mergebypoly` is recorded as wrapping): both
+ * polygons are fanned into triangles from the coordinate origin, every pair of triangles
+ * (o,a,b) x (o,c,d) is intersected by cutting the first with the three half-planes of the
+ * second, and the SIGNED areas are summed.  No convexity assumption, no shared code with
+ * the two routines above.  eps = 1e-8 as published.                                      */
+typedef struct { double x, y; } pt_d;
+static int sig_d(double d) { const double eps = 1e-8; return (d > eps) - (d < -eps); }
+static double cross3_d(pt_d o, pt_d a, pt_d b) { return (a.x - o.x) * (b.y - o.y) - (b.x - o.x) * (a.y - o.y); }
+static double fan_area_d(const pt_d *ps, int n) {
+  double r = 0.0; int i;
+  for (i = 0; i < n; ++i) r += ps[i].x * ps[(i + 1) % n].y - ps[i].y * ps[(i + 1) % n].x;
+  return r / 2.0;
+}
+static int line_cross_d(pt_d a, pt_d b, pt_d c, pt_d d, pt_d *p) {
+  double s1 = cross3_d(a, b, c), s2 = cross3_d(a, b, d);
+  if (sig_d(s1) == 0 && sig_d(s2) == 0) return 2;
+  if (sig_d(s2 - s1) == 0) return 0;
+  p->x = (c.x * s2 - d.x * s1) / (s2 - s1);
+  p->y = (c.y * s2 - d.y * s1) / (s2 - s1);
+  return 1;
+}
+/* keep the part of polygon p (n vertices) on the left of a->b */
+static void polygon_cut_d(pt_d *p, int *n, pt_d a, pt_d b) {
+  pt_d pp[16];
+  int m = 0, i;
+  p[*n] = p[0];
+  for (i = 0; i < *n; ++i) {
+    if (sig_d(cross3_d(a, b, p[i])) > 0) pp[m++] = p[i];
+    if (sig_d(cross3_d(a, b, p[i])) != sig_d(cross3_d(a, b, p[i + 1])))
+      line_cross_d(a, b, p[i], p[i + 1], &pp[m++]);
+  }
+  *n = 0;
+  for (i = 0; i < m; ++i)
+    if (!i || !(pp[i].x == pp[i - 1].x && pp[i].y == pp[i - 1].y)) p[(*n)++] = pp[i];
+  while (*n > 1 && p[*n - 1].x == p[0].x && p[*n - 1].y == p[0].y) (*n)--;
+}
+static double tri_inter_d(pt_d a, pt_d b, pt_d c, pt_d d) {
+  pt_d o = {0.0, 0.0};
+  int s1 = sig_d(cross3_d(o, a, b)), s2 = sig_d(cross3_d(o, c, d));
+  if (s1 == 0 || s2 == 0) return 0.0;
+  if (s1 == -1) { pt_d t = a; a = b; b = t; }
+  if (s2 == -1) { pt_d t = c; c = d; d = t; }
+  pt_d p[16] = {o, a, b};
+  int n = 3;
+  polygon_cut_d(p, &n, o, c);
+  polygon_cut_d(p, &n, c, d);
+  polygon_cut_d(p, &n, d, o);
+  double res = fabs(fan_area_d(p, n));
+  if (s1 * s2 == -1) res = -res;
+  return res;
+}
+static double poly_inter_fan_d(const pt_d *ps1, int n1, const pt_d *ps2, int n2) {
+  pt_d a[8], b[8];
+  int i, j;
+  for (i = 0; i < n1; ++i) a[i] = ps1[i];
+  for (i = 0; i < n2; ++i) b[i] = ps2[i];
+  if (fan_area_d(a, n1) < 0) for (i = 0; i < n1 / 2; ++i) { pt_d t = a[i]; a[i] = a[n1 - 1 - i]; a[n1 - 1 - i] = t; }
+  if (fan_area_d(b, n2) < 0) for (i = 0; i < n2 / 2; ++i) { pt_d t = b[i]; b[i] = b[n2 - 1 - i]; b[n2 - 1 - i] = t; }
+  a[n1] = a[0]; b[n2] = b[0];
+  double res = 0.0;
+  for (i = 0; i < n1; ++i)
+    for (j = 0; j < n2; ++j) res += tri_inter_d(a[i], a[i + 1], b[j], b[j + 1]);
+  return res;
+}
+
+/* aligned pairs: a, b (n, 5) theta-OBBs (kind 0) or (n, 8) polygons (kind 1), fp64 in,
+ * iou[i] out.  The fan is taken from the coordinate origin as published; `recentre` != 0
+ * first translates both polygons so that a's first vertex is the origin (the fan's signed
+ * triangles then stay small -- at DOTA coordinates ~2e4 the published form loses ~1e-7
+ * of the area to cancellation, which is what this flag lets a test quantify).            */
+OBBO_API int obbo_polyiou_f64(const double *a, const double *b, long n, int kind, int recentre,
+                              double *iou) {
+  long i;
+  int k, stride = kind ? 8 : 5;
+  for (i = 0; i < n; ++i) {
+    double ax[4], ay[4], bx[4], by[4];
+    pt_d pa[5], pb[5];
+    if (kind) { for (k = 0; k < 4; ++k) { ax[k] = a[i * 8 + 2 * k]; ay[k] = a[i * 8 + 2 * k + 1]; bx[k] = b[i * 8 + 2 * k]; by[k] = b[i * 8 + 2 * k + 1]; } }
+    else { rbox_corners_d(a + i * stride, ax, ay); rbox_corners_d(b + i * stride, bx, by); }
+    double ox = recentre ? ax[0] : 0.0, oy = recentre ? ay[0] : 0.0;
+    for (k = 0; k < 4; ++k) { pa[k].x = ax[k] - ox; pa[k].y = ay[k] - oy; pb[k].x = bx[k] - ox; pb[k].y = by[k] - oy; }
+    double aa = fabs(fan_area_d(pa, 4)), ab = fabs(fan_area_d(pb, 4));
+    double inter = poly_inter_fan_d(pa, 4, pb, 4);
+    double uni = aa + ab - inter;
+    iou[i] = uni > 0 ? inter / uni : 0.0;
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* threaded legs for the CPU baseline (bench.py "all cores")            */
+/* ------------------------------------------------------------------ */
+/* Same arithmetic, rows / RoIs dealt to OpenMP threads.  Built with -fopenmp; without it
+ * the pragmas vanish and these are the serial routines.                                  */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+OBBO_API int obbo_max_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+OBBO_API int obbo_overlaps_mt_f32(const float *a, long m, const float *b, long n,
+                                  int kind, int mode, int threads, float *out) {
+  long i;
+  int stride = kind ? 8 : 5;
+  if (m < 0 || n < 0) return -1;
+  obbo_quad *QB = (obbo_quad *)malloc(sizeof(obbo_quad) * (size_t)(n > 0 ? n : 1));
+  if (!QB) return -2;
+  for (i = 0; i < n; ++i) {
+    if (kind) obbo_quad_from_poly_f32(b + i * stride, &QB[i]);
+    else obbo_quad_from_rbox_f32(b + i * stride, &QB[i]);
+  }
+  (void)threads;
+#pragma omp parallel for schedule(dynamic, 16) num_threads(threads)
+  for (i = 0; i < m; ++i) {
+    obbo_quad A;
+    long j;
+    if (kind) obbo_quad_from_poly_f32(a + i * stride, &A);
+    else obbo_quad_from_rbox_f32(a + i * stride, &A);
+    for (j = 0; j < n; ++j) out[i * n + j] = quad_overlap_f32(&A, &QB[j], mode);
+  }
+  free(QB);
+  return 0;
+}
+
+OBBO_API int obbo_rroi_align_forward_mt_f32(const float *feat, int B, int C, int H, int W,
+                                            const float *rois, long K, int ph, int pw,
+                                            float scale, int sample_num, float min_size,
+                                            int threads, float *out) {
+  long k;
+  (void)threads;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
+  for (k = 0; k < K; ++k)
+    obbo_rroi_align_forward_f32(feat, B, C, H, W, rois + k * 6, 1, ph, pw, scale, sample_num, min_size,
+                                out + k * (long)C * ph * pw);
+  return 0;
+}
+
+/* rotated NMS with the inner (suppression) loop of one kept box dealt to threads: the
+ * outer loop is the serial dependency of nms_cpu.cpp:35-58, the inner one is independent
+ * per j.  Same keep set as obbo_nms_f32 by construction (each j is decided by the same
+ * kept i in the same order).                                                            */
+OBBO_API long obbo_nms_mt_f32(const float *dets, long n, float thr, int threads, int64_t *keep) {
+  long i;
+  if (n <= 0) return 0;
+  key_idx *ord = (key_idx *)malloc(sizeof(key_idx) * (size_t)n);
+  obbo_quad *Q = (obbo_quad *)malloc(sizeof(obbo_quad) * (size_t)n);
+  uint8_t *sup = (uint8_t *)calloc((size_t)n, 1);
+  if (!ord || !Q || !sup) { free(ord); free(Q); free(sup); return -2; }
+  for (i = 0; i < n; ++i) { ord[i].key = obbo_score_key(dets[i * 6 + 5]); ord[i].idx = i; }
+  qsort(ord, (size_t)n, sizeof(key_idx), cmp_key_idx);
+  for (i = 0; i < n; ++i) obbo_quad_from_rbox_f32(dets + ord[i].idx * 6, &Q[i]);
+  (void)threads;
+#pragma omp parallel num_threads(threads)
+  {
+    long ii, j;
+    for (ii = 0; ii < n; ++ii) {
+      /* sup[ii] is final here: every i < ii has finished (barrier below) */
+      if (!sup[ii]) {
+        const obbo_quad *A = &Q[ii];
+#pragma omp for schedule(static) nowait
+        for (j = ii + 1; j < n; ++j) {
+          if (sup[j]) continue;
+          float dx = Q[j].ox - A->ox;
+          if (fabs_sel(dx) > A->ex + Q[j].ex) continue;
+          float dy = Q[j].oy - A->oy;
+          if (fabs_sel(dy) > A->ey + Q[j].ey) continue;
+          if (quad_overlap_f32(A, &Q[j], 0) >= thr) sup[j] = 1;
+        }
+      }
+#pragma omp barrier
+    }
+  }
+  uint8_t *kept = (uint8_t *)calloc((size_t)n, 1);
+  for (i = 0; i < n; ++i) if (!sup[i]) kept[ord[i].idx] = 1;
+  long k = 0;
+  for (i = 0; i < n; ++i) if (kept[i]) keep[k++] = i;
+  free(kept); free(ord); free(Q); free(sup);
+  return k;
+}
+
+OBBO_API const char *obbo_version(void) { return "obb-oracle 2 (OBB-GEOM v1)"; }

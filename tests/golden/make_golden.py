@@ -10,6 +10,8 @@ What is captured (SURVEY.md 8c anchors):
   multiclass.npz     A3  core/post_processing/bbox_nms.py:6-76, rbbox_nms.py:6-119
   thetaobb_codec.npz A5  core/rbbox/transforms.py:191-203,280-293,321-395
   assigner.npz           core/bbox/assigners/max_iou_assigner.py:8-202 (MaxIoUAssigner)
+  soft_nms.npz           mmdet/ops/nms/src/nms_cpu.cpp:71-210 via nms_wrapper.py:63-118
+  hbb_nms_ties.npz       nms_cpu.cpp:5-68 on INTEGER boxes (IoU == thr happens: `>=` decides)
 """
 import importlib.util
 import os
@@ -220,6 +222,51 @@ def main():
     out['labels'] = labels.numpy()
     out['overlaps'] = geometry.bbox_overlaps(gts, boxes).numpy()
     np.savez_compressed(os.path.join(HERE, 'assigner.npz'), **out)
+    # ---- Soft-NMS (own generator: the fixtures above keep their random streams) -------
+    rng2 = np.random.default_rng(20261004)
+    out = {}
+    doc6 = np.array([[4., 3., 5., 3., 0.9], [4., 3., 5., 4., 0.9], [3., 1., 3., 1., 0.5],
+                     [3., 1., 3., 1., 0.5], [3., 1., 3., 1., 0.4], [3., 1., 3., 1., 0.0]], dtype=np.float32)
+    out['doc6_dets'] = doc6
+    nd, inds = nms_wrapper.soft_nms(doc6, 0.7, sigma=0.5)
+    out['doc6_new_dets'] = nd; out['doc6_inds'] = inds
+    t4 = np.array([[49.1, 32.4, 51.0, 35.9, 0.9], [49.3, 32.9, 51.0, 35.3, 0.9],
+                   [35.3, 11.5, 39.9, 14.5, 0.4], [35.2, 11.7, 39.7, 15.7, 0.3]], dtype=np.float32)
+    out['test4_dets'] = t4
+    nd, inds = nms_wrapper.soft_nms(t4, 0.7)
+    out['test4_new_dets'] = nd; out['test4_inds'] = inds
+    for tag, n, canvas, thr, method, sigma, min_score, ties in (
+            ('a', 300, 128, 0.3, 'linear', 0.5, 1e-3, False),
+            ('b', 300, 128, 0.3, 'gaussian', 0.5, 1e-3, False),
+            ('c', 2000, 400, 0.5, 'linear', 0.5, 0.05, True),
+            ('d', 2000, 400, 0.5, 'gaussian', 0.3, 0.05, True),
+            ('e', 1000, 1000, 0.3, 'linear', 0.5, 1e-3, False)):
+        boxes = rand_hbb(rng2, n, canvas)
+        score = rng2.uniform(0, 1, n).astype(np.float32)
+        if ties:
+            score[::3] = np.float32(0.5)       # equal scores: the first position wins (:114-121)
+        dets = np.concatenate([boxes, score[:, None]], 1)
+        nd, inds = nms_wrapper.soft_nms(dets, thr, method=method, sigma=sigma, min_score=min_score)
+        out['rand_%s_dets' % tag] = dets
+        out['rand_%s_cfg' % tag] = np.array([thr, sigma, min_score], dtype=np.float64)
+        out['rand_%s_method' % tag] = np.array(method)
+        out['rand_%s_new_dets' % tag] = nd
+        out['rand_%s_inds' % tag] = inds
+    np.savez_compressed(os.path.join(HERE, 'soft_nms.npz'), **out)
+
+    # ---- HBB NMS on integer boxes: exact IoU == thr ties (nms_cpu.cpp:56 `>=`) ----------
+    out = {}
+    two = np.array([[0, 0, 9, 9, 0.9], [0, 0, 9, 19, 0.8], [0, 0, 9, 29, 0.7]], dtype=np.float32)
+    out['half_dets'] = two                      # IoU(0,1) = 100/200 = 0.5 exactly
+    out['half_keep'] = nms_wrapper.nms(two, 0.5)[1]
+    for tag, n, canvas, thr in (('a', 2000, 96, 0.5), ('b', 2000, 64, 0.25), ('c', 3000, 200, 0.5)):
+        boxes = rand_hbb(rng2, n, canvas, 4, 40, integer=True)
+        score = ((rng2.permutation(n) + 0.5) / n).astype(np.float32)
+        dets = np.concatenate([boxes, score[:, None]], 1)
+        out['int_%s_dets' % tag] = dets
+        out['int_%s_thr' % tag] = np.float32(thr)
+        out['int_%s_keep' % tag] = nms_wrapper.nms(dets, thr)[1]
+    np.savez_compressed(os.path.join(HERE, 'hbb_nms_ties.npz'), **out)
     print('wrote', sorted(f for f in os.listdir(HERE) if f.endswith('.npz')))
 
 
