@@ -25,6 +25,10 @@ KIND_RBOX = 0
 KIND_POLY = 1
 KIND_HBB = 2   # NMS only: x1, y1, x2, y2 (+ score) with the reference's +1 convention
 MODE = {'iou': 0, 'iof': 1}
+NMS_STRICT = 1          # OBB_NMS_STRICT: suppress on `>` (nms_kernel.cu:61) instead of `>=` (nms_cpu.cpp:56)
+NMS_RESULT_BYTES = 64   # OBB_NMS_RESULT_BYTES
+# obb_set_tuning knobs (test / experiment hooks, include/obbops.h)
+TUNE_NMS_FUSED_MAX, TUNE_NMS_DIRECT_MAX, TUNE_NMS_SCAN_BLOCKS, TUNE_RROI_GROUPS, TUNE_OVERLAPS_ROWS = range(5)
 
 _lib = None
 
@@ -57,6 +61,20 @@ def lib():
         L.obb_nms_grouped_f32.argtypes = [vp, i64, i32, f32, vp, vp, vp, ctypes.POINTER(i64), vp,
                                           ctypes.c_size_t, vp]
         L.obb_nms_grouped_f32.restype = i32
+        L.obb_nms_ex_f32.argtypes = [vp, i64, i32, f32, vp, vp, i32, vp, ctypes.POINTER(i64), vp,
+                                     ctypes.c_size_t, vp]
+        L.obb_nms_ex_f32.restype = i32
+        L.obb_nms_async_f32.argtypes = [vp, i64, i32, f32, vp, vp, i32, vp, vp, vp, ctypes.c_size_t, vp]
+        L.obb_nms_async_f32.restype = i32
+        L.obb_nms_async_result.argtypes = [vp, i64, ctypes.c_size_t, ctypes.POINTER(i64)]
+        L.obb_nms_async_result.restype = i32
+        L.obb_soft_nms_workspace_bytes.argtypes = [i64]
+        L.obb_soft_nms_workspace_bytes.restype = ctypes.c_size_t
+        L.obb_soft_nms_f32.argtypes = [vp, i64, f32, i32, f32, f32, vp, vp, ctypes.POINTER(i64), vp,
+                                       ctypes.c_size_t, vp]
+        L.obb_soft_nms_f32.restype = i32
+        L.obb_set_tuning.argtypes = [i32, i64]
+        L.obb_set_tuning.restype = i32
         rroi = [vp, i32, i32, i32, i32, vp, i64, i32, i32, f32, i32, f32, vp, vp]
         L.obb_rroi_align_forward_f32.argtypes = rroi
         L.obb_rroi_align_forward_f32.restype = i32
@@ -75,6 +93,11 @@ def lib():
         L.obb_rbox_to_poly_f32.restype = i32
         _lib = L
     return _lib
+
+
+def set_tuning(knob, value):
+    """Test / experiment hook: force a launch-geometry or routing knob (value < 0 = default)."""
+    check(lib().obb_set_tuning(int(knob), int(value)))
 
 
 def check(rc):

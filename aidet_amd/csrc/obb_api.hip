@@ -1,6 +1,8 @@
 // obb_api.hip -- version / error plumbing of the C ABI (include/obbops.h).
 #include <string.h>
 
+#include <atomic>
+
 #include "obb_common.h"
 
 namespace obb {
@@ -17,12 +19,25 @@ int set_err(int code, const char *fmt, ...) {
   return code;
 }
 
+static std::atomic<int64_t> g_tune[OBB_TUNE_COUNT] = {{-1}, {-1}, {-1}, {-1}, {-1}};
+
+int64_t tuning(int knob, int64_t def) {
+  const int64_t v = g_tune[knob].load(std::memory_order_relaxed);
+  return v < 0 ? def : v;
+}
+
 }  // namespace obb
 
-extern "C" int obb_version(void) { return 100; }
+extern "C" int obb_set_tuning(int knob, int64_t value) {
+  if (knob < 0 || knob >= OBB_TUNE_COUNT) return obb::set_err(OBB_EINVAL, "obb_set_tuning: unknown knob %d", knob);
+  obb::g_tune[knob].store(value < 0 ? -1 : value, std::memory_order_relaxed);
+  return OBB_OK;
+}
+
+extern "C" int obb_version(void) { return 101; }
 
 extern "C" const char *obb_build_info(void) {
-  return "libobbops 1.0 | OBB-GEOM v1 | gfx950 | -ffp-contract=off | HIP " __VERSION__;
+  return "libobbops 1.1 | OBB-GEOM v1 | gfx950 | -ffp-contract=off | HIP " __VERSION__;
 }
 
 extern "C" const char *obb_last_error(void) { return obb::err_buf(); }

@@ -28,6 +28,9 @@ int set_err(int code, const char *fmt, ...);
                           hipGetErrorString(e_), __FILE__, __LINE__);              \
   } while (0)
 
+// obb_set_tuning() values (obb_api.hip); `def` when the knob is unset
+int64_t tuning(int knob, int64_t def);
+
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 }  // namespace obb

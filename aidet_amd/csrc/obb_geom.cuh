@@ -195,11 +195,13 @@ __device__ __forceinline__ bool aabb_reject(float aox, float aoy, float aex, flo
   return (fabs_sel(dx) > lox) || (fabs_sel(dy) > loy);
 }
 
-// overlap of two quad records; mode 0 = iou, 1 = iof (inter / area(A)).
-__device__ __forceinline__ float quad_overlap(const Quad &A, const Quad &B, int mode) {
+// overlap of two quad records; mode 0 = iou, 1 = iof (inter / area(A)).  `rej` = the spec's
+// AABB prefilter fired (the value is then an exact 0 and, in NMS, the pair does not interact
+// whatever the threshold: the oracle `continue`s, obb_oracle.c obbo_nms_ex_f32).
+__device__ __forceinline__ float quad_overlap(const Quad &A, const Quad &B, int mode, bool &rej) {
   float dx = B.ox - A.ox, dy = B.oy - A.oy;
   float lox = A.ex + B.ex, loy = A.ey + B.ey;
-  bool rej = (fabs_sel(dx) > lox) || (fabs_sel(dy) > loy);
+  rej = (fabs_sel(dx) > lox) || (fabs_sel(dy) > loy);
   float inter = quad_inter(A, B, dx, dy);
   float lim = min_sel(A.area, B.area);
   inter = min_sel(inter, lim);
@@ -209,6 +211,25 @@ __device__ __forceinline__ float quad_overlap(const Quad &A, const Quad &B, int 
   bool ok = den > 0.0f;
   float v = inter / den;
   return (rej || !ok) ? 0.0f : v;
+}
+
+__device__ __forceinline__ float quad_overlap(const Quad &A, const Quad &B, int mode) {
+  bool rej;
+  return quad_overlap(A, B, mode, rej);
+}
+
+// The reference's HORIZONTAL pair overlap in its own operation order (nms_cpu.cpp:19,47-55):
+// a / b = x1, y1, x2, y2; areas = ((x2 - x1) + 1) * ((y2 - y1) + 1).  max_sel / min_sel have
+// std::max / std::min's operand order, so NaNs travel the same way.
+__device__ __forceinline__ float hbb_area(float x1, float y1, float x2, float y2) {
+  return ((x2 - x1) + 1.0f) * ((y2 - y1) + 1.0f);
+}
+__device__ __forceinline__ float hbb_overlap(const float (&a)[4], float aarea, const float (&b)[4], float barea) {
+  const float xx1 = max_sel(a[0], b[0]), yy1 = max_sel(a[1], b[1]);
+  const float xx2 = min_sel(a[2], b[2]), yy2 = min_sel(a[3], b[3]);
+  const float w = max_sel(0.0f, (xx2 - xx1) + 1.0f), h = max_sel(0.0f, (yy2 - yy1) + 1.0f);
+  const float inter = w * h;
+  return inter / ((aarea + barea) - inter);
 }
 
 // order-preserving score key: ascending key order == descending score,

@@ -49,6 +49,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <string.h>
+
 #include "obb_common.h"
 #include "obb_geom.cuh"
 
@@ -105,7 +107,13 @@ struct NmsHostInfo {
   long long rounds;
   unsigned long long cand_total, cand_worst;
   unsigned int heavy_units, light_units;
+  unsigned int route, pad;   // 0 fused, 1 direct, 2 sorted: which capacity check applies (obb_nms_async_result)
 };
+static_assert(sizeof(NmsHostInfo) <= OBB_NMS_RESULT_BYTES, "the async result record holds NmsHostInfo");
+
+// narrow-phase flags (kernel arguments; wave-uniform)
+constexpr int kFlagStrict = 1;   // suppress on ov > thr (nms_kernel.cu:61) instead of ov >= thr (nms_cpu.cpp:56)
+constexpr int kFlagHbb = 2;      // records hold x1,y1,x2,y2 in rx[]: the reference's own pair arithmetic
 
 // candidate counters: one per shard, each alone in a 256-byte slot (returning
 // atomics on words that share a cache line serialise at the memory side)
@@ -129,6 +137,19 @@ __device__ __forceinline__ float fkey_inv(uint32_t k) {
 
 __device__ __forceinline__ uint32_t shfl_xor_u(uint32_t v, int o) {
   return (uint32_t)__shfl_xor((int)v, o);
+}
+
+// OBB_KIND_HBB records: the raw x1,y1,x2,y2 travel in rx[] (ry[] unused) so that the narrow
+// phase can evaluate nms_cpu.cpp:47-55 on the reference's own floats; origin / extents (the
+// theta = 0 box with the +1 widths, load_quad<2>) still feed the broad phase: the continuous
+// box [x1-.5, x2+.5] x [y1-.5, y2+.5] meets another one exactly when the reference's
+// (xx2 - xx1) + 1 is positive (up to roundings that the interval margin covers).  A box with
+// (x2 - x1) + 1 <= 0 or (y2 - y1) + 1 <= 0 has w = 0 or h = 0 against every partner in the
+// reference (inter = 0, ovr = 0 or NaN: never >= a positive threshold): it is isolated.
+__device__ __forceinline__ void hbb_record(const float *__restrict__ row, QuadRec &r, bool &wellformed) {
+  const float x1 = row[0], y1 = row[1], x2 = row[2], y2 = row[3];
+  r.rx[0] = x1; r.rx[1] = y1; r.rx[2] = x2; r.rx[3] = y2;
+  wellformed = ((x2 - x1) + 1.0f > 0.0f) && ((y2 - y1) + 1.0f > 0.0f);
 }
 
 // ---- 1: prep -------------------------------------------------------------------
@@ -173,6 +194,8 @@ __global__ __launch_bounds__(256) void nms_prep_kernel(const float *__restrict__
     r.area = q.area; r.skey = score_key(row[S - 1]);
     r.group = group ? group[b] : 0;
     r.thr = thrs ? thrs[b] : thr;
+    bool wellformed = true;
+    if (KIND == 2) hbb_record(row, r, wellformed);
     rec[b] = r;
     ar[b] = q.area;
     float4 v;
@@ -181,7 +204,7 @@ __global__ __launch_bounds__(256) void nms_prep_kernel(const float *__restrict__
     // a box with a non-finite interval can never reach overlap >= thr in the spec
     // (its prefilter / area guards fail): isolate it from the scan
     const float big = 3.0e38f;
-    const bool fin = (fabs_sel(v.x) < big) && (fabs_sel(v.y) < big) && (fabs_sel(v.z) < big) &&
+    const bool fin = wellformed && (fabs_sel(v.x) < big) && (fabs_sel(v.y) < big) && (fabs_sel(v.z) < big) &&
                      (fabs_sel(v.w) < big);
     if (!fin) { v.x = 1.0f; v.y = -1.0f; v.z = 1.0f; v.w = -1.0f; }  // lo > hi = "isolated"
     iv[b] = v;
@@ -930,8 +953,17 @@ __device__ __forceinline__ void swap_if(bool c, float &a, float &b) {
 // One candidate pair: the edge points from the box that PRECEDES in the greedy order
 // (smaller score key, then smaller index) to the other one; the clip always takes the
 // preceding box as the subject A, exactly like the i-before-j loop of nms_cpu.cpp:35-58.
+__device__ __forceinline__ bool narrow_hit(const Quad &A, const Quad &B, float thr, int flags) {
+  float ov;
+  bool rej = false;
+  if (flags & kFlagHbb) ov = hbb_overlap(A.rx, A.area, B.rx, B.area);
+  else ov = quad_overlap(A, B, 0, rej);
+  const bool over = (flags & kFlagStrict) ? (ov > thr) : (ov >= thr);
+  return over && !rej;
+}
+
 __device__ __forceinline__ bool clip_loaded(Quad &A, Quad &B, uint32_t ka, uint32_t kb, int ga, int gb,
-                                            float ta, float tb, uint2 pr, uint32_t &src, uint32_t &dst) {
+                                            float ta, float tb, uint2 pr, int flags, uint32_t &src, uint32_t &dst) {
   const bool b_first = (kb < ka) || (kb == ka && pr.y < pr.x);
   const float thr = b_first ? tb : ta;  // the earlier box's threshold
   src = b_first ? pr.y : pr.x;
@@ -941,11 +973,10 @@ __device__ __forceinline__ bool clip_loaded(Quad &A, Quad &B, uint32_t ka, uint3
   swap_if(b_first, A.area, B.area);
 #pragma unroll
   for (int k = 0; k < 4; ++k) { swap_if(b_first, A.rx[k], B.rx[k]); swap_if(b_first, A.ry[k], B.ry[k]); }
-  const float ov = quad_overlap(A, B, 0);
-  return (ga == gb) && (ov >= thr);
+  return (ga == gb) && narrow_hit(A, B, thr, flags);
 }
 
-__device__ __forceinline__ bool clip_pair(const QuadRec *__restrict__ rec, uint2 pr, uint32_t &src,
+__device__ __forceinline__ bool clip_pair(const QuadRec *__restrict__ rec, uint2 pr, int flags, uint32_t &src,
                                           uint32_t &dst) {
   Quad A, B;
   uint32_t ka, kb;
@@ -953,7 +984,7 @@ __device__ __forceinline__ bool clip_pair(const QuadRec *__restrict__ rec, uint2
   float ta, tb;
   load_rec(rec, pr.x, A, ka, ga, ta);
   load_rec(rec, pr.y, B, kb, gb, tb);
-  return clip_loaded(A, B, ka, kb, ga, gb, ta, tb, pr, src, dst);
+  return clip_loaded(A, B, ka, kb, ga, gb, ta, tb, pr, flags, src, dst);
 }
 
 // hits of one wave -> its shard's edge segment (+ the in-degree of the targets)
@@ -995,6 +1026,7 @@ __device__ __forceinline__ bool prune_aabb_f(const Prune &pr, float4 a, float ra
 struct DirectSink {
   Prune pr;
   bool per_box_thr;                         // thresholds come from the records (pr.thr unused)
+  int flags;                                // kFlagStrict | kFlagHbb
   const float4 *__restrict__ iv;
   const float *__restrict__ ar;
   const QuadRec *__restrict__ rec;
@@ -1035,7 +1067,7 @@ struct DirectSink {
     if (lane == 0) atomicAdd(ccnt, (unsigned long long)__popcll(mk));
     bool hit = false;
     uint32_t src = 0, dst = 0;
-    if (keep) hit = clip_loaded(A, B, ka, kb, ga, gb, ta, tb, e, src, dst);
+    if (keep) hit = clip_loaded(A, B, ka, kb, ga, gb, ta, tb, e, flags, src, dst);
     push_edges(hit, src, dst, eseg, segcap, ecnt, cnt, lane);
   }
 };
@@ -1068,7 +1100,7 @@ __global__ __launch_bounds__(64 * kNmsWaves) void nms_scan_direct_kernel(const f
                                                                 const float *__restrict__ ar,
                                                                 const QuadRec *__restrict__ rec,
                                                                 uint32_t n, int rows_per_wave, float thr,
-                                                                int per_box_thr,
+                                                                int per_box_thr, int flags,
                                                                 uint2 *__restrict__ edges,
                                                                 unsigned long long segcap,
                                                                 unsigned long long *__restrict__ ccnts,
@@ -1088,6 +1120,7 @@ __global__ __launch_bounds__(64 * kNmsWaves) void nms_scan_direct_kernel(const f
   DirectSink sink;
   sink.pr.thr = thr; sink.pr.cpx = 0.0f; sink.pr.cpy = 0.0f;
   sink.per_box_thr = per_box_thr != 0;
+  sink.flags = flags;
   sink.iv = iv; sink.ar = ar; sink.rec = rec;
   sink.eseg = edges + (size_t)shard * segcap;
   sink.segcap = segcap;
@@ -1133,7 +1166,7 @@ __global__ __launch_bounds__(64 * kNmsWaves) void nms_scan_direct_kernel(const f
 // loop of nms_cpu.cpp:35-58.  grid = (blocks per shard, shards).
 __global__ __launch_bounds__(256) void nms_clip_kernel(const uint2 *__restrict__ cands,
                                                        unsigned long long segcap,
-                                                       const QuadRec *__restrict__ rec,
+                                                       const QuadRec *__restrict__ rec, int flags,
                                                        uint2 *__restrict__ edges,
                                                        NmsCounters *__restrict__ ctr,
                                                        unsigned long long *__restrict__ ccnts,
@@ -1152,7 +1185,7 @@ __global__ __launch_bounds__(256) void nms_clip_kernel(const uint2 *__restrict__
     const unsigned long long e = base + lane;
     bool hit = false;
     uint32_t src = 0, dst = 0;
-    if (e < total) hit = clip_pair(rec, cand[e], src, dst);
+    if (e < total) hit = clip_pair(rec, cand[e], flags, src, dst);
     push_edges(hit, src, dst, eseg, segcap, ecnt, cnt, lane);
   }
 }
@@ -1360,6 +1393,7 @@ __global__ __launch_bounds__(COMPACT ? kResolveThreadsCompact : kResolveThreads)
         hinfo->rounds = (long long)__hip_atomic_load(reinterpret_cast<unsigned long long *>(&ctr->rounds), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         hinfo->cand_total = v; hinfo->cand_worst = mx;
         hinfo->heavy_units = 0u; hinfo->light_units = 0u;
+        hinfo->route = 1u; hinfo->pad = 0u;
       }
     }
   }
@@ -1370,46 +1404,30 @@ __device__ __forceinline__ bool kept_flag(const int *__restrict__ cnt, int64_t i
   return word_kept(cnt[i]);
 }
 
-__global__ __launch_bounds__(1024) void nms_count_kernel(const int *__restrict__ cnt, int64_t n,
-                                                         int *__restrict__ blockcnt) {
-  __shared__ int wsum[16];
-  const int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x;
-  const bool f = (i < n) && kept_flag(cnt, i);
-  const uint64_t mk = __ballot(f);
-  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = __popcll(mk);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int t = 0;
-    for (int k = 0; k < 16; ++k) t += wsum[k];
-    blockcnt[blockIdx.x] = t;
-  }
-}
+// One pass, no second launch: a block takes a TICKET (its rank in start order, so every
+// block it will wait for is already running -- HIP promises nothing about dispatch order),
+// publishes the number of kept boxes of its 1024-box slice with a VALID bit in one agent-scope
+// word, and sums the words of all earlier tickets, polling the few that are not there yet.
+// The payload IS the flagged word, so no fence is involved; nobody waits for a later ticket.
+constexpr unsigned int kCountValid = 0x80000000u;
 
-__global__ __launch_bounds__(1024) void nms_write_kernel(const int *__restrict__ cnt, int64_t n,
-                                                         const int *__restrict__ blockcnt,
-                                                         int64_t *__restrict__ keep,
-                                                         NmsCounters *__restrict__ ctr,
-                                                         const unsigned long long *__restrict__ ccnts,
-                                                         NmsHostInfo *__restrict__ hinfo) {
+__global__ __launch_bounds__(1024) void nms_compact_kernel(const int *__restrict__ cnt, int64_t n,
+                                                           unsigned int *__restrict__ blockcnt,   // [0] ticket, [1 + t] count | VALID
+                                                           int64_t *__restrict__ keep,
+                                                           NmsCounters *__restrict__ ctr,
+                                                           const unsigned long long *__restrict__ ccnts,
+                                                           NmsHostInfo *__restrict__ hinfo) {
   __shared__ int wsum[16];
-  __shared__ long long sbase;
   __shared__ long long red[16];
+  __shared__ unsigned int s_ticket;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // base = sum of the counts of all previous blocks
-  long long part = 0;
-  for (int b = tid; b < (int)blockIdx.x; b += 1024) part += blockcnt[b];
-  for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o);
-  if (lane == 0) red[wave] = part;
-  const int64_t i = (int64_t)blockIdx.x * 1024 + tid;
+  if (tid == 0) s_ticket = __hip_atomic_fetch_add(&blockcnt[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  const unsigned int t = s_ticket;
+  const int64_t i = (int64_t)t * 1024 + tid;
   const bool f = (i < n) && kept_flag(cnt, i);
   const uint64_t mk = __ballot(f);
   if (lane == 0) wsum[wave] = __popcll(mk);
-  __syncthreads();
-  if (tid == 0) {
-    long long t = 0;
-    for (int k = 0; k < 16; ++k) t += red[k];
-    sbase = t;
-  }
   __syncthreads();
   int off = 0, tot = 0;
 #pragma unroll
@@ -1418,20 +1436,34 @@ __global__ __launch_bounds__(1024) void nms_write_kernel(const int *__restrict__
     off += (k < wave) ? v : 0;
     tot += v;
   }
+  if (tid == 0) __hip_atomic_store(&blockcnt[1 + t], (unsigned int)tot | kCountValid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  long long part = 0;
+  for (unsigned int b = tid; b < t; b += 1024) {
+    unsigned int v;
+    do { v = __hip_atomic_load(&blockcnt[1 + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (!(v & kCountValid));
+    part += (long long)(v & ~kCountValid);
+  }
+  for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o);
+  if (lane == 0) red[wave] = part;
+  __syncthreads();
+  long long sbase = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) sbase += red[k];
   if (f) keep[sbase + off + __popcll(mk & ((1ull << lane) - 1ull))] = i;
-  if (blockIdx.x == gridDim.x - 1 && wave == 0) {  // fold the padded shard counters for the host
+  if (t == gridDim.x - 1 && wave == 0) {  // fold the padded shard counters for the host
     unsigned long long v = ccnts[(size_t)lane * kCandStride], mx = v;
     const unsigned long long ev = ccnts[(size_t)(kShards + lane) * kCandStride];
     mx = ev > mx ? ev : mx;   // fullest segment of either kind
     for (int o = 32; o > 0; o >>= 1) {
       v += __shfl_xor(v, o);
-      const unsigned long long t = __shfl_xor(mx, o);
-      mx = t > mx ? t : mx;
+      const unsigned long long tt = __shfl_xor(mx, o);
+      mx = tt > mx ? tt : mx;
     }
     if (lane == 0) {
       hinfo->kept = sbase + tot; hinfo->edges = ctr->edges; hinfo->rounds = ctr->rounds;
       hinfo->cand_total = v; hinfo->cand_worst = mx;
       hinfo->heavy_units = ctr->heavy_units; hinfo->light_units = ctr->light_units;
+      hinfo->route = 2u; hinfo->pad = 0u;
     }
   }
 }
@@ -1449,7 +1481,7 @@ constexpr int kDirectMax = 65536;
 
 template <int KIND>
 __global__ __launch_bounds__(1024) void nms_small_kernel(const float *__restrict__ dets, int n,
-                                                         float thr_global,
+                                                         float thr_global, int flags,
                                                          const int32_t *__restrict__ group,
                                                          const float *__restrict__ thrs,
                                                          QuadRec *__restrict__ rec,
@@ -1486,12 +1518,14 @@ __global__ __launch_bounds__(1024) void nms_small_kernel(const float *__restrict
     r.area = q.area; r.skey = score_key(row[S - 1]);
     r.group = group ? group[tid] : 0;
     r.thr = thrs ? thrs[tid] : thr_global;
+    bool wellformed = true;
+    if (KIND == 2) hbb_record(row, r, wellformed);
     rec[tid] = r;
     skey[tid] = r.skey;
     area[tid] = q.area;
     nms_interval(q.ox, q.ex, xl, xh);
     nms_interval(q.oy, q.ey, yl, yh);
-    fin = (fabs_sel(xl) < big) && (fabs_sel(xh) < big) && (fabs_sel(yl) < big) && (fabs_sel(yh) < big);
+    fin = wellformed && (fabs_sel(xl) < big) && (fabs_sel(xh) < big) && (fabs_sel(yl) < big) && (fabs_sel(yh) < big);
   }
   cnt[tid] = 0;
   state[tid] = kUndecided;
@@ -1560,8 +1594,7 @@ __global__ __launch_bounds__(1024) void nms_small_kernel(const float *__restrict
         swap_if(b_first, A.area, B.area);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { swap_if(b_first, A.rx[k], B.rx[k]); swap_if(b_first, A.ry[k], B.ry[k]); }
-        const float ov = quad_overlap(A, B, 0);
-        hit = (ga == gb) && (ov >= (b_first ? tb : ta));
+        hit = (ga == gb) && narrow_hit(A, B, b_first ? tb : ta, flags);
       }
       const uint64_t mk = __ballot(hit);
       if (mk) {
@@ -1682,6 +1715,7 @@ __global__ __launch_bounds__(1024) void nms_small_kernel(const float *__restrict
     hinfo->cand_total = found;
     hinfo->cand_worst = 0ull;
     hinfo->heavy_units = 0u; hinfo->light_units = 0u;
+    hinfo->route = 0u; hinfo->pad = 0u;
   }
 }
 
@@ -1740,9 +1774,9 @@ static int nms_layout(int64_t n, int64_t edge_capacity, NmsLayout &L) {
   L.cnt = take(nn * 4);
   L.ctr = take(sizeof(NmsCounters));
   L.ccnts = take((size_t)2 * kShards * kCandStride * sizeof(unsigned long long));  // candidates | edges
+  L.blockcnt = take(((nn + 1023) / 1024 + 1) * 4);   // ticket + one flagged count per 1024 boxes
   L.hist = take(kCells * 4);
   L.zero_end = off;
-  L.blockcnt = take(((nn + 1023) / 1024) * 4);
   // variable part, all 8-byte entries: [cands | edges | units]; candidates and edges
   // share one capacity, the unit list gets 1/8 of it (never more than unit_worst).
   // The split is re-derived from the actual workspace size at run time (nms_split).
@@ -1780,29 +1814,17 @@ extern "C" size_t obb_nms_workspace_bytes(int64_t n, int kind, int64_t edge_capa
   return L.total;
 }
 
-extern "C" int obb_nms_f32(const float *dets_dev, int64_t n, int kind, float iou_thr,
-                           int64_t *keep_dev, int64_t *info_host, void *workspace_dev,
-                           size_t workspace_bytes, void *stream) {
-  return obb_nms_grouped_f32(dets_dev, n, kind, iou_thr, nullptr, nullptr, keep_dev, info_host,
-                             workspace_dev, workspace_bytes, stream);
-}
+namespace obb {
 
-extern "C" int obb_nms_grouped_f32(const float *dets_dev, int64_t n, int kind, float iou_thr,
-                                   const int32_t *group_dev, const float *thr_dev,
-                                   int64_t *keep_dev, int64_t *info_host, void *workspace_dev,
-                                   size_t workspace_bytes, void *stream) {
-  using namespace obb;
-  if (info_host) { info_host[0] = 0; info_host[1] = 0; info_host[2] = 0; info_host[3] = 0; }
-  if (n < 0) return set_err(OBB_EINVAL, "obb_nms_f32: negative n");
-  if (kind != OBB_KIND_RBOX && kind != OBB_KIND_POLY && kind != OBB_KIND_HBB) return set_err(OBB_EINVAL, "obb_nms_f32: bad kind %d", kind);
-  if (n == 0) return OBB_OK;
-  if (n > (int64_t)kTile * 65535) return set_err(OBB_EINVAL, "obb_nms_f32: n = %lld exceeds %lld", (long long)n, (long long)kTile * 65535);
-  if (!dets_dev || !keep_dev || !workspace_dev) return set_err(OBB_EINVAL, "obb_nms_f32: null pointer");
-  if (reinterpret_cast<uintptr_t>(workspace_dev) & 255u) return set_err(OBB_EINVAL, "obb_nms_f32: workspace must be 256-byte aligned");
+// Host-side state of one enqueued call: what the capacity check needs afterwards.
+struct NmsEnqueued {
+  unsigned long long cap = 0, segcap = 0;
+  unsigned int ucap = 0;
+  bool timed = false, direct = false, fused = false;
+};
 
-  // pair capacity = whatever the caller's workspace holds beyond the fixed part,
-  // split evenly between the candidate lists and the edge list
-  NmsLayout L;
+// capacities the kernels were (or would be) launched with for a workspace of this size
+static int nms_capacities(int64_t n, size_t workspace_bytes, NmsLayout &L, NmsEnqueued &q) {
   int rc = nms_layout(n, 1, L);
   if (rc != OBB_OK) return rc;
   const size_t fixed = L.cands;
@@ -1810,8 +1832,97 @@ extern "C" int obb_nms_grouped_f32(const float *dets_dev, int64_t n, int kind, f
   if (workspace_bytes > fixed) nms_split((workspace_bytes - fixed) / sizeof(uint2), L.unit_worst, segcap, ucap64);
   if (segcap == 0 || ucap64 == 0)
     return set_err(OBB_EWORKSPACE, "obb_nms_f32: workspace %zu bytes < minimum %zu", workspace_bytes, L.total + 2 * kShards * sizeof(uint2));
-  const unsigned long long cap = segcap * kShards;
-  const unsigned int ucap = (unsigned int)ucap64;
+  q.segcap = segcap;
+  q.cap = segcap * kShards;
+  q.ucap = (unsigned int)ucap64;
+  return OBB_OK;
+}
+
+// The verdict on a finished call from the record its last kernel wrote.
+static int nms_verdict(const NmsHostInfo &h, const NmsEnqueued &q, int64_t *info_host) {
+  if (info_host) {
+    info_host[0] = h.kept;
+    info_host[1] = (int64_t)h.edges;
+    info_host[2] = h.rounds;
+    info_host[3] = (int64_t)h.cand_total;
+  }
+  if (h.route == 0u) {   // fused: the edge list may use the whole pair capacity
+    const unsigned long long ecap64 = 2ull * q.cap;
+    const unsigned long long ecap = ecap64 > 0xFFFFFFFFull ? 0xFFFFFFFFull : ecap64;
+    if (h.edges > ecap) {
+      const unsigned long long need = h.edges / 2 + h.edges / 8 + 1024;   // edges fit in 2 * capacity
+      if (info_host) { info_host[0] = 0; info_host[3] = (int64_t)need; }
+      return set_err(OBB_EWORKSPACE, "obb_nms_f32: %llu overlap edges exceed the pair capacity %llu; retry with edge_capacity >= %llu",
+                     h.edges, q.cap, need);
+    }
+    return OBB_OK;
+  }
+  if ((unsigned long long)h.heavy_units + h.light_units > q.ucap) {
+    // the unit list is 1/8 of the pair capacity: ask for a capacity that holds it
+    unsigned long long need = ((unsigned long long)h.heavy_units + h.light_units) * 8;
+    need += need / 4 + 1024;
+    if (need < q.cap * 2) need = q.cap * 2;
+    if (info_host) { info_host[0] = 0; info_host[3] = (int64_t)need; }
+    return set_err(OBB_EWORKSPACE, "obb_nms_f32: %u scan units exceed the unit capacity %u; retry with edge_capacity >= %llu",
+                   h.heavy_units + h.light_units, q.ucap, need);
+  }
+  if (h.cand_worst > q.segcap) {
+    // capacity that fits the fullest candidate / edge segment on a retry.  Which of the 64
+    // shards a wave feeds depends on its wave id, i.e. on scheduling: the fullest shard of the
+    // retry may differ from this run's, hence the 25 % slack AND the doubling floor -- a caller
+    // that loops on OBB_EWORKSPACE (aidet_amd/nms_wrapper.py does) always terminates, because
+    // n (n - 1) / 2 pairs per shard is a hard upper bound.
+    unsigned long long need = h.cand_worst * kShards;
+    need += need / 4 + 1024;
+    if (need < q.cap * 2) need = q.cap * 2;
+    if (info_host) { info_host[0] = 0; info_host[3] = (int64_t)need; }
+    return set_err(OBB_EWORKSPACE, "obb_nms_f32: %llu candidate pairs / %llu overlap edges exceed the pair capacity %llu; retry with edge_capacity >= %llu",
+                   h.cand_total, h.edges, q.cap, need);
+  }
+  return OBB_OK;
+}
+
+// argument checks shared by the synchronous and the asynchronous entry points (no HIP call:
+// they also run on a machine without a GPU)
+static int nms_validate(const char *who, const float *dets_dev, int64_t n, int kind, float iou_thr,
+                        const float *thr_dev, int flags_in, const int64_t *keep_dev,
+                        const void *workspace_dev) {
+  if (n < 0) return set_err(OBB_EINVAL, "%s: negative n", who);
+  if (kind != OBB_KIND_RBOX && kind != OBB_KIND_POLY && kind != OBB_KIND_HBB) return set_err(OBB_EINVAL, "%s: bad kind %d", who, kind);
+  if (flags_in & ~OBB_NMS_STRICT) return set_err(OBB_EINVAL, "%s: unknown flags 0x%x", who, flags_in);
+  // Horizontal boxes follow nms_cpu.cpp to the letter, and there a threshold <= 0 makes EVERY
+  // later box of a group a victim of the first one (ovr >= thr holds for disjoint boxes too).
+  // That is a different algorithm (arg-max per group), not an NMS: refused rather than served
+  // with different results.  (Rotated kinds: the spec's AABB prefilter is part of the
+  // operator, disjoint boxes never interact, any threshold is well defined.)
+  if (kind == OBB_KIND_HBB && !(flags_in & OBB_NMS_STRICT) && !thr_dev && !(iou_thr > 0.0f))
+    return set_err(OBB_EINVAL, "%s: iou_thr = %g with horizontal boxes and the `>=` rule would suppress every box but the best of each group (nms_cpu.cpp:56); use a positive threshold or OBB_NMS_STRICT", who, (double)iou_thr);
+  if (n == 0) return OBB_OK;   // nothing is read or written
+  if (n > (int64_t)kTile * 65535) return set_err(OBB_EINVAL, "%s: n = %lld exceeds %lld", who, (long long)n, (long long)kTile * 65535);
+  if (!dets_dev || !keep_dev || !workspace_dev) return set_err(OBB_EINVAL, "%s: null pointer", who);
+  if (reinterpret_cast<uintptr_t>(workspace_dev) & 255u) return set_err(OBB_EINVAL, "%s: workspace must be 256-byte aligned", who);
+  return OBB_OK;
+}
+
+// Validates, lays out the workspace and enqueues every kernel of one call on `stream`; the
+// last kernel writes the NmsHostInfo record to `result` (device-visible memory: the pinned
+// buffer of the synchronous entry points, or the caller's device record of the async one).
+static int nms_enqueue(const char *who, const float *dets_dev, int64_t n, int kind, float iou_thr,
+                       const int32_t *group_dev, const float *thr_dev, int flags_in,
+                       int64_t *keep_dev, NmsHostInfo *result, void *workspace_dev,
+                       size_t workspace_bytes, hipStream_t st, NmsEnqueued &q) {
+  int rc = nms_validate(who, dets_dev, n, kind, iou_thr, thr_dev, flags_in, keep_dev, workspace_dev);
+  if (rc != OBB_OK) return rc;
+  if (!result) return set_err(OBB_EINVAL, "%s: null result record", who);
+  const int flags = (flags_in & OBB_NMS_STRICT ? kFlagStrict : 0) | (kind == OBB_KIND_HBB ? kFlagHbb : 0);
+
+  // pair capacity = whatever the caller's workspace holds beyond the fixed part,
+  // split evenly between the candidate lists and the edge list
+  NmsLayout L;
+  rc = nms_capacities(n, workspace_bytes, L, q);
+  if (rc != OBB_OK) return rc;
+  const unsigned long long cap = q.cap, segcap = q.segcap;
+  const unsigned int ucap = q.ucap;
 
   char *ws = static_cast<char *>(workspace_dev);
   QuadRec *rec = reinterpret_cast<QuadRec *>(ws + L.rec);
@@ -1836,66 +1947,41 @@ extern "C" int obb_nms_grouped_f32(const float *dets_dev, int64_t n, int kind, f
   int *cnt = reinterpret_cast<int *>(ws + L.cnt);
   NmsCounters *ctr = reinterpret_cast<NmsCounters *>(ws + L.ctr);
   unsigned long long *ccnts = reinterpret_cast<unsigned long long *>(ws + L.ccnts);
-  int *blockcnt = reinterpret_cast<int *>(ws + L.blockcnt);
+  unsigned int *blockcnt = reinterpret_cast<unsigned int *>(ws + L.blockcnt);
   uint2 *cands = reinterpret_cast<uint2 *>(ws + L.cands);
   uint2 *edges = cands + cap;
   uint2 *units = edges + cap;
-  hipStream_t st = (hipStream_t)stream;
   const int nt = (int)L.ntiles;
 
   unsigned pblocks = (unsigned)((n + 255) / 256);
   if (pblocks > (unsigned)kPrepBlocks) pblocks = kPrepBlocks;
 
-  // result counters arrive in pinned host memory written by the last kernel
-  static thread_local NmsHostInfo *hinfo = nullptr;
-  if (!hinfo) {
-    void *p = nullptr;
-    OBB_HIP_TRY(hipHostMalloc(&p, 256, hipHostMallocPortable | hipHostMallocMapped));
-    hinfo = static_cast<NmsHostInfo *>(p);
-  }
-  NmsHostInfo *hinfo_dev = nullptr;
-  OBB_HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&hinfo_dev), hinfo, 0));
-
   NmsProfile &prof = g_prof;
   const bool timed = prof.on;
+  q.timed = timed;
   if (timed && !prof.created) {
     for (int k = 0; k <= kPhases; ++k) OBB_HIP_TRY(hipEventCreate(&prof.ev[k]));
     prof.created = true;
   }
 #define OBB_PHASE(k) do { if (timed && (prof.level >= 2 || (k) == 3 || (k) == 4)) OBB_HIP_TRY(hipEventRecord(prof.ev[k], st)); } while (0)
-  int64_t fused_max = kFusedDefault, direct_max = kDirectDefault;
-  if (const char *e = getenv("OBB_NMS_FUSED_MAX")) fused_max = atoll(e);     // tuning knobs
-  if (const char *e = getenv("OBB_NMS_DIRECT_MAX")) direct_max = atoll(e);
+  int64_t fused_max = tuning(OBB_TUNE_NMS_FUSED_MAX, kFusedDefault);
+  int64_t direct_max = tuning(OBB_TUNE_NMS_DIRECT_MAX, kDirectDefault);
   if (fused_max > kSmallMax) fused_max = kSmallMax;
   if (direct_max > kDirectMax) direct_max = kDirectMax;
-  const bool fused = n <= fused_max && !getenv("OBB_NMS_NO_FUSED");
+  const bool fused = n <= fused_max;
   const bool direct = !fused && n <= direct_max;
+  q.fused = fused; q.direct = direct;
   if (fused) {
     // fused single-launch path; the edge list may use the whole pair capacity
     const unsigned long long ecap64 = 2ull * cap;
     const unsigned int ecap = ecap64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned int)ecap64;
     if (kind == OBB_KIND_RBOX)
-      hipLaunchKernelGGL(nms_small_kernel<0>, dim3(1), dim3(1024), 0, st, dets_dev, (int)n, iou_thr, group_dev, thr_dev, rec, cands, ecap, keep_dev, hinfo_dev);
+      hipLaunchKernelGGL(nms_small_kernel<0>, dim3(1), dim3(1024), 0, st, dets_dev, (int)n, iou_thr, flags, group_dev, thr_dev, rec, cands, ecap, keep_dev, result);
     else if (kind == OBB_KIND_POLY)
-      hipLaunchKernelGGL(nms_small_kernel<1>, dim3(1), dim3(1024), 0, st, dets_dev, (int)n, iou_thr, group_dev, thr_dev, rec, cands, ecap, keep_dev, hinfo_dev);
+      hipLaunchKernelGGL(nms_small_kernel<1>, dim3(1), dim3(1024), 0, st, dets_dev, (int)n, iou_thr, flags, group_dev, thr_dev, rec, cands, ecap, keep_dev, result);
     else
-      hipLaunchKernelGGL(nms_small_kernel<2>, dim3(1), dim3(1024), 0, st, dets_dev, (int)n, iou_thr, group_dev, thr_dev, rec, cands, ecap, keep_dev, hinfo_dev);
+      hipLaunchKernelGGL(nms_small_kernel<2>, dim3(1), dim3(1024), 0, st, dets_dev, (int)n, iou_thr, flags, group_dev, thr_dev, rec, cands, ecap, keep_dev, result);
     OBB_LAUNCH_CHECK();
-    OBB_HIP_TRY(hipStreamSynchronize(st));
-    const NmsHostInfo hs = *hinfo;
-    if (timed) { for (int k = 0; k < kPhases; ++k) prof.ms[k] = 0.0f; prof.have = true; }
-    if (info_host) {
-      info_host[0] = hs.kept;
-      info_host[1] = (int64_t)hs.edges;
-      info_host[2] = hs.rounds;
-      info_host[3] = (int64_t)hs.cand_total;
-    }
-    if (hs.edges > ecap) {
-      const unsigned long long need = hs.edges / 2 + hs.edges / 8 + 1024;   // edges fit in 2 * capacity
-      if (info_host) { info_host[0] = 0; info_host[3] = (int64_t)need; }
-      return set_err(OBB_EWORKSPACE, "obb_nms_f32: %llu overlap edges exceed the pair capacity %llu; retry with edge_capacity >= %llu",
-                     hs.edges, cap, need);
-    }
     return OBB_OK;
   }
   // threshold-aware pruning: the call's threshold, or per pair the smaller of the two boxes'
@@ -1922,11 +2008,11 @@ extern "C" int obb_nms_grouped_f32(const float *dets_dev, int64_t n, int kind, f
     while (rpw > 4 && ((n + rpw - 1) / rpw) * (long long)(nt + 1) / 2 < 2048) rpw >>= 1;
     const unsigned nparts = (unsigned)((n + rpw - 1) / rpw);
     hipLaunchKernelGGL(nms_scan_direct_kernel, dim3((nparts + kNmsWaves - 1) / kNmsWaves, (unsigned)nt), dim3(64 * kNmsWaves), 0, st,
-                       iv, ar, rec, (uint32_t)n, rpw, prune_thr, thr_dev ? 1 : 0, edges, segcap, ccnts, cnt);
+                       iv, ar, rec, (uint32_t)n, rpw, prune_thr, thr_dev ? 1 : 0, flags, edges, segcap, ccnts, cnt);
     OBB_LAUNCH_CHECK();
     OBB_PHASE(4);
     OBB_PHASE(5);
-    hipLaunchKernelGGL(nms_resolve_kernel<true>, dim3(kShards), dim3(kResolveThreadsCompact), 0, st, edges, segcap, cnt, ctr, ccnts, n, keep_dev, hinfo_dev);
+    hipLaunchKernelGGL(nms_resolve_kernel<true>, dim3(kShards), dim3(kResolveThreadsCompact), 0, st, edges, segcap, cnt, ctr, ccnts, n, keep_dev, result);
     OBB_LAUNCH_CHECK();
     OBB_PHASE(6);
     OBB_PHASE(7);
@@ -1954,69 +2040,122 @@ extern "C" int obb_nms_grouped_f32(const float *dets_dev, int64_t n, int kind, f
     OBB_PHASE(3);
     {
       const long long maxblocks = ((long long)L.unit_worst + kNmsWaves - 1) / kNmsWaves;
-      long long pb = kScanBlocks;
-      if (const char *e = getenv("OBB_NMS_SCAN_BLOCKS")) pb = atoll(e) > 0 ? atoll(e) : pb;  // tuning knob
+      const long long pb = tuning(OBB_TUNE_NMS_SCAN_BLOCKS, kScanBlocks);
       const unsigned gb = (unsigned)(maxblocks < pb ? maxblocks : pb);
       hipLaunchKernelGGL(nms_scan_kernel, dim3(gb), dim3(64 * kNmsWaves), 0, st, qs, pf, pg, pt, cellpx, prune_thr, tbox, nt, units, ucap, cands, segcap, ctr, ccnts);
       OBB_LAUNCH_CHECK();
     }
     // phase 4: clip (narrow phase)
     OBB_PHASE(4);
-    hipLaunchKernelGGL(nms_clip_kernel, dim3(kClipBlocksPerShard, kShards), dim3(256), 0, st, cands, segcap, rec, edges, ctr, ccnts, cnt);
+    hipLaunchKernelGGL(nms_clip_kernel, dim3(kClipBlocksPerShard, kShards), dim3(256), 0, st, cands, segcap, rec, flags, edges, ctr, ccnts, cnt);
     OBB_LAUNCH_CHECK();
     // phase 5: resolve
     OBB_PHASE(5);
-    hipLaunchKernelGGL(nms_resolve_kernel<false>, dim3(kShards), dim3(kResolveThreads), 0, st, edges, segcap, cnt, ctr, ccnts, n, keep_dev, hinfo_dev);
+    hipLaunchKernelGGL(nms_resolve_kernel<false>, dim3(kShards), dim3(kResolveThreads), 0, st, edges, segcap, cnt, ctr, ccnts, n, keep_dev, result);
     OBB_LAUNCH_CHECK();
-    // phase 6: compaction
+    // phase 6: compaction (one pass: every block publishes its count and sums its predecessors')
     OBB_PHASE(6);
     const unsigned cblocks = (unsigned)((n + 1023) / 1024);
-    hipLaunchKernelGGL(nms_count_kernel, dim3(cblocks), dim3(1024), 0, st, cnt, n, blockcnt);
-    OBB_LAUNCH_CHECK();
-    hipLaunchKernelGGL(nms_write_kernel, dim3(cblocks), dim3(1024), 0, st, cnt, n, blockcnt, keep_dev, ctr, ccnts, hinfo_dev);
+    hipLaunchKernelGGL(nms_compact_kernel, dim3(cblocks), dim3(1024), 0, st, cnt, n, blockcnt, keep_dev, ctr, ccnts, result);
     OBB_LAUNCH_CHECK();
     OBB_PHASE(7);
   }
 #undef OBB_PHASE
+  return OBB_OK;
+}
+
+// one pinned, device-mapped result record per calling thread (synchronous entry points)
+static int nms_pinned_record(NmsHostInfo *&host, NmsHostInfo *&dev) {
+  static thread_local NmsHostInfo *hinfo = nullptr;
+  if (!hinfo) {
+    void *p = nullptr;
+    OBB_HIP_TRY(hipHostMalloc(&p, 256, hipHostMallocPortable | hipHostMallocMapped));
+    hinfo = static_cast<NmsHostInfo *>(p);
+  }
+  host = hinfo;
+  OBB_HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&dev), hinfo, 0));
+  return OBB_OK;
+}
+
+}  // namespace obb
+
+extern "C" int obb_nms_f32(const float *dets_dev, int64_t n, int kind, float iou_thr,
+                           int64_t *keep_dev, int64_t *info_host, void *workspace_dev,
+                           size_t workspace_bytes, void *stream) {
+  return obb_nms_ex_f32(dets_dev, n, kind, iou_thr, nullptr, nullptr, 0, keep_dev, info_host,
+                        workspace_dev, workspace_bytes, stream);
+}
+
+extern "C" int obb_nms_grouped_f32(const float *dets_dev, int64_t n, int kind, float iou_thr,
+                                   const int32_t *group_dev, const float *thr_dev,
+                                   int64_t *keep_dev, int64_t *info_host, void *workspace_dev,
+                                   size_t workspace_bytes, void *stream) {
+  return obb_nms_ex_f32(dets_dev, n, kind, iou_thr, group_dev, thr_dev, 0, keep_dev, info_host,
+                        workspace_dev, workspace_bytes, stream);
+}
+
+extern "C" int obb_nms_ex_f32(const float *dets_dev, int64_t n, int kind, float iou_thr,
+                              const int32_t *group_dev, const float *thr_dev, int flags,
+                              int64_t *keep_dev, int64_t *info_host, void *workspace_dev,
+                              size_t workspace_bytes, void *stream) {
+  using namespace obb;
+  if (info_host) { info_host[0] = 0; info_host[1] = 0; info_host[2] = 0; info_host[3] = 0; }
+  int rc = nms_validate("obb_nms_f32", dets_dev, n, kind, iou_thr, thr_dev, flags, keep_dev, workspace_dev);
+  if (rc != OBB_OK) return rc;
+  if (n == 0) return OBB_OK;
+  NmsHostInfo *hinfo = nullptr, *hinfo_dev = nullptr;
+  rc = nms_pinned_record(hinfo, hinfo_dev);
+  if (rc != OBB_OK) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  NmsEnqueued q;
+  rc = nms_enqueue("obb_nms_f32", dets_dev, n, kind, iou_thr, group_dev, thr_dev, flags, keep_dev, hinfo_dev,
+                   workspace_dev, workspace_bytes, st, q);
+  if (rc != OBB_OK) return rc;
   OBB_HIP_TRY(hipStreamSynchronize(st));
   const NmsHostInfo h = *hinfo;
-  if (timed) {
+  NmsProfile &prof = g_prof;
+  if (q.timed) {
     for (int k = 0; k < kPhases; ++k) {
       prof.ms[k] = 0.0f;
-      if (prof.level >= 2 || k == 3) OBB_HIP_TRY(hipEventElapsedTime(&prof.ms[k], prof.ev[k], prof.ev[k + 1]));
+      if (!q.fused && (prof.level >= 2 || k == 3)) OBB_HIP_TRY(hipEventElapsedTime(&prof.ms[k], prof.ev[k], prof.ev[k + 1]));
     }
     prof.have = true;
   }
   static_assert(kShards == 64, "the counter folds use one wave");
-  if (getenv("OBB_NMS_DEBUG"))
-    fprintf(stderr, "obb_nms: n=%lld tiles=%d path=%s heavy_units=%u light_units=%u (capacity %u) candidates=%llu edges=%llu\n",
-            (long long)n, nt, direct ? "direct" : "sorted", h.heavy_units, h.light_units, ucap, h.cand_total, h.edges);
-  const unsigned long long ncand = h.cand_total, worst = h.cand_worst;
-  if (info_host) {
-    info_host[0] = h.kept;
-    info_host[1] = (int64_t)h.edges;
-    info_host[2] = h.rounds;
-    info_host[3] = (int64_t)ncand;
+  return nms_verdict(h, q, info_host);
+}
+
+extern "C" int obb_nms_async_f32(const float *dets_dev, int64_t n, int kind, float iou_thr,
+                                 const int32_t *group_dev, const float *thr_dev, int flags,
+                                 int64_t *keep_dev, void *result_dev, void *workspace_dev,
+                                 size_t workspace_bytes, void *stream) {
+  using namespace obb;
+  if (!result_dev) return set_err(OBB_EINVAL, "obb_nms_async_f32: null result record");
+  hipStream_t st = (hipStream_t)stream;
+  int rc = nms_validate("obb_nms_async_f32", dets_dev, n, kind, iou_thr, thr_dev, flags, keep_dev, workspace_dev);
+  if (rc != OBB_OK) return rc;
+  if (n == 0) {   // an all-zero record: K = 0, route "fused" (its check passes for 0 edges)
+    OBB_HIP_TRY(hipMemsetAsync(result_dev, 0, OBB_NMS_RESULT_BYTES, st));
+    return OBB_OK;
   }
-  if ((unsigned long long)h.heavy_units + h.light_units > ucap) {
-    // the unit list is 1/8 of the pair capacity: ask for a capacity that holds it
-    unsigned long long need = ((unsigned long long)h.heavy_units + h.light_units) * 8;
-    need += need / 4 + 1024;
-    if (need < cap * 2) need = cap * 2;
-    if (info_host) { info_host[0] = 0; info_host[3] = (int64_t)need; }
-    return set_err(OBB_EWORKSPACE, "obb_nms_f32: %u scan units exceed the unit capacity %u; retry with edge_capacity >= %llu",
-                   h.heavy_units + h.light_units, ucap, need);
-  }
-  if (worst > segcap) {
-    // capacity that fits the fullest candidate / edge segment on a retry, with 25 %
-    // slack: the unit -> shard assignment varies slightly from run to run
-    unsigned long long need = worst * kShards;
-    need += need / 4 + 1024;
-    if (info_host) { info_host[0] = 0; info_host[3] = (int64_t)need; }
-    return set_err(OBB_EWORKSPACE, "obb_nms_f32: %llu candidate pairs / %llu overlap edges exceed the pair capacity %llu; retry with edge_capacity >= %llu",
-                   ncand, h.edges, cap, need);
-  }
-  return OBB_OK;
+  NmsEnqueued q;
+  return nms_enqueue("obb_nms_async_f32", dets_dev, n, kind, iou_thr, group_dev, thr_dev, flags, keep_dev,
+                     static_cast<NmsHostInfo *>(result_dev), workspace_dev, workspace_bytes, st, q);
+}
+
+extern "C" int obb_nms_async_result(const void *result_host, int64_t n, size_t workspace_bytes,
+                                    int64_t *info_host) {
+  using namespace obb;
+  if (!result_host || !info_host) return set_err(OBB_EINVAL, "obb_nms_async_result: null pointer");
+  info_host[0] = info_host[1] = info_host[2] = info_host[3] = 0;
+  if (n == 0) return OBB_OK;
+  NmsHostInfo h;
+  memcpy(&h, result_host, sizeof(h));
+  NmsLayout L;
+  NmsEnqueued q;
+  int rc = nms_capacities(n, workspace_bytes, L, q);
+  if (rc != OBB_OK) return rc;
+  return nms_verdict(h, q, info_host);
 }
 
 extern "C" int obb_nms_profile_enable(int on) {

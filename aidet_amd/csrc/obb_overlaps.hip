@@ -315,7 +315,7 @@ extern "C" int obb_overlaps_f32(const float *a_dev, int64_t m, const float *b_de
     rows = r;
     if (col_tiles * ((m + r - 1) / r) >= 512) break;
   }
-  if (const char *e = getenv("OBB_OV_ROWS")) { const int r = atoi(e); if (r >= 8 && r <= kMaxRows) rows = r; }   // tuning knob
+  { const int64_t r = tuning(OBB_TUNE_OVERLAPS_ROWS, rows); if (r >= 8 && r <= kMaxRows) rows = (int)r; }
   const int64_t row_tiles2 = (m + rows - 1) / rows;
   if (row_tiles2 > 65535 || col_tiles > 2147483647LL)
     return set_err(OBB_EINVAL, "obb_overlaps_f32: problem too large for one launch (m=%lld n=%lld)", (long long)m, (long long)n);

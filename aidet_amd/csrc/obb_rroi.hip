@@ -567,7 +567,7 @@ static int rroi_forward_launch(const char *who, const float *feat_dev, int B, in
   // multiple of 8 = one chunk per XCD and round (see the kernel)
   const int groups = (C + kChanPerThread - 1) / kChanPerThread;
   int gpb = (groups % 32 == 0) ? 4 : ((groups % 16 == 0) ? 2 : 3);
-  if (const char *e = getenv("OBB_RROI_GPB")) gpb = atoi(e) > 0 ? atoi(e) : gpb;  // tuning knob
+  { const int64_t g = tuning(OBB_TUNE_RROI_GROUPS, gpb); if (g > 0 && g <= 64) gpb = (int)g; }
   const unsigned chunks = (unsigned)((groups + gpb - 1) / gpb);
   if (chunks > 65535u) return set_err(OBB_EINVAL, "%s: too many channels (%d)", who, C);
   // 16-byte LDS-DMA needs 16-byte aligned rows: W % 4 == 0 and an aligned base
@@ -594,7 +594,8 @@ static int rroi_backward_launch(const char *who, const float *grad_out_dev, int 
   if (!grad_out_dev || !rois_dev || !grad_feat_dev) return set_err(OBB_EINVAL, "%s: null pointer", who);
   // same block geometry as the forward kernel (32 channels per block when C allows)
   const int groups = (C + kChanPerThread - 1) / kChanPerThread;
-  const int gpb = (groups % 32 == 0) ? 4 : ((groups % 16 == 0) ? 2 : 3);
+  int gpb = (groups % 32 == 0) ? 4 : ((groups % 16 == 0) ? 2 : 3);
+  { const int64_t g = tuning(OBB_TUNE_RROI_GROUPS, gpb); if (g > 0 && g <= 64) gpb = (int)g; }
   const unsigned chunks = (unsigned)((groups + gpb - 1) / gpb);
   if (chunks > 65535u) return set_err(OBB_EINVAL, "%s: too many channels (%d)", who, C);
   const unsigned long long nblk = (unsigned long long)((chunks + 7u) / 8u) * 8ull * (unsigned long long)K;

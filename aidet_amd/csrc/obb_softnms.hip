@@ -1,0 +1,227 @@
+// obb_softnms.hip -- Soft-NMS on the GPU for gfx950.
+//
+// Replaces soft_nms_cpu_kernel (mmdet/ops/nms/src/nms_cpu.cpp:71-210), which the reference
+// only offers on the CPU (nms_wrapper.py:64 "Dispatch to only CPU Soft NMS implementations").
+//
+// Soft-NMS is a chain of n DEPENDENT rounds: pick the best remaining box, decay the scores
+// of the others by their overlap with it, drop what falls below min_score.  The reference
+// keeps the boxes in one array it permutes in place, and that permutation is observable:
+//   * the arg-max uses a STRICT `<` (:114-121), so among equal scores the box at the LOWEST
+//     POSITION of the current array wins -- positions, not original indices;
+//   * the pick is swapped with position i (:123-140);
+//   * a dropped box is overwritten by the LAST box of the array, which is then examined at
+//     that position (:184-198: pos is decremented and incremented again).
+// One workgroup replays exactly that array:
+//   round i:  (1) block-wide arg-max over positions [i, nd)  -> swap with i
+//             (2) every position p > i: overlap with box i in the reference's own
+//                 arithmetic (nms_cpu.cpp:155-163 = hbb_overlap), decay, drop flag
+//             (3) the drops are compacted the way the sequential loop would have done it:
+//                 with M survivors the new end is nd' = i + 1 + M; the holes (dropped
+//                 positions below nd', ascending) are filled by the survivors at or above
+//                 nd' taken from the END downwards -- the k-th hole receives the k-th
+//                 survivor counted from the end.  (Sequentially: the loop reaches the holes
+//                 in ascending order and each time pulls the current last element; a pulled
+//                 element that is itself dropped is pulled over again, i.e. skipped.)
+// State (7 words per box) lives in LDS up to 2048 boxes and in the caller's workspace
+// above that; ~8 block barriers per round.
+#include "obb_common.h"
+#include "obb_geom.cuh"
+
+namespace obb {
+
+constexpr int kSoftThreads = 1024;
+constexpr int kSoftLds = 2048;   // boxes whose state fits the LDS arrays below (56 KiB)
+
+struct SoftState {
+  float *x1, *y1, *x2, *y2, *sc, *ar;
+  int *id;
+};
+
+struct Best { float s; int p; };
+
+// candidate b replaces a: higher score, or the same score at a lower position.  A NaN score
+// never wins (nms_cpu.cpp:116 `max_score < scores[pos]` is false for it).
+__device__ __forceinline__ Best better(Best a, Best b) {
+  const bool take = (a.s < b.s) || (a.s == b.s && b.p < a.p);
+  return take ? b : a;
+}
+
+template <bool LDS>
+__global__ __launch_bounds__(kSoftThreads) void soft_nms_kernel(const float *__restrict__ dets, int n,
+                                                                float thr, int method, float sigma,
+                                                                float min_score, float *__restrict__ ws,
+                                                                float *__restrict__ out_dets,
+                                                                int64_t *__restrict__ out_inds,
+                                                                long long *__restrict__ result) {
+  __shared__ float lds[LDS ? 7 * kSoftLds : 7];
+  __shared__ Best wbest[16];
+  __shared__ int wcnt[16];
+  __shared__ int holes[LDS ? kSoftLds : 1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cap = LDS ? kSoftLds : n;
+  float *base = LDS ? lds : ws;
+  SoftState S;
+  S.x1 = base; S.y1 = base + cap; S.x2 = base + 2 * cap; S.y2 = base + 3 * cap;
+  S.sc = base + 4 * cap; S.ar = base + 5 * cap; S.id = reinterpret_cast<int *>(base + 6 * cap);
+  int *hole = LDS ? holes : reinterpret_cast<int *>(ws + 7 * (size_t)n);
+  for (int p = tid; p < n; p += kSoftThreads) {
+    const float *d = dets + (size_t)p * 5;
+    const float a = d[0], b = d[1], c = d[2], e = d[3];
+    S.x1[p] = a; S.y1[p] = b; S.x2[p] = c; S.y2[p] = e; S.sc[p] = d[4];
+    S.ar[p] = hbb_area(a, b, c, e);
+    S.id[p] = p;
+  }
+  __syncthreads();
+  int nd = n;
+  for (int i = 0; i < nd; ++i) {
+    // ---- (1) arg-max over [i, nd), first of equal scores
+    Best b{-__builtin_huge_valf(), 0x7fffffff};
+    for (int p = i + tid; p < nd; p += kSoftThreads) b = better(b, Best{S.sc[p], p});
+    for (int o = 32; o > 0; o >>= 1) {
+      Best t{__shfl_xor(b.s, o), __shfl_xor(b.p, o)};
+      b = better(b, t);
+    }
+    if (lane == 0) wbest[wave] = b;
+    __syncthreads();
+    Best g = wbest[0];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) g = better(g, wbest[k]);
+    // scores[i] is the starting value of the reference's scan: a NaN there stays the maximum,
+    // and when nothing compares greater (all -inf / NaN) position i is the pick as well
+    const float si = S.sc[i];
+    int mp = (si != si || g.p == 0x7fffffff) ? i : g.p;
+    __syncthreads();   // every thread has read wbest / sc[i]
+    if (tid < 7 && mp != i) {   // swap the 7 words of positions i and mp (bit patterns: one is an index)
+      uint32_t *arr = reinterpret_cast<uint32_t *>(base) + (size_t)tid * cap;
+      const uint32_t t = arr[i];
+      arr[i] = arr[mp];
+      arr[mp] = t;
+    }
+    __syncthreads();
+    // ---- (2) decay + drop flags; (3) compaction
+    const float a4[4] = {S.x1[i], S.y1[i], S.x2[i], S.y2[i]};
+    const float iarea = S.ar[i];
+    const int first = i + 1, count = nd - first;
+    int drops_before = 0;     // running count of dropped positions in earlier chunks
+    bool any = false;
+    // pass A: new scores (the drop flag of a position is re-derived from its stored score below)
+    for (int c0 = 0; c0 < count; c0 += kSoftThreads) {
+      const int p = first + c0 + tid;
+      bool drop = false;
+      if (p < nd) {
+        const float b4[4] = {S.x1[p], S.y1[p], S.x2[p], S.y2[p]};
+        const float ovr = hbb_overlap(a4, iarea, b4, S.ar[p]);
+        float weight = 1.0f;
+        if (method == 1) { if (ovr > thr) weight = 1.0f - ovr; }
+        else if (method == 2) weight = expf(-(ovr * ovr) / sigma);
+        else weight = (ovr > thr) ? 0.0f : 1.0f;
+        const float s = weight * S.sc[p];
+        S.sc[p] = s;
+        drop = s < min_score;
+      }
+      any = any || drop;
+    }
+    if (!__syncthreads_or(any ? 1 : 0)) continue;   // block-uniform: nothing dropped this round
+    // total drops -> M, nd'
+    int mydrops = 0;
+    for (int c0 = 0; c0 < count; c0 += kSoftThreads) {
+      const int p = first + c0 + tid;
+      mydrops += (p < nd && S.sc[p] < min_score) ? 1 : 0;
+    }
+    for (int o = 32; o > 0; o >>= 1) mydrops += __shfl_xor(mydrops, o);
+    if (lane == 0) wcnt[wave] = mydrops;
+    __syncthreads();
+    int D = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) D += wcnt[k];
+    const int M = count - D, nd2 = first + M;
+    __syncthreads();   // wcnt is reused below
+    // holes: dropped positions below nd2, ranked ascending
+    drops_before = 0;
+    for (int c0 = 0; c0 < count; c0 += kSoftThreads) {
+      const int p = first + c0 + tid;
+      const bool drop = p < nd && S.sc[p] < min_score;
+      const uint64_t mk = __ballot(drop);
+      if (lane == 0) wcnt[wave] = __popcll(mk);
+      __syncthreads();
+      int off = 0, tot = 0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) { const int v = wcnt[k]; off += (k < wave) ? v : 0; tot += v; }
+      const int dpre = drops_before + off + __popcll(mk & ((1ull << lane) - 1ull));   // drops in (i, p)
+      if (drop && p < nd2) hole[dpre] = p;
+      drops_before += tot;
+      __syncthreads();
+    }
+    // fillers: survivors at or above nd2; rank from the end = M - (survivors in (i, p])
+    drops_before = 0;
+    for (int c0 = 0; c0 < count; c0 += kSoftThreads) {
+      const int p = first + c0 + tid;
+      const bool drop = p < nd && S.sc[p] < min_score;
+      const uint64_t mk = __ballot(drop);
+      if (lane == 0) wcnt[wave] = __popcll(mk);
+      __syncthreads();
+      int off = 0, tot = 0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) { const int v = wcnt[k]; off += (k < wave) ? v : 0; tot += v; }
+      const int dpre = drops_before + off + __popcll(mk & ((1ull << lane) - 1ull));
+      if (p < nd && !drop && p >= nd2) {
+        const int kept_incl = (p - i) - dpre;          // survivors in (i, p], p itself included
+        const int r = M - kept_incl;                   // survivors above p = rank from the end
+        const int dst = hole[r];
+        S.x1[dst] = S.x1[p]; S.y1[dst] = S.y1[p]; S.x2[dst] = S.x2[p]; S.y2[dst] = S.y2[p];
+        S.sc[dst] = S.sc[p]; S.ar[dst] = S.ar[p]; S.id[dst] = S.id[p];
+      }
+      drops_before += tot;
+      __syncthreads();
+    }
+    nd = nd2;
+  }
+  for (int p = tid; p < nd; p += kSoftThreads) {
+    float *o = out_dets + (size_t)p * 5;
+    o[0] = S.x1[p]; o[1] = S.y1[p]; o[2] = S.x2[p]; o[3] = S.y2[p]; o[4] = S.sc[p];
+    out_inds[p] = S.id[p];
+  }
+  if (tid == 0) result[0] = nd;
+}
+
+}  // namespace obb
+
+extern "C" size_t obb_soft_nms_workspace_bytes(int64_t n) {
+  if (n <= obb::kSoftLds) return 256;
+  return obb::align_up((size_t)n * 8 * sizeof(float), 256);
+}
+
+extern "C" int obb_soft_nms_f32(const float *dets_dev, int64_t n, float iou_thr, int method, float sigma,
+                                float min_score, float *out_dets_dev, int64_t *out_inds_dev,
+                                int64_t *count_host, void *workspace_dev, size_t workspace_bytes,
+                                void *stream) {
+  using namespace obb;
+  if (count_host) *count_host = 0;
+  if (n < 0) return set_err(OBB_EINVAL, "obb_soft_nms_f32: negative n");
+  if (method < 0 || method > 2) return set_err(OBB_EINVAL, "obb_soft_nms_f32: bad method %d (0 hard, 1 linear, 2 gaussian)", method);
+  if (n == 0) return OBB_OK;
+  if (n > (1 << 22)) return set_err(OBB_EINVAL, "obb_soft_nms_f32: n = %lld exceeds %d", (long long)n, 1 << 22);
+  if (!dets_dev || !out_dets_dev || !out_inds_dev || !count_host || !workspace_dev)
+    return set_err(OBB_EINVAL, "obb_soft_nms_f32: null pointer");
+  if (workspace_bytes < obb_soft_nms_workspace_bytes(n))
+    return set_err(OBB_EWORKSPACE, "obb_soft_nms_f32: workspace %zu bytes < %zu", workspace_bytes, obb_soft_nms_workspace_bytes(n));
+  // K comes back through one pinned, device-mapped word per calling thread
+  static thread_local long long *pinned = nullptr;
+  if (!pinned) {
+    void *p = nullptr;
+    OBB_HIP_TRY(hipHostMalloc(&p, 64, hipHostMallocPortable | hipHostMallocMapped));
+    pinned = static_cast<long long *>(p);
+  }
+  long long *pinned_dev = nullptr;
+  OBB_HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&pinned_dev), pinned, 0));
+  hipStream_t st = (hipStream_t)stream;
+  float *ws = static_cast<float *>(workspace_dev);
+  if (n <= kSoftLds)
+    hipLaunchKernelGGL(soft_nms_kernel<true>, dim3(1), dim3(kSoftThreads), 0, st, dets_dev, (int)n, iou_thr, method, sigma, min_score, ws, out_dets_dev, out_inds_dev, pinned_dev);
+  else
+    hipLaunchKernelGGL(soft_nms_kernel<false>, dim3(1), dim3(kSoftThreads), 0, st, dets_dev, (int)n, iou_thr, method, sigma, min_score, ws, out_dets_dev, out_inds_dev, pinned_dev);
+  OBB_LAUNCH_CHECK();
+  OBB_HIP_TRY(hipStreamSynchronize(st));
+  *count_host = *pinned;
+  return OBB_OK;
+}

@@ -1,15 +1,20 @@
-"""Rotated / polygon NMS with the calling conventions of the reference's
-``mmdet/ops/nms/nms_wrapper.py`` (``nms`` at :7-60), so that
+"""NMS operators with the calling conventions of the reference's
+``mmdet/ops/nms/nms_wrapper.py`` (``nms`` :7-60, ``soft_nms`` :63-118), so that
 ``getattr(nms_wrapper, nms_cfg['type'])(cls_dets, **cfg)`` -- the selection the
 reference does in mmdet/core/post_processing/bbox_nms.py:60-64 and
-rbbox_nms.py:25-27 -- works with ``type='rnms'`` / ``'poly_nms'`` /
-``'thetaobb_nms'`` (the name the reference's disabled call expects,
+rbbox_nms.py:25-27 -- works with ``type='nms'`` / ``'soft_nms'`` / ``'rnms'`` /
+``'poly_nms'`` / ``'thetaobb_nms'`` (the name the reference's disabled call expects,
 rbbox_nms.py:97).
 
-All compute is the HIP path ``obb_nms_f32`` (include/obbops.h); there is no CPU
+All compute is the HIP library behind include/obbops.h; there is no CPU
 implementation.  CPU tensors / numpy arrays are moved to the GPU and the result
 is returned in the caller's container type and device, as the reference does
 for ``device_id`` (nms_wrapper.py:41-43).
+
+Threshold rule.  Every op suppresses on ``overlap >= iou_thr``, the rule of the CPU
+reference (nms_cpu.cpp:56) that BASELINE.json names as the oracle.  The reference's own
+CUDA kernel uses ``>`` (nms_kernel.cu:61); pass ``strict=True`` to get that comparison
+(the two only differ for pairs whose IoU equals the threshold exactly).
 """
 import ctypes
 import threading
@@ -20,11 +25,15 @@ import torch
 from . import _lib
 
 
-# Workspace cache: the call is synchronous on its stream (it returns the keep count),
+# Workspace cache: a call is synchronous on its stream (it returns the keep count),
 # so one buffer per (thread, device, stream) can be reused by the next call there.
 # (ctypes releases the GIL during the call, hence per thread.)
 _tls = threading.local()
 _ws_bytes = {}
+
+# upper bound on the workspace a retry may ask for (a dense scene needs 16 B per
+# overlapping pair; the library reports the pair capacity that suffices)
+MAX_WORKSPACE_BYTES = 64 << 30
 
 
 def _workspace(L, dev, stream, n, kind, capacity):
@@ -38,6 +47,11 @@ def _workspace(L, dev, stream, n, kind, capacity):
         if len(_ws_bytes) > 4096:
             _ws_bytes.clear()
         _ws_bytes[key] = nbytes
+    if nbytes > MAX_WORKSPACE_BYTES:
+        raise _lib.ObbOpsError(
+            'NMS on %d boxes needs a %.1f GiB pair workspace (capacity %d pairs): more than '
+            'nms_wrapper.MAX_WORKSPACE_BYTES; the scene is almost all mutual overlaps' %
+            (n, nbytes / 2.0 ** 30, capacity))
     cache = getattr(_tls, 'ws', None)
     if cache is None:
         cache = _tls.ws = {}
@@ -49,8 +63,38 @@ def _workspace(L, dev, stream, n, kind, capacity):
     return ws, nbytes
 
 
-def _run_nms(dets_dev, kind, iou_thr, groups=None, thrs=None):
-    """dets_dev: contiguous fp32 HIP tensor (n, 6|9). Returns int64 keep (K,).
+def _side_inputs(dev, n, groups, thrs):
+    gptr = tptr = None
+    if groups is not None:
+        groups = groups.detach().to(device=dev, dtype=torch.int32).contiguous()
+        assert groups.numel() == n
+        gptr = groups.data_ptr()
+    if thrs is not None:
+        thrs = thrs.detach().to(device=dev, dtype=torch.float32).contiguous()
+        assert thrs.numel() == n
+        tptr = thrs.data_ptr()
+    return groups, gptr, thrs, tptr
+
+
+class _OnDevice(object):
+    """`with _OnDevice(dev):` -- torch's current device = dev (kernels launch there)."""
+
+    def __init__(self, dev):
+        self.dev, self.prev = dev, None
+
+    def __enter__(self):
+        cur = torch.cuda.current_device()
+        if cur != self.dev.index:
+            self.prev = cur
+            torch.cuda.set_device(self.dev)
+
+    def __exit__(self, *exc):
+        if self.prev is not None:
+            torch.cuda.set_device(self.prev)
+
+
+def _run_nms(dets_dev, kind, iou_thr, groups=None, thrs=None, strict=False):
+    """dets_dev: contiguous fp32 HIP tensor (n, 5|6|9). Returns int64 keep (K,).
 
     groups: optional int tensor (n,) -- only boxes of equal group interact.
     thrs: optional float tensor (n,) -- per-box threshold (the earlier box's applies).
@@ -62,32 +106,20 @@ def _run_nms(dets_dev, kind, iou_thr, groups=None, thrs=None):
     info = getattr(_tls, 'info', None)      # (argtypes convert plain ints: no c_void_p objects per call)
     if info is None:
         info = _tls.info = (ctypes.c_int64 * 4)()
-    gptr = tptr = None
-    if groups is not None:
-        groups = groups.detach().to(device=dev, dtype=torch.int32).contiguous()
-        assert groups.numel() == n
-        gptr = groups.data_ptr()
-    if thrs is not None:
-        thrs = thrs.detach().to(device=dev, dtype=torch.float32).contiguous()
-        assert thrs.numel() == n
-        tptr = thrs.data_ptr()
-    cur = torch.cuda.current_device()
-    same_dev = cur == dev.index
-    if not same_dev:
-        torch.cuda.set_device(dev)
-    try:
+    groups, gptr, thrs, tptr = _side_inputs(dev, n, groups, thrs)
+    flags = _lib.NMS_STRICT if strict else 0
+    with _OnDevice(dev):
         stream = _lib.current_stream_handle(dev)
         capacity = 0  # library default
-        for _ in range(3):
+        while True:
             ws, nbytes = _workspace(L, dev, stream, n, kind, capacity)
-            rc = L.obb_nms_grouped_f32(dets_dev.data_ptr(), n, kind, iou_thr, gptr, tptr,
-                                       keep.data_ptr(), info, ws.data_ptr(), nbytes, stream)
+            rc = L.obb_nms_ex_f32(dets_dev.data_ptr(), n, kind, iou_thr, gptr, tptr, flags,
+                                  keep.data_ptr(), info, ws.data_ptr(), nbytes, stream)
             if rc != _lib.OBB_EWORKSPACE:
                 break
-            capacity = int(info[3])  # a pair capacity the library says suffices
-    finally:
-        if not same_dev:
-            torch.cuda.set_device(cur)
+            # a pair capacity the library says suffices; every request at least doubles, so the
+            # loop ends (at the latest in _workspace's byte budget)
+            capacity = max(int(info[3]), 2 * capacity)
     if rc != _lib.OBB_OK:
         _lib.check(rc)
     return keep[:info[0]], (info[1], info[2], info[3])
@@ -99,7 +131,7 @@ def _as_tensor(x):
     return torch.as_tensor(np.asarray(x))
 
 
-def _nms_generic(dets, iou_thr, device_id, cols, kind, name, groups=None, thrs=None):
+def _nms_generic(dets, iou_thr, device_id, cols, kind, name, groups=None, thrs=None, strict=False):
     # container handling mirrors nms_wrapper.py:36-47
     if isinstance(dets, torch.Tensor):
         is_numpy = False
@@ -118,7 +150,7 @@ def _nms_generic(dets, iou_thr, device_id, cols, kind, name, groups=None, thrs=N
         inds = dets_th.new_zeros(0, dtype=torch.long)
     else:
         d = _lib.to_device_f32(dets_th, device_id)
-        inds, _ = _run_nms(d, kind, float(iou_thr), _as_tensor(groups), _as_tensor(thrs))
+        inds, _ = _run_nms(d, kind, float(iou_thr), _as_tensor(groups), _as_tensor(thrs), strict)
         if not is_numpy:
             inds = inds.to(dets_th.device)  # keep lives where the input lives
     if is_numpy:
@@ -126,7 +158,7 @@ def _nms_generic(dets, iou_thr, device_id, cols, kind, name, groups=None, thrs=N
     return dets[inds, :], inds
 
 
-def rnms(dets, iou_thr, device_id=None, groups=None, thrs=None):
+def rnms(dets, iou_thr, device_id=None, groups=None, thrs=None, strict=False):
     """Greedy NMS on theta-OBBs.
 
     Arguments:
@@ -140,6 +172,8 @@ def rnms(dets, iou_thr, device_id=None, groups=None, thrs=None):
             call -- what bbox_nms.py:56-63 does with coordinate offsets).
         thrs (float array, optional): (n,) per-box threshold replacing iou_thr
             (per-class thresholds of the DOTA merge, dota.py:321-331).
+        strict (bool): suppress on ``>`` (the reference's CUDA kernel,
+            nms_kernel.cu:61) instead of ``>=``.
 
     Returns:
         tuple: kept dets and int64 indices (ascending, nms_cpu.cpp:59), same
@@ -153,14 +187,14 @@ def rnms(dets, iou_thr, device_id=None, groups=None, thrs=None):
         >>> kept, inds = rnms(dets, 0.7)
         >>> assert len(inds) == len(kept) == 4
     """
-    return _nms_generic(dets, iou_thr, device_id, 6, _lib.KIND_RBOX, 'rnms', groups, thrs)
+    return _nms_generic(dets, iou_thr, device_id, 6, _lib.KIND_RBOX, 'rnms', groups, thrs, strict)
 
 
-def poly_nms(dets, iou_thr, device_id=None, groups=None, thrs=None):
+def poly_nms(dets, iou_thr, device_id=None, groups=None, thrs=None, strict=False):
     """Greedy NMS on convex quadrilaterals: dets (n, 9) <x1,y1,..,x4,y4,score>
     (the 8-point polygons the reference writes for the DOTA merge,
     mmdet/datasets/dota.py:197-235, merged by the external mergebypoly)."""
-    return _nms_generic(dets, iou_thr, device_id, 9, _lib.KIND_POLY, 'poly_nms', groups, thrs)
+    return _nms_generic(dets, iou_thr, device_id, 9, _lib.KIND_POLY, 'poly_nms', groups, thrs, strict)
 
 
 # the names the reference's own (disabled) call sites use
@@ -168,31 +202,155 @@ thetaobb_nms = rnms      # mmdet/core/post_processing/rbbox_nms.py:97
 pointobb_nms = poly_nms
 
 
-def nms(dets, iou_thr, device_id=None, groups=None):
-    """Horizontal-box NMS with the reference's exact signature
-    (nms_wrapper.py:7), served by the rotated kernels through the theta = 0
-    mapping  w = x2-x1+1, h = y2-y1+1, centre = box centre  (the continuous box
-    [x1-.5, x2+.5] x [y1-.5, y2+.5] has the reference's +1 intersection widths,
-    nms_cpu.cpp:19,52-55).  dets: (n, 5) <x1, y1, x2, y2, score>."""
+def nms(dets, iou_thr, device_id=None, groups=None, thrs=None, strict=False):
+    """Horizontal-box NMS with the reference's signature (nms_wrapper.py:7):
+    dets (n, 5) <x1, y1, x2, y2, score> -> (dets[inds], inds).
+
+    The pairs are decided with the reference's own arithmetic -- areas
+    ``(x2-x1+1)*(y2-y1+1)``, intersection widths ``min(x2)-max(x1)+1``,
+    ``inter / (a_i + a_j - inter) >= iou_thr`` (nms_cpu.cpp:19,47-56) -- in a dedicated
+    narrow phase of the HIP kernels (OBB_KIND_HBB), not with the rotated clip.
+    ``iou_thr <= 0`` raises: under ``>=`` the reference then suppresses every box but the
+    best one (disjoint boxes included), which no NMS kernel should silently imitate.
+
+    Example (nms_wrapper.py:24-34):
+        >>> dets = np.array([[49.1, 32.4, 51.0, 35.9, 0.9],
+        >>>                  [49.3, 32.9, 51.0, 35.3, 0.9],
+        >>>                  [49.2, 31.8, 51.0, 35.4, 0.5],
+        >>>                  [35.1, 11.5, 39.1, 15.7, 0.5],
+        >>>                  [35.6, 11.8, 39.3, 14.2, 0.5],
+        >>>                  [35.3, 11.5, 39.9, 14.5, 0.4],
+        >>>                  [35.2, 11.7, 39.7, 15.7, 0.3]], dtype=np.float32)
+        >>> suppressed, inds = nms(dets, 0.7)
+        >>> assert len(inds) == len(suppressed) == 3
+    """
+    if not strict and thrs is None and not float(iou_thr) > 0.0:
+        raise ValueError('nms: iou_thr must be positive (got {}); with the reference\'s `>=` rule a '
+                         'non-positive threshold keeps only the best box'.format(iou_thr))
+    return _nms_generic(dets, iou_thr, device_id, 5, _lib.KIND_HBB, 'nms', groups, thrs, strict)
+
+
+def soft_nms(dets, iou_thr, method='linear', sigma=0.5, min_score=1e-3, device_id=None):
+    """Soft-NMS with the reference's signature (nms_wrapper.py:63-118), on the GPU.
+
+    The reference runs it on the CPU only (:64); here one HIP workgroup replays
+    ``soft_nms_cpu_kernel`` (nms_cpu.cpp:71-210) including its in-place array permutation,
+    so equal scores resolve identically.
+
+    Arguments:
+        dets (torch.Tensor or np.ndarray): (n, 5) bboxes with scores.
+        iou_thr (float): IoU threshold of the linear method.
+        method (str): 'linear' or 'gaussian'.
+        sigma (float): gaussian decay parameter.
+        min_score (float): boxes whose decayed score falls below it are dropped.
+
+    Returns:
+        tuple: new dets (k, 5) with decayed scores, in selection order, and their original
+        indices (k,) -- same container type, dtype and device as the input.
+
+    Example (nms_wrapper.py:80-89):
+        >>> dets = np.array([[4., 3., 5., 3., 0.9], [4., 3., 5., 4., 0.9], [3., 1., 3., 1., 0.5],
+        >>>                  [3., 1., 3., 1., 0.5], [3., 1., 3., 1., 0.4], [3., 1., 3., 1., 0.0]],
+        >>>                 dtype=np.float32)
+        >>> new_dets, inds = soft_nms(dets, 0.7, sigma=0.5)
+        >>> assert len(inds) == len(new_dets) == 3
+    """
     if isinstance(dets, torch.Tensor):
-        is_numpy = False
-        dets_th = dets
+        is_tensor = True
+        dets_th = dets.detach()
     elif isinstance(dets, np.ndarray):
-        is_numpy = True
+        is_tensor = False
         dets_th = torch.from_numpy(dets)
     else:
         raise TypeError('dets must be either a Tensor or numpy array, but got {}'.format(
             type(dets)))
+    method_codes = {'linear': 1, 'gaussian': 2}
+    if method not in method_codes:
+        raise ValueError('Invalid method for SoftNMS: {}'.format(method))
     if dets_th.dim() != 2 or dets_th.size(1) != 5:
-        raise ValueError('nms expects dets of shape (n, 5), got {}'.format(tuple(dets_th.shape)))
-    if dets_th.shape[0] == 0:
-        inds = dets_th.new_zeros(0, dtype=torch.long)
+        raise ValueError('soft_nms expects dets of shape (n, 5), got {}'.format(tuple(dets_th.shape)))
+    n = dets_th.size(0)
+    if n == 0:
+        new_dets = dets_th.new_zeros((0, 5), dtype=torch.float32)
+        inds = torch.zeros(0, dtype=torch.long)
     else:
         d = _lib.to_device_f32(dets_th, device_id)
-        # the kernel reads x1, y1, x2, y2 and builds the theta = 0 OBB itself (OBB_KIND_HBB)
-        inds, _ = _run_nms(d, _lib.KIND_HBB, float(iou_thr), _as_tensor(groups))
-        if not is_numpy:
-            inds = inds.to(dets_th.device)
-    if is_numpy:
-        inds = inds.cpu().numpy()
-    return dets[inds, :], inds
+        dev = d.device
+        L = _lib.lib()
+        out = torch.empty((n, 5), dtype=torch.float32, device=dev)
+        oinds = torch.empty(n, dtype=torch.int64, device=dev)
+        ws = torch.empty(L.obb_soft_nms_workspace_bytes(n), dtype=torch.uint8, device=dev)
+        count = ctypes.c_int64(0)
+        with _OnDevice(dev):
+            rc = L.obb_soft_nms_f32(d.data_ptr(), n, float(iou_thr), method_codes[method], float(sigma),
+                                    float(min_score), out.data_ptr(), oinds.data_ptr(),
+                                    ctypes.byref(count), ws.data_ptr(), ws.numel(),
+                                    _lib.current_stream_handle(dev))
+        _lib.check(rc)
+        new_dets, inds = out[:count.value], oinds[:count.value]
+    if is_tensor:
+        return (new_dets.to(device=dets.device, dtype=dets.dtype),
+                inds.to(device=dets.device, dtype=torch.long))
+    return new_dets.cpu().numpy().astype(dets.dtype), inds.cpu().numpy().astype(np.int64)
+
+
+# ---------------------------------------------------------------------------------------------
+# Asynchronous form: queue several NMS calls, collect them with ONE synchronisation.
+# A detector calls NMS once per FPN level (rpn_head.py:92) and once per class
+# (rbbox_nms.py:43); each synchronous call costs a host round trip of ~40 us on top of the
+# kernels.  `nms_enqueue` returns a ticket, `nms_collect` turns tickets into keep tensors.
+# ---------------------------------------------------------------------------------------------
+_KINDS = {'nms': (_lib.KIND_HBB, 5), 'rnms': (_lib.KIND_RBOX, 6), 'poly_nms': (_lib.KIND_POLY, 9)}
+
+
+class NmsTicket(object):
+    __slots__ = ('dets', 'kind', 'iou_thr', 'groups', 'thrs', 'strict', 'keep', 'record', 'nbytes')
+
+
+def nms_enqueue(dets, iou_thr, op='nms', groups=None, thrs=None, strict=False):
+    """Queue ``op`` ('nms' | 'rnms' | 'poly_nms') on ``dets`` (fp32 HIP tensor) on the current
+    stream without waiting for it (obb_nms_async_f32).  The calls of one stream may share the
+    thread's workspace: they execute in order."""
+    kind, cols = _KINDS[op]
+    if not (isinstance(dets, torch.Tensor) and dets.is_cuda):
+        raise TypeError('nms_enqueue takes a HIP tensor')
+    if dets.dim() != 2 or dets.size(1) != cols:
+        raise ValueError('{} expects dets of shape (n, {}), got {}'.format(op, cols, tuple(dets.shape)))
+    if op == 'nms' and not strict and thrs is None and not float(iou_thr) > 0.0:
+        raise ValueError('nms: iou_thr must be positive (got {})'.format(iou_thr))
+    d = dets.detach().to(dtype=torch.float32).contiguous()
+    n, dev = d.size(0), d.device
+    t = NmsTicket()
+    t.dets, t.kind, t.iou_thr, t.strict = d, kind, float(iou_thr), bool(strict)
+    t.groups, gptr, t.thrs, tptr = _side_inputs(dev, n, _as_tensor(groups), _as_tensor(thrs))
+    t.keep = torch.empty(n, dtype=torch.int64, device=dev)
+    t.record = torch.empty(_lib.NMS_RESULT_BYTES // 8, dtype=torch.int64, device=dev)
+    L = _lib.lib()
+    with _OnDevice(dev):
+        stream = _lib.current_stream_handle(dev)
+        ws, t.nbytes = _workspace(L, dev, stream, n, kind, 0)
+        _lib.check(L.obb_nms_async_f32(d.data_ptr(), n, kind, t.iou_thr, gptr, tptr,
+                                       _lib.NMS_STRICT if strict else 0, t.keep.data_ptr(),
+                                       t.record.data_ptr(), ws.data_ptr(), t.nbytes, stream))
+    return t
+
+
+def nms_collect(tickets):
+    """Keep tensors (ascending int64 indices) of queued calls: one device-to-host copy of all
+    result records.  A call whose pair lists overflowed the default workspace is repeated
+    synchronously with the capacity the library asks for."""
+    if not tickets:
+        return []
+    L = _lib.lib()
+    recs = torch.stack([t.record for t in tickets]).cpu().numpy()    # synchronises the stream
+    info = (ctypes.c_int64 * 4)()
+    out = []
+    for t, rec in zip(tickets, recs):
+        rc = L.obb_nms_async_result(rec.ctypes.data, t.dets.size(0), t.nbytes, info)
+        if rc == _lib.OBB_EWORKSPACE:
+            keep, _ = _run_nms(t.dets, t.kind, t.iou_thr, t.groups, t.thrs, t.strict)
+        else:
+            _lib.check(rc)
+            keep = t.keep[:info[0]]
+        out.append(keep)
+    return out

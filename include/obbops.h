@@ -102,7 +102,9 @@ OBB_API int obb_overlaps_f32(const float *a_dev, int64_t m, const float *b_dev, 
  *              meet) the workspace can hold; pass 0 for the default
  *              (max(256K, 64 n)).  If more exist the call returns
  *              OBB_EWORKSPACE with info_host[3] = a capacity that suffices;
- *              call again with it.  n*(n-1)/2 * 1.25 always suffices.
+ *              call again with it (loop: which of the library's 64 internal pair lists a
+ *              pair lands in depends on scheduling, so a retry can ask for more once
+ *              again; every request at least doubles and 64 * n*(n-1)/2 always suffices).
  * Synchronises `stream` before returning.
  * ------------------------------------------------------------------------- */
 OBB_API size_t obb_nms_workspace_bytes(int64_t n, int kind, int64_t pair_capacity);
@@ -122,6 +124,61 @@ OBB_API int obb_nms_grouped_f32(const float *dets_dev, int64_t n, int kind, floa
                                 const int32_t *group_dev, const float *thr_dev,
                                 int64_t *keep_dev, int64_t *info_host, void *workspace_dev,
                                 size_t workspace_bytes, void *stream);
+
+/* Extended form: everything obb_nms_grouped_f32 does, plus `flags`:
+ *   OBB_NMS_STRICT  suppress on overlap > iou_thr -- the comparison of the reference's CUDA
+ *                   kernel (devIoU > thr, mmdet/ops/nms/src/nms_kernel.cu:61) -- instead of the
+ *                   CPU reference's >= (nms_cpu.cpp:56), which is the default everywhere.  The
+ *                   two only differ for pairs whose IoU EQUALS the threshold (integer boxes).
+ * OBB_KIND_HBB rows are decided with the reference's own arithmetic (nms_cpu.cpp:19,47-56:
+ * +1 widths, inter / (a_i + a_j - inter)), not with the polygon clip.  With that kind and
+ * the >= rule, iou_thr <= 0 is refused (OBB_EINVAL): in the reference it suppresses every box
+ * but the best one of a group, which is not an NMS.                                          */
+#define OBB_NMS_STRICT 1
+OBB_API int obb_nms_ex_f32(const float *dets_dev, int64_t n, int kind, float iou_thr,
+                           const int32_t *group_dev, const float *thr_dev, int flags,
+                           int64_t *keep_dev, int64_t *info_host, void *workspace_dev,
+                           size_t workspace_bytes, void *stream);
+
+/* Asynchronous form: enqueues the same kernels and returns WITHOUT synchronising `stream`
+ * (the reference's nms_cuda copies the mask to the host and loops there, nms_kernel.cu:104-131;
+ * a detector calls it once per FPN level and once per class, rpn_head.py:92, rbbox_nms.py:43 --
+ * here those calls can be queued back to back and collected with one synchronisation).
+ *   result_dev  OBB_NMS_RESULT_BYTES of device (or device-mapped host) memory; the last kernel
+ *               writes the call's result record there.  int64 word 0 of the record is K, so a
+ *               consumer on the same stream can use keep_dev[0 .. K) without the host.
+ * After the caller has synchronised and copied the record to the host,
+ * obb_nms_async_result(record, n, workspace_bytes, info_host) fills info_host[4] like
+ * obb_nms_f32 and returns OBB_OK, or OBB_EWORKSPACE (info_host[3] = a capacity that suffices;
+ * keep_dev is then invalid and the call must be repeated with a larger workspace).
+ * Each in-flight call needs its own workspace and record unless they are on ONE stream.    */
+#define OBB_NMS_RESULT_BYTES 64
+OBB_API int obb_nms_async_f32(const float *dets_dev, int64_t n, int kind, float iou_thr,
+                              const int32_t *group_dev, const float *thr_dev, int flags,
+                              int64_t *keep_dev, void *result_dev, void *workspace_dev,
+                              size_t workspace_bytes, void *stream);
+OBB_API int obb_nms_async_result(const void *result_host, int64_t n, size_t workspace_bytes,
+                                 int64_t *info_host);
+
+/* ---------------------------------------------------------------------------
+ * Soft-NMS on horizontal boxes.
+ * Replaces: at::Tensor soft_nms(dets, threshold, method, sigma, min_score)
+ *           mmdet/ops/nms/src/nms_cpu.cpp:71-210 (CPU only in the reference,
+ *           nms_wrapper.py:63-118), including its in-place array permutation, which decides
+ *           ties between equal scores.
+ *   dets_dev      (n, 5) x1, y1, x2, y2, score
+ *   method        0 hard, 1 linear, 2 gaussian (the wrapper exposes 1 and 2, nms_wrapper.py:103)
+ *   out_dets_dev  (n, 5): the K surviving boxes in selection order with their decayed scores
+ *   out_inds_dev  int64[n]: their original indices
+ *   count_host    K
+ * One workgroup (the rounds are a dependency chain); synchronises `stream`.
+ * method 2 calls the device expf: scores may differ from glibc's in the last ulp.
+ * ------------------------------------------------------------------------- */
+OBB_API size_t obb_soft_nms_workspace_bytes(int64_t n);
+OBB_API int obb_soft_nms_f32(const float *dets_dev, int64_t n, float iou_thr, int method, float sigma,
+                             float min_score, float *out_dets_dev, int64_t *out_inds_dev,
+                             int64_t *count_host, void *workspace_dev, size_t workspace_bytes,
+                             void *stream);
 
 /* Optional per-phase device timing of obb_nms_f32 (HIP events recorded on the
  * caller's stream; thread-local).  Phases: 0 clear + prep + quantise, 1 spatial
@@ -185,6 +242,20 @@ OBB_API int obb_roi_align_backward_f32(const float *grad_out_dev, int B, int C, 
  *           cv2 call on the host).  in (n,5) -> out (n,8).
  * ------------------------------------------------------------------------- */
 OBB_API int obb_rbox_to_poly_f32(const float *rbox_dev, int64_t n, float *poly_dev, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * Test / tuning hooks.  NOT part of the drop-in surface (no reference counterpart): the
+ * parity tests use them to force every size through every code path, and the experiment
+ * scripts under tools/ to sweep launch geometry.  Process-wide; value < 0 restores the
+ * built-in default.  The library reads no environment variable.
+ * ------------------------------------------------------------------------- */
+#define OBB_TUNE_NMS_FUSED_MAX 0      /* largest n served by the single-workgroup kernel (<= 1024)   */
+#define OBB_TUNE_NMS_DIRECT_MAX 1     /* largest n served without the spatial sort (<= 65536)        */
+#define OBB_TUNE_NMS_SCAN_BLOCKS 2    /* grid of the sorted route's scan kernel                      */
+#define OBB_TUNE_RROI_GROUPS 3        /* 8-channel groups per RoI-Align block                        */
+#define OBB_TUNE_OVERLAPS_ROWS 4      /* rows per block of the pairwise-overlap kernel (8..64)       */
+#define OBB_TUNE_COUNT 5
+OBB_API int obb_set_tuning(int knob, int64_t value);
 
 #ifdef __cplusplus
 }

@@ -43,3 +43,18 @@ def hbb_to_rbox(b, rot=False):
     if b.shape[1] > 4:
         cols.append(b[:, 4])
     return np.stack(cols, 1).astype(np.float32)
+
+
+@pytest.fixture
+def nms_route():
+    """`nms_route('fused' | 'direct' | 'sorted' | 'auto')` forces the NMS code path through the
+    library's tuning hooks (include/obbops.h, obb_set_tuning); defaults are restored afterwards."""
+    from aidet_amd import _lib
+
+    def force(route):
+        fused = {'fused': 1024, 'direct': 0, 'sorted': 0, 'auto': -1}[route]
+        direct = {'fused': -1, 'direct': 65536, 'sorted': 0, 'auto': -1}[route]
+        _lib.set_tuning(_lib.TUNE_NMS_FUSED_MAX, fused)
+        _lib.set_tuning(_lib.TUNE_NMS_DIRECT_MAX, direct)
+    yield force
+    force('auto')

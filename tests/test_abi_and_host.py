@@ -55,6 +55,38 @@ def test_argument_validation_without_gpu():
     assert L.obb_rbox_to_poly_f32(null, 0, null, null) == _lib.OBB_OK
     buf = (ctypes.c_float * 7)()
     assert L.obb_nms_profile_last(buf) == _lib.OBB_EINVAL   # nothing profiled yet
+    # round 2 entry points
+    one = ctypes.c_void_p(256)   # (never dereferenced: validation fails first)
+    assert L.obb_nms_ex_f32(one, 5, 0, 0.5, null, null, 8, one, info, one, 1 << 20, null) == _lib.OBB_EINVAL
+    assert b'flags' in L.obb_last_error()
+    assert L.obb_nms_ex_f32(one, 5, _lib.KIND_HBB, 0.0, null, null, 0, one, info, one, 1 << 20, null) == _lib.OBB_EINVAL
+    assert b'nms_cpu.cpp:56' in L.obb_last_error()       # horizontal boxes, `>=`, thr <= 0
+    assert L.obb_nms_ex_f32(null, 0, _lib.KIND_HBB, 0.5, null, null, 0, null, info, null, 0, null) == _lib.OBB_OK
+    assert L.obb_nms_async_f32(one, 5, 0, 0.5, null, null, 0, one, null, one, 1 << 20, null) == _lib.OBB_EINVAL
+    assert L.obb_nms_async_result(null, 5, 1 << 20, info) == _lib.OBB_EINVAL
+    rec = (ctypes.c_int64 * 8)()                           # all-zero record = empty result
+    assert L.obb_nms_async_result(rec, 0, 0, info) == _lib.OBB_OK and info[0] == 0
+    ws = L.obb_nms_workspace_bytes(1000, 0, 0)
+    rec[0] = 7                                             # K = 7, fused route, no overflow
+    assert L.obb_nms_async_result(rec, 1000, ws, info) == _lib.OBB_OK and info[0] == 7
+    rec[1] = 1 << 40                                       # more edges than the workspace holds
+    assert L.obb_nms_async_result(rec, 1000, ws, info) == _lib.OBB_EWORKSPACE and info[3] > (1 << 39)
+    cnt = ctypes.c_int64(5)
+    assert L.obb_soft_nms_f32(null, -1, 0.5, 1, 0.5, 0.001, null, null, ctypes.byref(cnt), null, 0, null) == _lib.OBB_EINVAL
+    assert L.obb_soft_nms_f32(null, 3, 0.5, 7, 0.5, 0.001, null, null, ctypes.byref(cnt), null, 0, null) == _lib.OBB_EINVAL
+    assert L.obb_soft_nms_f32(null, 0, 0.5, 1, 0.5, 0.001, null, null, ctypes.byref(cnt), null, 0, null) == _lib.OBB_OK
+    assert cnt.value == 0
+    assert L.obb_soft_nms_workspace_bytes(100) == 256 and L.obb_soft_nms_workspace_bytes(5000) >= 5000 * 32
+    assert L.obb_set_tuning(99, 1) == _lib.OBB_EINVAL
+    assert L.obb_set_tuning(_lib.TUNE_NMS_FUSED_MAX, 64) == _lib.OBB_OK
+    assert L.obb_set_tuning(_lib.TUNE_NMS_FUSED_MAX, -1) == _lib.OBB_OK
+
+
+def test_library_reads_no_environment_variable():
+    """Test knobs are explicit API calls (obb_set_tuning), not getenv in the entry points."""
+    for f in os.listdir(os.path.join(ROOT, 'aidet_amd', 'csrc')):
+        if f.endswith(('.hip', '.cuh', '.h', '.cpp')):
+            assert 'getenv' not in open(os.path.join(ROOT, 'aidet_amd', 'csrc', f)).read(), f
 
 
 def test_wrapper_type_errors_match_reference():

@@ -142,9 +142,11 @@ def nms_path(request, monkeypatch):
     """The library routes n <= 128 to the fused kernel, n <= 10240 to the direct
     (unsorted) scan and the rest to the spatially sorted pipeline; 'sorted' forces the
     last one for every n above the fused limit, so each test covers both."""
+    from aidet_amd import _lib
     if request.param == 'sorted':
-        monkeypatch.setenv('OBB_NMS_DIRECT_MAX', '0')
-    return request.param
+        _lib.set_tuning(_lib.TUNE_NMS_DIRECT_MAX, 0)
+    yield request.param
+    _lib.set_tuning(_lib.TUNE_NMS_DIRECT_MAX, -1)
 
 
 @pytest.mark.parametrize('n,canvas', [(1, 10), (2, 10), (63, 64), (64, 64), (65, 64), (257, 128),
@@ -601,9 +603,9 @@ def test_rotated_max_iou_assigner_matches_reference_at_theta0(golden):
 
 @pytest.mark.parametrize('n,canvas', [(1, 10), (2, 10), (64, 64), (257, 100), (700, 150), (1024, 200),
                                       (1024, 60)])
-def test_rnms_fused_and_general_paths_agree(n, canvas, monkeypatch):
-    """n <= 1024 can take the fused single-launch kernel; OBB_NMS_NO_FUSED=1 forces the
-    direct scan, OBB_NMS_DIRECT_MAX=0 on top of it the sorted pipeline.  All three must
+def test_rnms_fused_and_general_paths_agree(n, canvas, nms_route):
+    """n <= 1024 can take the fused single-launch kernel; the tuning hooks of the library
+    (obb_set_tuning) force the direct scan or the sorted pipeline instead.  All three must
     reproduce the oracle (dense canvas 60: ~1e5 edges)."""
     from aidet_amd import poly_nms, rnms
     d = oracle.synth_boxes(n, canvas, 300 + n)
@@ -612,12 +614,8 @@ def test_rnms_fused_and_general_paths_agree(n, canvas, monkeypatch):
     refg = oracle.rnms(d, 0.45, groups=g)
     p = np.concatenate([oracle.rbox_to_poly(d).astype(np.float32), d[:, 5:6]], 1)
     refp = oracle.poly_nms(p, 0.45)
-    monkeypatch.setenv('OBB_NMS_FUSED_MAX', '1024')   # route every case to the fused kernel
     for path in ('fused', 'direct', 'sorted'):
-        if path != 'fused':
-            monkeypatch.setenv('OBB_NMS_NO_FUSED', '1')
-        if path == 'sorted':
-            monkeypatch.setenv('OBB_NMS_DIRECT_MAX', '0')
+        nms_route(path)
         assert np.array_equal(rnms(t(d), 0.45)[1].cpu().numpy(), ref), path
         assert np.array_equal(rnms(t(d), 0.45, groups=g)[1].cpu().numpy(), refg), path
         assert np.array_equal(poly_nms(t(p), 0.45)[1].cpu().numpy(), refp), path
@@ -834,3 +832,157 @@ def test_hbb_roi_align_kernel_side_mapping_forward_and_backward(aligned):
     out1.backward(g)
     out2.backward(g)
     assert float((f1.grad - f2.grad).abs().max()) <= 1e-4 * max(1.0, float(f2.grad.abs().max()))
+
+
+# --------------------------------------------------------------------------
+# round 2: dedicated HBB narrow phase, strict compare, Soft-NMS, async calls
+# --------------------------------------------------------------------------
+@pytest.mark.parametrize('route', ['auto', 'fused', 'direct', 'sorted'])
+def test_hbb_nms_exact_ties_match_reference(golden, route, nms_route):
+    """Integer boxes: IoU == thr happens and nms_cpu.cpp:56 suppresses on `>=`.  The HBB rows
+    are decided by the reference's own arithmetic in the kernel (OBB_KIND_HBB narrow phase)."""
+    from aidet_amd import nms
+    g = golden('hbb_nms_ties.npz')
+    nms_route(route)
+    assert nms(g['half_dets'], 0.5)[1].tolist() == g['half_keep'].tolist() == [0, 2]
+    assert nms(g['half_dets'], 0.5, strict=True)[1].tolist() == [0, 1]       # nms_kernel.cu:61 `>`
+    for tag in 'abc':
+        d, thr, keep = g['int_%s_dets' % tag], float(g['int_%s_thr' % tag]), g['int_%s_keep' % tag]
+        if route == 'fused' and len(d) > 1024:
+            d = d[:1024]
+            keep = oracle.hbb_nms(d, thr)
+        assert np.array_equal(nms(t(d), thr)[1].cpu().numpy(), keep), tag
+        assert np.array_equal(nms(t(d), thr, strict=True)[1].cpu().numpy(), oracle.hbb_nms(d, thr, strict=True)), tag
+        grp = (np.arange(len(d)) % 5).astype(np.int32)
+        assert np.array_equal(nms(t(d), thr, groups=grp)[1].cpu().numpy(), oracle.hbb_nms(d, thr, groups=grp)), tag
+
+
+def test_hbb_nms_malformed_and_nonpositive_threshold():
+    from aidet_amd import nms, rnms
+    d = np.array([[0, 0, 10, 10, 0.9], [1, 1, 11, 11, 0.8], [20, 5, 3, 9, 0.7],      # x2 < x1 - 1: inert
+                  [2, 2, 9, 9, np.nan], [np.nan, 0, 5, 5, 0.6], [0, 0, 10, 10, 0.5],
+                  [4, 4, 3, 3, 0.4]], np.float32)                                    # w = h = 0: inert
+    assert np.array_equal(nms(t(d), 0.5)[1].cpu().numpy(), oracle.hbb_nms(d, 0.5))
+    with pytest.raises(ValueError):
+        nms(t(d), 0.0)
+    with pytest.raises(ValueError):
+        nms(t(d), -1.0)
+    nms(t(d), 0.0, strict=True)            # `>` with thr 0 is an ordinary NMS
+    # rotated kinds: the AABB prefilter is part of the operator, every threshold is defined
+    r = oracle.synth_boxes(600, 200, 77)
+    for thr in (0.0, -0.5):
+        assert np.array_equal(rnms(t(r), thr)[1].cpu().numpy(), oracle.rnms(r, thr))
+
+
+def test_rotated_strict_compare(nms_path):
+    from aidet_amd import rnms
+    two = np.array([[10, 10, 8, 4, 0.3, 0.9], [10, 10, 8, 4, 0.3, 0.8]], np.float32)
+    assert rnms(two, 1.0)[1].tolist() == [0] and rnms(two, 1.0, strict=True)[1].tolist() == [0, 1]
+    d = oracle.synth_boxes(5000, 300, 4)
+    d[1000:1500] = d[:500]                  # exact duplicates: IoU == 1
+    d[1000:1500, 5] *= 0.5
+    assert np.array_equal(rnms(t(d), 1.0)[1].cpu().numpy(), oracle.rnms(d, 1.0))
+    assert np.array_equal(rnms(t(d), 1.0, strict=True)[1].cpu().numpy(), oracle.rnms(d, 1.0, strict=True))
+    assert len(oracle.rnms(d, 1.0)) < len(oracle.rnms(d, 1.0, strict=True))
+
+
+def test_soft_nms_matches_reference(golden):
+    """soft_nms_cpu_kernel (nms_cpu.cpp:71-210) through nms_wrapper.soft_nms (:63-118): the
+    fixtures were produced by the reference's own build."""
+    from aidet_amd.nms_wrapper import soft_nms
+    g = golden('soft_nms.npz')
+    nd, inds = soft_nms(g['doc6_dets'], 0.7, sigma=0.5)
+    assert isinstance(nd, np.ndarray) and inds.dtype == np.int64 and len(inds) == 3
+    assert np.array_equal(inds, g['doc6_inds']) and np.array_equal(nd, g['doc6_new_dets'])
+    nd, inds = soft_nms(torch.from_numpy(g['test4_dets']), 0.7)       # tests/test_soft_nms.py: 4 outputs
+    assert isinstance(nd, torch.Tensor) and not nd.is_cuda and inds.dtype == torch.long
+    assert np.array_equal(inds.numpy(), g['test4_inds']) and np.array_equal(nd.numpy(), g['test4_new_dets'])
+    for tag in 'abcde':
+        thr, sigma, min_score = (float(v) for v in g['rand_%s_cfg' % tag])
+        method = str(g['rand_%s_method' % tag])
+        nd, inds = soft_nms(t(g['rand_%s_dets' % tag]), thr, method, sigma, min_score)
+        assert nd.is_cuda and inds.is_cuda
+        assert np.array_equal(inds.cpu().numpy(), g['rand_%s_inds' % tag]), tag
+        want = g['rand_%s_new_dets' % tag]
+        assert np.array_equal(nd.cpu().numpy()[:, :4], want[:, :4]), tag
+        tol = 0.0 if method == 'linear' else 1e-6          # gaussian: device expf vs glibc expf
+        assert np.abs(nd.cpu().numpy()[:, 4] - want[:, 4]).max() <= tol, tag
+    d64 = g['doc6_dets'].astype(np.float64)
+    nd, inds = soft_nms(d64, 0.7, sigma=0.5)
+    assert nd.dtype == np.float64 and inds.tolist() == g['doc6_inds'].tolist()
+    with pytest.raises(ValueError):
+        soft_nms(g['doc6_dets'], 0.7, method='bogus')
+    with pytest.raises(TypeError):
+        soft_nms([[0, 0, 1, 1, 1]], 0.7)
+    nd, inds = soft_nms(np.zeros((0, 5), np.float32), 0.5)
+    assert nd.shape == (0, 5) and inds.shape == (0,)
+
+
+@pytest.mark.parametrize('n,canvas,method', [(1, 10, 'linear'), (2049, 400, 'linear'), (5000, 500, 'gaussian'),
+                                             (3000, 120, 'linear')])
+def test_soft_nms_vs_oracle_sizes(n, canvas, method):
+    """n > 2048 keeps the state in the workspace instead of LDS; dense scenes drop a lot."""
+    from aidet_amd.nms_wrapper import soft_nms
+    rng = np.random.default_rng(n)
+    x1, y1 = rng.uniform(0, canvas, n), rng.uniform(0, canvas, n)
+    d = np.stack([x1, y1, x1 + rng.uniform(4, 60, n), y1 + rng.uniform(4, 60, n), rng.uniform(0, 1, n)], 1).astype(np.float32)
+    d[::4, 4] = np.float32(0.25)
+    nd, inds = soft_nms(t(d), 0.3, method, 0.5, 0.05)
+    rd, ri = oracle.soft_nms(d, 0.3, method, 0.5, 0.05)
+    assert np.array_equal(inds.cpu().numpy(), ri)
+    assert np.abs(nd.cpu().numpy() - rd).max() <= (0.0 if method == 'linear' else 1e-6)
+
+
+def test_nms_async_tickets_match_sync_calls():
+    """obb_nms_async_f32: several calls queued on one stream, one synchronisation."""
+    from aidet_amd import nms, nms_wrapper, rnms
+    sets, want = [], []
+    for i, n in enumerate((0, 1, 100, 2000, 2000, 30000)):
+        d = oracle.synth_boxes(n, 40.0 * max(n, 1) ** 0.5, 50 + i)
+        sets.append(('rnms', t(d), 0.4 + 0.05 * i))
+        want.append(oracle.rnms(d, 0.4 + 0.05 * i))
+    rng = np.random.default_rng(1)
+    x1, y1 = rng.uniform(0, 300, 2000), rng.uniform(0, 300, 2000)
+    h = np.stack([x1, y1, x1 + rng.uniform(5, 50, 2000), y1 + rng.uniform(5, 50, 2000),
+                  (rng.permutation(2000) + .5) / 2000], 1).astype(np.float32)
+    sets.append(('nms', t(h), 0.7))
+    want.append(oracle.hbb_nms(h, 0.7))
+    tickets = [nms_wrapper.nms_enqueue(d, thr, op=op) for op, d, thr in sets]
+    keeps = nms_wrapper.nms_collect(tickets)
+    for k, w in zip(keeps, want):
+        assert k.dtype == torch.int64 and np.array_equal(k.cpu().numpy(), w)
+    # overflow of the default pair workspace inside a ticket -> repeated synchronously
+    dup = np.tile(oracle.synth_boxes(1, 10, 3), (3000, 1))
+    dup[:, 5] = (np.arange(3000, 0, -1) / 3001).astype(np.float32)
+    tk = nms_wrapper.nms_enqueue(t(dup), 0.5, op='rnms')
+    assert nms_wrapper.nms_collect([tk])[0].tolist() == [0]
+
+
+def test_rnms_dense_all_overlap_needs_the_retry_loop():
+    """20 000 mutually overlapping boxes = 2e8 pairs: the default workspace (64 n pairs)
+    overflows, the wrapper loops on OBB_EWORKSPACE with the capacity the library reports."""
+    from aidet_amd import rnms
+    n = 20000
+    rng = np.random.default_rng(8)
+    d = np.zeros((n, 6), np.float32)
+    d[:, 0] = 500 + rng.uniform(-2, 2, n); d[:, 1] = 500 + rng.uniform(-2, 2, n)
+    d[:, 2] = 200; d[:, 3] = 100; d[:, 4] = rng.uniform(-0.02, 0.02, n)
+    d[:, 5] = (rng.permutation(n) + 0.5) / n
+    kept, inds = rnms(t(d), 0.5)
+    assert inds.tolist() == [int(np.argmax(d[:, 5]))]
+    kept, inds = rnms(t(d), 0.999)       # near-duplicates at a threshold almost nothing reaches
+    assert np.array_equal(inds.cpu().numpy(), oracle.rnms(d, 0.999))
+
+
+def test_multiclass_nms_reference_golden_on_gpu(golden):
+    """bbox_nms.py:6-76 captured outputs (mc_bboxes / mc_labels) through the HIP nms."""
+    from aidet_amd.post_processing import multiclass_nms
+    g = golden('multiclass.npz')
+    cfg = dict(type='nms', iou_thr=float(g['iou_thr']))
+    for grouped in (False, True):
+        det, lab = multiclass_nms(t(g['multi_bboxes']), t(g['multi_scores']), float(g['score_thr']), cfg,
+                                  int(g['max_num']), grouped=grouped)
+        assert np.array_equal(det.cpu().numpy(), g['mc_bboxes']) and np.array_equal(lab.cpu().numpy(), g['mc_labels'])
+    det, lab = multiclass_nms(t(g['multi_bboxes']), t(g['multi_scores']), float(g['score_thr']),
+                              dict(type='soft_nms', iou_thr=0.5, min_score=0.05), 100)
+    assert det.shape[1] == 5 and len(det) == len(lab) <= 100
