@@ -2,19 +2,30 @@
 
 Reference path: every rank pickles its per-patch results,
 ``collect_results_gpu`` all-gathers the pickles (mmdet/apis/test.py:116-146),
-rank 0 writes DOTA text files and the external ``wwtool.mergebypoly_mp`` runs a
-per-class polygon NMS on the CPU (mmdet/datasets/dota.py:310-336).
+rank 0 writes DOTA text files and the external ``wwtool.mergebypoly_mp`` /
+``mergebyrec_mp`` run a per-class NMS on the CPU (mmdet/datasets/dota.py:310-336).
 
-Here the detections stay tensors: one ``all_gather`` of the counts, one
-``all_gather`` of the padded ``(Nmax, 8)`` fp32 rows
-``[cx, cy, w, h, theta, score, label, image_id]`` over RCCL (xGMI; the payload is
-a few MB, i.e. latency bound), then ONE grouped rotated NMS (group = image *
-num_classes + label, optional per-class thresholds) on the GPU.  The keep set
-equals the single-process result by construction: the gathered rows are the same
-multiset and greedy NMS depends on the row order only through score ties (lower
-index wins); passing global sequence numbers (``seq``) restores the order a single
-process would have produced for the rank-strided patches of
-DistributedSampler (distributed_sampler.py:18-25), ties included.
+Here the detections stay tensors: ONE ``all_gather_into_tensor`` of the counts, ONE of the
+padded fp32 rows over RCCL (xGMI; a few MB, i.e. latency bound), then a grouped NMS on the GPU
+(group = image * num_classes + label, optional per-class thresholds).  Two merge layouts,
+identical results:
+
+  ``replicated``  every rank runs the one global grouped NMS on all gathered rows (fewest
+                  collectives; what the reference's rank 0 does, on every rank)
+  ``sharded``     (image, class) groups are independent, so rank r merges the groups with
+                  ``group % world == r`` and the keep indices are all-gathered -- two more small
+                  collectives, 1/world of the NMS work per rank
+
+The keep set equals the single-process result by construction: the gathered rows are the same
+multiset, and greedy NMS depends on the row order only through score ties (lower index wins);
+passing global sequence numbers (``seq``) restores the order a single process would have
+produced for the rank-strided patches of DistributedSampler (distributed_sampler.py:18-25),
+ties included.
+
+Row layouts (fp32), chosen by the number of columns:
+   8  theta-OBB   cx, cy, w, h, theta, score, label, image_id      -> ``rnms``
+  11  polygon     x1, y1, ..., x4, y4, score, label, image_id      -> ``poly_nms`` (Task1 text rows)
+   7  horizontal  x1, y1, x2, y2, score, label, image_id           -> ``nms``      (Task2 / mergebyrec)
 """
 import torch
 import torch.distributed as dist
@@ -22,6 +33,7 @@ import torch.distributed as dist
 from . import nms_wrapper
 
 COLS = 8  # cx, cy, w, h, theta, score, label, image_id
+_LAYOUT = {8: ('rnms', 6), 11: ('poly_nms', 9), 7: ('nms', 5)}   # columns -> (op, columns of box + score)
 
 
 def shard_patches(num_patches, rank, world_size):
@@ -31,64 +43,108 @@ def shard_patches(num_patches, rank, world_size):
     return list(range(rank, num_patches, world_size))
 
 
+def _world(group):
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(group), dist.get_rank(group)
+    return 1, 0
+
+
 def gather_detections(local, group=None):
     """All-gather variable-length detection rows.
+
+    Two collectives, one host read: ``all_gather_into_tensor`` of the row counts, ``.tolist()``,
+    ``all_gather_into_tensor`` of the rows padded to the largest count (the reference gathers
+    pickled bytes the same way, test.py:124-133).
 
     Args:
         local (Tensor): (n_local, C) rows on this rank's device (n_local may be 0).
     Returns:
         list[Tensor]: the rows of every rank, in rank order (on every rank).
     """
-    if not (dist.is_available() and dist.is_initialized()):
+    world, _ = _world(group)
+    if world == 1:
         return [local]
-    world = dist.get_world_size(group)
     n = torch.tensor([local.size(0)], dtype=torch.int64, device=local.device)
-    counts = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(counts, n, group=group)             # cf. test.py:124
-    counts = [int(c.item()) for c in counts]
+    counts = torch.empty(world, dtype=torch.int64, device=local.device)
+    dist.all_gather_into_tensor(counts, n, group=group)             # cf. test.py:124
+    counts = counts.tolist()
     nmax = max(max(counts), 1)
     pad = local.new_zeros((nmax, local.size(1)))
     pad[:local.size(0)] = local
-    parts = [torch.zeros_like(pad) for _ in range(world)]
-    dist.all_gather(parts, pad, group=group)            # cf. test.py:133
-    return [p[:c] for p, c in zip(parts, counts)]
+    parts = local.new_empty((world * nmax, local.size(1)))
+    dist.all_gather_into_tensor(parts, pad, group=group)            # cf. test.py:133
+    return [parts[r * nmax:r * nmax + c] for r, c in enumerate(counts)]
 
 
-def merge_detections(dets, iou_thr, num_classes, class_thrs=None, nms_fn=None):
-    """Global per-(image, class) rotated NMS of gathered detections.
+def _split_rows(dets, num_classes):
+    cols = dets.size(1)
+    if cols not in _LAYOUT:
+        raise ValueError('detection rows must have 8 (theta-OBB), 11 (polygon) or 7 (horizontal) '
+                         'columns, got {}'.format(cols))
+    op, nbox = _LAYOUT[cols]
+    labels = dets[:, nbox].long()
+    groups = dets[:, nbox + 1].long() * int(num_classes) + labels
+    return op, dets[:, :nbox].contiguous(), labels, groups
+
+
+def merge_detections(dets, iou_thr, num_classes, class_thrs=None, nms_fn=None, strict=False,
+                     only_groups=None):
+    """Global per-(image, class) NMS of gathered detections.
 
     Args:
-        dets (Tensor): (N, 8) rows [cx, cy, w, h, theta, score, label, image_id]
-            in full-image coordinates.
+        dets (Tensor): (N, 8 | 11 | 7) rows in full-image coordinates (module docstring).
         iou_thr (float): threshold (reference default for the merge: 0.3 flat,
             dota.py:329-331).
         num_classes (int): number of classes (labels are 0-based).
-        class_thrs (sequence, optional): per-class thresholds (dota.py:321-327).
-        nms_fn: NMS op ``f(dets(N,6), iou_thr, groups=..., thrs=...) -> (dets, keep)``;
-            defaults to the HIP ``rnms``.
+        class_thrs (sequence, optional): per-class thresholds (dota.py:320-327,
+            ``dota_io.class_thresholds``).
+        nms_fn: NMS op ``f(dets, iou_thr, groups=..., thrs=...) -> (dets, keep)``;
+            defaults to the HIP op of the row layout.
+        strict (bool): suppress on ``>`` instead of ``>=``.  The DOTA devkit's merge that the
+            reference delegates to [external] keeps ``ovr <= thresh``, i.e. it is strict; the
+            in-tree CPU NMS (nms_cpu.cpp:56) is not.  Default False = the in-tree rule.
+        only_groups ((world, rank), optional): merge only the groups with
+            ``group % world == rank`` (the sharded layout).
     Returns:
-        (kept rows (K, 8), keep indices (K,) into ``dets``)
+        (kept rows, keep indices (K,) into ``dets``, ascending)
     """
-    nms_fn = nms_fn or nms_wrapper.rnms
     if dets.size(0) == 0:
         return dets, torch.zeros(0, dtype=torch.long, device=dets.device)
-    labels = dets[:, 6].long()
-    groups = dets[:, 7].long() * int(num_classes) + labels
+    op, boxes, labels, groups = _split_rows(dets, num_classes)
     thrs = None
     if class_thrs is not None:
         thrs = torch.as_tensor(class_thrs, dtype=torch.float32, device=dets.device)[labels]
-    _, keep = nms_fn(dets[:, :6].contiguous(), iou_thr, groups=groups, thrs=thrs)
+    kw = {'strict': True} if strict else {}
+    sel = None
+    if only_groups is not None:
+        world, rank = only_groups
+        sel = (groups % world == rank).nonzero(as_tuple=True)[0]
+        boxes, groups = boxes[sel], groups[sel]
+        thrs = None if thrs is None else thrs[sel]
+        if sel.numel() == 0:
+            return dets[:0], sel
+    nms_fn = nms_fn or getattr(nms_wrapper, op)
+    _, keep = nms_fn(boxes, iou_thr, groups=groups, thrs=thrs, **kw)
     keep = torch.as_tensor(keep, device=dets.device)
+    if sel is not None:
+        keep = sel[keep]
     return dets[keep], keep
 
 
+def _restore_order(parts, ncols):
+    """rows of all ranks -> ascending global sequence number (two trailing fp32 columns)."""
+    allrows = torch.cat(parts, 0) if len(parts) > 1 else parts[0]
+    key = allrows[:, -2].to(torch.int64) * (1 << 20) + allrows[:, -1].to(torch.int64)
+    return allrows[torch.argsort(key, stable=True)][:, :ncols]
+
+
 def distributed_merge(local, iou_thr, num_classes, class_thrs=None, group=None, nms_fn=None,
-                      seq=None):
+                      seq=None, layout='replicated', strict=False, mark=None):
     """gather_detections + merge_detections.  Every rank returns the same result
     (the reference evaluates on rank 0 only, tools/dota/dota_test.py:157-166).
 
     Args:
-        local (Tensor): (n_local, 8) rows of this rank.
+        local (Tensor): (n_local, 8 | 11 | 7) rows of this rank.
         seq (Tensor, optional): (n_local,) int64 global sequence number of each row
             (e.g. patch_index * 2**20 + row_in_patch).  When given, the gathered
             rows are put back into ascending ``seq`` order, i.e. the order a single
@@ -96,22 +152,89 @@ def distributed_merge(local, iou_thr, num_classes, class_thrs=None, group=None, 
             interleave of collect_results, test.py:141-145).  Only matters for
             score TIES (lower row index wins); the keep set for distinct scores is
             order independent.
+        layout: 'replicated' | 'sharded' (module docstring).
+        mark (callable, optional): ``mark('gather')`` / ``mark('merge')`` are called after the
+            respective phase (e.g. to record HIP events).
     Returns:
-        (kept rows (K, 8), keep indices into the gathered rows, gathered rows)
+        (kept rows, keep indices into the gathered rows, gathered rows)
     """
+    if layout not in ('replicated', 'sharded'):
+        raise ValueError('layout must be "replicated" or "sharded"')
+    mark = mark or (lambda name: None)
+    ncols = local.size(1)
     if seq is not None:
-        rows = torch.cat([local, seq.to(local.dtype).new_zeros((local.size(0), 0))], 1)
         # sequence numbers travel as two float32 columns (hi, lo) to stay exact
         s64 = seq.to(torch.int64)
         hi = (s64 >> 20).to(local.dtype)[:, None]
         lo = (s64 & ((1 << 20) - 1)).to(local.dtype)[:, None]
-        rows = torch.cat([local, hi, lo], 1)
-        parts = gather_detections(rows, group)
-        allrows = torch.cat(parts, 0) if len(parts) > 1 else parts[0]
-        key = allrows[:, -2].to(torch.int64) * (1 << 20) + allrows[:, -1].to(torch.int64)
-        allrows = allrows[torch.argsort(key, stable=True)][:, :COLS]
+        allrows = _restore_order(gather_detections(torch.cat([local, hi, lo], 1), group), ncols)
     else:
         parts = gather_detections(local, group)
         allrows = torch.cat(parts, 0) if len(parts) > 1 else parts[0]
-    kept, keep = merge_detections(allrows, iou_thr, num_classes, class_thrs, nms_fn)
+    mark('gather')
+    world, rank = _world(group)
+    if layout == 'sharded' and world > 1:
+        _, mine = merge_detections(allrows, iou_thr, num_classes, class_thrs, nms_fn, strict,
+                                   only_groups=(world, rank))
+        keep = torch.cat(gather_detections(mine[:, None], group), 0)[:, 0].sort()[0]
+        kept = allrows[keep]
+    else:
+        kept, keep = merge_detections(allrows, iou_thr, num_classes, class_thrs, nms_fn, strict)
+    mark('merge')
     return kept, keep, allrows
+
+
+def local_patch_nms(dets, labels, patch_index, iou_thr, num_classes, nms_fn=None):
+    """The per-patch, per-class NMS every rank applies to its own detections before the
+    exchange (what the detector's ``multiclass_*nms`` does image by image,
+    rbbox_head.py:287-295) -- all patches of the rank in ONE grouped launch
+    (group = patch * num_classes + label).
+
+    Args:
+        dets (Tensor): (n, 6) theta-OBBs + score, patch coordinates.
+        labels, patch_index (Tensor): (n,) class and global patch number of each row.
+    Returns:
+        keep indices (ascending) into ``dets``.
+    """
+    if dets.size(0) == 0:
+        return torch.zeros(0, dtype=torch.long, device=dets.device)
+    nms_fn = nms_fn or nms_wrapper.rnms
+    _, keep = nms_fn(dets, iou_thr, groups=patch_index.long() * int(num_classes) + labels.long())
+    return torch.as_tensor(keep, device=dets.device)
+
+
+def patch_rows_to_image(dets, labels, patch_index, patch_xy, patch_image, rate=1.0):
+    """theta-OBB rows of many patches -> (n, 8) merge rows in image coordinates, vectorised
+    (``dota_io.patch_rows_to_image`` does one patch from its file name).
+
+    Args:
+        dets (Tensor): (n, 6) cx, cy, w, h, theta, score in patch pixels.
+        patch_index (Tensor): (n,) global patch number of each row.
+        patch_xy (Tensor): (P, 2) left/top of every patch; patch_image (P,) its image id.
+    """
+    off = patch_xy[patch_index]
+    out = dets.new_empty((dets.size(0), 8))
+    out[:, 0:2] = (dets[:, 0:2] + off) / rate
+    out[:, 2:4] = dets[:, 2:4] / rate
+    out[:, 4:6] = dets[:, 4:6]
+    out[:, 6] = labels.to(out.dtype)
+    out[:, 7] = patch_image[patch_index].to(out.dtype)
+    return out
+
+
+def tiled_inference_merge(dets, labels, patch_index, seq, patch_xy, patch_image, num_classes,
+                          local_thr=0.5, merge_thr=0.3, class_thrs=None, group=None,
+                          layout='replicated', nms_fn=None, mark=None):
+    """One pass of BASELINE.json configs[4] over this rank's patches:
+
+        per-patch, per-class rotated NMS of the local detections (one grouped launch)
+        -> image coordinates -> all-gather over RCCL -> merged per-(image, class) NMS
+
+    ``mark(name)`` (optional) is called between the phases ('local', 'gather', 'merge'), e.g.
+    to record HIP events.  Returns ``distributed_merge``'s triple."""
+    mark = mark or (lambda name: None)
+    keep = local_patch_nms(dets, labels, patch_index, local_thr, num_classes, nms_fn)
+    rows = patch_rows_to_image(dets[keep], labels[keep], patch_index[keep], patch_xy, patch_image)
+    mark('local')
+    return distributed_merge(rows, merge_thr, num_classes, class_thrs, group, nms_fn, seq[keep],
+                             layout, mark=mark)

@@ -52,7 +52,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, ties, out):
+def _worker(rank, world, port, ties, layout, out):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -64,18 +64,18 @@ def _worker(rank, world, port, ties, out):
         local = torch.cat(rows, 0) if rows else torch.zeros((0, 8))
         seq = torch.cat(seq, 0) if seq else torch.zeros((0,), dtype=torch.int64)
         kept, keep, allrows = dota_merge.distributed_merge(
-            local, 0.3, NUM_CLASSES, class_thrs=CLASS_THRS, nms_fn=oracle_nms, seq=seq)
+            local, 0.3, NUM_CLASSES, class_thrs=CLASS_THRS, nms_fn=oracle_nms, seq=seq, layout=layout)
         out[rank] = (kept.numpy(), keep.numpy(), allrows.numpy())
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('ties', [False, True])
-def test_two_rank_merge_equals_single_process(ties):
-    world = 2
+@pytest.mark.parametrize('ties,layout,world', [(False, 'replicated', 2), (True, 'replicated', 2),
+                                               (True, 'sharded', 2), (False, 'sharded', 3)])
+def test_multi_rank_merge_equals_single_process(ties, layout, world):
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), ties, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), ties, layout, out), nprocs=world, join=True)
     patches = make_patches(11, 7, ties)
     single = torch.from_numpy(np.concatenate(patches, 0))
     ref_kept, ref_keep = dota_merge.merge_detections(single, 0.3, NUM_CLASSES, CLASS_THRS,
@@ -112,6 +112,82 @@ def test_single_process_without_process_group():
     assert kept.shape == (0, 8) and keep.numel() == 0
 
 
+def test_merge_row_layouts_polygon_and_horizontal():
+    """11-column polygon rows (Task1 text rows) and 7-column horizontal rows (Task2 /
+    mergebyrec, dota.py:300,334) go through poly_nms / nms with the same grouping."""
+    from aidet_amd import dota_io
+    r = np.concatenate(make_patches(6, 5), 0)
+    poly = np.concatenate([oracle.rbox_to_poly(r).astype(np.float32), r[:, 5:8]], 1)
+
+    def poly_fn(d, thr, groups=None, thrs=None):
+        k = torch.from_numpy(oracle.poly_nms(d.numpy(), thr, groups=groups.numpy(), thrs=thrs.numpy()))
+        return d[k], k
+
+    def hbb_fn(d, thr, groups=None, thrs=None, strict=False):
+        assert thrs is None or len(set(thrs.tolist())) == 1      # (the oracle's HBB loop takes one threshold)
+        k = torch.from_numpy(oracle.hbb_nms(d.numpy(), thr if thrs is None else float(thrs[0]),
+                                            groups=groups.numpy(), strict=strict))
+        return d[k], k
+    _, keep_p = dota_merge.merge_detections(torch.from_numpy(poly), 0.3, NUM_CLASSES, CLASS_THRS, nms_fn=poly_fn)
+    _, keep_r = dota_merge.merge_detections(torch.from_numpy(r), 0.3, NUM_CLASSES, CLASS_THRS, nms_fn=oracle_nms)
+    assert np.array_equal(keep_p.numpy(), keep_r.numpy())        # same boxes, two encodings
+    hb = np.stack([r[:, 0] - r[:, 2] / 2, r[:, 1] - r[:, 3] / 2, r[:, 0] + r[:, 2] / 2, r[:, 1] + r[:, 3] / 2,
+                   r[:, 5], r[:, 6], r[:, 7]], 1).astype(np.float32)
+    kept, keep_h = dota_merge.merge_detections(torch.from_numpy(hb), 0.3, NUM_CLASSES, nms_fn=hbb_fn)
+    want = []
+    for img in (0, 1):
+        for c in range(NUM_CLASSES):
+            idx = np.nonzero((hb[:, 6] == img) & (hb[:, 5] == c))[0]
+            if len(idx):
+                want.append(idx[oracle.hbb_nms(hb[idx, :5], 0.3)])
+    assert np.array_equal(keep_h.numpy(), np.sort(np.concatenate(want))) and kept.shape[1] == 7
+    _, keep_s = dota_merge.merge_detections(torch.from_numpy(hb), 0.3, NUM_CLASSES, nms_fn=hbb_fn, strict=True)
+    assert len(keep_s) >= len(keep_h)
+    with pytest.raises(ValueError):
+        dota_merge.merge_detections(torch.zeros((3, 9)), 0.3, NUM_CLASSES, nms_fn=oracle_nms)
+    assert dota_io.class_thresholds(task='hbb')[4] == 0.1 and dota_io.class_thresholds(task='obb')[4] == 0.35
+
+
+def test_text_round_trip_quantisation_is_exact():
+    """quantize_text == float('%.1f' % v) for every fp32 v (what dota.py:304 does to the
+    numbers the external merge reads), incl. the decimal ties fp32 can hit."""
+    from aidet_amd import dota_io
+    rng = np.random.default_rng(0)
+    v = np.concatenate([rng.uniform(-50, 1100, 20000), rng.integers(-2000, 22000, 4000) / 20.0,
+                        rng.integers(0, 4000, 2000) / 8.0, [0.05, 0.15, 0.25, 0.35, 1023.95, -0.05, 0.0]]).astype(np.float32)
+    got = dota_io.quantize_text(torch.from_numpy(v), 1).numpy()
+    want = np.array([np.float32(float('%.1f' % x)) for x in v.tolist()], np.float32)
+    assert np.array_equal(got, want)
+    s = rng.uniform(0, 1, 5000).astype(np.float32)
+    got = dota_io.quantize_text(torch.from_numpy(s), 3).numpy()
+    assert np.array_equal(got, np.array([np.float32(float('%.3f' % x)) for x in s.tolist()], np.float32))
+
+
+def test_polygon_and_box_rows_files_and_storage_tank(tmp_path):
+    from aidet_amd import dota_io
+    ids = {}
+    tank = dota_io.DOTA_CLASSES.index('storage-tank')
+    polys = torch.tensor([[10.04, 20.06, 30.0, 20.0, 30.0, 40.0, 10.0, 40.0], [1., 2., 5., 2., 5., 9., 1., 9.]])
+    bboxes = torch.tensor([[9.96, 19.0, 31.0, 41.0], [0., 0., 6., 10.]])
+    labels = torch.tensor([tank, 1])
+    rows = dota_io.patch_polys_to_image(polys, torch.tensor([0.91234, 0.5]), labels, 'P1__1__100___200', ids,
+                                        quantize=True, bboxes=bboxes, storage_tank_as_hbb=True)
+    assert rows.shape == (2, 11) and ids == {'P1': 0}
+    # the storage tank's polygon is its (quantised) horizontal box, dota.py:302-303
+    assert torch.allclose(rows[0, :8], torch.tensor([110.0, 219.0, 131.0, 219.0, 131.0, 241.0, 110.0, 241.0]))
+    assert abs(float(rows[0, 8]) - 0.912) < 1e-7 and rows[0, 9] == tank
+    assert torch.allclose(rows[1, :8], torch.tensor([101., 202., 105., 202., 105., 209., 101., 209.]))
+    hb = dota_io.patch_bboxes_to_image(bboxes, torch.tensor([0.9, 0.5]), labels, 'P1__0.5__100___200', ids, quantize=True)
+    assert torch.allclose(hb[0, :4], torch.tensor([220.0, 438.0, 262.0, 482.0])) and hb.shape == (2, 7)
+    c1 = dota_io.write_task1(str(tmp_path), rows, None, ['P1'])
+    c2 = dota_io.write_task2(str(tmp_path), hb, ['P1'])
+    assert c1['storage-tank'] == 1 and c2['ship'] == 1
+    l1 = open(os.path.join(str(tmp_path), 'Task1_storage-tank.txt')).read().split()
+    assert l1[:3] == ['P1', '0.912', '110.0'] and len(l1) == 10
+    l2 = open(os.path.join(str(tmp_path), 'Task2_ship.txt')).read().split()
+    assert l2 == ['P1', '0.500', '200.0', '400.0', '212.0', '420.0']
+
+
 def test_shard_patches_is_rank_strided():
     assert dota_merge.shard_patches(10, 1, 4) == [1, 5, 9]
     got = sorted(sum((dota_merge.shard_patches(10, r, 4) for r in range(4)), []))
@@ -139,3 +215,59 @@ def test_dota_io_names_rows_and_files(tmp_path):
     line = open(os.path.join(str(tmp_path), 'Task1_ship.txt')).read().split()
     assert line[0] == 'P7' and line[1] == '0.900' and len(line) == 10
     assert all(re_.match(r'^-?\d+\.\d$', v) for v in line[2:])
+
+
+# ---- configs[4] as one function: per-patch NMS -> image coords -> gather -> merged NMS ---------
+def _tiled_inputs(rank, world):
+    import workloads
+    scene = workloads.tiled_scene(images=2, image_size=2048, objects_per_image=1500, num_classes=NUM_CLASSES, seed=5)
+    P = len(scene['patch_name'])
+    idx = np.nonzero(np.isin(scene['patch'], np.asarray(dota_merge.shard_patches(P, rank, world))))[0]
+    f = lambda a: torch.from_numpy(a)
+    return (f(scene['dets'][idx]), f(scene['label'][idx]), f(scene['patch'][idx]), f(idx.astype(np.int64)),
+            f(scene['patch_xy']), f(scene['patch_image'])), scene
+
+
+def _tiled_worker(rank, world, port, layout, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        args, _ = _tiled_inputs(rank, world)
+        kept, keep, allrows = dota_merge.tiled_inference_merge(*args, NUM_CLASSES, 0.5, 0.3, CLASS_THRS,
+                                                               layout=layout, nms_fn=oracle_nms)
+        out[rank] = (kept.numpy(), keep.numpy(), allrows.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('layout', ['replicated', 'sharded'])
+def test_tiled_inference_merge_two_ranks_equal_one(layout):
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_tiled_worker, args=(world, _free_port(), layout, out), nprocs=world, join=True)
+    args, scene = _tiled_inputs(0, 1)
+    marks = []
+    kept, keep, allrows = dota_merge.tiled_inference_merge(*args, NUM_CLASSES, 0.5, 0.3, CLASS_THRS,
+                                                           nms_fn=oracle_nms, mark=marks.append)
+    assert marks == ['local', 'gather', 'merge']
+    for r in range(world):
+        assert np.array_equal(out[r][2], allrows.numpy())
+        assert np.array_equal(out[r][1], keep.numpy()) and np.array_equal(out[r][0], kept.numpy())
+    # the overlap bands really produce duplicates, and the merge removes them
+    n = len(scene['dets'])
+    assert len(allrows) <= n and 0.3 * n < len(keep) < 0.95 * len(allrows)
+    # image coordinates: every kept centre lies inside its image
+    assert float(kept[:, 0].min()) > -5 and float(kept[:, 0].max()) < 2048 + 5
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    """`--gpus N` must not be silently ignored.  (Fails before torch is imported.)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RANK='0', WORLD_SIZE='1')
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '4'], env=env,
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and 'disagree' in r.stderr

@@ -986,3 +986,34 @@ def test_multiclass_nms_reference_golden_on_gpu(golden):
     det, lab = multiclass_nms(t(g['multi_bboxes']), t(g['multi_scores']), float(g['score_thr']),
                               dict(type='soft_nms', iou_thr=0.5, min_score=0.05), 100)
     assert det.shape[1] == 5 and len(det) == len(lab) <= 100
+
+
+def test_tiled_inference_merge_hip_equals_oracle_ops():
+    """configs[4] on one GPU with the HIP rnms vs the same function with the oracle's op."""
+    from aidet_amd import dota_io, dota_merge
+    from test_dist_merge import _tiled_inputs, oracle_nms, NUM_CLASSES, CLASS_THRS
+    args, _ = _tiled_inputs(0, 1)
+    kept, keep, allrows = dota_merge.tiled_inference_merge(*[a.cuda() for a in args], NUM_CLASSES, 0.5, 0.3, CLASS_THRS)
+    rk, rkeep, rall = dota_merge.tiled_inference_merge(*args, NUM_CLASSES, 0.5, 0.3, CLASS_THRS, nms_fn=oracle_nms)
+    assert np.array_equal(allrows.cpu().numpy(), rall.numpy())
+    assert np.array_equal(keep.cpu().numpy(), rkeep.numpy())
+
+
+def test_bench_distributed_path_runs_on_one_gpu():
+    """`bench.py` N > 1 code path (RCCL process group, all_gather_into_tensor, merged NMS, the
+    single-rank cross-check) forced onto one GPU: what an 8-GPU SCALE run would time."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OBB_BENCH_FORCE_DIST='1', RANK='0', WORLD_SIZE='1', LOCAL_RANK='0',
+               MASTER_ADDR='127.0.0.1', MASTER_PORT='29533')
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1'],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
+    j = json.loads(line)
+    assert j['scaling'] == 'strong' and j['rccl_ranks'] == 1 and j['n_gpus'] == 1
+    assert j['keep_equals_single_rank_run'] is True and j['same_keep_on_all_ranks'] is True
+    assert j['value'] > 1e7 and set(j['phases_rank0']) == {'local_nms_us', 'gather_us', 'merge_us'}
