@@ -162,6 +162,8 @@ def distributed_merge(local, iou_thr, num_classes, class_thrs=None, group=None, 
         raise ValueError('layout must be "replicated" or "sharded"')
     mark = mark or (lambda name: None)
     ncols = local.size(1)
+    if seq is not None and _world(group)[0] == 1:
+        seq = None      # one rank: the local rows ARE the single-process order
     if seq is not None:
         # sequence numbers travel as two float32 columns (hi, lo) to stay exact
         s64 = seq.to(torch.int64)
