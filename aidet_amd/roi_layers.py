@@ -100,6 +100,70 @@ class RoIAlign(nn.Module):
             self.use_torchvision, self.aligned)
 
 
+class SingleRoIExtractor(nn.Module):
+    """``SingleRoIExtractor`` of mmdet/models/roi_extractors/single_level.py:11-107 for horizontal
+    (K, 5) RoIs: every RoI is pooled from the ONE pyramid level its scale selects
+    (``floor(log2(sqrt(w * h) / finest_scale + 1e-6))``, +1 pixel widths, :69-73).
+
+    The reference builds its layers with ``getattr(ops, type)(spatial_scale=1/s, **cfg)``
+    (:45-52); here ``type`` is looked up among this module's layers (RoIAlign, RRoIAlign).
+    """
+
+    def __init__(self, roi_layer, out_channels, featmap_strides, finest_scale=56):
+        super(SingleRoIExtractor, self).__init__()
+        cfg = dict(roi_layer)
+        layer_cls = {'RoIAlign': RoIAlign, 'RRoIAlign': RRoIAlign}[cfg.pop('type', 'RoIAlign')]
+        self.roi_layers = nn.ModuleList([layer_cls(spatial_scale=1 / s, **cfg) for s in featmap_strides])
+        self.out_channels = out_channels
+        self.featmap_strides = featmap_strides
+        self.finest_scale = finest_scale
+
+    @property
+    def num_inputs(self):
+        return len(self.featmap_strides)
+
+    def init_weights(self):
+        pass
+
+    def map_roi_levels(self, rois, num_levels):
+        scale = torch.sqrt((rois[:, 3] - rois[:, 1] + 1) * (rois[:, 4] - rois[:, 2] + 1))
+        target_lvls = torch.floor(torch.log2(scale / self.finest_scale + 1e-6))
+        return target_lvls.clamp(min=0, max=num_levels - 1).long()
+
+    def roi_rescale(self, rois, scale_factor):
+        """grow / shrink every RoI about its centre (single_level.py:75-87)."""
+        cx, cy = (rois[:, 1] + rois[:, 3]) * 0.5, (rois[:, 2] + rois[:, 4]) * 0.5
+        new_w = (rois[:, 3] - rois[:, 1] + 1) * scale_factor
+        new_h = (rois[:, 4] - rois[:, 2] + 1) * scale_factor
+        return torch.stack((rois[:, 0], cx - new_w * 0.5 + 0.5, cy - new_h * 0.5 + 0.5,
+                            cx + new_w * 0.5 - 0.5, cy + new_h * 0.5 - 0.5), dim=-1)
+
+    def forward(self, feats, rois, roi_scale_factor=None):
+        feats = [f.float() for f in feats]   # force_fp32(apply_to=('feats',)), single_level.py:89
+        if len(feats) == 1:
+            return self.roi_layers[0](feats[0], rois)
+        out_size = self.roi_layers[0].out_size
+        target_lvls = self.map_roi_levels(rois, len(feats))
+        if roi_scale_factor is not None:
+            rois = self.roi_rescale(rois, roi_scale_factor)
+        # one pass over the levels with the RoIs grouped by level (a stable sort and ONE host
+        # read of the level sizes) instead of a boolean mask, a gather and a scatter per level
+        order = torch.argsort(target_lvls, stable=True)
+        sizes = torch.bincount(target_lvls, minlength=len(feats)).tolist()
+        sorted_rois = rois[order]
+        parts, start = [], 0
+        for i, n in enumerate(sizes):
+            if n:
+                parts.append(self.roi_layers[i](feats[i], sorted_rois[start:start + n]))
+            start += n
+        if not parts:
+            return feats[0].new_zeros(0, self.out_channels, *out_size)
+        roi_feats = torch.cat(parts, 0)
+        out = torch.empty_like(roi_feats)
+        out[order] = roi_feats
+        return out
+
+
 class RotatedSingleRoIExtractor(nn.Module):
     """Extract rotated RoI features from a single level chosen by RoI scale."""
 
