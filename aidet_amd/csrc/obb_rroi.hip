@@ -206,11 +206,12 @@ __device__ __forceinline__ void rroi_forward_direct(const float *__restrict__ fe
 
 // ---- staged kernels: shared pieces ---------------------------------------------------------
 #ifndef OBB_STAGE_FLOATS
-#define OBB_STAGE_FLOATS 6144
+#define OBB_STAGE_FLOATS 5120
 #endif
-constexpr int kStageFloats = OBB_STAGE_FLOATS;  // input tile [pixel][channel + 1] (24 KiB)
+constexpr int kStageFloats = OBB_STAGE_FLOATS;  // input tile [channel][odd pitch] (20 KiB)
 constexpr int kMaxTabSamples = 256;   // sample table (8 KiB); 7x7 bins x 2x2 samples = 196
-constexpr int kMaxBins = 64;          // bins of a staged RoI (output tile 64 x 65 floats)
+constexpr int kMaxBins = 64;          // bins of a staged RoI
+constexpr int kMaxPassChan = 32;      // channels per staging pass (output tile 32 x 65 floats)
 constexpr int kBinPitchMax = 65;
 
 struct Footprint { int x0, y0, w, h; };
@@ -248,17 +249,17 @@ __device__ __forceinline__ bool block_to_work(int K, int chunks, int64_t &k, int
   return chunk < chunks;
 }
 
-// channels per staging pass: the largest power of two <= 64 whose tile fits, not (much) more
-// than the block owns
-__device__ __forceinline__ int pass_channels(int fsz, int owned) {
-  int cb = 64;
-  while (cb > 1 && (fsz * (cb + 1) > kStageFloats || (cb >> 1) >= owned)) cb >>= 1;
+// channels per staging pass: the largest power of two <= kMaxPassChan whose planes fit the
+// tile (odd pitch per plane), not (much) more than the block owns
+__device__ __forceinline__ int pass_channels(int cpitch, int owned) {
+  int cb = kMaxPassChan;
+  while (cb > 1 && (cpitch * cb > kStageFloats || (cb >> 1) >= owned)) cb >>= 1;
   return cb;
 }
 
-// sample table: tap offsets (pixel index in the footprint x pitch) and weights, once per block
+// sample table: footprint-local tap offsets and weights, once per block
 __device__ __forceinline__ void build_table(const RoiFrame &f, const Footprint &fp, int H, int W, int pw,
-                                            int spb, int nsamp, int pitch, int4 *s_off, float4 *s_wgt) {
+                                            int spb, int nsamp, int4 *s_off, float4 *s_wgt) {
   for (int sidx = threadIdx.x; sidx < nsamp; sidx += 256) {
     const int bin = sidx / spb, q = sidx - bin * spb;
     const int bi = bin / pw, bj = bin - bi * pw;
@@ -271,22 +272,34 @@ __device__ __forceinline__ void build_table(const RoiFrame &f, const Footprint &
     auto cl = [](int v, int n) { return v < 0 ? 0 : (v >= n ? n - 1 : v); };
     const int ly0 = cl(yl - fp.y0, fp.h) * fp.w, ly1 = cl(yh - fp.y0, fp.h) * fp.w;
     const int lx0 = cl(xl - fp.x0, fp.w), lx1 = cl(xh - fp.x0, fp.w);
-    s_off[sidx] = live ? make_int4((ly0 + lx0) * pitch, (ly0 + lx1) * pitch, (ly1 + lx0) * pitch, (ly1 + lx1) * pitch)
-                       : make_int4(0, 0, 0, 0);
+    s_off[sidx] = live ? make_int4(ly0 + lx0, ly0 + lx1, ly1 + lx0, ly1 + lx1) : make_int4(0, 0, 0, 0);
     s_wgt[sidx] = make_float4(w[0], w[1], w[2], w[3]);
   }
 }
 
-// ---- forward, staged -----------------------------------------------------------------------
-// grid: (K x channel chunks, XCD-aware order); block: 256 threads.
+// ---- forward, staged ---------------------------------------------------------------------
+// grid: (K x channel chunks, XCD-aware order); block: 256 threads; item = (channel group, bin).
+// The RoI's footprint (the axis-aligned pixel box that contains every bilinear tap of every
+// sample) of each channel plane is first copied into LDS by LDS-DMA (16 bytes per lane where
+// the rows allow it: 1 KiB per wave-instruction, nothing passes through VGPRs); the ~4 x
+// samples x channels taps are then LDS gathers instead of scattered 4-byte global loads.
+// Values and operation order are unchanged.
+// (A variant with a transposed tile -- lane = (bin, channel), bank-conflict free, every lane
+// busy -- was built and measured this round: 71 us against 50 us for this one at configs[2].
+// It needs dword DMA or register staging for the odd pitch, i.e. 4x the staging instructions,
+// and a table read per tap group)
+constexpr int kFwdStageFloats = 6144;               // LDS tile per block (24 KiB)
+constexpr int kWaveFloats = kFwdStageFloats / 4;    // private quarter of a wave (small footprints)
+constexpr int kWavePad = 256;                       // room for the tail lanes of a wave's last DMA instruction
+
+template <bool X4>
 __global__ __launch_bounds__(256) void rroi_forward_kernel(
     const float *__restrict__ feat, int B, int C, int H, int W, const float *__restrict__ rois,
     int ph, int pw, float scale, int sample_num, float min_size, int chan_per_block,
     int K, int chunks, int roi_kind, float *__restrict__ out) {
-  __shared__ float tile[kStageFloats];
-  __shared__ int4 s_off[kMaxTabSamples];
-  __shared__ float4 s_wgt[kMaxTabSamples];
-  __shared__ float otile[64 * kBinPitchMax];
+  __shared__ __attribute__((aligned(16))) float tile[4 * (kWaveFloats + kWavePad)];  // block-wide: kFwdStageFloats + pad
+  __shared__ int4 s_off[kMaxTabSamples];      // per sample: 4 footprint-local tap offsets
+  __shared__ float4 s_wgt[kMaxTabSamples];    // per sample: 4 bilinear weights
   int64_t k;
   int chunk;
   if (!block_to_work(K, chunks, k, chunk)) return;
@@ -296,74 +309,181 @@ __global__ __launch_bounds__(256) void rroi_forward_kernel(
   const int c_block = chunk * chan_per_block;
   const int c_end = min(C, c_block + chan_per_block);
   const int64_t plane = (int64_t)H * W;
-  float *oblk = out + (k * C + c_block) * (int64_t)nb;       // this block's outputs are contiguous
-  const int nout = (c_end - c_block) * nb;
   const long long spb64 = (long long)f.gh * f.gw;
   if (f.b < 0 || f.b >= B || spb64 <= 0) {
     // invalid batch index: zeros.  Empty sampling grid: the sum of nothing over the count --
     // 0 (V2, rotated) or 0/0 = NaN (V1 divides by gh*gw, roi_align_kernel.cu:113)
     const float v = (f.b < 0 || f.b >= B) ? 0.0f : 0.0f / f.cnt;
-    for (int it = threadIdx.x; it < nout; it += 256) oblk[it] = v;
+    for (int it = threadIdx.x; it < (c_end - c_block) * nb; it += 256)
+      out[(k * C + c_block) * (int64_t)nb + it] = v;
     return;
   }
-  const Footprint fp = roi_footprint(f, H, W);
-  const int fsz = fp.w * fp.h;                       // pixels per channel plane
+  Footprint fp = roi_footprint(f, H, W);
+  if (X4) {  // 16-byte LDS-DMA: rows start and end on multiples of 4 floats (W % 4 == 0)
+    const int x1 = (fp.x0 + fp.w - 1) | 3;
+    fp.x0 &= ~3;
+    fp.w = x1 - fp.x0 + 1;
+  }
+  const int fsz = fp.w * fp.h;                       // floats per channel plane
   const int spb = (int)(spb64 > kMaxTabSamples ? kMaxTabSamples + 1 : spb64);   // samples per bin
   const int nsamp = nb * spb;
   // block-uniform: huge RoI / huge sampling grid / >2^31-element tensors gather directly
-  if (2 * fsz > kStageFloats || nb > kMaxBins || nsamp > kMaxTabSamples || (int64_t)B * C * plane >= (1ll << 31)) {
+  if (fsz > kFwdStageFloats || nsamp > kMaxTabSamples || (int64_t)B * C * plane >= (1ll << 31)) {
     rroi_forward_direct(feat, C, H, W, f, k, ph, pw, c_block, c_end, out);
     return;
   }
-  const int cb = pass_channels(fsz, c_end - c_block);  // channels per pass (power of two)
-  const int pitch = cb + 1;
-  build_table(f, fp, H, W, pw, spb, nsamp, pitch, s_off, s_wgt);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int lc = lane & (cb - 1);                    // channel of this lane inside the pass
-  const int bsub = lane / cb, bpw = 64 / cb;         // bin slot of this lane, bins per wave step
-  const int nbp = nb | 1;                            // odd pitch of the output tile
-  const uint32_t m_fsz = fsz > 1 ? 0xFFFFFFFFu / (uint32_t)fsz + 1u : 0u;   // exact idx / fsz for idx < 2^16
-  const uint32_t m_w = fp.w > 1 ? 0xFFFFFFFFu / (uint32_t)fp.w + 1u : 0u;
-  const uint32_t m_nb = nb > 1 ? 0xFFFFFFFFu / (uint32_t)nb + 1u : 0u;
-  for (int cp = c_block; cp < c_end; cp += cb) {
-    const int nch = min(cb, c_end - cp);
-    // stage nch footprints, transposed: consecutive threads read consecutive x of a row
-    const float *src = feat + ((int64_t)f.b * C + cp) * plane + (int64_t)fp.y0 * W + fp.x0;
-    const int total = nch * fsz;
-    for (int idx = threadIdx.x; idx < total; idx += 256) {
-      const uint32_t c = fsz > 1 ? __umulhi((uint32_t)idx, m_fsz) : (uint32_t)idx;
-      const uint32_t p = (uint32_t)idx - c * (uint32_t)fsz;
-      const uint32_t y = fp.w > 1 ? __umulhi(p, m_w) : p;
-      const uint32_t x = p - y * (uint32_t)fp.w;
-      tile[p * (uint32_t)pitch + c] = src[(int64_t)c * plane + (int64_t)y * W + x];
+  // sample table: coordinates, taps and weights are computed ONCE per RoI and block
+  // (the reference recomputes them for every output element, roi_align_kernel.cu:70-113)
+  for (int sidx = threadIdx.x; sidx < nsamp; sidx += 256) {
+    const int bin = sidx / spb, q = sidx - bin * spb;
+    const int bi = bin / pw, bj = bin - bi * pw;
+    const int iy = q / f.gw, ix = q - iy * f.gw;
+    float x, y, w[4];
+    int yl, xl, yh, xh;
+    sample_xy(f, bi, bj, iy, ix, x, y);
+    const bool live = bilinear_taps_xy(H, W, y, x, yl, xl, yh, xh, w);
+    // tap coordinates -> footprint-local offsets (clamped: never out of the tile)
+    auto cl = [](int v, int n) { return v < 0 ? 0 : (v >= n ? n - 1 : v); };
+    const int ly0 = cl(yl - fp.y0, fp.h) * fp.w, ly1 = cl(yh - fp.y0, fp.h) * fp.w;
+    const int lx0 = cl(xl - fp.x0, fp.w), lx1 = cl(xh - fp.x0, fp.w);
+    s_off[sidx] = live ? make_int4(ly0 + lx0, ly0 + lx1, ly1 + lx0, ly1 + lx1) : make_int4(0, 0, 0, 0);
+    s_wgt[sidx] = make_float4(w[0], w[1], w[2], w[3]);
+  }
+  if (fsz <= kWaveFloats && nb <= 64 && spb <= 4) {
+    // ---- small footprint (the common case): every WAVE stages and reduces its own quarter of
+    // the block's channels in a private LDS region -- no block barriers after this one, so
+    // the four waves (and the other blocks of the CU) drift apart and one wave's DMA latency
+    // hides behind another's gathers.  A lane owns one bin: its <= 4 samples' tap offsets
+    // and weights are read from the table ONCE into registers and reused for every channel.
+    __syncthreads();   // table complete
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float *wt = tile + wave * (kWaveFloats + kWavePad);
+    const int per_wave = (c_end - c_block + 3) >> 2;
+    const int cw0 = c_block + wave * per_wave, cw1 = min(c_end, cw0 + per_wave);
+    int4 so[4];
+    float4 sw[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const bool on = lane < nb && q < spb;
+      so[q] = on ? s_off[lane * spb + q] : make_int4(0, 0, 0, 0);
+      sw[q] = on ? s_wgt[lane * spb + q] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    __syncthreads();   // tile (and, in the first pass, the table) complete
-    for (int bin0 = wave * bpw; bin0 < nb; bin0 += 4 * bpw) {
-      const int bin = bin0 + bsub;
-      const bool on = bin < nb && lc < nch;
-      const int tb = (bin < nb ? bin : nb - 1) * spb;
-      const float *p = tile + lc;
-      float acc = 0.0f;
-      for (int q = 0; q < spb; ++q) {
-        const int4 o = s_off[tb + q];
-        const float4 w = s_wgt[tb + q];
-        float v = w.x * p[o.x];
-        v = v + w.y * p[o.y];
-        v = v + w.z * p[o.z];
-        v = v + w.w * p[o.w];
-        acc = acc + v;
+    const int cpw = kWaveFloats / fsz;               // channels per pass (>= 1)
+    const uint32_t plane32w = (uint32_t)plane;
+    for (int cp = cw0; cp < cw1; cp += cpw) {
+      const int nch = min(cpw, cw1 - cp);
+      const float *src = feat + ((int64_t)f.b * C + cp) * plane + (int64_t)fp.y0 * W + fp.x0;
+      const int total = nch * fsz;
+      if (X4) {
+        const int q4 = fsz >> 2, rw4 = fp.w >> 2, total4 = total >> 2;
+        const uint32_t m_q4 = q4 > 1 ? 0xFFFFFFFFu / (uint32_t)q4 + 1u : 0u;
+        const uint32_t m_r4 = rw4 > 1 ? 0xFFFFFFFFu / (uint32_t)rw4 + 1u : 0u;
+        for (int base = 0; base < total4; base += 64) {
+          const uint32_t idx = (uint32_t)min(base + lane, total4 - 1);
+          const uint32_t c = q4 > 1 ? __umulhi(idx, m_q4) : idx;
+          const uint32_t r = idx - c * (uint32_t)q4;
+          const uint32_t y = rw4 > 1 ? __umulhi(r, m_r4) : r;
+          const uint32_t x = (r - y * (uint32_t)rw4) << 2;
+          const uint32_t off = c * plane32w + y * (uint32_t)W + x;
+          __builtin_amdgcn_global_load_lds(src + off, (__attribute__((address_space(3))) void *)(wt + base * 4), 16, 0, 0);
+        }
+      } else {
+        const uint32_t m_fszw = fsz > 1 ? 0xFFFFFFFFu / (uint32_t)fsz + 1u : 0u;
+        const uint32_t m_ww = fp.w > 1 ? 0xFFFFFFFFu / (uint32_t)fp.w + 1u : 0u;
+        for (int base = 0; base < total; base += 64) {
+          const uint32_t idx = (uint32_t)min(base + lane, total - 1);
+          const uint32_t c = fsz > 1 ? __umulhi(idx, m_fszw) : idx;
+          const uint32_t r = idx - c * (uint32_t)fsz;
+          const uint32_t y = fp.w > 1 ? __umulhi(r, m_ww) : r;
+          const uint32_t x = r - y * (uint32_t)fp.w;
+          const uint32_t off = c * plane32w + y * (uint32_t)W + x;
+          __builtin_amdgcn_global_load_lds(src + off, (__attribute__((address_space(3))) void *)(wt + base), 4, 0, 0);
+        }
       }
-      if (on) otile[lc * nbp + bin] = acc / f.cnt;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      for (int c = 0; c < nch; ++c) {
+        const float *p = wt + c * fsz;
+        float acc = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (q < spb) {
+            float v = sw[q].x * p[so[q].x];
+            v = v + sw[q].y * p[so[q].y];
+            v = v + sw[q].z * p[so[q].z];
+            v = v + sw[q].w * p[so[q].w];
+            acc = acc + v;
+          }
+        }
+        if (lane < nb) out[((k * C + cp + c) * (int64_t)nb) + lane] = acc / f.cnt;
+      }
+      // the next pass overwrites this region: its gathers are done (their values were consumed)
+      __builtin_amdgcn_wave_barrier();
+    }
+    return;
+  }
+  const int cpp = kFwdStageFloats / fsz;                // channels per pass (>= 1)
+  const uint32_t m_nb = nb > 1 ? 0xFFFFFFFFu / (uint32_t)nb + 1u : 0u;  // it / nb for it < 2^16
+  const uint32_t m_fsz = fsz > 1 ? 0xFFFFFFFFu / (uint32_t)fsz + 1u : 0u;
+  const uint32_t m_w = fp.w > 1 ? 0xFFFFFFFFu / (uint32_t)fp.w + 1u : 0u;
+  const uint32_t plane32 = (uint32_t)plane;
+  for (int cp = c_block; cp < c_end; cp += cpp) {
+    const int nch = min(cpp, c_end - cp);
+    // stage nch footprints with LDS-DMA (global_load_lds_dword): every lane supplies
+    // its own source address, a wave-instruction lands 64 consecutive floats in the
+    // tile, nothing passes through VGPRs and all loads are in flight together.
+    // flat index -> (channel, y, x) by exact multiply-high division (idx < 2^14);
+    // 32-bit element offsets from a uniform base.
+    const float *src = feat + ((int64_t)f.b * C + cp) * plane + (int64_t)fp.y0 * W + fp.x0;
+    {
+      const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+      const int total = nch * fsz;
+      if (X4) {
+        // 16 bytes per lane: one wave-instruction lands 1 KiB (64 chunks of 4 floats)
+        const int q4 = fsz >> 2, rw4 = fp.w >> 2, total4 = total >> 2;   // chunks per plane / row / pass
+        const uint32_t m_q4 = q4 > 1 ? 0xFFFFFFFFu / (uint32_t)q4 + 1u : 0u;
+        const uint32_t m_r4 = rw4 > 1 ? 0xFFFFFFFFu / (uint32_t)rw4 + 1u : 0u;
+        for (int base = wave * 64; base < total4; base += 256) {
+          const uint32_t idx = (uint32_t)min(base + lane, total4 - 1);
+          const uint32_t c = q4 > 1 ? __umulhi(idx, m_q4) : idx;
+          const uint32_t r = idx - c * (uint32_t)q4;
+          const uint32_t y = rw4 > 1 ? __umulhi(r, m_r4) : r;
+          const uint32_t x = (r - y * (uint32_t)rw4) << 2;
+          const uint32_t off = c * plane32 + y * (uint32_t)W + x;
+          __builtin_amdgcn_global_load_lds(src + off, (__attribute__((address_space(3))) void *)(tile + base * 4), 16, 0, 0);
+        }
+      } else {
+        for (int base = wave * 64; base < total; base += 256) {
+          const uint32_t idx = (uint32_t)min(base + lane, total - 1);  // tail lanes re-load the last float into the pad
+          const uint32_t c = fsz > 1 ? __umulhi(idx, m_fsz) : idx;
+          const uint32_t r = idx - c * (uint32_t)fsz;
+          const uint32_t y = fp.w > 1 ? __umulhi(r, m_w) : r;
+          const uint32_t x = r - y * (uint32_t)fp.w;
+          const uint32_t off = c * plane32 + y * (uint32_t)W + x;
+          __builtin_amdgcn_global_load_lds(src + off, (__attribute__((address_space(3))) void *)(tile + base), 4, 0, 0);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
-    // (channel, bin) order = the output's own order: one contiguous run per pass
-    float *dst = out + (k * C + cp) * (int64_t)nb;
-    for (int i = threadIdx.x; i < nch * nb; i += 256) {
-      const int c = nb > 1 ? (int)__umulhi((uint32_t)i, m_nb) : i, bin = i - c * nb;
-      dst[i] = otile[c * nbp + bin];
+    // one output element per item: consecutive threads = consecutive bins of a channel
+    // (coalesced stores); tap offsets / weights come from the block's sample table
+    for (int it = threadIdx.x; it < nch * nb; it += 256) {
+      const int c = nb > 1 ? (int)__umulhi((uint32_t)it, m_nb) : it, bin = it - c * nb;
+      const float *p = tile + c * fsz;
+      float acc = 0.0f;
+      for (int q = 0; q < spb; ++q) {
+        const int4 l = s_off[bin * spb + q];
+        const float4 w = s_wgt[bin * spb + q];
+        float v = w.x * p[l.x];
+        v = v + w.y * p[l.y];
+        v = v + w.z * p[l.z];
+        v = v + w.w * p[l.w];
+        acc = acc + v;
+      }
+      out[((k * C + cp + c) * (int64_t)nb) + bin] = acc / f.cnt;
     }
-    // no barrier here: the next pass writes `tile` (every thread is past the compute loop) and
-    // touches `otile` only after its own first barrier (every thread is past this loop)
+    __syncthreads();
   }
 }
 
@@ -410,19 +530,36 @@ __device__ __forceinline__ void rroi_backward_direct(const float *__restrict__ g
 }
 
 // ---- backward, staged -----------------------------------------------------------------------
-// Mirror image of the forward kernel: the gradient of a pass's channels is accumulated in the
-// transposed LDS tile (ds_add_f32; lane = (bin, channel), so the lanes of a bin add to
-// consecutive banks and taps that neighbouring bins share meet in LDS, not in L2), then the
-// touched pixels are added to the gradient map with global float atomics, in row segments of
-// consecutive addresses.  Float atomics commute only up to rounding: tolerance 1e-4 * max|g|.
+// The gradient of the map is a SCATTER of every output gradient to its 16 taps.  Scattering
+// with LDS float atomics (the obvious mirror of the forward kernel) measured ~3 clocks per
+// LANE on gfx950 -- 0.53 of the 0.59 ms this kernel used to take.  So the block turns the
+// scatter into a GATHER once per RoI:
+//   1. the sample table (as in the forward kernel) is inverted into a CSR list "pixel ->
+//      (bin, weight / count) of every tap that lands on it" -- integer LDS atomics for the counts and
+//      the slots, one block-wide scan; ~4 entries per pixel, 784 per RoI; done ONCE, it is
+//      the same for every channel;
+//   2. per pass over <= 32 channels: a lane is (pixel, channel), channel in the low lane
+//      bits; it walks its pixel's list and sums g[channel][bin] * w / count out of LDS
+//      (reads of consecutive channels = distinct banks), plain LDS store of the sum;
+//   3. the touched pixels are added to the gradient map with global float atomics, in row
+//      segments of consecutive addresses (RoIs overlap, so this part stays atomic).
+// The order in which a pixel's contributions are summed follows the slot order (atomic
+// tickets): results are reproducible to rounding only, like the reference's atomicAdd
+// backward (roi_align_kernel_v2.cu:179-263); tolerance 1e-4 * max|g|.
+constexpr int kBwdMaxPix = 1024;                       // footprint pixels of the staged backward
+constexpr int kBwdMaxEntries = 4 * kMaxTabSamples;     // taps of a RoI (4 per sample)
+
 __global__ __launch_bounds__(256) void rroi_backward_kernel(
     const float *__restrict__ gout, int B, int C, int H, int W, const float *__restrict__ rois,
     int ph, int pw, float scale, int sample_num, float min_size, int chan_per_block,
     int K, int chunks, int roi_kind, float *__restrict__ gfeat) {
-  __shared__ float tile[kStageFloats];
-  __shared__ int4 s_off[kMaxTabSamples];
-  __shared__ float4 s_wgt[kMaxTabSamples];
-  __shared__ float gtile[64 * kBinPitchMax];
+  __shared__ __attribute__((aligned(16))) float tile[kStageFloats];   // first the sample table, then sums [channel][pixel]
+  __shared__ int2 entry[kBwdMaxEntries];               // (bin, weight bits), grouped by pixel
+  __shared__ int pstart[kBwdMaxPix + 1];               // CSR offsets; during the build: counts
+  __shared__ int pfill[kBwdMaxPix];
+  __shared__ float gtile[kMaxPassChan * kBinPitchMax];
+  __shared__ int wsum[4];
+  static_assert(kStageFloats * 4 >= kMaxTabSamples * 32, "the sample table fits the tile it is built in");
   int64_t k;
   int chunk;
   if (!block_to_work(K, chunks, k, chunk)) return;
@@ -436,61 +573,116 @@ __global__ __launch_bounds__(256) void rroi_backward_kernel(
   const int64_t plane = (int64_t)H * W;
   const Footprint fp = roi_footprint(f, H, W);
   const int fsz = fp.w * fp.h;
+  const int cpitch = fsz | 1;
   const int spb = (int)(spb64 > kMaxTabSamples ? kMaxTabSamples + 1 : spb64);
   const int nsamp = nb * spb;
-  if (2 * fsz > kStageFloats || nb > kMaxBins || nsamp > kMaxTabSamples || (int64_t)B * C * plane >= (1ll << 31)) {
+  if (fsz > kBwdMaxPix || cpitch > kStageFloats || nb > kMaxBins || nsamp > kMaxTabSamples ||
+      (int64_t)B * C * plane >= (1ll << 31)) {
     rroi_backward_direct(gout, C, H, W, f, k, ph, pw, c_block, c_end, gfeat);
     return;
   }
-  const int cb = pass_channels(fsz, c_end - c_block);
-  const int pitch = cb + 1;
-  build_table(f, fp, H, W, pw, spb, nsamp, pitch, s_off, s_wgt);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // ---- 1. sample table (in the tile's memory) and its inverse
+  int4 *s_off = reinterpret_cast<int4 *>(tile);
+  float4 *s_wgt = reinterpret_cast<float4 *>(tile) + kMaxTabSamples;
+  for (int i = tid; i < fsz; i += 256) { pstart[i] = 0; pfill[i] = 0; }
+  build_table(f, fp, H, W, pw, spb, nsamp, s_off, s_wgt);
+  __syncthreads();
+  const int ntap = nsamp * 4;
+  auto tap_of = [&](int t, int &pix, float &w) {
+    const int sidx = t >> 2, j = t & 3;
+    const int4 o = s_off[sidx];
+    const float4 ww = s_wgt[sidx];
+    pix = j == 0 ? o.x : (j == 1 ? o.y : (j == 2 ? o.z : o.w));
+    w = j == 0 ? ww.x : (j == 1 ? ww.y : (j == 2 ? ww.z : ww.w));
+  };
+  for (int t = tid; t < ntap; t += 256) {
+    int pix;
+    float w;
+    tap_of(t, pix, w);
+    if (w != 0.0f) atomicAdd(&pstart[pix], 1);       // (a zero weight adds nothing, also in the direct kernel)
+  }
+  __syncthreads();
+  {  // exclusive scan of the counts (<= 1024 pixels: 4 per thread)
+    int c4[4], sum = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int i = tid * 4 + u; c4[u] = i < fsz ? pstart[i] : 0; sum += c4[u]; }
+    int inc = sum;
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o); if (lane >= o) inc += v; }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int base = inc - sum;
+    for (int w2 = 0; w2 < wave; ++w2) base += wsum[w2];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int i = tid * 4 + u; if (i < fsz) pstart[i] = base; base += c4[u]; }
+    if (tid == 255) pstart[fsz] = base;               // (tid 255 owns the last pixels: base = total)
+    __syncthreads();
+  }
+  for (int t = tid; t < ntap; t += 256) {
+    int pix;
+    float w;
+    tap_of(t, pix, w);
+    if (w != 0.0f) {
+      const int slot = pstart[pix] + atomicAdd(&pfill[pix], 1);
+      entry[slot] = make_int2(t / (4 * spb), __float_as_int(w / f.cnt));   // weight / count: one division per tap and RoI
+    }
+  }
+  __syncthreads();   // entries complete; the table in `tile` is dead from here on
+  // ---- 2. / 3. passes over the channels
+  const int cb = pass_channels(cpitch, c_end - c_block);
   const int lc = lane & (cb - 1);
-  const int bsub = lane / cb, bpw = 64 / cb;
+  const int psub = lane / cb, ppw = 64 / cb;         // pixel slot of this lane, pixels per wave step
   const int nbp = nb | 1;
-  const uint32_t m_fsz = fsz > 1 ? 0xFFFFFFFFu / (uint32_t)fsz + 1u : 0u;
+  const uint32_t m_cp = 0xFFFFFFFFu / (uint32_t)cpitch + 1u;
   const uint32_t m_w = fp.w > 1 ? 0xFFFFFFFFu / (uint32_t)fp.w + 1u : 0u;
   const uint32_t m_nb = nb > 1 ? 0xFFFFFFFFu / (uint32_t)nb + 1u : 0u;
   for (int cp = c_block; cp < c_end; cp += cb) {
     const int nch = min(cb, c_end - cp);
-    for (int i = threadIdx.x; i < fsz * pitch; i += 256) tile[i] = 0.0f;
     const float *gsrc = gout + (k * C + cp) * (int64_t)nb;   // contiguous (channel, bin) run
-    for (int i = threadIdx.x; i < nch * nb; i += 256) {
-      const int c = nb > 1 ? (int)__umulhi((uint32_t)i, m_nb) : i, bin = i - c * nb;
-      gtile[c * nbp + bin] = gsrc[i];
-    }
-    __syncthreads();
-    for (int bin0 = wave * bpw; bin0 < nb; bin0 += 4 * bpw) {
-      const int bin = bin0 + bsub;
-      if (bin < nb && lc < nch) {
-        const float g = gtile[lc * nbp + bin];
-        float *p = tile + lc;
-        for (int q = 0; q < spb; ++q) {
-          const int4 o = s_off[bin * spb + q];
-          const float4 w = s_wgt[bin * spb + q];
-          // same per-tap arithmetic as the direct kernel: (g * w) / count
-          atomicAdd(p + o.x, (g * w.x) / f.cnt);
-          atomicAdd(p + o.y, (g * w.y) / f.cnt);
-          atomicAdd(p + o.z, (g * w.z) / f.cnt);
-          atomicAdd(p + o.w, (g * w.w) / f.cnt);
+    const int gtot = nch * nb;
+    for (int base = 0; base < gtot; base += 256 * 4) {        // (4 loads in flight per thread)
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = gsrc[min(base + u * 256 + tid, gtot - 1)];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = base + u * 256 + tid;
+        if (i < gtot) {
+          const int c = nb > 1 ? (int)__umulhi((uint32_t)i, m_nb) : i, bin = i - c * nb;
+          gtile[c * nbp + bin] = v[u];
         }
       }
     }
     __syncthreads();
-    float *dst = gfeat + ((int64_t)f.b * C + cp) * plane + (int64_t)fp.y0 * W + fp.x0;
-    const int total = nch * fsz;
-    for (int idx = threadIdx.x; idx < total; idx += 256) {
-      const uint32_t c = fsz > 1 ? __umulhi((uint32_t)idx, m_fsz) : (uint32_t)idx;
-      const uint32_t p = (uint32_t)idx - c * (uint32_t)fsz;
-      const float v = tile[p * (uint32_t)pitch + c];
-      if (v != 0.0f) {
-        const uint32_t y = fp.w > 1 ? __umulhi(p, m_w) : p;
-        const uint32_t x = p - y * (uint32_t)fp.w;
-        atomicAdd(dst + (int64_t)c * plane + (int64_t)y * W + x, v);
+    const float *gl = gtile + lc * nbp;
+    for (int p0 = wave * ppw; p0 < fsz; p0 += 4 * ppw) {
+      const int pix = p0 + psub;
+      if (pix < fsz && lc < nch) {
+        const int e0 = pstart[pix], e1 = pstart[pix + 1];
+        float acc = 0.0f;
+        for (int e = e0; e < e1; ++e) {
+          const int2 en = entry[e];
+          acc = acc + gl[en.x] * __int_as_float(en.y);   // g * (w / count)
+        }
+        tile[lc * cpitch + pix] = acc;
       }
     }
-    __syncthreads();   // the next pass clears the tile
+    __syncthreads();
+    float *dst = gfeat + ((int64_t)f.b * C + cp) * plane + (int64_t)fp.y0 * W + fp.x0;
+    const int total = nch * cpitch;
+    for (int idx = tid; idx < total; idx += 256) {
+      const uint32_t c = cpitch > 1 ? __umulhi((uint32_t)idx, m_cp) : (uint32_t)idx;
+      const uint32_t p = (uint32_t)idx - c * (uint32_t)cpitch;
+      if (p < (uint32_t)fsz) {                        // (not the pitch's pad word)
+        const float v = tile[idx];
+        if (v != 0.0f) {
+          const uint32_t y = fp.w > 1 ? __umulhi(p, m_w) : p;
+          const uint32_t x = p - y * (uint32_t)fp.w;
+          atomicAdd(dst + (int64_t)c * plane + (int64_t)y * W + x, v);
+        }
+      }
+    }
+    __syncthreads();   // the next pass rewrites gtile and the tile
   }
 }
 
@@ -507,21 +699,22 @@ static int rroi_check(const char *who, int B, int C, int H, int W, int64_t K, in
 
 namespace obb {
 
-// channels per block: the planes one XCD works on at a time (one chunk, see block_to_work)
-// should fit its 4 MiB L2 with room to spare -- ~2 MiB of planes -- within [8, 64]
-static int rroi_chan_per_block(int C, int H, int W) {
-  const long long plane_bytes = (long long)H * W * 4;
-  int cpb = 64;
-  while (cpb > 8 && cpb * plane_bytes > (2ll << 20)) cpb >>= 1;
+// channels per block.  One XCD works on one chunk at a time (block_to_work), so a small chunk
+// would keep its planes L2 resident (8 channels of a 256 x 256 map = 2 MiB) -- but a block then
+// amortises its prologue (frame, sample table) over too little work: measured at configs[2]
+// (tools/exp_rroi_cpb.py) forward 81 / 55 / 48 / 96 us and backward 0.33 / 0.30 / 0.34 /
+// 0.48 ms for 8 / 16 / 32 / 64 channels per block.
+static int rroi_chan_per_block(int C, bool backward) {
+  int cpb = backward ? 16 : 32;
+  while (cpb > 8 && cpb > C) cpb >>= 1;
   const int64_t g = tuning(OBB_TUNE_RROI_GROUPS, -1);   // test / experiment hook: groups of 8 channels
   if (g > 0 && g <= 64) cpb = (int)g * kChanPerThread;
-  (void)C;
   return cpb;
 }
 
-static int rroi_geometry(const char *who, int C, int H, int W, int64_t K, int &cpb, unsigned &chunks,
+static int rroi_geometry(const char *who, int C, bool backward, int64_t K, int &cpb, unsigned &chunks,
                          unsigned long long &nblk) {
-  cpb = rroi_chan_per_block(C, H, W);
+  cpb = rroi_chan_per_block(C, backward);
   chunks = (unsigned)((C + cpb - 1) / cpb);
   nblk = (unsigned long long)((chunks + 7u) / 8u) * 8ull * (unsigned long long)K;
   if (nblk > 2147483647ull) return set_err(OBB_EINVAL, "%s: too many blocks (K=%lld, C=%d)", who, (long long)K, C);
@@ -539,10 +732,16 @@ static int rroi_forward_launch(const char *who, const float *feat_dev, int B, in
   int cpb;
   unsigned chunks;
   unsigned long long nblk;
-  rc = rroi_geometry(who, C, H, W, K, cpb, chunks, nblk);
+  rc = rroi_geometry(who, C, false, K, cpb, chunks, nblk);
   if (rc != OBB_OK) return rc;
-  hipLaunchKernelGGL(rroi_forward_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
-                     feat_dev, B, C, H, W, rois_dev, ph, pw, spatial_scale, sample_num, min_size, cpb, (int)K, (int)chunks, roi_kind, out_dev);
+  // 16-byte staging loads need 16-byte aligned rows: W % 4 == 0 and an aligned base
+  const bool x4 = (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(feat_dev) & 15u) == 0);
+  if (x4)
+    hipLaunchKernelGGL(rroi_forward_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
+                       feat_dev, B, C, H, W, rois_dev, ph, pw, spatial_scale, sample_num, min_size, cpb, (int)K, (int)chunks, roi_kind, out_dev);
+  else
+    hipLaunchKernelGGL(rroi_forward_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
+                       feat_dev, B, C, H, W, rois_dev, ph, pw, spatial_scale, sample_num, min_size, cpb, (int)K, (int)chunks, roi_kind, out_dev);
   OBB_LAUNCH_CHECK();
   return OBB_OK;
 }
@@ -558,7 +757,7 @@ static int rroi_backward_launch(const char *who, const float *grad_out_dev, int 
   int cpb;
   unsigned chunks;
   unsigned long long nblk;
-  rc = rroi_geometry(who, C, H, W, K, cpb, chunks, nblk);
+  rc = rroi_geometry(who, C, true, K, cpb, chunks, nblk);
   if (rc != OBB_OK) return rc;
   hipLaunchKernelGGL(rroi_backward_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
                      grad_out_dev, B, C, H, W, rois_dev, ph, pw, spatial_scale, sample_num, min_size, cpb, (int)K, (int)chunks, roi_kind, grad_feat_dev);

@@ -806,9 +806,11 @@ def test_overlaps_16k_x_16k_properties():
 
 
 @pytest.mark.parametrize('aligned', [False, True])
-def test_hbb_roi_align_kernel_side_mapping_forward_and_backward(aligned):
-    """RoIAlign decodes [b, x1, y1, x2, y2] in the kernel (obb_roi_align_*): same values as the
-    rotated op on the explicitly mapped theta = 0 RoIs, forward (bit for bit) and backward."""
+def test_hbb_roi_align_uses_the_reference_expressions(aligned):
+    """RoIAlign evaluates [b, x1, y1, x2, y2] with the reference's OWN expressions (V1:
+    roi_align_kernel.cu:79-113, V2 aligned: roi_align_kernel_v2.cu:79-124), not through a
+    mapped rotated RoI: bit for bit the oracle's V1 / V2 restatement, degenerate RoIs included,
+    and within 1e-4 of the rotated op on the explicitly mapped theta = 0 RoIs."""
     from aidet_amd import rroi_align
     from aidet_amd.roi_layers import RoIAlign
     rng = np.random.default_rng(3)
@@ -816,6 +818,8 @@ def test_hbb_roi_align_kernel_side_mapping_forward_and_backward(aligned):
     K = 70
     xy = rng.uniform(-10, 190, (K, 2)); wh = rng.uniform(2, 90, (K, 2))
     rois = np.concatenate([rng.integers(0, 2, (K, 1)), xy, xy + wh], 1).astype(np.float32)
+    rois[5, 3] = rois[5, 1] - 7.0        # x2 < x1 - 1: V1 clamps the width to 0 but keeps the start
+    rois[6, 4] = rois[6, 2] - 1.0        # zero height in V1
     scale = 0.25
     b, x1, y1, x2, y2 = [t(rois[:, i].copy()) for i in range(5)]
     if not aligned:
@@ -826,12 +830,21 @@ def test_hbb_roi_align_kernel_side_mapping_forward_and_backward(aligned):
     f1 = t(feat).requires_grad_(True)
     f2 = t(feat).requires_grad_(True)
     out1 = RoIAlign(7, scale, sample_num=2, aligned=aligned)(f1, t(rois))
+    ref = oracle.roi_align_forward(feat, rois, 7, scale, 2, version=2 if aligned else 1, aligned=aligned)
+    assert np.array_equal(out1.detach().cpu().numpy(), ref)
+    ok = np.ones(K, bool); ok[[5, 6]] = False          # (the mapped rotated RoI is a different box there)
     out2 = rroi_align(f2, mapped, 7, scale, 2, 0.0)
-    assert torch.equal(out1, out2)
+    assert float((out1 - out2)[t(ok)].abs().max()) <= 1e-4
     g = t(rng.standard_normal(tuple(out1.shape)).astype(np.float32))
+    g[5:7] = 0
     out1.backward(g)
     out2.backward(g)
     assert float((f1.grad - f2.grad).abs().max()) <= 1e-4 * max(1.0, float(f2.grad.abs().max()))
+    # adaptive sampling grid on an empty RoI: V1 divides 0 by gh * gw = 0 -> NaN, V2 -> 0
+    z = np.array([[0, 10, 10, 9, 9]], np.float32)      # (x2 + 1 - x1) = 0
+    o = RoIAlign(2, 1.0, sample_num=0, aligned=aligned)(t(feat), t(z)).cpu().numpy()
+    r = oracle.roi_align_forward(feat, z, 2, 1.0, 0, version=2 if aligned else 1, aligned=aligned)
+    assert np.array_equal(np.isnan(o), np.isnan(r)) and np.array_equal(np.nan_to_num(o), np.nan_to_num(r))
 
 
 # --------------------------------------------------------------------------
