@@ -12,6 +12,12 @@ What is captured (SURVEY.md 8c anchors):
   assigner.npz           core/bbox/assigners/max_iou_assigner.py:8-202 (MaxIoUAssigner)
   soft_nms.npz           mmdet/ops/nms/src/nms_cpu.cpp:71-210 via nms_wrapper.py:63-118
   hbb_nms_ties.npz       nms_cpu.cpp:5-68 on INTEGER boxes (IoU == thr happens: `>=` decides)
+  detector_parts.npz     config 4, everything between the convolutions and the results:
+                         core/anchor/anchor_generator.py:4-98, core/bbox/transforms.py:34-168
+                         (delta2bbox, bbox2roi), models/anchor_heads/rpn_head.py:55-104 through
+                         anchor_head.py:254-283 (RPNHead.get_bboxes on the reference's CPU nms),
+                         models/roi_extractors/single_level.py:54-87 (map_roi_levels, roi_rescale),
+                         models/bbox_heads/bbox_head.py:139-176 (get_det_bboxes, cfg=None)
 """
 import importlib.util
 import os
@@ -267,7 +273,128 @@ def main():
         out['int_%s_thr' % tag] = np.float32(thr)
         out['int_%s_keep' % tag] = nms_wrapper.nms(dets, thr)[1]
     np.savez_compressed(os.path.join(HERE, 'hbb_nms_ties.npz'), **out)
+    detector_parts(nms_wrapper, bbox_nms)
     print('wrote', sorted(f for f in os.listdir(HERE) if f.endswith('.npz')))
+
+
+def detector_parts(nms_wrapper, bbox_nms):
+    """Load the reference's RPNHead / AnchorHead / SingleRoIExtractor / BBoxHead classes with stub
+    packages around them (mmcv, registries and losses are not needed on the test path) and
+    capture their outputs on seeded random network outputs."""
+    from torch import nn
+
+    def pkg(name):
+        m = sys.modules.get(name)
+        if m is None:
+            m = types.ModuleType(name)
+            m.__path__ = []
+            sys.modules[name] = m
+        return m
+
+    class _Registry(object):
+        def register_module(self, cls):
+            return cls
+
+    def force_fp32(*a, **k):
+        return lambda fn: fn
+
+    def auto_fp16(*a, **k):
+        return lambda fn: fn
+
+    anchor_gen = _load('ref_anchor_generator', REF + '/mmdet/core/anchor/anchor_generator.py')
+    pkg('mmcv'); cnn = pkg('mmcv.cnn'); cnn.normal_init = lambda *a, **k: None
+    sys.modules['mmcv'].cnn = cnn
+    bt = _load('ref_bbox_transforms', REF + '/mmdet/core/bbox/transforms.py')
+    core = pkg('mmdet.core')
+    core.AnchorGenerator = anchor_gen.AnchorGenerator
+    core.delta2bbox = bt.delta2bbox
+    core.force_fp32 = force_fp32
+    core.auto_fp16 = auto_fp16
+    core.multi_apply = lambda fn, *args: tuple(map(list, zip(*map(fn, *args))))
+    core.anchor_target = None
+    core.multiclass_nms = bbox_nms.multiclass_nms
+    core.bbox_target = None
+    ops = pkg('mmdet.ops'); ops.nms = nms_wrapper.nms
+    sys.modules['mmdet'].ops = ops
+    models = pkg('mmdet.models')
+    reg = pkg('mmdet.models.registry'); reg.HEADS = _Registry(); reg.ROI_EXTRACTORS = _Registry()
+    bld = pkg('mmdet.models.builder'); bld.build_loss = lambda cfg: nn.Module()
+    loss = pkg('mmdet.models.losses'); loss.accuracy = None
+    pkg('mmdet.models.anchor_heads'); pkg('mmdet.models.roi_extractors'); pkg('mmdet.models.bbox_heads')
+    _load('mmdet.models.anchor_heads.anchor_head', REF + '/mmdet/models/anchor_heads/anchor_head.py')
+    rpn = _load('mmdet.models.anchor_heads.rpn_head', REF + '/mmdet/models/anchor_heads/rpn_head.py')
+    sl = _load('mmdet.models.roi_extractors.single_level', REF + '/mmdet/models/roi_extractors/single_level.py')
+    bh = _load('mmdet.models.bbox_heads.bbox_head', REF + '/mmdet/models/bbox_heads/bbox_head.py')
+
+    class Cfg(dict):
+        __getattr__ = dict.__getitem__
+
+    rng = np.random.default_rng(20261005)
+    torch.manual_seed(5)
+    out = {}
+    # ---- anchors: config 4's generators (strides 4..64, scale 8, ratios .5/1/2)
+    strides = [4, 8, 16, 32, 64]
+    gens = [anchor_gen.AnchorGenerator(s, [8], [0.5, 1.0, 2.0]) for s in strides]
+    out['anchor_strides'] = np.array(strides)
+    for i, g in enumerate(gens):
+        out['base_anchors_%d' % i] = g.base_anchors.numpy()
+        out['grid_small_%d' % i] = g.grid_anchors((3, 5), strides[i], device='cpu').numpy()
+        full = g.grid_anchors((1024 // strides[i], 1024 // strides[i]), strides[i], device='cpu').numpy()
+        out['grid_tile_rows_%d' % i] = np.arange(0, len(full), 997)
+        out['grid_tile_sample_%d' % i] = full[::997]
+        out['grid_tile_sum_%d' % i] = full.astype(np.float64).sum(0)
+        out['grid_tile_len_%d' % i] = np.int64(len(full))
+    g9 = anchor_gen.AnchorGenerator(9, [1.], [1.])
+    out['doc_grid'] = g9.grid_anchors((2, 2), device='cpu').numpy()
+    g2 = anchor_gen.AnchorGenerator(16, [2., 4.], [0.5, 2.0], scale_major=False, ctr=(3.0, 5.0))
+    out['ctr_base_anchors'] = g2.base_anchors.numpy()
+    # ---- delta2bbox
+    rois = torch.Tensor([[0., 0., 1., 1.], [0., 0., 1., 1.], [0., 0., 1., 1.], [5., 5., 5., 5.]])
+    deltas = torch.Tensor([[0., 0., 0., 0.], [1., 1., 1., 1.], [0., 0., 2., -1.], [0.7, -1.9, -0.5, 0.3]])
+    out['d2b_doc_rois'] = rois.numpy(); out['d2b_doc_deltas'] = deltas.numpy()
+    out['d2b_doc_out'] = bt.delta2bbox(rois, deltas, max_shape=(32, 32)).numpy()
+    R = torch.from_numpy(rand_hbb(rng, 300, 900))
+    D = torch.randn(300, 16 * 4) * 0.7
+    out['d2b_rois'] = R.numpy(); out['d2b_deltas'] = D.numpy()
+    out['d2b_out'] = bt.delta2bbox(R, D, [0., 0., 0., 0.], [0.1, 0.1, 0.2, 0.2], (1024, 1024, 3)).numpy()
+    out['d2b_out_noclip'] = bt.delta2bbox(R, D[:, :4], [0.1, -0.1, 0.05, 0.], [1., 1., 1., 1.]).numpy()
+    out['bbox2roi'] = bt.bbox2roi([R[:3, :], R[:0, :], torch.cat([R[3:5], torch.ones(2, 1)], 1)]).numpy()
+    # ---- RPNHead.get_bboxes (anchor_head.py:254-283 -> rpn_head.py:55-104) on a 256 x 256 image
+    head = rpn.RPNHead(in_channels=8, feat_channels=8, anchor_scales=[8], anchor_ratios=[0.5, 1.0, 2.0],
+                       anchor_strides=strides, target_means=[.0, .0, .0, .0], target_stds=[1.0, 1.0, 1.0, 1.0],
+                       loss_cls=dict(type='CrossEntropyLoss', use_sigmoid=True, loss_weight=1.0),
+                       loss_bbox=dict(type='SmoothL1Loss', beta=1.0 / 9.0, loss_weight=1.0))
+    sizes = [64, 32, 16, 8, 4]
+    cls = [torch.randn(1, 3, s, s) * 2 for s in sizes]
+    reg = [torch.randn(1, 12, s, s) * 0.5 for s in sizes]
+    for i in range(5):
+        out['rpn_cls_%d' % i] = cls[i].numpy(); out['rpn_reg_%d' % i] = reg[i].numpy()
+    metas = [dict(img_shape=(256, 256, 3), scale_factor=1.0)]
+    cfgs = {'a': Cfg(nms_across_levels=False, nms_pre=300, nms_post=300, max_num=300, nms_thr=0.7, min_bbox_size=0),
+            'b': Cfg(nms_across_levels=False, nms_pre=500, nms_post=120, max_num=200, nms_thr=0.5, min_bbox_size=8),
+            'c': Cfg(nms_across_levels=True, nms_pre=200, nms_post=200, max_num=150, nms_thr=0.7, min_bbox_size=0)}
+    for tag, cfg in cfgs.items():
+        props = head.get_bboxes(cls, reg, metas, cfg)[0]
+        out['rpn_%s_cfg' % tag] = np.array([cfg.nms_across_levels, cfg.nms_pre, cfg.nms_post, cfg.max_num,
+                                             cfg.nms_thr, cfg.min_bbox_size], dtype=np.float64)
+        out['rpn_%s_proposals' % tag] = props.numpy()
+    # ---- SingleRoIExtractor.map_roi_levels / roi_rescale
+    ext = sl.SingleRoIExtractor.__new__(sl.SingleRoIExtractor)
+    ext.finest_scale = 56
+    rr = torch.cat([torch.zeros(400, 1), torch.from_numpy(rand_hbb(rng, 400, 900, 4, 700))], 1)
+    rr[:8, 1:] = torch.tensor([[0, 0, 111, 111], [0, 0, 110, 111], [0, 0, 223, 223], [0, 0, 222, 223],
+                               [0, 0, 447, 447], [0, 0, 446, 447], [0, 0, 55, 55], [0, 0, 2000, 2000.]])
+    out['lvl_rois'] = rr.numpy()
+    out['lvl_target'] = ext.map_roi_levels(rr, 4).numpy()
+    out['lvl_rescaled'] = ext.roi_rescale(rr, 1.25).numpy()
+    # ---- BBoxHead.get_det_bboxes without NMS (softmax + decode + rescale)
+    bbh = bh.BBoxHead.__new__(bh.BBoxHead)
+    bbh.target_means = [0., 0., 0., 0.]; bbh.target_stds = [0.1, 0.1, 0.2, 0.2]
+    cs = torch.randn(300, 16) * 2
+    roi5 = torch.cat([torch.zeros(300, 1), R], 1)
+    bb, sc = bbh.get_det_bboxes(roi5, cs, D, (1024, 1024, 3), 2.0, rescale=True, cfg=None)
+    out['head_cls_score'] = cs.numpy(); out['head_bboxes'] = bb.numpy(); out['head_scores'] = sc.numpy()
+    np.savez_compressed(os.path.join(HERE, 'detector_parts.npz'), **out)
 
 
 if __name__ == '__main__':
