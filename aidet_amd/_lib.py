@@ -85,6 +85,10 @@ def lib():
         L.obb_roi_align_forward_f32.restype = i32
         L.obb_roi_align_backward_f32.argtypes = roi
         L.obb_roi_align_backward_f32.restype = i32
+        L.obb_roi_align_levels_forward_f32.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(i32), ctypes.POINTER(i32),
+                                                       ctypes.POINTER(f32), i32, i32, i32, vp, vp, i64, i32, i32,
+                                                       i32, i32, f32, vp, vp]
+        L.obb_roi_align_levels_forward_f32.restype = i32
         L.obb_nms_profile_enable.argtypes = [i32]
         L.obb_nms_profile_enable.restype = i32
         L.obb_nms_profile_last.argtypes = [ctypes.POINTER(f32)]

@@ -216,6 +216,13 @@ constexpr int kBinPitchMax = 65;
 
 struct Footprint { int x0, y0, w, h; };
 
+// feature pyramid of the multi-level forward (obb_roi_align_levels_forward_f32): passed by value
+struct LevelTable {
+  const float *feat[OBB_MAX_LEVELS];
+  int H[OBB_MAX_LEVELS], W[OBB_MAX_LEVELS];
+  float scale[OBB_MAX_LEVELS];
+};
+
 __device__ __forceinline__ Footprint roi_footprint(const RoiFrame &f, int H, int W) {
   float lox, hix, loy, hiy;
   if (f.kind == 0) {
@@ -294,8 +301,8 @@ constexpr int kWavePad = 256;                       // room for the tail lanes o
 
 template <bool X4>
 __global__ __launch_bounds__(256) void rroi_forward_kernel(
-    const float *__restrict__ feat, int B, int C, int H, int W, const float *__restrict__ rois,
-    int ph, int pw, float scale, int sample_num, float min_size, int chan_per_block,
+    const LevelTable lv, const int *__restrict__ roi_level, int num_levels, int B, int C,
+    const float *__restrict__ rois, int ph, int pw, int sample_num, float min_size, int chan_per_block,
     int K, int chunks, int roi_kind, float *__restrict__ out) {
   __shared__ __attribute__((aligned(16))) float tile[4 * (kWaveFloats + kWavePad)];  // block-wide: kFwdStageFloats + pad
   __shared__ int4 s_off[kMaxTabSamples];      // per sample: 4 footprint-local tap offsets
@@ -303,6 +310,13 @@ __global__ __launch_bounds__(256) void rroi_forward_kernel(
   int64_t k;
   int chunk;
   if (!block_to_work(K, chunks, k, chunk)) return;
+  // pyramid level of this RoI (block-uniform): feature map, its size and scale
+  const int lvl_raw = roi_level ? roi_level[k] : 0;
+  const bool lvl_ok = lvl_raw >= 0 && lvl_raw < num_levels;
+  const int lvl = lvl_ok ? lvl_raw : 0;
+  const float *__restrict__ feat = lv.feat[lvl];
+  const int H = lv.H[lvl], W = lv.W[lvl];
+  const float scale = lv.scale[lvl];
   RoiFrame f;
   make_frame(rois + k * roi_stride(roi_kind), roi_kind, scale, ph, pw, sample_num, min_size, f);
   const int nb = ph * pw;
@@ -310,10 +324,10 @@ __global__ __launch_bounds__(256) void rroi_forward_kernel(
   const int c_end = min(C, c_block + chan_per_block);
   const int64_t plane = (int64_t)H * W;
   const long long spb64 = (long long)f.gh * f.gw;
-  if (f.b < 0 || f.b >= B || spb64 <= 0) {
-    // invalid batch index: zeros.  Empty sampling grid: the sum of nothing over the count --
-    // 0 (V2, rotated) or 0/0 = NaN (V1 divides by gh*gw, roi_align_kernel.cu:113)
-    const float v = (f.b < 0 || f.b >= B) ? 0.0f : 0.0f / f.cnt;
+  if (!lvl_ok || f.b < 0 || f.b >= B || spb64 <= 0) {
+    // invalid batch / level index: zeros.  Empty sampling grid: the sum of nothing over the
+    // count -- 0 (V2, rotated) or 0/0 = NaN (V1 divides by gh*gw, roi_align_kernel.cu:113)
+    const float v = (!lvl_ok || f.b < 0 || f.b >= B) ? 0.0f : 0.0f / f.cnt;
     for (int it = threadIdx.x; it < (c_end - c_block) * nb; it += 256)
       out[(k * C + c_block) * (int64_t)nb + it] = v;
     return;
@@ -721,29 +735,44 @@ static int rroi_geometry(const char *who, int C, bool backward, int64_t K, int &
   return OBB_OK;
 }
 
-static int rroi_forward_launch(const char *who, const float *feat_dev, int B, int C, int H, int W,
-                               const float *rois_dev, int64_t K, int ph, int pw, float spatial_scale,
-                               int sample_num, float min_size, int roi_kind, float *out_dev, void *stream) {
-  int rc = rroi_check(who, B, C, H, W, K, ph, pw);
-  if (rc != OBB_OK) return rc;
+static int rroi_forward_launch_levels(const char *who, const LevelTable &lv, int num_levels, const int *roi_level_dev,
+                                      int B, int C, const float *rois_dev, int64_t K, int ph, int pw,
+                                      int sample_num, float min_size, int roi_kind, float *out_dev, void *stream) {
+  bool x4 = true;   // 16-byte staging loads need 16-byte aligned rows: W % 4 == 0 and an aligned base, on every level
+  for (int l = 0; l < num_levels; ++l) {
+    int rc = rroi_check(who, B, C, lv.H[l], lv.W[l], K, ph, pw);
+    if (rc != OBB_OK) return rc;
+    if (K > 0 && C > 0) {
+      if (!lv.feat[l]) return set_err(OBB_EINVAL, "%s: null feature map (level %d)", who, l);
+      if (lv.H[l] == 0 || lv.W[l] == 0 || B == 0) return set_err(OBB_EINVAL, "%s: empty feature map with %lld RoIs", who, (long long)K);
+    }
+    x4 = x4 && (lv.W[l] % 4 == 0) && ((reinterpret_cast<uintptr_t>(lv.feat[l]) & 15u) == 0);
+  }
   if (K == 0 || C == 0) return OBB_OK;
-  if (!feat_dev || !rois_dev || !out_dev) return set_err(OBB_EINVAL, "%s: null pointer", who);
-  if (H == 0 || W == 0 || B == 0) return set_err(OBB_EINVAL, "%s: empty feature map with %lld RoIs", who, (long long)K);
+  if (!rois_dev || !out_dev) return set_err(OBB_EINVAL, "%s: null pointer", who);
   int cpb;
   unsigned chunks;
   unsigned long long nblk;
-  rc = rroi_geometry(who, C, false, K, cpb, chunks, nblk);
+  int rc = rroi_geometry(who, C, false, K, cpb, chunks, nblk);
   if (rc != OBB_OK) return rc;
-  // 16-byte staging loads need 16-byte aligned rows: W % 4 == 0 and an aligned base
-  const bool x4 = (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(feat_dev) & 15u) == 0);
   if (x4)
     hipLaunchKernelGGL(rroi_forward_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
-                       feat_dev, B, C, H, W, rois_dev, ph, pw, spatial_scale, sample_num, min_size, cpb, (int)K, (int)chunks, roi_kind, out_dev);
+                       lv, roi_level_dev, num_levels, B, C, rois_dev, ph, pw, sample_num, min_size, cpb, (int)K, (int)chunks, roi_kind, out_dev);
   else
     hipLaunchKernelGGL(rroi_forward_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
-                       feat_dev, B, C, H, W, rois_dev, ph, pw, spatial_scale, sample_num, min_size, cpb, (int)K, (int)chunks, roi_kind, out_dev);
+                       lv, roi_level_dev, num_levels, B, C, rois_dev, ph, pw, sample_num, min_size, cpb, (int)K, (int)chunks, roi_kind, out_dev);
   OBB_LAUNCH_CHECK();
   return OBB_OK;
+}
+
+static int rroi_forward_launch(const char *who, const float *feat_dev, int B, int C, int H, int W,
+                               const float *rois_dev, int64_t K, int ph, int pw, float spatial_scale,
+                               int sample_num, float min_size, int roi_kind, float *out_dev, void *stream) {
+  LevelTable lv = {};
+  lv.feat[0] = feat_dev; lv.H[0] = H; lv.W[0] = W; lv.scale[0] = spatial_scale;
+  if (K > 0 && C > 0 && !feat_dev) return set_err(OBB_EINVAL, "%s: null pointer", who);
+  return rroi_forward_launch_levels(who, lv, 1, nullptr, B, C, rois_dev, K, ph, pw, sample_num, min_size, roi_kind,
+                                    out_dev, stream);
 }
 
 static int rroi_backward_launch(const char *who, const float *grad_out_dev, int B, int C, int H, int W,
@@ -797,4 +826,24 @@ extern "C" int obb_roi_align_backward_f32(const float *grad_out_dev, int B, int 
                                           float *grad_feat_dev, void *stream) {
   return obb::rroi_backward_launch("obb_roi_align_backward_f32", grad_out_dev, B, C, H, W, rois_dev, K, ph, pw,
                                    spatial_scale, sample_num, 0.0f, aligned ? 2 : 1, grad_feat_dev, stream);
+}
+
+extern "C" int obb_roi_align_levels_forward_f32(const float *const *feat_devs_host, const int *H_host,
+                                                const int *W_host, const float *scale_host, int num_levels,
+                                                int B, int C, const float *rois_dev,
+                                                const int32_t *roi_level_dev, int64_t K, int ph, int pw,
+                                                int sample_num, int roi_kind, float min_size,
+                                                float *out_dev, void *stream) {
+  using namespace obb;
+  const char *who = "obb_roi_align_levels_forward_f32";
+  if (num_levels < 1 || num_levels > OBB_MAX_LEVELS) return set_err(OBB_EINVAL, "%s: num_levels = %d (1..%d)", who, num_levels, OBB_MAX_LEVELS);
+  if (roi_kind < 0 || roi_kind > 2) return set_err(OBB_EINVAL, "%s: bad RoI kind %d", who, roi_kind);
+  if (!feat_devs_host || !H_host || !W_host || !scale_host) return set_err(OBB_EINVAL, "%s: null level table", who);
+  if (K > 0 && num_levels > 1 && !roi_level_dev) return set_err(OBB_EINVAL, "%s: null level indices", who);
+  LevelTable lv = {};
+  for (int l = 0; l < num_levels; ++l) {
+    lv.feat[l] = feat_devs_host[l]; lv.H[l] = H_host[l]; lv.W[l] = W_host[l]; lv.scale[l] = scale_host[l];
+  }
+  return rroi_forward_launch_levels(who, lv, num_levels, roi_level_dev, B, C, rois_dev, K, ph, pw, sample_num,
+                                    roi_kind == 0 ? min_size : 0.0f, roi_kind, out_dev, stream);
 }

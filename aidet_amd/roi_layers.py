@@ -17,6 +17,8 @@ mmdet/models/roi_extractors/single_level.py:11-107 for (K, 6) rotated RoIs --
 level by sqrt(w*h) (the reference's sqrt((x2-x1+1)(y2-y1+1)), :69-73, for the
 box's own extent), optional roi_rescale (:75-87) of w and h.
 """
+import ctypes
+
 import torch
 from torch import nn
 from torch.autograd import Function
@@ -100,6 +102,46 @@ class RoIAlign(nn.Module):
             self.use_torchvision, self.aligned)
 
 
+def pyramid_roi_align(feats, rois, levels, out_size, scales, sample_num, roi_kind, min_size=1.0):
+    """RoI-Align of every RoI on the pyramid level ``levels`` names, in ONE kernel launch
+    (obb_roi_align_levels_forward_f32): no per-level mask / gather / launch / scatter
+    (single_level.py:101-106).  Inference only (no autograd graph).
+
+    feats: list of (B, C, H_l, W_l) fp32 HIP tensors; rois (K, 5 | 6); levels (K,) int;
+    roi_kind 0 rotated (K, 6), 1 horizontal V1, 2 horizontal V2 aligned."""
+    feats = [f.detach().to(torch.float32).contiguous() for f in feats]
+    dev = feats[0].device
+    r = rois.detach().to(device=dev, dtype=torch.float32).contiguous()
+    lv = levels.detach().to(device=dev, dtype=torch.int32).contiguous()
+    B, C = feats[0].shape[:2]
+    K, n = r.size(0), len(feats)
+    out_h, out_w = _pair(out_size)
+    out = torch.empty((K, C, out_h, out_w), dtype=torch.float32, device=dev)
+    if K == 0 or C == 0:
+        return out
+    ptrs = (ctypes.c_void_p * n)(*[f.data_ptr() for f in feats])
+    hs = (ctypes.c_int * n)(*[f.shape[2] for f in feats])
+    ws = (ctypes.c_int * n)(*[f.shape[3] for f in feats])
+    sc = (ctypes.c_float * n)(*[float(x) for x in scales])
+    with torch.cuda.device(dev):
+        rc = _lib.lib().obb_roi_align_levels_forward_f32(ptrs, hs, ws, sc, n, B, C, r.data_ptr(), lv.data_ptr(), K,
+                                                         out_h, out_w, int(sample_num), int(roi_kind), float(min_size),
+                                                         out.data_ptr(), _lib.current_stream_handle(dev))
+    _lib.check(rc)
+    return out
+
+
+def _fusable(layers, feats, rois):
+    """one launch over the pyramid: inference, HIP tensors, identical layers"""
+    if torch.is_grad_enabled() and any(f.requires_grad for f in feats):
+        return False
+    a = layers[0]
+    return all(f.is_cuda for f in feats) and rois.is_cuda and len(feats) <= 8 and all(
+        type(l) is type(a) and l.out_size == a.out_size and l.sample_num == a.sample_num and
+        getattr(l, 'aligned', None) == getattr(a, 'aligned', None) and
+        getattr(l, 'min_size', None) == getattr(a, 'min_size', None) for l in layers)
+
+
 class SingleRoIExtractor(nn.Module):
     """``SingleRoIExtractor`` of mmdet/models/roi_extractors/single_level.py:11-107 for horizontal
     (K, 5) RoIs: every RoI is pooled from the ONE pyramid level its scale selects
@@ -146,7 +188,12 @@ class SingleRoIExtractor(nn.Module):
         target_lvls = self.map_roi_levels(rois, len(feats))
         if roi_scale_factor is not None:
             rois = self.roi_rescale(rois, roi_scale_factor)
-        # one pass over the levels with the RoIs grouped by level (a stable sort and ONE host
+        if _fusable(self.roi_layers, feats, rois):
+            a = self.roi_layers[0]
+            kind = 0 if isinstance(a, RRoIAlign) else (2 if a.aligned else 1)
+            return pyramid_roi_align(feats, rois, target_lvls, out_size, [l.spatial_scale for l in self.roi_layers],
+                                     a.sample_num, kind, getattr(a, 'min_size', 1.0))
+        # (training) one pass over the levels with the RoIs grouped by level (a stable sort and ONE host
         # read of the level sizes) instead of a boolean mask, a gather and a scatter per level
         order = torch.argsort(target_lvls, stable=True)
         sizes = torch.bincount(target_lvls, minlength=len(feats)).tolist()
@@ -205,9 +252,13 @@ class RotatedSingleRoIExtractor(nn.Module):
         out_size = self.roi_layers[0].out_size
         num_levels = len(feats)
         target_lvls = self.map_roi_levels(rois, num_levels)
-        roi_feats = feats[0].new_zeros(rois.size(0), self.out_channels, *out_size)
         if roi_scale_factor is not None:
             rois = self.roi_rescale(rois, roi_scale_factor)
+        if _fusable(self.roi_layers, feats, rois):
+            a = self.roi_layers[0]
+            return pyramid_roi_align(feats, rois, target_lvls, out_size, [l.spatial_scale for l in self.roi_layers],
+                                     a.sample_num, 0, a.min_size)
+        roi_feats = feats[0].new_zeros(rois.size(0), self.out_channels, *out_size)
         for i in range(num_levels):
             inds = target_lvls == i
             if inds.any():

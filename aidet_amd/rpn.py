@@ -34,32 +34,45 @@ def rpn_proposals(cls_scores, bbox_preds, mlvl_anchors, img_shape, cfg, target_m
     """
     nms_op = nms_op or nms_wrapper.nms
     nms_pre, nms_post, max_num = _cfg(cfg, 'nms_pre'), _cfg(cfg, 'nms_post'), _cfg(cfg, 'max_num')
-    boxes, scores, levels = [], [], []
-    for lvl, (cls, reg, anchors) in enumerate(zip(cls_scores, bbox_preds, mlvl_anchors)):
+    min_size = _cfg(cfg, 'min_bbox_size')
+    num_levels = len(cls_scores)
+    lvl_scores, lvl_regs = [], []
+    for cls, reg in zip(cls_scores, bbox_preds):
         assert cls.size()[-2:] == reg.size()[-2:]
         cls = cls.permute(1, 2, 0)
         if use_sigmoid_cls:
-            s = cls.reshape(-1).sigmoid()
+            lvl_scores.append(cls.reshape(-1).sigmoid())
         else:
-            s = cls.reshape(-1, 2).softmax(dim=1)[:, 1]
-        reg = reg.permute(1, 2, 0).reshape(-1, 4)
-        if nms_pre > 0 and s.shape[0] > nms_pre:
-            s, top = s.topk(nms_pre)
-            reg, anchors = reg[top, :], anchors[top, :]
-        b = delta2bbox(anchors, reg, target_means, target_stds, img_shape)
-        min_size = _cfg(cfg, 'min_bbox_size')
-        if min_size > 0:
-            ok = ((b[:, 2] - b[:, 0] + 1 >= min_size) & (b[:, 3] - b[:, 1] + 1 >= min_size)).nonzero(as_tuple=True)[0]
-            b, s = b[ok, :], s[ok]
-        boxes.append(b)
-        scores.append(s)
-        levels.append(b.new_full((b.size(0), ), lvl, dtype=torch.long))
-    dets = torch.cat([torch.cat(boxes), torch.cat(scores)[:, None]], dim=-1)
-    levels = torch.cat(levels)
+            lvl_scores.append(cls.reshape(-1, 2).softmax(dim=1)[:, 1])
+        lvl_regs.append(reg.permute(1, 2, 0).reshape(-1, 4))
+    # Levels with more than nms_pre anchors keep their nms_pre best (in descending score order,
+    # rpn_head.py:77-81) -- ONE batched top-k over those levels padded to a common length, not a
+    # top-k launch per level; smaller levels pass through in anchor order.
+    big = [i for i, s in enumerate(lvl_scores) if nms_pre > 0 and s.shape[0] > nms_pre]
+    picked = [None] * num_levels
+    if big:
+        width = max(lvl_scores[i].shape[0] for i in big)
+        padded = torch.stack([torch.nn.functional.pad(lvl_scores[i], (0, width - lvl_scores[i].shape[0]),
+                                                      value=float('-inf')) for i in big])
+        top_s, top_i = padded.topk(nms_pre, dim=1)
+        for row, i in enumerate(big):
+            picked[i] = (top_s[row], lvl_regs[i][top_i[row]], mlvl_anchors[i][top_i[row]])
+    for i in range(num_levels):
+        if picked[i] is None:
+            picked[i] = (lvl_scores[i], lvl_regs[i], mlvl_anchors[i])
+    scores = torch.cat([p[0] for p in picked])
+    levels = torch.cat([p[0].new_full((p[0].shape[0], ), i, dtype=torch.long) for i, p in enumerate(picked)])
+    # one decode for all levels (same means / stds / image clamp everywhere)
+    boxes = delta2bbox(torch.cat([p[2] for p in picked]), torch.cat([p[1] for p in picked]),
+                       target_means, target_stds, img_shape)
+    if min_size > 0:
+        ok = ((boxes[:, 2] - boxes[:, 0] + 1 >= min_size) & (boxes[:, 3] - boxes[:, 1] + 1 >= min_size)).nonzero(as_tuple=True)[0]
+        boxes, scores, levels = boxes[ok, :], scores[ok], levels[ok]
+    dets = torch.cat([boxes, scores[:, None]], dim=-1)
     proposals, keep = nms_op(dets, _cfg(cfg, 'nms_thr'), groups=levels)
     # `proposals[:nms_post]` per level: rank of every survivor inside its level
     lv = levels[keep]
-    first = torch.searchsorted(lv, torch.arange(len(cls_scores), device=lv.device))
+    first = torch.searchsorted(lv, torch.arange(num_levels, device=lv.device))
     rank = torch.arange(lv.numel(), device=lv.device) - first[lv]
     proposals = proposals[rank < nms_post]
     if _cfg(cfg, 'nms_across_levels'):

@@ -237,6 +237,29 @@ OBB_API int obb_roi_align_backward_f32(const float *grad_out_dev, int B, int C, 
                                float *grad_feat_dev, void *stream);
 
 /* ---------------------------------------------------------------------------
+ * RoI-Align over a feature PYRAMID in one launch.
+ * Replaces: the per-level loop of SingleRoIExtractor.forward
+ *           mmdet/models/roi_extractors/single_level.py:89-107 -- per level a boolean mask, a
+ *           gather of the RoIs, a kernel launch and a scatter into the (K, C, h, w) result.
+ *   feat_devs_host  [num_levels] device pointers to (B, C, H_l, W_l) fp32 maps (HOST array)
+ *   H_host, W_host, scale_host  [num_levels] map sizes and spatial scales (1 / stride)
+ *   roi_level_dev   int32[K] level of every RoI (single_level.py:54-73 map_roi_levels; computed
+ *                   by the caller so that the level borders are decided by the SAME float
+ *                   operations as the reference's); may be NULL when num_levels == 1.
+ *                   A level outside [0, num_levels) yields zeros for that RoI.
+ *   roi_kind        0: rois (K, 6) rotated, 1: (K, 5) horizontal V1, 2: (K, 5) V2 aligned
+ *   out_dev         (K, C, ph, pw), every RoI written in place: no per-level copies
+ * min_size applies to roi_kind 0 only (obb_rroi_align_forward_f32).
+ * ------------------------------------------------------------------------- */
+#define OBB_MAX_LEVELS 8
+OBB_API int obb_roi_align_levels_forward_f32(const float *const *feat_devs_host, const int *H_host,
+                                             const int *W_host, const float *scale_host, int num_levels,
+                                             int B, int C, const float *rois_dev,
+                                             const int32_t *roi_level_dev, int64_t K, int ph, int pw,
+                                             int sample_num, int roi_kind, float min_size,
+                                             float *out_dev, void *stream);
+
+/* ---------------------------------------------------------------------------
  * theta-OBB -> 4 corner points in cv2.boxPoints order.
  * Replaces: thetaobb2pointobb, mmdet/core/rbbox/transforms.py:45-55 (per-box
  *           cv2 call on the host).  in (n,5) -> out (n,8).

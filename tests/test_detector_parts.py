@@ -162,9 +162,9 @@ def test_detector_tile_forward(rotated):
     bb2, rb2 = model.simple_test(img, meta)
     assert all(np.array_equal(x, y) for x, y in zip(bb, bb2)) and all(np.array_equal(x, y) for x, y in zip(rb, rb2))
     if not rotated:
-        # the reference's keep re-use: the rotated result has exactly the horizontal one's scores
+        # the reference's keep re-use (rbbox_head.py:287-293): as many rotated boxes as horizontal
+        # ones (scored by the rotated head's own classifier)
         assert nb == nr
-        assert np.array_equal(np.sort(np.concatenate([b[:, 4] for b in bb])), np.sort(np.concatenate([r[:, 5] for r in rb])))
     # stage timers of the bench hook
     model.timers = {}
     model.simple_test(img, meta)

@@ -1030,3 +1030,40 @@ def test_bench_distributed_path_runs_on_one_gpu():
     assert j['scaling'] == 'strong' and j['rccl_ranks'] == 1 and j['n_gpus'] == 1
     assert j['keep_equals_single_rank_run'] is True and j['same_keep_on_all_ranks'] is True
     assert j['value'] > 1e7 and set(j['phases_rank0']) == {'local_nms_us', 'gather_us', 'merge_us'}
+
+
+def test_pyramid_roi_align_one_launch_equals_per_level_calls():
+    """SingleRoIExtractor (single_level.py:89-107): the inference path pools all levels in ONE
+    launch (obb_roi_align_levels_forward_f32); it must equal the per-level loop (taken when a
+    gradient is needed) bit for bit, and the oracle's V1 restatement level by level."""
+    from aidet_amd.roi_layers import RotatedSingleRoIExtractor, SingleRoIExtractor
+    rng = np.random.default_rng(12)
+    feats = [rng.standard_normal((2, 40, 64 >> i, 80 >> i)).astype(np.float32) for i in range(4)]
+    K = 300
+    x1, y1 = rng.uniform(0, 250, K), rng.uniform(0, 200, K)
+    size = np.exp(rng.uniform(np.log(6), np.log(600), (K, 2)))
+    rois = np.concatenate([rng.integers(0, 2, (K, 1)), x1[:, None], y1[:, None], x1[:, None] + size[:, :1],
+                           y1[:, None] + size[:, 1:]], 1).astype(np.float32)
+    ext = SingleRoIExtractor(dict(type='RoIAlign', out_size=7, sample_num=2), 40, [4, 8, 16, 32])
+    ft = [t(f) for f in feats]
+    with torch.no_grad():
+        fused = ext(ft, t(rois))
+    looped = ext([f.clone().requires_grad_(True) for f in ft], t(rois))
+    assert torch.equal(fused, looped.detach())
+    lv = ext.map_roi_levels(torch.from_numpy(rois), 4).numpy()
+    assert len(set(lv.tolist())) == 4
+    for l in range(4):
+        ref = oracle.roi_align_forward(feats[l], rois[lv == l], 7, 1.0 / (4 << l), 2, version=1)
+        assert np.array_equal(fused.cpu().numpy()[lv == l], ref), l
+    # rotated extractor
+    rr = np.concatenate([rois[:, :1], oracle.synth_boxes(K, 300, 4)[:, :5]], 1).astype(np.float32)
+    rr[:, 3:5] *= rng.choice([0.5, 1.0, 4.0], (K, 1))
+    rext = RotatedSingleRoIExtractor(dict(type='RRoIAlign', out_size=(5, 7), sample_num=2), 40, [4, 8, 16, 32])
+    with torch.no_grad():
+        fused = rext(ft, t(rr))
+    looped = rext([f.clone().requires_grad_(True) for f in ft], t(rr))
+    assert torch.equal(fused, looped.detach())
+    # a level index outside the pyramid gives zeros, like a batch index outside the batch
+    from aidet_amd.roi_layers import pyramid_roi_align
+    bad = pyramid_roi_align(ft, t(rois[:5]), torch.tensor([0, 9, -1, 3, 1]), 7, [1 / 4, 1 / 8, 1 / 16, 1 / 32], 2, 1)
+    assert float(bad[1].abs().max()) == 0.0 and float(bad[2].abs().max()) == 0.0 and float(bad[0].abs().max()) > 0
