@@ -1,6 +1,6 @@
 """Build hook: `python setup.py build_ext --inplace` (or `pip install -e .` offline) compiles
-libobbops.so (HIP kernels + C ABI, gfx950) and obbops_torch.so (ATen binding) in-tree through
-aidet_amd/csrc/Makefile -- the counterpart of the reference's `make_cuda_ext(...)` /
+libobbops.so (HIP kernels + C ABI, gfx950; aidet_amd/csrc/Makefile) and obbops_torch.so (ATen binding;
+torch.utils.cpp_extension, aidet_amd/torch_ext.py) in-tree -- the counterpart of the reference's `make_cuda_ext(...)` /
 `CUDAExtension` entries and `package_data={'mmdet.ops': ['*/*.so']}` (setup.py:90-110,204,224-298).
 """
 import os
@@ -30,7 +30,9 @@ class build_ext(Command):
         csrc = os.path.join(HERE, 'aidet_amd', 'csrc')
         subprocess.check_call(['make', '-C', csrc, '-j4'])
         if not self.no_torch:
-            subprocess.check_call(['make', '-C', csrc, 'torch', 'PY=' + sys.executable])
+            sys.path.insert(0, HERE)
+            from aidet_amd import torch_ext
+            torch_ext.build()
 
 
 class build_py_with_libs(build_py):
