@@ -106,9 +106,16 @@ def _run_nms(dets_dev, kind, iou_thr, groups=None, thrs=None, strict=False):
     info = getattr(_tls, 'info', None)      # (argtypes convert plain ints: no c_void_p objects per call)
     if info is None:
         info = _tls.info = (ctypes.c_int64 * 4)()
-    groups, gptr, thrs, tptr = _side_inputs(dev, n, groups, thrs)
+    gptr = tptr = None
+    if groups is not None or thrs is not None:
+        groups, gptr, thrs, tptr = _side_inputs(dev, n, groups, thrs)
     flags = _lib.NMS_STRICT if strict else 0
-    with _OnDevice(dev):
+    # (this function is the per-call overhead of every NMS: no context-manager object unless the
+    # device has to be switched)
+    cur = torch.cuda.current_device()
+    if cur != dev.index:
+        torch.cuda.set_device(dev)
+    try:
         stream = _lib.current_stream_handle(dev)
         capacity = 0  # library default
         while True:
@@ -120,9 +127,12 @@ def _run_nms(dets_dev, kind, iou_thr, groups=None, thrs=None, strict=False):
             # a pair capacity the library says suffices; every request at least doubles, so the
             # loop ends (at the latest in _workspace's byte budget)
             capacity = max(int(info[3]), 2 * capacity)
+    finally:
+        if cur != dev.index:
+            torch.cuda.set_device(cur)
     if rc != _lib.OBB_OK:
         _lib.check(rc)
-    return keep[:info[0]], (info[1], info[2], info[3])
+    return keep.narrow(0, 0, info[0]), (info[1], info[2], info[3])
 
 
 def _as_tensor(x):
