@@ -183,10 +183,10 @@ def kernel_counters(name, workload):
     c = load_counters()
     if not c:
         return None
-    k = c.get('kernels', {}).get(name)
-    if not k or k.get('workload') != workload:
-        return None
-    return k
+    for k in c.get('kernels', {}).values():
+        if k.get('kernel') == name and k.get('workload') == workload:
+            return k
+    return None
 
 
 def hbm_bytes(k):

@@ -76,7 +76,8 @@ for t, wl in WORKLOAD.items():
                 for c, v in agg[k].items():
                     key = c + '_KB' if c in ('FETCH_SIZE', 'WRITE_SIZE') else c
                     here[k][key] = round(v / len(cnt[k][c]), 1)
-    kern.update(here)
+    for k, v in here.items():                      # one record per (kernel, workload)
+        kern[k if k not in kern else '%s@%s' % (k, wl)] = dict(v, kernel=k)
 out = {
     'what': 'per-launch means from rocprofv3 on the MI355X box (tools/collect_profiles.sh): avg_us from '
             '`--kernel-trace --stats` of `bench.py --profile-target <t> --steps 20 --warmup 3`; counters from four '
@@ -100,7 +101,7 @@ def hbm(k):
 print('kernel                         workload            avg_us   HBM MB   HBM frac  VALU-issue frac')
 for k, v in sorted(kern.items()):
     t = v['avg_us'] * 1e-6
-    line = '%-30s %-18s %8.1f %8.2f %9.4f' % (k, v['workload'], v['avg_us'], hbm(v) / 1e6, hbm(v) / t / 8e12)
+    line = '%-30s %-18s %8.1f %8.2f %9.4f' % (v['kernel'], v['workload'], v['avg_us'], hbm(v) / 1e6, hbm(v) / t / 8e12)
     if 'SQ_INSTS_VALU' in v:
         line += ' %10.4f' % (v['SQ_INSTS_VALU'] / t / VALU_PEAK)
     print(line)
@@ -109,14 +110,15 @@ if call:
     print('rnms 100k: %d kernels, sum of avg_us %.1f, HBM bytes per call %.1f MB; bench ms_per_step %.4f'
           % (len(call), sum(v['avg_us'] for v in call), sum(hbm(v) for v in call) / 1e6, bench['ms_per_step']))
 for name, alg in (('iou_sparse', 20 * 2 * 16384 + 4 * 16384 ** 2), ('iou_dense', 20 * 2 * 16384 + 4 * 16384 ** 2)):
-    ks = [v for k, v in kern.items() if v['workload'] == name and k.startswith('overlaps_tile')]
+    ks = [v for k, v in kern.items() if v['workload'] == name and v['kernel'].startswith('overlaps_tile')]
     if ks:
         print('%s: algorithmic %.1f MB / %.1f us = %.0f GB/s = %.3f of 8 TB/s' % (
             name, alg / 1e6, ks[0]['avg_us'], alg / ks[0]['avg_us'] / 1e3, alg / ks[0]['avg_us'] / 1e3 / 8000))
 rk = bench.get('roofline_kernels', {}).get('kernels', [])
 for r in rk:
     if r['kernel'].startswith('rroi_'):
-        k = kern.get(r['kernel'])
+        ks = [v for v in kern.values() if v['kernel'] == r['kernel'] and v['workload'] in ('rroi_fwd', 'rroi_bwd')]
+        k = ks[0] if ks else None
         if k:
             print('%s: algorithmic %.1f MB / %.1f us (rocprof) = %.3f of 8 TB/s; counter/algorithmic = %.2f' % (
                 r['kernel'], r['algorithmic_bytes'] / 1e6, k['avg_us'], r['algorithmic_bytes'] / k['avg_us'] / 1e3 / 8000,
