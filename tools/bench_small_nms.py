@@ -3,7 +3,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import oracle
-from aidet_amd import rnms
+from aidet_amd import _lib, rnms
 
 def lat(d, reps=200):
     for _ in range(10): rnms(d, 0.5)
@@ -16,9 +16,9 @@ for canvas_per_box in (30.0, 8.0):     # sparse-ish / dense (RPN-like)
     for n in (16, 64, 128, 256, 384, 512, 768, 1024):
         canvas = (n ** 0.5) * canvas_per_box * 3
         d = torch.from_numpy(oracle.synth_boxes(n, canvas, 5)).cuda()
-        os.environ.pop('OBB_NMS_NO_FUSED', None)
+        _lib.set_tuning(_lib.TUNE_NMS_FUSED_MAX, 1024)   # every size through the fused kernel
         f = lat(d)
-        os.environ['OBB_NMS_NO_FUSED'] = '1'
+        _lib.set_tuning(_lib.TUNE_NMS_FUSED_MAX, 0)      # ... and through the general routes
         g = lat(d)
-        os.environ.pop('OBB_NMS_NO_FUSED', None)
+        _lib.set_tuning(_lib.TUNE_NMS_FUSED_MAX, -1)
         print('n=%5d canvas=%6.0f  fused %7.1f us   general %7.1f us' % (n, canvas, f, g))

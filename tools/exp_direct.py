@@ -25,9 +25,9 @@ for per_box in (63.0, 13.0, 5.0):
     for n in (4096, 8192, 12000, 16384, 20000, 25000, 32768, 50000):
         canvas = (n ** 0.5) * per_box
         d = torch.from_numpy(oracle.synth_boxes(n, canvas, 5)).cuda()
-        os.environ['OBB_NMS_DIRECT_MAX'] = '65536'
+        _lib.set_tuning(_lib.TUNE_NMS_DIRECT_MAX, 65536)
         a, k, c = lat_c(d)
-        os.environ['OBB_NMS_DIRECT_MAX'] = '0'
+        _lib.set_tuning(_lib.TUNE_NMS_DIRECT_MAX, 0)
         b, k2, c2 = lat_c(d)
         assert k == k2
         print('density %4.0f n=%6d kept=%6d cand=%8d  direct %7.1f us   sorted %7.1f us' % (per_box, n, k, c, a, b))
