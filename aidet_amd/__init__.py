@@ -6,7 +6,7 @@ operator surface:
 
   nms_wrapper.rnms / poly_nms / thetaobb_nms / nms   <-> mmdet/ops/nms/nms_wrapper.py:7-60
   nms_wrapper.soft_nms                               <-> mmdet/ops/nms/nms_wrapper.py:63-118
-  rbbox_geometry.rbbox_overlaps                      <-> mmdet/core/bbox/geometry.py:4-88
+  rbbox_geometry.rbbox_overlaps / bbox_overlaps      <-> mmdet/core/bbox/geometry.py:4-88
   rroi_align.RRoIAlign / rroi_align                  <-> mmdet/ops/roi_align/roi_align.py:9-152
   roi_layers.RoIAlign / SingleRoIExtractor           <-> roi_align.py:79-152, roi_extractors/single_level.py:11-107
   post_processing.*                                  <-> core/post_processing/bbox_nms.py, rbbox_nms.py
@@ -19,12 +19,12 @@ There is no CPU fallback: every op raises if the HIP library or a GPU is missing
 from .nms_wrapper import nms, poly_nms, rnms, soft_nms, thetaobb_nms
 from .post_processing import (get_det_rbboxes, multiclass_nms, multiclass_nms_with_index, multiclass_rnms,
                               thetaobb_nms_by_bbox_nms)
-from .rbbox_geometry import rbbox_overlaps, thetaobb2pointobb
+from .rbbox_geometry import bbox_overlaps, rbbox_overlaps, thetaobb2pointobb
 from .roi_layers import RoIAlign, RotatedSingleRoIExtractor, SingleRoIExtractor
 from .rroi_align import RRoIAlign, rroi_align
 
 __all__ = [
-    'rnms', 'poly_nms', 'thetaobb_nms', 'nms', 'soft_nms', 'rbbox_overlaps', 'thetaobb2pointobb',
+    'rnms', 'poly_nms', 'thetaobb_nms', 'nms', 'soft_nms', 'rbbox_overlaps', 'bbox_overlaps', 'thetaobb2pointobb',
     'RRoIAlign', 'rroi_align', 'RoIAlign', 'SingleRoIExtractor', 'RotatedSingleRoIExtractor',
     'multiclass_nms', 'multiclass_rnms', 'multiclass_nms_with_index', 'thetaobb_nms_by_bbox_nms', 'get_det_rbboxes'
 ]

@@ -9,7 +9,7 @@ The reference itself assigns with HORIZONTAL boxes even for its OBB models
 """
 import torch
 
-from .rbbox_geometry import rbbox_overlaps
+from .rbbox_geometry import bbox_overlaps, rbbox_overlaps
 
 
 class AssignResult(object):
@@ -92,8 +92,12 @@ class MaxIoUAssignerRotated(object):
         self.ignore_wrt_candidates = ignore_wrt_candidates
         self.gpu_assign_thr = gpu_assign_thr
 
+    box_dim = 5
+    overlaps_fn = staticmethod(rbbox_overlaps)
+
     def assign(self, rbboxes, gt_rbboxes, gt_rbboxes_ignore=None, gt_labels=None):
-        rbboxes = rbboxes[:, :5]
+        rbbox_overlaps = self.overlaps_fn
+        rbboxes = rbboxes[:, :self.box_dim]
         overlaps = rbbox_overlaps(gt_rbboxes, rbboxes)
         if (self.ignore_iof_thr > 0 and gt_rbboxes_ignore is not None
                 and gt_rbboxes_ignore.numel() > 0 and rbboxes.numel() > 0):
@@ -106,3 +110,11 @@ class MaxIoUAssignerRotated(object):
             overlaps[:, ignore_max_overlaps > self.ignore_iof_thr] = -1
         return assign_wrt_overlaps(overlaps, gt_labels, self.pos_iou_thr, self.neg_iou_thr,
                                    self.min_pos_iou, self.gt_max_assign_all)
+
+
+class MaxIoUAssigner(MaxIoUAssignerRotated):
+    """The reference's horizontal ``MaxIoUAssigner`` (max_iou_assigner.py:8-202) itself: same rules,
+    overlaps from ``bbox_overlaps`` (the kernel's horizontal kind is bit-equal to the reference's
+    geometry.py), so ``gt_inds`` / ``max_overlaps`` / labels equal the reference's exactly."""
+    box_dim = 4
+    overlaps_fn = staticmethod(bbox_overlaps)

@@ -232,6 +232,29 @@ __device__ __forceinline__ float hbb_overlap(const float (&a)[4], float aarea, c
   return inter / ((aarea + barea) - inter);
 }
 
+// The reference's horizontal IoU / IoF of bbox_overlaps (mmdet/core/bbox/geometry.py:61-86) in its
+// tensor-op order: wh = clamp((min(rb) - max(lt)) + 1, min = 0); overlap = w * h;
+// area = ((x2 - x1) + 1) * ((y2 - y1) + 1); iou = overlap / ((area1 + area2) - overlap),
+// iof = overlap / area1.  torch.max / min / clamp propagate NaN: so do nan_max / nan_min.
+__device__ __forceinline__ float nan_max(float a, float b) { return (a != a) ? a : ((b != b) ? b : (a < b ? b : a)); }
+__device__ __forceinline__ float nan_min(float a, float b) { return (a != a) ? a : ((b != b) ? b : (b < a ? b : a)); }
+__device__ __forceinline__ float hbb_pair_overlap(const float *__restrict__ a, const float *__restrict__ b, int mode) {
+  const float ltx = nan_max(a[0], b[0]), lty = nan_max(a[1], b[1]);
+  const float rbx = nan_min(a[2], b[2]), rby = nan_min(a[3], b[3]);
+  const float w = nan_max((rbx - ltx) + 1.0f, 0.0f), h = nan_max((rby - lty) + 1.0f, 0.0f);
+  const float overlap = w * h;
+  const float area1 = hbb_area(a[0], a[1], a[2], a[3]);
+  if (mode != 0) return overlap / area1;
+  const float area2 = hbb_area(b[0], b[1], b[2], b[3]);
+  return overlap / ((area1 + area2) - overlap);
+}
+// a horizontal box whose pairs the interval prefilter may decide: positive +1 extents, finite
+__device__ __forceinline__ bool hbb_regular(const float *__restrict__ r) {
+  const float big = 3.0e38f;
+  return ((r[2] - r[0]) + 1.0f > 0.0f) && ((r[3] - r[1]) + 1.0f > 0.0f) && (fabs_sel(r[0]) < big) &&
+         (fabs_sel(r[1]) < big) && (fabs_sel(r[2]) < big) && (fabs_sel(r[3]) < big);
+}
+
 // order-preserving score key: ascending key order == descending score,
 // -0 folded into +0 (oracle: obbo_score_key).
 __device__ __forceinline__ uint32_t score_key(float s) {

@@ -1,7 +1,8 @@
 // obb_overlaps.hip -- pairwise rotated / polygon overlaps for gfx950.
 //
 // Replaces bbox_overlaps (mmdet/core/bbox/geometry.py:4-88) for (.,5) theta-OBBs
-// and (.,8) polygons.  Output is the dense (m,n) fp32 matrix, so the kernel is
+// and (.,8) polygons, and -- OBB_KIND_HBB -- for the (.,4) horizontal boxes themselves, in the
+// reference's own arithmetic (hbb_pair_overlap, obb_geom.cuh).  Output is the dense (m,n) fp32 matrix, so the kernel is
 // HBM-write bound when most pairs are disjoint; the layout is chosen for that:
 //
 //   wave = 256 consecutive columns (4 per lane -> one 16-byte store per lane,
@@ -47,7 +48,11 @@ __device__ __forceinline__ void clip_and_store(const float *__restrict__ a,
                                                const float *__restrict__ b, int64_t i,
                                                int64_t j, int64_t n, int mode,
                                                float *__restrict__ out) {
-  constexpr int S = KIND ? 8 : 5;
+  constexpr int S = KIND == 0 ? 5 : (KIND == 1 ? 8 : 4);
+  if (KIND == 2) {
+    out[i * n + j] = hbb_pair_overlap(a + i * S, b + j * S, mode);
+    return;
+  }
   Quad A, B;
   load_quad<KIND>(a + i * S, A);
   load_quad<KIND>(b + j * S, B);
@@ -68,7 +73,7 @@ template <int KIND, bool VEC>
 __global__ __launch_bounds__(256) void overlaps_tile_kernel(
     const float *__restrict__ a, int64_t m, const float *__restrict__ b, int64_t n,
     int mode, int rows_per_block, float *__restrict__ out) {
-  constexpr int S = KIND ? 8 : 5;
+  constexpr int S = KIND == 0 ? 5 : (KIND == 1 ? 8 : 4);
   __shared__ uint2 qrow[kMaxRows];                // packed (lo, hi|G) per row
   __shared__ uint32_t queue[kWaves][kQueue];
   __shared__ float red[kWaves][4];
@@ -87,18 +92,25 @@ __global__ __launch_bounds__(256) void overlaps_tile_kernel(
   const float big = 3.0e38f;
   float rxl = big, rxh = -big, ryl = big, ryh = -big;   // this thread's row
   bool rfin = false;
+  // OBB_KIND_HBB: the reference defines a value for EVERY pair, also for boxes the prefilter
+  // cannot speak for (non-positive +1 extent: negative or zero areas give -0 / NaN; non-finite
+  // coordinates propagate) -- such "irregular" boxes meet everything, i.e. all their pairs take
+  // the exact arithmetic
+  bool runiv = false;
   if ((int)threadIdx.x < ti) {
     Quad A;
     load_quad<KIND>(a + (i0 + threadIdx.x) * S, A);
     interval(A.ox, A.ex, rxl, rxh);
     interval(A.oy, A.ey, ryl, ryh);
     rfin = (fabs_sel(rxl) < big) && (fabs_sel(rxh) < big) && (fabs_sel(ryl) < big) && (fabs_sel(ryh) < big);
+    if (KIND == 2 && !(rfin && hbb_regular(a + (i0 + threadIdx.x) * S))) { runiv = true; rfin = false; }
   }
   float cxl[kColsPerLane], cxh[kColsPerLane], cyl[kColsPerLane], cyh[kColsPerLane];
-  bool cfin[kColsPerLane];
+  bool cfin[kColsPerLane], cuniv[kColsPerLane];
 #pragma unroll
   for (int c = 0; c < kColsPerLane; ++c) {
     cfin[c] = false;
+    cuniv[c] = false;
     cxl[c] = big; cxh[c] = -big; cyl[c] = big; cyh[c] = -big;
     if (j0 + c < n) {
       Quad B;
@@ -106,6 +118,7 @@ __global__ __launch_bounds__(256) void overlaps_tile_kernel(
       interval(B.ox, B.ex, cxl[c], cxh[c]);
       interval(B.oy, B.ey, cyl[c], cyh[c]);
       cfin[c] = (fabs_sel(cxl[c]) < big) && (fabs_sel(cxh[c]) < big) && (fabs_sel(cyl[c]) < big) && (fabs_sel(cyh[c]) < big);
+      if (KIND == 2 && !(cfin[c] && hbb_regular(b + (j0 + c) * S))) { cuniv[c] = true; cfin[c] = false; }
     }
   }
   // ---- 1b: frame = bounding box of all finite intervals of the block
@@ -148,6 +161,7 @@ __global__ __launch_bounds__(256) void overlaps_tile_kernel(
       o.x = qz(rxl, bx, sx) | (qz(ryl, by, sy) << 16);
       o.y = (qz(rxh, bx, sx) | (qz(ryh, by, sy) << 16)) | kGuard;
     }
+    if (runiv) o = make_uint2(0u, (kQMax | (kQMax << 16)) | kGuard);   // meets every interval
     qrow[threadIdx.x] = o;
   }
   uint2 col[kColsPerLane];
@@ -158,6 +172,7 @@ __global__ __launch_bounds__(256) void overlaps_tile_kernel(
       col[c].x = qz(cxl[c], bx, sx) | (qz(cyl[c], by, sy) << 16);
       col[c].y = (qz(cxh[c], bx, sx) | (qz(cyh[c], by, sy) << 16)) | kGuard;
     }
+    if (cuniv[c]) col[c] = make_uint2(0u, (kQMax | (kQMax << 16)) | kGuard);
   }
   __syncthreads();
   if (threadIdx.x == 0) fin_n = 0;   // (published by the barrier at the end of the scan)
@@ -258,9 +273,13 @@ template <int KIND>
 __global__ __launch_bounds__(256) void overlaps_aligned_kernel(
     const float *__restrict__ a, const float *__restrict__ b, int64_t n, int mode,
     float *__restrict__ out) {
-  constexpr int S = KIND ? 8 : 5;
+  constexpr int S = KIND == 0 ? 5 : (KIND == 1 ? 8 : 4);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (int64_t)gridDim.x * blockDim.x) {
+    if (KIND == 2) {
+      out[i] = hbb_pair_overlap(a + i * S, b + i * S, mode);
+      continue;
+    }
     Quad A, B;
     load_quad<KIND>(a + i * S, A);
     load_quad<KIND>(b + i * S, B);
@@ -290,7 +309,7 @@ extern "C" int obb_overlaps_f32(const float *a_dev, int64_t m, const float *b_de
                                 int kind, int mode, int aligned, float *out_dev, void *stream) {
   using namespace obb;
   if (m < 0 || n < 0) return set_err(OBB_EINVAL, "obb_overlaps_f32: negative size (m=%lld n=%lld)", (long long)m, (long long)n);
-  if (kind != OBB_KIND_RBOX && kind != OBB_KIND_POLY) return set_err(OBB_EINVAL, "obb_overlaps_f32: bad kind %d", kind);
+  if (kind != OBB_KIND_RBOX && kind != OBB_KIND_POLY && kind != OBB_KIND_HBB) return set_err(OBB_EINVAL, "obb_overlaps_f32: bad kind %d", kind);
   if (mode != OBB_MODE_IOU && mode != OBB_MODE_IOF) return set_err(OBB_EINVAL, "obb_overlaps_f32: bad mode %d", mode);
   if (aligned && m != n) return set_err(OBB_EINVAL, "obb_overlaps_f32: aligned needs m == n (%lld vs %lld)", (long long)m, (long long)n);
   if (m == 0 || n == 0) return OBB_OK;
@@ -301,8 +320,10 @@ extern "C" int obb_overlaps_f32(const float *a_dev, int64_t m, const float *b_de
     if (blocks > 8192) blocks = 8192;
     if (kind == OBB_KIND_RBOX)
       hipLaunchKernelGGL(overlaps_aligned_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, st, a_dev, b_dev, n, mode, out_dev);
-    else
+    else if (kind == OBB_KIND_POLY)
       hipLaunchKernelGGL(overlaps_aligned_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, a_dev, b_dev, n, mode, out_dev);
+    else
+      hipLaunchKernelGGL(overlaps_aligned_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, st, a_dev, b_dev, n, mode, out_dev);
     OBB_LAUNCH_CHECK();
     return OBB_OK;
   }
@@ -324,7 +345,8 @@ extern "C" int obb_overlaps_f32(const float *a_dev, int64_t m, const float *b_de
 #define OBB_LAUNCH_TILE(K, V) \
   hipLaunchKernelGGL((overlaps_tile_kernel<K, V>), grid, dim3(256), 0, st, a_dev, m, b_dev, n, mode, rows, out_dev)
   if (kind == OBB_KIND_RBOX) { if (vec) OBB_LAUNCH_TILE(0, true); else OBB_LAUNCH_TILE(0, false); }
-  else { if (vec) OBB_LAUNCH_TILE(1, true); else OBB_LAUNCH_TILE(1, false); }
+  else if (kind == OBB_KIND_POLY) { if (vec) OBB_LAUNCH_TILE(1, true); else OBB_LAUNCH_TILE(1, false); }
+  else { if (vec) OBB_LAUNCH_TILE(2, true); else OBB_LAUNCH_TILE(2, false); }
 #undef OBB_LAUNCH_TILE
   OBB_LAUNCH_CHECK();
   return OBB_OK;

@@ -63,6 +63,28 @@ def rbbox_overlaps(rbboxes1, rbboxes2, mode='iou', is_aligned=False):
     return _overlaps(rbboxes1, rbboxes2, mode, is_aligned, 5, _lib.KIND_RBOX)
 
 
+def bbox_overlaps(bboxes1, bboxes2, mode='iou', is_aligned=False):
+    """Overlap between two sets of HORIZONTAL boxes: the reference's ``bbox_overlaps``
+    (mmdet/core/bbox/geometry.py:4-88) with the same signature, return shapes and values
+    -- the kernel's horizontal kind evaluates geometry.py:61-86 in its tensor-op order
+    (+1 widths; the -0 / NaN results of degenerate boxes included), so results are
+    bit-equal to the reference's fp32 CPU result.
+
+    Args:
+        bboxes1 (Tensor): (m, 4) <x1, y1, x2, y2>; bboxes2 (Tensor): (n, 4).
+        mode (str): "iou" or "iof" (intersection over the area of bboxes1).
+
+    Example (geometry.py:21-35):
+        >>> bboxes1 = torch.FloatTensor([[0, 0, 10, 10], [10, 10, 20, 20], [32, 32, 38, 42]]).cuda()
+        >>> bboxes2 = torch.FloatTensor([[0, 0, 10, 20], [0, 10, 10, 19], [10, 10, 20, 20]]).cuda()
+        >>> bbox_overlaps(bboxes1, bboxes2)
+        tensor([[0.5238, 0.0500, 0.0041],
+                [0.0323, 0.0452, 1.0000],
+                [0.0000, 0.0000, 0.0000]], device='cuda:0')
+    """
+    return _overlaps(bboxes1, bboxes2, mode, is_aligned, 4, _lib.KIND_HBB)
+
+
 def pointobb_overlaps(polys1, polys2, mode='iou', is_aligned=False):
     """Same for convex quadrilaterals (m, 8) <x1, y1, ..., x4, y4> (pointobb)."""
     return _overlaps(polys1, polys2, mode, is_aligned, 8, _lib.KIND_POLY)

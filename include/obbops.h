@@ -33,7 +33,7 @@
  *        cv2.boxPoints meaning used by mmdet/core/rbbox/transforms.py:45-55)
  *   kind OBB_KIND_POLY: row = x1,y1,x2,y2,x3,y3,x4,y4 (convex quad, any
  *        orientation; the pointobb of transforms.py:45-55)
- *   kind OBB_KIND_HBB (obb_nms_* only): row = x1, y1, x2, y2 with the reference's +1 pixel
+ *   kind OBB_KIND_HBB (obb_nms_*, obb_overlaps_f32): row = x1, y1, x2, y2 with the reference's +1 pixel
  *        convention (nms_cpu.cpp:19,52-55): the box is the theta = 0 OBB with centre
  *        ((x1+x2)/2, (y1+y2)/2), w = x2-x1+1, h = y2-y1+1 -- the continuous box
  *        [x1-.5, x2+.5] x [y1-.5, y2+.5], whose intersection widths are the reference's.
@@ -62,7 +62,7 @@ extern "C" {
 
 #define OBB_KIND_RBOX 0
 #define OBB_KIND_POLY 1
-#define OBB_KIND_HBB 2  /* NMS only: row = x1,y1,x2,y2 (+score), the reference's horizontal boxes */
+#define OBB_KIND_HBB 2  /* NMS and overlaps: row = x1,y1,x2,y2 (+score for NMS), the reference's horizontal boxes */
 #define OBB_MODE_IOU 0
 #define OBB_MODE_IOF 1
 
@@ -75,7 +75,9 @@ OBB_API const char *obb_last_error(void);
  * Pairwise overlaps.
  * Replaces: bbox_overlaps(bboxes1, bboxes2, mode, is_aligned)
  *           mmdet/core/bbox/geometry.py:4-88  (pure-torch HBB IoU/IoF), for
- *           rotated boxes.  a_dev (m, 5|8), b_dev (n, 5|8) row-major fp32.
+ *           rotated boxes -- and, with OBB_KIND_HBB, for the horizontal boxes themselves in the
+ *           reference's own arithmetic (geometry.py:61-86: +1 widths, NaN / -0 results of
+ *           degenerate boxes included).  a_dev (m, 5|8|4), b_dev (n, 5|8|4) row-major fp32.
  *   aligned == 0: out_dev is (m, n) row-major.
  *   aligned != 0: m must equal n, out_dev is (m).
  * m*n == 0 is a no-op returning OBB_OK (reference: geometry.py:54-55).

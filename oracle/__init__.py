@@ -60,6 +60,8 @@ def lib():
         L.obbo_nms_grouped_f32.restype = ctypes.c_long
         L.obbo_hbb_nms_f32.argtypes = [_f32p, ctypes.c_long, ctypes.c_float, _i64p]
         L.obbo_hbb_nms_f32.restype = ctypes.c_long
+        L.obbo_hbb_overlaps_f32.argtypes = [_f32p, ctypes.c_long, _f32p, ctypes.c_long, ctypes.c_int, ctypes.c_int, _f32p]
+        L.obbo_hbb_overlaps_f32.restype = ctypes.c_int
         L.obbo_nms_ex_f32.argtypes = [_f32p, ctypes.c_long, ctypes.c_int, ctypes.c_float,
                                       ctypes.POINTER(ctypes.c_int32), _f32p, ctypes.c_int, _i64p]
         L.obbo_nms_ex_f32.restype = ctypes.c_long
@@ -130,6 +132,20 @@ def overlaps(a, b, mode='iou', is_aligned=False, kind='rbox'):
         return out
     rc = lib().obbo_overlaps_f32(_p(a), m, _p(b), n, 0 if kind == 'rbox' else 1,
                                  _mode(mode), 1 if is_aligned else 0, _p(out))
+    assert rc == 0
+    return out
+
+
+def bbox_overlaps(a, b, mode='iou', is_aligned=False):
+    """Restatement of the reference's horizontal bbox_overlaps (geometry.py:47-88), fp32:
+    (m,4),(n,4) xyxy -> (m,n) or (m,)."""
+    a = _f32(a).reshape(-1, 4)
+    b = _f32(b).reshape(-1, 4)
+    m, n = a.shape[0], b.shape[0]
+    out = np.zeros((m,) if is_aligned else (m, n), dtype=np.float32)
+    if m * n == 0:
+        return out
+    rc = lib().obbo_hbb_overlaps_f32(_p(a), m, _p(b), n, _mode(mode), 1 if is_aligned else 0, _p(out))
     assert rc == 0
     return out
 

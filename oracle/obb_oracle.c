@@ -742,6 +742,33 @@ OBBO_API long obbo_hbb_nms_f32(const float *dets, long n, float thr, int64_t *ke
 }
 
 /* ------------------------------------------------------------------ */
+/* horizontal bbox_overlaps restatement of geometry.py:47-88 (fp32)     */
+/* ------------------------------------------------------------------ */
+/* torch.max / torch.min / clamp propagate NaN */
+static inline float nan_max(float a, float b) { return (a != a) ? a : ((b != b) ? b : (a < b ? b : a)); }
+static inline float nan_min(float a, float b) { return (a != a) ? a : ((b != b) ? b : (b < a ? b : a)); }
+static inline float hbb_pair_overlap_f32(const float *a, const float *b, int mode) {
+  float ltx = nan_max(a[0], b[0]), lty = nan_max(a[1], b[1]);       /* lt = max(b1[:, :2], b2[:, :2])  :61,75 */
+  float rbx = nan_min(a[2], b[2]), rby = nan_min(a[3], b[3]);       /* rb = min(b1[:, 2:], b2[:, 2:])          */
+  float w = nan_max((rbx - ltx) + 1.0f, 0.0f), h = nan_max((rby - lty) + 1.0f, 0.0f);   /* (rb - lt + 1).clamp(min=0) */
+  float overlap = w * h;
+  float area1 = hbb_area_f32(a);
+  if (mode) return overlap / area1;                                  /* iof :72,86 */
+  return overlap / ((area1 + hbb_area_f32(b)) - overlap);            /* iou :70,84 */
+}
+
+OBBO_API int obbo_hbb_overlaps_f32(const float *a, long m, const float *b, long n, int mode,
+                                   int aligned, float *out) {
+  long i, j;
+  if (m < 0 || n < 0 || (aligned && m != n)) return -1;
+  for (i = 0; i < m; ++i) {
+    if (aligned) out[i] = hbb_pair_overlap_f32(a + i * 4, b + i * 4, mode);
+    else for (j = 0; j < n; ++j) out[i * n + j] = hbb_pair_overlap_f32(a + i * 4, b + j * 4, mode);
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------ */
 /* Soft-NMS restatement of nms_cpu.cpp:71-210 (fp32 instantiation)      */
 /* ------------------------------------------------------------------ */
 /* dets (n,5) = x1,y1,x2,y2,score.  method 0 = hard (weight 0 when ovr > thr), 1 = linear

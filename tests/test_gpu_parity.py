@@ -1067,3 +1067,52 @@ def test_pyramid_roi_align_one_launch_equals_per_level_calls():
     from aidet_amd.roi_layers import pyramid_roi_align
     bad = pyramid_roi_align(ft, t(rois[:5]), torch.tensor([0, 9, -1, 3, 1]), 7, [1 / 4, 1 / 8, 1 / 16, 1 / 32], 2, 1)
     assert float(bad[1].abs().max()) == 0.0 and float(bad[2].abs().max()) == 0.0 and float(bad[0].abs().max()) > 0
+
+
+def test_horizontal_bbox_overlaps_matches_reference_bit_for_bit(golden):
+    """aidet_amd.bbox_overlaps = the reference's bbox_overlaps (geometry.py:4-88) on the GPU:
+    bit-equal to the values the reference produced (hbb_iou.npz), and to the oracle on
+    degenerate rows (negative / zero extents, NaN, inf) where the reference yields -0 / NaN."""
+    from aidet_amd import bbox_overlaps
+    g = golden('hbb_iou.npz')
+    eq = lambda x, y: np.array_equal(x, y, equal_nan=True)
+    assert eq(bbox_overlaps(t(g['doc_b1']), t(g['doc_b2'])).cpu().numpy(), g['doc_iou'])
+    assert eq(bbox_overlaps(t(g['rand_b1']), t(g['rand_b2'])).cpu().numpy(), g['rand_iou'])
+    assert eq(bbox_overlaps(t(g['rand_b1']), t(g['rand_b2']), 'iof').cpu().numpy(), g['rand_iof'])
+    assert eq(bbox_overlaps(t(g['rand_b1']), t(g['rand_b2'][:200]), is_aligned=True).cpu().numpy(), g['rand_iou_aligned'])
+    assert eq(bbox_overlaps(t(g['rand_b1']), t(g['rand_b2'][:200]), 'iof', True).cpu().numpy(), g['rand_iof_aligned'])
+    assert eq(bbox_overlaps(t(g['int_b1']), t(g['int_b2'])).cpu().numpy(), g['int_iou'])
+    assert tuple(bbox_overlaps(torch.zeros(0, 4), t(g['doc_b2'])).shape) == (0, 3)          # geometry.py:37-44
+    assert tuple(bbox_overlaps(t(g['doc_b1']), torch.zeros(0, 4), is_aligned=False).shape) == (3, 0)
+    rng = np.random.default_rng(9)
+    for m, n, canvas in ((700, 1300, 300), (2500, 4100, 4000), (33, 5000, 60)):
+        x1, y1 = rng.uniform(0, canvas, m), rng.uniform(0, canvas, m)
+        a = np.stack([x1, y1, x1 + rng.uniform(2, 90, m), y1 + rng.uniform(2, 90, m)], 1).astype(np.float32)
+        x1, y1 = rng.uniform(0, canvas, n), rng.uniform(0, canvas, n)
+        b = np.stack([x1, y1, x1 + rng.uniform(2, 90, n), y1 + rng.uniform(2, 90, n)], 1).astype(np.float32)
+        a[3] = [50, 50, 40, 90]; a[4] = [10, 10, 9, 9]; a[5] = [np.nan, 0, 5, 5]; a[6] = [0, 0, np.inf, 5]
+        b[7] = [60, 60, 20, 20]; b[8] = [10, 10, 9, 9]; b[9] = [0, np.nan, 5, 5]
+        for mode in ('iou', 'iof'):
+            got = bbox_overlaps(t(a), t(b), mode).cpu().numpy()
+            assert eq(got, oracle.bbox_overlaps(a, b, mode)), (m, n, mode)
+    # same boxes as theta = 0 OBBs with the +1 widths: the rotated op agrees within 1e-5 where both are defined
+    from aidet_amd import rbbox_overlaps
+    rb = lambda h: t(hbb_to_rbox(h))
+    reg = bbox_overlaps(t(g['rand_b1']), t(g['rand_b2'])).cpu().numpy()
+    assert np.abs(rbbox_overlaps(rb(g['rand_b1']), rb(g['rand_b2'])).cpu().numpy() - reg).max() <= 1e-5
+
+
+def test_horizontal_max_iou_assigner_equals_reference(golden):
+    """MaxIoUAssigner on horizontal boxes with the HIP bbox_overlaps: the reference's assignment
+    (assigner.npz), max_overlaps bit for bit."""
+    from aidet_amd.assigners import MaxIoUAssigner
+    g = golden('assigner.npz')
+    boxes, gts, ign, labels = t(g['boxes']), t(g['gts']), t(g['ign']), t(g['labels'])
+    cases = (('a', dict(pos_iou_thr=0.5, neg_iou_thr=0.4, min_pos_iou=0.3), False),
+             ('b', dict(pos_iou_thr=0.7, neg_iou_thr=(0.1, 0.3), min_pos_iou=0.0, gt_max_assign_all=False), False),
+             ('c', dict(pos_iou_thr=0.5, neg_iou_thr=0.5, min_pos_iou=0.5, ignore_iof_thr=0.5), True))
+    for tag, kw, use_ign in cases:
+        r = MaxIoUAssigner(**kw).assign(boxes, gts, ign if use_ign else None, labels)
+        assert np.array_equal(r.gt_inds.cpu().numpy(), g['assign_%s_gt_inds' % tag]), tag
+        assert np.array_equal(r.labels.cpu().numpy(), g['assign_%s_labels' % tag]), tag
+        assert np.array_equal(r.max_overlaps.cpu().numpy(), g['assign_%s_max_overlaps' % tag]), tag
