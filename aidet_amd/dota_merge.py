@@ -33,6 +33,7 @@ import torch.distributed as dist
 from . import nms_wrapper
 
 COLS = 8  # cx, cy, w, h, theta, score, label, image_id
+LOCAL = 'local'   # pass as `group` to run a function on this rank alone although a process group exists
 _LAYOUT = {8: ('rnms', 6), 11: ('poly_nms', 9), 7: ('nms', 5)}   # columns -> (op, columns of box + score)
 
 
@@ -44,6 +45,8 @@ def shard_patches(num_patches, rank, world_size):
 
 
 def _world(group):
+    if group is LOCAL:
+        return 1, 0
     if dist.is_available() and dist.is_initialized():
         return dist.get_world_size(group), dist.get_rank(group)
     return 1, 0

@@ -400,6 +400,16 @@ def extras(dev, args):
         t0 = time.perf_counter()
         nms_wrapper.nms_collect([nms_wrapper.nms_enqueue(hd, 0.7) for _ in range(5)])
         ta.append(time.perf_counter() - t0)
+    sn = []
+    for _ in range(12):
+        t0 = time.perf_counter()
+        sd, si = nms_wrapper.soft_nms(hd, 0.5, min_score=0.05)
+        sn.append(time.perf_counter() - t0)
+    t0 = time.perf_counter()
+    _rd, ri = oracle.soft_nms(hb, 0.5, 'linear', 0.5, 0.05)
+    res['soft_nms_2000'] = {'ms_per_call': round(float(np.median(sn[2:])) * 1e3, 3), 'kept': int(si.numel()),
+                            'cpu_oracle_ms': round((time.perf_counter() - t0) * 1e3, 2),
+                            'index_exact_vs_oracle': bool(np.array_equal(si.cpu().numpy(), ri))}
     res['hbb_nms_rpn_2000'] = {'us_per_sync_call': round(float(np.median(ts)) * 1e6, 1),
                                'us_per_call_5_queued': round(float(np.median(ta)) * 1e6 / 5, 1),
                                'kept': int(nms(hd, 0.7)[1].numel())}
@@ -572,7 +582,9 @@ def bench_tiled(args):
     # ... and they equal a single-rank run of ALL patches (rank 0, untimed, no collectives)
     ok_single, single = None, None
     if rank == 0:
-        s1, e1, rows1 = tiled_on_this_rank(dev, 0, 1, steps=max(3, args.steps // 4), warmup=1, layout='replicated')
+        from aidet_amd import dota_merge
+        s1, e1, rows1 = tiled_on_this_rank(dev, 0, 1, steps=max(3, args.steps // 4), warmup=1, layout='replicated',
+                                           group=dota_merge.LOCAL)     # (no collective: the other ranks are not in it)
         ok_single = bool(np.array_equal(rows1.cpu().numpy(), kept_rows.cpu().numpy()))
         single = {'ms_per_step': s1['ms_per_step'], 'boxes_per_s': s1['boxes_per_s']}
     total = summary['detections']

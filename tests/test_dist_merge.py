@@ -237,6 +237,13 @@ def _tiled_worker(rank, world, port, layout, out):
         kept, keep, allrows = dota_merge.tiled_inference_merge(*args, NUM_CLASSES, 0.5, 0.3, CLASS_THRS,
                                                                layout=layout, nms_fn=oracle_nms)
         out[rank] = (kept.numpy(), keep.numpy(), allrows.numpy())
+        if rank == 0:
+            # what bench.py's cross-check does: the whole job on rank 0 ALONE while a process group
+            # exists (group=LOCAL: no collective is entered, the other rank is not waiting in one)
+            solo, _ = _tiled_inputs(0, 1)
+            k1, _, _ = dota_merge.tiled_inference_merge(*solo, NUM_CLASSES, 0.5, 0.3, CLASS_THRS, layout=layout,
+                                                        nms_fn=oracle_nms, group=dota_merge.LOCAL)
+            out['solo'] = k1.numpy()
     finally:
         dist.destroy_process_group()
 
@@ -255,6 +262,7 @@ def test_tiled_inference_merge_two_ranks_equal_one(layout):
     for r in range(world):
         assert np.array_equal(out[r][2], allrows.numpy())
         assert np.array_equal(out[r][1], keep.numpy()) and np.array_equal(out[r][0], kept.numpy())
+    assert np.array_equal(out['solo'], kept.numpy())
     # the overlap bands really produce duplicates, and the merge removes them
     n = len(scene['dets'])
     assert len(allrows) <= n and 0.3 * n < len(keep) < 0.95 * len(allrows)
