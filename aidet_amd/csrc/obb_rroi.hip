@@ -561,19 +561,21 @@ __device__ __forceinline__ void rroi_backward_direct(const float *__restrict__ g
 // tickets): results are reproducible to rounding only, like the reference's atomicAdd
 // backward (roi_align_kernel_v2.cu:179-263); tolerance 1e-4 * max|g|.
 constexpr int kBwdMaxPix = 1024;                       // footprint pixels of the staged backward
+constexpr int kBwdStageFloats = 4096;                  // sums tile (16 KiB): 16 channels x 255 pixels, 8 x 511, 4 x 1023
 constexpr int kBwdMaxEntries = 4 * kMaxTabSamples;     // taps of a RoI (4 per sample)
 
 __global__ __launch_bounds__(256) void rroi_backward_kernel(
     const float *__restrict__ gout, int B, int C, int H, int W, const float *__restrict__ rois,
     int ph, int pw, float scale, int sample_num, float min_size, int chan_per_block,
     int K, int chunks, int roi_kind, float *__restrict__ gfeat) {
-  __shared__ __attribute__((aligned(16))) float tile[kStageFloats];   // first the sample table, then sums [channel][pixel]
+  __shared__ __attribute__((aligned(16))) float tile[kBwdStageFloats];   // first the sample table, then sums [channel][pixel]
   __shared__ int2 entry[kBwdMaxEntries];               // (bin, weight bits), grouped by pixel
   __shared__ int pstart[kBwdMaxPix + 1];               // CSR offsets; during the build: counts
-  __shared__ int pfill[kBwdMaxPix];
   __shared__ float gtile[kMaxPassChan * kBinPitchMax];
   __shared__ int wsum[4];
-  static_assert(kStageFloats * 4 >= kMaxTabSamples * 32, "the sample table fits the tile it is built in");
+  int *pfill = reinterpret_cast<int *>(gtile);         // slot tickets of the build (gtile is loaded after it)
+  static_assert(kBwdStageFloats * 4 >= kMaxTabSamples * 32, "the sample table fits the tile it is built in");
+  static_assert(kMaxPassChan * kBinPitchMax >= kBwdMaxPix, "the slot tickets fit the gradient tile");
   int64_t k;
   int chunk;
   if (!block_to_work(K, chunks, k, chunk)) return;
@@ -590,7 +592,7 @@ __global__ __launch_bounds__(256) void rroi_backward_kernel(
   const int cpitch = fsz | 1;
   const int spb = (int)(spb64 > kMaxTabSamples ? kMaxTabSamples + 1 : spb64);
   const int nsamp = nb * spb;
-  if (fsz > kBwdMaxPix || cpitch > kStageFloats || nb > kMaxBins || nsamp > kMaxTabSamples ||
+  if (fsz > kBwdMaxPix || cpitch > kBwdStageFloats || nb > kMaxBins || nsamp > kMaxTabSamples ||
       (int64_t)B * C * plane >= (1ll << 31)) {
     rroi_backward_direct(gout, C, H, W, f, k, ph, pw, c_block, c_end, gfeat);
     return;
@@ -643,7 +645,8 @@ __global__ __launch_bounds__(256) void rroi_backward_kernel(
   }
   __syncthreads();   // entries complete; the table in `tile` is dead from here on
   // ---- 2. / 3. passes over the channels
-  const int cb = pass_channels(cpitch, c_end - c_block);
+  int cb = pass_channels(cpitch, c_end - c_block);
+  while (cb > 1 && cpitch * cb > kBwdStageFloats) cb >>= 1;
   const int lc = lane & (cb - 1);
   const int psub = lane / cb, ppw = 64 / cb;         // pixel slot of this lane, pixels per wave step
   const int nbp = nb | 1;
