@@ -22,31 +22,67 @@
 //                 survivor counted from the end.  (Sequentially: the loop reaches the holes
 //                 in ascending order and each time pulls the current last element; a pulled
 //                 element that is itself dropped is pulled over again, i.e. skipped.)
-// State (7 words per box) lives in LDS up to 2048 boxes and in the caller's workspace
-// above that; ~8 block barriers per round.
+// A round without drops costs TWO barriers: the decay pass also votes on the next pick (valid when
+// no position moves).  State (7 words per box) lives in LDS up to 2048 boxes and in the caller's
+// workspace above that.
 #include "obb_common.h"
 #include "obb_geom.cuh"
 
 namespace obb {
 
-constexpr int kSoftThreads = 1024;
 constexpr int kSoftLds = 2048;   // boxes whose state fits the LDS arrays below (56 KiB)
+// A round is a chain of ~10 dependent LDS round trips and two block barriers around a few
+// instructions per box: 1.2 - 2.0 us per round whatever the reductions are made of (shuffles ->
+// DPP moves: -6 %; eight barriers -> two: -8 %), i.e. about the speed of the CPU loop it replaces
+// (3.4 ms vs 3.3 ms at n = 2000 on this host).  The op exists so that `type='soft_nms'` works on
+// device tensors without a round trip to the host, not for speed.
 
 struct SoftState {
   float *x1, *y1, *x2, *y2, *sc, *ar;
   int *id;
 };
 
-struct Best { float s; int p; };
+// The pick of a round = the maximum of a 64-bit key over the remaining positions:
+//   high word: order-preserving image of the score (-0 folded into +0; 0 for a NaN, which
+//              never wins: nms_cpu.cpp:116 `max_score < scores[pos]` is false for it)
+//   low word : ~position, so that among equal scores the LOWEST position wins (:114-121)
+// A key of 0 means "nothing comparable".  Maxima of keys are reduced inside a wave with DPP
+// moves (a shuffle is an LDS-crossbar round trip: twelve of them were ~1/3 of a round).
+__device__ __forceinline__ unsigned long long pick_key(float s, int p) {
+  const float t = s + 0.0f;
+  uint32_t u = __float_as_uint(t);
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  if (s != s) u = 0u;
+  return ((unsigned long long)u << 32) | (uint32_t)(~(uint32_t)p);
+}
+__device__ __forceinline__ int key_pos(unsigned long long k) { return (int)(~(uint32_t)k); }
+__device__ __forceinline__ bool key_none(unsigned long long k) { return (k >> 32) == 0ull; }
 
-// candidate b replaces a: higher score, or the same score at a lower position.  A NaN score
-// never wins (nms_cpu.cpp:116 `max_score < scores[pos]` is false for it).
-__device__ __forceinline__ Best better(Best a, Best b) {
-  const bool take = (a.s < b.s) || (a.s == b.s && b.p < a.p);
-  return take ? b : a;
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_max(unsigned long long v) {
+  const int lo = __builtin_amdgcn_mov_dpp((int)(uint32_t)v, CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_mov_dpp((int)(uint32_t)(v >> 32), CTRL, 0xf, 0xf, true);
+  const unsigned long long o = ((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo;
+  return o > v ? o : v;
+}
+// maximum over the 64 lanes, returned in every lane
+__device__ __forceinline__ unsigned long long wave_max_key(unsigned long long v) {
+  v = dpp_max<0xB1>(v);    // quad_perm [1,0,3,2]: lane ^ 1
+  v = dpp_max<0x4E>(v);    // quad_perm [2,3,0,1]: lane ^ 2
+  v = dpp_max<0x141>(v);   // row_half_mirror: 7 - lane inside a group of 8
+  v = dpp_max<0x140>(v);   // row_mirror: 15 - lane inside a row of 16 -> every lane holds its row's maximum
+  unsigned long long m = 0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, r * 16);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), r * 16);
+    const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+    m = o > m ? o : m;
+  }
+  return m;
 }
 
-template <bool LDS>
+template <bool LDS, int kSoftThreads>
 __global__ __launch_bounds__(kSoftThreads) void soft_nms_kernel(const float *__restrict__ dets, int n,
                                                                 float thr, int method, float sigma,
                                                                 float min_score, float *__restrict__ ws,
@@ -54,8 +90,9 @@ __global__ __launch_bounds__(kSoftThreads) void soft_nms_kernel(const float *__r
                                                                 int64_t *__restrict__ out_inds,
                                                                 long long *__restrict__ result) {
   __shared__ float lds[LDS ? 7 * kSoftLds : 7];
-  __shared__ Best wbest[16];
-  __shared__ int wcnt[16];
+  constexpr int kW = kSoftThreads / 64;
+  __shared__ unsigned long long wbest[kW];
+  __shared__ int wcnt[kW];
   __shared__ int holes[LDS ? kSoftLds : 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int cap = LDS ? kSoftLds : n;
@@ -73,41 +110,41 @@ __global__ __launch_bounds__(kSoftThreads) void soft_nms_kernel(const float *__r
   }
   __syncthreads();
   int nd = n;
-  for (int i = 0; i < nd; ++i) {
-    // ---- (1) arg-max over [i, nd), first of equal scores
-    Best b{-__builtin_huge_valf(), 0x7fffffff};
-    for (int p = i + tid; p < nd; p += kSoftThreads) b = better(b, Best{S.sc[p], p});
-    for (int o = 32; o > 0; o >>= 1) {
-      Best t{__shfl_xor(b.s, o), __shfl_xor(b.p, o)};
-      b = better(b, t);
-    }
+  // block-wide arg-max over [from, nd): the first of equal scores, NaN never wins unless it sits
+  // at `from` (the starting value of the reference's scan, nms_cpu.cpp:100-121); two barriers
+  auto argmax_from = [&](int from) -> int {
+    unsigned long long b = 0;
+    for (int p = from + tid; p < nd; p += kSoftThreads) { const unsigned long long k = pick_key(S.sc[p], p); b = k > b ? k : b; }
+    b = wave_max_key(b);
+    __syncthreads();                 // (wbest may still be read from the previous use)
     if (lane == 0) wbest[wave] = b;
     __syncthreads();
-    Best g = wbest[0];
+    unsigned long long g = wbest[0];
 #pragma unroll
-    for (int k = 1; k < 16; ++k) g = better(g, wbest[k]);
-    // scores[i] is the starting value of the reference's scan: a NaN there stays the maximum,
-    // and when nothing compares greater (all -inf / NaN) position i is the pick as well
-    const float si = S.sc[i];
-    int mp = (si != si || g.p == 0x7fffffff) ? i : g.p;
-    __syncthreads();   // every thread has read wbest / sc[i]
-    if (tid < 7 && mp != i) {   // swap the 7 words of positions i and mp (bit patterns: one is an index)
+    for (int k = 1; k < kW; ++k) g = wbest[k] > g ? wbest[k] : g;
+    const float s0 = S.sc[from];
+    return (s0 != s0 || key_none(g)) ? from : key_pos(g);
+  };
+  int mp = nd > 0 ? argmax_from(0) : 0;
+  for (int i = 0; i < nd; ++i) {
+    // ---- (1) the pick goes to position i
+    __syncthreads();                 // every thread is done with the previous round's state
+    if (tid < 7 && mp != i) {        // swap the 7 words of positions i and mp (bit patterns: one is an index)
       uint32_t *arr = reinterpret_cast<uint32_t *>(base) + (size_t)tid * cap;
       const uint32_t t = arr[i];
       arr[i] = arr[mp];
       arr[mp] = t;
     }
     __syncthreads();
-    // ---- (2) decay + drop flags; (3) compaction
+    // ---- (2) decay of every later position; the SAME pass finds the next pick among the
+    // survivors (valid when nothing is dropped, i.e. when no position moves) and votes on drops
     const float a4[4] = {S.x1[i], S.y1[i], S.x2[i], S.y2[i]};
     const float iarea = S.ar[i];
     const int first = i + 1, count = nd - first;
-    int drops_before = 0;     // running count of dropped positions in earlier chunks
     bool any = false;
-    // pass A: new scores (the drop flag of a position is re-derived from its stored score below)
+    unsigned long long nb = 0;
     for (int c0 = 0; c0 < count; c0 += kSoftThreads) {
       const int p = first + c0 + tid;
-      bool drop = false;
       if (p < nd) {
         const float b4[4] = {S.x1[p], S.y1[p], S.x2[p], S.y2[p]};
         const float ovr = hbb_overlap(a4, iarea, b4, S.ar[p]);
@@ -115,14 +152,31 @@ __global__ __launch_bounds__(kSoftThreads) void soft_nms_kernel(const float *__r
         if (method == 1) { if (ovr > thr) weight = 1.0f - ovr; }
         else if (method == 2) weight = expf(-(ovr * ovr) / sigma);
         else weight = (ovr > thr) ? 0.0f : 1.0f;
-        const float s = weight * S.sc[p];
-        S.sc[p] = s;
-        drop = s < min_score;
+        const float sn = weight * S.sc[p];
+        S.sc[p] = sn;
+        any = any || (sn < min_score);
+        const unsigned long long k = pick_key(sn, p);
+        nb = k > nb ? k : nb;
       }
-      any = any || drop;
     }
-    if (!__syncthreads_or(any ? 1 : 0)) continue;   // block-uniform: nothing dropped this round
-    // total drops -> M, nd'
+    nb = wave_max_key(nb);
+    const bool wany = __any(any) != 0;
+    if (lane == 0) { wbest[wave] = nb; wcnt[wave] = wany ? 1 : 0; }
+    __syncthreads();
+    unsigned long long g = wbest[0];
+    int drops = wcnt[0];
+#pragma unroll
+    for (int k = 1; k < kW; ++k) { g = wbest[k] > g ? wbest[k] : g; drops |= wcnt[k]; }
+    if (!drops) {                    // block-uniform: nothing moves, the vote above is the next pick
+      if (first < nd) {
+        const float s0 = S.sc[first];
+        mp = (s0 != s0 || key_none(g)) ? first : key_pos(g);
+      }
+      continue;
+    }
+    __syncthreads();                 // wcnt is reused below
+    // ---- (3) compaction of the drops, as the sequential loop would have left the array
+    int drops_before = 0;
     int mydrops = 0;
     for (int c0 = 0; c0 < count; c0 += kSoftThreads) {
       const int p = first + c0 + tid;
@@ -133,7 +187,7 @@ __global__ __launch_bounds__(kSoftThreads) void soft_nms_kernel(const float *__r
     __syncthreads();
     int D = 0;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) D += wcnt[k];
+    for (int k = 0; k < kW; ++k) D += wcnt[k];
     const int M = count - D, nd2 = first + M;
     __syncthreads();   // wcnt is reused below
     // holes: dropped positions below nd2, ranked ascending
@@ -146,7 +200,7 @@ __global__ __launch_bounds__(kSoftThreads) void soft_nms_kernel(const float *__r
       __syncthreads();
       int off = 0, tot = 0;
 #pragma unroll
-      for (int k = 0; k < 16; ++k) { const int v = wcnt[k]; off += (k < wave) ? v : 0; tot += v; }
+      for (int k = 0; k < kW; ++k) { const int v = wcnt[k]; off += (k < wave) ? v : 0; tot += v; }
       const int dpre = drops_before + off + __popcll(mk & ((1ull << lane) - 1ull));   // drops in (i, p)
       if (drop && p < nd2) hole[dpre] = p;
       drops_before += tot;
@@ -162,7 +216,7 @@ __global__ __launch_bounds__(kSoftThreads) void soft_nms_kernel(const float *__r
       __syncthreads();
       int off = 0, tot = 0;
 #pragma unroll
-      for (int k = 0; k < 16; ++k) { const int v = wcnt[k]; off += (k < wave) ? v : 0; tot += v; }
+      for (int k = 0; k < kW; ++k) { const int v = wcnt[k]; off += (k < wave) ? v : 0; tot += v; }
       const int dpre = drops_before + off + __popcll(mk & ((1ull << lane) - 1ull));
       if (p < nd && !drop && p >= nd2) {
         const int kept_incl = (p - i) - dpre;          // survivors in (i, p], p itself included
@@ -175,7 +229,9 @@ __global__ __launch_bounds__(kSoftThreads) void soft_nms_kernel(const float *__r
       __syncthreads();
     }
     nd = nd2;
+    if (first < nd) mp = argmax_from(first);   // positions moved: a pass of its own
   }
+  __syncthreads();
   for (int p = tid; p < nd; p += kSoftThreads) {
     float *o = out_dets + (size_t)p * 5;
     o[0] = S.x1[p]; o[1] = S.y1[p]; o[2] = S.x2[p]; o[3] = S.y2[p]; o[4] = S.sc[p];
@@ -216,10 +272,12 @@ extern "C" int obb_soft_nms_f32(const float *dets_dev, int64_t n, float iou_thr,
   OBB_HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&pinned_dev), pinned, 0));
   hipStream_t st = (hipStream_t)stream;
   float *ws = static_cast<float *>(workspace_dev);
-  if (n <= kSoftLds)
-    hipLaunchKernelGGL(soft_nms_kernel<true>, dim3(1), dim3(kSoftThreads), 0, st, dets_dev, (int)n, iou_thr, method, sigma, min_score, ws, out_dets_dev, out_inds_dev, pinned_dev);
+  if (n <= 768)          // measured (tools/bench_soft_nms.py): 1.15 us per round with 4 waves, 1.6 with 16 at n = 500
+    hipLaunchKernelGGL((soft_nms_kernel<true, 256>), dim3(1), dim3(256), 0, st, dets_dev, (int)n, iou_thr, method, sigma, min_score, ws, out_dets_dev, out_inds_dev, pinned_dev);
+  else if (n <= kSoftLds)   // 2.0 us per round with 16 waves, 2.3 with 4 at n = 2000
+    hipLaunchKernelGGL((soft_nms_kernel<true, 1024>), dim3(1), dim3(1024), 0, st, dets_dev, (int)n, iou_thr, method, sigma, min_score, ws, out_dets_dev, out_inds_dev, pinned_dev);
   else
-    hipLaunchKernelGGL(soft_nms_kernel<false>, dim3(1), dim3(kSoftThreads), 0, st, dets_dev, (int)n, iou_thr, method, sigma, min_score, ws, out_dets_dev, out_inds_dev, pinned_dev);
+    hipLaunchKernelGGL((soft_nms_kernel<false, 1024>), dim3(1), dim3(1024), 0, st, dets_dev, (int)n, iou_thr, method, sigma, min_score, ws, out_dets_dev, out_inds_dev, pinned_dev);
   OBB_LAUNCH_CHECK();
   OBB_HIP_TRY(hipStreamSynchronize(st));
   *count_host = *pinned;
