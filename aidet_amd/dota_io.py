@@ -123,6 +123,8 @@ def patch_polys_to_image(polys, scores, labels, patch_name, image_ids, quantize=
     name, rate, x, y = parse_patch_name(patch_name)
     img = image_ids.setdefault(name, len(image_ids))
     if storage_tank_as_hbb:
+        if bboxes is None:
+            raise ValueError('storage_tank_as_hbb needs the detections\' horizontal boxes (bboxes=)')
         tank = labels == classes.index('storage-tank')
         polys = torch.where(tank[:, None], bbox2pointobb(bboxes), polys)
     if quantize:

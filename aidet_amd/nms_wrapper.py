@@ -352,7 +352,15 @@ def nms_collect(tickets):
     if not tickets:
         return []
     L = _lib.lib()
-    recs = torch.stack([t.record for t in tickets]).cpu().numpy()    # synchronises the stream
+    # one copy per device (tickets of one device: one stacked copy; it synchronises that stream)
+    by_dev = {}
+    for i, t in enumerate(tickets):
+        by_dev.setdefault(t.record.device, []).append(i)
+    recs = [None] * len(tickets)
+    for idx in by_dev.values():
+        host = torch.stack([tickets[i].record for i in idx]).cpu().numpy()
+        for row, i in zip(host, idx):
+            recs[i] = row
     info = (ctypes.c_int64 * 4)()
     out = []
     for t, rec in zip(tickets, recs):

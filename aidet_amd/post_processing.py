@@ -137,16 +137,30 @@ def multiclass_nms_with_index(multi_bboxes, multi_scores, score_thr, nms_cfg, ma
     boxes = _per_class_boxes(multi_bboxes, num_fg, 4)[rows, cls]
     dets = torch.cat([boxes, multi_scores[rows, cls + 1][:, None]], 1)
     nms_op, cfg = _resolve_op(nms_cfg, 'nms')
-    kept, keep = nms_op(dets, groups=cls, **cfg)
-    labels = cls[keep]
-    # segments of the keep list: candidates and survivors per class in ONE host read
-    counts = torch.stack([per_class, torch.bincount(labels, minlength=num_fg)]).tolist()
-    bbox_keep_inds, start, kstart = [], 0, 0
-    for m, k in zip(*counts):
-        if m:
-            bbox_keep_inds.append(keep[kstart:kstart + k] - start)
-        start += m
-        kstart += k
+    if nms_op is nms_wrapper.soft_nms:
+        # Soft-NMS re-scores and re-orders its input and has no grouped form: class by class,
+        # as the reference does for every op (rbbox_nms.py:29-49)
+        parts, bbox_keep_inds, start = [], [], 0
+        for m in per_class.tolist():
+            if m:
+                d, k = nms_op(dets[start:start + m], **cfg)
+                parts.append(d)
+                bbox_keep_inds.append(k)
+            start += m
+        kept = torch.cat(parts)
+        labels = torch.cat([cls.new_full((len(k), ), c) for c, k in zip(
+            [c for c, m in enumerate(per_class.tolist()) if m], bbox_keep_inds)])
+    else:
+        kept, keep = nms_op(dets, groups=cls, **cfg)
+        labels = cls[keep]
+        # segments of the keep list: candidates and survivors per class in ONE host read
+        counts = torch.stack([per_class, torch.bincount(labels, minlength=num_fg)]).tolist()
+        bbox_keep_inds, start, kstart = [], 0, 0
+        for m, k in zip(*counts):
+            if m:
+                bbox_keep_inds.append(keep[kstart:kstart + k] - start)
+            start += m
+            kstart += k
     kept, labels = _top_by_score(kept, labels, max_num)
     return kept, labels, bbox_cls_inds, bbox_keep_inds
 

@@ -8,6 +8,7 @@ What is captured (SURVEY.md 8c anchors):
   hbb_iou.npz        A1  mmdet/core/bbox/geometry.py:4-88   bbox_overlaps
   hbb_nms.npz        A2  mmdet/ops/nms/src/nms_cpu.cpp:5-68 via nms_wrapper.py:7-60
   multiclass.npz     A3  core/post_processing/bbox_nms.py:6-76, rbbox_nms.py:6-119
+  multiclass_soft.npz    the same two functions with nms_cfg type='soft_nms' (on multiclass.npz's inputs)
   thetaobb_codec.npz A5  core/rbbox/transforms.py:191-203,280-293,321-395
   assigner.npz           core/bbox/assigners/max_iou_assigner.py:8-202 (MaxIoUAssigner)
   soft_nms.npz           mmdet/ops/nms/src/nms_cpu.cpp:71-210 via nms_wrapper.py:63-118
@@ -273,6 +274,17 @@ def main():
         out['int_%s_thr' % tag] = np.float32(thr)
         out['int_%s_keep' % tag] = nms_wrapper.nms(dets, thr)[1]
     np.savez_compressed(os.path.join(HERE, 'hbb_nms_ties.npz'), **out)
+    # ---- class-wise orchestration with type='soft_nms' (rbbox_nms.py:25-43 resolves any op by name)
+    g = np.load(os.path.join(HERE, 'multiclass.npz'))
+    mb, ms = torch.from_numpy(g['multi_bboxes']), torch.from_numpy(g['multi_scores'])
+    cfg = dict(type='soft_nms', iou_thr=0.5, min_score=0.05)
+    bb, ll, ci, ki = rbbox_nms.multiclass_nms_with_index(mb, ms, 0.05, cfg, 100)
+    out = {'idx_bboxes': bb.numpy(), 'idx_labels': ll.numpy()}
+    for i, k in enumerate(ki):
+        out['idx_keep_%d' % i] = k.numpy()
+    m2, l2 = bbox_nms.multiclass_nms(mb, ms, 0.05, cfg, 100)
+    out['mc_bboxes'] = m2.numpy(); out['mc_labels'] = l2.numpy()
+    np.savez_compressed(os.path.join(HERE, 'multiclass_soft.npz'), **out)
     detector_parts(nms_wrapper, bbox_nms)
     print('wrote', sorted(f for f in os.listdir(HERE) if f.endswith('.npz')))
 

@@ -996,9 +996,14 @@ def test_multiclass_nms_reference_golden_on_gpu(golden):
         det, lab = multiclass_nms(t(g['multi_bboxes']), t(g['multi_scores']), float(g['score_thr']), cfg,
                                   int(g['max_num']), grouped=grouped)
         assert np.array_equal(det.cpu().numpy(), g['mc_bboxes']) and np.array_equal(lab.cpu().numpy(), g['mc_labels'])
-    det, lab = multiclass_nms(t(g['multi_bboxes']), t(g['multi_scores']), float(g['score_thr']),
-                              dict(type='soft_nms', iou_thr=0.5, min_score=0.05), 100)
-    assert det.shape[1] == 5 and len(det) == len(lab) <= 100
+    from aidet_amd.post_processing import multiclass_nms_with_index
+    w = golden('multiclass_soft.npz')        # the same inputs through type='soft_nms' in the reference
+    soft = dict(type='soft_nms', iou_thr=0.5, min_score=0.05)
+    det, lab = multiclass_nms(t(g['multi_bboxes']), t(g['multi_scores']), float(g['score_thr']), soft, 100)
+    assert np.array_equal(det.cpu().numpy(), w['mc_bboxes']) and np.array_equal(lab.cpu().numpy(), w['mc_labels'])
+    b, l, ci, ki = multiclass_nms_with_index(t(g['multi_bboxes']), t(g['multi_scores']), float(g['score_thr']), soft, 100)
+    assert np.array_equal(b.cpu().numpy(), w['idx_bboxes']) and np.array_equal(l.cpu().numpy(), w['idx_labels'])
+    assert all(np.array_equal(k.cpu().numpy(), w['idx_keep_%d' % i]) for i, k in enumerate(ki))
 
 
 def test_tiled_inference_merge_hip_equals_oracle_ops():

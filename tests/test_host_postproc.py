@@ -65,6 +65,27 @@ def test_multiclass_nms_reproduces_reference(golden, oracle_ops):
     assert np.array_equal(det2.numpy(), g['mc_bboxes']) and np.array_equal(lab2.numpy(), g['mc_labels'])
 
 
+def test_multiclass_with_soft_nms_reproduces_reference(golden, monkeypatch):
+    """nms_cfg type='soft_nms' (the alternative the config's comment names, dota_v002...:133-134):
+    class by class like the reference; keep lists, re-scored boxes and the offset-trick variant."""
+    from aidet_amd import nms_wrapper
+    from aidet_amd.post_processing import multiclass_nms, multiclass_nms_with_index
+
+    def soft(dets, iou_thr, method='linear', sigma=0.5, min_score=1e-3, device_id=None):
+        nd, inds = oracle.soft_nms(dets.numpy(), iou_thr, method, sigma, min_score)
+        return torch.from_numpy(nd), torch.from_numpy(inds)
+    monkeypatch.setattr(nms_wrapper, 'soft_nms', soft)
+    g, w = golden('multiclass.npz'), golden('multiclass_soft.npz')
+    mb, ms = torch.from_numpy(g['multi_bboxes']), torch.from_numpy(g['multi_scores'])
+    cfg = dict(type='soft_nms', iou_thr=0.5, min_score=0.05)
+    b, l, ci, ki = multiclass_nms_with_index(mb, ms, 0.05, cfg, 100)
+    assert np.array_equal(b.numpy(), w['idx_bboxes']) and np.array_equal(l.numpy(), w['idx_labels'])
+    for i, k in enumerate(ki):
+        assert np.array_equal(k.numpy(), w['idx_keep_%d' % i])
+    d, l2 = multiclass_nms(mb, ms, 0.05, cfg, 100)
+    assert np.array_equal(d.numpy(), w['mc_bboxes']) and np.array_equal(l2.numpy(), w['mc_labels'])
+
+
 def test_multiclass_edge_cases(oracle_ops):
     from aidet_amd.post_processing import (multiclass_nms, multiclass_nms_with_index, multiclass_rnms,
                                            thetaobb_nms_by_bbox_nms)
