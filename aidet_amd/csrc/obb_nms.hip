@@ -64,7 +64,8 @@ constexpr int kSubRows = kTile / kSub;  // 32 rows: one scan unit = (row sub-til
 constexpr int kRowChunk = 4;
 constexpr int kNmsQueue = 64 + kTile;  // carry (<= 63) + one row's worst case
 constexpr int kCullChunk = 1024;        // column tiles per cull block (LDS list: kSub entries each)
-constexpr int kCells = 65536;           // max Morton cells of the counting sort (8 + 8 bits)
+constexpr int kCells = 262144;          // max Morton cells of the counting sort (9 + 9 bits)
+constexpr int kScanBlockCells = 1024;   // cells per block of the multi-block cell scan (kCells / 1024 blocks at most)
 constexpr int kShards = 64;            // candidate lists / counters (atomic rate)
 constexpr int kPrepBlocks = 1024;     // upper bound on blocks of the prep kernel
 constexpr int kScanBlocks = 2048;     // grid of the scan kernel (waves loop over units)
@@ -538,6 +539,50 @@ __global__ __launch_bounds__(1024) void nms_cellscan_kernel(uint32_t *__restrict
 }
 
 // sid[position] = box id; positions inside a cell are handed out atomically
+// More than 65 536 cells (n > 10^6, or large grouped calls): one block would need a second
+// pass over 1 MB; instead 256-thread blocks of 1024 cells chain their totals the way
+// nms_compact_kernel does (ticket = rank in start order, a flagged word per block, every block
+// sums the words of all earlier tickets).  flags[0] = ticket counter, flags[1 + t] = total | VALID.
+__global__ __launch_bounds__(256) void nms_cellscan_big_kernel(uint32_t *__restrict__ hist,
+                                                               unsigned int *__restrict__ flags) {
+  __shared__ uint32_t wsum[4];
+  __shared__ unsigned int s_ticket;
+  __shared__ unsigned long long red[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) s_ticket = __hip_atomic_fetch_add(&flags[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  const unsigned int t = s_ticket;
+  uint4 *h4 = reinterpret_cast<uint4 *>(hist + (size_t)t * kScanBlockCells) + tid;
+  const uint4 a = *h4;
+  const uint32_t tot = a.x + a.y + a.z + a.w;
+  uint32_t inc = tot;
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t v = (uint32_t)__shfl_up((int)inc, o);
+    if (lane >= o) inc += v;
+  }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  uint32_t base = inc - tot, all = 0;
+  for (int k = 0; k < 4; ++k) { base += (k < wave) ? wsum[k] : 0u; all += wsum[k]; }
+  if (tid == 0) __hip_atomic_store(&flags[1 + t], all | 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  unsigned long long part = 0;
+  for (unsigned int b = tid; b < t; b += 256) {
+    unsigned int v;
+    do { v = __hip_atomic_load(&flags[1 + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (!(v & 0x80000000u));
+    part += (unsigned long long)(v & 0x7FFFFFFFu);
+  }
+  for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o);
+  if (lane == 0) red[wave] = part;
+  __syncthreads();
+  base += (uint32_t)(red[0] + red[1] + red[2] + red[3]);
+  uint4 o;
+  o.x = base; base += a.x;
+  o.y = base; base += a.y;
+  o.z = base; base += a.z;
+  o.w = base;
+  *h4 = o;
+}
+
 __global__ __launch_bounds__(256) void nms_scatter_kernel(const uint32_t *__restrict__ ckey,
                                                           int64_t n, uint32_t *__restrict__ offs,
                                                           uint32_t *__restrict__ sid) {
@@ -1733,7 +1778,7 @@ static thread_local NmsProfile g_prof;
 
 // ---- workspace layout ------------------------------------------------------------
 struct NmsLayout {
-  size_t rec, iv, ar, part, pstat, qb, ckey, sid, qs, pf, pg, pt, tgr, sgr, ginfo, cellpx, tbox, sbox, zero_begin, cnt, ctr, ccnts, hist,
+  size_t rec, iv, ar, part, pstat, qb, ckey, sid, qs, pf, pg, pt, tgr, sgr, ginfo, cellpx, tbox, sbox, zero_begin, cnt, ctr, ccnts, hist, scanflags,
       zero_end, blockcnt, cands, edges, total;
   unsigned long long cap;         // candidate pairs == overlap edges capacity
   unsigned long long unit_worst;  // every (sub-tile, tile) unit there can be
@@ -1775,7 +1820,8 @@ static int nms_layout(int64_t n, int64_t edge_capacity, NmsLayout &L) {
   L.ctr = take(sizeof(NmsCounters));
   L.ccnts = take((size_t)2 * kShards * kCandStride * sizeof(unsigned long long));  // candidates | edges
   L.blockcnt = take(((nn + 1023) / 1024 + 1) * 4);   // ticket + one flagged count per 1024 boxes
-  L.hist = take(kCells * 4);
+  L.scanflags = take((kCells / kScanBlockCells + 1) * 4);   // multi-block cell scan: ticket + one flagged total per block
+  L.hist = take(kCells * 4);   // (LAST of the zeroed range: only the cells a call uses are cleared)
   L.zero_end = off;
   // variable part, all 8-byte entries: [cands | edges | units]; candidates and edges
   // share one capacity, the unit list gets 1/8 of it (never more than unit_worst).
@@ -1948,6 +1994,7 @@ static int nms_enqueue(const char *who, const float *dets_dev, int64_t n, int ki
   NmsCounters *ctr = reinterpret_cast<NmsCounters *>(ws + L.ctr);
   unsigned long long *ccnts = reinterpret_cast<unsigned long long *>(ws + L.ccnts);
   unsigned int *blockcnt = reinterpret_cast<unsigned int *>(ws + L.blockcnt);
+  unsigned int *scanflags = reinterpret_cast<unsigned int *>(ws + L.scanflags);
   uint2 *cands = reinterpret_cast<uint2 *>(ws + L.cands);
   uint2 *edges = cands + cap;
   uint2 *units = edges + cap;
@@ -1988,9 +2035,15 @@ static int nms_enqueue(const char *who, const float *dets_dev, int64_t n, int ki
   const float prune_thr = thr_dev ? 0.0f : iou_thr;
   // phase 0: prep (+ clears the counters) [+ quantise]
   OBB_PHASE(0);
+  // cells ~ n/16 .. n/4, a power of 4 in [4096, 262144]; grouped calls of that size get the next
+  // power: the group bucket takes bits away from space (a merged NMS of 1.25 M boxes in 240
+  // groups had 6 bits of space left per bucket: ~80 boxes per cell, contended histogram words)
+  int hbits = 6;
+  while (hbits < 9 && (1ll << (2 * hbits)) * 16 < n) ++hbits;
+  if (group_dev && n >= (1 << 18) && hbits < 9) ++hbits;
   {
-    // the direct path never touches the cell histogram
-    const size_t zbytes = (direct ? L.hist : L.zero_end) - L.zero_begin;
+    // the direct path never touches the cell histogram; the sorted one clears the cells it uses
+    const size_t zbytes = (direct ? L.scanflags : L.hist + ((size_t)4 << (2 * hbits))) - L.zero_begin;
     uint4 *zero = reinterpret_cast<uint4 *>(ws + L.zero_begin);
     if (kind == OBB_KIND_RBOX)
       hipLaunchKernelGGL(nms_prep_kernel<0>, dim3(pblocks), dim3(256), 0, st, dets_dev, n, rec, iv, ar, direct ? nullptr : part, pstat, group_dev, thr_dev, iou_thr, zero, zbytes / sizeof(uint4));
@@ -2017,16 +2070,14 @@ static int nms_enqueue(const char *who, const float *dets_dev, int64_t n, int ki
     OBB_PHASE(6);
     OBB_PHASE(7);
   } else {
-    // cells ~ n/16 .. n/4, a power of 4 in [4096, 65536]
-    int hbits = 6;
-    while (hbits < 8 && (1ll << (2 * hbits)) * 16 < n) ++hbits;
     hipLaunchKernelGGL(nms_quant_kernel, dim3(pblocks), dim3(256), 0, st, iv, n, part, pstat, (int)pblocks, qb, ckey, hist, hbits, cellpx, group_dev, ginfo);
     OBB_LAUNCH_CHECK();
     // phase 1: spatial sort
     OBB_PHASE(1);
     if (hbits == 6) hipLaunchKernelGGL(nms_cellscan_kernel<4>, dim3(1), dim3(1024), 0, st, hist);
     else if (hbits == 7) hipLaunchKernelGGL(nms_cellscan_kernel<16>, dim3(1), dim3(1024), 0, st, hist);
-    else hipLaunchKernelGGL(nms_cellscan_kernel<64>, dim3(1), dim3(1024), 0, st, hist);
+    else if (hbits == 8) hipLaunchKernelGGL(nms_cellscan_kernel<64>, dim3(1), dim3(1024), 0, st, hist);
+    else hipLaunchKernelGGL(nms_cellscan_big_kernel, dim3((1u << (2 * hbits)) / kScanBlockCells), dim3(256), 0, st, hist, scanflags);
     OBB_LAUNCH_CHECK();
     hipLaunchKernelGGL(nms_scatter_kernel, dim3(pblocks), dim3(256), 0, st, ckey, n, hist, sid);
     OBB_LAUNCH_CHECK();
