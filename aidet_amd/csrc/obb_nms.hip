@@ -91,8 +91,6 @@ struct alignas(16) QuadRec {  // 64 bytes: four float4 loads
 // share a cache line serialise at the memory side.
 struct NmsCounters {
   alignas(256) unsigned long long edges;   // overlap edges found (may exceed capacity)
-  alignas(256) unsigned int light_units;   // light scan units (stored from the back of the list)
-  alignas(256) unsigned int heavy_units;   // heavy scan units (stored from the front)
   alignas(256) long long kept;             // K
   long long rounds;                        // resolve sweeps (most of any shard)
   unsigned int done;                       // resolve workgroups finished
@@ -107,8 +105,9 @@ struct NmsHostInfo {
   unsigned long long edges;
   long long rounds;
   unsigned long long cand_total, cand_worst;
-  unsigned int heavy_units, light_units;
-  unsigned int route, pad;   // 0 fused, 1 direct, 2 sorted: which capacity check applies (obb_nms_async_result)
+  unsigned int heavy_units, light_units;   // scan units over all shards of the unit list
+  unsigned int route;        // 0 fused, 1 direct, 2 sorted: which capacity check applies (obb_nms_async_result)
+  unsigned int unit_worst;   // fullest shard of the unit list (heavy + light)
 };
 static_assert(sizeof(NmsHostInfo) <= OBB_NMS_RESULT_BYTES, "the async result record holds NmsHostInfo");
 
@@ -119,6 +118,11 @@ constexpr int kFlagHbb = 2;      // records hold x1,y1,x2,y2 in rx[]: the refere
 // candidate counters: one per shard, each alone in a 256-byte slot (returning
 // atomics on words that share a cache line serialise at the memory side)
 constexpr int kCandStride = 32;  // in unsigned long long
+// scan-unit counters: heavy[kShards] | light[kShards], 128 bytes apart.  The unit list is cut
+// into kShards segments (tile A feeds segment A % kShards; heavy units from the front of the
+// segment, light ones from its back): ONE pair of counters took a returning atomic from
+// every cull block, ~90 per microsecond -- all of the cull kernel's time at 100k boxes.
+constexpr int kUnitStride = 32;  // in unsigned int
 
 __device__ __forceinline__ void nms_interval(float o, float e, float &lo, float &hi) {
   // margin 2^-21 (|o| + e): covers every rounding of the spec's prefilter
@@ -701,10 +705,10 @@ __global__ __launch_bounds__(256) void nms_cull_kernel(const uint2 *__restrict__
                                                        const uint32_t *__restrict__ tgr,
                                                        const uint32_t *__restrict__ sgr, int nt,
                                                        uint2 *__restrict__ units,
-                                                       unsigned int ucap,
-                                                       NmsCounters *__restrict__ ctr) {
-  // survivors are collected in LDS and published with two global atomics per block
-  // (a returning atomic on one address sustains only ~90 per microsecond)
+                                                       unsigned int scap,
+                                                       unsigned int *__restrict__ ucnts) {
+  // survivors are collected in LDS and published with two global atomics per block, on
+  // the counters of this tile's shard of the unit list
   __shared__ uint32_t lists[kCullChunk * kSub];   // sub << 16 | B; heavy from the front, light from the back
   __shared__ unsigned int nh, nl, gbase_h, gbase_l;
   const int A = blockIdx.x;
@@ -741,19 +745,21 @@ __global__ __launch_bounds__(256) void nms_cull_kernel(const uint2 *__restrict__
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    gbase_h = nh ? atomicAdd(&ctr->heavy_units, nh) : 0u;
-    gbase_l = nl ? atomicAdd(&ctr->light_units, nl) : 0u;
+    const unsigned int sh = (unsigned int)A & (kShards - 1);
+    gbase_h = nh ? atomicAdd(&ucnts[sh * kUnitStride], nh) : 0u;
+    gbase_l = nl ? atomicAdd(&ucnts[(kShards + sh) * kUnitStride], nl) : 0u;
   }
   __syncthreads();
-  // a list that does not fit is reported by the host (heavy + light > ucap); never
-  // write outside it
+  // a segment that does not fit is reported to the host (heavy + light > scap, see
+  // nms_compact_kernel); never write outside it
+  uint2 *seg = units + (size_t)((unsigned int)A & (kShards - 1)) * scap;
   for (unsigned int k = threadIdx.x; k < nh; k += 256) {
     const uint32_t v = lists[k];
-    if (gbase_h + k < ucap) units[gbase_h + k] = make_uint2(((uint32_t)A << 16) | (v & 0xFFFFu), v >> 16);
+    if (gbase_h + k < scap) seg[gbase_h + k] = make_uint2(((uint32_t)A << 16) | (v & 0xFFFFu), v >> 16);
   }
   for (unsigned int k = threadIdx.x; k < nl; k += 256) {
     const uint32_t v = lists[span - 1 - k];
-    if (gbase_l + k < ucap) units[ucap - 1u - (gbase_l + k)] = make_uint2(((uint32_t)A << 16) | (v & 0xFFFFu), v >> 16);
+    if (gbase_l + k < scap) seg[scap - 1u - (gbase_l + k)] = make_uint2(((uint32_t)A << 16) | (v & 0xFFFFu), v >> 16);
   }
 }
 
@@ -917,10 +923,10 @@ __global__ __launch_bounds__(64 * kNmsWaves) void nms_scan_kernel(const uint2 *_
                                                        const float *__restrict__ cellpx, float thr,
                                                        const uint2 *__restrict__ tbox, int nt,
                                                        const uint2 *__restrict__ units,
-                                                       unsigned int ucap,
+                                                       unsigned int scap,
+                                                       const unsigned int *__restrict__ ucnts,
                                                        uint2 *__restrict__ cands,
                                                        unsigned long long segcap,
-                                                       NmsCounters *__restrict__ ctr,
                                                        unsigned long long *__restrict__ ccnts) {
   __shared__ uint2 queue[kNmsWaves][kNmsQueue];
   const int lane = threadIdx.x & 63;
@@ -936,8 +942,17 @@ __global__ __launch_bounds__(64 * kNmsWaves) void nms_scan_kernel(const uint2 *_
   sink.cand = cands + (size_t)shard * segcap;
   sink.segcap = segcap;
   sink.ccnt = ccnts + (size_t)shard * kCandStride;
-  const unsigned int nheavy = ctr->heavy_units, nlight = ctr->light_units;
-  if (nheavy + nlight > ucap) return;   // unit list overflow: reported by the host, nothing valid to scan
+  // lane s holds shard s of the unit list: its counts and their exclusive prefix sums
+  const unsigned int cnt_h = ucnts[lane * kUnitStride], cnt_l = ucnts[(kShards + lane) * kUnitStride];
+  if (__ballot(cnt_h + cnt_l > scap) != 0ull) return;   // unit list overflow: reported by the host, nothing valid to scan
+  unsigned int inc_h = cnt_h, inc_l = cnt_l;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned int th = __shfl_up(inc_h, o), tl = __shfl_up(inc_l, o);
+    if (lane >= o) { inc_h += th; inc_l += tl; }
+  }
+  const unsigned int ex_h = inc_h - cnt_h, ex_l = inc_l - cnt_l;
+  const unsigned int nheavy = __builtin_amdgcn_readlane(inc_h, 63), nlight = __builtin_amdgcn_readlane(inc_l, 63);
   const unsigned int ndiag = (unsigned int)nt * kSub;
   const unsigned int nun = ndiag + nheavy + nlight;
   for (unsigned int k = gw; k < nun; k += nw) {
@@ -945,8 +960,15 @@ __global__ __launch_bounds__(64 * kNmsWaves) void nms_scan_kernel(const uint2 *_
     if (k < ndiag) {
       A = B = k / kSub; sub = k % kSub;
     } else {
+      // all heavy units first (LPT order), then the light ones; the shard of a flat index is
+      // the last lane whose exclusive prefix is <= it (empty shards share a prefix with the next)
       const unsigned int j = k - ndiag;
-      const uint2 un = (j < nheavy) ? units[j] : units[ucap - 1u - (j - nheavy)];
+      const bool hv = j < nheavy;
+      const unsigned int jj = hv ? j : j - nheavy;
+      const int sh = __popcll(__ballot((hv ? ex_h : ex_l) <= jj)) - 1;
+      const unsigned int within = jj - (unsigned int)__builtin_amdgcn_readlane(hv ? ex_h : ex_l, sh);
+      const uint2 *seg = units + (size_t)sh * scap;
+      const uint2 un = hv ? seg[within] : seg[scap - 1u - within];
       A = un.x >> 16; B = un.x & 0xFFFFu; sub = un.y;
     }
     const uint32_t sa0 = A * kTile + sub * kSubRows;         // this unit's 32 rows
@@ -1438,7 +1460,7 @@ __global__ __launch_bounds__(COMPACT ? kResolveThreadsCompact : kResolveThreads)
         hinfo->rounds = (long long)__hip_atomic_load(reinterpret_cast<unsigned long long *>(&ctr->rounds), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         hinfo->cand_total = v; hinfo->cand_worst = mx;
         hinfo->heavy_units = 0u; hinfo->light_units = 0u;
-        hinfo->route = 1u; hinfo->pad = 0u;
+        hinfo->route = 1u; hinfo->unit_worst = 0u;
       }
     }
   }
@@ -1461,6 +1483,7 @@ __global__ __launch_bounds__(1024) void nms_compact_kernel(const int *__restrict
                                                            int64_t *__restrict__ keep,
                                                            NmsCounters *__restrict__ ctr,
                                                            const unsigned long long *__restrict__ ccnts,
+                                                           const unsigned int *__restrict__ ucnts,
                                                            NmsHostInfo *__restrict__ hinfo) {
   __shared__ int wsum[16];
   __shared__ long long red[16];
@@ -1499,16 +1522,20 @@ __global__ __launch_bounds__(1024) void nms_compact_kernel(const int *__restrict
     unsigned long long v = ccnts[(size_t)lane * kCandStride], mx = v;
     const unsigned long long ev = ccnts[(size_t)(kShards + lane) * kCandStride];
     mx = ev > mx ? ev : mx;   // fullest segment of either kind
+    unsigned int uh = ucnts[lane * kUnitStride], ul = ucnts[(kShards + lane) * kUnitStride], uw = uh + ul;
     for (int o = 32; o > 0; o >>= 1) {
       v += __shfl_xor(v, o);
       const unsigned long long tt = __shfl_xor(mx, o);
       mx = tt > mx ? tt : mx;
+      uh += __shfl_xor(uh, o); ul += __shfl_xor(ul, o);
+      const unsigned int tw = __shfl_xor(uw, o);
+      uw = tw > uw ? tw : uw;
     }
     if (lane == 0) {
       hinfo->kept = sbase + tot; hinfo->edges = ctr->edges; hinfo->rounds = ctr->rounds;
       hinfo->cand_total = v; hinfo->cand_worst = mx;
-      hinfo->heavy_units = ctr->heavy_units; hinfo->light_units = ctr->light_units;
-      hinfo->route = 2u; hinfo->pad = 0u;
+      hinfo->heavy_units = uh; hinfo->light_units = ul;
+      hinfo->route = 2u; hinfo->unit_worst = uw;
     }
   }
 }
@@ -1760,7 +1787,7 @@ __global__ __launch_bounds__(1024) void nms_small_kernel(const float *__restrict
     hinfo->cand_total = found;
     hinfo->cand_worst = 0ull;
     hinfo->heavy_units = 0u; hinfo->light_units = 0u;
-    hinfo->route = 0u; hinfo->pad = 0u;
+    hinfo->route = 0u; hinfo->unit_worst = 0u;
   }
 }
 
@@ -1778,10 +1805,10 @@ static thread_local NmsProfile g_prof;
 
 // ---- workspace layout ------------------------------------------------------------
 struct NmsLayout {
-  size_t rec, iv, ar, part, pstat, qb, ckey, sid, qs, pf, pg, pt, tgr, sgr, ginfo, cellpx, tbox, sbox, zero_begin, cnt, ctr, ccnts, hist, scanflags,
+  size_t rec, iv, ar, part, pstat, qb, ckey, sid, qs, pf, pg, pt, tgr, sgr, ginfo, cellpx, tbox, sbox, zero_begin, cnt, ctr, ccnts, ucnts, hist, scanflags,
       zero_end, blockcnt, cands, edges, total;
   unsigned long long cap;         // candidate pairs == overlap edges capacity
-  unsigned long long unit_worst;  // every (sub-tile, tile) unit there can be
+  unsigned long long unit_worst;  // kShards x the most units one shard of the unit list can get
   int64_t ntiles;
 };
 
@@ -1814,11 +1841,15 @@ static int nms_layout(int64_t n, int64_t edge_capacity, NmsLayout &L) {
   L.cellpx = take(2 * sizeof(float));
   L.tbox = take(nt * sizeof(uint2));
   L.sbox = take(nt * kSub * sizeof(uint2));
-  L.unit_worst = (unsigned long long)nt * (nt + 1) / 2 * kSub;   // (diagonal ones are not listed)
+  {  // shard 0 takes tiles 0, 64, 128, ...; tile A lists at most (nt - 1 - A) * kSub units
+    const unsigned long long m = (nt + kShards - 1) / kShards;
+    L.unit_worst = (m * nt - kShards * (m * (m - 1) / 2)) * kSub * kShards;
+  }
   L.zero_begin = off;
   L.cnt = take(nn * 4);
   L.ctr = take(sizeof(NmsCounters));
   L.ccnts = take((size_t)2 * kShards * kCandStride * sizeof(unsigned long long));  // candidates | edges
+  L.ucnts = take((size_t)2 * kShards * kUnitStride * sizeof(unsigned int));        // heavy | light scan units
   L.blockcnt = take(((nn + 1023) / 1024 + 1) * 4);   // ticket + one flagged count per 1024 boxes
   L.scanflags = take((kCells / kScanBlockCells + 1) * 4);   // multi-block cell scan: ticket + one flagged total per block
   L.hist = take(kCells * 4);   // (LAST of the zeroed range: only the cells a call uses are cleared)
@@ -1847,6 +1878,7 @@ static void nms_split(unsigned long long entries, unsigned long long unit_worst,
     if (ucap > unit_worst) ucap = unit_worst;
   }
   if (ucap > 0xFFFFFFFFull) ucap = 0xFFFFFFFFull;
+  ucap -= ucap % kShards;   // kShards equal segments
   segcap = (entries - ucap) / 2 / kShards;
 }
 
@@ -1881,6 +1913,8 @@ static int nms_capacities(int64_t n, size_t workspace_bytes, NmsLayout &L, NmsEn
   q.segcap = segcap;
   q.cap = segcap * kShards;
   q.ucap = (unsigned int)ucap64;
+  if (q.ucap < kShards)
+    return set_err(OBB_EWORKSPACE, "obb_nms_f32: workspace %zu bytes < minimum %zu", workspace_bytes, L.total + 2 * kShards * sizeof(uint2));
   return OBB_OK;
 }
 
@@ -1903,14 +1937,16 @@ static int nms_verdict(const NmsHostInfo &h, const NmsEnqueued &q, int64_t *info
     }
     return OBB_OK;
   }
-  if ((unsigned long long)h.heavy_units + h.light_units > q.ucap) {
-    // the unit list is 1/8 of the pair capacity: ask for a capacity that holds it
-    unsigned long long need = ((unsigned long long)h.heavy_units + h.light_units) * 8;
+  if (h.unit_worst > q.ucap / kShards) {
+    // the unit list is 1/8 of the pair capacity, cut into kShards segments: ask for a capacity
+    // whose segments hold the fullest one (which tile feeds which segment does not depend on
+    // scheduling, and L.unit_worst segments always fit, so a retry loop terminates)
+    unsigned long long need = (unsigned long long)h.unit_worst * kShards * 8;
     need += need / 4 + 1024;
     if (need < q.cap * 2) need = q.cap * 2;
     if (info_host) { info_host[0] = 0; info_host[3] = (int64_t)need; }
-    return set_err(OBB_EWORKSPACE, "obb_nms_f32: %u scan units exceed the unit capacity %u; retry with edge_capacity >= %llu",
-                   h.heavy_units + h.light_units, q.ucap, need);
+    return set_err(OBB_EWORKSPACE, "obb_nms_f32: %u scan units in one of %d segments exceed the segment capacity %u; retry with edge_capacity >= %llu",
+                   h.unit_worst, kShards, q.ucap / kShards, need);
   }
   if (h.cand_worst > q.segcap) {
     // capacity that fits the fullest candidate / edge segment on a retry.  Which of the 64
@@ -1993,6 +2029,7 @@ static int nms_enqueue(const char *who, const float *dets_dev, int64_t n, int ki
   int *cnt = reinterpret_cast<int *>(ws + L.cnt);
   NmsCounters *ctr = reinterpret_cast<NmsCounters *>(ws + L.ctr);
   unsigned long long *ccnts = reinterpret_cast<unsigned long long *>(ws + L.ccnts);
+  unsigned int *ucnts = reinterpret_cast<unsigned int *>(ws + L.ucnts);
   unsigned int *blockcnt = reinterpret_cast<unsigned int *>(ws + L.blockcnt);
   unsigned int *scanflags = reinterpret_cast<unsigned int *>(ws + L.scanflags);
   uint2 *cands = reinterpret_cast<uint2 *>(ws + L.cands);
@@ -2085,7 +2122,7 @@ static int nms_enqueue(const char *who, const float *dets_dev, int64_t n, int ki
     OBB_PHASE(2);
     hipLaunchKernelGGL(nms_permute_kernel, dim3((unsigned)nt), dim3(kTile), 0, st, qb, sid, ar, n, qs, pf, tbox, sbox, group_dev, ginfo, pg, tgr, sgr, thr_dev, pt);
     OBB_LAUNCH_CHECK();
-    hipLaunchKernelGGL(nms_cull_kernel, dim3((unsigned)nt, (unsigned)((nt + kCullChunk - 1) / kCullChunk)), dim3(256), 0, st, tbox, sbox, tgr, sgr, nt, units, ucap, ctr);
+    hipLaunchKernelGGL(nms_cull_kernel, dim3((unsigned)nt, (unsigned)((nt + kCullChunk - 1) / kCullChunk)), dim3(256), 0, st, tbox, sbox, tgr, sgr, nt, units, ucap / kShards, ucnts);
     OBB_LAUNCH_CHECK();
     // phase 3: scan (broad phase)
     OBB_PHASE(3);
@@ -2093,7 +2130,7 @@ static int nms_enqueue(const char *who, const float *dets_dev, int64_t n, int ki
       const long long maxblocks = ((long long)L.unit_worst + kNmsWaves - 1) / kNmsWaves;
       const long long pb = tuning(OBB_TUNE_NMS_SCAN_BLOCKS, kScanBlocks);
       const unsigned gb = (unsigned)(maxblocks < pb ? maxblocks : pb);
-      hipLaunchKernelGGL(nms_scan_kernel, dim3(gb), dim3(64 * kNmsWaves), 0, st, qs, pf, pg, pt, cellpx, prune_thr, tbox, nt, units, ucap, cands, segcap, ctr, ccnts);
+      hipLaunchKernelGGL(nms_scan_kernel, dim3(gb), dim3(64 * kNmsWaves), 0, st, qs, pf, pg, pt, cellpx, prune_thr, tbox, nt, units, ucap / kShards, ucnts, cands, segcap, ccnts);
       OBB_LAUNCH_CHECK();
     }
     // phase 4: clip (narrow phase)
@@ -2107,7 +2144,7 @@ static int nms_enqueue(const char *who, const float *dets_dev, int64_t n, int ki
     // phase 6: compaction (one pass: every block publishes its count and sums its predecessors')
     OBB_PHASE(6);
     const unsigned cblocks = (unsigned)((n + 1023) / 1024);
-    hipLaunchKernelGGL(nms_compact_kernel, dim3(cblocks), dim3(1024), 0, st, cnt, n, blockcnt, keep_dev, ctr, ccnts, result);
+    hipLaunchKernelGGL(nms_compact_kernel, dim3(cblocks), dim3(1024), 0, st, cnt, n, blockcnt, keep_dev, ctr, ccnts, ucnts, result);
     OBB_LAUNCH_CHECK();
     OBB_PHASE(7);
   }
