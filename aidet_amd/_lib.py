@@ -28,7 +28,7 @@ MODE = {'iou': 0, 'iof': 1}
 NMS_STRICT = 1          # OBB_NMS_STRICT: suppress on `>` (nms_kernel.cu:61) instead of `>=` (nms_cpu.cpp:56)
 NMS_RESULT_BYTES = 64   # OBB_NMS_RESULT_BYTES
 # obb_set_tuning knobs (test / experiment hooks, include/obbops.h)
-TUNE_NMS_FUSED_MAX, TUNE_NMS_DIRECT_MAX, TUNE_NMS_SCAN_BLOCKS, TUNE_RROI_GROUPS, TUNE_OVERLAPS_ROWS = range(5)
+TUNE_NMS_FUSED_MAX, TUNE_NMS_DIRECT_MAX, TUNE_NMS_SCAN_BLOCKS, TUNE_RROI_GROUPS, TUNE_OVERLAPS_ROWS, TUNE_NMS_INLINE_MAX = range(6)
 
 _lib = None
 

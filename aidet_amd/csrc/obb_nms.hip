@@ -68,7 +68,7 @@ constexpr int kCells = 262144;          // max Morton cells of the counting sort
 constexpr int kScanBlockCells = 1024;   // cells per block of the multi-block cell scan (kCells / 1024 blocks at most)
 constexpr int kShards = 64;            // candidate lists / counters (atomic rate)
 constexpr int kPrepBlocks = 1024;     // upper bound on blocks of the prep kernel
-constexpr int kScanBlocks = 2048;     // grid of the scan kernel (waves loop over units)
+constexpr int kScanBlocks = 2048;     // grid of the scan kernel = one resident set at 8 waves/SIMD (waves loop over units)
 constexpr int kClipBlocksPerShard = 32;
 
 constexpr uint8_t kUndecided = 0, kKept = 1, kSuppressed = 2;
@@ -804,200 +804,7 @@ __device__ __forceinline__ bool prune_aabb(const Prune &pr, uint32_t rlo, uint32
   return I * (1.0f + pr.thr) >= (pr.thr * (ra + ca)) * 0.999999f;
 }
 
-// The per-wave LDS queue holds RAW candidates as spatial positions (row, column).  A
-// batch of 64 is pruned with one candidate per lane (the two bounds cost ~40 VALU: per
-// batch, not per candidate), and the survivors go to the wave's global candidate list
-// as (box id, box id) with one returning atomic per batch.
-struct SortedSink {
-  Prune pr;
-  const uint4 *__restrict__ pf;             // per position: packed interval, area, box id
-  const int32_t *__restrict__ pg;           // per position: group id (grouped calls, else null)
-  const float *__restrict__ pt;             // per position: threshold (per-box thresholds, else null)
-  uint2 *__restrict__ cand;                 // this wave's candidate segment
-  unsigned long long segcap;
-  unsigned long long *__restrict__ ccnt;
-
-  __device__ __forceinline__ void flush(const uint2 *q, int count, int lane) const {
-    bool keep = lane < count;
-    uint2 ids = make_uint2(0u, 0u);
-    if (keep) {
-      const uint2 e = q[lane];
-      const uint4 a = pf[e.x], b = pf[e.y];
-      const float ra = __uint_as_float(a.z), ca = __uint_as_float(b.z);
-      ids = make_uint2(a.w, b.w);
-      if (pg) keep = pg[e.x] == pg[e.y];   // boxes of different groups never interact
-      // per-box thresholds: the one that applies is the earlier box's, i.e. one of the two --
-      // a pair that cannot reach the SMALLER one cannot reach it either
-      Prune p = pr;
-      if (pt) p.thr = min_sel(pt[e.x], pt[e.y]);
-      if (keep && p.thr > 0.0f) {
-        // an interval that touches the first or last cell may have been CLAMPED into the frame
-        // (robust frame, nms_quant_kernel): its cells then say nothing about its extent
-        const bool edge = qedge(a.x, a.y) || qedge(b.x, b.y);
-        keep = prune_area(p, ra, ca) && (edge || prune_aabb(p, a.x, a.y, ra, b.x, b.y, ca));
-      }
-    }
-    const uint64_t mk = __ballot(keep);
-    if (mk == 0) return;
-    unsigned long long base = 0;
-    if (lane == 0) base = atomicAdd(ccnt, (unsigned long long)__popcll(mk));
-    base = __shfl(base, 0) + (unsigned long long)__popcll(mk & ((1ull << lane) - 1ull));
-    if (keep && base < segcap) cand[base] = ids;
-  }
-};
-
-template <bool DIAG, class Sink>
-__device__ __forceinline__ void nms_scan_rows(uint2 rv, uint32_t rows, uint32_t sa0, uint32_t sb0,
-                                              const uint2 (&col)[4], const Sink &sink, uint2 *q, int &qn,
-                                              int lane) {
-  const uint64_t lt_mask = (1ull << lane) - 1ull;
-  const uint32_t sbl = sb0 + lane * kNmsColsPerLane;
-  while (rows) {   // `rows`: the rows of this sub-tile that meet the column tile's box
-    // a chunk of rows: the per-pair results stay in registers, the lanes with a candidate
-    // come out of the vote as a scalar mask
-    uint32_t t[kRowChunk][4];
-    uint64_t lm[kRowChunk];
-    int rr[kRowChunk];
-#pragma unroll
-    for (int u = 0; u < kRowChunk; ++u) {
-      // lane kSubRows holds a sentinel row (never a candidate): padding of the last chunk
-      const int r = rows ? __builtin_ctz(rows) : kSubRows;
-      rows &= rows - 1u;
-      rr[u] = r;
-      const uint32_t rlo = (uint32_t)__builtin_amdgcn_readlane((int)rv.x, r);
-      const uint32_t rhi = (uint32_t)__builtin_amdgcn_readlane((int)rv.y, r);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) t[u][c] = qdisjoint(rlo, rhi, col[c].x, col[c].y);
-      if (DIAG) {  // only pairs (row, col) with col > row exist in a diagonal tile
-        const uint32_t sa = sa0 + r;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) t[u][c] |= (sbl + c > sa) ? 0u : 1u;
-      }
-      const uint32_t m = min(min(t[u][0], t[u][1]), min(t[u][2], t[u][3]));
-      lm[u] = __ballot(m == 0u);
-    }
-#pragma unroll
-    for (int u = 0; u < kRowChunk; ++u) {
-      if (lm[u] == 0) continue;   // (wave-uniform) no candidate in this row: the usual case
-      const uint32_t sa = sa0 + (uint32_t)rr[u];
-      uint64_t mk = lm[u];
-      if (__popcll(mk) <= 2) {
-        // one or two lanes: read their four results back and push from scalar registers
-        while (mk) {
-          const int l = __builtin_ctzll(mk);
-          mk &= mk - 1ull;
-          const uint32_t sb = sb0 + (uint32_t)l * kNmsColsPerLane;
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            if (__builtin_amdgcn_readlane((int)t[u][c], l) == 0) {
-              if (lane == 0) q[qn] = make_uint2(sa, sb + (uint32_t)c);
-              ++qn;
-            }
-          }
-        }
-      } else {
-#pragma unroll
-        for (int c = 0; c < kNmsColsPerLane; ++c) {
-          const bool cnd = t[u][c] == 0u;
-          const uint64_t mc = __ballot(cnd);
-          if (cnd) q[qn + __popcll(mc & lt_mask)] = make_uint2(sa, sbl + c);
-          qn += __popcll(mc);
-        }
-      }
-      while (qn >= 64) {  // prune + flush a full batch
-        qn -= 64;
-        __builtin_amdgcn_wave_barrier();
-        sink.flush(q + qn, 64, lane);
-      }
-    }
-  }
-}
-
-// Wave g handles units g, g + (waves in the grid), ... of
-//   [ diagonal units (sub-tile vs. its own tile, implicit) | heavy ... | light ... ].
-// Consecutive blocks land on different CUs, so this deals the expensive units evenly.
-__global__ __launch_bounds__(64 * kNmsWaves) void nms_scan_kernel(const uint2 *__restrict__ qs,
-                                                       const uint4 *__restrict__ pf,
-                                                       const int32_t *__restrict__ pg,
-                                                       const float *__restrict__ pt,
-                                                       const float *__restrict__ cellpx, float thr,
-                                                       const uint2 *__restrict__ tbox, int nt,
-                                                       const uint2 *__restrict__ units,
-                                                       unsigned int scap,
-                                                       const unsigned int *__restrict__ ucnts,
-                                                       uint2 *__restrict__ cands,
-                                                       unsigned long long segcap,
-                                                       unsigned long long *__restrict__ ccnts) {
-  __shared__ uint2 queue[kNmsWaves][kNmsQueue];
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  uint2 *q = queue[wave];
-  int qn = 0;
-  const uint32_t gw = blockIdx.x * kNmsWaves + wave;       // global wave id
-  const uint32_t nw = gridDim.x * kNmsWaves;
-  const int shard = (int)(gw & (kShards - 1));
-  SortedSink sink;
-  sink.pr.thr = thr; sink.pr.cpx = cellpx[0]; sink.pr.cpy = cellpx[1];
-  sink.pf = pf; sink.pg = pg; sink.pt = pt;
-  sink.cand = cands + (size_t)shard * segcap;
-  sink.segcap = segcap;
-  sink.ccnt = ccnts + (size_t)shard * kCandStride;
-  // lane s holds shard s of the unit list: its counts and their exclusive prefix sums
-  const unsigned int cnt_h = ucnts[lane * kUnitStride], cnt_l = ucnts[(kShards + lane) * kUnitStride];
-  if (__ballot(cnt_h + cnt_l > scap) != 0ull) return;   // unit list overflow: reported by the host, nothing valid to scan
-  unsigned int inc_h = cnt_h, inc_l = cnt_l;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const unsigned int th = __shfl_up(inc_h, o), tl = __shfl_up(inc_l, o);
-    if (lane >= o) { inc_h += th; inc_l += tl; }
-  }
-  const unsigned int ex_h = inc_h - cnt_h, ex_l = inc_l - cnt_l;
-  const unsigned int nheavy = __builtin_amdgcn_readlane(inc_h, 63), nlight = __builtin_amdgcn_readlane(inc_l, 63);
-  const unsigned int ndiag = (unsigned int)nt * kSub;
-  const unsigned int nun = ndiag + nheavy + nlight;
-  for (unsigned int k = gw; k < nun; k += nw) {
-    uint32_t A, B, sub;
-    if (k < ndiag) {
-      A = B = k / kSub; sub = k % kSub;
-    } else {
-      // all heavy units first (LPT order), then the light ones; the shard of a flat index is
-      // the last lane whose exclusive prefix is <= it (empty shards share a prefix with the next)
-      const unsigned int j = k - ndiag;
-      const bool hv = j < nheavy;
-      const unsigned int jj = hv ? j : j - nheavy;
-      const int sh = __popcll(__ballot((hv ? ex_h : ex_l) <= jj)) - 1;
-      const unsigned int within = jj - (unsigned int)__builtin_amdgcn_readlane(hv ? ex_h : ex_l, sh);
-      const uint2 *seg = units + (size_t)sh * scap;
-      const uint2 un = hv ? seg[within] : seg[scap - 1u - within];
-      A = un.x >> 16; B = un.x & 0xFFFFu; sub = un.y;
-    }
-    const uint32_t sa0 = A * kTile + sub * kSubRows;         // this unit's 32 rows
-    const uint32_t sb0 = B * kTile;                          // 256 columns
-    // qs is padded to whole tiles (sentinel intervals never match); lanes >= 32 hold a
-    // sentinel row
-    const bool rl = lane < kSubRows;
-    uint2 rv = make_uint2(kSentLo, kSentHi);
-    if (rl) rv = qs[sa0 + lane];
-    const uint2 tb = tbox[B];
-    uint2 col[4];
-    {
-      const uint4 *cp = reinterpret_cast<const uint4 *>(qs + sb0 + lane * kNmsColsPerLane);
-      const uint4 a = cp[0], b = cp[1];
-      col[0] = make_uint2(a.x, a.y); col[1] = make_uint2(a.z, a.w);
-      col[2] = make_uint2(b.x, b.y); col[3] = make_uint2(b.z, b.w);
-    }
-    // only rows whose interval meets the column tile's box can have a candidate
-    const uint32_t rows = (uint32_t)__ballot(rl && qdisjoint(rv.x, rv.y, tb.x, tb.y) == 0u);
-    if (A == B) nms_scan_rows<true>(rv, rows, sa0, sb0, col, sink, q, qn, lane);
-    else nms_scan_rows<false>(rv, rows, sa0, sb0, col, sink, q, qn, lane);
-  }
-  if (qn > 0) {  // final partial batch, once per wave
-    __builtin_amdgcn_wave_barrier();
-    sink.flush(q, qn, lane);
-  }
-}
-
-// ---- narrow-phase helpers (clip kernel and the direct scan) ------------------------------
+// ---- narrow-phase helpers (clip kernel, the direct scan and the in-line clip of the sorted scan) ------------------------------
 __device__ __forceinline__ void load_rec(const QuadRec *__restrict__ rec, uint32_t p, Quad &q,
                                          uint32_t &key, int &grp, float &thr) {
   const float4 *r = reinterpret_cast<const float4 *>(rec + p);
@@ -1071,6 +878,254 @@ __device__ __forceinline__ void push_edges(bool hit, uint32_t src, uint32_t dst,
       atomicAdd(&cnt[dst], 1);
     }
   }
+}
+
+// The per-wave LDS queue holds RAW candidates as spatial positions (row, column).  A
+// batch of 64 is pruned with one candidate per lane (the two bounds cost ~40 VALU: per
+// batch, not per candidate), and the survivors go to the wave's global candidate list
+// as (box id, box id) with one returning atomic per batch.
+//
+// INLINE (n up to a few 10^5, where the call is a chain of latency-bound launches): the
+// survivors are not listed but collected in a second per-wave LDS queue and CLIPPED by this
+// wave as soon as 64 of them are there (full lanes in dense scenes; one partial batch at the
+// end of the wave in sparse ones) -- the clip launch, its candidate list round trip and its
+// load chain disappear (100k sparse boxes: scan 21 + clip 17 + 2.5 us gap -> one kernel).
+constexpr int kClipQueue = 128;   // carry (<= 63) + one pruned batch (<= 64)
+
+template <bool INLINE>
+struct SortedSink {
+  Prune pr;
+  const uint4 *__restrict__ pf;             // per position: packed interval, area, box id
+  const int32_t *__restrict__ pg;           // per position: group id (grouped calls, else null)
+  const float *__restrict__ pt;             // per position: threshold (per-box thresholds, else null)
+  uint2 *__restrict__ cand;                 // this wave's candidate segment
+  unsigned long long segcap;
+  unsigned long long *__restrict__ ccnt;
+  // INLINE only
+  const QuadRec *__restrict__ rec;
+  int flags;
+  uint2 *__restrict__ eseg;                 // this wave's edge segment
+  unsigned long long *__restrict__ ecnt;
+  int *__restrict__ cnt;
+  uint2 *cq;                                // LDS: pruned candidates waiting for a full clip batch
+  int cqn;
+
+  __device__ __forceinline__ void clip_batch(const uint2 *b, int count, int lane) const {
+    bool hit = false;
+    uint32_t src = 0, dst = 0;
+    if (lane < count) hit = clip_pair(rec, b[lane], flags, src, dst);
+    push_edges(hit, src, dst, eseg, segcap, ecnt, cnt, lane);
+  }
+  __device__ __forceinline__ void finish(int lane) {   // end of the wave: the partial batch
+    if (INLINE && cqn > 0) {
+      __builtin_amdgcn_wave_barrier();
+      clip_batch(cq, cqn, lane);
+      cqn = 0;
+    }
+  }
+
+  __device__ __forceinline__ void flush(const uint2 *q, int count, int lane) {
+    bool keep = lane < count;
+    uint2 ids = make_uint2(0u, 0u);
+    if (keep) {
+      const uint2 e = q[lane];
+      const uint4 a = pf[e.x], b = pf[e.y];
+      const float ra = __uint_as_float(a.z), ca = __uint_as_float(b.z);
+      ids = make_uint2(a.w, b.w);
+      if (pg) keep = pg[e.x] == pg[e.y];   // boxes of different groups never interact
+      // per-box thresholds: the one that applies is the earlier box's, i.e. one of the two --
+      // a pair that cannot reach the SMALLER one cannot reach it either
+      Prune p = pr;
+      if (pt) p.thr = min_sel(pt[e.x], pt[e.y]);
+      if (keep && p.thr > 0.0f) {
+        // an interval that touches the first or last cell may have been CLAMPED into the frame
+        // (robust frame, nms_quant_kernel): its cells then say nothing about its extent
+        const bool edge = qedge(a.x, a.y) || qedge(b.x, b.y);
+        keep = prune_area(p, ra, ca) && (edge || prune_aabb(p, a.x, a.y, ra, b.x, b.y, ca));
+      }
+    }
+    const uint64_t mk = __ballot(keep);
+    if (mk == 0) return;
+    if (INLINE) {
+      if (lane == 0) atomicAdd(ccnt, (unsigned long long)__popcll(mk));   // statistics only
+      if (keep) cq[cqn + __popcll(mk & ((1ull << lane) - 1ull))] = ids;
+      cqn += __popcll(mk);
+      if (cqn >= 64) {
+        cqn -= 64;
+        __builtin_amdgcn_wave_barrier();
+        clip_batch(cq + cqn, 64, lane);
+      }
+      return;
+    }
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(ccnt, (unsigned long long)__popcll(mk));
+    base = __shfl(base, 0) + (unsigned long long)__popcll(mk & ((1ull << lane) - 1ull));
+    if (keep && base < segcap) cand[base] = ids;
+  }
+};
+
+template <bool DIAG, class Sink>
+__device__ __forceinline__ void nms_scan_rows(uint2 rv, uint32_t rows, uint32_t sa0, uint32_t sb0,
+                                              const uint2 (&col)[4], Sink &sink, uint2 *q, int &qn,
+                                              int lane) {
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+  const uint32_t sbl = sb0 + lane * kNmsColsPerLane;
+  while (rows) {   // `rows`: the rows of this sub-tile that meet the column tile's box
+    // a chunk of rows: the per-pair results stay in registers, the lanes with a candidate
+    // come out of the vote as a scalar mask
+    uint32_t t[kRowChunk][4];
+    uint64_t lm[kRowChunk];
+    int rr[kRowChunk];
+#pragma unroll
+    for (int u = 0; u < kRowChunk; ++u) {
+      // lane kSubRows holds a sentinel row (never a candidate): padding of the last chunk
+      const int r = rows ? __builtin_ctz(rows) : kSubRows;
+      rows &= rows - 1u;
+      rr[u] = r;
+      const uint32_t rlo = (uint32_t)__builtin_amdgcn_readlane((int)rv.x, r);
+      const uint32_t rhi = (uint32_t)__builtin_amdgcn_readlane((int)rv.y, r);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) t[u][c] = qdisjoint(rlo, rhi, col[c].x, col[c].y);
+      if (DIAG) {  // only pairs (row, col) with col > row exist in a diagonal tile
+        const uint32_t sa = sa0 + r;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) t[u][c] |= (sbl + c > sa) ? 0u : 1u;
+      }
+      const uint32_t m = min(min(t[u][0], t[u][1]), min(t[u][2], t[u][3]));
+      lm[u] = __ballot(m == 0u);
+    }
+#pragma unroll
+    for (int u = 0; u < kRowChunk; ++u) {
+      if (lm[u] == 0) continue;   // (wave-uniform) no candidate in this row: the usual case
+      const uint32_t sa = sa0 + (uint32_t)rr[u];
+      uint64_t mk = lm[u];
+      if (__popcll(mk) <= 2) {
+        // one or two lanes: read their four results back and push from scalar registers
+        while (mk) {
+          const int l = __builtin_ctzll(mk);
+          mk &= mk - 1ull;
+          const uint32_t sb = sb0 + (uint32_t)l * kNmsColsPerLane;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            if (__builtin_amdgcn_readlane((int)t[u][c], l) == 0) {
+              if (lane == 0) q[qn] = make_uint2(sa, sb + (uint32_t)c);
+              ++qn;
+            }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < kNmsColsPerLane; ++c) {
+          const bool cnd = t[u][c] == 0u;
+          const uint64_t mc = __ballot(cnd);
+          if (cnd) q[qn + __popcll(mc & lt_mask)] = make_uint2(sa, sbl + c);
+          qn += __popcll(mc);
+        }
+      }
+      while (qn >= 64) {  // prune + flush a full batch
+        qn -= 64;
+        __builtin_amdgcn_wave_barrier();
+        sink.flush(q + qn, 64, lane);
+      }
+    }
+  }
+}
+
+// Wave g handles units g, g + (waves in the grid), ... of
+//   [ diagonal units (sub-tile vs. its own tile, implicit) | heavy ... | light ... ].
+// Consecutive blocks land on different CUs, so this deals the expensive units evenly.
+template <bool INLINE>
+__global__ __launch_bounds__(64 * kNmsWaves) void nms_scan_kernel(const uint2 *__restrict__ qs,
+                                                       const uint4 *__restrict__ pf,
+                                                       const int32_t *__restrict__ pg,
+                                                       const float *__restrict__ pt,
+                                                       const float *__restrict__ cellpx, float thr,
+                                                       const uint2 *__restrict__ tbox, int nt,
+                                                       const uint2 *__restrict__ units,
+                                                       unsigned int scap,
+                                                       const unsigned int *__restrict__ ucnts,
+                                                       uint2 *__restrict__ cands,
+                                                       unsigned long long segcap,
+                                                       unsigned long long *__restrict__ ccnts,
+                                                       const QuadRec *__restrict__ rec, int flags,
+                                                       uint2 *__restrict__ edges,
+                                                       int *__restrict__ cnt) {
+  __shared__ uint2 queue[kNmsWaves][kNmsQueue];
+  __shared__ uint2 clipq[INLINE ? kNmsWaves : 1][INLINE ? kClipQueue : 1];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  uint2 *q = queue[wave];
+  int qn = 0;
+  const uint32_t gw = blockIdx.x * kNmsWaves + wave;       // global wave id
+  const uint32_t nw = gridDim.x * kNmsWaves;
+  const int shard = (int)(gw & (kShards - 1));
+  SortedSink<INLINE> sink;
+  sink.pr.thr = thr; sink.pr.cpx = cellpx[0]; sink.pr.cpy = cellpx[1];
+  sink.pf = pf; sink.pg = pg; sink.pt = pt;
+  sink.cand = cands + (size_t)shard * segcap;
+  sink.segcap = segcap;
+  // (INLINE: the candidates are only counted, in the statistics slot -- their list does not exist)
+  sink.ccnt = ccnts + (size_t)((INLINE ? 2 * kShards : 0) + shard) * kCandStride;
+  sink.rec = rec; sink.flags = flags;
+  sink.eseg = edges + (size_t)shard * segcap;
+  sink.ecnt = ccnts + (size_t)(kShards + shard) * kCandStride;
+  sink.cnt = cnt;
+  sink.cq = clipq[INLINE ? wave : 0];
+  sink.cqn = 0;
+  // lane s holds shard s of the unit list: its counts and their exclusive prefix sums
+  const unsigned int cnt_h = ucnts[lane * kUnitStride], cnt_l = ucnts[(kShards + lane) * kUnitStride];
+  if (__ballot(cnt_h + cnt_l > scap) != 0ull) return;   // unit list overflow: reported by the host, nothing valid to scan
+  unsigned int inc_h = cnt_h, inc_l = cnt_l;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned int th = __shfl_up(inc_h, o), tl = __shfl_up(inc_l, o);
+    if (lane >= o) { inc_h += th; inc_l += tl; }
+  }
+  const unsigned int ex_h = inc_h - cnt_h, ex_l = inc_l - cnt_l;
+  const unsigned int nheavy = __builtin_amdgcn_readlane(inc_h, 63), nlight = __builtin_amdgcn_readlane(inc_l, 63);
+  const unsigned int ndiag = (unsigned int)nt * kSub;
+  const unsigned int nun = ndiag + nheavy + nlight;
+  for (unsigned int k = gw; k < nun; k += nw) {
+    uint32_t A, B, sub;
+    if (k < ndiag) {
+      A = B = k / kSub; sub = k % kSub;
+    } else {
+      // all heavy units first (LPT order), then the light ones; the shard of a flat index is
+      // the last lane whose exclusive prefix is <= it (empty shards share a prefix with the next)
+      const unsigned int j = k - ndiag;
+      const bool hv = j < nheavy;
+      const unsigned int jj = hv ? j : j - nheavy;
+      const int sh = __popcll(__ballot((hv ? ex_h : ex_l) <= jj)) - 1;
+      const unsigned int within = jj - (unsigned int)__builtin_amdgcn_readlane(hv ? ex_h : ex_l, sh);
+      const uint2 *seg = units + (size_t)sh * scap;
+      const uint2 un = hv ? seg[within] : seg[scap - 1u - within];
+      A = un.x >> 16; B = un.x & 0xFFFFu; sub = un.y;
+    }
+    const uint32_t sa0 = A * kTile + sub * kSubRows;         // this unit's 32 rows
+    const uint32_t sb0 = B * kTile;                          // 256 columns
+    // qs is padded to whole tiles (sentinel intervals never match); lanes >= 32 hold a
+    // sentinel row
+    const bool rl = lane < kSubRows;
+    uint2 rv = make_uint2(kSentLo, kSentHi);
+    if (rl) rv = qs[sa0 + lane];
+    const uint2 tb = tbox[B];
+    uint2 col[4];
+    {
+      const uint4 *cp = reinterpret_cast<const uint4 *>(qs + sb0 + lane * kNmsColsPerLane);
+      const uint4 a = cp[0], b = cp[1];
+      col[0] = make_uint2(a.x, a.y); col[1] = make_uint2(a.z, a.w);
+      col[2] = make_uint2(b.x, b.y); col[3] = make_uint2(b.z, b.w);
+    }
+    // only rows whose interval meets the column tile's box can have a candidate
+    const uint32_t rows = (uint32_t)__ballot(rl && qdisjoint(rv.x, rv.y, tb.x, tb.y) == 0u);
+    if (A == B) nms_scan_rows<true>(rv, rows, sa0, sb0, col, sink, q, qn, lane);
+    else nms_scan_rows<false>(rv, rows, sa0, sb0, col, sink, q, qn, lane);
+  }
+  if (qn > 0) {  // final partial batch, once per wave
+    __builtin_amdgcn_wave_barrier();
+    sink.flush(q, qn, lane);
+  }
+  sink.finish(lane);
 }
 
 // ---- 6b: direct scan + clip (medium n, no spatial sort) --------------------------------
@@ -1522,6 +1577,7 @@ __global__ __launch_bounds__(1024) void nms_compact_kernel(const int *__restrict
     unsigned long long v = ccnts[(size_t)lane * kCandStride], mx = v;
     const unsigned long long ev = ccnts[(size_t)(kShards + lane) * kCandStride];
     mx = ev > mx ? ev : mx;   // fullest segment of either kind
+    v += ccnts[(size_t)(2 * kShards + lane) * kCandStride];   // (clipped in line: counted, never listed)
     unsigned int uh = ucnts[lane * kUnitStride], ul = ucnts[(kShards + lane) * kUnitStride], uw = uh + ul;
     for (int o = 32; o > 0; o >>= 1) {
       v += __shfl_xor(v, o);
@@ -1548,6 +1604,10 @@ __global__ __launch_bounds__(1024) void nms_compact_kernel(const int *__restrict
 // the caller's workspace.
 constexpr int kSmallMax = 1024;          // one box per thread
 constexpr int kFusedDefault = 128;       // largest n routed to the fused kernel (the direct path is faster above)
+// largest n whose sorted scan clips in line.  tools/exp_inline_clip.py: 20k / 50k sparse boxes 78 -> 73 / 91 -> 83 us and
+// no loss on dense scenes; from 100k on the 4 waves/SIMD of the bigger kernel cost more (dense 155 -> 171 us) than
+// the launch saves (sparse 111 -> 106 us)
+constexpr int64_t kInlineDefault = 65536;
 constexpr int kDirectDefault = 10240;    // largest n routed to the direct (unsorted) scan (measured crossover 11-12k)
 constexpr int kDirectMax = 65536;
 
@@ -1848,7 +1908,7 @@ static int nms_layout(int64_t n, int64_t edge_capacity, NmsLayout &L) {
   L.zero_begin = off;
   L.cnt = take(nn * 4);
   L.ctr = take(sizeof(NmsCounters));
-  L.ccnts = take((size_t)2 * kShards * kCandStride * sizeof(unsigned long long));  // candidates | edges
+  L.ccnts = take((size_t)3 * kShards * kCandStride * sizeof(unsigned long long));  // candidates | edges | candidates clipped in line
   L.ucnts = take((size_t)2 * kShards * kUnitStride * sizeof(unsigned int));        // heavy | light scan units
   L.blockcnt = take(((nn + 1023) / 1024 + 1) * 4);   // ticket + one flagged count per 1024 boxes
   L.scanflags = take((kCells / kScanBlockCells + 1) * 4);   // multi-block cell scan: ticket + one flagged total per block
@@ -2055,6 +2115,8 @@ static int nms_enqueue(const char *who, const float *dets_dev, int64_t n, int ki
   const bool fused = n <= fused_max;
   const bool direct = !fused && n <= direct_max;
   q.fused = fused; q.direct = direct;
+  // sorted route: up to here the scan clips its own candidates (one launch less on a latency-bound chain)
+  const bool inline_clip = n <= tuning(OBB_TUNE_NMS_INLINE_MAX, kInlineDefault);
   if (fused) {
     // fused single-launch path; the edge list may use the whole pair capacity
     const unsigned long long ecap64 = 2ull * cap;
@@ -2128,15 +2190,22 @@ static int nms_enqueue(const char *who, const float *dets_dev, int64_t n, int ki
     OBB_PHASE(3);
     {
       const long long maxblocks = ((long long)L.unit_worst + kNmsWaves - 1) / kNmsWaves;
-      const long long pb = tuning(OBB_TUNE_NMS_SCAN_BLOCKS, kScanBlocks);
+      // tools/exp_scan_blocks.py: the in-line kernel (4 waves/SIMD) is best at one resident grid; the
+      // listing one (8 waves/SIMD) gains 3-8 % from two to four grids' worth of smaller shares
+      const long long pb = tuning(OBB_TUNE_NMS_SCAN_BLOCKS, inline_clip ? kScanBlocks : (n > 262144 ? 4 * kScanBlocks : 2 * kScanBlocks));
       const unsigned gb = (unsigned)(maxblocks < pb ? maxblocks : pb);
-      hipLaunchKernelGGL(nms_scan_kernel, dim3(gb), dim3(64 * kNmsWaves), 0, st, qs, pf, pg, pt, cellpx, prune_thr, tbox, nt, units, ucap / kShards, ucnts, cands, segcap, ccnts);
+      if (inline_clip)
+        hipLaunchKernelGGL(nms_scan_kernel<true>, dim3(gb), dim3(64 * kNmsWaves), 0, st, qs, pf, pg, pt, cellpx, prune_thr, tbox, nt, units, ucap / kShards, ucnts, cands, segcap, ccnts, rec, flags, edges, cnt);
+      else
+        hipLaunchKernelGGL(nms_scan_kernel<false>, dim3(gb), dim3(64 * kNmsWaves), 0, st, qs, pf, pg, pt, cellpx, prune_thr, tbox, nt, units, ucap / kShards, ucnts, cands, segcap, ccnts, rec, flags, edges, cnt);
       OBB_LAUNCH_CHECK();
     }
-    // phase 4: clip (narrow phase)
+    // phase 4: clip (narrow phase) -- its own launch only where the scan lists its candidates
     OBB_PHASE(4);
-    hipLaunchKernelGGL(nms_clip_kernel, dim3(kClipBlocksPerShard, kShards), dim3(256), 0, st, cands, segcap, rec, flags, edges, ctr, ccnts, cnt);
-    OBB_LAUNCH_CHECK();
+    if (!inline_clip) {
+      hipLaunchKernelGGL(nms_clip_kernel, dim3(kClipBlocksPerShard, kShards), dim3(256), 0, st, cands, segcap, rec, flags, edges, ctr, ccnts, cnt);
+      OBB_LAUNCH_CHECK();
+    }
     // phase 5: resolve
     OBB_PHASE(5);
     hipLaunchKernelGGL(nms_resolve_kernel<false>, dim3(kShards), dim3(kResolveThreads), 0, st, edges, segcap, cnt, ctr, ccnts, n, keep_dev, result);

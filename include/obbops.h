@@ -279,7 +279,8 @@ OBB_API int obb_rbox_to_poly_f32(const float *rbox_dev, int64_t n, float *poly_d
 #define OBB_TUNE_NMS_SCAN_BLOCKS 2    /* grid of the sorted route's scan kernel                      */
 #define OBB_TUNE_RROI_GROUPS 3        /* 8-channel groups per RoI-Align block                        */
 #define OBB_TUNE_OVERLAPS_ROWS 4      /* rows per block of the pairwise-overlap kernel (8..64)       */
-#define OBB_TUNE_COUNT 5
+#define OBB_TUNE_NMS_INLINE_MAX 5     /* largest n whose sorted scan clips its candidates in line     */
+#define OBB_TUNE_COUNT 6
 OBB_API int obb_set_tuning(int knob, int64_t value);
 
 #ifdef __cplusplus

@@ -137,16 +137,19 @@ def test_overlaps_cpu_tensor_roundtrip():
 # --------------------------------------------------------------------------
 # rotated NMS: keep indices bit-exact
 # --------------------------------------------------------------------------
-@pytest.fixture(params=['auto', 'sorted'])
+@pytest.fixture(params=['auto', 'sorted', 'listed'])
 def nms_path(request, monkeypatch):
     """The library routes n <= 128 to the fused kernel, n <= 10240 to the direct
-    (unsorted) scan and the rest to the spatially sorted pipeline; 'sorted' forces the
-    last one for every n above the fused limit, so each test covers both."""
+    (unsorted) scan and the rest to the spatially sorted pipeline, whose scan clips its
+    candidates in line up to 65 536 boxes and lists them for a clip launch above; 'sorted' /
+    'listed' force the pipeline with one or the other for every n above the fused limit."""
     from aidet_amd import _lib
-    if request.param == 'sorted':
+    if request.param != 'auto':
         _lib.set_tuning(_lib.TUNE_NMS_DIRECT_MAX, 0)
+        _lib.set_tuning(_lib.TUNE_NMS_INLINE_MAX, (1 << 40) if request.param == 'sorted' else 0)
     yield request.param
     _lib.set_tuning(_lib.TUNE_NMS_DIRECT_MAX, -1)
+    _lib.set_tuning(_lib.TUNE_NMS_INLINE_MAX, -1)
 
 
 @pytest.mark.parametrize('n,canvas', [(1, 10), (2, 10), (63, 64), (64, 64), (65, 64), (257, 128),
@@ -614,7 +617,7 @@ def test_rnms_fused_and_general_paths_agree(n, canvas, nms_route):
     refg = oracle.rnms(d, 0.45, groups=g)
     p = np.concatenate([oracle.rbox_to_poly(d).astype(np.float32), d[:, 5:6]], 1)
     refp = oracle.poly_nms(p, 0.45)
-    for path in ('fused', 'direct', 'sorted'):
+    for path in ('fused', 'direct', 'sorted', 'listed'):
         nms_route(path)
         assert np.array_equal(rnms(t(d), 0.45)[1].cpu().numpy(), ref), path
         assert np.array_equal(rnms(t(d), 0.45, groups=g)[1].cpu().numpy(), refg), path
@@ -850,7 +853,7 @@ def test_hbb_roi_align_uses_the_reference_expressions(aligned):
 # --------------------------------------------------------------------------
 # round 2: dedicated HBB narrow phase, strict compare, Soft-NMS, async calls
 # --------------------------------------------------------------------------
-@pytest.mark.parametrize('route', ['auto', 'fused', 'direct', 'sorted'])
+@pytest.mark.parametrize('route', ['auto', 'fused', 'direct', 'sorted', 'listed'])
 def test_hbb_nms_exact_ties_match_reference(golden, route, nms_route):
     """Integer boxes: IoU == thr happens and nms_cpu.cpp:56 suppresses on `>=`.  The HBB rows
     are decided by the reference's own arithmetic in the kernel (OBB_KIND_HBB narrow phase)."""
