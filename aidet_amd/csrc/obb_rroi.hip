@@ -205,10 +205,7 @@ __device__ __forceinline__ void rroi_forward_direct(const float *__restrict__ fe
 }
 
 // ---- staged kernels: shared pieces ---------------------------------------------------------
-#ifndef OBB_STAGE_FLOATS
-#define OBB_STAGE_FLOATS 5120
-#endif
-constexpr int kStageFloats = OBB_STAGE_FLOATS;  // input tile [channel][odd pitch] (20 KiB)
+constexpr int kStageFloats = 5120;    // backward: most floats of one staging pass ([channel][odd pitch]; see kBwdStageFloats)
 constexpr int kMaxTabSamples = 256;   // sample table (8 KiB); 7x7 bins x 2x2 samples = 196
 constexpr int kMaxBins = 64;          // bins of a staged RoI
 constexpr int kMaxPassChan = 32;      // channels per staging pass (output tile 32 x 65 floats)
