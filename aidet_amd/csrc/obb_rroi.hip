@@ -208,7 +208,7 @@ __device__ __forceinline__ void rroi_forward_direct(const float *__restrict__ fe
 constexpr int kStageFloats = 5120;    // backward: most floats of one staging pass ([channel][odd pitch]; see kBwdStageFloats)
 constexpr int kMaxTabSamples = 256;   // sample table (8 KiB); 7x7 bins x 2x2 samples = 196
 constexpr int kMaxBins = 64;          // bins of a staged RoI
-constexpr int kMaxPassChan = 32;      // channels per staging pass (output tile 32 x 65 floats)
+constexpr int kMaxPassChan = 16;      // channels per staging pass (gradient tile 16 x 65 floats)
 constexpr int kBinPitchMax = 65;
 
 struct Footprint { int x0, y0, w, h; };
@@ -557,7 +557,7 @@ __device__ __forceinline__ void rroi_backward_direct(const float *__restrict__ g
 // The order in which a pixel's contributions are summed follows the slot order (atomic
 // tickets): results are reproducible to rounding only, like the reference's atomicAdd
 // backward (roi_align_kernel_v2.cu:179-263); tolerance 1e-4 * max|g|.
-constexpr int kBwdMaxPix = 1024;                       // footprint pixels of the staged backward
+constexpr int kBwdMaxPix = 2047;                       // footprint pixels of the staged backward (2 channels per pass there)
 constexpr int kBwdStageFloats = 4096;                  // sums tile (16 KiB): 16 channels x 255 pixels, 8 x 511, 4 x 1023
 constexpr int kBwdMaxEntries = 4 * kMaxTabSamples;     // taps of a RoI (4 per sample)
 
@@ -570,9 +570,8 @@ __global__ __launch_bounds__(256) void rroi_backward_kernel(
   __shared__ int pstart[kBwdMaxPix + 1];               // CSR offsets; during the build: counts
   __shared__ float gtile[kMaxPassChan * kBinPitchMax];
   __shared__ int wsum[4];
-  int *pfill = reinterpret_cast<int *>(gtile);         // slot tickets of the build (gtile is loaded after it)
-  static_assert(kBwdStageFloats * 4 >= kMaxTabSamples * 32, "the sample table fits the tile it is built in");
-  static_assert(kMaxPassChan * kBinPitchMax >= kBwdMaxPix, "the slot tickets fit the gradient tile");
+  int *pfill = reinterpret_cast<int *>(tile) + kMaxTabSamples * 8;   // slot tickets of the build: behind the sample table
+  static_assert(kBwdStageFloats >= kMaxTabSamples * 8 + kBwdMaxPix, "the sample table and the slot tickets fit the tile they are built in");
   int64_t k;
   int chunk;
   if (!block_to_work(K, chunks, k, chunk)) return;
@@ -616,10 +615,10 @@ __global__ __launch_bounds__(256) void rroi_backward_kernel(
     if (w != 0.0f) atomicAdd(&pstart[pix], 1);       // (a zero weight adds nothing, also in the direct kernel)
   }
   __syncthreads();
-  {  // exclusive scan of the counts (<= 1024 pixels: 4 per thread)
-    int c4[4], sum = 0;
+  {  // exclusive scan of the counts (<= 2048 pixels: 8 per thread)
+    int c4[8], sum = 0;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { const int i = tid * 4 + u; c4[u] = i < fsz ? pstart[i] : 0; sum += c4[u]; }
+    for (int u = 0; u < 8; ++u) { const int i = tid * 8 + u; c4[u] = i < fsz ? pstart[i] : 0; sum += c4[u]; }
     int inc = sum;
     for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o); if (lane >= o) inc += v; }
     if (lane == 63) wsum[wave] = inc;
@@ -627,7 +626,7 @@ __global__ __launch_bounds__(256) void rroi_backward_kernel(
     int base = inc - sum;
     for (int w2 = 0; w2 < wave; ++w2) base += wsum[w2];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { const int i = tid * 4 + u; if (i < fsz) pstart[i] = base; base += c4[u]; }
+    for (int u = 0; u < 8; ++u) { const int i = tid * 8 + u; if (i < fsz) pstart[i] = base; base += c4[u]; }
     if (tid == 255) pstart[fsz] = base;               // (tid 255 owns the last pixels: base = total)
     __syncthreads();
   }
