@@ -220,20 +220,31 @@ struct LevelTable {
   float scale[OBB_MAX_LEVELS];
 };
 
-__device__ __forceinline__ Footprint roi_footprint(const RoiFrame &f, int H, int W) {
+// The axis-aligned pixel box that holds every bilinear tap of every sample.  The samples
+// are an affine lattice, so their extreme coordinates are those of the four CORNER samples,
+// evaluated by the very expressions the sample table uses; interior samples repeat those
+// expressions with other small integers, i.e. they may exceed a corner by a few ulps of the
+// coordinate: margin 1e-3 px + 1e-6 |coordinate| (>= 8 ulps).  (The rectangle's own corners
+// plus a pixel of slack -- the first version -- cost ~3 more rows and columns per RoI: a
+// third of the bytes staged at configs[2].)
+__device__ __forceinline__ Footprint roi_footprint(const RoiFrame &f, int H, int W, int ph, int pw) {
   float lox, hix, loy, hiy;
-  if (f.kind == 0) {
-    const float hx = 0.5f * (fabs_sel(f.c) * f.rw + fabs_sel(f.s) * f.rh);
-    const float hy = 0.5f * (fabs_sel(f.s) * f.rw + fabs_sel(f.c) * f.rh);
-    lox = f.cx - hx; hix = f.cx + hx; loy = f.cy - hy; hiy = f.cy + hy;
-  } else {
-    const float ex = f.xs + f.rw, ey = f.ys + f.rh;
-    lox = min_sel(f.xs, ex); hix = max_sel(f.xs, ex);
-    loy = min_sel(f.ys, ey); hiy = max_sel(f.ys, ey);
+  {
+    float x, y;
+    sample_xy(f, 0, 0, 0, 0, x, y);
+    lox = hix = x; loy = hiy = y;
+    sample_xy(f, 0, pw - 1, 0, f.gw - 1, x, y);
+    lox = min_sel(lox, x); hix = max_sel(hix, x); loy = min_sel(loy, y); hiy = max_sel(hiy, y);
+    sample_xy(f, ph - 1, 0, f.gh - 1, 0, x, y);
+    lox = min_sel(lox, x); hix = max_sel(hix, x); loy = min_sel(loy, y); hiy = max_sel(hiy, y);
+    sample_xy(f, ph - 1, pw - 1, f.gh - 1, f.gw - 1, x, y);
+    lox = min_sel(lox, x); hix = max_sel(hix, x); loy = min_sel(loy, y); hiy = max_sel(hiy, y);
   }
-  // one pixel of slack on each side covers the high tap and any rounding
-  float fx0 = floorf(lox) - 1.0f, fx1 = floorf(hix) + 2.0f;
-  float fy0 = floorf(loy) - 1.0f, fy1 = floorf(hiy) + 2.0f;
+  const float mx = 1.0e-3f + 1.0e-6f * max_sel(fabs_sel(lox), fabs_sel(hix));
+  const float my = 1.0e-3f + 1.0e-6f * max_sel(fabs_sel(loy), fabs_sel(hiy));
+  // low tap of the smallest coordinate .. high tap (+ 1) of the largest
+  float fx0 = floorf(lox - mx), fx1 = floorf(hix + mx) + 1.0f;
+  float fy0 = floorf(loy - my), fy1 = floorf(hiy + my) + 1.0f;
   fx0 = min_sel(max_sel(fx0, 0.0f), (float)(W - 1)); fx1 = min_sel(max_sel(fx1, 0.0f), (float)(W - 1));
   fy0 = min_sel(max_sel(fy0, 0.0f), (float)(H - 1)); fy1 = min_sel(max_sel(fy1, 0.0f), (float)(H - 1));
   Footprint p;
@@ -329,7 +340,7 @@ __global__ __launch_bounds__(256) void rroi_forward_kernel(
       out[(k * C + c_block) * (int64_t)nb + it] = v;
     return;
   }
-  Footprint fp = roi_footprint(f, H, W);
+  Footprint fp = roi_footprint(f, H, W, ph, pw);
   if (X4) {  // 16-byte LDS-DMA: rows start and end on multiples of 4 floats (W % 4 == 0)
     const int x1 = (fp.x0 + fp.w - 1) | 3;
     fp.x0 &= ~3;
@@ -583,7 +594,7 @@ __global__ __launch_bounds__(256) void rroi_backward_kernel(
   const int c_block = chunk * chan_per_block;
   const int c_end = min(C, c_block + chan_per_block);
   const int64_t plane = (int64_t)H * W;
-  const Footprint fp = roi_footprint(f, H, W);
+  const Footprint fp = roi_footprint(f, H, W, ph, pw);
   const int fsz = fp.w * fp.h;
   const int cpitch = fsz | 1;
   const int spb = (int)(spb64 > kMaxTabSamples ? kMaxTabSamples + 1 : spb64);
