@@ -303,7 +303,7 @@ __device__ __forceinline__ void build_table(const RoiFrame &f, const Footprint &
 // busy -- was built and measured this round: 71 us against 50 us for this one at configs[2].
 // It needs dword DMA or register staging for the odd pitch, i.e. 4x the staging instructions,
 // and a table read per tap group)
-constexpr int kFwdStageFloats = 6144;               // LDS tile per block (24 KiB)
+constexpr int kFwdStageFloats = 5120;               // LDS tile per block (20 KiB; with the pads and the table 30 KiB: 5 blocks per CU)
 constexpr int kWaveFloats = kFwdStageFloats / 4;    // private quarter of a wave (small footprints)
 constexpr int kWavePad = 256;                       // room for the tail lanes of a wave's last DMA instruction
 
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256) void rroi_forward_kernel(
     const float *__restrict__ rois, int ph, int pw, int sample_num, float min_size, int chan_per_block,
     int K, int chunks, int roi_kind, float *__restrict__ out) {
   __shared__ __attribute__((aligned(16))) float tile[4 * (kWaveFloats + kWavePad)];  // block-wide: kFwdStageFloats + pad
-  __shared__ int4 s_off[kMaxTabSamples];      // per sample: 4 footprint-local tap offsets
+  __shared__ ushort4 s_off[kMaxTabSamples];   // per sample: 4 footprint-local tap offsets (< kFwdStageFloats)
   __shared__ float4 s_wgt[kMaxTabSamples];    // per sample: 4 bilinear weights
   int64_t k;
   int chunk;
@@ -368,7 +368,8 @@ __global__ __launch_bounds__(256) void rroi_forward_kernel(
     auto cl = [](int v, int n) { return v < 0 ? 0 : (v >= n ? n - 1 : v); };
     const int ly0 = cl(yl - fp.y0, fp.h) * fp.w, ly1 = cl(yh - fp.y0, fp.h) * fp.w;
     const int lx0 = cl(xl - fp.x0, fp.w), lx1 = cl(xh - fp.x0, fp.w);
-    s_off[sidx] = live ? make_int4(ly0 + lx0, ly0 + lx1, ly1 + lx0, ly1 + lx1) : make_int4(0, 0, 0, 0);
+    s_off[sidx] = live ? make_ushort4((unsigned short)(ly0 + lx0), (unsigned short)(ly0 + lx1), (unsigned short)(ly1 + lx0), (unsigned short)(ly1 + lx1))
+                       : make_ushort4(0, 0, 0, 0);
     s_wgt[sidx] = make_float4(w[0], w[1], w[2], w[3]);
   }
   if (fsz <= kWaveFloats && nb <= 64 && spb <= 4) {
@@ -387,7 +388,8 @@ __global__ __launch_bounds__(256) void rroi_forward_kernel(
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const bool on = lane < nb && q < spb;
-      so[q] = on ? s_off[lane * spb + q] : make_int4(0, 0, 0, 0);
+      const ushort4 o16 = s_off[on ? lane * spb + q : 0];
+      so[q] = on ? make_int4(o16.x, o16.y, o16.z, o16.w) : make_int4(0, 0, 0, 0);
       sw[q] = on ? s_wgt[lane * spb + q] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     const int cpw = kWaveFloats / fsz;               // channels per pass (>= 1)
@@ -495,7 +497,7 @@ __global__ __launch_bounds__(256) void rroi_forward_kernel(
       const float *p = tile + c * fsz;
       float acc = 0.0f;
       for (int q = 0; q < spb; ++q) {
-        const int4 l = s_off[bin * spb + q];
+        const ushort4 l = s_off[bin * spb + q];
         const float4 w = s_wgt[bin * spb + q];
         float v = w.x * p[l.x];
         v = v + w.y * p[l.y];
