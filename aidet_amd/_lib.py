@@ -95,6 +95,14 @@ def lib():
         L.obb_nms_profile_last.restype = i32
         L.obb_rbox_to_poly_f32.argtypes = [vp, i64, vp, vp]
         L.obb_rbox_to_poly_f32.restype = i32
+        L.obb_patch_groups_i32.argtypes = [vp, vp, i64, i64, vp, vp]
+        L.obb_patch_groups_i32.restype = i32
+        L.obb_patch_rows_to_image_f32.argtypes = [vp, vp, vp, i64, vp, i64, vp, vp, i64, f32, vp, vp]
+        L.obb_patch_rows_to_image_f32.restype = i32
+        L.obb_merge_rows_split_f32.argtypes = [vp, i64, i32, i64, vp, f32, vp, vp, vp, vp]
+        L.obb_merge_rows_split_f32.restype = i32
+        L.obb_gather_rows_f32.argtypes = [vp, i64, i32, vp, i64, vp, vp]
+        L.obb_gather_rows_f32.restype = i32
         _lib = L
     return _lib
 

@@ -269,6 +269,41 @@ OBB_API int obb_roi_align_levels_forward_f32(const float *const *feat_devs_host,
 OBB_API int obb_rbox_to_poly_f32(const float *rbox_dev, int64_t n, float *poly_dev, void *stream);
 
 /* ---------------------------------------------------------------------------
+ * Row plumbing of the tiled-inference merge (BASELINE.json configs[4]): what sits between the
+ * per-patch NMS and the merged per-(image, class) NMS.
+ * Replaces: the text round trip of mmdet/datasets/dota.py:197-336 -- patch offsets parsed from
+ *           the file name and added to the coordinates (:262-283, 302-305), per-class merge
+ *           thresholds (:320-331) -- and the host-side list surgery around it
+ *           (mmdet/apis/test.py:116-146).  All arrays are device pointers; int64 index arrays
+ *           as torch produces them.  Values are computed exactly like the tensor expressions
+ *           of aidet_amd/dota_merge.py (add, then divide by `rate`, in fp32).
+ *
+ * obb_patch_groups_i32:        groups[i] = (int32)(patch_index[i] * num_classes + labels[i])
+ * obb_patch_rows_to_image_f32: rows[i] = { (cx + ox) / rate, (cy + oy) / rate, w / rate, h / rate,
+ *                              theta, score, label, image } of detection keep[i] (keep = NULL:
+ *                              i) with (ox, oy) = patch_xy[patch_index], image =
+ *                              patch_image[patch_index]; dets (n,6), rows (k,8).  An index out
+ *                              of range gives a zero row with label = image = -1.
+ * obb_merge_rows_split_f32:    rows (n, cols = 8 | 11 | 7: box + score, label, image) ->
+ *                              boxes (n, cols - 2), groups[i] = (int32)(image * num_classes +
+ *                              label), thrs[i] = class_thrs[label] (thrs / class_thrs may be
+ *                              NULL; a label outside [0, num_classes) takes default_thr).
+ * obb_gather_rows_f32:         out[i, :] = src[idx[i], :]   (src (n, cols), idx (k,) int64)
+ * ------------------------------------------------------------------------- */
+OBB_API int obb_patch_groups_i32(const int64_t *labels_dev, const int64_t *patch_index_dev, int64_t n,
+                                 int64_t num_classes, int32_t *groups_dev, void *stream);
+OBB_API int obb_patch_rows_to_image_f32(const float *dets_dev, const int64_t *labels_dev,
+                                        const int64_t *patch_index_dev, int64_t n,
+                                        const int64_t *keep_dev, int64_t k, const float *patch_xy_dev,
+                                        const int64_t *patch_image_dev, int64_t num_patches, float rate,
+                                        float *rows_dev, void *stream);
+OBB_API int obb_merge_rows_split_f32(const float *rows_dev, int64_t n, int cols, int64_t num_classes,
+                                     const float *class_thrs_dev, float default_thr, float *boxes_dev,
+                                     int32_t *groups_dev, float *thrs_dev, void *stream);
+OBB_API int obb_gather_rows_f32(const float *src_dev, int64_t n, int cols, const int64_t *idx_dev, int64_t k,
+                                float *out_dev, void *stream);
+
+/* ---------------------------------------------------------------------------
  * Test / tuning hooks.  NOT part of the drop-in surface (no reference counterpart): the
  * parity tests use them to force every size through every code path, and the experiment
  * scripts under tools/ to sweep launch geometry.  Process-wide; value < 0 restores the

@@ -1124,3 +1124,54 @@ def test_horizontal_max_iou_assigner_equals_reference(golden):
         assert np.array_equal(r.gt_inds.cpu().numpy(), g['assign_%s_gt_inds' % tag]), tag
         assert np.array_equal(r.labels.cpu().numpy(), g['assign_%s_labels' % tag]), tag
         assert np.array_equal(r.max_overlaps.cpu().numpy(), g['assign_%s_max_overlaps' % tag]), tag
+
+
+def test_merge_row_kernels_equal_the_tensor_expressions():
+    """obb_merge.hip (patch groups, rows to image coordinates, row split, row gather) against the torch
+    composition of aidet_amd/dota_merge.py evaluated on the CPU: bit-identical, and the merged keep of
+    every row layout equals the one obtained through the generic wrappers."""
+    from aidet_amd import dota_merge, nms_wrapper
+    rng = np.random.default_rng(21)
+    n, P, C = 5000, 37, 15
+    dets = oracle.synth_boxes(n, 150, 4)
+    labels = torch.from_numpy(rng.integers(0, C, n))
+    pidx = torch.from_numpy(rng.integers(0, P, n))
+    pxy = torch.from_numpy(rng.integers(0, 8000, (P, 2)).astype(np.float32))
+    pim = torch.from_numpy(rng.integers(0, 5, P))
+    keep = torch.from_numpy(np.sort(rng.choice(n, 3000, replace=False)))
+    d = torch.from_numpy(dets)
+    for rate in (1.0, 0.5, 1.5):
+        for kp in (None, keep):
+            ref = dota_merge.patch_rows_to_image(d, labels, pidx, pxy, pim, rate, keep=kp)
+            got = dota_merge.patch_rows_to_image(d.cuda(), labels.cuda(), pidx.cuda(), pxy.cuda(), pim.cuda(), rate,
+                                                 keep=None if kp is None else kp.cuda())
+            assert np.array_equal(got.cpu().numpy(), ref.numpy()), (rate, kp is None)
+    # per-patch NMS: fused group ids vs the int64 expression through the wrapper
+    k1 = dota_merge.local_patch_nms(d.cuda(), labels.cuda(), pidx.cuda(), 0.5, C)
+    k2 = dota_merge.local_patch_nms(d.cuda(), labels.cuda(), pidx.cuda(), 0.5, C, nms_fn=nms_wrapper.rnms)
+    assert torch.equal(k1, k2) and 0 < k1.numel() < n
+    # merged NMS: every row layout, flat / per-class thresholds, strict
+    rows8 = dota_merge.patch_rows_to_image(d, labels, pidx, pxy * 0.05, pim, 1.0)
+    poly = np.concatenate([oracle.rbox_to_poly(rows8[:, :5].numpy()).astype(np.float32), rows8[:, 5:].numpy()], 1)
+    hb = rows8[:, :5].numpy()
+    box = np.stack([hb[:, 0] - hb[:, 2] / 2, hb[:, 1] - hb[:, 3] / 2, hb[:, 0] + hb[:, 2] / 2, hb[:, 1] + hb[:, 3] / 2], 1)
+    rows7 = np.concatenate([box, rows8[:, 5:].numpy()], 1).astype(np.float32)
+    thr_tab = [0.1 + 0.03 * c for c in range(C)]
+    for rows, op in ((rows8.numpy(), nms_wrapper.rnms), (poly, nms_wrapper.poly_nms), (rows7, nms_wrapper.nms)):
+        r = torch.from_numpy(rows).cuda()
+        for cthr in (None, thr_tab):
+            for strict in (False, True):
+                kept, kp = dota_merge.merge_detections(r, 0.3, C, cthr, strict=strict)
+                fn = (lambda dd, tt, groups=None, thrs=None, **kw: op(dd, tt, groups=groups, thrs=thrs, **kw))
+                rkept, rkp = dota_merge.merge_detections(r, 0.3, C, cthr, nms_fn=fn, strict=strict)
+                assert torch.equal(kp, rkp) and torch.equal(kept, rkept), (rows.shape[1], cthr is None, strict)
+                assert 0 < kp.numel() < len(rows)
+    # gather + degenerate inputs
+    idx = torch.from_numpy(rng.integers(0, n, 777)).cuda()
+    assert torch.equal(dota_merge.gather_rows(rows8.cuda(), idx), rows8.cuda()[idx])
+    assert dota_merge.gather_rows(rows8.cuda(), idx[:0]).shape == (0, 8)
+    e = dota_merge.patch_rows_to_image(d.cuda(), labels.cuda(), pidx.cuda(), pxy.cuda(), pim.cuda(), 1.0, keep=keep[:0].cuda())
+    assert e.shape == (0, 8)
+    bad = pidx.clone(); bad[0] = P + 3     # a patch index out of range: zero row, label = image = -1
+    z = dota_merge.patch_rows_to_image(d.cuda(), labels.cuda(), bad.cuda(), pxy.cuda(), pim.cuda())
+    assert z[0].tolist() == [0, 0, 0, 0, 0, 0, -1, -1] and torch.equal(z[1:].cpu(), dota_merge.patch_rows_to_image(d, labels, pidx, pxy, pim)[1:])
