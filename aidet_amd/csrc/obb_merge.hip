@@ -71,8 +71,10 @@ __global__ __launch_bounds__(kMergeThreads) void merge_split_kernel(const float 
   if (i >= n) return;
   const int nbox = cols - 2;
   const float *r = rows + i * cols;
-  float *b = boxes + i * nbox;
-  for (int c = 0; c < nbox; ++c) b[c] = r[c];
+  if (boxes) {
+    float *b = boxes + i * nbox;
+    for (int c = 0; c < nbox; ++c) b[c] = r[c];
+  }
   const int64_t label = (int64_t)r[nbox], image = (int64_t)r[nbox + 1];   // (truncation, like Tensor.long())
   groups[i] = (int32_t)(image * num_classes + label);
   if (thrs) thrs[i] = (class_thrs && label >= 0 && label < num_classes) ? class_thrs[label] : default_thr;
@@ -140,7 +142,7 @@ extern "C" int obb_merge_rows_split_f32(const float *rows_dev, int64_t n, int co
   if (cols != 7 && cols != 8 && cols != 11)
     return obb::set_err(OBB_EINVAL, "obb_merge_rows_split_f32: rows have 8 (theta-OBB), 11 (polygon) or 7 (horizontal) columns, got %d", cols);
   if (n == 0) return OBB_OK;
-  if (!rows_dev || !boxes_dev || !groups_dev) return obb::set_err(OBB_EINVAL, "obb_merge_rows_split_f32: null pointer");
+  if (!rows_dev || !groups_dev) return obb::set_err(OBB_EINVAL, "obb_merge_rows_split_f32: null pointer");
   unsigned blocks;
   int rc = obb::merge_grid("obb_merge_rows_split_f32", n, blocks);
   if (rc != OBB_OK) return rc;

@@ -146,24 +146,38 @@ def merge_detections(dets, iou_thr, num_classes, class_thrs=None, nms_fn=None, s
     """
     if dets.size(0) == 0:
         return dets, torch.zeros(0, dtype=torch.long, device=dets.device)
-    if (nms_fn is None and only_groups is None and _on_gpu(dets) and dets.dtype == torch.float32
-            and dets.size(1) in _LAYOUT and float(iou_thr) > 0.0):
+    if (nms_fn is None and _on_gpu(dets) and dets.dtype == torch.float32 and dets.size(1) in _LAYOUT
+            and float(iou_thr) > 0.0):
         # fused: one kernel splits the rows into boxes | int32 groups | thresholds, the grouped NMS reads
         # them as they are, one kernel gathers the kept rows
         rows = dets.contiguous()
-        n, cols = rows.shape
-        dev = rows.device
-        boxes = rows.new_empty((n, cols - 2))
-        groups = torch.empty(n, dtype=torch.int32, device=dev)
-        thrs = cthr = None
+        cols, dev, L = rows.size(1), rows.device, _lib.lib()
+        cthr = None
         if class_thrs is not None:
             cthr = torch.as_tensor(class_thrs, dtype=torch.float32, device=dev).contiguous()
             assert cthr.numel() >= int(num_classes), 'one threshold per class'
-            thrs = torch.empty(n, dtype=torch.float32, device=dev)
-        _call(dev, _lib.lib().obb_merge_rows_split_f32, rows.data_ptr(), n, cols, int(num_classes),
-              None if cthr is None else cthr.data_ptr(), float(iou_thr), boxes.data_ptr(), groups.data_ptr(),
-              None if thrs is None else thrs.data_ptr())
+
+        def split(r, want_boxes):
+            m = r.size(0)
+            bx = r.new_empty((m, cols - 2)) if want_boxes else None
+            gr = torch.empty(m, dtype=torch.int32, device=dev)
+            th = torch.empty(m, dtype=torch.float32, device=dev) if (want_boxes and cthr is not None) else None
+            _call(dev, L.obb_merge_rows_split_f32, r.data_ptr(), m, cols, int(num_classes),
+                  None if cthr is None else cthr.data_ptr(), float(iou_thr), None if bx is None else bx.data_ptr(),
+                  gr.data_ptr(), None if th is None else th.data_ptr())
+            return bx, gr, th
+
+        sel, mine = None, rows
+        if only_groups is not None:      # the sharded layout: this rank's (image, class) groups only
+            world, rank = only_groups
+            sel = (split(rows, False)[1] % world == rank).nonzero(as_tuple=True)[0]
+            if sel.numel() == 0:
+                return dets[:0], sel
+            mine = gather_rows(rows, sel)
+        boxes, groups, thrs = split(mine, True)
         keep, _ = nms_wrapper._run_nms(boxes, _KIND[_LAYOUT[cols][0]], float(iou_thr), groups, thrs, strict)
+        if sel is not None:
+            keep = sel[keep]
         return gather_rows(rows, keep), keep
     op, boxes, labels, groups = _split_rows(dets, num_classes)
     thrs = None

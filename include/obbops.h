@@ -286,8 +286,8 @@ OBB_API int obb_rbox_to_poly_f32(const float *rbox_dev, int64_t n, float *poly_d
  *                              of range gives a zero row with label = image = -1.
  * obb_merge_rows_split_f32:    rows (n, cols = 8 | 11 | 7: box + score, label, image) ->
  *                              boxes (n, cols - 2), groups[i] = (int32)(image * num_classes +
- *                              label), thrs[i] = class_thrs[label] (thrs / class_thrs may be
- *                              NULL; a label outside [0, num_classes) takes default_thr).
+ *                              label), thrs[i] = class_thrs[label] (boxes / thrs / class_thrs may
+ *                              be NULL; a label outside [0, num_classes) takes default_thr).
  * obb_gather_rows_f32:         out[i, :] = src[idx[i], :]   (src (n, cols), idx (k,) int64)
  * ------------------------------------------------------------------------- */
 OBB_API int obb_patch_groups_i32(const int64_t *labels_dev, const int64_t *patch_index_dev, int64_t n,

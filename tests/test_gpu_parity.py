@@ -1166,6 +1166,17 @@ def test_merge_row_kernels_equal_the_tensor_expressions():
                 rkept, rkp = dota_merge.merge_detections(r, 0.3, C, cthr, nms_fn=fn, strict=strict)
                 assert torch.equal(kp, rkp) and torch.equal(kept, rkept), (rows.shape[1], cthr is None, strict)
                 assert 0 < kp.numel() < len(rows)
+    # the sharded layout: the groups of one rank only; the union over the ranks is the whole keep
+    r8 = rows8.cuda()
+    full = dota_merge.merge_detections(r8, 0.3, C, thr_tab)[1]
+    parts = []
+    for rank in range(3):
+        kept, kp = dota_merge.merge_detections(r8, 0.3, C, thr_tab, only_groups=(3, rank))
+        fn = (lambda dd, tt, groups=None, thrs=None, **kw: nms_wrapper.rnms(dd, tt, groups=groups, thrs=thrs, **kw))
+        rkept, rkp = dota_merge.merge_detections(r8, 0.3, C, thr_tab, nms_fn=fn, only_groups=(3, rank))
+        assert torch.equal(kp, rkp) and torch.equal(kept, rkept) and kp.numel() > 0
+        parts.append(kp)
+    assert torch.equal(torch.cat(parts).sort()[0], full)
     # gather + degenerate inputs
     idx = torch.from_numpy(rng.integers(0, n, 777)).cuda()
     assert torch.equal(dota_merge.gather_rows(rows8.cuda(), idx), rows8.cuda()[idx])
