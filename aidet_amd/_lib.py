@@ -101,7 +101,7 @@ def lib():
         L.obb_patch_rows_to_image_f32.restype = i32
         L.obb_merge_rows_split_f32.argtypes = [vp, i64, i32, i64, vp, f32, vp, vp, vp, vp]
         L.obb_merge_rows_split_f32.restype = i32
-        L.obb_gather_rows_f32.argtypes = [vp, i64, i32, vp, i64, vp, vp]
+        L.obb_gather_rows_f32.argtypes = [vp, i64, i32, vp, i64, i32, vp, vp]
         L.obb_gather_rows_f32.restype = i32
         _lib = L
     return _lib

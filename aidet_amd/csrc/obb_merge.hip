@@ -80,14 +80,14 @@ __global__ __launch_bounds__(kMergeThreads) void merge_split_kernel(const float 
   if (thrs) thrs[i] = (class_thrs && label >= 0 && label < num_classes) ? class_thrs[label] : default_thr;
 }
 
-// out[i, :] = src[idx[i], :]; one thread per 4-byte word, consecutive threads = consecutive words
+// out[i, :out_cols] = src[idx[i], :out_cols]; one thread per 4-byte word, consecutive threads = consecutive words
 __global__ __launch_bounds__(kMergeThreads) void gather_rows_kernel(const float *__restrict__ src, int cols,
                                                                     int64_t n, const int64_t *__restrict__ idx,
-                                                                    int64_t k, float *__restrict__ out) {
+                                                                    int64_t k, int out_cols, float *__restrict__ out) {
   const int64_t w = (int64_t)blockIdx.x * kMergeThreads + threadIdx.x;
-  if (w >= k * cols) return;
-  const int64_t i = w / cols;
-  const int c = (int)(w - i * cols);
+  if (w >= k * out_cols) return;
+  const int64_t i = w / out_cols;
+  const int c = (int)(w - i * out_cols);
   const int64_t s = idx[i];
   out[w] = (s >= 0 && s < n) ? src[s * cols + c] : 0.0f;
 }
@@ -153,15 +153,15 @@ extern "C" int obb_merge_rows_split_f32(const float *rows_dev, int64_t n, int co
 }
 
 extern "C" int obb_gather_rows_f32(const float *src_dev, int64_t n, int cols, const int64_t *idx_dev, int64_t k,
-                                   float *out_dev, void *stream) {
-  if (n < 0 || k < 0 || cols <= 0) return obb::set_err(OBB_EINVAL, "obb_gather_rows_f32: bad size");
+                                   int out_cols, float *out_dev, void *stream) {
+  if (n < 0 || k < 0 || cols <= 0 || out_cols <= 0 || out_cols > cols) return obb::set_err(OBB_EINVAL, "obb_gather_rows_f32: bad size");
   if (k == 0) return OBB_OK;
   if (!src_dev || !idx_dev || !out_dev) return obb::set_err(OBB_EINVAL, "obb_gather_rows_f32: null pointer");
   unsigned blocks;
-  int rc = obb::merge_grid("obb_gather_rows_f32", k * cols, blocks);
+  int rc = obb::merge_grid("obb_gather_rows_f32", k * out_cols, blocks);
   if (rc != OBB_OK) return rc;
   hipLaunchKernelGGL(obb::gather_rows_kernel, dim3(blocks), dim3(obb::kMergeThreads), 0, (hipStream_t)stream,
-                     src_dev, cols, n, idx_dev, k, out_dev);
+                     src_dev, cols, n, idx_dev, k, out_cols, out_dev);
   OBB_LAUNCH_CHECK();
   return OBB_OK;
 }

@@ -58,15 +58,16 @@ def _call(dev, fn, *args):
         _lib.check(fn(*args, _lib.current_stream_handle(dev)))
 
 
-def gather_rows(rows, index):
-    """rows[index] for (n, c) fp32 rows on the GPU (one streaming kernel; torch's index_select takes 0.16 ms
-    for 7.7e5 rows of 32 bytes, this 0.02 ms)."""
+def gather_rows(rows, index, ncols=None):
+    """rows[index][:, :ncols] for (n, c) fp32 rows on the GPU (one streaming kernel; torch's index_select
+    takes 0.16 ms for 7.7e5 rows of 32 bytes, this 0.02 ms)."""
+    ncols = rows.size(1) if ncols is None else int(ncols)
     if not (_on_gpu(rows, index) and rows.dtype == torch.float32 and rows.dim() == 2 and rows.size(1) > 0):
-        return rows[index]
+        return rows[index][:, :ncols]
     rows, index = rows.contiguous(), _i64(index)
-    out = rows.new_empty((index.numel(), rows.size(1)))
+    out = rows.new_empty((index.numel(), ncols))
     _call(rows.device, _lib.lib().obb_gather_rows_f32, rows.data_ptr(), rows.size(0), rows.size(1),
-          index.data_ptr(), index.numel(), out.data_ptr())
+          index.data_ptr(), index.numel(), ncols, out.data_ptr())
     return out
 
 
@@ -97,9 +98,16 @@ def gather_detections(local, group=None):
     Returns:
         list[Tensor]: the rows of every rank, in rank order (on every rank).
     """
+    parts, counts, nmax = _gather_padded(local, group)
+    return [parts[r * nmax:r * nmax + c] for r, c in enumerate(counts)]
+
+
+def _gather_padded(local, group=None, pad_last=0.0):
+    """-> (all ranks' rows padded to the largest count, the counts, that count); the last column of
+    the padding rows holds ``pad_last``."""
     world, _ = _world(group)
     if world == 1:
-        return [local]
+        return local, [local.size(0)], local.size(0)
     n = torch.tensor([local.size(0)], dtype=torch.int64, device=local.device)
     counts = torch.empty(world, dtype=torch.int64, device=local.device)
     dist.all_gather_into_tensor(counts, n, group=group)             # cf. test.py:124
@@ -107,9 +115,11 @@ def gather_detections(local, group=None):
     nmax = max(max(counts), 1)
     pad = local.new_zeros((nmax, local.size(1)))
     pad[:local.size(0)] = local
+    if pad_last != 0.0:
+        pad[local.size(0):, -1] = pad_last
     parts = local.new_empty((world * nmax, local.size(1)))
     dist.all_gather_into_tensor(parts, pad, group=group)            # cf. test.py:133
-    return [parts[r * nmax:r * nmax + c] for r, c in enumerate(counts)]
+    return parts, counts, nmax
 
 
 def _split_rows(dets, num_classes):
@@ -207,8 +217,25 @@ def _restore_order(parts, ncols):
     return allrows[torch.argsort(key, stable=True)][:, :ncols]
 
 
+_PAD_KEY = float((1 << 24) - 1)      # key of the padding rows of the gather: sorts behind every real key
+
+
+def _restore_by_key(padded, total, ncols, key_max=None):
+    """The padded rows of all ranks (``_gather_padded`` with ``_PAD_KEY``), a small integer key in the last
+    column, every key value on ONE rank -> the ``total`` real rows in ascending key, rank-local order
+    inside a key: a stable sort on a 16-bit key when ``key_max`` < 2**15 - 1 (62 us for 1.25e6 rows on
+    MI355X, 110 us on 32 bits; the int64 sort of ``_restore_order`` takes 250 us), then ONE gather that
+    also drops the padding and the key column."""
+    small = key_max is not None and int(key_max) < (1 << 15) - 1
+    key = padded[:, -1]
+    key = key.clamp(max=32767.0).to(torch.int16) if small else key.to(torch.int32)
+    order = torch.argsort(key, stable=True)[:total]
+    return gather_rows(padded, order, ncols)
+
+
 def distributed_merge(local, iou_thr, num_classes, class_thrs=None, group=None, nms_fn=None,
-                      seq=None, layout='replicated', strict=False, mark=None):
+                      seq=None, layout='replicated', strict=False, mark=None, order_key=None,
+                      order_key_max=None):
     """gather_detections + merge_detections.  Every rank returns the same result
     (the reference evaluates on rank 0 only, tools/dota/dota_test.py:157-166).
 
@@ -221,6 +248,12 @@ def distributed_merge(local, iou_thr, num_classes, class_thrs=None, group=None, 
             interleave of collect_results, test.py:141-145).  Only matters for
             score TIES (lower row index wins); the keep set for distinct scores is
             order independent.
+        order_key (Tensor, optional): (n_local,) small non-negative integers (< 2**24), e.g. the patch
+            index, with the same purpose as ``seq`` and one promise that makes restoring the order
+            cheap: every key value lives on ONE rank.  The single-process order is then ascending
+            key, rank-local order inside a key.  Takes precedence over ``seq``.
+        order_key_max (int, optional): an upper bound of the keys (e.g. the number of patches); below
+            2**15 the sort runs on 16-bit keys.
         layout: 'replicated' | 'sharded' (module docstring).
         mark (callable, optional): ``mark('gather')`` / ``mark('merge')`` are called after the
             respective phase (e.g. to record HIP events).
@@ -231,9 +264,13 @@ def distributed_merge(local, iou_thr, num_classes, class_thrs=None, group=None, 
         raise ValueError('layout must be "replicated" or "sharded"')
     mark = mark or (lambda name: None)
     ncols = local.size(1)
-    if seq is not None and _world(group)[0] == 1:
-        seq = None      # one rank: the local rows ARE the single-process order
-    if seq is not None:
+    if _world(group)[0] == 1:
+        seq = order_key = None      # one rank: the local rows ARE the single-process order
+    if order_key is not None:
+        key = order_key.to(local.dtype)[:, None]         # (exact in fp32 below 2**24)
+        padded, counts, _ = _gather_padded(torch.cat([local, key], 1), group, _PAD_KEY)
+        allrows = _restore_by_key(padded, sum(counts), ncols, order_key_max)
+    elif seq is not None:
         # sequence numbers travel as two float32 columns (hi, lo) to stay exact
         s64 = seq.to(torch.int64)
         hi = (s64 >> 20).to(local.dtype)[:, None]
@@ -247,7 +284,12 @@ def distributed_merge(local, iou_thr, num_classes, class_thrs=None, group=None, 
     if layout == 'sharded' and world > 1:
         _, mine = merge_detections(allrows, iou_thr, num_classes, class_thrs, nms_fn, strict,
                                    only_groups=(world, rank))
-        keep = torch.cat(gather_detections(mine[:, None], group), 0)[:, 0].sort()[0]
+        # every row belongs to exactly one rank's groups: the keep set is the union, exchanged as ONE
+        # all-reduce of a byte mask (an all-gather of index lists needs two collectives and a sort)
+        mask = torch.zeros(allrows.size(0), dtype=torch.uint8, device=allrows.device)
+        mask[mine] = 1
+        dist.all_reduce(mask, op=dist.ReduceOp.MAX, group=group)
+        keep = mask.nonzero(as_tuple=True)[0]
         kept = gather_rows(allrows, keep)
     else:
         kept, keep = merge_detections(allrows, iou_thr, num_classes, class_thrs, nms_fn, strict)
@@ -329,7 +371,14 @@ def tiled_inference_merge(dets, labels, patch_index, seq, patch_xy, patch_image,
     keep = local_patch_nms(dets, labels, patch_index, local_thr, num_classes, nms_fn)
     rows = patch_rows_to_image(dets, labels, patch_index, patch_xy, patch_image, keep=keep)
     mark('local')
-    # (sequence numbers only matter when rows of several ranks are interleaved)
-    seq_kept = seq[keep] if (seq is not None and _world(group)[0] > 1) else None
-    return distributed_merge(rows, merge_thr, num_classes, class_thrs, group, nms_fn, seq_kept,
-                             layout, mark=mark)
+    # (the order only matters when rows of several ranks are interleaved.  A patch lives on one rank and
+    # its rows are contiguous and in order there, so the patch index restores the single-process order;
+    # ``seq`` -- arbitrary global row numbers -- is the general, slower way and is used without it)
+    okey = skept = None
+    if _world(group)[0] > 1:
+        if patch_index is not None and int(patch_xy.size(0)) < (1 << 24):
+            okey = patch_index[keep]
+        elif seq is not None:
+            skept = seq[keep]
+    return distributed_merge(rows, merge_thr, num_classes, class_thrs, group, nms_fn, skept,
+                             layout, mark=mark, order_key=okey, order_key_max=int(patch_xy.size(0)))

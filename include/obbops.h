@@ -288,7 +288,8 @@ OBB_API int obb_rbox_to_poly_f32(const float *rbox_dev, int64_t n, float *poly_d
  *                              boxes (n, cols - 2), groups[i] = (int32)(image * num_classes +
  *                              label), thrs[i] = class_thrs[label] (boxes / thrs / class_thrs may
  *                              be NULL; a label outside [0, num_classes) takes default_thr).
- * obb_gather_rows_f32:         out[i, :] = src[idx[i], :]   (src (n, cols), idx (k,) int64)
+ * obb_gather_rows_f32:         out[i, :out_cols] = src[idx[i], :out_cols]   (src (n, cols), idx (k,) int64,
+ *                              out (k, out_cols), 1 <= out_cols <= cols)
  * ------------------------------------------------------------------------- */
 OBB_API int obb_patch_groups_i32(const int64_t *labels_dev, const int64_t *patch_index_dev, int64_t n,
                                  int64_t num_classes, int32_t *groups_dev, void *stream);
@@ -301,7 +302,7 @@ OBB_API int obb_merge_rows_split_f32(const float *rows_dev, int64_t n, int cols,
                                      const float *class_thrs_dev, float default_thr, float *boxes_dev,
                                      int32_t *groups_dev, float *thrs_dev, void *stream);
 OBB_API int obb_gather_rows_f32(const float *src_dev, int64_t n, int cols, const int64_t *idx_dev, int64_t k,
-                                float *out_dev, void *stream);
+                                int out_cols, float *out_dev, void *stream);
 
 /* ---------------------------------------------------------------------------
  * Test / tuning hooks.  NOT part of the drop-in surface (no reference counterpart): the
