@@ -1533,6 +1533,9 @@ __device__ __forceinline__ bool kept_flag(const int *__restrict__ cnt, int64_t i
 // The payload IS the flagged word, so no fence is involved; nobody waits for a later ticket.
 constexpr unsigned int kCountValid = 0x80000000u;
 
+// PER slices of 1024 boxes per block: the ticket is a returning atomic on ONE word (~90 per
+// microsecond), 14 us of tickets alone at 1.25e6 boxes with one slice per block.
+template <int PER>
 __global__ __launch_bounds__(1024) void nms_compact_kernel(const int *__restrict__ cnt, int64_t n,
                                                            unsigned int *__restrict__ blockcnt,   // [0] ticket, [1 + t] count | VALID
                                                            int64_t *__restrict__ keep,
@@ -1540,24 +1543,37 @@ __global__ __launch_bounds__(1024) void nms_compact_kernel(const int *__restrict
                                                            const unsigned long long *__restrict__ ccnts,
                                                            const unsigned int *__restrict__ ucnts,
                                                            NmsHostInfo *__restrict__ hinfo) {
-  __shared__ int wsum[16];
+  __shared__ int wsum[PER][16];
   __shared__ long long red[16];
   __shared__ unsigned int s_ticket;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid == 0) s_ticket = __hip_atomic_fetch_add(&blockcnt[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
   const unsigned int t = s_ticket;
-  const int64_t i = (int64_t)t * 1024 + tid;
-  const bool f = (i < n) && kept_flag(cnt, i);
-  const uint64_t mk = __ballot(f);
-  if (lane == 0) wsum[wave] = __popcll(mk);
-  __syncthreads();
-  int off = 0, tot = 0;
+  const int64_t i0 = (int64_t)t * (PER * 1024) + tid;
+  bool f[PER];
+  uint64_t mk[PER];
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    const int v = wsum[k];
-    off += (k < wave) ? v : 0;
-    tot += v;
+  for (int u = 0; u < PER; ++u) {
+    const int64_t i = i0 + u * 1024;
+    f[u] = (i < n) && kept_flag(cnt, i);
+  }
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    mk[u] = __ballot(f[u]);
+    if (lane == 0) wsum[u][wave] = __popcll(mk[u]);
+  }
+  __syncthreads();
+  int off[PER], tot = 0;   // start of this wave's kept boxes of slice u inside the block
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    off[u] = tot;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int v = wsum[u][k];
+      off[u] += (k < wave) ? v : 0;
+      tot += v;
+    }
   }
   if (tid == 0) __hip_atomic_store(&blockcnt[1 + t], (unsigned int)tot | kCountValid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   long long part = 0;
@@ -1572,7 +1588,9 @@ __global__ __launch_bounds__(1024) void nms_compact_kernel(const int *__restrict
   long long sbase = 0;
 #pragma unroll
   for (int k = 0; k < 16; ++k) sbase += red[k];
-  if (f) keep[sbase + off + __popcll(mk & ((1ull << lane) - 1ull))] = i;
+#pragma unroll
+  for (int u = 0; u < PER; ++u)
+    if (f[u]) keep[sbase + off[u] + __popcll(mk[u] & ((1ull << lane) - 1ull))] = i0 + u * 1024;
   if (t == gridDim.x - 1 && wave == 0) {  // fold the padded shard counters for the host
     unsigned long long v = ccnts[(size_t)lane * kCandStride], mx = v;
     const unsigned long long ev = ccnts[(size_t)(kShards + lane) * kCandStride];
@@ -2212,8 +2230,13 @@ static int nms_enqueue(const char *who, const float *dets_dev, int64_t n, int ki
     OBB_LAUNCH_CHECK();
     // phase 6: compaction (one pass: every block publishes its count and sums its predecessors')
     OBB_PHASE(6);
-    const unsigned cblocks = (unsigned)((n + 1023) / 1024);
-    hipLaunchKernelGGL(nms_compact_kernel, dim3(cblocks), dim3(1024), 0, st, cnt, n, blockcnt, keep_dev, ctr, ccnts, ucnts, result);
+    if (n >= (1 << 18)) {
+      const unsigned cblocks = (unsigned)((n + 4095) / 4096);
+      hipLaunchKernelGGL(nms_compact_kernel<4>, dim3(cblocks), dim3(1024), 0, st, cnt, n, blockcnt, keep_dev, ctr, ccnts, ucnts, result);
+    } else {
+      const unsigned cblocks = (unsigned)((n + 1023) / 1024);
+      hipLaunchKernelGGL(nms_compact_kernel<1>, dim3(cblocks), dim3(1024), 0, st, cnt, n, blockcnt, keep_dev, ctr, ccnts, ucnts, result);
+    }
     OBB_LAUNCH_CHECK();
     OBB_PHASE(7);
   }
