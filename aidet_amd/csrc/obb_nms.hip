@@ -64,6 +64,7 @@ constexpr int kSubRows = kTile / kSub;  // 32 rows: one scan unit = (row sub-til
 constexpr int kRowChunk = 4;
 constexpr int kNmsQueue = 64 + kTile;  // carry (<= 63) + one row's worst case
 constexpr int kCullChunk = 1024;        // column tiles per cull block (LDS list: kSub entries each)
+constexpr int kSuper = 16;              // tiles per supertile: the cull kernel tests these first (8 words each)
 constexpr int kCells = 262144;          // max Morton cells of the counting sort (9 + 9 bits)
 constexpr int kScanBlockCells = 1024;   // cells per block of the multi-block cell scan (kCells / 1024 blocks at most)
 constexpr int kShards = 64;            // candidate lists / counters (atomic rate)
@@ -612,7 +613,8 @@ __global__ __launch_bounds__(256) void nms_permute_kernel(const uint2 *__restric
                                                           uint32_t *__restrict__ tgr,
                                                           uint32_t *__restrict__ sgr,
                                                           const float *__restrict__ thrs,
-                                                          float *__restrict__ pt) {
+                                                          float *__restrict__ pt,
+                                                          unsigned int *__restrict__ super) {
   __shared__ uint4 wred[4];
   __shared__ uint2 gred[4];
   const int64_t s = (int64_t)blockIdx.x * kTile + threadIdx.x;
@@ -666,10 +668,16 @@ __global__ __launch_bounds__(256) void nms_permute_kernel(const uint2 *__restric
     }
     // a tile of sentinels only keeps lo = max, hi = 0: it meets nothing
     tbox[blockIdx.x] = make_uint2(m.x | (m.y << 16), (m.z | (m.w << 16)) | kGuard);
+    // bounding box (and bucket range) of the SUPERTILE of kSuper consecutive tiles: every field is kept
+    // as a maximum (the lows complemented) so that the zero-filled words mean "empty"
+    unsigned int *sp = super + (size_t)(blockIdx.x / kSuper) * 8;
+    atomicMax(sp + 0, 0x7FFFu - m.x); atomicMax(sp + 1, 0x7FFFu - m.y);
+    atomicMax(sp + 2, m.z); atomicMax(sp + 3, m.w);
     if (group) {
       uint2 r = gred[0];
       for (int k = 1; k < 4; ++k) { r.x = min(r.x, gred[k].x); r.y = max(r.y, gred[k].y); }
       tgr[blockIdx.x] = r.x | (r.y << 16);
+      atomicMax(sp + 4, 0xFFFFu - r.x); atomicMax(sp + 5, r.y);
     }
   }
 }
@@ -706,28 +714,50 @@ __global__ __launch_bounds__(256) void nms_cull_kernel(const uint2 *__restrict__
                                                        const uint32_t *__restrict__ sgr, int nt,
                                                        uint2 *__restrict__ units,
                                                        unsigned int scap,
-                                                       unsigned int *__restrict__ ucnts) {
+                                                       unsigned int *__restrict__ ucnts,
+                                                       const unsigned int *__restrict__ super) {
   // survivors are collected in LDS and published with two global atomics per block, on
   // the counters of this tile's shard of the unit list
   __shared__ uint32_t lists[kCullChunk * kSub];   // sub << 16 | B; heavy from the front, light from the back
-  __shared__ unsigned int nh, nl, gbase_h, gbase_l;
+  __shared__ unsigned int nh, nl, gbase_h, gbase_l, nsup;
+  __shared__ uint16_t slist[kCullChunk / kSuper + 2];
   const int A = blockIdx.x;
   const int b0 = A + (int)blockIdx.y * kCullChunk;   // this block's column tiles [b0, b1)
   if (b0 >= nt) return;
   const int b1 = min(nt, b0 + kCullChunk);
   const int span = (b1 - b0) * kSub;
-  if (threadIdx.x == 0) { nh = 0; nl = 0; }
+  if (threadIdx.x == 0) { nh = 0; nl = 0; nsup = 0; }
   __syncthreads();
   const uint2 a = tbox[A];
+  // first the supertiles of the chunk (<= 65): a spatially sorted scene meets a handful of them
+  {
+    const int s0 = b0 / kSuper, ns = (b1 - 1) / kSuper - s0 + 1;
+    const uint32_t gaT = tgr ? tgr[A] : 0xFFFF0000u;
+    if ((int)threadIdx.x < ns) {
+      const uint4 *sp = reinterpret_cast<const uint4 *>(super + (size_t)(s0 + threadIdx.x) * 8);
+      const uint4 bx = sp[0];
+      const uint32_t lo = (0x7FFFu - bx.x) | ((0x7FFFu - bx.y) << 16), hi = (bx.z | (bx.w << 16)) | kGuard;
+      bool meet = bx.x + bx.z >= 0x7FFFu && qdisjoint(a.x, a.y, lo, hi) == 0u;   // (lo <= hi: not empty)
+      if (meet && tgr) {
+        const uint4 gx = sp[1];
+        meet = ranges_meet(gaT, (0xFFFFu - gx.x) | (gx.y << 16));
+      }
+      if (meet) slist[atomicAdd(&nsup, 1u)] = (uint16_t)(s0 + threadIdx.x);
+    }
+    __syncthreads();
+  }
+  const int ncheck = (int)nsup * kSuper;
   uint2 sa[kSub];
 #pragma unroll
   for (int w = 0; w < kSub; ++w) sa[w] = sbox[(size_t)A * kSub + w];
   uint32_t ga[kSub];   // grouped calls: bucket range of every sub-tile (else "everything")
 #pragma unroll
   for (int w = 0; w < kSub; ++w) ga[w] = sgr ? sgr[(size_t)A * kSub + w] : 0xFFFF0000u;
-  for (int B = b0 + threadIdx.x; B < b1; B += 256) {
+  for (int it = threadIdx.x; it < ncheck; it += 256) {
+    const int B = (int)slist[it / kSuper] * kSuper + (it % kSuper);
+    if (B < b0 || B >= b1 || B == A) continue;                       // (diagonal units are implicit)
     const uint2 b = tbox[B];
-    if (B == A || qdisjoint(a.x, a.y, b.x, b.y) != 0u) continue;   // diagonal units are implicit
+    if (qdisjoint(a.x, a.y, b.x, b.y) != 0u) continue;
     const uint32_t gb = tgr ? tgr[B] : 0xFFFF0000u;
 #pragma unroll
     for (int w = 0; w < kSub; ++w) {
@@ -1883,7 +1913,7 @@ static thread_local NmsProfile g_prof;
 
 // ---- workspace layout ------------------------------------------------------------
 struct NmsLayout {
-  size_t rec, iv, ar, part, pstat, qb, ckey, sid, qs, pf, pg, pt, tgr, sgr, ginfo, cellpx, tbox, sbox, zero_begin, cnt, ctr, ccnts, ucnts, hist, scanflags,
+  size_t rec, iv, ar, part, pstat, qb, ckey, sid, qs, pf, pg, pt, tgr, sgr, ginfo, cellpx, tbox, sbox, zero_begin, cnt, ctr, ccnts, ucnts, super, hist, scanflags,
       zero_end, blockcnt, cands, edges, total;
   unsigned long long cap;         // candidate pairs == overlap edges capacity
   unsigned long long unit_worst;  // kShards x the most units one shard of the unit list can get
@@ -1928,6 +1958,7 @@ static int nms_layout(int64_t n, int64_t edge_capacity, NmsLayout &L) {
   L.ctr = take(sizeof(NmsCounters));
   L.ccnts = take((size_t)3 * kShards * kCandStride * sizeof(unsigned long long));  // candidates | edges | candidates clipped in line
   L.ucnts = take((size_t)2 * kShards * kUnitStride * sizeof(unsigned int));        // heavy | light scan units
+  L.super = take(((nt + kSuper - 1) / kSuper) * 8 * 4);   // supertile boxes / bucket ranges (maxima: zero = empty)
   L.blockcnt = take(((nn + 1023) / 1024 + 1) * 4);   // ticket + one flagged count per 1024 boxes
   L.scanflags = take((kCells / kScanBlockCells + 1) * 4);   // multi-block cell scan: ticket + one flagged total per block
   L.hist = take(kCells * 4);   // (LAST of the zeroed range: only the cells a call uses are cleared)
@@ -2108,6 +2139,7 @@ static int nms_enqueue(const char *who, const float *dets_dev, int64_t n, int ki
   NmsCounters *ctr = reinterpret_cast<NmsCounters *>(ws + L.ctr);
   unsigned long long *ccnts = reinterpret_cast<unsigned long long *>(ws + L.ccnts);
   unsigned int *ucnts = reinterpret_cast<unsigned int *>(ws + L.ucnts);
+  unsigned int *super = reinterpret_cast<unsigned int *>(ws + L.super);
   unsigned int *blockcnt = reinterpret_cast<unsigned int *>(ws + L.blockcnt);
   unsigned int *scanflags = reinterpret_cast<unsigned int *>(ws + L.scanflags);
   uint2 *cands = reinterpret_cast<uint2 *>(ws + L.cands);
@@ -2200,9 +2232,9 @@ static int nms_enqueue(const char *who, const float *dets_dev, int64_t n, int ki
     OBB_LAUNCH_CHECK();
     // phase 2: permute + tile boxes + unit culling
     OBB_PHASE(2);
-    hipLaunchKernelGGL(nms_permute_kernel, dim3((unsigned)nt), dim3(kTile), 0, st, qb, sid, ar, n, qs, pf, tbox, sbox, group_dev, ginfo, pg, tgr, sgr, thr_dev, pt);
+    hipLaunchKernelGGL(nms_permute_kernel, dim3((unsigned)nt), dim3(kTile), 0, st, qb, sid, ar, n, qs, pf, tbox, sbox, group_dev, ginfo, pg, tgr, sgr, thr_dev, pt, super);
     OBB_LAUNCH_CHECK();
-    hipLaunchKernelGGL(nms_cull_kernel, dim3((unsigned)nt, (unsigned)((nt + kCullChunk - 1) / kCullChunk)), dim3(256), 0, st, tbox, sbox, tgr, sgr, nt, units, ucap / kShards, ucnts);
+    hipLaunchKernelGGL(nms_cull_kernel, dim3((unsigned)nt, (unsigned)((nt + kCullChunk - 1) / kCullChunk)), dim3(256), 0, st, tbox, sbox, tgr, sgr, nt, units, ucap / kShards, ucnts, super);
     OBB_LAUNCH_CHECK();
     // phase 3: scan (broad phase)
     OBB_PHASE(3);
