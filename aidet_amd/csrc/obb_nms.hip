@@ -65,6 +65,7 @@ constexpr int kRowChunk = 4;
 constexpr int kNmsQueue = 64 + kTile;  // carry (<= 63) + one row's worst case
 constexpr int kCullChunk = 1024;        // column tiles per cull block (LDS list: kSub entries each)
 constexpr int kSuper = 16;              // tiles per supertile: the cull kernel tests these first (8 words each)
+constexpr int kSuperMinTiles = 1024;    // calls with fewer tiles (n <= 262144) do without supertiles
 constexpr int kCells = 262144;          // max Morton cells of the counting sort (9 + 9 bits)
 constexpr int kScanBlockCells = 1024;   // cells per block of the multi-block cell scan (kCells / 1024 blocks at most)
 constexpr int kShards = 64;            // candidate lists / counters (atomic rate)
@@ -672,14 +673,17 @@ __global__ __launch_bounds__(256) void nms_permute_kernel(const uint2 *__restric
     tbox[blockIdx.x] = make_uint2(m.x | (m.y << 16), (m.z | (m.w << 16)) | kGuard);
     // bounding box (and bucket range) of the SUPERTILE of kSuper consecutive tiles: every field is kept
     // as a maximum (the lows complemented) so that the zero-filled words mean "empty"
-    unsigned int *sp = super + (size_t)(blockIdx.x / kSuper) * 8;
-    atomicMax(sp + 0, 0x7FFFu - m.x); atomicMax(sp + 1, 0x7FFFu - m.y);
-    atomicMax(sp + 2, m.z); atomicMax(sp + 3, m.w);
+    // (only kept for large calls: super == nullptr below kSuperMinTiles tiles)
+    unsigned int *sp = super ? super + (size_t)(blockIdx.x / kSuper) * 8 : nullptr;
+    if (sp) {
+      atomicMax(sp + 0, 0x7FFFu - m.x); atomicMax(sp + 1, 0x7FFFu - m.y);
+      atomicMax(sp + 2, m.z); atomicMax(sp + 3, m.w);
+    }
     if (group) {
       uint2 r = gred[0];
       for (int k = 1; k < 4; ++k) { r.x = min(r.x, gred[k].x); r.y = max(r.y, gred[k].y); }
       tgr[blockIdx.x] = r.x | (r.y << 16);
-      atomicMax(sp + 4, 0xFFFFu - r.x); atomicMax(sp + 5, r.y);
+      if (sp) { atomicMax(sp + 4, 0xFFFFu - r.x); atomicMax(sp + 5, r.y); }
     }
   }
 }
@@ -732,7 +736,9 @@ __global__ __launch_bounds__(256) void nms_cull_kernel(const uint2 *__restrict__
   __syncthreads();
   const uint2 a = tbox[A];
   // first the supertiles of the chunk (<= 65): a spatially sorted scene meets a handful of them
-  {
+  // (small calls have no supertiles -- one more barrier and a round of atomics cost 1.7 us at
+  // 100k boxes -- and visit every tile of the chunk)
+  if (super) {
     const int s0 = b0 / kSuper, ns = (b1 - 1) / kSuper - s0 + 1;
     const uint32_t gaT = tgr ? tgr[A] : 0xFFFF0000u;
     if ((int)threadIdx.x < ns) {
@@ -748,7 +754,7 @@ __global__ __launch_bounds__(256) void nms_cull_kernel(const uint2 *__restrict__
     }
     __syncthreads();
   }
-  const int ncheck = (int)nsup * kSuper;
+  const int ncheck = super ? (int)nsup * kSuper : b1 - b0;
   uint2 sa[kSub];
 #pragma unroll
   for (int w = 0; w < kSub; ++w) sa[w] = sbox[(size_t)A * kSub + w];
@@ -756,7 +762,7 @@ __global__ __launch_bounds__(256) void nms_cull_kernel(const uint2 *__restrict__
 #pragma unroll
   for (int w = 0; w < kSub; ++w) ga[w] = sgr ? sgr[(size_t)A * kSub + w] : 0xFFFF0000u;
   for (int it = threadIdx.x; it < ncheck; it += 256) {
-    const int B = (int)slist[it / kSuper] * kSuper + (it % kSuper);
+    const int B = super ? (int)slist[it / kSuper] * kSuper + (it % kSuper) : b0 + it;
     if (B < b0 || B >= b1 || B == A) continue;                       // (diagonal units are implicit)
     const uint2 b = tbox[B];
     if (qdisjoint(a.x, a.y, b.x, b.y) != 0u) continue;
@@ -2236,9 +2242,9 @@ static int nms_enqueue(const char *who, const float *dets_dev, int64_t n, int ki
     OBB_LAUNCH_CHECK();
     // phase 2: permute + tile boxes + unit culling
     OBB_PHASE(2);
-    hipLaunchKernelGGL(nms_permute_kernel, dim3((unsigned)nt), dim3(kTile), 0, st, qb, sid, ar, n, qs, pf, tbox, sbox, group_dev, ginfo, pg, tgr, sgr, thr_dev, pt, super);
+    hipLaunchKernelGGL(nms_permute_kernel, dim3((unsigned)nt), dim3(kTile), 0, st, qb, sid, ar, n, qs, pf, tbox, sbox, group_dev, ginfo, pg, tgr, sgr, thr_dev, pt, nt >= kSuperMinTiles ? super : nullptr);
     OBB_LAUNCH_CHECK();
-    hipLaunchKernelGGL(nms_cull_kernel, dim3((unsigned)nt, (unsigned)((nt + kCullChunk - 1) / kCullChunk)), dim3(256), 0, st, tbox, sbox, tgr, sgr, nt, units, ucap / kShards, ucnts, super);
+    hipLaunchKernelGGL(nms_cull_kernel, dim3((unsigned)nt, (unsigned)((nt + kCullChunk - 1) / kCullChunk)), dim3(256), 0, st, tbox, sbox, tgr, sgr, nt, units, ucap / kShards, ucnts, nt >= kSuperMinTiles ? super : nullptr);
     OBB_LAUNCH_CHECK();
     // phase 3: scan (broad phase)
     OBB_PHASE(3);
