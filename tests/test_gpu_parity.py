@@ -1186,3 +1186,23 @@ def test_merge_row_kernels_equal_the_tensor_expressions():
     bad = pidx.clone(); bad[0] = P + 3     # a patch index out of range: zero row, label = image = -1
     z = dota_merge.patch_rows_to_image(d.cuda(), labels.cuda(), bad.cuda(), pxy.cuda(), pim.cuda())
     assert z[0].tolist() == [0, 0, 0, 0, 0, 0, -1, -1] and torch.equal(z[1:].cpu(), dota_merge.patch_rows_to_image(d, labels, pidx, pxy, pim)[1:])
+
+
+def test_grouped_rnms_large_call_matches_oracle_group_by_group():
+    """4e5 boxes in 20 000 groups sharing one coordinate range (the merged NMS of tiled inference at
+    a size where the sort uses 2^18 cells, the cull kernel its supertiles and the compaction four
+    slices per block): groups never interact, so the oracle can check any of them on its own."""
+    from aidet_amd import rnms
+    rng = np.random.default_rng(31)
+    n, ng = 400000, 20000
+    d = oracle.synth_boxes(n, 250.0, 17)                # ~20 boxes per group on a 250 px canvas: dense
+    groups = rng.integers(0, ng, n).astype(np.int32) * 7919 - 50000000     # arbitrary ids
+    thrs = rng.choice([0.1, 0.3, 0.5], n).astype(np.float32)
+    for kw in ({}, {'thrs': thrs}):
+        keep = rnms(t(d), 0.4, groups=groups, **kw)[1].cpu().numpy()
+        assert np.all(np.diff(keep) > 0) and 0.3 * n < len(keep) < n
+        kept = np.zeros(n, bool); kept[keep] = True
+        for g in np.unique(groups)[rng.integers(0, ng - 1, 150)]:
+            idx = np.nonzero(groups == g)[0]
+            ref = oracle.rnms(d[idx], 0.4, thrs=None if not kw else thrs[idx])
+            assert np.array_equal(np.nonzero(kept[idx])[0], ref), int(g)
