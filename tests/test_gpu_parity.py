@@ -1206,3 +1206,25 @@ def test_grouped_rnms_large_call_matches_oracle_group_by_group():
             idx = np.nonzero(groups == g)[0]
             ref = oracle.rnms(d[idx], 0.4, thrs=None if not kw else thrs[idx])
             assert np.array_equal(np.nonzero(kept[idx])[0], ref), int(g)
+
+
+@pytest.mark.parametrize('n,canvas,ng', [(30000, 2500.0, 0), (70000, 3000.0, 900), (150000, 9000.0, 0),
+                                         (300000, 6000.0, 40000), (600000, 30000.0, 7)])
+def test_rnms_routes_agree_at_sizes_the_oracle_cannot_reach(n, canvas, ng, nms_route):
+    """Every route computes the same greedy fixpoint: direct (n <= 65 536), sorted with the clip in
+    line, sorted with candidate lists -- dense scenes, few / very many groups, per-box thresholds."""
+    from aidet_amd import rnms
+    rng = np.random.default_rng(n)
+    d = t(oracle.synth_boxes(n, canvas, n % 97))
+    groups = None if ng == 0 else torch.from_numpy(rng.integers(0, ng, n).astype(np.int32)).cuda()
+    thrs = torch.from_numpy(rng.choice([0.2, 0.45, 0.7], n).astype(np.float32)).cuda() if n % 20000 == 0 else None
+    ref = None
+    for route in ('listed', 'sorted', 'direct', 'auto'):
+        if route == 'direct' and n > 65536:
+            continue
+        nms_route(route)
+        keep = rnms(d, 0.5, groups=groups, thrs=thrs)[1]
+        if ref is None:
+            ref = keep
+            assert 0.2 * n < keep.numel() < n
+        assert torch.equal(keep, ref), route
