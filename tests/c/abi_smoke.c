@@ -17,6 +17,12 @@ int main(void) {
   if (obb_nms_workspace_bytes(100000, OBB_KIND_RBOX, 0) == 0) return 7;
   if (obb_overlaps_f32(0, 0, 0, 5, OBB_KIND_RBOX, OBB_MODE_IOU, 0, 0, 0) != OBB_OK) return 8;   /* empty */
   if (obb_overlaps_f32(0, 3, 0, 5, 9, OBB_MODE_IOU, 0, 0, 0) != OBB_EINVAL) return 9;            /* bad kind */
+  /* the row plumbing of the tiled merge: argument checks run without a GPU */
+  if (obb_patch_groups_i32(0, 0, 0, 15, 0, 0) != OBB_OK) return 10;                                  /* n = 0 */
+  if (obb_patch_rows_to_image_f32(0, 0, 0, 5, 0, 5, 0, 0, 1, 0.0f, 0, 0) != OBB_EINVAL) return 11;   /* rate <= 0 */
+  if (obb_merge_rows_split_f32(0, 4, 9, 15, 0, 0.3f, 0, 0, 0, 0) != OBB_EINVAL) return 12;           /* 9 columns */
+  if (obb_gather_rows_f32(0, 4, 8, 0, 0, 8, 0, 0) != OBB_OK) return 13;                              /* k = 0 */
+  if (obb_gather_rows_f32(0, 4, 8, 0, 2, 9, 0, 0) != OBB_EINVAL) return 14;                          /* out_cols > cols */
   printf("c abi ok: %s\n", obb_build_info());
   return 0;
 }
