@@ -614,14 +614,22 @@ def bench_tiled(args):
         'speedup_vs_single_rank': round(single['ms_per_step'] / ms, 3) if single else None,
         'note': 'N = 1 of this script times BASELINE configs[1] (rnms on 100k boxes); this line times '
                 'configs[4], the only part of the path with a data-path collective.  The job is a few hundred '
-                'microseconds of latency-bound kernels: xGMI/RCCL latency (2 all_gathers, 4 when sharded) is '
-                'what strong scaling runs into.',
+                'microseconds of latency-bound kernels: xGMI/RCCL latency (2 all_gathers, + 1 all_reduce of a '
+                'byte mask when sharded) is what strong scaling runs into.',
     }
+    # the verdict travels to every rank BEFORE anybody leaves: a rank that raised on its own would
+    # leave the others waiting in the barrier
+    ok = torch.tensor([1 if (rank != 0 or (same_on_all_ranks and ok_single)) else 0], dtype=torch.int64, device=dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    ok = bool(ok.item())
     if rank == 0:
-        assert same_on_all_ranks and ok_single, 'distributed merge differs from the single-rank result'
+        if not ok:
+            out['error'] = 'distributed merge differs from the single-rank result'
         print(json.dumps(out))
     dist.barrier()
     dist.destroy_process_group()
+    if not ok:
+        sys.exit(1)
 
 
 # ==============================================================================================
