@@ -10,12 +10,14 @@ operator surface:
   rroi_align.RRoIAlign / rroi_align                  <-> mmdet/ops/roi_align/roi_align.py:9-152
   roi_layers.RoIAlign / SingleRoIExtractor           <-> roi_align.py:79-152, roi_extractors/single_level.py:11-107
   post_processing.*                                  <-> core/post_processing/bbox_nms.py, rbbox_nms.py
+  merge_augs.merge_aug_{proposals,bboxes,scores}     <-> core/post_processing/merge_augs.py:8-78 (test-time augmentation)
   rpn.rpn_proposals, anchors, bbox_transforms        <-> anchor_heads/rpn_head.py:55-104, core/anchor, core/bbox/transforms.py
   dota_merge / dota_io                               <-> apis/test.py:116-146, datasets/dota.py:278-336
   models.ThetaOBBRCNN                                <-> detectors/rbbox_cnn.py:214-253 (test path, config 4)
 
 There is no CPU fallback: every op raises if the HIP library or a GPU is missing.
 """
+from .merge_augs import merge_aug_bboxes, merge_aug_proposals, merge_aug_scores
 from .nms_wrapper import nms, poly_nms, rnms, soft_nms, thetaobb_nms
 from .post_processing import (get_det_rbboxes, multiclass_nms, multiclass_nms_with_index, multiclass_rnms,
                               thetaobb_nms_by_bbox_nms)
@@ -26,6 +28,7 @@ from .rroi_align import RRoIAlign, rroi_align
 __all__ = [
     'rnms', 'poly_nms', 'thetaobb_nms', 'nms', 'soft_nms', 'rbbox_overlaps', 'bbox_overlaps', 'thetaobb2pointobb',
     'RRoIAlign', 'rroi_align', 'RoIAlign', 'SingleRoIExtractor', 'RotatedSingleRoIExtractor',
-    'multiclass_nms', 'multiclass_rnms', 'multiclass_nms_with_index', 'thetaobb_nms_by_bbox_nms', 'get_det_rbboxes'
+    'multiclass_nms', 'multiclass_rnms', 'multiclass_nms_with_index', 'thetaobb_nms_by_bbox_nms', 'get_det_rbboxes',
+    'merge_aug_proposals', 'merge_aug_bboxes', 'merge_aug_scores'
 ]
 __version__ = '0.2.0'

@@ -63,3 +63,27 @@ def bbox2result(bboxes, labels, num_classes):
                 for _ in range(num_classes - 1)]
     b, l = bboxes.detach().cpu().numpy(), labels.detach().cpu().numpy()
     return [b[l == i, :] for i in range(num_classes - 1)]
+
+
+def bbox_flip(bboxes, img_shape):
+    """Mirror (..., 4k) xyxy boxes left-right inside an image of width ``img_shape[1]``
+    (transforms.py:114-131; the +1 pixel convention: x -> W - x - 1, with x1 / x2 swapping roles).
+    Tensor or ndarray in, same type out."""
+    assert bboxes.shape[-1] % 4 == 0
+    w = img_shape[1]
+    out = bboxes.clone() if isinstance(bboxes, torch.Tensor) else np.array(bboxes, copy=True)
+    out[..., 0::4] = w - bboxes[..., 2::4] - 1
+    out[..., 2::4] = w - bboxes[..., 0::4] - 1
+    return out
+
+
+def bbox_mapping(bboxes, img_shape, scale_factor, flip):
+    """Original image scale -> a test-time augmentation's scale (transforms.py:134-139):
+    scale first, then flip inside the augmented image."""
+    scaled = bboxes * scale_factor
+    return bbox_flip(scaled, img_shape) if flip else scaled
+
+
+def bbox_mapping_back(bboxes, img_shape, scale_factor, flip):
+    """The inverse (transforms.py:142-146): un-flip inside the augmented image, then divide."""
+    return (bbox_flip(bboxes, img_shape) if flip else bboxes) / scale_factor

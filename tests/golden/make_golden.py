@@ -406,6 +406,38 @@ def detector_parts(nms_wrapper, bbox_nms):
     roi5 = torch.cat([torch.zeros(300, 1), R], 1)
     bb, sc = bbh.get_det_bboxes(roi5, cs, D, (1024, 1024, 3), 2.0, rescale=True, cfg=None)
     out['head_cls_score'] = cs.numpy(); out['head_bboxes'] = bb.numpy(); out['head_scores'] = sc.numpy()
+    # ---- test-time augmentation merges (core/post_processing/merge_augs.py, core/bbox/transforms.py:114-146)
+    pkg('mmdet.core.bbox').bbox_mapping_back = bt.bbox_mapping_back
+    pkg('mmdet.core.post_processing')
+    ma = _load('mmdet.core.post_processing.merge_augs', REF + '/mmdet/core/post_processing/merge_augs.py')
+    rng2 = np.random.default_rng(777)
+    fb = torch.from_numpy(rand_hbb(rng2, 40, 380).reshape(20, 8))
+    out['aug_flip_in'] = fb.numpy()
+    out['aug_flip_out'] = bt.bbox_flip(fb, (300, 400, 3)).numpy()
+    out['aug_map_out'] = bt.bbox_mapping(fb, (450, 600, 3), 1.5, True).numpy()
+    out['aug_map_noflip'] = bt.bbox_mapping(fb, (450, 600, 3), 1.5, False).numpy()
+    out['aug_mapback_out'] = bt.bbox_mapping_back(fb, (450, 600, 3), 1.5, True).numpy()
+    metas = [dict(img_shape=(300, 400, 3), scale_factor=1.0, flip=False),
+             dict(img_shape=(450, 600, 3), scale_factor=1.5, flip=True),
+             dict(img_shape=(225, 300, 3), scale_factor=0.75, flip=False)]
+    props = []
+    for k, (m, cnt) in enumerate(zip(metas, (150, 130, 90))):
+        b = rand_hbb(rng2, cnt, int(380 * m['scale_factor']), 8, int(110 * m['scale_factor']))
+        sc = (rng2.permutation(1000)[:cnt] * 3 + k + 0.5) / 3000.0      # distinct over all three lists
+        props.append(torch.from_numpy(np.concatenate([b, sc[:, None]], 1).astype(np.float32)))
+        out['aug_props_%d' % k] = props[-1].numpy()
+    out['aug_metas'] = np.array([[m['img_shape'][0], m['img_shape'][1], m['scale_factor'], float(m['flip'])] for m in metas])
+    out['aug_props_merged'] = ma.merge_aug_proposals(props, metas, Cfg(nms_thr=0.7, max_num=120)).numpy()
+    out['aug_props_merged_all'] = ma.merge_aug_proposals(props, metas, Cfg(nms_thr=0.5, max_num=100000)).numpy()
+    ab = [torch.from_numpy(rand_hbb(rng2, 50 * 16, 380).reshape(50, 64)) * m['scale_factor'] for m in metas]
+    asc = [torch.from_numpy(rng2.random((50, 16)).astype(np.float32)) for _ in metas]
+    for k in range(3):
+        out['aug_bboxes_%d' % k] = ab[k].numpy(); out['aug_scores_%d' % k] = asc[k].numpy()
+    mb, ms = ma.merge_aug_bboxes(ab, asc, [[m] for m in metas], None)
+    out['aug_bboxes_merged'] = mb.numpy(); out['aug_scores_merged'] = ms.numpy()
+    out['aug_bboxes_only'] = ma.merge_aug_bboxes(ab, None, [[m] for m in metas], None).numpy()
+    out['aug_scores_mean_np'] = ma.merge_aug_scores([a.numpy() for a in asc])
+    out['aug_scores_mean_t'] = ma.merge_aug_scores(asc).numpy()
     np.savez_compressed(os.path.join(HERE, 'detector_parts.npz'), **out)
 
 

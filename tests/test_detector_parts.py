@@ -118,7 +118,52 @@ def test_model_builds_with_the_configured_shapes():
     assert [len(x) for x in a] == [32 * 32 * 3, 16 * 16 * 3, 8 * 8 * 3, 4 * 4 * 3, 2 * 2 * 3]
 
 
+def _aug_metas(g):
+    return [dict(img_shape=(int(r[0]), int(r[1]), 3), scale_factor=float(r[2]), flip=bool(r[3])) for r in g['aug_metas']]
+
+
+def test_bbox_flip_mapping_and_aug_merges_reproduce_reference(golden):
+    """core/bbox/transforms.py:114-146 and merge_augs.py:46-78 (no NMS in these)."""
+    from aidet_amd.bbox_transforms import bbox_flip, bbox_mapping, bbox_mapping_back
+    from aidet_amd.merge_augs import merge_aug_bboxes, merge_aug_proposals, merge_aug_scores
+    g = golden('detector_parts.npz')
+    fb = torch.from_numpy(g['aug_flip_in'])
+    assert np.array_equal(bbox_flip(fb, (300, 400, 3)).numpy(), g['aug_flip_out'])
+    assert np.array_equal(bbox_flip(g['aug_flip_in'], (300, 400, 3)), g['aug_flip_out'])      # ndarray in, ndarray out
+    assert np.array_equal(bbox_mapping(fb, (450, 600, 3), 1.5, True).numpy(), g['aug_map_out'])
+    assert np.array_equal(bbox_mapping(fb, (450, 600, 3), 1.5, False).numpy(), g['aug_map_noflip'])
+    assert np.array_equal(bbox_mapping_back(fb, (450, 600, 3), 1.5, True).numpy(), g['aug_mapback_out'])
+    assert np.array_equal(fb.numpy(), g['aug_flip_in'])                                        # inputs untouched
+    metas = _aug_metas(g)
+    ab = [torch.from_numpy(g['aug_bboxes_%d' % k]) for k in range(3)]
+    asc = [torch.from_numpy(g['aug_scores_%d' % k]) for k in range(3)]
+    mb, ms = merge_aug_bboxes(ab, asc, [[m] for m in metas], None)
+    assert np.array_equal(mb.numpy(), g['aug_bboxes_merged']) and np.array_equal(ms.numpy(), g['aug_scores_merged'])
+    assert np.array_equal(merge_aug_bboxes(ab, None, [[m] for m in metas]).numpy(), g['aug_bboxes_only'])
+    assert np.array_equal(merge_aug_scores(asc).numpy(), g['aug_scores_mean_t'])
+    assert np.array_equal(merge_aug_scores([a.numpy() for a in asc]), g['aug_scores_mean_np'])
+    # merge_aug_proposals with the oracle's op injected (the HIP op: GPU test below)
+    props = [torch.from_numpy(g['aug_props_%d' % k]) for k in range(3)]
+    for cfg, key in ((dict(nms_thr=0.7, max_num=120), 'aug_props_merged'), (dict(nms_thr=0.5, max_num=100000), 'aug_props_merged_all')):
+        got = merge_aug_proposals(props, metas, cfg, nms_op=_oracle_nms).numpy()
+        assert np.array_equal(got, g[key]), key
+
+
 # ---- on the GPU: the HIP ops inside the same functions, then the whole detector -----------------
+@pytest.mark.gpu
+def test_merge_aug_proposals_on_gpu_reproduces_reference(golden):
+    """aug_test_rpn's merge (test_mixins.py:37-59 -> merge_augs.py:8-43) on the HIP nms."""
+    from aidet_amd.merge_augs import merge_aug_proposals
+    g = golden('detector_parts.npz')
+    props = [torch.from_numpy(g['aug_props_%d' % k]).cuda() for k in range(3)]
+    for cfg, key in ((dict(nms_thr=0.7, max_num=120), 'aug_props_merged'), (dict(nms_thr=0.5, max_num=100000), 'aug_props_merged_all')):
+        got = merge_aug_proposals(props, _aug_metas(g), cfg).cpu().numpy()
+        # same survivors in the same order; torch divides by a scalar on the GPU as a multiplication by
+        # its reciprocal, so mapped-back coordinates may differ from the CPU reference in the last ulp
+        assert got.shape == g[key].shape and np.array_equal(got[:, 4], g[key][:, 4]), key
+        assert np.abs(got - g[key]).max() <= 1e-4, key
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('tag', ['a', 'b', 'c'])
 def test_rpn_proposals_on_gpu_reproduce_reference(golden, tag):
