@@ -200,43 +200,62 @@ def thetaobb_nms_by_bbox_nms(multi_bboxes, multi_scores, bbox_cls_inds, bbox_kee
 
 def get_det_rbboxes(rois, cls_score, rbbox_pred, img_shape, scale_factor, rescale=False, cfg=None,
                     target_means=(0., 0., 0., 0., 0.), target_stds=(0.1, 0.1, 0.2, 0.2, 0.1),
-                    bbox_cls_inds=None, bbox_keep_inds=None, rotated_nms=True):
-    """theta-OBB detections of one image from the rbbox head's outputs.
+                    bbox_cls_inds=None, bbox_keep_inds=None, rotated_nms=True, encode=None):
+    """Oriented detections of one image from the rbbox head's outputs.
 
     Counterpart of ``RBBoxHead.get_det_rbboxes_parallel``
-    (mmdet/models/bbox_heads/rbbox_head.py:253-296, encode='thetaobb'): softmax,
-    ``delta2thetaobb`` with the head's means/stds, optional rescale, then NMS.
+    (mmdet/models/bbox_heads/rbbox_head.py:253-296): softmax, the decoder of the head's
+    encoding with the head's means/stds, optional rescale, then NMS.  ``encode`` (default:
+    ``cfg.encode`` if the config has one, else 'thetaobb', the encoding of config 4) selects
+    ``delta2thetaobb`` / ``delta2pointobb`` / ``delta2hobb`` and the matching rescale, as the
+    reference's two dictionaries do (:264-269); ``target_means`` / ``target_stds`` must have the
+    encoding's length (5 / 8 / 5).
 
     ``rotated_nms=True`` runs the call the reference left commented out (:294-295):
     ``multiclass_rnms(thetaobbs, scores, cfg.score_thr, polygon_nms_iou_thr,
     max_per_img)``.  ``rotated_nms=False`` reproduces the reference's behaviour, i.e.
     re-applies the horizontal keep indices (:287-293) -- then ``bbox_cls_inds`` /
-    ``bbox_keep_inds`` from ``multiclass_nms_with_index`` are required.
+    ``bbox_keep_inds`` from ``multiclass_nms_with_index`` are required.  The true NMS of the
+    'pointobb' encoding is ``poly_nms`` on the decoded corner points; 'hobb' boxes have no polygon
+    form here and only support the keep re-use.
 
     ``cfg`` needs ``score_thr``, ``max_per_img`` and ``polygon_nms_iou_thr`` (attribute or
     key access), as test_cfg.rcnn of configs/dota/dota_v002_theta_obb_r50_v1_train.py:125-132.
     """
     import torch.nn.functional as F
 
-    from .rbbox_transforms import delta2thetaobb, thetaobb_rescale
+    from . import rbbox_transforms as T
 
     def get(name):
         return cfg[name] if isinstance(cfg, dict) else getattr(cfg, name)
+
+    if encode is None:
+        encode = 'thetaobb'
+        if cfg is not None and (('encode' in cfg) if isinstance(cfg, dict) else hasattr(cfg, 'encode')):
+            encode = get('encode')
+    formats = {'thetaobb': (T.delta2thetaobb, T.thetaobb_rescale, 5, 'rnms'),
+               'pointobb': (T.delta2pointobb, T.pointobb_rescale, 8, 'poly_nms'),
+               'hobb': (T.delta2hobb, T.hobb_rescale, 5, None)}
+    if encode not in formats:
+        raise ValueError('encode must be one of {}, got {!r}'.format(sorted(formats), encode))
+    decode, rescale_fn, dim, rotated_op = formats[encode]
 
     if isinstance(cls_score, list):
         cls_score = sum(cls_score) / float(len(cls_score))
     scores = F.softmax(cls_score, dim=1) if cls_score is not None else None
     if rbbox_pred is not None:
-        rbboxes = delta2thetaobb(rois[:, 1:], rbbox_pred, target_means, target_stds, img_shape)
+        rbboxes = decode(rois[:, 1:], rbbox_pred, target_means, target_stds, img_shape)
     else:
         rbboxes = rois[:, 1:]
     if rescale:
-        rbboxes = thetaobb_rescale(rbboxes, scale_factor, reverse_flag=True)
+        rbboxes = rescale_fn(rbboxes, scale_factor, reverse_flag=True)
     if cfg is None:
         return rbboxes, scores
     if rotated_nms:
+        if rotated_op is None:
+            raise ValueError("encode='hobb' has no rotated NMS: pass rotated_nms=False (the reference's keep re-use)")
         return multiclass_rnms(rbboxes, scores, get('score_thr'),
-                               dict(type='rnms', iou_thr=get('polygon_nms_iou_thr')),
-                               get('max_per_img'))
+                               dict(type=rotated_op, iou_thr=get('polygon_nms_iou_thr')),
+                               get('max_per_img'), out_dim_reg=dim)
     return thetaobb_nms_by_bbox_nms(rbboxes, scores, bbox_cls_inds, bbox_keep_inds,
-                                    get('max_per_img'), out_dim_reg=5)
+                                    get('max_per_img'), out_dim_reg=dim)

@@ -7,6 +7,16 @@ Restatement of the theta-OBB parts of the reference's
 They define what the (cx, cy, w, h, theta) numbers fed to the rotated kernels
 mean; the anchor angle is fixed at -pi/2 (:332,383).  Outputs are checked
 against values captured from the reference (tests/golden/thetaobb_codec.npz).
+
+The reference's ``RBBoxHead`` has two more encodings of an oriented box, selected by ``encode=``:
+``pointobb`` (the four corner points, 8 numbers) and ``hobb`` (two corner points + a height).  Their
+codecs -- ``pointobb2delta`` / ``delta2pointobb`` (:412-504), ``hobb2delta`` / ``delta2hobb``
+(:522-599) -- and the host-side helpers around them (``pointobb2bbox`` :57-70, the two point-order rules
+:93-134, ``hobb2pointobb`` :137-163, ``pointobb_flip`` :205-240, ``*_rescale`` :295-318,
+``*_mapping(_back)`` :507-519, 602-613) are restated below and pinned by
+tests/golden/obb_codecs.npz.  Not here: the routines that are thin wrappers of OpenCV
+(``pointobb2thetaobb`` = ``cv2.minAreaRect``, ``maskobb2thetaobb``, and with them ``thetaobb2hobb``
+and ``hobb_flip``): cv2 is not part of this image, so they could neither be pinned nor used.
 """
 import math
 
@@ -97,3 +107,159 @@ def rbbox2result(rbboxes, labels, num_classes):
     rbboxes = rbboxes.cpu().numpy()
     labels = labels.cpu().numpy()
     return [rbboxes[labels == i, :] for i in range(num_classes - 1)]
+
+
+# ---- pointobb (x1, y1, ..., x4, y4) and hobb (x1, y1, x2, y2, h) encodings ------------------------
+# A proposal (xmin, ymin, xmax, ymax) anchors point k of a pointobb at its own corner k, clockwise from
+# the top-left one; offsets are measured in units of the proposal's +1-pixel width / height.
+_CORNER_OF = (0, 1, 2, 1, 2, 3, 0, 3)       # proposal column that anchors each pointobb coordinate
+
+
+def _anchor_and_size(rois, ncoord):
+    pw = rois[..., 2] - rois[..., 0] + 1.0
+    ph = rois[..., 3] - rois[..., 1] + 1.0
+    anchor = rois[..., list(_CORNER_OF[:ncoord])]
+    size = torch.stack([pw, ph] * (ncoord // 2), dim=-1)
+    return anchor, size, pw, ph
+
+
+def _normalise(deltas, means, stds):
+    return deltas.sub_(deltas.new_tensor(means).unsqueeze(0)).div_(deltas.new_tensor(stds).unsqueeze(0))
+
+
+def pointobb2delta(proposals, gt, means=(0, 0, 0, 0, 0, 0, 0, 0), stds=(1, 1, 1, 1, 1, 1, 1, 1)):
+    """proposals (n,4) xyxy, gt (n,8) corner points -> deltas (n,8): (point - corner) / (pw | ph)."""
+    assert proposals.size(0) == gt.size(0)
+    anchor, size, _, _ = _anchor_and_size(proposals.float(), 8)
+    return _normalise((gt.float() - anchor) / size, means, stds)
+
+
+def delta2pointobb(rois, deltas, means=(0, 0, 0, 0, 0, 0, 0, 0), stds=(1, 1, 1, 1, 1, 1, 1, 1), max_shape=None,
+                   wh_ratio_clip=16 / 1000):
+    """rois (n,4) xyxy, deltas (n, 8k) -> corner points (n, 8k).  (``max_shape`` and ``wh_ratio_clip``
+    are accepted and ignored, as in the reference.)"""
+    k = deltas.size(1) // 8
+    d = deltas * deltas.new_tensor(stds).repeat(1, k) + deltas.new_tensor(means).repeat(1, k)
+    anchor, size, _, _ = _anchor_and_size(rois, 8)
+    return (size.unsqueeze(1) * d.view(-1, k, 8) + anchor.unsqueeze(1)).view_as(deltas)
+
+
+def hobb2delta(proposals, gt, means=(0, 0, 0, 0, 0), stds=(1, 1, 1, 1, 1)):
+    """proposals (n,4) xyxy, gt (n,5) first point, second point, height -> deltas (n,5); the height is
+    encoded linearly, (h + 1 - ph) / ph."""
+    assert proposals.size(0) == gt.size(0)
+    gt = gt.float()
+    anchor, size, _, ph = _anchor_and_size(proposals.float(), 4)
+    pts = (gt[..., :4] - anchor) / size
+    dh = ((gt[..., 4] + 1.0) - ph) / ph
+    return _normalise(torch.cat([pts, dh.unsqueeze(-1)], dim=-1), means, stds)
+
+
+def delta2hobb(rois, deltas, means=(0, 0, 0, 0, 0), stds=(1, 1, 1, 1, 1), max_shape=None, wh_ratio_clip=16 / 1000):
+    """rois (n,4) xyxy, deltas (n, 5k) -> hobbs (n, 5k); the height delta is clamped to
+    +-|log(wh_ratio_clip)| and decoded as ph * dh + ph (no exponential, no -1: the reference's rule)."""
+    k = deltas.size(1) // 5
+    d = (deltas * deltas.new_tensor(stds).repeat(1, k) + deltas.new_tensor(means).repeat(1, k)).view(-1, k, 5)
+    max_ratio = np.abs(np.log(wh_ratio_clip))
+    anchor, size, _, ph = _anchor_and_size(rois, 4)
+    pts = size.unsqueeze(1) * d[..., :4] + anchor.unsqueeze(1)
+    ph = ph.unsqueeze(1)
+    gh = ph * d[..., 4].clamp(min=-max_ratio, max=max_ratio) + ph
+    return torch.cat([pts, gh.unsqueeze(-1)], dim=-1).view_as(deltas)
+
+
+def pointobb_rescale(pointobbs, scale_factor, reverse_flag=False):
+    """scale (divide if ``reverse_flag``) every coordinate IN PLACE and return the argument (:295-306)."""
+    if not reverse_flag:
+        pointobbs *= scale_factor
+    else:
+        pointobbs /= scale_factor
+    return pointobbs
+
+
+def hobb_rescale(hobbs, scale_factor, reverse_flag=False):
+    """same for hobbs: the two points and the height all scale (:308-318)."""
+    return pointobb_rescale(hobbs, scale_factor, reverse_flag)
+
+
+def pointobb2bbox(pointobb):
+    """[x1, y1, ..., x4, y4] -> enclosing [xmin, ymin, xmax, ymax] (:57-70)."""
+    xs, ys = pointobb[0::2], pointobb[1::2]
+    return [min(xs), min(ys), max(xs), max(ys)]
+
+
+def pointobb_extreme_sort(pointobb):
+    """Rotate the point list so that the TOP point (smallest y; of two equally high ones the left
+    one) comes first -- "top, right, bottom, left" for a clockwise quad (:93-115)."""
+    pts = np.asarray(pointobb, dtype=np.float64).reshape(4, 2)
+    by_y = np.argsort(pts[:, 1])
+    a, b = int(by_y[0]), int(by_y[1])
+    top = a if (pts[a, 1] != pts[b, 1] or pts[a, 0] < pts[b, 0]) else b
+    pointobb = list(pointobb)
+    return pointobb[2 * top:] + pointobb[:2 * top]
+
+
+def _best_rotation(quads):
+    """(n, 8) float64 quads -> each rotated so that its points lie closest (sum of squared distances)
+    to the corners of its own bounding box taken clockwise from the top-left one; ties: fewest shifts."""
+    xs, ys = quads[:, 0::2], quads[:, 1::2]
+    x0, y0, x1, y1 = xs.min(1), ys.min(1), xs.max(1), ys.max(1)
+    ref = np.stack([x0, y0, x1, y0, x1, y1, x0, y1], axis=1)
+    rolled = np.stack([np.roll(quads, s, axis=1) for s in (0, 2, 4, 6)], axis=1)      # (n, 4, 8)
+    dist = ((rolled - ref[:, None, :]) ** 2).sum(axis=2)
+    return rolled[np.arange(len(quads)), dist.argmin(axis=1)]
+
+
+def pointobb_best_point_sort(pointobb):
+    """The point order the flip uses (:118-134): see ``_best_rotation``.  One quad as a list."""
+    return _best_rotation(np.asarray(pointobb, dtype=np.float64).reshape(1, 8))[0].tolist()
+
+
+def pointobb_flip(pointobbs, img_shape):
+    """Mirror (..., 8) corner-point boxes left-right (x -> W - x - 1), restore the clockwise sense
+    (points 2 and 4 trade places) and put every quad into its best-point order (:205-240).  float64 out."""
+    assert pointobbs.shape[-1] % 8 == 0
+    q = np.array(pointobbs, dtype=np.float64, copy=True).reshape(-1, 8)
+    q[:, 0::2] = img_shape[1] - q[:, 0::2] - 1
+    q = q[:, [0, 1, 6, 7, 4, 5, 2, 3]]
+    out = _best_rotation(q)
+    return out[0] if np.ndim(pointobbs) == 1 else out.reshape(np.shape(pointobbs))
+
+
+def pointobb_mapping(pointobbs, img_shape, scale_factor, flip):
+    """original image scale -> an augmentation's scale (:507-512): scale, then flip."""
+    scaled = pointobbs * scale_factor
+    return pointobb_flip(scaled, img_shape) if flip else scaled
+
+
+def pointobb_mapping_back(pointobbs, img_shape, scale_factor, flip):
+    """the inverse (:514-518): un-flip, then divide."""
+    return (pointobb_flip(pointobbs, img_shape) if flip else pointobbs) / scale_factor
+
+
+def hobb2pointobb(hobb):
+    """[x1, y1, x2, y2, h] -> the quad whose side 1-2 is given and whose points 3, 4 lie h away from it,
+    truncated to integers (:137-163)."""
+    x1, y1, x2, y2, h = hobb[:5]
+    turn = np.pi / 2.0 - np.arctan2(y2 - y1, x2 - x1)
+    dx, dy = h * np.cos(turn), h * np.sin(turn)
+    return [int(v) for v in (x1, y1, x2, y2, x2 - dx, y2 + dy, x1 - dx, y1 + dy)]
+
+
+def _no_hobb_flip():
+    raise NotImplementedError('flipping a hobb goes through cv2.minAreaRect in the reference '
+                              '(transforms.py:243-275); OpenCV is not part of this build')
+
+
+def hobb_mapping(hobbs, img_shape, scale_factor, flip):
+    """original image scale -> an augmentation's scale (:602-607); ``flip=True`` is not available."""
+    if flip:
+        _no_hobb_flip()
+    return hobbs * scale_factor
+
+
+def hobb_mapping_back(hobbs, img_shape, scale_factor, flip):
+    """the inverse (:609-613); ``flip=True`` is not available."""
+    if flip:
+        _no_hobb_flip()
+    return hobbs / scale_factor

@@ -200,6 +200,54 @@ def main():
     out['rescale_out'] = transforms.thetaobb_rescale(dec.clone(), 1.7).numpy()
     out['rescale_rev_out'] = transforms.thetaobb_rescale(dec.clone(), 1.7, reverse_flag=True).numpy()
     np.savez_compressed(os.path.join(HERE, 'thetaobb_codec.npz'), **out)
+    # ---- the other two head encodings of core/rbbox/transforms.py: pointobb (8 numbers) and hobb
+    # (two corner points + height), incl. the host-side point-order helpers.  The cv2-based routines
+    # (pointobb2thetaobb, thetaobb2pointobb, hobb_flip) cannot run here (no cv2 in the image).
+    out = {}
+    rng3 = np.random.default_rng(4242)
+    torch.manual_seed(11)
+    Rp = torch.from_numpy(rand_hbb(rng3, 48, 600))
+    gtp = Rp[:, [0, 1, 2, 1, 2, 3, 0, 3]] + torch.randn(48, 8) * 6            # quads near the proposal corners
+    m8, s8 = [0.01, -0.02, 0., 0.03, 0., 0., 0.02, -0.01], [.1, .1, .2, .2, .1, .1, .2, .2]
+    out['p_rois'] = Rp.numpy(); out['p_gt'] = gtp.numpy()
+    out['p_means'] = np.array(m8, np.float32); out['p_stds'] = np.array(s8, np.float32)
+    out['p_enc'] = transforms.pointobb2delta(Rp, gtp, m8, s8).numpy()
+    out['p_enc_default'] = transforms.pointobb2delta(Rp, gtp).numpy()
+    Dp = torch.randn(48, 24) * 0.4
+    out['p_deltas'] = Dp.numpy()
+    out['p_dec'] = transforms.delta2pointobb(Rp, Dp, m8, s8).numpy()
+    out['p_dec_default'] = transforms.delta2pointobb(Rp, Dp[:, :8]).numpy()
+    gth = torch.cat([gtp[:, :4], (torch.rand(48, 1) * 80 + 4)], 1)
+    m5, s5 = [0., 0.01, -0.01, 0., 0.02], [.1, .1, .2, .2, .1]
+    out['h_gt'] = gth.numpy(); out['h_means'] = np.array(m5, np.float32); out['h_stds'] = np.array(s5, np.float32)
+    out['h_enc'] = transforms.hobb2delta(Rp, gth, m5, s5).numpy()
+    Dh = torch.randn(48, 15) * 0.6
+    Dh[::7, 4::5] = 9.0                                                            # beyond the log-ratio clamp
+    out['h_deltas'] = Dh.numpy()
+    out['h_dec'] = transforms.delta2hobb(Rp, Dh, m5, s5).numpy()
+    out['h_dec_default'] = transforms.delta2hobb(Rp, Dh[:, :5]).numpy()
+    out['p_rescale'] = transforms.pointobb_rescale(gtp.clone(), 1.3).numpy()
+    out['p_rescale_rev'] = transforms.pointobb_rescale(gtp.clone(), 1.3, reverse_flag=True).numpy()
+    out['h_rescale'] = transforms.hobb_rescale(gth.clone(), 0.8).numpy()
+    out['h_rescale_rev'] = transforms.hobb_rescale(gth.clone(), 0.8, reverse_flag=True).numpy()
+    quads = gtp.numpy().astype(np.float64)
+    quads[5] = [10., 20., 50., 20., 50., 60., 10., 60.]                           # axis-aligned: ties in both sort rules
+    quads[6] = [50., 20., 50., 60., 10., 60., 10., 20.]
+    out['q_in'] = quads
+    out['q_bbox'] = np.array([transforms.pointobb2bbox(q.tolist()) for q in quads])
+    out['q_extreme'] = np.array([transforms.pointobb_extreme_sort(q.tolist()) for q in quads])
+    out['q_best'] = np.array([transforms.pointobb_best_point_sort(q.tolist()) for q in quads])
+    out['q_flip'] = transforms.pointobb_flip(quads, (600, 800, 3))
+    out['q_flip_one'] = transforms.pointobb_flip(quads[3], (600, 800, 3))
+    out['q_map'] = transforms.pointobb_mapping(quads, (900, 1200, 3), 1.5, True)
+    out['q_map_noflip'] = transforms.pointobb_mapping(quads, (900, 1200, 3), 1.5, False)
+    out['q_mapback'] = transforms.pointobb_mapping_back(quads, (900, 1200, 3), 1.5, True)
+    hb = np.concatenate([quads[:, :4], np.abs(rng3.normal(40, 15, (48, 1)))], 1)
+    out['hq_in'] = hb
+    out['hq_points'] = np.array([transforms.hobb2pointobb(h.tolist()) for h in hb])
+    out['hq_map_noflip'] = transforms.hobb_mapping(hb, (900, 1200, 3), 1.5, False)
+    out['hq_mapback_noflip'] = transforms.hobb_mapping_back(hb, (900, 1200, 3), 1.5, False)
+    np.savez_compressed(os.path.join(HERE, 'obb_codecs.npz'), **out)
     # ---- MaxIoUAssigner (mmdet/core/bbox/assigners/max_iou_assigner.py:8-202) -------
     out = {}
     pk = types.ModuleType('refbbox'); pk.__path__ = []; sys.modules['refbbox'] = pk

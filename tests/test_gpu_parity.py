@@ -1228,3 +1228,54 @@ def test_rnms_routes_agree_at_sizes_the_oracle_cannot_reach(n, canvas, ng, nms_r
             ref = keep
             assert 0.2 * n < keep.numel() < n
         assert torch.equal(keep, ref), route
+
+
+def test_get_det_rbboxes_pointobb_and_hobb_encodings():
+    """RBBoxHead's other two encodings (rbbox_head.py:264-269): 'pointobb' decodes to corner points and
+    gets the true polygon NMS per class (or the keep re-use), 'hobb' the keep re-use only."""
+    from aidet_amd.post_processing import get_det_rbboxes, multiclass_nms_with_index
+    from aidet_amd.rbbox_transforms import delta2hobb, delta2pointobb
+    rng = np.random.default_rng(8)
+    n, ncls = 260, 5
+    x1 = rng.uniform(0, 300, n); y1 = rng.uniform(0, 300, n)
+    rois = np.stack([np.zeros(n), x1, y1, x1 + rng.uniform(12, 80, n), y1 + rng.uniform(12, 80, n)], 1).astype(np.float32)
+    cls_score = (rng.standard_normal((n, ncls)) * 2).astype(np.float32)
+    m8, s8 = (0.,) * 8, (.1, .1, .2, .2, .1, .1, .2, .2)
+    pred8 = (rng.standard_normal((n, ncls * 8)) * 0.3).astype(np.float32)
+    cfg = dict(score_thr=0.05, max_per_img=80, polygon_nms_iou_thr=0.3, encode='pointobb')
+    det, lab = get_det_rbboxes(t(rois), t(cls_score), t(pred8), (512, 512, 3), 1.0, cfg=cfg, target_means=m8, target_stds=s8)
+    det, lab = det.cpu().numpy(), lab.cpu().numpy()
+    assert det.shape[1] == 9 and len(det) == len(lab) <= 80
+    # oracle: decode on the CPU, per-class polygon NMS, best 80
+    sc = torch.softmax(torch.from_numpy(cls_score), 1).numpy()
+    quads = delta2pointobb(torch.from_numpy(rois[:, 1:]), torch.from_numpy(pred8), m8, s8).numpy()
+    rows, labs = [], []
+    for c in range(1, ncls):
+        m = sc[:, c] > 0.05
+        d = np.concatenate([quads[m, c * 8:(c + 1) * 8], sc[m, c:c + 1]], 1).astype(np.float32)
+        k = oracle.poly_nms(d, 0.3)
+        rows.append(d[k]); labs.append(np.full(len(k), c - 1))
+    rows, labs = np.concatenate(rows), np.concatenate(labs)
+    top = np.argsort(-rows[:, 8], kind='stable')[:80]
+    assert np.abs(det[:, 8] - rows[top, 8]).max() <= 1e-6 and np.array_equal(lab, labs[top])
+    assert np.abs(det[:, :8] - rows[top, :8]).max() <= 1e-3
+    # keep re-use with both encodings: the rows the horizontal NMS kept, in its order
+    bb = np.tile(rois[:, 1:], (1, ncls)).astype(np.float32)
+    nms_cfg = dict(type='nms', iou_thr=0.5)
+    for enc, pred, means, stds, dim, dec in (('pointobb', pred8, m8, s8, 8, delta2pointobb),
+                                             ('hobb', (rng.standard_normal((n, ncls * 5)) * 0.3).astype(np.float32),
+                                              (0.,) * 5, (.1, .1, .2, .2, .1), 5, delta2hobb)):
+        _, hl, ci, ki = multiclass_nms_with_index(t(bb), t(cls_score).softmax(1), 0.05, nms_cfg, 80)
+        d2, l2 = get_det_rbboxes(t(rois), t(cls_score), t(pred), (512, 512, 3), 2.0, rescale=True,
+                                 cfg=dict(cfg, encode=enc), target_means=means, target_stds=stds,
+                                 bbox_cls_inds=ci, bbox_keep_inds=ki, rotated_nms=False)
+        assert d2.shape[1] == dim + 1 and torch.equal(l2, hl)
+        full = dec(torch.from_numpy(rois[:, 1:]), torch.from_numpy(pred), means, stds).numpy() / 2.0
+        got = d2.cpu().numpy()
+        # every returned box is the decoded (and rescaled) box of its class for some row with that score
+        for r, c in zip(got, l2.cpu().numpy()):
+            cand = full[:, (c + 1) * dim:(c + 2) * dim]
+            assert np.abs(cand - r[:dim]).max(1).min() <= 1e-3
+    with pytest.raises(ValueError):
+        get_det_rbboxes(t(rois), t(cls_score), t(pred), (512, 512, 3), 1.0, cfg=dict(cfg, encode='hobb'),
+                        target_means=(0.,) * 5, target_stds=(1.,) * 5)

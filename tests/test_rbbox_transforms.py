@@ -1,6 +1,7 @@
 """CPU tests: theta-OBB codec vs values captured from the reference
 (tests/golden/thetaobb_codec.npz, anchor A5) and host-side RoI-layer mappings."""
 import numpy as np
+import pytest
 import torch
 
 from aidet_amd import rbbox_transforms as T
@@ -80,3 +81,48 @@ def test_assign_wrt_overlaps_matches_reference(golden):
     assert r.gt_inds.tolist() == [0, 0, 0] and r.labels.tolist() == [0, 0, 0]
     r = assign_wrt_overlaps(torch.zeros((2, 0)))
     assert r.gt_inds.numel() == 0
+
+
+def test_pointobb_and_hobb_formats_reproduce_reference(golden):
+    """The other two head encodings of core/rbbox/transforms.py and their host-side helpers, against
+    values captured from the reference (tests/golden/obb_codecs.npz)."""
+    from aidet_amd import rbbox_transforms as T
+    g = golden('obb_codecs.npz')
+    R, gt8, D8 = (torch.from_numpy(g[k]) for k in ('p_rois', 'p_gt', 'p_deltas'))
+    m8, s8 = g['p_means'].tolist(), g['p_stds'].tolist()
+    assert np.array_equal(T.pointobb2delta(R, gt8, m8, s8).numpy(), g['p_enc'])
+    assert np.array_equal(T.pointobb2delta(R, gt8).numpy(), g['p_enc_default'])
+    assert np.array_equal(T.delta2pointobb(R, D8, m8, s8).numpy(), g['p_dec'])
+    assert np.array_equal(T.delta2pointobb(R, D8[:, :8]).numpy(), g['p_dec_default'])
+    gt5, D5 = torch.from_numpy(g['h_gt']), torch.from_numpy(g['h_deltas'])
+    m5, s5 = g['h_means'].tolist(), g['h_stds'].tolist()
+    assert np.array_equal(T.hobb2delta(R, gt5, m5, s5).numpy(), g['h_enc'])
+    assert np.array_equal(T.delta2hobb(R, D5, m5, s5).numpy(), g['h_dec'])
+    assert np.array_equal(T.delta2hobb(R, D5[:, :5]).numpy(), g['h_dec_default'])
+    # round trip: decode(encode(gt)) == gt up to rounding
+    back = T.delta2pointobb(R, T.pointobb2delta(R, gt8, m8, s8), m8, s8)
+    assert float((back - gt8).abs().max()) < 1e-3
+    # rescale works in place and returns its argument
+    x = gt8.clone(); y = T.pointobb_rescale(x, 1.3)
+    assert y is x and np.array_equal(x.numpy(), g['p_rescale'])
+    assert np.array_equal(T.pointobb_rescale(gt8.clone(), 1.3, reverse_flag=True).numpy(), g['p_rescale_rev'])
+    assert np.array_equal(T.hobb_rescale(gt5.clone(), 0.8).numpy(), g['h_rescale'])
+    assert np.array_equal(T.hobb_rescale(gt5.clone(), 0.8, reverse_flag=True).numpy(), g['h_rescale_rev'])
+    # point-order helpers, flip and mappings (host side, numpy)
+    q = g['q_in']
+    assert np.array_equal(np.array([T.pointobb2bbox(r.tolist()) for r in q]), g['q_bbox'])
+    assert np.array_equal(np.array([T.pointobb_extreme_sort(r.tolist()) for r in q]), g['q_extreme'])
+    assert np.array_equal(np.array([T.pointobb_best_point_sort(r.tolist()) for r in q]), g['q_best'])
+    assert np.array_equal(T.pointobb_flip(q, (600, 800, 3)), g['q_flip'])
+    one = T.pointobb_flip(q[3], (600, 800, 3))
+    assert one.shape == (8,) and np.array_equal(one, g['q_flip_one'])
+    assert np.array_equal(T.pointobb_mapping(q, (900, 1200, 3), 1.5, True), g['q_map'])
+    assert np.array_equal(T.pointobb_mapping(q, (900, 1200, 3), 1.5, False), g['q_map_noflip'])
+    assert np.array_equal(T.pointobb_mapping_back(q, (900, 1200, 3), 1.5, True), g['q_mapback'])
+    assert np.array_equal(q, g['q_in'])                       # inputs untouched
+    hb = g['hq_in']
+    assert np.array_equal(np.array([T.hobb2pointobb(h.tolist()) for h in hb]), g['hq_points'])
+    assert np.array_equal(T.hobb_mapping(hb, (900, 1200, 3), 1.5, False), g['hq_map_noflip'])
+    assert np.array_equal(T.hobb_mapping_back(hb, (900, 1200, 3), 1.5, False), g['hq_mapback_noflip'])
+    with pytest.raises(NotImplementedError):
+        T.hobb_mapping(hb, (900, 1200, 3), 1.5, True)
