@@ -11,6 +11,7 @@ operator surface:
   roi_layers.RoIAlign / SingleRoIExtractor           <-> roi_align.py:79-152, roi_extractors/single_level.py:11-107
   post_processing.*                                  <-> core/post_processing/bbox_nms.py, rbbox_nms.py
   merge_augs.merge_aug_{proposals,bboxes,scores}     <-> core/post_processing/merge_augs.py:8-78 (test-time augmentation)
+  rbbox_transforms.*, rbbox_target.rbbox_target      <-> core/rbbox/transforms.py, core/rbbox/rbbox_target.py
   rpn.rpn_proposals, anchors, bbox_transforms        <-> anchor_heads/rpn_head.py:55-104, core/anchor, core/bbox/transforms.py
   dota_merge / dota_io                               <-> apis/test.py:116-146, datasets/dota.py:278-336
   models.ThetaOBBRCNN                                <-> detectors/rbbox_cnn.py:214-253 (test path, config 4)

@@ -247,6 +247,41 @@ def main():
     out['hq_points'] = np.array([transforms.hobb2pointobb(h.tolist()) for h in hb])
     out['hq_map_noflip'] = transforms.hobb_mapping(hb, (900, 1200, 3), 1.5, False)
     out['hq_mapback_noflip'] = transforms.hobb_mapping_back(hb, (900, 1200, 3), 1.5, False)
+    # ---- rbbox_target (core/rbbox/rbbox_target.py): training targets of the rbbox head, all encodings
+    for name in ('mmdet.core', 'mmdet.core.rbbox', 'mmdet.core.utils'):
+        if name not in sys.modules:
+            m = types.ModuleType(name); m.__path__ = []; sys.modules[name] = m
+    sys.modules['mmdet.core.rbbox.transforms'] = transforms
+    sys.modules['mmdet.core.utils'].multi_apply = lambda fn, *args, **kw: tuple(map(list, zip(*map(lambda *a: fn(*a, **kw), *args))))
+    rt = _load('mmdet.core.rbbox.rbbox_target', REF + '/mmdet/core/rbbox/rbbox_target.py')
+
+    class _Enc(object):
+        def __init__(self, e):
+            self.encode = e
+    pos = [Rp[:14], Rp[14:14], Rp[20:31]]                    # image 1 has no positives
+    neg = [Rp[31:40], Rp[40:44], Rp[44:44]]                  # image 2 has no negatives
+    inds = [torch.from_numpy(rng3.integers(0, 6, 14)), torch.zeros(0, dtype=torch.long), torch.from_numpy(rng3.integers(0, 3, 11))]
+    glab = [torch.from_numpy(rng3.integers(1, 16, 6)), torch.from_numpy(rng3.integers(1, 16, 2)), torch.from_numpy(rng3.integers(1, 16, 3))]
+    for k in range(3):
+        out['t_pos_%d' % k] = pos[k].numpy(); out['t_neg_%d' % k] = neg[k].numpy()
+        out['t_inds_%d' % k] = inds[k].numpy(); out['t_labels_%d' % k] = glab[k].numpy()
+    gts = {'thetaobb': [torch.cat([gtp[:6, :2], gtp[:6, 2:4].abs() + 5, torch.rand(6, 1) - 1.2], 1),
+                        torch.cat([gtp[6:8, :2], gtp[6:8, 2:4].abs() + 5, torch.rand(2, 1) - 1.2], 1),
+                        torch.cat([gtp[8:11, :2], gtp[8:11, 2:4].abs() + 5, torch.rand(3, 1) - 1.2], 1)],
+           'pointobb': [gtp[:6], gtp[6:8], gtp[8:11]],
+           'hobb': [gth[:6], gth[6:8], gth[8:11]]}
+    cfgt = {'thetaobb': ([0.] * 5, [.1, .1, .2, .2, .1], 5), 'pointobb': (m8, s8, 8), 'hobb': (m5, s5, 5)}
+    import contextlib, io
+    for enc, gl in gts.items():
+        mm, ss, dim = cfgt[enc]
+        for k in range(3):
+            out['t_gt_%s_%d' % (enc, k)] = gl[k].numpy()
+        with contextlib.redirect_stdout(io.StringIO()):      # ("num_pos = 0" is printed for image 1)
+            res = rt.rbbox_target(pos, neg, inds, gl, glab, _Enc(enc), mm, ss, out_dim_reg=dim)
+            per = rt.rbbox_target(pos, neg, inds, gl, glab, _Enc(enc), mm, ss, out_dim_reg=dim, concat=False)
+        for nm, v in zip(('labels', 'label_weights', 'targets', 'weights'), res):
+            out['t_%s_%s' % (enc, nm)] = v.numpy()
+        out['t_%s_split' % enc] = np.array([len(x) for x in per[0]])
     np.savez_compressed(os.path.join(HERE, 'obb_codecs.npz'), **out)
     # ---- MaxIoUAssigner (mmdet/core/bbox/assigners/max_iou_assigner.py:8-202) -------
     out = {}

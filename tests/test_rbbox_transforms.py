@@ -126,3 +126,22 @@ def test_pointobb_and_hobb_formats_reproduce_reference(golden):
     assert np.array_equal(T.hobb_mapping_back(hb, (900, 1200, 3), 1.5, False), g['hq_mapback_noflip'])
     with pytest.raises(NotImplementedError):
         T.hobb_mapping(hb, (900, 1200, 3), 1.5, True)
+
+
+@pytest.mark.parametrize('enc,dim', [('thetaobb', 5), ('pointobb', 8), ('hobb', 5)])
+def test_rbbox_target_reproduces_reference(golden, enc, dim):
+    """core/rbbox/rbbox_target.py on three images (one without positives, one without negatives)."""
+    from aidet_amd.rbbox_target import rbbox_target
+    g = golden('obb_codecs.npz')
+    ld = lambda k: torch.from_numpy(g[k])
+    pos, neg = [ld('t_pos_%d' % k) for k in range(3)], [ld('t_neg_%d' % k) for k in range(3)]
+    inds, glab = [ld('t_inds_%d' % k) for k in range(3)], [ld('t_labels_%d' % k) for k in range(3)]
+    gts = [ld('t_gt_%s_%d' % (enc, k)) for k in range(3)]
+    means, stds = {'thetaobb': ([0.] * 5, [.1, .1, .2, .2, .1]), 'pointobb': (g['p_means'].tolist(), g['p_stds'].tolist()),
+                   'hobb': (g['h_means'].tolist(), g['h_stds'].tolist())}[enc]
+    res = rbbox_target(pos, neg, inds, gts, glab, dict(encode=enc), means, stds, out_dim_reg=dim)
+    for name, got in zip(('labels', 'label_weights', 'targets', 'weights'), res):
+        want = g['t_%s_%s' % (enc, name)]
+        assert got.numpy().dtype == want.dtype and np.array_equal(got.numpy(), want), name
+    per = rbbox_target(pos, neg, inds, gts, glab, dict(encode=enc), means, stds, out_dim_reg=dim, concat=False)
+    assert [len(x) for x in per[0]] == g['t_%s_split' % enc].tolist()
