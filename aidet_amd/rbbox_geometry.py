@@ -8,6 +8,48 @@ import torch
 from . import _lib
 
 
+def _hbb_overlaps_torch(b1, b2, mode, is_aligned):
+    """geometry.py:57-86 as differentiable tensor expressions: only used for the BACKWARD of
+    ``bbox_overlaps`` (the forward values come from the kernel)."""
+    area1 = (b1[:, 2] - b1[:, 0] + 1) * (b1[:, 3] - b1[:, 1] + 1)
+    area2 = (b2[:, 2] - b2[:, 0] + 1) * (b2[:, 3] - b2[:, 1] + 1)
+    if is_aligned:
+        lt, rb = torch.max(b1[:, :2], b2[:, :2]), torch.min(b1[:, 2:], b2[:, 2:])
+    else:
+        lt, rb = torch.max(b1[:, None, :2], b2[:, :2]), torch.min(b1[:, None, 2:], b2[:, 2:])
+        area1 = area1[:, None]
+    wh = (rb - lt + 1).clamp(min=0)
+    overlap = wh[..., 0] * wh[..., 1]
+    return overlap / (area1 + area2 - overlap) if mode == 'iou' else overlap / area1
+
+
+class _HbbOverlapsGrad(torch.autograd.Function):
+    """``bbox_overlaps`` with a gradient, so that it also serves the reference's IoU loss
+    (models/losses/iou_loss.py:25 calls ``bbox_overlaps(pred, target, is_aligned=True)`` and
+    differentiates through it).  Forward: the HIP kernel.  Backward: autograd of the reference's tensor
+    expressions, re-evaluated on the saved boxes."""
+
+    @staticmethod
+    def forward(ctx, b1, b2, mode, is_aligned):
+        ctx.save_for_backward(b1, b2)
+        ctx.args = (mode, is_aligned)
+        with torch.no_grad():
+            return _overlaps(b1, b2, mode, is_aligned, 4, _lib.KIND_HBB)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        b1, b2 = ctx.saved_tensors
+        mode, is_aligned = ctx.args
+        with torch.enable_grad():
+            x1 = b1.detach().float().requires_grad_(True)
+            x2 = b2.detach().float().requires_grad_(True)
+            out = _hbb_overlaps_torch(x1, x2, mode, is_aligned)
+            g1, g2 = torch.autograd.grad(out, [x1, x2], grad_out.reshape(out.shape).to(out.dtype), allow_unused=True)
+        need1, need2 = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        return (g1.to(b1.dtype) if need1 and g1 is not None else None,
+                g2.to(b2.dtype) if need2 and g2 is not None else None, None, None)
+
+
 def _overlaps(b1, b2, mode, is_aligned, cols, kind):
     assert mode in ['iou', 'iof']
     if not isinstance(b1, torch.Tensor) or not isinstance(b2, torch.Tensor):
@@ -25,6 +67,11 @@ def _overlaps(b1, b2, mode, is_aligned, cols, kind):
     # are uninitialised in the reference, zeros here.
     if rows * n == 0:
         return b1.new_zeros((rows, 1) if is_aligned else (rows, n))
+    if torch.is_grad_enabled() and (b1.requires_grad or b2.requires_grad):
+        if kind != _lib.KIND_HBB:
+            raise RuntimeError('rbbox_overlaps / pointobb_overlaps have no gradient: detach the boxes '
+                               '(target assignment) or use bbox_overlaps for a horizontal IoU loss')
+        return _HbbOverlapsGrad.apply(b1, b2, mode, is_aligned)
     a = _lib.to_device_f32(b1)
     b = _lib.to_device_f32(b2).to(a.device)
     out = torch.empty((rows,) if is_aligned else (rows, n), dtype=torch.float32, device=a.device)

@@ -1279,3 +1279,33 @@ def test_get_det_rbboxes_pointobb_and_hobb_encodings():
     with pytest.raises(ValueError):
         get_det_rbboxes(t(rois), t(cls_score), t(pred), (512, 512, 3), 1.0, cfg=dict(cfg, encode='hobb'),
                         target_means=(0.,) * 5, target_stds=(1.,) * 5)
+
+
+def test_bbox_overlaps_is_differentiable_like_the_reference_expression():
+    """iou_loss.py:25 differentiates through bbox_overlaps(pred, target, is_aligned=True): values from the
+    kernel, gradients equal to autograd of geometry.py's tensor expressions; the rotated ops refuse."""
+    from aidet_amd import bbox_overlaps, rbbox_overlaps
+    from aidet_amd.rbbox_geometry import _hbb_overlaps_torch
+    rng = np.random.default_rng(4)
+    x1, y1 = rng.uniform(0, 200, 300), rng.uniform(0, 200, 300)
+    a = np.stack([x1, y1, x1 + rng.uniform(5, 80, 300), y1 + rng.uniform(5, 80, 300)], 1).astype(np.float32)
+    b = (a + rng.normal(0, 6, a.shape)).astype(np.float32)
+    for aligned, mode in ((True, 'iou'), (False, 'iou'), (True, 'iof'), (False, 'iof')):
+        p, q = t(a).requires_grad_(True), t(b[:64] if not aligned else b).requires_grad_(True)
+        out = bbox_overlaps(p, q, mode, aligned)
+        loss = (1 - out).pow(2).sum()
+        loss.backward()
+        pr, qr = t(a).requires_grad_(True), t(b[:64] if not aligned else b).requires_grad_(True)
+        ref = _hbb_overlaps_torch(pr, qr, mode, aligned)
+        (1 - ref).pow(2).sum().backward()
+        assert float((out.detach() - ref.detach()).abs().max()) <= 1e-6
+        assert float((p.grad - pr.grad).abs().max()) <= 1e-5 and float((q.grad - qr.grad).abs().max()) <= 1e-5
+        assert float(p.grad.abs().sum()) > 0
+    # only one side needs a gradient (the loss's target is detached)
+    p = t(a).requires_grad_(True)
+    bbox_overlaps(p, t(b), 'iou', True).sum().backward()
+    assert p.grad is not None
+    with pytest.raises(RuntimeError):
+        rbbox_overlaps(torch.rand(4, 5, device='cuda', requires_grad=True), torch.rand(4, 5, device='cuda'))
+    with torch.no_grad():      # target assignment: fine without a graph
+        assert rbbox_overlaps(torch.rand(4, 5, device='cuda', requires_grad=True), torch.rand(4, 5, device='cuda')).shape == (4, 4)
