@@ -23,13 +23,21 @@ from .nms_wrapper import nms, poly_nms, rnms, soft_nms, thetaobb_nms
 from .post_processing import (get_det_rbboxes, multiclass_nms, multiclass_nms_with_index, multiclass_rnms,
                               thetaobb_nms_by_bbox_nms)
 from .rbbox_geometry import bbox_overlaps, rbbox_overlaps, thetaobb2pointobb
-from .roi_layers import RoIAlign, RotatedSingleRoIExtractor, SingleRoIExtractor
+from .roi_layers import RoIAlign, RotatedSingleRoIExtractor, SingleRoIExtractor, roi_align
 from .rroi_align import RRoIAlign, rroi_align
 
 __all__ = [
     'rnms', 'poly_nms', 'thetaobb_nms', 'nms', 'soft_nms', 'rbbox_overlaps', 'bbox_overlaps', 'thetaobb2pointobb',
-    'RRoIAlign', 'rroi_align', 'RoIAlign', 'SingleRoIExtractor', 'RotatedSingleRoIExtractor',
+    'RRoIAlign', 'rroi_align', 'RoIAlign', 'roi_align', 'SingleRoIExtractor', 'RotatedSingleRoIExtractor',
     'multiclass_nms', 'multiclass_rnms', 'multiclass_nms_with_index', 'thetaobb_nms_by_bbox_nms', 'get_det_rbboxes',
     'merge_aug_proposals', 'merge_aug_bboxes', 'merge_aug_scores'
 ]
 __version__ = '0.2.0'
+
+
+def get_compiler_version():
+    """Compiler that built libobbops.so (counterpart of mmdet/ops/utils: ``get_compiler_version`` /
+    ``get_compiling_cuda_version``, used by the reference's collect_env)."""
+    from . import _lib
+    return _lib.lib().obb_build_info().decode()
+
