@@ -218,9 +218,10 @@ def test_dota_io_names_rows_and_files(tmp_path):
 
 
 # ---- configs[4] as one function: per-patch NMS -> image coords -> gather -> merged NMS ---------
-def _tiled_inputs(rank, world):
+def _tiled_inputs(rank, world, images=2, image_size=2048, objects=1500):
     import workloads
-    scene = workloads.tiled_scene(images=2, image_size=2048, objects_per_image=1500, num_classes=NUM_CLASSES, seed=5)
+    scene = workloads.tiled_scene(images=images, image_size=image_size, objects_per_image=objects,
+                                  num_classes=NUM_CLASSES, seed=5)
     P = len(scene['patch_name'])
     idx = np.nonzero(np.isin(scene['patch'], np.asarray(dota_merge.shard_patches(P, rank, world))))[0]
     f = lambda a: torch.from_numpy(a)
@@ -228,19 +229,19 @@ def _tiled_inputs(rank, world):
             f(scene['patch_xy']), f(scene['patch_image'])), scene
 
 
-def _tiled_worker(rank, world, port, layout, out):
+def _tiled_worker(rank, world, port, layout, out, scene_kw=None):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
-        args, _ = _tiled_inputs(rank, world)
+        args, _ = _tiled_inputs(rank, world, **(scene_kw or {}))
         kept, keep, allrows = dota_merge.tiled_inference_merge(*args, NUM_CLASSES, 0.5, 0.3, CLASS_THRS,
                                                                layout=layout, nms_fn=oracle_nms)
         out[rank] = (kept.numpy(), keep.numpy(), allrows.numpy())
         if rank == 0:
             # what bench.py's cross-check does: the whole job on rank 0 ALONE while a process group
             # exists (group=LOCAL: no collective is entered, the other rank is not waiting in one)
-            solo, _ = _tiled_inputs(0, 1)
+            solo, _ = _tiled_inputs(0, 1, **(scene_kw or {}))
             k1, _, _ = dota_merge.tiled_inference_merge(*solo, NUM_CLASSES, 0.5, 0.3, CLASS_THRS, layout=layout,
                                                         nms_fn=oracle_nms, group=dota_merge.LOCAL)
             out['solo'] = k1.numpy()
@@ -268,6 +269,23 @@ def test_tiled_inference_merge_two_ranks_equal_one(layout):
     assert len(allrows) <= n and 0.3 * n < len(keep) < 0.95 * len(allrows)
     # image coordinates: every kept centre lies inside its image
     assert float(kept[:, 0].min()) > -5 and float(kept[:, 0].max()) < 2048 + 5
+
+
+@pytest.mark.parametrize('layout', ['replicated', 'sharded'])
+def test_tiled_inference_merge_with_ranks_that_have_nothing(layout):
+    """One image of one patch on three ranks: ranks 1 and 2 contribute no detections at all (empty local
+    NMS, zero-row gather contributions, no groups of their own in the sharded merge)."""
+    world, kw = 3, dict(images=1, image_size=1024, objects=400)
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_tiled_worker, args=(world, _free_port(), layout, out, kw), nprocs=world, join=True)
+    args, scene = _tiled_inputs(0, 1, **kw)
+    assert len(scene['patch_name']) == 1
+    kept, keep, allrows = dota_merge.tiled_inference_merge(*args, NUM_CLASSES, 0.5, 0.3, CLASS_THRS, nms_fn=oracle_nms)
+    for r in range(world):
+        assert np.array_equal(out[r][2], allrows.numpy())
+        assert np.array_equal(out[r][1], keep.numpy()) and np.array_equal(out[r][0], kept.numpy())
+    assert 0 < len(keep) <= len(allrows)
 
 
 def test_bench_refuses_a_world_size_that_contradicts_gpus():
