@@ -354,6 +354,10 @@ __global__ __launch_bounds__(256) void nms_quant_kernel(const float4 *__restrict
   __shared__ float sb[4];
   __shared__ float win[4];     // window of the robust frame: x lo, x hi, y lo, y hi
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  // this thread's first box is requested now: its memory round trip overlaps the reduction below
+  const int64_t b_first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  float4 v_first = make_float4(1.0f, -1.0f, 1.0f, -1.0f);
+  if (b_first < n) v_first = iv[b_first];
   // (every block repeats this reduction of <= 1024 partials: cheaper than one more launch)
   uint4 a = make_uint4(0u, 0u, 0u, 0u);
   for (int k = threadIdx.x; k < nparts; k += 256) {
@@ -492,7 +496,7 @@ __global__ __launch_bounds__(256) void nms_quant_kernel(const float4 *__restrict
   };
   for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n;
        b += (int64_t)gridDim.x * blockDim.x) {
-    const float4 v = iv[b];
+    const float4 v = (b == b_first) ? v_first : iv[b];
     uint2 o = make_uint2(kSentLo, kSentHi);
     uint32_t mk = (1u << (2 * cell_hbits)) - 1u;  // isolated boxes go to the last cell
     if (v.x <= v.y) {
@@ -1336,16 +1340,23 @@ __global__ __launch_bounds__(256) void nms_clip_kernel(const uint2 *__restrict__
   const uint2 *cand = cands + (size_t)shard * segcap;
   uint2 *eseg = edges + (size_t)shard * segcap;                       // this shard's edge segment
   unsigned long long *ecnt = ccnts + (size_t)(kShards + shard) * kCandStride;
+  // the first candidate of this lane is loaded together with the shard's count (one memory round
+  // trip instead of two on a latency-bound kernel; the slot exists whatever the count says)
+  const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+  const unsigned long long first = (unsigned long long)blockIdx.x * blockDim.x + (threadIdx.x & ~63);
+  uint2 pr = make_uint2(0u, 0u);
+  if (first + lane < segcap) pr = cand[first + lane];
   unsigned long long total = ccnts[(size_t)shard * kCandStride];
   if (total > segcap) total = segcap;  // overflow is reported by the host
   // whole waves iterate together so that the ballot below sees all 64 lanes
-  const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
-  for (unsigned long long base = (unsigned long long)blockIdx.x * blockDim.x + (threadIdx.x & ~63);
-       base < total; base += stride) {
+  for (unsigned long long base = first; base < total; base += stride) {
     const unsigned long long e = base + lane;
     bool hit = false;
     uint32_t src = 0, dst = 0;
-    if (e < total) hit = clip_pair(rec, cand[e], flags, src, dst);
+    if (e < total) {
+      if (base != first) pr = cand[e];
+      hit = clip_pair(rec, pr, flags, src, dst);
+    }
     push_edges(hit, src, dst, eseg, segcap, ecnt, cnt, lane);
   }
 }
