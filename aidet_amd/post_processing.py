@@ -45,7 +45,9 @@ def _top_by_score(dets, labels, max_num):
 
 
 def _multiclass(multi_boxes, multi_scores, score_thr, nms_cfg, max_num, score_factors, d,
-                default_op, offset_trick):
+                default_op, offset_trick, report=None):
+    """``report`` = (multi_boxes_out, d_out): the NMS decides on ``multi_boxes`` but the returned rows are the
+    boxes of the same (row, class) in ``multi_boxes_out`` (another encoding of the same detections)."""
     num_fg = multi_scores.size(1) - 1
     boxes = _per_class_boxes(multi_boxes, num_fg, d)
     scores = multi_scores[:, 1:]
@@ -53,9 +55,10 @@ def _multiclass(multi_boxes, multi_scores, score_thr, nms_cfg, max_num, score_fa
     if score_factors is not None:
         scores = scores * score_factors[:, None]
     rows, labels = valid.nonzero(as_tuple=True)          # row-major, like bbox_nms.py:43
-    boxes, scores = boxes[rows, labels], scores[rows, labels]
+    shown = boxes if report is None else _per_class_boxes(report[0], num_fg, report[1])
+    boxes, scores, shown = boxes[rows, labels], scores[rows, labels], shown[rows, labels]
     if boxes.numel() == 0:
-        return multi_boxes.new_zeros((0, d + 1)), multi_boxes.new_zeros((0, ), dtype=torch.long)
+        return multi_boxes.new_zeros((0, shown.size(-1) + 1)), multi_boxes.new_zeros((0, ), dtype=torch.long)
     nms_op, cfg = _resolve_op(nms_cfg, default_op)
     if offset_trick:
         # bbox_nms.py:56-59 verbatim in effect: the classes are pushed apart by
@@ -65,7 +68,7 @@ def _multiclass(multi_boxes, multi_scores, score_thr, nms_cfg, max_num, score_fa
     else:
         # same per-class NMS without moving (and thereby rounding) a coordinate
         dets, keep = nms_op(torch.cat([boxes, scores[:, None]], 1), groups=labels, **cfg)
-    out = torch.cat([boxes[keep], dets[:, -1:]], 1)      # dets[:, -1]: soft-NMS rescored
+    out = torch.cat([shown[keep], dets[:, -1:]], 1)      # dets[:, -1]: soft-NMS rescored
     labels = labels[keep]
     if max_num > 0 or offset_trick:   # (the new rotated op does not inherit the max_num=-1 quirk)
         out, labels = _top_by_score(out, labels, max_num)
@@ -95,7 +98,7 @@ def multiclass_nms(multi_bboxes, multi_scores, score_thr, nms_cfg, max_num=-1, s
 
 
 def multiclass_rnms(multi_rbboxes, multi_scores, score_thr, nms_cfg, max_num=-1,
-                    score_factors=None, out_dim_reg=5):
+                    score_factors=None, out_dim_reg=5, report=None):
     """Rotated NMS for multi-class theta-OBBs: the contract of ``multiclass_nms``
     (bbox_nms.py:6-76) with ``out_dim_reg`` numbers per box and ``type='rnms'``.
 
@@ -103,7 +106,7 @@ def multiclass_rnms(multi_rbboxes, multi_scores, score_thr, nms_cfg, max_num=-1,
         tuple: (rbboxes (k, out_dim_reg + 1), labels (k,)); labels are 0-based.
     """
     return _multiclass(multi_rbboxes, multi_scores, score_thr, nms_cfg, max_num, score_factors,
-                       out_dim_reg, 'rnms', offset_trick=False)
+                       out_dim_reg, 'rnms', offset_trick=False, report=report)
 
 
 def _class_major(masks):
@@ -216,8 +219,8 @@ def get_det_rbboxes(rois, cls_score, rbbox_pred, img_shape, scale_factor, rescal
     max_per_img)``.  ``rotated_nms=False`` reproduces the reference's behaviour, i.e.
     re-applies the horizontal keep indices (:287-293) -- then ``bbox_cls_inds`` /
     ``bbox_keep_inds`` from ``multiclass_nms_with_index`` are required.  The true NMS of the
-    'pointobb' encoding is ``poly_nms`` on the decoded corner points; 'hobb' boxes have no polygon
-    form here and only support the keep re-use.
+    'pointobb' encoding is ``poly_nms`` on the decoded corner points; 'hobb' boxes are suppressed as the
+    quadrilaterals ``rbbox_transforms.hobb_corner_points`` builds from them (the returned rows stay hobbs).
 
     ``cfg`` needs ``score_thr``, ``max_per_img`` and ``polygon_nms_iou_thr`` (attribute or
     key access), as test_cfg.rcnn of configs/dota/dota_v002_theta_obb_r50_v1_train.py:125-132.
@@ -235,7 +238,7 @@ def get_det_rbboxes(rois, cls_score, rbbox_pred, img_shape, scale_factor, rescal
             encode = get('encode')
     formats = {'thetaobb': (T.delta2thetaobb, T.thetaobb_rescale, 5, 'rnms'),
                'pointobb': (T.delta2pointobb, T.pointobb_rescale, 8, 'poly_nms'),
-               'hobb': (T.delta2hobb, T.hobb_rescale, 5, None)}
+               'hobb': (T.delta2hobb, T.hobb_rescale, 5, 'poly_nms')}
     if encode not in formats:
         raise ValueError('encode must be one of {}, got {!r}'.format(sorted(formats), encode))
     decode, rescale_fn, dim, rotated_op = formats[encode]
@@ -252,10 +255,13 @@ def get_det_rbboxes(rois, cls_score, rbbox_pred, img_shape, scale_factor, rescal
     if cfg is None:
         return rbboxes, scores
     if rotated_nms:
-        if rotated_op is None:
-            raise ValueError("encode='hobb' has no rotated NMS: pass rotated_nms=False (the reference's keep re-use)")
-        return multiclass_rnms(rbboxes, scores, get('score_thr'),
-                               dict(type=rotated_op, iou_thr=get('polygon_nms_iou_thr')),
-                               get('max_per_img'), out_dim_reg=dim)
+        nms_cfg = dict(type=rotated_op, iou_thr=get('polygon_nms_iou_thr'))
+        if encode != 'hobb':
+            return multiclass_rnms(rbboxes, scores, get('score_thr'), nms_cfg, get('max_per_img'), out_dim_reg=dim)
+        # hobb: the NMS sees each box's quadrilateral, the rows that come back are the hobbs themselves
+        n, k = rbboxes.size(0), rbboxes.size(1) // 5
+        quads = T.hobb_corner_points(rbboxes.view(n, k, 5)).reshape(n, k * 8)
+        return multiclass_rnms(quads, scores, get('score_thr'), nms_cfg, get('max_per_img'), out_dim_reg=8,
+                               report=(rbboxes, 5))
     return thetaobb_nms_by_bbox_nms(rbboxes, scores, bbox_cls_inds, bbox_keep_inds,
                                     get('max_per_img'), out_dim_reg=dim)

@@ -246,6 +246,17 @@ def hobb2pointobb(hobb):
     return [int(v) for v in (x1, y1, x2, y2, x2 - dx, y2 + dy, x1 - dx, y1 + dy)]
 
 
+def hobb_corner_points(hobbs):
+    """(n, 5) hobbs -> (n, 8) corner points, the construction of ``hobb2pointobb`` (:137-163) on tensors and
+    WITHOUT its truncation to integers: points 3 and 4 lie ``h`` away from the side 1-2 along its normal
+    (dx, dy)/|.| -> (-dy, dx)/|.|.  Used to give hobb detections a true polygon NMS; a degenerate side
+    (both points equal) yields the normal (0, 1) of ``atan2(0, 0) = 0``."""
+    x1, y1, x2, y2, h = hobbs.unbind(-1)
+    turn = math.pi / 2.0 - torch.atan2(y2 - y1, x2 - x1)
+    dx, dy = h * torch.cos(turn), h * torch.sin(turn)
+    return torch.stack([x1, y1, x2, y2, x2 - dx, y2 + dy, x1 - dx, y1 + dy], dim=-1)
+
+
 def _no_hobb_flip():
     raise NotImplementedError('flipping a hobb goes through cv2.minAreaRect in the reference '
                               '(transforms.py:243-275); OpenCV is not part of this build')
