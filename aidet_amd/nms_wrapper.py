@@ -165,7 +165,22 @@ def _nms_generic(dets, iou_thr, device_id, cols, kind, name, groups=None, thrs=N
             inds = inds.to(dets_th.device)  # keep lives where the input lives
     if is_numpy:
         inds = inds.cpu().numpy()
-    return dets[inds, :], inds
+        return dets[inds, :], inds
+    return _take_rows(dets, inds), inds
+
+
+def _take_rows(dets, inds):
+    """dets[inds, :] -- fp32 rows on the GPU through the library's row gather (torch's advanced indexing
+    costs 20-40 us for 1e5 rows of 24 bytes, a third of a 100k-box call)."""
+    if dets.is_cuda and dets.dtype == torch.float32 and inds.numel() >= 4096 and inds.device == dets.device:   # (below: the ctypes call costs more)
+        src = dets.contiguous()
+        out = src.new_empty((inds.numel(), src.size(1)))
+        with torch.cuda.device(src.device):
+            _lib.check(_lib.lib().obb_gather_rows_f32(src.data_ptr(), src.size(0), src.size(1), inds.data_ptr(),
+                                                      inds.numel(), src.size(1), out.data_ptr(),
+                                                      _lib.current_stream_handle(src.device)))
+        return out
+    return dets[inds, :]
 
 
 def rnms(dets, iou_thr, device_id=None, groups=None, thrs=None, strict=False):
