@@ -43,7 +43,7 @@ class build_py_with_libs(build_py):
 
 setup(
     name='aidet_amd',
-    version='1.0',
+    version='1.1.0',
     description='MI355X-native oriented-bounding-box operators (rotated IoU / NMS / RoI-Align) for AIDet',
     packages=find_packages(include=['aidet_amd', 'aidet_amd.*']),
     package_data={'aidet_amd': ['lib/*.so']},
