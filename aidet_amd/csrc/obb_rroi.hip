@@ -577,7 +577,7 @@ constexpr int kBwdMaxEntries = 4 * kMaxTabSamples;     // taps of a RoI (4 per s
 __global__ __launch_bounds__(256) void rroi_backward_kernel(
     const float *__restrict__ gout, int B, int C, int H, int W, const float *__restrict__ rois,
     int ph, int pw, float scale, int sample_num, float min_size, int chan_per_block,
-    int K, int chunks, int roi_kind, float *__restrict__ gfeat) {
+    int K, int chunks, int roi_kind, float *__restrict__ gfeat, int only_unstaged) {
   __shared__ __attribute__((aligned(16))) float tile[kBwdStageFloats];   // first the sample table, then sums [channel][pixel]
   __shared__ int2 entry[kBwdMaxEntries];               // (bin, weight bits), grouped by pixel
   __shared__ int pstart[kBwdMaxPix + 1];               // CSR offsets; during the build: counts
@@ -606,6 +606,7 @@ __global__ __launch_bounds__(256) void rroi_backward_kernel(
     rroi_backward_direct(gout, C, H, W, f, k, ph, pw, c_block, c_end, gfeat);
     return;
   }
+  if (only_unstaged) return;   // (the gather formulation below served this RoI)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // ---- 1. sample table (in the tile's memory) and its inverse
   int4 *s_off = reinterpret_cast<int4 *>(tile);
@@ -712,6 +713,227 @@ __global__ __launch_bounds__(256) void rroi_backward_kernel(
   }
 }
 
+// ---- backward, GATHER formulation (needs a workspace; deterministic) ------------------------------
+// The scatter above ends in ~1.6e6 atomic row requests per launch (one per channel and footprint row),
+// the floor of that design.  With a workspace the whole backward becomes a gather from the MAP side:
+//   plan    (one block per RoI)   frame, footprint and the inverted sample table "pixel -> (bin,
+//           weight / count) of every tap on it" -- the prologue of the kernel above, built ONCE per RoI
+//           instead of once per channel chunk, the taps of a pixel sorted by tap number;
+//   gather  (one block per 16 x 16 map tile and 16 channels)  the RoIs whose footprint meets the tile,
+//           found by testing all K plans, hence in RoI order; every thread owns one pixel and walks
+//           the lists of that pixel in all those RoIs, 16 channel sums in registers; ONE plain store
+//           per map element, which is written whether a RoI touched it or not (no zero fill needed).
+// No atomics, and a fixed summation order (RoI index, then tap number): results are reproducible bit
+// for bit, which the reference's atomicAdd backward (roi_align_kernel_v2.cu:179-263) is not.
+// RoIs the plan cannot hold (footprint > 2047 pixels, > 256 samples, > 64 bins) are added afterwards by
+// the atomics kernel (`only_unstaged`).
+constexpr int kGTile = 16;                          // map tile: 16 x 16 pixels = one pixel per thread
+constexpr int kGChan = 32;                          // channels per gather block (sums in registers)
+constexpr int kGList = 2048;                        // RoIs of one tile held in LDS at a time
+constexpr int kPlanPix = kBwdMaxPix + 2;            // CSR offsets per RoI (16 bit)
+
+struct alignas(16) RoiPlan { int b, x0, y0, w, h, state, nb, pad; };   // state 1: planned (else nothing here)
+
+template <bool UNUSED = false>
+__device__ __forceinline__ bool plan_holds(int fsz, int nb, int nsamp) {
+  return fsz <= kBwdMaxPix && (fsz | 1) <= kBwdStageFloats && nb <= kMaxBins && nsamp <= kMaxTabSamples;
+}
+
+__global__ __launch_bounds__(256) void rroi_plan_kernel(
+    int B, int H, int W, const float *__restrict__ rois, int ph, int pw, float scale, int sample_num,
+    float min_size, int roi_kind, RoiPlan *__restrict__ plan, unsigned short *__restrict__ rstart,
+    int2 *__restrict__ rentry) {
+  __shared__ __attribute__((aligned(16))) float tile[kBwdStageFloats];   // sample table | per-pixel counts
+  __shared__ int2 entry[kBwdMaxEntries];               // (bin | tap << 8, weight bits), grouped by pixel
+  __shared__ int pstart[kBwdMaxPix + 1];
+  __shared__ int wsum[4];
+  int *pfill = reinterpret_cast<int *>(tile) + kMaxTabSamples * 8;
+  const int64_t k = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  RoiFrame f;
+  make_frame(rois + k * roi_stride(roi_kind), roi_kind, scale, ph, pw, sample_num, min_size, f);
+  const long long spb64 = (long long)f.gh * f.gw;
+  RoiPlan pl = {f.b, 0, 0, 0, 0, 0, ph * pw, 0};
+  const bool live = f.b >= 0 && f.b < B && spb64 > 0;
+  const int nb = ph * pw;
+  const Footprint fp = live ? roi_footprint(f, H, W, ph, pw) : Footprint{0, 0, 0, 0};
+  const int fsz = fp.w * fp.h;
+  const int spb = (int)(spb64 > kMaxTabSamples ? kMaxTabSamples + 1 : (spb64 > 0 ? spb64 : 1));
+  const int nsamp = nb * spb;
+  if (!live || !plan_holds(fsz, nb, nsamp)) {        // nothing sampled, or left to the atomics kernel
+    if (tid == 0) plan[k] = pl;
+    return;
+  }
+  int4 *s_off = reinterpret_cast<int4 *>(tile);
+  float4 *s_wgt = reinterpret_cast<float4 *>(tile) + kMaxTabSamples;
+  for (int i = tid; i < fsz; i += 256) { pstart[i] = 0; pfill[i] = 0; }
+  build_table(f, fp, H, W, pw, spb, nsamp, s_off, s_wgt);
+  __syncthreads();
+  const int ntap = nsamp * 4;
+  auto tap_of = [&](int t, int &pix, float &w) {
+    const int sidx = t >> 2, j = t & 3;
+    const int4 o = s_off[sidx];
+    const float4 ww = s_wgt[sidx];
+    pix = j == 0 ? o.x : (j == 1 ? o.y : (j == 2 ? o.z : o.w));
+    w = j == 0 ? ww.x : (j == 1 ? ww.y : (j == 2 ? ww.z : ww.w));
+  };
+  for (int t = tid; t < ntap; t += 256) {
+    int pix;
+    float w;
+    tap_of(t, pix, w);
+    if (w != 0.0f) atomicAdd(&pstart[pix], 1);
+  }
+  __syncthreads();
+  {  // exclusive scan of the counts (<= 2048 pixels: 8 per thread)
+    int c8[8], sum = 0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const int i = tid * 8 + u; c8[u] = i < fsz ? pstart[i] : 0; sum += c8[u]; }
+    int inc = sum;
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o); if (lane >= o) inc += v; }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int base = inc - sum;
+    for (int w2 = 0; w2 < wave; ++w2) base += wsum[w2];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const int i = tid * 8 + u; if (i < fsz) pstart[i] = base; base += c8[u]; }
+    if (tid == 255) pstart[fsz] = base;
+    __syncthreads();
+  }
+  for (int t = tid; t < ntap; t += 256) {
+    int pix;
+    float w;
+    tap_of(t, pix, w);
+    if (w != 0.0f) {
+      const int slot = pstart[pix] + atomicAdd(&pfill[pix], 1);
+      entry[slot] = make_int2((t / (4 * spb)) | (t << 8), __float_as_int(w / f.cnt));
+    }
+  }
+  __syncthreads();
+  // the slots of a pixel were handed out in arrival order; the plan stores every pixel's taps in TAP order
+  // so that the sums of the gather kernel do not depend on it.  A wave takes a pixel at a time, a lane one
+  // of its entries and counts the entries with a smaller tap number (the lists are short: ~4 entries on
+  // average; an insertion sort per thread took 0.25 ms on a 2 x 2 pixel RoI with ~90 taps per pixel)
+  unsigned short *rs = rstart + k * (int64_t)kPlanPix;
+  int2 *re = rentry + k * (int64_t)kBwdMaxEntries;
+  for (int i = tid; i <= fsz; i += 256) rs[i] = (unsigned short)pstart[i];
+  unsigned int *bm = reinterpret_cast<unsigned int *>(tile) + wave * 64;   // (the sample table is dead: 32 bitmap words + 32 prefixes per wave)
+  for (int pix = wave; pix < fsz; pix += 4) {
+    const int e0 = pstart[pix], m = pstart[pix + 1] - e0;   // (wave-uniform)
+    if (m <= 64) {
+      // one entry per lane: the rank is counted over the lanes' registers (no memory in the loop)
+      int2 mine = make_int2(0x7FFFFFFF, 0);
+      if (lane < m) mine = entry[e0 + lane];
+      const int key = mine.x >> 8;
+      int rank = 0;
+      for (int j = 0; j < m; ++j) rank += (__builtin_amdgcn_readlane(key, j) < key) ? 1 : 0;
+      if (lane < m) re[e0 + rank] = make_int2(mine.x & 0xFF, mine.y);
+    } else {
+      // a pixel of a tiny RoI holds up to all 1024 taps: rank = number of set bits below the tap's own
+      // in a 1024-bit map of the taps present (cost independent of m)
+      if (lane < 32) bm[lane] = 0u;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      for (int l = lane; l < m; l += 64) {
+        const int key = entry[e0 + l].x >> 8;
+        atomicOr(&bm[key >> 5], 1u << (key & 31));
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      {
+        const unsigned int wv = lane < 32 ? bm[lane] : 0u;
+        int inc = __popc(wv);
+        const int own = inc;
+        for (int o = 1; o < 32; o <<= 1) { const int v = __shfl_up(inc, o); if (lane >= o) inc += v; }
+        if (lane < 32) bm[32 + lane] = (unsigned int)(inc - own);     // set bits in the words before this one
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      for (int l = lane; l < m; l += 64) {
+        const int2 mine = entry[e0 + l];
+        const int key = mine.x >> 8;
+        const int rank = (int)bm[32 + (key >> 5)] + __popc(bm[key >> 5] & ((1u << (key & 31)) - 1u));
+        re[e0 + rank] = make_int2(mine.x & 0xFF, mine.y);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  if (tid == 0) { pl.x0 = fp.x0; pl.y0 = fp.y0; pl.w = fp.w; pl.h = fp.h; pl.state = 1; plan[k] = pl; }
+}
+
+__global__ __launch_bounds__(256) void rroi_gather_kernel(
+    const float *__restrict__ gout, int C, int H, int W, int K, const RoiPlan *__restrict__ plan,
+    const unsigned short *__restrict__ rstart, const int2 *__restrict__ rentry, float *__restrict__ gfeat) {
+  __shared__ int list[kGList];
+  __shared__ float gtile[kGChan * (kMaxBins + 1)];
+  __shared__ int wcnt[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tiles_x = (W + kGTile - 1) / kGTile;
+  const int tx0 = ((int)blockIdx.x % tiles_x) * kGTile, ty0 = ((int)blockIdx.x / tiles_x) * kGTile;
+  const int c0 = (int)blockIdx.y * kGChan, cc = min(kGChan, C - c0);
+  const int b = (int)blockIdx.z;
+  const int x = tx0 + (tid & (kGTile - 1)), y = ty0 + tid / kGTile;
+  const bool inmap = x < W && y < H;
+  float acc[kGChan];
+#pragma unroll
+  for (int c = 0; c < kGChan; ++c) acc[c] = 0.0f;
+  for (int base = 0; base < K; base += kGList) {
+    // ---- the RoIs of this batch of plans whose footprint meets the tile, in RoI order
+    int n = 0;   // block-uniform
+    const int lim = min(K, base + kGList);
+    for (int r0 = base; r0 < lim; r0 += 256) {
+      const int r = r0 + tid;
+      bool hit = false;
+      if (r < lim) {
+        const RoiPlan p = plan[r];
+        hit = p.state == 1 && p.b == b && p.x0 < tx0 + kGTile && p.x0 + p.w > tx0 && p.y0 < ty0 + kGTile && p.y0 + p.h > ty0;
+      }
+      const uint64_t mk = __ballot(hit);
+      if (lane == 0) wcnt[wave] = __popcll(mk);
+      __syncthreads();
+      int off = 0, tot = 0;
+#pragma unroll
+      for (int w2 = 0; w2 < 4; ++w2) { const int v = wcnt[w2]; off += (w2 < wave) ? v : 0; tot += v; }
+      if (hit) list[n + off + __popcll(mk & ((1ull << lane) - 1ull))] = r;
+      n += tot;
+      __syncthreads();
+    }
+    // ---- their contributions to this thread's pixel
+    for (int i = 0; i < n; ++i) {
+      const int r = list[i];
+      const RoiPlan p = plan[r];
+      const int nb = p.nb, nbp = nb | 1;
+      const float *gsrc = gout + ((int64_t)r * C + c0) * nb;    // contiguous (channel, bin) run
+      const int gtot = cc * nb;
+      for (int q = tid; q < gtot; q += 256) {
+        const int c = q / nb, bin = q - c * nb;
+        gtile[c * nbp + bin] = gsrc[q];
+      }
+      __syncthreads();
+      const int px = x - p.x0, py = y - p.y0;
+      if (inmap && px >= 0 && px < p.w && py >= 0 && py < p.h) {
+        const unsigned short *rs = rstart + (int64_t)r * kPlanPix + (py * p.w + px);
+        const int e0 = rs[0], e1 = rs[1];
+        const int2 *re = rentry + (int64_t)r * kBwdMaxEntries;
+        for (int e = e0; e < e1; ++e) {
+          const int2 en = re[e];
+          const float wgt = __int_as_float(en.y);
+          const float *g = gtile + en.x;
+#pragma unroll
+          for (int c = 0; c < kGChan; ++c) acc[c] = acc[c] + g[c * nbp] * wgt;   // (channels >= cc: stale LDS, never stored)
+        }
+      }
+      __syncthreads();   // the next RoI overwrites gtile
+    }
+  }
+  if (inmap) {
+    float *dst = gfeat + (((int64_t)b * C + c0) * H + y) * (int64_t)W + x;
+#pragma unroll
+    for (int c = 0; c < kGChan; ++c)
+      if (c < cc) dst[(int64_t)c * H * W] = acc[c];
+  }
+}
+
 static int rroi_check(const char *who, int B, int C, int H, int W, int64_t K, int ph, int pw) {
   if (B < 0 || C < 0 || H < 0 || W < 0 || K < 0)
     return set_err(OBB_EINVAL, "%s: negative dimension", who);
@@ -801,7 +1023,7 @@ static int rroi_backward_launch(const char *who, const float *grad_out_dev, int 
   rc = rroi_geometry(who, C, true, K, cpb, chunks, nblk);
   if (rc != OBB_OK) return rc;
   hipLaunchKernelGGL(rroi_backward_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
-                     grad_out_dev, B, C, H, W, rois_dev, ph, pw, spatial_scale, sample_num, min_size, cpb, (int)K, (int)chunks, roi_kind, grad_feat_dev);
+                     grad_out_dev, B, C, H, W, rois_dev, ph, pw, spatial_scale, sample_num, min_size, cpb, (int)K, (int)chunks, roi_kind, grad_feat_dev, 0);
   OBB_LAUNCH_CHECK();
   return OBB_OK;
 }
@@ -838,6 +1060,84 @@ extern "C" int obb_roi_align_backward_f32(const float *grad_out_dev, int B, int 
                                           float *grad_feat_dev, void *stream) {
   return obb::rroi_backward_launch("obb_roi_align_backward_f32", grad_out_dev, B, C, H, W, rois_dev, K, ph, pw,
                                    spatial_scale, sample_num, 0.0f, aligned ? 2 : 1, grad_feat_dev, stream);
+}
+
+namespace obb {
+
+struct GatherLayout { size_t plan, rstart, rentry, total; };
+
+static GatherLayout gather_layout(int64_t K) {
+  GatherLayout L;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+  const size_t k = (size_t)(K > 0 ? K : 1);
+  L.plan = take(k * sizeof(RoiPlan));
+  L.rstart = take(k * kPlanPix * sizeof(unsigned short));
+  L.rentry = take(k * kBwdMaxEntries * sizeof(int2));
+  L.total = off;
+  return L;
+}
+
+}  // namespace obb
+
+extern "C" size_t obb_roi_backward_workspace_bytes(int64_t K) {
+  if (K < 0) return 0;
+  return obb::gather_layout(K).total;
+}
+
+extern "C" int obb_roi_backward_gather_f32(const float *grad_out_dev, int B, int C, int H, int W,
+                                           const float *rois_dev, int64_t K, int roi_kind, int ph, int pw,
+                                           float spatial_scale, int sample_num, float min_size,
+                                           float *grad_feat_dev, void *workspace_dev, size_t workspace_bytes,
+                                           void *stream) {
+  using namespace obb;
+  const char *who = "obb_roi_backward_gather_f32";
+  if (roi_kind < 0 || roi_kind > 2) return set_err(OBB_EINVAL, "%s: roi_kind %d (0 rotated, 1 RoIAlign V1, 2 V2-aligned)", who, roi_kind);
+  int rc = rroi_check(who, B, C, H, W, K, ph, pw);
+  if (rc != OBB_OK) return rc;
+  if (C == 0 || H == 0 || W == 0 || B == 0) return OBB_OK;
+  if (!grad_feat_dev) return set_err(OBB_EINVAL, "%s: null pointer", who);
+  hipStream_t st = (hipStream_t)stream;
+  const size_t map_elems = (size_t)B * C * H * W;
+  if (K == 0) {   // the gradient map is OVERWRITTEN by this entry point: nothing contributes
+    OBB_HIP_TRY(hipMemsetAsync(grad_feat_dev, 0, map_elems * sizeof(float), st));
+    return OBB_OK;
+  }
+  if (!grad_out_dev || !rois_dev || !workspace_dev) return set_err(OBB_EINVAL, "%s: null pointer", who);
+  const GatherLayout L = gather_layout(K);
+  if (workspace_bytes < L.total)
+    return set_err(OBB_EWORKSPACE, "%s: workspace %zu bytes < obb_roi_backward_workspace_bytes(%lld) = %zu", who, workspace_bytes, (long long)K, L.total);
+  if ((reinterpret_cast<uintptr_t>(workspace_dev) & 15u) != 0) return set_err(OBB_EINVAL, "%s: workspace must be 16-byte aligned", who);
+  if (K > 2147483647LL / 2 || (int64_t)B * C * H * W >= (1ll << 31)) {
+    // beyond 32-bit indexing: the atomics path alone (it needs a zeroed map)
+    OBB_HIP_TRY(hipMemsetAsync(grad_feat_dev, 0, map_elems * sizeof(float), st));
+    return rroi_backward_launch(who, grad_out_dev, B, C, H, W, rois_dev, K, ph, pw, spatial_scale, sample_num, min_size,
+                                roi_kind, grad_feat_dev, stream);
+  }
+  char *ws = static_cast<char *>(workspace_dev);
+  RoiPlan *plan = reinterpret_cast<RoiPlan *>(ws + L.plan);
+  unsigned short *rstart = reinterpret_cast<unsigned short *>(ws + L.rstart);
+  int2 *rentry = reinterpret_cast<int2 *>(ws + L.rentry);
+  hipLaunchKernelGGL(rroi_plan_kernel, dim3((unsigned)K), dim3(256), 0, st, B, H, W, rois_dev, ph, pw, spatial_scale,
+                     sample_num, min_size, roi_kind, plan, rstart, rentry);
+  OBB_LAUNCH_CHECK();
+  const unsigned tiles = (unsigned)(((W + kGTile - 1) / kGTile) * ((H + kGTile - 1) / kGTile));
+  const unsigned chunks = (unsigned)((C + kGChan - 1) / kGChan);
+  if (chunks > 65535u || B > 65535) return set_err(OBB_EINVAL, "%s: too many channels / images", who);
+  hipLaunchKernelGGL(rroi_gather_kernel, dim3(tiles, chunks, (unsigned)B), dim3(256), 0, st, grad_out_dev, C, H, W, (int)K,
+                     plan, rstart, rentry, grad_feat_dev);
+  OBB_LAUNCH_CHECK();
+  // the RoIs the plan could not hold are ADDED by the atomics kernel: its usual geometry (a large RoI's
+  // channels spread over 16 blocks), blocks of planned RoIs leave right after the footprint test
+  int cpb;
+  unsigned achunks;
+  unsigned long long nblk;
+  rc = rroi_geometry(who, C, true, K, cpb, achunks, nblk);
+  if (rc != OBB_OK) return rc;
+  hipLaunchKernelGGL(rroi_backward_kernel, dim3((unsigned)nblk), dim3(256), 0, st, grad_out_dev, B, C, H, W, rois_dev, ph, pw,
+                     spatial_scale, sample_num, min_size, cpb, (int)K, (int)achunks, roi_kind, grad_feat_dev, 1);
+  OBB_LAUNCH_CHECK();
+  return OBB_OK;
 }
 
 extern "C" int obb_roi_align_levels_forward_f32(const float *const *feat_devs_host, const int *H_host,

@@ -29,6 +29,47 @@ from . import _lib
 from .rroi_align import RRoIAlign, rroi_align  # noqa: F401  (rroi_align: the mapping the kernel now does itself)
 
 
+# Which backward runs: 'auto' | 'gather' (obb_roi_backward_gather_f32: plan per RoI + one block per map tile; no
+# atomics, no zero fill, bit-reproducible) | 'atomics' (the scatter kernels behind obb_(r)roi_align_backward_f32).
+# Measured on MI355X (tools/bench_roi_backward.py): 512 RoIs covering the 256^2 map 1.8x: scatter 0.19 ms, gather
+# 0.26 ms; 2000 RoIs covering it 22x (config 4's first level): scatter 1.67 ms, gather 0.80 ms -- the scatter pays
+# per atomic request and for its direct-atomics tail, the gather per (tile, RoI) pair.  'auto' = gather from
+# GATHER_MIN_ROIS RoIs on.
+BACKWARD = 'auto'
+GATHER_MIN_ROIS = 1024
+
+
+def roi_backward(grad_out, rois, feature_size, roi_kind, out_h, out_w, spatial_scale, sample_num, min_size):
+    """Gradient of any RoI-Align flavour w.r.t. the feature map: (K, C, ph, pw) -> (B, C, H, W), fp32.
+
+    ``roi_kind`` 0: rotated (K, 6) rows, 1: RoIAlign V1, 2: V2-aligned (K, 5) rows.  ``roi_layers.BACKWARD``
+    selects the formulation (see there)."""
+    B, C, H, W = feature_size
+    g = grad_out.detach().to(torch.float32).contiguous()
+    K = rois.size(0)
+    dev = g.device
+    L = _lib.lib()
+    with torch.cuda.device(dev):
+        st = _lib.current_stream_handle(dev)
+        if BACKWARD == 'gather' or (BACKWARD == 'auto' and K >= GATHER_MIN_ROIS):
+            grad = torch.empty((B, C, H, W), dtype=torch.float32, device=dev)
+            ws = torch.empty(max(int(L.obb_roi_backward_workspace_bytes(K)), 16), dtype=torch.uint8, device=dev)
+            _lib.check(L.obb_roi_backward_gather_f32(g.data_ptr(), B, C, H, W, rois.data_ptr(), K, roi_kind, out_h, out_w,
+                                                     spatial_scale, sample_num, min_size, grad.data_ptr(), ws.data_ptr(),
+                                                     ws.numel(), st))
+            return grad
+        grad = torch.zeros((B, C, H, W), dtype=torch.float32, device=dev)
+        if K > 0 and C > 0:
+            if roi_kind == 0:
+                _lib.check(L.obb_rroi_align_backward_f32(g.data_ptr(), B, C, H, W, rois.data_ptr(), K, out_h, out_w,
+                                                         spatial_scale, sample_num, min_size, grad.data_ptr(), st))
+            else:
+                _lib.check(L.obb_roi_align_backward_f32(g.data_ptr(), B, C, H, W, rois.data_ptr(), K, out_h, out_w,
+                                                        spatial_scale, sample_num, 1 if roi_kind == 2 else 0,
+                                                        grad.data_ptr(), st))
+    return grad
+
+
 class RoIAlignFunction(Function):
     """Horizontal RoIAlign (roi_align.py:9-73): features NCHW, rois (K, 5)
     [batch, x1, y1, x2, y2]; gradient w.r.t. the features only."""
@@ -64,16 +105,8 @@ class RoIAlignFunction(Function):
         out_h, out_w, scale, sample_num, aligned = ctx.args
         grad_input = None
         if ctx.needs_input_grad[0]:
-            g = grad_output.detach().to(torch.float32).contiguous()
-            grad_input = torch.zeros((B, C, H, W), dtype=torch.float32, device=g.device)
-            K = r.size(0)
-            if K > 0 and C > 0:
-                with torch.cuda.device(g.device):
-                    rc = _lib.lib().obb_roi_align_backward_f32(
-                        g.data_ptr(), B, C, H, W, r.data_ptr(), K, out_h, out_w, scale, sample_num, aligned,
-                        grad_input.data_ptr(), _lib.current_stream_handle(g.device))
-                _lib.check(rc)
-            grad_input = grad_input.to(ctx.in_dtype)
+            grad_input = roi_backward(grad_output, r, (B, C, H, W), 2 if aligned else 1, out_h, out_w, scale,
+                                      sample_num, 0.0).to(ctx.in_dtype)
         return grad_input, None, None, None, None, None
 
 

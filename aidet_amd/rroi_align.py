@@ -58,18 +58,9 @@ class RRoIAlignFunction(Function):
         assert grad_output.is_cuda
         grad_input = None
         if ctx.needs_input_grad[0]:
-            g = grad_output.detach().to(torch.float32).contiguous()
-            grad_input = torch.zeros((B, C, H, W), dtype=torch.float32, device=g.device)
-            K = r.size(0)
-            if K > 0 and C > 0:
-                with torch.cuda.device(g.device):
-                    rc = _lib.lib().obb_rroi_align_backward_f32(
-                        ctypes.c_void_p(g.data_ptr()), B, C, H, W, ctypes.c_void_p(r.data_ptr()),
-                        K, out_h, out_w, ctypes.c_float(ctx.spatial_scale), ctx.sample_num,
-                        ctypes.c_float(ctx.min_size), ctypes.c_void_p(grad_input.data_ptr()),
-                        _lib.stream_ptr(g.device))
-                _lib.check(rc)
-            grad_input = grad_input.to(ctx.in_dtype)
+            from .roi_layers import roi_backward
+            grad_input = roi_backward(grad_output, r, (B, C, H, W), 0, out_h, out_w, ctx.spatial_scale,
+                                      ctx.sample_num, ctx.min_size).to(ctx.in_dtype)
         # gradient w.r.t. features only, like roi_align.py:46-73
         return grad_input, None, None, None, None, None
 

@@ -262,6 +262,24 @@ OBB_API int obb_roi_align_levels_forward_f32(const float *const *feat_devs_host,
                                              float *out_dev, void *stream);
 
 /* ---------------------------------------------------------------------------
+ * RoI-Align backward as a GATHER (any roi_kind: 0 rotated (K,6) rows, 1 RoIAlign V1, 2 V2-aligned
+ * (K,5) rows), with a caller-provided workspace of obb_roi_backward_workspace_bytes(K) bytes.
+ * Replaces: the same reference kernels as obb_rroi_align_backward_f32 / obb_roi_align_backward_f32
+ *           (ROIAlignBackwardV1 roi_align_kernel.cu:188-280, RoIAlignBackwardFeatureV2
+ *           roi_align_kernel_v2.cu:179-263, both atomicAdd scatters).
+ * Differences from those two entry points: grad_feat is OVERWRITTEN (every element of the
+ * (B,C,H,W) map is stored exactly once: no zero fill by the caller), no atomics are used for RoIs
+ * of up to 2047 footprint pixels / 256 samples / 64 bins, and the result is reproducible bit for bit
+ * (fixed summation order: RoI index, then tap number).  Larger RoIs are added by the atomics kernel.
+ * ------------------------------------------------------------------------- */
+OBB_API size_t obb_roi_backward_workspace_bytes(int64_t K);
+OBB_API int obb_roi_backward_gather_f32(const float *grad_out_dev, int B, int C, int H, int W,
+                                        const float *rois_dev, int64_t K, int roi_kind, int ph, int pw,
+                                        float spatial_scale, int sample_num, float min_size,
+                                        float *grad_feat_dev, void *workspace_dev, size_t workspace_bytes,
+                                        void *stream);
+
+/* ---------------------------------------------------------------------------
  * theta-OBB -> 4 corner points in cv2.boxPoints order.
  * Replaces: thetaobb2pointobb, mmdet/core/rbbox/transforms.py:45-55 (per-box
  *           cv2 call on the host).  in (n,5) -> out (n,8).

@@ -23,6 +23,8 @@ int main(void) {
   if (obb_merge_rows_split_f32(0, 4, 9, 15, 0, 0.3f, 0, 0, 0, 0) != OBB_EINVAL) return 12;           /* 9 columns */
   if (obb_gather_rows_f32(0, 4, 8, 0, 0, 8, 0, 0) != OBB_OK) return 13;                              /* k = 0 */
   if (obb_gather_rows_f32(0, 4, 8, 0, 2, 9, 0, 0) != OBB_EINVAL) return 14;                          /* out_cols > cols */
+  if (obb_roi_backward_workspace_bytes(512) == 0) return 15;
+  if (obb_roi_backward_gather_f32(0, 1, 1, 8, 8, 0, 4, 7, 7, 7, 0.25f, 2, 1.0f, 0, 0, 0, 0) != OBB_EINVAL) return 16;   /* roi_kind 7 */
   printf("c abi ok: %s\n", obb_build_info());
   return 0;
 }

@@ -1326,3 +1326,50 @@ def test_bbox_overlaps_is_differentiable_like_the_reference_expression():
         rbbox_overlaps(torch.rand(4, 5, device='cuda', requires_grad=True), torch.rand(4, 5, device='cuda'))
     with torch.no_grad():      # target assignment: fine without a graph
         assert rbbox_overlaps(torch.rand(4, 5, device='cuda', requires_grad=True), torch.rand(4, 5, device='cuda')).shape == (4, 4)
+
+
+@pytest.mark.parametrize('mode', ['gather', 'atomics'])
+def test_roi_backward_formulations_match_the_oracle(mode):
+    """Both backward formulations (roi_layers.BACKWARD) on rotated and horizontal RoIs incl. RoIs too large for
+    the plan (atomics fallback inside the gather entry point), RoIs off the map, an empty batch index and two
+    images; the gather result of plannable RoIs is bit-reproducible and needs no zero-filled map."""
+    from aidet_amd import RRoIAlign, RoIAlign, roi_layers
+    rng = np.random.default_rng(77)
+    old = roi_layers.BACKWARD
+    roi_layers.BACKWARD = mode
+    try:
+        feat = rng.standard_normal((2, 24, 72, 88)).astype(np.float32)
+        K = 90
+        r = oracle.synth_boxes(K, 300, 9)[:, :5]
+        r[:6, 2:4] *= 6.0                    # large: footprints beyond 2047 pixels at scale 0.5
+        r[6:10, :2] += 2000                  # far off the map
+        rois = np.concatenate([rng.integers(0, 2, (K, 1)).astype(np.float32), r], 1)
+        rois[10, 0] = 5                      # batch index out of range: no gradient
+        g = rng.standard_normal((K, 24, 7, 7)).astype(np.float32)
+        for scale, sn in ((0.5, 2), (0.25, 0)):
+            f = t(feat).requires_grad_(True)
+            out = RRoIAlign(7, scale, sample_num=sn)(f, t(rois))
+            out.backward(t(g))
+            ref = oracle.rroi_align_backward(g, rois, feat.shape, scale, sn)
+            assert float((f.grad - t(ref)).abs().max()) <= 1e-4 * max(1.0, float(np.abs(ref).max())), (mode, scale, sn)
+        hb = np.stack([r[:, 0] - r[:, 2] / 2, r[:, 1] - r[:, 3] / 2, r[:, 0] + r[:, 2] / 2, r[:, 1] + r[:, 3] / 2], 1)
+        hrois = np.concatenate([rois[:, :1], hb], 1).astype(np.float32)
+        for aligned in (False, True):     # horizontal kinds: the two formulations against each other
+            grads = {}
+            for m2 in ('gather', 'atomics'):
+                roi_layers.BACKWARD = m2
+                f = t(feat).requires_grad_(True)
+                RoIAlign(7, 0.5, sample_num=2, aligned=aligned)(f, t(hrois)).backward(t(g))
+                grads[m2] = f.grad
+            roi_layers.BACKWARD = mode
+            scale_g = max(1.0, float(grads['atomics'].abs().max()))
+            assert float((grads['gather'] - grads['atomics']).abs().max()) <= 1e-4 * scale_g, aligned
+            assert float(grads['gather'].abs().sum()) > 0
+        if mode == 'gather':
+            small = rois[12:].copy()          # plannable RoIs only: two runs are bit-identical
+            f1, f2 = t(feat).requires_grad_(True), t(feat).requires_grad_(True)
+            lay = RRoIAlign(7, 0.5, sample_num=2)
+            lay(f1, t(small)).backward(t(g[12:])); lay(f2, t(small)).backward(t(g[12:]))
+            assert torch.equal(f1.grad, f2.grad)
+    finally:
+        roi_layers.BACKWARD = old
