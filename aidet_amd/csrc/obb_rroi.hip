@@ -728,7 +728,7 @@ __global__ __launch_bounds__(256) void rroi_backward_kernel(
 // RoIs the plan cannot hold (footprint > 2047 pixels, > 256 samples, > 64 bins) are added afterwards by
 // the atomics kernel (`only_unstaged`).
 constexpr int kGTile = 16;                          // map tile: 16 x 16 pixels = one pixel per thread
-constexpr int kGChan = 32;                          // channels per gather block (sums in registers)
+constexpr int kGChan = 32;                          // channels per gather block (sums in registers; 16 measured the same)
 constexpr int kGList = 2048;                        // RoIs of one tile held in LDS at a time
 constexpr int kPlanPix = kBwdMaxPix + 2;            // CSR offsets per RoI (16 bit)
 
@@ -816,9 +816,36 @@ __global__ __launch_bounds__(256) void rroi_plan_kernel(
   unsigned short *rs = rstart + k * (int64_t)kPlanPix;
   int2 *re = rentry + k * (int64_t)kBwdMaxEntries;
   for (int i = tid; i <= fsz; i += 256) rs[i] = (unsigned short)pstart[i];
+  // (a) a thread per pixel for the usual short lists (<= 8 taps: ranks by compares in registers) -- a wave per
+  //     pixel walked the 2047 pixels of a large footprint one LDS round trip at a time: 0.1 ms for one RoI;
+  // (b) the few longer lists (small RoIs: many taps per pixel) are queued and taken by whole waves.
+  __shared__ int longq[kBwdMaxEntries / 8 + 1];
+  __shared__ int nlong;
+  if (tid == 0) nlong = 0;
+  __syncthreads();
+  for (int pix = tid; pix < fsz; pix += 256) {
+    const int e0 = pstart[pix], m = pstart[pix + 1] - e0;
+    if (m > 8) { longq[atomicAdd(&nlong, 1)] = pix; continue; }
+    int2 en[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) en[u] = u < m ? entry[e0 + u] : make_int2(0x7FFFFFFF, 0);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (u < m) {
+        int rank = 0;
+#pragma unroll
+        for (int v = 0; v < 8; ++v) rank += ((en[v].x >> 8) < (en[u].x >> 8)) ? 1 : 0;
+        re[e0 + rank] = make_int2(en[u].x & 0xFF, en[u].y);
+      }
+    }
+  }
+  __syncthreads();
   unsigned int *bm = reinterpret_cast<unsigned int *>(tile) + wave * 64;   // (the sample table is dead: 32 bitmap words + 32 prefixes per wave)
-  for (int pix = wave; pix < fsz; pix += 4) {
-    const int e0 = pstart[pix], m = pstart[pix + 1] - e0;   // (wave-uniform)
+  const int nq = nlong;
+  for (int qi = __builtin_amdgcn_readfirstlane(wave); qi < nq; qi += 4) {
+    const int pix = __builtin_amdgcn_readfirstlane(longq[qi]);
+    const int e0 = __builtin_amdgcn_readfirstlane(pstart[pix]);   // (wave-uniform: tell the compiler, or the
+    const int m = __builtin_amdgcn_readfirstlane(pstart[pix + 1]) - e0;   //  v_readlane below becomes a waterfall loop)
     if (m <= 64) {
       // one entry per lane: the rank is counted over the lanes' registers (no memory in the loop)
       int2 mine = make_int2(0x7FFFFFFF, 0);
@@ -905,22 +932,32 @@ __global__ __launch_bounds__(256) void rroi_gather_kernel(
       const int nb = p.nb, nbp = nb | 1;
       const float *gsrc = gout + ((int64_t)r * C + c0) * nb;    // contiguous (channel, bin) run
       const int gtot = cc * nb;
+      // this pixel's list bounds are requested together with the gradients (one memory round trip)
+      const int px = x - p.x0, py = y - p.y0;
+      const bool mine = inmap && px >= 0 && px < p.w && py >= 0 && py < p.h;
+      int e0 = 0, e1 = 0;
+      if (mine) {
+        const unsigned short *rs = rstart + (int64_t)r * kPlanPix + (py * p.w + px);
+        e0 = rs[0]; e1 = rs[1];
+      }
       for (int q = tid; q < gtot; q += 256) {
         const int c = q / nb, bin = q - c * nb;
         gtile[c * nbp + bin] = gsrc[q];
       }
       __syncthreads();
-      const int px = x - p.x0, py = y - p.y0;
-      if (inmap && px >= 0 && px < p.w && py >= 0 && py < p.h) {
-        const unsigned short *rs = rstart + (int64_t)r * kPlanPix + (py * p.w + px);
-        const int e0 = rs[0], e1 = rs[1];
-        const int2 *re = rentry + (int64_t)r * kBwdMaxEntries;
-        for (int e = e0; e < e1; ++e) {
-          const int2 en = re[e];
-          const float wgt = __int_as_float(en.y);
-          const float *g = gtile + en.x;
+      const int2 *re = rentry + (int64_t)r * kBwdMaxEntries;
+      for (int e = e0; e < e1; e += 4) {      // four entries per round trip (lists average ~4)
+        int2 en[4];
 #pragma unroll
-          for (int c = 0; c < kGChan; ++c) acc[c] = acc[c] + g[c * nbp] * wgt;   // (channels >= cc: stale LDS, never stored)
+        for (int u = 0; u < 4; ++u) en[u] = re[min(e + u, e1 - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (e + u < e1) {
+            const float wgt = __int_as_float(en[u].y);
+            const float *g = gtile + en[u].x;
+#pragma unroll
+            for (int c = 0; c < kGChan; ++c) acc[c] = acc[c] + g[c * nbp] * wgt;   // (channels >= cc: stale LDS, never stored)
+          }
         }
       }
       __syncthreads();   // the next RoI overwrites gtile
