@@ -1,5 +1,5 @@
 """One-off extended run of the bounded fuzz sweeps of tests/test_gpu_fuzz.py (more seeds than the
-driver-run blocks 0..5).  usage: python tools/soak_fuzz.py FIRST_BLOCK LAST_BLOCK"""
+driver-run blocks 0..5).  usage: python tools/soak_fuzz.py FIRST_BLOCK LAST_BLOCK [gather|atomics]"""
 import os, sys, time
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, 'tests'))
@@ -17,6 +17,9 @@ def force(route):
 
 
 a, b = int(sys.argv[1]), int(sys.argv[2])
+if len(sys.argv) > 3:      # e.g. `gather`: force the RoI-Align backward formulation (roi_layers.BACKWARD)
+    from aidet_amd import roi_layers
+    roi_layers.BACKWARD = sys.argv[3]
 t0 = time.time()
 nms = getattr(F.test_fuzz_rnms_all_routes, '__wrapped__', F.test_fuzz_rnms_all_routes)
 ops = getattr(F.test_fuzz_overlaps_and_rroi_align, '__wrapped__', F.test_fuzz_overlaps_and_rroi_align)
