@@ -455,6 +455,28 @@ def extras(dev, args):
     hr = torch.from_numpy(np.concatenate([np.zeros((2000, 1), np.float32), hb[:, :4]], 1)).to(dev)
     hl = RoIAlign(7, 0.25, sample_num=2)
     res['roi_align_2000x256x7x7'] = {'ms': round(_time_gpu(lambda: hl(feat, hr), 30), 4)}
+    # RoI-Align backward, both formulations (scatter: atomics into a zero-filled map; gather: plan + one block per
+    # map tile, overwrites the map, bit-reproducible), at configs[2] and at the config-4 shape above
+    stp = _lib.current_stream_handle(dev)
+    bw = {}
+    for tag, rr, kind, ms_ in (('rroi_512', rois, 0, 1.0), ('roi_2000', hr, 1, 0.0)):
+        kk = rr.shape[0]
+        go = torch.randn(kk, 256, 7, 7, device=dev)
+        gm = torch.empty_like(feat)
+        wsb2 = torch.empty(L.obb_roi_backward_workspace_bytes(kk), dtype=torch.uint8, device=dev)
+
+        def gather():
+            _lib.check(L.obb_roi_backward_gather_f32(go.data_ptr(), 1, 256, 256, 256, rr.data_ptr(), kk, kind, 7, 7, 0.25, 2, ms_,
+                                                     gm.data_ptr(), wsb2.data_ptr(), wsb2.numel(), stp))
+
+        def scatter():
+            gm.zero_()
+            if kind == 0:
+                _lib.check(L.obb_rroi_align_backward_f32(go.data_ptr(), 1, 256, 256, 256, rr.data_ptr(), kk, 7, 7, 0.25, 2, 1.0, gm.data_ptr(), stp))
+            else:
+                _lib.check(L.obb_roi_align_backward_f32(go.data_ptr(), 1, 256, 256, 256, rr.data_ptr(), kk, 7, 7, 0.25, 2, 0, gm.data_ptr(), stp))
+        bw[tag] = {'gather_ms': round(_time_gpu(gather, 20), 4), 'scatter_incl_zero_fill_ms': round(_time_gpu(scatter, 20), 4)}
+    res['roi_align_backward_256ch_7x7'] = bw
     # configs[4] on ONE GPU: the same step the N > 1 line times, without the exchange
     res['cfg5_tiled_merge_1gpu'] = tiled_on_this_rank(dev, 0, 1, steps=10, warmup=2, layout='replicated')[0]
     try:
