@@ -728,7 +728,7 @@ __global__ __launch_bounds__(256) void rroi_backward_kernel(
 // RoIs the plan cannot hold (footprint > 2047 pixels, > 256 samples, > 64 bins) are added afterwards by
 // the atomics kernel (`only_unstaged`).
 constexpr int kGTile = 16;                          // map tile: 16 x 16 pixels = one pixel per thread
-constexpr int kGChan = 32;                          // channels per gather block (sums in registers; 16 measured the same)
+constexpr int kGChan = 16;                          // channels per gather block (sums in registers)
 constexpr int kGList = 2048;                        // RoIs of one tile held in LDS at a time
 constexpr int kPlanPix = kBwdMaxPix + 2;            // CSR offsets per RoI (16 bit)
 
@@ -892,7 +892,7 @@ __global__ __launch_bounds__(256) void rroi_gather_kernel(
     const float *__restrict__ gout, int C, int H, int W, int K, const RoiPlan *__restrict__ plan,
     const unsigned short *__restrict__ rstart, const int2 *__restrict__ rentry, float *__restrict__ gfeat) {
   __shared__ int list[kGList];
-  __shared__ float gtile[kGChan * (kMaxBins + 1)];
+  __shared__ float gtiles[2][kGChan * (kMaxBins + 1)];   // double buffered: one barrier per RoI
   __shared__ int wcnt[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tiles_x = (W + kGTile - 1) / kGTile;
@@ -926,9 +926,12 @@ __global__ __launch_bounds__(256) void rroi_gather_kernel(
       __syncthreads();
     }
     // ---- their contributions to this thread's pixel
+    RoiPlan pn = n > 0 ? plan[list[0]] : RoiPlan{};
     for (int i = 0; i < n; ++i) {
       const int r = list[i];
-      const RoiPlan p = plan[r];
+      const RoiPlan p = pn;
+      if (i + 1 < n) pn = plan[list[i + 1]];            // (in flight while this RoI is summed)
+      float *gtile = gtiles[i & 1];
       const int nb = p.nb, nbp = nb | 1;
       const float *gsrc = gout + ((int64_t)r * C + c0) * nb;    // contiguous (channel, bin) run
       const int gtot = cc * nb;
@@ -960,7 +963,8 @@ __global__ __launch_bounds__(256) void rroi_gather_kernel(
           }
         }
       }
-      __syncthreads();   // the next RoI overwrites gtile
+      // (no barrier here: the next RoI stages into the OTHER buffer, and nobody passes its barrier before
+      // every thread is done with this one)
     }
   }
   if (inmap) {

@@ -32,11 +32,11 @@ from .rroi_align import RRoIAlign, rroi_align  # noqa: F401  (rroi_align: the ma
 # Which backward runs: 'auto' | 'gather' (obb_roi_backward_gather_f32: plan per RoI + one block per map tile; no
 # atomics, no zero fill, bit-reproducible) | 'atomics' (the scatter kernels behind obb_(r)roi_align_backward_f32).
 # Measured on MI355X (tools/bench_roi_backward.py): 512 RoIs covering the 256^2 map 1.8x: scatter 0.19 ms, gather
-# 0.20 ms; 2000 RoIs covering it 22x (config 4's first level): scatter 1.67 ms, gather 0.68 ms -- the scatter pays
+# 0.19 ms; 2000 RoIs covering it 22x (config 4's first level): scatter 1.67 ms, gather 0.71 ms -- the scatter pays
 # per atomic request and for its direct-atomics tail, the gather per (tile, RoI) pair.  'auto' = gather from
 # GATHER_MIN_ROIS RoIs on.
 BACKWARD = 'auto'
-GATHER_MIN_ROIS = 1024
+GATHER_MIN_ROIS = 512
 
 
 def roi_backward(grad_out, rois, feature_size, roi_kind, out_h, out_w, spatial_scale, sample_num, min_size):
