@@ -28,7 +28,8 @@ MODE = {'iou': 0, 'iof': 1}
 NMS_STRICT = 1          # OBB_NMS_STRICT: suppress on `>` (nms_kernel.cu:61) instead of `>=` (nms_cpu.cpp:56)
 NMS_RESULT_BYTES = 64   # OBB_NMS_RESULT_BYTES
 # obb_set_tuning knobs (test / experiment hooks, include/obbops.h)
-TUNE_NMS_FUSED_MAX, TUNE_NMS_DIRECT_MAX, TUNE_NMS_SCAN_BLOCKS, TUNE_RROI_GROUPS, TUNE_OVERLAPS_ROWS, TUNE_NMS_INLINE_MAX = range(6)
+(TUNE_NMS_FUSED_MAX, TUNE_NMS_DIRECT_MAX, TUNE_NMS_SCAN_BLOCKS, TUNE_RROI_GROUPS, TUNE_OVERLAPS_ROWS, TUNE_NMS_INLINE_MAX,
+ TUNE_RROI_ORDER_MIN) = range(7)
 
 _lib = None
 
@@ -73,6 +74,14 @@ def lib():
         L.obb_soft_nms_f32.argtypes = [vp, i64, f32, i32, f32, f32, vp, vp, ctypes.POINTER(i64), vp,
                                        ctypes.c_size_t, vp]
         L.obb_soft_nms_f32.restype = i32
+        L.obb_soft_nms_grouped_f32.argtypes = [vp, i64, vp, i64, f32, i32, f32, f32, vp, vp, vp, vp, ctypes.c_size_t, vp]
+        L.obb_soft_nms_grouped_f32.restype = i32
+        L.obb_rpn_select_decode_f32.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(i32),
+                                                ctypes.POINTER(i32), i32, i32, i32, i32, ctypes.POINTER(f32), ctypes.POINTER(f32),
+                                                f32, i32, i32, vp, vp, ctypes.POINTER(i64), vp]
+        L.obb_rpn_select_decode_f32.restype = i32
+        L.obb_rows_topk_f32.argtypes = [vp, i64, i32, i32, vp, i64, ctypes.POINTER(i32), i32, i32, i32, vp, vp, vp, vp]
+        L.obb_rows_topk_f32.restype = i32
         L.obb_set_tuning.argtypes = [i32, i64]
         L.obb_set_tuning.restype = i32
         rroi = [vp, i32, i32, i32, i32, vp, i64, i32, i32, f32, i32, f32, vp, vp]
@@ -89,6 +98,12 @@ def lib():
                                                        ctypes.POINTER(f32), i32, i32, i32, vp, vp, i64, i32, i32,
                                                        i32, i32, f32, vp, vp]
         L.obb_roi_align_levels_forward_f32.restype = i32
+        L.obb_roi_forward_workspace_bytes.argtypes = [i64]
+        L.obb_roi_forward_workspace_bytes.restype = ctypes.c_size_t
+        L.obb_roi_align_forward_ws_f32.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(i32), ctypes.POINTER(i32),
+                                                   ctypes.POINTER(f32), i32, i32, i32, vp, vp, i64, i32, i32,
+                                                   i32, i32, f32, vp, vp, ctypes.c_size_t, vp]
+        L.obb_roi_align_forward_ws_f32.restype = i32
         L.obb_nms_profile_enable.argtypes = [i32]
         L.obb_nms_profile_enable.restype = i32
         L.obb_nms_profile_last.argtypes = [ctypes.POINTER(f32)]

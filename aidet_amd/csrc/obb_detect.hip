@@ -1,0 +1,326 @@
+// obb_detect.hip -- the detector's proposal / detection selection stages as HIP kernels (gfx950).
+//
+// Between a head's convolutions and its NMS the reference runs a chain of small tensor ops per FPN level --
+// sigmoid, top-k, gather of anchors and deltas, delta2bbox, clamp, cat (RPNHead.get_bboxes_single,
+// mmdet/models/anchor_heads/rpn_head.py:55-104; delta2bbox, mmdet/core/bbox/transforms.py:34-111) -- and after
+// it a per-level cut and one more top-k (:93-103).  On a GPU that is ~40 latency-bound launches around one NMS
+// call (1.27 ms of a 10 ms tile, of which the NMS kernels are ~40 us).  Here:
+//
+//   rpn_select_decode_kernel   one workgroup per level: exact top-`nms_pre` of the level's anchors by score
+//                              (3-pass radix select on the order-preserving image of the LOGIT -- the sigmoid is
+//                              monotone, so the order is the reference's -- then a bitonic sort of the <= 2048
+//                              selected: descending score, equal scores by ascending anchor index), gather of
+//                              the selected anchors' deltas out of the (4A, H, W) map, delta2bbox in the
+//                              reference's expression order, image clamp -> (n, 5) rows + level ids, level-major
+//   rows_topk_kernel           rows[keep] -> per-level cut (`proposals[:nms_post]`, :96) -> the `top` best by
+//                              score, descending (:100-103), one workgroup
+//
+// Scores are 1 / (1 + exp(-logit)) with the device expf: within ~1e-7 of torch's sigmoid; boxes within ~1e-4 px
+// of torch's delta2bbox (its exp).  Which anchors are selected and their order do not depend on that rounding
+// (the keys are the logits).
+#include "obb_common.h"
+#include "obb_geom.h"
+
+namespace obb {
+
+constexpr int kSelMax = 2048;       // most rows a selection keeps (nms_pre / max_num <= 2048)
+constexpr int kSelThreads = 1024;
+
+// larger float <=> larger key; -0 folded into +0; NaN sorts below everything (never selected before a number)
+__device__ __forceinline__ uint32_t sel_key(float f) {
+  if (f != f) return 1u;            // NaN: below every number, above 0 = "excluded" (rows_topk_kernel)
+  const float t = f + 0.0f;
+  const uint32_t u = __float_as_uint(t);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);   // (>= 0x007FFFFF for -inf: never 0 or 1)
+}
+
+struct SelScratch {
+  uint32_t hist[2048];
+  uint32_t wsum[16];
+  uint32_t prefix, krem, ngt, neq;
+  int cgt, ceq;
+};
+
+// Exact top-k of key(i), i in [0, n): on return sk[0..k) / si[0..k) hold the k largest keys and their indices,
+// sorted by (key descending, index ascending).  k <= kSelMax, k <= n.  All 1024 threads call it.
+// `key` is evaluated up to 4 times per element (three histogram passes + the collection): it should be a load.
+template <class KeyFn>
+__device__ void block_topk_sorted(KeyFn key, int n, int k, uint32_t *sk, uint32_t *si, SelScratch &sc) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // ---- radix select: the k-th largest key T, digit by digit from the top (11 + 11 + 10 bits)
+  if (tid == 0) { sc.prefix = 0u; sc.krem = (uint32_t)k; }
+  __syncthreads();
+  const int shifts[3] = {21, 10, 0}, bits[3] = {11, 11, 10};
+  uint32_t himask = 0u;
+  for (int pass = 0; pass < 3; ++pass) {
+    const int sh = shifts[pass], nb = 1 << bits[pass];
+    for (int b = tid; b < nb; b += kSelThreads) sc.hist[b] = 0u;
+    __syncthreads();
+    const uint32_t pre = sc.prefix;
+    for (int i = tid; i < n; i += kSelThreads) {
+      const uint32_t kk = key(i);
+      if ((kk & himask) == pre) atomicAdd(&sc.hist[(kk >> sh) & (uint32_t)(nb - 1)], 1u);
+    }
+    __syncthreads();
+    // the digit d with  count(digits > d) < krem <= count(digits >= d): suffix sums over the bins
+    {
+      const int per = nb / kSelThreads > 0 ? nb / kSelThreads : 1;     // 2 bins per thread (11 bits) or 1
+      uint32_t v[2] = {0u, 0u}, tot = 0u;
+      for (int u = 0; u < per; ++u) { const int b = tid * per + u; v[u] = b < nb ? sc.hist[b] : 0u; tot += v[u]; }
+      // inclusive suffix sum across threads: reverse the lane / wave order
+      uint32_t inc = tot;
+      for (int o = 1; o < 64; o <<= 1) { const uint32_t t2 = (uint32_t)__shfl_down((int)inc, o); if (lane + o < 64) inc += t2; }
+      if (lane == 0) sc.wsum[wave] = inc;
+      __syncthreads();
+      uint32_t above = inc - tot;                       // bins of later lanes of this wave
+      for (int w2 = wave + 1; w2 < kSelThreads / 64; ++w2) above += sc.wsum[w2];
+      // bins of this thread, from the highest down
+      const uint32_t kr = sc.krem;
+      __syncthreads();
+      for (int u = per - 1; u >= 0; --u) {
+        const int b = tid * per + u;
+        if (b < nb && above < kr && kr <= above + v[u]) {   // exactly one (thread, bin) satisfies this
+          sc.prefix = pre | ((uint32_t)b << sh);
+          sc.krem = kr - above;
+        }
+        above += v[u];
+      }
+      __syncthreads();
+    }
+    himask |= (uint32_t)(nb - 1) << sh;
+  }
+  const uint32_t T = sc.prefix;
+  const int need_eq = (int)sc.krem;                     // how many keys == T belong to the top k
+  // ---- collect: every key > T, and the first `need_eq` keys == T in index order (chunks in order; inside a chunk
+  // by ballot rank)
+  if (tid == 0) { sc.cgt = 0; sc.ceq = 0; }
+  __syncthreads();
+  const int ngt_total = k - need_eq;
+  for (int base = 0; base < n; base += kSelThreads) {
+    const int i = base + tid;
+    uint32_t kk = 0u;
+    bool gt = false, eq = false;
+    if (i < n) { kk = key(i); gt = kk > T; eq = kk == T; }
+    const uint64_t mg = __ballot(gt), me = __ballot(eq);
+    if (lane == 0) { sc.wsum[wave] = (uint32_t)__popcll(mg) | ((uint32_t)__popcll(me) << 16); }
+    __syncthreads();
+    int og = sc.cgt, oe = sc.ceq, tg = 0, te = 0;
+    for (int w2 = 0; w2 < kSelThreads / 64; ++w2) {
+      const uint32_t v = sc.wsum[w2];
+      if (w2 < wave) { og += (int)(v & 0xFFFFu); oe += (int)(v >> 16); }
+      tg += (int)(v & 0xFFFFu); te += (int)(v >> 16);
+    }
+    const uint64_t lt = (1ull << lane) - 1ull;
+    if (gt) { const int p = og + __popcll(mg & lt); sk[p] = kk; si[p] = (uint32_t)i; }
+    if (eq) { const int r = oe + __popcll(me & lt); if (r < need_eq) { sk[ngt_total + r] = kk; si[ngt_total + r] = (uint32_t)i; } }
+    __syncthreads();
+    if (tid == 0) { sc.cgt += tg; sc.ceq += te; }
+    __syncthreads();
+  }
+  // ---- bitonic sort of the k entries by (key descending, index ascending); padded to a power of two with
+  // entries that sort last
+  int m = 1;
+  while (m < k) m <<= 1;
+  for (int i = k + tid; i < m; i += kSelThreads) { sk[i] = 0u; si[i] = 0xFFFFFFFFu; }
+  __syncthreads();
+  auto before = [](uint32_t ka, uint32_t ia, uint32_t kb, uint32_t ib) { return ka > kb || (ka == kb && ia < ib); };
+  for (int size = 2; size <= m; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t2 = tid; t2 < (m >> 1); t2 += kSelThreads) {
+        const int lo = ((t2 / stride) * 2 * stride) + (t2 % stride), hi = lo + stride;
+        const bool up = ((lo & size) == 0);             // this run is sorted "best first"
+        const uint32_t ka = sk[lo], ia = si[lo], kb = sk[hi], ib = si[hi];
+        const bool swap = up ? before(kb, ib, ka, ia) : before(ka, ia, kb, ib);
+        if (swap) { sk[lo] = kb; si[lo] = ib; sk[hi] = ka; si[hi] = ia; }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+struct RpnLevels {
+  const float *cls[OBB_MAX_LEVELS];      // (A * cls_out, H, W) logits
+  const float *reg[OBB_MAX_LEVELS];      // (A * 4, H, W) deltas
+  const float *anchors[OBB_MAX_LEVELS];  // (H * W * A, 4)
+  int H[OBB_MAX_LEVELS], W[OBB_MAX_LEVELS];
+  int out_base[OBB_MAX_LEVELS + 1];      // first output row of every level
+};
+
+struct BoxCodec { float m[4], s[4]; float max_ratio; int max_h, max_w; };
+
+// delta2bbox (transforms.py:34-111) for one box, the reference's expression order
+__device__ __forceinline__ float4 decode_box(float ax1, float ay1, float ax2, float ay2, float d0, float d1, float d2,
+                                             float d3, const BoxCodec &c) {
+  const float dx = d0 * c.s[0] + c.m[0], dy = d1 * c.s[1] + c.m[1];
+  float dw = d2 * c.s[2] + c.m[2], dh = d3 * c.s[3] + c.m[3];
+  dw = dw < -c.max_ratio ? -c.max_ratio : (dw > c.max_ratio ? c.max_ratio : dw);
+  dh = dh < -c.max_ratio ? -c.max_ratio : (dh > c.max_ratio ? c.max_ratio : dh);
+  const float px = (ax1 + ax2) * 0.5f, py = (ay1 + ay2) * 0.5f;
+  const float pw = ax2 - ax1 + 1.0f, ph = ay2 - ay1 + 1.0f;
+  const float gw = pw * expf(dw), gh = ph * expf(dh);
+  const float gx = px + pw * dx, gy = py + ph * dy;
+  float x1 = gx - gw * 0.5f + 0.5f, y1 = gy - gh * 0.5f + 0.5f;
+  float x2 = gx + gw * 0.5f - 0.5f, y2 = gy + gh * 0.5f - 0.5f;
+  if (c.max_h > 0) {
+    const float mw = (float)(c.max_w - 1), mh = (float)(c.max_h - 1);
+    x1 = x1 < 0.0f ? 0.0f : (x1 > mw ? mw : x1); x2 = x2 < 0.0f ? 0.0f : (x2 > mw ? mw : x2);
+    y1 = y1 < 0.0f ? 0.0f : (y1 > mh ? mh : y1); y2 = y2 < 0.0f ? 0.0f : (y2 > mh ? mh : y2);
+  }
+  return make_float4(x1, y1, x2, y2);
+}
+
+__global__ __launch_bounds__(kSelThreads) void rpn_select_decode_kernel(const RpnLevels lv, int A, int use_sigmoid,
+                                                                        int nms_pre, const BoxCodec codec,
+                                                                        float *__restrict__ dets,
+                                                                        int32_t *__restrict__ levels) {
+  __shared__ uint32_t sk[kSelMax], si[kSelMax];
+  __shared__ SelScratch sc;
+  const int l = blockIdx.x, tid = threadIdx.x;
+  const int H = lv.H[l], W = lv.W[l], HW = H * W;
+  const int n = HW * A;
+  const float *__restrict__ cls = lv.cls[l];
+  const float *__restrict__ reg = lv.reg[l];
+  const float *__restrict__ anc = lv.anchors[l];
+  const int k = lv.out_base[l + 1] - lv.out_base[l];    // min(nms_pre, n) (nms_pre <= 0: n)
+  // anchor index i = p * A + a (the order of cls.permute(1, 2, 0).reshape(-1), rpn_head.py:66-75); its logit sits
+  // at cls[a * HW + p] (sigmoid) or is the difference of the two class logits (softmax: p(fg) = sigmoid(l1 - l0))
+  auto logit = [&](int i) -> float {
+    const int p = i / A, a = i - p * A;
+    if (use_sigmoid) return cls[a * HW + p];
+    return cls[(2 * a + 1) * HW + p] - cls[(2 * a) * HW + p];
+  };
+  const bool select = k < n;
+  if (select) block_topk_sorted([&](int i) { return sel_key(logit(i)); }, n, k, sk, si, sc);
+  float *out = dets + (size_t)lv.out_base[l] * 5;
+  int32_t *olv = levels + lv.out_base[l];
+  for (int j = tid; j < k; j += kSelThreads) {
+    const int i = select ? (int)si[j] : j;
+    const int p = i / A, a = i - p * A;
+    const float4 an = reinterpret_cast<const float4 *>(anc)[i];
+    const float *r = reg + (size_t)(a * 4) * HW + p;
+    const float4 b = decode_box(an.x, an.y, an.z, an.w, r[0], r[HW], r[2 * HW], r[3 * HW], codec);
+    const float s = 1.0f / (1.0f + expf(-logit(i)));
+    out[j * 5 + 0] = b.x; out[j * 5 + 1] = b.y; out[j * 5 + 2] = b.z; out[j * 5 + 3] = b.w; out[j * 5 + 4] = s;
+    olv[j] = l;
+  }
+}
+
+struct LevelBases { int num; int base[OBB_MAX_LEVELS + 1]; };
+
+// rows[keep] -> per-level cut (rank inside the level < nms_post; keep is ascending and the rows are level-major) ->
+// the `top` best by column `score_col`, descending (equal scores: the earlier row first)
+__global__ __launch_bounds__(kSelThreads) void rows_topk_kernel(const float *__restrict__ rows, int cols, int score_col,
+                                                                const int64_t *__restrict__ keep, int K,
+                                                                const LevelBases lb, int nms_post, int top,
+                                                                float *__restrict__ out, int64_t *__restrict__ out_idx,
+                                                                int64_t *__restrict__ count) {
+  __shared__ uint32_t sk[kSelMax], si[kSelMax];
+  __shared__ SelScratch sc;
+  __shared__ int before_level[OBB_MAX_LEVELS + 1];   // kept rows below the first row of every level
+  __shared__ int nvalid;
+  const int tid = threadIdx.x;
+  if (tid <= lb.num) {                                // lower bound of base[tid] in keep
+    int lo = 0, hi = K;
+    const int64_t b = lb.base[tid];
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (keep[mid] < b) lo = mid + 1; else hi = mid; }
+    before_level[tid] = lo;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int v = 0;
+    for (int l2 = 0; l2 < lb.num; ++l2) { const int c = before_level[l2 + 1] - before_level[l2]; v += c < nms_post ? c : nms_post; }
+    nvalid = lb.num > 0 ? v : K;
+  }
+  __syncthreads();
+  auto valid = [&](int j) -> bool {
+    if (lb.num == 0) return true;
+    int l2 = 0;
+    while (l2 + 1 < lb.num && j >= before_level[l2 + 1]) ++l2;
+    return j - before_level[l2] < nms_post;
+  };
+  const int k = nvalid < top ? nvalid : top;
+  if (tid == 0) count[0] = k;
+  if (k == 0) return;
+  block_topk_sorted([&](int j) { return valid(j) ? sel_key(rows[keep[j] * cols + score_col]) : 0u; }, K, k, sk, si, sc);
+  for (int j = tid; j < k; j += kSelThreads) {
+    const int64_t r = keep[si[j]];
+    for (int c = 0; c < cols; ++c) out[(size_t)j * cols + c] = rows[r * cols + c];
+    if (out_idx) out_idx[j] = r;
+  }
+}
+
+}  // namespace obb
+
+extern "C" int obb_rpn_select_decode_f32(const float *const *cls_devs_host, const float *const *reg_devs_host,
+                                         const float *const *anchor_devs_host, const int *H_host, const int *W_host,
+                                         int num_levels, int num_anchors, int use_sigmoid, int nms_pre,
+                                         const float *means_host, const float *stds_host, float wh_ratio_clip,
+                                         int max_h, int max_w, float *dets_dev, int32_t *levels_dev,
+                                         int64_t *num_rows_host, void *stream) {
+  using namespace obb;
+  const char *who = "obb_rpn_select_decode_f32";
+  if (num_rows_host) *num_rows_host = 0;
+  if (num_levels < 1 || num_levels > OBB_MAX_LEVELS) return set_err(OBB_EINVAL, "%s: num_levels = %d (1..%d)", who, num_levels, OBB_MAX_LEVELS);
+  if (num_anchors < 1) return set_err(OBB_EINVAL, "%s: num_anchors = %d", who, num_anchors);
+  if (!cls_devs_host || !reg_devs_host || !anchor_devs_host || !H_host || !W_host || !means_host || !stds_host || !num_rows_host)
+    return set_err(OBB_EINVAL, "%s: null pointer", who);
+  if (nms_pre > kSelMax) return set_err(OBB_EINVAL, "%s: nms_pre = %d exceeds %d", who, nms_pre, kSelMax);
+  if (!(wh_ratio_clip > 0.0f)) return set_err(OBB_EINVAL, "%s: wh_ratio_clip must be positive", who);
+  RpnLevels lv = {};
+  int64_t total = 0;
+  for (int l = 0; l < num_levels; ++l) {
+    if (H_host[l] < 0 || W_host[l] < 0) return set_err(OBB_EINVAL, "%s: negative map size", who);
+    const int64_t n = (int64_t)H_host[l] * W_host[l] * num_anchors;
+    if (n > 2147483647LL / 8) return set_err(OBB_EINVAL, "%s: level %d too large", who, l);
+    if (n > 0 && (!cls_devs_host[l] || !reg_devs_host[l] || !anchor_devs_host[l])) return set_err(OBB_EINVAL, "%s: null level %d", who, l);
+    if (nms_pre <= 0 && n > kSelMax * 64) return set_err(OBB_EINVAL, "%s: nms_pre <= 0 with %lld anchors on level %d", who, (long long)n, l);
+    lv.cls[l] = cls_devs_host[l]; lv.reg[l] = reg_devs_host[l]; lv.anchors[l] = anchor_devs_host[l];
+    lv.H[l] = H_host[l]; lv.W[l] = W_host[l];
+    lv.out_base[l] = (int)total;
+    total += (nms_pre > 0 && n > nms_pre) ? nms_pre : n;
+  }
+  lv.out_base[num_levels] = (int)total;
+  *num_rows_host = total;
+  if (total == 0 || (!dets_dev && !levels_dev)) return OBB_OK;     // (sizing call: the row count depends on shapes only)
+  if (!dets_dev || !levels_dev) return set_err(OBB_EINVAL, "%s: null output", who);
+  for (int l = 0; l < num_levels; ++l)
+    if (reinterpret_cast<uintptr_t>(anchor_devs_host[l]) & 15u) return set_err(OBB_EINVAL, "%s: anchors must be 16-byte aligned", who);
+  BoxCodec c;
+  for (int k = 0; k < 4; ++k) { c.m[k] = means_host[k]; c.s[k] = stds_host[k]; }
+  c.max_ratio = fabsf(logf(wh_ratio_clip));
+  c.max_h = max_h; c.max_w = max_w;
+  hipLaunchKernelGGL(rpn_select_decode_kernel, dim3((unsigned)num_levels), dim3(kSelThreads), 0, (hipStream_t)stream, lv, num_anchors,
+                     use_sigmoid ? 1 : 0, nms_pre, c, dets_dev, levels_dev);
+  OBB_LAUNCH_CHECK();
+  return OBB_OK;
+}
+
+extern "C" int obb_rows_topk_f32(const float *rows_dev, int64_t num_rows, int cols, int score_col,
+                                 const int64_t *keep_dev, int64_t K, const int *level_base_host, int num_levels,
+                                 int nms_post, int top, float *out_dev, int64_t *out_idx_dev, int64_t *count_dev,
+                                 void *stream) {
+  using namespace obb;
+  const char *who = "obb_rows_topk_f32";
+  if (num_rows < 0 || K < 0 || cols < 1 || score_col < 0 || score_col >= cols) return set_err(OBB_EINVAL, "%s: bad shape", who);
+  if (num_levels < 0 || num_levels > OBB_MAX_LEVELS) return set_err(OBB_EINVAL, "%s: num_levels = %d", who, num_levels);
+  if (top < 0 || top > kSelMax) return set_err(OBB_EINVAL, "%s: top = %d (0..%d)", who, top, kSelMax);
+  if (K > 2147483647LL / 4 || num_rows > 2147483647LL) return set_err(OBB_EINVAL, "%s: too many rows", who);
+  if (!count_dev) return set_err(OBB_EINVAL, "%s: null pointer", who);
+  hipStream_t st = (hipStream_t)stream;
+  if (K == 0 || top == 0) {
+    OBB_HIP_TRY(hipMemsetAsync(count_dev, 0, sizeof(int64_t), st));
+    return OBB_OK;
+  }
+  if (!rows_dev || !keep_dev || !out_dev) return set_err(OBB_EINVAL, "%s: null pointer", who);
+  LevelBases lb = {};
+  lb.num = num_levels;
+  if (num_levels > 0) {
+    if (!level_base_host) return set_err(OBB_EINVAL, "%s: null level bases", who);
+    for (int l = 0; l <= num_levels; ++l) lb.base[l] = level_base_host[l];
+  }
+  if (nms_post <= 0) nms_post = 2147483647;
+  hipLaunchKernelGGL(rows_topk_kernel, dim3(1), dim3(kSelThreads), 0, st, rows_dev, cols, score_col, keep_dev, (int)K, lb, nms_post, top,
+                     out_dev, out_idx_dev, count_dev);
+  OBB_LAUNCH_CHECK();
+  return OBB_OK;
+}

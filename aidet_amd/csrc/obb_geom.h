@@ -1,4 +1,4 @@
-// obb_geom.cuh -- device geometry core ("OBB-GEOM v1") for gfx950.
+// obb_geom.h -- device geometry core ("OBB-GEOM v1") for gfx950.
 //
 // Register-only, branch-free convex quad x convex quad intersection for wave64:
 // the subject is kept as up to 8 boundary SEGMENTS with compile-time indices

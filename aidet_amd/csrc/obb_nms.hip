@@ -52,7 +52,7 @@
 #include <string.h>
 
 #include "obb_common.h"
-#include "obb_geom.cuh"
+#include "obb_geom.h"
 
 namespace obb {
 
@@ -159,36 +159,23 @@ __device__ __forceinline__ void hbb_record(const float *__restrict__ row, QuadRe
   wellformed = ((x2 - x1) + 1.0f > 0.0f) && ((y2 - y1) + 1.0f > 0.0f);
 }
 
-// ---- 1: prep -------------------------------------------------------------------
-constexpr int kStat = 5;   // per-block statistics of the box centres (doubles)
-// part[block] = { max key(xhi), max ~key(xlo), max key(yhi), max ~key(ylo) } of the block's
-// boxes near its mean centre; pstat[block] = their count and centre sums
+// ---- 1: prep (DIRECT route: positions are box ids, no global frame, no spatial sort) ----------------------
+// per box: 64-byte quad record, conservative float interval, area; clears the call's counters
 template <int KIND>
 __global__ __launch_bounds__(256) void nms_prep_kernel(const float *__restrict__ dets, int64_t n,
                                                        QuadRec *__restrict__ rec,
                                                        float4 *__restrict__ iv,
                                                        float *__restrict__ ar,
-                                                       uint4 *__restrict__ part,
-                                                       double *__restrict__ pstat,
                                                        const int32_t *__restrict__ group,
                                                        const float *__restrict__ thrs,
                                                        float thr, uint4 *__restrict__ zero,
                                                        size_t zero_vecs) {
   constexpr int S = KIND == 0 ? 6 : (KIND == 1 ? 9 : 5);
-  __shared__ uint4 wred[4];
-  __shared__ double sred[4][kStat];
-  __shared__ double ssum[kStat];
-  __shared__ uint4 cred[4];
-  double st[kStat] = {0.0, 0.0, 0.0, 0.0, 0.0};   // count, sum x, sum y, sum x^2, sum y^2 of the centres
-  // clear the counters / flags / histogram of this call (nothing reads them before the
-  // next kernel): saves the separate fill launch
+  // clear the counters / flags of this call (nothing reads them before the next kernel): saves the separate
+  // fill launch
   for (size_t z = (size_t)blockIdx.x * blockDim.x + threadIdx.x; z < zero_vecs;
        z += (size_t)gridDim.x * blockDim.x)
     zero[z] = make_uint4(0u, 0u, 0u, 0u);
-  float4 mine = make_float4(1.0f, -1.0f, 1.0f, -1.0f);   // this thread's (last) interval
-  uint32_t axh = 0, axl = 0, ayh = 0, ayl = 0;   // bounding box of all finite intervals (keys)
-  uint32_t cxh = 0, cxl = 0, cyh = 0, cyl = 0;   // bounding box of their centres
-  const bool single = (int64_t)gridDim.x * blockDim.x >= n;   // one box per thread: no re-read below
   for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n;
        b += (int64_t)gridDim.x * blockDim.x) {
     const float *row = dets + b * S;
@@ -215,100 +202,6 @@ __global__ __launch_bounds__(256) void nms_prep_kernel(const float *__restrict__
                      (fabs_sel(v.w) < big);
     if (!fin) { v.x = 1.0f; v.y = -1.0f; v.z = 1.0f; v.w = -1.0f; }  // lo > hi = "isolated"
     iv[b] = v;
-    mine = v;
-    if (fin) {
-      const double cx = 0.5 * ((double)v.x + (double)v.y), cy = 0.5 * ((double)v.z + (double)v.w);
-      st[0] += 1.0; st[1] += cx; st[2] += cy; st[3] += cx * cx; st[4] += cy * cy;
-      axh = max(axh, fkey(v.y)); axl = max(axl, ~fkey(v.x));
-      ayh = max(ayh, fkey(v.w)); ayl = max(ayl, ~fkey(v.z));
-      const float fx = (float)cx, fy = (float)cy;
-      cxh = max(cxh, fkey(fx)); cxl = max(cxl, ~fkey(fx));
-      cyh = max(cyh, fkey(fy)); cyl = max(cyl, ~fkey(fy));
-    }
-  }
-  if (!part) return;   // direct route: no global frame, no statistics
-  // Statistics for the ROBUST quantisation frame (nms_quant_kernel): the block's bounding
-  // box and centre sums are taken over its boxes within 3 sigma of the BLOCK's mean centre
-  // only (a uniform block spans 1.7 sigma: nothing is dropped; a stray box at 1e8 is).  Which
-  // boxes shape the frame never changes the result, only how well the grid fits the scene.
-  auto block_sum = [&](double (&v)[kStat]) {   // -> ssum[], valid after the barriers
-#pragma unroll
-    for (int k = 0; k < kStat; ++k)
-      for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o);
-    if ((threadIdx.x & 63) == 0)
-      for (int k = 0; k < kStat; ++k) sred[threadIdx.x >> 6][k] = v[k];
-    __syncthreads();
-    if (threadIdx.x < kStat) ssum[threadIdx.x] = (sred[0][threadIdx.x] + sred[1][threadIdx.x]) + (sred[2][threadIdx.x] + sred[3][threadIdx.x]);
-    __syncthreads();
-  };
-  for (int o = 32; o > 0; o >>= 1) {
-    axh = max(axh, shfl_xor_u(axh, o)); axl = max(axl, shfl_xor_u(axl, o));
-    ayh = max(ayh, shfl_xor_u(ayh, o)); ayl = max(ayl, shfl_xor_u(ayl, o));
-    cxh = max(cxh, shfl_xor_u(cxh, o)); cxl = max(cxl, shfl_xor_u(cxl, o));
-    cyh = max(cyh, shfl_xor_u(cyh, o)); cyl = max(cyl, shfl_xor_u(cyl, o));
-  }
-  if ((threadIdx.x & 63) == 0) {
-    wred[threadIdx.x >> 6] = make_uint4(axh, axl, ayh, ayl);
-    cred[threadIdx.x >> 6] = make_uint4(cxh, cxl, cyh, cyl);
-  }
-  block_sum(st);   // (its barriers also publish wred / cred)
-  double mx = 0.0, my = 0.0, rx = 0.0, ry = 0.0;
-  bool trim = false;
-  if (ssum[0] >= 1.0) {
-    mx = ssum[1] / ssum[0]; my = ssum[2] / ssum[0];
-    const double vx = ssum[3] / ssum[0] - mx * mx, vy = ssum[4] / ssum[0] - my * my;
-    rx = 3.0 * sqrt(vx > 0.0 ? vx : 0.0) * 1.000001 + 1e-30 + 1e-9 * (mx < 0.0 ? -mx : mx);
-    ry = 3.0 * sqrt(vy > 0.0 ? vy : 0.0) * 1.000001 + 1e-30 + 1e-9 * (my < 0.0 ? -my : my);
-    uint4 c = cred[0];
-    for (int k = 1; k < 4; ++k) {
-      c.x = max(c.x, cred[k].x); c.y = max(c.y, cred[k].y);
-      c.z = max(c.z, cred[k].z); c.w = max(c.w, cred[k].w);
-    }
-    // any centre further than 3 sigma from the block's mean?  (block-uniform)
-    trim = (double)fkey_inv(c.x) - mx > rx || mx - (double)fkey_inv(~c.y) > rx ||
-           (double)fkey_inv(c.z) - my > ry || my - (double)fkey_inv(~c.w) > ry;
-  }
-  if (!trim) {   // the usual case: the block's own bounding box and sums stand
-    if (threadIdx.x == 0) {
-      uint4 a = wred[0];
-      for (int k = 1; k < 4; ++k) {
-        a.x = max(a.x, wred[k].x); a.y = max(a.y, wred[k].y);
-        a.z = max(a.z, wred[k].z); a.w = max(a.w, wred[k].w);
-      }
-      part[blockIdx.x] = a;
-      for (int k = 0; k < kStat; ++k) pstat[(size_t)blockIdx.x * kStat + k] = ssum[k];
-    }
-    return;
-  }
-  __syncthreads();   // ssum / wred are rewritten below
-  uint32_t mxh = 0, mxl = 0, myh = 0, myl = 0;
-  double tr[kStat] = {0.0, 0.0, 0.0, 0.0, 0.0};
-  for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n;
-       b += (int64_t)gridDim.x * blockDim.x) {
-    const float4 v = single ? mine : iv[b];   // (this thread's own store)
-    if (!(v.x <= v.y)) continue;
-    const double cx = 0.5 * ((double)v.x + (double)v.y), cy = 0.5 * ((double)v.z + (double)v.w);
-    const double dx = cx - mx, dy = cy - my;
-    if ((dx < 0.0 ? -dx : dx) <= rx && (dy < 0.0 ? -dy : dy) <= ry) {
-      mxh = max(mxh, fkey(v.y)); mxl = max(mxl, ~fkey(v.x));
-      myh = max(myh, fkey(v.w)); myl = max(myl, ~fkey(v.z));
-      tr[0] += 1.0; tr[1] += cx; tr[2] += cy; tr[3] += cx * cx; tr[4] += cy * cy;
-    }
-  }
-  for (int o = 32; o > 0; o >>= 1) {
-    mxh = max(mxh, shfl_xor_u(mxh, o)); mxl = max(mxl, shfl_xor_u(mxl, o));
-    myh = max(myh, shfl_xor_u(myh, o)); myl = max(myl, shfl_xor_u(myl, o));
-  }
-  if ((threadIdx.x & 63) == 0) wred[threadIdx.x >> 6] = make_uint4(mxh, mxl, myh, myl);
-  block_sum(tr);   // (its barriers also publish wred)
-  if (threadIdx.x == 0) {
-    uint4 a = wred[0];
-    for (int k = 1; k < 4; ++k) {
-      a.x = max(a.x, wred[k].x); a.y = max(a.y, wred[k].y);
-      a.z = max(a.z, wred[k].z); a.w = max(a.w, wred[k].w);
-    }
-    part[blockIdx.x] = a;
-    for (int k = 0; k < kStat; ++k) pstat[(size_t)blockIdx.x * kStat + k] = ssum[k];
   }
 }
 
@@ -336,185 +229,8 @@ __device__ __forceinline__ uint32_t spread15(uint32_t v) {  // 15 bits -> even b
   return v;
 }
 
-// floor() of a monotone map is monotone, so lo_a <= hi_b ==> q(lo_a) <= q(hi_b):
-// the quantised test never loses a real overlap.
-__global__ __launch_bounds__(256) void nms_quant_kernel(const float4 *__restrict__ iv, int64_t n,
-                                                        const uint4 *__restrict__ part,
-                                                        const double *__restrict__ pstat, int nparts,
-                                                        uint2 *__restrict__ qb,
-                                                        uint32_t *__restrict__ ckey,
-                                                        uint32_t *__restrict__ crank,
-                                                        uint32_t *__restrict__ hist, int cell_hbits,
-                                                        float *__restrict__ cellpx,
-                                                        const int32_t *__restrict__ group,
-                                                        int *__restrict__ ginfo) {
-  __shared__ uint4 wred[4];
-  __shared__ double dred[4][kStat];
-  __shared__ double dsum[kStat];
-  __shared__ float sb[4];
-  __shared__ float win[4];     // window of the robust frame: x lo, x hi, y lo, y hi
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  // this thread's first box is requested now: its memory round trip overlaps the reduction below
-  const int64_t b_first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  float4 v_first = make_float4(1.0f, -1.0f, 1.0f, -1.0f);
-  if (b_first < n) v_first = iv[b_first];
-  // (every block repeats this reduction of <= 1024 partials: cheaper than one more launch)
-  uint4 a = make_uint4(0u, 0u, 0u, 0u);
-  for (int k = threadIdx.x; k < nparts; k += 256) {
-    const uint4 p = part[k];
-    a.x = max(a.x, p.x); a.y = max(a.y, p.y); a.z = max(a.z, p.z); a.w = max(a.w, p.w);
-  }
-  for (int o = 32; o > 0; o >>= 1) {
-    a.x = max(a.x, shfl_xor_u(a.x, o)); a.y = max(a.y, shfl_xor_u(a.y, o));
-    a.z = max(a.z, shfl_xor_u(a.z, o)); a.w = max(a.w, shfl_xor_u(a.w, o));
-  }
-  if (lane == 0) wred[wv] = a;
-  // ROBUST FRAME.  Any frame gives the same result (coordinates clamp into it, and a
-  // clamped monotone map is monotone), but one far-away box would stretch the bounding
-  // box of the scene until all other boxes share a handful of cells (measured: 0.13 ->
-  // 10 ms at n = 100k for ONE box at 1e8).  So: a first window = mean +- 8 sigma of the
-  // box centres; the frame = bounding box of the prep blocks that lie inside it.
-  auto block_sum = [&](double (&v)[kStat]) {   // -> dsum[], valid after the barrier
-#pragma unroll
-    for (int k = 0; k < kStat; ++k)
-      for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o);
-    if (lane == 0)
-      for (int k = 0; k < kStat; ++k) dred[wv][k] = v[k];
-    __syncthreads();
-    if (threadIdx.x < kStat) dsum[threadIdx.x] = (dred[0][threadIdx.x] + dred[1][threadIdx.x]) + (dred[2][threadIdx.x] + dred[3][threadIdx.x]);
-    __syncthreads();
-  };
-  auto window = [&](float x0, float x1, float y0, float y1) {   // thread 0: dsum -> win[], inside [x0,x1] x [y0,y1]
-    const double cnt = dsum[0];
-    float wx0 = x0, wx1 = x1, wy0 = y0, wy1 = y1;
-    if (cnt >= 1.0) {
-      const double mx = dsum[1] / cnt, my = dsum[2] / cnt;
-      double vx = dsum[3] / cnt - mx * mx, vy = dsum[4] / cnt - my * my;
-      vx = vx > 0.0 ? vx : 0.0; vy = vy > 0.0 ? vy : 0.0;
-      // + the largest box extent does not matter: intervals beyond the window clamp
-      const double rx = 8.0 * sqrt(vx), ry = 8.0 * sqrt(vy);
-      wx0 = max_sel(x0, (float)(mx - rx)); wx1 = min_sel(x1, (float)(mx + rx));
-      wy0 = max_sel(y0, (float)(my - ry)); wy1 = min_sel(y1, (float)(my + ry));
-      if (!(wx0 <= wx1)) { wx0 = x0; wx1 = x1; }
-      if (!(wy0 <= wy1)) { wy0 = y0; wy1 = y1; }
-    }
-    win[0] = wx0; win[1] = wx1; win[2] = wy0; win[3] = wy1;
-  };
-  double sv[kStat] = {0.0, 0.0, 0.0, 0.0, 0.0};
-  for (int k = threadIdx.x; k < nparts; k += 256)
-    for (int j = 0; j < kStat; ++j) sv[j] += pstat[(size_t)k * kStat + j];
-  block_sum(sv);   // (its barriers also publish wred)
-  float bx0 = 0.0f, bx1 = 0.0f, by0 = 0.0f, by1 = 0.0f;   // bounding box of the finite boxes
-  bool any;
-  {
-    uint4 m = wred[0];
-    for (int k = 1; k < 4; ++k) {
-      m.x = max(m.x, wred[k].x); m.y = max(m.y, wred[k].y);
-      m.z = max(m.z, wred[k].z); m.w = max(m.w, wred[k].w);
-    }
-    any = m.x != 0u;  // at least one finite box
-    if (any) { bx0 = fkey_inv(~m.y); bx1 = fkey_inv(m.x); by0 = fkey_inv(~m.w); by1 = fkey_inv(m.z); }
-  }
-  if (threadIdx.x == 0) window(bx0, bx1, by0, by1);
-  __syncthreads();
-  // (the usual case -- the window holds the whole bounding box, every block is clean -- needs
-  // no second pass: block-uniform)
-  const bool cut = win[0] > bx0 || win[1] < bx1 || win[2] > by0 || win[3] < by1;
-  if (cut) {
-    // the frame = bounding box of the CLEAN blocks: those whose own bounding box lies inside
-    // the first window (a block with an outlier is dropped whole; without outliers every
-    // block is clean and this is the bounding box of the scene)
-    const float wx0 = win[0], wx1 = win[1], wy0 = win[2], wy1 = win[3];
-    uint4 c = make_uint4(0u, 0u, 0u, 0u);
-    double s2[kStat] = {0.0, 0.0, 0.0, 0.0, 0.0};   // [0]: boxes in clean blocks
-    for (int k = threadIdx.x; k < nparts; k += 256) {
-      const uint4 p = part[k];
-      if (p.x == 0u) continue;   // no finite box in that block
-      const bool inside = fkey_inv(~p.y) >= wx0 && fkey_inv(p.x) <= wx1 && fkey_inv(~p.w) >= wy0 && fkey_inv(p.z) <= wy1;
-      if (inside) {
-        c.x = max(c.x, p.x); c.y = max(c.y, p.y); c.z = max(c.z, p.z); c.w = max(c.w, p.w);
-        s2[0] += pstat[(size_t)k * kStat];
-      }
-    }
-    for (int o = 32; o > 0; o >>= 1) {
-      c.x = max(c.x, shfl_xor_u(c.x, o)); c.y = max(c.y, shfl_xor_u(c.y, o));
-      c.z = max(c.z, shfl_xor_u(c.z, o)); c.w = max(c.w, shfl_xor_u(c.w, o));
-    }
-    if (lane == 0) wred[wv] = c;   // (the previous contents were consumed before the last barrier)
-    block_sum(s2);
-  }
-  if (threadIdx.x == 0) {
-    // enough clean blocks: their bounding box is the frame (otherwise outliers are everywhere
-    // -- a multi-modal scene -- and the first window stays)
-    if (cut && (dsum[0] * 8.0 >= (double)n || dsum[0] >= 4096.0)) {
-      uint4 m = wred[0];
-      for (int k = 1; k < 4; ++k) {
-        m.x = max(m.x, wred[k].x); m.y = max(m.y, wred[k].y);
-        m.z = max(m.z, wred[k].z); m.w = max(m.w, wred[k].w);
-      }
-      win[0] = fkey_inv(~m.y); win[1] = fkey_inv(m.x); win[2] = fkey_inv(~m.w); win[3] = fkey_inv(m.z);
-    }
-    const float x0 = win[0], x1 = win[1], y0 = win[2], y1 = win[3];
-    const float rx = any ? x1 - x0 : 0.0f, ry = any ? y1 - y0 : 0.0f;
-    sb[0] = any ? x0 : 0.0f; sb[1] = any ? y0 : 0.0f;
-    sb[2] = rx > 0.0f ? (float)kQMax / rx : 0.0f;
-    sb[3] = ry > 0.0f ? (float)kQMax / ry : 0.0f;
-    if (blockIdx.x == 0) {
-      // pixels per cell, rounded UP (used for an upper bound of AABB overlaps)
-      cellpx[0] = rx > 0.0f ? (rx / (float)kQMax) * 1.000001f : 0.0f;
-      cellpx[1] = ry > 0.0f ? (ry / (float)kQMax) * 1.000001f : 0.0f;
-    }
-  }
-  __syncthreads();
-  // bucket bits of a grouped call (every block repeats the estimate: 1024 loads)
-  int gbits = 0;
-  if (group) {
-    __shared__ uint32_t gbm[128];   // 4096-bit map of 12-bit group hashes
-    if (threadIdx.x < 128) gbm[threadIdx.x] = 0u;
-    __syncthreads();
-    const int64_t ns = n < 1024 ? n : 1024;
-    for (int64_t k = threadIdx.x; k < ns; k += 256) {
-      const uint32_t h = group_hash(group[(k * n) / ns]) >> 20;
-      atomicOr(&gbm[h >> 5], 1u << (h & 31u));
-    }
-    __syncthreads();
-    int d = 0;
-    for (int k = 0; k < 128; ++k) d += __popc(gbm[k]);   // (uniform: every thread the same)
-    const int total = 2 * cell_hbits;
-    int want = 0;
-    while ((1 << want) < d) ++want;
-    want = (d * 10 >= (int)ns * 7) ? total : want + 2;   // samples nearly all distinct: "very many groups"
-    gbits = d <= 1 ? 0 : (want > total - 4 ? total - 4 : want);
-    if (blockIdx.x == 0 && threadIdx.x == 0) ginfo[0] = gbits;
-  }
-  const int cbits = 2 * cell_hbits - gbits;
-  const float bx = sb[0], by = sb[1], sx = sb[2], sy = sb[3];
-  auto qz = [](float x, float b, float s) {
-    float u = floorf((x - b) * s);
-    u = u < 0.0f ? 0.0f : (u > (float)kQMax ? (float)kQMax : u);
-    return (uint32_t)u;
-  };
-  for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n;
-       b += (int64_t)gridDim.x * blockDim.x) {
-    const float4 v = (b == b_first) ? v_first : iv[b];
-    uint2 o = make_uint2(kSentLo, kSentHi);
-    uint32_t mk = (1u << (2 * cell_hbits)) - 1u;  // isolated boxes go to the last cell
-    if (v.x <= v.y) {
-      const uint32_t xl = qz(v.x, bx, sx), xh = qz(v.y, bx, sx);
-      const uint32_t yl = qz(v.z, by, sy), yh = qz(v.w, by, sy);
-      o.x = xl | (yl << 16);
-      o.y = (xh | (yh << 16)) | kGuard;
-      const int sh = 16 - cell_hbits;  // (lo + hi) is a 16-bit centre*2: keep its top bits
-      mk = spread15((xl + xh) >> sh) | (spread15((yl + yh) >> sh) << 1);
-      if (gbits > 0) mk = (group_bucket(group[b], gbits) << cbits) | (mk >> gbits);   // bucket, then coarser space
-    }
-    qb[b] = o;
-    ckey[b] = mk;
-    // the count of the cell AND this box's rank inside it: the scatter pass then needs no second
-    // round of atomics (which cost per request, not per byte: 1.25e6 scattered ones take ~45 us)
-    crank[b] = atomicAdd(&hist[mk], 1u);
-  }
-}
+// (floor() of a monotone map is monotone, so lo_a <= hi_b ==> q(lo_a) <= q(hi_b): the quantised test of
+// nms_prepq_kernel never loses a real overlap.)
 
 // exclusive scan of the cell counts, in place (one block, PER cells per thread;
 // the cell count adapts to n so that this stays a few microseconds)
@@ -596,55 +312,379 @@ __global__ __launch_bounds__(256) void nms_cellscan_big_kernel(uint32_t *__restr
   *h4 = o;
 }
 
-__global__ __launch_bounds__(256) void nms_scatter_kernel(const uint32_t *__restrict__ ckey,
-                                                          const uint32_t *__restrict__ crank,
-                                                          int64_t n, const uint32_t *__restrict__ offs,
-                                                          uint32_t *__restrict__ sid) {
-  for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n;
-       b += (int64_t)gridDim.x * blockDim.x)
-    sid[offs[ckey[b]] + crank[b]] = (uint32_t)b;
+
+// =====================================================================================================
+// Round 3: the front half of the sorted route in THREE launches instead of six
+//   frame     clears the call's counters / histogram / tile-box words (all blocks) and, in block 0, takes the
+//             quantisation frame from a strided SAMPLE of <= 4096 boxes (conservative boxes without
+//             trigonometry, three rounds of 3-sigma trimming in fp32 about the previous mean).  Any frame
+//             gives the same keep set (coordinates clamp into it; DESIGN 3.1 "robust frame") -- only the
+//             speed depends on how well it fits, so a sample is as good as the exact bounding box that the
+//             prep kernel used to reduce in fp64 over all boxes, and the two kernels that produced and
+//             consumed those partials (prep: 11 us, quant: 10.6 us at 100k boxes) become one pass.
+//   prepq     per box: quad record, conservative interval -> grid over the frame, Morton cell, histogram
+//             add whose returned value is the box's rank inside its cell.
+//   sortscat  every block scans the (<= 16384) cell counts into LDS for itself (64 KB from L2: cheaper than
+//             a launch boundary), then writes its boxes' packed intervals and 16-byte records straight to
+//             their sorted positions -- the cell scan, the index scatter and the gather half of the permute
+//             kernel in one launch.
+// The tile / sub-tile boxes are then reduced by the CULL kernel itself (nms_cullbox_kernel): a block takes a
+// ticket, reduces the boxes of tile `ticket`, publishes the tile box as one 8-byte word and tests its sub-tiles
+// against the tiles of all EARLIER tickets, polling their words (they have all started, none waits for anybody
+// before publishing: no deadlock; the hand-over pattern of nms_compact_kernel).
+// =====================================================================================================
+constexpr int kFrameSamples = 4096;
+struct alignas(16) NmsFrame { float bx, by, sx, sy; float cpx, cpy; int gbits; int any; };
+
+// conservative axis-aligned box of one input row, no trigonometry (frame only: never affects a result)
+template <int KIND>
+__device__ __forceinline__ float4 sample_box(const float *__restrict__ row) {
+  float lox, hix, loy, hiy;
+  if (KIND == 0) {
+    const float cx = row[0], cy = row[1], w = row[2], h = row[3];
+    const float r = 0.5f * sqrtf(w * w + h * h) * 1.000001f;   // half diagonal >= both half extents
+    lox = cx - r; hix = cx + r; loy = cy - r; hiy = cy + r;
+  } else if (KIND == 2) {
+    lox = row[0] - 0.5f; hix = row[2] + 0.5f; loy = row[1] - 0.5f; hiy = row[3] + 0.5f;
+  } else {
+    lox = min_sel(min_sel(row[0], row[2]), min_sel(row[4], row[6])); hix = max_sel(max_sel(row[0], row[2]), max_sel(row[4], row[6]));
+    loy = min_sel(min_sel(row[1], row[3]), min_sel(row[5], row[7])); hiy = max_sel(max_sel(row[1], row[3]), max_sel(row[5], row[7]));
+  }
+  const float big = 3.0e38f;
+  const bool fin = (fabs_sel(lox) < big) && (fabs_sel(hix) < big) && (fabs_sel(loy) < big) && (fabs_sel(hiy) < big) && lox <= hix && loy <= hiy;
+  return fin ? make_float4(lox, hix, loy, hiy) : make_float4(1.0f, -1.0f, 1.0f, -1.0f);
 }
 
-// ---- 4: permute into spatial order + tile bounding boxes ---------------------------
-// one block = one tile of 256 spatial positions
-__global__ __launch_bounds__(256) void nms_permute_kernel(const uint2 *__restrict__ qb,
-                                                          const uint32_t *__restrict__ sid,
-                                                          const float *__restrict__ ar_in,
-                                                          int64_t n, uint2 *__restrict__ qs,
-                                                          uint4 *__restrict__ pf,
+template <int KIND>
+__global__ __launch_bounds__(1024) void nms_frame_kernel(const float *__restrict__ dets, int64_t n,
+                                                        const int32_t *__restrict__ group, int cell_hbits,
+                                                        NmsFrame *__restrict__ frame,
+                                                        uint4 *__restrict__ zero, size_t zero_vecs) {
+  constexpr int S = KIND == 0 ? 6 : (KIND == 1 ? 9 : 5);
+  for (size_t z = (size_t)blockIdx.x * blockDim.x + threadIdx.x; z < zero_vecs; z += (size_t)gridDim.x * blockDim.x)
+    zero[z] = make_uint4(0u, 0u, 0u, 0u);
+  if (blockIdx.x != 0) return;
+  __shared__ float4 sm[kFrameSamples];       // lo x, hi x, lo y, hi y of every sample (lo > hi: not finite)
+  __shared__ float red[16][8];
+  __shared__ float tot[8];
+  __shared__ uint32_t gbm[128];
+  constexpr int T = 1024, PER = kFrameSamples / T;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int ns = (int)(n < kFrameSamples ? n : kFrameSamples);
+  const int64_t stride = n / ns;                        // (>= 1; the samples cover [0, ns * stride))
+  {  // all of a thread's rows are requested before the first is used (a loop of dependent round trips took 30 us)
+    float4 b[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int i = tid + u * T;
+      b[u] = i < ns ? sample_box<KIND>(dets + ((int64_t)i * stride) * S) : make_float4(1.0f, -1.0f, 1.0f, -1.0f);
+    }
+#pragma unroll
+    for (int u = 0; u < PER; ++u) sm[tid + u * T] = b[u];
+  }
+  if (tid < 128) gbm[tid] = 0u;
+  __syncthreads();
+  // block-wide sums of up to 8 floats -> tot[], valid after the call
+  auto block_sum = [&](float (&v)[8], int m) {
+    for (int k = 0; k < m; ++k)
+      for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o);
+    if (lane == 0) for (int k = 0; k < m; ++k) red[wv][k] = v[k];
+    __syncthreads();
+    if (tid < m) {
+      float a = 0.0f;
+      for (int w2 = 0; w2 < 16; ++w2) a += red[w2][tid];
+      tot[tid] = a;
+    }
+    __syncthreads();
+  };
+  __shared__ uint4 wred[16];
+  __shared__ uint4 bbox_all;
+  // ---- the usual case in ONE pass: centre statistics about the first sample (fp32: the shift keeps a scene far from
+  // the origin from cancelling) and the bounding box of all finite samples.  No centre further than 3.5 sigma from
+  // the mean (a uniform scene spans 1.7 sigma) = no outlier: the bounding box is the frame.
+  float mx = 0.0f, my = 0.0f, wx = 3.0e38f, wy = 3.0e38f;     // window = mean +- (wx, wy)
+  float cnt_in = 0.0f;
+  bool robust = false;
+  {
+    const float4 b0 = sm[0];
+    const float px = b0.x <= b0.y ? 0.5f * (b0.x + b0.y) : 0.0f, py = b0.x <= b0.y ? 0.5f * (b0.z + b0.w) : 0.0f;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    uint32_t axh = 0, axl = 0, ayh = 0, ayl = 0, cxh = 0, cxl = 0, cyh = 0, cyl = 0;
+    for (int i = tid; i < ns; i += T) {
+      const float4 b = sm[i];
+      if (!(b.x <= b.y)) continue;
+      const float cx = 0.5f * (b.x + b.y), cy = 0.5f * (b.z + b.w);
+      const float dx = cx - px, dy = cy - py;
+      v[0] += 1.0f; v[1] += dx; v[2] += dy; v[3] += dx * dx; v[4] += dy * dy;
+      axh = max(axh, fkey(b.y)); axl = max(axl, ~fkey(b.x)); ayh = max(ayh, fkey(b.w)); ayl = max(ayl, ~fkey(b.z));
+      cxh = max(cxh, fkey(cx)); cxl = max(cxl, ~fkey(cx)); cyh = max(cyh, fkey(cy)); cyl = max(cyl, ~fkey(cy));
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      axh = max(axh, shfl_xor_u(axh, o)); axl = max(axl, shfl_xor_u(axl, o));
+      ayh = max(ayh, shfl_xor_u(ayh, o)); ayl = max(ayl, shfl_xor_u(ayl, o));
+      cxh = max(cxh, shfl_xor_u(cxh, o)); cxl = max(cxl, shfl_xor_u(cxl, o));
+      cyh = max(cyh, shfl_xor_u(cyh, o)); cyl = max(cyl, shfl_xor_u(cyl, o));
+    }
+    __shared__ uint4 cred[16];
+    if (lane == 0) { wred[wv] = make_uint4(axh, axl, ayh, ayl); cred[wv] = make_uint4(cxh, cxl, cyh, cyl); }
+    block_sum(v, 5);   // (its barriers also publish wred / cred)
+    uint4 m = wred[0], c = cred[0];
+    for (int k = 1; k < 16; ++k) {
+      m.x = max(m.x, wred[k].x); m.y = max(m.y, wred[k].y); m.z = max(m.z, wred[k].z); m.w = max(m.w, wred[k].w);
+      c.x = max(c.x, cred[k].x); c.y = max(c.y, cred[k].y); c.z = max(c.z, cred[k].z); c.w = max(c.w, cred[k].w);
+    }
+    if (tid == 0) bbox_all = m;
+    const float cnt = tot[0];
+    if (cnt >= 1.0f) {
+      const float ex = tot[1] / cnt, ey = tot[2] / cnt;
+      float vx = tot[3] / cnt - ex * ex, vy = tot[4] / cnt - ey * ey;
+      vx = vx > 0.0f ? vx : 0.0f; vy = vy > 0.0f ? vy : 0.0f;
+      mx = px + ex; my = py + ey;
+      const float rx = 3.5f * sqrtf(vx) * 1.000001f + 1e-30f + 1e-5f * (fabs_sel(mx) + fabs_sel(px));
+      const float ry = 3.5f * sqrtf(vy) * 1.000001f + 1e-30f + 1e-5f * (fabs_sel(my) + fabs_sel(py));
+      // any centre beyond the window?  (block-uniform; a non-finite variance -- overflow -- also lands here)
+      robust = !(fkey_inv(c.x) - mx <= rx && mx - fkey_inv(~c.y) <= rx && fkey_inv(c.z) - my <= ry && my - fkey_inv(~c.w) <= ry);
+      cnt_in = cnt;
+    }
+    __syncthreads();
+  }
+  // ---- outliers: three rounds of 3-sigma trimming about the previous mean (round 0: the plain mean, in case the
+  // first sample itself was the outlier), then a generous last window (8 sigma: intervals beyond it just clamp)
+  if (robust) {
+    mx = 0.0f; my = 0.0f; wx = 3.0e38f; wy = 3.0e38f;
+    for (int round = 0; round < 4; ++round) {
+      float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      for (int i = tid; i < ns; i += T) {
+        const float4 b = sm[i];
+        if (!(b.x <= b.y)) continue;
+        const float dx = 0.5f * (b.x + b.y) - mx, dy = 0.5f * (b.z + b.w) - my;
+        if (fabs_sel(dx) <= wx && fabs_sel(dy) <= wy) { v[0] += 1.0f; v[1] += dx; v[2] += dy; v[3] += dx * dx; v[4] += dy * dy; }
+      }
+      block_sum(v, 5);
+      const float c = tot[0];
+      if (!(c >= 1.0f)) break;                    // (block-uniform) nothing inside: keep the previous window
+      cnt_in = c;
+      const float ex = tot[1] / c, ey = tot[2] / c;
+      float vx = tot[3] / c - ex * ex, vy = tot[4] / c - ey * ey;
+      vx = vx > 0.0f ? vx : 0.0f; vy = vy > 0.0f ? vy : 0.0f;
+      mx += ex; my += ey;
+      const float k = round < 3 ? 3.0f : 8.0f;
+      if (round > 0) {
+        wx = k * sqrtf(vx) * 1.000001f + 1e-30f + 1e-6f * fabs_sel(mx);
+        wy = k * sqrtf(vy) * 1.000001f + 1e-30f + 1e-6f * fabs_sel(my);
+      }
+      __syncthreads();
+    }
+  }
+  // frame = bounding box of the samples whose centre lies inside the last window (all finite samples when there was
+  // no outlier, or when the window leaves too few: a multi-modal scene keeps its bounding box)
+  const bool trim = robust && cnt_in * 8.0f >= (float)ns;
+  if (trim) {    // (block-uniform)
+    uint32_t axh = 0, axl = 0, ayh = 0, ayl = 0;
+    for (int i = tid; i < ns; i += T) {
+      const float4 b = sm[i];
+      if (!(b.x <= b.y)) continue;
+      const float dx = 0.5f * (b.x + b.y) - mx, dy = 0.5f * (b.z + b.w) - my;
+      if (fabs_sel(dx) <= wx && fabs_sel(dy) <= wy) {
+        axh = max(axh, fkey(b.y)); axl = max(axl, ~fkey(b.x));
+        ayh = max(ayh, fkey(b.w)); ayl = max(ayl, ~fkey(b.z));
+      }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      axh = max(axh, shfl_xor_u(axh, o)); axl = max(axl, shfl_xor_u(axl, o));
+      ayh = max(ayh, shfl_xor_u(ayh, o)); ayl = max(ayl, shfl_xor_u(ayl, o));
+    }
+    if (lane == 0) wred[wv] = make_uint4(axh, axl, ayh, ayl);
+  }
+  // bucket bits of a grouped call: distinct 12-bit group hashes among <= 1024 strided samples
+  if (group) {
+    const int64_t gs = n < 1024 ? n : 1024;
+    for (int64_t k = tid; k < gs; k += T) {
+      const uint32_t h = group_hash(group[(k * n) / gs]) >> 20;
+      atomicOr(&gbm[h >> 5], 1u << (h & 31u));
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    uint4 m = bbox_all;
+    if (trim) {
+      m = wred[0];
+      for (int k = 1; k < 16; ++k) {
+        m.x = max(m.x, wred[k].x); m.y = max(m.y, wred[k].y);
+        m.z = max(m.z, wred[k].z); m.w = max(m.w, wred[k].w);
+      }
+    }
+    NmsFrame f;
+    f.any = m.x != 0u;
+    float x0 = 0.0f, x1 = 0.0f, y0 = 0.0f, y1 = 0.0f;
+    if (f.any) { x0 = fkey_inv(~m.y); x1 = fkey_inv(m.x); y0 = fkey_inv(~m.w); y1 = fkey_inv(m.z); }
+    // the sample misses the outermost boxes by ~range / samples: a margin of 8 such steps (cells are 1 / 32767)
+    const float gx = (x1 - x0) * (8.0f / (float)kFrameSamples), gy = (y1 - y0) * (8.0f / (float)kFrameSamples);
+    x0 -= gx; x1 += gx; y0 -= gy; y1 += gy;
+    const float rx = f.any ? x1 - x0 : 0.0f, ry = f.any ? y1 - y0 : 0.0f;
+    const bool okx = rx > 0.0f && rx < 3.0e38f, oky = ry > 0.0f && ry < 3.0e38f;
+    f.bx = f.any ? x0 : 0.0f; f.by = f.any ? y0 : 0.0f;
+    f.sx = okx ? (float)kQMax / rx : 0.0f;
+    f.sy = oky ? (float)kQMax / ry : 0.0f;
+    // pixels per cell, rounded UP (used for an upper bound of AABB overlaps)
+    f.cpx = okx ? (rx / (float)kQMax) * 1.000001f : 0.0f;
+    f.cpy = oky ? (ry / (float)kQMax) * 1.000001f : 0.0f;
+    int gbits = 0;
+    if (group) {
+      const int64_t gs = n < 1024 ? n : 1024;
+      int d = 0;
+      for (int k = 0; k < 128; ++k) d += __popc(gbm[k]);
+      const int total = 2 * cell_hbits;
+      int want = 0;
+      while ((1 << want) < d) ++want;
+      want = (d * 10 >= (int)gs * 7) ? total : want + 2;   // samples nearly all distinct: "very many groups"
+      gbits = d <= 1 ? 0 : (want > total - 4 ? total - 4 : want);
+    }
+    f.gbits = gbits;
+    *frame = f;
+  }
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void nms_prepq_kernel(const float *__restrict__ dets, int64_t n,
+                                                        QuadRec *__restrict__ rec, uint2 *__restrict__ qb,
+                                                        float *__restrict__ ar, uint32_t *__restrict__ ckey,
+                                                        uint32_t *__restrict__ crank, uint32_t *__restrict__ hist,
+                                                        int cell_hbits, const NmsFrame *__restrict__ frame,
+                                                        const int32_t *__restrict__ group,
+                                                        const float *__restrict__ thrs, float thr) {
+  constexpr int S = KIND == 0 ? 6 : (KIND == 1 ? 9 : 5);
+  const NmsFrame fr = *frame;
+  const int gbits = fr.gbits, cbits = 2 * cell_hbits - gbits;
+  auto qz = [](float x, float b, float s) {
+    float u = floorf((x - b) * s);
+    u = u < 0.0f ? 0.0f : (u > (float)kQMax ? (float)kQMax : u);   // (NaN -> kQMax by the second select: never happens, x is finite)
+    return (uint32_t)u;
+  };
+  for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n; b += (int64_t)gridDim.x * blockDim.x) {
+    const float *row = dets + b * S;
+    Quad q;
+    load_quad<KIND>(row, q);
+    QuadRec r;
+    r.ox = q.ox; r.oy = q.oy; r.ex = q.ex; r.ey = q.ey;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { r.rx[k] = q.rx[k]; r.ry[k] = q.ry[k]; }
+    r.area = q.area; r.skey = score_key(row[S - 1]);
+    const int32_t g = group ? group[b] : 0;
+    r.group = g;
+    r.thr = thrs ? thrs[b] : thr;
+    bool wellformed = true;
+    if (KIND == 2) hbb_record(row, r, wellformed);
+    rec[b] = r;
+    ar[b] = q.area;
+    float4 v;
+    nms_interval(q.ox, q.ex, v.x, v.y);
+    nms_interval(q.oy, q.ey, v.z, v.w);
+    // a box with a non-finite interval can never reach overlap >= thr in the spec (its prefilter / area
+    // guards fail): isolate it from the scan
+    const float big = 3.0e38f;
+    const bool fin = wellformed && (fabs_sel(v.x) < big) && (fabs_sel(v.y) < big) && (fabs_sel(v.z) < big) && (fabs_sel(v.w) < big);
+    uint2 o = make_uint2(kSentLo, kSentHi);
+    uint32_t mk = (1u << (2 * cell_hbits)) - 1u;  // isolated boxes go to the last cell
+    if (fin) {
+      const uint32_t xl = qz(v.x, fr.bx, fr.sx), xh = qz(v.y, fr.bx, fr.sx);
+      const uint32_t yl = qz(v.z, fr.by, fr.sy), yh = qz(v.w, fr.by, fr.sy);
+      o.x = xl | (yl << 16);
+      o.y = (xh | (yh << 16)) | kGuard;
+      const int sh = 16 - cell_hbits;  // (lo + hi) is a 16-bit centre*2: keep its top bits
+      mk = spread15((xl + xh) >> sh) | (spread15((yl + yh) >> sh) << 1);
+      if (gbits > 0) mk = (group_bucket(g, gbits) << cbits) | (mk >> gbits);   // bucket, then coarser space
+    }
+    qb[b] = o;
+    ckey[b] = mk;
+    // the count of the cell AND this box's rank inside it (one round of scattered atomics per call)
+    crank[b] = atomicAdd(&hist[mk], 1u);
+  }
+}
+
+// CELLS > 0: the block scans hist[0 .. CELLS) into LDS itself; CELLS == 0: `hist` already holds the offsets
+// (calls with more than 16384 cells run the cell-scan kernels first).  One box per thread and step.
+template <int CELLS>
+__global__ __launch_bounds__(1024) void nms_sortscatter_kernel(const uint32_t *__restrict__ hist,
+                                                               const uint2 *__restrict__ qb,
+                                                               const float *__restrict__ ar,
+                                                               const uint32_t *__restrict__ ckey,
+                                                               const uint32_t *__restrict__ crank, int64_t n,
+                                                               int64_t npos, const int32_t *__restrict__ group,
+                                                               const float *__restrict__ thrs,
+                                                               uint2 *__restrict__ qs, uint4 *__restrict__ pf,
+                                                               int32_t *__restrict__ pg, float *__restrict__ pt) {
+  __shared__ uint32_t offs[CELLS > 0 ? CELLS : 1];
+  __shared__ uint32_t wsum[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t b0 = (int64_t)blockIdx.x * 1024 + tid;
+  // this thread's first box is requested before the scan: its round trip overlaps it
+  uint32_t key0 = 0, rank0 = 0;
+  if (b0 < n) { key0 = ckey[b0]; rank0 = crank[b0]; }
+  if (CELLS > 0) {
+    constexpr int PER = CELLS > 0 ? CELLS / 1024 : 4;
+    uint32_t v[PER], tot = 0;
+    const uint4 *h4 = reinterpret_cast<const uint4 *>(hist + tid * PER);
+#pragma unroll
+    for (int k = 0; k < PER / 4; ++k) {
+      const uint4 a = h4[k];
+      v[4 * k] = a.x; v[4 * k + 1] = a.y; v[4 * k + 2] = a.z; v[4 * k + 3] = a.w;
+      tot += a.x + a.y + a.z + a.w;
+    }
+    uint32_t inc = tot;
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t t = (uint32_t)__shfl_up((int)inc, o);
+      if (lane >= o) inc += t;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t base = inc - tot;
+    for (int k = 0; k < wave; ++k) base += wsum[k];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) { offs[tid * PER + k] = base; base += v[k]; }
+    __syncthreads();
+  }
+  for (int64_t b = b0; b < n; b += (int64_t)gridDim.x * 1024) {
+    const uint32_t key = (b == b0) ? key0 : ckey[b], rank = (b == b0) ? rank0 : crank[b];
+    const uint32_t pos = (CELLS > 0 ? offs[key] : hist[key]) + rank;
+    const uint2 o = qb[b];
+    qs[pos] = o;
+    // one 16-byte record per position for the candidate batches (one gather instead of three)
+    pf[pos] = make_uint4(o.x, o.y, __float_as_uint(ar[b]), (uint32_t)b);
+    if (pg) pg[pos] = group[b];
+    if (pt) pt[pos] = thrs[b];
+  }
+  // the padding of the last tile: sentinels (they meet nothing)
+  if (blockIdx.x == 0) {
+    for (int64_t s2 = n + tid; s2 < npos; s2 += 1024) {
+      qs[s2] = make_uint2(kSentLo, kSentHi);
+      pf[s2] = make_uint4(kSentLo, kSentHi, 0u, 0u);
+      if (pg) pg[s2] = 0;
+      if (pt) pt[s2] = 0.0f;
+    }
+  }
+}
+
+// ---- 4: tile bounding boxes (calls of >= kSuperMinTiles tiles; smaller ones: nms_cullbox_kernel) -------------
+// one block = one tile of 256 spatial positions: bounding box per tile and per sub-tile of 32, bucket ranges of
+// grouped calls, supertile boxes
+__global__ __launch_bounds__(256) void nms_tilebox_kernel(const uint2 *__restrict__ qs, int64_t n,
                                                           uint2 *__restrict__ tbox,
                                                           uint2 *__restrict__ sbox,
-                                                          const int32_t *__restrict__ group,
-                                                          const int *__restrict__ ginfo,
-                                                          int32_t *__restrict__ pg,
+                                                          const int32_t *__restrict__ pg,
+                                                          const NmsFrame *__restrict__ frame,
                                                           uint32_t *__restrict__ tgr,
                                                           uint32_t *__restrict__ sgr,
-                                                          const float *__restrict__ thrs,
-                                                          float *__restrict__ pt,
                                                           unsigned int *__restrict__ super) {
   __shared__ uint4 wred[4];
   __shared__ uint2 gred[4];
   const int64_t s = (int64_t)blockIdx.x * kTile + threadIdx.x;
-  uint2 o = make_uint2(kSentLo, kSentHi);
-  float ar = 0.0f;
-  uint32_t id = 0;
-  if (s < n) {
-    id = sid[s];
-    o = qb[id];
-    ar = ar_in[id];
-  }
-  qs[s] = o;
-  // one 16-byte record per position for the candidate batches (one gather instead of three)
-  pf[s] = make_uint4(o.x, o.y, __float_as_uint(ar), id);
-  if (thrs) pt[s] = (s < n) ? thrs[id] : 0.0f;
-  // grouped calls: the group of every position and the bucket range (lo | hi << 16) of
-  // every sub-tile / tile (empty: lo > hi)
+  const uint2 o = qs[s];
+  // grouped calls: the bucket range (lo | hi << 16) of every sub-tile / tile (empty: lo > hi)
   uint32_t glo = 0xFFFFu, ghi = 0u;
-  if (group) {
-    const int32_t g = (s < n) ? group[id] : 0;
-    pg[s] = g;
+  if (pg) {
     // (padding and isolated boxes meet nothing: they do not widen the range)
-    if (s < n && o.x != kSentLo) { glo = ghi = group_bucket(g, ginfo[0]); }
+    if (s < n && o.x != kSentLo) { glo = ghi = group_bucket(pg[s], frame->gbits); }
   }
   uint32_t xl = o.x & 0x7FFFu, yl = (o.x >> 16) & 0x7FFFu;
   uint32_t xh = o.y & 0x7FFFu, yh = (o.y >> 16) & 0x7FFFu;
@@ -654,7 +694,7 @@ __global__ __launch_bounds__(256) void nms_permute_kernel(const uint2 *__restric
   }
   // bounding box of each run of 32 consecutive positions (a sub-tile of sentinels
   // keeps lo = max, hi = 0: it meets nothing)
-  if (group) {
+  if (pg) {
     for (int k = kSubRows / 2; k > 0; k >>= 1) { glo = min(glo, shfl_xor_u(glo, k)); ghi = max(ghi, shfl_xor_u(ghi, k)); }
     if ((threadIdx.x & (kSubRows - 1)) == 0) sgr[(size_t)blockIdx.x * kSub + (threadIdx.x / kSubRows)] = glo | (ghi << 16);
     glo = min(glo, shfl_xor_u(glo, 32)); ghi = max(ghi, shfl_xor_u(ghi, 32));
@@ -677,13 +717,12 @@ __global__ __launch_bounds__(256) void nms_permute_kernel(const uint2 *__restric
     tbox[blockIdx.x] = make_uint2(m.x | (m.y << 16), (m.z | (m.w << 16)) | kGuard);
     // bounding box (and bucket range) of the SUPERTILE of kSuper consecutive tiles: every field is kept
     // as a maximum (the lows complemented) so that the zero-filled words mean "empty"
-    // (only kept for large calls: super == nullptr below kSuperMinTiles tiles)
     unsigned int *sp = super ? super + (size_t)(blockIdx.x / kSuper) * 8 : nullptr;
     if (sp) {
       atomicMax(sp + 0, 0x7FFFu - m.x); atomicMax(sp + 1, 0x7FFFu - m.y);
       atomicMax(sp + 2, m.z); atomicMax(sp + 3, m.w);
     }
-    if (group) {
+    if (pg) {
       uint2 r = gred[0];
       for (int k = 1; k < 4; ++k) { r.x = min(r.x, gred[k].x); r.y = max(r.y, gred[k].y); }
       tgr[blockIdx.x] = r.x | (r.y << 16);
@@ -800,6 +839,129 @@ __global__ __launch_bounds__(256) void nms_cull_kernel(const uint2 *__restrict__
     if (gbase_h + k < scap) seg[gbase_h + k] = make_uint2(((uint32_t)A << 16) | (v & 0xFFFFu), v >> 16);
   }
   for (unsigned int k = threadIdx.x; k < nl; k += 256) {
+    const uint32_t v = lists[span - 1 - k];
+    if (gbase_l + k < scap) seg[scap - 1u - (gbase_l + k)] = make_uint2(((uint32_t)A << 16) | (v & 0xFFFFu), v >> 16);
+  }
+}
+
+// ---- 4 + 5 in one launch (calls of fewer than kSuperMinTiles tiles) ---------------------------------------------
+// A block takes a TICKET (its rank in start order), reduces the boxes of tile A = ticket out of the sorted
+// intervals, publishes the tile box as ONE 8-byte word (its guard bits double as the VALID flag: the words are
+// zero-filled by the frame kernel) and lists the units (sub-tile of A, tile B) for all B < A whose boxes meet --
+// the mirror image of nms_cull_kernel's B > A, the same set of tile pairs.  Tiles B < A belong to tickets that
+// were handed out earlier: those blocks are running and publish without waiting for anyone, so a poll always
+// ends (bounded anyway; a timeout is reported as a unit-list overflow).  Visibility: the payload IS the flagged
+// word (agent-scope store / load), the bucket range of a grouped call is stored before it behind an
+// s_waitcnt vmcnt(0) and read with agent-scope loads after it (MI355X_MICROARCH.md, handoff-flag).
+__global__ __launch_bounds__(256) void nms_cullbox_kernel(const uint2 *__restrict__ qs, int64_t n,
+                                                          const int32_t *__restrict__ pg,
+                                                          const NmsFrame *__restrict__ frame, int nt,
+                                                          uint2 *__restrict__ tbox, uint32_t *__restrict__ tgr,
+                                                          uint2 *__restrict__ units, unsigned int scap,
+                                                          unsigned int *__restrict__ ucnts,
+                                                          unsigned int *__restrict__ ticket) {
+  __shared__ uint32_t lists[kCullChunk * kSub];   // sub << 16 | B; heavy from the front, light from the back
+  __shared__ unsigned int nh, nl, gbase_h, gbase_l, s_ticket;
+  __shared__ uint4 wred[4];
+  __shared__ uint2 gred[4];
+  __shared__ uint2 s_sub[kSub];
+  __shared__ uint32_t s_sgr[kSub];
+  __shared__ uint2 s_tile;
+  __shared__ uint32_t s_tgr;
+  const int tid = threadIdx.x;
+  if (tid == 0) { s_ticket = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); nh = 0; nl = 0; }
+  __syncthreads();
+  const int A = (int)s_ticket;
+  // ---- the boxes of tile A
+  const int64_t s = (int64_t)A * kTile + tid;
+  const uint2 o = qs[s];
+  uint32_t glo = 0xFFFFu, ghi = 0u;
+  if (pg && s < n && o.x != kSentLo) { glo = ghi = group_bucket(pg[s], frame->gbits); }
+  uint32_t xl = o.x & 0x7FFFu, yl = (o.x >> 16) & 0x7FFFu;
+  uint32_t xh = o.y & 0x7FFFu, yh = (o.y >> 16) & 0x7FFFu;
+  for (int k = kSubRows / 2; k > 0; k >>= 1) {
+    xl = min(xl, shfl_xor_u(xl, k)); yl = min(yl, shfl_xor_u(yl, k));
+    xh = max(xh, shfl_xor_u(xh, k)); yh = max(yh, shfl_xor_u(yh, k));
+    glo = min(glo, shfl_xor_u(glo, k)); ghi = max(ghi, shfl_xor_u(ghi, k));
+  }
+  if ((tid & (kSubRows - 1)) == 0) {
+    s_sub[tid / kSubRows] = make_uint2(xl | (yl << 16), (xh | (yh << 16)) | kGuard);
+    s_sgr[tid / kSubRows] = pg ? (glo | (ghi << 16)) : 0xFFFF0000u;
+  }
+  xl = min(xl, shfl_xor_u(xl, 32)); yl = min(yl, shfl_xor_u(yl, 32));
+  xh = max(xh, shfl_xor_u(xh, 32)); yh = max(yh, shfl_xor_u(yh, 32));
+  glo = min(glo, shfl_xor_u(glo, 32)); ghi = max(ghi, shfl_xor_u(ghi, 32));
+  if ((tid & 63) == 0) { wred[tid >> 6] = make_uint4(xl, yl, xh, yh); gred[tid >> 6] = make_uint2(glo, ghi); }
+  __syncthreads();
+  if (tid == 0) {
+    uint4 m = wred[0];
+    uint2 r = gred[0];
+    for (int k = 1; k < 4; ++k) {
+      m.x = min(m.x, wred[k].x); m.y = min(m.y, wred[k].y);
+      m.z = max(m.z, wred[k].z); m.w = max(m.w, wred[k].w);
+      r.x = min(r.x, gred[k].x); r.y = max(r.y, gred[k].y);
+    }
+    const uint2 tb = make_uint2(m.x | (m.y << 16), (m.z | (m.w << 16)) | kGuard);
+    const uint32_t tg = pg ? (r.x | (r.y << 16)) : 0xFFFF0000u;
+    s_tile = tb; s_tgr = tg;
+    if (pg) {
+      __hip_atomic_store(&tgr[A], tg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(&tbox[A]),
+                       (unsigned long long)tb.x | ((unsigned long long)tb.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  // ---- units (sub-tile of A, tile B) for B < A
+  const uint2 a = s_tile;
+  const uint32_t gaT = s_tgr;
+  (void)gaT;
+  uint2 sa[kSub];
+  uint32_t ga[kSub];
+#pragma unroll
+  for (int w = 0; w < kSub; ++w) { sa[w] = s_sub[w]; ga[w] = s_sgr[w]; }
+  const int span = A * kSub;   // (A < kCullChunk: the fused kernel serves calls of < kSuperMinTiles tiles)
+  bool timeout = false;
+  for (int B = tid; B < A; B += 256) {
+    unsigned long long raw;
+    int spins = 0;
+    do {
+      raw = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(&tbox[B]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } while (!((raw >> 32) & 0x80000000ull) && ++spins < (1 << 22));
+    if (!((raw >> 32) & 0x80000000ull)) { timeout = true; continue; }
+    const uint2 b = make_uint2((uint32_t)raw, (uint32_t)(raw >> 32));
+    if (qdisjoint(a.x, a.y, b.x, b.y) != 0u) continue;
+    const uint32_t gb = pg ? __hip_atomic_load(&tgr[B], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xFFFF0000u;
+#pragma unroll
+    for (int w = 0; w < kSub; ++w) {
+      if (qdisjoint(sa[w].x, sa[w].y, b.x, b.y) != 0u || !ranges_meet(ga[w], gb)) continue;
+      // shared part of the two boxes vs. the sub-tile's own box: most rows active?
+      const uint32_t ilo = __builtin_elementwise_max(sa[w].x & 0x7FFFu, b.x & 0x7FFFu) |
+                           (__builtin_elementwise_max(sa[w].x >> 16, b.x >> 16) << 16);
+      const uint32_t ihi = __builtin_elementwise_min(sa[w].y & 0x7FFFu, b.y & 0x7FFFu) |
+                           (__builtin_elementwise_min((sa[w].y >> 16) & 0x7FFFu, (b.y >> 16) & 0x7FFFu) << 16) | kGuard;
+      const bool heavy = qbox_area(ilo, ihi) * 4.0f >= qbox_area(sa[w].x, sa[w].y);
+      const uint32_t v = ((uint32_t)w << 16) | (uint32_t)B;
+      if (heavy) lists[atomicAdd(&nh, 1u)] = v;
+      else lists[span - 1 - atomicAdd(&nl, 1u)] = v;
+    }
+  }
+  const unsigned int sh = (unsigned int)A & (kShards - 1);
+  if (timeout) atomicMax(&ucnts[sh * kUnitStride], 0x7FFFFFFFu);   // "cannot happen": reported as an overflow of the unit list
+  __syncthreads();
+  if (tid == 0) {
+    gbase_h = nh ? atomicAdd(&ucnts[sh * kUnitStride], nh) : 0u;
+    gbase_l = nl ? atomicAdd(&ucnts[(kShards + sh) * kUnitStride], nl) : 0u;
+  }
+  __syncthreads();
+  // a segment that does not fit is reported to the host (heavy + light > scap, see
+  // nms_compact_kernel); never write outside it
+  uint2 *seg = units + (size_t)sh * scap;
+  for (unsigned int k = tid; k < nh; k += 256) {
+    const uint32_t v = lists[k];
+    if (gbase_h + k < scap) seg[gbase_h + k] = make_uint2(((uint32_t)A << 16) | (v & 0xFFFFu), v >> 16);
+  }
+  for (unsigned int k = tid; k < nl; k += 256) {
     const uint32_t v = lists[span - 1 - k];
     if (gbase_l + k < scap) seg[scap - 1u - (gbase_l + k)] = make_uint2(((uint32_t)A << 16) | (v & 0xFFFFu), v >> 16);
   }
@@ -1932,7 +2094,7 @@ static thread_local NmsProfile g_prof;
 
 // ---- workspace layout ------------------------------------------------------------
 struct NmsLayout {
-  size_t rec, iv, ar, part, pstat, qb, ckey, crank, sid, qs, pf, pg, pt, tgr, sgr, ginfo, cellpx, tbox, sbox, zero_begin, cnt, ctr, ccnts, ucnts, super, hist, scanflags,
+  size_t rec, iv, ar, qb, ckey, crank, qs, pf, pg, pt, tgr, sgr, frame, tbox, sbox, zero_begin, cnt, ctr, ccnts, ucnts, super, hist, scanflags, ticket,
       zero_end, blockcnt, cands, edges, total;
   unsigned long long cap;         // candidate pairs == overlap edges capacity
   unsigned long long unit_worst;  // kShards x the most units one shard of the unit list can get
@@ -1951,25 +2113,20 @@ static int nms_layout(int64_t n, int64_t edge_capacity, NmsLayout &L) {
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
   L.rec = take(nn * sizeof(QuadRec));
-  L.iv = take(nn * sizeof(float4));
+  L.iv = take(nn * sizeof(float4));       // (direct route only)
   L.ar = take(nn * sizeof(float));
-  L.part = take(kPrepBlocks * sizeof(uint4));
-  L.pstat = take((size_t)kPrepBlocks * kStat * sizeof(double));
   L.qb = take(nn * sizeof(uint2));
   L.ckey = take(nn * 4);
   L.crank = take(nn * 4);
-  L.sid = take((nt * kTile) * 4);
   L.qs = take((nt * kTile + kRowChunk) * sizeof(uint2));
   L.pf = take((nt * kTile) * sizeof(uint4));
   L.pg = take((nt * kTile) * sizeof(int32_t));
   L.pt = take((nt * kTile) * sizeof(float));
-  L.tgr = take(nt * sizeof(uint32_t));
   L.sgr = take(nt * kSub * sizeof(uint32_t));
-  L.ginfo = take(4 * sizeof(int));
-  L.cellpx = take(2 * sizeof(float));
-  L.tbox = take(nt * sizeof(uint2));
+  L.frame = take(sizeof(NmsFrame));
   L.sbox = take(nt * kSub * sizeof(uint2));
-  {  // shard 0 takes tiles 0, 64, 128, ...; tile A lists at most (nt - 1 - A) * kSub units
+  {  // shard s takes tiles s, s + 64, ...; tile A lists at most (nt - 1 - A) * kSub units (its pairs with later tiles:
+     // nms_cull_kernel) or A * kSub (with earlier tiles: nms_cullbox_kernel) -- the bound below covers both
     const unsigned long long m = (nt + kShards - 1) / kShards;
     L.unit_worst = (m * nt - kShards * (m * (m - 1) / 2)) * kSub * kShards;
   }
@@ -1981,6 +2138,9 @@ static int nms_layout(int64_t n, int64_t edge_capacity, NmsLayout &L) {
   L.super = take(((nt + kSuper - 1) / kSuper) * 8 * 4);   // supertile boxes / bucket ranges (maxima: zero = empty)
   L.blockcnt = take(((nn + 1023) / 1024 + 1) * 4);   // ticket + one flagged count per 1024 boxes
   L.scanflags = take((kCells / kScanBlockCells + 1) * 4);   // multi-block cell scan: ticket + one flagged total per block
+  L.ticket = take(4);                                // nms_cullbox_kernel: tile tickets
+  L.tbox = take(nt * sizeof(uint2));                 // (zero = "not published yet" for nms_cullbox_kernel)
+  L.tgr = take(nt * sizeof(uint32_t));
   L.hist = take(kCells * 4);   // (LAST of the zeroed range: only the cells a call uses are cleared)
   L.zero_end = off;
   // variable part, all 8-byte entries: [cands | edges | units]; candidates and edges
@@ -2139,21 +2299,18 @@ static int nms_enqueue(const char *who, const float *dets_dev, int64_t n, int ki
   QuadRec *rec = reinterpret_cast<QuadRec *>(ws + L.rec);
   float4 *iv = reinterpret_cast<float4 *>(ws + L.iv);
   float *ar = reinterpret_cast<float *>(ws + L.ar);
-  uint4 *part = reinterpret_cast<uint4 *>(ws + L.part);
-  double *pstat = reinterpret_cast<double *>(ws + L.pstat);
   uint2 *qb = reinterpret_cast<uint2 *>(ws + L.qb);
   uint32_t *ckey = reinterpret_cast<uint32_t *>(ws + L.ckey);
   uint32_t *crank = reinterpret_cast<uint32_t *>(ws + L.crank);
   uint32_t *hist = reinterpret_cast<uint32_t *>(ws + L.hist);
-  uint32_t *sid = reinterpret_cast<uint32_t *>(ws + L.sid);
   uint2 *qs = reinterpret_cast<uint2 *>(ws + L.qs);
   uint4 *pf = reinterpret_cast<uint4 *>(ws + L.pf);
   int32_t *pg = group_dev ? reinterpret_cast<int32_t *>(ws + L.pg) : nullptr;
   float *pt = thr_dev ? reinterpret_cast<float *>(ws + L.pt) : nullptr;
-  uint32_t *tgr = group_dev ? reinterpret_cast<uint32_t *>(ws + L.tgr) : nullptr;
+  uint32_t *tgr = reinterpret_cast<uint32_t *>(ws + L.tgr);
   uint32_t *sgr = group_dev ? reinterpret_cast<uint32_t *>(ws + L.sgr) : nullptr;
-  int *ginfo = reinterpret_cast<int *>(ws + L.ginfo);
-  float *cellpx = reinterpret_cast<float *>(ws + L.cellpx);
+  NmsFrame *frame = reinterpret_cast<NmsFrame *>(ws + L.frame);
+  const float *cellpx = &frame->cpx;       // (cpx, cpy)
   uint2 *tbox = reinterpret_cast<uint2 *>(ws + L.tbox);
   uint2 *sbox = reinterpret_cast<uint2 *>(ws + L.sbox);
   int *cnt = reinterpret_cast<int *>(ws + L.cnt);
@@ -2163,6 +2320,7 @@ static int nms_enqueue(const char *who, const float *dets_dev, int64_t n, int ki
   unsigned int *super = reinterpret_cast<unsigned int *>(ws + L.super);
   unsigned int *blockcnt = reinterpret_cast<unsigned int *>(ws + L.blockcnt);
   unsigned int *scanflags = reinterpret_cast<unsigned int *>(ws + L.scanflags);
+  unsigned int *ticket = reinterpret_cast<unsigned int *>(ws + L.ticket);
   uint2 *cands = reinterpret_cast<uint2 *>(ws + L.cands);
   uint2 *edges = cands + cap;
   uint2 *units = edges + cap;
@@ -2211,16 +2369,35 @@ static int nms_enqueue(const char *who, const float *dets_dev, int64_t n, int ki
   int hbits = 6;
   while (hbits < 9 && (1ll << (2 * hbits)) * 16 < n) ++hbits;
   if (group_dev && n >= (1 << 18) && hbits < 9) ++hbits;
-  {
-    // the direct path never touches the cell histogram; the sorted one clears the cells it uses
-    const size_t zbytes = (direct ? L.scanflags : L.hist + ((size_t)4 << (2 * hbits))) - L.zero_begin;
-    uint4 *zero = reinterpret_cast<uint4 *>(ws + L.zero_begin);
+  // the direct path never touches the cell histogram; the sorted one clears the cells it uses
+  const size_t zbytes = (direct ? L.scanflags : L.hist + ((size_t)4 << (2 * hbits))) - L.zero_begin;
+  uint4 *zero = reinterpret_cast<uint4 *>(ws + L.zero_begin);
+  const size_t zero_vecs = zbytes / sizeof(uint4);
+  if (direct) {
     if (kind == OBB_KIND_RBOX)
-      hipLaunchKernelGGL(nms_prep_kernel<0>, dim3(pblocks), dim3(256), 0, st, dets_dev, n, rec, iv, ar, direct ? nullptr : part, pstat, group_dev, thr_dev, iou_thr, zero, zbytes / sizeof(uint4));
+      hipLaunchKernelGGL(nms_prep_kernel<0>, dim3(pblocks), dim3(256), 0, st, dets_dev, n, rec, iv, ar, group_dev, thr_dev, iou_thr, zero, zero_vecs);
     else if (kind == OBB_KIND_POLY)
-      hipLaunchKernelGGL(nms_prep_kernel<1>, dim3(pblocks), dim3(256), 0, st, dets_dev, n, rec, iv, ar, direct ? nullptr : part, pstat, group_dev, thr_dev, iou_thr, zero, zbytes / sizeof(uint4));
+      hipLaunchKernelGGL(nms_prep_kernel<1>, dim3(pblocks), dim3(256), 0, st, dets_dev, n, rec, iv, ar, group_dev, thr_dev, iou_thr, zero, zero_vecs);
     else
-      hipLaunchKernelGGL(nms_prep_kernel<2>, dim3(pblocks), dim3(256), 0, st, dets_dev, n, rec, iv, ar, direct ? nullptr : part, pstat, group_dev, thr_dev, iou_thr, zero, zbytes / sizeof(uint4));
+      hipLaunchKernelGGL(nms_prep_kernel<2>, dim3(pblocks), dim3(256), 0, st, dets_dev, n, rec, iv, ar, group_dev, thr_dev, iou_thr, zero, zero_vecs);
+    OBB_LAUNCH_CHECK();
+  } else {
+    // frame (sampled, block 0) + clearing of the call's counters, histogram cells and tile-box words
+    unsigned zb = (unsigned)((zero_vecs + 4095) / 4096);
+    zb = zb < 1u ? 1u : (zb > 128u ? 128u : zb);
+    if (kind == OBB_KIND_RBOX)
+      hipLaunchKernelGGL(nms_frame_kernel<0>, dim3(zb), dim3(1024), 0, st, dets_dev, n, group_dev, hbits, frame, zero, zero_vecs);
+    else if (kind == OBB_KIND_POLY)
+      hipLaunchKernelGGL(nms_frame_kernel<1>, dim3(zb), dim3(1024), 0, st, dets_dev, n, group_dev, hbits, frame, zero, zero_vecs);
+    else
+      hipLaunchKernelGGL(nms_frame_kernel<2>, dim3(zb), dim3(1024), 0, st, dets_dev, n, group_dev, hbits, frame, zero, zero_vecs);
+    OBB_LAUNCH_CHECK();
+    if (kind == OBB_KIND_RBOX)
+      hipLaunchKernelGGL(nms_prepq_kernel<0>, dim3(pblocks), dim3(256), 0, st, dets_dev, n, rec, qb, ar, ckey, crank, hist, hbits, frame, group_dev, thr_dev, iou_thr);
+    else if (kind == OBB_KIND_POLY)
+      hipLaunchKernelGGL(nms_prepq_kernel<1>, dim3(pblocks), dim3(256), 0, st, dets_dev, n, rec, qb, ar, ckey, crank, hist, hbits, frame, group_dev, thr_dev, iou_thr);
+    else
+      hipLaunchKernelGGL(nms_prepq_kernel<2>, dim3(pblocks), dim3(256), 0, st, dets_dev, n, rec, qb, ar, ckey, crank, hist, hbits, frame, group_dev, thr_dev, iou_thr);
     OBB_LAUNCH_CHECK();
   }
   if (direct) {
@@ -2240,23 +2417,36 @@ static int nms_enqueue(const char *who, const float *dets_dev, int64_t n, int ki
     OBB_PHASE(6);
     OBB_PHASE(7);
   } else {
-    hipLaunchKernelGGL(nms_quant_kernel, dim3(pblocks), dim3(256), 0, st, iv, n, part, pstat, (int)pblocks, qb, ckey, crank, hist, hbits, cellpx, group_dev, ginfo);
-    OBB_LAUNCH_CHECK();
-    // phase 1: spatial sort
+    // phase 1: spatial sort = cell scan (inside every scatter block up to 16384 cells) + scatter of the packed
+    // intervals and per-position records to their sorted positions
     OBB_PHASE(1);
-    if (hbits == 6) hipLaunchKernelGGL(nms_cellscan_kernel<4>, dim3(1), dim3(1024), 0, st, hist);
-    else if (hbits == 7) hipLaunchKernelGGL(nms_cellscan_kernel<16>, dim3(1), dim3(1024), 0, st, hist);
-    else if (hbits == 8) hipLaunchKernelGGL(nms_cellscan_kernel<64>, dim3(1), dim3(1024), 0, st, hist);
-    else hipLaunchKernelGGL(nms_cellscan_big_kernel, dim3((1u << (2 * hbits)) / kScanBlockCells), dim3(256), 0, st, hist, scanflags);
-    OBB_LAUNCH_CHECK();
-    hipLaunchKernelGGL(nms_scatter_kernel, dim3(pblocks), dim3(256), 0, st, ckey, crank, n, hist, sid);
-    OBB_LAUNCH_CHECK();
-    // phase 2: permute + tile boxes + unit culling
+    {
+      unsigned sblocks = (unsigned)((n + 1023) / 1024);
+      if (sblocks > 2048u) sblocks = 2048u;
+      const int64_t npos = (int64_t)nt * kTile;
+      if (hbits == 6) {
+        hipLaunchKernelGGL(nms_sortscatter_kernel<4096>, dim3(sblocks), dim3(1024), 0, st, hist, qb, ar, ckey, crank, n, npos, group_dev, thr_dev, qs, pf, pg, pt);
+      } else if (hbits == 7) {
+        hipLaunchKernelGGL(nms_sortscatter_kernel<16384>, dim3(sblocks), dim3(1024), 0, st, hist, qb, ar, ckey, crank, n, npos, group_dev, thr_dev, qs, pf, pg, pt);
+      } else {
+        if (hbits == 8) hipLaunchKernelGGL(nms_cellscan_kernel<64>, dim3(1), dim3(1024), 0, st, hist);
+        else hipLaunchKernelGGL(nms_cellscan_big_kernel, dim3((1u << (2 * hbits)) / kScanBlockCells), dim3(256), 0, st, hist, scanflags);
+        OBB_LAUNCH_CHECK();
+        hipLaunchKernelGGL(nms_sortscatter_kernel<0>, dim3(sblocks), dim3(1024), 0, st, hist, qb, ar, ckey, crank, n, npos, group_dev, thr_dev, qs, pf, pg, pt);
+      }
+      OBB_LAUNCH_CHECK();
+    }
+    // phase 2: tile boxes + unit culling (one launch below kSuperMinTiles tiles)
     OBB_PHASE(2);
-    hipLaunchKernelGGL(nms_permute_kernel, dim3((unsigned)nt), dim3(kTile), 0, st, qb, sid, ar, n, qs, pf, tbox, sbox, group_dev, ginfo, pg, tgr, sgr, thr_dev, pt, nt >= kSuperMinTiles ? super : nullptr);
-    OBB_LAUNCH_CHECK();
-    hipLaunchKernelGGL(nms_cull_kernel, dim3((unsigned)nt, (unsigned)((nt + kCullChunk - 1) / kCullChunk)), dim3(256), 0, st, tbox, sbox, tgr, sgr, nt, units, ucap / kShards, ucnts, nt >= kSuperMinTiles ? super : nullptr);
-    OBB_LAUNCH_CHECK();
+    if (nt < kSuperMinTiles) {
+      hipLaunchKernelGGL(nms_cullbox_kernel, dim3((unsigned)nt), dim3(256), 0, st, qs, n, pg, frame, nt, tbox, tgr, units, ucap / kShards, ucnts, ticket);
+      OBB_LAUNCH_CHECK();
+    } else {
+      hipLaunchKernelGGL(nms_tilebox_kernel, dim3((unsigned)nt), dim3(kTile), 0, st, qs, n, tbox, sbox, pg, frame, tgr, sgr, super);
+      OBB_LAUNCH_CHECK();
+      hipLaunchKernelGGL(nms_cull_kernel, dim3((unsigned)nt, (unsigned)((nt + kCullChunk - 1) / kCullChunk)), dim3(256), 0, st, tbox, sbox, group_dev ? tgr : nullptr, sgr, nt, units, ucap / kShards, ucnts, super);
+      OBB_LAUNCH_CHECK();
+    }
     // phase 3: scan (broad phase)
     OBB_PHASE(3);
     {

@@ -2,7 +2,7 @@
 //
 // Replaces bbox_overlaps (mmdet/core/bbox/geometry.py:4-88) for (.,5) theta-OBBs
 // and (.,8) polygons, and -- OBB_KIND_HBB -- for the (.,4) horizontal boxes themselves, in the
-// reference's own arithmetic (hbb_pair_overlap, obb_geom.cuh).  Output is the dense (m,n) fp32 matrix, so the kernel is
+// reference's own arithmetic (hbb_pair_overlap, obb_geom.h).  Output is the dense (m,n) fp32 matrix, so the kernel is
 // HBM-write bound when most pairs are disjoint; the layout is chosen for that:
 //
 //   wave = 256 consecutive columns (4 per lane -> one 16-byte store per lane,
@@ -14,7 +14,7 @@
 //          64 pairs at once (full lane utilisation for the ~1000-instruction
 //          polygon clip instead of 1-2 live lanes per wave).
 #include "obb_common.h"
-#include "obb_geom.cuh"
+#include "obb_geom.h"
 
 namespace obb {
 

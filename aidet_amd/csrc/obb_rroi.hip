@@ -33,7 +33,7 @@
 #include <cstdlib>
 
 #include "obb_common.h"
-#include "obb_geom.cuh"
+#include "obb_geom.h"
 
 namespace obb {
 
@@ -308,16 +308,23 @@ constexpr int kWaveFloats = kFwdStageFloats / 4;    // private quarter of a wave
 constexpr int kWavePad = 256;                       // room for the tail lanes of a wave's last DMA instruction
 
 template <bool X4>
-__global__ __launch_bounds__(256) void rroi_forward_kernel(
+__global__ __launch_bounds__(256, 5) void rroi_forward_kernel(
     const LevelTable lv, const int *__restrict__ roi_level, int num_levels, int B, int C,
     const float *__restrict__ rois, int ph, int pw, int sample_num, float min_size, int chan_per_block,
-    int K, int chunks, int roi_kind, float *__restrict__ out) {
+    int K, int chunks, int roi_kind, const int *__restrict__ roi_order, float *__restrict__ out) {
   __shared__ __attribute__((aligned(16))) float tile[4 * (kWaveFloats + kWavePad)];  // block-wide: kFwdStageFloats + pad
   __shared__ ushort4 s_off[kMaxTabSamples];   // per sample: 4 footprint-local tap offsets (< kFwdStageFloats)
   __shared__ float4 s_wgt[kMaxTabSamples];    // per sample: 4 bilinear weights
   int64_t k;
   int chunk;
   if (!block_to_work(K, chunks, k, chunk)) return;
+  // the blocks visit the RoIs in the order of `roi_order` (Morton order of their centres, rroi_order_kernel):
+  // RoIs that run at the same time on an XCD then share footprint lines in its L2 (fetch 189 -> 70 MB at
+  // configs[2]); where a RoI's results go does not depend on it
+  if (roi_order) {
+    const int kk = roi_order[k];
+    if (kk >= 0 && kk < K) k = kk;
+  }
   // pyramid level of this RoI (block-uniform): feature map, its size and scale
   const int lvl_raw = roi_level ? roi_level[k] : 0;
   const bool lvl_ok = lvl_raw >= 0 && lvl_raw < num_levels;
@@ -346,7 +353,12 @@ __global__ __launch_bounds__(256) void rroi_forward_kernel(
     fp.x0 &= ~3;
     fp.w = x1 - fp.x0 + 1;
   }
-  const int fsz = fp.w * fp.h;                       // floats per channel plane
+  // LDS image of a footprint: row pitch = an ODD number of 16-byte slots (X4) / of floats.  With an even
+  // number the rows of the image alias on the 32 banks (pitch 16 floats: two row phases; pitch 32: every
+  // row on the same banks) and the y / y + 1 taps of neighbouring bins collide; the pad slot of a row is
+  // loaded from the row's last chunk (a per-lane SOURCE address: the LDS side of LDS-DMA is linear).
+  const int pitch = X4 ? (((fp.w >> 2) | 1) << 2) : (fp.w | 1);
+  const int fsz = pitch * fp.h;                      // floats per channel plane in LDS
   const int spb = (int)(spb64 > kMaxTabSamples ? kMaxTabSamples + 1 : spb64);   // samples per bin
   const int nsamp = nb * spb;
   // block-uniform: huge RoI / huge sampling grid / >2^31-element tensors gather directly
@@ -366,7 +378,7 @@ __global__ __launch_bounds__(256) void rroi_forward_kernel(
     const bool live = bilinear_taps_xy(H, W, y, x, yl, xl, yh, xh, w);
     // tap coordinates -> footprint-local offsets (clamped: never out of the tile)
     auto cl = [](int v, int n) { return v < 0 ? 0 : (v >= n ? n - 1 : v); };
-    const int ly0 = cl(yl - fp.y0, fp.h) * fp.w, ly1 = cl(yh - fp.y0, fp.h) * fp.w;
+    const int ly0 = cl(yl - fp.y0, fp.h) * pitch, ly1 = cl(yh - fp.y0, fp.h) * pitch;
     const int lx0 = cl(xl - fp.x0, fp.w), lx1 = cl(xh - fp.x0, fp.w);
     s_off[sidx] = live ? make_ushort4((unsigned short)(ly0 + lx0), (unsigned short)(ly0 + lx1), (unsigned short)(ly1 + lx0), (unsigned short)(ly1 + lx1))
                        : make_ushort4(0, 0, 0, 0);
@@ -394,40 +406,60 @@ __global__ __launch_bounds__(256) void rroi_forward_kernel(
     }
     const int cpw = kWaveFloats / fsz;               // channels per pass (>= 1)
     const uint32_t plane32w = (uint32_t)plane;
+    // mean over the samples: a division, or -- a power-of-two count (2 x 2 samples), the usual case -- the
+    // exact same value from a multiplication (scaling by a power of two rounds identically)
+    const uint32_t cbits = __float_as_uint(f.cnt);
+    const bool cnt_pow2 = (cbits & 0x007FFFFFu) == 0u && f.cnt >= 1.0f;
+    const float cnt_inv = cnt_pow2 ? 1.0f / f.cnt : 0.0f;
+    // source offsets of a pass's DMA instructions: the same for every pass (only the channel base moves),
+    // computed ONCE per wave -- slot -> (channel, row, chunk) costs two multiply-high divisions per lane
+    // (a bound that depends on X4 -- `X4 ? 5 : 1` -- made hipcc 7.2 drop the kernel's host stub without a diagnostic)
+    constexpr int kMaxInst = 5;                       // 16-byte path: <= kWaveFloats / 256 instructions per pass
+    static_assert(kMaxInst * 256 == kWaveFloats, "one pass = at most kMaxInst 1-KiB DMA instructions");
+    uint32_t doff[kMaxInst], dch[kMaxInst];
+    const int slots = X4 ? (fsz >> 2) : fsz;           // 16-byte (dword) slots per channel
+    const int rslots = X4 ? (pitch >> 2) : pitch;      // ... per row (the last one is the pad)
+    const int rvalid = X4 ? (fp.w >> 2) : fp.w;        // ... that hold pixels
+    const uint32_t m_slots = slots > 1 ? 0xFFFFFFFFu / (uint32_t)slots + 1u : 0u;
+    const uint32_t m_rslots = rslots > 1 ? 0xFFFFFFFFu / (uint32_t)rslots + 1u : 0u;
+    auto slot_off = [&](uint32_t idx, uint32_t &c) -> uint32_t {
+      c = slots > 1 ? __umulhi(idx, m_slots) : idx;
+      const uint32_t r = idx - c * (uint32_t)slots;
+      const uint32_t y = rslots > 1 ? __umulhi(r, m_rslots) : r;
+      uint32_t x = r - y * (uint32_t)rslots;
+      x = min(x, (uint32_t)(rvalid - 1));              // the pad slot re-loads the row's last chunk
+      return y * (uint32_t)W + (X4 ? (x << 2) : x);
+    };
+    if (X4) {
+#pragma unroll
+      for (int j = 0; j < kMaxInst; ++j) {
+        const uint32_t idx = (uint32_t)min(j * 64 + lane, cpw * slots - 1);
+        doff[j] = slot_off(idx, dch[j]);
+      }
+    }
     for (int cp = cw0; cp < cw1; cp += cpw) {
       const int nch = min(cpw, cw1 - cp);
       const float *src = feat + ((int64_t)f.b * C + cp) * plane + (int64_t)fp.y0 * W + fp.x0;
-      const int total = nch * fsz;
+      const int total = nch * slots;
       if (X4) {
-        const int q4 = fsz >> 2, rw4 = fp.w >> 2, total4 = total >> 2;
-        const uint32_t m_q4 = q4 > 1 ? 0xFFFFFFFFu / (uint32_t)q4 + 1u : 0u;
-        const uint32_t m_r4 = rw4 > 1 ? 0xFFFFFFFFu / (uint32_t)rw4 + 1u : 0u;
-        for (int base = 0; base < total4; base += 64) {
-          const uint32_t idx = (uint32_t)min(base + lane, total4 - 1);
-          const uint32_t c = q4 > 1 ? __umulhi(idx, m_q4) : idx;
-          const uint32_t r = idx - c * (uint32_t)q4;
-          const uint32_t y = rw4 > 1 ? __umulhi(r, m_r4) : r;
-          const uint32_t x = (r - y * (uint32_t)rw4) << 2;
-          const uint32_t off = c * plane32w + y * (uint32_t)W + x;
-          __builtin_amdgcn_global_load_lds(src + off, (__attribute__((address_space(3))) void *)(wt + base * 4), 16, 0, 0);
+#pragma unroll
+        for (int j = 0; j < kMaxInst; ++j) {
+          if (j * 64 < total) {                        // (wave-uniform)
+            // a last, shorter pass: slots of channels it does not have re-load its last channel
+            const uint32_t c = min(dch[j], (uint32_t)(nch - 1));
+            __builtin_amdgcn_global_load_lds(src + (c * plane32w + doff[j]), (__attribute__((address_space(3))) void *)(wt + j * 256), 16, 0, 0);
+          }
         }
       } else {
-        const uint32_t m_fszw = fsz > 1 ? 0xFFFFFFFFu / (uint32_t)fsz + 1u : 0u;
-        const uint32_t m_ww = fp.w > 1 ? 0xFFFFFFFFu / (uint32_t)fp.w + 1u : 0u;
         for (int base = 0; base < total; base += 64) {
-          const uint32_t idx = (uint32_t)min(base + lane, total - 1);
-          const uint32_t c = fsz > 1 ? __umulhi(idx, m_fszw) : idx;
-          const uint32_t r = idx - c * (uint32_t)fsz;
-          const uint32_t y = fp.w > 1 ? __umulhi(r, m_ww) : r;
-          const uint32_t x = r - y * (uint32_t)fp.w;
-          const uint32_t off = c * plane32w + y * (uint32_t)W + x;
-          __builtin_amdgcn_global_load_lds(src + off, (__attribute__((address_space(3))) void *)(wt + base), 4, 0, 0);
+          uint32_t c;
+          const uint32_t o = slot_off((uint32_t)min(base + lane, total - 1), c);
+          __builtin_amdgcn_global_load_lds(src + (c * plane32w + o), (__attribute__((address_space(3))) void *)(wt + base), 4, 0, 0);
         }
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_wave_barrier();
-      for (int c = 0; c < nch; ++c) {
-        const float *p = wt + c * fsz;
+      auto bin_sum = [&](const float *p) -> float {
         float acc = 0.0f;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -439,7 +471,14 @@ __global__ __launch_bounds__(256) void rroi_forward_kernel(
             acc = acc + v;
           }
         }
-        if (lane < nb) out[((k * C + cp + c) * (int64_t)nb) + lane] = acc / f.cnt;
+        return cnt_pow2 ? acc * cnt_inv : acc / f.cnt;
+      };
+      float *o = out + ((k * C + cp) * (int64_t)nb) + lane;
+      // (two channels per step -- 2 x 16 LDS reads in flight together -- needs 116 VGPRs: 4 waves per SIMD instead of 5,
+      // 41 -> 45 us; capped at 96 registers it spills: 79 us)
+      for (int c = 0; c < nch; ++c) {
+        const float r0 = bin_sum(wt + c * fsz);
+        if (lane < nb) o[(int64_t)c * nb] = r0;
       }
       // the next pass overwrites this region: its gathers are done (their values were consumed)
       __builtin_amdgcn_wave_barrier();
@@ -449,7 +488,7 @@ __global__ __launch_bounds__(256) void rroi_forward_kernel(
   const int cpp = kFwdStageFloats / fsz;                // channels per pass (>= 1)
   const uint32_t m_nb = nb > 1 ? 0xFFFFFFFFu / (uint32_t)nb + 1u : 0u;  // it / nb for it < 2^16
   const uint32_t m_fsz = fsz > 1 ? 0xFFFFFFFFu / (uint32_t)fsz + 1u : 0u;
-  const uint32_t m_w = fp.w > 1 ? 0xFFFFFFFFu / (uint32_t)fp.w + 1u : 0u;
+  const uint32_t m_w = pitch > 1 ? 0xFFFFFFFFu / (uint32_t)pitch + 1u : 0u;
   const uint32_t plane32 = (uint32_t)plane;
   for (int cp = c_block; cp < c_end; cp += cpp) {
     const int nch = min(cpp, c_end - cp);
@@ -464,15 +503,16 @@ __global__ __launch_bounds__(256) void rroi_forward_kernel(
       const int total = nch * fsz;
       if (X4) {
         // 16 bytes per lane: one wave-instruction lands 1 KiB (64 chunks of 4 floats)
-        const int q4 = fsz >> 2, rw4 = fp.w >> 2, total4 = total >> 2;   // chunks per plane / row / pass
+        const int q4 = fsz >> 2, rw4 = pitch >> 2, total4 = total >> 2;   // slots per plane / row (incl. the pad) / pass
         const uint32_t m_q4 = q4 > 1 ? 0xFFFFFFFFu / (uint32_t)q4 + 1u : 0u;
         const uint32_t m_r4 = rw4 > 1 ? 0xFFFFFFFFu / (uint32_t)rw4 + 1u : 0u;
+        const uint32_t xlast = (uint32_t)((fp.w >> 2) - 1);
         for (int base = wave * 64; base < total4; base += 256) {
           const uint32_t idx = (uint32_t)min(base + lane, total4 - 1);
           const uint32_t c = q4 > 1 ? __umulhi(idx, m_q4) : idx;
           const uint32_t r = idx - c * (uint32_t)q4;
           const uint32_t y = rw4 > 1 ? __umulhi(r, m_r4) : r;
-          const uint32_t x = (r - y * (uint32_t)rw4) << 2;
+          const uint32_t x = min(r - y * (uint32_t)rw4, xlast) << 2;   // (the pad slot re-loads the row's last chunk)
           const uint32_t off = c * plane32 + y * (uint32_t)W + x;
           __builtin_amdgcn_global_load_lds(src + off, (__attribute__((address_space(3))) void *)(tile + base * 4), 16, 0, 0);
         }
@@ -481,8 +521,8 @@ __global__ __launch_bounds__(256) void rroi_forward_kernel(
           const uint32_t idx = (uint32_t)min(base + lane, total - 1);  // tail lanes re-load the last float into the pad
           const uint32_t c = fsz > 1 ? __umulhi(idx, m_fsz) : idx;
           const uint32_t r = idx - c * (uint32_t)fsz;
-          const uint32_t y = fp.w > 1 ? __umulhi(r, m_w) : r;
-          const uint32_t x = r - y * (uint32_t)fp.w;
+          const uint32_t y = pitch > 1 ? __umulhi(r, m_w) : r;
+          const uint32_t x = min(r - y * (uint32_t)pitch, (uint32_t)(fp.w - 1));
           const uint32_t off = c * plane32 + y * (uint32_t)W + x;
           __builtin_amdgcn_global_load_lds(src + off, (__attribute__((address_space(3))) void *)(tile + base), 4, 0, 0);
         }
@@ -975,6 +1015,61 @@ __global__ __launch_bounds__(256) void rroi_gather_kernel(
   }
 }
 
+// ---- Morton order of the RoIs (forward, with a workspace) ----------------------------------------------------
+// key = pyramid level | Morton code of the RoI centre on a 32 x 32 grid over its map; ONE workgroup counts,
+// scans and scatters (8192 bins in LDS): order[rank] = RoI.  The order inside a cell follows the LDS atomics'
+// arrival -- it decides which block works on which RoI, never a result.
+constexpr int kOrderBins = 8192;     // 8 levels x 1024 cells
+constexpr int kOrderMaxK = 65536;    // above: identity order (the caller passes no order)
+// below: not worth its launch (measured: 512 RoIs covering a 256^2 map 1.8x: the ordered kernel is 2 us faster, the order
+// kernel and its launch boundary cost 9; 2000 RoIs covering it 22x: 224 -> 187 us all in)
+constexpr int kOrderMinK = 1024;
+
+__device__ __forceinline__ uint32_t roi_order_key(const float *__restrict__ roi, int kind, int lvl, const LevelTable &lv) {
+  const float cx = kind == 0 ? roi[1] : 0.5f * (roi[1] + roi[3]);
+  const float cy = kind == 0 ? roi[2] : 0.5f * (roi[2] + roi[4]);
+  const float sc = lv.scale[lvl];
+  float ux = cx * sc * 32.0f / (float)max(lv.W[lvl], 1), uy = cy * sc * 32.0f / (float)max(lv.H[lvl], 1);
+  ux = ux >= 0.0f ? (ux < 31.0f ? ux : 31.0f) : 0.0f;      // (NaN -> 0)
+  uy = uy >= 0.0f ? (uy < 31.0f ? uy : 31.0f) : 0.0f;
+  uint32_t x = (uint32_t)ux, y = (uint32_t)uy;
+  x = (x | (x << 4)) & 0x0F0Fu; x = (x | (x << 2)) & 0x3333u; x = (x | (x << 1)) & 0x5555u;
+  y = (y | (y << 4)) & 0x0F0Fu; y = (y | (y << 2)) & 0x3333u; y = (y | (y << 1)) & 0x5555u;
+  return ((uint32_t)lvl << 10) | x | (y << 1);
+}
+
+__global__ __launch_bounds__(1024) void rroi_order_kernel(const LevelTable lv, const int *__restrict__ roi_level,
+                                                          int num_levels, const float *__restrict__ rois, int K,
+                                                          int roi_kind, int *__restrict__ order, int *__restrict__ tmp) {
+  __shared__ uint32_t hist[kOrderBins];
+  __shared__ uint32_t wsum[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < kOrderBins; i += 1024) hist[i] = 0u;
+  __syncthreads();
+  const int S = roi_stride(roi_kind);
+  auto key_of = [&](int k) {
+    const int l = roi_level ? roi_level[k] : 0;
+    return roi_order_key(rois + (int64_t)k * S, roi_kind, (l >= 0 && l < num_levels) ? (l & 7) : 0, lv);
+  };
+  for (int k = tid; k < K; k += 1024) tmp[k] = (int)atomicAdd(&hist[key_of(k)], 1u);   // rank inside the cell
+  __syncthreads();
+  {  // exclusive scan of the 8192 counts: 8 per thread
+    uint32_t v[8], tot = 0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { v[u] = hist[tid * 8 + u]; tot += v[u]; }
+    uint32_t inc = tot;
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)inc, o); if (lane >= o) inc += t; }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t base = inc - tot;
+    for (int w2 = 0; w2 < wave; ++w2) base += wsum[w2];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { hist[tid * 8 + u] = base; base += v[u]; }
+    __syncthreads();
+  }
+  for (int k = tid; k < K; k += 1024) order[hist[key_of(k)] + (uint32_t)tmp[k]] = k;
+}
+
 static int rroi_check(const char *who, int B, int C, int H, int W, int64_t K, int ph, int pw) {
   if (B < 0 || C < 0 || H < 0 || W < 0 || K < 0)
     return set_err(OBB_EINVAL, "%s: negative dimension", who);
@@ -1012,7 +1107,8 @@ static int rroi_geometry(const char *who, int C, bool backward, int64_t K, int &
 
 static int rroi_forward_launch_levels(const char *who, const LevelTable &lv, int num_levels, const int *roi_level_dev,
                                       int B, int C, const float *rois_dev, int64_t K, int ph, int pw,
-                                      int sample_num, float min_size, int roi_kind, float *out_dev, void *stream) {
+                                      int sample_num, float min_size, int roi_kind, float *out_dev, void *stream,
+                                      int *order_ws = nullptr) {
   bool x4 = true;   // 16-byte staging loads need 16-byte aligned rows: W % 4 == 0 and an aligned base, on every level
   for (int l = 0; l < num_levels; ++l) {
     int rc = rroi_check(who, B, C, lv.H[l], lv.W[l], K, ph, pw);
@@ -1030,12 +1126,21 @@ static int rroi_forward_launch_levels(const char *who, const LevelTable &lv, int
   unsigned long long nblk;
   int rc = rroi_geometry(who, C, false, K, cpb, chunks, nblk);
   if (rc != OBB_OK) return rc;
+  // with a workspace: the RoIs are visited in Morton order of their centres (one small launch; pays from a few
+  // hundred RoIs on: the footprints of RoIs that run together then share lines in an XCD's L2)
+  const int *order = nullptr;
+  if (order_ws && K >= tuning(OBB_TUNE_RROI_ORDER_MIN, kOrderMinK) && K <= kOrderMaxK) {
+    hipLaunchKernelGGL(rroi_order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, lv, roi_level_dev, num_levels, rois_dev,
+                       (int)K, roi_kind, order_ws, order_ws + K);
+    OBB_LAUNCH_CHECK();
+    order = order_ws;
+  }
   if (x4)
     hipLaunchKernelGGL(rroi_forward_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
-                       lv, roi_level_dev, num_levels, B, C, rois_dev, ph, pw, sample_num, min_size, cpb, (int)K, (int)chunks, roi_kind, out_dev);
+                       lv, roi_level_dev, num_levels, B, C, rois_dev, ph, pw, sample_num, min_size, cpb, (int)K, (int)chunks, roi_kind, order, out_dev);
   else
     hipLaunchKernelGGL(rroi_forward_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
-                       lv, roi_level_dev, num_levels, B, C, rois_dev, ph, pw, sample_num, min_size, cpb, (int)K, (int)chunks, roi_kind, out_dev);
+                       lv, roi_level_dev, num_levels, B, C, rois_dev, ph, pw, sample_num, min_size, cpb, (int)K, (int)chunks, roi_kind, order, out_dev);
   OBB_LAUNCH_CHECK();
   return OBB_OK;
 }
@@ -1199,4 +1304,37 @@ extern "C" int obb_roi_align_levels_forward_f32(const float *const *feat_devs_ho
   }
   return rroi_forward_launch_levels(who, lv, num_levels, roi_level_dev, B, C, rois_dev, K, ph, pw, sample_num,
                                     roi_kind == 0 ? min_size : 0.0f, roi_kind, out_dev, stream);
+}
+
+extern "C" size_t obb_roi_forward_workspace_bytes(int64_t K) {
+  if (K < 0) return 0;
+  return obb::align_up((size_t)(K > 0 ? K : 1) * 2 * sizeof(int32_t), 256);
+}
+
+extern "C" int obb_roi_align_forward_ws_f32(const float *const *feat_devs_host, const int *H_host,
+                                            const int *W_host, const float *scale_host, int num_levels,
+                                            int B, int C, const float *rois_dev,
+                                            const int32_t *roi_level_dev, int64_t K, int ph, int pw,
+                                            int sample_num, int roi_kind, float min_size,
+                                            float *out_dev, void *workspace_dev, size_t workspace_bytes,
+                                            void *stream) {
+  using namespace obb;
+  const char *who = "obb_roi_align_forward_ws_f32";
+  if (num_levels < 1 || num_levels > OBB_MAX_LEVELS) return set_err(OBB_EINVAL, "%s: num_levels = %d (1..%d)", who, num_levels, OBB_MAX_LEVELS);
+  if (roi_kind < 0 || roi_kind > 2) return set_err(OBB_EINVAL, "%s: bad RoI kind %d", who, roi_kind);
+  if (!feat_devs_host || !H_host || !W_host || !scale_host) return set_err(OBB_EINVAL, "%s: null level table", who);
+  if (K > 0 && num_levels > 1 && !roi_level_dev) return set_err(OBB_EINVAL, "%s: null level indices", who);
+  if (workspace_dev) {
+    if (workspace_bytes < obb_roi_forward_workspace_bytes(K))
+      return set_err(OBB_EWORKSPACE, "%s: workspace %zu bytes < obb_roi_forward_workspace_bytes(%lld) = %zu", who, workspace_bytes,
+                     (long long)K, obb_roi_forward_workspace_bytes(K));
+    if (reinterpret_cast<uintptr_t>(workspace_dev) & 3u) return set_err(OBB_EINVAL, "%s: workspace must be 4-byte aligned", who);
+  }
+  LevelTable lv = {};
+  for (int l = 0; l < num_levels; ++l) {
+    lv.feat[l] = feat_devs_host[l]; lv.H[l] = H_host[l]; lv.W[l] = W_host[l]; lv.scale[l] = scale_host[l];
+  }
+  return rroi_forward_launch_levels(who, lv, num_levels, roi_level_dev, B, C, rois_dev, K, ph, pw, sample_num,
+                                    roi_kind == 0 ? min_size : 0.0f, roi_kind, out_dev, stream,
+                                    static_cast<int *>(workspace_dev));
 }

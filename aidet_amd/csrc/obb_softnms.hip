@@ -26,7 +26,7 @@
 // no position moves).  State (7 words per box) lives in LDS up to 2048 boxes and in the caller's
 // workspace above that.
 #include "obb_common.h"
-#include "obb_geom.cuh"
+#include "obb_geom.h"
 
 namespace obb {
 
@@ -82,13 +82,30 @@ __device__ __forceinline__ unsigned long long wave_max_key(unsigned long long v)
   return m;
 }
 
+// GROUPED calls (`seg` != nullptr): workgroup g replays the reference's loop on the rows [seg[g], seg[g + 1]) as an
+// array of its own -- exactly what the per-class Python loop of multiclass_nms_with_index does with one soft_nms
+// call per class (rbbox_nms.py:29-49) -- so the classes of a detection head run CONCURRENTLY (one workgroup
+// each) instead of back to back with a host synchronisation per class.  Outputs of group g: rows
+// [seg[g], seg[g] + result[g]) of out_dets / out_inds (indices relative to the group's first row).
 template <bool LDS, int kSoftThreads>
 __global__ __launch_bounds__(kSoftThreads) void soft_nms_kernel(const float *__restrict__ dets, int n,
                                                                 float thr, int method, float sigma,
                                                                 float min_score, float *__restrict__ ws,
                                                                 float *__restrict__ out_dets,
                                                                 int64_t *__restrict__ out_inds,
-                                                                long long *__restrict__ result) {
+                                                                long long *__restrict__ result,
+                                                                const int64_t *__restrict__ seg) {
+  if (seg) {
+    const int64_t off = seg[blockIdx.x];
+    n = (int)(seg[blockIdx.x + 1] - off);
+    dets += off * 5;
+    out_dets += off * 5;
+    out_inds += off;
+    ws += off * 8;
+    result += blockIdx.x;
+    if (n <= 0) { if (threadIdx.x == 0) result[0] = 0; return; }   // (block-uniform)
+    if (LDS && n > kSoftLds) { if (threadIdx.x == 0) result[0] = -1; return; }   // (the host routes such calls to the workspace variant)
+  }
   __shared__ float lds[LDS ? 7 * kSoftLds : 7];
   constexpr int kW = kSoftThreads / 64;
   __shared__ unsigned long long wbest[kW];
@@ -273,13 +290,42 @@ extern "C" int obb_soft_nms_f32(const float *dets_dev, int64_t n, float iou_thr,
   hipStream_t st = (hipStream_t)stream;
   float *ws = static_cast<float *>(workspace_dev);
   if (n <= 768)          // measured (tools/bench_soft_nms.py): 1.15 us per round with 4 waves, 1.6 with 16 at n = 500
-    hipLaunchKernelGGL((soft_nms_kernel<true, 256>), dim3(1), dim3(256), 0, st, dets_dev, (int)n, iou_thr, method, sigma, min_score, ws, out_dets_dev, out_inds_dev, pinned_dev);
+    hipLaunchKernelGGL((soft_nms_kernel<true, 256>), dim3(1), dim3(256), 0, st, dets_dev, (int)n, iou_thr, method, sigma, min_score, ws, out_dets_dev, out_inds_dev, pinned_dev, nullptr);
   else if (n <= kSoftLds)   // 2.0 us per round with 16 waves, 2.3 with 4 at n = 2000
-    hipLaunchKernelGGL((soft_nms_kernel<true, 1024>), dim3(1), dim3(1024), 0, st, dets_dev, (int)n, iou_thr, method, sigma, min_score, ws, out_dets_dev, out_inds_dev, pinned_dev);
+    hipLaunchKernelGGL((soft_nms_kernel<true, 1024>), dim3(1), dim3(1024), 0, st, dets_dev, (int)n, iou_thr, method, sigma, min_score, ws, out_dets_dev, out_inds_dev, pinned_dev, nullptr);
   else
-    hipLaunchKernelGGL((soft_nms_kernel<false, 1024>), dim3(1), dim3(1024), 0, st, dets_dev, (int)n, iou_thr, method, sigma, min_score, ws, out_dets_dev, out_inds_dev, pinned_dev);
+    hipLaunchKernelGGL((soft_nms_kernel<false, 1024>), dim3(1), dim3(1024), 0, st, dets_dev, (int)n, iou_thr, method, sigma, min_score, ws, out_dets_dev, out_inds_dev, pinned_dev, nullptr);
   OBB_LAUNCH_CHECK();
   OBB_HIP_TRY(hipStreamSynchronize(st));
   *count_host = *pinned;
+  return OBB_OK;
+}
+
+extern "C" int obb_soft_nms_grouped_f32(const float *dets_dev, int64_t n, const int64_t *seg_dev, int64_t num_groups,
+                                        float iou_thr, int method, float sigma, float min_score,
+                                        float *out_dets_dev, int64_t *out_inds_dev, int64_t *counts_dev,
+                                        void *workspace_dev, size_t workspace_bytes, void *stream) {
+  using namespace obb;
+  const char *who = "obb_soft_nms_grouped_f32";
+  if (n < 0 || num_groups < 0) return set_err(OBB_EINVAL, "%s: negative size", who);
+  if (method < 0 || method > 2) return set_err(OBB_EINVAL, "%s: bad method %d (0 hard, 1 linear, 2 gaussian)", who, method);
+  if (num_groups == 0) return OBB_OK;
+  if (n > (1 << 22) || num_groups > (1 << 20)) return set_err(OBB_EINVAL, "%s: n = %lld / %lld groups too large", who, (long long)n, (long long)num_groups);
+  if (!seg_dev || !counts_dev || (n > 0 && (!dets_dev || !out_dets_dev || !out_inds_dev || !workspace_dev)))
+    return set_err(OBB_EINVAL, "%s: null pointer", who);
+  if (n > 0 && workspace_bytes < obb_soft_nms_workspace_bytes(n))
+    return set_err(OBB_EWORKSPACE, "%s: workspace %zu bytes < %zu", who, workspace_bytes, obb_soft_nms_workspace_bytes(n));
+  hipStream_t st = (hipStream_t)stream;
+  float *ws = static_cast<float *>(workspace_dev);
+  long long *res = reinterpret_cast<long long *>(counts_dev);
+  const unsigned g = (unsigned)num_groups;
+  // no group is larger than n: up to kSoftLds rows in all, every group's state fits the LDS arrays
+  if (n <= kSoftLds && n <= 768 * num_groups)
+    hipLaunchKernelGGL((soft_nms_kernel<true, 256>), dim3(g), dim3(256), 0, st, dets_dev, 0, iou_thr, method, sigma, min_score, ws, out_dets_dev, out_inds_dev, res, seg_dev);
+  else if (n <= kSoftLds)
+    hipLaunchKernelGGL((soft_nms_kernel<true, 1024>), dim3(g), dim3(1024), 0, st, dets_dev, 0, iou_thr, method, sigma, min_score, ws, out_dets_dev, out_inds_dev, res, seg_dev);
+  else
+    hipLaunchKernelGGL((soft_nms_kernel<false, 1024>), dim3(g), dim3(1024), 0, st, dets_dev, 0, iou_thr, method, sigma, min_score, ws, out_dets_dev, out_inds_dev, res, seg_dev);
+  OBB_LAUNCH_CHECK();
   return OBB_OK;
 }

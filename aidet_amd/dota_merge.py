@@ -15,6 +15,13 @@ identical results:
   ``sharded``     (image, class) groups are independent, so rank r merges the groups with
                   ``group % world == r`` and the keep indices are all-gathered -- two more small
                   collectives, 1/world of the NMS work per rank
+  ``routed``      every row travels ONLY to the rank that owns its image (``image % world``): one
+                  ``all_gather_into_tensor`` of the send-count vectors, one ``all_to_all_single`` of the
+                  rows; every rank then restores the order of, and merges, its own images' rows --
+                  1/world of EVERY phase (the two layouts above still receive and re-order all rows on
+                  every rank).  The kept rows stay with their owner (the reference writes one result per
+                  image, dota.py:310-336) unless the caller asks for them everywhere
+                  (``gather_result=True``: one more padded all-gather of the kept rows only).
 
 The keep set equals the single-process result by construction: the gathered rows are the same
 multiset, and greedy NMS depends on the row order only through score ties (lower index wins);
@@ -156,6 +163,10 @@ def merge_detections(dets, iou_thr, num_classes, class_thrs=None, nms_fn=None, s
     """
     if dets.size(0) == 0:
         return dets, torch.zeros(0, dtype=torch.long, device=dets.device)
+    if dets.size(1) == 7 and not strict and class_thrs is not None and not all(float(v) > 0.0 for v in class_thrs):
+        # horizontal rows follow nms_cpu.cpp to the letter, where a threshold <= 0 under `>=` suppresses every later
+        # box of the group, disjoint ones included: refused like nms_wrapper.nms refuses it
+        raise ValueError('merge_detections: per-class thresholds of horizontal rows must be positive under the `>=` rule')
     if (nms_fn is None and _on_gpu(dets) and dets.dtype == torch.float32 and dets.size(1) in _LAYOUT
             and float(iou_thr) > 0.0):
         # fused: one kernel splits the rows into boxes | int32 groups | thresholds, the grouped NMS reads
@@ -233,9 +244,69 @@ def _restore_by_key(padded, total, ncols, key_max=None):
     return gather_rows(padded, order, ncols)
 
 
+def _sort_by_small_key(key, key_max):
+    """stable argsort of small non-negative integer keys (16-bit sort when they fit)."""
+    small = key_max is not None and int(key_max) < (1 << 15) - 1
+    k = key.clamp(max=32767.0).to(torch.int16) if small else key.to(torch.int32)
+    return torch.argsort(k, stable=True)
+
+
+def routed_merge(local, iou_thr, num_classes, class_thrs=None, group=None, nms_fn=None, strict=False, mark=None,
+                 order_key=None, order_key_max=None, gather_result=True):
+    """The ``routed`` layout (module docstring): rows -> the owner of their image (``image % world``) by
+    all_to_all, order restored and merged there.
+
+    Args:
+        local (Tensor): (n_local, 8 | 11 | 7) rows of this rank; the LAST column is the image id.
+        order_key (Tensor, optional): (n_local,) small non-negative integers (< 2**24; e.g. the patch index), every
+            key value on ONE rank and non-decreasing in this rank's row order: the single-process order is ascending
+            key, rank-local order inside a key.  Without it rows of different ranks keep rank order (only score
+            TIES between rows of different ranks can then differ from a single-process run).
+        gather_result (bool): True -> every rank returns ALL kept rows, in single-process order (what the other
+            layouts return); False -> the kept rows of this rank's images only.
+    Returns:
+        (kept rows, keep indices into this rank's routed rows, this rank's routed rows)
+    """
+    mark = mark or (lambda name: None)
+    world, rank = _world(group)
+    ncols = local.size(1)
+    dev = local.device
+    key = (order_key.to(local.dtype) if order_key is not None else local.new_zeros(local.size(0)))[:, None]
+    rows = torch.cat([local, key], 1)
+    if world > 1:
+        dest = local[:, -1].to(torch.int64) % world
+        order = _sort_by_small_key(dest.to(local.dtype), world)
+        send = gather_rows(rows, order)
+        mat = torch.empty(world * world, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(mat, torch.bincount(dest, minlength=world), group=group)
+        mat = mat.view(world, world).tolist()                        # mat[src][dst]; the one host read
+        in_splits, out_splits = mat[rank], [mat[src][rank] for src in range(world)]
+        recv = send.new_empty((sum(out_splits), ncols + 1))
+        dist.all_to_all_single(recv, send, out_splits, in_splits, group=group)
+        # rows of one source arrive together and in order; patches interleave over the sources
+        mine = recv
+        if order_key is not None and mine.size(0) > 0:
+            mine = gather_rows(recv, _sort_by_small_key(recv[:, -1], order_key_max))
+    else:
+        mine = rows
+    mark('gather')
+    allrows = mine[:, :ncols].contiguous()
+    kept, keep = merge_detections(allrows, iou_thr, num_classes, class_thrs, nms_fn, strict)
+    if gather_result and world > 1:
+        kk = torch.cat([kept, mine[keep][:, -1:]], 1) if kept.size(0) else mine[:0]
+        padded, counts, _ = _gather_padded(kk, group, _PAD_KEY)
+        if order_key is not None:
+            kept = _restore_by_key(padded, sum(counts), ncols, order_key_max)
+        else:
+            nmax = padded.size(0) // world
+            kept = torch.cat([padded[r * nmax:r * nmax + c] for r, c in enumerate(counts)], 0)[:, :ncols]
+    mark('merge')
+    return kept, keep, allrows
+
+
 def distributed_merge(local, iou_thr, num_classes, class_thrs=None, group=None, nms_fn=None,
                       seq=None, layout='replicated', strict=False, mark=None, order_key=None,
-                      order_key_max=None):
+                      order_key_max=None, gather_result=True):
     """gather_detections + merge_detections.  Every rank returns the same result
     (the reference evaluates on rank 0 only, tools/dota/dota_test.py:157-166).
 
@@ -254,18 +325,25 @@ def distributed_merge(local, iou_thr, num_classes, class_thrs=None, group=None, 
             key, rank-local order inside a key.  Takes precedence over ``seq``.
         order_key_max (int, optional): an upper bound of the keys (e.g. the number of patches); below
             2**15 the sort runs on 16-bit keys.
-        layout: 'replicated' | 'sharded' (module docstring).
+        layout: 'replicated' | 'sharded' | 'routed' (module docstring; 'routed' = ``routed_merge``: its keep
+            indices / gathered rows are this rank's routed rows, not all rows).
+        gather_result (bool): 'routed' only -- False leaves the kept rows with the rank that owns their image.
         mark (callable, optional): ``mark('gather')`` / ``mark('merge')`` are called after the
             respective phase (e.g. to record HIP events).
     Returns:
         (kept rows, keep indices into the gathered rows, gathered rows)
     """
-    if layout not in ('replicated', 'sharded'):
-        raise ValueError('layout must be "replicated" or "sharded"')
+    if layout not in ('replicated', 'sharded', 'routed'):
+        raise ValueError('layout must be "replicated", "sharded" or "routed"')
     mark = mark or (lambda name: None)
     ncols = local.size(1)
     if _world(group)[0] == 1:
         seq = order_key = None      # one rank: the local rows ARE the single-process order
+    if layout == 'routed':
+        if seq is not None and order_key is None:
+            raise ValueError("layout='routed' restores the order from `order_key` (small integers), not from `seq`")
+        return routed_merge(local, iou_thr, num_classes, class_thrs, group, nms_fn, strict, mark, order_key,
+                            order_key_max, gather_result)
     if order_key is not None:
         key = order_key.to(local.dtype)[:, None]         # (exact in fp32 below 2**24)
         padded, counts, _ = _gather_padded(torch.cat([local, key], 1), group, _PAD_KEY)
@@ -359,7 +437,7 @@ def patch_rows_to_image(dets, labels, patch_index, patch_xy, patch_image, rate=1
 
 def tiled_inference_merge(dets, labels, patch_index, seq, patch_xy, patch_image, num_classes,
                           local_thr=0.5, merge_thr=0.3, class_thrs=None, group=None,
-                          layout='replicated', nms_fn=None, mark=None):
+                          layout='replicated', nms_fn=None, mark=None, gather_result=True):
     """One pass of BASELINE.json configs[4] over this rank's patches:
 
         per-patch, per-class rotated NMS of the local detections (one grouped launch)
@@ -381,4 +459,5 @@ def tiled_inference_merge(dets, labels, patch_index, seq, patch_xy, patch_image,
         elif seq is not None:
             skept = seq[keep]
     return distributed_merge(rows, merge_thr, num_classes, class_thrs, group, nms_fn, skept,
-                             layout, mark=mark, order_key=okey, order_key_max=int(patch_xy.size(0)))
+                             layout, mark=mark, order_key=okey, order_key_max=int(patch_xy.size(0)),
+                             gather_result=gather_result)

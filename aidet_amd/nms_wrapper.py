@@ -172,7 +172,11 @@ def _nms_generic(dets, iou_thr, device_id, cols, kind, name, groups=None, thrs=N
 def _take_rows(dets, inds):
     """dets[inds, :] -- fp32 rows on the GPU through the library's row gather (torch's advanced indexing
     costs 20-40 us for 1e5 rows of 24 bytes, a third of a 100k-box call)."""
-    if dets.is_cuda and dets.dtype == torch.float32 and inds.numel() >= 4096 and inds.device == dets.device:   # (below: the ctypes call costs more)
+    # (the raw kernel has no autograd history: rows that must stay differentiable w.r.t. dets, as the reference's
+    # dets[inds, :] are, take torch's indexing whatever their number)
+    differentiable = torch.is_grad_enabled() and dets.requires_grad
+    if (dets.is_cuda and dets.dtype == torch.float32 and inds.numel() >= 4096 and inds.device == dets.device
+            and not differentiable):   # (below 4096 rows the ctypes call costs more)
         src = dets.contiguous()
         out = src.new_empty((inds.numel(), src.size(1)))
         with torch.cuda.device(src.device):
@@ -252,6 +256,12 @@ def nms(dets, iou_thr, device_id=None, groups=None, thrs=None, strict=False):
     if not strict and thrs is None and not float(iou_thr) > 0.0:
         raise ValueError('nms: iou_thr must be positive (got {}); with the reference\'s `>=` rule a '
                          'non-positive threshold keeps only the best box'.format(iou_thr))
+    if not strict and thrs is not None:
+        # the same rule box by box: a per-box threshold <= 0 would have to suppress every later box of its group,
+        # disjoint ones included (nms_cpu.cpp:56), which the kernels' broad phase never even tests
+        t = _as_tensor(thrs)
+        if t.numel() and not bool((t > 0).all()):
+            raise ValueError('nms: every per-box threshold must be positive under the `>=` rule')
     return _nms_generic(dets, iou_thr, device_id, 5, _lib.KIND_HBB, 'nms', groups, thrs, strict)
 
 
@@ -319,6 +329,45 @@ def soft_nms(dets, iou_thr, method='linear', sigma=0.5, min_score=1e-3, device_i
     return new_dets.cpu().numpy().astype(dets.dtype), inds.cpu().numpy().astype(np.int64)
 
 
+def soft_nms_grouped(dets, seg_sizes, iou_thr, method='linear', sigma=0.5, min_score=1e-3):
+    """Soft-NMS of several independent groups in ONE launch (``obb_soft_nms_grouped_f32``): the rows of ``dets`` (n, 5)
+    are grouped contiguously, ``seg_sizes`` (list of ints or int tensor) their sizes.  Group g gets exactly the result
+    of ``soft_nms(dets[group g], ...)`` -- the per-class calls of ``multiclass_nms_with_index`` (rbbox_nms.py:29-49) --
+    but the groups run concurrently, one workgroup each, with one host read for all the counts.
+
+    Returns:
+        list of (new_dets (k_g, 5), inds (k_g,) relative to the group's first row), one pair per group.
+    """
+    method_codes = {'linear': 1, 'gaussian': 2}
+    if method not in method_codes:
+        raise ValueError('Invalid method for SoftNMS: {}'.format(method))
+    if not (isinstance(dets, torch.Tensor) and dets.dim() == 2 and dets.size(1) == 5):
+        raise ValueError('soft_nms_grouped expects a (n, 5) tensor')
+    d = _lib.to_device_f32(dets.detach())
+    dev = d.device
+    sizes = torch.as_tensor(seg_sizes, dtype=torch.int64).reshape(-1)
+    G, n = sizes.numel(), d.size(0)
+    seg = torch.zeros(G + 1, dtype=torch.int64)
+    seg[1:] = torch.cumsum(sizes.cpu(), 0)
+    assert int(seg[-1]) == n, 'segment sizes must add up to the number of rows'
+    if G == 0:
+        return []
+    L = _lib.lib()
+    seg_dev = seg.to(dev)
+    out = torch.empty((n, 5), dtype=torch.float32, device=dev)
+    oinds = torch.empty(n, dtype=torch.int64, device=dev)
+    counts = torch.empty(G, dtype=torch.int64, device=dev)
+    ws = torch.empty(max(int(L.obb_soft_nms_workspace_bytes(n)), 256), dtype=torch.uint8, device=dev)
+    with _OnDevice(dev):
+        _lib.check(L.obb_soft_nms_grouped_f32(d.data_ptr(), n, seg_dev.data_ptr(), G, float(iou_thr), method_codes[method],
+                                              float(sigma), float(min_score), out.data_ptr(), oinds.data_ptr(),
+                                              counts.data_ptr(), ws.data_ptr(), ws.numel(), _lib.current_stream_handle(dev)))
+    res = []
+    for g, (o, k) in enumerate(zip(seg[:-1].tolist(), counts.tolist())):      # (the one synchronisation)
+        res.append((out[o:o + k].to(device=dets.device, dtype=dets.dtype), oinds[o:o + k].to(dets.device)))
+    return res
+
+
 # ---------------------------------------------------------------------------------------------
 # Asynchronous form: queue several NMS calls, collect them with ONE synchronisation.
 # A detector calls NMS once per FPN level (rpn_head.py:92) and once per class
@@ -329,7 +378,7 @@ _KINDS = {'nms': (_lib.KIND_HBB, 5), 'rnms': (_lib.KIND_RBOX, 6), 'poly_nms': (_
 
 
 class NmsTicket(object):
-    __slots__ = ('dets', 'kind', 'iou_thr', 'groups', 'thrs', 'strict', 'keep', 'record', 'nbytes')
+    __slots__ = ('dets', 'kind', 'iou_thr', 'groups', 'thrs', 'strict', 'keep', 'record', 'nbytes', 'event')
 
 
 def nms_enqueue(dets, iou_thr, op='nms', groups=None, thrs=None, strict=False):
@@ -357,6 +406,9 @@ def nms_enqueue(dets, iou_thr, op='nms', groups=None, thrs=None, strict=False):
         _lib.check(L.obb_nms_async_f32(d.data_ptr(), n, kind, t.iou_thr, gptr, tptr,
                                        _lib.NMS_STRICT if strict else 0, t.keep.data_ptr(),
                                        t.record.data_ptr(), ws.data_ptr(), t.nbytes, stream))
+        # the kernels run on the stream that is current NOW; whoever collects may be on another one
+        t.event = torch.cuda.Event()
+        t.event.record(torch.cuda.current_stream(dev))
     return t
 
 
@@ -367,13 +419,21 @@ def nms_collect(tickets):
     if not tickets:
         return []
     L = _lib.lib()
-    # one copy per device (tickets of one device: one stacked copy; it synchronises that stream)
+    # one copy per device (tickets of one device: one stacked copy).  The copy runs on the stream that is
+    # current HERE, which first waits for the event every ticket recorded on ITS stream at enqueue time
+    # (tickets queued under `with torch.cuda.stream(s)` -- one side stream per FPN level -- and
+    # collected outside it would otherwise be read before their kernels finished); the keep tensors
+    # handed out below are ordered behind the same wait.
     by_dev = {}
     for i, t in enumerate(tickets):
         by_dev.setdefault(t.record.device, []).append(i)
     recs = [None] * len(tickets)
-    for idx in by_dev.values():
-        host = torch.stack([tickets[i].record for i in idx]).cpu().numpy()
+    for dev, idx in by_dev.items():
+        cur = torch.cuda.current_stream(dev)
+        for i in idx:
+            cur.wait_event(tickets[i].event)
+        with torch.cuda.device(dev):
+            host = torch.stack([tickets[i].record for i in idx]).cpu().numpy()
         for row, i in zip(host, idx):
             recs[i] = row
     info = (ctypes.c_int64 * 4)()

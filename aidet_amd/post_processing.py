@@ -65,6 +65,17 @@ def _multiclass(multi_boxes, multi_scores, score_thr, nms_cfg, max_num, score_fa
         # label * (max coordinate + 1), so the op sees the same floats as the reference's
         shift = labels.to(boxes) * (boxes.max() + 1)
         dets, keep = nms_op(torch.cat([boxes + shift[:, None], scores[:, None]], 1), **cfg)
+    elif nms_op is nms_wrapper.soft_nms:
+        # grouped Soft-NMS = every class an array of its own (soft_nms_grouped); the candidates are put into class-major
+        # order for it and `keep` is mapped back to the row-major list
+        if d != 4:
+            raise ValueError("type='soft_nms' is a horizontal-box op (nms_cpu.cpp:71-210): it cannot decide rotated boxes")
+        order = torch.argsort(labels, stable=True)
+        sizes = torch.bincount(labels, minlength=num_fg)
+        res = nms_wrapper.soft_nms_grouped(torch.cat([boxes, scores[:, None]], 1)[order], sizes, **cfg)
+        starts = (torch.cumsum(sizes, 0) - sizes).tolist()
+        dets = torch.cat([r[0] for r in res]) if res else boxes.new_zeros((0, 5))
+        keep = torch.cat([order[r[1] + st] for r, st in zip(res, starts)]) if res else order[:0]
     else:
         # same per-class NMS without moving (and thereby rounding) a coordinate
         dets, keep = nms_op(torch.cat([boxes, scores[:, None]], 1), groups=labels, **cfg)
@@ -141,18 +152,21 @@ def multiclass_nms_with_index(multi_bboxes, multi_scores, score_thr, nms_cfg, ma
     dets = torch.cat([boxes, multi_scores[rows, cls + 1][:, None]], 1)
     nms_op, cfg = _resolve_op(nms_cfg, 'nms')
     if nms_op is nms_wrapper.soft_nms:
-        # Soft-NMS re-scores and re-orders its input and has no grouped form: class by class,
-        # as the reference does for every op (rbbox_nms.py:29-49)
-        parts, bbox_keep_inds, start = [], [], 0
-        for m in per_class.tolist():
-            if m:
-                d, k = nms_op(dets[start:start + m], **cfg)
-                parts.append(d)
-                bbox_keep_inds.append(k)
-            start += m
-        kept = torch.cat(parts)
-        labels = torch.cat([cls.new_full((len(k), ), c) for c, k in zip(
-            [c for c, m in enumerate(per_class.tolist()) if m], bbox_keep_inds)])
+        # Soft-NMS re-scores and re-orders its input: class by class, as the reference does for every op
+        # (rbbox_nms.py:29-49) -- one workgroup per class in ONE launch on the GPU (the classes are independent
+        # arrays there too), the Python loop with one call per class elsewhere
+        sizes = per_class.tolist()
+        present = [c for c, m in enumerate(sizes) if m]
+        if dets.is_cuda:
+            res = nms_wrapper.soft_nms_grouped(dets, [sizes[c] for c in present], **cfg)
+        else:
+            res, start = [], 0
+            for c in present:
+                res.append(nms_op(dets[start:start + sizes[c]], **cfg))
+                start += sizes[c]
+        kept = torch.cat([d for d, _ in res])
+        bbox_keep_inds = [k for _, k in res]
+        labels = torch.cat([cls.new_full((len(k), ), c) for c, k in zip(present, bbox_keep_inds)])
     else:
         kept, keep = nms_op(dets, groups=cls, **cfg)
         labels = cls[keep]

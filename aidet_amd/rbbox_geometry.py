@@ -50,7 +50,118 @@ class _HbbOverlapsGrad(torch.autograd.Function):
                 g2.to(b2.dtype) if need2 and g2 is not None else None, None, None)
 
 
-def _overlaps(b1, b2, mode, is_aligned, cols, kind):
+def rbox_corners(b):
+    """(n, 5) theta-OBBs -> (n, 4, 2) corners (tensor expressions; the cv2.boxPoints meaning of the angle)."""
+    cx, cy, w, h, th = b.unbind(-1)
+    c, s = torch.cos(th), torch.sin(th)
+    lx = torch.stack([-w, w, w, -w], -1) * 0.5
+    ly = torch.stack([-h, -h, h, h], -1) * 0.5
+    return torch.stack([cx[:, None] + lx * c[:, None] - ly * s[:, None],
+                        cy[:, None] + lx * s[:, None] + ly * c[:, None]], -1)
+
+
+def _cross2(a, b):
+    return a[..., 0] * b[..., 1] - a[..., 1] * b[..., 0]
+
+
+def _quad_intersection_area(P, Q):
+    """Area of the intersection of two convex quads (n, 4, 2) with the SAME winding, as differentiable tensor
+    expressions: the vertices of the intersection are the corners of one quad inside the other (4 + 4) and
+    the crossings of their sides (16); the valid ones are ordered by angle about their centroid and the
+    shoelace formula sums them (invalid slots repeat the first vertex: zero area)."""
+    n = P.size(0)
+    org = P.mean(1, keepdim=True).detach()             # coordinates relative to the first box: no cancellation
+    P, Q = P - org, Q - org
+    eps = 1e-12 if P.dtype == torch.float64 else 1e-7
+
+    def inside(pts, quad):                             # pts (n, 4, 2) in quad (n, 4, 2): same side of all 4 edges
+        a = quad[:, None, :, :]                        # (n, 1, 4, 2)
+        e = torch.roll(quad, -1, 1)[:, None, :, :] - a
+        cr = _cross2(e, pts[:, :, None, :] - a)        # (n, 4 pts, 4 edges)
+        sgn = _cross2(torch.roll(quad, -1, 1) - quad, torch.roll(quad, -2, 1) - torch.roll(quad, -1, 1)).sum(1)  # winding
+        cr = cr * torch.sign(sgn)[:, None, None]
+        return (cr >= -eps).all(-1)
+    p_in, q_in = inside(P, Q), inside(Q, P)
+    r = (torch.roll(P, -1, 1) - P)[:, :, None, :]      # (n, 4, 1, 2) sides of P
+    sd = (torch.roll(Q, -1, 1) - Q)[:, None, :, :]     # (n, 1, 4, 2) sides of Q
+    qp = Q[:, None, :, :] - P[:, :, None, :]           # (n, 4, 4, 2)
+    den = _cross2(r, sd)
+    ok = den.abs() > eps
+    den_s = torch.where(ok, den, torch.ones_like(den))
+    t = _cross2(qp, sd) / den_s
+    u = _cross2(qp, r) / den_s
+    hit = ok & (t >= 0) & (t <= 1) & (u >= 0) & (u <= 1)
+    x = P[:, :, None, :] + t[..., None] * r            # (n, 4, 4, 2)
+    pts = torch.cat([P, Q, x.reshape(n, 16, 2)], 1)    # (n, 24, 2)
+    valid = torch.cat([p_in, q_in, hit.reshape(n, 16)], 1)
+    cnt = valid.sum(1, keepdim=True).clamp(min=1)
+    ctr = (pts * valid[..., None]).sum(1, keepdim=True) / cnt[..., None]
+    d = (pts - ctr).detach()
+    ang = torch.atan2(d[..., 1], d[..., 0])
+    ang = torch.where(valid, ang, torch.full_like(ang, 1e9))
+    order = ang.argsort(1)
+    srt = torch.gather(pts, 1, order[..., None].expand(-1, -1, 2))
+    vs = torch.gather(valid, 1, order)
+    srt = torch.where(vs[..., None], srt, srt[:, :1])  # invalid slots: the first vertex (adds no area)
+    area = 0.5 * _cross2(srt, torch.roll(srt, -1, 1)).sum(1).abs()
+    return torch.where(valid.sum(1) >= 3, area, torch.zeros_like(area))
+
+
+def rbbox_overlaps_torch(b1, b2, mode='iou', is_aligned=False):
+    """Rotated IoU / IoF as DIFFERENTIABLE tensor expressions (any device, fp32 or fp64): the second algorithm
+    behind the gradient of ``rbbox_overlaps`` (the reference's IoU loss differentiates through the aligned
+    horizontal IoU, models/losses/iou_loss.py:25; this is the rotated counterpart).  Values agree with the
+    kernel's to rounding; the kernel, not this, produces the forward values of ``rbbox_overlaps``."""
+    assert mode in ('iou', 'iof')
+    if not is_aligned:
+        m, n = b1.size(0), b2.size(0)
+        b1 = b1[:, None, :].expand(m, n, 5).reshape(-1, 5)
+        b2 = b2[None, :, :].expand(m, n, 5).reshape(-1, 5)
+    inter = _quad_intersection_area(rbox_corners(b1), rbox_corners(b2))
+    a1, a2 = b1[:, 2] * b1[:, 3], b2[:, 2] * b2[:, 3]
+    inter = torch.min(inter, torch.min(a1, a2).clamp(min=0))
+    den = a1 + a2 - inter if mode == 'iou' else a1
+    out = torch.where(den > 0, inter / torch.where(den > 0, den, torch.ones_like(den)), torch.zeros_like(den))
+    return out if is_aligned else out.view(m, n)
+
+
+class _RboxOverlapsGrad(torch.autograd.Function):
+    """``rbbox_overlaps`` with a gradient (a rotated IoU loss): forward = the HIP kernel, backward = autograd of
+    ``rbbox_overlaps_torch`` re-evaluated on the saved boxes (the pattern of ``_HbbOverlapsGrad``)."""
+    MAX_PAIRS = 1 << 20
+
+    @staticmethod
+    def forward(ctx, b1, b2, mode, is_aligned):
+        ctx.save_for_backward(b1, b2)
+        ctx.args = (mode, is_aligned)
+        with torch.no_grad():
+            return _overlaps(b1, b2, mode, is_aligned, 5, _lib.KIND_RBOX)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        b1, b2 = ctx.saved_tensors
+        mode, is_aligned = ctx.args
+        with torch.enable_grad():
+            x1 = b1.detach().float().requires_grad_(True)
+            x2 = b2.detach().float().requires_grad_(True)
+            out = rbbox_overlaps_torch(x1, x2, mode, is_aligned)
+            g1, g2 = torch.autograd.grad(out, [x1, x2], grad_out.reshape(out.shape).to(out.dtype), allow_unused=True)
+        need1, need2 = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        return (g1.to(b1.dtype) if need1 and g1 is not None else None,
+                g2.to(b2.dtype) if need2 and g2 is not None else None, None, None)
+
+
+def row_block(m, rank, world):
+    """[lo, hi) of the rows rank ``rank`` of ``world`` owns when ``m`` query rows are dealt in contiguous blocks
+    of ceil(m / world) (the row-block partition of ``rbbox_overlaps`` needs no communication)."""
+    rank, world = int(rank), int(world)
+    if not 0 <= rank < world:
+        raise ValueError('row_shard=(rank, world) needs 0 <= rank < world, got ({}, {})'.format(rank, world))
+    per = (int(m) + world - 1) // world
+    return min(rank * per, int(m)), min((rank + 1) * per, int(m))
+
+
+def _overlaps(b1, b2, mode, is_aligned, cols, kind, row_shard=None):
     assert mode in ['iou', 'iof']
     if not isinstance(b1, torch.Tensor) or not isinstance(b2, torch.Tensor):
         raise TypeError('boxes must be torch.Tensor, got {} and {}'.format(type(b1), type(b2)))
@@ -60,6 +171,13 @@ def _overlaps(b1, b2, mode, is_aligned, cols, kind):
         b2 = b2.reshape(0, cols)
     assert b1.dim() == 2 and b1.size(1) == cols, 'expected (m, %d) boxes' % cols
     assert b2.dim() == 2 and b2.size(1) == cols, 'expected (n, %d) boxes' % cols
+    if row_shard is not None:
+        # this rank's block of query rows against ALL of b2 (aligned mode: the same block of both)
+        lo, hi = row_block(b1.size(0), *row_shard)
+        b1 = b1[lo:hi]
+        if is_aligned:
+            assert b2.size(0) >= hi
+            b2 = b2[lo:hi]
     rows, n = b1.size(0), b2.size(0)
     if is_aligned:
         assert rows == n
@@ -68,10 +186,15 @@ def _overlaps(b1, b2, mode, is_aligned, cols, kind):
     if rows * n == 0:
         return b1.new_zeros((rows, 1) if is_aligned else (rows, n))
     if torch.is_grad_enabled() and (b1.requires_grad or b2.requires_grad):
-        if kind != _lib.KIND_HBB:
-            raise RuntimeError('rbbox_overlaps / pointobb_overlaps have no gradient: detach the boxes '
-                               '(target assignment) or use bbox_overlaps for a horizontal IoU loss')
-        return _HbbOverlapsGrad.apply(b1, b2, mode, is_aligned)
+        if kind == _lib.KIND_HBB:
+            return _HbbOverlapsGrad.apply(b1, b2, mode, is_aligned)
+        if kind == _lib.KIND_RBOX:
+            if rows * (1 if is_aligned else n) > _RboxOverlapsGrad.MAX_PAIRS:
+                raise RuntimeError('rbbox_overlaps: a gradient over {} pairs is not supported (the backward holds 24 '
+                                   'candidate vertices per pair); use is_aligned=True on matched pairs, as an IoU loss '
+                                   'does'.format(rows * (1 if is_aligned else n)))
+            return _RboxOverlapsGrad.apply(b1, b2, mode, is_aligned)
+        raise RuntimeError('pointobb_overlaps has no gradient: detach the boxes (target assignment)')
     a = _lib.to_device_f32(b1)
     b = _lib.to_device_f32(b2).to(a.device)
     out = torch.empty((rows,) if is_aligned else (rows, n), dtype=torch.float32, device=a.device)
@@ -84,7 +207,7 @@ def _overlaps(b1, b2, mode, is_aligned, cols, kind):
     return out.to(device=b1.device, dtype=b1.dtype if b1.is_floating_point() else torch.float32)
 
 
-def rbbox_overlaps(rbboxes1, rbboxes2, mode='iou', is_aligned=False):
+def rbbox_overlaps(rbboxes1, rbboxes2, mode='iou', is_aligned=False, row_shard=None):
     """Overlap between two sets of theta-OBBs.
 
     Same calling shape as the reference's ``bbox_overlaps`` (geometry.py:4).
@@ -95,11 +218,16 @@ def rbbox_overlaps(rbboxes1, rbboxes2, mode='iou', is_aligned=False):
         rbboxes2 (Tensor): (n, 5); if ``is_aligned`` then m == n.
         mode (str): "iou" or "iof" (intersection over the area of rbboxes1).
         is_aligned (bool): pairwise instead of all-pairs.
+        row_shard ((rank, world), optional): compute only this rank's contiguous block of query rows
+            (``row_block``) against all of ``rbboxes2`` -- the multi-GPU partition of the op: independent row
+            blocks, no communication; the blocks of all ranks concatenated are the full matrix.
 
     Returns:
         Tensor: (m, n), or (m,) when aligned ((m, 1) for empty aligned input,
         as geometry.py:54-55).  Computed in fp32 on the HIP device; returned on
-        the input's device in the input's dtype.
+        the input's device in the input's dtype.  Differentiable w.r.t. both box sets (forward: the kernel;
+        backward: autograd of ``rbbox_overlaps_torch``), so that a rotated IoU loss can be built on it the way
+        the reference builds its IoU loss on ``bbox_overlaps(..., is_aligned=True)`` (losses/iou_loss.py:25).
 
     Example:
         >>> a = torch.tensor([[0., 0., 1., 1., 0.]]).cuda()
@@ -107,7 +235,7 @@ def rbbox_overlaps(rbboxes1, rbboxes2, mode='iou', is_aligned=False):
         >>> rbbox_overlaps(a, b)   # regular octagon: sqrt(2)/2
         tensor([[0.7071]], device='cuda:0')
     """
-    return _overlaps(rbboxes1, rbboxes2, mode, is_aligned, 5, _lib.KIND_RBOX)
+    return _overlaps(rbboxes1, rbboxes2, mode, is_aligned, 5, _lib.KIND_RBOX, row_shard)
 
 
 def bbox_overlaps(bboxes1, bboxes2, mode='iou', is_aligned=False):

@@ -14,9 +14,17 @@ codecs -- ``pointobb2delta`` / ``delta2pointobb`` (:412-504), ``hobb2delta`` / `
 (:522-599) -- and the host-side helpers around them (``pointobb2bbox`` :57-70, the two point-order rules
 :93-134, ``hobb2pointobb`` :137-163, ``pointobb_flip`` :205-240, ``*_rescale`` :295-318,
 ``*_mapping(_back)`` :507-519, 602-613) are restated below and pinned by
-tests/golden/obb_codecs.npz.  Not here: the routines that are thin wrappers of OpenCV
-(``pointobb2thetaobb`` = ``cv2.minAreaRect``, ``maskobb2thetaobb``, and with them ``thetaobb2hobb``
-and ``hobb_flip``): cv2 is not part of this image, so they could neither be pinned nor used.
+tests/golden/obb_codecs.npz.
+
+The inverse codecs the reference builds on OpenCV -- ``pointobb2thetaobb`` = ``cv2.minAreaRect`` (:30-43),
+``thetaobb2pointobb`` = ``cv2.boxPoints`` (:45-55), and on top of them ``thetaobb2hobb`` (:73-91) and ``hobb_flip``
+(:243-278) -- are restated WITHOUT cv2 (``min_area_rect``: rotating calipers over the edge directions of the four
+points; ``box_points``: ``RotatedRect::points``), in the angle / size convention of the OpenCV releases the
+reference was written against (theta in [-90, 0) degrees, the `width` is the side along (cos theta, sin theta);
+an axis-aligned box therefore comes back as theta = -90 with width and height swapped).  cv2 is not part of
+this image, so these four are pinned by round trips and analytic cases only (tests/test_rbbox_transforms.py),
+not by vectors of the reference.  Still not here: ``maskobb2thetaobb`` (:166-189; RLE decoding by pycocotools
+and ``cv2.findContours`` -- a mask pipeline, not a box codec).
 """
 import math
 
@@ -257,20 +265,108 @@ def hobb_corner_points(hobbs):
     return torch.stack([x1, y1, x2, y2, x2 - dx, y2 + dy, x1 - dx, y1 + dy], dim=-1)
 
 
-def _no_hobb_flip():
-    raise NotImplementedError('flipping a hobb goes through cv2.minAreaRect in the reference '
-                              '(transforms.py:243-275); OpenCV is not part of this build')
+# ---- the OpenCV-backed inverse codecs, without OpenCV ---------------------------------------------------
+def box_points(thetaobbs):
+    """(..., 5) cx, cy, w, h, theta [rad] -> (..., 8) corners in ``cv2.boxPoints`` order
+    (OpenCV ``RotatedRect::points``: a = sin/2, b = cos/2; p0 = (cx - a h - b w, cy + b h - a w),
+    p1 = (cx + a h - b w, cy - b h - a w), p2 = 2c - p0, p3 = 2c - p1).  Host-side float64 twin of the
+    device op ``rbbox_geometry.thetaobb2pointobb``."""
+    t = np.asarray(thetaobbs, dtype=np.float64)
+    cx, cy, w, h, th = (t[..., i] for i in range(5))
+    a, b = np.sin(th) * 0.5, np.cos(th) * 0.5
+    x0, y0 = cx - a * h - b * w, cy + b * h - a * w
+    x1, y1 = cx + a * h - b * w, cy - b * h - a * w
+    return np.stack([x0, y0, x1, y1, 2 * cx - x0, 2 * cy - y0, 2 * cx - x1, 2 * cy - y1], axis=-1)
+
+
+def min_area_rect(quads):
+    """(n, 8) four points each -> (n, 5) cx, cy, w, h, theta [DEGREES] of the smallest enclosing rectangle,
+    in the convention of ``cv2.minAreaRect`` as the reference uses it (:38-40): theta in [-90, 0), `w` the
+    side along (cos theta, sin theta).
+
+    The minimal rectangle has a side collinear with a hull edge, so the six directions through two of the
+    four points are tried (the four sides first, then the diagonals, which only matter for point sets that
+    are not a convex quad in order); the smallest area wins, ties go to the earlier direction (OpenCV's
+    choice among equal areas depends on its hull start point: a square may come back rotated by 90 degrees,
+    which describes the same box).  Coincident points: a zero-length direction is skipped; all four equal
+    gives w = h = 0, theta = -90 (OpenCV returns angle 0 there)."""
+    q = np.asarray(quads, dtype=np.float64).reshape(-1, 4, 2)
+    n = q.shape[0]
+    best = np.full(n, np.inf)
+    out = np.zeros((n, 5))
+    out[:, 0:2] = q.mean(axis=1)
+    out[:, 4] = -90.0
+    for i, j in ((0, 1), (1, 2), (2, 3), (3, 0), (0, 2), (1, 3)):
+        d = q[:, j] - q[:, i]
+        ln = np.hypot(d[:, 0], d[:, 1])
+        ok = ln > 0
+        u = np.where(ok[:, None], d / np.where(ok, ln, 1.0)[:, None], np.array([1.0, 0.0]))
+        v = np.stack([-u[:, 1], u[:, 0]], axis=1)
+        a = (q * u[:, None, :]).sum(-1)
+        b = (q * v[:, None, :]).sum(-1)
+        a0, a1, b0, b1 = a.min(1), a.max(1), b.min(1), b.max(1)
+        lu, lv = a1 - a0, b1 - b0
+        area = np.where(ok, lu * lv, np.inf)
+        take = area < best
+        if not take.any():
+            continue
+        best = np.where(take, area, best)
+        ctr = u * ((a0 + a1) * 0.5)[:, None] + v * ((b0 + b1) * 0.5)[:, None]
+        phi = np.degrees(np.arctan2(u[:, 1], u[:, 0]))
+        k = np.floor(phi / 90.0) + 1.0
+        theta = phi - 90.0 * k
+        theta = np.where(theta >= 0.0, theta - 90.0, theta)        # (rounding at a multiple of 90)
+        k = np.where(phi - 90.0 * k >= 0.0, k + 1.0, k)
+        odd = (k.astype(np.int64) % 2) != 0
+        w, h = np.where(odd, lv, lu), np.where(odd, lu, lv)
+        new = np.stack([ctr[:, 0], ctr[:, 1], w, h, theta], axis=1)
+        out = np.where(take[:, None], new, out)
+    return out
+
+
+def pointobb2thetaobb(pointobb, truncate=True):
+    """[x1, y1, ..., x4, y4] -> [cx, cy, w, h, theta (rad)] (:30-43): the reference truncates the points to
+    integers (``np.int0``) before ``cv2.minAreaRect``; ``truncate=False`` skips that (exact round trips)."""
+    pts = np.asarray(pointobb, dtype=np.float64).reshape(8)
+    if truncate:
+        pts = np.trunc(pts)
+    x, y, w, h, theta = min_area_rect(pts[None])[0]
+    return [float(x), float(y), float(w), float(h), float(theta / 180.0 * np.pi)]
+
+
+def thetaobb2pointobb_host(thetaobb):
+    """[cx, cy, w, h, theta (rad)] -> the 8 corner coordinates, ``cv2.boxPoints`` order (:45-55)."""
+    return box_points(np.asarray(thetaobb, dtype=np.float64)[:5]).tolist()
+
+
+def thetaobb2hobb(thetaobb, pointobb_sort_fun):
+    """theta-OBB -> hobb [x1, y1, x2, y2, h] (:73-91): corner points, put into the order of
+    ``pointobb_sort_fun``; the first two are kept, h = distance of the last point from the first."""
+    p = pointobb_sort_fun(thetaobb2pointobb_host(thetaobb))
+    h = float(np.sqrt((p[6] - p[0]) ** 2 + (p[7] - p[1]) ** 2))
+    return [p[0], p[1], p[2], p[3], h]
+
+
+def hobb_flip(hobbs, img_shape):
+    """Mirror (..., 5) hobbs left-right the way the reference does (:243-278, its live branch): every hobb ->
+    integer corner points (``hobb2pointobb``) -> ``pointobb_flip`` -> ``pointobb2thetaobb`` (integer points,
+    minimal rectangle) -> ``thetaobb2hobb`` in best-point order.  float64 (n, 5) out."""
+    hobbs = np.asarray(hobbs, dtype=np.float64)
+    if hobbs.ndim == 1:
+        hobbs = hobbs[np.newaxis, ...]
+    assert hobbs.shape[-1] % 5 == 0
+    quads = np.array([hobb2pointobb(hb) for hb in hobbs.reshape(-1, 5)], dtype=np.float64)
+    quads = pointobb_flip(quads, img_shape).reshape(-1, 8)
+    out = [thetaobb2hobb(pointobb2thetaobb(qd), pointobb_best_point_sort) for qd in quads]
+    return np.array(out, dtype=np.float64)
 
 
 def hobb_mapping(hobbs, img_shape, scale_factor, flip):
-    """original image scale -> an augmentation's scale (:602-607); ``flip=True`` is not available."""
-    if flip:
-        _no_hobb_flip()
-    return hobbs * scale_factor
+    """original image scale -> an augmentation's scale (:602-607): scale, then flip."""
+    scaled = hobbs * scale_factor
+    return hobb_flip(scaled, img_shape) if flip else scaled
 
 
 def hobb_mapping_back(hobbs, img_shape, scale_factor, flip):
-    """the inverse (:609-613); ``flip=True`` is not available."""
-    if flip:
-        _no_hobb_flip()
-    return hobbs / scale_factor
+    """the inverse (:609-613): un-flip, then divide."""
+    return (hobb_flip(hobbs, img_shape) if flip else hobbs) / scale_factor

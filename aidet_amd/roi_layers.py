@@ -70,6 +70,33 @@ def roi_backward(grad_out, rois, feature_size, roi_kind, out_h, out_w, spatial_s
     return grad
 
 
+def roi_forward(feats, rois, levels, out_h, out_w, scales, sample_num, roi_kind, min_size):
+    """The forward of every RoI-Align flavour: ``obb_roi_align_forward_ws_f32`` -- one launch over the level(s) after
+    one small launch that orders the RoIs along a Morton curve (L2 locality; workspace from torch's caching allocator).
+
+    feats: list of contiguous fp32 (B, C, H_l, W_l) HIP tensors; rois: contiguous fp32 (K, 5 | 6) on the same device;
+    levels: int32 (K,) or None for a single map.  Returns (K, C, out_h, out_w) fp32."""
+    dev = feats[0].device
+    B, C = feats[0].shape[:2]
+    K, n = rois.size(0), len(feats)
+    out = torch.empty((K, C, out_h, out_w), dtype=torch.float32, device=dev)
+    if K == 0 or C == 0:
+        return out
+    L = _lib.lib()
+    ptrs = (ctypes.c_void_p * n)(*[f.data_ptr() for f in feats])
+    hs = (ctypes.c_int * n)(*[f.shape[2] for f in feats])
+    wd = (ctypes.c_int * n)(*[f.shape[3] for f in feats])
+    sc = (ctypes.c_float * n)(*[float(x) for x in scales])
+    ws = torch.empty(int(L.obb_roi_forward_workspace_bytes(K)), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = L.obb_roi_align_forward_ws_f32(ptrs, hs, wd, sc, n, B, C, rois.data_ptr(),
+                                            None if levels is None else levels.data_ptr(), K, out_h, out_w,
+                                            int(sample_num), int(roi_kind), float(min_size), out.data_ptr(),
+                                            ws.data_ptr(), ws.numel(), _lib.current_stream_handle(dev))
+    _lib.check(rc)
+    return out
+
+
 class RoIAlignFunction(Function):
     """Horizontal RoIAlign (roi_align.py:9-73): features NCHW, rois (K, 5)
     [batch, x1, y1, x2, y2]; gradient w.r.t. the features only."""
@@ -86,15 +113,7 @@ class RoIAlignFunction(Function):
         feat = features.detach().to(torch.float32).contiguous()
         r = rois.detach().to(device=feat.device, dtype=torch.float32).contiguous()
         ctx.save_for_backward(r)
-        B, C, H, W = feat.shape
-        K = r.size(0)
-        out = torch.empty((K, C, out_h, out_w), dtype=torch.float32, device=feat.device)
-        if K > 0 and C > 0:
-            with torch.cuda.device(feat.device):
-                rc = _lib.lib().obb_roi_align_forward_f32(
-                    feat.data_ptr(), B, C, H, W, r.data_ptr(), K, out_h, out_w, ctx.args[2], ctx.args[3],
-                    ctx.args[4], out.data_ptr(), _lib.current_stream_handle(feat.device))
-            _lib.check(rc)
+        out = roi_forward([feat], r, None, out_h, out_w, [ctx.args[2]], ctx.args[3], 2 if aligned else 1, 0.0)
         return out.to(features.dtype)
 
     @staticmethod
@@ -137,7 +156,7 @@ class RoIAlign(nn.Module):
 
 def pyramid_roi_align(feats, rois, levels, out_size, scales, sample_num, roi_kind, min_size=1.0):
     """RoI-Align of every RoI on the pyramid level ``levels`` names, in ONE kernel launch
-    (obb_roi_align_levels_forward_f32): no per-level mask / gather / launch / scatter
+    (obb_roi_align_forward_ws_f32): no per-level mask / gather / launch / scatter
     (single_level.py:101-106).  Inference only (no autograd graph).
 
     feats: list of (B, C, H_l, W_l) fp32 HIP tensors; rois (K, 5 | 6); levels (K,) int;
@@ -146,22 +165,8 @@ def pyramid_roi_align(feats, rois, levels, out_size, scales, sample_num, roi_kin
     dev = feats[0].device
     r = rois.detach().to(device=dev, dtype=torch.float32).contiguous()
     lv = levels.detach().to(device=dev, dtype=torch.int32).contiguous()
-    B, C = feats[0].shape[:2]
-    K, n = r.size(0), len(feats)
     out_h, out_w = _pair(out_size)
-    out = torch.empty((K, C, out_h, out_w), dtype=torch.float32, device=dev)
-    if K == 0 or C == 0:
-        return out
-    ptrs = (ctypes.c_void_p * n)(*[f.data_ptr() for f in feats])
-    hs = (ctypes.c_int * n)(*[f.shape[2] for f in feats])
-    ws = (ctypes.c_int * n)(*[f.shape[3] for f in feats])
-    sc = (ctypes.c_float * n)(*[float(x) for x in scales])
-    with torch.cuda.device(dev):
-        rc = _lib.lib().obb_roi_align_levels_forward_f32(ptrs, hs, ws, sc, n, B, C, r.data_ptr(), lv.data_ptr(), K,
-                                                         out_h, out_w, int(sample_num), int(roi_kind), float(min_size),
-                                                         out.data_ptr(), _lib.current_stream_handle(dev))
-    _lib.check(rc)
-    return out
+    return roi_forward(feats, r, lv, out_h, out_w, scales, sample_num, roi_kind, min_size)
 
 
 def _fusable(layers, feats, rois):

@@ -10,14 +10,67 @@ grouped launch (group = level): boxes of different levels never interact, and be
 keep list comes back ascending in the concatenated index, it IS the reference's
 ``torch.cat(mlvl_proposals)`` order (level-major, descending score inside a level).
 """
+import ctypes
+
 import torch
 
-from . import nms_wrapper
+from . import _lib, nms_wrapper
 from .bbox_transforms import delta2bbox
+
+SEL_MAX = 2048     # obb_rpn_select_decode_f32 / obb_rows_topk_f32 keep at most this many rows per selection
 
 
 def _cfg(cfg, name):
     return cfg[name] if isinstance(cfg, dict) else getattr(cfg, name)
+
+
+FUSED = True    # False: the tensor-op path below also on the GPU (the specification the fused path is tested against)
+
+
+def _rpn_proposals_fused(cls_scores, bbox_preds, mlvl_anchors, img_shape, nms_pre, nms_post, max_num, nms_thr,
+                         means, stds, use_sigmoid):
+    """The same proposals from three launches + one NMS call: ``obb_rpn_select_decode_f32`` (per level: exact top
+    ``nms_pre`` by score, delta2bbox, clamp), the grouped horizontal NMS, ``obb_rows_topk_f32`` (per-level cut at
+    ``nms_post``, top ``max_num`` by score)."""
+    L = _lib.lib()
+    dev = cls_scores[0].device
+    n = len(cls_scores)
+    cls = [c.detach().contiguous() for c in cls_scores]
+    reg = [r.detach().contiguous() for r in bbox_preds]
+    anc = [a.detach().contiguous() for a in mlvl_anchors]
+    A = reg[0].size(0) // 4
+    hs = (ctypes.c_int * n)(*[c.size(-2) for c in cls])
+    wd = (ctypes.c_int * n)(*[c.size(-1) for c in cls])
+    per_level = [min(nms_pre, c.size(-2) * c.size(-1) * A) for c in cls]
+    N = sum(per_level)
+    if N == 0:
+        return cls[0].new_zeros((0, 5))
+    dets = torch.empty((N, 5), dtype=torch.float32, device=dev)
+    levels = torch.empty(N, dtype=torch.int32, device=dev)
+    rows = ctypes.c_int64(0)
+    pc = (ctypes.c_void_p * n)(*[c.data_ptr() for c in cls])
+    pr = (ctypes.c_void_p * n)(*[r.data_ptr() for r in reg])
+    pa = (ctypes.c_void_p * n)(*[a.data_ptr() for a in anc])
+    mh, mw = (int(img_shape[0]), int(img_shape[1])) if img_shape is not None else (0, 0)
+    with torch.cuda.device(dev):
+        st = _lib.current_stream_handle(dev)
+        _lib.check(L.obb_rpn_select_decode_f32(pc, pr, pa, hs, wd, n, A, 1 if use_sigmoid else 0, int(nms_pre),
+                                               (ctypes.c_float * 4)(*[float(v) for v in means]),
+                                               (ctypes.c_float * 4)(*[float(v) for v in stds]), 16 / 1000.0, mh, mw,
+                                               dets.data_ptr(), levels.data_ptr(), ctypes.byref(rows), st))
+        assert rows.value == N
+        keep, _ = nms_wrapper._run_nms(dets, _lib.KIND_HBB, float(nms_thr), levels)
+        K = int(keep.numel())
+        base = [0]
+        for m in per_level:
+            base.append(base[-1] + m)
+        out = torch.empty((max_num, 5), dtype=torch.float32, device=dev)
+        count = torch.empty(1, dtype=torch.int64, device=dev)
+        _lib.check(L.obb_rows_topk_f32(dets.data_ptr(), N, 5, 4, keep.data_ptr(), K, (ctypes.c_int * (n + 1))(*base), n,
+                                       int(nms_post), int(max_num), out.data_ptr(), None, count.data_ptr(), st))
+    # every level keeps all its survivors when it has at most nms_post candidates: the count is then known here
+    num = min(max_num, K) if all(m <= nms_post for m in per_level) else int(count.item())
+    return out[:num]
 
 
 def rpn_proposals(cls_scores, bbox_preds, mlvl_anchors, img_shape, cfg, target_means=(.0, .0, .0, .0),
@@ -32,10 +85,15 @@ def rpn_proposals(cls_scores, bbox_preds, mlvl_anchors, img_shape, cfg, target_m
         cfg: ``nms_pre``, ``nms_post``, ``max_num``, ``nms_thr``, ``min_bbox_size``,
             ``nms_across_levels`` (test_cfg.rpn of configs/dota/dota_v002...:118-124).
     """
-    nms_op = nms_op or nms_wrapper.nms
     nms_pre, nms_post, max_num = _cfg(cfg, 'nms_pre'), _cfg(cfg, 'nms_post'), _cfg(cfg, 'max_num')
     min_size = _cfg(cfg, 'min_bbox_size')
     num_levels = len(cls_scores)
+    if (nms_op is None and FUSED and min_size <= 0 and not _cfg(cfg, 'nms_across_levels') and 0 < nms_pre <= SEL_MAX
+            and 0 < max_num <= SEL_MAX and num_levels <= 8
+            and all(t.is_cuda and t.dtype == torch.float32 for t in list(cls_scores) + list(bbox_preds) + list(mlvl_anchors))):
+        return _rpn_proposals_fused(cls_scores, bbox_preds, mlvl_anchors, img_shape, nms_pre, nms_post, max_num,
+                                    _cfg(cfg, 'nms_thr'), target_means, target_stds, use_sigmoid_cls)
+    nms_op = nms_op or nms_wrapper.nms
     lvl_scores, lvl_regs = [], []
     for cls, reg in zip(cls_scores, bbox_preds):
         assert cls.size()[-2:] == reg.size()[-2:]

@@ -36,17 +36,8 @@ class RRoIAlignFunction(Function):
         feat = features.detach().to(torch.float32).contiguous()
         r = rois.detach().to(device=feat.device, dtype=torch.float32).contiguous()
         ctx.save_for_backward(r)
-        B, C, H, W = feat.shape
-        K = r.size(0)
-        out = torch.empty((K, C, out_h, out_w), dtype=torch.float32, device=feat.device)
-        if K > 0 and C > 0:
-            with torch.cuda.device(feat.device):
-                rc = _lib.lib().obb_rroi_align_forward_f32(
-                    ctypes.c_void_p(feat.data_ptr()), B, C, H, W, ctypes.c_void_p(r.data_ptr()),
-                    K, out_h, out_w, ctypes.c_float(ctx.spatial_scale), ctx.sample_num,
-                    ctypes.c_float(ctx.min_size), ctypes.c_void_p(out.data_ptr()),
-                    _lib.stream_ptr(feat.device))
-            _lib.check(rc)
+        from .roi_layers import roi_forward
+        out = roi_forward([feat], r, None, out_h, out_w, [ctx.spatial_scale], ctx.sample_num, 0, ctx.min_size)
         return out.to(features.dtype)
 
     @staticmethod

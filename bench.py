@@ -6,27 +6,32 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W
   `python bench.py --gpus 4`) this script starts that launcher itself as a child process,
   before anything touches the GPU.  Rank 0 prints ONE JSON line.
 
-N = 1 -- BASELINE.json configs[1]: rotated NMS (`rnms`) on 100 000 synthetic theta-OBBs,
-  IoU thr 0.5, boxes resident in HBM.  One step = one full rnms call incl. the count
-  read-back.  `value` = boxes/s.
-N > 1 -- BASELINE.json configs[4], the one place where the path has a real exchange:
-  tiled inference.  The patches of a fixed set of large images are dealt rank-strided
-  (DistributedSampler, distributed_sampler.py:18-25); one step = per-patch rotated NMS of
-  the rank's detections -> image coordinates -> RCCL all-gather -> merged per-(image, class)
-  rotated NMS with the per-class thresholds of dota.py:324.  Total work is fixed
-  ("scaling": "strong"); `value` = all detections of all ranks / step time.  The keep set is
-  checked against a single-rank run of the same patches (not timed).
+EVERY line (N = 1, 2, 4, 8) carries the same two legs, so the driver's 1 -> 8 curve compares like with like:
 
-Extra objects on the N = 1 line:
-  roofline         dominant kernel (nms_scan_kernel): VALU-issue bound from the committed SQ
-                   counters, HBM accounting from the committed FETCH/WRITE counters, kernel
-                   time from HIP events inside the timed region.  Every `frac` is <= 1.
+  replica  (the timed K steps; `value`)  BASELINE.json configs[1] on every rank: rotated NMS (`rnms`) on
+           100 000 synthetic theta-OBBs, IoU thr 0.5, boxes resident in HBM.  One step = one full rnms call
+           incl. the count read-back.  No data-path collective (independent units): "scaling": "weak",
+           `value` = N x 100 000 x K / max-over-ranks time.  Beside it every rank computes its ROW BLOCK of a
+           16 384 x 16 384 `rbbox_overlaps` (rows dealt in blocks over the ranks, SURVEY 8e(2), no
+           communication): `config.iou_pairs_per_s` = all pairs / max-over-ranks time (strong scaling).
+  cfg5     BASELINE.json configs[4], the one place where the path has a real exchange: tiled inference.  The
+           patches of a fixed set of large images are dealt rank-strided (DistributedSampler,
+           distributed_sampler.py:18-25); one step = per-patch rotated NMS of the rank's detections ->
+           image coordinates -> RCCL exchange -> merged per-(image, class) rotated NMS with the per-class
+           thresholds of dota.py:324.  Total work is fixed (strong scaling): `config.cfg5_boxes_per_s`,
+           `config.cfg5_speedup_vs_single_rank`.  Layouts: `replicated` (north star: all-gather, every rank
+           merges everything; the default), `sharded` and `routed` (all-to-all keyed by image: every phase
+           divides by N) are timed too at N > 1; each keep set is checked against a single-rank run.
+
+The driver keeps the SCALARS of `roofline` and `config` (nested objects and long strings do not survive into
+BENCH_r*.json), so everything BASELINE's metric names is a scalar there: IoU pairs/s, HBM fractions, traffic
+ratios.  Extra objects on the N = 1 line (for profiles/, humans):
   roofline_kernels the HBM-bound kernels (rbbox_overlaps sparse / dense, RRoIAlign forward /
                    backward) with SURVEY 8(d)'s algorithmic bytes, plus the fill / copy rates
                    this GPU reaches.
   cpu_baseline     the C oracle on this host: 1 thread (the reference's loop is serial,
-                   nms_cpu.cpp:35-58) and all cores (OpenMP legs of the oracle).
-  also             side metrics outside the timed region (latencies, cfg5 on one GPU, ...).
+                   nms_cpu.cpp:35-58) and all cores (OpenMP legs of the oracle, best of 3).
+  also             side metrics outside the timed region (latencies, config 4, ...).
 """
 import argparse
 import ctypes
@@ -44,7 +49,8 @@ HBM_PEAK_GBS = 8000.0                 # MI355X HBM3E spec (MI355X_MICROARCH.md)
 # VALU issue: 256 CUs x 4 SIMD-32; a wave64 VALU op occupies its SIMD for 2 cycles
 # (MI355X_MICROARCH.md, cycle constants: v_fma_f32 wave64 = 2 cyc throughput)
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0  # G wave-instructions / s at 2.4 GHz
-COUNTERS = os.path.join(ROOT, 'profiles', 'r02_counters.json')
+COUNTER_FILES = [os.path.join(ROOT, 'profiles', 'r03_counters.json'), os.path.join(ROOT, 'profiles', 'r02_counters.json')]
+IOU_M = 16384                         # rbbox_overlaps leg: 16k x 16k, canvas 8192 (SURVEY 8d scale-up of configs[0])
 
 
 def parse_args():
@@ -57,9 +63,11 @@ def parse_args():
                     help='20000 = DOTA-sparse scene (headline); 4096 = dense stress variant')
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
     ap.add_argument('--no-extras', action='store_true', help='skip the side metrics')
-    ap.add_argument('--merge-layout', default='auto', choices=['auto', 'replicated', 'sharded'])
+    ap.add_argument('--merge-layout', default='replicated', choices=['replicated', 'sharded', 'routed'],
+                    help='layout of the cfg5 leg that config.cfg5_* reports (the others are timed beside it at N > 1)')
+    ap.add_argument('--no-cfg5', action='store_true', help='skip the cfg5 leg')
     ap.add_argument('--profile-target', default=None,
-                    choices=['nms', 'iou_sparse', 'iou_dense', 'rroi_fwd', 'rroi_bwd', 'roi_fwd', 'cfg5'],
+                    choices=['nms', 'iou_sparse', 'iou_dense', 'rroi_fwd', 'rroi_bwd', 'rroi_bwd_scatter', 'roi_fwd', 'cfg5'],
                     help='run ONLY this op (for rocprofv3 passes: one workload per kernel name)')
     return ap.parse_args()
 
@@ -82,29 +90,52 @@ def main():
         sys.stderr.write('bench.py: --gpus %d but WORLD_SIZE=%d: the launcher and the flag disagree\n'
                          % (args.gpus, env_world))
         sys.exit(2)
-    if args.gpus > 1 or os.environ.get('OBB_BENCH_FORCE_DIST') == '1':
-        bench_tiled(args)
-    elif args.profile_target:
+    if args.profile_target:
         profile_target(args)
     else:
-        bench_single(args)
+        bench_all(args)
 
 
 # ==============================================================================================
-# N = 1: rotated NMS on 100k boxes
+# the two legs of every line
 # ==============================================================================================
-def bench_single(args):
+def bench_all(args):
     import numpy as np
     import torch
 
     import workloads
-    from aidet_amd import _lib
+    from aidet_amd import _lib, rbbox_overlaps
     from aidet_amd.nms_wrapper import _run_nms
 
-    torch.cuda.set_device(0)
-    dev = torch.device('cuda', 0)
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    dist = None
+    if world > 1 or os.environ.get('OBB_BENCH_FORCE_DIST') == '1':
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if dist is not None:
+        dist.init_process_group('nccl', rank=rank, world_size=world)
+        assert dist.get_world_size() == world
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        tt = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
+    # ---- leg 1: replica -- configs[1] on every rank ------------------------------------------
     n = args.boxes
-    boxes = workloads.boxes(n, args.canvas, 3)
+    boxes = workloads.boxes(n, args.canvas, 3)      # (the same scene on every rank: independent replicas)
     d = torch.from_numpy(boxes).to(dev)
     L = _lib.lib()
 
@@ -127,10 +158,11 @@ def bench_single(args):
         phase_tab += np.frombuffer(pbuf, dtype=np.float32)
     phase_tab /= 5
 
-    # ---- timed region: exactly K steps, sync on both sides -------------------------------
+    # ---- timed region: exactly K steps, barrier + sync on both sides, max over ranks -----------
     L.obb_nms_profile_enable(1)
     phases = np.zeros(7, dtype=np.float64)
     buf = (ctypes.c_float * 7)()
+    barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -138,46 +170,156 @@ def bench_single(args):
         L.obb_nms_profile_last(buf)
         phases += np.frombuffer(buf, dtype=np.float32)
     torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    barrier()
+    elapsed = max_over_ranks(time.perf_counter() - t0)
     L.obb_nms_profile_enable(0)
     phases /= max(args.steps, 1)
 
     ms_per_step = elapsed * 1e3 / args.steps
-    value = n * args.steps / elapsed
+    value = world * n * args.steps / elapsed
     scan_ms = float(phases[3])  # nms_scan_kernel, HIP events inside the timed region
 
+    # the IoU half of BASELINE's metric: this rank's row block of 16k x 16k (no communication)
+    a, b = make_iou(dev, IOU_M, 8192)
+    shard = (rank, world)
+    rbbox_overlaps(a, b, row_shard=shard)
+    barrier()
+    iou_ms = max_over_ranks(_time_gpu(lambda: rbbox_overlaps(a, b, row_shard=shard), 10))
+    iou_pairs = IOU_M * IOU_M / (iou_ms * 1e-3)
+    del a, b
+
+    # ---- leg 2: cfg5 (strong scaling) -------------------------------------------------------------
+    cfg5 = None
+    if not args.no_cfg5:
+        cfg5 = cfg5_leg(args, dev, rank, world, dist)
+
+    rk = None
+    if rank == 0 and world == 1 and not args.no_extras:
+        rk = roofline_kernels(dev)
+    roof = nms_roofline(n, args.canvas, kept, scan_ms, ms_per_step, rk)
+    roof['iou_rowblock_pairs_per_s'] = round(iou_pairs, 1)
+    roof['iou_rowblock_hbm_frac'] = round((20 * (IOU_M // world + IOU_M) * world + 4 * IOU_M * IOU_M) / (iou_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
     out = {
         'metric': 'rotated-NMS boxes/sec', 'value': round(value, 1), 'unit': 'boxes/s',
-        'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': 'rnms: %d theta-OBBs per GPU, canvas %g, w,h~logU(8,128), '
                                'theta~U(-pi/2,0), IoU thr 0.5 (BASELINE configs[1])' % (n, args.canvas),
                    'boxes_per_gpu': n, 'kept': kept, 'overlap_edges': info[0],
-                   'resolve_rounds': info[1], 'candidate_pairs': info[2], 'parallelism': 'single GPU'},
-        'roofline': nms_roofline(n, args.canvas, kept, scan_ms, ms_per_step),
+                   'resolve_rounds': info[1], 'candidate_pairs': info[2],
+                   'parallelism': 'single GPU' if world == 1 else 'replica x%d (no data-path collective)' % world,
+                   'iou_workload': 'rbbox_overlaps %d x %d, canvas 8192, rows in %d block(s)' % (IOU_M, IOU_M, world),
+                   'iou_pairs_per_s': round(iou_pairs, 1), 'iou_ms': round(iou_ms, 4)},
+        'roofline': roof,
         'phase_ms': {k: round(float(v), 4) for k, v in zip(
             ['prep_quant', 'cell_sort', 'permute_cull', 'scan', 'clip', 'resolve', 'compact'], phase_tab)},
     }
-    if not args.no_extras:
-        out['roofline_kernels'] = roofline_kernels(dev)
-        out['also'] = extras(dev, args)
-    if not args.no_cpu:
-        out['cpu_baseline'] = cpu_baseline(boxes, keep)
-    print(json.dumps(out))
+    if dist is not None:
+        out['rccl_ranks'] = dist.get_world_size()
+    ok = True
+    if cfg5 is not None:
+        out['config'].update(cfg5['flat'])
+        out['cfg5'] = cfg5['detail']
+        ok = cfg5['ok']
+    if rank == 0 and world == 1:
+        if rk is not None:
+            out['roofline_kernels'] = rk
+            out['also'] = extras(dev, args)
+        if not args.no_cpu:
+            out['cpu_baseline'] = cpu_baseline(boxes, keep)
+    if rank == 0:
+        if not ok:
+            out['error'] = 'distributed merge differs from the single-rank result'
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if not ok:
+        sys.exit(1)
+
+
+def cfg5_leg(args, dev, rank, world, dist):
+    """BASELINE configs[4] on `world` ranks: every layout timed (the chosen one with the full step count), each
+    keep set compared with a single-rank run of all patches.  -> {'flat': scalars for `config`, 'detail', 'ok'}"""
+    import hashlib
+
+    import numpy as np
+    import torch
+    from aidet_amd import dota_merge
+    steps = max(5, min(args.steps, 20))
+    layouts = [args.merge_layout] + ([l for l in ('replicated', 'sharded', 'routed') if l != args.merge_layout] if world > 1 else [])
+    ref_rows, single = None, None
+    if rank == 0:   # the single-rank run of ALL patches (untimed reference for the keep sets; no collectives)
+        s1, _e1, ref_rows = tiled_on_this_rank(dev, 0, 1, steps=steps if world > 1 else 2, warmup=1, layout='replicated',
+                                               group=dota_merge.LOCAL)
+        single = s1
+    detail, ok_all, flat = {}, True, {}
+    for li, layout in enumerate(layouts):
+        st = steps if li == 0 else max(3, steps // 2)
+        barrier = dist.barrier if dist is not None else None
+        group = None if dist is not None else dota_merge.LOCAL
+        summary, elapsed, kept_rows = tiled_on_this_rank(dev, rank, world, st, args.warmup, layout, group=group, barrier=barrier)
+        same = True
+        if dist is not None:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)          # the slowest rank's time is the job's
+            elapsed = float(tt.item())
+            # every rank holds the same kept rows?  (hash all-reduced as min / max)
+            digest = int(hashlib.sha256(kept_rows.cpu().numpy().tobytes()).hexdigest()[:15], 16)
+            hh = torch.tensor([digest, -digest], dtype=torch.int64, device=dev)
+            dist.all_reduce(hh, op=dist.ReduceOp.MAX)
+            same = bool(hh[0].item() == -hh[1].item())
+        ok_single = None
+        if rank == 0:
+            ok_single = bool(np.array_equal(ref_rows.cpu().numpy(), kept_rows.cpu().numpy()))
+        ms = elapsed * 1e3 / st
+        total = summary['detections']
+        rec = dict(summary, ms_per_step=round(ms, 4), boxes_per_s=round(total * st / elapsed, 1), steps=st,
+                   same_keep_on_all_ranks=same, keep_equals_single_rank_run=ok_single)
+        detail[layout] = rec
+        # the verdict travels to every rank BEFORE anybody leaves (a rank that raised on its own would leave the
+        # others waiting in the next collective)
+        good = 1 if (rank != 0 or (same and ok_single)) else 0
+        if dist is not None:
+            g = torch.tensor([good], dtype=torch.int64, device=dev)
+            dist.all_reduce(g, op=dist.ReduceOp.MIN)
+            good = int(g.item())
+        ok_all = ok_all and bool(good)
+        if li == 0:
+            flat = {'cfg5_workload': 'tiled merge (configs[4]): %d images 8192^2, %d patches, %d detections'
+                                     % (summary['images'], summary['patches'], total),
+                    'cfg5_layout': layout, 'cfg5_ms_per_step': round(ms, 4),
+                    'cfg5_boxes_per_s': round(total * st / elapsed, 1),
+                    'cfg5_kept_after_merge': summary['kept_after_merge'],
+                    'cfg5_local_nms_us': summary['local_nms_us'], 'cfg5_exchange_us': summary['gather_us'],
+                    'cfg5_merge_us': summary['merge_us'], 'cfg5_keep_ok': bool(good)}
+            if single is not None:
+                flat['cfg5_single_rank_ms_per_step'] = single['ms_per_step']
+                flat['cfg5_speedup_vs_single_rank'] = round(single['ms_per_step'] / ms, 3)
+        else:
+            flat['cfg5_%s_ms_per_step' % layout] = round(ms, 4)
+            if single is not None:
+                flat['cfg5_%s_speedup_vs_single_rank' % layout] = round(single['ms_per_step'] / ms, 3)
+    return {'flat': flat, 'detail': detail, 'ok': ok_all}
 
 
 def load_counters():
-    try:
-        with open(COUNTERS) as f:
-            return json.load(f)
-    except (OSError, ValueError):
-        return None
+    """The newest committed counter file (profiles/r03_counters.json, else round 2's)."""
+    for path in COUNTER_FILES:
+        try:
+            with open(path) as f:
+                c = json.load(f)
+                c['_file'] = os.path.relpath(path, ROOT)
+                return c
+        except (OSError, ValueError):
+            continue
+    return None
 
 
 def kernel_counters(name, workload):
     """Per-launch PMC means of `name` from the committed rocprofv3 passes
-    (profiles/r02_counters.json, built by tools/make_profiles.py; PMC collection needs
+    (profiles/r0x_counters.json, built by tools/make_profiles.py; PMC collection needs
     rocprofv3 around the process, so it cannot be taken live).  Only returned for the workload
     the counters were measured on."""
     c = load_counters()
@@ -196,25 +338,26 @@ def hbm_bytes(k):
     return int(2 * k['FETCH_SIZE_KB'] * 1024 + k['WRITE_SIZE_KB'] * 1024)
 
 
-def nms_roofline(n, canvas, kept, scan_ms, step_ms):
+def nms_roofline(n, canvas, kept, scan_ms, step_ms, rk=None):
     """nms_scan_kernel is bound by VALU ISSUE (3 full-rate ops per tested pair plus the
     candidate path), not by HBM: its counter traffic is a few MB per launch.  The rest of the
-    call is launch/latency bound (10 dependent launches of 4-20 us)."""
+    call is launch/latency bound (dependent launches of 4-20 us).  Everything is a SCALAR (the
+    driver's record keeps scalars of this object only); `rk` = roofline_kernels(), whose HBM-bound
+    kernels are flattened in beside it."""
     wl = 'nms_%d_%g' % (n, canvas)
     k = kernel_counters('nms_scan_kernel', wl)
+    c = load_counters()
     words = (n + 63) // 64
     r = {
         'kernel': 'nms_scan_kernel', 'bound': 'valu_issue', 'unit': 'G wave-instr/s',
         'achieved': None, 'peak': round(VALU_PEAK_GINST, 1), 'frac': None, 'traffic': None,
         'kernel_ms': round(scan_ms, 4),
-        'peak_definition': '256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction',
         'compulsory_bytes_whole_call': 24 * n + 8 * kept,
         # SURVEY 8(d)'s model of the REFERENCE algorithm (n x n/64 bit mask written, kept rows
         # read back): what this pipeline avoids moving -- not an achieved rate
         'reference_algorithm_bytes': 24 * n + 4 * n * words + 4 * kept * words + 8 * kept,
-        'note': 'VALU-issue bound kernel inside a launch/latency-bound call; HBM is idle '
-                '(see hbm / whole_call_hbm).  Counter values: ' +
-                ('profiles/r02_counters.json' if k else 'not available for this workload'),
+        'note': 'VALU-issue bound kernel in a latency-bound call; HBM fracs beside it',
+        'counters': c['_file'] if (c and k) else None,
     }
     if k and scan_ms > 0:
         if 'SQ_INSTS_VALU' in k:
@@ -225,17 +368,28 @@ def nms_roofline(n, canvas, kept, scan_ms, step_ms):
         tb = hbm_bytes(k)
         if tb:
             r['traffic'] = tb
-            r['hbm'] = {'achieved_GBps': round(tb / (scan_ms * 1e-3) / 1e9, 1), 'peak_GBps': HBM_PEAK_GBS,
-                        'frac': round(tb / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-        c = load_counters()
+            r['hbm_frac'] = round(tb / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         tot = 0
         for name, kk in c['kernels'].items():
             if kk.get('workload') == wl and hbm_bytes(kk):
                 tot += hbm_bytes(kk)
         if tot:
-            r['whole_call_hbm'] = {'traffic': tot, 'achieved_GBps': round(tot / (step_ms * 1e-3) / 1e9, 1),
-                                   'frac': round(tot / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                   'traffic_over_compulsory': round(tot / float(24 * n + 8 * kept), 2)}
+            r['whole_call_traffic'] = tot
+            r['whole_call_hbm_frac'] = round(tot / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            r['traffic_over_compulsory'] = round(tot / float(24 * n + 8 * kept), 2)
+    if rk:
+        r['measured_fill_GBps'] = rk['measured_peak']['fill_GBps']
+        r['measured_copy_GBps'] = rk['measured_peak']['copy_GBps']
+        for row in rk['kernels']:
+            t = row['tag']
+            r[t + '_ms'] = row['kernel_ms']
+            r[t + '_hbm_frac'] = row['frac']
+            if row.get('pairs_per_s'):
+                r[t + '_pairs_per_s'] = row['pairs_per_s']
+            if row.get('traffic'):
+                r[t + '_traffic_over_algorithmic'] = round(row['traffic'] / float(row['algorithmic_bytes']), 3)
+            if row.get('lds_conflict_share') is not None:
+                r[t + '_lds_conflict_share'] = row['lds_conflict_share']
     return r
 
 
@@ -279,9 +433,8 @@ def make_rroi(dev, K=512, C=256, HW=256):
     return feat, rois
 
 
-def rroi_algorithmic_bytes(rois_np, C, H, W, scale, ph, pw):
-    """4*K*C*ph*pw (write) + 4*C*min(sum_k footprint_k, H*W) (compulsory feature
-    reads; footprint = clipped AABB pixel count of RoI k on the map) + 24*K."""
+def rroi_footprint_pixels(rois_np, H, W, scale):
+    """sum over the RoIs of the clipped AABB pixel count on the map (SURVEY 8(d)'s footprint)."""
     import numpy as np
     cx, cy, w, h, th = (rois_np[:, i].astype(np.float64) for i in range(1, 6))
     cx, cy, w, h = cx * scale, cy * scale, np.maximum(w * scale, 1), np.maximum(h * scale, 1)
@@ -289,9 +442,24 @@ def rroi_algorithmic_bytes(rois_np, C, H, W, scale, ph, pw):
     hy = 0.5 * (np.abs(np.sin(th)) * w + np.abs(np.cos(th)) * h)
     x0 = np.clip(np.floor(cx - hx), 0, W - 1); x1 = np.clip(np.floor(cx + hx) + 1, 0, W - 1)
     y0 = np.clip(np.floor(cy - hy), 0, H - 1); y1 = np.clip(np.floor(cy + hy) + 1, 0, H - 1)
-    foot = float(((x1 - x0 + 1) * (y1 - y0 + 1)).sum())
-    K = len(rois_np)
-    return int(4 * K * C * ph * pw + 4 * C * min(foot, H * W) + 24 * K)
+    return float(((x1 - x0 + 1) * (y1 - y0 + 1)).sum())
+
+
+def sum_counters(names, workload):
+    """HBM bytes, time and LDS conflict share summed over the kernels `names` of one profiled workload."""
+    tot, us, conf, act, n = 0, 0.0, 0.0, 0.0, 0
+    for nm in names:
+        k = kernel_counters(nm, workload)
+        if not k:
+            continue
+        n += 1
+        tot += hbm_bytes(k) or 0
+        us += k.get('avg_us', 0.0)
+        conf += k.get('SQ_LDS_BANK_CONFLICT', 0.0)
+        act += k.get('SQ_LDS_IDX_ACTIVE', 0.0)
+    if n == 0:
+        return None
+    return {'traffic': tot or None, 'rocprof_us': round(us, 2), 'lds_conflict_share': round(conf / act, 3) if act > 0 else None}
 
 
 def roofline_kernels(dev):
@@ -313,7 +481,7 @@ def roofline_kernels(dev):
         ms = _time_gpu(lambda: rbbox_overlaps(a, b), 10)
         alg = 20 * (2 * m) + 4 * m * m
         k = kernel_counters('overlaps_tile_kernel', tag)
-        res.append({'kernel': 'overlaps_tile_kernel', 'workload': 'rbbox_overlaps %d x %d, canvas %d' % (m, m, canvas),
+        res.append({'tag': tag, 'kernel': 'overlaps_tile_kernel', 'workload': 'rbbox_overlaps %d x %d, canvas %d' % (m, m, canvas),
                     'bound': 'hbm' if tag == 'iou_sparse' else 'hbm (stream) + valu (clip of 1.2 % of the pairs)',
                     'algorithmic_bytes': alg, 'kernel_ms': round(ms, 4), 'pairs_per_s': round(m * m / (ms * 1e-3), 1),
                     'achieved': round(alg / (ms * 1e-3) / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -322,31 +490,49 @@ def roofline_kernels(dev):
                     'traffic': hbm_bytes(k)})
     feat, rois = make_rroi(dev)
     layer = RRoIAlign(7, 0.25, sample_num=2)
-    alg = rroi_algorithmic_bytes(rois.cpu().numpy(), 256, 256, 256, 0.25, 7, 7)
+    rn = rois.cpu().numpy()
+    foot = rroi_footprint_pixels(rn, 256, 256, 0.25)
+    K, C, H, W = 512, 256, 256, 256
+    alg = int(4 * K * C * 49 + 4 * C * min(foot, H * W) + 24 * K)
     ms = _time_gpu(lambda: layer(feat, rois), 50)
-    k = kernel_counters('rroi_forward_kernel', 'rroi_fwd')
-    res.append({'kernel': 'rroi_forward_kernel', 'workload': 'RRoIAlign 512 RoIs x 256 ch x 7x7, 256^2 map, 2x2 samples (configs[2])',
+    pc = sum_counters(['rroi_forward_kernel', 'rroi_order_kernel'], 'rroi_fwd') or {}
+    res.append({'tag': 'rroi_fwd', 'kernel': 'rroi_forward_kernel', 'workload': 'RRoIAlign 512 RoIs x 256 ch x 7x7, 256^2 map, 2x2 samples (configs[2])',
                 'bound': 'hbm', 'algorithmic_bytes': alg, 'kernel_ms': round(ms, 4),
                 'rois_per_s': round(512 / (ms * 1e-3), 1),
                 'achieved': round(alg / (ms * 1e-3) / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), 'traffic': hbm_bytes(k)})
-    # backward: reads grad_out (25.7 MB), atomically adds into the touched pixels
+                'frac': round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), 'traffic': pc.get('traffic'),
+                'lds_conflict_share': pc.get('lds_conflict_share'), 'rocprof_us': pc.get('rocprof_us')})
+    # backward, the formulation the autograd Function runs at this size (and the one the `rroi_bwd` passes
+    # profiled): plan + gather (+ the atomics kernel for RoIs the plan cannot hold).  Algorithmic bytes of its
+    # own: the gradient of the output is read once (25.7 MB), every touched map element written once.
     from aidet_amd import _lib
     L = _lib.lib()
     gout = torch.randn(512, 256, 7, 7, device=dev)
-    gfeat = torch.zeros_like(feat)
+    gfeat = torch.empty_like(feat)
     st = _lib.current_stream_handle(dev)
+    ws = torch.empty(L.obb_roi_backward_workspace_bytes(512), dtype=torch.uint8, device=dev)
+    alg_b = int(4 * K * C * 49 + 4 * C * min(foot, H * W) + 24 * K)
 
-    def bwd():
+    def bwd_gather():
+        _lib.check(L.obb_roi_backward_gather_f32(gout.data_ptr(), 1, 256, 256, 256, rois.data_ptr(), 512, 0, 7, 7, 0.25, 2, 1.0,
+                                                 gfeat.data_ptr(), ws.data_ptr(), ws.numel(), st))
+
+    def bwd_scatter():
+        gfeat.zero_()
         _lib.check(L.obb_rroi_align_backward_f32(gout.data_ptr(), 1, 256, 256, 256, rois.data_ptr(), 512, 7, 7,
                                                  0.25, 2, 1.0, gfeat.data_ptr(), st))
-    ms = _time_gpu(bwd, 20)
-    k = kernel_counters('rroi_backward_kernel', 'rroi_bwd')
-    res.append({'kernel': 'rroi_backward_kernel', 'workload': 'RRoIAlign backward, same shape (float atomics into the map)',
-                'bound': 'hbm (memory-side float atomics, ~1.3 TB/s of added bytes chip-wide)',
-                'algorithmic_bytes': alg, 'kernel_ms': round(ms, 4),
-                'achieved': round(alg / (ms * 1e-3) / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), 'traffic': hbm_bytes(k)})
+    for tag, fn, names, wl, what in (
+            ('rroi_bwd', bwd_gather, ['rroi_plan_kernel', 'rroi_gather_kernel', 'rroi_backward_kernel'], 'rroi_bwd',
+             'gather formulation: plan + one block per map tile (+ atomics for unplanned RoIs); bit-reproducible'),
+            ('rroi_bwd_scatter', bwd_scatter, ['rroi_backward_kernel'], 'rroi_bwd_scatter',
+             'scatter formulation incl. the zero fill of the map (float atomics into the map)')):
+        ms = _time_gpu(fn, 20)
+        pc = sum_counters(names, wl) or {}
+        res.append({'tag': tag, 'kernel': '+'.join(names), 'workload': 'RRoIAlign backward, same shape; ' + what,
+                    'bound': 'hbm', 'algorithmic_bytes': alg_b, 'kernel_ms': round(ms, 4),
+                    'achieved': round(alg_b / (ms * 1e-3) / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                    'frac': round(alg_b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), 'traffic': pc.get('traffic'),
+                    'rocprof_us': pc.get('rocprof_us')})
     return {'measured_peak': peaks, 'kernels': res}
 
 
@@ -477,8 +663,6 @@ def extras(dev, args):
                 _lib.check(L.obb_roi_align_backward_f32(go.data_ptr(), 1, 256, 256, 256, rr.data_ptr(), kk, 7, 7, 0.25, 2, 0, gm.data_ptr(), stp))
         bw[tag] = {'gather_ms': round(_time_gpu(gather, 20), 4), 'scatter_incl_zero_fill_ms': round(_time_gpu(scatter, 20), 4)}
     res['roi_align_backward_256ch_7x7'] = bw
-    # configs[4] on ONE GPU: the same step the N > 1 line times, without the exchange
-    res['cfg5_tiled_merge_1gpu'] = tiled_on_this_rank(dev, 0, 1, steps=10, warmup=2, layout='replicated')[0]
     try:
         from aidet_amd.models import bench_cfg4
         res['cfg4_tile'] = bench_cfg4(dev)
@@ -497,9 +681,12 @@ def cpu_baseline(boxes, keep):
     ref = oracle.rnms(boxes, 0.5)
     dt1 = time.perf_counter() - t0
     nthr = oracle.max_threads()
-    t0 = time.perf_counter()
-    ref_mt = oracle.rnms_mt(boxes, 0.5, nthr)
-    dtn = time.perf_counter() - t0
+    runs = []
+    for _ in range(3):      # (the all-cores leg varies 4.6-6.7 s from run to run: best of 3, all three stated)
+        t0 = time.perf_counter()
+        ref_mt = oracle.rnms_mt(boxes, 0.5, nthr)
+        runs.append(time.perf_counter() - t0)
+    dtn = min(runs)
     model = ''
     try:
         for line in open('/proc/cpuinfo'):
@@ -511,8 +698,8 @@ def cpu_baseline(boxes, keep):
     same = bool(np.array_equal(ref, keep.cpu().numpy())) and bool(np.array_equal(ref, ref_mt))
     return {'value': round(len(boxes) / dt1, 1), 'unit': 'boxes/s', 'cores': 1, 'kind': 'port',
             'sample': 'the full %d-box workload, one run, %.1f s' % (len(boxes), dt1),
-            'all_cores': {'value': round(len(boxes) / dtn, 1), 'unit': 'boxes/s', 'cores': nthr,
-                          'sample': 'the full workload, one run, %.1f s' % dtn},
+            'all_cores_value': round(len(boxes) / dtn, 1), 'all_cores_threads': nthr,
+            'all_cores_sample': 'full workload, best of 3 runs (%s s)' % ', '.join('%.1f' % r for r in runs),
             'host_cpus': os.cpu_count(), 'cpu_model': model, 'keep_bit_exact_vs_gpu': same}
 
 
@@ -543,8 +730,6 @@ def tiled_on_this_rank(dev, rank, world, steps, warmup, layout, group=None, barr
     patch_image = torch.from_numpy(scene['patch_image']).to(dev)
     thrs = dota_io.class_thresholds()
     total = len(scene['dets'])
-    if layout == 'auto':
-        layout = 'sharded' if (world > 1 and total >= 300000) else 'replicated'
     ev = {}
 
     def mark(name):
@@ -552,11 +737,14 @@ def tiled_on_this_rank(dev, rank, world, steps, warmup, layout, group=None, barr
         e.record()
         ev[name] = e
 
-    def step(timed=False):
+    def step(timed=False, gather_result=False):
         if timed:
             mark('start')
+        # (routed: the kept rows stay with the rank that owns their image inside the timed steps -- the layout's
+        # end state; one extra untimed pass below gathers them for the comparison with the single-rank run)
         return dota_merge.tiled_inference_merge(dets, labels, patch, seq, patch_xy, patch_image, C, 0.5, 0.3, thrs,
-                                                group=group, layout=layout, mark=mark if timed else None)
+                                                group=group, layout=layout, mark=mark if timed else None,
+                                                gather_result=gather_result or layout != 'routed')
     for _ in range(warmup + 1):
         kept, keep, allrows = step()
     if barrier:
@@ -574,84 +762,14 @@ def tiled_on_this_rank(dev, rank, world, steps, warmup, layout, group=None, barr
     ph = {'local_nms_us': round(ev['start'].elapsed_time(ev['local']) * 1e3, 1),
           'gather_us': round(ev['local'].elapsed_time(ev['gather']) * 1e3, 1),
           'merge_us': round(ev['gather'].elapsed_time(ev['merge']) * 1e3, 1)}
+    kept_here = int(keep.numel())
+    if layout == 'routed' and world > 1:
+        kept, keep, allrows = step(gather_result=True)
     summary = {'ms_per_step': round(elapsed * 1e3 / steps, 4), 'boxes_per_s': round(total * steps / elapsed, 1),
                'detections': total, 'patches': P, 'images': int(scene['patch_image'].max()) + 1,
-               'local_detections': int(len(idx)), 'gathered_after_local_nms': int(allrows.size(0)),
-               'kept_after_merge': int(keep.numel()), 'layout': layout, **ph}
-    return summary, elapsed, allrows[keep][:, :6]
-
-
-def bench_tiled(args):
-    import hashlib
-
-    import numpy as np
-    import torch
-    import torch.distributed as dist
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    os.environ.setdefault('MASTER_PORT', '29500')
-    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
-    dist.init_process_group('nccl', rank=rank, world_size=world)
-    assert dist.get_world_size() == world == args.gpus or os.environ.get('OBB_BENCH_FORCE_DIST') == '1'
-    summary, elapsed, kept_rows = tiled_on_this_rank(dev, rank, world, args.steps, args.warmup, args.merge_layout,
-                                                     barrier=dist.barrier)
-    tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    dist.all_reduce(tt, op=dist.ReduceOp.MAX)          # the slowest rank's time is the job's
-    elapsed = float(tt.item())
-    # every rank holds the same kept rows?  (hash all-reduced as min / max)
-    digest = int(hashlib.sha256(kept_rows.cpu().numpy().tobytes()).hexdigest()[:15], 16)
-    hh = torch.tensor([digest, -digest], dtype=torch.int64, device=dev)
-    dist.all_reduce(hh, op=dist.ReduceOp.MAX)
-    same_on_all_ranks = bool(hh[0].item() == -hh[1].item())
-    # ... and they equal a single-rank run of ALL patches (rank 0, untimed, no collectives)
-    ok_single, single = None, None
-    if rank == 0:
-        from aidet_amd import dota_merge
-        s1, e1, rows1 = tiled_on_this_rank(dev, 0, 1, steps=max(3, args.steps // 4), warmup=1, layout='replicated',
-                                           group=dota_merge.LOCAL)     # (no collective: the other ranks are not in it)
-        ok_single = bool(np.array_equal(rows1.cpu().numpy(), kept_rows.cpu().numpy()))
-        single = {'ms_per_step': s1['ms_per_step'], 'boxes_per_s': s1['boxes_per_s']}
-    total = summary['detections']
-    ms = elapsed * 1e3 / args.steps
-    out = {
-        'metric': 'rotated-NMS boxes/sec', 'value': round(total * args.steps / elapsed, 1), 'unit': 'boxes/s',
-        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 4),
-        'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'rccl_ranks': dist.get_world_size(),
-        'config': {'workload': 'tiled inference merge (BASELINE configs[4]): %d images of 8192^2 cut into %d '
-                               'patches of 1024^2 (gap 200), %d detections; per-patch rnms 0.5 -> image coords -> '
-                               'RCCL all_gather -> merged per-(image,class) rnms, thresholds of dota.py:324'
-                               % (summary['images'], summary['patches'], total),
-                   'parallelism': 'patches rank-strided x%d, merge %s' % (world, summary['layout']),
-                   'detections': total, 'kept_after_merge': summary['kept_after_merge']},
-        'phases_rank0': {k: summary[k] for k in ('local_nms_us', 'gather_us', 'merge_us')},
-        'gathered_after_local_nms': summary['gathered_after_local_nms'],
-        'same_keep_on_all_ranks': same_on_all_ranks,
-        'keep_equals_single_rank_run': ok_single,
-        'single_rank_same_workload': single,
-        'speedup_vs_single_rank': round(single['ms_per_step'] / ms, 3) if single else None,
-        'note': 'N = 1 of this script times BASELINE configs[1] (rnms on 100k boxes); this line times '
-                'configs[4], the only part of the path with a data-path collective.  The job is a few hundred '
-                'microseconds of latency-bound kernels: xGMI/RCCL latency (2 all_gathers, + 1 all_reduce of a '
-                'byte mask when sharded) is what strong scaling runs into.',
-    }
-    # the verdict travels to every rank BEFORE anybody leaves: a rank that raised on its own would
-    # leave the others waiting in the barrier
-    ok = torch.tensor([1 if (rank != 0 or (same_on_all_ranks and ok_single)) else 0], dtype=torch.int64, device=dev)
-    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-    ok = bool(ok.item())
-    if rank == 0:
-        if not ok:
-            out['error'] = 'distributed merge differs from the single-rank result'
-        print(json.dumps(out))
-    dist.barrier()
-    dist.destroy_process_group()
-    if not ok:
-        sys.exit(1)
+               'local_detections': int(len(idx)), 'rows_merged_on_this_rank': int(allrows.size(0)),
+               'kept_on_this_rank': kept_here, 'kept_after_merge': int(kept.size(0)), 'layout': layout, **ph}
+    return summary, elapsed, kept[:, :6].contiguous()
 
 
 # ==============================================================================================
@@ -671,11 +789,21 @@ def profile_target(args):
     elif t in ('iou_sparse', 'iou_dense'):
         a, b = make_iou(dev, 16384, 8192 if t == 'iou_sparse' else 1024)
         fn = lambda: rbbox_overlaps(a, b)
-    elif t in ('rroi_fwd', 'rroi_bwd'):
+    elif t in ('rroi_fwd', 'rroi_bwd', 'rroi_bwd_scatter'):
         feat, rois = make_rroi(dev)
         layer = RRoIAlign(7, 0.25, sample_num=2)
         if t == 'rroi_fwd':
             fn = lambda: layer(feat, rois)
+        elif t == 'rroi_bwd_scatter':   # the scatter formulation alone (incl. the zero fill it needs), through the C ABI
+            g = torch.randn(512, 256, 7, 7, device=dev)
+            gm = torch.empty_like(feat)
+            st = _lib.current_stream_handle(dev)
+            L = _lib.lib()
+
+            def fn():
+                gm.zero_()
+                _lib.check(L.obb_rroi_align_backward_f32(g.data_ptr(), 1, 256, 256, 256, rois.data_ptr(), 512, 7, 7,
+                                                         0.25, 2, 1.0, gm.data_ptr(), st))
         else:
             feat.requires_grad_(True)
             g = torch.randn(512, 256, 7, 7, device=dev)

@@ -182,6 +182,20 @@ OBB_API int obb_soft_nms_f32(const float *dets_dev, int64_t n, float iou_thr, in
                              int64_t *count_host, void *workspace_dev, size_t workspace_bytes,
                              void *stream);
 
+/* Soft-NMS of several INDEPENDENT groups in one launch: workgroup g replays the reference's loop on the rows
+ * [seg_dev[g], seg_dev[g + 1]) as an array of its own.
+ * Replaces: the per-class loop of multiclass_nms_with_index, mmdet/core/post_processing/rbbox_nms.py:29-49
+ *           (one `soft_nms` call = one host round trip per class; a detection head has 15 classes).
+ *   dets_dev      (n, 5), the rows of a group contiguous (class-major), seg_dev int64[num_groups + 1] ascending
+ *   out_dets_dev / out_inds_dev  group g's survivors at rows seg[g] .. seg[g] + counts[g]; indices are relative
+ *                 to the group's first row (what the per-class call returns)
+ *   counts_dev    int64[num_groups] (DEVICE memory: the call does not synchronise)
+ *   workspace     obb_soft_nms_workspace_bytes(n) bytes */
+OBB_API int obb_soft_nms_grouped_f32(const float *dets_dev, int64_t n, const int64_t *seg_dev, int64_t num_groups,
+                                     float iou_thr, int method, float sigma, float min_score,
+                                     float *out_dets_dev, int64_t *out_inds_dev, int64_t *counts_dev,
+                                     void *workspace_dev, size_t workspace_bytes, void *stream);
+
 /* Optional per-phase device timing of obb_nms_f32 (HIP events recorded on the
  * caller's stream; thread-local).  Phases: 0 clear + prep + quantise, 1 spatial
  * counting sort, 2 permute + tile culling, 3 scan (broad phase), 4 clip (narrow
@@ -262,6 +276,28 @@ OBB_API int obb_roi_align_levels_forward_f32(const float *const *feat_devs_host,
                                              float *out_dev, void *stream);
 
 /* ---------------------------------------------------------------------------
+ * RoI-Align forward (pyramid or single map, any roi_kind) with a caller-provided WORKSPACE of
+ * obb_roi_forward_workspace_bytes(K) bytes: the arguments and results of
+ * obb_roi_align_levels_forward_f32, plus one small launch that puts the RoIs into the Morton order of
+ * their centres -- the blocks then visit them in that order, RoIs that run at the same time share
+ * footprint lines in an XCD's L2 and the kernel fetches each map byte about once (configs[2]: 189 -> 70 MB
+ * from the fabric).  Which block computes a RoI never changes a value; out_dev is in the caller's RoI order.
+ * workspace_dev == NULL is allowed (no ordering = obb_roi_align_levels_forward_f32).
+ * Replaces: the same reference code as obb_roi_align_levels_forward_f32 (RoIAlign V1 / V2 kernels,
+ *           roi_align_kernel.cu:64-141, roi_align_kernel_v2.cu:62-128; SingleRoIExtractor.forward
+ *           single_level.py:89-107) -- none of which takes a workspace (THCudaMalloc scratch is the
+ *           reference's convention for ops that need one, nms_kernel.cu:94).
+ * ------------------------------------------------------------------------- */
+OBB_API size_t obb_roi_forward_workspace_bytes(int64_t K);
+OBB_API int obb_roi_align_forward_ws_f32(const float *const *feat_devs_host, const int *H_host,
+                                         const int *W_host, const float *scale_host, int num_levels,
+                                         int B, int C, const float *rois_dev,
+                                         const int32_t *roi_level_dev, int64_t K, int ph, int pw,
+                                         int sample_num, int roi_kind, float min_size,
+                                         float *out_dev, void *workspace_dev, size_t workspace_bytes,
+                                         void *stream);
+
+/* ---------------------------------------------------------------------------
  * RoI-Align backward as a GATHER (any roi_kind: 0 rotated (K,6) rows, 1 RoIAlign V1, 2 V2-aligned
  * (K,5) rows), with a caller-provided workspace of obb_roi_backward_workspace_bytes(K) bytes.
  * Replaces: the same reference kernels as obb_rroi_align_backward_f32 / obb_roi_align_backward_f32
@@ -323,6 +359,37 @@ OBB_API int obb_gather_rows_f32(const float *src_dev, int64_t n, int cols, const
                                 int out_cols, float *out_dev, void *stream);
 
 /* ---------------------------------------------------------------------------
+ * Proposal / detection SELECTION stages of the detector (config 4), between a head's convolutions and its NMS.
+ * Replaces: the per-level tensor-op chain of RPNHead.get_bboxes_single, mmdet/models/anchor_heads/rpn_head.py:55-104
+ *           (sigmoid :71, per-level topk :77-81, delta2bbox :82-83 = mmdet/core/bbox/transforms.py:34-111, the
+ *           `proposals[:nms_post]` cut :96 and the final topk :100-103) -- ~40 small launches around one NMS call.
+ *
+ * obb_rpn_select_decode_f32: per level (one workgroup each) the `nms_pre` best anchors by score (all of a level with
+ *   at most nms_pre anchors, in anchor order), decoded with delta2bbox and clamped to (max_h, max_w) (max_h <= 0: no
+ *   clamp) -> dets_dev (N, 5) [x1, y1, x2, y2, score], levels_dev int32[N], level-major, descending score inside a
+ *   selected level (equal scores: ascending anchor index; torch.topk leaves that order unspecified).
+ *   N = sum_l min(nms_pre, H_l W_l A) is returned in *num_rows_host (no synchronisation: it depends on shapes only;
+ *   call once with dets_dev = NULL to size the outputs).  cls / reg / anchors: HOST arrays of device pointers to the
+ *   (A * cls_out, H, W) logits, the (4 A, H, W) deltas and the (H W A, 4) anchors of every level; use_sigmoid 1:
+ *   cls_out = 1, score = sigmoid(logit); 0: cls_out = 2, score = softmax(.)[1] (rpn_head.py:68-75).
+ *   nms_pre <= 2048.
+ * obb_rows_topk_f32: rows[keep] (keep ascending int64, as an NMS returns it) -> optional per-level cut (the rows
+ *   are level-major, level l = rows [level_base[l], level_base[l+1]); at most nms_post kept rows per level, in keep
+ *   order) -> the `top` (<= 2048) best by column score_col, descending, equal scores by ascending row -> out_dev
+ *   (count, cols), out_idx_dev int64[count] (source rows; may be NULL), count_dev int64[1] (device).
+ * ------------------------------------------------------------------------- */
+OBB_API int obb_rpn_select_decode_f32(const float *const *cls_devs_host, const float *const *reg_devs_host,
+                                      const float *const *anchor_devs_host, const int *H_host, const int *W_host,
+                                      int num_levels, int num_anchors, int use_sigmoid, int nms_pre,
+                                      const float *means_host, const float *stds_host, float wh_ratio_clip,
+                                      int max_h, int max_w, float *dets_dev, int32_t *levels_dev,
+                                      int64_t *num_rows_host, void *stream);
+OBB_API int obb_rows_topk_f32(const float *rows_dev, int64_t num_rows, int cols, int score_col,
+                              const int64_t *keep_dev, int64_t K, const int *level_base_host, int num_levels,
+                              int nms_post, int top, float *out_dev, int64_t *out_idx_dev, int64_t *count_dev,
+                              void *stream);
+
+/* ---------------------------------------------------------------------------
  * Test / tuning hooks.  NOT part of the drop-in surface (no reference counterpart): the
  * parity tests use them to force every size through every code path, and the experiment
  * scripts under tools/ to sweep launch geometry.  Process-wide; value < 0 restores the
@@ -334,7 +401,8 @@ OBB_API int obb_gather_rows_f32(const float *src_dev, int64_t n, int cols, const
 #define OBB_TUNE_RROI_GROUPS 3        /* 8-channel groups per RoI-Align block                        */
 #define OBB_TUNE_OVERLAPS_ROWS 4      /* rows per block of the pairwise-overlap kernel (8..64)       */
 #define OBB_TUNE_NMS_INLINE_MAX 5     /* largest n whose sorted scan clips its candidates in line     */
-#define OBB_TUNE_COUNT 6
+#define OBB_TUNE_RROI_ORDER_MIN 6     /* fewest RoIs the workspace forward puts into Morton order      */
+#define OBB_TUNE_COUNT 7
 OBB_API int obb_set_tuning(int knob, int64_t value);
 
 #ifdef __cplusplus

@@ -288,6 +288,88 @@ def test_tiled_inference_merge_with_ranks_that_have_nothing(layout):
     assert 0 < len(keep) <= len(allrows)
 
 
+def _routed_worker(rank, world, port, ties, gather_result, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        patches = make_patches(11, 7, ties)
+        mine = dota_merge.shard_patches(len(patches), rank, world)
+        rows = [torch.from_numpy(patches[i]) for i in mine]
+        key = [torch.full((len(patches[i]),), i, dtype=torch.int64) for i in mine]
+        local = torch.cat(rows, 0) if rows else torch.zeros((0, 8))
+        key = torch.cat(key, 0) if key else torch.zeros((0,), dtype=torch.int64)
+        marks = []
+        kept, keep, routed = dota_merge.distributed_merge(
+            local, 0.3, NUM_CLASSES, class_thrs=CLASS_THRS, nms_fn=oracle_nms, layout='routed', order_key=key,
+            order_key_max=len(patches), gather_result=gather_result, mark=marks.append)
+        assert marks == ['gather', 'merge']
+        out[rank] = (kept.numpy(), keep.numpy(), routed.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('ties,world', [(False, 2), (True, 2), (True, 3)])
+def test_routed_merge_equals_single_process(ties, world):
+    """layout='routed': rows travel only to the owner of their image (image % world) by all_to_all; the kept rows,
+    gathered back, are the single-process result in the single-process order -- score ties included (the patch index
+    restores the interleave of the rank-strided patches)."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_routed_worker, args=(world, _free_port(), ties, True, out), nprocs=world, join=True)
+    patches = make_patches(11, 7, ties)
+    single = np.concatenate(patches, 0)
+    ref_kept, _ = dota_merge.merge_detections(torch.from_numpy(single), 0.3, NUM_CLASSES, CLASS_THRS, nms_fn=oracle_nms)
+    for r in range(world):
+        kept, keep, routed = out[r]
+        assert np.array_equal(kept, ref_kept.numpy())
+        # this rank received exactly the rows of its images, in single-process order
+        assert np.array_equal(routed, single[single[:, 7].astype(np.int64) % world == r])
+    assert 0 < len(ref_kept) < len(single)
+
+
+def test_routed_merge_without_the_final_gather_leaves_results_with_the_owner():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_routed_worker, args=(world, _free_port(), True, False, out), nprocs=world, join=True)
+    single = np.concatenate(make_patches(11, 7, True), 0)
+    ref_kept, _ = dota_merge.merge_detections(torch.from_numpy(single), 0.3, NUM_CLASSES, CLASS_THRS, nms_fn=oracle_nms)
+    ref = ref_kept.numpy()
+    for r in range(world):
+        kept, keep, routed = out[r]
+        assert np.array_equal(kept, ref[ref[:, 7].astype(np.int64) % world == r])
+        assert np.array_equal(kept, routed[keep])
+
+
+@pytest.mark.parametrize('world,kw', [(2, None), (3, dict(images=1, image_size=1024, objects=400))])
+def test_tiled_inference_merge_routed_equals_one_rank(world, kw):
+    """configs[4] with the routed exchange on 2 ranks, and on 3 ranks of which two own no image and one has no
+    detections at all (empty all_to_all contributions)."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_tiled_worker, args=(world, _free_port(), 'routed', out, kw), nprocs=world, join=True)
+    args, scene = _tiled_inputs(0, 1, **(kw or {}))
+    kept, keep, allrows = dota_merge.tiled_inference_merge(*args, NUM_CLASSES, 0.5, 0.3, CLASS_THRS, nms_fn=oracle_nms)
+    for r in range(world):
+        assert np.array_equal(out[r][0], kept.numpy())
+    assert np.array_equal(out['solo'], kept.numpy())
+    assert 0 < len(keep) <= len(allrows)
+
+
+def test_rbbox_overlaps_row_blocks_tile_the_matrix():
+    """rbbox_overlaps partitions by ROW BLOCKS with no communication; the blocks of all ranks
+    concatenated are every row exactly once, also when the rows do not divide evenly or ranks get none."""
+    from aidet_amd.rbbox_geometry import row_block
+    for m in (0, 1, 7, 16, 100, 16384):
+        for world in (1, 2, 3, 8):
+            blocks = [row_block(m, r, world) for r in range(world)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == m
+            assert all(a[1] == b[0] for a, b in zip(blocks, blocks[1:])) and all(lo <= hi for lo, hi in blocks)
+    with pytest.raises(ValueError):
+        row_block(10, 4, 4)
+
+
 def test_bench_refuses_a_world_size_that_contradicts_gpus():
     """`--gpus N` must not be silently ignored.  (Fails before torch is imported.)"""
     import subprocess

@@ -1030,14 +1030,21 @@ def test_bench_distributed_path_runs_on_one_gpu():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, OBB_BENCH_FORCE_DIST='1', RANK='0', WORLD_SIZE='1', LOCAL_RANK='0',
                MASTER_ADDR='127.0.0.1', MASTER_PORT='29533')
-    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1'],
-                       env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
-    line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
-    j = json.loads(line)
-    assert j['scaling'] == 'strong' and j['rccl_ranks'] == 1 and j['n_gpus'] == 1
-    assert j['keep_equals_single_rank_run'] is True and j['same_keep_on_all_ranks'] is True
-    assert j['value'] > 1e7 and set(j['phases_rank0']) == {'local_nms_us', 'gather_us', 'merge_us'}
+    for layout in ('replicated', 'routed'):
+        r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1',
+                            '--no-cpu', '--no-extras', '--merge-layout', layout],
+                           env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
+        j = json.loads(line)
+        # every line carries both legs: the replica leg is `value` (weak), the cfg5 leg sits in `config` as scalars
+        assert j['scaling'] == 'weak' and j['rccl_ranks'] == 1 and j['n_gpus'] == 1 and j['value'] > 1e7
+        c = j['config']
+        assert c['cfg5_layout'] == layout and c['cfg5_keep_ok'] is True and c['cfg5_boxes_per_s'] > 1e7
+        assert c['iou_pairs_per_s'] > 1e10 and c['cfg5_speedup_vs_single_rank'] > 0
+        d = j['cfg5'][layout]
+        assert d['keep_equals_single_rank_run'] is True and d['same_keep_on_all_ranks'] is True
+        assert all(not isinstance(v, (dict, list)) for v in list(j['roofline'].values()) + list(c.values()))
 
 
 def test_pyramid_roi_align_one_launch_equals_per_level_calls():
@@ -1300,9 +1307,10 @@ def test_get_det_rbboxes_pointobb_and_hobb_encodings():
 
 def test_bbox_overlaps_is_differentiable_like_the_reference_expression():
     """iou_loss.py:25 differentiates through bbox_overlaps(pred, target, is_aligned=True): values from the
-    kernel, gradients equal to autograd of geometry.py's tensor expressions; the rotated ops refuse."""
+    kernel, gradients equal to autograd of geometry.py's tensor expressions; the rotated op has its own gradient
+    (tests/test_round3_gpu.py), the polygon op refuses."""
     from aidet_amd import bbox_overlaps, rbbox_overlaps
-    from aidet_amd.rbbox_geometry import _hbb_overlaps_torch
+    from aidet_amd.rbbox_geometry import _hbb_overlaps_torch, pointobb_overlaps
     rng = np.random.default_rng(4)
     x1, y1 = rng.uniform(0, 200, 300), rng.uniform(0, 200, 300)
     a = np.stack([x1, y1, x1 + rng.uniform(5, 80, 300), y1 + rng.uniform(5, 80, 300)], 1).astype(np.float32)
@@ -1323,7 +1331,7 @@ def test_bbox_overlaps_is_differentiable_like_the_reference_expression():
     bbox_overlaps(p, t(b), 'iou', True).sum().backward()
     assert p.grad is not None
     with pytest.raises(RuntimeError):
-        rbbox_overlaps(torch.rand(4, 5, device='cuda', requires_grad=True), torch.rand(4, 5, device='cuda'))
+        pointobb_overlaps(torch.rand(4, 8, device='cuda', requires_grad=True), torch.rand(4, 8, device='cuda'))
     with torch.no_grad():      # target assignment: fine without a graph
         assert rbbox_overlaps(torch.rand(4, 5, device='cuda', requires_grad=True), torch.rand(4, 5, device='cuda')).shape == (4, 4)
 

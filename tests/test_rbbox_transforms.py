@@ -124,8 +124,52 @@ def test_pointobb_and_hobb_formats_reproduce_reference(golden):
     assert np.array_equal(np.array([T.hobb2pointobb(h.tolist()) for h in hb]), g['hq_points'])
     assert np.array_equal(T.hobb_mapping(hb, (900, 1200, 3), 1.5, False), g['hq_map_noflip'])
     assert np.array_equal(T.hobb_mapping_back(hb, (900, 1200, 3), 1.5, False), g['hq_mapback_noflip'])
-    with pytest.raises(NotImplementedError):
-        T.hobb_mapping(hb, (900, 1200, 3), 1.5, True)
+    # (flip=True goes through the minimal rectangle: test_min_area_rect_codecs_without_opencv)
+    flipped = T.hobb_mapping(hb, (900, 1200, 3), 1.5, True)
+    assert flipped.shape == hb.shape and np.isfinite(flipped).all()
+
+
+def test_min_area_rect_codecs_without_opencv():
+    """pointobb2thetaobb (cv2.minAreaRect in the reference, transforms.py:30-43), thetaobb2hobb (:73-91) and
+    hobb_flip (:243-278) restated without cv2: the angle / size convention (theta in [-pi/2, 0), `w` along
+    (cos, sin)), the axis-aligned quirk, and the round trip through the corner points."""
+    rng = np.random.default_rng(0)
+    n = 4000
+    t = np.stack([rng.uniform(0, 1000, n), rng.uniform(0, 1000, n), np.exp(rng.uniform(np.log(8), np.log(128), n)),
+                  np.exp(rng.uniform(np.log(8), np.log(128), n)), rng.uniform(-np.pi / 2, 0, n)], 1)
+    t = t[np.abs(t[:, 2] - t[:, 3]) > 1e-3]                 # (a square has two minimal rectangles)
+    r = T.min_area_rect(T.box_points(t))
+    assert ((r[:, 4] >= -90.0) & (r[:, 4] < 0.0)).all()
+    r[:, 4] *= np.pi / 180.0
+    assert np.abs(r - t).max() < 1e-4                       # thetaobb -> pointobb -> thetaobb is the identity
+    # any cyclic rotation / reversal of the point list describes the same box
+    q = T.box_points(t[:50])
+    for perm in ([2, 3, 4, 5, 6, 7, 0, 1], [6, 7, 4, 5, 2, 3, 0, 1]):
+        r2 = T.min_area_rect(q[:, perm]); r2[:, 4] *= np.pi / 180.0
+        assert np.abs(r2 - t[:50]).max() < 1e-4
+    # the box_points twin equals the device op's formula on theta = 0: corners of the upright box
+    assert np.allclose(T.box_points([10., 20., 4., 2., 0.]), [8, 21, 8, 19, 12, 19, 12, 21])
+    # axis-aligned rectangle 10 wide, 4 high: OpenCV (< 4.5.1) reports angle -90 and the sizes swapped
+    assert T.pointobb2thetaobb([0, 0, 10, 0, 10, 4, 0, 4]) == [5.0, 2.0, 4.0, 10.0, -np.pi / 2]
+    # a 45-degree rectangle with integer corners: sides 3*sqrt(2) and 4*sqrt(2)
+    x, y, w, h, th = T.pointobb2thetaobb([3, 0, 7, 4, 4, 7, 0, 3])
+    assert np.allclose([x, y, w, h, th], [3.5, 3.5, 3 * 2 ** 0.5, 4 * 2 ** 0.5, -np.pi / 4])
+    # the reference truncates the points to integers first (np.int0)
+    assert T.pointobb2thetaobb([0.9, 0.9, 10.9, 0.2, 10.5, 4.7, 0.1, 4.9]) == T.pointobb2thetaobb([0, 0, 10, 0, 10, 4, 0, 4])
+    assert T.pointobb2thetaobb([0.5, 0, 10.5, 0, 10.5, 4, 0.5, 4], truncate=False)[0] == 5.5
+    # degenerate inputs stay finite
+    assert np.isfinite(T.min_area_rect(np.zeros((1, 8)))).all()
+    assert np.isfinite(T.min_area_rect(np.array([[0, 0, 5, 5, 5, 5, 0, 0.]]))).all()
+    # thetaobb2hobb: first two corners in the sort function's order + the length of the side 4-1
+    hb = T.thetaobb2hobb([50., 50., 40., 20., -0.3], T.pointobb_best_point_sort)
+    p = T.pointobb_best_point_sort(T.thetaobb2pointobb_host([50., 50., 40., 20., -0.3]))
+    assert hb[:4] == p[:4] and abs(hb[4] - 20.0) < 1e-9
+    # hobb_flip mirrors about x = (W - 1) / 2: flipping twice returns the box up to the integer truncations
+    h0 = np.array([[100., 40., 160., 60., 30.], [20., 20., 80., 20., 25.]])
+    once = T.hobb_flip(h0, (300, 400, 3))
+    assert once.shape == (2, 5) and np.allclose(once[1], [319., 20., 379., 20., 25.], atol=1.5)
+    twice = T.hobb_flip(once, (300, 400, 3))
+    assert np.abs(twice - h0).max() < 3.0
 
 
 @pytest.mark.parametrize('enc,dim', [('thetaobb', 5), ('pointobb', 8), ('hobb', 5)])

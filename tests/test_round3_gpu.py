@@ -1,0 +1,297 @@
+"""GPU tests of the round-3 additions (run on the MI355X box: `pytest -m gpu`): the gradient and the row-block
+partition of rbbox_overlaps, tickets collected from another stream, the workspace forward of RoI-Align (Morton-ordered
+block numbering) against the plain entry points and the oracle."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    assert torch.cuda.is_available(), 'GPU tests need a HIP device (no CPU path exists)'
+    return torch.device('cuda:0')
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev())
+
+
+def test_rbbox_overlaps_has_a_gradient_for_a_rotated_iou_loss():
+    """iou_loss.py:25 differentiates through bbox_overlaps(pred, target, is_aligned=True); the rotated op does the same:
+    forward = the kernel's values (bit-equal to the no-grad call), backward = autograd of the torch restatement."""
+    from aidet_amd import rbbox_overlaps
+    from aidet_amd.rbbox_geometry import rbbox_overlaps_torch
+    a = oracle.synth_boxes(600, 200, 1)[:, :5]
+    b = a + np.array([3., 2., 1., -1., 0.2], np.float32)
+    pa, pb = t(a).requires_grad_(True), t(b)
+    iou = rbbox_overlaps(pa, pb, is_aligned=True)
+    assert iou.requires_grad and torch.equal(iou.detach(), rbbox_overlaps(t(a), t(b), is_aligned=True))
+    (1 - iou).sum().backward()
+    ref_in = torch.from_numpy(a).double().requires_grad_(True)
+    (1 - rbbox_overlaps_torch(ref_in, torch.from_numpy(b).double(), 'iou', True)).sum().backward()
+    assert pa.grad.shape == (600, 5) and float((pa.grad.cpu().double() - ref_in.grad).abs().max()) < 1e-3
+    assert float(pa.grad.abs().max()) > 1e-3
+    # all-pairs mode and the second argument
+    qa, qb = t(a[:40]).requires_grad_(True), t(b[:50]).requires_grad_(True)
+    rbbox_overlaps(qa, qb).sum().backward()
+    assert qa.grad.shape == (40, 5) and qb.grad.shape == (50, 5) and float(qb.grad.abs().max()) > 0
+    with pytest.raises(RuntimeError):      # a gradient over millions of pairs is refused, not silently dropped
+        rbbox_overlaps(t(oracle.synth_boxes(2000, 500, 3)[:, :5]).requires_grad_(True), t(oracle.synth_boxes(2000, 500, 4)[:, :5]))
+
+
+def test_rbbox_overlaps_row_shard_blocks_concatenate_to_the_full_matrix():
+    """the multi-GPU partition of rbbox_overlaps is by row blocks, no communication."""
+    from aidet_amd import rbbox_overlaps
+    a = t(oracle.synth_boxes(1001, 600, 5)[:, :5])
+    b = t(oracle.synth_boxes(777, 600, 6)[:, :5])
+    full = rbbox_overlaps(a, b)
+    for world in (1, 2, 3, 8):
+        parts = [rbbox_overlaps(a, b, row_shard=(r, world)) for r in range(world)]
+        assert torch.equal(torch.cat(parts, 0), full)
+    al = rbbox_overlaps(a[:777], b, is_aligned=True)
+    assert torch.equal(torch.cat([rbbox_overlaps(a[:777], b, is_aligned=True, row_shard=(r, 4)) for r in range(4)]), al)
+    assert rbbox_overlaps(a[:3], b, row_shard=(7, 8)).shape == (0, 777)
+
+
+def test_nms_tickets_enqueued_on_side_streams_are_collected_from_the_default_stream():
+    """the ticket records an event on ITS stream; nms_collect waits for it before reading the record."""
+    from aidet_amd import nms_wrapper
+    scenes = [oracle.synth_boxes(3000 + 500 * i, 900, 20 + i) for i in range(5)]
+    dets = [t(s) for s in scenes]
+    streams = [torch.cuda.Stream() for _ in scenes]
+    for rep in range(20):
+        tickets = []
+        for d, s in zip(dets, streams):
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                # a long-running kernel in front of the NMS on the side stream: the collector must not overtake it
+                junk = torch.randn(2048, 2048, device=dev()) @ torch.randn(2048, 2048, device=dev())
+                tickets.append(nms_wrapper.nms_enqueue(d, 0.5, op='rnms'))
+        keeps = nms_wrapper.nms_collect(tickets)          # (on the default stream)
+        for k, s in zip(keeps, scenes):
+            assert np.array_equal(k.cpu().numpy(), oracle.rnms(s, 0.5))
+        del junk
+
+
+def test_kept_rows_stay_differentiable_whatever_their_number():
+    """dets[inds] of a large call went through the raw row-gather kernel and lost its autograd history."""
+    from aidet_amd import rnms
+    d = t(oracle.synth_boxes(20000, 4000, 9)).requires_grad_(True)
+    kept, inds = rnms(d, 0.5)
+    assert inds.numel() >= 4096 and kept.requires_grad
+    kept[:, :2].sum().backward()
+    assert float(d.grad[inds, 0].min()) == 1.0 and float(d.grad.sum()) == 2.0 * inds.numel()
+    with torch.no_grad():
+        k2, _ = rnms(d, 0.5)
+    assert torch.equal(k2, kept.detach())
+
+
+@pytest.mark.parametrize('kind,K', [(0, 512), (1, 2000), (2, 300), (0, 70000)])
+def test_roi_forward_with_workspace_equals_the_plain_entry_points(kind, K):
+    """obb_roi_align_forward_ws_f32 visits the RoIs in Morton order of their centres (rroi_order_kernel); which block
+    computes a RoI must not change a bit of the output.  K = 70000 is beyond the order kernel's range (identity)."""
+    from aidet_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(K)
+    C, H, W = (32, 96, 128) if K < 10000 else (8, 64, 64)
+    feat = t(rng.standard_normal((2, C, H, W)).astype(np.float32))
+    if kind == 0:
+        r = oracle.synth_boxes(K, 4 * W, 3)[:, :5]
+        r[:, 1] *= H / W
+        rois = np.concatenate([rng.integers(0, 2, (K, 1)).astype(np.float32), r], 1)
+    else:
+        x1, y1 = rng.uniform(0, 4 * W - 40, K), rng.uniform(0, 4 * H - 40, K)
+        rois = np.stack([rng.integers(0, 2, K), x1, y1, x1 + rng.uniform(4, 160, K), y1 + rng.uniform(4, 160, K)], 1).astype(np.float32)
+    rt = t(rois)
+    st = _lib.current_stream_handle(dev())
+    plain = torch.empty((K, C, 7, 7), device=dev())
+    if kind == 0:
+        _lib.check(L.obb_rroi_align_forward_f32(feat.data_ptr(), 2, C, H, W, rt.data_ptr(), K, 7, 7, 0.25, 2, 1.0, plain.data_ptr(), st))
+    else:
+        _lib.check(L.obb_roi_align_forward_f32(feat.data_ptr(), 2, C, H, W, rt.data_ptr(), K, 7, 7, 0.25, 2, 1 if kind == 2 else 0, plain.data_ptr(), st))
+    ws = torch.empty(L.obb_roi_forward_workspace_bytes(K), dtype=torch.uint8, device=dev())
+    ptr = (ctypes.c_void_p * 1)(feat.data_ptr())
+    hh, ww, sc = (ctypes.c_int * 1)(H), (ctypes.c_int * 1)(W), (ctypes.c_float * 1)(0.25)
+    for order_min in (64, 1 << 40):
+        _lib.set_tuning(_lib.TUNE_RROI_ORDER_MIN, order_min)
+        out = torch.full((K, C, 7, 7), float('nan'), device=dev())
+        _lib.check(L.obb_roi_align_forward_ws_f32(ptr, hh, ww, sc, 1, 2, C, rt.data_ptr(), None, K, 7, 7, 2, kind, 1.0, out.data_ptr(),
+                                                  ws.data_ptr(), ws.numel(), st))
+        assert torch.equal(out, plain)
+    _lib.set_tuning(_lib.TUNE_RROI_ORDER_MIN, -1)
+    if K <= 65536:   # the order the kernel left in the workspace is a permutation of the RoIs
+        order = ws[:4 * K].view(torch.int32)
+        _lib.check(L.obb_roi_align_forward_ws_f32(ptr, hh, ww, sc, 1, 2, C, rt.data_ptr(), None, K, 7, 7, 2, kind, 1.0, out.data_ptr(),
+                                                  ws.data_ptr(), ws.numel(), st))
+        assert torch.equal(torch.sort(order.long())[0], torch.arange(K, device=dev()))
+    # too small a workspace is refused, none at all is allowed
+    assert L.obb_roi_align_forward_ws_f32(ptr, hh, ww, sc, 1, 2, C, rt.data_ptr(), None, K, 7, 7, 2, kind, 1.0, out.data_ptr(),
+                                          ws.data_ptr(), 8, st) == _lib.OBB_EWORKSPACE
+    _lib.check(L.obb_roi_align_forward_ws_f32(ptr, hh, ww, sc, 1, 2, C, rt.data_ptr(), None, K, 7, 7, 2, kind, 1.0, out.data_ptr(), None, 0, st))
+    assert torch.equal(out, plain)
+    if K <= 2000:    # ... and equal the oracle
+        if kind == 0:
+            ref = oracle.rroi_align_forward(feat.cpu().numpy(), rois, 7, 0.25, 2)
+        else:
+            ref = oracle.roi_align_forward(feat.cpu().numpy(), rois, 7, 0.25, 2, version=2 if kind == 2 else 1, aligned=kind == 2)
+        assert np.array_equal(out.cpu().numpy(), ref) or np.abs(out.cpu().numpy() - ref).max() <= 1e-4
+
+
+def test_grouped_soft_nms_equals_one_call_per_group(golden):
+    """obb_soft_nms_grouped_f32: one workgroup per group, every group an array of its own = the per-class calls of
+    multiclass_nms_with_index (rbbox_nms.py:29-49).  Index-exact (ties included: the scores are quantised)."""
+    from aidet_amd import nms_wrapper, soft_nms
+    rng = np.random.default_rng(3)
+    sizes = [0, 37, 1, 300, 0, 768, 129, 5]
+    groups = []
+    for i, m in enumerate(sizes):
+        x1, y1 = rng.uniform(0, 300, m), rng.uniform(0, 300, m)
+        sc = np.round(rng.uniform(0, 1, m) * 50) / 50            # many equal scores
+        groups.append(np.stack([x1, y1, x1 + rng.uniform(5, 80, m), y1 + rng.uniform(5, 80, m), sc], 1).astype(np.float32))
+    allrows = np.concatenate(groups, 0)
+    for method, kw in (('linear', dict(iou_thr=0.3, min_score=0.05)), ('gaussian', dict(iou_thr=0.3, sigma=0.4, min_score=0.02))):
+        res = nms_wrapper.soft_nms_grouped(t(allrows), sizes, method=method, **kw)
+        assert len(res) == len(sizes)
+        for g, (d, k) in zip(groups, res):
+            rd, ri = oracle.soft_nms(g, kw['iou_thr'], method, kw.get('sigma', 0.5), kw['min_score'])
+            assert np.array_equal(k.cpu().numpy(), ri)
+            assert d.shape == rd.shape
+            assert np.array_equal(d.cpu().numpy(), rd) if method == 'linear' else np.allclose(d.cpu().numpy(), rd, atol=1e-6, rtol=0)
+            if len(g):    # ... and the single-group entry point
+                d1, k1 = soft_nms(t(g), kw['iou_thr'], method=method, sigma=kw.get('sigma', 0.5), min_score=kw['min_score'])
+                assert torch.equal(k1, k) and torch.equal(d1, d)
+    # groups beyond the LDS variant (n > 2048 in all): state in the workspace
+    big = [groups[5]] * 4
+    res = nms_wrapper.soft_nms_grouped(t(np.concatenate(big, 0)), [len(b) for b in big], 0.3, min_score=0.05)
+    rd, ri = oracle.soft_nms(groups[5], 0.3, 'linear', 0.5, 0.05)
+    for d, k in res:
+        assert np.array_equal(k.cpu().numpy(), ri) and np.array_equal(d.cpu().numpy(), rd)
+    assert nms_wrapper.soft_nms_grouped(t(np.zeros((0, 5), np.float32)), [], 0.3) == []
+
+
+def test_multiclass_soft_nms_is_one_launch_and_still_reproduces_the_reference(golden):
+    """multiclass_nms_with_index(type='soft_nms') on the reference's own fixture, through the grouped launch; and the
+    grouped branch of multiclass_nms (it raised a TypeError for soft_nms)."""
+    from aidet_amd import multiclass_nms, multiclass_nms_with_index
+    g, s = golden('multiclass.npz'), golden('multiclass_soft.npz')
+    mb, ms = t(g['multi_bboxes']), t(g['multi_scores'])
+    cfg = dict(type='soft_nms', iou_thr=0.5, min_score=0.05)
+    boxes, labels, cls_inds, keep_inds = multiclass_nms_with_index(mb, ms, 0.05, cfg, 100)
+    assert np.array_equal(labels.cpu().numpy(), s['idx_labels']) and np.allclose(boxes.cpu().numpy(), s['idx_bboxes'], atol=1e-6)
+    for i, k in enumerate(keep_inds):
+        assert np.array_equal(k.cpu().numpy(), s['idx_keep_%d' % i])
+    b2, l2 = multiclass_nms(mb, ms, 0.05, cfg, 100)                       # the reference's offset trick: one global array
+    assert np.array_equal(l2.cpu().numpy(), s['mc_labels']) and np.allclose(b2.cpu().numpy(), s['mc_bboxes'], atol=1e-6)
+    b3, l3 = multiclass_nms(mb, ms, 0.05, cfg, 100, grouped=True)         # every class an array of its own
+    assert b3.shape == b2.shape and sorted(l3.tolist()) == sorted(l2.tolist())
+    assert np.allclose(np.sort(b3[:, 4].cpu().numpy()), np.sort(b2[:, 4].cpu().numpy()), atol=1e-6)
+
+
+def test_per_box_thresholds_of_horizontal_nms_must_be_positive():
+    """a per-box threshold <= 0 under `>=` is the reference's suppress-everything rule, not served."""
+    from aidet_amd import nms
+    from aidet_amd import dota_merge
+    h = np.array([[0, 0, 10, 10, .9], [20, 20, 30, 30, .8], [0, 0, 10, 10, .7]], np.float32)
+    with pytest.raises(ValueError):
+        nms(t(h), 0.5, thrs=np.array([0.5, 0.0, 0.5], np.float32))
+    kept, inds = nms(t(h), 0.5, thrs=np.array([0.5, 0.5, 0.5], np.float32))
+    assert inds.tolist() == [0, 1]
+    rows = np.concatenate([h, np.zeros((3, 2), np.float32)], 1)            # 7 columns: horizontal merge rows
+    with pytest.raises(ValueError):
+        dota_merge.merge_detections(t(rows), 0.3, 2, class_thrs=[0.0, 0.3])
+
+
+@pytest.mark.parametrize('case', ['k2049', 'k5000', 'tiny', 'edge2047', 'edge2048'])
+def test_gather_backward_list_batches_long_lists_and_capacity_edges(case):
+    """the gather backward beyond its first unit test -- more RoIs than one LDS list batch (2048), pixels with
+    many taps (tiny RoIs: the plan's long-list queue and bit-map ranks), and footprints of exactly 2047 (planned) and
+    2048 (left to the atomics kernel) pixels.  Gather vs atomics vs oracle; the gather is bit-reproducible."""
+    from aidet_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(7)
+    C, H, W, scale, sn = 8, 64, 96, 1.0, 2
+    if case in ('k2049', 'k5000'):
+        K = 2049 if case == 'k2049' else 5000
+        r = oracle.synth_boxes(K, 90, 5)[:, :5]
+        r[:, 2:4] = np.clip(r[:, 2:4] * 0.25, 2, 30)
+        r[:, 1] *= H / 90.0
+    elif case == 'tiny':
+        K = 300
+        r = oracle.synth_boxes(K, 90, 6)[:, :5]
+        r[:, 2:4] = rng.uniform(0.05, 2.0, (K, 2))          # sub-pixel to 2 x 2 px: up to 196 taps on one pixel
+        r[:, 1] *= H / 90.0
+    else:
+        # an upright RoI whose 2 x 2 x 49 samples span exactly 23 x 89 = 2047 (or 32 x 64 = 2048) pixels
+        K = 1
+        fw, fh = (89, 23) if case == 'edge2047' else (64, 32)
+        w, h = (fw - 1.5) * 14 / 13.0, (fh - 1.5) * 14 / 13.0
+        r = np.array([[2.0 + 0.25 + w / 2 * 13 / 14.0 + w / 28.0, 2.25 + h / 2 * 13 / 14.0 + h / 28.0, w, h, 0.0]], np.float32)
+    rois = np.concatenate([np.zeros((K, 1), np.float32), r.astype(np.float32)], 1)
+    g = rng.standard_normal((K, C, 7, 7)).astype(np.float32)
+    gt, rt = t(g), t(rois)
+    st = _lib.current_stream_handle(dev())
+    ws = torch.empty(L.obb_roi_backward_workspace_bytes(K), dtype=torch.uint8, device=dev())
+    outs = []
+    for rep in range(2):
+        gm = torch.full((1, C, H, W), float('nan'), device=dev())
+        _lib.check(L.obb_roi_backward_gather_f32(gt.data_ptr(), 1, C, H, W, rt.data_ptr(), K, 0, 7, 7, scale, sn, 1.0, gm.data_ptr(),
+                                                 ws.data_ptr(), ws.numel(), st))
+        outs.append(gm.clone())
+    assert torch.equal(outs[0], outs[1])                                   # bit-reproducible
+    at = torch.zeros((1, C, H, W), device=dev())
+    _lib.check(L.obb_rroi_align_backward_f32(gt.data_ptr(), 1, C, H, W, rt.data_ptr(), K, 7, 7, scale, sn, 1.0, at.data_ptr(), st))
+    ref = oracle.rroi_align_backward(g, rois, (1, C, H, W), scale, sn)
+    tol = 1e-4 * max(1.0, float(np.abs(ref).max()))
+    assert np.abs(outs[0].cpu().numpy() - ref).max() <= tol
+    assert np.abs(at.cpu().numpy() - ref).max() <= tol
+    if case.startswith('edge'):
+        touched = int((ref[0, 0] != 0).sum())
+        assert touched > 1500                                              # the footprint really is that large
+
+
+@pytest.mark.parametrize('sigmoid', [True, False])
+def test_fused_rpn_selection_equals_the_tensor_op_path(sigmoid):
+    """obb_rpn_select_decode_f32 + grouped nms + obb_rows_topk_f32 against the tensor-op path of rpn.py (the
+    restatement of rpn_head.py:55-104 that detector_parts.npz pins): the same proposals in the same order on a 1024^2
+    tile's five levels, also with an nms_post cut and a max_num below the survivors."""
+    from aidet_amd import rpn
+    from aidet_amd.anchors import AnchorGenerator
+    g = torch.Generator().manual_seed(5)
+    strides = [4, 8, 16, 32, 64]
+    A = 3
+    cls = [torch.randn((A if sigmoid else 2 * A, 256 // (s // 4), 256 // (s // 4)), generator=g).to(dev()) for s in strides]
+    reg = [(0.3 * torch.randn((4 * A, c.size(1), c.size(2)), generator=g)).to(dev()) for c in cls]
+    anchors = [AnchorGenerator(s, [8], [0.5, 1.0, 2.0]).grid_anchors(c.shape[-2:], s, device=dev()) for s, c in zip(strides, cls)]
+    for cfg in (dict(nms_pre=2000, nms_post=2000, max_num=2000, nms_thr=0.7, min_bbox_size=0, nms_across_levels=False),
+                dict(nms_pre=1000, nms_post=300, max_num=700, nms_thr=0.6, min_bbox_size=0, nms_across_levels=False)):
+        rpn.FUSED = True
+        got = rpn.rpn_proposals(cls, reg, anchors, (1024, 1024, 3), cfg, use_sigmoid_cls=sigmoid)
+        rpn.FUSED = False
+        try:
+            want = rpn.rpn_proposals(cls, reg, anchors, (1024, 1024, 3), cfg, use_sigmoid_cls=sigmoid)
+        finally:
+            rpn.FUSED = True
+        assert got.shape == want.shape and got.shape[0] == min(cfg['max_num'], want.shape[0])
+        assert float((got - want).abs().max()) <= 2e-4
+        assert bool((got[:-1, 4] >= got[1:, 4]).all())
+    # the selection kernel alone against torch.topk on one level, incl. equal scores (ties: ascending anchor index)
+    from aidet_amd import _lib
+    L = _lib.lib()
+    c1 = torch.round(torch.randn((A, 64, 64), generator=g) * 4).to(dev()) / 4         # many equal logits
+    r1 = torch.zeros((4 * A, 64, 64), device=dev())
+    a1 = AnchorGenerator(8, [8], [0.5, 1.0, 2.0]).grid_anchors((64, 64), 8, device=dev())
+    dets = torch.empty((500, 5), device=dev()); lv = torch.empty(500, dtype=torch.int32, device=dev())
+    rows = ctypes.c_int64(0)
+    _lib.check(L.obb_rpn_select_decode_f32((ctypes.c_void_p * 1)(c1.data_ptr()), (ctypes.c_void_p * 1)(r1.data_ptr()),
+                                           (ctypes.c_void_p * 1)(a1.data_ptr()), (ctypes.c_int * 1)(64), (ctypes.c_int * 1)(64), 1, A, 1, 500,
+                                           (ctypes.c_float * 4)(0, 0, 0, 0), (ctypes.c_float * 4)(1, 1, 1, 1), 16 / 1000.0, 0, 0,
+                                           dets.data_ptr(), lv.data_ptr(), ctypes.byref(rows), _lib.current_stream_handle(dev())))
+    flat = c1.permute(1, 2, 0).reshape(-1)
+    order = torch.sort(flat, descending=True, stable=True)[1][:500]       # stable: equal logits by ascending index
+    assert rows.value == 500 and torch.allclose(dets[:, 4], flat[order].sigmoid(), atol=1e-6)
+    assert torch.allclose(dets[:, :4], a1[order], atol=1e-4)              # zero deltas: the anchors themselves
