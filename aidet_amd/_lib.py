@@ -29,7 +29,7 @@ NMS_STRICT = 1          # OBB_NMS_STRICT: suppress on `>` (nms_kernel.cu:61) ins
 NMS_RESULT_BYTES = 64   # OBB_NMS_RESULT_BYTES
 # obb_set_tuning knobs (test / experiment hooks, include/obbops.h)
 (TUNE_NMS_FUSED_MAX, TUNE_NMS_DIRECT_MAX, TUNE_NMS_SCAN_BLOCKS, TUNE_RROI_GROUPS, TUNE_OVERLAPS_ROWS, TUNE_NMS_INLINE_MAX,
- TUNE_RROI_ORDER_MIN) = range(7)
+ TUNE_RROI_ORDER_MIN, TUNE_RROI_GATHER_CHAN) = range(8)
 
 _lib = None
 
@@ -82,6 +82,12 @@ def lib():
         L.obb_rpn_select_decode_f32.restype = i32
         L.obb_rows_topk_f32.argtypes = [vp, i64, i32, i32, vp, i64, ctypes.POINTER(i32), i32, i32, i32, vp, vp, vp, vp]
         L.obb_rows_topk_f32.restype = i32
+        L.obb_head_select_decode_f32.argtypes = [vp, vp, vp, i64, i32, i32, i32, f32, ctypes.POINTER(f32), ctypes.POINTER(f32), f32,
+                                                 i32, i32, f32, vp, vp, vp, vp, vp]
+        L.obb_head_select_decode_f32.restype = i32
+        L.obb_head_gather_decode_f32.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp, i64, ctypes.POINTER(f32), ctypes.POINTER(f32),
+                                                 f32, i32, i32, f32, vp, vp]
+        L.obb_head_gather_decode_f32.restype = i32
         L.obb_set_tuning.argtypes = [i32, i64]
         L.obb_set_tuning.restype = i32
         rroi = [vp, i32, i32, i32, i32, vp, i64, i32, i32, f32, i32, f32, vp, vp]

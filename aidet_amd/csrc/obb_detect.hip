@@ -25,6 +25,7 @@ namespace obb {
 
 constexpr int kSelMax = 2048;       // most rows a selection keeps (nms_pre / max_num <= 2048)
 constexpr int kSelThreads = 1024;
+constexpr int kSelBatch = 16;       // keys a thread has in flight in the streaming passes
 
 // larger float <=> larger key; -0 folded into +0; NaN sorts below everything (never selected before a number)
 __device__ __forceinline__ uint32_t sel_key(float f) {
@@ -34,18 +35,65 @@ __device__ __forceinline__ uint32_t sel_key(float f) {
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);   // (>= 0x007FFFFF for -inf: never 0 or 1)
 }
 
+// In-place bitonic sort of k entries by (key descending, index ascending); the arrays must have room for k rounded up
+// to a power of two (the padding sorts last).  66 barrier steps at k = 2048, ~30 us.  (A rank sort -- count the
+// entries that come before each one -- needs no barrier but k^2 compares: 80-100 us of LDS / VALU time on one CU at
+// k = 2000; it was the larger part of the first version of these kernels.)
+__device__ __forceinline__ void bitonic_sort(uint32_t *sk, uint32_t *si, int k) {
+  const int tid = threadIdx.x;
+  int m = 1;
+  while (m < k) m <<= 1;
+  for (int i = k + tid; i < m; i += kSelThreads) { sk[i] = 0u; si[i] = 0xFFFFFFFFu; }
+  __syncthreads();
+  auto before = [](uint32_t ka, uint32_t ia, uint32_t kb, uint32_t ib) { return ka > kb || (ka == kb && ia < ib); };
+  for (int size = 2; size <= m; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t2 = tid; t2 < (m >> 1); t2 += kSelThreads) {
+        const int lo = ((t2 / stride) * 2 * stride) + (t2 % stride), hi = lo + stride;
+        const bool up = ((lo & size) == 0);             // this run is sorted "best first"
+        const uint32_t ka = sk[lo], ia = si[lo], kb = sk[hi], ib = si[hi];
+        const bool swap = up ? before(kb, ib, ka, ia) : before(ka, ia, kb, ib);
+        if (swap) { sk[lo] = kb; si[lo] = ib; sk[hi] = ka; si[hi] = ia; }
+      }
+      __syncthreads();
+    }
+  }
+}
+
 struct SelScratch {
   uint32_t hist[2048];
   uint32_t wsum[16];
-  uint32_t prefix, krem, ngt, neq;
+  uint32_t prefix, krem;
   int cgt, ceq;
+  int wcount[16];
+  int overflow;
 };
+
+// hist[digit] += 1 for the active lanes of a wave.  Keys of a detection head cluster (logits near 0, probabilities
+// near the threshold): their top digits fall into one or two bins, and 10^5 LDS atomics on ONE word serialise
+// (0.3 ms for the 196 608 anchors of a stride-4 level).  The three most common digits of the wave are therefore
+// added once per wave; what is left (a uniform pass: nearly everything) goes through plain atomics.
+__device__ __forceinline__ void hist_add(uint32_t *hist, uint32_t digit, bool active, int lane) {
+  uint64_t rem = __ballot(active);
+#pragma unroll
+  for (int it = 0; it < 3; ++it) {
+    if (rem == 0ull) break;                              // (wave-uniform)
+    const int leader = __ffsll((long long)rem) - 1;
+    const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)digit, leader);
+    const uint64_t m = __ballot(active && digit == d) & rem;
+    if (lane == leader) atomicAdd(&hist[d], (uint32_t)__popcll(m));
+    rem &= ~m;
+  }
+  if ((rem >> lane) & 1ull) atomicAdd(&hist[digit], 1u);
+}
 
 // Exact top-k of key(i), i in [0, n): on return sk[0..k) / si[0..k) hold the k largest keys and their indices,
 // sorted by (key descending, index ascending).  k <= kSelMax, k <= n.  All 1024 threads call it.
 // `key` is evaluated up to 4 times per element (three histogram passes + the collection): it should be a load.
+// idxmap (optional): the indices reported (and used as the tie-break of the final order) are idxmap[i] instead of i.
 template <class KeyFn>
-__device__ void block_topk_sorted(KeyFn key, int n, int k, uint32_t *sk, uint32_t *si, SelScratch &sc) {
+__device__ void block_topk_sorted(KeyFn key, int n, int k, uint32_t *sk, uint32_t *si, SelScratch &sc,
+                                  const uint32_t *idxmap = nullptr) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // ---- radix select: the k-th largest key T, digit by digit from the top (11 + 11 + 10 bits)
   if (tid == 0) { sc.prefix = 0u; sc.krem = (uint32_t)k; }
@@ -57,9 +105,18 @@ __device__ void block_topk_sorted(KeyFn key, int n, int k, uint32_t *sk, uint32_
     for (int b = tid; b < nb; b += kSelThreads) sc.hist[b] = 0u;
     __syncthreads();
     const uint32_t pre = sc.prefix;
-    for (int i = tid; i < n; i += kSelThreads) {
-      const uint32_t kk = key(i);
-      if ((kk & himask) == pre) atomicAdd(&sc.hist[(kk >> sh) & (uint32_t)(nb - 1)], 1u);
+    // (whole waves iterate together: hist_add votes.  kSelBatch keys per thread are requested before the first is
+    // used: one key per iteration was one exposed memory round trip per 1024 keys -- 0.3 ms for a stride-4 level)
+    for (int base = 0; base < n; base += kSelBatch * kSelThreads) {
+      uint32_t kk[kSelBatch];
+#pragma unroll
+      for (int u = 0; u < kSelBatch; ++u) { const int i = base + u * kSelThreads + tid; kk[u] = i < n ? key(i) : 0u; }
+#pragma unroll
+      for (int u = 0; u < kSelBatch; ++u) {
+        const int i = base + u * kSelThreads + tid;
+        if (base + u * kSelThreads < n)                    // (block-uniform)
+          hist_add(sc.hist, (kk[u] >> sh) & (uint32_t)(nb - 1), i < n && (kk[u] & himask) == pre, lane);
+      }
     }
     __syncthreads();
     // the digit d with  count(digits > d) < krem <= count(digits >= d): suffix sums over the bins
@@ -96,12 +153,19 @@ __device__ void block_topk_sorted(KeyFn key, int n, int k, uint32_t *sk, uint32_
   if (tid == 0) { sc.cgt = 0; sc.ceq = 0; }
   __syncthreads();
   const int ngt_total = k - need_eq;
-  for (int base = 0; base < n; base += kSelThreads) {
+  for (int base0 = 0; base0 < n; base0 += kSelBatch * kSelThreads) {
+   uint32_t kb[kSelBatch];
+#pragma unroll
+   for (int u = 0; u < kSelBatch; ++u) { const int i = base0 + u * kSelThreads + tid; kb[u] = i < n ? key(i) : 0u; }
+#pragma unroll
+   for (int u = 0; u < kSelBatch; ++u) {
+    const int base = base0 + u * kSelThreads;
+    if (base >= n) break;                                        // (block-uniform)
     const int i = base + tid;
-    uint32_t kk = 0u;
-    bool gt = false, eq = false;
-    if (i < n) { kk = key(i); gt = kk > T; eq = kk == T; }
+    const uint32_t kk = kb[u];
+    const bool gt = i < n && kk > T, eq = i < n && kk == T;
     const uint64_t mg = __ballot(gt), me = __ballot(eq);
+    if (__syncthreads_or((mg | me) != 0ull) == 0) continue;    // (block-uniform) nothing to take in this chunk: the usual case
     if (lane == 0) { sc.wsum[wave] = (uint32_t)__popcll(mg) | ((uint32_t)__popcll(me) << 16); }
     __syncthreads();
     int og = sc.cgt, oe = sc.ceq, tg = 0, te = 0;
@@ -111,31 +175,78 @@ __device__ void block_topk_sorted(KeyFn key, int n, int k, uint32_t *sk, uint32_
       tg += (int)(v & 0xFFFFu); te += (int)(v >> 16);
     }
     const uint64_t lt = (1ull << lane) - 1ull;
-    if (gt) { const int p = og + __popcll(mg & lt); sk[p] = kk; si[p] = (uint32_t)i; }
-    if (eq) { const int r = oe + __popcll(me & lt); if (r < need_eq) { sk[ngt_total + r] = kk; si[ngt_total + r] = (uint32_t)i; } }
+    if (gt) { const int p = og + __popcll(mg & lt); sk[p] = kk; si[p] = idxmap ? idxmap[i] : (uint32_t)i; }
+    if (eq) { const int r = oe + __popcll(me & lt); if (r < need_eq) { sk[ngt_total + r] = kk; si[ngt_total + r] = idxmap ? idxmap[i] : (uint32_t)i; } }
     __syncthreads();
     if (tid == 0) { sc.cgt += tg; sc.ceq += te; }
     __syncthreads();
+   }
   }
-  // ---- bitonic sort of the k entries by (key descending, index ascending); padded to a power of two with
-  // entries that sort last
-  int m = 1;
-  while (m < k) m <<= 1;
-  for (int i = k + tid; i < m; i += kSelThreads) { sk[i] = 0u; si[i] = 0xFFFFFFFFu; }
   __syncthreads();
-  auto before = [](uint32_t ka, uint32_t ia, uint32_t kb, uint32_t ib) { return ka > kb || (ka == kb && ia < ib); };
-  for (int size = 2; size <= m; size <<= 1) {
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      for (int t2 = tid; t2 < (m >> 1); t2 += kSelThreads) {
-        const int lo = ((t2 / stride) * 2 * stride) + (t2 % stride), hi = lo + stride;
-        const bool up = ((lo & size) == 0);             // this run is sorted "best first"
-        const uint32_t ka = sk[lo], ia = si[lo], kb = sk[hi], ib = si[hi];
-        const bool swap = up ? before(kb, ib, ka, ia) : before(ka, ia, kb, ib);
-        if (swap) { sk[lo] = kb; si[lo] = ib; sk[hi] = ka; si[hi] = ia; }
-      }
-      __syncthreads();
+  bitonic_sort(sk, si, k);
+  __syncthreads();
+}
+
+// The same for a LARGE n (a stride-4 level has 196 608 anchors, of which 2000 are wanted): a threshold from a strided
+// sample first -- the sample key whose rank says "about 2 k keys are at least this large" -- then ONE pass over all keys
+// that compacts the candidates above it into per-wave LDS segments (wave-local counters: no barrier in the pass), then
+// the exact selection among the <= 8192 candidates.  Too few candidates (< k) or a full segment: the plain routine.
+constexpr int kCandCap = 8192, kCandPerWave = kCandCap / (kSelThreads / 64);
+constexpr int kSampleN = 2048;
+template <class KeyFn>
+__device__ void block_topk_sorted_big(KeyFn key, int n, int k, uint32_t *sk, uint32_t *si, uint32_t *ck, uint32_t *ci,
+                                      SelScratch &sc) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // sample: kSampleN strided keys; its q-th largest, q = 2 k / n of the sample, is the prefilter threshold
+  // (pseudo-random positions: a fixed stride of n / 2048 is a multiple of the anchors per location on every FPN level,
+  // i.e. it would sample ONE anchor shape -- whose scores are shifted against the others' -- and miss the threshold)
+  int q = (int)((2.0f * (float)k / (float)n) * (float)kSampleN) + 1;
+  q = q < 8 ? 8 : (q > kSampleN ? kSampleN : q);
+  for (int j = tid; j < kSampleN; j += kSelThreads) ck[j] = key((int)(((uint64_t)(uint32_t)j * 2654435761ull) % (uint64_t)n));
+  __syncthreads();
+  block_topk_sorted([&](int j) { return ck[j]; }, kSampleN, q, sk, si, sc);
+  const uint32_t T0 = sk[q - 1];
+  __syncthreads();
+  if (tid == 0) sc.overflow = 0;
+  int mine = 0;                                          // candidates of this wave so far (wave-uniform)
+  uint32_t *wk = ck + wave * kCandPerWave, *wi = ci + wave * kCandPerWave;
+  for (int base = 0; base < n; base += kSelBatch * kSelThreads) {
+    uint32_t kk[kSelBatch];
+#pragma unroll
+    for (int u = 0; u < kSelBatch; ++u) { const int i = base + u * kSelThreads + tid; kk[u] = i < n ? key(i) : 0u; }
+#pragma unroll
+    for (int u = 0; u < kSelBatch; ++u) {
+      const int i = base + u * kSelThreads + tid;
+      const bool take = i < n && kk[u] >= T0;
+      const uint64_t m = __ballot(take);
+      if (m == 0ull) continue;
+      const int p = mine + __popcll(m & ((1ull << lane) - 1ull));
+      if (take && p < kCandPerWave) { wk[p] = kk[u]; wi[p] = (uint32_t)i; }
+      mine += __popcll(m);
     }
   }
+  if (lane == 0) { sc.wcount[wave] = mine < kCandPerWave ? mine : kCandPerWave; if (mine > kCandPerWave) sc.overflow = 1; }
+  __syncthreads();
+  int total = 0, off = 0;
+  for (int w2 = 0; w2 < kSelThreads / 64; ++w2) { off += (w2 < wave) ? sc.wcount[w2] : 0; total += sc.wcount[w2]; }
+  const bool fallback = sc.overflow != 0 || total < k;   // (block-uniform)
+  if (fallback) {
+    __syncthreads();
+    block_topk_sorted(key, n, k, sk, si, sc);
+    return;
+  }
+  // candidates -> one dense list (in place: wave w's segment moves down to offset `off`; waves go in order)
+  const int cnt = sc.wcount[wave];
+  uint32_t vk[kCandPerWave / 64], vi[kCandPerWave / 64];
+#pragma unroll
+  for (int u = 0; u < kCandPerWave / 64; ++u) { const int j = lane + u * 64; vk[u] = j < cnt ? wk[j] : 0u; vi[u] = j < cnt ? wi[j] : 0u; }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < kCandPerWave / 64; ++u) { const int j = lane + u * 64; if (j < cnt) { ck[off + j] = vk[u]; ci[off + j] = vi[u]; } }
+  __syncthreads();
+  // exact top-k among the candidates, reported and tie-broken by ANCHOR index (which members of a tie AT the k-th key
+  // are taken follows the candidate order -- wave-major -- not the anchor order: torch.topk leaves that open too)
+  block_topk_sorted([&](int j) { return ck[j]; }, total, k, sk, si, sc, ci);
 }
 
 struct RpnLevels {
@@ -174,6 +285,7 @@ __global__ __launch_bounds__(kSelThreads) void rpn_select_decode_kernel(const Rp
                                                                         float *__restrict__ dets,
                                                                         int32_t *__restrict__ levels) {
   __shared__ uint32_t sk[kSelMax], si[kSelMax];
+  __shared__ uint32_t ck[kCandCap], ci[kCandCap];
   __shared__ SelScratch sc;
   const int l = blockIdx.x, tid = threadIdx.x;
   const int H = lv.H[l], W = lv.W[l], HW = H * W;
@@ -190,7 +302,10 @@ __global__ __launch_bounds__(kSelThreads) void rpn_select_decode_kernel(const Rp
     return cls[(2 * a + 1) * HW + p] - cls[(2 * a) * HW + p];
   };
   const bool select = k < n;
-  if (select) block_topk_sorted([&](int i) { return sel_key(logit(i)); }, n, k, sk, si, sc);
+  if (select) {
+    if (n >= 4 * kCandCap) block_topk_sorted_big([&](int i) { return sel_key(logit(i)); }, n, k, sk, si, ck, ci, sc);
+    else block_topk_sorted([&](int i) { return sel_key(logit(i)); }, n, k, sk, si, sc);
+  }
   float *out = dets + (size_t)lv.out_base[l] * 5;
   int32_t *olv = levels + lv.out_base[l];
   for (int j = tid; j < k; j += kSelThreads) {
@@ -202,6 +317,131 @@ __global__ __launch_bounds__(kSelThreads) void rpn_select_decode_kernel(const Rp
     const float s = 1.0f / (1.0f + expf(-logit(i)));
     out[j * 5 + 0] = b.x; out[j * 5 + 1] = b.y; out[j * 5 + 2] = b.z; out[j * 5 + 3] = b.w; out[j * 5 + 4] = s;
     olv[j] = l;
+  }
+}
+
+
+// ---- detection heads: softmax + score threshold + decode of the (RoI, class) candidates -----------------------------
+// Replaces: BBoxHead.get_det_bboxes up to its NMS (mmdet/models/bbox_heads/bbox_head.py:139-176: softmax :149,
+//           delta2bbox over ALL classes :152-153, rescale :160-166) and the candidate list the class-wise NMS builds
+//           (multiclass_nms_with_index, rbbox_nms.py:22-43: per class `scores[:, i] > score_thr`, boxes of that class);
+//           RBBoxHead.get_det_rbboxes_parallel, rbbox_head.py:253-296 (delta2thetaobb, core/rbbox/transforms.py:356-395).
+// One workgroup: probabilities of up to 2048 RoIs into LDS (one RoI per thread), then class by class an ORDERED
+// compaction of the RoIs above the threshold (ballot ranks: the class-major, RoI-ascending list that nonzero() of
+// the (class, RoI) mask yields), then one decode per listed candidate -- instead of decoding every class of every RoI.
+constexpr int kHeadMaxRois = 2048;
+constexpr int kHeadMaxClasses = 16;     // foreground classes whose probabilities fit the LDS matrix below (128 KiB)
+
+struct HeadCodec { float m[5], s[5]; float max_ratio; int max_h, max_w; float inv_scale; int rescale; int dim; };
+
+// dim 4: delta2bbox (transforms.py:34-111) + optional division by scale_factor; dim 5: delta2thetaobb
+// (core/rbbox/transforms.py:356-395: anchor angle -pi/2, no clamp to the image) + thetaobb_rescale
+__device__ __forceinline__ void head_decode(const float *__restrict__ roi, const float *__restrict__ d,
+                                            const HeadCodec &c, float *__restrict__ out) {
+  const float ax1 = roi[1], ay1 = roi[2], ax2 = roi[3], ay2 = roi[4];
+  if (c.dim == 4) {
+    BoxCodec bc;
+    for (int k = 0; k < 4; ++k) { bc.m[k] = c.m[k]; bc.s[k] = c.s[k]; }
+    bc.max_ratio = c.max_ratio; bc.max_h = c.max_h; bc.max_w = c.max_w;
+    float4 b = decode_box(ax1, ay1, ax2, ay2, d[0], d[1], d[2], d[3], bc);
+    if (c.rescale) { b.x = b.x / c.inv_scale; b.y = b.y / c.inv_scale; b.z = b.z / c.inv_scale; b.w = b.w / c.inv_scale; }
+    out[0] = b.x; out[1] = b.y; out[2] = b.z; out[3] = b.w;
+  } else {
+    const float dx = d[0] * c.s[0] + c.m[0], dy = d[1] * c.s[1] + c.m[1];
+    float dw = d[2] * c.s[2] + c.m[2], dh = d[3] * c.s[3] + c.m[3];
+    const float dt = d[4] * c.s[4] + c.m[4];
+    dw = dw < -c.max_ratio ? -c.max_ratio : (dw > c.max_ratio ? c.max_ratio : dw);
+    dh = dh < -c.max_ratio ? -c.max_ratio : (dh > c.max_ratio ? c.max_ratio : dh);
+    const float px = (ax1 + ax2) * 0.5f, py = (ay1 + ay2) * 0.5f;
+    const float pw = ax2 - ax1 + 1.0f, ph = ay2 - ay1 + 1.0f;
+    float gw = pw * expf(dw), gh = ph * expf(dh);
+    float gx = px + pw * dx, gy = py + ph * dy;
+    const float gt = dt + (-1.57079632679489661923f);
+    if (c.rescale) { gx = gx / c.inv_scale; gy = gy / c.inv_scale; gw = gw / c.inv_scale; gh = gh / c.inv_scale; }   // (the angle is not scaled)
+    out[0] = gx; out[1] = gy; out[2] = gw; out[3] = gh; out[4] = gt;
+  }
+}
+
+// softmax of one row of (C1) logits: exp(x - max) / sum, classes summed in ascending order
+__device__ __forceinline__ void row_softmax(const float *__restrict__ x, int C1, float &mx, float &sum) {
+  mx = x[0];
+  for (int c = 1; c < C1; ++c) mx = x[c] > mx ? x[c] : mx;
+  sum = 0.0f;
+  for (int c = 0; c < C1; ++c) sum += expf(x[c] - mx);
+}
+
+__global__ __launch_bounds__(1024) void head_select_decode_kernel(const float *__restrict__ rois, const float *__restrict__ cls_score,
+                                                                  const float *__restrict__ pred, int n, int C1, int pred_cols,
+                                                                  float score_thr, const HeadCodec codec,
+                                                                  float *__restrict__ dets, int32_t *__restrict__ rows,
+                                                                  int32_t *__restrict__ labels, int64_t *__restrict__ counts) {
+  extern __shared__ float prob[];                  // [class - 1][n] probabilities of the foreground classes
+  __shared__ int wcnt[16];
+  __shared__ int s_total;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int C = C1 - 1, d = codec.dim;
+  for (int r = tid; r < n; r += 1024) {
+    const float *x = cls_score + (size_t)r * C1;
+    float mx, sum;
+    row_softmax(x, C1, mx, sum);
+    for (int c = 1; c < C1; ++c) prob[(size_t)(c - 1) * n + r] = expf(x[c] - mx) / sum;
+  }
+  if (tid == 0) s_total = 0;
+  __syncthreads();
+  // ---- class by class: the RoIs with prob > thr, ascending
+  for (int c = 0; c < C; ++c) {
+    const int before = s_total;
+    int running = 0;
+    for (int base = 0; base < n; base += 1024) {
+      const int r = base + tid;
+      const bool ok = r < n && prob[(size_t)c * n + r] > score_thr;
+      const uint64_t mk = __ballot(ok);
+      if (lane == 0) wcnt[wave] = __popcll(mk);
+      __syncthreads();
+      int off = 0, tot = 0;
+#pragma unroll
+      for (int w2 = 0; w2 < 16; ++w2) { const int v = wcnt[w2]; off += (w2 < wave) ? v : 0; tot += v; }
+      if (ok) {
+        const int p = before + running + off + __popcll(mk & ((1ull << lane) - 1ull));
+        rows[p] = r; labels[p] = c;
+      }
+      running += tot;
+      __syncthreads();
+    }
+    if (tid == 0) { counts[c] = running; s_total = before + running; }
+    __syncthreads();
+  }
+  const int M = s_total;
+  if (tid == 0) counts[C] = M;
+  // ---- decode the listed candidates (their rows / labels were written by this workgroup: visible after the barrier)
+  for (int p = tid; p < M; p += 1024) {
+    const int r = rows[p], c = labels[p];
+    const float *dl = pred + (size_t)r * pred_cols + (pred_cols > d ? (size_t)(c + 1) * d : 0);
+    float *o = dets + (size_t)p * (d + 1);
+    head_decode(rois + (size_t)r * 5, dl, codec, o);
+    o[d] = prob[(size_t)c * n + r];
+  }
+}
+
+// the (RoI, class) pairs a previous selection kept -> rows of ANOTHER head's outputs: its softmax score of that class and
+// its decoded box of that class (thetaobb_nms_by_bbox_nms, rbbox_nms.py:64-119: "the rotated boxes that survive are
+// those whose horizontal boxes survived")
+__global__ __launch_bounds__(256) void head_gather_decode_kernel(const float *__restrict__ rois, const float *__restrict__ cls_score,
+                                                                 const float *__restrict__ pred, int C1, int pred_cols,
+                                                                 const int32_t *__restrict__ rows, const int32_t *__restrict__ labels,
+                                                                 const int64_t *__restrict__ sel, int K, const HeadCodec codec,
+                                                                 float *__restrict__ dets) {
+  const int d = codec.dim;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < K; j += gridDim.x * blockDim.x) {
+    const int64_t p = sel ? sel[j] : j;
+    const int r = rows[p], c = labels[p];
+    const float *x = cls_score + (size_t)r * C1;
+    float mx, sum;
+    row_softmax(x, C1, mx, sum);
+    const float *dl = pred + (size_t)r * pred_cols + (pred_cols > d ? (size_t)(c + 1) * d : 0);
+    float *o = dets + (size_t)j * (d + 1);
+    head_decode(rois + (size_t)r * 5, dl, codec, o);
+    o[d] = expf(x[c + 1] - mx) / sum;
   }
 }
 
@@ -321,6 +561,77 @@ extern "C" int obb_rows_topk_f32(const float *rows_dev, int64_t num_rows, int co
   if (nms_post <= 0) nms_post = 2147483647;
   hipLaunchKernelGGL(rows_topk_kernel, dim3(1), dim3(kSelThreads), 0, st, rows_dev, cols, score_col, keep_dev, (int)K, lb, nms_post, top,
                      out_dev, out_idx_dev, count_dev);
+  OBB_LAUNCH_CHECK();
+  return OBB_OK;
+}
+
+namespace obb {
+static int head_codec(const char *who, int dim, const float *means_host, const float *stds_host, float wh_ratio_clip, int max_h,
+                      int max_w, float scale_factor, HeadCodec &c) {
+  if (dim != 4 && dim != 5) return set_err(OBB_EINVAL, "%s: dim = %d (4 horizontal, 5 theta-OBB)", who, dim);
+  if (!means_host || !stds_host) return set_err(OBB_EINVAL, "%s: null pointer", who);
+  if (!(wh_ratio_clip > 0.0f)) return set_err(OBB_EINVAL, "%s: wh_ratio_clip must be positive", who);
+  for (int k = 0; k < 5; ++k) { c.m[k] = k < dim ? means_host[k] : 0.0f; c.s[k] = k < dim ? stds_host[k] : 1.0f; }
+  c.max_ratio = fabsf(logf(wh_ratio_clip));
+  c.max_h = max_h; c.max_w = max_w;
+  c.rescale = scale_factor > 0.0f ? 1 : 0;
+  c.inv_scale = scale_factor > 0.0f ? scale_factor : 1.0f;
+  c.dim = dim;
+  return OBB_OK;
+}
+}  // namespace obb
+
+extern "C" int obb_head_select_decode_f32(const float *rois_dev, const float *cls_score_dev, const float *pred_dev,
+                                          int64_t n, int num_classes, int pred_cols, int dim, float score_thr,
+                                          const float *means_host, const float *stds_host, float wh_ratio_clip,
+                                          int max_h, int max_w, float scale_factor, float *dets_dev,
+                                          int32_t *rows_dev, int32_t *labels_dev, int64_t *counts_dev, void *stream) {
+  using namespace obb;
+  const char *who = "obb_head_select_decode_f32";
+  if (n < 0 || num_classes < 2) return set_err(OBB_EINVAL, "%s: n = %lld, num_classes = %d", who, (long long)n, num_classes);
+  if (n > kHeadMaxRois || num_classes - 1 > kHeadMaxClasses)
+    return set_err(OBB_EINVAL, "%s: at most %d RoIs and %d foreground classes", who, kHeadMaxRois, kHeadMaxClasses);
+  if (pred_cols != dim && pred_cols != dim * num_classes) return set_err(OBB_EINVAL, "%s: pred_cols = %d (dim or dim * num_classes)", who, pred_cols);
+  HeadCodec c;
+  int rc = head_codec(who, dim, means_host, stds_host, wh_ratio_clip, max_h, max_w, scale_factor, c);
+  if (rc != OBB_OK) return rc;
+  if (!counts_dev) return set_err(OBB_EINVAL, "%s: null pointer", who);
+  hipStream_t st = (hipStream_t)stream;
+  if (n == 0) {
+    OBB_HIP_TRY(hipMemsetAsync(counts_dev, 0, sizeof(int64_t) * (size_t)num_classes, st));
+    return OBB_OK;
+  }
+  if (!rois_dev || !cls_score_dev || !pred_dev || !dets_dev || !rows_dev || !labels_dev) return set_err(OBB_EINVAL, "%s: null pointer", who);
+  const size_t lds = (size_t)(num_classes - 1) * (size_t)n * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {   // (up to 128 KiB of dynamic LDS: above the 64 KiB a kernel gets without asking)
+    OBB_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(head_select_decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    kHeadMaxRois * kHeadMaxClasses * (int)sizeof(float)));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(head_select_decode_kernel, dim3(1), dim3(1024), lds, st, rois_dev, cls_score_dev, pred_dev, (int)n, num_classes,
+                     pred_cols, score_thr, c, dets_dev, rows_dev, labels_dev, counts_dev);
+  OBB_LAUNCH_CHECK();
+  return OBB_OK;
+}
+
+extern "C" int obb_head_gather_decode_f32(const float *rois_dev, const float *cls_score_dev, const float *pred_dev,
+                                          int num_classes, int pred_cols, int dim, const int32_t *rows_dev,
+                                          const int32_t *labels_dev, const int64_t *sel_dev, int64_t K,
+                                          const float *means_host, const float *stds_host, float wh_ratio_clip,
+                                          int max_h, int max_w, float scale_factor, float *dets_dev, void *stream) {
+  using namespace obb;
+  const char *who = "obb_head_gather_decode_f32";
+  if (K < 0 || num_classes < 2 || K > 2147483647LL) return set_err(OBB_EINVAL, "%s: bad size", who);
+  if (pred_cols != dim && pred_cols != dim * num_classes) return set_err(OBB_EINVAL, "%s: pred_cols = %d (dim or dim * num_classes)", who, pred_cols);
+  HeadCodec c;
+  int rc = head_codec(who, dim, means_host, stds_host, wh_ratio_clip, max_h, max_w, scale_factor, c);
+  if (rc != OBB_OK) return rc;
+  if (K == 0) return OBB_OK;
+  if (!rois_dev || !cls_score_dev || !pred_dev || !rows_dev || !labels_dev || !dets_dev) return set_err(OBB_EINVAL, "%s: null pointer", who);
+  const unsigned blocks = (unsigned)((K + 255) / 256);
+  hipLaunchKernelGGL(head_gather_decode_kernel, dim3(blocks > 1024u ? 1024u : blocks), dim3(256), 0, (hipStream_t)stream, rois_dev, cls_score_dev,
+                     pred_dev, num_classes, pred_cols, rows_dev, labels_dev, sel_dev, (int)K, c, dets_dev);
   OBB_LAUNCH_CHECK();
   return OBB_OK;
 }

@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256) void nms_cellscan_big_kernel(uint32_t *__restr
 // against the tiles of all EARLIER tickets, polling their words (they have all started, none waits for anybody
 // before publishing: no deadlock; the hand-over pattern of nms_compact_kernel).
 // =====================================================================================================
-constexpr int kFrameSamples = 4096;
+constexpr int kFrameSamples = 1024;     // (4 per thread of ONE 256-thread workgroup: 4096 samples on 16 waves took 14 us, mostly barriers)
 struct alignas(16) NmsFrame { float bx, by, sx, sy; float cpx, cpy; int gbits; int any; };
 
 // conservative axis-aligned box of one input row, no trigonometry (frame only: never affects a result)
@@ -356,7 +356,7 @@ __device__ __forceinline__ float4 sample_box(const float *__restrict__ row) {
 }
 
 template <int KIND>
-__global__ __launch_bounds__(1024) void nms_frame_kernel(const float *__restrict__ dets, int64_t n,
+__global__ __launch_bounds__(256) void nms_frame_kernel(const float *__restrict__ dets, int64_t n,
                                                         const int32_t *__restrict__ group, int cell_hbits,
                                                         NmsFrame *__restrict__ frame,
                                                         uint4 *__restrict__ zero, size_t zero_vecs) {
@@ -365,10 +365,10 @@ __global__ __launch_bounds__(1024) void nms_frame_kernel(const float *__restrict
     zero[z] = make_uint4(0u, 0u, 0u, 0u);
   if (blockIdx.x != 0) return;
   __shared__ float4 sm[kFrameSamples];       // lo x, hi x, lo y, hi y of every sample (lo > hi: not finite)
-  __shared__ float red[16][8];
+  __shared__ float red[4][8];
   __shared__ float tot[8];
   __shared__ uint32_t gbm[128];
-  constexpr int T = 1024, PER = kFrameSamples / T;
+  constexpr int T = 256, PER = kFrameSamples / T, NW = T / 64;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int ns = (int)(n < kFrameSamples ? n : kFrameSamples);
   const int64_t stride = n / ns;                        // (>= 1; the samples cover [0, ns * stride))
@@ -392,12 +392,12 @@ __global__ __launch_bounds__(1024) void nms_frame_kernel(const float *__restrict
     __syncthreads();
     if (tid < m) {
       float a = 0.0f;
-      for (int w2 = 0; w2 < 16; ++w2) a += red[w2][tid];
+      for (int w2 = 0; w2 < NW; ++w2) a += red[w2][tid];
       tot[tid] = a;
     }
     __syncthreads();
   };
-  __shared__ uint4 wred[16];
+  __shared__ uint4 wred[NW];
   __shared__ uint4 bbox_all;
   // ---- the usual case in ONE pass: centre statistics about the first sample (fp32: the shift keeps a scene far from
   // the origin from cancelling) and the bounding box of all finite samples.  No centre further than 3.5 sigma from
@@ -425,11 +425,11 @@ __global__ __launch_bounds__(1024) void nms_frame_kernel(const float *__restrict
       cxh = max(cxh, shfl_xor_u(cxh, o)); cxl = max(cxl, shfl_xor_u(cxl, o));
       cyh = max(cyh, shfl_xor_u(cyh, o)); cyl = max(cyl, shfl_xor_u(cyl, o));
     }
-    __shared__ uint4 cred[16];
+    __shared__ uint4 cred[NW];
     if (lane == 0) { wred[wv] = make_uint4(axh, axl, ayh, ayl); cred[wv] = make_uint4(cxh, cxl, cyh, cyl); }
     block_sum(v, 5);   // (its barriers also publish wred / cred)
     uint4 m = wred[0], c = cred[0];
-    for (int k = 1; k < 16; ++k) {
+    for (int k = 1; k < NW; ++k) {
       m.x = max(m.x, wred[k].x); m.y = max(m.y, wred[k].y); m.z = max(m.z, wred[k].z); m.w = max(m.w, wred[k].w);
       c.x = max(c.x, cred[k].x); c.y = max(c.y, cred[k].y); c.z = max(c.z, cred[k].z); c.w = max(c.w, cred[k].w);
     }
@@ -509,7 +509,7 @@ __global__ __launch_bounds__(1024) void nms_frame_kernel(const float *__restrict
     uint4 m = bbox_all;
     if (trim) {
       m = wred[0];
-      for (int k = 1; k < 16; ++k) {
+      for (int k = 1; k < NW; ++k) {
         m.x = max(m.x, wred[k].x); m.y = max(m.y, wred[k].y);
         m.z = max(m.z, wred[k].z); m.w = max(m.w, wred[k].w);
       }
@@ -2383,14 +2383,14 @@ static int nms_enqueue(const char *who, const float *dets_dev, int64_t n, int ki
     OBB_LAUNCH_CHECK();
   } else {
     // frame (sampled, block 0) + clearing of the call's counters, histogram cells and tile-box words
-    unsigned zb = (unsigned)((zero_vecs + 4095) / 4096);
-    zb = zb < 1u ? 1u : (zb > 128u ? 128u : zb);
+    unsigned zb = (unsigned)((zero_vecs + 1023) / 1024) + 1u;     // (block 0 also takes the frame)
+    zb = zb > 256u ? 256u : zb;
     if (kind == OBB_KIND_RBOX)
-      hipLaunchKernelGGL(nms_frame_kernel<0>, dim3(zb), dim3(1024), 0, st, dets_dev, n, group_dev, hbits, frame, zero, zero_vecs);
+      hipLaunchKernelGGL(nms_frame_kernel<0>, dim3(zb), dim3(256), 0, st, dets_dev, n, group_dev, hbits, frame, zero, zero_vecs);
     else if (kind == OBB_KIND_POLY)
-      hipLaunchKernelGGL(nms_frame_kernel<1>, dim3(zb), dim3(1024), 0, st, dets_dev, n, group_dev, hbits, frame, zero, zero_vecs);
+      hipLaunchKernelGGL(nms_frame_kernel<1>, dim3(zb), dim3(256), 0, st, dets_dev, n, group_dev, hbits, frame, zero, zero_vecs);
     else
-      hipLaunchKernelGGL(nms_frame_kernel<2>, dim3(zb), dim3(1024), 0, st, dets_dev, n, group_dev, hbits, frame, zero, zero_vecs);
+      hipLaunchKernelGGL(nms_frame_kernel<2>, dim3(zb), dim3(256), 0, st, dets_dev, n, group_dev, hbits, frame, zero, zero_vecs);
     OBB_LAUNCH_CHECK();
     if (kind == OBB_KIND_RBOX)
       hipLaunchKernelGGL(nms_prepq_kernel<0>, dim3(pblocks), dim3(256), 0, st, dets_dev, n, rec, qb, ar, ckey, crank, hist, hbits, frame, group_dev, thr_dev, iou_thr);

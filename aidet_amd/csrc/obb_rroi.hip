@@ -768,7 +768,7 @@ __global__ __launch_bounds__(256) void rroi_backward_kernel(
 // RoIs the plan cannot hold (footprint > 2047 pixels, > 256 samples, > 64 bins) are added afterwards by
 // the atomics kernel (`only_unstaged`).
 constexpr int kGTile = 16;                          // map tile: 16 x 16 pixels = one pixel per thread
-constexpr int kGChan = 16;                          // channels per gather block (sums in registers)
+constexpr int kGChanDefault = 16;                   // channels per gather block (sums in registers); OBB_TUNE_RROI_GATHER_CHAN
 constexpr int kGList = 2048;                        // RoIs of one tile held in LDS at a time
 constexpr int kPlanPix = kBwdMaxPix + 2;            // CSR offsets per RoI (16 bit)
 
@@ -928,22 +928,27 @@ __global__ __launch_bounds__(256) void rroi_plan_kernel(
   if (tid == 0) { pl.x0 = fp.x0; pl.y0 = fp.y0; pl.w = fp.w; pl.h = fp.h; pl.state = 1; plan[k] = pl; }
 }
 
+// (Round 3: a variant that takes FOUR RoIs per step -- their plan records, CSR bounds, gradients and first entries
+// requested together, two barriers per step instead of one per RoI -- was built and measured: 155 -> 185 us at
+// configs[2], 0.70 -> 0.84 ms at the config-4 shape (99 VGPRs, five workgroups per CU instead of eight; the kernel is
+// bound by resident workgroups x the length of the longest tile's chain, and the chain did not shorten).  Dropped.)
+template <int CH>
 __global__ __launch_bounds__(256) void rroi_gather_kernel(
     const float *__restrict__ gout, int C, int H, int W, int K, const RoiPlan *__restrict__ plan,
     const unsigned short *__restrict__ rstart, const int2 *__restrict__ rentry, float *__restrict__ gfeat) {
   __shared__ int list[kGList];
-  __shared__ float gtiles[2][kGChan * (kMaxBins + 1)];   // double buffered: one barrier per RoI
+  __shared__ float gtiles[2][CH * (kMaxBins + 1)];   // double buffered: one barrier per RoI
   __shared__ int wcnt[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tiles_x = (W + kGTile - 1) / kGTile;
   const int tx0 = ((int)blockIdx.x % tiles_x) * kGTile, ty0 = ((int)blockIdx.x / tiles_x) * kGTile;
-  const int c0 = (int)blockIdx.y * kGChan, cc = min(kGChan, C - c0);
+  const int c0 = (int)blockIdx.y * CH, cc = min(CH, C - c0);
   const int b = (int)blockIdx.z;
   const int x = tx0 + (tid & (kGTile - 1)), y = ty0 + tid / kGTile;
   const bool inmap = x < W && y < H;
-  float acc[kGChan];
+  float acc[CH];
 #pragma unroll
-  for (int c = 0; c < kGChan; ++c) acc[c] = 0.0f;
+  for (int c = 0; c < CH; ++c) acc[c] = 0.0f;
   for (int base = 0; base < K; base += kGList) {
     // ---- the RoIs of this batch of plans whose footprint meets the tile, in RoI order
     int n = 0;   // block-uniform
@@ -999,7 +1004,7 @@ __global__ __launch_bounds__(256) void rroi_gather_kernel(
             const float wgt = __int_as_float(en[u].y);
             const float *g = gtile + en[u].x;
 #pragma unroll
-            for (int c = 0; c < kGChan; ++c) acc[c] = acc[c] + g[c * nbp] * wgt;   // (channels >= cc: stale LDS, never stored)
+            for (int c = 0; c < CH; ++c) acc[c] = acc[c] + g[c * nbp] * wgt;   // (channels >= cc: stale LDS, never stored)
           }
         }
       }
@@ -1010,7 +1015,7 @@ __global__ __launch_bounds__(256) void rroi_gather_kernel(
   if (inmap) {
     float *dst = gfeat + (((int64_t)b * C + c0) * H + y) * (int64_t)W + x;
 #pragma unroll
-    for (int c = 0; c < kGChan; ++c)
+    for (int c = 0; c < CH; ++c)
       if (c < cc) dst[(int64_t)c * H * W] = acc[c];
   }
 }
@@ -1268,10 +1273,15 @@ extern "C" int obb_roi_backward_gather_f32(const float *grad_out_dev, int B, int
                      sample_num, min_size, roi_kind, plan, rstart, rentry);
   OBB_LAUNCH_CHECK();
   const unsigned tiles = (unsigned)(((W + kGTile - 1) / kGTile) * ((H + kGTile - 1) / kGTile));
-  const unsigned chunks = (unsigned)((C + kGChan - 1) / kGChan);
+  const int gch = (int)tuning(OBB_TUNE_RROI_GATHER_CHAN, kGChanDefault) >= 32 ? 32 : 16;
+  const unsigned chunks = (unsigned)((C + gch - 1) / gch);
   if (chunks > 65535u || B > 65535) return set_err(OBB_EINVAL, "%s: too many channels / images", who);
-  hipLaunchKernelGGL(rroi_gather_kernel, dim3(tiles, chunks, (unsigned)B), dim3(256), 0, st, grad_out_dev, C, H, W, (int)K,
-                     plan, rstart, rentry, grad_feat_dev);
+  if (gch == 32)
+    hipLaunchKernelGGL(rroi_gather_kernel<32>, dim3(tiles, chunks, (unsigned)B), dim3(256), 0, st, grad_out_dev, C, H, W, (int)K,
+                       plan, rstart, rentry, grad_feat_dev);
+  else
+    hipLaunchKernelGGL(rroi_gather_kernel<16>, dim3(tiles, chunks, (unsigned)B), dim3(256), 0, st, grad_out_dev, C, H, W, (int)K,
+                       plan, rstart, rentry, grad_feat_dev);
   OBB_LAUNCH_CHECK();
   // the RoIs the plan could not hold are ADDED by the atomics kernel: its usual geometry (a large RoI's
   // channels spread over 16 blocks), blocks of planned RoIs leave right after the footprint test

@@ -32,7 +32,8 @@ import torch.nn.functional as F
 
 from ..anchors import AnchorGenerator
 from ..bbox_transforms import bbox2result, bbox2roi, delta2bbox
-from ..post_processing import get_det_rbboxes, multiclass_nms_with_index
+from ..post_processing import (detect_horizontal_fused, detect_rotated_fused, get_det_rbboxes, head_fusable,
+                               multiclass_nms_with_index)
 from ..rbbox_transforms import rbbox2result
 from ..roi_layers import SingleRoIExtractor
 from ..rpn import rpn_proposals
@@ -137,11 +138,11 @@ class RPNHead(nn.Module):
                                        zip(self.anchor_generators, featmap_sizes, self.anchor_strides)]
         return self._anchor_cache[key]
 
-    def get_bboxes(self, cls_scores, bbox_preds, img_metas, cfg):
+    def get_bboxes(self, cls_scores, bbox_preds, img_metas, cfg, fused=None):
         """anchor_head.py:254-283 for the RPN: one (n, 5) proposal tensor per image."""
         mlvl_anchors = self.anchors([tuple(c.shape[-2:]) for c in cls_scores], cls_scores[0].device)
         return [rpn_proposals([c[i].detach() for c in cls_scores], [b[i].detach() for b in bbox_preds],
-                              mlvl_anchors, meta['img_shape'], cfg) for i, meta in enumerate(img_metas)]
+                              mlvl_anchors, meta['img_shape'], cfg, fused=fused) for i, meta in enumerate(img_metas)]
 
 
 class SharedFCHead(nn.Module):
@@ -172,8 +173,12 @@ class ThetaOBBRCNN(nn.Module):
     theta-OBBs (``multiclass_rnms``).
     """
 
-    def __init__(self, test_cfg=None, rotated_nms=False):
+    def __init__(self, test_cfg=None, rotated_nms=False, fused=True):
         super(ThetaOBBRCNN, self).__init__()
+        # fused=True: the selection stages of the RPN and of both heads run as the HIP kernels of obb_detect.hip
+        # (three to four launches per stage); False: the tensor-op restatement of the reference's functions, op by op
+        # (aidet_amd.rpn / post_processing) -- the specification the fused path is tested against
+        self.fused = fused
         self.backbone = ResNet50()
         self.neck = FPN()
         self.rpn_head = RPNHead()
@@ -233,7 +238,7 @@ class ThetaOBBRCNN(nn.Module):
         self._tick('backbone_fpn')
         cls_scores, bbox_preds = self.rpn_head(x)
         self._tick('rpn_convs')
-        proposals = self.rpn_head.get_bboxes(cls_scores, bbox_preds, img_meta, self.test_cfg['rpn'])
+        proposals = self.rpn_head.get_bboxes(cls_scores, bbox_preds, img_meta, self.test_cfg['rpn'], fused=self.fused)
         self._tick('rpn_decode_nms')
         img_shape, scale_factor = img_meta[0]['img_shape'], img_meta[0]['scale_factor']
         rois = bbox2roi(proposals)
@@ -242,13 +247,20 @@ class ThetaOBBRCNN(nn.Module):
         self._tick('roi_align_bbox')
         cls_score, bbox_pred = self.bbox_head(roi_feats)
         self._tick('bbox_head_fc')
-        scores = F.softmax(cls_score, dim=1)
-        bboxes = delta2bbox(rois[:, 1:], bbox_pred, (0., 0., 0., 0.), self.bbox_target_stds, img_shape)
-        if rescale:
-            bboxes = bboxes / scale_factor
         rcnn = self.test_cfg['rcnn']
-        det_bboxes, det_labels, cls_inds, keep_inds = multiclass_nms_with_index(
-            bboxes, scores, rcnn['score_thr'], rcnn['nms'], rcnn['max_per_img'])
+        fused = (self.fused and rcnn['nms'].get('type', 'nms') == 'nms' and self.test_cfg['rbbox'].get('encode', 'thetaobb') == 'thetaobb'
+                 and head_fusable(rois, cls_score, bbox_pred, rcnn['max_per_img']))
+        selection = cls_inds = keep_inds = None
+        if fused:
+            det_bboxes, det_labels, selection = detect_horizontal_fused(
+                rois, cls_score, bbox_pred, img_shape, scale_factor, rescale, rcnn, (0., 0., 0., 0.), self.bbox_target_stds)
+        else:
+            scores = F.softmax(cls_score, dim=1)
+            bboxes = delta2bbox(rois[:, 1:], bbox_pred, (0., 0., 0., 0.), self.bbox_target_stds, img_shape)
+            if rescale:
+                bboxes = bboxes / scale_factor
+            det_bboxes, det_labels, cls_inds, keep_inds = multiclass_nms_with_index(
+                bboxes, scores, rcnn['score_thr'], rcnn['nms'], rcnn['max_per_img'])
         self._tick('bbox_decode_nms')
         bbox_results = bbox2result(det_bboxes, det_labels, self.bbox_head.num_classes)
         # ---- rotated branch (test_mixins.py:352-380): its own extractor and trunk
@@ -256,19 +268,24 @@ class ThetaOBBRCNN(nn.Module):
         self._tick('roi_align_rbbox')
         cls_score, rbbox_pred = self.rbbox_head(roi_feats)
         self._tick('rbbox_head_fc')
-        det_rbboxes, det_rlabels = get_det_rbboxes(
-            rois, cls_score, rbbox_pred, img_shape, scale_factor, rescale=rescale, cfg=self.test_cfg['rbbox'],
-            target_stds=self.rbbox_target_stds, bbox_cls_inds=cls_inds, bbox_keep_inds=keep_inds,
-            rotated_nms=self.rotated_nms)
+        if fused:
+            det_rbboxes, det_rlabels = detect_rotated_fused(
+                rois, cls_score, rbbox_pred, img_shape, scale_factor, rescale, self.test_cfg['rbbox'], (0., 0., 0., 0., 0.),
+                self.rbbox_target_stds, selection=None if self.rotated_nms else selection)
+        else:
+            det_rbboxes, det_rlabels = get_det_rbboxes(
+                rois, cls_score, rbbox_pred, img_shape, scale_factor, rescale=rescale, cfg=self.test_cfg['rbbox'],
+                target_stds=self.rbbox_target_stds, bbox_cls_inds=cls_inds, bbox_keep_inds=keep_inds,
+                rotated_nms=self.rotated_nms)
         self._tick('rbbox_decode_nms')
         rbbox_results = rbbox2result(det_rbboxes, det_rlabels, self.rbbox_head.num_classes)
         self._tick('results_to_host')
         return bbox_results, rbbox_results
 
 
-def build_detector(device, rotated_nms=False, seed=0):
+def build_detector(device, rotated_nms=False, seed=0, fused=True):
     torch.manual_seed(seed)
-    return ThetaOBBRCNN(rotated_nms=rotated_nms).to(device).eval()
+    return ThetaOBBRCNN(rotated_nms=rotated_nms, fused=fused).to(device).eval()
 
 
 def demo_inputs(device, size=1024, seed=0):

@@ -16,9 +16,11 @@ ascending keep list by a segmented split.
 (``multiclass_thetaobb_nms(thetaobbs, scores, cfg.score_thr,
 cfg.polygon_nms_iou_thr, cfg.max_per_img)``, rbbox_head.py:294-295).
 """
+import ctypes
+
 import torch
 
-from . import nms_wrapper
+from . import _lib, nms_wrapper
 
 
 def _per_class_boxes(multi_boxes, num_fg, d):
@@ -279,3 +281,128 @@ def get_det_rbboxes(rois, cls_score, rbbox_pred, img_shape, scale_factor, rescal
                                report=(rbboxes, 5))
     return thetaobb_nms_by_bbox_nms(rbboxes, scores, bbox_cls_inds, bbox_keep_inds,
                                     get('max_per_img'), out_dim_reg=dim)
+
+
+# ---- the same stages as fused launches (the detector's inference path) -------------------------------------------------
+HEAD_MAX_ROIS, HEAD_MAX_FG, TOPK_MAX = 2048, 16, 2048      # capacities of obb_head_select_decode_f32 / obb_rows_topk_f32
+
+
+def head_fusable(rois, cls_score, pred, max_num):
+    """True when the fused head kernels serve this call: fp32 HIP tensors, at most 2048 RoIs / 16 foreground classes,
+    a cap of at most 2048 detections."""
+    ts = (rois, cls_score, pred)
+    return (all(isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 for t in ts)
+            and rois.size(0) <= HEAD_MAX_ROIS and 2 <= cls_score.size(1) <= HEAD_MAX_FG + 1 and 0 < max_num <= TOPK_MAX
+            and not torch.is_grad_enabled())
+
+
+def _codec(dim, means, stds, img_shape, scale_factor):
+    m = (ctypes.c_float * 5)(*([float(v) for v in means] + [0.0] * (5 - dim)))
+    sd = (ctypes.c_float * 5)(*([float(v) for v in stds] + [1.0] * (5 - dim)))
+    mh, mw = (int(img_shape[0]), int(img_shape[1])) if (img_shape is not None and dim == 4) else (0, 0)
+    return m, sd, mh, mw, float(scale_factor) if scale_factor else 0.0
+
+
+def select_decode_candidates(rois, cls_score, pred, dim, score_thr, means, stds, img_shape=None, scale_factor=None):
+    """softmax -> ``score > score_thr`` -> decode of the listed (RoI, class) pairs, ONE launch
+    (``obb_head_select_decode_f32``): what ``get_det_bboxes`` / ``get_det_rbboxes_parallel`` compute before their NMS
+    and what ``multiclass_nms_with_index`` lists, without decoding every class of every RoI.
+
+    Returns (dets (M, dim + 1), rows int32 (M,), labels int32 (M,), per-class counts (list)), class-major."""
+    L = _lib.lib()
+    dev = rois.device
+    r, c, p = rois.detach().contiguous(), cls_score.detach().contiguous(), pred.detach().contiguous()
+    n, C1 = c.size(0), c.size(1)
+    cap = max(n * (C1 - 1), 1)
+    dets = torch.empty((cap, dim + 1), dtype=torch.float32, device=dev)
+    rows = torch.empty(cap, dtype=torch.int32, device=dev)
+    labels = torch.empty(cap, dtype=torch.int32, device=dev)
+    counts = torch.empty(C1, dtype=torch.int64, device=dev)
+    m, sd, mh, mw, sf = _codec(dim, means, stds, img_shape, scale_factor)
+    with torch.cuda.device(dev):
+        _lib.check(L.obb_head_select_decode_f32(r.data_ptr(), c.data_ptr(), p.data_ptr(), n, C1, p.size(1), dim, float(score_thr),
+                                                m, sd, 16 / 1000.0, mh, mw, sf, dets.data_ptr(), rows.data_ptr(),
+                                                labels.data_ptr(), counts.data_ptr(), _lib.current_stream_handle(dev)))
+    counts = counts.tolist()             # (the one host read of the stage: sizes the NMS call)
+    M = counts[-1]
+    return dets[:M], rows[:M], labels[:M], counts[:-1]
+
+
+def gather_decode(rois, cls_score, pred, dim, rows, labels, sel, means, stds, img_shape=None, scale_factor=None):
+    """Decoded box + softmax score of another head for the (RoI, class) pairs ``rows[sel]``, ``labels[sel]``
+    (``obb_head_gather_decode_f32``) -> (K, dim + 1)."""
+    L = _lib.lib()
+    dev = rois.device
+    r, c, p = rois.detach().contiguous(), cls_score.detach().contiguous(), pred.detach().contiguous()
+    K = int(sel.numel()) if sel is not None else int(rows.numel())
+    out = torch.empty((K, dim + 1), dtype=torch.float32, device=dev)
+    m, sd, mh, mw, sf = _codec(dim, means, stds, img_shape, scale_factor)
+    with torch.cuda.device(dev):
+        _lib.check(L.obb_head_gather_decode_f32(r.data_ptr(), c.data_ptr(), p.data_ptr(), c.size(1), p.size(1), dim,
+                                                rows.data_ptr(), labels.data_ptr(), None if sel is None else sel.data_ptr(), K,
+                                                m, sd, 16 / 1000.0, mh, mw, sf, out.data_ptr(), _lib.current_stream_handle(dev)))
+    return out
+
+
+def top_rows_by_score(rows, keep, max_num):
+    """``rows[keep]``, cut to the ``max_num`` best by the last column when more survive (then in descending score order,
+    bbox_nms.py:68-74) -> (rows_out, source indices into ``rows``); ``keep`` = None: all rows."""
+    dev = rows.device
+    if keep is None:
+        keep = torch.arange(rows.size(0), device=dev)
+    K = int(keep.numel())
+    if K <= max_num:
+        return _take(rows, keep), keep
+    L = _lib.lib()
+    out = torch.empty((max_num, rows.size(1)), dtype=torch.float32, device=dev)
+    idx = torch.empty(max_num, dtype=torch.int64, device=dev)
+    count = torch.empty(1, dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(L.obb_rows_topk_f32(rows.data_ptr(), rows.size(0), rows.size(1), rows.size(1) - 1, keep.data_ptr(), K, None, 0, 0,
+                                       int(max_num), out.data_ptr(), idx.data_ptr(), count.data_ptr(), _lib.current_stream_handle(dev)))
+    return out, idx             # (K > max_num valid rows: exactly max_num come back)
+
+
+def _take(rows, idx):
+    return rows[idx] if idx.numel() else rows[:0]
+
+
+def detect_horizontal_fused(rois, cls_score, bbox_pred, img_shape, scale_factor, rescale, cfg, target_means, target_stds):
+    """``get_det_bboxes`` + ``multiclass_nms_with_index`` of one image in four launches: candidates (select + decode),
+    grouped horizontal NMS, top-``max_per_img``.  Returns (det_bboxes (k, 5), det_labels (k,), selection) where
+    ``selection`` = (rows, labels, keep) names the kept (RoI, class) pairs for the rotated head's keep re-use."""
+    get = (lambda k: cfg[k]) if isinstance(cfg, dict) else (lambda k: getattr(cfg, k))
+    nms_cfg = dict(get('nms'))
+    op = nms_cfg.pop('type', 'nms')
+    assert op == 'nms', 'the fused head path serves the hard horizontal NMS'
+    dets, rows, labels, _ = select_decode_candidates(rois, cls_score, bbox_pred, 4, get('score_thr'), target_means, target_stds,
+                                                     img_shape, scale_factor if rescale else None)
+    if dets.size(0) == 0:
+        e = torch.zeros(0, dtype=torch.long, device=rois.device)
+        return dets.new_zeros((0, 5)), e, (rows, labels, e)
+    keep, _ = nms_wrapper._run_nms(dets, _lib.KIND_HBB, float(nms_cfg['iou_thr']), labels)
+    out, idx = top_rows_by_score(dets, keep, get('max_per_img'))
+    return out, labels[idx].long(), (rows, labels, keep)
+
+
+def detect_rotated_fused(rois, cls_score, rbbox_pred, img_shape, scale_factor, rescale, cfg, target_means, target_stds,
+                         selection=None):
+    """``get_det_rbboxes`` of one image, theta-OBB encoding: ``selection`` given -> the reference's keep re-use (the
+    rotated head's own score and decoded theta-OBB of every kept (RoI, class) pair, rbbox_nms.py:64-119); else the true
+    rotated NMS (``multiclass_rnms``): candidates, grouped ``rnms``, top-``max_per_img``."""
+    get = (lambda k: cfg[k]) if isinstance(cfg, dict) else (lambda k: getattr(cfg, k))
+    sf = scale_factor if rescale else None
+    if selection is not None:
+        rows, labels, keep = selection
+        if keep.numel() == 0:
+            return rois.new_zeros((0, 6)), keep
+        dets = gather_decode(rois, cls_score, rbbox_pred, 5, rows, labels, keep, target_means, target_stds, img_shape, sf)
+        out, idx = top_rows_by_score(dets, None, get('max_per_img'))
+        return out, labels[keep[idx]].long()
+    dets, rows, labels, _ = select_decode_candidates(rois, cls_score, rbbox_pred, 5, get('score_thr'), target_means, target_stds,
+                                                     img_shape, sf)
+    if dets.size(0) == 0:
+        return dets.new_zeros((0, 6)), torch.zeros(0, dtype=torch.long, device=rois.device)
+    keep, _ = nms_wrapper._run_nms(dets, _lib.KIND_RBOX, float(get('polygon_nms_iou_thr')), labels)
+    out, idx = top_rows_by_score(dets, keep, get('max_per_img'))
+    return out, labels[idx].long()

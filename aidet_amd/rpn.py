@@ -74,7 +74,7 @@ def _rpn_proposals_fused(cls_scores, bbox_preds, mlvl_anchors, img_shape, nms_pr
 
 
 def rpn_proposals(cls_scores, bbox_preds, mlvl_anchors, img_shape, cfg, target_means=(.0, .0, .0, .0),
-                  target_stds=(1.0, 1.0, 1.0, 1.0), use_sigmoid_cls=True, nms_op=None):
+                  target_stds=(1.0, 1.0, 1.0, 1.0), use_sigmoid_cls=True, nms_op=None, fused=None):
     """Proposals (n, 5) [x1, y1, x2, y2, score] of one image.
 
     Args:
@@ -84,11 +84,14 @@ def rpn_proposals(cls_scores, bbox_preds, mlvl_anchors, img_shape, cfg, target_m
         img_shape (tuple): (H, W, ...) of the network input: boxes are clamped into it.
         cfg: ``nms_pre``, ``nms_post``, ``max_num``, ``nms_thr``, ``min_bbox_size``,
             ``nms_across_levels`` (test_cfg.rpn of configs/dota/dota_v002...:118-124).
+        fused (bool, optional): the HIP selection kernels (``_rpn_proposals_fused``) where they apply (fp32 HIP
+            tensors, ``nms_pre`` / ``max_num`` <= 2048, no ``min_bbox_size``, no ``nms_across_levels``); default: the
+            module switch ``FUSED``.  False: the tensor-op path below (the specification).
     """
     nms_pre, nms_post, max_num = _cfg(cfg, 'nms_pre'), _cfg(cfg, 'nms_post'), _cfg(cfg, 'max_num')
     min_size = _cfg(cfg, 'min_bbox_size')
     num_levels = len(cls_scores)
-    if (nms_op is None and FUSED and min_size <= 0 and not _cfg(cfg, 'nms_across_levels') and 0 < nms_pre <= SEL_MAX
+    if (nms_op is None and (FUSED if fused is None else fused) and min_size <= 0 and not _cfg(cfg, 'nms_across_levels') and 0 < nms_pre <= SEL_MAX
             and 0 < max_num <= SEL_MAX and num_levels <= 8
             and all(t.is_cuda and t.dtype == torch.float32 for t in list(cls_scores) + list(bbox_preds) + list(mlvl_anchors))):
         return _rpn_proposals_fused(cls_scores, bbox_preds, mlvl_anchors, img_shape, nms_pre, nms_post, max_num,

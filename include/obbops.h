@@ -389,6 +389,34 @@ OBB_API int obb_rows_topk_f32(const float *rows_dev, int64_t num_rows, int cols,
                               int nms_post, int top, float *out_dev, int64_t *out_idx_dev, int64_t *count_dev,
                               void *stream);
 
+/* Detection heads: what sits between a head's FC outputs and its class-wise NMS.
+ * Replaces: BBoxHead.get_det_bboxes up to the NMS, mmdet/models/bbox_heads/bbox_head.py:139-166 (softmax :149,
+ *           delta2bbox of EVERY class of every RoI :152-153, rescale :160-166), the candidate lists of
+ *           multiclass_nms_with_index (mmdet/core/post_processing/rbbox_nms.py:22-43: per class
+ *           `scores[:, i] > score_thr`), RBBoxHead.get_det_rbboxes_parallel (rbbox_head.py:253-296: delta2thetaobb,
+ *           mmdet/core/rbbox/transforms.py:356-395) and thetaobb_nms_by_bbox_nms (rbbox_nms.py:64-119).
+ *
+ * obb_head_select_decode_f32: rois (n, 5) [b, x1, y1, x2, y2], cls_score (n, num_classes) logits (class 0 =
+ *   background), pred (n, pred_cols) deltas with pred_cols = dim * num_classes (class specific) or dim (class
+ *   agnostic); dim 4 = delta2bbox (+ clamp to (max_h, max_w) when max_h > 0), dim 5 = delta2thetaobb; scale_factor
+ *   > 0 divides the box (not the angle) by it (`rescale=True`).  Output: the (RoI, class) pairs with softmax
+ *   probability > score_thr, CLASS-MAJOR, RoIs ascending inside a class (the order of nonzero() on the (class, RoI)
+ *   mask): dets_dev (M, dim + 1) decoded box + score, rows_dev / labels_dev int32[M] (RoI index, 0-based foreground
+ *   class), counts_dev int64[num_classes]: candidates per foreground class, then M (device memory: no
+ *   synchronisation).  Capacity of the outputs: n * (num_classes - 1) rows.  n <= 2048, num_classes <= 17.
+ * obb_head_gather_decode_f32: the same decode + softmax score of ANOTHER head for the (rows[p], labels[p]) pairs
+ *   p = sel[j] (sel = NULL: p = j), j < K -> dets_dev (K, dim + 1). */
+OBB_API int obb_head_select_decode_f32(const float *rois_dev, const float *cls_score_dev, const float *pred_dev,
+                                       int64_t n, int num_classes, int pred_cols, int dim, float score_thr,
+                                       const float *means_host, const float *stds_host, float wh_ratio_clip,
+                                       int max_h, int max_w, float scale_factor, float *dets_dev,
+                                       int32_t *rows_dev, int32_t *labels_dev, int64_t *counts_dev, void *stream);
+OBB_API int obb_head_gather_decode_f32(const float *rois_dev, const float *cls_score_dev, const float *pred_dev,
+                                       int num_classes, int pred_cols, int dim, const int32_t *rows_dev,
+                                       const int32_t *labels_dev, const int64_t *sel_dev, int64_t K,
+                                       const float *means_host, const float *stds_host, float wh_ratio_clip,
+                                       int max_h, int max_w, float scale_factor, float *dets_dev, void *stream);
+
 /* ---------------------------------------------------------------------------
  * Test / tuning hooks.  NOT part of the drop-in surface (no reference counterpart): the
  * parity tests use them to force every size through every code path, and the experiment
@@ -402,7 +430,8 @@ OBB_API int obb_rows_topk_f32(const float *rows_dev, int64_t num_rows, int cols,
 #define OBB_TUNE_OVERLAPS_ROWS 4      /* rows per block of the pairwise-overlap kernel (8..64)       */
 #define OBB_TUNE_NMS_INLINE_MAX 5     /* largest n whose sorted scan clips its candidates in line     */
 #define OBB_TUNE_RROI_ORDER_MIN 6     /* fewest RoIs the workspace forward puts into Morton order      */
-#define OBB_TUNE_COUNT 7
+#define OBB_TUNE_RROI_GATHER_CHAN 7   /* channels per block of the gather backward (16 or 32)          */
+#define OBB_TUNE_COUNT 8
 OBB_API int obb_set_tuning(int knob, int64_t value);
 
 #ifdef __cplusplus

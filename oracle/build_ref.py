@@ -1,10 +1,15 @@
 """Build oracle/_ref/ from the reference's OWN sources (where they lie).
 
-Only meaningful in the build container, where /root/reference exists.  The GPU
-box uses the prebuilt oracle/_ref/*.so that travels with the snapshot.  No
+Only meaningful in the build container, where /root/reference exists.  No
 reference source is copied into this repository: the compiler reads
 /root/reference/mmdet/ops/nms/src/nms_cpu.cpp in place and writes only into
-oracle/_ref/ (git-ignored).
+oracle/_ref/ (git-ignored: the compiled module never enters the history).  The
+prebuilt oracle/_ref/nms_cpu.so travels with the working-tree snapshot to the GPU
+box like the product's own .so files; there it is the live checker of
+tests/test_round3_gpu.py::test_hip_nms_and_soft_nms_against_the_reference_build_live
+(the HIP `nms` / `soft_nms` against the reference's own compiled loops on fresh
+boxes) and of nothing else -- the product never loads it, and a snapshot without
+it only skips that test.
 
 Built:  oracle/_ref/nms_cpu.so   -- pybind module of the reference's CPU NMS
         (mmdet/ops/nms/src/nms_cpu.cpp:62-68 `nms`, :212-215 exports).

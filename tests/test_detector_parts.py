@@ -215,3 +215,151 @@ def test_detector_tile_forward(rotated):
     model.simple_test(img, meta)
     assert {'backbone_fpn', 'rpn_decode_nms', 'roi_align_bbox', 'bbox_decode_nms', 'roi_align_rbbox',
             'rbbox_decode_nms'} <= set(model.timers)
+
+
+@pytest.mark.gpu
+def test_detector_tile_ops_in_situ_against_the_oracle():
+    """BASELINE configs[3], op by op ON THE TENSORS OF THE REAL TILE: the 1024 x 1024 tile is run
+    through the conv trunk once, then every operator stage is fed the real intermediate tensors and compared with the
+    oracle / the tensor-op specification:
+      RPN      selection kernel vs torch.topk on the 196 k + 49 k + 12 k + 3 k + 768 anchors' logits; grouped 5-level
+               nms(0.7) on the decoded boxes: index-exact vs oracle.hbb_nms(groups=level)
+      RoIAlign V1 on the 2000 real proposals, level by level: bit-equal vs oracle.roi_align_forward
+      bbox     candidates of the fused kernel = the tensor-op candidates (softmax, > 0.05, delta2bbox); class-wise
+               nms(0.5): index-exact vs oracle.hbb_nms(groups=class); detections of fused and tensor-op path agree
+      rbbox    keep re-use rows = the tensor-op path's; true rotated NMS on the decoded theta-OBBs: index-exact vs
+               oracle.rnms(groups=class)
+    """
+    import ctypes
+
+    import oracle
+    from aidet_amd import _lib, nms_wrapper, post_processing as pp
+    from aidet_amd.bbox_transforms import bbox2roi, delta2bbox
+    from aidet_amd.models import build_detector, demo_inputs
+    from aidet_amd.rbbox_transforms import delta2thetaobb
+    from aidet_amd.rpn import rpn_proposals
+    dev = torch.device('cuda:0')
+    model = build_detector(dev)
+    img, meta = demo_inputs(dev)
+    cfg = model.test_cfg
+    with torch.no_grad():
+        x = model.extract_feat(img)
+        cls_scores, bbox_preds = model.rpn_head(x)
+        cls = [c[0].contiguous() for c in cls_scores]
+        reg = [r[0].contiguous() for r in bbox_preds]
+        anchors = model.rpn_head.anchors([tuple(c.shape[-2:]) for c in cls], dev)
+        # ---- RPN selection + decode
+        L = _lib.lib()
+        n = len(cls)
+        per_level = [min(2000, c.numel()) for c in cls]
+        N = sum(per_level)
+        dets = torch.empty((N, 5), device=dev)
+        levels = torch.empty(N, dtype=torch.int32, device=dev)
+        rows = ctypes.c_int64(0)
+        _lib.check(L.obb_rpn_select_decode_f32((ctypes.c_void_p * n)(*[c.data_ptr() for c in cls]), (ctypes.c_void_p * n)(*[r.data_ptr() for r in reg]),
+                                               (ctypes.c_void_p * n)(*[a.data_ptr() for a in anchors]), (ctypes.c_int * n)(*[c.size(1) for c in cls]),
+                                               (ctypes.c_int * n)(*[c.size(2) for c in cls]), n, 3, 1, 2000, (ctypes.c_float * 4)(0, 0, 0, 0),
+                                               (ctypes.c_float * 4)(1, 1, 1, 1), 16 / 1000.0, 1024, 1024, dets.data_ptr(), levels.data_ptr(),
+                                               ctypes.byref(rows), _lib.current_stream_handle(dev)))
+        assert rows.value == N == 2000 * 4 + 768
+        start = 0
+        for l, (c, r, a) in enumerate(zip(cls, reg, anchors)):
+            flat = c.permute(1, 2, 0).reshape(-1)
+            m = per_level[l]
+            got = dets[start:start + m]
+            if flat.numel() > m:
+                top_s, top_i = flat.sigmoid().topk(m)
+                assert torch.allclose(got[:, 4], top_s, atol=1e-6)                      # the same scores, descending
+                want = delta2bbox(a[top_i], r.permute(1, 2, 0).reshape(-1, 4)[top_i], (0, 0, 0, 0), (1, 1, 1, 1), (1024, 1024, 3))
+                if bool((top_s[:-1] > top_s[1:]).all()):     # (equal scores: torch.topk's order among them is unspecified)
+                    assert float((got[:, :4] - want).abs().max()) <= 2e-4
+            else:
+                want = delta2bbox(a, r.permute(1, 2, 0).reshape(-1, 4), (0, 0, 0, 0), (1, 1, 1, 1), (1024, 1024, 3))
+                assert float((got[:, :4] - want).abs().max()) <= 2e-4 and torch.allclose(got[:, 4], flat.sigmoid(), atol=1e-6)
+            assert bool((levels[start:start + m] == l).all())
+            start += m
+        # ---- grouped 5-level NMS on the real decoded boxes: index-exact
+        keep, _ = nms_wrapper._run_nms(dets, _lib.KIND_HBB, 0.7, levels)
+        ref = oracle.hbb_nms(dets.cpu().numpy(), 0.7, groups=levels.cpu().numpy())
+        assert np.array_equal(keep.cpu().numpy(), ref) and 2000 < len(ref) < N
+        # ---- proposals: fused == tensor-op path
+        prop = rpn_proposals(cls, reg, anchors, (1024, 1024, 3), cfg['rpn'], fused=True)
+        prop_ref = rpn_proposals(cls, reg, anchors, (1024, 1024, 3), cfg['rpn'], fused=False)
+        from test_round3_gpu import same_rows_up_to_score_ties
+        assert prop.shape == prop_ref.shape == (2000, 5) and same_rows_up_to_score_ties(prop, prop_ref)
+        rois = bbox2roi([prop])
+        # ---- RoIAlign V1 on the real RoIs, level by level, bit-equal with the oracle
+        ext = model.bbox_roi_extractor
+        feats = ext(x[:4], rois)
+        lv = ext.map_roi_levels(rois, 4).cpu().numpy()
+        rn = rois.cpu().numpy()
+        fn = feats.cpu().numpy()
+        assert len(set(lv.tolist())) >= 3
+        for l in range(4):
+            idx = np.nonzero(lv == l)[0][:160]          # (160 RoIs per level: a few seconds of oracle time)
+            if len(idx) == 0:
+                continue
+            want = oracle.roi_align_forward(x[l].cpu().numpy(), rn[idx], 7, 1.0 / (4 << l), 2, version=1)
+            assert np.array_equal(fn[idx], want), 'level %d' % l
+        # ---- bbox head on the real features
+        cls_score, bbox_pred = model.bbox_head(feats)
+        cd, crows, clab, counts = pp.select_decode_candidates(rois, cls_score, bbox_pred, 4, 0.05, (0, 0, 0, 0), model.bbox_target_stds, (1024, 1024, 3))
+        scores = torch.softmax(cls_score, 1)
+        boxes = delta2bbox(rois[:, 1:], bbox_pred, (0., 0., 0., 0.), model.bbox_target_stds, (1024, 1024, 3))
+        mask = (scores[:, 1:] > 0.05).t()
+        wl, wr = mask.nonzero(as_tuple=True)
+        edge = ((scores[:, 1:] - 0.05).abs() < 1e-6).any()
+        if not bool(edge):                              # (no probability within 1e-6 of the threshold: identical lists)
+            assert torch.equal(crows.long(), wr) and torch.equal(clab.long(), wl) and counts == mask.sum(1).tolist()
+            want = boxes.view(-1, 16, 4)[wr, wl + 1]
+            assert float((cd[:, :4] - want).abs().max()) <= 2e-4 and torch.allclose(cd[:, 4], scores[wr, wl + 1], atol=1e-6)
+        keep, _ = nms_wrapper._run_nms(cd, _lib.KIND_HBB, 0.5, clab)
+        ref = oracle.hbb_nms(cd.cpu().numpy(), 0.5, groups=clab.cpu().numpy())
+        assert np.array_equal(keep.cpu().numpy(), ref) and len(ref) > 100
+        db, dl, sel = pp.detect_horizontal_fused(rois, cls_score, bbox_pred, (1024, 1024, 3), 1.0, False, cfg['rcnn'], (0, 0, 0, 0), model.bbox_target_stds)
+        rb, rl, cls_inds, keep_inds = pp.multiclass_nms_with_index(boxes, scores, 0.05, cfg['rcnn']['nms'], 1000)
+
+        def same_detections(got, got_l, want, want_l, pool, pool_l):
+            # a random-init head saturates: hundreds of heavily overlapping detections share one score.  WHICH of them the
+            # cut at max_per_img keeps (and in what order) is the sort's business, and boxes decoded by the kernel differ
+            # from torch's by ~1e-4 px, enough to flip an IoU that sits on the threshold.  The NMS decisions themselves are
+            # checked index-exact against the oracle above; here: the same score sequence, and every returned (row, label)
+            # is one of the NMS survivors
+            assert got.shape == want.shape and torch.allclose(got[:, -1], want[:, -1], atol=1e-6)
+            assert bool((got[:-1, -1] >= got[1:, -1]).all()) or got.size(0) <= 1
+            have = {tuple(np.round(r, 2)) + (int(l),) for r, l in zip(pool.cpu().numpy(), pool_l.cpu().numpy())}
+            assert all(tuple(np.round(r, 2)) + (int(l),) in have for r, l in zip(got.cpu().numpy(), got_l.cpu().numpy()))
+        same_detections(db, dl, rb, rl, cd[keep], clab[keep])
+        # ---- rotated head: keep re-use and the true rotated NMS
+        rfeats = model.rbbox_roi_extractor(x[:4], rois)
+        rcls, rpred = model.rbbox_head(rfeats)
+        fr, fl = pp.detect_rotated_fused(rois, rcls, rpred, (1024, 1024, 3), 1.0, False, cfg['rbbox'], (0,) * 5, model.rbbox_target_stds, selection=sel)
+        wr_, wl_ = pp.get_det_rbboxes(rois, rcls, rpred, (1024, 1024, 3), 1.0, cfg=cfg['rbbox'], target_stds=model.rbbox_target_stds,
+                                      bbox_cls_inds=cls_inds, bbox_keep_inds=keep_inds, rotated_nms=False)
+        pool = pp.gather_decode(rois, rcls, rpred, 5, sel[0], sel[1], sel[2], (0,) * 5, model.rbbox_target_stds)
+        same_detections(fr, fl, wr_, wl_, pool, sel[1][sel[2]])
+        td, trows, tlab, _ = pp.select_decode_candidates(rois, rcls, rpred, 5, 0.05, (0,) * 5, model.rbbox_target_stds)
+        tb = delta2thetaobb(rois[:, 1:], rpred, (0,) * 5, model.rbbox_target_stds).view(-1, 16, 5)[trows.long(), tlab.long() + 1]
+        assert float((td[:, :5] - tb).abs().max()) <= 2e-4
+        rkeep, _ = nms_wrapper._run_nms(td, _lib.KIND_RBOX, 0.5, tlab)
+        ref = oracle.rnms(td.cpu().numpy(), 0.5, groups=tlab.cpu().numpy())
+        assert np.array_equal(rkeep.cpu().numpy(), ref) and len(ref) > 100
+        fr2, fl2 = pp.detect_rotated_fused(rois, rcls, rpred, (1024, 1024, 3), 1.0, False, cfg['rbbox'], (0,) * 5, model.rbbox_target_stds)
+        wr2, wl2 = pp.get_det_rbboxes(rois, rcls, rpred, (1024, 1024, 3), 1.0, cfg=cfg['rbbox'], target_stds=model.rbbox_target_stds, rotated_nms=True)
+        same_detections(fr2, fl2, wr2, wl2, td[rkeep], tlab[rkeep])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('rotated', [False, True])
+def test_detector_fused_stages_equal_the_tensor_op_stages(rotated):
+    """The whole tile through the fused selection kernels and through the tensor-op restatement: the same detections."""
+    from aidet_amd.models import build_detector, demo_inputs
+    dev = torch.device('cuda:0')
+    img, meta = demo_inputs(dev)
+    a = build_detector(dev, rotated_nms=rotated, fused=True).simple_test(img, meta)
+    b = build_detector(dev, rotated_nms=rotated, fused=False).simple_test(img, meta)
+    # (per class: the same number of detections with the same scores; rows of equal score may be other members of the tie)
+    for x, y in zip(a[0] + a[1], b[0] + b[1]):
+        assert x.shape == y.shape
+        if x.size:
+            assert np.allclose(np.sort(x[:, -1]), np.sort(y[:, -1]), atol=1e-6)

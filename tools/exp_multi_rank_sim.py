@@ -87,3 +87,56 @@ for world in (1, 2, 4, 8):
              ev['gather'].elapsed_time(ev['merge']) * 1e3, keep.numel()), flush=True)
     dota_merge._gather_padded, dota_merge._world = real_gp, real_world
     dota_merge.dist.all_reduce = real_all_reduce
+
+
+# ---- the ROUTED layout: rows travel only to the owner of their image (image % world) by all_to_all ----------------
+for world in (2, 4, 8):
+    inputs = [rank_inputs(r, world) for r in range(world)]
+    parts = []
+    for r in range(world):
+        d, l, p, s = inputs[r]
+        k = dota_merge.local_patch_nms(d, l, p, 0.5, C)
+        rows = dota_merge.patch_rows_to_image(d, l, p, patch_xy, patch_image, keep=k)
+        parts.append(torch.cat([rows, p[k].float()[:, None]], 1))
+    # what every source sends to rank 0, in source order (a source's rows sorted by destination keep their order)
+    to0 = [t[(t[:, 7].long() % world) == 0] for t in parts]
+    mat = torch.stack([torch.bincount(t[:, 7].long() % world, minlength=world) for t in parts]).to(dev)   # mat[src][dst]
+
+    def fake_allgather(out, inp, group=None):
+        out.copy_(mat.reshape(-1))            # (row 0 is what this rank just counted itself)
+
+    def fake_all_to_all(recv, send, out_splits, in_splits, group=None):
+        o = in_splits[0]
+        recv[:o] = send[:o]                   # this rank's own rows for itself
+        for src in range(1, world):           # the others' rows are "received"
+            recv[o:o + out_splits[src]] = to0[src]
+            o += out_splits[src]
+
+    real = (dota_merge.dist.all_gather_into_tensor, dota_merge.dist.all_to_all_single, dota_merge._world)
+    dota_merge.dist.all_gather_into_tensor, dota_merge.dist.all_to_all_single = fake_allgather, fake_all_to_all
+    dota_merge._world = lambda group: (world, 0)
+    d, l, p, s = inputs[0]
+    ev = {}
+
+    def mark(name):
+        e = torch.cuda.Event(enable_timing=True); e.record(); ev[name] = e
+
+    def step(timed=False):
+        if timed:
+            mark('start')
+        return dota_merge.tiled_inference_merge(d, l, p, s, patch_xy, patch_image, C, 0.5, 0.3, thrs, layout='routed',
+                                                mark=mark if timed else None, gather_result=False)
+    for _ in range(3):
+        kept, keep, mine = step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 10 * 1e3
+    step(True); torch.cuda.synchronize()
+    print('ranks %d (routed): rank 0 computes %.3f ms per pass  [local nms %.0f us | route + restore order %.0f us | merge %.0f us]  '
+          'rows merged here %d, kept here %d' % (world, ms, ev['start'].elapsed_time(ev['local']) * 1e3,
+                                                 ev['local'].elapsed_time(ev['gather']) * 1e3, ev['gather'].elapsed_time(ev['merge']) * 1e3,
+                                                 mine.size(0), keep.numel()), flush=True)
+    dota_merge.dist.all_gather_into_tensor, dota_merge.dist.all_to_all_single, dota_merge._world = real
