@@ -73,6 +73,39 @@ at::Tensor nms_impl(const at::Tensor &dets_in, int kind, double thr, const c10::
   return keep.narrow(0, 0, info[0]);
 }
 
+// The wrapper's hot path (aidet_amd.nms_wrapper._run_nms): ONE attempt of obb_nms_ex_f32 on tensors that already are
+// what the C ABI takes (fp32 contiguous dets, int32 groups, fp32 per-box thresholds), everything else -- allocation of
+// the keep list and of the workspace, device guard, stream lookup -- on this side of the interpreter.  Returns
+// (keep[:K], rc, info[4]); rc == OBB_EWORKSPACE leaves the retry with a larger `capacity` (info[3]) to the caller.
+std::tuple<at::Tensor, int64_t, std::vector<int64_t>> nms_ex(const at::Tensor &dets, int64_t kind, double thr,
+                                                             const c10::optional<at::Tensor> &groups,
+                                                             const c10::optional<at::Tensor> &thrs, int64_t flags,
+                                                             int64_t capacity) {
+  TORCH_CHECK(dets.is_cuda() && dets.scalar_type() == at::kFloat && dets.is_contiguous() && dets.dim() == 2,
+              "nms_ex takes a contiguous fp32 HIP tensor");
+  const int64_t n = dets.size(0);
+  HIPGuardMasqueradingAsCUDA guard(dets.device());
+  const int32_t *gp = nullptr;
+  const float *tp = nullptr;
+  if (groups.has_value()) {
+    TORCH_CHECK(groups->is_cuda() && groups->scalar_type() == at::kInt && groups->is_contiguous() && groups->numel() == n, "groups: int32[n]");
+    gp = groups->data_ptr<int32_t>();
+  }
+  if (thrs.has_value()) {
+    TORCH_CHECK(thrs->is_cuda() && thrs->scalar_type() == at::kFloat && thrs->is_contiguous() && thrs->numel() == n, "thrs: fp32[n]");
+    tp = thrs->data_ptr<float>();
+  }
+  at::Tensor keep = at::empty({n}, dets.options().dtype(at::kLong));
+  std::vector<int64_t> info(4, 0);
+  const size_t bytes = obb_nms_workspace_bytes(n, (int)kind, capacity);
+  TORCH_CHECK(bytes > 0, "obb_nms_workspace_bytes: ", obb_last_error());
+  at::Tensor ws = at::empty({(int64_t)bytes}, dets.options().dtype(at::kByte));
+  const int rc = obb_nms_ex_f32(dets.data_ptr<float>(), n, (int)kind, (float)thr, gp, tp, (int)flags, keep.data_ptr<int64_t>(),
+                                info.data(), ws.data_ptr(), bytes, current_stream(dets));
+  if (rc != OBB_OK && rc != OBB_EWORKSPACE) check_rc(rc, "obb_nms_ex_f32");
+  return std::make_tuple(keep.narrow(0, 0, rc == OBB_OK ? info[0] : 0), (int64_t)rc, info);
+}
+
 at::Tensor rnms(const at::Tensor &dets, double thr) { return nms_impl(dets, OBB_KIND_RBOX, thr, c10::nullopt, c10::nullopt); }
 at::Tensor poly_nms(const at::Tensor &dets, double thr) { return nms_impl(dets, OBB_KIND_POLY, thr, c10::nullopt, c10::nullopt); }
 // horizontal boxes (n, 5) x1, y1, x2, y2, score: the signature of nms_cuda.nms (nms_cuda.cpp:8)
@@ -188,6 +221,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.doc() = "ATen binding of libobbops (rotated IoU / NMS / RoI-Align on gfx950)";
   m.def("version", []() { return obb_version(); });
   m.def("build_info", []() { return std::string(obb_build_info()); });
+  m.def("nms_ex", &nms_ex, "one attempt of obb_nms_ex_f32: (keep, rc, info)", py::arg("dets"), py::arg("kind"), py::arg("threshold"),
+        py::arg("groups") = py::none(), py::arg("thrs") = py::none(), py::arg("flags") = 0, py::arg("capacity") = 0);
   m.def("rnms", &rnms, "rotated NMS: keep indices (int64, ascending)", py::arg("dets"), py::arg("threshold"));
   m.def("poly_nms", &poly_nms, "polygon NMS: keep indices", py::arg("dets"), py::arg("threshold"));
   m.def("nms", &hbb_nms, "horizontal-box NMS (the reference's +1 convention): keep indices", py::arg("dets"), py::arg("threshold"));

@@ -70,6 +70,9 @@ def roi_backward(grad_out, rois, feature_size, roi_kind, out_h, out_w, spatial_s
     return grad
 
 
+ORDER_MIN_ROIS = 1024    # = kOrderMinK of obb_rroi.hip: fewer RoIs are not worth the ordering launch
+
+
 def roi_forward(feats, rois, levels, out_h, out_w, scales, sample_num, roi_kind, min_size):
     """The forward of every RoI-Align flavour: ``obb_roi_align_forward_ws_f32`` -- one launch over the level(s) after
     one small launch that orders the RoIs along a Morton curve (L2 locality; workspace from torch's caching allocator).
@@ -87,12 +90,23 @@ def roi_forward(feats, rois, levels, out_h, out_w, scales, sample_num, roi_kind,
     hs = (ctypes.c_int * n)(*[f.shape[2] for f in feats])
     wd = (ctypes.c_int * n)(*[f.shape[3] for f in feats])
     sc = (ctypes.c_float * n)(*[float(x) for x in scales])
-    ws = torch.empty(int(L.obb_roi_forward_workspace_bytes(K)), dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev):
+    # (the library orders the RoIs from ORDER_MIN_ROIS on; below, no workspace is needed -- and this function is per-call
+    # overhead of a 40 us kernel: no allocation, no context manager unless the device has to be switched)
+    ws_ptr, ws_bytes = None, 0
+    if K >= ORDER_MIN_ROIS:
+        ws = torch.empty(8 * K + 256, dtype=torch.uint8, device=dev)
+        ws_ptr, ws_bytes = ws.data_ptr(), ws.numel()
+    cur = torch.cuda.current_device()
+    if cur != dev.index:
+        torch.cuda.set_device(dev)
+    try:
         rc = L.obb_roi_align_forward_ws_f32(ptrs, hs, wd, sc, n, B, C, rois.data_ptr(),
                                             None if levels is None else levels.data_ptr(), K, out_h, out_w,
                                             int(sample_num), int(roi_kind), float(min_size), out.data_ptr(),
-                                            ws.data_ptr(), ws.numel(), _lib.current_stream_handle(dev))
+                                            ws_ptr, ws_bytes, _lib.current_stream_handle(dev))
+    finally:
+        if cur != dev.index:
+            torch.cuda.set_device(cur)
     _lib.check(rc)
     return out
 

@@ -494,7 +494,17 @@ def roofline_kernels(dev):
     foot = rroi_footprint_pixels(rn, 256, 256, 0.25)
     K, C, H, W = 512, 256, 256, 256
     alg = int(4 * K * C * 49 + 4 * C * min(foot, H * W) + 24 * K)
-    ms = _time_gpu(lambda: layer(feat, rois), 50)
+    # (timed through the C ABI, like the backward below: the Python layer's per-call overhead is as long as this kernel)
+    from aidet_amd import _lib
+    L = _lib.lib()
+    st = _lib.current_stream_handle(dev)
+    out_f = torch.empty((512, 256, 7, 7), device=dev)
+
+    def fwd():
+        _lib.check(L.obb_rroi_align_forward_f32(feat.data_ptr(), 1, 256, 256, 256, rois.data_ptr(), 512, 7, 7, 0.25, 2, 1.0,
+                                                out_f.data_ptr(), st))
+    ms = _time_gpu(fwd, 50)
+    assert torch.equal(out_f, layer(feat, rois))
     pc = sum_counters(['rroi_forward_kernel', 'rroi_order_kernel'], 'rroi_fwd') or {}
     res.append({'tag': 'rroi_fwd', 'kernel': 'rroi_forward_kernel', 'workload': 'RRoIAlign 512 RoIs x 256 ch x 7x7, 256^2 map, 2x2 samples (configs[2])',
                 'bound': 'hbm', 'algorithmic_bytes': alg, 'kernel_ms': round(ms, 4),
@@ -505,11 +515,8 @@ def roofline_kernels(dev):
     # backward, the formulation the autograd Function runs at this size (and the one the `rroi_bwd` passes
     # profiled): plan + gather (+ the atomics kernel for RoIs the plan cannot hold).  Algorithmic bytes of its
     # own: the gradient of the output is read once (25.7 MB), every touched map element written once.
-    from aidet_amd import _lib
-    L = _lib.lib()
     gout = torch.randn(512, 256, 7, 7, device=dev)
     gfeat = torch.empty_like(feat)
-    st = _lib.current_stream_handle(dev)
     ws = torch.empty(L.obb_roi_backward_workspace_bytes(512), dtype=torch.uint8, device=dev)
     alg_b = int(4 * K * C * 49 + 4 * C * min(foot, H * W) + 24 * K)
 

@@ -25,18 +25,26 @@ def sel():
     _lib.check(L.obb_rpn_select_decode_f32(*args, n, 3, 1, 2000, (ctypes.c_float * 4)(0, 0, 0, 0), (ctypes.c_float * 4)(1, 1, 1, 1), 16 / 1000.0, 1024, 1024,
                                            dets.data_ptr(), lv.data_ptr(), ctypes.byref(rows), st))
 sel()
-keep, _ = nms_wrapper._run_nms(dets, _lib.KIND_HBB, 0.7, lv)
+keep, ninfo = nms_wrapper._run_nms(dets, _lib.KIND_HBB, 0.7, lv)
 K = keep.numel(); base = [0]
 for m in per: base.append(base[-1] + m)
 out = torch.empty((2000, 5), device=dev); cnt = torch.empty(1, dtype=torch.int64, device=dev)
 def topk():
     _lib.check(L.obb_rows_topk_f32(dets.data_ptr(), N, 5, 4, keep.data_ptr(), K, (ctypes.c_int * (n + 1))(*base), n, 2000, 2000, out.data_ptr(), None, cnt.data_ptr(), st))
 res = {'select_decode_ms': round(bench._time_gpu(sel, 20), 4), 'nms_ms': round(bench._time_gpu(lambda: nms_wrapper._run_nms(dets, _lib.KIND_HBB, 0.7, lv), 20), 4),
-       'rows_topk_ms': round(bench._time_gpu(topk, 20), 4), 'kept': int(K),
+       'rows_topk_ms': round(bench._time_gpu(topk, 20), 4), 'kept': int(K), 'nms_edges_rounds_candidates': [int(v) for v in ninfo],
        'rpn_fused_ms': round(bench._time_gpu(lambda: rpn_proposals(cls, reg, anchors, (1024, 1024, 3), model.test_cfg['rpn'], fused=True), 20), 4),
        'rpn_tensor_ops_ms': round(bench._time_gpu(lambda: rpn_proposals(cls, reg, anchors, (1024, 1024, 3), model.test_cfg['rpn'], fused=False), 20), 4)}
 for name, dm in (('nms_sorted_route_ms', 0), ('nms_direct_route_ms', 65536)):
     _lib.set_tuning(_lib.TUNE_NMS_DIRECT_MAX, dm)
     res[name] = round(bench._time_gpu(lambda: nms_wrapper._run_nms(dets, _lib.KIND_HBB, 0.7, lv), 20), 4)
 _lib.set_tuning(_lib.TUNE_NMS_DIRECT_MAX, -1)
+L.obb_nms_profile_enable(2)
+pbuf = (ctypes.c_float * 7)()
+nms_wrapper._ext = None          # (the phase profile is read through the ctypes path's thread)
+for _ in range(3):
+    nms_wrapper._run_nms(dets, _lib.KIND_HBB, 0.7, lv)
+L.obb_nms_profile_last(pbuf)
+res['nms_phase_ms'] = [round(float(v), 4) for v in pbuf]
+L.obb_nms_profile_enable(0)
 print(json.dumps(res))

@@ -7,11 +7,11 @@ import json
 import os
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r02'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r03'
 src = 'gpurun_out/collect'
 dst = 'profiles'
 WORKLOAD = {'nms': 'nms_100000_20000', 'iou_sparse': 'iou_sparse', 'iou_dense': 'iou_dense',
-            'rroi_fwd': 'rroi_fwd', 'rroi_bwd': 'rroi_bwd', 'roi_fwd': 'roi_fwd'}
+            'rroi_fwd': 'rroi_fwd', 'rroi_bwd': 'rroi_bwd', 'rroi_bwd_scatter': 'rroi_bwd_scatter', 'roi_fwd': 'roi_fwd'}
 OURS = ('nms_', 'overlaps_', 'rroi_', 'soft_nms', 'rbox_to_poly')
 
 
@@ -114,13 +114,20 @@ for name, alg in (('iou_sparse', 20 * 2 * 16384 + 4 * 16384 ** 2), ('iou_dense',
     if ks:
         print('%s: algorithmic %.1f MB / %.1f us = %.0f GB/s = %.3f of 8 TB/s' % (
             name, alg / 1e6, ks[0]['avg_us'], alg / ks[0]['avg_us'] / 1e3, alg / ks[0]['avg_us'] / 1e3 / 8000))
+for name in ('multi_rank_sim.txt', 'roi_backward.txt', 'detect.json'):
+    if os.path.exists(os.path.join(src, name)):
+        with open(os.path.join(src, name)) as f, open('%s/%s_%s' % (dst, tag, name), 'w') as g:
+            g.write(''.join(l for l in f if 'amdgpu.ids' not in l))
+if os.path.isdir(src + '/trace_cfg4') and find(src + '/trace_cfg4', 'kernel_stats.csv'):
+    copy_stats(src + '/trace_cfg4', '%s/%s_kernel_stats_cfg4.csv' % (dst, tag))
 rk = bench.get('roofline_kernels', {}).get('kernels', [])
 for r in rk:
     if r['kernel'].startswith('rroi_'):
-        ks = [v for v in kern.values() if v['kernel'] == r['kernel'] and v['workload'] in ('rroi_fwd', 'rroi_bwd')]
-        k = ks[0] if ks else None
-        if k:
-            print('%s: algorithmic %.1f MB / %.1f us (rocprof) = %.3f of 8 TB/s; counter/algorithmic = %.2f' % (
-                r['kernel'], r['algorithmic_bytes'] / 1e6, k['avg_us'], r['algorithmic_bytes'] / k['avg_us'] / 1e3 / 8000,
-                hbm(k) / r['algorithmic_bytes']))
+        names = r['kernel'].split('+')
+        ks = [v for v in kern.values() if v['kernel'] in names and v['workload'] == r.get('tag')]
+        if ks:
+            us, tb = sum(k['avg_us'] for k in ks), sum(hbm(k) for k in ks)
+            print('%s [%s]: algorithmic %.1f MB / %.1f us (rocprof, %d kernels) = %.3f of 8 TB/s; counter/algorithmic = %.2f' % (
+                r['kernel'], r.get('tag'), r['algorithmic_bytes'] / 1e6, us, len(ks), r['algorithmic_bytes'] / us / 1e3 / 8000,
+                tb / r['algorithmic_bytes']))
 print('bench value', bench['value'], 'ms/step', bench['ms_per_step'], 'roofline', json.dumps(bench['roofline'])[:300])
