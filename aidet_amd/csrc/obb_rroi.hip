@@ -614,10 +614,13 @@ constexpr int kBwdMaxPix = 2047;                       // footprint pixels of th
 constexpr int kBwdStageFloats = 4096;                  // sums tile (16 KiB): 16 channels x 255 pixels, 8 x 511, 4 x 1023
 constexpr int kBwdMaxEntries = 4 * kMaxTabSamples;     // taps of a RoI (4 per sample)
 
+// plan record of the gather formulation (rroi_plan_kernel); state 1: planned, 2: left to the atomics kernel, 0: nothing sampled
+struct alignas(16) RoiPlan { int b, x0, y0, w, h, state, nb, pad; };
+
 __global__ __launch_bounds__(256) void rroi_backward_kernel(
     const float *__restrict__ gout, int B, int C, int H, int W, const float *__restrict__ rois,
     int ph, int pw, float scale, int sample_num, float min_size, int chan_per_block,
-    int K, int chunks, int roi_kind, float *__restrict__ gfeat, int only_unstaged) {
+    int K, int chunks, int roi_kind, float *__restrict__ gfeat, int only_unstaged, const RoiPlan *__restrict__ plan) {
   __shared__ __attribute__((aligned(16))) float tile[kBwdStageFloats];   // first the sample table, then sums [channel][pixel]
   __shared__ int2 entry[kBwdMaxEntries];               // (bin, weight bits), grouped by pixel
   __shared__ int pstart[kBwdMaxPix + 1];               // CSR offsets; during the build: counts
@@ -628,6 +631,7 @@ __global__ __launch_bounds__(256) void rroi_backward_kernel(
   int64_t k;
   int chunk;
   if (!block_to_work(K, chunks, k, chunk)) return;
+  if (plan && plan[k].state != 2) return;   // (after the gather kernel: only what the plan left over)
   RoiFrame f;
   make_frame(rois + k * roi_stride(roi_kind), roi_kind, scale, ph, pw, sample_num, min_size, f);
   const long long spb64 = (long long)f.gh * f.gw;
@@ -772,8 +776,6 @@ constexpr int kGChanDefault = 16;                   // channels per gather block
 constexpr int kGList = 2048;                        // RoIs of one tile held in LDS at a time
 constexpr int kPlanPix = kBwdMaxPix + 2;            // CSR offsets per RoI (16 bit)
 
-struct alignas(16) RoiPlan { int b, x0, y0, w, h, state, nb, pad; };   // state 1: planned (else nothing here)
-
 template <bool UNUSED = false>
 __device__ __forceinline__ bool plan_holds(int fsz, int nb, int nsamp) {
   return fsz <= kBwdMaxPix && (fsz | 1) <= kBwdStageFloats && nb <= kMaxBins && nsamp <= kMaxTabSamples;
@@ -801,6 +803,7 @@ __global__ __launch_bounds__(256) void rroi_plan_kernel(
   const int spb = (int)(spb64 > kMaxTabSamples ? kMaxTabSamples + 1 : (spb64 > 0 ? spb64 : 1));
   const int nsamp = nb * spb;
   if (!live || !plan_holds(fsz, nb, nsamp)) {        // nothing sampled, or left to the atomics kernel
+    pl.state = live ? 2 : 0;
     if (tid == 0) plan[k] = pl;
     return;
   }
@@ -928,16 +931,23 @@ __global__ __launch_bounds__(256) void rroi_plan_kernel(
   if (tid == 0) { pl.x0 = fp.x0; pl.y0 = fp.y0; pl.w = fp.w; pl.h = fp.h; pl.state = 1; plan[k] = pl; }
 }
 
-// (Round 3: a variant that takes FOUR RoIs per step -- their plan records, CSR bounds, gradients and first entries
-// requested together, two barriers per step instead of one per RoI -- was built and measured: 155 -> 185 us at
-// configs[2], 0.70 -> 0.84 ms at the config-4 shape (99 VGPRs, five workgroups per CU instead of eight; the kernel is
-// bound by resident workgroups x the length of the longest tile's chain, and the chain did not shorten).  Dropped.)
-template <int CH>
-__global__ __launch_bounds__(256) void rroi_gather_kernel(
+// Every global request of a RoI is issued one RoI ahead: while RoI i is summed, the plan record of RoI i+2, the
+// list bounds and the gradients of RoI i+1 (in registers) are in flight, and the first four entries of RoI i+1 are
+// requested as soon as its bounds are there -- a RoI costs one barrier and its sums, no exposed round trip.
+// Every one of these loads is UNCONDITIONAL (clamped to an address that is always valid, the predicate applied where
+// the value is used): a load under a branch is waited for at the end of the branch, which serialises the requests
+// (round 2's kernel had four such round trips per RoI: 156 us at configs[2]; this one 98 us -- the rest of the step
+// came from the compile-time bin count, the scalar RoI index and fused multiply-adds: 2434 -> ~1000 VALU per wave).
+// (Also measured and dropped in round 3: FOUR RoIs per step, two barriers per step: 155 -> 185 us, 99 VGPRs.)
+// NB: bins per RoI when known at compile time (49: the LDS reads of the sums take immediate offsets), 0: from the plan.
+template <int CH, int NB>
+__global__ __launch_bounds__(256) void rroi_gather_pipe_kernel(
     const float *__restrict__ gout, int C, int H, int W, int K, const RoiPlan *__restrict__ plan,
     const unsigned short *__restrict__ rstart, const int2 *__restrict__ rentry, float *__restrict__ gfeat) {
+  constexpr int G = CH * kMaxBins / 256;            // gradient words a thread stages per RoI
+  static_assert(G * 256 == CH * kMaxBins, "gradient staging");
   __shared__ int list[kGList];
-  __shared__ float gtiles[2][CH * (kMaxBins + 1)];   // double buffered: one barrier per RoI
+  __shared__ float gtiles[2][CH * (kMaxBins + 1)];
   __shared__ int wcnt[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tiles_x = (W + kGTile - 1) / kGTile;
@@ -949,17 +959,28 @@ __global__ __launch_bounds__(256) void rroi_gather_kernel(
   float acc[CH];
 #pragma unroll
   for (int c = 0; c < CH; ++c) acc[c] = 0.0f;
+  struct Foot { int x0, y0, w, h, nb; };
+  auto foot = [&](int r) { const RoiPlan p = plan[r]; return Foot{p.x0, p.y0, p.w, p.h, NB ? NB : p.nb}; };   // (r is wave-uniform: scalar loads)
+  auto pick = [&](int i) { return __builtin_amdgcn_readfirstlane(list[i]); };
+  // list bounds of this thread's pixel (pixel 0 of the footprint when the pixel is outside: masked by `mine` later)
+  auto mine_of = [&](const Foot &f) {
+    const int px = x - f.x0, py = y - f.y0;
+    return inmap && px >= 0 && px < f.w && py >= 0 && py < f.h;
+  };
+  auto bounds = [&](int r, const Foot &f, bool mine, int &e0, int &e1) {
+    const int pix = mine ? (y - f.y0) * f.w + (x - f.x0) : 0;
+    const unsigned short *rs = rstart + (int64_t)r * kPlanPix + pix;
+    e0 = rs[0]; e1 = rs[1];
+  };
   for (int base = 0; base < K; base += kGList) {
-    // ---- the RoIs of this batch of plans whose footprint meets the tile, in RoI order
     int n = 0;   // block-uniform
     const int lim = min(K, base + kGList);
+    RoiPlan pq = plan[min(base + tid, lim - 1)];
     for (int r0 = base; r0 < lim; r0 += 256) {
       const int r = r0 + tid;
-      bool hit = false;
-      if (r < lim) {
-        const RoiPlan p = plan[r];
-        hit = p.state == 1 && p.b == b && p.x0 < tx0 + kGTile && p.x0 + p.w > tx0 && p.y0 < ty0 + kGTile && p.y0 + p.h > ty0;
-      }
+      const RoiPlan p = pq;
+      pq = plan[min(r + 256, lim - 1)];          // (the next round's records travel during this round's barriers)
+      const bool hit = r < lim && p.state == 1 && p.b == b && p.x0 < tx0 + kGTile && p.x0 + p.w > tx0 && p.y0 < ty0 + kGTile && p.y0 + p.h > ty0;
       const uint64_t mk = __ballot(hit);
       if (lane == 0) wcnt[wave] = __popcll(mk);
       __syncthreads();
@@ -970,47 +991,100 @@ __global__ __launch_bounds__(256) void rroi_gather_kernel(
       n += tot;
       __syncthreads();
     }
-    // ---- their contributions to this thread's pixel
-    RoiPlan pn = n > 0 ? plan[list[0]] : RoiPlan{};
+    if (n == 0) continue;
+    // ---- prologue: everything of RoI 0, the plan record of RoI 1
+    int r_cur = pick(0), r_nxt = pick(min(1, n - 1));
+    Foot f_cur = foot(r_cur), f_nxt = foot(r_nxt);
+    bool m_cur = mine_of(f_cur);
+    int e0_cur, e1_cur;
+    bounds(r_cur, f_cur, m_cur, e0_cur, e1_cur);
+    float g_cur[G];
+    {
+      const float *gsrc = gout + ((int64_t)r_cur * C + c0) * f_cur.nb;
+      const int last = cc * f_cur.nb - 1;
+#pragma unroll
+      for (int u = 0; u < G; ++u) g_cur[u] = gsrc[min(tid + 256 * u, last)];
+    }
+    int2 en_cur[4];
+    {
+      const int2 *re = rentry + (int64_t)r_cur * kBwdMaxEntries;
+      const int first = m_cur ? e0_cur : 0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) en_cur[u] = re[min(first + u, kBwdMaxEntries - 1)];
+    }
     for (int i = 0; i < n; ++i) {
-      const int r = list[i];
-      const RoiPlan p = pn;
-      if (i + 1 < n) pn = plan[list[i + 1]];            // (in flight while this RoI is summed)
       float *gtile = gtiles[i & 1];
-      const int nb = p.nb, nbp = nb | 1;
-      const float *gsrc = gout + ((int64_t)r * C + c0) * nb;    // contiguous (channel, bin) run
-      const int gtot = cc * nb;
-      // this pixel's list bounds are requested together with the gradients (one memory round trip)
-      const int px = x - p.x0, py = y - p.y0;
-      const bool mine = inmap && px >= 0 && px < p.w && py >= 0 && py < p.h;
-      int e0 = 0, e1 = 0;
-      if (mine) {
-        const unsigned short *rs = rstart + (int64_t)r * kPlanPix + (py * p.w + px);
-        e0 = rs[0]; e1 = rs[1];
-      }
-      for (int q = tid; q < gtot; q += 256) {
-        const int c = q / nb, bin = q - c * nb;
-        gtile[c * nbp + bin] = gsrc[q];
-      }
-      __syncthreads();
-      const int2 *re = rentry + (int64_t)r * kBwdMaxEntries;
-      for (int e = e0; e < e1; e += 4) {      // four entries per round trip (lists average ~4)
-        int2 en[4];
+      const int nb = f_cur.nb, nbp = nb | 1;
+      // stage this RoI's gradients (requested one RoI ago)
+      {
+        const int gtot = cc * nb;
+        if (nb & 1) {            // pitch == bins: a straight copy
 #pragma unroll
-        for (int u = 0; u < 4; ++u) en[u] = re[min(e + u, e1 - 1)];
+          for (int u = 0; u < G; ++u) {
+            const int q = tid + 256 * u;
+            if (q < gtot) gtile[q] = g_cur[u];
+          }
+        } else {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          if (e + u < e1) {
-            const float wgt = __int_as_float(en[u].y);
-            const float *g = gtile + en[u].x;
-#pragma unroll
-            for (int c = 0; c < CH; ++c) acc[c] = acc[c] + g[c * nbp] * wgt;   // (channels >= cc: stale LDS, never stored)
+          for (int u = 0; u < G; ++u) {
+            const int q = tid + 256 * u;
+            if (q < gtot) { const int c = q / nb, bin = q - c * nb; gtile[c * nbp + bin] = g_cur[u]; }
           }
         }
       }
-      // (no barrier here: the next RoI stages into the OTHER buffer, and nobody passes its barrier before
-      // every thread is done with this one)
+      // requests of the next RoI (bounds + gradients) and of the one after (plan record); past the end of the
+      // list they repeat the last RoI's and are never used
+      const bool m_nxt = mine_of(f_nxt);
+      int e0_nxt, e1_nxt;
+      bounds(r_nxt, f_nxt, m_nxt, e0_nxt, e1_nxt);
+      {
+        const float *gsrc = gout + ((int64_t)r_nxt * C + c0) * f_nxt.nb;
+        const int last = cc * f_nxt.nb - 1;
+#pragma unroll
+        for (int u = 0; u < G; ++u) g_cur[u] = gsrc[min(tid + 256 * u, last)];
+      }
+      const int r_nn = pick(min(i + 2, n - 1));
+      const Foot f_nn = foot(r_nn);
+      __syncthreads();
+      // sums of this RoI: the first four entries are already here
+      const int e0 = m_cur ? e0_cur : 0, e1 = m_cur ? e1_cur : 0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (e0 + u < e1) {
+          const float wgt = __int_as_float(en_cur[u].y);
+          const float *g = gtile + en_cur[u].x;
+#pragma unroll
+          for (int c = 0; c < CH; ++c) acc[c] = fmaf(g[c * nbp], wgt, acc[c]);
+        }
+      }
+      if (e0 + 4 < e1) {
+        const int2 *re = rentry + (int64_t)r_cur * kBwdMaxEntries;
+        for (int e = e0 + 4; e < e1; e += 4) {
+          int2 en[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) en[u] = re[min(e + u, e1 - 1)];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (e + u < e1) {
+              const float wgt = __int_as_float(en[u].y);
+              const float *g = gtile + en[u].x;
+#pragma unroll
+              for (int c = 0; c < CH; ++c) acc[c] = fmaf(g[c * nbp], wgt, acc[c]);
+            }
+          }
+        }
+      }
+      // the next RoI's first entries (its bounds were requested before the barrier)
+      {
+        const int2 *rn = rentry + (int64_t)r_nxt * kBwdMaxEntries;
+        const int first = m_nxt ? e0_nxt : 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) en_cur[u] = rn[min(first + u, kBwdMaxEntries - 1)];
+      }
+      r_cur = r_nxt; f_cur = f_nxt; m_cur = m_nxt; e0_cur = e0_nxt; e1_cur = e1_nxt;
+      r_nxt = r_nn; f_nxt = f_nn;
     }
+    __syncthreads();   // (the next batch of plans rewrites the list)
   }
   if (inmap) {
     float *dst = gfeat + (((int64_t)b * C + c0) * H + y) * (int64_t)W + x;
@@ -1174,7 +1248,7 @@ static int rroi_backward_launch(const char *who, const float *grad_out_dev, int 
   rc = rroi_geometry(who, C, true, K, cpb, chunks, nblk);
   if (rc != OBB_OK) return rc;
   hipLaunchKernelGGL(rroi_backward_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
-                     grad_out_dev, B, C, H, W, rois_dev, ph, pw, spatial_scale, sample_num, min_size, cpb, (int)K, (int)chunks, roi_kind, grad_feat_dev, 0);
+                     grad_out_dev, B, C, H, W, rois_dev, ph, pw, spatial_scale, sample_num, min_size, cpb, (int)K, (int)chunks, roi_kind, grad_feat_dev, 0, nullptr);
   OBB_LAUNCH_CHECK();
   return OBB_OK;
 }
@@ -1273,15 +1347,20 @@ extern "C" int obb_roi_backward_gather_f32(const float *grad_out_dev, int B, int
                      sample_num, min_size, roi_kind, plan, rstart, rentry);
   OBB_LAUNCH_CHECK();
   const unsigned tiles = (unsigned)(((W + kGTile - 1) / kGTile) * ((H + kGTile - 1) / kGTile));
-  const int gch = (int)tuning(OBB_TUNE_RROI_GATHER_CHAN, kGChanDefault) >= 32 ? 32 : 16;
+  const int gt = (int)tuning(OBB_TUNE_RROI_GATHER_CHAN, kGChanDefault);
+  const int gch = gt >= 32 ? 32 : 16;
   const unsigned chunks = (unsigned)((C + gch - 1) / gch);
   if (chunks > 65535u || B > 65535) return set_err(OBB_EINVAL, "%s: too many channels / images", who);
-  if (gch == 32)
-    hipLaunchKernelGGL(rroi_gather_kernel<32>, dim3(tiles, chunks, (unsigned)B), dim3(256), 0, st, grad_out_dev, C, H, W, (int)K,
-                       plan, rstart, rentry, grad_feat_dev);
-  else
-    hipLaunchKernelGGL(rroi_gather_kernel<16>, dim3(tiles, chunks, (unsigned)B), dim3(256), 0, st, grad_out_dev, C, H, W, (int)K,
-                       plan, rstart, rentry, grad_feat_dev);
+  const dim3 ggrid(tiles, chunks, (unsigned)B);
+#define OBB_GATHER(CH, NB)                                                                                              \
+  hipLaunchKernelGGL((rroi_gather_pipe_kernel<CH, NB>), ggrid, dim3(256), 0, st, grad_out_dev, C, H, W, (int)K, plan, \
+                     rstart, rentry, grad_feat_dev)
+  if (gch == 32) {
+    if (ph * pw == 49) OBB_GATHER(32, 49); else OBB_GATHER(32, 0);
+  } else {
+    if (ph * pw == 49) OBB_GATHER(16, 49); else OBB_GATHER(16, 0);
+  }
+#undef OBB_GATHER
   OBB_LAUNCH_CHECK();
   // the RoIs the plan could not hold are ADDED by the atomics kernel: its usual geometry (a large RoI's
   // channels spread over 16 blocks), blocks of planned RoIs leave right after the footprint test
@@ -1291,7 +1370,7 @@ extern "C" int obb_roi_backward_gather_f32(const float *grad_out_dev, int B, int
   rc = rroi_geometry(who, C, true, K, cpb, achunks, nblk);
   if (rc != OBB_OK) return rc;
   hipLaunchKernelGGL(rroi_backward_kernel, dim3((unsigned)nblk), dim3(256), 0, st, grad_out_dev, B, C, H, W, rois_dev, ph, pw,
-                     spatial_scale, sample_num, min_size, cpb, (int)K, (int)achunks, roi_kind, grad_feat_dev, 1);
+                     spatial_scale, sample_num, min_size, cpb, (int)K, (int)achunks, roi_kind, grad_feat_dev, 1, plan);
   OBB_LAUNCH_CHECK();
   return OBB_OK;
 }
