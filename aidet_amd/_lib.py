@@ -127,8 +127,21 @@ def lib():
         L.obb_patch_rows_to_image_f32.restype = i32
         L.obb_merge_rows_split_f32.argtypes = [vp, i64, i32, i64, vp, f32, vp, vp, vp, vp]
         L.obb_merge_rows_split_f32.restype = i32
+        L.obb_merge_rows_split_ld_f32.argtypes = [vp, i64, i32, i32, i64, vp, f32, vp, vp, vp, vp]
+        L.obb_merge_rows_split_ld_f32.restype = i32
+        L.obb_patch_rows_to_image_keyed_f32.argtypes = [vp, vp, vp, i64, vp, i64, vp, vp, i64, f32, vp, vp, vp]
+        L.obb_patch_rows_to_image_keyed_f32.restype = i32
         L.obb_gather_rows_f32.argtypes = [vp, i64, i32, vp, i64, i32, vp, vp]
         L.obb_gather_rows_f32.restype = i32
+        L.obb_rows_route_workspace_bytes.argtypes = [i64, i32]
+        L.obb_rows_route_workspace_bytes.restype = ctypes.c_size_t
+        L.obb_rows_route_f32.argtypes = [vp, i64, i32, i32, i32, vp, vp, vp, vp, ctypes.c_size_t, vp]
+        L.obb_rows_route_f32.restype = i32
+        L.obb_rows_restore_workspace_bytes.argtypes = [i32, i64]
+        L.obb_rows_restore_workspace_bytes.restype = ctypes.c_size_t
+        L.obb_rows_restore_f32.argtypes = [vp, i64, i32, i32, ctypes.POINTER(ctypes.c_int64), i32, i64, i32, i64, vp, vp, vp,
+                                           ctypes.c_size_t, vp]
+        L.obb_rows_restore_f32.restype = i32
         _lib = L
     return _lib
 

@@ -10,6 +10,8 @@
 //   obb_patch_rows_to_image_f32  kept rows -> image coordinates + label + image id
 //   obb_merge_rows_split_f32     merge rows -> boxes | group ids | per-class thresholds
 //   obb_gather_rows_f32          rows[idx]
+//   obb_rows_route_f32           rows -> stable buckets by (image id % world) + per-bucket counts  (routed layout)
+//   obb_rows_restore_f32         the sorted runs of several ranks -> one run in ascending key      (all layouts)
 // Pure data movement plus one add and one divide per coordinate, evaluated exactly like the
 // tensor expressions they replace (aidet_amd/dota_merge.py): results are bit-identical.
 #include "obb_common.h"
@@ -36,11 +38,13 @@ __global__ __launch_bounds__(kMergeThreads) void patch_rows_kernel(const float *
                                                                    int64_t n, const float *__restrict__ patch_xy,
                                                                    const int64_t *__restrict__ patch_image,
                                                                    int64_t num_patches, float rate,
-                                                                   float *__restrict__ out) {
+                                                                   float *__restrict__ out,
+                                                                   int64_t *__restrict__ patch_of_row) {
   const int64_t i = (int64_t)blockIdx.x * kMergeThreads + threadIdx.x;
   if (i >= k) return;
   const int64_t src = keep ? keep[i] : i;
   float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f), b = make_float4(0.0f, 0.0f, -1.0f, -1.0f);
+  if (patch_of_row) patch_of_row[i] = (src >= 0 && src < n) ? patch_index[src] : -1;
   if (src >= 0 && src < n) {
     const int64_t p = patch_index[src];
     if (p >= 0 && p < num_patches) {
@@ -60,7 +64,7 @@ __global__ __launch_bounds__(kMergeThreads) void patch_rows_kernel(const float *
 
 // rows (n, nbox + 2): [box + score | label | image]  ->  boxes (n, nbox), group = image * classes + label,
 // thr = class_thrs[label] (labels outside [0, classes) take `default_thr`)
-__global__ __launch_bounds__(kMergeThreads) void merge_split_kernel(const float *__restrict__ rows, int cols,
+__global__ __launch_bounds__(kMergeThreads) void merge_split_kernel(const float *__restrict__ rows, int cols, int ld,
                                                                     int64_t n, int64_t num_classes,
                                                                     const float *__restrict__ class_thrs,
                                                                     float default_thr,
@@ -70,7 +74,7 @@ __global__ __launch_bounds__(kMergeThreads) void merge_split_kernel(const float 
   const int64_t i = (int64_t)blockIdx.x * kMergeThreads + threadIdx.x;
   if (i >= n) return;
   const int nbox = cols - 2;
-  const float *r = rows + i * cols;
+  const float *r = rows + i * ld;
   if (boxes) {
     float *b = boxes + i * nbox;
     for (int c = 0; c < nbox; ++c) b[c] = r[c];
@@ -90,6 +94,204 @@ __global__ __launch_bounds__(kMergeThreads) void gather_rows_kernel(const float 
   const int c = (int)(w - i * out_cols);
   const int64_t s = idx[i];
   out[w] = (s >= 0 && s < n) ? src[s * cols + c] : 0.0f;
+}
+
+
+// ---- routing and order restoration (config 5 over several ranks) -------------------------------------------------
+// The tensor-op forms (a stable 16-bit argsort + gather + bincount, aidet_amd/dota_merge.py) are ~25 small
+// launches, 0.3 ms of a 0.67 ms pass in the 8-rank simulation; both are counting sorts with structure:
+//   route:   <= 64 buckets (destination rank) -> per-block bucket counts, one scan, a stable scatter;
+//   restore: every rank's rows arrive as ONE run in non-decreasing key, so the rows of a (key, source) pair are
+//            contiguous: position = start[(key, source)] + distance to the first row of the pair.
+constexpr int kRouteRows = 1024;        // rows per block (4 per thread)
+constexpr int kRouteMaxWorld = 64;
+constexpr int kScanThreads = 1024;
+
+struct SegStarts { int64_t s[kRouteMaxWorld + 1]; };   // row range of every source in the gathered / received rows
+
+__device__ __forceinline__ int route_bucket(float id, int world) {
+  const int64_t v = (int64_t)id;                     // (truncation, like Tensor.to(int64))
+  const int64_t m = v % (int64_t)world;
+  return (int)(m < 0 ? m + world : m);               // (the sign of the divisor, like Tensor.__mod__)
+}
+
+__global__ __launch_bounds__(256) void route_count_kernel(const float *__restrict__ rows, int cols, int id_col,
+                                                          int64_t n, int world, const int64_t *__restrict__ key,
+                                                          int nblocks, int *__restrict__ blockcnt,
+                                                          int *__restrict__ blockviol) {
+  __shared__ int hist[kRouteMaxWorld];
+  __shared__ int viol;
+  const int tid = threadIdx.x;
+  if (tid < kRouteMaxWorld) hist[tid] = 0;
+  if (tid == 0) viol = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * kRouteRows;
+  int bad = 0;
+#pragma unroll
+  for (int u = 0; u < kRouteRows / 256; ++u) {
+    const int64_t i = base + u * 256 + tid;
+    if (i < n) {
+      atomicAdd(&hist[route_bucket(rows[i * cols + id_col], world)], 1);
+      if (key && i > 0 && key[i] < key[i - 1]) ++bad;
+    }
+  }
+  if (bad) atomicAdd(&viol, bad);
+  __syncthreads();
+  if (tid < world) blockcnt[(int64_t)tid * nblocks + blockIdx.x] = hist[tid];
+  if (tid == 0) blockviol[blockIdx.x] = viol;
+}
+
+// exclusive scan of a[0, m) in place by ONE workgroup (m is a few 10^4: bucket x block counts, key x source counts)
+__device__ __forceinline__ int block_scan_inplace(int *__restrict__ a, int64_t m, int *part /* LDS, kScanThreads / 64 + 1 */) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t chunk = (m + kScanThreads - 1) / kScanThreads;
+  const int64_t lo = tid * chunk, hi = lo + chunk < m ? lo + chunk : m;
+  int sum = 0;
+  for (int64_t j = lo; j < hi; ++j) sum += a[j];
+  int inc = sum;
+  for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o); if (lane >= o) inc += v; }
+  if (lane == 63) part[wave] = inc;
+  __syncthreads();
+  int pre = inc - sum, total = 0;
+  for (int w = 0; w < kScanThreads / 64; ++w) { const int v = part[w]; pre += (w < wave) ? v : 0; total += v; }
+  for (int64_t j = lo; j < hi; ++j) { const int v = a[j]; a[j] = pre; pre += v; }
+  __syncthreads();
+  return total;
+}
+
+__global__ __launch_bounds__(kScanThreads) void route_scan_kernel(int *__restrict__ blockcnt, int world, int nblocks,
+                                                                  const int *__restrict__ blockviol,
+                                                                  int64_t *__restrict__ counts) {
+  __shared__ int part[kScanThreads / 64 + 1];
+  __shared__ int vsum;
+  const int tid = threadIdx.x;
+  if (tid == 0) vsum = 0;
+  __syncthreads();
+  int v = 0;
+  for (int j = tid; j < nblocks; j += kScanThreads) v += blockviol[j];
+  if (v) atomicAdd(&vsum, v);
+  const int total = block_scan_inplace(blockcnt, (int64_t)world * nblocks, part);
+  if (tid < world) {
+    const int lo = blockcnt[(int64_t)tid * nblocks];
+    const int hi = tid + 1 < world ? blockcnt[(int64_t)(tid + 1) * nblocks] : total;
+    counts[tid] = hi - lo;
+  }
+  if (tid == 0) counts[world] = vsum;
+}
+
+__global__ __launch_bounds__(256) void route_scatter_kernel(const float *__restrict__ rows, int cols, int id_col,
+                                                            int64_t n, int world, const int64_t *__restrict__ key,
+                                                            int nblocks, const int *__restrict__ offs,
+                                                            float *__restrict__ out) {
+  constexpr int kU = kRouteRows / 256;
+  __shared__ int wc[kU * 4 + 1][kRouteMaxWorld];     // rows of bucket b in (pass u, wave w); after the prefix: before it
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int j = tid; j < (kU * 4 + 1) * kRouteMaxWorld; j += 256) (&wc[0][0])[j] = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * kRouteRows;
+  int bk[kU], rk[kU];
+#pragma unroll
+  for (int u = 0; u < kU; ++u) {
+    const int64_t i = base + u * 256 + tid;
+    const bool valid = i < n;
+    bk[u] = valid ? route_bucket(rows[i * cols + id_col], world) : -1;
+    rk[u] = 0;
+    uint64_t rem = __ballot(valid);
+    while (rem) {                                    // one round per bucket present in the wave
+      const int lead = __builtin_ctzll(rem);
+      const int bl = __builtin_amdgcn_readlane(bk[u], lead);
+      const uint64_t m = __ballot(bk[u] == bl);
+      if (bk[u] == bl) rk[u] = __popcll(m & ((1ull << lane) - 1ull));
+      if (lane == lead) wc[u * 4 + wave][bl] = __popcll(m);
+      rem &= ~m;
+    }
+  }
+  __syncthreads();
+  if (tid < world) {                                 // exclusive prefix over (pass, wave) in row order, per bucket
+    int run = offs[(int64_t)tid * nblocks + blockIdx.x];
+    for (int j = 0; j < kU * 4; ++j) { const int v = wc[j][tid]; wc[j][tid] = run; run += v; }
+  }
+  __syncthreads();
+  const int oc = cols + 1;
+#pragma unroll
+  for (int u = 0; u < kU; ++u) {
+    const int64_t i = base + u * 256 + tid;
+    if (i >= n) continue;
+    const int64_t pos = (int64_t)wc[u * 4 + wave][bk[u]] + rk[u];
+    const float *src = rows + i * cols;
+    float *dst = out + pos * oc;
+    for (int c = 0; c < cols; ++c) dst[c] = src[c];
+    dst[cols] = key ? (float)key[i] : 0.0f;
+  }
+}
+
+__device__ __forceinline__ int seg_of(const SegStarts &sg, int world, int64_t i) {
+  int lo = 0, hi = world - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (sg.s[mid] <= i) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+// cnt[key * world + source] += 1 per real row (one atomic per run and wave), first[...] = the run's first row;
+// cnt[m] counts the rows that break the promise (a key smaller than its predecessor's in the same source)
+__global__ __launch_bounds__(256) void restore_mark_kernel(const float *__restrict__ rows, int cols, int key_col,
+                                                           int64_t n, SegStarts sg, int world, int key_max,
+                                                           int64_t m, int *__restrict__ cnt,
+                                                           int64_t *__restrict__ first) {
+  const int lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int64_t idx = -1;
+  bool boundary = false;
+  if (i < n) {
+    const int s = seg_of(sg, world, i);
+    const float kf = rows[i * cols + key_col];
+    if (kf >= 0.0f && kf <= (float)key_max) {
+      const int k = (int)kf;
+      idx = (int64_t)k * world + s;
+      boundary = true;
+      if (i > sg.s[s]) {
+        const float pf = rows[(i - 1) * cols + key_col];
+        if (pf >= 0.0f && pf <= (float)key_max) {
+          boundary = (int)pf != k;
+          if ((int)pf > k) atomicAdd(&cnt[m], 1);
+        }
+      }
+    }
+  }
+  if (boundary) first[idx] = i;
+  // runs inside the wave: a head lane adds the length of its run
+  const int64_t prev = __shfl_up(idx, 1);
+  const bool valid = idx >= 0;
+  const bool head = valid && (lane == 0 || prev != idx);
+  const uint64_t stop = (__ballot(head) | ~__ballot(valid)) >> 1 >> lane;     // heads / gaps above this lane
+  if (head) atomicAdd(&cnt[idx], stop ? __builtin_ctzll(stop) + 1 : 64 - lane);
+}
+
+__global__ __launch_bounds__(kScanThreads) void restore_scan_kernel(int *__restrict__ cnt, int64_t m,
+                                                                    int *__restrict__ status) {
+  __shared__ int part[kScanThreads / 64 + 1];
+  const int bad = cnt[m];
+  block_scan_inplace(cnt, m, part);
+  if (threadIdx.x == 0 && status && bad) *status = bad;
+}
+
+__global__ __launch_bounds__(256) void restore_scatter_kernel(const float *__restrict__ rows, int cols, int key_col,
+                                                              int64_t n, SegStarts sg, int world, int key_max,
+                                                              const int *__restrict__ start,
+                                                              const int64_t *__restrict__ first, int out_cols,
+                                                              int64_t total, float *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float kf = rows[i * cols + key_col];
+  if (!(kf >= 0.0f && kf <= (float)key_max)) return;      // padding
+  const int64_t idx = (int64_t)(int)kf * world + seg_of(sg, world, i);
+  const int64_t pos = (int64_t)start[idx] + (i - first[idx]);
+  if (pos < 0 || pos >= total) return;                     // (only when the promise is broken: reported in `status`)
+  const float *src = rows + i * cols;
+  float *dst = out + pos * out_cols;
+  for (int c = 0; c < out_cols; ++c) dst[c] = src[c];
 }
 
 static int merge_grid(const char *who, int64_t items, unsigned &blocks) {
@@ -115,11 +317,11 @@ extern "C" int obb_patch_groups_i32(const int64_t *labels_dev, const int64_t *pa
   return OBB_OK;
 }
 
-extern "C" int obb_patch_rows_to_image_f32(const float *dets_dev, const int64_t *labels_dev,
-                                           const int64_t *patch_index_dev, int64_t n,
-                                           const int64_t *keep_dev, int64_t k, const float *patch_xy_dev,
-                                           const int64_t *patch_image_dev, int64_t num_patches, float rate,
-                                           float *rows_dev, void *stream) {
+extern "C" int obb_patch_rows_to_image_keyed_f32(const float *dets_dev, const int64_t *labels_dev,
+                                                 const int64_t *patch_index_dev, int64_t n,
+                                                 const int64_t *keep_dev, int64_t k, const float *patch_xy_dev,
+                                                 const int64_t *patch_image_dev, int64_t num_patches, float rate,
+                                                 float *rows_dev, int64_t *patch_of_row_dev, void *stream) {
   if (n < 0 || k < 0 || num_patches < 0) return obb::set_err(OBB_EINVAL, "obb_patch_rows_to_image_f32: negative size");
   if (!(rate > 0.0f)) return obb::set_err(OBB_EINVAL, "obb_patch_rows_to_image_f32: rate must be positive");
   if (k == 0) return OBB_OK;
@@ -130,7 +332,34 @@ extern "C" int obb_patch_rows_to_image_f32(const float *dets_dev, const int64_t 
   if (rc != OBB_OK) return rc;
   hipLaunchKernelGGL(obb::patch_rows_kernel, dim3(blocks), dim3(obb::kMergeThreads), 0, (hipStream_t)stream,
                      dets_dev, labels_dev, patch_index_dev, keep_dev, k, n, patch_xy_dev, patch_image_dev,
-                     num_patches, rate, rows_dev);
+                     num_patches, rate, rows_dev, patch_of_row_dev);
+  OBB_LAUNCH_CHECK();
+  return OBB_OK;
+}
+
+extern "C" int obb_patch_rows_to_image_f32(const float *dets_dev, const int64_t *labels_dev,
+                                           const int64_t *patch_index_dev, int64_t n,
+                                           const int64_t *keep_dev, int64_t k, const float *patch_xy_dev,
+                                           const int64_t *patch_image_dev, int64_t num_patches, float rate,
+                                           float *rows_dev, void *stream) {
+  return obb_patch_rows_to_image_keyed_f32(dets_dev, labels_dev, patch_index_dev, n, keep_dev, k, patch_xy_dev,
+                                           patch_image_dev, num_patches, rate, rows_dev, nullptr, stream);
+}
+
+extern "C" int obb_merge_rows_split_ld_f32(const float *rows_dev, int64_t n, int cols, int ld, int64_t num_classes,
+                                           const float *class_thrs_dev, float default_thr, float *boxes_dev,
+                                           int32_t *groups_dev, float *thrs_dev, void *stream) {
+  if (n < 0) return obb::set_err(OBB_EINVAL, "obb_merge_rows_split_f32: negative n");
+  if (cols != 7 && cols != 8 && cols != 11)
+    return obb::set_err(OBB_EINVAL, "obb_merge_rows_split_f32: rows have 8 (theta-OBB), 11 (polygon) or 7 (horizontal) columns, got %d", cols);
+  if (ld < cols) return obb::set_err(OBB_EINVAL, "obb_merge_rows_split_f32: row pitch %d below %d columns", ld, cols);
+  if (n == 0) return OBB_OK;
+  if (!rows_dev || !groups_dev) return obb::set_err(OBB_EINVAL, "obb_merge_rows_split_f32: null pointer");
+  unsigned blocks;
+  int rc = obb::merge_grid("obb_merge_rows_split_f32", n, blocks);
+  if (rc != OBB_OK) return rc;
+  hipLaunchKernelGGL(obb::merge_split_kernel, dim3(blocks), dim3(obb::kMergeThreads), 0, (hipStream_t)stream,
+                     rows_dev, cols, ld, n, num_classes, class_thrs_dev, default_thr, boxes_dev, groups_dev, thrs_dev);
   OBB_LAUNCH_CHECK();
   return OBB_OK;
 }
@@ -138,18 +367,8 @@ extern "C" int obb_patch_rows_to_image_f32(const float *dets_dev, const int64_t 
 extern "C" int obb_merge_rows_split_f32(const float *rows_dev, int64_t n, int cols, int64_t num_classes,
                                         const float *class_thrs_dev, float default_thr, float *boxes_dev,
                                         int32_t *groups_dev, float *thrs_dev, void *stream) {
-  if (n < 0) return obb::set_err(OBB_EINVAL, "obb_merge_rows_split_f32: negative n");
-  if (cols != 7 && cols != 8 && cols != 11)
-    return obb::set_err(OBB_EINVAL, "obb_merge_rows_split_f32: rows have 8 (theta-OBB), 11 (polygon) or 7 (horizontal) columns, got %d", cols);
-  if (n == 0) return OBB_OK;
-  if (!rows_dev || !groups_dev) return obb::set_err(OBB_EINVAL, "obb_merge_rows_split_f32: null pointer");
-  unsigned blocks;
-  int rc = obb::merge_grid("obb_merge_rows_split_f32", n, blocks);
-  if (rc != OBB_OK) return rc;
-  hipLaunchKernelGGL(obb::merge_split_kernel, dim3(blocks), dim3(obb::kMergeThreads), 0, (hipStream_t)stream,
-                     rows_dev, cols, n, num_classes, class_thrs_dev, default_thr, boxes_dev, groups_dev, thrs_dev);
-  OBB_LAUNCH_CHECK();
-  return OBB_OK;
+  return obb_merge_rows_split_ld_f32(rows_dev, n, cols, cols, num_classes, class_thrs_dev, default_thr, boxes_dev,
+                                     groups_dev, thrs_dev, stream);
 }
 
 extern "C" int obb_gather_rows_f32(const float *src_dev, int64_t n, int cols, const int64_t *idx_dev, int64_t k,
@@ -162,6 +381,83 @@ extern "C" int obb_gather_rows_f32(const float *src_dev, int64_t n, int cols, co
   if (rc != OBB_OK) return rc;
   hipLaunchKernelGGL(obb::gather_rows_kernel, dim3(blocks), dim3(obb::kMergeThreads), 0, (hipStream_t)stream,
                      src_dev, cols, n, idx_dev, k, out_cols, out_dev);
+  OBB_LAUNCH_CHECK();
+  return OBB_OK;
+}
+
+extern "C" size_t obb_rows_route_workspace_bytes(int64_t n, int world) {
+  if (n < 0 || world < 1 || world > obb::kRouteMaxWorld) return 0;
+  const int64_t nblocks = (n + obb::kRouteRows - 1) / obb::kRouteRows;
+  return (size_t)((nblocks * world + nblocks + 16) * sizeof(int));
+}
+
+extern "C" int obb_rows_route_f32(const float *rows_dev, int64_t n, int cols, int id_col, int world,
+                                  const int64_t *order_key_dev, float *out_dev, int64_t *counts_dev,
+                                  void *workspace_dev, size_t workspace_bytes, void *stream) {
+  if (n < 0 || cols <= 0 || id_col < 0 || id_col >= cols) return obb::set_err(OBB_EINVAL, "obb_rows_route_f32: bad size");
+  if (world < 1 || world > obb::kRouteMaxWorld) return obb::set_err(OBB_EINVAL, "obb_rows_route_f32: 1 <= world <= %d", obb::kRouteMaxWorld);
+  if (!counts_dev) return obb::set_err(OBB_EINVAL, "obb_rows_route_f32: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  if (n == 0) {
+    OBB_HIP_TRY(hipMemsetAsync(counts_dev, 0, (size_t)(world + 1) * sizeof(int64_t), st));
+    return OBB_OK;
+  }
+  if (!rows_dev || !out_dev || !workspace_dev) return obb::set_err(OBB_EINVAL, "obb_rows_route_f32: null pointer");
+  if (n > (1ll << 30)) return obb::set_err(OBB_EINVAL, "obb_rows_route_f32: too many rows");
+  if (workspace_bytes < obb_rows_route_workspace_bytes(n, world))
+    return obb::set_err(OBB_EWORKSPACE, "obb_rows_route_f32: workspace of %zu bytes, %zu needed", workspace_bytes,
+                        obb_rows_route_workspace_bytes(n, world));
+  const int nblocks = (int)((n + obb::kRouteRows - 1) / obb::kRouteRows);
+  int *blockcnt = static_cast<int *>(workspace_dev);
+  int *blockviol = blockcnt + (size_t)nblocks * world;
+  hipLaunchKernelGGL(obb::route_count_kernel, dim3((unsigned)nblocks), dim3(256), 0, st, rows_dev, cols, id_col, n, world,
+                     order_key_dev, nblocks, blockcnt, blockviol);
+  OBB_LAUNCH_CHECK();
+  hipLaunchKernelGGL(obb::route_scan_kernel, dim3(1), dim3(obb::kScanThreads), 0, st, blockcnt, world, nblocks, blockviol, counts_dev);
+  OBB_LAUNCH_CHECK();
+  hipLaunchKernelGGL(obb::route_scatter_kernel, dim3((unsigned)nblocks), dim3(256), 0, st, rows_dev, cols, id_col, n, world,
+                     order_key_dev, nblocks, blockcnt, out_dev);
+  OBB_LAUNCH_CHECK();
+  return OBB_OK;
+}
+
+extern "C" size_t obb_rows_restore_workspace_bytes(int world, int64_t key_max) {
+  if (world < 1 || world > obb::kRouteMaxWorld || key_max < 0) return 0;
+  const int64_t m = (key_max + 1) * world;
+  if (m > OBB_RESTORE_MAX_SLOTS) return 0;
+  return (size_t)((m + 2) * sizeof(int) + 8 + m * sizeof(int64_t));
+}
+
+extern "C" int obb_rows_restore_f32(const float *rows_dev, int64_t n, int cols, int key_col, const int64_t *seg_start_host,
+                                    int world, int64_t key_max, int out_cols, int64_t total, float *out_dev,
+                                    int32_t *status_dev, void *workspace_dev, size_t workspace_bytes, void *stream) {
+  if (n < 0 || cols <= 0 || key_col < 0 || key_col >= cols || out_cols <= 0 || out_cols > cols || total < 0 || total > n)
+    return obb::set_err(OBB_EINVAL, "obb_rows_restore_f32: bad size");
+  if (world < 1 || world > obb::kRouteMaxWorld || !seg_start_host) return obb::set_err(OBB_EINVAL, "obb_rows_restore_f32: 1 <= world <= %d", obb::kRouteMaxWorld);
+  const size_t need = obb_rows_restore_workspace_bytes(world, key_max);
+  if (key_max < 0 || key_max >= (1 << 24) || need == 0)
+    return obb::set_err(OBB_EINVAL, "obb_rows_restore_f32: (key_max + 1) * world <= %d", OBB_RESTORE_MAX_SLOTS);
+  if (n == 0 || total == 0) return OBB_OK;
+  if (!rows_dev || !out_dev || !workspace_dev) return obb::set_err(OBB_EINVAL, "obb_rows_restore_f32: null pointer");
+  if (n > (1ll << 31) - 1) return obb::set_err(OBB_EINVAL, "obb_rows_restore_f32: too many rows");
+  if (workspace_bytes < need) return obb::set_err(OBB_EWORKSPACE, "obb_rows_restore_f32: workspace of %zu bytes, %zu needed", workspace_bytes, need);
+  obb::SegStarts sg;
+  for (int r = 0; r <= obb::kRouteMaxWorld; ++r) sg.s[r] = r < world ? seg_start_host[r] : n;
+  if (sg.s[0] != 0) return obb::set_err(OBB_EINVAL, "obb_rows_restore_f32: the first source starts at row 0");
+  for (int r = 1; r < world; ++r)
+    if (sg.s[r] < sg.s[r - 1] || sg.s[r] > n) return obb::set_err(OBB_EINVAL, "obb_rows_restore_f32: source starts must ascend within [0, n]");
+  const int64_t m = (key_max + 1) * world;
+  hipStream_t st = (hipStream_t)stream;
+  int *cnt = static_cast<int *>(workspace_dev);
+  int64_t *first = reinterpret_cast<int64_t *>(static_cast<char *>(workspace_dev) + (((size_t)(m + 2) * sizeof(int) + 7) & ~(size_t)7));
+  OBB_HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)(m + 1) * sizeof(int), st));
+  const unsigned blocks = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(obb::restore_mark_kernel, dim3(blocks), dim3(256), 0, st, rows_dev, cols, key_col, n, sg, world, (int)key_max, m, cnt, first);
+  OBB_LAUNCH_CHECK();
+  hipLaunchKernelGGL(obb::restore_scan_kernel, dim3(1), dim3(obb::kScanThreads), 0, st, cnt, m, status_dev);
+  OBB_LAUNCH_CHECK();
+  hipLaunchKernelGGL(obb::restore_scatter_kernel, dim3(blocks), dim3(256), 0, st, rows_dev, cols, key_col, n, sg, world, (int)key_max,
+                     cnt, first, out_cols, total, out_dev);
   OBB_LAUNCH_CHECK();
   return OBB_OK;
 }

@@ -941,7 +941,7 @@ __global__ __launch_bounds__(256) void rroi_plan_kernel(
 // (Also measured and dropped in round 3: FOUR RoIs per step, two barriers per step: 155 -> 185 us, 99 VGPRs.)
 // NB: bins per RoI when known at compile time (49: the LDS reads of the sums take immediate offsets), 0: from the plan.
 template <int CH, int NB>
-__global__ __launch_bounds__(256) void rroi_gather_pipe_kernel(
+__global__ __launch_bounds__(256) void rroi_gather_kernel(
     const float *__restrict__ gout, int C, int H, int W, int K, const RoiPlan *__restrict__ plan,
     const unsigned short *__restrict__ rstart, const int2 *__restrict__ rentry, float *__restrict__ gfeat) {
   constexpr int G = CH * kMaxBins / 256;            // gradient words a thread stages per RoI
@@ -1353,7 +1353,7 @@ extern "C" int obb_roi_backward_gather_f32(const float *grad_out_dev, int B, int
   if (chunks > 65535u || B > 65535) return set_err(OBB_EINVAL, "%s: too many channels / images", who);
   const dim3 ggrid(tiles, chunks, (unsigned)B);
 #define OBB_GATHER(CH, NB)                                                                                              \
-  hipLaunchKernelGGL((rroi_gather_pipe_kernel<CH, NB>), ggrid, dim3(256), 0, st, grad_out_dev, C, H, W, (int)K, plan, \
+  hipLaunchKernelGGL((rroi_gather_kernel<CH, NB>), ggrid, dim3(256), 0, st, grad_out_dev, C, H, W, (int)K, plan, \
                      rstart, rentry, grad_feat_dev)
   if (gch == 32) {
     if (ph * pw == 49) OBB_GATHER(32, 49); else OBB_GATHER(32, 0);

@@ -65,17 +65,114 @@ def _call(dev, fn, *args):
         _lib.check(fn(*args, _lib.current_stream_handle(dev)))
 
 
+def _row_pitch(rows):
+    """(tensor to read, row pitch in elements) of (n, c) fp32 rows: a column slice of wider contiguous rows is read in
+    place."""
+    if rows.dim() == 2 and rows.size(1) > 0 and rows.stride(1) == 1 and rows.stride(0) >= rows.size(1) and rows.size(0) > 0:
+        return rows, rows.stride(0)
+    rows = rows.contiguous()
+    return rows, rows.size(1)
+
+
 def gather_rows(rows, index, ncols=None):
     """rows[index][:, :ncols] for (n, c) fp32 rows on the GPU (one streaming kernel; torch's index_select
     takes 0.16 ms for 7.7e5 rows of 32 bytes, this 0.02 ms)."""
     ncols = rows.size(1) if ncols is None else int(ncols)
     if not (_on_gpu(rows, index) and rows.dtype == torch.float32 and rows.dim() == 2 and rows.size(1) > 0):
         return rows[index][:, :ncols]
-    rows, index = rows.contiguous(), _i64(index)
+    rows, ld = _row_pitch(rows)
+    index = _i64(index)
     out = rows.new_empty((index.numel(), ncols))
-    _call(rows.device, _lib.lib().obb_gather_rows_f32, rows.data_ptr(), rows.size(0), rows.size(1),
+    _call(rows.device, _lib.lib().obb_gather_rows_f32, rows.data_ptr(), rows.size(0), ld,
           index.data_ptr(), index.numel(), ncols, out.data_ptr())
     return out
+
+
+_class_thr_cache = {}
+
+
+def _class_thr_tensor(class_thrs, dev):
+    """per-class thresholds on the device, uploaded once per distinct list"""
+    if isinstance(class_thrs, torch.Tensor):
+        return class_thrs.detach().to(device=dev, dtype=torch.float32).contiguous()
+    key = (str(dev), tuple(float(v) for v in class_thrs))
+    t = _class_thr_cache.get(key)
+    if t is None:
+        if len(_class_thr_cache) > 64:
+            _class_thr_cache.clear()
+        t = _class_thr_cache[key] = torch.tensor(key[1], dtype=torch.float32, device=dev)
+    return t
+
+
+ROUTE_MAX_WORLD = 64            # obb_rows_route_f32 / obb_rows_restore_f32
+RESTORE_MAX_SLOTS = 1 << 20     # (key_max + 1) * world of obb_rows_restore_f32
+_order_flags = {}               # device -> pinned int32[1] the restore kernels report a broken key order in
+
+
+def _order_flag(dev):
+    f = _order_flags.get(dev)
+    if f is None:
+        f = _order_flags[dev] = torch.zeros(1, dtype=torch.int32).pin_memory()
+    return f
+
+
+def _check_order_flag(dev):
+    """After a host synchronisation that follows ``restore_rows`` (the merged NMS ends with one): did a source break
+    the promise of non-decreasing keys?"""
+    f = _order_flags.get(dev)
+    if f is not None and int(f[0]) != 0:
+        f[0] = 0
+        raise ValueError('order_key: the keys of a rank must be non-decreasing in its row order')
+
+
+def route_rows(rows, world, order_key=None):
+    """rows (n, c) -> (the rows in stable buckets by ``int(rows[:, -1]) % world`` with the key appended as one more
+    column, counts int64[world + 1]: rows per bucket and, last, how many keys are smaller than their predecessor).
+    On the GPU ``obb_rows_route_f32`` (three launches); the tensor expressions below are the CPU path and the
+    specification."""
+    n, c = rows.size(0), rows.size(1)
+    if (_on_gpu(rows) and rows.dtype == torch.float32 and world <= ROUTE_MAX_WORLD
+            and (order_key is None or _on_gpu(rows, order_key))):
+        L = _lib.lib()
+        rows = rows.contiguous()
+        key = _i64(order_key) if order_key is not None else None
+        out = rows.new_empty((n, c + 1))
+        counts = torch.empty(world + 1, dtype=torch.int64, device=rows.device)
+        ws = torch.empty(max(int(L.obb_rows_route_workspace_bytes(n, world)), 16), dtype=torch.uint8, device=rows.device)
+        _call(rows.device, L.obb_rows_route_f32, rows.data_ptr(), n, c, c - 1, world,
+              key.data_ptr() if key is not None else None, out.data_ptr(), counts.data_ptr(), ws.data_ptr(), ws.numel())
+        return out, counts
+    key = (order_key.to(rows.dtype) if order_key is not None else rows.new_zeros(n))[:, None]
+    dest = rows[:, -1].to(torch.int64) % world
+    order = _sort_by_small_key(dest.to(rows.dtype), world)
+    bad = (order_key[1:] < order_key[:-1]).sum().reshape(1).to(torch.int64) if order_key is not None and n > 1 \
+        else torch.zeros(1, dtype=torch.int64, device=rows.device)
+    return torch.cat([rows, key], 1)[order], torch.cat([torch.bincount(dest, minlength=world), bad])
+
+
+def restore_rows(rows, seg_starts, key_max, out_cols, total):
+    """The rows of ``len(seg_starts)`` sources (source r = rows[seg_starts[r]:seg_starts[r + 1]], each in
+    non-decreasing key = last column; keys outside [0, key_max] are padding) -> the ``total`` real rows in ascending
+    key, equal keys by source, ``out_cols`` columns.  On the GPU ``obb_rows_restore_f32`` (a counting sort over
+    (key, source) runs: one memset + three launches; the stable 16-bit argsort + gather it replaces: ~65 us for
+    1.6e5 rows); the tensor expressions are the CPU path and the specification."""
+    world = len(seg_starts)
+    if (_on_gpu(rows) and rows.dtype == torch.float32 and key_max is not None and world <= ROUTE_MAX_WORLD
+            and (int(key_max) + 1) * world <= RESTORE_MAX_SLOTS):
+        L = _lib.lib()
+        rows = rows.contiguous()
+        out = rows.new_empty((total, out_cols))
+        ws = torch.empty(int(L.obb_rows_restore_workspace_bytes(world, int(key_max))), dtype=torch.uint8, device=rows.device)
+        seg = (ctypes.c_int64 * world)(*[int(v) for v in seg_starts])
+        _call(rows.device, L.obb_rows_restore_f32, rows.data_ptr(), rows.size(0), rows.size(1), rows.size(1) - 1, seg, world,
+              int(key_max), int(out_cols), int(total), out.data_ptr(), _order_flag(rows.device).data_ptr(), ws.data_ptr(),
+              ws.numel())
+        return out
+    small = key_max is not None and int(key_max) < (1 << 15) - 1
+    key = rows[:, -1]
+    key = key.clamp(max=32767.0).to(torch.int16) if small else key.to(torch.int32)
+    order = torch.argsort(key, stable=True)[:total]
+    return gather_rows(rows, order, out_cols)
 
 
 def shard_patches(num_patches, rank, world_size):
@@ -171,19 +268,20 @@ def merge_detections(dets, iou_thr, num_classes, class_thrs=None, nms_fn=None, s
             and float(iou_thr) > 0.0):
         # fused: one kernel splits the rows into boxes | int32 groups | thresholds, the grouped NMS reads
         # them as they are, one kernel gathers the kept rows
-        rows = dets.contiguous()
+        rows, ld0 = _row_pitch(dets)          # (a column slice of wider rows is read in place)
         cols, dev, L = rows.size(1), rows.device, _lib.lib()
         cthr = None
         if class_thrs is not None:
-            cthr = torch.as_tensor(class_thrs, dtype=torch.float32, device=dev).contiguous()
+            cthr = _class_thr_tensor(class_thrs, dev)
             assert cthr.numel() >= int(num_classes), 'one threshold per class'
 
         def split(r, want_boxes):
+            r, ld = (rows, ld0) if r is rows else _row_pitch(r)
             m = r.size(0)
             bx = r.new_empty((m, cols - 2)) if want_boxes else None
             gr = torch.empty(m, dtype=torch.int32, device=dev)
             th = torch.empty(m, dtype=torch.float32, device=dev) if (want_boxes and cthr is not None) else None
-            _call(dev, L.obb_merge_rows_split_f32, r.data_ptr(), m, cols, int(num_classes),
+            _call(dev, L.obb_merge_rows_split_ld_f32, r.data_ptr(), m, cols, ld, int(num_classes),
                   None if cthr is None else cthr.data_ptr(), float(iou_thr), None if bx is None else bx.data_ptr(),
                   gr.data_ptr(), None if th is None else th.data_ptr())
             return bx, gr, th
@@ -231,17 +329,13 @@ def _restore_order(parts, ncols):
 _PAD_KEY = float((1 << 24) - 1)      # key of the padding rows of the gather: sorts behind every real key
 
 
-def _restore_by_key(padded, total, ncols, key_max=None):
-    """The padded rows of all ranks (``_gather_padded`` with ``_PAD_KEY``), a small integer key in the last
-    column, every key value on ONE rank -> the ``total`` real rows in ascending key, rank-local order
-    inside a key: a stable sort on a 16-bit key when ``key_max`` < 2**15 - 1 (62 us for 1.25e6 rows on
-    MI355X, 110 us on 32 bits; the int64 sort of ``_restore_order`` takes 250 us), then ONE gather that
-    also drops the padding and the key column."""
-    small = key_max is not None and int(key_max) < (1 << 15) - 1
-    key = padded[:, -1]
-    key = key.clamp(max=32767.0).to(torch.int16) if small else key.to(torch.int32)
-    order = torch.argsort(key, stable=True)[:total]
-    return gather_rows(padded, order, ncols)
+def _restore_by_key(padded, total, ncols, key_max=None, world=1):
+    """The padded rows of all ranks (``_gather_padded`` with ``_PAD_KEY``: ``world`` equal blocks, real rows first), a
+    small integer key in the last column, every rank's rows in non-decreasing key -> the ``total`` real rows in
+    ascending key, rank order inside a key (``restore_rows``), without the key column."""
+    nmax = padded.size(0) // max(world, 1)
+    kmax = key_max if key_max is not None else None
+    return restore_rows(padded, [r * nmax for r in range(max(world, 1))], kmax, ncols, total)
 
 
 def _sort_by_small_key(key, key_max):
@@ -271,32 +365,36 @@ def routed_merge(local, iou_thr, num_classes, class_thrs=None, group=None, nms_f
     world, rank = _world(group)
     ncols = local.size(1)
     dev = local.device
-    key = (order_key.to(local.dtype) if order_key is not None else local.new_zeros(local.size(0)))[:, None]
-    rows = torch.cat([local, key], 1)
     if world > 1:
-        dest = local[:, -1].to(torch.int64) % world
-        order = _sort_by_small_key(dest.to(local.dtype), world)
-        send = gather_rows(rows, order)
-        mat = torch.empty(world * world, dtype=torch.int64, device=dev)
-        dist.all_gather_into_tensor(mat, torch.bincount(dest, minlength=world), group=group)
-        mat = mat.view(world, world).tolist()                        # mat[src][dst]; the one host read
-        in_splits, out_splits = mat[rank], [mat[src][rank] for src in range(world)]
+        send, counts = route_rows(local, world, order_key)
+        mat = torch.empty(world * (world + 1), dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(mat, counts, group=group)
+        mat = mat.view(world, world + 1).tolist()                    # mat[src][dst] | unordered keys; the one host read
+        if any(row[world] for row in mat):
+            raise ValueError('order_key: the keys of a rank must be non-decreasing in its row order')
+        in_splits, out_splits = mat[rank][:world], [mat[src][rank] for src in range(world)]
         recv = send.new_empty((sum(out_splits), ncols + 1))
         dist.all_to_all_single(recv, send, out_splits, in_splits, group=group)
         # rows of one source arrive together and in order; patches interleave over the sources
         mine = recv
         if order_key is not None and mine.size(0) > 0:
-            mine = gather_rows(recv, _sort_by_small_key(recv[:, -1], order_key_max))
+            starts = [0]
+            for c in out_splits[:-1]:
+                starts.append(starts[-1] + c)
+            mine = restore_rows(recv, starts, order_key_max, ncols + 1, recv.size(0))
     else:
-        mine = rows
+        key = (order_key.to(local.dtype) if order_key is not None else local.new_zeros(local.size(0)))[:, None]
+        mine = torch.cat([local, key], 1)
     mark('gather')
-    allrows = mine[:, :ncols].contiguous()
+    allrows = mine[:, :ncols]                 # (read in place: the kernels take the row pitch)
     kept, keep = merge_detections(allrows, iou_thr, num_classes, class_thrs, nms_fn, strict)
+    if mine.is_cuda:
+        _check_order_flag(dev)
     if gather_result and world > 1:
-        kk = torch.cat([kept, mine[keep][:, -1:]], 1) if kept.size(0) else mine[:0]
+        kk = gather_rows(mine, keep) if kept.size(0) else mine[:0]      # (kept rows with their key column)
         padded, counts, _ = _gather_padded(kk, group, _PAD_KEY)
         if order_key is not None:
-            kept = _restore_by_key(padded, sum(counts), ncols, order_key_max)
+            kept = _restore_by_key(padded, sum(counts), ncols, order_key_max, world)
         else:
             nmax = padded.size(0) // world
             kept = torch.cat([padded[r * nmax:r * nmax + c] for r, c in enumerate(counts)], 0)[:, :ncols]
@@ -347,7 +445,7 @@ def distributed_merge(local, iou_thr, num_classes, class_thrs=None, group=None, 
     if order_key is not None:
         key = order_key.to(local.dtype)[:, None]         # (exact in fp32 below 2**24)
         padded, counts, _ = _gather_padded(torch.cat([local, key], 1), group, _PAD_KEY)
-        allrows = _restore_by_key(padded, sum(counts), ncols, order_key_max)
+        allrows = _restore_by_key(padded, sum(counts), ncols, order_key_max, len(counts))
     elif seq is not None:
         # sequence numbers travel as two float32 columns (hi, lo) to stay exact
         s64 = seq.to(torch.int64)
@@ -371,6 +469,8 @@ def distributed_merge(local, iou_thr, num_classes, class_thrs=None, group=None, 
         kept = gather_rows(allrows, keep)
     else:
         kept, keep = merge_detections(allrows, iou_thr, num_classes, class_thrs, nms_fn, strict)
+    if order_key is not None and allrows.is_cuda:
+        _check_order_flag(allrows.device)
     mark('merge')
     return kept, keep, allrows
 
@@ -400,7 +500,7 @@ def local_patch_nms(dets, labels, patch_index, iou_thr, num_classes, nms_fn=None
     return torch.as_tensor(keep, device=dets.device)
 
 
-def patch_rows_to_image(dets, labels, patch_index, patch_xy, patch_image, rate=1.0, keep=None):
+def patch_rows_to_image(dets, labels, patch_index, patch_xy, patch_image, rate=1.0, keep=None, with_patch=False):
     """theta-OBB rows of many patches -> (n, 8) merge rows in image coordinates, vectorised
     (``dota_io.patch_rows_to_image`` does one patch from its file name).
 
@@ -410,6 +510,8 @@ def patch_rows_to_image(dets, labels, patch_index, patch_xy, patch_image, rate=1
         patch_xy (Tensor): (P, 2) left/top of every patch; patch_image (P,) its image id.
         keep (Tensor, optional): (k,) row indices -- the result is that of ``dets[keep]``,
             ``labels[keep]``, ``patch_index[keep]`` (on the GPU the selection is never materialised).
+        with_patch (bool): also return ``patch_index[keep]`` (int64; written by the same kernel) -- the order key
+            of the multi-rank merge.
     """
     if (_on_gpu(dets, labels, patch_index, patch_xy, patch_image) and (keep is None or _on_gpu(dets, keep))
             and dets.dtype == torch.float32 and float(rate) > 0.0):
@@ -419,10 +521,11 @@ def patch_rows_to_image(dets, labels, patch_index, patch_xy, patch_image, rate=1
         kk = None if keep is None else _i64(keep)
         k = d.size(0) if kk is None else kk.numel()
         out = d.new_empty((k, 8))
-        _call(d.device, _lib.lib().obb_patch_rows_to_image_f32, d.data_ptr(), lab.data_ptr(), pid.data_ptr(),
+        pof = torch.empty(k, dtype=torch.int64, device=d.device) if with_patch else None
+        _call(d.device, _lib.lib().obb_patch_rows_to_image_keyed_f32, d.data_ptr(), lab.data_ptr(), pid.data_ptr(),
               d.size(0), None if kk is None else kk.data_ptr(), k, pxy.data_ptr(), pim.data_ptr(), pim.numel(),
-              float(rate), out.data_ptr())
-        return out
+              float(rate), out.data_ptr(), None if pof is None else pof.data_ptr())
+        return (out, pof) if with_patch else out
     if keep is not None:
         dets, labels, patch_index = dets[keep], labels[keep], patch_index[keep]
     off = patch_xy[patch_index]
@@ -432,7 +535,7 @@ def patch_rows_to_image(dets, labels, patch_index, patch_xy, patch_image, rate=1
     out[:, 4:6] = dets[:, 4:6]
     out[:, 6] = labels.to(out.dtype)
     out[:, 7] = patch_image[patch_index].to(out.dtype)
-    return out
+    return (out, patch_index.to(torch.int64)) if with_patch else out
 
 
 def tiled_inference_merge(dets, labels, patch_index, seq, patch_xy, patch_image, num_classes,
@@ -447,17 +550,16 @@ def tiled_inference_merge(dets, labels, patch_index, seq, patch_xy, patch_image,
     to record HIP events.  Returns ``distributed_merge``'s triple."""
     mark = mark or (lambda name: None)
     keep = local_patch_nms(dets, labels, patch_index, local_thr, num_classes, nms_fn)
-    rows = patch_rows_to_image(dets, labels, patch_index, patch_xy, patch_image, keep=keep)
+    use_patch_key = _world(group)[0] > 1 and patch_index is not None and int(patch_xy.size(0)) < (1 << 24)
+    rows = patch_rows_to_image(dets, labels, patch_index, patch_xy, patch_image, keep=keep, with_patch=use_patch_key)
+    rows, okey = rows if use_patch_key else (rows, None)
     mark('local')
     # (the order only matters when rows of several ranks are interleaved.  A patch lives on one rank and
     # its rows are contiguous and in order there, so the patch index restores the single-process order;
     # ``seq`` -- arbitrary global row numbers -- is the general, slower way and is used without it)
-    okey = skept = None
-    if _world(group)[0] > 1:
-        if patch_index is not None and int(patch_xy.size(0)) < (1 << 24):
-            okey = patch_index[keep]
-        elif seq is not None:
-            skept = seq[keep]
+    skept = None
+    if _world(group)[0] > 1 and okey is None and seq is not None:
+        skept = seq[keep]
     return distributed_merge(rows, merge_thr, num_classes, class_thrs, group, nms_fn, skept,
                              layout, mark=mark, order_key=okey, order_key_max=int(patch_xy.size(0)),
                              gather_result=gather_result)

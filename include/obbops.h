@@ -355,8 +355,49 @@ OBB_API int obb_patch_rows_to_image_f32(const float *dets_dev, const int64_t *la
 OBB_API int obb_merge_rows_split_f32(const float *rows_dev, int64_t n, int cols, int64_t num_classes,
                                      const float *class_thrs_dev, float default_thr, float *boxes_dev,
                                      int32_t *groups_dev, float *thrs_dev, void *stream);
+/* the same with one more output / a row pitch: patch_of_row_dev int64[k] (may be NULL) = the patch index of every
+ * output row (-1 for a source row out of range) -- the order key of the multi-rank merge; rows of `ld` >= cols floats
+ * (rows that carry more columns than the merge reads, e.g. that key) */
+OBB_API int obb_patch_rows_to_image_keyed_f32(const float *dets_dev, const int64_t *labels_dev,
+                                              const int64_t *patch_index_dev, int64_t n,
+                                              const int64_t *keep_dev, int64_t k, const float *patch_xy_dev,
+                                              const int64_t *patch_image_dev, int64_t num_patches, float rate,
+                                              float *rows_dev, int64_t *patch_of_row_dev, void *stream);
+OBB_API int obb_merge_rows_split_ld_f32(const float *rows_dev, int64_t n, int cols, int ld, int64_t num_classes,
+                                        const float *class_thrs_dev, float default_thr, float *boxes_dev,
+                                        int32_t *groups_dev, float *thrs_dev, void *stream);
 OBB_API int obb_gather_rows_f32(const float *src_dev, int64_t n, int cols, const int64_t *idx_dev, int64_t k,
                                 int out_cols, float *out_dev, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * Row routing and order restoration of the multi-rank merge (config 5).
+ * Replaces: the pickle / all_gather / interleave of collect_results, mmdet/apis/test.py:116-146 (every rank's
+ *           results to every rank, `ordered_results.extend(list(res))` restoring the dataset order), as far as the
+ *           rows stay on the device: which rows travel where and in which order they are merged.
+ *
+ * obb_rows_route_f32:   rows (n, cols) -> out (n, cols + 1): the rows in stable buckets by destination
+ *     ((int64)rows[i, id_col] mod world, the sign of the divisor), bucket 0 first, each with one more column holding
+ *     (float)order_key[i] (0 without keys); counts_dev int64[world + 1]: rows per bucket, and in [world] the number
+ *     of rows whose key is SMALLER than their predecessor's (the order restoration below needs 0).
+ *     world <= 64.  Three launches: per-block bucket counts, one scan, the scatter.
+ * obb_rows_restore_f32: the rows of `world` sources, source r in rows [seg_start_host[r], seg_start_host[r + 1])
+ *     (the last one ends at n), each source in non-decreasing key (column key_col, integers as float) -> out
+ *     (total, out_cols): all rows with 0 <= key <= key_max in ascending key; equal keys: ascending source, then the
+ *     source's order (a stable merge).  Rows with a key outside [0, key_max] are padding and dropped; `total` = the
+ *     number of real rows (the caller knows it from the exchanged counts).  (key_max + 1) * world <=
+ *     OBB_RESTORE_MAX_SLOTS.  A source that is not in non-decreasing key order: *status_dev (device-visible int32,
+ *     may be NULL; written only then) = the number of offending rows, the output is unspecified.
+ *     One memset + three launches.
+ * ------------------------------------------------------------------------- */
+#define OBB_RESTORE_MAX_SLOTS (1 << 20)
+OBB_API size_t obb_rows_route_workspace_bytes(int64_t n, int world);
+OBB_API int obb_rows_route_f32(const float *rows_dev, int64_t n, int cols, int id_col, int world,
+                               const int64_t *order_key_dev, float *out_dev, int64_t *counts_dev,
+                               void *workspace_dev, size_t workspace_bytes, void *stream);
+OBB_API size_t obb_rows_restore_workspace_bytes(int world, int64_t key_max);
+OBB_API int obb_rows_restore_f32(const float *rows_dev, int64_t n, int cols, int key_col, const int64_t *seg_start_host,
+                                 int world, int64_t key_max, int out_cols, int64_t total, float *out_dev,
+                                 int32_t *status_dev, void *workspace_dev, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------
  * Proposal / detection SELECTION stages of the detector (config 4), between a head's convolutions and its NMS.

@@ -358,3 +358,87 @@ def test_hip_nms_and_soft_nms_against_the_reference_build_live():
         gd, gi = soft_nms(t(b), 0.3, method={1: 'linear', 2: 'gaussian'}[method], sigma=0.5, min_score=0.05)
         assert np.array_equal(gi.cpu().numpy(), res[:, 5].astype(np.int64))
         assert np.allclose(gd.cpu().numpy(), res[:, :5], atol=1e-6, rtol=0)
+
+
+# ---- row routing / order restoration kernels (config 5 over several ranks) ------------------------------------------
+def _route_spec(rows, world, key):
+    """the tensor-op specification (dota_merge.route_rows on CPU tensors)"""
+    from aidet_amd import dota_merge
+    out, counts = dota_merge.route_rows(rows.cpu(), world, None if key is None else key.cpu())
+    return out, counts
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n,world,cols', [(0, 4, 8), (1, 1, 8), (1000, 2, 8), (1024, 8, 8), (5000, 3, 11), (70000, 8, 8), (4097, 64, 7)])
+def test_route_rows_matches_the_tensor_ops(n, world, cols):
+    from aidet_amd import dota_merge
+    g = torch.Generator().manual_seed(n + world)
+    rows = torch.randn(n, cols, generator=g)
+    rows[:, -1] = torch.randint(-2, 40, (n,), generator=g).float()      # image ids (negative: rows of no image)
+    key = torch.sort(torch.randint(0, 300, (n,), generator=g))[0]
+    for k in (key, None):
+        out, counts = dota_merge.route_rows(rows.cuda(), world, None if k is None else k.cuda())
+        ref, rcounts = _route_spec(rows, world, k)
+        assert torch.equal(counts.cpu(), rcounts)
+        assert torch.equal(out.cpu(), ref)
+    if n > 10:      # an unordered key is counted, not repaired
+        bad = key.clone(); bad[5] = 400
+        _, counts = dota_merge.route_rows(rows.cuda(), world, bad.cuda())
+        assert int(counts[-1]) == int((bad[1:] < bad[:-1]).sum()) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('world,per,kmax', [(1, 1000, 50), (2, 3000, 200), (8, 20000, 4000), (3, 0, 10), (64, 300, 2000), (5, 700, 32767)])
+def test_restore_rows_is_a_stable_merge_of_the_sources(world, per, kmax):
+    from aidet_amd import dota_merge
+    g = torch.Generator().manual_seed(world * 7 + per)
+    segs, starts = [], []
+    nmax = per + 5
+    for r in range(world):
+        m = int(torch.randint(0, per + 1, (1,), generator=g)) if per else 0
+        if r == 1:
+            m = 0                                              # an empty source
+        body = torch.randn(m, 9, generator=g)
+        # a source's keys ascend; two sources may hold the same key (a stable merge orders them by source)
+        body[:, -1] = torch.sort(torch.randint(0, kmax + 1, (m,), generator=g))[0].float()
+        pad = torch.zeros(nmax - m, 9); pad[:, -1] = dota_merge._PAD_KEY
+        segs.append(torch.cat([body, pad]))
+        starts.append(r * nmax)
+    rows = torch.cat(segs)
+    total = int((rows[:, -1] <= kmax).sum())
+    ref = rows[torch.argsort(rows[:, -1].to(torch.int32), stable=True)[:total]]
+    for oc in (9, 8):
+        out = dota_merge.restore_rows(rows.cuda(), starts, kmax, oc, total)
+        torch.cuda.synchronize()
+        assert torch.equal(out.cpu(), ref[:, :oc])
+    dota_merge._check_order_flag(torch.device('cuda', 0))       # nothing to report
+    assert torch.equal(dota_merge._restore_by_key(rows.cuda(), total, 8, kmax, world).cpu(), ref[:, :8])
+
+
+@pytest.mark.gpu
+def test_restore_rows_reports_a_source_that_is_out_of_order():
+    from aidet_amd import dota_merge
+    rows = torch.zeros(100, 9)
+    rows[:, -1] = torch.arange(100).float()
+    rows[40, -1] = 7.0                                          # smaller than its predecessor's 39
+    dota_merge.restore_rows(rows.cuda(), [0, 50], 200, 9, 100)
+    torch.cuda.synchronize()
+    with pytest.raises(ValueError, match='non-decreasing'):
+        dota_merge._check_order_flag(torch.device('cuda', 0))
+    dota_merge._check_order_flag(torch.device('cuda', 0))       # (the flag is cleared by the report)
+
+
+@pytest.mark.gpu
+def test_route_and_restore_refuse_bad_arguments():
+    from aidet_amd import _lib
+    L = _lib.lib()
+    r = torch.zeros(10, 8, device='cuda')
+    c = torch.zeros(70, dtype=torch.int64, device='cuda')
+    o = torch.zeros(10, 9, device='cuda')
+    ws = torch.zeros(1 << 16, dtype=torch.uint8, device='cuda')
+    assert L.obb_rows_route_f32(r.data_ptr(), 10, 8, 7, 65, None, o.data_ptr(), c.data_ptr(), ws.data_ptr(), ws.numel(), None) == _lib.OBB_EINVAL
+    assert L.obb_rows_route_f32(r.data_ptr(), 10, 8, 8, 4, None, o.data_ptr(), c.data_ptr(), ws.data_ptr(), ws.numel(), None) == _lib.OBB_EINVAL
+    assert L.obb_rows_route_f32(r.data_ptr(), 10, 8, 7, 4, None, o.data_ptr(), c.data_ptr(), ws.data_ptr(), 4, None) == _lib.OBB_EWORKSPACE
+    seg = (ctypes.c_int64 * 2)(0, 20)
+    assert L.obb_rows_restore_f32(r.data_ptr(), 10, 8, 7, seg, 2, 100, 8, 10, o.data_ptr(), None, ws.data_ptr(), ws.numel(), None) == _lib.OBB_EINVAL
+    assert L.obb_rows_restore_workspace_bytes(64, 1 << 20) == 0

@@ -22,7 +22,8 @@ def rank_inputs(rank, world):
             torch.from_numpy(scene['patch'][idx]).to(dev), torch.from_numpy(idx.astype(np.int64)).to(dev))
 
 
-for world in (1, 2, 4, 8):
+ONLY = os.environ.get('SIM_ONLY', '')     # e.g. 'routed8': one configuration (for a kernel trace)
+for world in (() if ONLY else (1, 2, 4, 8)):
     layout = 'sharded' if world > 1 else 'replicated'
     inputs = [rank_inputs(r, world) for r in range(world)]
     # contributions of the other ranks to the two gathers (rows + sequence columns; keep indices)
@@ -41,7 +42,7 @@ for world in (1, 2, 4, 8):
         padded0[:, -1] = dota_merge._PAD_KEY
         for r, t in enumerate(allparts):
             padded0[r * nmax:r * nmax + counts[r]] = t
-        allrows = dota_merge._restore_by_key(padded0, sum(counts), 8, P)
+        allrows = dota_merge._restore_by_key(padded0, sum(counts), 8, P, world)
         others_mask = torch.zeros(allrows.size(0), dtype=torch.uint8, device=dev)
         for r in range(1, world):
             others_mask[dota_merge.merge_detections(allrows, 0.3, C, thrs, only_groups=(world, r))[1]] = 1
@@ -90,7 +91,7 @@ for world in (1, 2, 4, 8):
 
 
 # ---- the ROUTED layout: rows travel only to the owner of their image (image % world) by all_to_all ----------------
-for world in (2, 4, 8):
+for world in ((int(ONLY[6:]), ) if ONLY.startswith('routed') else (2, 4, 8)):
     inputs = [rank_inputs(r, world) for r in range(world)]
     parts = []
     for r in range(world):
@@ -100,7 +101,9 @@ for world in (2, 4, 8):
         parts.append(torch.cat([rows, p[k].float()[:, None]], 1))
     # what every source sends to rank 0, in source order (a source's rows sorted by destination keep their order)
     to0 = [t[(t[:, 7].long() % world) == 0] for t in parts]
-    mat = torch.stack([torch.bincount(t[:, 7].long() % world, minlength=world) for t in parts]).to(dev)   # mat[src][dst]
+    others = torch.cat(to0[1:], 0)            # what the all_to_all delivers from the other ranks, in source order
+    mat = torch.stack([torch.cat([torch.bincount(t[:, 7].long() % world, minlength=world), torch.zeros(1, dtype=torch.int64, device=dev)])
+                       for t in parts]).to(dev)   # mat[src][dst] | unordered keys
 
     def fake_allgather(out, inp, group=None):
         out.copy_(mat.reshape(-1))            # (row 0 is what this rank just counted itself)
@@ -108,9 +111,7 @@ for world in (2, 4, 8):
     def fake_all_to_all(recv, send, out_splits, in_splits, group=None):
         o = in_splits[0]
         recv[:o] = send[:o]                   # this rank's own rows for itself
-        for src in range(1, world):           # the others' rows are "received"
-            recv[o:o + out_splits[src]] = to0[src]
-            o += out_splits[src]
+        recv[o:] = others                     # the others' rows are "received"
 
     real = (dota_merge.dist.all_gather_into_tensor, dota_merge.dist.all_to_all_single, dota_merge._world)
     dota_merge.dist.all_gather_into_tensor, dota_merge.dist.all_to_all_single = fake_allgather, fake_all_to_all
