@@ -561,12 +561,7 @@ __global__ __launch_bounds__(256) void nms_prepq_kernel(const float *__restrict_
     u = u < 0.0f ? 0.0f : (u > (float)kQMax ? (float)kQMax : u);   // (NaN -> kQMax by the second select: never happens, x is finite)
     return (uint32_t)u;
   };
-  const int lane = threadIdx.x & 63;
-  for (int64_t b0 = (int64_t)blockIdx.x * blockDim.x; b0 < n; b0 += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t b = b0 + threadIdx.x;
-    const bool valid = b < n;
-    uint32_t mk = 0;
-    if (valid) {
+  for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n; b += (int64_t)gridDim.x * blockDim.x) {
     const float *row = dets + b * S;
     Quad q;
     load_quad<KIND>(row, q);
@@ -590,7 +585,7 @@ __global__ __launch_bounds__(256) void nms_prepq_kernel(const float *__restrict_
     const float big = 3.0e38f;
     const bool fin = wellformed && (fabs_sel(v.x) < big) && (fabs_sel(v.y) < big) && (fabs_sel(v.z) < big) && (fabs_sel(v.w) < big);
     uint2 o = make_uint2(kSentLo, kSentHi);
-    mk = (1u << (2 * cell_hbits)) - 1u;  // isolated boxes go to the last cell
+    uint32_t mk = (1u << (2 * cell_hbits)) - 1u;  // isolated boxes go to the last cell
     if (fin) {
       const uint32_t xl = qz(v.x, fr.bx, fr.sx), xh = qz(v.y, fr.bx, fr.sx);
       const uint32_t yl = qz(v.z, fr.by, fr.sy), yh = qz(v.w, fr.by, fr.sy);
@@ -602,31 +597,8 @@ __global__ __launch_bounds__(256) void nms_prepq_kernel(const float *__restrict_
     }
     qb[b] = o;
     ckey[b] = mk;
-    }
-    // the count of the cell AND this box's rank inside it (one round of scattered atomics per call).  Rows that
-    // arrive clustered (the detections of one object, of one patch) hit the same cell from many lanes, and
-    // same-address atomics are served one after the other: where neighbouring lanes share cells, the lanes of a
-    // cell elect a leader that adds their number once (still ONE round: all leaders' atomics are issued together).
-    uint32_t rank = 0;
-    const uint32_t nb = (uint32_t)__shfl_xor((int)mk, 1);
-    if (__popcll(__ballot(valid && nb == mk)) >= 16) {          // (wave-uniform)
-      int leader = lane;
-      uint32_t mates = 1u, before = 0u;
-      uint64_t rem = __ballot(valid);
-      while (rem) {
-        const int lead = __builtin_ctzll(rem);
-        const uint32_t kl = (uint32_t)__builtin_amdgcn_readlane((int)mk, lead);
-        const uint64_t m = __ballot(valid && mk == kl);
-        if (valid && mk == kl) { leader = lead; mates = (uint32_t)__popcll(m); before = (uint32_t)__popcll(m & ((1ull << lane) - 1ull)); }
-        rem &= ~m;
-      }
-      uint32_t base = 0;
-      if (valid && leader == lane) base = atomicAdd(&hist[mk], mates);
-      rank = (uint32_t)__shfl((int)base, leader) + before;
-    } else if (valid) {
-      rank = atomicAdd(&hist[mk], 1u);
-    }
-    if (valid) crank[b] = rank;
+    // the count of the cell AND this box's rank inside it (one round of scattered atomics per call)
+    crank[b] = atomicAdd(&hist[mk], 1u);
   }
 }
 

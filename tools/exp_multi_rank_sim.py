@@ -23,7 +23,7 @@ def rank_inputs(rank, world):
 
 
 ONLY = os.environ.get('SIM_ONLY', '')     # e.g. 'routed8': one configuration (for a kernel trace)
-for world in (() if ONLY else (1, 2, 4, 8)):
+for world in ((1, ) if ONLY == 'single' else () if ONLY else (1, 2, 4, 8)):
     layout = 'sharded' if world > 1 else 'replicated'
     inputs = [rank_inputs(r, world) for r in range(world)]
     # contributions of the other ranks to the two gathers (rows + sequence columns; keep indices)
@@ -91,7 +91,7 @@ for world in (() if ONLY else (1, 2, 4, 8)):
 
 
 # ---- the ROUTED layout: rows travel only to the owner of their image (image % world) by all_to_all ----------------
-for world in ((int(ONLY[6:]), ) if ONLY.startswith('routed') else (2, 4, 8)):
+for world in ((int(ONLY[6:]), ) if ONLY.startswith('routed') else () if ONLY else (2, 4, 8)):
     inputs = [rank_inputs(r, world) for r in range(world)]
     parts = []
     for r in range(world):
