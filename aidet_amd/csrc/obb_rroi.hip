@@ -255,13 +255,26 @@ __device__ __forceinline__ Footprint roi_footprint(const RoiFrame &f, int H, int
 
 // XCD-aware block -> (RoI, channel chunk): consecutive ids take the SAME RoI and 8 DIFFERENT
 // chunks (one per XCD under round-robin dispatch); chunks 8r .. 8r+7 ("round" r) are swept
-// over all RoIs before round r + 1 starts.
+// over all RoIs before round r + 1 starts.  A last round of fewer than 8 chunks (C = 128: four chunks of 32
+// channels) shares its t chunks among 8 / t RoIs per group of ids, so that no XCD goes without work
+// (with ids of missing chunks simply leaving, four chunks ran on half of the XCDs: twice the time).
 __device__ __forceinline__ bool block_to_work(int K, int chunks, int64_t &k, int &chunk) {
   const uint32_t lin = blockIdx.x;
-  const uint32_t c8 = lin & 7u, rest = lin >> 3;
-  k = rest % (uint32_t)K;
-  chunk = (int)((rest / (uint32_t)K) * 8u + c8);
-  return chunk < chunks;
+  const uint32_t full = (uint32_t)chunks >> 3, tail = (uint32_t)chunks & 7u;
+  const uint32_t nfull = full * (uint32_t)K * 8u;
+  if (lin < nfull) {
+    const uint32_t c8 = lin & 7u, rest = lin >> 3;
+    k = rest % (uint32_t)K;
+    chunk = (int)((rest / (uint32_t)K) * 8u + c8);
+    return true;
+  }
+  if (tail == 0u) return false;
+  const uint32_t t = lin - nfull, c8 = t & 7u, rest = t >> 3;
+  const uint32_t reps = 8u / tail;                 // RoIs per group of 8 ids
+  if (c8 >= tail * reps) return false;
+  k = (int64_t)rest * reps + c8 / tail;
+  chunk = (int)(full * 8u + c8 % tail);
+  return k < K;
 }
 
 // channels per staging pass: the largest power of two <= kMaxPassChan whose planes fit the
@@ -303,7 +316,8 @@ __device__ __forceinline__ void build_table(const RoiFrame &f, const Footprint &
 // busy -- was built and measured this round: 71 us against 50 us for this one at configs[2].
 // It needs dword DMA or register staging for the odd pitch, i.e. 4x the staging instructions,
 // and a table read per tap group)
-constexpr int kFwdStageFloats = 5120;               // LDS tile per block (20 KiB; with the pads and the table 30 KiB: 5 blocks per CU)
+constexpr int kFwdStageFloats = 5120;               // LDS tile per block (20 KiB; with the pads and the table 30 KiB: 5 blocks per CU;
+                                                    // 4096 / 6 blocks per CU was measured: 39 -> 44 us at configs[2], more passes and 6 spilled registers)
 constexpr int kWaveFloats = kFwdStageFloats / 4;    // private quarter of a wave (small footprints)
 constexpr int kWavePad = 256;                       // room for the tail lanes of a wave's last DMA instruction
 
@@ -366,6 +380,69 @@ __global__ __launch_bounds__(256, 5) void rroi_forward_kernel(
     rroi_forward_direct(feat, C, H, W, f, k, ph, pw, c_block, c_end, out);
     return;
   }
+  // ---- small footprint (the common case): every WAVE stages and reduces its own quarter of the block's
+  // channels in a private LDS region -- no block barriers after the table's, so the four waves (and the other
+  // blocks of the CU) drift apart and one wave's DMA latency hides behind another's gathers.  A lane owns one
+  // bin: its <= 4 samples' tap offsets and weights are read from the table ONCE into registers and reused for
+  // every channel.  The wave's FIRST pass is requested before the sample table is built: the copy depends on
+  // the footprint only, and the table (trigonometry, ~100 instructions, a block barrier) is done while it travels.
+  const bool small = fsz <= kWaveFloats && nb <= 64 && spb <= 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float *wt = tile + wave * (kWaveFloats + kWavePad);
+  const int per_wave = (c_end - c_block + 3) >> 2;
+  const int cw0 = c_block + wave * per_wave, cw1 = min(c_end, cw0 + per_wave);
+  const int cpw = small ? kWaveFloats / fsz : 1;     // channels per pass (>= 1)
+  const uint32_t plane32w = (uint32_t)plane;
+  // source offsets of a pass's DMA instructions: the same for every pass (only the channel base moves),
+  // computed ONCE per wave -- slot -> (channel, row, chunk) costs two multiply-high divisions per lane
+  // (a bound that depends on X4 -- `X4 ? 5 : 1` -- made hipcc 7.2 drop the kernel's host stub without a diagnostic)
+  constexpr int kMaxInst = 5;                       // 16-byte path: <= kWaveFloats / 256 instructions per pass
+  static_assert(kMaxInst * 256 == kWaveFloats, "one pass = at most kMaxInst 1-KiB DMA instructions");
+  uint32_t doff[kMaxInst], dch[kMaxInst];
+  const int slots = X4 ? (fsz >> 2) : fsz;           // 16-byte (dword) slots per channel
+  const int rslots = X4 ? (pitch >> 2) : pitch;      // ... per row (the last one is the pad)
+  const int rvalid = X4 ? (fp.w >> 2) : fp.w;        // ... that hold pixels
+  const uint32_t m_slots = slots > 1 ? 0xFFFFFFFFu / (uint32_t)slots + 1u : 0u;
+  const uint32_t m_rslots = rslots > 1 ? 0xFFFFFFFFu / (uint32_t)rslots + 1u : 0u;
+  auto slot_off = [&](uint32_t idx, uint32_t &c) -> uint32_t {
+    c = slots > 1 ? __umulhi(idx, m_slots) : idx;
+    const uint32_t r = idx - c * (uint32_t)slots;
+    const uint32_t y = rslots > 1 ? __umulhi(r, m_rslots) : r;
+    uint32_t x = r - y * (uint32_t)rslots;
+    x = min(x, (uint32_t)(rvalid - 1));              // the pad slot re-loads the row's last chunk
+    return y * (uint32_t)W + (X4 ? (x << 2) : x);
+  };
+  auto stage_pass = [&](int cp) {
+    const int nch = min(cpw, cw1 - cp);
+    const float *src = feat + ((int64_t)f.b * C + cp) * plane + (int64_t)fp.y0 * W + fp.x0;
+    const int total = nch * slots;
+    if (X4) {
+#pragma unroll
+      for (int j = 0; j < kMaxInst; ++j) {
+        if (j * 64 < total) {                        // (wave-uniform)
+          // a last, shorter pass: slots of channels it does not have re-load its last channel
+          const uint32_t c = min(dch[j], (uint32_t)(nch - 1));
+          __builtin_amdgcn_global_load_lds(src + (c * plane32w + doff[j]), (__attribute__((address_space(3))) void *)(wt + j * 256), 16, 0, 0);
+        }
+      }
+    } else {
+      for (int base = 0; base < total; base += 64) {
+        uint32_t c;
+        const uint32_t o = slot_off((uint32_t)min(base + lane, total - 1), c);
+        __builtin_amdgcn_global_load_lds(src + (c * plane32w + o), (__attribute__((address_space(3))) void *)(wt + base), 4, 0, 0);
+      }
+    }
+  };
+  if (small) {
+    if (X4) {
+#pragma unroll
+      for (int j = 0; j < kMaxInst; ++j) {
+        const uint32_t idx = (uint32_t)min(j * 64 + lane, cpw * slots - 1);
+        doff[j] = slot_off(idx, dch[j]);
+      }
+    }
+    if (cw0 < cw1) stage_pass(cw0);
+  }
   // sample table: coordinates, taps and weights are computed ONCE per RoI and block
   // (the reference recomputes them for every output element, roi_align_kernel.cu:70-113)
   for (int sidx = threadIdx.x; sidx < nsamp; sidx += 256) {
@@ -384,17 +461,8 @@ __global__ __launch_bounds__(256, 5) void rroi_forward_kernel(
                        : make_ushort4(0, 0, 0, 0);
     s_wgt[sidx] = make_float4(w[0], w[1], w[2], w[3]);
   }
-  if (fsz <= kWaveFloats && nb <= 64 && spb <= 4) {
-    // ---- small footprint (the common case): every WAVE stages and reduces its own quarter of
-    // the block's channels in a private LDS region -- no block barriers after this one, so
-    // the four waves (and the other blocks of the CU) drift apart and one wave's DMA latency
-    // hides behind another's gathers.  A lane owns one bin: its <= 4 samples' tap offsets
-    // and weights are read from the table ONCE into registers and reused for every channel.
+  if (small) {
     __syncthreads();   // table complete
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float *wt = tile + wave * (kWaveFloats + kWavePad);
-    const int per_wave = (c_end - c_block + 3) >> 2;
-    const int cw0 = c_block + wave * per_wave, cw1 = min(c_end, cw0 + per_wave);
     int4 so[4];
     float4 sw[4];
 #pragma unroll
@@ -404,59 +472,14 @@ __global__ __launch_bounds__(256, 5) void rroi_forward_kernel(
       so[q] = on ? make_int4(o16.x, o16.y, o16.z, o16.w) : make_int4(0, 0, 0, 0);
       sw[q] = on ? s_wgt[lane * spb + q] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    const int cpw = kWaveFloats / fsz;               // channels per pass (>= 1)
-    const uint32_t plane32w = (uint32_t)plane;
     // mean over the samples: a division, or -- a power-of-two count (2 x 2 samples), the usual case -- the
     // exact same value from a multiplication (scaling by a power of two rounds identically)
     const uint32_t cbits = __float_as_uint(f.cnt);
     const bool cnt_pow2 = (cbits & 0x007FFFFFu) == 0u && f.cnt >= 1.0f;
     const float cnt_inv = cnt_pow2 ? 1.0f / f.cnt : 0.0f;
-    // source offsets of a pass's DMA instructions: the same for every pass (only the channel base moves),
-    // computed ONCE per wave -- slot -> (channel, row, chunk) costs two multiply-high divisions per lane
-    // (a bound that depends on X4 -- `X4 ? 5 : 1` -- made hipcc 7.2 drop the kernel's host stub without a diagnostic)
-    constexpr int kMaxInst = 5;                       // 16-byte path: <= kWaveFloats / 256 instructions per pass
-    static_assert(kMaxInst * 256 == kWaveFloats, "one pass = at most kMaxInst 1-KiB DMA instructions");
-    uint32_t doff[kMaxInst], dch[kMaxInst];
-    const int slots = X4 ? (fsz >> 2) : fsz;           // 16-byte (dword) slots per channel
-    const int rslots = X4 ? (pitch >> 2) : pitch;      // ... per row (the last one is the pad)
-    const int rvalid = X4 ? (fp.w >> 2) : fp.w;        // ... that hold pixels
-    const uint32_t m_slots = slots > 1 ? 0xFFFFFFFFu / (uint32_t)slots + 1u : 0u;
-    const uint32_t m_rslots = rslots > 1 ? 0xFFFFFFFFu / (uint32_t)rslots + 1u : 0u;
-    auto slot_off = [&](uint32_t idx, uint32_t &c) -> uint32_t {
-      c = slots > 1 ? __umulhi(idx, m_slots) : idx;
-      const uint32_t r = idx - c * (uint32_t)slots;
-      const uint32_t y = rslots > 1 ? __umulhi(r, m_rslots) : r;
-      uint32_t x = r - y * (uint32_t)rslots;
-      x = min(x, (uint32_t)(rvalid - 1));              // the pad slot re-loads the row's last chunk
-      return y * (uint32_t)W + (X4 ? (x << 2) : x);
-    };
-    if (X4) {
-#pragma unroll
-      for (int j = 0; j < kMaxInst; ++j) {
-        const uint32_t idx = (uint32_t)min(j * 64 + lane, cpw * slots - 1);
-        doff[j] = slot_off(idx, dch[j]);
-      }
-    }
     for (int cp = cw0; cp < cw1; cp += cpw) {
       const int nch = min(cpw, cw1 - cp);
-      const float *src = feat + ((int64_t)f.b * C + cp) * plane + (int64_t)fp.y0 * W + fp.x0;
-      const int total = nch * slots;
-      if (X4) {
-#pragma unroll
-        for (int j = 0; j < kMaxInst; ++j) {
-          if (j * 64 < total) {                        // (wave-uniform)
-            // a last, shorter pass: slots of channels it does not have re-load its last channel
-            const uint32_t c = min(dch[j], (uint32_t)(nch - 1));
-            __builtin_amdgcn_global_load_lds(src + (c * plane32w + doff[j]), (__attribute__((address_space(3))) void *)(wt + j * 256), 16, 0, 0);
-          }
-        }
-      } else {
-        for (int base = 0; base < total; base += 64) {
-          uint32_t c;
-          const uint32_t o = slot_off((uint32_t)min(base + lane, total - 1), c);
-          __builtin_amdgcn_global_load_lds(src + (c * plane32w + o), (__attribute__((address_space(3))) void *)(wt + base), 4, 0, 0);
-        }
-      }
+      if (cp != cw0) stage_pass(cp);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_wave_barrier();
       auto bin_sum = [&](const float *p) -> float {
@@ -1130,7 +1153,15 @@ __global__ __launch_bounds__(1024) void rroi_order_kernel(const LevelTable lv, c
     const int l = roi_level ? roi_level[k] : 0;
     return roi_order_key(rois + (int64_t)k * S, roi_kind, (l >= 0 && l < num_levels) ? (l & 7) : 0, lv);
   };
-  for (int k = tid; k < K; k += 1024) tmp[k] = (int)atomicAdd(&hist[key_of(k)], 1u);   // rank inside the cell
+  // (key, rank inside the cell) of a thread's first four RoIs stay in registers; only RoIs beyond 4096 go through `tmp`
+  uint32_t rkey[4], rrank[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int k = tid + u * 1024;
+    rkey[u] = 0u; rrank[u] = 0u;
+    if (k < K) { rkey[u] = key_of(k); rrank[u] = atomicAdd(&hist[rkey[u]], 1u); }
+  }
+  for (int k = tid + 4096; k < K; k += 1024) tmp[k] = (int)atomicAdd(&hist[key_of(k)], 1u);
   __syncthreads();
   {  // exclusive scan of the 8192 counts: 8 per thread
     uint32_t v[8], tot = 0;
@@ -1146,7 +1177,12 @@ __global__ __launch_bounds__(1024) void rroi_order_kernel(const LevelTable lv, c
     for (int u = 0; u < 8; ++u) { hist[tid * 8 + u] = base; base += v[u]; }
     __syncthreads();
   }
-  for (int k = tid; k < K; k += 1024) order[hist[key_of(k)] + (uint32_t)tmp[k]] = k;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int k = tid + u * 1024;
+    if (k < K) order[hist[rkey[u]] + rrank[u]] = k;
+  }
+  for (int k = tid + 4096; k < K; k += 1024) order[hist[key_of(k)] + (uint32_t)tmp[k]] = k;
 }
 
 static int rroi_check(const char *who, int B, int C, int H, int W, int64_t K, int ph, int pw) {
@@ -1179,7 +1215,9 @@ static int rroi_geometry(const char *who, int C, bool backward, int64_t K, int &
                          unsigned long long &nblk) {
   cpb = rroi_chan_per_block(C, backward);
   chunks = (unsigned)((C + cpb - 1) / cpb);
-  nblk = (unsigned long long)((chunks + 7u) / 8u) * 8ull * (unsigned long long)K;
+  const unsigned tail = chunks & 7u;             // (block_to_work: the last, partial round packs 8 / tail RoIs per group)
+  nblk = (unsigned long long)(chunks >> 3) * 8ull * (unsigned long long)K;
+  if (tail) nblk += ((unsigned long long)K + 8u / tail - 1) / (8u / tail) * 8ull;
   if (nblk > 2147483647ull) return set_err(OBB_EINVAL, "%s: too many blocks (K=%lld, C=%d)", who, (long long)K, C);
   return OBB_OK;
 }
