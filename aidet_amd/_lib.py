@@ -80,6 +80,12 @@ def lib():
                                                 ctypes.POINTER(i32), i32, i32, i32, i32, ctypes.POINTER(f32), ctypes.POINTER(f32),
                                                 f32, i32, i32, vp, vp, ctypes.POINTER(i64), vp]
         L.obb_rpn_select_decode_f32.restype = i32
+        L.obb_rpn_select_decode_ws_f32.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(i32),
+                                                   ctypes.POINTER(i32), i32, i32, i32, i32, ctypes.POINTER(f32), ctypes.POINTER(f32),
+                                                   f32, i32, i32, vp, vp, ctypes.POINTER(i64), vp, ctypes.c_size_t, vp]
+        L.obb_rpn_select_decode_ws_f32.restype = i32
+        L.obb_rpn_select_workspace_bytes.argtypes = [ctypes.POINTER(i32), ctypes.POINTER(i32), i32, i32, i32]
+        L.obb_rpn_select_workspace_bytes.restype = ctypes.c_size_t
         L.obb_rows_topk_f32.argtypes = [vp, i64, i32, i32, vp, i64, ctypes.POINTER(i32), i32, i32, i32, vp, vp, vp, vp]
         L.obb_rows_topk_f32.restype = i32
         L.obb_head_select_decode_f32.argtypes = [vp, vp, vp, i64, i32, i32, i32, f32, ctypes.POINTER(f32), ctypes.POINTER(f32), f32,

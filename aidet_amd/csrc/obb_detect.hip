@@ -35,29 +35,50 @@ __device__ __forceinline__ uint32_t sel_key(float f) {
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);   // (>= 0x007FFFFF for -inf: never 0 or 1)
 }
 
-// In-place bitonic sort of k entries by (key descending, index ascending); the arrays must have room for k rounded up
-// to a power of two (the padding sorts last).  66 barrier steps at k = 2048, ~30 us.  (A rank sort -- count the
-// entries that come before each one -- needs no barrier but k^2 compares: 80-100 us of LDS / VALU time on one CU at
-// k = 2000; it was the larger part of the first version of these kernels.)
+// In-place bitonic sort of k <= 2048 entries by (key descending, index ascending); the arrays hold kSelMax entries.
+// A thread keeps the entries at positions t and t + 1024 in registers (positions >= k: padding that sorts last): the
+// exchange at distance 1024 is inside the thread, distances below 64 are wave shuffles, only the 14 steps at distances
+// 64..512 go through LDS and a barrier.  (The all-LDS network was 66 barrier steps, ~30 us at k = 2048, the larger part
+// of every selection kernel; a rank sort -- count the entries that come before each one -- needs no barrier but k^2
+// compares: 80-100 us on one CU.)
 __device__ __forceinline__ void bitonic_sort(uint32_t *sk, uint32_t *si, int k) {
-  const int tid = threadIdx.x;
-  int m = 1;
-  while (m < k) m <<= 1;
-  for (int i = k + tid; i < m; i += kSelThreads) { sk[i] = 0u; si[i] = 0xFFFFFFFFu; }
+  static_assert(kSelMax == 2048 && kSelThreads == 1024, "two entries per thread");
+  const int t = threadIdx.x;
+  uint32_t k0 = t < k ? sk[t] : 0u, i0 = t < k ? si[t] : 0xFFFFFFFFu;
+  uint32_t k1 = t + 1024 < k ? sk[t + 1024] : 0u, i1 = t + 1024 < k ? si[t + 1024] : 0xFFFFFFFFu;
   __syncthreads();
-  auto before = [](uint32_t ka, uint32_t ia, uint32_t kb, uint32_t ib) { return ka > kb || (ka == kb && ia < ib); };
-  for (int size = 2; size <= m; size <<= 1) {
+  // keep the better (sorts first) or the worse of (mine, partner)
+  auto cx = [](uint32_t &mk, uint32_t &mi, uint32_t pk, uint32_t pi, bool take_better) {
+    const bool mine_first = mk > pk || (mk == pk && mi < pi);
+    if (take_better != mine_first) { mk = pk; mi = pi; }
+  };
+  for (int size = 2; size <= 2048; size <<= 1) {
+    const bool up0 = (t & size) == 0, up1 = ((t + 1024) & size) == 0;   // run sorted "best first"?
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      for (int t2 = tid; t2 < (m >> 1); t2 += kSelThreads) {
-        const int lo = ((t2 / stride) * 2 * stride) + (t2 % stride), hi = lo + stride;
-        const bool up = ((lo & size) == 0);             // this run is sorted "best first"
-        const uint32_t ka = sk[lo], ia = si[lo], kb = sk[hi], ib = si[hi];
-        const bool swap = up ? before(kb, ib, ka, ia) : before(ka, ia, kb, ib);
-        if (swap) { sk[lo] = kb; si[lo] = ib; sk[hi] = ka; si[hi] = ia; }
+      if (stride == 1024) {                           // (size 2048: both entries of the thread, best first)
+        const bool swap = k1 > k0 || (k1 == k0 && i1 < i0);
+        if (swap) { uint32_t a = k0; k0 = k1; k1 = a; a = i0; i0 = i1; i1 = a; }
+        continue;
       }
-      __syncthreads();
+      const bool am_lo = (t & stride) == 0;
+      uint32_t pk0, pi0, pk1, pi1;
+      if (stride < 64) {
+        pk0 = (uint32_t)__shfl_xor((int)k0, stride); pi0 = (uint32_t)__shfl_xor((int)i0, stride);
+        pk1 = (uint32_t)__shfl_xor((int)k1, stride); pi1 = (uint32_t)__shfl_xor((int)i1, stride);
+      } else {
+        sk[t] = k0; si[t] = i0; sk[t + 1024] = k1; si[t + 1024] = i1;
+        __syncthreads();
+        const int q = t ^ stride;
+        pk0 = sk[q]; pi0 = si[q]; pk1 = sk[q + 1024]; pi1 = si[q + 1024];
+        __syncthreads();
+      }
+      cx(k0, i0, pk0, pi0, am_lo == up0);
+      cx(k1, i1, pk1, pi1, am_lo == up1);
     }
   }
+  if (t < k) { sk[t] = k0; si[t] = i0; }
+  if (t + 1024 < k) { sk[t + 1024] = k1; si[t + 1024] = i1; }
+  __syncthreads();
 }
 
 struct SelScratch {
@@ -85,6 +106,36 @@ __device__ __forceinline__ void hist_add(uint32_t *hist, uint32_t digit, bool ac
     rem &= ~m;
   }
   if ((rem >> lane) & 1ull) atomicAdd(&hist[digit], 1u);
+}
+
+// One digit of a radix select: given the counts of the candidates' digits (bin(b), b in [0, nb)), the digit d with
+// count(digits > d) < krem <= count(digits >= d) -- suffix sums over the bins; sc.prefix / sc.krem move on to it.
+// All 1024 threads call it; it ends with a barrier.
+template <class BinFn>
+__device__ __forceinline__ void radix_digit(BinFn bin, int nb, int sh, uint32_t pre, SelScratch &sc) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int per = nb / kSelThreads > 0 ? nb / kSelThreads : 1;     // 2 bins per thread (11 bits) or 1
+  uint32_t v[2] = {0u, 0u}, tot = 0u;
+  for (int u = 0; u < per; ++u) { const int b = tid * per + u; v[u] = b < nb ? bin(b) : 0u; tot += v[u]; }
+  // inclusive suffix sum across threads: reverse the lane / wave order
+  uint32_t inc = tot;
+  for (int o = 1; o < 64; o <<= 1) { const uint32_t t2 = (uint32_t)__shfl_down((int)inc, o); if (lane + o < 64) inc += t2; }
+  if (lane == 0) sc.wsum[wave] = inc;
+  __syncthreads();
+  uint32_t above = inc - tot;                       // bins of later lanes of this wave
+  for (int w2 = wave + 1; w2 < kSelThreads / 64; ++w2) above += sc.wsum[w2];
+  // bins of this thread, from the highest down
+  const uint32_t kr = sc.krem;
+  __syncthreads();
+  for (int u = per - 1; u >= 0; --u) {
+    const int b = tid * per + u;
+    if (b < nb && above < kr && kr <= above + v[u]) {   // exactly one (thread, bin) satisfies this
+      sc.prefix = pre | ((uint32_t)b << sh);
+      sc.krem = kr - above;
+    }
+    above += v[u];
+  }
+  __syncthreads();
 }
 
 // Exact top-k of key(i), i in [0, n): on return sk[0..k) / si[0..k) hold the k largest keys and their indices,
@@ -119,31 +170,7 @@ __device__ void block_topk_sorted(KeyFn key, int n, int k, uint32_t *sk, uint32_
       }
     }
     __syncthreads();
-    // the digit d with  count(digits > d) < krem <= count(digits >= d): suffix sums over the bins
-    {
-      const int per = nb / kSelThreads > 0 ? nb / kSelThreads : 1;     // 2 bins per thread (11 bits) or 1
-      uint32_t v[2] = {0u, 0u}, tot = 0u;
-      for (int u = 0; u < per; ++u) { const int b = tid * per + u; v[u] = b < nb ? sc.hist[b] : 0u; tot += v[u]; }
-      // inclusive suffix sum across threads: reverse the lane / wave order
-      uint32_t inc = tot;
-      for (int o = 1; o < 64; o <<= 1) { const uint32_t t2 = (uint32_t)__shfl_down((int)inc, o); if (lane + o < 64) inc += t2; }
-      if (lane == 0) sc.wsum[wave] = inc;
-      __syncthreads();
-      uint32_t above = inc - tot;                       // bins of later lanes of this wave
-      for (int w2 = wave + 1; w2 < kSelThreads / 64; ++w2) above += sc.wsum[w2];
-      // bins of this thread, from the highest down
-      const uint32_t kr = sc.krem;
-      __syncthreads();
-      for (int u = per - 1; u >= 0; --u) {
-        const int b = tid * per + u;
-        if (b < nb && above < kr && kr <= above + v[u]) {   // exactly one (thread, bin) satisfies this
-          sc.prefix = pre | ((uint32_t)b << sh);
-          sc.krem = kr - above;
-        }
-        above += v[u];
-      }
-      __syncthreads();
-    }
+    radix_digit([&](int b) { return sc.hist[b]; }, nb, sh, pre, sc);
     himask |= (uint32_t)(nb - 1) << sh;
   }
   const uint32_t T = sc.prefix;
@@ -193,6 +220,11 @@ __device__ void block_topk_sorted(KeyFn key, int n, int k, uint32_t *sk, uint32_
 // the exact selection among the <= 8192 candidates.  Too few candidates (< k) or a full segment: the plain routine.
 constexpr int kCandCap = 8192, kCandPerWave = kCandCap / (kSelThreads / 64);
 constexpr int kSampleN = 2048;
+__device__ __forceinline__ int prefilter_rank(int k, int n) {
+  int q = (int)((2.0f * (float)k / (float)n) * (float)kSampleN) + 1;
+  return q < 8 ? 8 : (q > kSampleN ? kSampleN : q);
+}
+__device__ __forceinline__ int sample_pos(int j, int n) { return (int)(((uint64_t)(uint32_t)j * 2654435761ull) % (uint64_t)n); }
 template <class KeyFn>
 __device__ void block_topk_sorted_big(KeyFn key, int n, int k, uint32_t *sk, uint32_t *si, uint32_t *ck, uint32_t *ci,
                                       SelScratch &sc) {
@@ -200,9 +232,8 @@ __device__ void block_topk_sorted_big(KeyFn key, int n, int k, uint32_t *sk, uin
   // sample: kSampleN strided keys; its q-th largest, q = 2 k / n of the sample, is the prefilter threshold
   // (pseudo-random positions: a fixed stride of n / 2048 is a multiple of the anchors per location on every FPN level,
   // i.e. it would sample ONE anchor shape -- whose scores are shifted against the others' -- and miss the threshold)
-  int q = (int)((2.0f * (float)k / (float)n) * (float)kSampleN) + 1;
-  q = q < 8 ? 8 : (q > kSampleN ? kSampleN : q);
-  for (int j = tid; j < kSampleN; j += kSelThreads) ck[j] = key((int)(((uint64_t)(uint32_t)j * 2654435761ull) % (uint64_t)n));
+  const int q = prefilter_rank(k, n);
+  for (int j = tid; j < kSampleN; j += kSelThreads) ck[j] = key(sample_pos(j, n));
   __syncthreads();
   block_topk_sorted([&](int j) { return ck[j]; }, kSampleN, q, sk, si, sc);
   const uint32_t T0 = sk[q - 1];
@@ -280,10 +311,134 @@ __device__ __forceinline__ float4 decode_box(float ax1, float ay1, float ax2, fl
   return make_float4(x1, y1, x2, y2);
 }
 
+// ---- large levels over several workgroups (with a workspace) -----------------------------------------------------
+// One workgroup walking the 196 608 anchors of a stride-4 level is 0.32 ms of a 0.8 ms RPN stage (the sampled
+// prefilter above does not help where the logits cluster -- a random-init head: thousands of keys AT the threshold).
+// With a workspace a level is dealt to one workgroup per SLICE of 8192 anchors and selected EXACTLY by all of them
+// together: every thread keeps its 8 keys in registers (the level is read ONCE), each radix digit is a block
+// histogram added to the level's global one, a barrier among the level's workgroups (they are few -- 24 for a stride-4
+// level -- and co-resident: one per CU), and the same digit search in every workgroup; then the counts of keys above /
+// at the threshold per slice, one more barrier, and every workgroup writes its share of the k selected (key, anchor)
+// pairs -- keys above the threshold, then the first ties in ANCHOR order -- to the level's list.  The level's
+// workgroup of rpn_select_decode_kernel sorts and decodes that list.
+constexpr int kSliceAnchors = 8192;      // anchors per workgroup (8 per thread)
+constexpr int kMaxSlices = 64;           // slices per level (levels of up to 524 288 anchors)
+constexpr int kGroupMaxBlocks = 192;     // workgroups of one launch: all must be resident at once (256 CUs)
+constexpr int kGroupWords = 3 * 2048 + 8;   // per level: three global histograms + barrier counters
+struct RpnGroup {
+  int first_slice[OBB_MAX_LEVELS + 1];   // first slice of every level (a level without slices: same as the next)
+  uint32_t *words;                       // [levels][kGroupWords] zeroed before the launch
+  uint32_t *bcnt;                        // [slices][2] keys above / at the threshold
+  uint2 *sel;                            // [levels][kSelMax] the selected (key, anchor index) pairs
+};
+
+__device__ __forceinline__ uint32_t ld_agent(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// barrier among the `members` workgroups of a level (counter zero before the launch, used once)
+// (what the workgroups exchange is written by agent-scope atomics only -- performed at the coherence point, nothing
+// dirty in a cache -- and read back by agent-scope loads: every wave waits for its own atomics to be acknowledged,
+// then ONE thread arrives; a release / acquire fence pair would cost a cache write-back and invalidate per barrier)
+__device__ __forceinline__ void group_barrier(uint32_t *counter, uint32_t members) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < members) __builtin_amdgcn_s_sleep(2);
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(kSelThreads) void rpn_group_select_kernel(const RpnLevels lv, int A, int use_sigmoid, int num_levels,
+                                                                      const RpnGroup g) {
+  __shared__ SelScratch sc;
+  __shared__ int wc[2][kSliceAnchors / kSelThreads][kSelThreads / 64];
+  __shared__ uint32_t soff[2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int l = 0;
+  while (l + 1 < num_levels && (int)blockIdx.x >= g.first_slice[l + 1]) ++l;
+  const int slice = (int)blockIdx.x - g.first_slice[l];
+  const uint32_t members = (uint32_t)(g.first_slice[l + 1] - g.first_slice[l]);
+  const int HW = lv.H[l] * lv.W[l], n = HW * A;
+  const float *__restrict__ cls = lv.cls[l];
+  const int k = lv.out_base[l + 1] - lv.out_base[l];
+  uint32_t *ghist = g.words + (size_t)l * kGroupWords, *bar = ghist + 3 * 2048;
+  constexpr int kU = kSliceAnchors / kSelThreads;
+  uint32_t kk[kU];
+  bool in[kU];
+#pragma unroll
+  for (int u = 0; u < kU; ++u) {
+    const int i = slice * kSliceAnchors + u * kSelThreads + tid;
+    in[u] = i < n;
+    const int ii = in[u] ? i : n - 1;
+    const int p = ii / A, a = ii - p * A;
+    kk[u] = sel_key(use_sigmoid ? cls[a * HW + p] : cls[(2 * a + 1) * HW + p] - cls[(2 * a) * HW + p]);
+  }
+  if (tid == 0) { sc.prefix = 0u; sc.krem = (uint32_t)k; }
+  __syncthreads();
+  uint32_t himask = 0u;
+#pragma unroll
+  for (int pass = 0; pass < 3; ++pass) {
+    const int sh = pass == 0 ? 21 : (pass == 1 ? 10 : 0), nb = pass == 2 ? 1024 : 2048;
+    for (int b = tid; b < nb; b += kSelThreads) sc.hist[b] = 0u;
+    __syncthreads();
+    const uint32_t pre = sc.prefix;
+#pragma unroll
+    for (int u = 0; u < kU; ++u) hist_add(sc.hist, (kk[u] >> sh) & (uint32_t)(nb - 1), in[u] && (kk[u] & himask) == pre, lane);
+    __syncthreads();
+    uint32_t *gh = ghist + pass * 2048;
+    for (int b = tid; b < nb; b += kSelThreads) { const uint32_t v = sc.hist[b]; if (v) atomicAdd(&gh[b], v); }
+    group_barrier(&bar[pass], members);
+    radix_digit([&](int b) { return ld_agent(&gh[b]); }, nb, sh, pre, sc);
+    himask |= (uint32_t)(nb - 1) << sh;
+  }
+  const uint32_t T = sc.prefix;
+  const int need_eq = (int)sc.krem, ngt_total = k - need_eq;
+  // ---- this slice's keys above / at the threshold, in anchor order (pass-major, then thread)
+  uint64_t mg[kU], me[kU];
+#pragma unroll
+  for (int u = 0; u < kU; ++u) {
+    mg[u] = __ballot(in[u] && kk[u] > T);
+    me[u] = __ballot(in[u] && kk[u] == T);
+    if (lane == 0) { wc[0][u][wave] = __popcll(mg[u]); wc[1][u][wave] = __popcll(me[u]); }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int tg = 0, te = 0;
+    for (int u = 0; u < kU; ++u)
+      for (int w2 = 0; w2 < kSelThreads / 64; ++w2) { tg += wc[0][u][w2]; te += wc[1][u][w2]; }
+    __hip_atomic_store(&g.bcnt[2 * blockIdx.x], (uint32_t)tg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&g.bcnt[2 * blockIdx.x + 1], (uint32_t)te, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  group_barrier(&bar[3], members);
+  if (wave == 0) {                                     // keys of the earlier slices of this level (<= 64 slices: one wave)
+    uint32_t vg = 0, ve = 0;
+    if (lane < slice) { vg = ld_agent(&g.bcnt[2 * (g.first_slice[l] + lane)]); ve = ld_agent(&g.bcnt[2 * (g.first_slice[l] + lane) + 1]); }
+    for (int o = 32; o > 0; o >>= 1) { vg += (uint32_t)__shfl_xor((int)vg, o); ve += (uint32_t)__shfl_xor((int)ve, o); }
+    if (lane == 0) { soff[0] = vg; soff[1] = ve; }
+  }
+  __syncthreads();
+  uint2 *out = g.sel + (size_t)l * kSelMax;
+  int rung = (int)soff[0], rune = (int)soff[1];
+#pragma unroll
+  for (int u = 0; u < kU; ++u) {
+    int og = 0, oe = 0, tg = 0, te = 0;
+#pragma unroll
+    for (int w2 = 0; w2 < kSelThreads / 64; ++w2) {
+      const int a = wc[0][u][w2], b2 = wc[1][u][w2];
+      og += (w2 < wave) ? a : 0; oe += (w2 < wave) ? b2 : 0; tg += a; te += b2;
+    }
+    const uint64_t lt = (1ull << lane) - 1ull;
+    const uint32_t idx = (uint32_t)(slice * kSliceAnchors + u * kSelThreads + tid);
+    if ((mg[u] >> lane) & 1ull) { const int pos = rung + og + __popcll(mg[u] & lt); if (pos < ngt_total) out[pos] = make_uint2(kk[u], idx); }
+    if ((me[u] >> lane) & 1ull) { const int r = rune + oe + __popcll(me[u] & lt); if (r < need_eq) out[ngt_total + r] = make_uint2(kk[u], idx); }
+    rung += tg; rune += te;
+  }
+}
+
 __global__ __launch_bounds__(kSelThreads) void rpn_select_decode_kernel(const RpnLevels lv, int A, int use_sigmoid,
                                                                         int nms_pre, const BoxCodec codec,
                                                                         float *__restrict__ dets,
-                                                                        int32_t *__restrict__ levels) {
+                                                                        int32_t *__restrict__ levels, const RpnGroup g) {
   __shared__ uint32_t sk[kSelMax], si[kSelMax];
   __shared__ uint32_t ck[kCandCap], ci[kCandCap];
   __shared__ SelScratch sc;
@@ -302,7 +457,16 @@ __global__ __launch_bounds__(kSelThreads) void rpn_select_decode_kernel(const Rp
     return cls[(2 * a + 1) * HW + p] - cls[(2 * a) * HW + p];
   };
   const bool select = k < n;
-  if (select) {
+  bool done = false;
+  if (select && g.sel && g.first_slice[l + 1] > g.first_slice[l]) {
+    // the k (key, anchor) pairs rpn_group_select_kernel left for this level: sort them
+    const uint2 *list = g.sel + (size_t)l * kSelMax;
+    for (int j = tid; j < k; j += kSelThreads) { const uint2 e = list[j]; sk[j] = e.x; si[j] = e.y; }
+    __syncthreads();
+    bitonic_sort(sk, si, k);
+    done = true;
+  }
+  if (select && !done) {
     if (n >= 4 * kCandCap) block_topk_sorted_big([&](int i) { return sel_key(logit(i)); }, n, k, sk, si, ck, ci, sc);
     else block_topk_sorted([&](int i) { return sel_key(logit(i)); }, n, k, sk, si, sc);
   }
@@ -446,6 +610,7 @@ __global__ __launch_bounds__(256) void head_gather_decode_kernel(const float *__
 }
 
 struct LevelBases { int num; int base[OBB_MAX_LEVELS + 1]; };
+constexpr int kRowsKeys = 12288;     // kept rows whose keys rows_topk_kernel holds in LDS (48 KiB; five levels x 2000 fit)
 
 // rows[keep] -> per-level cut (rank inside the level < nms_post; keep is ascending and the rows are level-major) ->
 // the `top` best by column `score_col`, descending (equal scores: the earlier row first)
@@ -455,6 +620,7 @@ __global__ __launch_bounds__(kSelThreads) void rows_topk_kernel(const float *__r
                                                                 float *__restrict__ out, int64_t *__restrict__ out_idx,
                                                                 int64_t *__restrict__ count) {
   __shared__ uint32_t sk[kSelMax], si[kSelMax];
+  __shared__ uint32_t skeys[kRowsKeys];
   __shared__ SelScratch sc;
   __shared__ int before_level[OBB_MAX_LEVELS + 1];   // kept rows below the first row of every level
   __shared__ int nvalid;
@@ -481,7 +647,14 @@ __global__ __launch_bounds__(kSelThreads) void rows_topk_kernel(const float *__r
   const int k = nvalid < top ? nvalid : top;
   if (tid == 0) count[0] = k;
   if (k == 0) return;
-  block_topk_sorted([&](int j) { return valid(j) ? sel_key(rows[keep[j] * cols + score_col]) : 0u; }, K, k, sk, si, sc);
+  // the keys are read four times by the selection: once from memory (two dependent loads each), then from LDS
+  if (K <= kRowsKeys) {
+    for (int j = tid; j < K; j += kSelThreads) skeys[j] = valid(j) ? sel_key(rows[keep[j] * cols + score_col]) : 0u;
+    __syncthreads();
+    block_topk_sorted([&](int j) { return skeys[j]; }, K, k, sk, si, sc);
+  } else {
+    block_topk_sorted([&](int j) { return valid(j) ? sel_key(rows[keep[j] * cols + score_col]) : 0u; }, K, k, sk, si, sc);
+  }
   for (int j = tid; j < k; j += kSelThreads) {
     const int64_t r = keep[si[j]];
     for (int c = 0; c < cols; ++c) out[(size_t)j * cols + c] = rows[r * cols + c];
@@ -491,12 +664,51 @@ __global__ __launch_bounds__(kSelThreads) void rows_topk_kernel(const float *__r
 
 }  // namespace obb
 
+namespace obb {
+// slices of the levels that are selected by several workgroups: a real cut (n > nms_pre) of at least two slices
+static int rpn_slices(const int *H_host, const int *W_host, int num_levels, int num_anchors, int nms_pre, int *first_slice) {
+  int total = 0;
+  for (int l = 0; l < num_levels; ++l) {
+    first_slice[l] = total;
+    const int64_t n = (int64_t)H_host[l] * W_host[l] * num_anchors;
+    const int64_t sl = (n + kSliceAnchors - 1) / kSliceAnchors;
+    if (nms_pre > 0 && n > nms_pre && sl >= 2 && sl <= kMaxSlices && total + sl <= kGroupMaxBlocks) total += (int)sl;
+  }
+  first_slice[num_levels] = total;
+  return total;
+}
+static size_t rpn_ws_zeroed(int num_levels) { return (size_t)num_levels * kGroupWords * sizeof(uint32_t); }
+}  // namespace obb
+
+extern "C" size_t obb_rpn_select_workspace_bytes(const int *H_host, const int *W_host, int num_levels, int num_anchors,
+                                                 int nms_pre) {
+  if (!H_host || !W_host || num_levels < 1 || num_levels > OBB_MAX_LEVELS || num_anchors < 1) return 0;
+  int fs[OBB_MAX_LEVELS + 1];
+  for (int l = 0; l < num_levels; ++l)
+    if (H_host[l] < 0 || W_host[l] < 0 || (int64_t)H_host[l] * W_host[l] * num_anchors > 2147483647LL / 8) return 0;
+  const int slices = obb::rpn_slices(H_host, W_host, num_levels, num_anchors, nms_pre, fs);
+  if (!slices) return 0;
+  return 256 + obb::rpn_ws_zeroed(num_levels) + (size_t)slices * 2 * sizeof(uint32_t) + (size_t)num_levels * obb::kSelMax * sizeof(uint2);
+}
+
 extern "C" int obb_rpn_select_decode_f32(const float *const *cls_devs_host, const float *const *reg_devs_host,
                                          const float *const *anchor_devs_host, const int *H_host, const int *W_host,
                                          int num_levels, int num_anchors, int use_sigmoid, int nms_pre,
                                          const float *means_host, const float *stds_host, float wh_ratio_clip,
                                          int max_h, int max_w, float *dets_dev, int32_t *levels_dev,
                                          int64_t *num_rows_host, void *stream) {
+  return obb_rpn_select_decode_ws_f32(cls_devs_host, reg_devs_host, anchor_devs_host, H_host, W_host, num_levels, num_anchors,
+                                      use_sigmoid, nms_pre, means_host, stds_host, wh_ratio_clip, max_h, max_w, dets_dev,
+                                      levels_dev, num_rows_host, nullptr, 0, stream);
+}
+
+extern "C" int obb_rpn_select_decode_ws_f32(const float *const *cls_devs_host, const float *const *reg_devs_host,
+                                            const float *const *anchor_devs_host, const int *H_host, const int *W_host,
+                                            int num_levels, int num_anchors, int use_sigmoid, int nms_pre,
+                                            const float *means_host, const float *stds_host, float wh_ratio_clip,
+                                            int max_h, int max_w, float *dets_dev, int32_t *levels_dev,
+                                            int64_t *num_rows_host, void *workspace_dev, size_t workspace_bytes,
+                                            void *stream) {
   using namespace obb;
   const char *who = "obb_rpn_select_decode_f32";
   if (num_rows_host) *num_rows_host = 0;
@@ -529,8 +741,27 @@ extern "C" int obb_rpn_select_decode_f32(const float *const *cls_devs_host, cons
   for (int k = 0; k < 4; ++k) { c.m[k] = means_host[k]; c.s[k] = stds_host[k]; }
   c.max_ratio = fabsf(logf(wh_ratio_clip));
   c.max_h = max_h; c.max_w = max_w;
+  RpnGroup g = {};
+  if (workspace_dev) {
+    const int slices = rpn_slices(H_host, W_host, num_levels, num_anchors, nms_pre, g.first_slice);
+    if (slices > 0) {
+      const size_t need = obb_rpn_select_workspace_bytes(H_host, W_host, num_levels, num_anchors, nms_pre);
+      if (workspace_bytes < need) return set_err(OBB_EWORKSPACE, "%s: workspace of %zu bytes, %zu needed", who, workspace_bytes, need);
+      char *w = static_cast<char *>(workspace_dev);
+      w += (256 - (reinterpret_cast<uintptr_t>(w) & 255u)) & 255u;
+      g.words = reinterpret_cast<uint32_t *>(w);
+      g.sel = reinterpret_cast<uint2 *>(w + rpn_ws_zeroed(num_levels));
+      g.bcnt = reinterpret_cast<uint32_t *>(w + rpn_ws_zeroed(num_levels) + (size_t)num_levels * kSelMax * sizeof(uint2));
+      OBB_HIP_TRY(hipMemsetAsync(g.words, 0, rpn_ws_zeroed(num_levels), (hipStream_t)stream));
+      hipLaunchKernelGGL(rpn_group_select_kernel, dim3((unsigned)slices), dim3(kSelThreads), 0, (hipStream_t)stream, lv, num_anchors,
+                         use_sigmoid ? 1 : 0, num_levels, g);
+      OBB_LAUNCH_CHECK();
+    } else {
+      g = RpnGroup{};
+    }
+  }
   hipLaunchKernelGGL(rpn_select_decode_kernel, dim3((unsigned)num_levels), dim3(kSelThreads), 0, (hipStream_t)stream, lv, num_anchors,
-                     use_sigmoid ? 1 : 0, nms_pre, c, dets_dev, levels_dev);
+                     use_sigmoid ? 1 : 0, nms_pre, c, dets_dev, levels_dev, g);
   OBB_LAUNCH_CHECK();
   return OBB_OK;
 }

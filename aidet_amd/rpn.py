@@ -29,7 +29,7 @@ FUSED = True    # False: the tensor-op path below also on the GPU (the specifica
 
 def _rpn_proposals_fused(cls_scores, bbox_preds, mlvl_anchors, img_shape, nms_pre, nms_post, max_num, nms_thr,
                          means, stds, use_sigmoid):
-    """The same proposals from three launches + one NMS call: ``obb_rpn_select_decode_f32`` (per level: exact top
+    """The same proposals from four launches + one NMS call: ``obb_rpn_select_decode_ws_f32`` (per level: exact top
     ``nms_pre`` by score, delta2bbox, clamp), the grouped horizontal NMS, ``obb_rows_topk_f32`` (per-level cut at
     ``nms_post``, top ``max_num`` by score)."""
     L = _lib.lib()
@@ -54,10 +54,13 @@ def _rpn_proposals_fused(cls_scores, bbox_preds, mlvl_anchors, img_shape, nms_pr
     mh, mw = (int(img_shape[0]), int(img_shape[1])) if img_shape is not None else (0, 0)
     with torch.cuda.device(dev):
         st = _lib.current_stream_handle(dev)
-        _lib.check(L.obb_rpn_select_decode_f32(pc, pr, pa, hs, wd, n, A, 1 if use_sigmoid else 0, int(nms_pre),
-                                               (ctypes.c_float * 4)(*[float(v) for v in means]),
-                                               (ctypes.c_float * 4)(*[float(v) for v in stds]), 16 / 1000.0, mh, mw,
-                                               dets.data_ptr(), levels.data_ptr(), ctypes.byref(rows), st))
+        wsb = int(L.obb_rpn_select_workspace_bytes(hs, wd, n, A, int(nms_pre)))    # (> 0: large levels, several workgroups each)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if wsb else None
+        _lib.check(L.obb_rpn_select_decode_ws_f32(pc, pr, pa, hs, wd, n, A, 1 if use_sigmoid else 0, int(nms_pre),
+                                                  (ctypes.c_float * 4)(*[float(v) for v in means]),
+                                                  (ctypes.c_float * 4)(*[float(v) for v in stds]), 16 / 1000.0, mh, mw,
+                                                  dets.data_ptr(), levels.data_ptr(), ctypes.byref(rows),
+                                                  ws.data_ptr() if ws is not None else None, wsb, st))
         assert rows.value == N
         keep, _ = nms_wrapper._run_nms(dets, _lib.KIND_HBB, float(nms_thr), levels)
         K = int(keep.numel())

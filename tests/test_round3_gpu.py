@@ -442,3 +442,59 @@ def test_route_and_restore_refuse_bad_arguments():
     seg = (ctypes.c_int64 * 2)(0, 20)
     assert L.obb_rows_restore_f32(r.data_ptr(), 10, 8, 7, seg, 2, 100, 8, 10, o.data_ptr(), None, ws.data_ptr(), ws.numel(), None) == _lib.OBB_EINVAL
     assert L.obb_rows_restore_workspace_bytes(64, 1 << 20) == 0
+
+
+@pytest.mark.parametrize('case', ['random', 'ties', 'constant', 'softmax', 'ragged'])
+def test_rpn_selection_over_several_workgroups_is_exact(case):
+    """obb_rpn_select_decode_ws_f32: levels of two and more 8192-anchor slices are selected by all their workgroups
+    together (rpn_group_select_kernel: one read of the level, a barrier per radix digit).  The result is the stable
+    descending sort's first nms_pre anchors -- equal logits by ascending anchor index, also when thousands of them sit
+    AT the cut -- and equals the one-workgroup-per-level path wherever that one is defined the same way."""
+    from aidet_amd import _lib
+    from aidet_amd.anchors import AnchorGenerator
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(11)
+    A = 3
+    sizes = [(256, 256), (128, 128), (64, 64), (32, 32)] if case != 'ragged' else [(200, 333), (53, 61), (47, 59)]
+    sig = case != 'softmax'
+    cls = []
+    for (h, w) in sizes:
+        c = torch.randn((A if sig else 2 * A, h, w), generator=g)
+        if case == 'ties':
+            c = torch.round(c * 2) / 2                      # ~20 distinct values: the cut falls inside a huge tie
+        if case == 'constant':
+            c = torch.zeros_like(c)
+        cls.append(c.to(dev()))
+    reg = [torch.zeros((4 * A, c.size(1), c.size(2)), device=dev()) for c in cls]
+    anchors = [AnchorGenerator(4 << i, [8], [0.5, 1.0, 2.0]).grid_anchors(c.shape[-2:], 4 << i, device=dev()) for i, c in enumerate(cls)]
+    n = len(cls)
+    hs = (ctypes.c_int * n)(*[c.size(1) for c in cls]); wd = (ctypes.c_int * n)(*[c.size(2) for c in cls])
+    for nms_pre in (2000, 777):
+        per = [min(nms_pre, c.size(1) * c.size(2) * A) for c in cls]
+        N = sum(per)
+        wsb = int(L.obb_rpn_select_workspace_bytes(hs, wd, n, A, nms_pre))
+        assert wsb > 0
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev())
+        outs = []
+        for use_ws in (True, False):
+            dets = torch.empty((N, 5), device=dev()); lv = torch.empty(N, dtype=torch.int32, device=dev())
+            rows = ctypes.c_int64(0)
+            _lib.check(L.obb_rpn_select_decode_ws_f32((ctypes.c_void_p * n)(*[c.data_ptr() for c in cls]), (ctypes.c_void_p * n)(*[r.data_ptr() for r in reg]),
+                                                      (ctypes.c_void_p * n)(*[a.data_ptr() for a in anchors]), hs, wd, n, A, 1 if sig else 0, nms_pre,
+                                                      (ctypes.c_float * 4)(0, 0, 0, 0), (ctypes.c_float * 4)(1, 1, 1, 1), 16 / 1000.0, 0, 0,
+                                                      dets.data_ptr(), lv.data_ptr(), ctypes.byref(rows),
+                                                      ws.data_ptr() if use_ws else None, wsb if use_ws else 0, _lib.current_stream_handle(dev())))
+            assert rows.value == N
+            outs.append((dets, lv))
+        got, glv = outs[0]
+        base = 0
+        for l, c in enumerate(cls):
+            flat = c.permute(1, 2, 0).reshape(-1) if sig else (c[1::2] - c[0::2]).permute(1, 2, 0).reshape(-1)
+            order = torch.sort(flat, descending=True, stable=True)[1][:per[l]] if per[l] < flat.numel() else torch.arange(flat.numel(), device=dev())
+            assert bool((glv[base:base + per[l]] == l).all())
+            assert torch.allclose(got[base:base + per[l], 4], flat[order].sigmoid(), atol=1e-6), (case, l)
+            assert torch.equal(got[base:base + per[l], :4], anchors[l][order]), (case, l)     # zero deltas, no clamp: the anchors
+            base += per[l]
+        if case in ('random', 'softmax', 'ragged'):      # (no ties at the cut: both paths are defined alike)
+            assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    # the second call reuses the workspace as it was left (the entry point zeroes what it needs)

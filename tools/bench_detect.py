@@ -24,14 +24,22 @@ args = ((ctypes.c_void_p * n)(*[c.data_ptr() for c in cls]), (ctypes.c_void_p * 
 def sel():
     _lib.check(L.obb_rpn_select_decode_f32(*args, n, 3, 1, 2000, (ctypes.c_float * 4)(0, 0, 0, 0), (ctypes.c_float * 4)(1, 1, 1, 1), 16 / 1000.0, 1024, 1024,
                                            dets.data_ptr(), lv.data_ptr(), ctypes.byref(rows), st))
-sel()
+wsb = int(L.obb_rpn_select_workspace_bytes(args[3], args[4], n, 3, 2000))
+ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
+dets2 = torch.empty_like(dets); lv2 = torch.empty_like(lv)
+def sel_ws():
+    _lib.check(L.obb_rpn_select_decode_ws_f32(*args, n, 3, 1, 2000, (ctypes.c_float * 4)(0, 0, 0, 0), (ctypes.c_float * 4)(1, 1, 1, 1), 16 / 1000.0, 1024, 1024,
+                                              dets2.data_ptr(), lv2.data_ptr(), ctypes.byref(rows), ws.data_ptr(), wsb, st))
+sel(); sel_ws()
+same = bool(torch.equal(dets, dets2) and torch.equal(lv, lv2))
 keep, ninfo = nms_wrapper._run_nms(dets, _lib.KIND_HBB, 0.7, lv)
 K = keep.numel(); base = [0]
 for m in per: base.append(base[-1] + m)
 out = torch.empty((2000, 5), device=dev); cnt = torch.empty(1, dtype=torch.int64, device=dev)
 def topk():
     _lib.check(L.obb_rows_topk_f32(dets.data_ptr(), N, 5, 4, keep.data_ptr(), K, (ctypes.c_int * (n + 1))(*base), n, 2000, 2000, out.data_ptr(), None, cnt.data_ptr(), st))
-res = {'select_decode_ms': round(bench._time_gpu(sel, 20), 4), 'nms_ms': round(bench._time_gpu(lambda: nms_wrapper._run_nms(dets, _lib.KIND_HBB, 0.7, lv), 20), 4),
+res = {'select_decode_ms': round(bench._time_gpu(sel_ws, 20), 4), 'select_decode_one_workgroup_per_level_ms': round(bench._time_gpu(sel, 20), 4),
+       'select_decode_paths_equal': same, 'nms_ms': round(bench._time_gpu(lambda: nms_wrapper._run_nms(dets, _lib.KIND_HBB, 0.7, lv), 20), 4),
        'rows_topk_ms': round(bench._time_gpu(topk, 20), 4), 'kept': int(K), 'nms_edges_rounds_candidates': [int(v) for v in ninfo],
        'rpn_fused_ms': round(bench._time_gpu(lambda: rpn_proposals(cls, reg, anchors, (1024, 1024, 3), model.test_cfg['rpn'], fused=True), 20), 4),
        'rpn_tensor_ops_ms': round(bench._time_gpu(lambda: rpn_proposals(cls, reg, anchors, (1024, 1024, 3), model.test_cfg['rpn'], fused=False), 20), 4)}
