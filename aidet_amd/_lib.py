@@ -110,6 +110,8 @@ def lib():
                                                        ctypes.POINTER(f32), i32, i32, i32, vp, vp, i64, i32, i32,
                                                        i32, i32, f32, vp, vp]
         L.obb_roi_align_levels_forward_f32.restype = i32
+        L.obb_roi_map_levels_i32.argtypes = [vp, i64, i32, f32, i32, vp, vp]
+        L.obb_roi_map_levels_i32.restype = i32
         L.obb_roi_forward_workspace_bytes.argtypes = [i64]
         L.obb_roi_forward_workspace_bytes.restype = ctypes.c_size_t
         L.obb_roi_align_forward_ws_f32.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(i32), ctypes.POINTER(i32),

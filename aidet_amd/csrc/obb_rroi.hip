@@ -798,6 +798,7 @@ constexpr int kGTile = 16;                          // map tile: 16 x 16 pixels 
 constexpr int kGChanDefault = 16;                   // channels per gather block (sums in registers); OBB_TUNE_RROI_GATHER_CHAN
 constexpr int kGList = 2048;                        // RoIs of one tile held in LDS at a time
 constexpr int kPlanPix = kBwdMaxPix + 2;            // CSR offsets per RoI (16 bit)
+constexpr int kLptMax = 4096;                       // map tiles (all images) whose order is worked out: tile counts | ticket | order
 
 template <bool UNUSED = false>
 __device__ __forceinline__ bool plan_holds(int fsz, int nb, int nsamp) {
@@ -807,8 +808,9 @@ __device__ __forceinline__ bool plan_holds(int fsz, int nb, int nsamp) {
 __global__ __launch_bounds__(256) void rroi_plan_kernel(
     int B, int H, int W, const float *__restrict__ rois, int ph, int pw, float scale, int sample_num,
     float min_size, int roi_kind, RoiPlan *__restrict__ plan, unsigned short *__restrict__ rstart,
-    int2 *__restrict__ rentry) {
+    int2 *__restrict__ rentry, int *__restrict__ lpt, int tiles_x, int tiles_per_image) {
   __shared__ __attribute__((aligned(16))) float tile[kBwdStageFloats];   // sample table | per-pixel counts
+  __shared__ int s_last;
   __shared__ int2 entry[kBwdMaxEntries];               // (bin | tap << 8, weight bits), grouped by pixel
   __shared__ int pstart[kBwdMaxPix + 1];
   __shared__ int wsum[4];
@@ -825,10 +827,56 @@ __global__ __launch_bounds__(256) void rroi_plan_kernel(
   const int fsz = fp.w * fp.h;
   const int spb = (int)(spb64 > kMaxTabSamples ? kMaxTabSamples + 1 : (spb64 > 0 ? spb64 : 1));
   const int nsamp = nb * spb;
+  // Heavy map tiles first.  The gather kernel's blocks take one (map tile, channel chunk) each and last as long as
+  // RoIs meet the tile (2 .. 16 at configs[2]); in tile order the launch ends when the last heavy tile, started late,
+  // is done.  Every planned RoI counts itself into the tiles its footprint meets; the LAST plan block to finish (a
+  // ticket) orders every image's tiles by descending count (a counting sort) for the gather kernel's block -> tile map.
+  auto finish = [&]() {
+    if (!lpt) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (this wave's counts are acknowledged before the ticket is taken)
+    __syncthreads();
+    if (tid == 0) s_last = __hip_atomic_fetch_add(lpt + kLptMax, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (!s_last) return;
+    int *bucket = pstart;                    // [256] tiles per count (255 = "255 or more"), then their first rank
+    int *perm = lpt + kLptMax + 16;
+    for (int img = 0; img < B; ++img) {
+      __syncthreads();
+      bucket[tid] = 0;
+      __syncthreads();
+      const int *cnt = lpt + img * tiles_per_image;
+      for (int t = tid; t < tiles_per_image; t += 256) {
+        const int c = __hip_atomic_load(cnt + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        atomicAdd(&bucket[c > 255 ? 255 : c], 1);
+      }
+      __syncthreads();
+      {  // first rank of every count, heaviest first: exclusive scan over the buckets in descending order
+        const int mine = bucket[255 - tid];
+        int inc = mine;
+        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o); if (lane >= o) inc += v; }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        int base = inc - mine;
+        for (int w2 = 0; w2 < wave; ++w2) base += wsum[w2];
+        bucket[255 - tid] = base;
+      }
+      __syncthreads();
+      for (int t = tid; t < tiles_per_image; t += 256) {
+        const int c = __hip_atomic_load(cnt + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        perm[img * tiles_per_image + atomicAdd(&bucket[c > 255 ? 255 : c], 1)] = t;
+      }
+    }
+  };
   if (!live || !plan_holds(fsz, nb, nsamp)) {        // nothing sampled, or left to the atomics kernel
     pl.state = live ? 2 : 0;
     if (tid == 0) plan[k] = pl;
+    finish();
     return;
+  }
+  if (lpt) {
+    const int tx0 = fp.x0 / kGTile, tx1 = (fp.x0 + fp.w - 1) / kGTile, ty0 = fp.y0 / kGTile, ty1 = (fp.y0 + fp.h - 1) / kGTile;
+    const int nx = tx1 - tx0 + 1, nt = nx * (ty1 - ty0 + 1);
+    for (int i = tid; i < nt; i += 256) atomicAdd(&lpt[f.b * tiles_per_image + (ty0 + i / nx) * tiles_x + tx0 + i % nx], 1);
   }
   int4 *s_off = reinterpret_cast<int4 *>(tile);
   float4 *s_wgt = reinterpret_cast<float4 *>(tile) + kMaxTabSamples;
@@ -952,6 +1000,7 @@ __global__ __launch_bounds__(256) void rroi_plan_kernel(
     }
   }
   if (tid == 0) { pl.x0 = fp.x0; pl.y0 = fp.y0; pl.w = fp.w; pl.h = fp.h; pl.state = 1; plan[k] = pl; }
+  finish();
 }
 
 // Every global request of a RoI is issued one RoI ahead: while RoI i is summed, the plan record of RoI i+2, the
@@ -962,11 +1011,15 @@ __global__ __launch_bounds__(256) void rroi_plan_kernel(
 // (round 2's kernel had four such round trips per RoI: 156 us at configs[2]; this one 98 us -- the rest of the step
 // came from the compile-time bin count, the scalar RoI index and fused multiply-adds: 2434 -> ~1000 VALU per wave).
 // (Also measured and dropped in round 3: FOUR RoIs per step, two barriers per step: 155 -> 185 us, 99 VGPRs.)
+// Grid = (chunks, tiles, images): the channel chunks of a map tile run together (they read the same plan records, list
+// bounds and entries: 0.117 -> 0.108 ms at configs[2], 0.42 -> 0.385 at the config-4 shape against tiles fastest), the
+// tiles heavy first (rroi_plan_kernel's order: -> 0.107 / 0.370 ms).
 // NB: bins per RoI when known at compile time (49: the LDS reads of the sums take immediate offsets), 0: from the plan.
 template <int CH, int NB>
 __global__ __launch_bounds__(256) void rroi_gather_kernel(
     const float *__restrict__ gout, int C, int H, int W, int K, const RoiPlan *__restrict__ plan,
-    const unsigned short *__restrict__ rstart, const int2 *__restrict__ rentry, float *__restrict__ gfeat) {
+    const unsigned short *__restrict__ rstart, const int2 *__restrict__ rentry, float *__restrict__ gfeat,
+    const int *__restrict__ tile_order) {
   constexpr int G = CH * kMaxBins / 256;            // gradient words a thread stages per RoI
   static_assert(G * 256 == CH * kMaxBins, "gradient staging");
   __shared__ int list[kGList];
@@ -974,9 +1027,12 @@ __global__ __launch_bounds__(256) void rroi_gather_kernel(
   __shared__ int wcnt[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tiles_x = (W + kGTile - 1) / kGTile;
-  const int tx0 = ((int)blockIdx.x % tiles_x) * kGTile, ty0 = ((int)blockIdx.x / tiles_x) * kGTile;
-  const int c0 = (int)blockIdx.y * CH, cc = min(CH, C - c0);
   const int b = (int)blockIdx.z;
+  // grid (chunks, tiles, images): the channel chunks of a tile start together, the tiles in rroi_plan_kernel's order
+  // (heavy first; any order gives the same sums)
+  const int tl = tile_order ? tile_order[b * (int)gridDim.y + (int)blockIdx.y] : (int)blockIdx.y;
+  const int tx0 = (tl % tiles_x) * kGTile, ty0 = (tl / tiles_x) * kGTile;
+  const int c0 = (int)blockIdx.x * CH, cc = min(CH, C - c0);
   const int x = tx0 + (tid & (kGTile - 1)), y = ty0 + tid / kGTile;
   const bool inmap = x < W && y < H;
   float acc[CH];
@@ -1327,7 +1383,7 @@ extern "C" int obb_roi_align_backward_f32(const float *grad_out_dev, int B, int 
 
 namespace obb {
 
-struct GatherLayout { size_t plan, rstart, rentry, total; };
+struct GatherLayout { size_t plan, rstart, rentry, lpt, total; };
 
 static GatherLayout gather_layout(int64_t K) {
   GatherLayout L;
@@ -1337,6 +1393,7 @@ static GatherLayout gather_layout(int64_t K) {
   L.plan = take(k * sizeof(RoiPlan));
   L.rstart = take(k * kPlanPix * sizeof(unsigned short));
   L.rentry = take(k * kBwdMaxEntries * sizeof(int2));
+  L.lpt = take((size_t)(2 * kLptMax + 16) * sizeof(int));
   L.total = off;
   return L;
 }
@@ -1381,18 +1438,25 @@ extern "C" int obb_roi_backward_gather_f32(const float *grad_out_dev, int B, int
   RoiPlan *plan = reinterpret_cast<RoiPlan *>(ws + L.plan);
   unsigned short *rstart = reinterpret_cast<unsigned short *>(ws + L.rstart);
   int2 *rentry = reinterpret_cast<int2 *>(ws + L.rentry);
+  const int tiles_x = (W + kGTile - 1) / kGTile;
+  const unsigned tiles = (unsigned)(tiles_x * ((H + kGTile - 1) / kGTile));
+  int *lpt = nullptr;
+  if ((long long)tiles * B <= kLptMax) {     // tile counts and the ticket start at zero
+    lpt = reinterpret_cast<int *>(ws + L.lpt);
+    OBB_HIP_TRY(hipMemsetAsync(lpt, 0, (size_t)(kLptMax + 16) * sizeof(int), st));
+  }
   hipLaunchKernelGGL(rroi_plan_kernel, dim3((unsigned)K), dim3(256), 0, st, B, H, W, rois_dev, ph, pw, spatial_scale,
-                     sample_num, min_size, roi_kind, plan, rstart, rentry);
+                     sample_num, min_size, roi_kind, plan, rstart, rentry, lpt, tiles_x, (int)tiles);
   OBB_LAUNCH_CHECK();
-  const unsigned tiles = (unsigned)(((W + kGTile - 1) / kGTile) * ((H + kGTile - 1) / kGTile));
+  const int *tile_order = lpt ? lpt + kLptMax + 16 : nullptr;
   const int gt = (int)tuning(OBB_TUNE_RROI_GATHER_CHAN, kGChanDefault);
   const int gch = gt >= 32 ? 32 : 16;
   const unsigned chunks = (unsigned)((C + gch - 1) / gch);
-  if (chunks > 65535u || B > 65535) return set_err(OBB_EINVAL, "%s: too many channels / images", who);
-  const dim3 ggrid(tiles, chunks, (unsigned)B);
+  if (tiles > 65535u || B > 65535) return set_err(OBB_EINVAL, "%s: too many map tiles / images", who);
+  const dim3 ggrid(chunks, tiles, (unsigned)B);
 #define OBB_GATHER(CH, NB)                                                                                              \
   hipLaunchKernelGGL((rroi_gather_kernel<CH, NB>), ggrid, dim3(256), 0, st, grad_out_dev, C, H, W, (int)K, plan, \
-                     rstart, rentry, grad_feat_dev)
+                     rstart, rentry, grad_feat_dev, tile_order)
   if (gch == 32) {
     if (ph * pw == 49) OBB_GATHER(32, 49); else OBB_GATHER(32, 0);
   } else {
@@ -1431,6 +1495,37 @@ extern "C" int obb_roi_align_levels_forward_f32(const float *const *feat_devs_ho
   }
   return rroi_forward_launch_levels(who, lv, num_levels, roi_level_dev, B, C, rois_dev, K, ph, pw, sample_num,
                                     roi_kind == 0 ? min_size : 0.0f, roi_kind, out_dev, stream);
+}
+
+namespace obb {
+// SingleRoIExtractor.map_roi_levels (single_level.py:54-73) in ONE launch: level = clamp(floor(log2(scale / finest +
+// 1e-6)), 0, levels - 1), scale = sqrt(w * h) with w = x2 - x1 + 1 (horizontal RoIs) or the box's own sides (rotated) --
+// the same fp32 expression order as the tensor ops it replaces (eleven small launches, ~60 us of host time per call)
+__global__ __launch_bounds__(256) void roi_levels_kernel(const float *__restrict__ rois, int64_t K, int roi_kind,
+                                                         float finest_scale, int num_levels, int32_t *__restrict__ out) {
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= K) return;
+  const float *r = rois + k * roi_stride(roi_kind);
+  const float area = roi_kind == 0 ? r[3] * r[4] : (r[3] - r[1] + 1.0f) * (r[4] - r[2] + 1.0f);
+  const float lv = floorf(log2f(sqrtf(area) / finest_scale + 1e-6f));
+  const float hi = (float)(num_levels - 1);
+  const float c = lv < 0.0f ? 0.0f : (lv > hi ? hi : lv);          // (Tensor.clamp; NaN -> NaN -> (int) 0 below)
+  out[k] = c == c ? (int32_t)c : 0;
+}
+}  // namespace obb
+
+extern "C" int obb_roi_map_levels_i32(const float *rois_dev, int64_t K, int roi_kind, float finest_scale, int num_levels,
+                                      int32_t *levels_dev, void *stream) {
+  using namespace obb;
+  if (K < 0 || roi_kind < 0 || roi_kind > 2 || num_levels < 1 || !(finest_scale > 0.0f))
+    return set_err(OBB_EINVAL, "obb_roi_map_levels_i32: bad argument");
+  if (K == 0) return OBB_OK;
+  if (!rois_dev || !levels_dev) return set_err(OBB_EINVAL, "obb_roi_map_levels_i32: null pointer");
+  if (K > 2147483647LL) return set_err(OBB_EINVAL, "obb_roi_map_levels_i32: too many RoIs");
+  hipLaunchKernelGGL(roi_levels_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rois_dev, K, roi_kind,
+                     finest_scale, num_levels, levels_dev);
+  OBB_LAUNCH_CHECK();
+  return OBB_OK;
 }
 
 extern "C" size_t obb_roi_forward_workspace_bytes(int64_t K) {

@@ -168,6 +168,17 @@ class RoIAlign(nn.Module):
             self.use_torchvision, self.aligned)
 
 
+def map_levels(rois, num_levels, finest_scale, roi_kind):
+    """``map_roi_levels`` of the extractors below as ONE launch (int32 levels) for fp32 HIP RoIs; the tensor
+    expressions of the methods are the specification (and every other case)."""
+    r = rois.detach().contiguous()
+    out = torch.empty(r.size(0), dtype=torch.int32, device=r.device)
+    with torch.cuda.device(r.device):
+        _lib.check(_lib.lib().obb_roi_map_levels_i32(r.data_ptr(), r.size(0), int(roi_kind), float(finest_scale), int(num_levels),
+                                                    out.data_ptr(), _lib.current_stream_handle(r.device)))
+    return out
+
+
 def pyramid_roi_align(feats, rois, levels, out_size, scales, sample_num, roi_kind, min_size=1.0):
     """RoI-Align of every RoI on the pyramid level ``levels`` names, in ONE kernel launch
     (obb_roi_align_forward_ws_f32): no per-level mask / gather / launch / scatter
@@ -237,10 +248,12 @@ class SingleRoIExtractor(nn.Module):
         if len(feats) == 1:
             return self.roi_layers[0](feats[0], rois)
         out_size = self.roi_layers[0].out_size
-        target_lvls = self.map_roi_levels(rois, len(feats))
+        fused = _fusable(self.roi_layers, feats, rois)
+        target_lvls = (map_levels(rois, len(feats), self.finest_scale, 1) if fused and rois.dtype == torch.float32 and rois.size(1) == 5
+                       else self.map_roi_levels(rois, len(feats)))
         if roi_scale_factor is not None:
             rois = self.roi_rescale(rois, roi_scale_factor)
-        if _fusable(self.roi_layers, feats, rois):
+        if fused:
             a = self.roi_layers[0]
             kind = 0 if isinstance(a, RRoIAlign) else (2 if a.aligned else 1)
             return pyramid_roi_align(feats, rois, target_lvls, out_size, [l.spatial_scale for l in self.roi_layers],
@@ -303,10 +316,12 @@ class RotatedSingleRoIExtractor(nn.Module):
             return self.roi_layers[0](feats[0], rois)
         out_size = self.roi_layers[0].out_size
         num_levels = len(feats)
-        target_lvls = self.map_roi_levels(rois, num_levels)
+        fused = _fusable(self.roi_layers, feats, rois)
+        target_lvls = (map_levels(rois, num_levels, self.finest_scale, 0) if fused and rois.dtype == torch.float32 and rois.size(1) == 6
+                       else self.map_roi_levels(rois, num_levels))
         if roi_scale_factor is not None:
             rois = self.roi_rescale(rois, roi_scale_factor)
-        if _fusable(self.roi_layers, feats, rois):
+        if fused:
             a = self.roi_layers[0]
             return pyramid_roi_align(feats, rois, target_lvls, out_size, [l.spatial_scale for l in self.roi_layers],
                                      a.sample_num, 0, a.min_size)

@@ -274,6 +274,11 @@ OBB_API int obb_roi_align_levels_forward_f32(const float *const *feat_devs_host,
                                              const int32_t *roi_level_dev, int64_t K, int ph, int pw,
                                              int sample_num, int roi_kind, float min_size,
                                              float *out_dev, void *stream);
+/* SingleRoIExtractor.map_roi_levels, mmdet/models/roi_extractors/single_level.py:54-73, as one launch:
+ * levels_dev[k] = clamp(floor(log2(sqrt(area_k) / finest_scale + 1e-6)), 0, num_levels - 1), area = w * h of a rotated
+ * RoI (roi_kind 0: (K, 6) [b, cx, cy, w, h, theta]) or (x2 - x1 + 1)(y2 - y1 + 1) (kinds 1, 2: (K, 5)). */
+OBB_API int obb_roi_map_levels_i32(const float *rois_dev, int64_t K, int roi_kind, float finest_scale, int num_levels,
+                                   int32_t *levels_dev, void *stream);
 
 /* ---------------------------------------------------------------------------
  * RoI-Align forward (pyramid or single map, any roi_kind) with a caller-provided WORKSPACE of

@@ -498,3 +498,22 @@ def test_rpn_selection_over_several_workgroups_is_exact(case):
         if case in ('random', 'softmax', 'ragged'):      # (no ties at the cut: both paths are defined alike)
             assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     # the second call reuses the workspace as it was left (the entry point zeroes what it needs)
+
+
+def test_level_mapping_kernel_equals_the_tensor_expressions():
+    """obb_roi_map_levels_i32 against SingleRoIExtractor.map_roi_levels / RotatedSingleRoIExtractor.map_roi_levels
+    (single_level.py:54-73), incl. scales exactly on a level boundary (56 * 2^k), tiny and huge RoIs."""
+    from aidet_amd import roi_layers
+    g = torch.Generator().manual_seed(3)
+    K = 5000
+    x1, y1 = torch.rand(K, generator=g) * 900, torch.rand(K, generator=g) * 900
+    side = torch.exp(torch.rand(K, generator=g) * 7.0)            # 1 .. 1100 px
+    side[:8] = torch.tensor([56.0, 112.0, 224.0, 448.0, 55.999, 112.001, 0.5, 5000.0])
+    hb = torch.stack([torch.zeros(K), x1, y1, x1 + side - 1, y1 + side * (0.5 + torch.rand(K, generator=g)) - 1], 1).to(dev())
+    rb = torch.stack([torch.zeros(K), x1, y1, side, side * (0.5 + torch.rand(K, generator=g)), torch.zeros(K)], 1).to(dev())
+    for n in (4, 1):
+        ext = roi_layers.SingleRoIExtractor(dict(type='RoIAlign', out_size=7, sample_num=2), 8, [4, 8, 16, 32][:n])
+        assert torch.equal(roi_layers.map_levels(hb, n, ext.finest_scale, 1).long(), ext.map_roi_levels(hb, n))
+        rext = roi_layers.RotatedSingleRoIExtractor(dict(type='RRoIAlign', out_size=7, sample_num=2), 8, [4, 8, 16, 32][:n])
+        assert torch.equal(roi_layers.map_levels(rb, n, rext.finest_scale, 0).long(), rext.map_roi_levels(rb, n))
+    assert roi_layers.map_levels(hb[:0], 4, 56, 1).shape == (0,)
