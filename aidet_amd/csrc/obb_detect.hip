@@ -678,6 +678,19 @@ static int rpn_slices(const int *H_host, const int *W_host, int num_levels, int 
   return total;
 }
 static size_t rpn_ws_zeroed(int num_levels) { return (size_t)num_levels * kGroupWords * sizeof(uint32_t); }
+// the workgroups of rpn_group_select_kernel wait for each other: all of them must be resident at once, one per CU
+// (1024 threads).  A partitioned device (CPX: 32 CUs) may have fewer CUs than a launch wants -> the one-workgroup path.
+static int device_cus() {
+  static thread_local int cached_dev = -1, cached_cus = 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (dev != cached_dev) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 0;
+    cached_dev = dev; cached_cus = v;
+  }
+  return cached_cus;
+}
 }  // namespace obb
 
 extern "C" size_t obb_rpn_select_workspace_bytes(const int *H_host, const int *W_host, int num_levels, int num_anchors,
@@ -744,7 +757,7 @@ extern "C" int obb_rpn_select_decode_ws_f32(const float *const *cls_devs_host, c
   RpnGroup g = {};
   if (workspace_dev) {
     const int slices = rpn_slices(H_host, W_host, num_levels, num_anchors, nms_pre, g.first_slice);
-    if (slices > 0) {
+    if (slices > 0 && slices <= device_cus()) {
       const size_t need = obb_rpn_select_workspace_bytes(H_host, W_host, num_levels, num_anchors, nms_pre);
       if (workspace_bytes < need) return set_err(OBB_EWORKSPACE, "%s: workspace of %zu bytes, %zu needed", who, workspace_bytes, need);
       char *w = static_cast<char *>(workspace_dev);

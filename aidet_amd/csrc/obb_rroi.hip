@@ -1173,14 +1173,17 @@ __global__ __launch_bounds__(256) void rroi_gather_kernel(
   }
 }
 
-// ---- Morton order of the RoIs (forward, with a workspace) ----------------------------------------------------
-// key = pyramid level | Morton code of the RoI centre on a 32 x 32 grid over its map; ONE workgroup counts,
-// scans and scatters (8192 bins in LDS): order[rank] = RoI.  The order inside a cell follows the LDS atomics'
-// arrival -- it decides which block works on which RoI, never a result.
-constexpr int kOrderBins = 8192;     // 8 levels x 1024 cells
+// ---- order of the RoIs (forward, with a workspace) ------------------------------------------------------------
+// key = size class (largest first) | pyramid level | Morton code of the RoI centre on a 32 x 32 grid over its map;
+// ONE workgroup counts, scans and scatters (32 768 bins in LDS): order[rank] = RoI.  RoIs that run at the same time on
+// an XCD then share footprint lines in its L2 (Morton), and the RoIs whose blocks last longest -- the classes follow
+// the number of staging passes a footprint needs -- start first instead of last (tools/exp_rroi_order2.py: config-4
+// shape 220 us in the given order, 177 Morton only, 169 with the size classes).  The order inside a cell follows the
+// LDS atomics' arrival -- it decides which block works on which RoI, never a result.
+constexpr int kOrderBins = 32768;    // 4 size classes x 8 levels x 1024 cells
 constexpr int kOrderMaxK = 65536;    // above: identity order (the caller passes no order)
-// below: not worth its launch (measured: 512 RoIs covering a 256^2 map 1.8x: the ordered kernel is 2 us faster, the order
-// kernel and its launch boundary cost 9; 2000 RoIs covering it 22x: 224 -> 187 us all in)
+// below: not worth its launch (measured: 512 RoIs covering a 256^2 map 1.8x: the ordered kernel is 3 us faster, the order
+// kernel and its launch boundary cost 8; 2000 RoIs covering it 22x: 220 -> 175 us all in)
 constexpr int kOrderMinK = 1024;
 
 __device__ __forceinline__ uint32_t roi_order_key(const float *__restrict__ roi, int kind, int lvl, const LevelTable &lv) {
@@ -1193,16 +1196,21 @@ __device__ __forceinline__ uint32_t roi_order_key(const float *__restrict__ roi,
   uint32_t x = (uint32_t)ux, y = (uint32_t)uy;
   x = (x | (x << 4)) & 0x0F0Fu; x = (x | (x << 2)) & 0x3333u; x = (x | (x << 1)) & 0x5555u;
   y = (y | (y << 4)) & 0x0F0Fu; y = (y | (y << 2)) & 0x3333u; y = (y | (y << 1)) & 0x5555u;
-  return ((uint32_t)lvl << 10) | x | (y << 1);
+  // footprint estimate in map pixels -> class 0 (> 640: one channel per pass) .. 3 (<= 160: eight channels per pass)
+  const float w = kind == 0 ? roi[3] : roi[3] - roi[1] + 1.0f, h = kind == 0 ? roi[4] : roi[4] - roi[2] + 1.0f;
+  const float fpx = (w * sc + 2.0f) * (h * sc + 2.0f);
+  const uint32_t cls = fpx > 640.0f ? 0u : (fpx > 320.0f ? 1u : (fpx > 160.0f ? 2u : 3u));   // (NaN -> 3)
+  return (cls << 13) | ((uint32_t)lvl << 10) | x | (y << 1);
 }
 
 __global__ __launch_bounds__(1024) void rroi_order_kernel(const LevelTable lv, const int *__restrict__ roi_level,
                                                           int num_levels, const float *__restrict__ rois, int K,
                                                           int roi_kind, int *__restrict__ order, int *__restrict__ tmp) {
-  __shared__ uint32_t hist[kOrderBins];
+  __shared__ uint32_t hist[kOrderBins + kOrderBins / 32];   // bin i at i + i / 32: a thread's 32 consecutive bins on 32 banks
+  auto P = [](uint32_t i) { return i + (i >> 5); };
   __shared__ uint32_t wsum[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int i = tid; i < kOrderBins; i += 1024) hist[i] = 0u;
+  for (int i = tid; i < kOrderBins + kOrderBins / 32; i += 1024) hist[i] = 0u;
   __syncthreads();
   const int S = roi_stride(roi_kind);
   auto key_of = [&](int k) {
@@ -1215,30 +1223,29 @@ __global__ __launch_bounds__(1024) void rroi_order_kernel(const LevelTable lv, c
   for (int u = 0; u < 4; ++u) {
     const int k = tid + u * 1024;
     rkey[u] = 0u; rrank[u] = 0u;
-    if (k < K) { rkey[u] = key_of(k); rrank[u] = atomicAdd(&hist[rkey[u]], 1u); }
+    if (k < K) { rkey[u] = key_of(k); rrank[u] = atomicAdd(&hist[P(rkey[u])], 1u); }
   }
-  for (int k = tid + 4096; k < K; k += 1024) tmp[k] = (int)atomicAdd(&hist[key_of(k)], 1u);
+  for (int k = tid + 4096; k < K; k += 1024) tmp[k] = (int)atomicAdd(&hist[P(key_of(k))], 1u);
   __syncthreads();
-  {  // exclusive scan of the 8192 counts: 8 per thread
-    uint32_t v[8], tot = 0;
-#pragma unroll
-    for (int u = 0; u < 8; ++u) { v[u] = hist[tid * 8 + u]; tot += v[u]; }
+  {  // exclusive scan of the counts: kOrderBins / 1024 consecutive bins per thread
+    constexpr int kPer = kOrderBins / 1024;
+    uint32_t tot = 0;
+    for (int u = 0; u < kPer; ++u) tot += hist[P(tid * kPer + u)];
     uint32_t inc = tot;
     for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)inc, o); if (lane >= o) inc += t; }
     if (lane == 63) wsum[wave] = inc;
     __syncthreads();
     uint32_t base = inc - tot;
     for (int w2 = 0; w2 < wave; ++w2) base += wsum[w2];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) { hist[tid * 8 + u] = base; base += v[u]; }
+    for (int u = 0; u < kPer; ++u) { const uint32_t v = hist[P(tid * kPer + u)]; hist[P(tid * kPer + u)] = base; base += v; }
     __syncthreads();
   }
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const int k = tid + u * 1024;
-    if (k < K) order[hist[rkey[u]] + rrank[u]] = k;
+    if (k < K) order[hist[P(rkey[u])] + rrank[u]] = k;
   }
-  for (int k = tid + 4096; k < K; k += 1024) order[hist[key_of(k)] + (uint32_t)tmp[k]] = k;
+  for (int k = tid + 4096; k < K; k += 1024) order[hist[P(key_of(k))] + (uint32_t)tmp[k]] = k;
 }
 
 static int rroi_check(const char *who, int B, int C, int H, int W, int64_t K, int ph, int pw) {
