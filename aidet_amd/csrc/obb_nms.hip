@@ -71,7 +71,11 @@ constexpr int kScanBlockCells = 1024;   // cells per block of the multi-block ce
 constexpr int kShards = 64;            // candidate lists / counters (atomic rate)
 constexpr int kPrepBlocks = 1024;     // upper bound on blocks of the prep kernel
 constexpr int kScanBlocks = 2048;     // grid of the scan kernel = one resident set at 8 waves/SIMD (waves loop over units)
-constexpr int kClipBlocksPerShard = 32;
+// blocks of the clip kernel per candidate shard (lanes loop over their shard's list).  32 was round 2's value: at
+// 100k sparse boxes (17 k candidates = 270 per shard) 2048 workgroups were started to find 1 in 30 of them anything to do --
+// and STARTING them was 8 of the kernel's 16 us.  8: 11 us there, unchanged on the dense scene (6 100 candidates per
+// shard: three rounds per lane, 25 us); 4: 9.5 us / 33 us.
+constexpr int kClipBlocksPerShard = 8;
 
 constexpr uint8_t kUndecided = 0, kKept = 1, kSuppressed = 2;
 constexpr uint32_t kGuard = 0x80008000u;   // guard bits of the packed intervals
