@@ -654,7 +654,11 @@ __global__ __launch_bounds__(256) void rroi_backward_kernel(
   int64_t k;
   int chunk;
   if (!block_to_work(K, chunks, k, chunk)) return;
-  if (plan && plan[k].state != 2) return;   // (after the gather kernel: only what the plan left over)
+  // (after the gather kernel: only what the plan left over.  One workgroup per item that leaves at this word is the
+  // floor -- 4.3 us for 8192 items at configs[2]; 512 workgroups walking the items took 5.0 us, and a workgroup per 256
+  // items that works off its flagged ones serially 4.2 us there but 0.48 instead of 0.36 ms at the config-4 shape,
+  // whose 84 large RoIs x 16 chunks then share a few workgroups.)
+  if (plan && plan[k].state != 2) return;
   RoiFrame f;
   make_frame(rois + k * roi_stride(roi_kind), roi_kind, scale, ph, pw, sample_num, min_size, f);
   const long long spb64 = (long long)f.gh * f.gw;
