@@ -7,5 +7,5 @@ for set in "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES" "SQ_
   tag=$(echo $set | tr ' ' '_' | cut -c1-24)
   timeout 200 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/$tag -o p -- python3 bench.py --profile-target rroi_bwd --steps 5 --warmup 2 > /dev/null 2> $O/$tag.err
   f=$(find $O/$tag -name 'p_counter_collection.csv' | head -1)
-  [ -n "$f" ] && python tools/pmc_summary.py $(dirname $f) p | grep -E "rroi_gather|rroi_plan|rroi_backward"
+  [ -n "$f" ] && python tools/pmc_summary.py $(dirname $f) p | grep -E "rroi_gather|rroi_plan"
 done
