@@ -1015,6 +1015,11 @@ __global__ __launch_bounds__(256) void rroi_plan_kernel(
 // (round 2's kernel had four such round trips per RoI: 156 us at configs[2]; this one 98 us -- the rest of the step
 // came from the compile-time bin count, the scalar RoI index and fused multiply-adds: 2434 -> ~1000 VALU per wave).
 // (Also measured and dropped in round 3: FOUR RoIs per step, two barriers per step: 155 -> 185 us, 99 VGPRs.)
+// (Small RoIs are this kernel's slow case -- tools/exp_plan.py: 512 RoIs of 8-16 px 140 us, of 32-128 px 50 us: a 3 x 3
+// pixel footprint holds all 784 taps, ~90 per pixel, summed by 9 lanes of a wave.  Measured and dropped: the whole wave
+// summing a long list (lane = (entry slot, channel), two shuffles per entry: as many instructions as it saves), rounds
+// of 8 entries with the next round in flight (88 VGPRs, no gain: the lists are instruction-, not latency-bound).  What
+// would help is merging a pixel's consecutive taps of one bin in the plan: ~5x fewer entries for such RoIs.)
 // Grid = (chunks, tiles, images): the channel chunks of a map tile run together (they read the same plan records, list
 // bounds and entries: 0.117 -> 0.108 ms at configs[2], 0.42 -> 0.385 at the config-4 shape against tiles fastest), the
 // tiles heavy first (rroi_plan_kernel's order: -> 0.107 / 0.370 ms).
