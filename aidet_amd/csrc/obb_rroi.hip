@@ -895,11 +895,38 @@ __global__ __launch_bounds__(256) void rroi_plan_kernel(
     pix = j == 0 ? o.x : (j == 1 ? o.y : (j == 2 ? o.z : o.w));
     w = j == 0 ? ww.x : (j == 1 ? ww.y : (j == 2 ? ww.z : ww.w));
   };
-  for (int t = tid; t < ntap; t += 256) {
-    int pix;
-    float w;
-    tap_of(t, pix, w);
-    if (w != 0.0f) atomicAdd(&pstart[pix], 1);
+  // The taps of one bin that land on the SAME pixel become one entry (the sum of their weights / count, in tap order):
+  // a small RoI -- bins of a fraction of a pixel -- puts 3-4 of a bin's 16 taps on each of ~5 pixels, and the gather
+  // kernel pays per entry (512 RoIs of 8-16 px: 140 us of gather against 50 us for 32-128 px).  A bin's taps are
+  // consecutive tap numbers, i.e. consecutive lanes of one iteration here (when 4 x samples-per-bin is a power of two
+  // <= 64: groups of that many lanes); the first tap of a (bin, pixel) group is its leader and carries the sum.
+  const int tpb = 4 * spb;                                   // taps per bin
+  const bool merge = tpb <= 64 && (tpb & (tpb - 1)) == 0;
+  constexpr int kTapIters = kBwdMaxEntries / 256;            // <= 4 taps per thread
+  bool lead[kTapIters];
+  float wsumq[kTapIters];
+#pragma unroll
+  for (int it = 0; it < kTapIters; ++it) {
+    const int t = tid + it * 256;
+    int pix = -1;
+    float w = 0.0f;
+    if (t < ntap) { tap_of(t, pix, w); w = w != 0.0f ? w / f.cnt : 0.0f; }
+    if (w == 0.0f) pix = -1;                                 // (a zero weight adds nothing, also in the direct kernel)
+    lead[it] = pix >= 0;
+    wsumq[it] = w;
+    if (merge && tpb > 1 && __ballot(t < ntap)) {            // (wave-uniform)
+      const int g0 = lane & ~(tpb - 1), me = lane - g0;
+      float sum = 0.0f;
+      bool first = true;
+      for (int j = 0; j < tpb; ++j) {                        // ascending tap number: a fixed order
+        const int pj = __shfl(pix, g0 + j);
+        const float wj = __shfl(w, g0 + j);
+        if (pix >= 0 && pj == pix) { if (j < me) first = false; else sum += wj; }
+      }
+      lead[it] = pix >= 0 && first;
+      wsumq[it] = sum;
+    }
+    if (lead[it]) atomicAdd(&pstart[pix], 1);
   }
   __syncthreads();
   {  // exclusive scan of the counts (<= 2048 pixels: 8 per thread)
@@ -917,13 +944,15 @@ __global__ __launch_bounds__(256) void rroi_plan_kernel(
     if (tid == 255) pstart[fsz] = base;
     __syncthreads();
   }
-  for (int t = tid; t < ntap; t += 256) {
-    int pix;
-    float w;
-    tap_of(t, pix, w);
-    if (w != 0.0f) {
+#pragma unroll
+  for (int it = 0; it < kTapIters; ++it) {
+    const int t = tid + it * 256;
+    if (lead[it]) {
+      int pix;
+      float w;
+      tap_of(t, pix, w);
       const int slot = pstart[pix] + atomicAdd(&pfill[pix], 1);
-      entry[slot] = make_int2((t / (4 * spb)) | (t << 8), __float_as_int(w / f.cnt));
+      entry[slot] = make_int2((t / (4 * spb)) | (t << 8), __float_as_int(wsumq[it]));
     }
   }
   __syncthreads();
