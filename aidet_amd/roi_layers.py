@@ -31,12 +31,13 @@ from .rroi_align import RRoIAlign, rroi_align  # noqa: F401  (rroi_align: the ma
 
 # Which backward runs: 'auto' | 'gather' (obb_roi_backward_gather_f32: plan per RoI + one block per map tile; no
 # atomics, no zero fill, bit-reproducible) | 'atomics' (the scatter kernels behind obb_(r)roi_align_backward_f32).
-# Measured on MI355X (tools/bench_roi_backward.py): 512 RoIs covering the 256^2 map 1.8x: scatter 0.19 ms, gather
-# 0.19 ms; 2000 RoIs covering it 22x (config 4's first level): scatter 1.67 ms, gather 0.71 ms -- the scatter pays
-# per atomic request and for its direct-atomics tail, the gather per (tile, RoI) pair.  'auto' = gather from
-# GATHER_MIN_ROIS RoIs on.
+# Measured on MI355X (tools/exp_bwd_crossover.py, rotated RoIs on a 256^2 x 256-channel map; scatter incl. its zero fill):
+# 16 RoIs 0.034 / 0.039 ms (gather / scatter), 64: 0.037 / 0.052, 512: 0.071 / 0.193, 1024: 0.112 / 0.361; config 4's
+# first level (2000 horizontal RoIs covering the map 22x): 0.35 / 1.67 ms -- the scatter pays per atomic request and for
+# its direct-atomics tail, the gather per (tile, RoI) pair and entry (round 3: merged taps, pipelined requests).  'auto' =
+# gather from GATHER_MIN_ROIS RoIs on (below, the scatter's smaller fixed cost on small maps).
 BACKWARD = 'auto'
-GATHER_MIN_ROIS = 512
+GATHER_MIN_ROIS = 16
 
 
 def roi_backward(grad_out, rois, feature_size, roi_kind, out_h, out_w, spatial_scale, sample_num, min_size):
