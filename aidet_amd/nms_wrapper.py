@@ -96,6 +96,9 @@ class _OnDevice(object):
 _ext = False     # obbops_torch (the ATen-level binding): None = not built, False = not tried yet
 
 
+_capacity_hint = {}     # (kind, bit length of n, grouped) -> pair capacity that the last overflowing call needed
+
+
 def _fast_ext():
     """``obbops_torch`` when it is built (``__graft_entry__.build()`` does): one pybind11 call then does what the ctypes
     path below does in ~15 interpreter-level steps -- allocation of the keep list and the workspace, device guard, stream
@@ -123,7 +126,13 @@ def _run_nms(dets_dev, kind, iou_thr, groups=None, thrs=None, strict=False):
         if groups is not None or thrs is not None:
             groups, _g, thrs, _t = _side_inputs(dev, n, groups, thrs)
         flags = _lib.NMS_STRICT if strict else 0
-        capacity = 0
+        # A call whose pair lists overflow is repeated with the capacity the library asks for -- twice the time.  A
+        # caller that does this every time (the RPN of a dense scene: 8768 boxes, 5.7e5 overlapping pairs, 0.32 instead
+        # of 0.19 ms per call) gets that capacity from the start next time: the hint lives per (kind, size class)
+        # and is dropped again when the scenes turn out 8x sparser than it.
+        hkey = (kind, int(n).bit_length(), groups is not None)
+        capacity = _capacity_hint.get(hkey, 0)
+        hinted = capacity
         while True:
             keep, rc, info = ext.nms_ex(dets_dev, kind, iou_thr, groups, thrs, flags, capacity)
             if rc != _lib.OBB_EWORKSPACE:
@@ -135,6 +144,10 @@ def _run_nms(dets_dev, kind, iou_thr, groups=None, thrs=None, strict=False):
                     'NMS on %d boxes needs a %.1f GiB pair workspace (capacity %d pairs): more than '
                     'nms_wrapper.MAX_WORKSPACE_BYTES; the scene is almost all mutual overlaps' %
                     (n, nbytes / 2.0 ** 30, capacity))
+        if capacity != hinted:
+            _capacity_hint[hkey] = capacity
+        elif hinted and 8 * max(int(info[3]), int(info[1])) < hinted:
+            _capacity_hint.pop(hkey, None)
         return keep, (info[1], info[2], info[3])
     L = _lib.lib()
     keep = torch.empty(n, dtype=torch.int64, device=dev)
