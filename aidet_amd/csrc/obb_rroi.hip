@@ -637,6 +637,40 @@ constexpr int kBwdMaxPix = 2047;                       // footprint pixels of th
 constexpr int kBwdStageFloats = 4096;                  // sums tile (16 KiB): 16 channels x 255 pixels, 8 x 511, 4 x 1023
 constexpr int kBwdMaxEntries = 4 * kMaxTabSamples;     // taps of a RoI (4 per sample)
 
+// The taps of one bin that land on the SAME pixel become one entry: the first tap of such a group is its leader and
+// carries the sum of the group's weights (ascending tap number: a fixed order).  A bin's taps are `tpb` consecutive tap
+// numbers = consecutive lanes (tpb a power of two <= 64, the lane groups aligned).  pix < 0: no tap in this lane.
+__device__ __forceinline__ void merge_bin_taps(int pix, float w, int lane, int tpb, bool &lead, float &sum_out) {
+  const int g0 = lane & ~(tpb - 1), me = lane - g0;
+  float sum = 0.0f;
+  bool first = true;
+  if (tpb == 16) {
+    // 2 x 2 samples per bin, the usual case: a bin's taps are one DPP row.  Rotating the row by 16 - d brings lane
+    // me + d (mod 16): d = 1 .. 15 visits me + 1 .. 15 (summed, ascending: the order of the loop below), then
+    // 0 .. me - 1 (the leader test).  VALU moves only -- the same exchanges through ds_bpermute (128 per thread)
+    // kept the LDS pipe of the CU busy for 4.8 us of a 12.6 us plan block.
+    sum = pix >= 0 ? w : 0.0f;
+#define OBB_ROW_STEP(D)                                                                                       \
+    {                                                                                                         \
+      const int pj = __builtin_amdgcn_update_dpp(0, pix, 0x120 + (16 - (D)), 0xF, 0xF, false);                \
+      const float wj = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(w), 0x120 + (16 - (D)), 0xF, 0xF, false)); \
+      if (pix >= 0 && pj == pix) { if (me + (D) >= 16) first = false; else sum += wj; }                        \
+    }
+    OBB_ROW_STEP(1) OBB_ROW_STEP(2) OBB_ROW_STEP(3) OBB_ROW_STEP(4) OBB_ROW_STEP(5) OBB_ROW_STEP(6) OBB_ROW_STEP(7)
+    OBB_ROW_STEP(8) OBB_ROW_STEP(9) OBB_ROW_STEP(10) OBB_ROW_STEP(11) OBB_ROW_STEP(12) OBB_ROW_STEP(13)
+    OBB_ROW_STEP(14) OBB_ROW_STEP(15)
+#undef OBB_ROW_STEP
+  } else {
+    for (int j = 0; j < tpb; ++j) {                      // ascending tap number: a fixed order
+      const int pj = __shfl(pix, g0 + j);
+      const float wj = __shfl(w, g0 + j);
+      if (pix >= 0 && pj == pix) { if (j < me) first = false; else sum += wj; }
+    }
+  }
+  lead = pix >= 0 && first;
+  sum_out = sum;
+}
+
 // plan record of the gather formulation (rroi_plan_kernel); state 1: planned, 2: left to the atomics kernel, 0: nothing sampled
 struct alignas(16) RoiPlan { int b, x0, y0, w, h, state, nb, pad; };
 
@@ -693,11 +727,23 @@ __global__ __launch_bounds__(256) void rroi_backward_kernel(
     pix = j == 0 ? o.x : (j == 1 ? o.y : (j == 2 ? o.z : o.w));
     w = j == 0 ? ww.x : (j == 1 ? ww.y : (j == 2 ? ww.z : ww.w));
   };
-  for (int t = tid; t < ntap; t += 256) {
-    int pix;
-    float w;
-    tap_of(t, pix, w);
-    if (w != 0.0f) atomicAdd(&pstart[pix], 1);       // (a zero weight adds nothing, also in the direct kernel)
+  // (the taps of a bin that land on one pixel are merged into one entry, as in rroi_plan_kernel)
+  const int tpb = 4 * spb;
+  const bool merge = tpb <= 64 && (tpb & (tpb - 1)) == 0;
+  constexpr int kTapIters = kBwdMaxEntries / 256;
+  bool lead[kTapIters];
+  float wsumq[kTapIters];
+#pragma unroll
+  for (int it = 0; it < kTapIters; ++it) {
+    const int t = tid + it * 256;
+    int pix = -1;
+    float w = 0.0f;
+    if (t < ntap) { tap_of(t, pix, w); w = w != 0.0f ? w / f.cnt : 0.0f; }   // weight / count: one division per tap and RoI
+    if (w == 0.0f) pix = -1;                          // (a zero weight adds nothing, also in the direct kernel)
+    lead[it] = pix >= 0;
+    wsumq[it] = w;
+    if (merge && tpb > 1 && __ballot(t < ntap)) merge_bin_taps(pix, w, lane, tpb, lead[it], wsumq[it]);
+    if (lead[it]) atomicAdd(&pstart[pix], 1);
   }
   __syncthreads();
   {  // exclusive scan of the counts (<= 2048 pixels: 8 per thread)
@@ -715,13 +761,15 @@ __global__ __launch_bounds__(256) void rroi_backward_kernel(
     if (tid == 255) pstart[fsz] = base;               // (tid 255 owns the last pixels: base = total)
     __syncthreads();
   }
-  for (int t = tid; t < ntap; t += 256) {
-    int pix;
-    float w;
-    tap_of(t, pix, w);
-    if (w != 0.0f) {
+#pragma unroll
+  for (int it = 0; it < kTapIters; ++it) {
+    const int t = tid + it * 256;
+    if (lead[it]) {
+      int pix;
+      float w;
+      tap_of(t, pix, w);
       const int slot = pstart[pix] + atomicAdd(&pfill[pix], 1);
-      entry[slot] = make_int2(t / (4 * spb), __float_as_int(w / f.cnt));   // weight / count: one division per tap and RoI
+      entry[slot] = make_int2(t / (4 * spb), __float_as_int(wsumq[it]));
     }
   }
   __syncthreads();   // entries complete; the table in `tile` is dead from here on
@@ -914,36 +962,7 @@ __global__ __launch_bounds__(256) void rroi_plan_kernel(
     if (w == 0.0f) pix = -1;                                 // (a zero weight adds nothing, also in the direct kernel)
     lead[it] = pix >= 0;
     wsumq[it] = w;
-    if (merge && tpb > 1 && __ballot(t < ntap)) {            // (wave-uniform)
-      const int g0 = lane & ~(tpb - 1), me = lane - g0;
-      float sum = 0.0f;
-      bool first = true;
-      if (tpb == 16) {
-        // 2 x 2 samples per bin, the usual case: a bin's taps are one DPP row.  Rotating the row by 16 - d brings lane
-        // me + d (mod 16): d = 1 .. 15 visits me + 1 .. 15 (summed, ascending: the order of the loop below), then
-        // 0 .. me - 1 (the leader test).  VALU moves only -- the same exchanges through ds_bpermute (128 per thread)
-        // kept the LDS pipe of the CU busy for 4.8 us of a 12.6 us block.
-        sum = pix >= 0 ? w : 0.0f;
-#define OBB_ROW_STEP(D)                                                                                       \
-        {                                                                                                     \
-          const int pj = __builtin_amdgcn_update_dpp(0, pix, 0x120 + (16 - (D)), 0xF, 0xF, false);            \
-          const float wj = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(w), 0x120 + (16 - (D)), 0xF, 0xF, false)); \
-          if (pix >= 0 && pj == pix) { if (me + (D) >= 16) first = false; else sum += wj; }                    \
-        }
-        OBB_ROW_STEP(1) OBB_ROW_STEP(2) OBB_ROW_STEP(3) OBB_ROW_STEP(4) OBB_ROW_STEP(5) OBB_ROW_STEP(6) OBB_ROW_STEP(7)
-        OBB_ROW_STEP(8) OBB_ROW_STEP(9) OBB_ROW_STEP(10) OBB_ROW_STEP(11) OBB_ROW_STEP(12) OBB_ROW_STEP(13)
-        OBB_ROW_STEP(14) OBB_ROW_STEP(15)
-#undef OBB_ROW_STEP
-      } else {
-        for (int j = 0; j < tpb; ++j) {                      // ascending tap number: a fixed order
-          const int pj = __shfl(pix, g0 + j);
-          const float wj = __shfl(w, g0 + j);
-          if (pix >= 0 && pj == pix) { if (j < me) first = false; else sum += wj; }
-        }
-      }
-      lead[it] = pix >= 0 && first;
-      wsumq[it] = sum;
-    }
+    if (merge && tpb > 1 && __ballot(t < ntap)) merge_bin_taps(pix, w, lane, tpb, lead[it], wsumq[it]);   // (wave-uniform)
     if (lead[it]) atomicAdd(&pstart[pix], 1);
   }
   __syncthreads();
