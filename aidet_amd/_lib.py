@@ -76,6 +76,8 @@ def lib():
         L.obb_soft_nms_f32.restype = i32
         L.obb_soft_nms_grouped_f32.argtypes = [vp, i64, vp, i64, f32, i32, f32, f32, vp, vp, vp, vp, ctypes.c_size_t, vp]
         L.obb_soft_nms_grouped_f32.restype = i32
+        L.obb_soft_nms_grouped_max_f32.argtypes = [vp, i64, vp, i64, i64, f32, i32, f32, f32, vp, vp, vp, vp, ctypes.c_size_t, vp]
+        L.obb_soft_nms_grouped_max_f32.restype = i32
         L.obb_rpn_select_decode_f32.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(i32),
                                                 ctypes.POINTER(i32), i32, i32, i32, i32, ctypes.POINTER(f32), ctypes.POINTER(f32),
                                                 f32, i32, i32, vp, vp, ctypes.POINTER(i64), vp]

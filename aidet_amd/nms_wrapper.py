@@ -407,7 +407,7 @@ def soft_nms_grouped(dets, seg_sizes, iou_thr, method='linear', sigma=0.5, min_s
     counts = torch.empty(G, dtype=torch.int64, device=dev)
     ws = torch.empty(max(int(L.obb_soft_nms_workspace_bytes(n)), 256), dtype=torch.uint8, device=dev)
     with _OnDevice(dev):
-        _lib.check(L.obb_soft_nms_grouped_f32(d.data_ptr(), n, seg_dev.data_ptr(), G, float(iou_thr), method_codes[method],
+        _lib.check(L.obb_soft_nms_grouped_max_f32(d.data_ptr(), n, seg_dev.data_ptr(), G, int(sizes.max()) if G else 0, float(iou_thr), method_codes[method],
                                               float(sigma), float(min_score), out.data_ptr(), oinds.data_ptr(),
                                               counts.data_ptr(), ws.data_ptr(), ws.numel(), _lib.current_stream_handle(dev)))
     res = []

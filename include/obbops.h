@@ -195,6 +195,12 @@ OBB_API int obb_soft_nms_grouped_f32(const float *dets_dev, int64_t n, const int
                                      float iou_thr, int method, float sigma, float min_score,
                                      float *out_dets_dev, int64_t *out_inds_dev, int64_t *counts_dev,
                                      void *workspace_dev, size_t workspace_bytes, void *stream);
+/* the same with the caller's bound on the rows of ONE group (the segment offsets are device memory): groups of up to 2048
+ * rows keep their state in LDS whatever the total is.  A group larger than the bound gets count -1 (nothing written). */
+OBB_API int obb_soft_nms_grouped_max_f32(const float *dets_dev, int64_t n, const int64_t *seg_dev, int64_t num_groups,
+                                         int64_t max_group, float iou_thr, int method, float sigma, float min_score,
+                                         float *out_dets_dev, int64_t *out_inds_dev, int64_t *counts_dev,
+                                         void *workspace_dev, size_t workspace_bytes, void *stream);
 
 /* Optional per-phase device timing of obb_nms_f32 (HIP events recorded on the
  * caller's stream; thread-local).  Phases: 0 clear + prep + quantise, 1 spatial
