@@ -517,3 +517,36 @@ def test_level_mapping_kernel_equals_the_tensor_expressions():
         rext = roi_layers.RotatedSingleRoIExtractor(dict(type='RRoIAlign', out_size=7, sample_num=2), 8, [4, 8, 16, 32][:n])
         assert torch.equal(roi_layers.map_levels(rb, n, rext.finest_scale, 0).long(), rext.map_roi_levels(rb, n))
     assert roi_layers.map_levels(hb[:0], 4, 56, 1).shape == (0,)
+
+
+def test_grouped_soft_nms_keeps_lds_state_for_many_small_groups():
+    """obb_soft_nms_grouped_max_f32: 15 groups of ~400 rows (6000 in all, beyond the 2048 rows one LDS state holds) run
+    on the LDS variant because every GROUP fits, with the results of one call per group; a bound above the row count is
+    clamped to it."""
+    from aidet_amd import _lib
+    from aidet_amd.nms_wrapper import soft_nms, soft_nms_grouped
+    rng = np.random.default_rng(9)
+    parts, sizes = [], []
+    for c in range(15):
+        m = int(rng.integers(300, 420))
+        x1, y1 = rng.uniform(0, 600, m), rng.uniform(0, 600, m)
+        parts.append(np.stack([x1, y1, x1 + rng.uniform(8, 150, m), y1 + rng.uniform(8, 150, m), rng.uniform(0.05, 1, m)], 1).astype(np.float32))
+        sizes.append(m)
+    d = t(np.concatenate(parts))
+    got = soft_nms_grouped(d, sizes, 0.5, min_score=0.05)
+    o = 0
+    for m, (gd, gi) in zip(sizes, got):
+        wd, wi = soft_nms(d[o:o + m], 0.5, min_score=0.05)
+        assert torch.equal(gi, wi) and torch.equal(gd, wd)
+        o += m
+    # a bound above n
+    L = _lib.lib()
+    n = d.size(0)
+    seg = torch.tensor([0, 100, 1000], dtype=torch.int64, device=dev())
+    out = torch.full((n, 5), -7.0, device=dev()); oi = torch.zeros(n, dtype=torch.int64, device=dev())
+    counts = torch.zeros(2, dtype=torch.int64, device=dev())
+    ws = torch.empty(int(L.obb_soft_nms_workspace_bytes(n)), dtype=torch.uint8, device=dev())
+    _lib.check(L.obb_soft_nms_grouped_max_f32(d.data_ptr(), 1000, seg.data_ptr(), 2, 4000, 0.5, 1, 0.5, 0.05, out.data_ptr(), oi.data_ptr(),
+                                              counts.data_ptr(), ws.data_ptr(), ws.numel(), _lib.current_stream_handle(dev())))
+    torch.cuda.synchronize()
+    assert int(counts[0]) > 0 and int(counts[1]) > 0          # (a bound above n is clamped to n: both groups run)
