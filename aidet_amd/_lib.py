@@ -182,6 +182,25 @@ def require_gpu():
 _raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
 
 
+class on_device(object):
+    """``with on_device(dev):`` -- torch's current device = dev (kernels launch there).  Unlike ``torch.cuda.device`` it
+    does nothing when the device already is current (the usual case: ~4 us per call saved, and every operator of this
+    package makes several calls)."""
+
+    def __init__(self, dev):
+        self.dev, self.prev = dev, None
+
+    def __enter__(self):
+        cur = torch.cuda.current_device()
+        if cur != self.dev.index and self.dev.index is not None:
+            self.prev = cur
+            torch.cuda.set_device(self.dev)
+
+    def __exit__(self, *exc):
+        if self.prev is not None:
+            torch.cuda.set_device(self.prev)
+
+
 def current_stream_handle(device):
     """hipStream_t of torch's current stream on `device` as an int."""
     if _raw_stream is not None:

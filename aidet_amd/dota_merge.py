@@ -61,7 +61,7 @@ def _i64(t):
 
 
 def _call(dev, fn, *args):
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         _lib.check(fn(*args, _lib.current_stream_handle(dev)))
 
 

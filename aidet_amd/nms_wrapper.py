@@ -227,7 +227,7 @@ def _take_rows(dets, inds):
             and not differentiable):   # (below 4096 rows the ctypes call costs more)
         src = dets.contiguous()
         out = src.new_empty((inds.numel(), src.size(1)))
-        with torch.cuda.device(src.device):
+        with _lib.on_device(src.device):
             _lib.check(_lib.lib().obb_gather_rows_f32(src.data_ptr(), src.size(0), src.size(1), inds.data_ptr(),
                                                       inds.numel(), src.size(1), out.data_ptr(),
                                                       _lib.current_stream_handle(src.device)))
@@ -480,7 +480,7 @@ def nms_collect(tickets):
         cur = torch.cuda.current_stream(dev)
         for i in idx:
             cur.wait_event(tickets[i].event)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             host = torch.stack([tickets[i].record for i in idx]).cpu().numpy()
         for row, i in zip(host, idx):
             recs[i] = row

@@ -319,7 +319,7 @@ def select_decode_candidates(rois, cls_score, pred, dim, score_thr, means, stds,
     labels = torch.empty(cap, dtype=torch.int32, device=dev)
     counts = torch.empty(C1, dtype=torch.int64, device=dev)
     m, sd, mh, mw, sf = _codec(dim, means, stds, img_shape, scale_factor)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         _lib.check(L.obb_head_select_decode_f32(r.data_ptr(), c.data_ptr(), p.data_ptr(), n, C1, p.size(1), dim, float(score_thr),
                                                 m, sd, 16 / 1000.0, mh, mw, sf, dets.data_ptr(), rows.data_ptr(),
                                                 labels.data_ptr(), counts.data_ptr(), _lib.current_stream_handle(dev)))
@@ -337,7 +337,7 @@ def gather_decode(rois, cls_score, pred, dim, rows, labels, sel, means, stds, im
     K = int(sel.numel()) if sel is not None else int(rows.numel())
     out = torch.empty((K, dim + 1), dtype=torch.float32, device=dev)
     m, sd, mh, mw, sf = _codec(dim, means, stds, img_shape, scale_factor)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         _lib.check(L.obb_head_gather_decode_f32(r.data_ptr(), c.data_ptr(), p.data_ptr(), c.size(1), p.size(1), dim,
                                                 rows.data_ptr(), labels.data_ptr(), None if sel is None else sel.data_ptr(), K,
                                                 m, sd, 16 / 1000.0, mh, mw, sf, out.data_ptr(), _lib.current_stream_handle(dev)))
@@ -357,7 +357,7 @@ def top_rows_by_score(rows, keep, max_num):
     out = torch.empty((max_num, rows.size(1)), dtype=torch.float32, device=dev)
     idx = torch.empty(max_num, dtype=torch.int64, device=dev)
     count = torch.empty(1, dtype=torch.int64, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         _lib.check(L.obb_rows_topk_f32(rows.data_ptr(), rows.size(0), rows.size(1), rows.size(1) - 1, keep.data_ptr(), K, None, 0, 0,
                                        int(max_num), out.data_ptr(), idx.data_ptr(), count.data_ptr(), _lib.current_stream_handle(dev)))
     return out, idx             # (K > max_num valid rows: exactly max_num come back)

@@ -198,7 +198,7 @@ def _overlaps(b1, b2, mode, is_aligned, cols, kind, row_shard=None):
     a = _lib.to_device_f32(b1)
     b = _lib.to_device_f32(b2).to(a.device)
     out = torch.empty((rows,) if is_aligned else (rows, n), dtype=torch.float32, device=a.device)
-    with torch.cuda.device(a.device):
+    with _lib.on_device(a.device):
         rc = _lib.lib().obb_overlaps_f32(
             ctypes.c_void_p(a.data_ptr()), rows, ctypes.c_void_p(b.data_ptr()), n, kind,
             _lib.MODE[mode], 1 if is_aligned else 0, ctypes.c_void_p(out.data_ptr()),
@@ -279,7 +279,7 @@ def thetaobb2pointobb(thetaobbs):
         return thetaobbs.new_zeros((0, 8))
     a = _lib.to_device_f32(t)
     out = torch.empty((n, 8), dtype=torch.float32, device=a.device)
-    with torch.cuda.device(a.device):
+    with _lib.on_device(a.device):
         rc = _lib.lib().obb_rbox_to_poly_f32(ctypes.c_void_p(a.data_ptr()), n,
                                              ctypes.c_void_p(out.data_ptr()),
                                              _lib.stream_ptr(a.device))

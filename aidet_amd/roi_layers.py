@@ -50,7 +50,7 @@ def roi_backward(grad_out, rois, feature_size, roi_kind, out_h, out_w, spatial_s
     K = rois.size(0)
     dev = g.device
     L = _lib.lib()
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         st = _lib.current_stream_handle(dev)
         if BACKWARD == 'gather' or (BACKWARD == 'auto' and K >= GATHER_MIN_ROIS):
             grad = torch.empty((B, C, H, W), dtype=torch.float32, device=dev)
@@ -174,7 +174,7 @@ def map_levels(rois, num_levels, finest_scale, roi_kind):
     expressions of the methods are the specification (and every other case)."""
     r = rois.detach().contiguous()
     out = torch.empty(r.size(0), dtype=torch.int32, device=r.device)
-    with torch.cuda.device(r.device):
+    with _lib.on_device(r.device):
         _lib.check(_lib.lib().obb_roi_map_levels_i32(r.data_ptr(), r.size(0), int(roi_kind), float(finest_scale), int(num_levels),
                                                     out.data_ptr(), _lib.current_stream_handle(r.device)))
     return out

@@ -52,7 +52,7 @@ def _rpn_proposals_fused(cls_scores, bbox_preds, mlvl_anchors, img_shape, nms_pr
     pr = (ctypes.c_void_p * n)(*[r.data_ptr() for r in reg])
     pa = (ctypes.c_void_p * n)(*[a.data_ptr() for a in anc])
     mh, mw = (int(img_shape[0]), int(img_shape[1])) if img_shape is not None else (0, 0)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         st = _lib.current_stream_handle(dev)
         wsb = int(L.obb_rpn_select_workspace_bytes(hs, wd, n, A, int(nms_pre)))    # (> 0: large levels, several workgroups each)
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if wsb else None
