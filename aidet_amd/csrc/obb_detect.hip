@@ -325,11 +325,13 @@ constexpr int kSliceAnchors = 8192;      // anchors per workgroup (8 per thread)
 constexpr int kMaxSlices = 64;           // slices per level (levels of up to 524 288 anchors)
 constexpr int kGroupMaxBlocks = 192;     // workgroups of one launch: all must be resident at once (256 CUs)
 constexpr int kGroupWords = 3 * 2048 + 8;   // per level: three global histograms + barrier counters
+constexpr int kGroupFailWord = 4;           // bar[0..3]: the four barriers; bar[4]: a barrier of the level timed out
 struct RpnGroup {
   int first_slice[OBB_MAX_LEVELS + 1];   // first slice of every level (a level without slices: same as the next)
   uint32_t *words;                       // [levels][kGroupWords] zeroed before the launch
   uint32_t *bcnt;                        // [slices][2] keys above / at the threshold
   uint2 *sel;                            // [levels][kSelMax] the selected (key, anchor index) pairs
+  int64_t spin_ticks;                    // bound of a barrier wait (wall clock, 100 MHz)
 };
 
 __device__ __forceinline__ uint32_t ld_agent(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -338,14 +340,29 @@ __device__ __forceinline__ uint32_t ld_agent(const uint32_t *p) { return __hip_a
 // (what the workgroups exchange is written by agent-scope atomics only -- performed at the coherence point, nothing
 // dirty in a cache -- and read back by agent-scope loads: every wave waits for its own atomics to be acknowledged,
 // then ONE thread arrives; a release / acquire fence pair would cost a cache write-back and invalidate per barrier)
-__device__ __forceinline__ void group_barrier(uint32_t *counter, uint32_t members) {
+// The wait is BOUNDED: co-residency of a level's workgroups is sized on the host (slices <= CUs) but not
+// guaranteed -- a CU mask, another process or stream on the CUs, a partitioned device.  After kGroupSpinTicks of the
+// 100 MHz wall clock the waiting workgroup raises the level's `fail` word and leaves; a workgroup that gets through a
+// barrier while `fail` is up leaves too, so every member ends (possibly one barrier later), and
+// rpn_select_decode_kernel, which runs after this launch, selects a failed level alone (block_topk_sorted_big).
+constexpr int64_t kGroupSpinTicks = 25000000;      // 0.25 s (OBB_TUNE_RPN_BARRIER_TICKS)
+__device__ __forceinline__ bool group_barrier(uint32_t *counter, uint32_t members, uint32_t *fail, int *s_flag, uint64_t ticks) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
     __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < members) __builtin_amdgcn_s_sleep(2);
+    const uint64_t t0 = wall_clock64();
+    int ok = 1;
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < members) {
+      __builtin_amdgcn_s_sleep(2);
+      if (wall_clock64() - t0 >= ticks) { ok = 0; break; }
+    }
+    if (!ok) __hip_atomic_fetch_or(fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else if (__hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) ok = 0;
+    *s_flag = ok;
   }
   __syncthreads();
+  return *s_flag != 0;
 }
 
 __global__ __launch_bounds__(kSelThreads) void rpn_group_select_kernel(const RpnLevels lv, int A, int use_sigmoid, int num_levels,
@@ -353,6 +370,7 @@ __global__ __launch_bounds__(kSelThreads) void rpn_group_select_kernel(const Rpn
   __shared__ SelScratch sc;
   __shared__ int wc[2][kSliceAnchors / kSelThreads][kSelThreads / 64];
   __shared__ uint32_t soff[2];
+  __shared__ int s_bar_ok;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int l = 0;
   while (l + 1 < num_levels && (int)blockIdx.x >= g.first_slice[l + 1]) ++l;
@@ -387,7 +405,7 @@ __global__ __launch_bounds__(kSelThreads) void rpn_group_select_kernel(const Rpn
     __syncthreads();
     uint32_t *gh = ghist + pass * 2048;
     for (int b = tid; b < nb; b += kSelThreads) { const uint32_t v = sc.hist[b]; if (v) atomicAdd(&gh[b], v); }
-    group_barrier(&bar[pass], members);
+    if (!group_barrier(&bar[pass], members, &bar[kGroupFailWord], &s_bar_ok, (uint64_t)g.spin_ticks)) return;
     radix_digit([&](int b) { return ld_agent(&gh[b]); }, nb, sh, pre, sc);
     himask |= (uint32_t)(nb - 1) << sh;
   }
@@ -409,7 +427,7 @@ __global__ __launch_bounds__(kSelThreads) void rpn_group_select_kernel(const Rpn
     __hip_atomic_store(&g.bcnt[2 * blockIdx.x], (uint32_t)tg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(&g.bcnt[2 * blockIdx.x + 1], (uint32_t)te, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  group_barrier(&bar[3], members);
+  if (!group_barrier(&bar[3], members, &bar[kGroupFailWord], &s_bar_ok, (uint64_t)g.spin_ticks)) return;
   if (wave == 0) {                                     // keys of the earlier slices of this level (<= 64 slices: one wave)
     uint32_t vg = 0, ve = 0;
     if (lane < slice) { vg = ld_agent(&g.bcnt[2 * (g.first_slice[l] + lane)]); ve = ld_agent(&g.bcnt[2 * (g.first_slice[l] + lane) + 1]); }
@@ -458,7 +476,8 @@ __global__ __launch_bounds__(kSelThreads) void rpn_select_decode_kernel(const Rp
   };
   const bool select = k < n;
   bool done = false;
-  if (select && g.sel && g.first_slice[l + 1] > g.first_slice[l]) {
+  if (select && g.sel && g.first_slice[l + 1] > g.first_slice[l] &&
+      ld_agent(g.words + (size_t)l * kGroupWords + 3 * 2048 + kGroupFailWord) == 0u) {      // (block-uniform)
     // the k (key, anchor) pairs rpn_group_select_kernel left for this level: sort them
     const uint2 *list = g.sel + (size_t)l * kSelMax;
     for (int j = tid; j < k; j += kSelThreads) { const uint2 e = list[j]; sk[j] = e.x; si[j] = e.y; }
@@ -765,6 +784,7 @@ extern "C" int obb_rpn_select_decode_ws_f32(const float *const *cls_devs_host, c
       g.words = reinterpret_cast<uint32_t *>(w);
       g.sel = reinterpret_cast<uint2 *>(w + rpn_ws_zeroed(num_levels));
       g.bcnt = reinterpret_cast<uint32_t *>(w + rpn_ws_zeroed(num_levels) + (size_t)num_levels * kSelMax * sizeof(uint2));
+      g.spin_ticks = tuning(OBB_TUNE_RPN_BARRIER_TICKS, kGroupSpinTicks);
       OBB_HIP_TRY(hipMemsetAsync(g.words, 0, rpn_ws_zeroed(num_levels), (hipStream_t)stream));
       hipLaunchKernelGGL(rpn_group_select_kernel, dim3((unsigned)slices), dim3(kSelThreads), 0, (hipStream_t)stream, lv, num_anchors,
                          use_sigmoid ? 1 : 0, num_levels, g);

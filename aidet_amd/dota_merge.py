@@ -39,6 +39,7 @@ import ctypes
 import torch
 import torch.distributed as dist
 
+from . import _collectives as coll
 from . import _lib, nms_wrapper
 
 COLS = 8  # cx, cy, w, h, theta, score, label, image_id
@@ -214,7 +215,7 @@ def _gather_padded(local, group=None, pad_last=0.0):
         return local, [local.size(0)], local.size(0)
     n = torch.tensor([local.size(0)], dtype=torch.int64, device=local.device)
     counts = torch.empty(world, dtype=torch.int64, device=local.device)
-    dist.all_gather_into_tensor(counts, n, group=group)             # cf. test.py:124
+    coll.all_gather_into_tensor(counts, n, group=group)             # cf. test.py:124
     counts = counts.tolist()
     nmax = max(max(counts), 1)
     pad = local.new_zeros((nmax, local.size(1)))
@@ -222,7 +223,7 @@ def _gather_padded(local, group=None, pad_last=0.0):
     if pad_last != 0.0:
         pad[local.size(0):, -1] = pad_last
     parts = local.new_empty((world * nmax, local.size(1)))
-    dist.all_gather_into_tensor(parts, pad, group=group)            # cf. test.py:133
+    coll.all_gather_into_tensor(parts, pad, group=group)            # cf. test.py:133
     return parts, counts, nmax
 
 
@@ -368,13 +369,13 @@ def routed_merge(local, iou_thr, num_classes, class_thrs=None, group=None, nms_f
     if world > 1:
         send, counts = route_rows(local, world, order_key)
         mat = torch.empty(world * (world + 1), dtype=torch.int64, device=dev)
-        dist.all_gather_into_tensor(mat, counts, group=group)
+        coll.all_gather_into_tensor(mat, counts, group=group)
         mat = mat.view(world, world + 1).tolist()                    # mat[src][dst] | unordered keys; the one host read
         if any(row[world] for row in mat):
             raise ValueError('order_key: the keys of a rank must be non-decreasing in its row order')
         in_splits, out_splits = mat[rank][:world], [mat[src][rank] for src in range(world)]
         recv = send.new_empty((sum(out_splits), ncols + 1))
-        dist.all_to_all_single(recv, send, out_splits, in_splits, group=group)
+        coll.all_to_all_single(recv, send, out_splits, in_splits, group=group)
         # rows of one source arrive together and in order; patches interleave over the sources
         mine = recv
         if order_key is not None and mine.size(0) > 0:
@@ -464,7 +465,7 @@ def distributed_merge(local, iou_thr, num_classes, class_thrs=None, group=None, 
         # all-reduce of a byte mask (an all-gather of index lists needs two collectives and a sort)
         mask = torch.zeros(allrows.size(0), dtype=torch.uint8, device=allrows.device)
         mask[mine] = 1
-        dist.all_reduce(mask, op=dist.ReduceOp.MAX, group=group)
+        coll.all_reduce(mask, op=dist.ReduceOp.MAX, group=group)
         keep = mask.nonzero(as_tuple=True)[0]
         kept = gather_rows(allrows, keep)
     else:

@@ -66,6 +66,10 @@ def parse_args():
     ap.add_argument('--merge-layout', default='replicated', choices=['replicated', 'sharded', 'routed'],
                     help='layout of the cfg5 leg that config.cfg5_* reports (the others are timed beside it at N > 1)')
     ap.add_argument('--no-cfg5', action='store_true', help='skip the cfg5 leg')
+    ap.add_argument('--transport', default='rccl', choices=['rccl', 'gloo'],
+                    help='rccl (default; backend "nccl" IS RCCL on ROCm, one rank per GPU) | gloo: DEBUG ONLY -- the ranks may '
+                         'share GPUs (rank r uses cuda:(r mod #GPUs)) and every collective is staged through host memory '
+                         '(aidet_amd/_collectives.py), so that the N > 1 code path can be smoke-run on a one-GPU box')
     ap.add_argument('--profile-target', default=None,
                     choices=['nms', 'iou_sparse', 'iou_dense', 'rroi_fwd', 'rroi_bwd', 'rroi_bwd_scatter', 'roi_fwd', 'cfg5'],
                     help='run ONLY this op (for rocprofv3 passes: one workload per kernel name)')
@@ -116,11 +120,14 @@ def bench_all(args):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    if args.transport == 'gloo':
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if dist is not None:
-        dist.init_process_group('nccl', rank=rank, world_size=world)
+        dist.init_process_group('nccl' if args.transport == 'rccl' else 'gloo', rank=rank, world_size=world)
         assert dist.get_world_size() == world
+    from aidet_amd import _collectives as coll
 
     def barrier():
         if dist is not None:
@@ -130,7 +137,7 @@ def bench_all(args):
         if dist is None:
             return x
         tt = torch.tensor([x], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        coll.all_reduce(tt, op=dist.ReduceOp.MAX)
         return float(tt.item())
 
     # ---- leg 1: replica -- configs[1] on every rank ------------------------------------------
@@ -217,6 +224,8 @@ def bench_all(args):
     }
     if dist is not None:
         out['rccl_ranks'] = dist.get_world_size()
+        out['transport'] = 'rccl' if args.transport == 'rccl' else \
+            'gloo (debug: ranks share GPUs, collectives staged through host; timings are not product numbers)'
     ok = True
     if cfg5 is not None:
         out['config'].update(cfg5['flat'])
@@ -246,6 +255,7 @@ def cfg5_leg(args, dev, rank, world, dist):
 
     import numpy as np
     import torch
+    from aidet_amd import _collectives as coll
     from aidet_amd import dota_merge
     steps = max(5, min(args.steps, 20))
     layouts = [args.merge_layout] + ([l for l in ('replicated', 'sharded', 'routed') if l != args.merge_layout] if world > 1 else [])
@@ -263,12 +273,12 @@ def cfg5_leg(args, dev, rank, world, dist):
         same = True
         if dist is not None:
             tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)          # the slowest rank's time is the job's
+            coll.all_reduce(tt, op=dist.ReduceOp.MAX)          # the slowest rank's time is the job's
             elapsed = float(tt.item())
             # every rank holds the same kept rows?  (hash all-reduced as min / max)
             digest = int(hashlib.sha256(kept_rows.cpu().numpy().tobytes()).hexdigest()[:15], 16)
             hh = torch.tensor([digest, -digest], dtype=torch.int64, device=dev)
-            dist.all_reduce(hh, op=dist.ReduceOp.MAX)
+            coll.all_reduce(hh, op=dist.ReduceOp.MAX)
             same = bool(hh[0].item() == -hh[1].item())
         ok_single = None
         if rank == 0:
@@ -283,7 +293,7 @@ def cfg5_leg(args, dev, rank, world, dist):
         good = 1 if (rank != 0 or (same and ok_single)) else 0
         if dist is not None:
             g = torch.tensor([good], dtype=torch.int64, device=dev)
-            dist.all_reduce(g, op=dist.ReduceOp.MIN)
+            coll.all_reduce(g, op=dist.ReduceOp.MIN)
             good = int(g.item())
         ok_all = ok_all and bool(good)
         if li == 0:

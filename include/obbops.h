@@ -496,7 +496,8 @@ OBB_API int obb_head_gather_decode_f32(const float *rois_dev, const float *cls_s
 #define OBB_TUNE_NMS_INLINE_MAX 5     /* largest n whose sorted scan clips its candidates in line     */
 #define OBB_TUNE_RROI_ORDER_MIN 6     /* fewest RoIs the workspace forward puts into Morton order      */
 #define OBB_TUNE_RROI_GATHER_CHAN 7   /* channels per block of the gather backward (16 or 32)          */
-#define OBB_TUNE_COUNT 8
+#define OBB_TUNE_RPN_BARRIER_TICKS 8  /* bound (100 MHz ticks) of the level barrier of the RPN selection; 0 forces the fallback */
+#define OBB_TUNE_COUNT 9
 OBB_API int obb_set_tuning(int knob, int64_t value);
 
 #ifdef __cplusplus
