@@ -152,6 +152,17 @@ def lib():
         L.obb_rows_restore_f32.argtypes = [vp, i64, i32, i32, ctypes.POINTER(ctypes.c_int64), i32, i64, i32, i64, vp, vp, vp,
                                            ctypes.c_size_t, vp]
         L.obb_rows_restore_f32.restype = i32
+        L.obb_tiled_local_workspace_bytes.argtypes = [i64, i32, i64]
+        L.obb_tiled_local_workspace_bytes.restype = ctypes.c_size_t
+        L.obb_tiled_local_f32.argtypes = [vp, vp, vp, i64, vp, vp, i64, i64, f32, f32, i32, vp, vp, vp, ctypes.c_size_t, vp]
+        L.obb_tiled_local_f32.restype = i32
+        L.obb_tiled_merge_workspace_bytes.argtypes = [i64, i32, i32, i64, i64]
+        L.obb_tiled_merge_workspace_bytes.restype = ctypes.c_size_t
+        L.obb_tiled_merge_f32.argtypes = [vp, i64, i32, i32, ctypes.POINTER(ctypes.c_int64), i32, i64, i64, i64, vp, f32, i32, vp,
+                                          vp, i32, vp, vp, vp, vp, ctypes.c_size_t, vp]
+        L.obb_tiled_merge_f32.restype = i32
+        L.obb_tiled_result.argtypes = [vp, i32, i64, i32, i32, i64, ctypes.c_size_t, ctypes.POINTER(i64)]
+        L.obb_tiled_result.restype = i32
         _lib = L
     return _lib
 

@@ -15,6 +15,7 @@
 // Pure data movement plus one add and one divide per coordinate, evaluated exactly like the
 // tensor expressions they replace (aidet_amd/dota_merge.py): results are bit-identical.
 #include "obb_common.h"
+#include "obb_nms_internal.h"
 
 namespace obb {
 
@@ -294,6 +295,210 @@ __global__ __launch_bounds__(256) void restore_scatter_kernel(const float *__res
   for (int c = 0; c < out_cols; ++c) dst[c] = src[c];
 }
 
+
+// ---- one tiled pass without the host (round 4) ---------------------------------------------------------------------
+// obb_tiled_local_f32 / obb_tiled_merge_f32 enqueue a whole rank-side phase of BASELINE configs[4]; the kept count of
+// the phase's NMS is read from its result record ON THE DEVICE (word 0), so the kernels after it are launched over
+// the upper bound (all rows) and the threads beyond K leave.
+
+// image row of kept detection i (patch_rows_kernel's arithmetic, evaluated by whoever needs the row)
+struct TiledSrc {
+  const float *dets; const int64_t *labels, *patch; int64_t n;
+  const int64_t *keep; const void *record;           // ascending keep list + result record of the per-patch NMS
+  const float *patch_xy; const int64_t *patch_image; int64_t num_patches; float rate;
+};
+struct TiledCaps { unsigned long long cap, segcap; unsigned int ucap; };   // what the NMS was launched with
+
+// K of the phase's NMS as the exchange publishes it: the kept count, or -(a pair capacity that suffices) when the
+// call overflowed its pair lists (every rank sees every rank's word after the all-gather of the counts and repeats
+// the exchange together)
+__device__ __forceinline__ int64_t tiled_k_word(const void *record, const TiledCaps &c) {
+  const NmsHostInfo h = *reinterpret_cast<const NmsHostInfo *>(record);
+  const unsigned long long need = nms_need_capacity(h, c.cap, c.segcap, c.ucap, nullptr);
+  return need ? -(int64_t)need : (int64_t)h.kept;
+}
+
+__device__ __forceinline__ int64_t tiled_patch_of(const TiledSrc &t, int64_t i, int64_t &src) {
+  src = t.keep[i];
+  return (src >= 0 && src < t.n) ? t.patch[src] : -1;
+}
+__device__ __forceinline__ float tiled_image_of(const TiledSrc &t, int64_t src, int64_t p) {
+  return (src >= 0 && src < t.n && p >= 0 && p < t.num_patches) ? (float)t.patch_image[p] : -1.0f;
+}
+__device__ __forceinline__ void tiled_row(const TiledSrc &t, int64_t src, int64_t p, float4 &a, float4 &b) {
+  a = make_float4(0.0f, 0.0f, 0.0f, 0.0f); b = make_float4(0.0f, 0.0f, -1.0f, -1.0f);
+  if (src >= 0 && src < t.n && p >= 0 && p < t.num_patches) {
+    const float2 *d = reinterpret_cast<const float2 *>(t.dets + src * 6);
+    const float2 d0 = d[0], d1 = d[1], d2 = d[2];
+    const float2 o = reinterpret_cast<const float2 *>(t.patch_xy)[p];
+    a.x = (d0.x + o.x) / t.rate; a.y = (d0.y + o.y) / t.rate;
+    a.z = d1.x / t.rate; a.w = d1.y / t.rate;
+    b.x = d2.x; b.y = d2.y;
+    b.z = (float)t.labels[src];
+    b.w = (float)t.patch_image[p];
+  }
+}
+__device__ __forceinline__ void tiled_store_row(float *__restrict__ out, int64_t pos, const float4 &a, const float4 &b, float key) {
+  float *d = out + pos * 9;                      // rows of 36 bytes: 4-byte stores
+  d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w; d[8] = key;
+}
+
+// one rank: rows in keep order, counts = [K, 0, K]
+__global__ __launch_bounds__(kMergeThreads) void tiled_rows_kernel(const TiledSrc t, const TiledCaps caps, float *__restrict__ out,
+                                                                   int64_t *__restrict__ counts) {
+  const int64_t K = nms_record_kept(t.record);
+  const int64_t i = (int64_t)blockIdx.x * kMergeThreads + threadIdx.x;
+  if (i == 0) { counts[0] = K; counts[1] = 0; counts[2] = tiled_k_word(t.record, caps); }
+  if (i >= K) return;
+  int64_t src;
+  const int64_t p = tiled_patch_of(t, i, src);
+  float4 a, b;
+  tiled_row(t, src, p, a, b);
+  tiled_store_row(out, i, a, b, (float)p);
+}
+
+__global__ __launch_bounds__(256) void tiled_route_count_kernel(const TiledSrc t, int world, int nblocks,
+                                                                int *__restrict__ blockcnt, int *__restrict__ blockviol) {
+  __shared__ int hist[kRouteMaxWorld];
+  __shared__ int viol;
+  const int tid = threadIdx.x;
+  const int64_t K = nms_record_kept(t.record);
+  if (tid < kRouteMaxWorld) hist[tid] = 0;
+  if (tid == 0) viol = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * kRouteRows;
+  int bad = 0;
+#pragma unroll
+  for (int u = 0; u < kRouteRows / 256; ++u) {
+    const int64_t i = base + u * 256 + tid;
+    if (i < K) {
+      int64_t src, sp;
+      const int64_t p = tiled_patch_of(t, i, src);
+      atomicAdd(&hist[route_bucket(tiled_image_of(t, src, p), world)], 1);
+      if (i > 0 && p < tiled_patch_of(t, i - 1, sp)) ++bad;
+    }
+  }
+  if (bad) atomicAdd(&viol, bad);
+  __syncthreads();
+  if (tid < world) blockcnt[(int64_t)tid * nblocks + blockIdx.x] = hist[tid];
+  if (tid == 0) blockviol[blockIdx.x] = viol;
+}
+
+__global__ __launch_bounds__(kScanThreads) void tiled_route_scan_kernel(int *__restrict__ blockcnt, int world, int nblocks,
+                                                                        const int *__restrict__ blockviol,
+                                                                        const void *__restrict__ record, const TiledCaps caps,
+                                                                        int64_t *__restrict__ counts) {
+  __shared__ int part[kScanThreads / 64 + 1];
+  __shared__ int vsum;
+  const int tid = threadIdx.x;
+  if (tid == 0) vsum = 0;
+  __syncthreads();
+  int v = 0;
+  for (int j = tid; j < nblocks; j += kScanThreads) v += blockviol[j];
+  if (v) atomicAdd(&vsum, v);
+  const int total = block_scan_inplace(blockcnt, (int64_t)world * nblocks, part);
+  if (tid < world) {
+    const int lo = blockcnt[(int64_t)tid * nblocks];
+    const int hi = tid + 1 < world ? blockcnt[(int64_t)(tid + 1) * nblocks] : total;
+    counts[tid] = hi - lo;
+  }
+  if (tid == 0) { counts[world] = vsum; counts[world + 1] = tiled_k_word(record, caps); }
+}
+
+__global__ __launch_bounds__(256) void tiled_route_scatter_kernel(const TiledSrc t, int world, int nblocks,
+                                                                  const int *__restrict__ offs, float *__restrict__ out) {
+  constexpr int kU = kRouteRows / 256;
+  __shared__ int wc[kU * 4 + 1][kRouteMaxWorld];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t K = nms_record_kept(t.record);
+  const int64_t base = (int64_t)blockIdx.x * kRouteRows;
+  if (base >= K) return;                                  // (block-uniform)
+  for (int j = tid; j < (kU * 4 + 1) * kRouteMaxWorld; j += 256) (&wc[0][0])[j] = 0;
+  __syncthreads();
+  int bk[kU], rk[kU];
+  int64_t srcs[kU], ps[kU];
+#pragma unroll
+  for (int u = 0; u < kU; ++u) {
+    const int64_t i = base + u * 256 + tid;
+    const bool valid = i < K;
+    srcs[u] = -1; ps[u] = -1;
+    if (valid) ps[u] = tiled_patch_of(t, i, srcs[u]);
+    bk[u] = valid ? route_bucket(tiled_image_of(t, srcs[u], ps[u]), world) : -1;
+    rk[u] = 0;
+    uint64_t rem = __ballot(valid);
+    while (rem) {                                    // one round per bucket present in the wave
+      const int lead = __builtin_ctzll(rem);
+      const int bl = __builtin_amdgcn_readlane(bk[u], lead);
+      const uint64_t m = __ballot(bk[u] == bl);
+      if (bk[u] == bl) rk[u] = __popcll(m & ((1ull << lane) - 1ull));
+      if (lane == lead) wc[u * 4 + wave][bl] = __popcll(m);
+      rem &= ~m;
+    }
+  }
+  __syncthreads();
+  if (tid < world) {                                 // exclusive prefix over (pass, wave) in row order, per bucket
+    int run = offs[(int64_t)tid * nblocks + blockIdx.x];
+    for (int j = 0; j < kU * 4; ++j) { const int v = wc[j][tid]; wc[j][tid] = run; run += v; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < kU; ++u) {
+    const int64_t i = base + u * 256 + tid;
+    if (i >= K) continue;
+    const int64_t pos = (int64_t)wc[u * 4 + wave][bk[u]] + rk[u];
+    float4 a, b;
+    tiled_row(t, srcs[u], ps[u], a, b);
+    tiled_store_row(out, pos, a, b, (float)ps[u]);
+  }
+}
+
+// kept rows of the merged NMS: out[i, :out_cols] = rows[keep[i], :out_cols] for i < K (K from the record)
+__global__ __launch_bounds__(kMergeThreads) void tiled_gather_kernel(const float *__restrict__ rows, int ld, int64_t n,
+                                                                     const int64_t *__restrict__ keep,
+                                                                     const void *__restrict__ record, int out_cols,
+                                                                     float *__restrict__ out) {
+  const int64_t K = nms_record_kept(record);
+  const int64_t w = (int64_t)blockIdx.x * kMergeThreads + threadIdx.x;
+  if (w >= K * out_cols) return;
+  const int64_t i = w / out_cols;
+  const int c = (int)(w - i * out_cols);
+  const int64_t s = keep[i];
+  out[w] = (s >= 0 && s < n) ? rows[s * ld + c] : 0.0f;
+}
+
+struct TiledLocalLayout { size_t keep, route, nms, nms_bytes, total; int nblocks; };
+static int tiled_local_layout(int64_t n, int world, int64_t pair_capacity, TiledLocalLayout &L) {
+  if (n < 0 || world < 1 || world > kRouteMaxWorld) return OBB_EINVAL;
+  const size_t nn = (size_t)(n > 0 ? n : 1);
+  L.nblocks = (int)((nn + kRouteRows - 1) / kRouteRows);
+  size_t off = 0;
+  L.keep = off; off = align_up(off + nn * sizeof(int64_t), 256);
+  L.route = off; off = align_up(off + ((size_t)L.nblocks * world + L.nblocks + 16) * sizeof(int), 256);
+  L.nms = off;
+  L.nms_bytes = obb_nms_workspace_bytes(n, OBB_KIND_RBOX, pair_capacity);
+  if (L.nms_bytes == 0) return OBB_EINVAL;
+  L.total = off + L.nms_bytes;
+  return OBB_OK;
+}
+
+struct TiledMergeLayout { size_t restore, restore_bytes, nms, nms_bytes, total; };
+static int tiled_merge_layout(int64_t total_rows, int kind, int world, int64_t key_max, int64_t pair_capacity, TiledMergeLayout &L) {
+  size_t off = 0;
+  L.restore = off; L.restore_bytes = 0;
+  if (key_max >= 0) {
+    L.restore_bytes = obb_rows_restore_workspace_bytes(world, key_max);
+    if (L.restore_bytes == 0) return OBB_EINVAL;
+    off = align_up(off + L.restore_bytes, 256);
+  }
+  L.nms = off;
+  L.nms_bytes = obb_nms_workspace_bytes(total_rows, kind, pair_capacity);
+  if (L.nms_bytes == 0) return OBB_EINVAL;
+  L.total = off + L.nms_bytes;
+  return OBB_OK;
+}
+
+static int tiled_kind(int cols) { return cols == 8 ? OBB_KIND_RBOX : (cols == 11 ? OBB_KIND_POLY : (cols == 7 ? OBB_KIND_HBB : -1)); }
+
 static int merge_grid(const char *who, int64_t items, unsigned &blocks) {
   const int64_t b = (items + kMergeThreads - 1) / kMergeThreads;
   if (b > 2147483647LL) return set_err(OBB_EINVAL, "%s: too many rows", who);
@@ -460,4 +665,134 @@ extern "C" int obb_rows_restore_f32(const float *rows_dev, int64_t n, int cols, 
                      cnt, first, out_cols, total, out_dev);
   OBB_LAUNCH_CHECK();
   return OBB_OK;
+}
+
+// ---- fused phases of a tiled pass ------------------------------------------------------------------------------------
+extern "C" size_t obb_tiled_local_workspace_bytes(int64_t n, int world, int64_t pair_capacity) {
+  obb::TiledLocalLayout L;
+  if (obb::tiled_local_layout(n, world, pair_capacity, L) != OBB_OK) return 0;
+  return L.total;
+}
+
+extern "C" int obb_tiled_local_f32(const float *dets_dev, const int64_t *labels_dev, const int64_t *patch_index_dev,
+                                   int64_t n, const float *patch_xy_dev, const int64_t *patch_image_dev,
+                                   int64_t num_patches, int64_t num_classes, float rate, float iou_thr, int world,
+                                   float *rows_dev, int64_t *counts_dev, void *workspace_dev, size_t workspace_bytes,
+                                   void *stream) {
+  using namespace obb;
+  const char *who = "obb_tiled_local_f32";
+  if (n < 0 || num_patches < 0 || num_classes < 1) return set_err(OBB_EINVAL, "%s: bad size", who);
+  if (world < 1 || world > kRouteMaxWorld) return set_err(OBB_EINVAL, "%s: 1 <= world <= %d", who, kRouteMaxWorld);
+  if (!(rate > 0.0f)) return set_err(OBB_EINVAL, "%s: rate must be positive", who);
+  if (!counts_dev) return set_err(OBB_EINVAL, "%s: null pointer", who);
+  hipStream_t st = (hipStream_t)stream;
+  const size_t cbytes = (size_t)(world + 2) * sizeof(int64_t) + OBB_NMS_RESULT_BYTES;
+  if (n == 0) {      // nothing detected: zero counts, an all-zero record (K = 0)
+    OBB_HIP_TRY(hipMemsetAsync(counts_dev, 0, cbytes, st));
+    return OBB_OK;
+  }
+  if (!dets_dev || !labels_dev || !patch_index_dev || !patch_xy_dev || !patch_image_dev || !rows_dev || !workspace_dev)
+    return set_err(OBB_EINVAL, "%s: null pointer", who);
+  if (n > (1ll << 30)) return set_err(OBB_EINVAL, "%s: too many rows", who);
+  if (reinterpret_cast<uintptr_t>(workspace_dev) & 255u) return set_err(OBB_EINVAL, "%s: workspace must be 256-byte aligned", who);
+  TiledLocalLayout L;
+  if (tiled_local_layout(n, world, 1, L) != OBB_OK) return set_err(OBB_EINVAL, "%s: bad size", who);
+  if (workspace_bytes <= L.nms) return set_err(OBB_EWORKSPACE, "%s: workspace of %zu bytes, %zu needed", who, workspace_bytes, obb_tiled_local_workspace_bytes(n, world, 0));
+  char *ws = static_cast<char *>(workspace_dev);
+  int64_t *keep = reinterpret_cast<int64_t *>(ws + L.keep);
+  void *record = counts_dev + world + 2;
+  NmsSource src = {};
+  src.dets = dets_dev; src.pitch = 6; src.mode = 1;
+  src.a64 = labels_dev; src.b64 = patch_index_dev; src.mult = num_classes;
+  NmsEnqueued q;
+  int rc = nms_enqueue_source(who, src, n, OBB_KIND_RBOX, iou_thr, 0, keep, record, ws + L.nms, workspace_bytes - L.nms, st, q);
+  if (rc != OBB_OK) return rc;
+  TiledSrc t = {dets_dev, labels_dev, patch_index_dev, n, keep, record, patch_xy_dev, patch_image_dev, num_patches, rate};
+  const TiledCaps caps = {q.cap, q.segcap, q.ucap};
+  if (world == 1) {
+    hipLaunchKernelGGL(tiled_rows_kernel, dim3((unsigned)((n + kMergeThreads - 1) / kMergeThreads)), dim3(kMergeThreads), 0, st, t, caps, rows_dev, counts_dev);
+    OBB_LAUNCH_CHECK();
+    return OBB_OK;
+  }
+  int *blockcnt = reinterpret_cast<int *>(ws + L.route);
+  int *blockviol = blockcnt + (size_t)L.nblocks * world;
+  hipLaunchKernelGGL(tiled_route_count_kernel, dim3((unsigned)L.nblocks), dim3(256), 0, st, t, world, L.nblocks, blockcnt, blockviol);
+  OBB_LAUNCH_CHECK();
+  hipLaunchKernelGGL(tiled_route_scan_kernel, dim3(1), dim3(kScanThreads), 0, st, blockcnt, world, L.nblocks, blockviol, record, caps, counts_dev);
+  OBB_LAUNCH_CHECK();
+  hipLaunchKernelGGL(tiled_route_scatter_kernel, dim3((unsigned)L.nblocks), dim3(256), 0, st, t, world, L.nblocks, blockcnt, rows_dev);
+  OBB_LAUNCH_CHECK();
+  return OBB_OK;
+}
+
+extern "C" size_t obb_tiled_merge_workspace_bytes(int64_t total_rows, int cols, int world, int64_t key_max, int64_t pair_capacity) {
+  obb::TiledMergeLayout L;
+  const int kind = obb::tiled_kind(cols);
+  if (kind < 0 || total_rows < 0) return 0;
+  if (obb::tiled_merge_layout(total_rows, kind, world, key_max, pair_capacity, L) != OBB_OK) return 0;
+  return L.total;
+}
+
+extern "C" int obb_tiled_merge_f32(const float *recv_dev, int64_t m, int cols, int ld, const int64_t *seg_start_host,
+                                   int world, int64_t key_max, int64_t total_rows, int64_t num_classes,
+                                   const float *class_thrs_dev, float iou_thr, int flags, float *ordered_dev,
+                                   float *kept_dev, int out_cols, int64_t *keep_dev, void *result_dev,
+                                   int32_t *status_dev, void *workspace_dev, size_t workspace_bytes, void *stream) {
+  using namespace obb;
+  const char *who = "obb_tiled_merge_f32";
+  const int kind = tiled_kind(cols);
+  if (kind < 0) return set_err(OBB_EINVAL, "%s: rows have 8 (theta-OBB), 11 (polygon) or 7 (horizontal) columns, got %d", who, cols);
+  if (m < 0 || total_rows < 0 || total_rows > m || ld < cols || out_cols < 1 || out_cols > ld || num_classes < 1)
+    return set_err(OBB_EINVAL, "%s: bad size", who);
+  if (!result_dev) return set_err(OBB_EINVAL, "%s: null result record", who);
+  hipStream_t st = (hipStream_t)stream;
+  if (total_rows == 0) {
+    OBB_HIP_TRY(hipMemsetAsync(result_dev, 0, OBB_NMS_RESULT_BYTES, st));
+    return OBB_OK;
+  }
+  if (!recv_dev || !kept_dev || !keep_dev || !workspace_dev) return set_err(OBB_EINVAL, "%s: null pointer", who);
+  if (reinterpret_cast<uintptr_t>(workspace_dev) & 255u) return set_err(OBB_EINVAL, "%s: workspace must be 256-byte aligned", who);
+  TiledMergeLayout L;
+  if (tiled_merge_layout(total_rows, kind, world, key_max, 1, L) != OBB_OK) return set_err(OBB_EINVAL, "%s: bad size (world, key_max)", who);
+  if (workspace_bytes <= L.nms) return set_err(OBB_EWORKSPACE, "%s: workspace of %zu bytes, %zu needed", who, workspace_bytes, obb_tiled_merge_workspace_bytes(total_rows, cols, world, key_max, 0));
+  char *ws = static_cast<char *>(workspace_dev);
+  const float *rows = recv_dev;
+  if (key_max >= 0) {      // the sources' runs -> one run in ascending key (ld - 1 = the key column)
+    if (!ordered_dev || ld < cols + 1) return set_err(OBB_EINVAL, "%s: order restoration needs a key column and an output", who);
+    int rc = obb_rows_restore_f32(recv_dev, m, ld, ld - 1, seg_start_host, world, key_max, ld, total_rows, ordered_dev, status_dev,
+                                  ws + L.restore, L.restore_bytes, stream);
+    if (rc != OBB_OK) return rc;
+    rows = ordered_dev;
+  } else if (total_rows != m) {
+    return set_err(OBB_EINVAL, "%s: without order restoration every row is real (total_rows == m)", who);
+  }
+  NmsSource src = {};
+  src.dets = rows; src.pitch = ld; src.mode = 2; src.mult = num_classes; src.thr_table = class_thrs_dev;
+  NmsEnqueued q;
+  int rc = nms_enqueue_source(who, src, total_rows, kind, iou_thr, flags, keep_dev, result_dev, ws + L.nms, workspace_bytes - L.nms, st, q);
+  if (rc != OBB_OK) return rc;
+  unsigned blocks;
+  rc = merge_grid(who, total_rows * out_cols, blocks);
+  if (rc != OBB_OK) return rc;
+  hipLaunchKernelGGL(tiled_gather_kernel, dim3(blocks), dim3(kMergeThreads), 0, st, rows, ld, total_rows, keep_dev, result_dev, out_cols, kept_dev);
+  OBB_LAUNCH_CHECK();
+  return OBB_OK;
+}
+
+extern "C" int obb_tiled_result(const void *record_host, int phase, int64_t n, int cols, int world, int64_t key_max,
+                                size_t workspace_bytes, int64_t *info_host) {
+  using namespace obb;
+  size_t nms_off = 0;
+  if (phase == 0) {
+    TiledLocalLayout L;
+    if (tiled_local_layout(n, world, 1, L) != OBB_OK) return set_err(OBB_EINVAL, "obb_tiled_result: bad size");
+    nms_off = L.nms;
+  } else {
+    TiledMergeLayout L;
+    const int kind = tiled_kind(cols);
+    if (kind < 0 || tiled_merge_layout(n, kind, world, key_max, 1, L) != OBB_OK) return set_err(OBB_EINVAL, "obb_tiled_result: bad size");
+    nms_off = L.nms;
+  }
+  if (workspace_bytes <= nms_off) return set_err(OBB_EINVAL, "obb_tiled_result: workspace smaller than the phase's fixed part");
+  return obb_nms_async_result(record_host, n, workspace_bytes - nms_off, info_host);
 }

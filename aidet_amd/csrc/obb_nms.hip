@@ -53,6 +53,7 @@
 
 #include "obb_common.h"
 #include "obb_geom.h"
+#include "obb_nms_internal.h"
 
 namespace obb {
 
@@ -68,7 +69,7 @@ constexpr int kSuper = 16;              // tiles per supertile: the cull kernel 
 constexpr int kSuperMinTiles = 1024;    // calls with fewer tiles (n <= 262144) do without supertiles
 constexpr int kCells = 262144;          // max Morton cells of the counting sort (9 + 9 bits)
 constexpr int kScanBlockCells = 1024;   // cells per block of the multi-block cell scan (kCells / 1024 blocks at most)
-constexpr int kShards = 64;            // candidate lists / counters (atomic rate)
+constexpr int kShards = kNmsShards;     // candidate lists / counters (atomic rate)
 constexpr int kPrepBlocks = 1024;     // upper bound on blocks of the prep kernel
 constexpr int kScanBlocks = 2048;     // grid of the scan kernel = one resident set at 8 waves/SIMD (waves loop over units)
 // blocks of the clip kernel per candidate shard (lanes loop over their shard's list).  32 was round 2's value: at
@@ -104,17 +105,8 @@ struct NmsCounters {
   unsigned long long cand_worst;           // fullest shard
 };
 
-// what the host needs after a call: written by the LAST kernel straight into pinned
-// host memory (a device-to-host copy of the counters is one more ~5 us launch)
-struct NmsHostInfo {
-  long long kept;
-  unsigned long long edges;
-  long long rounds;
-  unsigned long long cand_total, cand_worst;
-  unsigned int heavy_units, light_units;   // scan units over all shards of the unit list
-  unsigned int route;        // 0 fused, 1 direct, 2 sorted: which capacity check applies (obb_nms_async_result)
-  unsigned int unit_worst;   // fullest shard of the unit list (heavy + light)
-};
+// (NmsHostInfo -- what the host needs after a call, written by the LAST kernel straight into pinned host memory or
+// the caller's device record -- lives in obb_nms_internal.h)
 static_assert(sizeof(NmsHostInfo) <= OBB_NMS_RESULT_BYTES, "the async result record holds NmsHostInfo");
 
 // narrow-phase flags (kernel arguments; wave-uniform)
@@ -163,15 +155,35 @@ __device__ __forceinline__ void hbb_record(const float *__restrict__ row, QuadRe
   wellformed = ((x2 - x1) + 1.0f > 0.0f) && ((y2 - y1) + 1.0f > 0.0f);
 }
 
+// ---- box source (obb_nms_internal.h): group / threshold of box b, whose row starts at `row`; S = columns of box + score
+template <int S>
+__device__ __forceinline__ int32_t src_group(const NmsSource &s, int64_t b, const float *__restrict__ row) {
+  if (s.mode == 1) return (int32_t)(s.b64[b] * s.mult + s.a64[b]);                 // (wraps like Tensor.to(int32))
+  if (s.mode == 2) {
+    const int64_t label = (int64_t)row[S], image = (int64_t)row[S + 1];            // (truncation, like Tensor.long())
+    return (int32_t)(image * s.mult + label);
+  }
+  return s.group ? s.group[b] : 0;
+}
+template <int S>
+__device__ __forceinline__ float src_thr(const NmsSource &s, int64_t b, const float *__restrict__ row, float thr) {
+  if (s.mode == 2) {
+    if (!s.thr_table) return thr;
+    const int64_t label = (int64_t)row[S];
+    return (label >= 0 && label < s.mult) ? s.thr_table[label] : thr;
+  }
+  return s.thrs ? s.thrs[b] : thr;
+}
+__device__ __forceinline__ bool src_grouped(const NmsSource &s) { return s.mode != 0 || s.group != nullptr; }
+__device__ __forceinline__ bool src_thresholds(const NmsSource &s) { return s.mode == 2 ? s.thr_table != nullptr : s.thrs != nullptr; }
+
 // ---- 1: prep (DIRECT route: positions are box ids, no global frame, no spatial sort) ----------------------
 // per box: 64-byte quad record, conservative float interval, area; clears the call's counters
 template <int KIND>
-__global__ __launch_bounds__(256) void nms_prep_kernel(const float *__restrict__ dets, int64_t n,
+__global__ __launch_bounds__(256) void nms_prep_kernel(const NmsSource src, int64_t n,
                                                        QuadRec *__restrict__ rec,
                                                        float4 *__restrict__ iv,
                                                        float *__restrict__ ar,
-                                                       const int32_t *__restrict__ group,
-                                                       const float *__restrict__ thrs,
                                                        float thr, uint4 *__restrict__ zero,
                                                        size_t zero_vecs) {
   constexpr int S = KIND == 0 ? 6 : (KIND == 1 ? 9 : 5);
@@ -182,7 +194,7 @@ __global__ __launch_bounds__(256) void nms_prep_kernel(const float *__restrict__
     zero[z] = make_uint4(0u, 0u, 0u, 0u);
   for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n;
        b += (int64_t)gridDim.x * blockDim.x) {
-    const float *row = dets + b * S;
+    const float *row = src.dets + b * src.pitch;
     Quad q;
     load_quad<KIND>(row, q);
     QuadRec r;
@@ -190,8 +202,10 @@ __global__ __launch_bounds__(256) void nms_prep_kernel(const float *__restrict__
 #pragma unroll
     for (int k = 0; k < 4; ++k) { r.rx[k] = q.rx[k]; r.ry[k] = q.ry[k]; }
     r.area = q.area; r.skey = score_key(row[S - 1]);
-    r.group = group ? group[b] : 0;
-    r.thr = thrs ? thrs[b] : thr;
+    r.group = src_group<S>(src, b, row);
+    r.thr = src_thr<S>(src, b, row, thr);
+    if (src.gout) src.gout[b] = r.group;
+    if (src.tout) src.tout[b] = r.thr;
     bool wellformed = true;
     if (KIND == 2) hbb_record(row, r, wellformed);
     rec[b] = r;
@@ -360,8 +374,7 @@ __device__ __forceinline__ float4 sample_box(const float *__restrict__ row) {
 }
 
 template <int KIND>
-__global__ __launch_bounds__(256) void nms_frame_kernel(const float *__restrict__ dets, int64_t n,
-                                                        const int32_t *__restrict__ group, int cell_hbits,
+__global__ __launch_bounds__(256) void nms_frame_kernel(const NmsSource src, int64_t n, int cell_hbits,
                                                         NmsFrame *__restrict__ frame,
                                                         uint4 *__restrict__ zero, size_t zero_vecs) {
   constexpr int S = KIND == 0 ? 6 : (KIND == 1 ? 9 : 5);
@@ -381,7 +394,7 @@ __global__ __launch_bounds__(256) void nms_frame_kernel(const float *__restrict_
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
       const int i = tid + u * T;
-      b[u] = i < ns ? sample_box<KIND>(dets + ((int64_t)i * stride) * S) : make_float4(1.0f, -1.0f, 1.0f, -1.0f);
+      b[u] = i < ns ? sample_box<KIND>(src.dets + ((int64_t)i * stride) * src.pitch) : make_float4(1.0f, -1.0f, 1.0f, -1.0f);
     }
 #pragma unroll
     for (int u = 0; u < PER; ++u) sm[tid + u * T] = b[u];
@@ -501,10 +514,12 @@ __global__ __launch_bounds__(256) void nms_frame_kernel(const float *__restrict_
     if (lane == 0) wred[wv] = make_uint4(axh, axl, ayh, ayl);
   }
   // bucket bits of a grouped call: distinct 12-bit group hashes among <= 1024 strided samples
-  if (group) {
+  const bool grouped = src_grouped(src);
+  if (grouped) {
     const int64_t gs = n < 1024 ? n : 1024;
     for (int64_t k = tid; k < gs; k += T) {
-      const uint32_t h = group_hash(group[(k * n) / gs]) >> 20;
+      const int64_t bb = (k * n) / gs;
+      const uint32_t h = group_hash(src_group<S>(src, bb, src.dets + bb * src.pitch)) >> 20;
       atomicOr(&gbm[h >> 5], 1u << (h & 31u));
     }
   }
@@ -534,7 +549,7 @@ __global__ __launch_bounds__(256) void nms_frame_kernel(const float *__restrict_
     f.cpx = okx ? (rx / (float)kQMax) * 1.000001f : 0.0f;
     f.cpy = oky ? (ry / (float)kQMax) * 1.000001f : 0.0f;
     int gbits = 0;
-    if (group) {
+    if (grouped) {
       const int64_t gs = n < 1024 ? n : 1024;
       int d = 0;
       for (int k = 0; k < 128; ++k) d += __popc(gbm[k]);
@@ -550,13 +565,11 @@ __global__ __launch_bounds__(256) void nms_frame_kernel(const float *__restrict_
 }
 
 template <int KIND>
-__global__ __launch_bounds__(256) void nms_prepq_kernel(const float *__restrict__ dets, int64_t n,
+__global__ __launch_bounds__(256) void nms_prepq_kernel(const NmsSource src, int64_t n,
                                                         QuadRec *__restrict__ rec, uint2 *__restrict__ qb,
                                                         float *__restrict__ ar, uint32_t *__restrict__ ckey,
                                                         uint32_t *__restrict__ crank, uint32_t *__restrict__ hist,
-                                                        int cell_hbits, const NmsFrame *__restrict__ frame,
-                                                        const int32_t *__restrict__ group,
-                                                        const float *__restrict__ thrs, float thr) {
+                                                        int cell_hbits, const NmsFrame *__restrict__ frame, float thr) {
   constexpr int S = KIND == 0 ? 6 : (KIND == 1 ? 9 : 5);
   const NmsFrame fr = *frame;
   const int gbits = fr.gbits, cbits = 2 * cell_hbits - gbits;
@@ -566,7 +579,7 @@ __global__ __launch_bounds__(256) void nms_prepq_kernel(const float *__restrict_
     return (uint32_t)u;
   };
   for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n; b += (int64_t)gridDim.x * blockDim.x) {
-    const float *row = dets + b * S;
+    const float *row = src.dets + b * src.pitch;
     Quad q;
     load_quad<KIND>(row, q);
     QuadRec r;
@@ -574,9 +587,11 @@ __global__ __launch_bounds__(256) void nms_prepq_kernel(const float *__restrict_
 #pragma unroll
     for (int k = 0; k < 4; ++k) { r.rx[k] = q.rx[k]; r.ry[k] = q.ry[k]; }
     r.area = q.area; r.skey = score_key(row[S - 1]);
-    const int32_t g = group ? group[b] : 0;
+    const int32_t g = src_group<S>(src, b, row);
     r.group = g;
-    r.thr = thrs ? thrs[b] : thr;
+    r.thr = src_thr<S>(src, b, row, thr);
+    if (src.gout) src.gout[b] = g;
+    if (src.tout) src.tout[b] = r.thr;
     bool wellformed = true;
     if (KIND == 2) hbb_record(row, r, wellformed);
     rec[b] = r;
@@ -1849,10 +1864,8 @@ constexpr int kDirectDefault = 10240;    // largest n routed to the direct (unso
 constexpr int kDirectMax = 65536;
 
 template <int KIND>
-__global__ __launch_bounds__(1024) void nms_small_kernel(const float *__restrict__ dets, int n,
+__global__ __launch_bounds__(1024) void nms_small_kernel(const NmsSource src, int n,
                                                          float thr_global, int flags,
-                                                         const int32_t *__restrict__ group,
-                                                         const float *__restrict__ thrs,
                                                          QuadRec *__restrict__ rec,
                                                          uint2 *__restrict__ edges,
                                                          unsigned int ecap,
@@ -1877,7 +1890,7 @@ __global__ __launch_bounds__(1024) void nms_small_kernel(const float *__restrict
   bool fin = false;
   if (tid == 0) n_edges = 0;
   if (tid < n) {
-    const float *row = dets + (int64_t)tid * S;
+    const float *row = src.dets + (int64_t)tid * src.pitch;
     Quad q;
     load_quad<KIND>(row, q);
     QuadRec r;
@@ -1885,8 +1898,8 @@ __global__ __launch_bounds__(1024) void nms_small_kernel(const float *__restrict
 #pragma unroll
     for (int k = 0; k < 4; ++k) { r.rx[k] = q.rx[k]; r.ry[k] = q.ry[k]; }
     r.area = q.area; r.skey = score_key(row[S - 1]);
-    r.group = group ? group[tid] : 0;
-    r.thr = thrs ? thrs[tid] : thr_global;
+    r.group = src_group<S>(src, tid, row);
+    r.thr = src_thr<S>(src, tid, row, thr_global);
     bool wellformed = true;
     if (KIND == 2) hbb_record(row, r, wellformed);
     rec[tid] = r;
@@ -1936,7 +1949,7 @@ __global__ __launch_bounds__(1024) void nms_small_kernel(const float *__restrict
 
   // ---- b: pair scan (rows r, columns c > r), candidates -> clip -> edges
   Prune pr;
-  pr.thr = thrs ? 0.0f : thr_global; pr.cpx = frame[4]; pr.cpy = frame[5];
+  pr.thr = src_thresholds(src) ? 0.0f : thr_global; pr.cpx = frame[4]; pr.cpy = frame[5];
   uint2 *q = queue[wave];
   int qn = 0;
   const uint64_t lt_mask = (1ull << lane) - 1ull;
@@ -2102,7 +2115,7 @@ static thread_local NmsProfile g_prof;
 
 // ---- workspace layout ------------------------------------------------------------
 struct NmsLayout {
-  size_t rec, iv, ar, qb, ckey, crank, qs, pf, pg, pt, tgr, sgr, frame, tbox, sbox, zero_begin, cnt, ctr, ccnts, ucnts, super, hist, scanflags, ticket,
+  size_t rec, iv, ar, qb, ckey, crank, gsrc, tsrc, qs, pf, pg, pt, tgr, sgr, frame, tbox, sbox, zero_begin, cnt, ctr, ccnts, ucnts, super, hist, scanflags, ticket,
       zero_end, blockcnt, cands, edges, total;
   unsigned long long cap;         // candidate pairs == overlap edges capacity
   unsigned long long unit_worst;  // kShards x the most units one shard of the unit list can get
@@ -2126,6 +2139,8 @@ static int nms_layout(int64_t n, int64_t edge_capacity, NmsLayout &L) {
   L.qb = take(nn * sizeof(uint2));
   L.ckey = take(nn * 4);
   L.crank = take(nn * 4);
+  L.gsrc = take(nn * 4);       // per-box group / threshold derived by the prep kernel (NmsSource modes 1, 2)
+  L.tsrc = take(nn * 4);
   L.qs = take((nt * kTile + kRowChunk) * sizeof(uint2));
   L.pf = take((nt * kTile) * sizeof(uint4));
   L.pg = take((nt * kTile) * sizeof(int32_t));
@@ -2191,12 +2206,8 @@ extern "C" size_t obb_nms_workspace_bytes(int64_t n, int kind, int64_t edge_capa
 
 namespace obb {
 
-// Host-side state of one enqueued call: what the capacity check needs afterwards.
-struct NmsEnqueued {
-  unsigned long long cap = 0, segcap = 0;
-  unsigned int ucap = 0;
-  bool timed = false, direct = false, fused = false;
-};
+// (NmsEnqueued -- the host-side state of one enqueued call: what the capacity check needs afterwards -- lives in
+// obb_nms_internal.h)
 
 // capacities the kernels were (or would be) launched with for a workspace of this size
 static int nms_capacities(int64_t n, size_t workspace_bytes, NmsLayout &L, NmsEnqueued &q) {
@@ -2215,7 +2226,8 @@ static int nms_capacities(int64_t n, size_t workspace_bytes, NmsLayout &L, NmsEn
   return OBB_OK;
 }
 
-// The verdict on a finished call from the record its last kernel wrote.
+// The verdict on a finished call from the record its last kernel wrote (the capacity rules: nms_need_capacity,
+// obb_nms_internal.h -- shared with the device-side check of the tiled phases).
 static int nms_verdict(const NmsHostInfo &h, const NmsEnqueued &q, int64_t *info_host) {
   if (info_host) {
     info_host[0] = h.kept;
@@ -2223,48 +2235,24 @@ static int nms_verdict(const NmsHostInfo &h, const NmsEnqueued &q, int64_t *info
     info_host[2] = h.rounds;
     info_host[3] = (int64_t)h.cand_total;
   }
-  if (h.route == 0u) {   // fused: the edge list may use the whole pair capacity
-    const unsigned long long ecap64 = 2ull * q.cap;
-    const unsigned long long ecap = ecap64 > 0xFFFFFFFFull ? 0xFFFFFFFFull : ecap64;
-    if (h.edges > ecap) {
-      const unsigned long long need = h.edges / 2 + h.edges / 8 + 1024;   // edges fit in 2 * capacity
-      if (info_host) { info_host[0] = 0; info_host[3] = (int64_t)need; }
-      return set_err(OBB_EWORKSPACE, "obb_nms_f32: %llu overlap edges exceed the pair capacity %llu; retry with edge_capacity >= %llu",
-                     h.edges, q.cap, need);
-    }
-    return OBB_OK;
-  }
-  if (h.unit_worst > q.ucap / kShards) {
-    // the unit list is 1/8 of the pair capacity, cut into kShards segments: ask for a capacity
-    // whose segments hold the fullest one (which tile feeds which segment does not depend on
-    // scheduling, and L.unit_worst segments always fit, so a retry loop terminates)
-    unsigned long long need = (unsigned long long)h.unit_worst * kShards * 8;
-    need += need / 4 + 1024;
-    if (need < q.cap * 2) need = q.cap * 2;
-    if (info_host) { info_host[0] = 0; info_host[3] = (int64_t)need; }
+  int why = 0;
+  const unsigned long long need = nms_need_capacity(h, q.cap, q.segcap, q.ucap, &why);
+  if (need == 0) return OBB_OK;
+  if (info_host) { info_host[0] = 0; info_host[3] = (int64_t)need; }
+  if (why == 1)
+    return set_err(OBB_EWORKSPACE, "obb_nms_f32: %llu overlap edges exceed the pair capacity %llu; retry with edge_capacity >= %llu",
+                   h.edges, q.cap, need);
+  if (why == 2)
     return set_err(OBB_EWORKSPACE, "obb_nms_f32: %u scan units in one of %d segments exceed the segment capacity %u; retry with edge_capacity >= %llu",
                    h.unit_worst, kShards, q.ucap / kShards, need);
-  }
-  if (h.cand_worst > q.segcap) {
-    // capacity that fits the fullest candidate / edge segment on a retry.  Which of the 64
-    // shards a wave feeds depends on its wave id, i.e. on scheduling: the fullest shard of the
-    // retry may differ from this run's, hence the 25 % slack AND the doubling floor -- a caller
-    // that loops on OBB_EWORKSPACE (aidet_amd/nms_wrapper.py does) always terminates, because
-    // n (n - 1) / 2 pairs per shard is a hard upper bound.
-    unsigned long long need = h.cand_worst * kShards;
-    need += need / 4 + 1024;
-    if (need < q.cap * 2) need = q.cap * 2;
-    if (info_host) { info_host[0] = 0; info_host[3] = (int64_t)need; }
-    return set_err(OBB_EWORKSPACE, "obb_nms_f32: %llu candidate pairs / %llu overlap edges exceed the pair capacity %llu; retry with edge_capacity >= %llu",
-                   h.cand_total, h.edges, q.cap, need);
-  }
-  return OBB_OK;
+  return set_err(OBB_EWORKSPACE, "obb_nms_f32: %llu candidate pairs / %llu overlap edges exceed the pair capacity %llu; retry with edge_capacity >= %llu",
+                 h.cand_total, h.edges, q.cap, need);
 }
 
 // argument checks shared by the synchronous and the asynchronous entry points (no HIP call:
 // they also run on a machine without a GPU)
 static int nms_validate(const char *who, const float *dets_dev, int64_t n, int kind, float iou_thr,
-                        const float *thr_dev, int flags_in, const int64_t *keep_dev,
+                        bool thr_dev, int flags_in, const int64_t *keep_dev,
                         const void *workspace_dev) {
   if (n < 0) return set_err(OBB_EINVAL, "%s: negative n", who);
   if (kind != OBB_KIND_RBOX && kind != OBB_KIND_POLY && kind != OBB_KIND_HBB) return set_err(OBB_EINVAL, "%s: bad kind %d", who, kind);
@@ -2286,13 +2274,20 @@ static int nms_validate(const char *who, const float *dets_dev, int64_t n, int k
 // Validates, lays out the workspace and enqueues every kernel of one call on `stream`; the
 // last kernel writes the NmsHostInfo record to `result` (device-visible memory: the pinned
 // buffer of the synchronous entry points, or the caller's device record of the async one).
-static int nms_enqueue(const char *who, const float *dets_dev, int64_t n, int kind, float iou_thr,
-                       const int32_t *group_dev, const float *thr_dev, int flags_in,
-                       int64_t *keep_dev, NmsHostInfo *result, void *workspace_dev,
+int nms_enqueue_source(const char *who, NmsSource src, int64_t n, int kind, float iou_thr, int flags_in,
+                       int64_t *keep_dev, void *result_v, void *workspace_dev,
                        size_t workspace_bytes, hipStream_t st, NmsEnqueued &q) {
-  int rc = nms_validate(who, dets_dev, n, kind, iou_thr, thr_dev, flags_in, keep_dev, workspace_dev);
+  NmsHostInfo *result = static_cast<NmsHostInfo *>(result_v);
+  const bool has_thr = src.mode == 2 ? src.thr_table != nullptr : src.thrs != nullptr;
+  int rc = nms_validate(who, src.dets, n, kind, iou_thr, has_thr, flags_in, keep_dev, workspace_dev);
   if (rc != OBB_OK) return rc;
   if (!result) return set_err(OBB_EINVAL, "%s: null result record", who);
+  {
+    const int S = kind == OBB_KIND_RBOX ? 6 : (kind == OBB_KIND_POLY ? 9 : 5);
+    if (src.pitch < S + (src.mode == 2 ? 2 : 0)) return set_err(OBB_EINVAL, "%s: row pitch %lld below the %d columns read", who, (long long)src.pitch, S + (src.mode == 2 ? 2 : 0));
+    if (src.mode < 0 || src.mode > 2) return set_err(OBB_EINVAL, "%s: bad source mode", who);
+    if (n > 0 && src.mode == 1 && (!src.a64 || !src.b64)) return set_err(OBB_EINVAL, "%s: null label / patch array", who);
+  }
   const int flags = (flags_in & OBB_NMS_STRICT ? kFlagStrict : 0) | (kind == OBB_KIND_HBB ? kFlagHbb : 0);
 
   // pair capacity = whatever the caller's workspace holds beyond the fixed part,
@@ -2313,6 +2308,16 @@ static int nms_enqueue(const char *who, const float *dets_dev, int64_t n, int ki
   uint32_t *hist = reinterpret_cast<uint32_t *>(ws + L.hist);
   uint2 *qs = reinterpret_cast<uint2 *>(ws + L.qs);
   uint4 *pf = reinterpret_cast<uint4 *>(ws + L.pf);
+  // per-box group / threshold as the later stages read them: the caller's arrays, or what the prep kernel derives
+  const int32_t *group_dev = src.group;
+  const float *thr_dev = src.thrs;
+  src.gout = nullptr; src.tout = nullptr;
+  if (src.mode != 0) {
+    src.gout = reinterpret_cast<int32_t *>(ws + L.gsrc);
+    group_dev = src.gout;
+    thr_dev = nullptr;
+    if (src.mode == 2 && src.thr_table) { src.tout = reinterpret_cast<float *>(ws + L.tsrc); thr_dev = src.tout; }
+  }
   int32_t *pg = group_dev ? reinterpret_cast<int32_t *>(ws + L.pg) : nullptr;
   float *pt = thr_dev ? reinterpret_cast<float *>(ws + L.pt) : nullptr;
   uint32_t *tgr = reinterpret_cast<uint32_t *>(ws + L.tgr);
@@ -2359,11 +2364,11 @@ static int nms_enqueue(const char *who, const float *dets_dev, int64_t n, int ki
     const unsigned long long ecap64 = 2ull * cap;
     const unsigned int ecap = ecap64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned int)ecap64;
     if (kind == OBB_KIND_RBOX)
-      hipLaunchKernelGGL(nms_small_kernel<0>, dim3(1), dim3(1024), 0, st, dets_dev, (int)n, iou_thr, flags, group_dev, thr_dev, rec, cands, ecap, keep_dev, result);
+      hipLaunchKernelGGL(nms_small_kernel<0>, dim3(1), dim3(1024), 0, st, src, (int)n, iou_thr, flags, rec, cands, ecap, keep_dev, result);
     else if (kind == OBB_KIND_POLY)
-      hipLaunchKernelGGL(nms_small_kernel<1>, dim3(1), dim3(1024), 0, st, dets_dev, (int)n, iou_thr, flags, group_dev, thr_dev, rec, cands, ecap, keep_dev, result);
+      hipLaunchKernelGGL(nms_small_kernel<1>, dim3(1), dim3(1024), 0, st, src, (int)n, iou_thr, flags, rec, cands, ecap, keep_dev, result);
     else
-      hipLaunchKernelGGL(nms_small_kernel<2>, dim3(1), dim3(1024), 0, st, dets_dev, (int)n, iou_thr, flags, group_dev, thr_dev, rec, cands, ecap, keep_dev, result);
+      hipLaunchKernelGGL(nms_small_kernel<2>, dim3(1), dim3(1024), 0, st, src, (int)n, iou_thr, flags, rec, cands, ecap, keep_dev, result);
     OBB_LAUNCH_CHECK();
     return OBB_OK;
   }
@@ -2383,29 +2388,29 @@ static int nms_enqueue(const char *who, const float *dets_dev, int64_t n, int ki
   const size_t zero_vecs = zbytes / sizeof(uint4);
   if (direct) {
     if (kind == OBB_KIND_RBOX)
-      hipLaunchKernelGGL(nms_prep_kernel<0>, dim3(pblocks), dim3(256), 0, st, dets_dev, n, rec, iv, ar, group_dev, thr_dev, iou_thr, zero, zero_vecs);
+      hipLaunchKernelGGL(nms_prep_kernel<0>, dim3(pblocks), dim3(256), 0, st, src, n, rec, iv, ar, iou_thr, zero, zero_vecs);
     else if (kind == OBB_KIND_POLY)
-      hipLaunchKernelGGL(nms_prep_kernel<1>, dim3(pblocks), dim3(256), 0, st, dets_dev, n, rec, iv, ar, group_dev, thr_dev, iou_thr, zero, zero_vecs);
+      hipLaunchKernelGGL(nms_prep_kernel<1>, dim3(pblocks), dim3(256), 0, st, src, n, rec, iv, ar, iou_thr, zero, zero_vecs);
     else
-      hipLaunchKernelGGL(nms_prep_kernel<2>, dim3(pblocks), dim3(256), 0, st, dets_dev, n, rec, iv, ar, group_dev, thr_dev, iou_thr, zero, zero_vecs);
+      hipLaunchKernelGGL(nms_prep_kernel<2>, dim3(pblocks), dim3(256), 0, st, src, n, rec, iv, ar, iou_thr, zero, zero_vecs);
     OBB_LAUNCH_CHECK();
   } else {
     // frame (sampled, block 0) + clearing of the call's counters, histogram cells and tile-box words
     unsigned zb = (unsigned)((zero_vecs + 1023) / 1024) + 1u;     // (block 0 also takes the frame)
     zb = zb > 256u ? 256u : zb;
     if (kind == OBB_KIND_RBOX)
-      hipLaunchKernelGGL(nms_frame_kernel<0>, dim3(zb), dim3(256), 0, st, dets_dev, n, group_dev, hbits, frame, zero, zero_vecs);
+      hipLaunchKernelGGL(nms_frame_kernel<0>, dim3(zb), dim3(256), 0, st, src, n, hbits, frame, zero, zero_vecs);
     else if (kind == OBB_KIND_POLY)
-      hipLaunchKernelGGL(nms_frame_kernel<1>, dim3(zb), dim3(256), 0, st, dets_dev, n, group_dev, hbits, frame, zero, zero_vecs);
+      hipLaunchKernelGGL(nms_frame_kernel<1>, dim3(zb), dim3(256), 0, st, src, n, hbits, frame, zero, zero_vecs);
     else
-      hipLaunchKernelGGL(nms_frame_kernel<2>, dim3(zb), dim3(256), 0, st, dets_dev, n, group_dev, hbits, frame, zero, zero_vecs);
+      hipLaunchKernelGGL(nms_frame_kernel<2>, dim3(zb), dim3(256), 0, st, src, n, hbits, frame, zero, zero_vecs);
     OBB_LAUNCH_CHECK();
     if (kind == OBB_KIND_RBOX)
-      hipLaunchKernelGGL(nms_prepq_kernel<0>, dim3(pblocks), dim3(256), 0, st, dets_dev, n, rec, qb, ar, ckey, crank, hist, hbits, frame, group_dev, thr_dev, iou_thr);
+      hipLaunchKernelGGL(nms_prepq_kernel<0>, dim3(pblocks), dim3(256), 0, st, src, n, rec, qb, ar, ckey, crank, hist, hbits, frame, iou_thr);
     else if (kind == OBB_KIND_POLY)
-      hipLaunchKernelGGL(nms_prepq_kernel<1>, dim3(pblocks), dim3(256), 0, st, dets_dev, n, rec, qb, ar, ckey, crank, hist, hbits, frame, group_dev, thr_dev, iou_thr);
+      hipLaunchKernelGGL(nms_prepq_kernel<1>, dim3(pblocks), dim3(256), 0, st, src, n, rec, qb, ar, ckey, crank, hist, hbits, frame, iou_thr);
     else
-      hipLaunchKernelGGL(nms_prepq_kernel<2>, dim3(pblocks), dim3(256), 0, st, dets_dev, n, rec, qb, ar, ckey, crank, hist, hbits, frame, group_dev, thr_dev, iou_thr);
+      hipLaunchKernelGGL(nms_prepq_kernel<2>, dim3(pblocks), dim3(256), 0, st, src, n, rec, qb, ar, ckey, crank, hist, hbits, frame, iou_thr);
     OBB_LAUNCH_CHECK();
   }
   if (direct) {
@@ -2495,6 +2500,19 @@ static int nms_enqueue(const char *who, const float *dets_dev, int64_t n, int ki
   return OBB_OK;
 }
 
+// the plain entry points: rows of S floats, group / threshold arrays
+static int nms_enqueue(const char *who, const float *dets_dev, int64_t n, int kind, float iou_thr,
+                       const int32_t *group_dev, const float *thr_dev, int flags_in,
+                       int64_t *keep_dev, NmsHostInfo *result, void *workspace_dev,
+                       size_t workspace_bytes, hipStream_t st, NmsEnqueued &q) {
+  NmsSource src = {};
+  src.dets = dets_dev;
+  src.pitch = kind == OBB_KIND_RBOX ? 6 : (kind == OBB_KIND_POLY ? 9 : 5);
+  src.group = group_dev;
+  src.thrs = thr_dev;
+  return nms_enqueue_source(who, src, n, kind, iou_thr, flags_in, keep_dev, result, workspace_dev, workspace_bytes, st, q);
+}
+
 // one pinned, device-mapped result record per calling thread (synchronous entry points)
 static int nms_pinned_record(NmsHostInfo *&host, NmsHostInfo *&dev) {
   static thread_local NmsHostInfo *hinfo = nullptr;
@@ -2531,7 +2549,7 @@ extern "C" int obb_nms_ex_f32(const float *dets_dev, int64_t n, int kind, float 
                               size_t workspace_bytes, void *stream) {
   using namespace obb;
   if (info_host) { info_host[0] = 0; info_host[1] = 0; info_host[2] = 0; info_host[3] = 0; }
-  int rc = nms_validate("obb_nms_f32", dets_dev, n, kind, iou_thr, thr_dev, flags, keep_dev, workspace_dev);
+  int rc = nms_validate("obb_nms_f32", dets_dev, n, kind, iou_thr, thr_dev != nullptr, flags, keep_dev, workspace_dev);
   if (rc != OBB_OK) return rc;
   if (n == 0) return OBB_OK;
   NmsHostInfo *hinfo = nullptr, *hinfo_dev = nullptr;
@@ -2563,7 +2581,7 @@ extern "C" int obb_nms_async_f32(const float *dets_dev, int64_t n, int kind, flo
   using namespace obb;
   if (!result_dev) return set_err(OBB_EINVAL, "obb_nms_async_f32: null result record");
   hipStream_t st = (hipStream_t)stream;
-  int rc = nms_validate("obb_nms_async_f32", dets_dev, n, kind, iou_thr, thr_dev, flags, keep_dev, workspace_dev);
+  int rc = nms_validate("obb_nms_async_f32", dets_dev, n, kind, iou_thr, thr_dev != nullptr, flags, keep_dev, workspace_dev);
   if (rc != OBB_OK) return rc;
   if (n == 0) {   // an all-zero record: K = 0, route "fused" (its check passes for 0 edges)
     OBB_HIP_TRY(hipMemsetAsync(result_dev, 0, OBB_NMS_RESULT_BYTES, st));

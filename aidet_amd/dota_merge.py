@@ -539,6 +539,188 @@ def patch_rows_to_image(dets, labels, patch_index, patch_xy, patch_image, rate=1
     return (out, patch_index.to(torch.int64)) if with_patch else out
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# Fused phases (round 4): ``obb_tiled_local_f32`` / ``obb_tiled_merge_f32`` enqueue a whole rank-side phase each --
+# the group ids and per-class thresholds are derived inside the NMS's first kernel, the kernels behind an NMS read
+# its keep count from the result record on the device -- so a pass has ONE host read per exchange (the count
+# matrix the collectives need anyway) and one at its end (the merged keep count) instead of a wrapper round trip
+# per kernel.  The step-by-step functions above stay: they are the CPU path of the gloo tests, the specification the
+# GPU tests compare the fused path with, and the route of the ``sharded`` layout.
+# ---------------------------------------------------------------------------------------------------------------
+FUSED = True                 # module switch (tests force the step-by-step path with it)
+_phase_ws = {}               # (device index, stream) -> uint8 workspace shared by the phases (stream-ordered)
+_phase_capacity = {}         # (phase, bit length of n) -> pair capacity the last overflowing call needed
+
+
+def _phase_workspace(dev, nbytes):
+    key = (dev.index, _lib.current_stream_handle(dev))
+    ws = _phase_ws.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = _phase_ws[key] = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+    return ws
+
+
+def _capacity_error(what, n, nbytes, capacity):
+    return _lib.ObbOpsError('%s on %d rows needs a %.1f GiB pair workspace (capacity %d pairs): more than '
+                            'nms_wrapper.MAX_WORKSPACE_BYTES' % (what, n, nbytes / 2.0 ** 30, capacity))
+
+
+def tiled_local_phase(dets, labels, patch_index, patch_xy, patch_image, num_classes, iou_thr, world=1, rate=1.0,
+                      capacity=None):
+    """``obb_tiled_local_f32``: per-patch, per-class rotated NMS of this rank's detections -> the kept rows in image
+    coordinates with their patch index as a 9th column, in keep order (``world`` 1) or bucketed by destination rank
+    ``image % world``.  Nothing is synchronised.
+
+    Returns (rows (n, 9) buffer of which the first K rows are valid, counts int64[world + 2 + 8] on the device:
+    rows per destination | order violations | K, or -(pair capacity needed) after an overflow | the NMS record).
+    """
+    L = _lib.lib()
+    dev, n = dets.device, dets.size(0)
+    d, lab, pid = dets.contiguous(), _i64(labels), _i64(patch_index)
+    pxy = patch_xy.detach().to(torch.float32).contiguous()
+    pim = _i64(patch_image)
+    rows = d.new_empty((n, 9))
+    counts = torch.empty(world + 2 + _lib.NMS_RESULT_BYTES // 8, dtype=torch.int64, device=dev)
+    if capacity is None:
+        capacity = _phase_capacity.get((0, int(n).bit_length()), 0)
+    nbytes = int(L.obb_tiled_local_workspace_bytes(n, world, capacity))
+    if nbytes > nms_wrapper.MAX_WORKSPACE_BYTES:
+        raise _capacity_error('the per-patch NMS', n, nbytes, capacity)
+    ws = _phase_workspace(dev, nbytes)
+    _call(dev, L.obb_tiled_local_f32, d.data_ptr(), lab.data_ptr(), pid.data_ptr(), n, pxy.data_ptr(), pim.data_ptr(),
+          pim.numel(), int(num_classes), float(rate), float(iou_thr), int(world), rows.data_ptr(), counts.data_ptr(),
+          ws.data_ptr(), nbytes)
+    return rows, counts
+
+
+def _note_capacity(phase, n, need):
+    _phase_capacity[(phase, int(n).bit_length())] = int(need)
+
+
+def tiled_merge_phase(recv, seg_starts, key_max, total, num_classes, iou_thr, class_thrs=None, strict=False, cols=8,
+                      out_cols=None):
+    """``obb_tiled_merge_f32``: the rows of ``len(seg_starts)`` sources (``recv`` (m, ld), columns = ``cols`` merge
+    columns [+ ... + key]) -> order restored by the key column (``key_max`` None: used as they are) -> merged
+    per-(image, class) NMS -> kept rows.  ONE host read (the result record) at the end; an overflow of the pair lists
+    repeats the phase with the capacity the library names.
+
+    Returns (kept rows (K, out_cols), keep indices (K,) into the ordered rows, ordered rows (total, ld))."""
+    L = _lib.lib()
+    dev = recv.device
+    recv, ld = _row_pitch(recv)
+    m, world = recv.size(0), len(seg_starts)
+    out_cols = cols if out_cols is None else int(out_cols)
+    if total == 0:
+        return recv.new_empty((0, out_cols)), torch.zeros(0, dtype=torch.int64, device=dev), recv[:0]
+    kmax = -1 if key_max is None else int(key_max)
+    cthr = None
+    if class_thrs is not None:
+        cthr = _class_thr_tensor(class_thrs, dev)
+        assert cthr.numel() >= int(num_classes), 'one threshold per class'
+    ordered = recv.new_empty((total, ld)) if kmax >= 0 else None
+    kept = recv.new_empty((total, out_cols))
+    keep = torch.empty(total, dtype=torch.int64, device=dev)
+    record = torch.empty(_lib.NMS_RESULT_BYTES // 8, dtype=torch.int64, device=dev)
+    seg = (ctypes.c_int64 * world)(*[int(v) for v in seg_starts])
+    info = (ctypes.c_int64 * 4)()
+    capacity = _phase_capacity.get((1, int(total).bit_length()), 0)
+    while True:
+        nbytes = int(L.obb_tiled_merge_workspace_bytes(total, cols, world, kmax, capacity))
+        if nbytes == 0:
+            raise _lib.ObbOpsError('obb_tiled_merge_workspace_bytes failed: ' + L.obb_last_error().decode())
+        if nbytes > nms_wrapper.MAX_WORKSPACE_BYTES:
+            raise _capacity_error('the merged NMS', total, nbytes, capacity)
+        ws = _phase_workspace(dev, nbytes)
+        _call(dev, L.obb_tiled_merge_f32, recv.data_ptr(), m, cols, ld, seg, world, kmax, int(total), int(num_classes),
+              None if cthr is None else cthr.data_ptr(), float(iou_thr), _lib.NMS_STRICT if strict else 0,
+              None if ordered is None else ordered.data_ptr(), kept.data_ptr(), out_cols, keep.data_ptr(),
+              record.data_ptr(), _order_flag(dev).data_ptr() if kmax >= 0 else None, ws.data_ptr(), nbytes)
+        with _lib.on_device(dev):
+            rec = record.cpu().numpy()                                   # the phase's one host read
+        rc = L.obb_tiled_result(rec.ctypes.data, 1, int(total), cols, world, kmax, nbytes, info)
+        if rc != _lib.OBB_EWORKSPACE:
+            _lib.check(rc)
+            break
+        capacity = max(int(info[3]), 2 * capacity)
+        _note_capacity(1, total, capacity)
+    k = int(info[0])
+    return kept[:k], keep[:k], (ordered if ordered is not None else recv)
+
+
+def _fusable(dets, labels, patch_index, patch_xy, patch_image, layout, nms_fn, local_thr, merge_thr, class_thrs):
+    return (FUSED and nms_fn is None and layout in ('replicated', 'routed') and dets.dim() == 2 and dets.size(1) == 6
+            and dets.dtype == torch.float32 and _on_gpu(dets, labels, patch_index, patch_xy, patch_image)
+            and float(merge_thr) > 0.0 and int(patch_xy.size(0)) < (1 << 24)
+            and (class_thrs is None or isinstance(class_thrs, (list, tuple, torch.Tensor))))
+
+
+def _tiled_fused(dets, labels, patch_index, patch_xy, patch_image, num_classes, local_thr, merge_thr, class_thrs, group,
+                 layout, mark, gather_result):
+    """tiled_inference_merge on the fused phases (layouts ``replicated`` and ``routed``)."""
+    world, rank = _world(group)
+    dev, n, P = dets.device, dets.size(0), int(patch_xy.size(0))
+    route_world = world if layout == 'routed' else 1
+    if route_world > ROUTE_MAX_WORLD or (world > 1 and (P + 1) * world > RESTORE_MAX_SLOTS):
+        return None
+    capacity = None
+    while True:
+        rows, counts = tiled_local_phase(dets, labels, patch_index, patch_xy, patch_image, num_classes, local_thr,
+                                         route_world, capacity=capacity)
+        mark('local')
+        width = counts.numel()
+        if world > 1:
+            mat = torch.empty(world * width, dtype=torch.int64, device=dev)
+            coll.all_gather_into_tensor(mat, counts, group=group)
+            mat = mat.view(world, width).tolist()                       # the exchange's one host read
+        else:
+            with _lib.on_device(dev):
+                mat = [counts.tolist()]
+        kwords = [row[route_world + 1] for row in mat]
+        if all(k >= 0 for k in kwords):
+            break
+        # a rank's per-patch NMS overflowed its pair lists (every rank sees it): that rank repeats its phase with the
+        # capacity its kernels asked for, everybody repeats the exchange of the counts
+        if kwords[rank] < 0:
+            capacity = max(-kwords[rank], 2 * (capacity or 0))
+            _note_capacity(0, n, capacity)
+            nbytes = int(_lib.lib().obb_tiled_local_workspace_bytes(n, route_world, capacity))
+            if nbytes > nms_wrapper.MAX_WORKSPACE_BYTES:
+                raise _capacity_error('the per-patch NMS', n, nbytes, capacity)
+    K = kwords[rank]
+    if layout == 'routed' and world > 1:
+        if any(row[world] for row in mat):
+            raise ValueError('order_key: the keys of a rank must be non-decreasing in its row order')
+        in_splits, out_splits = mat[rank][:world], [mat[src][rank] for src in range(world)]
+        recv = rows.new_empty((sum(out_splits), 9))
+        coll.all_to_all_single(recv, rows[:K], out_splits, in_splits, group=group)
+        starts = [0]
+        for c in out_splits[:-1]:
+            starts.append(starts[-1] + c)
+        total, key_max = recv.size(0), P
+    elif world > 1:                                                       # replicated: everything to everybody
+        nmax = max(max(kwords), 1)
+        pad = rows.new_zeros((nmax, 9))
+        pad[:K] = rows[:K]
+        pad[K:, -1] = _PAD_KEY
+        recv = rows.new_empty((world * nmax, 9))
+        coll.all_gather_into_tensor(recv, pad, group=group)             # cf. test.py:133
+        starts, total, key_max = [r * nmax for r in range(world)], sum(kwords), P
+    else:
+        recv, starts, total, key_max = rows[:K], [0], K, None
+    mark('gather')
+    want_key = layout == 'routed' and world > 1 and gather_result
+    kept, keep, ordered = tiled_merge_phase(recv, starts, key_max, total, num_classes, merge_thr, class_thrs,
+                                            cols=8, out_cols=9 if want_key else 8)
+    if key_max is not None:
+        _check_order_flag(dev)
+    allrows = ordered[:, :8]
+    if want_key:
+        padded, cnts, _ = _gather_padded(kept, group, _PAD_KEY)
+        kept = _restore_by_key(padded, sum(cnts), 8, P, world)
+    mark('merge')
+    return kept, keep, allrows
+
+
 def tiled_inference_merge(dets, labels, patch_index, seq, patch_xy, patch_image, num_classes,
                           local_thr=0.5, merge_thr=0.3, class_thrs=None, group=None,
                           layout='replicated', nms_fn=None, mark=None, gather_result=True):
@@ -550,6 +732,11 @@ def tiled_inference_merge(dets, labels, patch_index, seq, patch_xy, patch_image,
     ``mark(name)`` (optional) is called between the phases ('local', 'gather', 'merge'), e.g.
     to record HIP events.  Returns ``distributed_merge``'s triple."""
     mark = mark or (lambda name: None)
+    if _fusable(dets, labels, patch_index, patch_xy, patch_image, layout, nms_fn, local_thr, merge_thr, class_thrs):
+        res = _tiled_fused(dets, labels, patch_index, patch_xy, patch_image, num_classes, local_thr, merge_thr, class_thrs,
+                           group, layout, mark, gather_result)
+        if res is not None:
+            return res
     keep = local_patch_nms(dets, labels, patch_index, local_thr, num_classes, nms_fn)
     use_patch_key = _world(group)[0] > 1 and patch_index is not None and int(patch_xy.size(0)) < (1 << 24)
     rows = patch_rows_to_image(dets, labels, patch_index, patch_xy, patch_image, keep=keep, with_patch=use_patch_key)

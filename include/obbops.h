@@ -411,6 +411,49 @@ OBB_API int obb_rows_restore_f32(const float *rows_dev, int64_t n, int cols, int
                                  int32_t *status_dev, void *workspace_dev, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------
+ * One rank-side PHASE of a tiled pass (config 5) per call, without the host in between (round 4).
+ * Replaces: what a rank does between the detector and the collectives of multi_gpu_test / collect_results_gpu
+ *           (mmdet/apis/test.py:31-146) and what rank 0 does after them in DOTADataset.merge_txt
+ *           (mmdet/datasets/dota.py:310-336: per image and class, thresholds :321-331) -- as TWO calls that each
+ *           enqueue all their kernels and return without synchronising.  The kept count of a phase's NMS is read by
+ *           the following kernels from the NMS result record on the device.
+ *
+ * obb_tiled_local_f32: the n detections of this rank's patches (dets (n, 6) theta-OBB + score in patch pixels,
+ *   labels / patch_index int64[n]) -> per-patch, per-class rotated NMS (group = patch * num_classes + label, derived
+ *   inside the NMS's first kernel) -> the K kept rows in image coordinates, rows_dev (n, 9) capacity:
+ *   [(cx + ox) / rate, (cy + oy) / rate, w / rate, h / rate, theta, score, label, image, patch] -- in keep order
+ *   (world == 1) or in stable buckets by destination rank `image mod world` (2 <= world <= 64), bucket 0 first.
+ *   counts_dev: int64[world + 2] + OBB_NMS_RESULT_BYTES: rows per destination | rows whose patch index is smaller
+ *   than their predecessor's (0 for a rank that visits its patches in order) | K | the NMS's result record.
+ * obb_tiled_merge_f32: rows received from `world` sources (recv_dev (m, ld), source r = rows [seg_start_host[r],
+ *   seg_start_host[r + 1]); columns [box + score | label | image | ... | key]) -> (key_max >= 0) the `total_rows`
+ *   real rows in ascending key = column ld - 1, a stable merge of the sources (obb_rows_restore_f32) into ordered_dev
+ *   (total_rows, ld) -> per-(image, class) NMS of those rows read in place (group = image * num_classes + label and
+ *   thr = class_thrs_dev[label] derived inside the NMS's first kernel; cols 8 / 11 / 7 = theta-OBB / polygon /
+ *   horizontal rows) -> keep_dev int64 (ascending, into the ordered rows) and kept_dev (K, out_cols) = their first
+ *   out_cols columns.  key_max < 0: the rows are used as they are (total_rows == m).  result_dev: the NMS's
+ *   result record (device), K in word 0.
+ * obb_tiled_result(record copied to the host, phase 0 local / 1 merge, the sizes the phase was called with):
+ *   info_host[4] like obb_nms_f32; OBB_EWORKSPACE when the phase's pair lists overflowed (repeat the phase with a
+ *   workspace for pair_capacity >= info_host[3]).
+ * ------------------------------------------------------------------------- */
+OBB_API size_t obb_tiled_local_workspace_bytes(int64_t n, int world, int64_t pair_capacity);
+OBB_API int obb_tiled_local_f32(const float *dets_dev, const int64_t *labels_dev, const int64_t *patch_index_dev,
+                                int64_t n, const float *patch_xy_dev, const int64_t *patch_image_dev,
+                                int64_t num_patches, int64_t num_classes, float rate, float iou_thr, int world,
+                                float *rows_dev, int64_t *counts_dev, void *workspace_dev, size_t workspace_bytes,
+                                void *stream);
+OBB_API size_t obb_tiled_merge_workspace_bytes(int64_t total_rows, int cols, int world, int64_t key_max,
+                                               int64_t pair_capacity);
+OBB_API int obb_tiled_merge_f32(const float *recv_dev, int64_t m, int cols, int ld, const int64_t *seg_start_host,
+                                int world, int64_t key_max, int64_t total_rows, int64_t num_classes,
+                                const float *class_thrs_dev, float iou_thr, int flags, float *ordered_dev,
+                                float *kept_dev, int out_cols, int64_t *keep_dev, void *result_dev,
+                                int32_t *status_dev, void *workspace_dev, size_t workspace_bytes, void *stream);
+OBB_API int obb_tiled_result(const void *record_host, int phase, int64_t n, int cols, int world, int64_t key_max,
+                             size_t workspace_bytes, int64_t *info_host);
+
+/* ---------------------------------------------------------------------------
  * Proposal / detection SELECTION stages of the detector (config 4), between a head's convolutions and its NMS.
  * Replaces: the per-level tensor-op chain of RPNHead.get_bboxes_single, mmdet/models/anchor_heads/rpn_head.py:55-104
  *           (sigmoid :71, per-level topk :77-81, delta2bbox :82-83 = mmdet/core/bbox/transforms.py:34-111, the
