@@ -49,8 +49,10 @@ HBM_PEAK_GBS = 8000.0                 # MI355X HBM3E spec (MI355X_MICROARCH.md)
 # VALU issue: 256 CUs x 4 SIMD-32; a wave64 VALU op occupies its SIMD for 2 cycles
 # (MI355X_MICROARCH.md, cycle constants: v_fma_f32 wave64 = 2 cyc throughput)
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0  # G wave-instructions / s at 2.4 GHz
-COUNTER_FILES = [os.path.join(ROOT, 'profiles', 'r03_counters.json'), os.path.join(ROOT, 'profiles', 'r02_counters.json')]
-IOU_M = 16384                         # rbbox_overlaps leg: 16k x 16k, canvas 8192 (SURVEY 8d scale-up of configs[0])
+COUNTER_FILES = [os.path.join(ROOT, 'profiles', 'r04_counters.json'), os.path.join(ROOT, 'profiles', 'r03_counters.json')]
+IOU_M = 16384                         # rbbox_overlaps leg: 16k x 16k (SURVEY 8d scale-up of configs[0])
+IOU_CANVAS = 1024                     # ... at configs[0]'s density (boxes on a 1024 canvas; 1.2 % of the pairs clipped)
+IOU_SPARSE_CANVAS = 8192              # the write-bound extreme beside it (0.02 % clipped): `iou_sparse_*`
 
 
 def parse_args():
@@ -66,12 +68,13 @@ def parse_args():
     ap.add_argument('--merge-layout', default='replicated', choices=['replicated', 'sharded', 'routed'],
                     help='layout of the cfg5 leg that config.cfg5_* reports (the others are timed beside it at N > 1)')
     ap.add_argument('--no-cfg5', action='store_true', help='skip the cfg5 leg')
+    ap.add_argument('--no-cfg5-large', action='store_true', help='skip the 1e7-detection size of the cfg5 leg (128 images)')
     ap.add_argument('--transport', default='rccl', choices=['rccl', 'gloo'],
                     help='rccl (default; backend "nccl" IS RCCL on ROCm, one rank per GPU) | gloo: DEBUG ONLY -- the ranks may '
                          'share GPUs (rank r uses cuda:(r mod #GPUs)) and every collective is staged through host memory '
                          '(aidet_amd/_collectives.py), so that the N > 1 code path can be smoke-run on a one-GPU box')
     ap.add_argument('--profile-target', default=None,
-                    choices=['nms', 'iou_sparse', 'iou_dense', 'rroi_fwd', 'rroi_bwd', 'rroi_bwd_scatter', 'roi_fwd', 'cfg5'],
+                    choices=['nms', 'iou_sparse', 'iou_dense', 'iou_allclip', 'rroi_fwd', 'rroi_bwd', 'rroi_bwd_scatter', 'roi_fwd', 'cfg5'],
                     help='run ONLY this op (for rocprofv3 passes: one workload per kernel name)')
     return ap.parse_args()
 
@@ -186,14 +189,17 @@ def bench_all(args):
     value = world * n * args.steps / elapsed
     scan_ms = float(phases[3])  # nms_scan_kernel, HIP events inside the timed region
 
-    # the IoU half of BASELINE's metric: this rank's row block of 16k x 16k (no communication)
-    a, b = make_iou(dev, IOU_M, 8192)
+    # the IoU half of BASELINE's metric: this rank's row block of 16k x 16k (no communication), at configs[0]'s
+    # density (canvas 1024); the sparse extreme (canvas 8192: nearly every pair is an exact zero) beside it
     shard = (rank, world)
-    rbbox_overlaps(a, b, row_shard=shard)
-    barrier()
-    iou_ms = max_over_ranks(_time_gpu(lambda: rbbox_overlaps(a, b, row_shard=shard), 10))
-    iou_pairs = IOU_M * IOU_M / (iou_ms * 1e-3)
-    del a, b
+    iou_ms, iou_pairs = {}, {}
+    for tag, canvas in (('cfg', IOU_CANVAS), ('sparse', IOU_SPARSE_CANVAS)):
+        a, b = make_iou(dev, IOU_M, canvas)
+        rbbox_overlaps(a, b, row_shard=shard)
+        barrier()
+        iou_ms[tag] = max_over_ranks(_time_gpu(lambda: rbbox_overlaps(a, b, row_shard=shard), 10))
+        iou_pairs[tag] = IOU_M * IOU_M / (iou_ms[tag] * 1e-3)
+        del a, b
 
     # ---- leg 2: cfg5 (strong scaling) -------------------------------------------------------------
     cfg5 = None
@@ -204,8 +210,11 @@ def bench_all(args):
     if rank == 0 and world == 1 and not args.no_extras:
         rk = roofline_kernels(dev)
     roof = nms_roofline(n, args.canvas, kept, scan_ms, ms_per_step, rk)
-    roof['iou_rowblock_pairs_per_s'] = round(iou_pairs, 1)
-    roof['iou_rowblock_hbm_frac'] = round((20 * (IOU_M // world + IOU_M) * world + 4 * IOU_M * IOU_M) / (iou_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    iou_bytes = 20 * (IOU_M // world + IOU_M) * world + 4 * IOU_M * IOU_M
+    roof['iou_rowblock_pairs_per_s'] = round(iou_pairs['cfg'], 1)
+    roof['iou_rowblock_hbm_frac'] = round(iou_bytes / (iou_ms['cfg'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    roof['iou_sparse_rowblock_pairs_per_s'] = round(iou_pairs['sparse'], 1)
+    roof['iou_sparse_rowblock_hbm_frac'] = round(iou_bytes / (iou_ms['sparse'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
     out = {
         'metric': 'rotated-NMS boxes/sec', 'value': round(value, 1), 'unit': 'boxes/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -216,8 +225,10 @@ def bench_all(args):
                    'boxes_per_gpu': n, 'kept': kept, 'overlap_edges': info[0],
                    'resolve_rounds': info[1], 'candidate_pairs': info[2],
                    'parallelism': 'single GPU' if world == 1 else 'replica x%d (no data-path collective)' % world,
-                   'iou_workload': 'rbbox_overlaps %d x %d, canvas 8192, rows in %d block(s)' % (IOU_M, IOU_M, world),
-                   'iou_pairs_per_s': round(iou_pairs, 1), 'iou_ms': round(iou_ms, 4)},
+                   'iou_workload': 'rbbox_overlaps %d x %d, canvas %d (configs[0] density), rows in %d block(s)' % (IOU_M, IOU_M, IOU_CANVAS, world),
+                   'iou_pairs_per_s': round(iou_pairs['cfg'], 1), 'iou_ms': round(iou_ms['cfg'], 4),
+                   'iou_sparse_pairs_per_s': round(iou_pairs['sparse'], 1), 'iou_sparse_ms': round(iou_ms['sparse'], 4),
+                   'iou_sparse_workload': 'the same on canvas %d (0.02 %% of the pairs clipped: write bound)' % IOU_SPARSE_CANVAS},
         'roofline': roof,
         'phase_ms': {k: round(float(v), 4) for k, v in zip(
             ['prep_quant', 'cell_sort', 'permute_cull', 'scan', 'clip', 'resolve', 'compact'], phase_tab)},
@@ -235,6 +246,8 @@ def bench_all(args):
         if rk is not None:
             out['roofline_kernels'] = rk
             out['also'] = extras(dev, args)
+            # the headline workload without the Python wrapper: one obb_nms_f32 call through the bare C ABI
+            out['config']['nms_c_abi_us_per_call'] = out['also']['rnms_100k_c_abi']['us_per_call']
         if not args.no_cpu:
             out['cpu_baseline'] = cpu_baseline(boxes, keep)
     if rank == 0:
@@ -311,6 +324,37 @@ def cfg5_leg(args, dev, rank, world, dist):
             flat['cfg5_%s_ms_per_step' % layout] = round(ms, 4)
             if single is not None:
                 flat['cfg5_%s_speedup_vs_single_rank' % layout] = round(single['ms_per_step'] / ms, 3)
+    # ---- the size where strong scaling has room: 128 images, 1.0e7 detections (routed at N > 1: every phase divides)
+    if not args.no_cfg5_large:
+        layout = args.merge_layout if world == 1 else 'routed'
+        big_ref, big_single = None, None
+        st = 3
+        if rank == 0 and world > 1:
+            big_single, _e, big_ref = tiled_on_this_rank(dev, 0, 1, steps=st, warmup=1, layout='replicated', group=dota_merge.LOCAL, images=128)
+        barrier = dist.barrier if dist is not None else None
+        group = None if dist is not None else dota_merge.LOCAL
+        summary, elapsed, kept_rows = tiled_on_this_rank(dev, rank, world, st, 1, layout, group=group, barrier=barrier, images=128)
+        good = 1
+        if dist is not None:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            coll.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+            if rank == 0:
+                good = int(bool(np.array_equal(big_ref.cpu().numpy(), kept_rows.cpu().numpy())))
+            g = torch.tensor([good], dtype=torch.int64, device=dev)
+            coll.all_reduce(g, op=dist.ReduceOp.MIN)
+            good = int(g.item())
+        ms = elapsed * 1e3 / st
+        flat.update({'cfg5_large_workload': 'tiled merge, %d images 8192^2, %d patches, %d detections (%s)'
+                                            % (summary['images'], summary['patches'], summary['detections'], layout),
+                     'cfg5_large_ms_per_step': round(ms, 4), 'cfg5_large_boxes_per_s': round(summary['detections'] * st / elapsed, 1),
+                     'cfg5_large_keep_ok': bool(good)})
+        if big_single is not None:
+            flat['cfg5_large_single_rank_ms_per_step'] = big_single['ms_per_step']
+            flat['cfg5_large_speedup_vs_single_rank'] = round(big_single['ms_per_step'] / ms, 3)
+        ok_all = ok_all and bool(good)
+        detail['large_' + layout] = dict(summary, ms_per_step=round(ms, 4))
+        _scenes.clear()
     return {'flat': flat, 'detail': detail, 'ok': ok_all}
 
 
@@ -400,6 +444,8 @@ def nms_roofline(n, canvas, kept, scan_ms, step_ms, rk=None):
                 r[t + '_traffic_over_algorithmic'] = round(row['traffic'] / float(row['algorithmic_bytes']), 3)
             if row.get('lds_conflict_share') is not None:
                 r[t + '_lds_conflict_share'] = row['lds_conflict_share']
+            if row.get('valu_issue_frac') is not None:
+                r[t + '_valu_issue_frac'] = row['valu_issue_frac']
     return r
 
 
@@ -430,6 +476,19 @@ def make_iou(dev, m, canvas):
     a = torch.from_numpy(workloads.boxes(m, canvas, 1)[:, :5]).to(dev)
     b = torch.from_numpy(workloads.boxes(m, canvas, 2)[:, :5]).to(dev)
     return a, b
+
+
+def make_iou_allclip(dev, m):
+    """m + m boxes that ALL overlap each other: centres within 16 px, sides 32-128 px"""
+    import numpy as np
+    import torch
+    out = []
+    for seed in (1, 2):
+        rng = np.random.default_rng(seed)
+        bx = np.stack([rng.uniform(0, 16, m), rng.uniform(0, 16, m), np.exp(rng.uniform(np.log(32.0), np.log(128.0), m)),
+                       np.exp(rng.uniform(np.log(32.0), np.log(128.0), m)), rng.uniform(-np.pi / 2, 0.0, m)], 1).astype(np.float32)
+        out.append(torch.from_numpy(bx).to(dev))
+    return out
 
 
 def make_rroi(dev, K=512, C=256, HW=256):
@@ -498,6 +557,21 @@ def roofline_kernels(dev):
                     'frac': round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                     'frac_of_measured_fill': round(alg / (ms * 1e-3) / 1e9 / peaks['fill_GBps'], 4),
                     'traffic': hbm_bytes(k)})
+    # every pair overlapping: 4096 x 4096 boxes of 32-128 px whose centres lie within 16 px -- all 1.7e7 pairs go through
+    # the clip (~1100 VALU each): the VALU-issue-bound extreme of the op
+    a, b = make_iou_allclip(dev, 4096)
+    ms = _time_gpu(lambda: rbbox_overlaps(a, b), 10)
+    nz = float((rbbox_overlaps(a, b) > 0).float().mean().item())
+    k = kernel_counters('overlaps_tile_kernel', 'iou_allclip')
+    alg = 20 * (2 * 4096) + 4 * 4096 * 4096
+    row = {'tag': 'iou_allclip', 'kernel': 'overlaps_tile_kernel', 'workload': 'rbbox_overlaps 4096 x 4096, all pairs overlapping (clip bound)',
+           'bound': 'valu_issue', 'algorithmic_bytes': alg, 'kernel_ms': round(ms, 4), 'pairs_per_s': round(4096 * 4096 / (ms * 1e-3), 1),
+           'achieved': round(alg / (ms * 1e-3) / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+           'frac': round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), 'traffic': hbm_bytes(k), 'nonzero_share': round(nz, 4)}
+    if k and 'SQ_INSTS_VALU' in k:
+        row['valu_issue_frac'] = round(k['SQ_INSTS_VALU'] / (ms * 1e-3) / 1e9 / VALU_PEAK_GINST, 4)
+    res.append(row)
+    del a, b
     feat, rois = make_rroi(dev)
     layer = RRoIAlign(7, 0.25, sample_num=2)
     rn = rois.cpu().numpy()
@@ -688,6 +762,31 @@ def extras(dev, args):
     return res
 
 
+def cpu_side_baselines():
+    """The oracle's other two ops on this host, 1 thread, bounded samples: rbbox_overlaps 1000 x 1000 on a 1024 canvas
+    (BASELINE configs[0] itself) and RRoIAlign on 128 of configs[2]'s 512 RoIs (256 channels, 7 x 7, 2 x 2 samples)."""
+    import numpy as np
+    import oracle
+    import workloads
+    a, b = workloads.boxes(1000, 1024, 1)[:, :5].copy(), workloads.boxes(1000, 1024, 2)[:, :5].copy()
+    oracle.overlaps(a[:64], b)
+    t0 = time.perf_counter()
+    reps = 0
+    while time.perf_counter() - t0 < 1.0:
+        oracle.overlaps(a, b)
+        reps += 1
+    iou_rate = reps * 1e6 / (time.perf_counter() - t0)
+    rng = np.random.default_rng(5)
+    feat = rng.standard_normal((1, 256, 256, 256)).astype(np.float32)
+    r = workloads.boxes(512, 1024, 5)[:128, :5]
+    rois = np.concatenate([np.zeros((128, 1), np.float32), r], 1)
+    t0 = time.perf_counter()
+    oracle.rroi_align_forward(feat, rois, 7, 0.25, 2)
+    roi_rate = 128 / (time.perf_counter() - t0)
+    return {'iou_pairs_per_s_1_thread': round(iou_rate, 1), 'iou_sample': 'rbbox_overlaps 1000 x 1000, canvas 1024 (configs[0]), %d repetitions' % reps,
+            'rroi_rois_per_s_1_thread': round(roi_rate, 1), 'rroi_sample': '128 of the 512 RoIs of configs[2], 256 channels, 7 x 7 bins, 2 x 2 samples'}
+
+
 def cpu_baseline(boxes, keep):
     """The C oracle (port of the reference's serial loop, nms_cpu.cpp:35-58) on this host on the
     SAME boxes: 1 thread -- what the reference's CPU path is -- and all cores (the suppression
@@ -713,7 +812,8 @@ def cpu_baseline(boxes, keep):
     except OSError:
         pass
     same = bool(np.array_equal(ref, keep.cpu().numpy())) and bool(np.array_equal(ref, ref_mt))
-    return {'value': round(len(boxes) / dt1, 1), 'unit': 'boxes/s', 'cores': 1, 'kind': 'port',
+    side = cpu_side_baselines()
+    return {**side, 'value': round(len(boxes) / dt1, 1), 'unit': 'boxes/s', 'cores': 1, 'kind': 'port',
             'sample': 'the full %d-box workload, one run, %.1f s' % (len(boxes), dt1),
             'all_cores_value': round(len(boxes) / dtn, 1), 'all_cores_threads': nthr,
             'all_cores_sample': 'full workload, best of 3 runs (%s s)' % ', '.join('%.1f' % r for r in runs),
@@ -723,15 +823,25 @@ def cpu_baseline(boxes, keep):
 # ==============================================================================================
 # N > 1 (and the one-GPU side metric): tiled inference, gather + merged rotated NMS
 # ==============================================================================================
-def tiled_on_this_rank(dev, rank, world, steps, warmup, layout, group=None, barrier=None):
+_scenes = {}
+
+
+def tiled_scene_cached(images):
+    import workloads
+    if images not in _scenes:
+        _scenes.clear()                 # (one scene at a time: the large one is 0.4 GB of host arrays)
+        _scenes[images] = workloads.tiled_scene(images=images)
+    return _scenes[images]
+
+
+def tiled_on_this_rank(dev, rank, world, steps, warmup, layout, group=None, barrier=None, images=16):
     """Runs BASELINE configs[4] with this rank's patches; returns (summary dict, elapsed s,
     kept sequence numbers of the last step)."""
     import numpy as np
     import torch
 
-    import workloads
     from aidet_amd import dota_io, dota_merge
-    scene = workloads.tiled_scene()
+    scene = tiled_scene_cached(images)
     C = scene['num_classes']
     P = len(scene['patch_name'])
     mine = np.isin(scene['patch'], np.asarray(dota_merge.shard_patches(P, rank, world)))
@@ -805,6 +915,9 @@ def profile_target(args):
         fn = lambda: _run_nms(d, _lib.KIND_RBOX, 0.5)
     elif t in ('iou_sparse', 'iou_dense'):
         a, b = make_iou(dev, 16384, 8192 if t == 'iou_sparse' else 1024)
+        fn = lambda: rbbox_overlaps(a, b)
+    elif t == 'iou_allclip':
+        a, b = make_iou_allclip(dev, 4096)
         fn = lambda: rbbox_overlaps(a, b)
     elif t in ('rroi_fwd', 'rroi_bwd', 'rroi_bwd_scatter'):
         feat, rois = make_rroi(dev)

@@ -1032,7 +1032,7 @@ def test_bench_distributed_path_runs_on_one_gpu():
                MASTER_ADDR='127.0.0.1', MASTER_PORT='29533')
     for layout in ('replicated', 'routed'):
         r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1',
-                            '--no-cpu', '--no-extras', '--merge-layout', layout],
+                            '--no-cpu', '--no-extras', '--no-cfg5-large', '--merge-layout', layout],
                            env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
