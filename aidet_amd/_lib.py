@@ -29,7 +29,7 @@ NMS_STRICT = 1          # OBB_NMS_STRICT: suppress on `>` (nms_kernel.cu:61) ins
 NMS_RESULT_BYTES = 64   # OBB_NMS_RESULT_BYTES
 # obb_set_tuning knobs (test / experiment hooks, include/obbops.h)
 (TUNE_NMS_FUSED_MAX, TUNE_NMS_DIRECT_MAX, TUNE_NMS_SCAN_BLOCKS, TUNE_RROI_GROUPS, TUNE_OVERLAPS_ROWS, TUNE_NMS_INLINE_MAX,
- TUNE_RROI_ORDER_MIN, TUNE_RROI_GATHER_CHAN, TUNE_RPN_BARRIER_TICKS) = range(9)
+ TUNE_RROI_ORDER_MIN, TUNE_RROI_GATHER_CHAN, TUNE_RPN_BARRIER_TICKS, TUNE_SOFT_NMS_REG) = range(10)
 
 _lib = None
 
@@ -54,6 +54,8 @@ def lib():
         L.obb_last_error.restype = ctypes.c_char_p
         L.obb_overlaps_f32.argtypes = [vp, i64, vp, i64, i32, i32, i32, vp, vp]
         L.obb_overlaps_f32.restype = i32
+        L.obb_hbb_overlaps_f64.argtypes = [vp, i64, vp, i64, i32, i32, vp, vp]
+        L.obb_hbb_overlaps_f64.restype = i32
         L.obb_nms_workspace_bytes.argtypes = [i64, i32, i64]
         L.obb_nms_workspace_bytes.restype = ctypes.c_size_t
         L.obb_nms_f32.argtypes = [vp, i64, i32, f32, vp, ctypes.POINTER(i64), vp,
@@ -65,6 +67,8 @@ def lib():
         L.obb_nms_ex_f32.argtypes = [vp, i64, i32, f32, vp, vp, i32, vp, ctypes.POINTER(i64), vp,
                                      ctypes.c_size_t, vp]
         L.obb_nms_ex_f32.restype = i32
+        L.obb_nms_hbb_f64.argtypes = [vp, i64, f32, vp, vp, i32, vp, ctypes.POINTER(i64), vp, ctypes.c_size_t, vp]
+        L.obb_nms_hbb_f64.restype = i32
         L.obb_nms_async_f32.argtypes = [vp, i64, i32, f32, vp, vp, i32, vp, vp, vp, ctypes.c_size_t, vp]
         L.obb_nms_async_f32.restype = i32
         L.obb_nms_async_result.argtypes = [vp, i64, ctypes.c_size_t, ctypes.POINTER(i64)]
@@ -74,6 +78,8 @@ def lib():
         L.obb_soft_nms_f32.argtypes = [vp, i64, f32, i32, f32, f32, vp, vp, ctypes.POINTER(i64), vp,
                                        ctypes.c_size_t, vp]
         L.obb_soft_nms_f32.restype = i32
+        L.obb_soft_nms_f64.argtypes = [vp, i64, f32, i32, f32, f32, vp, vp, ctypes.POINTER(i64), vp]
+        L.obb_soft_nms_f64.restype = i32
         L.obb_soft_nms_grouped_f32.argtypes = [vp, i64, vp, i64, f32, i32, f32, f32, vp, vp, vp, vp, ctypes.c_size_t, vp]
         L.obb_soft_nms_grouped_f32.restype = i32
         L.obb_soft_nms_grouped_max_f32.argtypes = [vp, i64, vp, i64, i64, f32, i32, f32, f32, vp, vp, vp, vp, ctypes.c_size_t, vp]

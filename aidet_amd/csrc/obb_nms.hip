@@ -112,6 +112,8 @@ static_assert(sizeof(NmsHostInfo) <= OBB_NMS_RESULT_BYTES, "the async result rec
 // narrow-phase flags (kernel arguments; wave-uniform)
 constexpr int kFlagStrict = 1;   // suppress on ov > thr (nms_kernel.cu:61) instead of ov >= thr (nms_cpu.cpp:56)
 constexpr int kFlagHbb = 2;      // records hold x1,y1,x2,y2 in rx[]: the reference's own pair arithmetic
+constexpr int kFlagF64 = 4;      // (with kFlagHbb) the records hold the four coordinates as DOUBLES in rx[] | ry[] and the
+                                 // score key has 64 bits (skey | klo[box]): nms_cpu_kernel<double>, nms_cpu.cpp:62-68
 
 // candidate counters: one per shard, each alone in a 256-byte slot (returning
 // atomics on words that share a cache line serialise at the memory side)
@@ -155,6 +157,54 @@ __device__ __forceinline__ void hbb_record(const float *__restrict__ row, QuadRe
   wellformed = ((x2 - x1) + 1.0f > 0.0f) && ((y2 - y1) + 1.0f > 0.0f);
 }
 
+// float64 horizontal boxes (the reference dispatches nms_cpu_kernel on the scalar type, nms_cpu.cpp:62-68, and
+// tests/test_nms.py:33-41 runs float64): the broad phase works on the coordinates ROUNDED to fp32 (the interval margin
+// of 2^-21 covers the rounding), the narrow phase evaluates nms_cpu.cpp:19,47-56 on the doubles themselves, and
+// "precedes" is decided on the 64-bit order-preserving key of the double score.
+__device__ __forceinline__ uint64_t score_key64(double s) {
+  const double t = s + 0.0;                                     // -0 -> +0
+  uint64_t u = (uint64_t)__double_as_longlong(t);
+  u = (u & 0x8000000000000000ull) ? ~u : (u | 0x8000000000000000ull);
+  return ~u;
+}
+__device__ __forceinline__ double dmax_sel(double a, double b) { return (a < b) ? b : a; }     // std::max(a, b)
+__device__ __forceinline__ double dmin_sel(double a, double b) { return (b < a) ? b : a; }     // std::min(a, b)
+__device__ __forceinline__ void quad_doubles(const Quad &q, double (&d)[4]) {
+  d[0] = __hiloint2double(__float_as_int(q.rx[1]), __float_as_int(q.rx[0]));
+  d[1] = __hiloint2double(__float_as_int(q.rx[3]), __float_as_int(q.rx[2]));
+  d[2] = __hiloint2double(__float_as_int(q.ry[1]), __float_as_int(q.ry[0]));
+  d[3] = __hiloint2double(__float_as_int(q.ry[3]), __float_as_int(q.ry[2]));
+}
+__device__ __forceinline__ void rec_put_doubles(QuadRec &r, const double (&d)[4]) {
+  r.rx[0] = __int_as_float(__double2loint(d[0])); r.rx[1] = __int_as_float(__double2hiint(d[0]));
+  r.rx[2] = __int_as_float(__double2loint(d[1])); r.rx[3] = __int_as_float(__double2hiint(d[1]));
+  r.ry[0] = __int_as_float(__double2loint(d[2])); r.ry[1] = __int_as_float(__double2hiint(d[2]));
+  r.ry[2] = __int_as_float(__double2loint(d[3])); r.ry[3] = __int_as_float(__double2hiint(d[3]));
+}
+// nms_cpu.cpp:19,47-56 in double: iarea / area of j, xx1 = max(ix1, x1[j]), ..., w = max(0, xx2 - xx1 + 1), ovr
+__device__ __forceinline__ double hbb_overlap_f64(const Quad &A, const Quad &B) {
+  double a[4], b[4];
+  quad_doubles(A, a); quad_doubles(B, b);
+  const double aarea = ((a[2] - a[0]) + 1.0) * ((a[3] - a[1]) + 1.0), barea = ((b[2] - b[0]) + 1.0) * ((b[3] - b[1]) + 1.0);
+  const double xx1 = dmax_sel(a[0], b[0]), yy1 = dmax_sel(a[1], b[1]);
+  const double xx2 = dmin_sel(a[2], b[2]), yy2 = dmin_sel(a[3], b[3]);
+  const double w = dmax_sel(0.0, (xx2 - xx1) + 1.0), h = dmax_sel(0.0, (yy2 - yy1) + 1.0);
+  const double inter = w * h;
+  return inter / ((aarea + barea) - inter);
+}
+// one row of doubles -> the fp32 row the broad phase is built from + the record's double payload
+template <class Src>
+__device__ __forceinline__ void f64_row(const Src &src, int64_t b, float (&rowf)[5], double (&d)[4], uint64_t &key, bool &wellformed) {
+  const double *r = src.dets64 + b * src.pitch;
+  d[0] = r[0]; d[1] = r[1]; d[2] = r[2]; d[3] = r[3];
+  const double sc = r[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) rowf[k] = (float)d[k];
+  rowf[4] = (float)sc;
+  key = score_key64(sc);
+  wellformed = ((d[2] - d[0]) + 1.0 > 0.0) && ((d[3] - d[1]) + 1.0 > 0.0);
+}
+
 // ---- box source (obb_nms_internal.h): group / threshold of box b, whose row starts at `row`; S = columns of box + score
 template <int S>
 __device__ __forceinline__ int32_t src_group(const NmsSource &s, int64_t b, const float *__restrict__ row) {
@@ -179,7 +229,7 @@ __device__ __forceinline__ bool src_thresholds(const NmsSource &s) { return s.mo
 
 // ---- 1: prep (DIRECT route: positions are box ids, no global frame, no spatial sort) ----------------------
 // per box: 64-byte quad record, conservative float interval, area; clears the call's counters
-template <int KIND>
+template <int KIND, bool F64 = false>
 __global__ __launch_bounds__(256) void nms_prep_kernel(const NmsSource src, int64_t n,
                                                        QuadRec *__restrict__ rec,
                                                        float4 *__restrict__ iv,
@@ -194,7 +244,13 @@ __global__ __launch_bounds__(256) void nms_prep_kernel(const NmsSource src, int6
     zero[z] = make_uint4(0u, 0u, 0u, 0u);
   for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n;
        b += (int64_t)gridDim.x * blockDim.x) {
-    const float *row = src.dets + b * src.pitch;
+    float rowf[5];
+    double d64[4];
+    uint64_t key64 = 0;
+    bool wf64 = true;
+    const float *row;
+    if constexpr (F64) { f64_row(src, b, rowf, d64, key64, wf64); row = rowf; }
+    else row = src.dets + b * src.pitch;
     Quad q;
     load_quad<KIND>(row, q);
     QuadRec r;
@@ -208,6 +264,7 @@ __global__ __launch_bounds__(256) void nms_prep_kernel(const NmsSource src, int6
     if (src.tout) src.tout[b] = r.thr;
     bool wellformed = true;
     if (KIND == 2) hbb_record(row, r, wellformed);
+    if constexpr (F64) { rec_put_doubles(r, d64); r.skey = (uint32_t)(key64 >> 32); src.klo[b] = (uint32_t)key64; wellformed = wf64; }
     rec[b] = r;
     ar[b] = q.area;
     float4 v;
@@ -373,7 +430,7 @@ __device__ __forceinline__ float4 sample_box(const float *__restrict__ row) {
   return fin ? make_float4(lox, hix, loy, hiy) : make_float4(1.0f, -1.0f, 1.0f, -1.0f);
 }
 
-template <int KIND>
+template <int KIND, bool F64 = false>
 __global__ __launch_bounds__(256) void nms_frame_kernel(const NmsSource src, int64_t n, int cell_hbits,
                                                         NmsFrame *__restrict__ frame,
                                                         uint4 *__restrict__ zero, size_t zero_vecs) {
@@ -394,7 +451,13 @@ __global__ __launch_bounds__(256) void nms_frame_kernel(const NmsSource src, int
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
       const int i = tid + u * T;
-      b[u] = i < ns ? sample_box<KIND>(src.dets + ((int64_t)i * stride) * src.pitch) : make_float4(1.0f, -1.0f, 1.0f, -1.0f);
+      if constexpr (F64) {
+        float rowf[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        if (i < ns) { const double *r64 = src.dets64 + ((int64_t)i * stride) * src.pitch; for (int k = 0; k < 4; ++k) rowf[k] = (float)r64[k]; }
+        b[u] = i < ns ? sample_box<KIND>(rowf) : make_float4(1.0f, -1.0f, 1.0f, -1.0f);
+      } else {
+        b[u] = i < ns ? sample_box<KIND>(src.dets + ((int64_t)i * stride) * src.pitch) : make_float4(1.0f, -1.0f, 1.0f, -1.0f);
+      }
     }
 #pragma unroll
     for (int u = 0; u < PER; ++u) sm[tid + u * T] = b[u];
@@ -564,7 +627,7 @@ __global__ __launch_bounds__(256) void nms_frame_kernel(const NmsSource src, int
   }
 }
 
-template <int KIND>
+template <int KIND, bool F64 = false>
 __global__ __launch_bounds__(256) void nms_prepq_kernel(const NmsSource src, int64_t n,
                                                         QuadRec *__restrict__ rec, uint2 *__restrict__ qb,
                                                         float *__restrict__ ar, uint32_t *__restrict__ ckey,
@@ -579,7 +642,13 @@ __global__ __launch_bounds__(256) void nms_prepq_kernel(const NmsSource src, int
     return (uint32_t)u;
   };
   for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n; b += (int64_t)gridDim.x * blockDim.x) {
-    const float *row = src.dets + b * src.pitch;
+    float rowf[5];
+    double d64[4];
+    uint64_t key64 = 0;
+    bool wf64 = true;
+    const float *row;
+    if constexpr (F64) { f64_row(src, b, rowf, d64, key64, wf64); row = rowf; }
+    else row = src.dets + b * src.pitch;
     Quad q;
     load_quad<KIND>(row, q);
     QuadRec r;
@@ -594,6 +663,7 @@ __global__ __launch_bounds__(256) void nms_prepq_kernel(const NmsSource src, int
     if (src.tout) src.tout[b] = r.thr;
     bool wellformed = true;
     if (KIND == 2) hbb_record(row, r, wellformed);
+    if constexpr (F64) { rec_put_doubles(r, d64); r.skey = (uint32_t)(key64 >> 32); src.klo[b] = (uint32_t)key64; wellformed = wf64; }
     rec[b] = r;
     ar[b] = q.area;
     float4 v;
@@ -1053,6 +1123,10 @@ __device__ __forceinline__ void swap_if(bool c, float &a, float &b) {
 __device__ __forceinline__ bool narrow_hit(const Quad &A, const Quad &B, float thr, int flags) {
   float ov;
   bool rej = false;
+  if (flags & kFlagF64) {       // (wave-uniform) nms_cpu_kernel<double>: `ovr >= threshold` with the float threshold promoted
+    const double ovd = hbb_overlap_f64(A, B), td = (double)thr;
+    return (flags & kFlagStrict) ? (ovd > td) : (ovd >= td);
+  }
   if (flags & kFlagHbb) ov = hbb_overlap(A.rx, A.area, B.rx, B.area);
   else ov = quad_overlap(A, B, 0, rej);
   const bool over = (flags & kFlagStrict) ? (ov > thr) : (ov >= thr);
@@ -1060,8 +1134,13 @@ __device__ __forceinline__ bool narrow_hit(const Quad &A, const Quad &B, float t
 }
 
 __device__ __forceinline__ bool clip_loaded(Quad &A, Quad &B, uint32_t ka, uint32_t kb, int ga, int gb,
-                                            float ta, float tb, uint2 pr, int flags, uint32_t &src, uint32_t &dst) {
-  const bool b_first = (kb < ka) || (kb == ka && pr.y < pr.x);
+                                            float ta, float tb, uint2 pr, int flags, uint32_t &src, uint32_t &dst,
+                                            const uint32_t *__restrict__ klo = nullptr) {
+  bool b_first = (kb < ka) || (kb == ka && pr.y < pr.x);
+  if ((flags & kFlagF64) && kb == ka) {      // equal high words: the low words of the 64-bit score keys decide
+    const uint32_t la = klo[pr.x], lb = klo[pr.y];
+    b_first = (lb < la) || (lb == la && pr.y < pr.x);
+  }
   const float thr = b_first ? tb : ta;  // the earlier box's threshold
   src = b_first ? pr.y : pr.x;
   dst = b_first ? pr.x : pr.y;
@@ -1074,14 +1153,14 @@ __device__ __forceinline__ bool clip_loaded(Quad &A, Quad &B, uint32_t ka, uint3
 }
 
 __device__ __forceinline__ bool clip_pair(const QuadRec *__restrict__ rec, uint2 pr, int flags, uint32_t &src,
-                                          uint32_t &dst) {
+                                          uint32_t &dst, const uint32_t *__restrict__ klo = nullptr) {
   Quad A, B;
   uint32_t ka, kb;
   int ga, gb;
   float ta, tb;
   load_rec(rec, pr.x, A, ka, ga, ta);
   load_rec(rec, pr.y, B, kb, gb, tb);
-  return clip_loaded(A, B, ka, kb, ga, gb, ta, tb, pr, flags, src, dst);
+  return clip_loaded(A, B, ka, kb, ga, gb, ta, tb, pr, flags, src, dst, klo);
 }
 
 // hits of one wave -> its shard's edge segment (+ the in-degree of the targets)
@@ -1126,6 +1205,7 @@ struct SortedSink {
   unsigned long long *__restrict__ ccnt;
   // INLINE only
   const QuadRec *__restrict__ rec;
+  const uint32_t *__restrict__ klo;         // low words of 64-bit score keys (kFlagF64, else null)
   int flags;
   uint2 *__restrict__ eseg;                 // this wave's edge segment
   unsigned long long *__restrict__ ecnt;
@@ -1136,7 +1216,7 @@ struct SortedSink {
   __device__ __forceinline__ void clip_batch(const uint2 *b, int count, int lane) const {
     bool hit = false;
     uint32_t src = 0, dst = 0;
-    if (lane < count) hit = clip_pair(rec, b[lane], flags, src, dst);
+    if (lane < count) hit = clip_pair(rec, b[lane], flags, src, dst, klo);
     push_edges(hit, src, dst, eseg, segcap, ecnt, cnt, lane);
   }
   __device__ __forceinline__ void finish(int lane) {   // end of the wave: the partial batch
@@ -1272,7 +1352,7 @@ __global__ __launch_bounds__(64 * kNmsWaves) void nms_scan_kernel(const uint2 *_
                                                        unsigned long long *__restrict__ ccnts,
                                                        const QuadRec *__restrict__ rec, int flags,
                                                        uint2 *__restrict__ edges,
-                                                       int *__restrict__ cnt) {
+                                                       int *__restrict__ cnt, const uint32_t *__restrict__ klo) {
   __shared__ uint2 queue[kNmsWaves][kNmsQueue];
   __shared__ uint2 clipq[INLINE ? kNmsWaves : 1][INLINE ? kClipQueue : 1];
   const int lane = threadIdx.x & 63;
@@ -1289,7 +1369,7 @@ __global__ __launch_bounds__(64 * kNmsWaves) void nms_scan_kernel(const uint2 *_
   sink.segcap = segcap;
   // (INLINE: the candidates are only counted, in the statistics slot -- their list does not exist)
   sink.ccnt = ccnts + (size_t)((INLINE ? 2 * kShards : 0) + shard) * kCandStride;
-  sink.rec = rec; sink.flags = flags;
+  sink.rec = rec; sink.flags = flags; sink.klo = klo;
   sink.eseg = edges + (size_t)shard * segcap;
   sink.ecnt = ccnts + (size_t)(kShards + shard) * kCandStride;
   sink.cnt = cnt;
@@ -1379,6 +1459,7 @@ struct DirectSink {
   const float4 *__restrict__ iv;
   const float *__restrict__ ar;
   const QuadRec *__restrict__ rec;
+  const uint32_t *__restrict__ klo;         // low words of 64-bit score keys (kFlagF64, else null)
   uint2 *__restrict__ eseg;                 // this wave's edge segment
   unsigned long long segcap;
   unsigned long long *__restrict__ ccnt;    // candidate statistics (not an index)
@@ -1416,7 +1497,7 @@ struct DirectSink {
     if (lane == 0) atomicAdd(ccnt, (unsigned long long)__popcll(mk));
     bool hit = false;
     uint32_t src = 0, dst = 0;
-    if (keep) hit = clip_loaded(A, B, ka, kb, ga, gb, ta, tb, e, flags, src, dst);
+    if (keep) hit = clip_loaded(A, B, ka, kb, ga, gb, ta, tb, e, flags, src, dst, klo);
     push_edges(hit, src, dst, eseg, segcap, ecnt, cnt, lane);
   }
 };
@@ -1453,7 +1534,7 @@ __global__ __launch_bounds__(64 * kNmsWaves) void nms_scan_direct_kernel(const f
                                                                 uint2 *__restrict__ edges,
                                                                 unsigned long long segcap,
                                                                 unsigned long long *__restrict__ ccnts,
-                                                                int *__restrict__ cnt) {
+                                                                int *__restrict__ cnt, const uint32_t *__restrict__ klo) {
   __shared__ uint2 queue[kNmsWaves][kNmsQueue];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1470,7 +1551,7 @@ __global__ __launch_bounds__(64 * kNmsWaves) void nms_scan_direct_kernel(const f
   sink.pr.thr = thr; sink.pr.cpx = 0.0f; sink.pr.cpy = 0.0f;
   sink.per_box_thr = per_box_thr != 0;
   sink.flags = flags;
-  sink.iv = iv; sink.ar = ar; sink.rec = rec;
+  sink.iv = iv; sink.ar = ar; sink.rec = rec; sink.klo = klo;
   sink.eseg = edges + (size_t)shard * segcap;
   sink.segcap = segcap;
   sink.ccnt = ccnts + (size_t)shard * kCandStride;
@@ -1519,7 +1600,7 @@ __global__ __launch_bounds__(256) void nms_clip_kernel(const uint2 *__restrict__
                                                        uint2 *__restrict__ edges,
                                                        NmsCounters *__restrict__ ctr,
                                                        unsigned long long *__restrict__ ccnts,
-                                                       int *__restrict__ cnt) {
+                                                       int *__restrict__ cnt, const uint32_t *__restrict__ klo) {
   const int lane = threadIdx.x & 63;
   const int shard = blockIdx.y;
   const uint2 *cand = cands + (size_t)shard * segcap;
@@ -1540,7 +1621,7 @@ __global__ __launch_bounds__(256) void nms_clip_kernel(const uint2 *__restrict__
     uint32_t src = 0, dst = 0;
     if (e < total) {
       if (base != first) pr = cand[e];
-      hit = clip_pair(rec, pr, flags, src, dst);
+      hit = clip_pair(rec, pr, flags, src, dst, klo);
     }
     push_edges(hit, src, dst, eseg, segcap, ecnt, cnt, lane);
   }
@@ -1863,7 +1944,7 @@ constexpr int64_t kInlineDefault = 65536;
 constexpr int kDirectDefault = 10240;    // largest n routed to the direct (unsorted) scan (measured crossover 11-12k)
 constexpr int kDirectMax = 65536;
 
-template <int KIND>
+template <int KIND, bool F64 = false>
 __global__ __launch_bounds__(1024) void nms_small_kernel(const NmsSource src, int n,
                                                          float thr_global, int flags,
                                                          QuadRec *__restrict__ rec,
@@ -1890,7 +1971,13 @@ __global__ __launch_bounds__(1024) void nms_small_kernel(const NmsSource src, in
   bool fin = false;
   if (tid == 0) n_edges = 0;
   if (tid < n) {
-    const float *row = src.dets + (int64_t)tid * src.pitch;
+    float rowf[5];
+    double d64[4];
+    uint64_t key64 = 0;
+    bool wf64 = true;
+    const float *row;
+    if constexpr (F64) { f64_row(src, tid, rowf, d64, key64, wf64); row = rowf; }
+    else row = src.dets + (int64_t)tid * src.pitch;
     Quad q;
     load_quad<KIND>(row, q);
     QuadRec r;
@@ -1902,6 +1989,7 @@ __global__ __launch_bounds__(1024) void nms_small_kernel(const NmsSource src, in
     r.thr = src_thr<S>(src, tid, row, thr_global);
     bool wellformed = true;
     if (KIND == 2) hbb_record(row, r, wellformed);
+    if constexpr (F64) { rec_put_doubles(r, d64); r.skey = (uint32_t)(key64 >> 32); src.klo[tid] = (uint32_t)key64; wellformed = wf64; }
     rec[tid] = r;
     skey[tid] = r.skey;
     area[tid] = q.area;
@@ -1953,6 +2041,7 @@ __global__ __launch_bounds__(1024) void nms_small_kernel(const NmsSource src, in
   uint2 *q = queue[wave];
   int qn = 0;
   const uint64_t lt_mask = (1ull << lane) - 1ull;
+  const uint32_t *klo_p = src.klo;
   auto drain = [&](bool flush) {
     while (qn >= 64 || (flush && qn > 0)) {
       const int take = qn < 64 ? qn : 64;
@@ -1968,7 +2057,13 @@ __global__ __launch_bounds__(1024) void nms_small_kernel(const NmsSource src, in
         float ta, tb;
         load_rec(rec, prr.x, A, ka, ga, ta);
         load_rec(rec, prr.y, B, kb, gb, tb);
-        const bool b_first = (kb < ka) || (kb == ka && prr.y < prr.x);
+        bool b_first = (kb < ka) || (kb == ka && prr.y < prr.x);
+        if constexpr (F64) {
+          if (kb == ka) {      // (the low words were written by this block before the first barrier)
+            const uint32_t la = klo_p[prr.x], lb = klo_p[prr.y];
+            b_first = (lb < la) || (lb == la && prr.y < prr.x);
+          }
+        }
         src = b_first ? prr.y : prr.x;
         dst = b_first ? prr.x : prr.y;
         swap_if(b_first, A.ox, B.ox); swap_if(b_first, A.oy, B.oy);
@@ -2279,16 +2374,18 @@ int nms_enqueue_source(const char *who, NmsSource src, int64_t n, int kind, floa
                        size_t workspace_bytes, hipStream_t st, NmsEnqueued &q) {
   NmsHostInfo *result = static_cast<NmsHostInfo *>(result_v);
   const bool has_thr = src.mode == 2 ? src.thr_table != nullptr : src.thrs != nullptr;
-  int rc = nms_validate(who, src.dets, n, kind, iou_thr, has_thr, flags_in, keep_dev, workspace_dev);
+  int rc = nms_validate(who, src.dets64 ? reinterpret_cast<const float *>(src.dets64) : src.dets, n, kind, iou_thr, has_thr, flags_in, keep_dev, workspace_dev);
   if (rc != OBB_OK) return rc;
   if (!result) return set_err(OBB_EINVAL, "%s: null result record", who);
   {
     const int S = kind == OBB_KIND_RBOX ? 6 : (kind == OBB_KIND_POLY ? 9 : 5);
-    if (src.pitch < S + (src.mode == 2 ? 2 : 0)) return set_err(OBB_EINVAL, "%s: row pitch %lld below the %d columns read", who, (long long)src.pitch, S + (src.mode == 2 ? 2 : 0));
+    if (src.pitch < (src.dets64 ? 5 : S + (src.mode == 2 ? 2 : 0))) return set_err(OBB_EINVAL, "%s: row pitch %lld below the %d columns read", who, (long long)src.pitch, S + (src.mode == 2 ? 2 : 0));
     if (src.mode < 0 || src.mode > 2) return set_err(OBB_EINVAL, "%s: bad source mode", who);
     if (n > 0 && src.mode == 1 && (!src.a64 || !src.b64)) return set_err(OBB_EINVAL, "%s: null label / patch array", who);
   }
-  const int flags = (flags_in & OBB_NMS_STRICT ? kFlagStrict : 0) | (kind == OBB_KIND_HBB ? kFlagHbb : 0);
+  const bool f64 = src.dets64 != nullptr;
+  if (f64 && (kind != OBB_KIND_HBB || src.mode != 0)) return set_err(OBB_EINVAL, "%s: float64 rows are horizontal boxes with plain group / threshold arrays", who);
+  const int flags = (flags_in & OBB_NMS_STRICT ? kFlagStrict : 0) | (kind == OBB_KIND_HBB ? kFlagHbb : 0) | (f64 ? kFlagF64 : 0);
 
   // pair capacity = whatever the caller's workspace holds beyond the fixed part,
   // split evenly between the candidate lists and the edge list
@@ -2318,6 +2415,8 @@ int nms_enqueue_source(const char *who, NmsSource src, int64_t n, int kind, floa
     thr_dev = nullptr;
     if (src.mode == 2 && src.thr_table) { src.tout = reinterpret_cast<float *>(ws + L.tsrc); thr_dev = src.tout; }
   }
+  src.klo = f64 ? reinterpret_cast<uint32_t *>(ws + L.tsrc) : nullptr;     // (mode 0 derives no thresholds: the slot is free)
+  const uint32_t *klo = src.klo;
   int32_t *pg = group_dev ? reinterpret_cast<int32_t *>(ws + L.pg) : nullptr;
   float *pt = thr_dev ? reinterpret_cast<float *>(ws + L.pt) : nullptr;
   uint32_t *tgr = reinterpret_cast<uint32_t *>(ws + L.tgr);
@@ -2367,6 +2466,8 @@ int nms_enqueue_source(const char *who, NmsSource src, int64_t n, int kind, floa
       hipLaunchKernelGGL(nms_small_kernel<0>, dim3(1), dim3(1024), 0, st, src, (int)n, iou_thr, flags, rec, cands, ecap, keep_dev, result);
     else if (kind == OBB_KIND_POLY)
       hipLaunchKernelGGL(nms_small_kernel<1>, dim3(1), dim3(1024), 0, st, src, (int)n, iou_thr, flags, rec, cands, ecap, keep_dev, result);
+    else if (f64)
+      hipLaunchKernelGGL((nms_small_kernel<2, true>), dim3(1), dim3(1024), 0, st, src, (int)n, iou_thr, flags, rec, cands, ecap, keep_dev, result);
     else
       hipLaunchKernelGGL(nms_small_kernel<2>, dim3(1), dim3(1024), 0, st, src, (int)n, iou_thr, flags, rec, cands, ecap, keep_dev, result);
     OBB_LAUNCH_CHECK();
@@ -2391,6 +2492,8 @@ int nms_enqueue_source(const char *who, NmsSource src, int64_t n, int kind, floa
       hipLaunchKernelGGL(nms_prep_kernel<0>, dim3(pblocks), dim3(256), 0, st, src, n, rec, iv, ar, iou_thr, zero, zero_vecs);
     else if (kind == OBB_KIND_POLY)
       hipLaunchKernelGGL(nms_prep_kernel<1>, dim3(pblocks), dim3(256), 0, st, src, n, rec, iv, ar, iou_thr, zero, zero_vecs);
+    else if (f64)
+      hipLaunchKernelGGL((nms_prep_kernel<2, true>), dim3(pblocks), dim3(256), 0, st, src, n, rec, iv, ar, iou_thr, zero, zero_vecs);
     else
       hipLaunchKernelGGL(nms_prep_kernel<2>, dim3(pblocks), dim3(256), 0, st, src, n, rec, iv, ar, iou_thr, zero, zero_vecs);
     OBB_LAUNCH_CHECK();
@@ -2402,6 +2505,8 @@ int nms_enqueue_source(const char *who, NmsSource src, int64_t n, int kind, floa
       hipLaunchKernelGGL(nms_frame_kernel<0>, dim3(zb), dim3(256), 0, st, src, n, hbits, frame, zero, zero_vecs);
     else if (kind == OBB_KIND_POLY)
       hipLaunchKernelGGL(nms_frame_kernel<1>, dim3(zb), dim3(256), 0, st, src, n, hbits, frame, zero, zero_vecs);
+    else if (f64)
+      hipLaunchKernelGGL((nms_frame_kernel<2, true>), dim3(zb), dim3(256), 0, st, src, n, hbits, frame, zero, zero_vecs);
     else
       hipLaunchKernelGGL(nms_frame_kernel<2>, dim3(zb), dim3(256), 0, st, src, n, hbits, frame, zero, zero_vecs);
     OBB_LAUNCH_CHECK();
@@ -2409,6 +2514,8 @@ int nms_enqueue_source(const char *who, NmsSource src, int64_t n, int kind, floa
       hipLaunchKernelGGL(nms_prepq_kernel<0>, dim3(pblocks), dim3(256), 0, st, src, n, rec, qb, ar, ckey, crank, hist, hbits, frame, iou_thr);
     else if (kind == OBB_KIND_POLY)
       hipLaunchKernelGGL(nms_prepq_kernel<1>, dim3(pblocks), dim3(256), 0, st, src, n, rec, qb, ar, ckey, crank, hist, hbits, frame, iou_thr);
+    else if (f64)
+      hipLaunchKernelGGL((nms_prepq_kernel<2, true>), dim3(pblocks), dim3(256), 0, st, src, n, rec, qb, ar, ckey, crank, hist, hbits, frame, iou_thr);
     else
       hipLaunchKernelGGL(nms_prepq_kernel<2>, dim3(pblocks), dim3(256), 0, st, src, n, rec, qb, ar, ckey, crank, hist, hbits, frame, iou_thr);
     OBB_LAUNCH_CHECK();
@@ -2421,7 +2528,7 @@ int nms_enqueue_source(const char *who, NmsSource src, int64_t n, int kind, floa
     while (rpw > 4 && ((n + rpw - 1) / rpw) * (long long)(nt + 1) / 2 < 2048) rpw >>= 1;
     const unsigned nparts = (unsigned)((n + rpw - 1) / rpw);
     hipLaunchKernelGGL(nms_scan_direct_kernel, dim3((nparts + kNmsWaves - 1) / kNmsWaves, (unsigned)nt), dim3(64 * kNmsWaves), 0, st,
-                       iv, ar, rec, (uint32_t)n, rpw, prune_thr, thr_dev ? 1 : 0, flags, edges, segcap, ccnts, cnt);
+                       iv, ar, rec, (uint32_t)n, rpw, prune_thr, thr_dev ? 1 : 0, flags, edges, segcap, ccnts, cnt, klo);
     OBB_LAUNCH_CHECK();
     OBB_PHASE(4);
     OBB_PHASE(5);
@@ -2469,15 +2576,15 @@ int nms_enqueue_source(const char *who, NmsSource src, int64_t n, int kind, floa
       const long long pb = tuning(OBB_TUNE_NMS_SCAN_BLOCKS, inline_clip ? kScanBlocks : (n > 262144 ? 4 * kScanBlocks : 2 * kScanBlocks));
       const unsigned gb = (unsigned)(maxblocks < pb ? maxblocks : pb);
       if (inline_clip)
-        hipLaunchKernelGGL(nms_scan_kernel<true>, dim3(gb), dim3(64 * kNmsWaves), 0, st, qs, pf, pg, pt, cellpx, prune_thr, tbox, nt, units, ucap / kShards, ucnts, cands, segcap, ccnts, rec, flags, edges, cnt);
+        hipLaunchKernelGGL(nms_scan_kernel<true>, dim3(gb), dim3(64 * kNmsWaves), 0, st, qs, pf, pg, pt, cellpx, prune_thr, tbox, nt, units, ucap / kShards, ucnts, cands, segcap, ccnts, rec, flags, edges, cnt, klo);
       else
-        hipLaunchKernelGGL(nms_scan_kernel<false>, dim3(gb), dim3(64 * kNmsWaves), 0, st, qs, pf, pg, pt, cellpx, prune_thr, tbox, nt, units, ucap / kShards, ucnts, cands, segcap, ccnts, rec, flags, edges, cnt);
+        hipLaunchKernelGGL(nms_scan_kernel<false>, dim3(gb), dim3(64 * kNmsWaves), 0, st, qs, pf, pg, pt, cellpx, prune_thr, tbox, nt, units, ucap / kShards, ucnts, cands, segcap, ccnts, rec, flags, edges, cnt, klo);
       OBB_LAUNCH_CHECK();
     }
     // phase 4: clip (narrow phase) -- its own launch only where the scan lists its candidates
     OBB_PHASE(4);
     if (!inline_clip) {
-      hipLaunchKernelGGL(nms_clip_kernel, dim3(kClipBlocksPerShard, kShards), dim3(256), 0, st, cands, segcap, rec, flags, edges, ctr, ccnts, cnt);
+      hipLaunchKernelGGL(nms_clip_kernel, dim3(kClipBlocksPerShard, kShards), dim3(256), 0, st, cands, segcap, rec, flags, edges, ctr, ccnts, cnt, klo);
       OBB_LAUNCH_CHECK();
     }
     // phase 5: resolve
@@ -2571,6 +2678,29 @@ extern "C" int obb_nms_ex_f32(const float *dets_dev, int64_t n, int kind, float 
     prof.have = true;
   }
   static_assert(kShards == 64, "the counter folds use one wave");
+  return nms_verdict(h, q, info_host);
+}
+
+extern "C" int obb_nms_hbb_f64(const double *dets_dev, int64_t n, float iou_thr, const int32_t *group_dev,
+                               const float *thr_dev, int flags, int64_t *keep_dev, int64_t *info_host,
+                               void *workspace_dev, size_t workspace_bytes, void *stream) {
+  using namespace obb;
+  if (info_host) { info_host[0] = 0; info_host[1] = 0; info_host[2] = 0; info_host[3] = 0; }
+  int rc = nms_validate("obb_nms_hbb_f64", reinterpret_cast<const float *>(dets_dev), n, OBB_KIND_HBB, iou_thr, thr_dev != nullptr, flags,
+                        keep_dev, workspace_dev);
+  if (rc != OBB_OK) return rc;
+  if (n == 0) return OBB_OK;
+  NmsHostInfo *hinfo = nullptr, *hinfo_dev = nullptr;
+  rc = nms_pinned_record(hinfo, hinfo_dev);
+  if (rc != OBB_OK) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  NmsSource src = {};
+  src.dets64 = dets_dev; src.pitch = 5; src.group = group_dev; src.thrs = thr_dev;
+  NmsEnqueued q;
+  rc = nms_enqueue_source("obb_nms_hbb_f64", src, n, OBB_KIND_HBB, iou_thr, flags, keep_dev, hinfo_dev, workspace_dev, workspace_bytes, st, q);
+  if (rc != OBB_OK) return rc;
+  OBB_HIP_TRY(hipStreamSynchronize(st));
+  const NmsHostInfo h = *hinfo;
   return nms_verdict(h, q, info_host);
 }
 

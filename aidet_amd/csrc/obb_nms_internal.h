@@ -17,6 +17,9 @@ namespace obb {
 //           -- replaces obb_merge_rows_split_f32.  dota.py:321-331 are the thresholds the table carries.
 // Modes 1 and 2 write the derived group (and threshold) per box to gout / tout for the later stages of the chain.
 struct NmsSource {
+  const double *dets64;        // float64 horizontal rows [x1, y1, x2, y2, score] (mode 0, OBB_KIND_HBB only; `dets` unused):
+                               // the narrow phase runs in double, nms_cpu_kernel<double> (nms_cpu.cpp:62-68)
+  uint32_t *klo;               // ... low words of the 64-bit score keys (workspace, n; set by the callee)
   const float *dets;
   int64_t pitch;               // floats per row (>= columns of box + score)
   int mode;

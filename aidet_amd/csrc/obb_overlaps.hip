@@ -303,7 +303,49 @@ __global__ __launch_bounds__(256) void rbox_to_poly_kernel(const float *__restri
   }
 }
 
+// ---- float64 horizontal boxes ----------------------------------------------------------------------------------
+// bbox_overlaps is dtype-generic in the reference (torch expressions, mmdet/core/bbox/geometry.py:47-88): double boxes
+// give double overlaps.  Same expressions as hbb_pair_overlap (geometry.py:61-86 in its tensor-op order, NaNs travelling
+// as torch.max / min / clamp move them), evaluated in double; one thread per output, consecutive threads = consecutive
+// columns (8-byte coalesced stores: the op is write bound).
+__device__ __forceinline__ double nan_max_d(double a, double b) { return (a != a) ? a : ((b != b) ? b : (a < b ? b : a)); }
+__device__ __forceinline__ double nan_min_d(double a, double b) { return (a != a) ? a : ((b != b) ? b : (b < a ? b : a)); }
+__device__ __forceinline__ double hbb_pair_overlap_d(const double *__restrict__ a, const double *__restrict__ b, int mode) {
+  const double ltx = nan_max_d(a[0], b[0]), lty = nan_max_d(a[1], b[1]);
+  const double rbx = nan_min_d(a[2], b[2]), rby = nan_min_d(a[3], b[3]);
+  const double w = nan_max_d((rbx - ltx) + 1.0, 0.0), h = nan_max_d((rby - lty) + 1.0, 0.0);
+  const double overlap = w * h;
+  const double area1 = ((a[2] - a[0]) + 1.0) * ((a[3] - a[1]) + 1.0);
+  if (mode != 0) return overlap / area1;
+  const double area2 = ((b[2] - b[0]) + 1.0) * ((b[3] - b[1]) + 1.0);
+  return overlap / ((area1 + area2) - overlap);
+}
+__global__ __launch_bounds__(256) void hbb_overlaps_f64_kernel(const double *__restrict__ a, int64_t m, const double *__restrict__ b,
+                                                               int64_t n, int mode, int aligned, double *__restrict__ out) {
+  const int64_t total = aligned ? n : m * n;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = aligned ? t : t / n, j = aligned ? t : t - i * n;
+    out[t] = hbb_pair_overlap_d(a + i * 4, b + j * 4, mode);
+  }
+}
+
 }  // namespace obb
+
+extern "C" int obb_hbb_overlaps_f64(const double *a_dev, int64_t m, const double *b_dev, int64_t n, int mode, int aligned,
+                                    double *out_dev, void *stream) {
+  using namespace obb;
+  if (m < 0 || n < 0) return set_err(OBB_EINVAL, "obb_hbb_overlaps_f64: negative size");
+  if (mode != OBB_MODE_IOU && mode != OBB_MODE_IOF) return set_err(OBB_EINVAL, "obb_hbb_overlaps_f64: bad mode %d", mode);
+  if (aligned && m != n) return set_err(OBB_EINVAL, "obb_hbb_overlaps_f64: aligned needs m == n");
+  if (m == 0 || n == 0) return OBB_OK;
+  if (!a_dev || !b_dev || !out_dev) return set_err(OBB_EINVAL, "obb_hbb_overlaps_f64: null pointer");
+  const int64_t total = aligned ? n : m * n;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(hbb_overlaps_f64_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a_dev, m, b_dev, n, mode, aligned, out_dev);
+  OBB_LAUNCH_CHECK();
+  return OBB_OK;
+}
 
 extern "C" int obb_overlaps_f32(const float *a_dev, int64_t m, const float *b_dev, int64_t n,
                                 int kind, int mode, int aligned, float *out_dev, void *stream) {

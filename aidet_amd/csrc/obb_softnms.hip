@@ -257,6 +257,268 @@ __global__ __launch_bounds__(kSoftThreads) void soft_nms_kernel(const float *__r
   if (tid == 0) result[0] = nd;
 }
 
+
+// =====================================================================================================================
+// Round 4: the state in REGISTERS, positions tracked instead of moved.
+// The reference's array permutation is observable only through POSITIONS (who sits at i, who is first among equal
+// scores, who fills a hole).  So a box never moves here: every thread keeps NB boxes in registers together with the
+// position each of them currently has in the reference's array, and a round is
+//   barrier -> read the waves' published candidates (key, coordinates, drop vote) -> the pick takes position i, the box
+//   that sat there takes the pick's old position (two register compares per box, no LDS traffic) -> decay of the local
+//   boxes against the pick's coordinates (boxes whose intersection is empty skip the division: their score is
+//   unchanged bit for bit) -> the NEXT round's candidate of the wave (key by DPP moves, its coordinates, the vote on
+//   drops) is published into the other half of a double buffer.
+// ONE barrier among 4 waves per round without drops (the array version: four to six among 16).  A round WITH drops
+// replays the reference's compaction on the positions: a bitmap of the dropped positions in LDS, its prefix counts,
+// the table "k-th hole -> position", and the survivors at or above the new end take the holes from the end downwards
+// (the same rule as in the array kernel above).  T = float | double (soft_nms_cpu_kernel<scalar_t>, nms_cpu.cpp:212-215:
+// float64 input is computed in double; thresholds stay float and are promoted, :170,:184).
+// =====================================================================================================================
+struct SoftKey3 { uint32_t hi, mid, lo; };   // hi:mid = order-preserving image of the score (0 = NaN: never wins), lo = ~position
+__device__ __forceinline__ bool key3_gt(const SoftKey3 &a, const SoftKey3 &b) {
+  return a.hi > b.hi || (a.hi == b.hi && (a.mid > b.mid || (a.mid == b.mid && a.lo > b.lo)));
+}
+__device__ __forceinline__ void score_image(float s, uint32_t &hi, uint32_t &mid) {
+  const float t = s + 0.0f;
+  uint32_t u = __float_as_uint(t);
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  hi = (s != s) ? 0u : u; mid = 0u;
+}
+__device__ __forceinline__ void score_image(double s, uint32_t &hi, uint32_t &mid) {
+  const double t = s + 0.0;
+  uint64_t u = (uint64_t)__double_as_longlong(t);
+  u = (u & 0x8000000000000000ull) ? ~u : (u | 0x8000000000000000ull);
+  if (s != s) u = 0ull;
+  hi = (uint32_t)(u >> 32); mid = (uint32_t)u;
+}
+template <int CTRL>
+__device__ __forceinline__ SoftKey3 dpp_max3(const SoftKey3 &v) {
+  SoftKey3 o;
+  o.hi = (uint32_t)__builtin_amdgcn_mov_dpp((int)v.hi, CTRL, 0xf, 0xf, true);
+  o.mid = (uint32_t)__builtin_amdgcn_mov_dpp((int)v.mid, CTRL, 0xf, 0xf, true);
+  o.lo = (uint32_t)__builtin_amdgcn_mov_dpp((int)v.lo, CTRL, 0xf, 0xf, true);
+  const bool gt = key3_gt(o, v);       // (component-wise selects: `gt ? o : v` on the structs goes through scratch)
+  SoftKey3 r;
+  r.hi = gt ? o.hi : v.hi; r.mid = gt ? o.mid : v.mid; r.lo = gt ? o.lo : v.lo;
+  return r;
+}
+__device__ __forceinline__ SoftKey3 wave_max_key3(SoftKey3 v) {
+  v = dpp_max3<0xB1>(v);
+  v = dpp_max3<0x4E>(v);
+  v = dpp_max3<0x141>(v);
+  v = dpp_max3<0x140>(v);
+  SoftKey3 m = {0u, 0u, 0u};
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    SoftKey3 o;
+    o.hi = (uint32_t)__builtin_amdgcn_readlane((int)v.hi, r * 16);
+    o.mid = (uint32_t)__builtin_amdgcn_readlane((int)v.mid, r * 16);
+    o.lo = (uint32_t)__builtin_amdgcn_readlane((int)v.lo, r * 16);
+    const bool gt = key3_gt(o, m);
+    m.hi = gt ? o.hi : m.hi; m.mid = gt ? o.mid : m.mid; m.lo = gt ? o.lo : m.lo;
+  }
+  return m;
+}
+__device__ __forceinline__ float soft_exp(float x) { return expf(x); }
+__device__ __forceinline__ double soft_exp(double x) { return exp(x); }
+
+constexpr int kSoftInf = 0x7FFFFFFF;      // position of a box that has left the array
+
+template <class T, int THREADS, int NB>
+__global__ __launch_bounds__(THREADS) void soft_nms_reg_kernel(const T *__restrict__ dets, int n, float thr_f, int method,
+                                                               float sigma_f, float min_score_f, T *__restrict__ out_dets,
+                                                               int64_t *__restrict__ out_inds, long long *__restrict__ result,
+                                                               const int64_t *__restrict__ seg) {
+  constexpr int kW = THREADS / 64, kCap = THREADS * NB;
+  if (seg) {
+    const int64_t off = seg[blockIdx.x];
+    n = (int)(seg[blockIdx.x + 1] - off);
+    dets += off * 5;
+    out_dets += off * 5;
+    out_inds += off;
+    result += blockIdx.x;
+    if (n <= 0) { if (threadIdx.x == 0) result[0] = 0; return; }          // (block-uniform)
+    if (n > kCap) { if (threadIdx.x == 0) result[0] = -1; return; }        // (the host sizes the launch by the largest group)
+  }
+  __shared__ SoftKey3 pkey[2][kW];
+  __shared__ T pcoord[2][kW][5];
+  __shared__ int pdrop[2][kW];
+  __shared__ uint32_t bitmap[kCap / 32], bpre[kCap / 32];
+  __shared__ unsigned short holepos[kCap];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const T thr = (T)thr_f, sigma = (T)sigma_f, min_score = (T)min_score_f, zero = (T)0, one = (T)1;
+  T x1[NB], y1[NB], x2[NB], y2[NB], sc[NB], ar[NB];
+  int id[NB], pos[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int p = b * THREADS + tid;
+    const bool in = p < n;
+    const T *d = dets + (size_t)(in ? p : 0) * 5;
+    x1[b] = d[0]; y1[b] = d[1]; x2[b] = d[2]; y2[b] = d[3]; sc[b] = in ? d[4] : zero;
+    ar[b] = ((x2[b] - x1[b]) + one) * ((y2[b] - y1[b]) + one);
+    id[b] = p;
+    pos[b] = in ? p : kSoftInf;
+  }
+  int nd = n;
+  // this wave's candidate for the pick among positions [from, nd): key by DPP, the owner lane publishes the coordinates
+  auto publish = [&](int from, int par, bool anydrop) {
+    SoftKey3 best = {0u, 0u, 0u};
+    bool have = false;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      if (pos[b] >= from && pos[b] < nd) {
+        SoftKey3 k;
+        score_image(sc[b], k.hi, k.mid);
+        // a NaN never wins (nms_cpu.cpp:116 `max_score < scores[pos]` is false for it) unless it sits at `from`, the
+        // scan's starting value (:100-121)
+        if (sc[b] != sc[b] && pos[b] == from) { k.hi = 0xFFFFFFFFu; k.mid = 0xFFFFFFFFu; }
+        k.lo = ~(uint32_t)pos[b];
+        const bool gt = !have || key3_gt(k, best);
+        best.hi = gt ? k.hi : best.hi; best.mid = gt ? k.mid : best.mid; best.lo = gt ? k.lo : best.lo;
+        have = true;
+      }
+    }
+    if (!have) { best.hi = 0u; best.mid = 0u; best.lo = 0u; }     // (lo = 0 = position 2^32 - 1: below every real key)
+    const SoftKey3 m = wave_max_key3(best);
+    const bool wdrop = __any(anydrop) != 0;
+    if (lane == 0) { pkey[par][wave] = m; pdrop[par][wave] = wdrop ? 1 : 0; }
+    if (m.lo != 0u) {
+      const int mpos = (int)(~m.lo);
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        if (pos[b] == mpos) {
+          pcoord[par][wave][0] = x1[b]; pcoord[par][wave][1] = y1[b]; pcoord[par][wave][2] = x2[b];
+          pcoord[par][wave][3] = y2[b]; pcoord[par][wave][4] = ar[b];
+        }
+      }
+    }
+  };
+  int par = 0;
+  publish(0, par, false);
+  for (int i = 0; i < nd; ++i) {
+    __syncthreads();
+    // ---- the winner among the waves' candidates
+    SoftKey3 g = pkey[par][0];
+    int gw = 0, drops = pdrop[par][0];
+#pragma unroll
+    for (int k = 1; k < kW; ++k) {
+      const SoftKey3 o = pkey[par][k];
+      drops |= pdrop[par][k];
+      const bool gt = key3_gt(o, g);
+      g.hi = gt ? o.hi : g.hi; g.mid = gt ? o.mid : g.mid; g.lo = gt ? o.lo : g.lo;
+      gw = gt ? k : gw;
+    }
+    if (drops) {
+      // ---- the previous round dropped boxes: compaction of the positions (first = i: the drops sit in [i, nd))
+      // (1) bitmap of the dropped positions
+      for (int w = tid; w < kCap / 32; w += THREADS) bitmap[w] = 0u;
+      __syncthreads();
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+        if (pos[b] >= i && pos[b] < nd && sc[b] < min_score) atomicOr(&bitmap[pos[b] >> 5], 1u << (pos[b] & 31));
+      __syncthreads();
+      // (2) prefix counts per word (every wave computes them; wave 0 stores them)
+      int D = 0;
+      {
+        int run = 0;
+        for (int w0 = 0; w0 < kCap / 32; w0 += 64) {
+          const bool inw = w0 + lane < kCap / 32;
+          const int c = inw ? __popc(bitmap[w0 + lane]) : 0;
+          int inc = c;
+          for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+          if (wave == 0 && inw) bpre[w0 + lane] = (uint32_t)(run + inc - c);
+          run += __shfl(inc, 63);
+        }
+        D = run;
+      }
+      const int count = nd - i, M = count - D, nd2 = i + M;
+      __syncthreads();
+      auto drops_before = [&](int p) -> int { return (int)bpre[p >> 5] + __popc(bitmap[p >> 5] & ((1u << (p & 31)) - 1u)); };
+      // (3) the holes: dropped positions below the new end, ascending
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+        if (pos[b] >= i && pos[b] < nd && sc[b] < min_score && pos[b] < nd2) holepos[drops_before(pos[b])] = (unsigned short)pos[b];
+      __syncthreads();
+      // (4) survivors at or above the new end fill the holes from the END downwards; dropped boxes leave
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        if (pos[b] >= i && pos[b] < nd) {
+          if (sc[b] < min_score) pos[b] = kSoftInf;
+          else if (pos[b] >= nd2) {
+            const int kept_incl = (pos[b] - (i - 1)) - drops_before(pos[b]);   // survivors in [i, p], p itself included
+            pos[b] = (int)holepos[M - kept_incl];                            // survivors above p = rank from the end
+          }
+        }
+      }
+      nd = nd2;
+      par ^= 1;
+      publish(i, par, false);         // positions moved: the candidates are taken again (no drop vote this time)
+      --i;                            // (this iteration placed nothing)
+      continue;
+    }
+    // ---- the pick takes position i; the box that sat there takes the pick's old position
+    const int mp = g.lo != 0u ? (int)(~g.lo) : i;
+    const T a0 = pcoord[par][gw][0], a1 = pcoord[par][gw][1], a2 = pcoord[par][gw][2], a3 = pcoord[par][gw][3], iarea = pcoord[par][gw][4];
+    bool anydrop = false;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      if (pos[b] == mp) pos[b] = i;
+      else if (pos[b] == i) pos[b] = mp;
+      if (pos[b] > i && pos[b] < nd) {
+        // nms_cpu.cpp:155-163 (= hbb_overlap) with the pick as box i
+        const T xx1 = a0 < x1[b] ? x1[b] : a0, yy1 = a1 < y1[b] ? y1[b] : a1;
+        const T xx2 = x2[b] < a2 ? x2[b] : a2, yy2 = y2[b] < a3 ? y2[b] : a3;
+        const T ww = (xx2 - xx1) + one, hh = (yy2 - yy1) + one;
+        const T w = zero < ww ? ww : zero, h = zero < hh ? hh : zero;
+        const T inter = w * h;
+        const T den = (iarea + ar[b]) - inter;
+        // empty intersection over a positive denominator: ovr = +0, every method's weight is exactly 1 (hard / linear:
+        // `0 > thr` must be false), the score is unchanged bit for bit -- no division, no exp
+        const bool skip = inter == zero && den > zero && (method == 2 || !(zero > thr));
+        if (!skip) {
+          const T ovr = inter / den;
+          T weight = one;
+          if (method == 1) { if (ovr > thr) weight = one - ovr; }
+          else if (method == 2) weight = soft_exp(-(ovr * ovr) / sigma);
+          else weight = (ovr > thr) ? zero : one;
+          sc[b] = weight * sc[b];
+        }
+        anydrop = anydrop || (sc[b] < min_score);
+      }
+    }
+    par ^= 1;
+    publish(i + 1, par, anydrop);
+  }
+  // (no drop vote can be pending here: a round that dropped boxes is followed by one more iteration -- i < nd still
+  // held -- whose compaction branch applied them; the round of the last position decays nothing)
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    if (pos[b] < nd) {
+      T *o = out_dets + (size_t)pos[b] * 5;
+      o[0] = x1[b]; o[1] = y1[b]; o[2] = x2[b]; o[3] = y2[b]; o[4] = sc[b];
+      out_inds[pos[b]] = id[b];
+    }
+  }
+  if (tid == 0) result[0] = nd;
+}
+
+constexpr int kSoftRegMaxF32 = 8192, kSoftRegMaxF64 = 4096;
+// the register kernel sized by the (largest) array; false = too large for it (float: the global-memory kernel serves it)
+template <class T>
+static bool soft_launch_reg(const T *dets, int64_t nmax, unsigned groups, float thr, int method, float sigma, float min_score,
+                            T *out_dets, int64_t *out_inds, long long *result, const int64_t *seg, hipStream_t st) {
+  const int n = seg ? 0 : (int)nmax;
+#define OBB_SOFT_REG(TH, NB) hipLaunchKernelGGL((soft_nms_reg_kernel<T, TH, NB>), dim3(groups), dim3(TH), 0, st, dets, n, thr, method, sigma, min_score, out_dets, out_inds, result, seg)
+  if (nmax <= 512) OBB_SOFT_REG(256, 2);
+  else if (nmax <= 1024) OBB_SOFT_REG(256, 4);
+  else if (nmax <= 2048) OBB_SOFT_REG(256, 8);
+  else if (nmax <= (sizeof(T) == 4 ? kSoftRegMaxF32 : kSoftRegMaxF64)) {
+    if constexpr (sizeof(T) == 4) OBB_SOFT_REG(1024, 8); else OBB_SOFT_REG(1024, 4);
+  } else return false;
+#undef OBB_SOFT_REG
+  return true;
+}
+
 }  // namespace obb
 
 extern "C" size_t obb_soft_nms_workspace_bytes(int64_t n) {
@@ -289,12 +551,43 @@ extern "C" int obb_soft_nms_f32(const float *dets_dev, int64_t n, float iou_thr,
   OBB_HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&pinned_dev), pinned, 0));
   hipStream_t st = (hipStream_t)stream;
   float *ws = static_cast<float *>(workspace_dev);
-  if (n <= 768)          // measured (tools/bench_soft_nms.py): 1.15 us per round with 4 waves, 1.6 with 16 at n = 500
+  // (the register-resident kernel below serves float64; for float rows it measured SLOWER than the LDS-array kernel --
+  // 6.3 vs 3.3 ms at n = 2000, 21 vs ~12 ms at n = 5000: with 8 boxes per lane a round is ~600 dependent VALU
+  // instructions on one wave per SIMD, DESIGN.md 3.4 -- so float keeps the array kernel; OBB_TUNE_SOFT_NMS_REG = 1 forces
+  // the register kernel for tests)
+  if (tuning(OBB_TUNE_SOFT_NMS_REG, 0) == 1 && soft_launch_reg<float>(dets_dev, n, 1, iou_thr, method, sigma, min_score, out_dets_dev, out_inds_dev, pinned_dev, nullptr, st)) {
+  } else if (n <= 768)          // measured (tools/bench_soft_nms.py): 1.15 us per round with 4 waves, 1.6 with 16 at n = 500
     hipLaunchKernelGGL((soft_nms_kernel<true, 256>), dim3(1), dim3(256), 0, st, dets_dev, (int)n, iou_thr, method, sigma, min_score, ws, out_dets_dev, out_inds_dev, pinned_dev, nullptr);
   else if (n <= kSoftLds)   // 2.0 us per round with 16 waves, 2.3 with 4 at n = 2000
     hipLaunchKernelGGL((soft_nms_kernel<true, 1024>), dim3(1), dim3(1024), 0, st, dets_dev, (int)n, iou_thr, method, sigma, min_score, ws, out_dets_dev, out_inds_dev, pinned_dev, nullptr);
   else
     hipLaunchKernelGGL((soft_nms_kernel<false, 1024>), dim3(1), dim3(1024), 0, st, dets_dev, (int)n, iou_thr, method, sigma, min_score, ws, out_dets_dev, out_inds_dev, pinned_dev, nullptr);
+  OBB_LAUNCH_CHECK();
+  OBB_HIP_TRY(hipStreamSynchronize(st));
+  *count_host = *pinned;
+  return OBB_OK;
+}
+
+extern "C" int obb_soft_nms_f64(const double *dets_dev, int64_t n, float iou_thr, int method, float sigma,
+                                float min_score, double *out_dets_dev, int64_t *out_inds_dev,
+                                int64_t *count_host, void *stream) {
+  using namespace obb;
+  if (count_host) *count_host = 0;
+  if (n < 0) return set_err(OBB_EINVAL, "obb_soft_nms_f64: negative n");
+  if (method < 0 || method > 2) return set_err(OBB_EINVAL, "obb_soft_nms_f64: bad method %d (0 hard, 1 linear, 2 gaussian)", method);
+  if (n == 0) return OBB_OK;
+  if (n > kSoftRegMaxF64) return set_err(OBB_EINVAL, "obb_soft_nms_f64: n = %lld exceeds %d (the float64 state lives in registers)", (long long)n, kSoftRegMaxF64);
+  if (!dets_dev || !out_dets_dev || !out_inds_dev || !count_host) return set_err(OBB_EINVAL, "obb_soft_nms_f64: null pointer");
+  static thread_local long long *pinned = nullptr;
+  if (!pinned) {
+    void *p = nullptr;
+    OBB_HIP_TRY(hipHostMalloc(&p, 64, hipHostMallocPortable | hipHostMallocMapped));
+    pinned = static_cast<long long *>(p);
+  }
+  long long *pinned_dev = nullptr;
+  OBB_HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&pinned_dev), pinned, 0));
+  hipStream_t st = (hipStream_t)stream;
+  soft_launch_reg<double>(dets_dev, n, 1, iou_thr, method, sigma, min_score, out_dets_dev, out_inds_dev, pinned_dev, nullptr, st);
   OBB_LAUNCH_CHECK();
   OBB_HIP_TRY(hipStreamSynchronize(st));
   *count_host = *pinned;

@@ -34,6 +34,7 @@ _ws_bytes = {}
 # upper bound on the workspace a retry may ask for (a dense scene needs 16 B per
 # overlapping pair; the library reports the pair capacity that suffices)
 MAX_WORKSPACE_BYTES = 64 << 30
+SOFT_NMS_F64_MAX = 4096     # obb_soft_nms_f64 keeps its state in registers
 
 
 def _workspace(L, dev, stream, n, kind, capacity):
@@ -183,6 +184,41 @@ def _run_nms(dets_dev, kind, iou_thr, groups=None, thrs=None, strict=False):
     return keep.narrow(0, 0, info[0]), (info[1], info[2], info[3])
 
 
+def _run_nms_f64(dets_dev, iou_thr, groups=None, thrs=None, strict=False):
+    """float64 horizontal boxes (n, 5) on the device -> int64 keep: ``obb_nms_hbb_f64`` (the reference computes float64
+    input in double, nms_cpu.cpp:62-68)."""
+    n, dev = dets_dev.size(0), dets_dev.device
+    L = _lib.lib()
+    keep = torch.empty(n, dtype=torch.int64, device=dev)
+    info = (ctypes.c_int64 * 4)()
+    groups, gptr, thrs, tptr = _side_inputs(dev, n, groups, thrs)
+    with _lib.on_device(dev):
+        stream = _lib.current_stream_handle(dev)
+        capacity = 0
+        while True:
+            ws, nbytes = _workspace(L, dev, stream, n, _lib.KIND_HBB, capacity)
+            rc = L.obb_nms_hbb_f64(dets_dev.data_ptr(), n, float(iou_thr), gptr, tptr, _lib.NMS_STRICT if strict else 0,
+                                   keep.data_ptr(), info, ws.data_ptr(), nbytes, stream)
+            if rc != _lib.OBB_EWORKSPACE:
+                break
+            capacity = max(int(info[3]), 2 * capacity)
+    _lib.check(rc)
+    return keep.narrow(0, 0, info[0])
+
+
+_warned_downcast = set()
+
+
+def _warn_downcast(name):
+    """The rotated operators compute in fp32 (the reference's GPU ops are float-only, nms_kernel.cu:76; its CPU NMS would
+    follow the input's dtype, nms_cpu.cpp:62-68): a float64 input is down-cast, and says so once per operator."""
+    if name not in _warned_downcast:
+        _warned_downcast.add(name)
+        import warnings
+        warnings.warn('%s: float64 input is computed in float32 on the GPU (only the horizontal `nms` / `soft_nms` / '
+                      '`bbox_overlaps` have a float64 path)' % name, UserWarning, stacklevel=3)
+
+
 def _as_tensor(x):
     if x is None or isinstance(x, torch.Tensor):
         return x
@@ -206,7 +242,17 @@ def _nms_generic(dets, iou_thr, device_id, cols, kind, name, groups=None, thrs=N
 
     if dets_th.shape[0] == 0:  # nms_wrapper.py:50-51
         inds = dets_th.new_zeros(0, dtype=torch.long)
+    elif kind == _lib.KIND_HBB and dets_th.dtype == torch.float64:
+        # the reference dispatches on the scalar type (nms_cpu.cpp:62-68): double boxes are decided in double
+        _lib.require_gpu()
+        dev = dets_th.device if dets_th.is_cuda else torch.device('cuda', torch.cuda.current_device() if device_id is None else device_id)
+        d = dets_th.detach().to(device=dev).contiguous()
+        inds = _run_nms_f64(d, float(iou_thr), _as_tensor(groups), _as_tensor(thrs), strict)
+        if not is_numpy:
+            inds = inds.to(dets_th.device)
     else:
+        if dets_th.dtype == torch.float64:
+            _warn_downcast(name)
         d = _lib.to_device_f32(dets_th, device_id)
         inds, _ = _run_nms(d, kind, float(iou_thr), _as_tensor(groups), _as_tensor(thrs), strict)
         if not is_numpy:
@@ -356,7 +402,21 @@ def soft_nms(dets, iou_thr, method='linear', sigma=0.5, min_score=1e-3, device_i
     if n == 0:
         new_dets = dets_th.new_zeros((0, 5), dtype=torch.float32)
         inds = torch.zeros(0, dtype=torch.long)
+    elif dets_th.dtype == torch.float64 and n <= SOFT_NMS_F64_MAX:
+        # the reference dispatches on the scalar type (nms_cpu.cpp:212-215): float64 rows are decayed in double
+        _lib.require_gpu()
+        dev = dets_th.device if dets_th.is_cuda else torch.device('cuda', torch.cuda.current_device() if device_id is None else device_id)
+        d = dets_th.to(device=dev).contiguous()
+        out = torch.empty((n, 5), dtype=torch.float64, device=dev)
+        oinds = torch.empty(n, dtype=torch.int64, device=dev)
+        count = ctypes.c_int64(0)
+        with _OnDevice(dev):
+            _lib.check(_lib.lib().obb_soft_nms_f64(d.data_ptr(), n, float(iou_thr), method_codes[method], float(sigma), float(min_score),
+                                                   out.data_ptr(), oinds.data_ptr(), ctypes.byref(count), _lib.current_stream_handle(dev)))
+        new_dets, inds = out[:count.value], oinds[:count.value]
     else:
+        if dets_th.dtype == torch.float64:
+            _warn_downcast('soft_nms (more than %d float64 rows)' % SOFT_NMS_F64_MAX)
         d = _lib.to_device_f32(dets_th, device_id)
         dev = d.device
         L = _lib.lib()

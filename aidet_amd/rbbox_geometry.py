@@ -195,6 +195,19 @@ def _overlaps(b1, b2, mode, is_aligned, cols, kind, row_shard=None):
                                    'does'.format(rows * (1 if is_aligned else n)))
             return _RboxOverlapsGrad.apply(b1, b2, mode, is_aligned)
         raise RuntimeError('pointobb_overlaps has no gradient: detach the boxes (target assignment)')
+    if kind == _lib.KIND_HBB and b1.dtype == torch.float64 and b2.dtype == torch.float64:
+        # the reference's expressions follow the input's dtype (geometry.py:47-88): double in, double out
+        _lib.require_gpu()
+        dev = b1.device if b1.is_cuda else (b2.device if b2.is_cuda else torch.device('cuda', torch.cuda.current_device()))
+        a, b = b1.detach().to(dev).contiguous(), b2.detach().to(dev).contiguous()
+        out = torch.empty((rows,) if is_aligned else (rows, n), dtype=torch.float64, device=dev)
+        with _lib.on_device(dev):
+            _lib.check(_lib.lib().obb_hbb_overlaps_f64(a.data_ptr(), rows, b.data_ptr(), n, _lib.MODE[mode], 1 if is_aligned else 0,
+                                                       out.data_ptr(), _lib.current_stream_handle(dev)))
+        return out.to(b1.device)
+    if b1.dtype == torch.float64 and kind != _lib.KIND_HBB:
+        from .nms_wrapper import _warn_downcast
+        _warn_downcast('rbbox_overlaps' if kind == _lib.KIND_RBOX else 'pointobb_overlaps')
     a = _lib.to_device_f32(b1)
     b = _lib.to_device_f32(b2).to(a.device)
     out = torch.empty((rows,) if is_aligned else (rows, n), dtype=torch.float32, device=a.device)

@@ -84,6 +84,10 @@ OBB_API const char *obb_last_error(void);
  * ------------------------------------------------------------------------- */
 OBB_API int obb_overlaps_f32(const float *a_dev, int64_t m, const float *b_dev, int64_t n,
                      int kind, int mode, int aligned, float *out_dev, void *stream);
+/* float64 horizontal boxes (m, 4) x (n, 4) -> double overlaps: bbox_overlaps is dtype-generic in the reference
+ * (mmdet/core/bbox/geometry.py:47-88); same expressions as the OBB_KIND_HBB kind of obb_overlaps_f32, in double. */
+OBB_API int obb_hbb_overlaps_f64(const double *a_dev, int64_t m, const double *b_dev, int64_t n, int mode, int aligned,
+                                 double *out_dev, void *stream);
 
 /* ---------------------------------------------------------------------------
  * Greedy rotated / polygon NMS.
@@ -142,6 +146,17 @@ OBB_API int obb_nms_ex_f32(const float *dets_dev, int64_t n, int kind, float iou
                            int64_t *keep_dev, int64_t *info_host, void *workspace_dev,
                            size_t workspace_bytes, void *stream);
 
+/* float64 horizontal boxes: dets_dev (n, 5) DOUBLES [x1, y1, x2, y2, score].
+ * Replaces: the double instantiation of nms_cpu_kernel<scalar_t> (AT_DISPATCH_FLOATING_TYPES,
+ *           mmdet/ops/nms/src/nms_cpu.cpp:62-68; exercised by tests/test_nms.py:33-41 with float64 arrays).
+ * Areas, intersection and `ovr >= threshold` are evaluated in double on the caller's doubles (the float threshold
+ * promoted, as the reference's `const float threshold` is), "precedes" on the 64-bit key of the double score; only the
+ * broad phase works on coordinates rounded to fp32 (conservatively).  Same keep / info / workspace contract as
+ * obb_nms_ex_f32 with kind = OBB_KIND_HBB (workspace: obb_nms_workspace_bytes(n, OBB_KIND_HBB, capacity)). */
+OBB_API int obb_nms_hbb_f64(const double *dets_dev, int64_t n, float iou_thr, const int32_t *group_dev,
+                            const float *thr_dev, int flags, int64_t *keep_dev, int64_t *info_host,
+                            void *workspace_dev, size_t workspace_bytes, void *stream);
+
 /* Asynchronous form: enqueues the same kernels and returns WITHOUT synchronising `stream`
  * (the reference's nms_cuda copies the mask to the host and loops there, nms_kernel.cu:104-131;
  * a detector calls it once per FPN level and once per class, rpn_head.py:92, rbbox_nms.py:43 --
@@ -181,6 +196,13 @@ OBB_API int obb_soft_nms_f32(const float *dets_dev, int64_t n, float iou_thr, in
                              float min_score, float *out_dets_dev, int64_t *out_inds_dev,
                              int64_t *count_host, void *workspace_dev, size_t workspace_bytes,
                              void *stream);
+
+/* float64 rows (n, 5): soft_nms_cpu_kernel<double> (AT_DISPATCH_FLOATING_TYPES, nms_cpu.cpp:212-215): overlaps, decayed scores
+ * and the `< min_score` / `> iou_thr` comparisons in double (the float arguments promoted, :170,:184); out_dets_dev
+ * (n, 5) doubles.  The state lives in registers: n <= 4096.  Synchronises `stream` (returns the count). */
+OBB_API int obb_soft_nms_f64(const double *dets_dev, int64_t n, float iou_thr, int method, float sigma,
+                             float min_score, double *out_dets_dev, int64_t *out_inds_dev,
+                             int64_t *count_host, void *stream);
 
 /* Soft-NMS of several INDEPENDENT groups in one launch: workgroup g replays the reference's loop on the rows
  * [seg_dev[g], seg_dev[g + 1]) as an array of its own.
@@ -540,7 +562,8 @@ OBB_API int obb_head_gather_decode_f32(const float *rois_dev, const float *cls_s
 #define OBB_TUNE_RROI_ORDER_MIN 6     /* fewest RoIs the workspace forward puts into Morton order      */
 #define OBB_TUNE_RROI_GATHER_CHAN 7   /* channels per block of the gather backward (16 or 32)          */
 #define OBB_TUNE_RPN_BARRIER_TICKS 8  /* bound (100 MHz ticks) of the level barrier of the RPN selection; 0 forces the fallback */
-#define OBB_TUNE_COUNT 9
+#define OBB_TUNE_SOFT_NMS_REG 9       /* 1: float Soft-NMS through the register-resident kernel (the float64 one), n <= 8192 */
+#define OBB_TUNE_COUNT 10
 OBB_API int obb_set_tuning(int knob, int64_t value);
 
 #ifdef __cplusplus

@@ -229,6 +229,54 @@ def soft_nms(dets, iou_thr, method='linear', sigma=0.5, min_score=1e-3):
     return out[:k, :5].copy(), out[:k, 5].astype(np.int64)
 
 
+def hbb_nms_f64(dets, iou_thr):
+    """nms_cpu_kernel<double> (nms_cpu.cpp:5-68): (n, 5) float64 rows -> ascending int64 keep indices; the threshold is a
+    float in the reference's signature and is promoted in the comparison."""
+    d = np.ascontiguousarray(dets, dtype=np.float64).reshape(-1, 5)
+    keep = np.zeros(d.shape[0], dtype=np.int64)
+    L = lib()
+    L.obbo_hbb_nms_f64.restype = ctypes.c_long
+    k = L.obbo_hbb_nms_f64(_p(d, _f64p), ctypes.c_long(d.shape[0]), ctypes.c_float(iou_thr), _p(keep, ctypes.POINTER(ctypes.c_int64)))
+    assert k >= 0
+    return keep[:k].copy()
+
+
+def soft_nms_f64(dets, iou_thr, method='linear', sigma=0.5, min_score=1e-3):
+    """soft_nms_cpu_kernel<double> (nms_cpu.cpp:71-215) -> (new_dets (k, 5) float64, inds (k,) int64)."""
+    codes = {'naive': 0, 'linear': 1, 'gaussian': 2}
+    d = np.ascontiguousarray(dets, dtype=np.float64).reshape(-1, 5)
+    out = np.zeros((d.shape[0], 6), dtype=np.float64)
+    L = lib()
+    L.obbo_soft_nms_f64.restype = ctypes.c_long
+    k = L.obbo_soft_nms_f64(_p(d, _f64p), ctypes.c_long(d.shape[0]), ctypes.c_float(iou_thr), codes[method], ctypes.c_float(sigma),
+                            ctypes.c_float(min_score), _p(out, _f64p))
+    assert k >= 0
+    return out[:k, :5].copy(), out[:k, 5].astype(np.int64)
+
+
+def bbox_overlaps_f64(a, b, mode='iou', is_aligned=False):
+    """geometry.py:47-88 on float64 boxes (numpy restatement of the same expressions)."""
+    a = np.asarray(a, dtype=np.float64).reshape(-1, 4)
+    b = np.asarray(b, dtype=np.float64).reshape(-1, 4)
+    if is_aligned:
+        lt, rb = np.maximum(a[:, :2], b[:, :2]), np.minimum(a[:, 2:], b[:, 2:])
+        wh = np.clip(rb - lt + 1, 0, None)
+        ov = wh[:, 0] * wh[:, 1]
+        a1 = (a[:, 2] - a[:, 0] + 1) * (a[:, 3] - a[:, 1] + 1)
+        if mode == 'iou':
+            a2 = (b[:, 2] - b[:, 0] + 1) * (b[:, 3] - b[:, 1] + 1)
+            return ov / (a1 + a2 - ov)
+        return ov / a1
+    lt, rb = np.maximum(a[:, None, :2], b[None, :, :2]), np.minimum(a[:, None, 2:], b[None, :, 2:])
+    wh = np.clip(rb - lt + 1, 0, None)
+    ov = wh[..., 0] * wh[..., 1]
+    a1 = (a[:, 2] - a[:, 0] + 1) * (a[:, 3] - a[:, 1] + 1)
+    if mode == 'iou':
+        a2 = (b[:, 2] - b[:, 0] + 1) * (b[:, 3] - b[:, 1] + 1)
+        return ov / (a1[:, None] + a2[None, :] - ov)
+    return ov / a1[:, None]
+
+
 def polyiou_f64(a, b, kind='rbox', recentre=False):
     """Aligned-pair IoU by the DOTA devkit's triangle-fan algorithm, fp64 (third,
     independent formulation; see obb_oracle.c)."""

@@ -832,6 +832,118 @@ OBBO_API long obbo_soft_nms_f32(const float *dets, long n, float thr, int method
 }
 
 /* ------------------------------------------------------------------ */
+/* the same two loops for float64 boxes: nms_cpu_kernel<double> /       */
+/* soft_nms_cpu_kernel<double> (AT_DISPATCH_FLOATING_TYPES,             */
+/* nms_cpu.cpp:62-68, :212-215).  The threshold stays a FLOAT in the    */
+/* reference's signature (`const float threshold`, :5,:71) and is       */
+/* promoted in the comparison (:56, :170).                              */
+/* ------------------------------------------------------------------ */
+typedef struct { uint64_t key; long idx; } key64_idx;
+static int cmp_key64_idx(const void *a, const void *b) {
+  const key64_idx *x = (const key64_idx *)a, *y = (const key64_idx *)b;
+  if (x->key != y->key) return x->key < y->key ? -1 : 1;
+  return x->idx < y->idx ? -1 : (x->idx > y->idx ? 1 : 0);
+}
+static uint64_t obbo_score_key64(double s) {
+  double t = s + 0.0;
+  uint64_t u;
+  memcpy(&u, &t, 8);
+  u = (u & 0x8000000000000000ull) ? ~u : (u | 0x8000000000000000ull);
+  return ~u;
+}
+static inline double dmax_sel(double a, double b) { return a < b ? b : a; }
+static inline double dmin_sel(double a, double b) { return b < a ? b : a; }
+
+OBBO_API long obbo_hbb_nms_f64(const double *dets, long n, float thr, int64_t *keep) {
+  long i, j;
+  if (n <= 0) return 0;
+  key64_idx *ord = (key64_idx *)malloc(sizeof(key64_idx) * (size_t)n);
+  double *areas = (double *)malloc(sizeof(double) * (size_t)n);
+  uint8_t *sup = (uint8_t *)calloc((size_t)n, 1);
+  if (!ord || !areas || !sup) { free(ord); free(areas); free(sup); return -2; }
+  for (i = 0; i < n; ++i) {
+    const double *d = dets + i * 5;
+    areas[i] = (d[2] - d[0] + 1.0) * (d[3] - d[1] + 1.0);
+    ord[i].key = obbo_score_key64(d[4]); ord[i].idx = i;
+  }
+  qsort(ord, (size_t)n, sizeof(key64_idx), cmp_key64_idx);
+  const double thrd = (double)thr;
+  for (i = 0; i < n; ++i) {
+    long a = ord[i].idx;
+    if (sup[a]) continue;
+    const double *da = dets + a * 5;
+    for (j = i + 1; j < n; ++j) {
+      long b = ord[j].idx;
+      if (sup[b]) continue;
+      const double *db = dets + b * 5;
+      double xx1 = dmax_sel(da[0], db[0]), yy1 = dmax_sel(da[1], db[1]);
+      double xx2 = dmin_sel(da[2], db[2]), yy2 = dmin_sel(da[3], db[3]);
+      double w = dmax_sel(0.0, xx2 - xx1 + 1.0), h = dmax_sel(0.0, yy2 - yy1 + 1.0);
+      double inter = w * h;
+      double ovr = inter / (areas[a] + areas[b] - inter);
+      if (ovr >= thrd) sup[b] = 1;
+    }
+  }
+  long k = 0;
+  for (i = 0; i < n; ++i) if (!sup[i]) keep[k++] = i;
+  free(ord); free(areas); free(sup);
+  return k;
+}
+
+OBBO_API long obbo_soft_nms_f64(const double *dets, long n, float thr, int method, float sigma,
+                                float min_score, double *out) {
+  long i, pos;
+  if (n <= 0) return 0;
+  double *x1 = (double *)malloc(sizeof(double) * (size_t)n * 7);
+  if (!x1) return -2;
+  double *y1 = x1 + n, *x2 = x1 + 2 * n, *y2 = x1 + 3 * n, *sc = x1 + 4 * n, *ar = x1 + 5 * n, *id = x1 + 6 * n;
+  for (i = 0; i < n; ++i) {
+    const double *d = dets + i * 5;
+    x1[i] = d[0]; y1[i] = d[1]; x2[i] = d[2]; y2[i] = d[3]; sc[i] = d[4];
+    ar[i] = (d[2] - d[0] + 1.0) * (d[3] - d[1] + 1.0);
+    id[i] = (double)i;
+  }
+  long nd = n;
+  for (i = 0; i < nd; ++i) {
+    double max_score = sc[i];
+    long max_pos = i;
+    for (pos = i + 1; pos < nd; ++pos)
+      if (max_score < sc[pos]) { max_score = sc[pos]; max_pos = pos; }
+    double t;
+#define OBBO_SWAP(a) t = a[i]; a[i] = a[max_pos]; a[max_pos] = t
+    OBBO_SWAP(x1); OBBO_SWAP(y1); OBBO_SWAP(x2); OBBO_SWAP(y2); OBBO_SWAP(sc); OBBO_SWAP(ar); OBBO_SWAP(id);
+#undef OBBO_SWAP
+    const double ix1 = x1[i], iy1 = y1[i], ix2 = x2[i], iy2 = y2[i], iarea = ar[i];
+    pos = i + 1;
+    while (pos < nd) {
+      double xx1 = dmax_sel(ix1, x1[pos]), yy1 = dmax_sel(iy1, y1[pos]);
+      double xx2 = dmin_sel(ix2, x2[pos]), yy2 = dmin_sel(iy2, y2[pos]);
+      double w = dmax_sel(0.0, xx2 - xx1 + 1.0), h = dmax_sel(0.0, yy2 - yy1 + 1.0);
+      double inter = w * h;
+      double ovr = inter / (iarea + ar[pos] - inter);
+      double weight = 1.0;
+      if (method == 1) { if (ovr > (double)thr) weight = 1.0 - ovr; }
+      else if (method == 2) weight = exp(-(ovr * ovr) / (double)sigma);
+      else weight = (ovr > (double)thr) ? 0.0 : 1.0;
+      sc[pos] = weight * sc[pos];
+      if (sc[pos] < (double)min_score) {
+        x1[pos] = x1[nd - 1]; y1[pos] = y1[nd - 1]; x2[pos] = x2[nd - 1]; y2[pos] = y2[nd - 1];
+        sc[pos] = sc[nd - 1]; ar[pos] = ar[nd - 1]; id[pos] = id[nd - 1];
+        nd = nd - 1;
+        pos = pos - 1;
+      }
+      pos = pos + 1;
+    }
+  }
+  for (i = 0; i < nd; ++i) {
+    double *o = out + i * 6;
+    o[0] = x1[i]; o[1] = y1[i]; o[2] = x2[i]; o[3] = y2[i]; o[4] = sc[i]; o[5] = id[i];
+  }
+  free(x1);
+  return nd;
+}
+
+/* ------------------------------------------------------------------ */
 /* fp64 triangle-fan polygon IoU ("polyiou")                            */
 /* ------------------------------------------------------------------ */
 /* THIRD, independent formulation of the rotated overlap: the algorithm published with the

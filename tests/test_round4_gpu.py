@@ -120,3 +120,95 @@ def test_fused_tiled_phases_repeat_a_phase_whose_pair_lists_overflow():
     assert rows.size(0) == n and k.size(0) == 1
     assert (1, n.bit_length()) in dota_merge._phase_capacity            # the merge phase overflowed and was repeated
     dota_merge._phase_capacity.clear()
+
+
+# ---- float64 fidelity (missing #3) --------------------------------------------------------------------------
+def test_float64_nms_is_decided_in_double_like_the_reference(golden, nms_route):
+    """`nms` on float64 rows -> obb_nms_hbb_f64: areas / intersection / `>=` in double, the order from the 64-bit score
+    key; index-exact with the reference's nms_cpu_kernel<double> (fixtures made by running it) on every route,
+    numpy and tensor containers, groups."""
+    from aidet_amd import nms
+    g = golden('hbb_f64.npz')
+    thr = {'between': 0.7, 'close': 1.0}
+    for route in ('auto', 'direct', 'sorted', 'listed', 'fused'):
+        nms_route(route)
+        for tag in ('a', 'b', 'c', 'int', 'fine', 'between', 'close'):
+            d = g['nms_%s_dets' % tag]
+            if route == 'fused' and len(d) > 1024:
+                continue
+            th = float(g['nms_%s_thr' % tag]) if tag not in thr else thr[tag]
+            kept, inds = nms(d, th)
+            assert isinstance(inds, np.ndarray) and kept.dtype == np.float64
+            assert np.array_equal(inds, g['nms_%s_keep' % tag]), (route, tag)
+    nms_route('auto')
+    d = g['nms_b_dets']
+    kept, inds = nms(torch.from_numpy(d).to(dev()), 0.3)
+    assert inds.is_cuda and kept.dtype == torch.float64 and np.array_equal(inds.cpu().numpy(), g['nms_b_keep'])
+    # groups: two copies of the scene in two groups = the scene's keep twice
+    two = np.concatenate([d, d], 0)
+    grp = np.repeat([3, 9], len(d)).astype(np.int32)
+    _, gi = nms(two, 0.3, groups=grp)
+    assert np.array_equal(gi, np.concatenate([g['nms_b_keep'], g['nms_b_keep'] + len(d)]))
+    # larger scenes against the oracle's double restatement (pinned to the fixtures on the CPU side)
+    rng = np.random.default_rng(3)
+    for n, canvas in ((20000, 1500), (70000, 3000)):
+        x1, y1 = rng.uniform(0, canvas, n), rng.uniform(0, canvas, n)
+        b = np.stack([x1, y1, x1 + np.exp(rng.uniform(2, 5, n)), y1 + np.exp(rng.uniform(2, 5, n)), 0.5 + rng.permutation(n) * 1e-12], 1)
+        assert np.array_equal(nms(b, 0.5)[1], oracle.hbb_nms_f64(b, 0.5)), n
+
+
+def test_float64_bbox_overlaps_and_soft_nms_follow_the_input_dtype(golden):
+    from aidet_amd import bbox_overlaps, soft_nms
+    g = golden('hbb_f64.npz')
+    b1, b2 = torch.from_numpy(g['iou_b1']), torch.from_numpy(g['iou_b2'])
+    for where in (lambda x: x, lambda x: x.to(dev())):
+        got = bbox_overlaps(where(b1), where(b2))
+        assert got.dtype == torch.float64 and np.array_equal(got.cpu().numpy(), g['iou'])
+        assert np.array_equal(bbox_overlaps(where(b1), where(b2), mode='iof').cpu().numpy(), g['iof'])
+        assert np.array_equal(bbox_overlaps(where(b1), where(b2[:150]), is_aligned=True).cpu().numpy(), g['iou_aligned'])
+    for t in 'abc':
+        cfg, m = g['soft_%s_cfg' % t], str(g['soft_%s_method' % t])
+        nd, inds = soft_nms(g['soft_%s_dets' % t], cfg[0], method=m, sigma=cfg[1], min_score=cfg[2])
+        assert nd.dtype == np.float64 and np.array_equal(inds, g['soft_%s_inds' % t]), t
+        tol = 0.0 if m == 'linear' else 1e-12          # (device exp)
+        assert np.abs(nd - g['soft_%s_new_dets' % t]).max() <= tol, t
+
+
+def test_float64_rotated_input_says_that_it_is_down_cast():
+    from aidet_amd import nms_wrapper, rnms
+    nms_wrapper._warned_downcast.discard('rnms')
+    d = oracle.synth_boxes(300, 200, 2).astype(np.float64)
+    with pytest.warns(UserWarning, match='float64 input is computed in float32'):
+        kept, inds = rnms(d, 0.5)
+    assert kept.dtype == np.float64 and np.array_equal(inds, oracle.rnms(d.astype(np.float32), 0.5))
+
+
+def test_register_soft_nms_replays_the_array_permutation():
+    """The register-resident Soft-NMS (positions tracked, boxes never moved) against the oracle's array loop: sizes
+    around every launch shape (2 / 4 / 8 boxes per thread, 16 waves, the global-memory kernel), ties, heavy drops
+    (min_score 0.3: many rounds compact), drops in the last rounds, NaN / -0 scores, all three methods."""
+    from aidet_amd import _lib, soft_nms
+    rng = np.random.default_rng(17)
+    _lib.set_tuning(_lib.TUNE_SOFT_NMS_REG, 1)      # (float rows default to the LDS-array kernel: it is the faster one)
+    try:
+        _register_soft_nms_cases(soft_nms, rng)
+    finally:
+        _lib.set_tuning(_lib.TUNE_SOFT_NMS_REG, -1)
+
+
+def _register_soft_nms_cases(soft_nms, rng):
+    for n, canvas, min_score in ((1, 50, 0.01), (2, 10, 0.3), (63, 60, 0.3), (500, 120, 0.3), (513, 200, 0.05), (1024, 200, 0.2),
+                                 (1500, 250, 0.05), (2048, 260, 0.3), (2049, 300, 0.1), (6000, 500, 0.05), (9000, 900, 0.05)):
+        x1, y1 = rng.uniform(0, canvas, n), rng.uniform(0, canvas, n)
+        d = np.stack([x1, y1, x1 + rng.uniform(4, 60, n), y1 + rng.uniform(4, 60, n), rng.uniform(0, 1, n)], 1).astype(np.float32)
+        d[::5, 4] = np.float32(0.5)                       # ties: the lowest POSITION of the current array wins
+        if n > 10:
+            d[3, 4] = np.nan; d[7, 4] = -0.0; d[n // 2, 4] = np.nan
+        for method, thr in (('linear', 0.3), ('gaussian', 0.3), ('linear', 0.0)):
+            nd, inds = soft_nms(d, thr, method=method, sigma=0.5, min_score=min_score)
+            rd, ri = oracle.soft_nms(d, thr, method, 0.5, min_score)
+            assert np.array_equal(inds, ri), (n, method, thr)
+            if method == 'linear':
+                assert np.array_equal(nd, rd, equal_nan=True), (n, method)
+            else:
+                assert np.allclose(nd, rd, rtol=0, atol=1e-6, equal_nan=True), (n, method)
