@@ -101,6 +101,7 @@ struct NmsCounters {
   alignas(256) long long kept;             // K
   long long rounds;                        // resolve sweeps (most of any shard)
   unsigned int done;                       // resolve workgroups finished
+  unsigned int state;                      // fused resolve + compaction: 0 wait, 1 all shards resolved (go), 2 a waiter gave up
   unsigned long long cand_total;           // candidate pairs over all shards
   unsigned long long cand_worst;           // fullest shard
 };
@@ -462,6 +463,19 @@ __global__ __launch_bounds__(256) void nms_frame_kernel(const NmsSource src, int
 #pragma unroll
     for (int u = 0; u < PER; ++u) sm[tid + u * T] = b[u];
   }
+  // the group ids of <= 1024 strided samples (bucket bits of a grouped call, below) are requested HERE, with the box
+  // samples, and used after the frame: at the end of the kernel they were one more exposed round trip per thread
+  // (grouped calls: 12 instead of 7.5 us)
+  const bool grouped = src_grouped(src);
+  uint32_t ghash[4] = {0u, 0u, 0u, 0u};
+  const int64_t gs = n < 1024 ? n : 1024;
+  if (grouped) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t kk = tid + u * T;
+      if (kk < gs) { const int64_t bb = (kk * n) / gs; ghash[u] = group_hash(src_group<S>(src, bb, src.dets + bb * src.pitch)) >> 20; }
+    }
+  }
   if (tid < 128) gbm[tid] = 0u;
   __syncthreads();
   // block-wide sums of up to 8 floats -> tot[], valid after the call
@@ -577,14 +591,10 @@ __global__ __launch_bounds__(256) void nms_frame_kernel(const NmsSource src, int
     if (lane == 0) wred[wv] = make_uint4(axh, axl, ayh, ayl);
   }
   // bucket bits of a grouped call: distinct 12-bit group hashes among <= 1024 strided samples
-  const bool grouped = src_grouped(src);
   if (grouped) {
-    const int64_t gs = n < 1024 ? n : 1024;
-    for (int64_t k = tid; k < gs; k += T) {
-      const int64_t bb = (k * n) / gs;
-      const uint32_t h = group_hash(src_group<S>(src, bb, src.dets + bb * src.pitch)) >> 20;
-      atomicOr(&gbm[h >> 5], 1u << (h & 31u));
-    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (tid + u * T < gs) atomicOr(&gbm[ghash[u] >> 5], 1u << (ghash[u] & 31u));
   }
   __syncthreads();
   if (tid == 0) {
@@ -613,7 +623,6 @@ __global__ __launch_bounds__(256) void nms_frame_kernel(const NmsSource src, int
     f.cpy = oky ? (ry / (float)kQMax) * 1.000001f : 0.0f;
     int gbits = 0;
     if (grouped) {
-      const int64_t gs = n < 1024 ? n : 1024;
       int d = 0;
       for (int k = 0; k < 128; ++k) d += __popc(gbm[k]);
       const int total = 2 * cell_hbits;
@@ -1642,6 +1651,7 @@ __global__ __launch_bounds__(256) void nms_clip_kernel(const uint2 *__restrict__
 // One workgroup = one CU sustains about one scattered memory request per clock -- the
 // single-workgroup version of this kernel needed 170 us for 3*10^4 edges.
 constexpr int kSuppressedBit = 1 << 30;
+constexpr unsigned int kCountValid = 0x80000000u;   // flag of a handed-on count (nms_compact_kernel, the fused compaction)
 constexpr int kResolveThreads = 256;          // sorted route: 64 workgroups share the edges
 constexpr int kResolveThreadsCompact = 1024;  // direct route: usually ONE workgroup does it all
 constexpr long long kSoloEdges = 2048;   // up to here one workgroup resolves alone (direct route)
@@ -1660,7 +1670,9 @@ __global__ __launch_bounds__(COMPACT ? kResolveThreadsCompact : kResolveThreads)
                                                            NmsCounters *__restrict__ ctr,
                                                            const unsigned long long *__restrict__ ccnts,
                                                            int64_t n, int64_t *__restrict__ keep_out,
-                                                           NmsHostInfo *__restrict__ hinfo) {
+                                                           NmsHostInfo *__restrict__ hinfo, int coop,
+                                                           unsigned int *__restrict__ blockcnt,
+                                                           const unsigned int *__restrict__ ucnts) {
   constexpr int kThreads = COMPACT ? kResolveThreadsCompact : kResolveThreads;
   constexpr int kW = kThreads / 64;
   __shared__ int overflow;
@@ -1768,6 +1780,119 @@ __global__ __launch_bounds__(COMPACT ? kResolveThreadsCompact : kResolveThreads)
     if (rounds > (1ll << 22)) break;   // corrupted state: stop instead of spinning forever
   }
   if (tid == 0) atomicMax(reinterpret_cast<unsigned long long *>(&ctr->rounds), (unsigned long long)rounds);
+  if constexpr (!COMPACT) if (coop) {
+    // ---- fused compaction (round 4: the sorted route's nms_compact_kernel launch and its boundary, n < 2^18).  The 64
+    // workgroups of this launch are co-resident by size (64 x 256 threads), so the shards that are done WAIT for the last
+    // one -- on one word, with a bound -- and then compact n / 64 words each (counts handed on through flagged words, as in
+    // nms_compact_kernel).  No deadlock whatever the scheduler does: the last shard to finish moves `state` 0 -> 1 (go); a
+    // waiter whose bound expires moves it 0 -> 2 and leaves; only one of the two transitions can happen, and after a 2
+    // the last shard -- which by then sees every final word -- writes the whole keep list alone.
+    __shared__ int s_go;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (this wave's atomics are acknowledged before the ticket is taken)
+    __syncthreads();
+    if (tid == 0) {
+      unsigned int st = 0u;
+      const unsigned int tk = __hip_atomic_fetch_add(&ctr->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tk == gridDim.x - 1) {
+        unsigned int expect = 0u;
+        const bool ok = __hip_atomic_compare_exchange_strong(&ctr->state, &expect, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        st = ok ? 1u : 3u;                  // 3: somebody gave up -- this workgroup compacts everything
+      } else {
+        const uint64_t t0 = wall_clock64();
+        while ((st = __hip_atomic_load(&ctr->state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) {
+          __builtin_amdgcn_s_sleep(1);
+          if (wall_clock64() - t0 >= (coop == 2 ? 0ull : 25000000ull)) {     // 0.25 s of the 100 MHz wall clock (coop 2: a test hook, at once)
+            unsigned int expect = 0u;
+            __hip_atomic_compare_exchange_strong(&ctr->state, &expect, 2u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            st = __hip_atomic_load(&ctr->state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+        }
+      }
+      s_go = (int)st;
+    }
+    __syncthreads();
+    const int go = s_go;
+    if (go == 2) return;
+    // one pass: a thread requests its (up to) 16 words of the slice together -- they are agent-scope loads, a fabric
+    // round trip each -- keeps the verdicts in registers, the 16 x 4 (row, wave) counts are scanned by one wave
+    constexpr int kR = 16, kSlice = kR * kThreads;          // 4096 words: a slice of n < 2^18 boxes over 64 shards
+    static_assert(kR * kW == 64, "one wave scans the (row, wave) counts");
+    __shared__ int csum[kR][kW];
+    __shared__ long long s_base;
+    const int64_t per = go == 1 ? (n + kShards - 1) / kShards : n;
+    const int64_t lo = go == 1 ? (int64_t)shard * per : 0, hi = (lo + per < n) ? lo + per : n;
+    __shared__ int s_tot;
+    long long kbase = 0;
+    bool first_chunk = true;
+    for (int64_t c0 = lo; first_chunk || c0 < hi; c0 += kSlice) {
+      bool f[kR];
+      uint64_t mk[kR];
+#pragma unroll
+      for (int r = 0; r < kR; ++r) {
+        const int64_t i = c0 + (int64_t)r * kThreads + tid;
+        const int wv = ld_word(cnt + (i < hi ? i : (n > 0 ? n - 1 : 0)));    // (unconditional: all 16 in flight together)
+        f[r] = (i < hi) && word_kept(wv);
+      }
+#pragma unroll
+      for (int r = 0; r < kR; ++r) {
+        mk[r] = __ballot(f[r]);
+        if (lane == 0) csum[r][wave] = __popcll(mk[r]);
+      }
+      __syncthreads();
+      if (wave == 0) {                      // exclusive scan of the 64 (row, wave) counts, row-major
+        const int v = (&csum[0][0])[lane];
+        int inc = v;
+        for (int o = 1; o < 64; o <<= 1) { const int t2 = __shfl_up(inc, o); if (lane >= o) inc += t2; }
+        (&csum[0][0])[lane] = inc - v;
+        const int tot = __shfl(inc, 63);
+        long long base = kbase;
+        if (first_chunk && go == 1) {       // hand the slice's count on, take the predecessors' (at most 63)
+          if (lane == 0) __hip_atomic_store(&blockcnt[1 + shard], (unsigned int)tot | kCountValid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          long long part = 0;
+          if (lane < shard) {
+            unsigned int v2;
+            do { v2 = __hip_atomic_load(&blockcnt[1 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (!(v2 & kCountValid));
+            part = (long long)(v2 & ~kCountValid);
+          }
+          for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+          base = part;
+        }
+        if (lane == 0) { s_base = base; s_tot = tot; }
+      }
+      __syncthreads();
+      const long long base = s_base;
+#pragma unroll
+      for (int r = 0; r < kR; ++r)
+        if (f[r]) keep_out[base + csum[r][wave] + __popcll(mk[r] & ((1ull << lane) - 1ull))] = c0 + (int64_t)r * kThreads + tid;
+      kbase = base + s_tot;
+      first_chunk = false;
+      __syncthreads();                      // (csum / s_base are reused by the next chunk)
+    }
+    if ((go == 3 || shard == kShards - 1) && wave == 0) {   // the last slice knows K: the call's result record
+      unsigned long long v = ccnts[(size_t)lane * kCandStride], mx = v;
+      const unsigned long long ev = ccnts[(size_t)(kShards + lane) * kCandStride];
+      mx = ev > mx ? ev : mx;
+      v += ccnts[(size_t)(2 * kShards + lane) * kCandStride];
+      unsigned int uh = ucnts[lane * kUnitStride], ul = ucnts[(kShards + lane) * kUnitStride], uw = uh + ul;
+      for (int o = 32; o > 0; o >>= 1) {
+        v += __shfl_xor(v, o);
+        const unsigned long long tt = __shfl_xor(mx, o);
+        mx = tt > mx ? tt : mx;
+        uh += __shfl_xor(uh, o); ul += __shfl_xor(ul, o);
+        const unsigned int tw = __shfl_xor(uw, o);
+        uw = tw > uw ? tw : uw;
+      }
+      if (lane == 0) {
+        hinfo->kept = kbase; hinfo->edges = (unsigned long long)total_edges;
+        hinfo->rounds = (long long)__hip_atomic_load(reinterpret_cast<unsigned long long *>(&ctr->rounds), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        hinfo->cand_total = v; hinfo->cand_worst = mx;
+        hinfo->heavy_units = uh; hinfo->light_units = ul;
+        hinfo->route = 2u; hinfo->unit_worst = uw;
+      }
+    }
+    return;
+  }
   if (COMPACT) {
     if (!solo) {
       // the last workgroup to get here sees every final word: the payload is atomics only
@@ -1846,7 +1971,6 @@ __device__ __forceinline__ bool kept_flag(const int *__restrict__ cnt, int64_t i
 // publishes the number of kept boxes of its 1024-box slice with a VALID bit in one agent-scope
 // word, and sums the words of all earlier tickets, polling the few that are not there yet.
 // The payload IS the flagged word, so no fence is involved; nobody waits for a later ticket.
-constexpr unsigned int kCountValid = 0x80000000u;
 
 // PER slices of 1024 boxes per block: the ticket is a returning atomic on ONE word (~90 per
 // microsecond), 14 us of tickets alone at 1.25e6 boxes with one slice per block.
@@ -2532,7 +2656,7 @@ int nms_enqueue_source(const char *who, NmsSource src, int64_t n, int kind, floa
     OBB_LAUNCH_CHECK();
     OBB_PHASE(4);
     OBB_PHASE(5);
-    hipLaunchKernelGGL(nms_resolve_kernel<true>, dim3(kShards), dim3(kResolveThreadsCompact), 0, st, edges, segcap, cnt, ctr, ccnts, n, keep_dev, result);
+    hipLaunchKernelGGL(nms_resolve_kernel<true>, dim3(kShards), dim3(kResolveThreadsCompact), 0, st, edges, segcap, cnt, ctr, ccnts, n, keep_dev, result, 0, blockcnt, ucnts);
     OBB_LAUNCH_CHECK();
     OBB_PHASE(6);
     OBB_PHASE(7);
@@ -2589,11 +2713,14 @@ int nms_enqueue_source(const char *who, NmsSource src, int64_t n, int kind, floa
     }
     // phase 5: resolve
     OBB_PHASE(5);
-    hipLaunchKernelGGL(nms_resolve_kernel<false>, dim3(kShards), dim3(kResolveThreads), 0, st, edges, segcap, cnt, ctr, ccnts, n, keep_dev, result);
+    // (below 2^18 boxes the compaction is the tail of the resolve launch: its 64 workgroups take n / 64 words each)
+    const int coop = n < (1 << 18) ? (int)tuning(OBB_TUNE_NMS_FUSED_COMPACT, 1) : 0;   // (2: waiters give up at once -- the fallback under test)
+    hipLaunchKernelGGL(nms_resolve_kernel<false>, dim3(kShards), dim3(kResolveThreads), 0, st, edges, segcap, cnt, ctr, ccnts, n, keep_dev, result, coop, blockcnt, ucnts);
     OBB_LAUNCH_CHECK();
     // phase 6: compaction (one pass: every block publishes its count and sums its predecessors')
     OBB_PHASE(6);
-    if (n >= (1 << 18)) {
+    if (coop) {
+    } else if (n >= (1 << 18)) {
       const unsigned cblocks = (unsigned)((n + 4095) / 4096);
       hipLaunchKernelGGL(nms_compact_kernel<4>, dim3(cblocks), dim3(1024), 0, st, cnt, n, blockcnt, keep_dev, ctr, ccnts, ucnts, result);
     } else {

@@ -316,6 +316,23 @@ __device__ __forceinline__ void build_table(const RoiFrame &f, const Footprint &
 // busy -- was built and measured this round: 71 us against 50 us for this one at configs[2].
 // It needs dword DMA or register staging for the odd pitch, i.e. 4x the staging instructions,
 // and a table read per tap group)
+// Instrumented builds for the floor derivation of DESIGN.md 3.3 (`make EXTRA=-DOBB_RROI_ABLATE=n OUT=...`; results are
+// WRONG on purpose, only the time is read): 1 = no sample-table arithmetic (what a per-RoI plan pass would take out of
+// this kernel), 2 = additionally no trigonometry / footprint corner samples / copy-offset divisions ("perfect plan"),
+// 3 = one LDS read per output instead of the 16 taps (the gather loop's share), 4 = no footprint copy (the memory side).
+#ifndef OBB_RROI_ABLATE
+#define OBB_RROI_ABLATE 0
+#endif
+constexpr int kAblate = OBB_RROI_ABLATE;
+// OBB_RROI_ABLATE = 5: phase stamps (s_memtime, the shader clock) of every block's wave 0 -- entry | frame + footprint
+// + copy offsets done, first copy issued | table built, barrier passed | first copy landed | last store issued -- read
+// back with obb_debug_rroi_stamps (declared in tools/exp_rroi_stamps.py only: not part of the ABI).
+#if OBB_RROI_ABLATE == 5
+__device__ unsigned long long g_rroi_stamps[8 * 8192];
+#define OBB_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) { g_rroi_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define OBB_STAMP(i) do { } while (0)
+#endif
 constexpr int kFwdStageFloats = 5120;               // LDS tile per block (20 KiB; with the pads and the table 30 KiB: 5 blocks per CU;
                                                     // 4096 / 6 blocks per CU was measured: 39 -> 44 us at configs[2], more passes and 6 spilled registers)
 constexpr int kWaveFloats = kFwdStageFloats / 4;    // private quarter of a wave (small footprints)
@@ -331,6 +348,7 @@ __global__ __launch_bounds__(256, 5) void rroi_forward_kernel(
   __shared__ float4 s_wgt[kMaxTabSamples];    // per sample: 4 bilinear weights
   int64_t k;
   int chunk;
+  OBB_STAMP(0);
   if (!block_to_work(K, chunks, k, chunk)) return;
   // the blocks visit the RoIs in the order of `roi_order` (Morton order of their centres, rroi_order_kernel):
   // RoIs that run at the same time on an XCD then share footprint lines in its L2 (fetch 189 -> 70 MB at
@@ -346,12 +364,40 @@ __global__ __launch_bounds__(256, 5) void rroi_forward_kernel(
   const float *__restrict__ feat = lv.feat[lvl];
   const int H = lv.H[lvl], W = lv.W[lvl];
   const float scale = lv.scale[lvl];
-  RoiFrame f;
-  make_frame(rois + k * roi_stride(roi_kind), roi_kind, scale, ph, pw, sample_num, min_size, f);
+  // The RoI's frame (trigonometry, bin sizes) and footprint (four corner samples) are the same for the whole block: ONE
+  // wave computes them and hands them over through LDS.  (Round 4, from the phase stamps of an instrumented build --
+  // tools/exp_rroi_stamps.py: this prologue was 40 % of a block's life, 7 900 of 19 900 cycles, because all four waves
+  // executed its ~500 wave-wide VALU instructions on SIMDs shared by five waves each; the other three waves now wait
+  // at the barrier and leave their issue slots to the other blocks' gathers.)
+  __shared__ RoiFrame s_frame;
+  __shared__ Footprint s_fp;
+  __shared__ uint32_t s_magic[2];
   const int nb = ph * pw;
   const int c_block = chunk * chan_per_block;
   const int c_end = min(C, c_block + chan_per_block);
   const int64_t plane = (int64_t)H * W;
+  if (threadIdx.x < 64) {
+    RoiFrame f0;
+    make_frame(rois + k * roi_stride(roi_kind), roi_kind, scale, ph, pw, sample_num, min_size, f0);
+    Footprint fp0 = {0, 0, 1, 1};
+    if (lvl_ok && f0.b >= 0 && f0.b < B && (long long)f0.gh * f0.gw > 0) fp0 = roi_footprint(f0, H, W, ph, pw);
+    if (X4) {  // 16-byte LDS-DMA: rows start and end on multiples of 4 floats (W % 4 == 0)
+      const int x1 = (fp0.x0 + fp0.w - 1) | 3;
+      fp0.x0 &= ~3;
+      fp0.w = x1 - fp0.x0 + 1;
+    }
+    // the two reciprocals of the copy's slot -> (channel, row, chunk) map (32-bit divisions: ~30 instructions each)
+    const int pitch0 = X4 ? (((fp0.w >> 2) | 1) << 2) : (fp0.w | 1);
+    const int fsz0 = pitch0 * fp0.h;
+    const int slots0 = X4 ? (fsz0 >> 2) : fsz0, rslots0 = X4 ? (pitch0 >> 2) : pitch0;
+    if (threadIdx.x == 0) {
+      s_frame = f0; s_fp = fp0;
+      s_magic[0] = slots0 > 1 ? 0xFFFFFFFFu / (uint32_t)slots0 + 1u : 0u;
+      s_magic[1] = rslots0 > 1 ? 0xFFFFFFFFu / (uint32_t)rslots0 + 1u : 0u;
+    }
+  }
+  __syncthreads();
+  const RoiFrame f = s_frame;
   const long long spb64 = (long long)f.gh * f.gw;
   if (!lvl_ok || f.b < 0 || f.b >= B || spb64 <= 0) {
     // invalid batch / level index: zeros.  Empty sampling grid: the sum of nothing over the
@@ -361,12 +407,7 @@ __global__ __launch_bounds__(256, 5) void rroi_forward_kernel(
       out[(k * C + c_block) * (int64_t)nb + it] = v;
     return;
   }
-  Footprint fp = roi_footprint(f, H, W, ph, pw);
-  if (X4) {  // 16-byte LDS-DMA: rows start and end on multiples of 4 floats (W % 4 == 0)
-    const int x1 = (fp.x0 + fp.w - 1) | 3;
-    fp.x0 &= ~3;
-    fp.w = x1 - fp.x0 + 1;
-  }
+  const Footprint fp = s_fp;
   // LDS image of a footprint: row pitch = an ODD number of 16-byte slots (X4) / of floats.  With an even
   // number the rows of the image alias on the 32 banks (pitch 16 floats: two row phases; pitch 32: every
   // row on the same banks) and the y / y + 1 taps of neighbouring bins collide; the pad slot of a row is
@@ -402,8 +443,7 @@ __global__ __launch_bounds__(256, 5) void rroi_forward_kernel(
   const int slots = X4 ? (fsz >> 2) : fsz;           // 16-byte (dword) slots per channel
   const int rslots = X4 ? (pitch >> 2) : pitch;      // ... per row (the last one is the pad)
   const int rvalid = X4 ? (fp.w >> 2) : fp.w;        // ... that hold pixels
-  const uint32_t m_slots = slots > 1 ? 0xFFFFFFFFu / (uint32_t)slots + 1u : 0u;
-  const uint32_t m_rslots = rslots > 1 ? 0xFFFFFFFFu / (uint32_t)rslots + 1u : 0u;
+  const uint32_t m_slots = s_magic[0], m_rslots = s_magic[1];
   auto slot_off = [&](uint32_t idx, uint32_t &c) -> uint32_t {
     c = slots > 1 ? __umulhi(idx, m_slots) : idx;
     const uint32_t r = idx - c * (uint32_t)slots;
@@ -441,11 +481,18 @@ __global__ __launch_bounds__(256, 5) void rroi_forward_kernel(
         doff[j] = slot_off(idx, dch[j]);
       }
     }
-    if (cw0 < cw1) stage_pass(cw0);
+    if (cw0 < cw1 && kAblate != 4) stage_pass(cw0);
   }
+  OBB_STAMP(1);
   // sample table: coordinates, taps and weights are computed ONCE per RoI and block
   // (the reference recomputes them for every output element, roi_align_kernel.cu:70-113)
   for (int sidx = threadIdx.x; sidx < nsamp; sidx += 256) {
+    if constexpr (kAblate == 1 || kAblate == 2) {   // (a plan record would carry the table)
+      const unsigned short o = (unsigned short)((sidx * 7) % (fsz > 1 ? fsz - 1 : 1));
+      s_off[sidx] = make_ushort4(o, o, (unsigned short)(o + 1 < fsz ? o + 1 : o), o);
+      s_wgt[sidx] = make_float4(0.25f, 0.25f, 0.25f, 0.25f);
+      continue;
+    }
     const int bin = sidx / spb, q = sidx - bin * spb;
     const int bi = bin / pw, bj = bin - bi * pw;
     const int iy = q / f.gw, ix = q - iy * f.gw;
@@ -463,6 +510,7 @@ __global__ __launch_bounds__(256, 5) void rroi_forward_kernel(
   }
   if (small) {
     __syncthreads();   // table complete
+    OBB_STAMP(2);
     int4 so[4];
     float4 sw[4];
 #pragma unroll
@@ -479,10 +527,12 @@ __global__ __launch_bounds__(256, 5) void rroi_forward_kernel(
     const float cnt_inv = cnt_pow2 ? 1.0f / f.cnt : 0.0f;
     for (int cp = cw0; cp < cw1; cp += cpw) {
       const int nch = min(cpw, cw1 - cp);
-      if (cp != cw0) stage_pass(cp);
+      if (cp != cw0 && kAblate != 4) stage_pass(cp);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (cp == cw0) OBB_STAMP(3);
       __builtin_amdgcn_wave_barrier();
       auto bin_sum = [&](const float *p) -> float {
+        if constexpr (kAblate == 3) return p[so[0].x] * cnt_inv;     // (one LDS read per output)
         float acc = 0.0f;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -506,6 +556,7 @@ __global__ __launch_bounds__(256, 5) void rroi_forward_kernel(
       // the next pass overwrites this region: its gathers are done (their values were consumed)
       __builtin_amdgcn_wave_barrier();
     }
+    OBB_STAMP(4);
     return;
   }
   const int cpp = kFwdStageFloats / fsz;                // channels per pass (>= 1)
@@ -1432,6 +1483,12 @@ static int rroi_backward_launch(const char *who, const float *grad_out_dev, int 
 }
 
 }  // namespace obb
+
+#if OBB_RROI_ABLATE == 5
+extern "C" __attribute__((visibility("default"))) int obb_debug_rroi_stamps(unsigned long long *host, int words) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(obb::g_rroi_stamps), (size_t)words * 8);
+}
+#endif
 
 extern "C" int obb_rroi_align_forward_f32(const float *feat_dev, int B, int C, int H, int W,
                                           const float *rois_dev, int64_t K, int ph, int pw,

@@ -26,6 +26,7 @@ op against values captured from the reference (tests/golden/detector_parts.npz).
 """
 import time
 
+import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -164,6 +165,15 @@ class SharedFCHead(nn.Module):
         return self.fc_cls(x), self.fc_reg(x)
 
 
+def _same_extractor(a, b):
+    """two SingleRoIExtractors that pool identically (same layer type and settings on the same strides)"""
+    def sig(e):
+        return (type(e), tuple(e.featmap_strides), e.finest_scale, e.out_channels,
+                tuple((type(l), tuple(np.atleast_1d(l.out_size)), float(l.spatial_scale), int(l.sample_num),
+                       bool(getattr(l, 'aligned', False)), bool(getattr(l, 'use_torchvision', False))) for l in e.roi_layers))
+    return sig(a) == sig(b)
+
+
 class ThetaOBBRCNN(nn.Module):
     """``RBBoxRCNN`` (rbbox_cnn.py) of the theta-OBB config, inference only.
 
@@ -186,6 +196,11 @@ class ThetaOBBRCNN(nn.Module):
         self.bbox_roi_extractor = SingleRoIExtractor(roi, 256, [4, 8, 16, 32])
         self.bbox_head = SharedFCHead(4)
         self.rbbox_roi_extractor = SingleRoIExtractor(roi, 256, [4, 8, 16, 32])
+        # Both branches pool the SAME RoIs from the same maps (test_mixins.py:281 and :352-380 call their extractors one
+        # after the other); an extractor has no weights, so when the two are configured alike the second call would
+        # recompute the first one's output bit for bit: at inference it is pooled once (VERDICT r3 next #3 iv: -0.35 ms
+        # per tile).  `pool_once=False` keeps the reference's two calls.
+        self.pool_once = True
         self.rbbox_head = SharedFCHead(5)
         self.test_cfg = test_cfg or TEST_CFG
         self.rotated_nms = rotated_nms
@@ -249,7 +264,7 @@ class ThetaOBBRCNN(nn.Module):
         self._tick('bbox_head_fc')
         rcnn = self.test_cfg['rcnn']
         fused = (self.fused and rcnn['nms'].get('type', 'nms') == 'nms' and self.test_cfg['rbbox'].get('encode', 'thetaobb') == 'thetaobb'
-                 and head_fusable(rois, cls_score, bbox_pred, rcnn['max_per_img']))
+                 and head_fusable(rois, cls_score, bbox_pred, rcnn['max_per_img'], scale_factor))
         selection = cls_inds = keep_inds = None
         if fused:
             det_bboxes, det_labels, selection = detect_horizontal_fused(
@@ -257,14 +272,16 @@ class ThetaOBBRCNN(nn.Module):
         else:
             scores = F.softmax(cls_score, dim=1)
             bboxes = delta2bbox(rois[:, 1:], bbox_pred, (0., 0., 0., 0.), self.bbox_target_stds, img_shape)
-            if rescale:
-                bboxes = bboxes / scale_factor
+            if rescale:     # (a scalar, or the 4-element array of keep_ratio=False: bbox_head.py:160-166)
+                bboxes = bboxes / (scale_factor if isinstance(scale_factor, (int, float)) else
+                                   torch.as_tensor(np.asarray(scale_factor), dtype=bboxes.dtype, device=bboxes.device))
             det_bboxes, det_labels, cls_inds, keep_inds = multiclass_nms_with_index(
                 bboxes, scores, rcnn['score_thr'], rcnn['nms'], rcnn['max_per_img'])
         self._tick('bbox_decode_nms')
         bbox_results = bbox2result(det_bboxes, det_labels, self.bbox_head.num_classes)
         # ---- rotated branch (test_mixins.py:352-380): its own extractor and trunk
-        roi_feats = self.rbbox_roi_extractor(x[:4], rois)
+        if not (self.pool_once and not torch.is_grad_enabled() and _same_extractor(self.bbox_roi_extractor, self.rbbox_roi_extractor)):
+            roi_feats = self.rbbox_roi_extractor(x[:4], rois)
         self._tick('roi_align_rbbox')
         cls_score, rbbox_pred = self.rbbox_head(roi_feats)
         self._tick('rbbox_head_fc')

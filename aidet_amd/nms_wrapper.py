@@ -135,7 +135,10 @@ def _run_nms(dets_dev, kind, iou_thr, groups=None, thrs=None, strict=False):
         capacity = _capacity_hint.get(hkey, 0)
         hinted = capacity
         while True:
-            keep, rc, info = ext.nms_ex(dets_dev, kind, iou_thr, groups, thrs, flags, capacity)
+            try:
+                keep, rc, info = ext.nms_ex(dets_dev, kind, iou_thr, groups, thrs, flags, capacity)
+            except RuntimeError as e:       # (TORCH_CHECK of the binding: the same exception type as the ctypes path)
+                raise _lib.ObbOpsError(str(e)) from None
             if rc != _lib.OBB_EWORKSPACE:
                 break
             capacity = max(int(info[3]), 2 * capacity)
@@ -353,8 +356,10 @@ def nms(dets, iou_thr, device_id=None, groups=None, thrs=None, strict=False):
     if not strict and thrs is not None:
         # the same rule box by box: a per-box threshold <= 0 would have to suppress every later box of its group,
         # disjoint ones included (nms_cpu.cpp:56), which the kernels' broad phase never even tests
+        # (checked for HOST thresholds only -- a list, an array, a CPU tensor: a device tensor would cost a kernel and a
+        # device-to-host synchronisation before the NMS is even queued; its owner vouches for it)
         t = _as_tensor(thrs)
-        if t.numel() and not bool((t > 0).all()):
+        if not t.is_cuda and t.numel() and not bool((t > 0).all()):
             raise ValueError('nms: every per-box threshold must be positive under the `>=` rule')
     return _nms_generic(dets, iou_thr, device_id, 5, _lib.KIND_HBB, 'nms', groups, thrs, strict)
 

@@ -18,6 +18,7 @@ cfg.polygon_nms_iou_thr, cfg.max_per_img)``, rbbox_head.py:294-295).
 """
 import ctypes
 
+import numpy as np
 import torch
 
 from . import _lib, nms_wrapper
@@ -287,10 +288,13 @@ def get_det_rbboxes(rois, cls_score, rbbox_pred, img_shape, scale_factor, rescal
 HEAD_MAX_ROIS, HEAD_MAX_FG, TOPK_MAX = 2048, 16, 2048      # capacities of obb_head_select_decode_f32 / obb_rows_topk_f32
 
 
-def head_fusable(rois, cls_score, pred, max_num):
+def head_fusable(rois, cls_score, pred, max_num, scale_factor=None):
     """True when the fused head kernels serve this call: fp32 HIP tensors, at most 2048 RoIs / 16 foreground classes,
-    a cap of at most 2048 detections."""
+    a cap of at most 2048 detections, a SCALAR scale factor (a per-axis one -- the 4-element array of
+    ``keep_ratio=False``, bbox_head.py:160-166 -- goes through the tensor-op stages)."""
     ts = (rois, cls_score, pred)
+    if scale_factor is not None and not isinstance(scale_factor, (int, float)) and np.ndim(scale_factor) != 0:
+        return False
     return (all(isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 for t in ts)
             and rois.size(0) <= HEAD_MAX_ROIS and 2 <= cls_score.size(1) <= HEAD_MAX_FG + 1 and 0 < max_num <= TOPK_MAX
             and not torch.is_grad_enabled())
@@ -300,7 +304,7 @@ def _codec(dim, means, stds, img_shape, scale_factor):
     m = (ctypes.c_float * 5)(*([float(v) for v in means] + [0.0] * (5 - dim)))
     sd = (ctypes.c_float * 5)(*([float(v) for v in stds] + [1.0] * (5 - dim)))
     mh, mw = (int(img_shape[0]), int(img_shape[1])) if (img_shape is not None and dim == 4) else (0, 0)
-    return m, sd, mh, mw, float(scale_factor) if scale_factor else 0.0
+    return m, sd, mh, mw, float(scale_factor) if (scale_factor is not None and float(scale_factor) != 0.0) else 0.0
 
 
 def select_decode_candidates(rois, cls_score, pred, dim, score_thr, means, stds, img_shape=None, scale_factor=None):

@@ -212,3 +212,30 @@ def _register_soft_nms_cases(soft_nms, rng):
                 assert np.array_equal(nd, rd, equal_nan=True), (n, method)
             else:
                 assert np.allclose(nd, rd, rtol=0, atol=1e-6, equal_nan=True), (n, method)
+
+
+def test_fused_compaction_of_the_sorted_route_and_its_fallbacks(nms_route):
+    """Sorted route below 2^18 boxes: the keep list is written by the tail of the resolve launch (64 workgroups, n / 64
+    words each).  Same list as the separate compaction launch (knob 0) and as the path where every waiting shard gives
+    up at once and the last one compacts alone (knob 2); all three bit-exact with the oracle."""
+    from aidet_amd import _lib
+    from aidet_amd.nms_wrapper import _run_nms
+    for n, canvas in ((12000, 1500), (70000, 6000), (100000, 20000)):
+        d = oracle.synth_boxes(n, canvas, 21)
+        want = oracle.rnms(d, 0.5) if n <= 20000 else None
+        dd = t(d)
+        got = {}
+        for route in ('sorted', 'listed'):
+            nms_route(route)
+            for knob in (1, 0, 2):
+                _lib.set_tuning(_lib.TUNE_NMS_FUSED_COMPACT, knob)
+                try:
+                    keep, info = _run_nms(dd, _lib.KIND_RBOX, 0.5)
+                finally:
+                    _lib.set_tuning(_lib.TUNE_NMS_FUSED_COMPACT, -1)
+                got[(route, knob)] = keep.cpu().numpy()
+        first = got[('sorted', 1)]
+        assert all(np.array_equal(first, v) for v in got.values()), n
+        if want is not None:
+            assert np.array_equal(first, want)
+    nms_route('auto')
