@@ -143,10 +143,31 @@ __global__ __launch_bounds__(256) void route_count_kernel(const float *__restric
 }
 
 // exclusive scan of a[0, m) in place by ONE workgroup (m is a few 10^4: bucket x block counts, key x source counts)
+constexpr int kScanLds = 16384;         // counts that are scanned in LDS (64 KiB): coalesced loads and stores
 __device__ __forceinline__ int block_scan_inplace(int *__restrict__ a, int64_t m, int *part /* LDS, kScanThreads / 64 + 1 */) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t chunk = (m + kScanThreads - 1) / kScanThreads;
   const int64_t lo = tid * chunk, hi = lo + chunk < m ? lo + chunk : m;
+  if (m <= kScanLds) {
+    // (the 12 808 (patch, source) counts of an 8-rank pass took 11 us with every thread walking its 13 words in global
+    // memory twice -- dependent round trips; staged: one coalesced load and one coalesced store per word)
+    __shared__ int buf[kScanLds];
+    for (int64_t j = tid; j < m; j += kScanThreads) buf[j] = a[j];
+    __syncthreads();
+    int sum = 0;
+    for (int64_t j = lo; j < hi; ++j) sum += buf[j];
+    int inc = sum;
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o); if (lane >= o) inc += v; }
+    if (lane == 63) part[wave] = inc;
+    __syncthreads();
+    int pre = inc - sum, total = 0;
+    for (int w = 0; w < kScanThreads / 64; ++w) { const int v = part[w]; pre += (w < wave) ? v : 0; total += v; }
+    for (int64_t j = lo; j < hi; ++j) { const int v = buf[j]; buf[j] = pre; pre += v; }
+    __syncthreads();
+    for (int64_t j = tid; j < m; j += kScanThreads) a[j] = buf[j];
+    __syncthreads();
+    return total;
+  }
   int sum = 0;
   for (int64_t j = lo; j < hi; ++j) sum += a[j];
   int inc = sum;

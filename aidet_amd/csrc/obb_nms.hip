@@ -2413,12 +2413,47 @@ static void nms_split(unsigned long long entries, unsigned long long unit_worst,
   segcap = (entries - ucap) / 2 / kShards;
 }
 
+// ---- capacity hints (round 4: moved here from the Python wrapper, so that C-ABI callers get them too) ---------------
+// A call whose pair lists overflow the default capacity (64 n pairs) is repeated with the capacity the library names --
+// twice the time.  A caller that does this every time (the RPN of a dense tile: 8768 boxes, 5.7e5 overlapping pairs)
+// should start there: the calling THREAD remembers, per (kind, size class of n), the capacity its last overflowing call
+// needed; obb_nms_workspace_bytes(n, kind, 0) sizes the default workspace with it, and a call that used less than an
+// eighth of a hinted capacity drops the hint again.  Thread-local, no locks; forgetting a hint costs one repeated call.
+struct CapHint { int kind, bits; unsigned long long cap; };
+constexpr int kCapHints = 16;
+static thread_local CapHint g_cap_hints[kCapHints] = {};
+static int size_class(int64_t n) { int b = 0; while (n > 0) { ++b; n >>= 1; } return b; }
+static unsigned long long cap_hint_get(int64_t n, int kind) {
+  const int bits = size_class(n);
+  for (const CapHint &h : g_cap_hints) if (h.cap && h.kind == kind && h.bits == bits) return h.cap;
+  return 0ull;
+}
+static void cap_hint_put(int64_t n, int kind, unsigned long long cap) {
+  const int bits = size_class(n);
+  CapHint *slot = nullptr;
+  for (CapHint &h : g_cap_hints) if (h.cap && h.kind == kind && h.bits == bits) { slot = &h; break; }
+  if (!slot) for (CapHint &h : g_cap_hints) if (!h.cap) { slot = &h; break; }
+  if (!slot) slot = &g_cap_hints[(unsigned)(bits + 7 * kind) % kCapHints];     // table full: replace one
+  slot->kind = kind; slot->bits = bits; slot->cap = cap;
+}
+// after a call's verdict: rc == OBB_EWORKSPACE -> remember `need`; a fitting call that used `used` pairs of a hinted capacity
+static void cap_hint_note(int64_t n, int kind, int rc, unsigned long long need, unsigned long long used) {
+  if (rc == OBB_EWORKSPACE) { if (need) cap_hint_put(n, kind, need); return; }
+  const unsigned long long h = cap_hint_get(n, kind);
+  if (rc == OBB_OK && h && 8ull * used < h) cap_hint_put(n, kind, 0ull);
+}
+
 }  // namespace obb
 
 extern "C" size_t obb_nms_workspace_bytes(int64_t n, int kind, int64_t edge_capacity) {
-  (void)kind;
   obb::NmsLayout L;
   if (n < 0) return 0;
+  if (edge_capacity <= 0) {        // the default capacity, or what this thread's last overflowing call of the size class needed
+    const unsigned long long h = obb::cap_hint_get(n, kind);
+    long long def = 64 * n;
+    if (def < (1 << 18)) def = 1 << 18;
+    edge_capacity = h > (unsigned long long)def ? (int64_t)h : 0;
+  }
   if (obb::nms_layout(n, edge_capacity, L) != OBB_OK) return 0;
   return L.total;
 }
@@ -2805,7 +2840,11 @@ extern "C" int obb_nms_ex_f32(const float *dets_dev, int64_t n, int kind, float 
     prof.have = true;
   }
   static_assert(kShards == 64, "the counter folds use one wave");
-  return nms_verdict(h, q, info_host);
+  int64_t info_local[4];
+  int64_t *info = info_host ? info_host : info_local;
+  rc = nms_verdict(h, q, info);
+  cap_hint_note(n, kind, rc, rc == OBB_EWORKSPACE ? (unsigned long long)info[3] : 0ull, h.cand_total > h.edges ? h.cand_total : h.edges);
+  return rc;
 }
 
 extern "C" int obb_nms_hbb_f64(const double *dets_dev, int64_t n, float iou_thr, const int32_t *group_dev,
@@ -2828,7 +2867,11 @@ extern "C" int obb_nms_hbb_f64(const double *dets_dev, int64_t n, float iou_thr,
   if (rc != OBB_OK) return rc;
   OBB_HIP_TRY(hipStreamSynchronize(st));
   const NmsHostInfo h = *hinfo;
-  return nms_verdict(h, q, info_host);
+  int64_t info_local[4];
+  int64_t *info = info_host ? info_host : info_local;
+  rc = nms_verdict(h, q, info);
+  cap_hint_note(n, OBB_KIND_HBB, rc, rc == OBB_EWORKSPACE ? (unsigned long long)info[3] : 0ull, h.cand_total > h.edges ? h.cand_total : h.edges);
+  return rc;
 }
 
 extern "C" int obb_nms_async_f32(const float *dets_dev, int64_t n, int kind, float iou_thr,
@@ -2861,7 +2904,12 @@ extern "C" int obb_nms_async_result(const void *result_host, int64_t n, size_t w
   NmsEnqueued q;
   int rc = nms_capacities(n, workspace_bytes, L, q);
   if (rc != OBB_OK) return rc;
-  return nms_verdict(h, q, info_host);
+  rc = nms_verdict(h, q, info_host);
+  // (the record does not say which kind it was: rotated boxes -- what the async form is used for in the tiled phases and
+  // the detector's queued calls; a hint under the wrong kind only costs one repeated call)
+  cap_hint_note(n, OBB_KIND_RBOX, rc, rc == OBB_EWORKSPACE ? (unsigned long long)info_host[3] : 0ull,
+                h.cand_total > h.edges ? h.cand_total : h.edges);
+  return rc;
 }
 
 extern "C" int obb_nms_profile_enable(int on) {

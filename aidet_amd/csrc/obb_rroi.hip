@@ -318,8 +318,8 @@ __device__ __forceinline__ void build_table(const RoiFrame &f, const Footprint &
 // and a table read per tap group)
 // Instrumented builds for the floor derivation of DESIGN.md 3.3 (`make EXTRA=-DOBB_RROI_ABLATE=n OUT=...`; results are
 // WRONG on purpose, only the time is read): 1 = no sample-table arithmetic (what a per-RoI plan pass would take out of
-// this kernel), 2 = additionally no trigonometry / footprint corner samples / copy-offset divisions ("perfect plan"),
-// 3 = one LDS read per output instead of the 16 taps (the gather loop's share), 4 = no footprint copy (the memory side).
+// this kernel), 3 = one LDS read per output instead of the 16 taps (the gather loop's share), 4 = no footprint copy (the
+// memory side), 5 = phase stamps (below).
 #ifndef OBB_RROI_ABLATE
 #define OBB_RROI_ABLATE 0
 #endif
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(256, 5) void rroi_forward_kernel(
   // sample table: coordinates, taps and weights are computed ONCE per RoI and block
   // (the reference recomputes them for every output element, roi_align_kernel.cu:70-113)
   for (int sidx = threadIdx.x; sidx < nsamp; sidx += 256) {
-    if constexpr (kAblate == 1 || kAblate == 2) {   // (a plan record would carry the table)
+    if constexpr (kAblate == 1) {   // (a plan record would carry the table)
       const unsigned short o = (unsigned short)((sidx * 7) % (fsz > 1 ? fsz - 1 : 1));
       s_off[sidx] = make_ushort4(o, o, (unsigned short)(o + 1 < fsz ? o + 1 : o), o);
       s_wgt[sidx] = make_float4(0.25f, 0.25f, 0.25f, 0.25f);

@@ -39,7 +39,8 @@ SOFT_NMS_F64_MAX = 4096     # obb_soft_nms_f64 keeps its state in registers
 
 def _workspace(L, dev, stream, n, kind, capacity):
     key = (n, kind, capacity)
-    nbytes = _ws_bytes.get(key)
+    # (capacity 0 = the library's default, which follows the calling thread's capacity hints: never cached here)
+    nbytes = _ws_bytes.get(key) if capacity else None
     if nbytes is None:
         nbytes = L.obb_nms_workspace_bytes(n, kind, capacity)
         if nbytes == 0:
@@ -97,7 +98,6 @@ class _OnDevice(object):
 _ext = False     # obbops_torch (the ATen-level binding): None = not built, False = not tried yet
 
 
-_capacity_hint = {}     # (kind, bit length of n, grouped) -> pair capacity that the last overflowing call needed
 
 
 def _fast_ext():
@@ -129,11 +129,10 @@ def _run_nms(dets_dev, kind, iou_thr, groups=None, thrs=None, strict=False):
         flags = _lib.NMS_STRICT if strict else 0
         # A call whose pair lists overflow is repeated with the capacity the library asks for -- twice the time.  A
         # caller that does this every time (the RPN of a dense scene: 8768 boxes, 5.7e5 overlapping pairs, 0.32 instead
-        # of 0.19 ms per call) gets that capacity from the start next time: the hint lives per (kind, size class)
-        # and is dropped again when the scenes turn out 8x sparser than it.
-        hkey = (kind, int(n).bit_length(), groups is not None)
-        capacity = _capacity_hint.get(hkey, 0)
-        hinted = capacity
+        # of 0.19 ms per call) gets that capacity from the start next time: the LIBRARY keeps the hint (per calling
+        # thread, kind and size class; obb_nms_workspace_bytes(n, kind, 0) follows it), so capacity 0 here means
+        # "the default, or what the last overflowing call of this size class needed".
+        capacity = 0
         while True:
             try:
                 keep, rc, info = ext.nms_ex(dets_dev, kind, iou_thr, groups, thrs, flags, capacity)
@@ -148,10 +147,6 @@ def _run_nms(dets_dev, kind, iou_thr, groups=None, thrs=None, strict=False):
                     'NMS on %d boxes needs a %.1f GiB pair workspace (capacity %d pairs): more than '
                     'nms_wrapper.MAX_WORKSPACE_BYTES; the scene is almost all mutual overlaps' %
                     (n, nbytes / 2.0 ** 30, capacity))
-        if capacity != hinted:
-            _capacity_hint[hkey] = capacity
-        elif hinted and 8 * max(int(info[3]), int(info[1])) < hinted:
-            _capacity_hint.pop(hkey, None)
         return keep, (info[1], info[2], info[3])
     L = _lib.lib()
     keep = torch.empty(n, dtype=torch.int64, device=dev)

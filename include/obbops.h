@@ -111,6 +111,11 @@ OBB_API int obb_hbb_overlaps_f64(const double *a_dev, int64_t m, const double *b
  *              call again with it (loop: which of the library's 64 internal pair lists a
  *              pair lands in depends on scheduling, so a retry can ask for more once
  *              again; every request at least doubles and 64 * n*(n-1)/2 always suffices).
+ *              Capacity hints: the calling THREAD remembers, per kind and size class of n (its bit length), the
+ *              capacity its last overflowing call needed; obb_nms_workspace_bytes(n, kind, 0) then sizes the default
+ *              workspace for it, so a caller that always asks for the default repeats a dense scene's call once, not
+ *              every time.  A fitting call that used less than 1/8 of a hinted capacity drops the hint.  (The only
+ *              mutable state of the library besides the error string and the profile: thread-local, no locks.)
  * Synchronises `stream` before returning.
  * ------------------------------------------------------------------------- */
 OBB_API size_t obb_nms_workspace_bytes(int64_t n, int kind, int64_t pair_capacity);

@@ -239,3 +239,37 @@ def test_fused_compaction_of_the_sorted_route_and_its_fallbacks(nms_route):
         if want is not None:
             assert np.array_equal(first, want)
     nms_route('auto')
+
+
+def test_library_side_capacity_hint_serves_c_abi_callers():
+    """the capacity hint lives in the library (per calling thread, kind, size class),
+    not in the Python wrapper.  A C-ABI caller that always sizes its workspace with obb_nms_workspace_bytes(n, kind, 0):
+    the first call of a scene of mutual duplicates overflows and names a capacity, the NEXT default-sized workspace is
+    large enough at once, and a sparse scene of the same size class drops the hint again."""
+    from aidet_amd import _lib
+    L = _lib.lib()
+    n = 3000
+    rng = np.random.default_rng(1)
+    dense = np.tile(np.array([[500.0, 400.0, 60.0, 30.0, -0.4, 0.0]], np.float32), (n, 1))
+    dense[:, 5] = (rng.permutation(n) + 0.5) / n
+    sparse = oracle.synth_boxes(n, 20000, 3)
+    keep = torch.empty(n, dtype=torch.int64, device=dev())
+    info = (ctypes.c_int64 * 4)()
+    st = _lib.current_stream_handle(dev())
+
+    def call(d):
+        nbytes = int(L.obb_nms_workspace_bytes(n, _lib.KIND_RBOX, 0))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev())
+        rc = L.obb_nms_f32(d.data_ptr(), n, _lib.KIND_RBOX, 0.5, keep.data_ptr(), info, ws.data_ptr(), nbytes, st)
+        return rc, nbytes, int(info[0]), int(info[3])
+    call(t(sparse))                                  # (whatever hint an earlier test left: a sparse call drops it)
+    rc0, b0, _, _ = call(t(sparse))
+    assert rc0 == 0
+    rc1, b1, _, need = call(t(dense))
+    assert rc1 == _lib.OBB_EWORKSPACE and b1 == b0 and need > 64 * n
+    rc2, b2, k2, _ = call(t(dense))                  # the default workspace now follows the hint
+    assert rc2 == 0 and b2 > b1 and k2 == 1
+    rc3, b3, k3, _ = call(t(sparse))                 # ... and is given up by a call that does not need it
+    assert rc3 == 0 and b3 == b2 and k3 == len(oracle.rnms(sparse, 0.5))
+    rc4, b4, _, _ = call(t(sparse))
+    assert rc4 == 0 and b4 == b0

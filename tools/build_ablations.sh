@@ -1,0 +1,14 @@
+#!/bin/bash
+# Instrumented builds of the library for tools/exp_rroi_ablate.py / exp_rroi_stamps.py (OBB_RROI_ABLATE = 1..5 in
+# aidet_amd/csrc/obb_rroi.hip): aidet_amd/lib/libobbops_abl<n>.so.  Built in scratch copies of csrc/ (the objects of
+# the product build are left alone).  The libraries are git-ignored like every *.so and travel with gpurun snapshots.
+set -e
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+for a in ${1:-1 3 4 5}; do
+  d=$(mktemp -d /tmp/obb_abl${a}_XXXX)
+  cp $ROOT/aidet_amd/csrc/*.hip $ROOT/aidet_amd/csrc/*.h $ROOT/aidet_amd/csrc/Makefile $d/
+  sed -i "s#\.\./\.\./include#$ROOT/include#g" $d/Makefile $d/obb_common.h
+  make -s -C $d -j8 EXTRA=-DOBB_RROI_ABLATE=$a OUT=$ROOT/aidet_amd/lib/libobbops_abl$a.so
+  rm -rf $d
+done
+ls -la $ROOT/aidet_amd/lib/libobbops_abl*.so

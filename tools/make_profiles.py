@@ -7,10 +7,10 @@ import json
 import os
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r03'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r04'
 src = 'gpurun_out/collect'
 dst = 'profiles'
-WORKLOAD = {'nms': 'nms_100000_20000', 'iou_sparse': 'iou_sparse', 'iou_dense': 'iou_dense',
+WORKLOAD = {'nms': 'nms_100000_20000', 'iou_sparse': 'iou_sparse', 'iou_dense': 'iou_dense', 'iou_allclip': 'iou_allclip',
             'rroi_fwd': 'rroi_fwd', 'rroi_bwd': 'rroi_bwd', 'rroi_bwd_scatter': 'rroi_bwd_scatter', 'roi_fwd': 'roi_fwd'}
 OURS = ('nms_', 'overlaps_', 'rroi_', 'soft_nms', 'rbox_to_poly')
 
@@ -114,12 +114,14 @@ for name, alg in (('iou_sparse', 20 * 2 * 16384 + 4 * 16384 ** 2), ('iou_dense',
     if ks:
         print('%s: algorithmic %.1f MB / %.1f us = %.0f GB/s = %.3f of 8 TB/s' % (
             name, alg / 1e6, ks[0]['avg_us'], alg / ks[0]['avg_us'] / 1e3, alg / ks[0]['avg_us'] / 1e3 / 8000))
-for name in ('multi_rank_sim.txt', 'roi_backward.txt', 'detect.json'):
+for name in ('multi_rank_sim.txt', 'multi_rank_sim_large.txt', 'roi_backward.txt', 'detect.json', 'soft_nms.txt', 'rroi_ablate.txt', 'rroi_stamps.txt'):
     if os.path.exists(os.path.join(src, name)):
         with open(os.path.join(src, name)) as f, open('%s/%s_%s' % (dst, tag, name), 'w') as g:
             g.write(''.join(l for l in f if 'amdgpu.ids' not in l))
 if os.path.isdir(src + '/trace_cfg4') and find(src + '/trace_cfg4', 'kernel_stats.csv'):
     copy_stats(src + '/trace_cfg4', '%s/%s_kernel_stats_cfg4.csv' % (dst, tag))
+if os.path.isdir(src + '/trace_sim8') and find(src + '/trace_sim8', 'kernel_stats.csv'):
+    copy_stats(src + '/trace_sim8', '%s/%s_kernel_stats_cfg5_rank0_of_8.csv' % (dst, tag))
 rk = bench.get('roofline_kernels', {}).get('kernels', [])
 for r in rk:
     if r['kernel'].startswith('rroi_'):
