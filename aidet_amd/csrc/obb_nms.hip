@@ -473,7 +473,15 @@ __global__ __launch_bounds__(256) void nms_frame_kernel(const NmsSource src, int
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int64_t kk = tid + u * T;
-      if (kk < gs) { const int64_t bb = (kk * n) / gs; ghash[u] = group_hash(src_group<S>(src, bb, src.dets + bb * src.pitch)) >> 20; }
+      // (sample kk sits in the kk-th of gs equal strides, at a position inside it that cycles with period 13 -- not a fixed
+      // stride, which a class-major or patch-major input may resonate with; no 64-bit division: four of them per thread
+      // were ~1.5 us of this one-block kernel)
+      if (kk < gs) {
+        const uint32_t gstride = (uint32_t)n / (uint32_t)gs;             // (n <= 2^24: 32-bit arithmetic)
+        int64_t bb = (int64_t)((uint32_t)kk * gstride + (((uint32_t)kk % 13u) * gstride) / 13u);
+        bb = bb < n ? bb : n - 1;
+        ghash[u] = group_hash(src_group<S>(src, bb, src.dets + bb * src.pitch)) >> 20;
+      }
     }
   }
   if (tid < 128) gbm[tid] = 0u;
@@ -597,6 +605,19 @@ __global__ __launch_bounds__(256) void nms_frame_kernel(const NmsSource src, int
       if (tid + u * T < gs) atomicOr(&gbm[ghash[u] >> 5], 1u << (ghash[u] & 31u));
   }
   __syncthreads();
+  // distinct 12-bit group hashes among the samples: 128 words counted by two waves (one thread walking them was 128
+  // dependent LDS reads, 3-4 us of a grouped call's frame kernel)
+  __shared__ int s_distinct;
+  if (grouped) {
+    if (tid == 0) s_distinct = 0;
+    __syncthreads();
+    if (tid < 128) {
+      int c = __popc(gbm[tid]);
+      for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+      if (lane == 0) atomicAdd(&s_distinct, c);
+    }
+    __syncthreads();
+  }
   if (tid == 0) {
     uint4 m = bbox_all;
     if (trim) {
@@ -623,8 +644,7 @@ __global__ __launch_bounds__(256) void nms_frame_kernel(const NmsSource src, int
     f.cpy = oky ? (ry / (float)kQMax) * 1.000001f : 0.0f;
     int gbits = 0;
     if (grouped) {
-      int d = 0;
-      for (int k = 0; k < 128; ++k) d += __popc(gbm[k]);
+      const int d = s_distinct;
       const int total = 2 * cell_hbits;
       int want = 0;
       while ((1 << want) < d) ++want;
@@ -695,8 +715,31 @@ __global__ __launch_bounds__(256) void nms_prepq_kernel(const NmsSource src, int
     }
     qb[b] = o;
     ckey[b] = mk;
-    // the count of the cell AND this box's rank inside it (one round of scattered atomics per call)
-    crank[b] = atomicAdd(&hist[mk], 1u);
+    // the count of the cell AND this box's rank inside it (one round of scattered atomics per call).
+    // Grouped calls: the rows of a tiled pass arrive in patch order, so the lanes of a wave share cells, and the merged
+    // rows put ~40 boxes into every used cell (30 groups hash into 30 of 128 buckets): returning atomics on ONE word
+    // serialise at the memory side (26 us for 156k merged rows against 11 us for as many per-patch rows,
+    // tools/exp_merge_prepq.py).  The lanes of a wave that share a cell send ONE atomic (one round per distinct cell
+    // in the wave) and rank themselves behind its result.
+    if (gbits > 0) {
+      const int lane = threadIdx.x & 63;
+      uint64_t rem = __ballot(true);
+      uint32_t myrank = 0, mycnt = 1;
+      int mylead = lane;
+      while (rem) {
+        const int lead = __builtin_ctzll(rem);
+        const uint32_t key = (uint32_t)__builtin_amdgcn_readlane((int)mk, lead);
+        const uint64_t m = __ballot(mk == key);
+        if (mk == key) { myrank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull)); mycnt = (uint32_t)__popcll(m); mylead = lead; }
+        rem &= ~m;
+      }
+      uint32_t base = 0;
+      if (mylead == lane) base = atomicAdd(&hist[mk], mycnt);
+      base = (uint32_t)__shfl((int)base, mylead);
+      crank[b] = base + myrank;
+    } else {
+      crank[b] = atomicAdd(&hist[mk], 1u);
+    }
   }
 }
 

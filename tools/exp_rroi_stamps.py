@@ -31,6 +31,6 @@ tot = s[:, 4] - s[:, 0]
 for i, nm in enumerate(names):
     d = s[:, i + 1] - s[:, i]
     print('%-62s median %6d  mean %6d  p90 %6d cycles (%.0f %% of the block)' % (nm, np.median(d), d.mean(), np.percentile(d, 90), 100.0 * d.sum() / tot.sum()))
-print('block life: median %d, mean %d, p90 %d, max %d cycles (100 MHz... s_memtime ticks at the shader clock)' % (np.median(tot), tot.mean(), np.percentile(tot, 90), tot.max()))
-span = s[:, 4].max() - s[:, 0].min()
-print('first entry -> last exit: %d cycles; sum of block lives / span = %.1f blocks in flight on average' % (span, tot.sum() / span))
+print('block life: median %d, mean %d, p90 %d, max %d cycles (s_memtime ticks at the shader clock)' % (np.median(tot), tot.mean(), np.percentile(tot, 90), tot.max()))
+print('4096 blocks / (256 CUs x 5 resident) = 3.2 rounds x %d cycles = %.0f k cycles = %.1f us at 2.1 GHz (the counters of the 8 XCDs are not synchronised: no global span)'
+      % (np.median(tot), 3.2 * np.median(tot) / 1e3, 3.2 * np.median(tot) / 2.1e3))
