@@ -25,6 +25,29 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 from torch.nn.modules.utils import _pair
 
+
+_warned_layout = set()
+
+
+def nchw_f32(features):
+    """The (B, C, H, W) fp32 contiguous view the kernels read.  A map that is not already that -- a channels-last trunk
+    output, a half-precision map, a strided slice -- is COPIED (67 MB at configs[2]); the reference's kernels read
+    `features.contiguous()` the same way (roi_align_cuda.cpp:44, CHECK_CONTIGUOUS), but silently costs are easy to
+    miss: say so once per cause."""
+    f = features.detach()
+    why = None
+    if f.dtype != torch.float32:
+        why = 'dtype %s' % str(f.dtype).replace('torch.', '')
+    elif not f.is_contiguous():
+        why = 'channels-last layout' if f.dim() == 4 and f.is_contiguous(memory_format=torch.channels_last) else 'non-contiguous strides'
+    if why is not None and why not in _warned_layout:
+        _warned_layout.add(why)
+        import warnings
+        warnings.warn('RoI-Align: the feature map (%s) is copied to contiguous NCHW fp32 before pooling (%.1f MB per call)'
+                      % (why, f.numel() * 4 / 1e6), UserWarning, stacklevel=3)
+    return f.to(torch.float32).contiguous()
+
+
 from . import _lib
 from .rroi_align import RRoIAlign, rroi_align  # noqa: F401  (rroi_align: the mapping the kernel now does itself)
 
@@ -125,7 +148,7 @@ class RoIAlignFunction(Function):
         ctx.args = (out_h, out_w, float(spatial_scale), int(sample_num), 1 if aligned else 0)
         ctx.feature_size = features.size()
         ctx.in_dtype = features.dtype
-        feat = features.detach().to(torch.float32).contiguous()
+        feat = nchw_f32(features)
         r = rois.detach().to(device=feat.device, dtype=torch.float32).contiguous()
         ctx.save_for_backward(r)
         out = roi_forward([feat], r, None, out_h, out_w, [ctx.args[2]], ctx.args[3], 2 if aligned else 1, 0.0)
@@ -187,7 +210,7 @@ def pyramid_roi_align(feats, rois, levels, out_size, scales, sample_num, roi_kin
 
     feats: list of (B, C, H_l, W_l) fp32 HIP tensors; rois (K, 5 | 6); levels (K,) int;
     roi_kind 0 rotated (K, 6), 1 horizontal V1, 2 horizontal V2 aligned."""
-    feats = [f.detach().to(torch.float32).contiguous() for f in feats]
+    feats = [nchw_f32(f) for f in feats]
     dev = feats[0].device
     r = rois.detach().to(device=dev, dtype=torch.float32).contiguous()
     lv = levels.detach().to(device=dev, dtype=torch.int32).contiguous()

@@ -14,6 +14,7 @@ from torch.autograd.function import once_differentiable
 from torch.nn.modules.utils import _pair
 
 from . import _lib
+from .roi_layers import nchw_f32
 
 
 class RRoIAlignFunction(Function):
@@ -33,7 +34,7 @@ class RRoIAlignFunction(Function):
         ctx.feature_size = features.size()
         ctx.in_dtype = features.dtype
 
-        feat = features.detach().to(torch.float32).contiguous()
+        feat = nchw_f32(features)
         r = rois.detach().to(device=feat.device, dtype=torch.float32).contiguous()
         ctx.save_for_backward(r)
         from .roi_layers import roi_forward
