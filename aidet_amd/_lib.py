@@ -29,7 +29,7 @@ NMS_STRICT = 1          # OBB_NMS_STRICT: suppress on `>` (nms_kernel.cu:61) ins
 NMS_RESULT_BYTES = 64   # OBB_NMS_RESULT_BYTES
 # obb_set_tuning knobs (test / experiment hooks, include/obbops.h)
 (TUNE_NMS_FUSED_MAX, TUNE_NMS_DIRECT_MAX, TUNE_NMS_SCAN_BLOCKS, TUNE_RROI_GROUPS, TUNE_OVERLAPS_ROWS, TUNE_NMS_INLINE_MAX,
- TUNE_RROI_ORDER_MIN, TUNE_RROI_GATHER_CHAN, TUNE_RPN_BARRIER_TICKS, TUNE_SOFT_NMS_REG, TUNE_NMS_FUSED_COMPACT) = range(11)
+ TUNE_RROI_ORDER_MIN, TUNE_RROI_GATHER_CHAN, TUNE_RPN_BARRIER_TICKS, TUNE_SOFT_NMS_REG, TUNE_NMS_FUSED_COMPACT, TUNE_RROI_PLAN) = range(12)
 
 _lib = None
 

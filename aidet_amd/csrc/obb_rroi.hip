@@ -319,7 +319,7 @@ __device__ __forceinline__ void build_table(const RoiFrame &f, const Footprint &
 // Instrumented builds for the floor derivation of DESIGN.md 3.3 (`make EXTRA=-DOBB_RROI_ABLATE=n OUT=...`; results are
 // WRONG on purpose, only the time is read): 1 = no sample-table arithmetic (what a per-RoI plan pass would take out of
 // this kernel), 3 = one LDS read per output instead of the 16 taps (the gather loop's share), 4 = no footprint copy (the
-// memory side), 5 = phase stamps (below).
+// memory side), 5 = phase stamps (below), 6 = no output stores.
 #ifndef OBB_RROI_ABLATE
 #define OBB_RROI_ABLATE 0
 #endif
@@ -338,11 +338,102 @@ constexpr int kFwdStageFloats = 5120;               // LDS tile per block (20 Ki
 constexpr int kWaveFloats = kFwdStageFloats / 4;    // private quarter of a wave (small footprints)
 constexpr int kWavePad = 256;                       // room for the tail lanes of a wave's last DMA instruction
 
+// ---- forward plan (round 4; with a workspace) ---------------------------------------------------------------------
+// Phase stamps of an instrumented build (tools/exp_rroi_stamps.py) put 40 % of a forward block's life into its prologue
+// -- RoI row, trigonometry, bin sizes, the four corner samples of the footprint, the copy's reciprocals: a chain of
+// ~400 DEPENDENT instructions -- and 8 % into the sample table + its barrier, all of it recomputed by each of the
+// C / 32 blocks of a RoI.  With a workspace one wave per RoI computes it ONCE (lane = bin: its <= 4 samples) into a
+// plan record; a forward block then reads the record's header with scalar loads and every lane its own table entries
+// straight into registers: no trigonometry, no LDS table, no block barrier -- the four waves of a block are independent.
+// Only RoIs on the small-footprint path (state 1) are planned; everything else runs as before.
+constexpr int kPlanTabEntries = 4 * 64;      // [sample of the bin][bin]
+struct alignas(16) FwdPlanHdr {
+  RoiFrame f;
+  Footprint fp;                               // (already widened to 16-byte chunks when the copy is 16 bytes wide)
+  int pitch, fsz;
+  uint32_t m_slots, m_rslots;
+  int state;                                  // 1: small-footprint path, table below; anything else: the block works it out itself
+  int lvl, spb, pad;
+};
+constexpr size_t kPlanHdrBytes = 128;
+static_assert(sizeof(FwdPlanHdr) <= kPlanHdrBytes, "plan header");
+constexpr size_t kPlanStride = kPlanHdrBytes + kPlanTabEntries * (sizeof(ushort4) + sizeof(float4));   // 6272 bytes per RoI
+constexpr int kPlanMinC = 64;                 // fewer channels: at most one block per RoI would read the record
+// Measured (tools/exp_rroi_plan.py, rocprof per kernel): the planned forward kernel is NOT faster at configs[2] (42.6 vs
+// 43.2 us: with the prologue gone the kernel sits on its second floor, ~190 MB of 64-byte sector traffic at ~5 TB/s) and
+// the plan launch costs 7 us + a boundary: 48.3 vs 42.6 us per call.  From ~1000 RoIs on -- where the Morton order has
+// already cut the traffic and a pre-launch exists anyway -- it pays: config-4 shape 168 vs 182 us for the kernel, 182 vs
+// 189 us per call.  Hence the same threshold as the order launch.
+constexpr int64_t kPlanMinK = 1024;
+constexpr int64_t kPlanMaxK = 16384;          // (105 MB of records)
+
+template <bool X4>
+__global__ __launch_bounds__(256) void rroi_fwd_plan_kernel(const LevelTable lv, const int *__restrict__ roi_level, int num_levels,
+                                                            int B, int C, const float *__restrict__ rois, int ph, int pw,
+                                                            int sample_num, float min_size, int K, int roi_kind,
+                                                            unsigned char *__restrict__ plan) {
+  const int lane = threadIdx.x & 63;
+  const int64_t k = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (k >= K) return;
+  const int lvl_raw = roi_level ? roi_level[k] : 0;
+  const bool lvl_ok = lvl_raw >= 0 && lvl_raw < num_levels;
+  const int lvl = lvl_ok ? lvl_raw : 0;
+  const int H = lv.H[lvl], W = lv.W[lvl];
+  RoiFrame f;
+  make_frame(rois + k * roi_stride(roi_kind), roi_kind, lv.scale[lvl], ph, pw, sample_num, min_size, f);
+  const int nb = ph * pw;
+  const long long spb64 = (long long)f.gh * f.gw;
+  const bool live = lvl_ok && f.b >= 0 && f.b < B && spb64 > 0;
+  Footprint fp = {0, 0, 1, 1};
+  if (live) fp = roi_footprint(f, H, W, ph, pw);
+  if (X4) {
+    const int x1 = (fp.x0 + fp.w - 1) | 3;
+    fp.x0 &= ~3;
+    fp.w = x1 - fp.x0 + 1;
+  }
+  const int pitch = X4 ? (((fp.w >> 2) | 1) << 2) : (fp.w | 1);
+  const int fsz = pitch * fp.h;
+  const int spb = (int)(spb64 > kMaxTabSamples ? kMaxTabSamples + 1 : (spb64 > 0 ? spb64 : 1));
+  const int nsamp = nb * spb;
+  const bool staged = live && fsz <= kFwdStageFloats && nsamp <= kMaxTabSamples && (int64_t)B * C * ((int64_t)H * W) < (1ll << 31);
+  const bool small = staged && fsz <= kWaveFloats && nb <= 64 && spb <= 4;
+  unsigned char *rec = plan + (size_t)k * kPlanStride;
+  if (lane == 0) {
+    FwdPlanHdr h;
+    h.f = f; h.fp = fp; h.pitch = pitch; h.fsz = fsz;
+    const int slots = X4 ? (fsz >> 2) : fsz, rslots = X4 ? (pitch >> 2) : pitch;
+    h.m_slots = slots > 1 ? 0xFFFFFFFFu / (uint32_t)slots + 1u : 0u;
+    h.m_rslots = rslots > 1 ? 0xFFFFFFFFu / (uint32_t)rslots + 1u : 0u;
+    h.state = small ? 1 : 0; h.lvl = lvl; h.spb = spb; h.pad = 0;
+    *reinterpret_cast<FwdPlanHdr *>(rec) = h;
+  }
+  if (!small) return;
+  ushort4 *t_off = reinterpret_cast<ushort4 *>(rec + kPlanHdrBytes);
+  float4 *t_wgt = reinterpret_cast<float4 *>(rec + kPlanHdrBytes + kPlanTabEntries * sizeof(ushort4));
+  if (lane < nb) {
+    const int bi = lane / pw, bj = lane - bi * pw;
+    for (int q = 0; q < spb; ++q) {              // the table loop of rroi_forward_kernel, sample (bin = lane, q)
+      const int iy = q / f.gw, ix = q - iy * f.gw;
+      float x, y, w[4];
+      int yl, xl, yh, xh;
+      sample_xy(f, bi, bj, iy, ix, x, y);
+      const bool on = bilinear_taps_xy(H, W, y, x, yl, xl, yh, xh, w);
+      auto cl = [](int v, int n) { return v < 0 ? 0 : (v >= n ? n - 1 : v); };
+      const int ly0 = cl(yl - fp.y0, fp.h) * pitch, ly1 = cl(yh - fp.y0, fp.h) * pitch;
+      const int lx0 = cl(xl - fp.x0, fp.w), lx1 = cl(xh - fp.x0, fp.w);
+      t_off[q * 64 + lane] = on ? make_ushort4((unsigned short)(ly0 + lx0), (unsigned short)(ly0 + lx1), (unsigned short)(ly1 + lx0), (unsigned short)(ly1 + lx1))
+                                : make_ushort4(0, 0, 0, 0);
+      t_wgt[q * 64 + lane] = make_float4(w[0], w[1], w[2], w[3]);
+    }
+  }
+}
+
 template <bool X4>
 __global__ __launch_bounds__(256, 5) void rroi_forward_kernel(
     const LevelTable lv, const int *__restrict__ roi_level, int num_levels, int B, int C,
     const float *__restrict__ rois, int ph, int pw, int sample_num, float min_size, int chan_per_block,
-    int K, int chunks, int roi_kind, const int *__restrict__ roi_order, float *__restrict__ out) {
+    int K, int chunks, int roi_kind, const int *__restrict__ roi_order, float *__restrict__ out,
+    const unsigned char *__restrict__ plan) {
   __shared__ __attribute__((aligned(16))) float tile[4 * (kWaveFloats + kWavePad)];  // block-wide: kFwdStageFloats + pad
   __shared__ ushort4 s_off[kMaxTabSamples];   // per sample: 4 footprint-local tap offsets (< kFwdStageFloats)
   __shared__ float4 s_wgt[kMaxTabSamples];    // per sample: 4 bilinear weights
@@ -357,8 +448,11 @@ __global__ __launch_bounds__(256, 5) void rroi_forward_kernel(
     const int kk = roi_order[k];
     if (kk >= 0 && kk < K) k = kk;
   }
+  // a plan record of this RoI (rroi_fwd_plan_kernel; block-uniform: scalar loads)?
+  const FwdPlanHdr *__restrict__ P = plan ? reinterpret_cast<const FwdPlanHdr *>(plan + (size_t)k * kPlanStride) : nullptr;
+  const bool planned = P != nullptr && P->state == 1;
   // pyramid level of this RoI (block-uniform): feature map, its size and scale
-  const int lvl_raw = roi_level ? roi_level[k] : 0;
+  const int lvl_raw = planned ? P->lvl : (roi_level ? roi_level[k] : 0);
   const bool lvl_ok = lvl_raw >= 0 && lvl_raw < num_levels;
   const int lvl = lvl_ok ? lvl_raw : 0;
   const float *__restrict__ feat = lv.feat[lvl];
@@ -376,6 +470,12 @@ __global__ __launch_bounds__(256, 5) void rroi_forward_kernel(
   const int c_block = chunk * chan_per_block;
   const int c_end = min(C, c_block + chan_per_block);
   const int64_t plane = (int64_t)H * W;
+  RoiFrame f;
+  Footprint fp;
+  uint32_t m_slots, m_rslots;
+  if (planned) {
+    f = P->f; fp = P->fp; m_slots = P->m_slots; m_rslots = P->m_rslots;
+  } else {
   if (threadIdx.x < 64) {
     RoiFrame f0;
     make_frame(rois + k * roi_stride(roi_kind), roi_kind, scale, ph, pw, sample_num, min_size, f0);
@@ -397,7 +497,8 @@ __global__ __launch_bounds__(256, 5) void rroi_forward_kernel(
     }
   }
   __syncthreads();
-  const RoiFrame f = s_frame;
+  f = s_frame; fp = s_fp; m_slots = s_magic[0]; m_rslots = s_magic[1];
+  }
   const long long spb64 = (long long)f.gh * f.gw;
   if (!lvl_ok || f.b < 0 || f.b >= B || spb64 <= 0) {
     // invalid batch / level index: zeros.  Empty sampling grid: the sum of nothing over the
@@ -407,7 +508,6 @@ __global__ __launch_bounds__(256, 5) void rroi_forward_kernel(
       out[(k * C + c_block) * (int64_t)nb + it] = v;
     return;
   }
-  const Footprint fp = s_fp;
   // LDS image of a footprint: row pitch = an ODD number of 16-byte slots (X4) / of floats.  With an even
   // number the rows of the image alias on the 32 banks (pitch 16 floats: two row phases; pitch 32: every
   // row on the same banks) and the y / y + 1 taps of neighbouring bins collide; the pad slot of a row is
@@ -443,7 +543,6 @@ __global__ __launch_bounds__(256, 5) void rroi_forward_kernel(
   const int slots = X4 ? (fsz >> 2) : fsz;           // 16-byte (dword) slots per channel
   const int rslots = X4 ? (pitch >> 2) : pitch;      // ... per row (the last one is the pad)
   const int rvalid = X4 ? (fp.w >> 2) : fp.w;        // ... that hold pixels
-  const uint32_t m_slots = s_magic[0], m_rslots = s_magic[1];
   auto slot_off = [&](uint32_t idx, uint32_t &c) -> uint32_t {
     c = slots > 1 ? __umulhi(idx, m_slots) : idx;
     const uint32_t r = idx - c * (uint32_t)slots;
@@ -486,7 +585,7 @@ __global__ __launch_bounds__(256, 5) void rroi_forward_kernel(
   OBB_STAMP(1);
   // sample table: coordinates, taps and weights are computed ONCE per RoI and block
   // (the reference recomputes them for every output element, roi_align_kernel.cu:70-113)
-  for (int sidx = threadIdx.x; sidx < nsamp; sidx += 256) {
+  for (int sidx = planned ? nsamp : (int)threadIdx.x; sidx < nsamp; sidx += 256) {     // (planned: the record carries the table)
     if constexpr (kAblate == 1) {   // (a plan record would carry the table)
       const unsigned short o = (unsigned short)((sidx * 7) % (fsz > 1 ? fsz - 1 : 1));
       s_off[sidx] = make_ushort4(o, o, (unsigned short)(o + 1 < fsz ? o + 1 : o), o);
@@ -509,16 +608,32 @@ __global__ __launch_bounds__(256, 5) void rroi_forward_kernel(
     s_wgt[sidx] = make_float4(w[0], w[1], w[2], w[3]);
   }
   if (small) {
-    __syncthreads();   // table complete
-    OBB_STAMP(2);
     int4 so[4];
     float4 sw[4];
+    if (planned) {
+      // every lane takes its bin's entries straight from the record ([sample][bin]: coalesced); the loads travel with
+      // the first copy, both are waited for together below -- no LDS table, no block barrier
+      const ushort4 *t_off = reinterpret_cast<const ushort4 *>(plan + (size_t)k * kPlanStride + kPlanHdrBytes);
+      const float4 *t_wgt = reinterpret_cast<const float4 *>(plan + (size_t)k * kPlanStride + kPlanHdrBytes + kPlanTabEntries * sizeof(ushort4));
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const bool on = lane < nb && q < spb;
+        const ushort4 o16 = t_off[on ? q * 64 + lane : 0];
+        const float4 w4 = t_wgt[on ? q * 64 + lane : 0];
+        so[q] = on ? make_int4(o16.x, o16.y, o16.z, o16.w) : make_int4(0, 0, 0, 0);
+        sw[q] = on ? w4 : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      OBB_STAMP(2);
+    } else {
+    __syncthreads();   // table complete
+    OBB_STAMP(2);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const bool on = lane < nb && q < spb;
       const ushort4 o16 = s_off[on ? lane * spb + q : 0];
       so[q] = on ? make_int4(o16.x, o16.y, o16.z, o16.w) : make_int4(0, 0, 0, 0);
       sw[q] = on ? s_wgt[lane * spb + q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     }
     // mean over the samples: a division, or -- a power-of-two count (2 x 2 samples), the usual case -- the
     // exact same value from a multiplication (scaling by a power of two rounds identically)
@@ -551,7 +666,8 @@ __global__ __launch_bounds__(256, 5) void rroi_forward_kernel(
       // 41 -> 45 us; capped at 96 registers it spills: 79 us)
       for (int c = 0; c < nch; ++c) {
         const float r0 = bin_sum(wt + c * fsz);
-        if (lane < nb) o[(int64_t)c * nb] = r0;
+        if constexpr (kAblate == 6) { if (lane < nb && r0 == 12345.678f) o[(int64_t)c * nb] = r0; }   // (no output stores)
+        else if (lane < nb) o[(int64_t)c * nb] = r0;
       }
       // the next pass overwrites this region: its gathers are done (their values were consumed)
       __builtin_amdgcn_wave_barrier();
@@ -1416,7 +1532,7 @@ static int rroi_geometry(const char *who, int C, bool backward, int64_t K, int &
 static int rroi_forward_launch_levels(const char *who, const LevelTable &lv, int num_levels, const int *roi_level_dev,
                                       int B, int C, const float *rois_dev, int64_t K, int ph, int pw,
                                       int sample_num, float min_size, int roi_kind, float *out_dev, void *stream,
-                                      int *order_ws = nullptr) {
+                                      int *order_ws = nullptr, unsigned char *plan_ws = nullptr) {
   bool x4 = true;   // 16-byte staging loads need 16-byte aligned rows: W % 4 == 0 and an aligned base, on every level
   for (int l = 0; l < num_levels; ++l) {
     int rc = rroi_check(who, B, C, lv.H[l], lv.W[l], K, ph, pw);
@@ -1443,12 +1559,25 @@ static int rroi_forward_launch_levels(const char *who, const LevelTable &lv, int
     OBB_LAUNCH_CHECK();
     order = order_ws;
   }
+  // with a workspace and enough channels: the per-RoI plan (one wave per RoI), read by all C / 32 blocks of the RoI
+  const unsigned char *plan = nullptr;
+  if (plan_ws && C >= kPlanMinC && K <= kPlanMaxK && K >= tuning(OBB_TUNE_RROI_PLAN, kPlanMinK)) {
+    const unsigned pb = (unsigned)((K + 3) / 4);
+    if (x4)
+      hipLaunchKernelGGL(rroi_fwd_plan_kernel<true>, dim3(pb), dim3(256), 0, (hipStream_t)stream, lv, roi_level_dev, num_levels, B, C, rois_dev,
+                         ph, pw, sample_num, min_size, (int)K, roi_kind, plan_ws);
+    else
+      hipLaunchKernelGGL(rroi_fwd_plan_kernel<false>, dim3(pb), dim3(256), 0, (hipStream_t)stream, lv, roi_level_dev, num_levels, B, C, rois_dev,
+                         ph, pw, sample_num, min_size, (int)K, roi_kind, plan_ws);
+    OBB_LAUNCH_CHECK();
+    plan = plan_ws;
+  }
   if (x4)
     hipLaunchKernelGGL(rroi_forward_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
-                       lv, roi_level_dev, num_levels, B, C, rois_dev, ph, pw, sample_num, min_size, cpb, (int)K, (int)chunks, roi_kind, order, out_dev);
+                       lv, roi_level_dev, num_levels, B, C, rois_dev, ph, pw, sample_num, min_size, cpb, (int)K, (int)chunks, roi_kind, order, out_dev, plan);
   else
     hipLaunchKernelGGL(rroi_forward_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
-                       lv, roi_level_dev, num_levels, B, C, rois_dev, ph, pw, sample_num, min_size, cpb, (int)K, (int)chunks, roi_kind, order, out_dev);
+                       lv, roi_level_dev, num_levels, B, C, rois_dev, ph, pw, sample_num, min_size, cpb, (int)K, (int)chunks, roi_kind, order, out_dev, plan);
   OBB_LAUNCH_CHECK();
   return OBB_OK;
 }
@@ -1672,9 +1801,11 @@ extern "C" int obb_roi_map_levels_i32(const float *rois_dev, int64_t K, int roi_
   return OBB_OK;
 }
 
+// [order: 2 K ints | plan records: K x kPlanStride bytes (K <= kPlanMaxK)]
+static size_t roi_forward_order_bytes(int64_t K) { return obb::align_up((size_t)(K > 0 ? K : 1) * 2 * sizeof(int32_t), 256); }
 extern "C" size_t obb_roi_forward_workspace_bytes(int64_t K) {
   if (K < 0) return 0;
-  return obb::align_up((size_t)(K > 0 ? K : 1) * 2 * sizeof(int32_t), 256);
+  return roi_forward_order_bytes(K) + (K <= obb::kPlanMaxK ? (size_t)(K > 0 ? K : 1) * obb::kPlanStride : 0);
 }
 
 extern "C" int obb_roi_align_forward_ws_f32(const float *const *feat_devs_host, const int *H_host,
@@ -1694,7 +1825,7 @@ extern "C" int obb_roi_align_forward_ws_f32(const float *const *feat_devs_host, 
     if (workspace_bytes < obb_roi_forward_workspace_bytes(K))
       return set_err(OBB_EWORKSPACE, "%s: workspace %zu bytes < obb_roi_forward_workspace_bytes(%lld) = %zu", who, workspace_bytes,
                      (long long)K, obb_roi_forward_workspace_bytes(K));
-    if (reinterpret_cast<uintptr_t>(workspace_dev) & 3u) return set_err(OBB_EINVAL, "%s: workspace must be 4-byte aligned", who);
+    if (reinterpret_cast<uintptr_t>(workspace_dev) & 15u) return set_err(OBB_EINVAL, "%s: workspace must be 16-byte aligned", who);
   }
   LevelTable lv = {};
   for (int l = 0; l < num_levels; ++l) {
@@ -1702,5 +1833,6 @@ extern "C" int obb_roi_align_forward_ws_f32(const float *const *feat_devs_host, 
   }
   return rroi_forward_launch_levels(who, lv, num_levels, roi_level_dev, B, C, rois_dev, K, ph, pw, sample_num,
                                     roi_kind == 0 ? min_size : 0.0f, roi_kind, out_dev, stream,
-                                    static_cast<int *>(workspace_dev));
+                                    static_cast<int *>(workspace_dev),
+                                    (workspace_dev && K <= kPlanMaxK) ? static_cast<unsigned char *>(workspace_dev) + roi_forward_order_bytes(K) : nullptr);
 }

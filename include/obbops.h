@@ -569,7 +569,8 @@ OBB_API int obb_head_gather_decode_f32(const float *rois_dev, const float *cls_s
 #define OBB_TUNE_RPN_BARRIER_TICKS 8  /* bound (100 MHz ticks) of the level barrier of the RPN selection; 0 forces the fallback */
 #define OBB_TUNE_SOFT_NMS_REG 9       /* 1: float Soft-NMS through the register-resident kernel (the float64 one), n <= 8192 */
 #define OBB_TUNE_NMS_FUSED_COMPACT 10  /* 0: the sorted route's compaction as a launch of its own (as from 2^18 boxes on); 2: the waiting shards give up at once */
-#define OBB_TUNE_COUNT 11
+#define OBB_TUNE_RROI_PLAN 11          /* fewest RoIs the workspace forward of RoI-Align plans per RoI (default 1024; 0 = always) */
+#define OBB_TUNE_COUNT 12
 OBB_API int obb_set_tuning(int knob, int64_t value);
 
 #ifdef __cplusplus

@@ -292,3 +292,33 @@ def test_channels_last_feature_map_is_copied_with_a_warning_once():
         warnings.simplefilter('error')
         layer(feat.contiguous(memory_format=torch.channels_last), rois)      # (once per cause)
         layer(feat, rois)
+
+
+def test_planned_roi_forward_is_bit_equal_to_the_unplanned_one():
+    """obb_roi_align_forward_ws_f32 with the per-RoI plan pass (rroi_fwd_plan_kernel: frame, footprint, copy reciprocals
+    and sample table once per RoI instead of once per block) forced for every RoI count against the same call without
+    it and against the workspace-free entry points: rotated and horizontal kinds, a pyramid, RoIs on every path
+    (tiny, large footprints, outside the map, invalid batch index), C not a multiple of 32."""
+    from aidet_amd import _lib
+    from aidet_amd.roi_layers import RotatedSingleRoIExtractor, SingleRoIExtractor
+    rng = np.random.default_rng(8)
+    feats = [t(rng.standard_normal((2, 72, 64 >> i, 96 >> i)).astype(np.float32)) for i in range(3)]
+    K = 700
+    x1, y1 = rng.uniform(-20, 380, K), rng.uniform(-20, 250, K)
+    size = np.exp(rng.uniform(np.log(2), np.log(500), (K, 2)))
+    rois = np.concatenate([rng.integers(0, 2, (K, 1)), x1[:, None], y1[:, None], x1[:, None] + size[:, :1], y1[:, None] + size[:, 1:]], 1).astype(np.float32)
+    rois[5, 0] = 7                                   # invalid batch index: zeros
+    rr = np.concatenate([rois[:, :1], oracle.synth_boxes(K, 380, 4)[:, :5]], 1).astype(np.float32)
+    rr[:, 3:5] *= rng.choice([0.1, 1.0, 6.0], (K, 1))
+    ext = SingleRoIExtractor(dict(type='RoIAlign', out_size=7, sample_num=2), 72, [4, 8, 16])
+    rext = RotatedSingleRoIExtractor(dict(type='RRoIAlign', out_size=(5, 7), sample_num=2), 72, [4, 8, 16])
+    got = {}
+    for knob in (0, 1 << 30):
+        _lib.set_tuning(_lib.TUNE_RROI_PLAN, knob)
+        try:
+            with torch.no_grad():
+                got[knob] = (ext(feats, t(rois)), rext(feats, t(rr)))
+        finally:
+            _lib.set_tuning(_lib.TUNE_RROI_PLAN, -1)
+    assert torch.equal(got[0][0], got[1 << 30][0]) and torch.equal(got[0][1], got[1 << 30][1])
+    assert float(got[0][0].abs().sum()) > 0 and bool((got[0][0][5] == 0).all())

@@ -34,8 +34,8 @@ if len(sys.argv) > 1 and sys.argv[1] == 'child':
     sys.exit(0)
 
 names = {0: 'product build', 1: 'no sample-table arithmetic',
-         3: 'one LDS read per output instead of 16 taps', 4: 'no footprint copy (LDS-DMA)'}
-for a in (0, 1, 3, 4):
+         3: 'one LDS read per output instead of 16 taps', 4: 'no footprint copy (LDS-DMA)', 6: 'no output stores'}
+for a in (0, 1, 3, 4, 6):
     lib = os.path.join(ROOT, 'aidet_amd', 'lib', 'libobbops.so' if a == 0 else 'libobbops_abl%d.so' % a)
     if not os.path.exists(lib):
         print(a, 'missing', lib)
