@@ -102,6 +102,7 @@ struct NmsCounters {
   long long rounds;                        // resolve sweeps (most of any shard)
   unsigned int done;                       // resolve workgroups finished
   unsigned int state;                      // fused resolve + compaction: 0 wait, 1 all shards resolved (go), 2 a waiter gave up
+  unsigned int grid_fail;                  // grid route: a crowded cell / a box over too many cells -- repeat on the sorted route
   unsigned long long cand_total;           // candidate pairs over all shards
   unsigned long long cand_worst;           // fullest shard
 };
@@ -410,7 +411,8 @@ __global__ __launch_bounds__(256) void nms_cellscan_big_kernel(uint32_t *__restr
 // before publishing: no deadlock; the hand-over pattern of nms_compact_kernel).
 // =====================================================================================================
 constexpr int kFrameSamples = 1024;     // (4 per thread of ONE 256-thread workgroup: 4096 samples on 16 waves took 14 us, mostly barriers)
-struct alignas(16) NmsFrame { float bx, by, sx, sy; float cpx, cpy; int gbits; int any; };
+struct alignas(16) NmsFrame { float bx, by, sx, sy; float cpx, cpy; int gbits; int any;
+                              int gshx, gshy, ggx, ggy; };   // grid route: cell = quantised coordinate >> gsh, ggx x ggy cells
 
 // conservative axis-aligned box of one input row, no trigonometry (frame only: never affects a result)
 template <int KIND>
@@ -434,7 +436,7 @@ __device__ __forceinline__ float4 sample_box(const float *__restrict__ row) {
 template <int KIND, bool F64 = false>
 __global__ __launch_bounds__(256) void nms_frame_kernel(const NmsSource src, int64_t n, int cell_hbits,
                                                         NmsFrame *__restrict__ frame,
-                                                        uint4 *__restrict__ zero, size_t zero_vecs) {
+                                                        uint4 *__restrict__ zero, size_t zero_vecs, int grid_log2) {
   constexpr int S = KIND == 0 ? 6 : (KIND == 1 ? 9 : 5);
   for (size_t z = (size_t)blockIdx.x * blockDim.x + threadIdx.x; z < zero_vecs; z += (size_t)gridDim.x * blockDim.x)
     zero[z] = make_uint4(0u, 0u, 0u, 0u);
@@ -506,6 +508,7 @@ __global__ __launch_bounds__(256) void nms_frame_kernel(const NmsSource src, int
   // the mean (a uniform scene spans 1.7 sigma) = no outlier: the bounding box is the frame.
   float mx = 0.0f, my = 0.0f, wx = 3.0e38f, wy = 3.0e38f;     // window = mean +- (wx, wy)
   float cnt_in = 0.0f;
+  float ext_mean = 0.0f, ext_sd = 0.0f;      // box extent (larger side of the conservative AABB) over the finite samples
   bool robust = false;
   {
     const float4 b0 = sm[0];
@@ -518,6 +521,7 @@ __global__ __launch_bounds__(256) void nms_frame_kernel(const NmsSource src, int
       const float cx = 0.5f * (b.x + b.y), cy = 0.5f * (b.z + b.w);
       const float dx = cx - px, dy = cy - py;
       v[0] += 1.0f; v[1] += dx; v[2] += dy; v[3] += dx * dx; v[4] += dy * dy;
+      { const float e = max_sel(b.y - b.x, b.w - b.z); v[5] += e; v[6] += e * e; }    // (grid route: cell size from the extents)
       axh = max(axh, fkey(b.y)); axl = max(axl, ~fkey(b.x)); ayh = max(ayh, fkey(b.w)); ayl = max(ayl, ~fkey(b.z));
       cxh = max(cxh, fkey(cx)); cxl = max(cxl, ~fkey(cx)); cyh = max(cyh, fkey(cy)); cyl = max(cyl, ~fkey(cy));
     }
@@ -529,7 +533,7 @@ __global__ __launch_bounds__(256) void nms_frame_kernel(const NmsSource src, int
     }
     __shared__ uint4 cred[NW];
     if (lane == 0) { wred[wv] = make_uint4(axh, axl, ayh, ayl); cred[wv] = make_uint4(cxh, cxl, cyh, cyl); }
-    block_sum(v, 5);   // (its barriers also publish wred / cred)
+    block_sum(v, 7);   // (its barriers also publish wred / cred)
     uint4 m = wred[0], c = cred[0];
     for (int k = 1; k < NW; ++k) {
       m.x = max(m.x, wred[k].x); m.y = max(m.y, wred[k].y); m.z = max(m.z, wred[k].z); m.w = max(m.w, wred[k].w);
@@ -537,6 +541,7 @@ __global__ __launch_bounds__(256) void nms_frame_kernel(const NmsSource src, int
     }
     if (tid == 0) bbox_all = m;
     const float cnt = tot[0];
+    if (cnt >= 1.0f) { ext_mean = tot[5] / cnt; const float ev = tot[6] / cnt - ext_mean * ext_mean; ext_sd = ev > 0.0f ? sqrtf(ev) : 0.0f; }
     if (cnt >= 1.0f) {
       const float ex = tot[1] / cnt, ey = tot[2] / cnt;
       float vx = tot[3] / cnt - ex * ex, vy = tot[4] / cnt - ey * ey;
@@ -652,6 +657,19 @@ __global__ __launch_bounds__(256) void nms_frame_kernel(const NmsSource src, int
       gbits = d <= 1 ? 0 : (want > total - 4 ? total - 4 : want);
     }
     f.gbits = gbits;
+    // grid route (nms_ginsert_kernel / nms_gprobe_kernel): cells = the 15-bit quantisation coarsened by a power of two,
+    // about (mean + one sigma of the sampled extents) wide -- most boxes touch 1-4 cells -- and at most 2^grid_log2 per axis
+    {
+      const float ctarget = ext_mean + ext_sd;
+      auto shift_for = [&](float scale) {
+        const float q = ctarget * scale;                      // cell size in quanta
+        int sh = 15 - grid_log2;
+        while (sh < 15 && (float)(1 << sh) < q) ++sh;
+        return sh;
+      };
+      f.gshx = shift_for(f.sx); f.gshy = shift_for(f.sy);
+      f.ggx = (int)(kQMax >> f.gshx) + 1; f.ggy = (int)(kQMax >> f.gshy) + 1;
+    }
     *frame = f;
   }
 }
@@ -739,6 +757,85 @@ __global__ __launch_bounds__(256) void nms_prepq_kernel(const NmsSource src, int
       crank[b] = base + myrank;
     } else {
       crank[b] = atomicAdd(&hist[mk], 1u);
+    }
+  }
+}
+
+// =====================================================================================================================
+// GRID route (round 4): frame -> insert -> probe + clip -> resolve + compaction = FOUR launches for ungrouped calls of
+// 10 241 .. 262 143 boxes whose scene is sparse enough (the headline's is: 100 000 boxes of 8-128 px on a 20 000^2
+// canvas).  The sorted route pays four launches (frame, prepq, sort-scatter, cull-box) before its first pair test to
+// be distribution-proof; a uniform grid needs none of that when no cell is crowded:
+//   insert   per box: the 64-byte record (as nms_prep_kernel), the packed 15-bit interval, and one 16-byte entry
+//            (interval, box id) into every cell its interval touches -- cells = the quantisation coarsened by a power of
+//            two, about one mean + sigma extent wide (nms_frame_kernel), fixed capacity kGridCap per cell;
+//   probe    thread = box a: the entries b > a of every cell it touches, four at a time; a pair whose intervals meet is
+//            a candidate IN ONE CELL ONLY -- the one that holds the lower corner of the intersection of the two intervals
+//            (both boxes touch it: the cell function is monotone) -- and goes through the same per-wave queue, pruning
+//            and clip as the direct route (DirectSink::flush); the edges are what every route produces;
+//   resolve  nms_resolve_kernel<false> with its fused compaction.
+// A crowded cell (more than kGridCap entries) or a box that touches more than kGridMaxCells cells raises `grid_fail`:
+// the call's record says route 3, the synchronous entry points repeat the call on the sorted route and the calling
+// thread remembers it for the size class (the next kGridSkipCalls calls go straight to the sorted route).
+// =====================================================================================================================
+constexpr int kGridCap = 32;             // entries per cell
+constexpr int kGridMaxCells = 64;        // cells one box may touch
+constexpr int kGridMaxLog2 = 8;          // at most 256 x 256 cells
+constexpr int kGridSkipCalls = 256;
+constexpr int64_t kGridAutoMax = 150000;
+
+template <int KIND>
+__global__ __launch_bounds__(256) void nms_ginsert_kernel(const NmsSource src, int64_t n, QuadRec *__restrict__ rec,
+                                                          float *__restrict__ ar,
+                                                          const NmsFrame *__restrict__ frame, float thr,
+                                                          uint32_t *__restrict__ gcnt, uint4 *__restrict__ gtab,
+                                                          NmsCounters *__restrict__ ctr) {
+  constexpr int S = KIND == 0 ? 6 : (KIND == 1 ? 9 : 5);
+  const NmsFrame fr = *frame;
+  auto qz = [](float x, float b, float s2) {
+    float u = floorf((x - b) * s2);
+    u = u < 0.0f ? 0.0f : (u > (float)kQMax ? (float)kQMax : u);
+    return (uint32_t)u;
+  };
+  for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n; b += (int64_t)gridDim.x * blockDim.x) {
+    const float *row = src.dets + b * src.pitch;
+    Quad q;
+    load_quad<KIND>(row, q);
+    QuadRec r;
+    r.ox = q.ox; r.oy = q.oy; r.ex = q.ex; r.ey = q.ey;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { r.rx[k] = q.rx[k]; r.ry[k] = q.ry[k]; }
+    r.area = q.area; r.skey = score_key(row[S - 1]);
+    r.group = 0;
+    r.thr = src_thr<S>(src, b, row, thr);
+    bool wellformed = true;
+    if (KIND == 2) hbb_record(row, r, wellformed);
+    rec[b] = r;
+    ar[b] = q.area;
+    float4 v;
+    nms_interval(q.ox, q.ex, v.x, v.y);
+    nms_interval(q.oy, q.ey, v.z, v.w);
+    const float big = 3.0e38f;
+    const bool fin = wellformed && (fabs_sel(v.x) < big) && (fabs_sel(v.y) < big) && (fabs_sel(v.z) < big) && (fabs_sel(v.w) < big);
+    uint2 o = make_uint2(kSentLo, kSentHi);     // an isolated box: in no cell, meets nothing
+    if (fin) {
+      const uint32_t xl = qz(v.x, fr.bx, fr.sx), xh = qz(v.y, fr.bx, fr.sx);
+      const uint32_t yl = qz(v.z, fr.by, fr.sy), yh = qz(v.w, fr.by, fr.sy);
+      o.x = xl | (yl << 16);
+      o.y = (xh | (yh << 16)) | kGuard;
+      const uint32_t cx0 = xl >> fr.gshx, cx1 = xh >> fr.gshx, cy0 = yl >> fr.gshy, cy1 = yh >> fr.gshy;
+      const uint32_t ncell = (cx1 - cx0 + 1u) * (cy1 - cy0 + 1u);
+      if (ncell > (uint32_t)kGridMaxCells) {
+        ctr->grid_fail = 1u;
+      } else {
+        for (uint32_t cy = cy0; cy <= cy1; ++cy)
+          for (uint32_t cx = cx0; cx <= cx1; ++cx) {
+            const uint32_t cell = cy * (uint32_t)fr.ggx + cx;
+            const uint32_t slot = atomicAdd(&gcnt[cell], 1u);
+            if (slot < (uint32_t)kGridCap) gtab[(size_t)cell * kGridCap + slot] = make_uint4(o.x, o.y, (uint32_t)b, 0u);
+            else ctr->grid_fail = 1u;
+          }
+      }
     }
   }
 }
@@ -1643,6 +1740,78 @@ __global__ __launch_bounds__(64 * kNmsWaves) void nms_scan_direct_kernel(const f
 
 // ---- 7: clip kernel -----------------------------------------------------------------------
 // One candidate pair per lane.  The edge points from the box that PRECEDES in the
+// grid route, probe + clip: see nms_ginsert_kernel.  A HALF-WAVE owns one cell (32 lanes = the cell's kGridCap entry
+// slots, one coalesced 512-byte read); every entry u of the cell is broadcast to its half-wave in turn and lane s tests
+// the pair (s, u) for u > s: each pair of a cell once.  Two dependent round trips per wave (the cell's count, its
+// entries) -- the first version walked a box's cells and their entries from the box's own thread: up to 27 dependent
+// round trips per wave, 42 us at 100k boxes.
+__global__ __launch_bounds__(64 * kNmsWaves) void nms_gprobe_kernel(const QuadRec *__restrict__ rec,
+                                                           const NmsFrame *__restrict__ frame,
+                                                           const uint32_t *__restrict__ gcnt, const uint4 *__restrict__ gtab,
+                                                           uint32_t ncells, float thr, int per_box_thr, int flags,
+                                                           uint2 *__restrict__ edges, unsigned long long segcap,
+                                                           unsigned long long *__restrict__ ccnts, int *__restrict__ cnt,
+                                                           const NmsCounters *__restrict__ ctr) {
+  static_assert(kGridCap == 32, "a half-wave per cell");
+  __shared__ uint2 queue[kNmsWaves][kNmsQueue];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t gw = blockIdx.x * kNmsWaves + wave;
+  const uint32_t cell = gw * 2u + (uint32_t)(lane >> 5);
+  const int s = lane & 31;
+  const uint32_t c = cell < ncells ? gcnt[cell] : 0u;
+  const int m = (int)(c < (uint32_t)kGridCap ? c : (uint32_t)kGridCap);
+  const int m0 = __builtin_amdgcn_readlane(m, 0), m1 = __builtin_amdgcn_readlane(m, 32);
+  const int mmax = m0 > m1 ? m0 : m1;
+  if (mmax < 2) return;                                        // (wave-uniform) no pair in either cell
+  if (__hip_atomic_load(&ctr->grid_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;   // the call is repeated on the sorted route
+  const NmsFrame fr = *frame;
+  const uint4 e = s < m ? gtab[(size_t)cell * kGridCap + s] : make_uint4(kSentLo, kSentHi, 0u, 0u);
+  const uint32_t ccy = cell / (uint32_t)fr.ggx, ccx = cell - ccy * (uint32_t)fr.ggx;
+  const uint32_t axl = e.x & 0x7FFFu, ayl = (e.x >> 16) & 0x7FFFu;
+  uint2 *q = queue[wave];
+  int qn = 0;
+  const int shard = (int)(gw & (kShards - 1));
+  DirectSink sink;
+  sink.pr.thr = thr; sink.pr.cpx = 0.0f; sink.pr.cpy = 0.0f;
+  sink.per_box_thr = per_box_thr != 0;
+  sink.flags = flags;
+  sink.iv = nullptr; sink.ar = nullptr; sink.rec = rec; sink.klo = nullptr;
+  sink.eseg = edges + (size_t)shard * segcap;
+  sink.segcap = segcap;
+  sink.ccnt = ccnts + (size_t)shard * kCandStride;
+  sink.ecnt = ccnts + (size_t)(kShards + shard) * kCandStride;
+  sink.cnt = cnt;
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+  const int half = lane & 32;
+  for (int u = 1; u < mmax; ++u) {
+    // entry u of this lane's cell, broadcast inside the half-wave
+    // (u is wave-uniform: two v_readlane per word and a select, not three LDS-crossbar permutes per step)
+    const uint32_t bx = half ? (uint32_t)__builtin_amdgcn_readlane((int)e.x, 32 + u) : (uint32_t)__builtin_amdgcn_readlane((int)e.x, u);
+    const uint32_t by = half ? (uint32_t)__builtin_amdgcn_readlane((int)e.y, 32 + u) : (uint32_t)__builtin_amdgcn_readlane((int)e.y, u);
+    const uint32_t bz = half ? (uint32_t)__builtin_amdgcn_readlane((int)e.z, 32 + u) : (uint32_t)__builtin_amdgcn_readlane((int)e.z, u);
+    // a candidate of THIS cell: the intervals meet and the cell holds the lower corner of their intersection (the one cell
+    // of all that both boxes touch where the pair is reported)
+    const uint32_t bxl = bx & 0x7FFFu, byl = (bx >> 16) & 0x7FFFu;
+    const uint32_t ox = (axl > bxl ? axl : bxl) >> fr.gshx, oy = (ayl > byl ? ayl : byl) >> fr.gshy;
+    const bool cnd = s < u && u < m && qdisjoint(e.x, e.y, bx, by) == 0u && ox == ccx && oy == ccy;
+    const uint64_t mc = __ballot(cnd);
+    if (mc) {
+      if (cnd) q[qn + __popcll(mc & lt_mask)] = make_uint2(e.z, bz);
+      qn += __popcll(mc);
+      if (qn >= 64) {
+        qn -= 64;
+        __builtin_amdgcn_wave_barrier();
+        sink.flush(q + qn, 64, lane);
+      }
+    }
+  }
+  if (qn > 0) {
+    __builtin_amdgcn_wave_barrier();
+    sink.flush(q, qn, lane);
+  }
+}
+
 // greedy order (smaller score key, then smaller index) to the other one; the clip
 // always takes the preceding box as the subject A, exactly like the i-before-j
 // loop of nms_cpu.cpp:35-58.  grid = (blocks per shard, shards).
@@ -1931,7 +2100,8 @@ __global__ __launch_bounds__(COMPACT ? kResolveThreadsCompact : kResolveThreads)
         hinfo->rounds = (long long)__hip_atomic_load(reinterpret_cast<unsigned long long *>(&ctr->rounds), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         hinfo->cand_total = v; hinfo->cand_worst = mx;
         hinfo->heavy_units = uh; hinfo->light_units = ul;
-        hinfo->route = 2u; hinfo->unit_worst = uw;
+        hinfo->route = __hip_atomic_load(&ctr->grid_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 3u : 2u;   // 3: repeat without the grid
+        hinfo->unit_worst = uw;
       }
     }
     return;
@@ -2377,11 +2547,12 @@ static thread_local NmsProfile g_prof;
 
 // ---- workspace layout ------------------------------------------------------------
 struct NmsLayout {
-  size_t rec, iv, ar, qb, ckey, crank, gsrc, tsrc, qs, pf, pg, pt, tgr, sgr, frame, tbox, sbox, zero_begin, cnt, ctr, ccnts, ucnts, super, hist, scanflags, ticket,
+  size_t rec, iv, ar, qb, ckey, crank, gsrc, tsrc, gtab, qs, pf, pg, pt, tgr, sgr, frame, tbox, sbox, zero_begin, cnt, ctr, ccnts, ucnts, super, hist, scanflags, ticket,
       zero_end, blockcnt, cands, edges, total;
   unsigned long long cap;         // candidate pairs == overlap edges capacity
   unsigned long long unit_worst;  // kShards x the most units one shard of the unit list can get
   int64_t ntiles;
+  int grid_log2;                  // grid route: cells per axis = 2^grid_log2 at most (0: no grid table in this layout)
 };
 
 static int nms_layout(int64_t n, int64_t edge_capacity, NmsLayout &L) {
@@ -2403,6 +2574,15 @@ static int nms_layout(int64_t n, int64_t edge_capacity, NmsLayout &L) {
   L.crank = take(nn * 4);
   L.gsrc = take(nn * 4);       // per-box group / threshold derived by the prep kernel (NmsSource modes 1, 2)
   L.tsrc = take(nn * 4);
+  // grid route: (2^g x 2^g cells) x kGridCap entries of 16 bytes; g from n (about half a cell per box), sizes where the route applies
+  L.grid_log2 = 0;
+  L.gtab = off;
+  if (n >= 256 && n < (1 << 18)) {
+    int g = 6;
+    while (g < kGridMaxLog2 && (1ll << (2 * g)) * 2 < n) ++g;
+    L.grid_log2 = g;
+    L.gtab = take(((size_t)1 << (2 * g)) * kGridCap * sizeof(uint4));
+  }
   L.qs = take((nt * kTile + kRowChunk) * sizeof(uint2));
   L.pf = take((nt * kTile) * sizeof(uint4));
   L.pg = take((nt * kTile) * sizeof(int32_t));
@@ -2484,6 +2664,24 @@ static void cap_hint_note(int64_t n, int kind, int rc, unsigned long long need, 
   if (rc == OBB_EWORKSPACE) { if (need) cap_hint_put(n, kind, need); return; }
   const unsigned long long h = cap_hint_get(n, kind);
   if (rc == OBB_OK && h && 8ull * used < h) cap_hint_put(n, kind, 0ull);
+}
+
+// grid route: after a failed try (a crowded cell) the thread's next kGridSkipCalls calls of the size class go straight to the
+// sorted route
+static thread_local int g_last_route = -1;     // obb_nms_last_route(): 0 fused, 1 direct, 2 sorted, 4 grid, 5 grid gave up -> sorted
+struct GridSkip { int kind, bits, left; };
+static thread_local GridSkip g_grid_skip[8] = {};
+static bool grid_skip_take(int64_t n, int kind) {
+  const int bits = size_class(n);
+  for (GridSkip &h : g_grid_skip)
+    if (h.left > 0 && h.kind == kind && h.bits == bits) { --h.left; return true; }
+  return false;
+}
+static void grid_skip_put(int64_t n, int kind) {
+  const int bits = size_class(n);
+  GridSkip *slot = &g_grid_skip[(unsigned)(bits + 3 * kind) % 8];
+  for (GridSkip &h : g_grid_skip) if (h.left <= 0) { slot = &h; break; }
+  slot->kind = kind; slot->bits = bits; slot->left = kGridSkipCalls;
 }
 
 }  // namespace obb
@@ -2677,6 +2875,47 @@ int nms_enqueue_source(const char *who, NmsSource src, int64_t n, int kind, floa
   }
   // threshold-aware pruning: the call's threshold, or per pair the smaller of the two boxes'
   const float prune_thr = thr_dev ? 0.0f : iou_thr;
+  // ---- grid route (see nms_ginsert_kernel): ungrouped float calls between the direct route's range and 2^18 boxes,
+  // from the entry points that can repeat a call (src.allow_grid), unless this thread's last try of the size class failed
+  {
+    const int64_t gknob = tuning(OBB_TUNE_NMS_GRID, -1);          // -1 auto, 0 never, 1 wherever it applies
+    // (auto: up to kGridAutoMax boxes -- with at most 256 x 256 cells a larger scene crowds them: 200k boxes measured 131 us
+    // on the grid against 125 us sorted; 100k: 71 vs 95, 50k: 65 vs 78, 20k: 52 vs 71, 12k: 51 vs 69)
+    const bool grid = !direct && L.grid_log2 > 0 && n > direct_max && !group_dev && src.mode == 0 && !f64 && src.allow_grid != 0 &&
+                      gknob != 0 && (gknob == 1 || (n <= kGridAutoMax && !grid_skip_take(n, kind)));
+    q.grid = grid;
+    if (grid) {
+      const size_t gcells = (size_t)1 << (2 * L.grid_log2);
+      const size_t zbytes = (L.hist + gcells * sizeof(uint32_t)) - L.zero_begin;      // (the cell counters live in the histogram's memory)
+      uint4 *zero = reinterpret_cast<uint4 *>(ws + L.zero_begin);
+      const size_t zero_vecs = zbytes / sizeof(uint4);
+      unsigned zb = (unsigned)((zero_vecs + 1023) / 1024) + 1u;
+      zb = zb > 256u ? 256u : zb;
+      uint4 *gtab = reinterpret_cast<uint4 *>(ws + L.gtab);
+      const int hbits = 7, grid_log2 = L.grid_log2;
+      OBB_PHASE(0);
+      if (kind == OBB_KIND_RBOX) hipLaunchKernelGGL(nms_frame_kernel<0>, dim3(zb), dim3(256), 0, st, src, n, hbits, frame, zero, zero_vecs, grid_log2);
+      else if (kind == OBB_KIND_POLY) hipLaunchKernelGGL(nms_frame_kernel<1>, dim3(zb), dim3(256), 0, st, src, n, hbits, frame, zero, zero_vecs, grid_log2);
+      else hipLaunchKernelGGL(nms_frame_kernel<2>, dim3(zb), dim3(256), 0, st, src, n, hbits, frame, zero, zero_vecs, grid_log2);
+      OBB_LAUNCH_CHECK();
+      if (kind == OBB_KIND_RBOX) hipLaunchKernelGGL(nms_ginsert_kernel<0>, dim3(pblocks), dim3(256), 0, st, src, n, rec, ar, frame, iou_thr, hist, gtab, ctr);
+      else if (kind == OBB_KIND_POLY) hipLaunchKernelGGL(nms_ginsert_kernel<1>, dim3(pblocks), dim3(256), 0, st, src, n, rec, ar, frame, iou_thr, hist, gtab, ctr);
+      else hipLaunchKernelGGL(nms_ginsert_kernel<2>, dim3(pblocks), dim3(256), 0, st, src, n, rec, ar, frame, iou_thr, hist, gtab, ctr);
+      OBB_LAUNCH_CHECK();
+      OBB_PHASE(1); OBB_PHASE(2);
+      OBB_PHASE(3);
+      hipLaunchKernelGGL(nms_gprobe_kernel, dim3((unsigned)((gcells / 2 + kNmsWaves - 1) / kNmsWaves)), dim3(64 * kNmsWaves), 0, st,
+                         rec, frame, hist, gtab, (uint32_t)gcells, prune_thr, thr_dev ? 1 : 0, flags, edges, segcap, ccnts, cnt, ctr);
+      OBB_LAUNCH_CHECK();
+      OBB_PHASE(4);
+      OBB_PHASE(5);
+      hipLaunchKernelGGL(nms_resolve_kernel<false>, dim3(kShards), dim3(kResolveThreads), 0, st, edges, segcap, cnt, ctr, ccnts, n, keep_dev, result, 1, blockcnt, ucnts);
+      OBB_LAUNCH_CHECK();
+      OBB_PHASE(6);
+      OBB_PHASE(7);
+      return OBB_OK;
+    }
+  }
   // phase 0: prep (+ clears the counters) [+ quantise]
   OBB_PHASE(0);
   // cells ~ n/16 .. n/4, a power of 4 in [4096, 262144]; grouped calls of that size get the next
@@ -2701,16 +2940,17 @@ int nms_enqueue_source(const char *who, NmsSource src, int64_t n, int kind, floa
     OBB_LAUNCH_CHECK();
   } else {
     // frame (sampled, block 0) + clearing of the call's counters, histogram cells and tile-box words
+    const int grid_log2 = kGridMaxLog2;                             // (the grid parameters are not used on this route)
     unsigned zb = (unsigned)((zero_vecs + 1023) / 1024) + 1u;     // (block 0 also takes the frame)
     zb = zb > 256u ? 256u : zb;
     if (kind == OBB_KIND_RBOX)
-      hipLaunchKernelGGL(nms_frame_kernel<0>, dim3(zb), dim3(256), 0, st, src, n, hbits, frame, zero, zero_vecs);
+      hipLaunchKernelGGL(nms_frame_kernel<0>, dim3(zb), dim3(256), 0, st, src, n, hbits, frame, zero, zero_vecs, grid_log2);
     else if (kind == OBB_KIND_POLY)
-      hipLaunchKernelGGL(nms_frame_kernel<1>, dim3(zb), dim3(256), 0, st, src, n, hbits, frame, zero, zero_vecs);
+      hipLaunchKernelGGL(nms_frame_kernel<1>, dim3(zb), dim3(256), 0, st, src, n, hbits, frame, zero, zero_vecs, grid_log2);
     else if (f64)
-      hipLaunchKernelGGL((nms_frame_kernel<2, true>), dim3(zb), dim3(256), 0, st, src, n, hbits, frame, zero, zero_vecs);
+      hipLaunchKernelGGL((nms_frame_kernel<2, true>), dim3(zb), dim3(256), 0, st, src, n, hbits, frame, zero, zero_vecs, grid_log2);
     else
-      hipLaunchKernelGGL(nms_frame_kernel<2>, dim3(zb), dim3(256), 0, st, src, n, hbits, frame, zero, zero_vecs);
+      hipLaunchKernelGGL(nms_frame_kernel<2>, dim3(zb), dim3(256), 0, st, src, n, hbits, frame, zero, zero_vecs, grid_log2);
     OBB_LAUNCH_CHECK();
     if (kind == OBB_KIND_RBOX)
       hipLaunchKernelGGL(nms_prepq_kernel<0>, dim3(pblocks), dim3(256), 0, st, src, n, rec, qb, ar, ckey, crank, hist, hbits, frame, iou_thr);
@@ -2816,12 +3056,13 @@ int nms_enqueue_source(const char *who, NmsSource src, int64_t n, int kind, floa
 static int nms_enqueue(const char *who, const float *dets_dev, int64_t n, int kind, float iou_thr,
                        const int32_t *group_dev, const float *thr_dev, int flags_in,
                        int64_t *keep_dev, NmsHostInfo *result, void *workspace_dev,
-                       size_t workspace_bytes, hipStream_t st, NmsEnqueued &q) {
+                       size_t workspace_bytes, hipStream_t st, NmsEnqueued &q, bool allow_grid = false) {
   NmsSource src = {};
   src.dets = dets_dev;
   src.pitch = kind == OBB_KIND_RBOX ? 6 : (kind == OBB_KIND_POLY ? 9 : 5);
   src.group = group_dev;
   src.thrs = thr_dev;
+  src.allow_grid = allow_grid ? 1 : 0;
   return nms_enqueue_source(who, src, n, kind, iou_thr, flags_in, keep_dev, result, workspace_dev, workspace_bytes, st, q);
 }
 
@@ -2870,9 +3111,21 @@ extern "C" int obb_nms_ex_f32(const float *dets_dev, int64_t n, int kind, float 
   hipStream_t st = (hipStream_t)stream;
   NmsEnqueued q;
   rc = nms_enqueue("obb_nms_f32", dets_dev, n, kind, iou_thr, group_dev, thr_dev, flags, keep_dev, hinfo_dev,
-                   workspace_dev, workspace_bytes, st, q);
+                   workspace_dev, workspace_bytes, st, q, true);
   if (rc != OBB_OK) return rc;
   OBB_HIP_TRY(hipStreamSynchronize(st));
+  g_last_route = q.grid ? 4 : (q.fused ? 0 : (q.direct ? 1 : 2));
+  if (q.grid && hinfo->route == 3u) {
+    g_last_route = 5;
+    // the grid route gave up (a crowded cell, a box over too many cells): the same call on the sorted route, and this
+    // thread's next calls of the size class go there directly
+    grid_skip_put(n, kind);
+    q = NmsEnqueued();
+    rc = nms_enqueue("obb_nms_f32", dets_dev, n, kind, iou_thr, group_dev, thr_dev, flags, keep_dev, hinfo_dev,
+                     workspace_dev, workspace_bytes, st, q, false);
+    if (rc != OBB_OK) return rc;
+    OBB_HIP_TRY(hipStreamSynchronize(st));
+  }
   const NmsHostInfo h = *hinfo;
   NmsProfile &prof = g_prof;
   if (q.timed) {
@@ -2954,6 +3207,8 @@ extern "C" int obb_nms_async_result(const void *result_host, int64_t n, size_t w
                 h.cand_total > h.edges ? h.cand_total : h.edges);
   return rc;
 }
+
+extern "C" int obb_nms_last_route(void) { return obb::g_last_route; }
 
 extern "C" int obb_nms_profile_enable(int on) {
   obb::g_prof.on = on != 0;

@@ -28,6 +28,7 @@ struct NmsSource {
   const int64_t *a64, *b64;    // mode 1: label, patch index
   int64_t mult;                // modes 1, 2: number of classes
   const float *thr_table;      // mode 2 (may be null: one threshold)
+  int allow_grid;              // 1: the caller can repeat the call when the grid route gives up (the synchronous entry points)
   int32_t *gout;               // modes 1, 2: workspace (n)
   float *tout;                 // mode 2 with a table: workspace (n)
 };
@@ -35,7 +36,7 @@ struct NmsSource {
 struct NmsEnqueued {
   unsigned long long cap = 0, segcap = 0;
   unsigned int ucap = 0;
-  bool timed = false, direct = false, fused = false;
+  bool timed = false, direct = false, fused = false, grid = false;
 };
 
 constexpr int kNmsShards = 64;

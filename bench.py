@@ -156,6 +156,7 @@ def bench_all(args):
     for _ in range(args.warmup):
         keep, info = step()
     kept = int(keep.numel())
+    route = int(L.obb_nms_last_route())      # 4: the four-launch grid route (sparse scenes); 2: the sorted route
 
     # per-phase table from a separate, untimed pass (an event between two kernels
     # costs a ~5 us bubble; the timed region only brackets the dominant kernel)
@@ -209,7 +210,7 @@ def bench_all(args):
     rk = None
     if rank == 0 and world == 1 and not args.no_extras:
         rk = roofline_kernels(dev)
-    roof = nms_roofline(n, args.canvas, kept, scan_ms, ms_per_step, rk)
+    roof = nms_roofline(n, args.canvas, kept, scan_ms, ms_per_step, rk, route)
     iou_bytes = 20 * (IOU_M // world + IOU_M) * world + 4 * IOU_M * IOU_M
     roof['iou_rowblock_pairs_per_s'] = round(iou_pairs['cfg'], 1)
     roof['iou_rowblock_hbm_frac'] = round(iou_bytes / (iou_ms['cfg'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
@@ -222,7 +223,8 @@ def bench_all(args):
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': 'rnms: %d theta-OBBs per GPU, canvas %g, w,h~logU(8,128), '
                                'theta~U(-pi/2,0), IoU thr 0.5 (BASELINE configs[1])' % (n, args.canvas),
-                   'boxes_per_gpu': n, 'kept': kept, 'overlap_edges': info[0],
+                   'boxes_per_gpu': n, 'kept': kept, 'nms_route': {0: 'fused', 1: 'direct', 2: 'sorted', 4: 'grid', 5: 'grid->sorted'}.get(route, str(route)),
+                   'overlap_edges': info[0],
                    'resolve_rounds': info[1], 'candidate_pairs': info[2],
                    'parallelism': 'single GPU' if world == 1 else 'replica x%d (no data-path collective)' % world,
                    'iou_workload': 'rbbox_overlaps %d x %d, canvas %d (configs[0] density), rows in %d block(s)' % (IOU_M, IOU_M, IOU_CANVAS, world),
@@ -231,7 +233,8 @@ def bench_all(args):
                    'iou_sparse_workload': 'the same on canvas %d (0.02 %% of the pairs clipped: write bound)' % IOU_SPARSE_CANVAS},
         'roofline': roof,
         'phase_ms': {k: round(float(v), 4) for k, v in zip(
-            ['prep_quant', 'cell_sort', 'permute_cull', 'scan', 'clip', 'resolve', 'compact'], phase_tab)},
+            ['prep_quant' if route != 4 else 'frame_insert', 'cell_sort', 'permute_cull', 'scan' if route != 4 else 'probe_clip', 'clip',
+             'resolve' if route != 4 else 'resolve_compact', 'compact'], phase_tab)},
     }
     if dist is not None:
         out['rccl_ranks'] = dist.get_world_size()
@@ -392,25 +395,28 @@ def hbm_bytes(k):
     return int(2 * k['FETCH_SIZE_KB'] * 1024 + k['WRITE_SIZE_KB'] * 1024)
 
 
-def nms_roofline(n, canvas, kept, scan_ms, step_ms, rk=None):
+def nms_roofline(n, canvas, kept, scan_ms, step_ms, rk=None, route=2):
     """nms_scan_kernel is bound by VALU ISSUE (3 full-rate ops per tested pair plus the
     candidate path), not by HBM: its counter traffic is a few MB per launch.  The rest of the
     call is launch/latency bound (dependent launches of 4-20 us).  Everything is a SCALAR (the
     driver's record keeps scalars of this object only); `rk` = roofline_kernels(), whose HBM-bound
     kernels are flattened in beside it."""
     wl = 'nms_%d_%g' % (n, canvas)
-    k = kernel_counters('nms_scan_kernel', wl)
+    kname = 'nms_gprobe_kernel' if route == 4 else 'nms_scan_kernel'      # the dominant kernel of the route the call took
+    k = kernel_counters(kname, wl)
     c = load_counters()
     words = (n + 63) // 64
     r = {
-        'kernel': 'nms_scan_kernel', 'bound': 'valu_issue', 'unit': 'G wave-instr/s',
+        'kernel': kname, 'bound': 'valu_issue', 'unit': 'G wave-instr/s',
         'achieved': None, 'peak': round(VALU_PEAK_GINST, 1), 'frac': None, 'traffic': None,
         'kernel_ms': round(scan_ms, 4),
         'compulsory_bytes_whole_call': 24 * n + 8 * kept,
         # SURVEY 8(d)'s model of the REFERENCE algorithm (n x n/64 bit mask written, kept rows
         # read back): what this pipeline avoids moving -- not an achieved rate
         'reference_algorithm_bytes': 24 * n + 4 * n * words + 4 * kept * words + 8 * kept,
-        'note': 'VALU-issue bound kernel in a latency-bound call; HBM fracs beside it',
+        'note': ('grid route (frame, insert, probe + clip, resolve + compaction): pair tests of a half-wave per cell and the clip of the '
+                 'candidates; a latency-bound call; HBM fracs beside it') if route == 4 else
+                'VALU-issue bound kernel in a latency-bound call; HBM fracs beside it',
         'counters': c['_file'] if (c and k) else None,
     }
     if k and scan_ms > 0:

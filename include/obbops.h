@@ -570,8 +570,12 @@ OBB_API int obb_head_gather_decode_f32(const float *rois_dev, const float *cls_s
 #define OBB_TUNE_SOFT_NMS_REG 9       /* 1: float Soft-NMS through the register-resident kernel (the float64 one), n <= 8192 */
 #define OBB_TUNE_NMS_FUSED_COMPACT 10  /* 0: the sorted route's compaction as a launch of its own (as from 2^18 boxes on); 2: the waiting shards give up at once */
 #define OBB_TUNE_RROI_PLAN 11          /* fewest RoIs the workspace forward of RoI-Align plans per RoI (default 1024; 0 = always) */
-#define OBB_TUNE_COUNT 12
+#define OBB_TUNE_NMS_GRID 12           /* grid route of the NMS: 0 never, 1 wherever it applies (ignoring the thread's skip hints); default auto */
+#define OBB_TUNE_COUNT 13
 OBB_API int obb_set_tuning(int knob, int64_t value);
+/* which route the calling thread's last synchronous obb_nms_*_f32 call took: 0 fused (one workgroup), 1 direct, 2 sorted,
+ * 4 grid, 5 grid gave up (crowded cell) and the call was repeated on the sorted route; -1 none yet */
+OBB_API int obb_nms_last_route(void);
 
 #ifdef __cplusplus
 }

@@ -47,18 +47,22 @@ def hbb_to_rbox(b, rot=False):
 
 @pytest.fixture
 def nms_route():
-    """`nms_route('fused' | 'direct' | 'sorted' | 'listed' | 'auto')` forces the NMS code path through
+    """`nms_route('fused' | 'direct' | 'sorted' | 'listed' | 'grid' | 'auto')` forces the NMS code path through
     the library's tuning hooks (include/obbops.h, obb_set_tuning); defaults are restored afterwards.
     'sorted' = spatial sort with the candidates clipped in line by the scan, 'listed' = spatial sort
     with the candidate lists and the separate clip launch (the default above 65 536 boxes)."""
     from aidet_amd import _lib
 
     def force(route):
-        fused = {'fused': 1024, 'direct': 0, 'sorted': 0, 'listed': 0, 'auto': -1}[route]
-        direct = {'fused': -1, 'direct': 65536, 'sorted': 0, 'listed': 0, 'auto': -1}[route]
-        inline = {'fused': -1, 'direct': -1, 'sorted': 1 << 40, 'listed': 0, 'auto': -1}[route]
+        fused = {'fused': 1024, 'direct': 0, 'sorted': 0, 'listed': 0, 'grid': 0, 'auto': -1}[route]
+        direct = {'fused': -1, 'direct': 65536, 'sorted': 0, 'listed': 0, 'grid': 0, 'auto': -1}[route]
+        inline = {'fused': -1, 'direct': -1, 'sorted': 1 << 40, 'listed': 0, 'grid': 0, 'auto': -1}[route]
+        # 'grid': the uniform-grid route wherever it applies (ungrouped float calls of 256 .. 2^18 - 1 boxes through the
+        # synchronous entry points; a scene it gives up on is repeated on the sorted route); off for 'sorted' / 'listed'
+        grid = {'fused': -1, 'direct': -1, 'sorted': 0, 'listed': 0, 'grid': 1, 'auto': -1}[route]
         _lib.set_tuning(_lib.TUNE_NMS_FUSED_MAX, fused)
         _lib.set_tuning(_lib.TUNE_NMS_DIRECT_MAX, direct)
         _lib.set_tuning(_lib.TUNE_NMS_INLINE_MAX, inline)
+        _lib.set_tuning(_lib.TUNE_NMS_GRID, grid)
     yield force
     force('auto')

@@ -54,7 +54,7 @@ def test_fuzz_rnms_all_routes(block, nms_route):
         strict = it % 9 == 0
         ref = oracle.rnms(d, thr, groups=groups, thrs=thrs, strict=strict)
         dt = t(d)
-        for route in ('auto', 'sorted', 'listed', 'direct', 'fused'):
+        for route in ('auto', 'sorted', 'listed', 'direct', 'fused', 'grid'):
             if route == 'fused' and len(d) > 1024:
                 continue
             nms_route(route)
@@ -69,7 +69,7 @@ def test_fuzz_rnms_all_routes(block, nms_route):
             if it % 2:
                 h[:, :4] = np.round(h[:, :4])        # integer boxes: IoU == thr happens
             h = h.astype(np.float32)
-            for route in ('auto', 'sorted', 'listed', 'direct'):
+            for route in ('auto', 'sorted', 'listed', 'direct', 'grid'):
                 nms_route(route)
                 got = nms(t(h), thr, groups=groups, strict=strict)[1].cpu().numpy()
                 mismatches += not np.array_equal(got, oracle.hbb_nms(h, thr, groups=groups, strict=strict))

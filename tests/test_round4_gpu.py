@@ -322,3 +322,58 @@ def test_planned_roi_forward_is_bit_equal_to_the_unplanned_one():
             _lib.set_tuning(_lib.TUNE_RROI_PLAN, -1)
     assert torch.equal(got[0][0], got[1 << 30][0]) and torch.equal(got[0][1], got[1 << 30][1])
     assert float(got[0][0].abs().sum()) > 0 and bool((got[0][0][5] == 0).all())
+
+
+def test_grid_route_is_exact_and_gives_up_on_crowded_scenes(nms_route):
+    """The uniform-grid route (frame -> insert -> probe + clip -> resolve + compaction: four launches): bit-exact with
+    the oracle / the sorted route on sparse scenes incl. polygons, horizontal boxes, per-box thresholds, far outliers,
+    non-finite rows and boxes that touch many cells; a crowded scene (every cell over capacity) makes it give up -- the
+    call is repeated on the sorted route (same result) and the thread skips the grid for the size class afterwards."""
+    from aidet_amd import _lib, nms, poly_nms, rnms
+    from aidet_amd.nms_wrapper import _run_nms
+    L = _lib.lib()
+    rng = np.random.default_rng(31)
+    # sparse scenes of several sizes: the grid serves them
+    for n, canvas in ((300, 2000), (5000, 6000), (20000, 9000), (100000, 20000), (200000, 30000)):
+        d = oracle.synth_boxes(n, canvas, 40 + n % 7)
+        if n == 5000:
+            d[7] = [np.nan, 5, 5, 5, 0, 0.9]; d[8] = [100, 100, 0, 0, 0, 0.8]; d[9] = [3e7, -2e7, 20, 30, -0.3, 0.7]   # NaN, empty, far away
+            d[10, 2:5] = [2500.0, 40.0, 0.0]                                           # a long box over ~20 cells
+        nms_route('grid')
+        got = rnms(t(d), 0.5)[1].cpu().numpy()
+        route = L.obb_nms_last_route()
+        nms_route('sorted')
+        want = rnms(t(d), 0.5)[1].cpu().numpy()
+        assert L.obb_nms_last_route() == 2
+        assert np.array_equal(got, want), n
+        assert route == 4, (n, route)
+        if n <= 20000:
+            assert np.array_equal(got, oracle.rnms(d, 0.5)), n
+    # a box that touches more cells than an entry list may hold gives the route up: same result through the sorted route
+    d = oracle.synth_boxes(5000, 6000, 9)
+    d[11, 2:5] = [3000.0, 2500.0, -0.7]
+    nms_route('grid')
+    got = rnms(t(d), 0.5)[1].cpu().numpy()
+    assert L.obb_nms_last_route() == 5 and np.array_equal(got, oracle.rnms(d, 0.5))
+    # other kinds, per-box thresholds, strict
+    d = oracle.synth_boxes(6000, 8000, 3)
+    p = np.concatenate([oracle.rbox_to_poly(d).astype(np.float32), d[:, 5:6]], 1)
+    h = np.stack([d[:, 0] - d[:, 2], d[:, 1] - d[:, 3], d[:, 0] + d[:, 2], d[:, 1] + d[:, 3], d[:, 5]], 1).astype(np.float32)
+    h[:, :4] = np.round(h[:, :4])
+    thrs = rng.choice([0.2, 0.5, 0.7], len(d)).astype(np.float32)
+    nms_route('grid')
+    assert np.array_equal(poly_nms(t(p), 0.4)[1].cpu().numpy(), oracle.poly_nms(p, 0.4)) and L.obb_nms_last_route() == 4
+    assert np.array_equal(nms(t(h), 0.5)[1].cpu().numpy(), oracle.hbb_nms(h, 0.5)) and L.obb_nms_last_route() == 4
+    assert np.array_equal(rnms(t(d), 0.5, thrs=thrs, strict=True)[1].cpu().numpy(), oracle.rnms(d, 0.5, thrs=thrs, strict=True))
+    # grouped calls never take the grid
+    g = rng.integers(0, 5, len(d)).astype(np.int32)
+    assert np.array_equal(rnms(t(d), 0.5, groups=g)[1].cpu().numpy(), oracle.rnms(d, 0.5, groups=g)) and L.obb_nms_last_route() == 2
+    # a crowded scene: 20 000 boxes on a 600 px canvas
+    dense = oracle.synth_boxes(20000, 600, 5)
+    nms_route('grid')
+    got = rnms(t(dense), 0.5)[1].cpu().numpy()
+    assert L.obb_nms_last_route() == 5
+    assert np.array_equal(got, oracle.rnms(dense, 0.5))
+    nms_route('auto')
+    _run_nms(t(dense), _lib.KIND_RBOX, 0.5)
+    assert L.obb_nms_last_route() == 2            # (the thread remembers: straight to the sorted route)
