@@ -118,7 +118,7 @@ def roi_forward(feats, rois, levels, out_h, out_w, scales, sample_num, roi_kind,
     # overhead of a 40 us kernel: no allocation, no context manager unless the device has to be switched)
     ws_ptr, ws_bytes = None, 0
     if K >= ORDER_MIN_ROIS:
-        ws = torch.empty(8 * K + 256, dtype=torch.uint8, device=dev)
+        ws = torch.empty(int(L.obb_roi_forward_workspace_bytes(K)), dtype=torch.uint8, device=dev)      # (order + per-RoI plan records)
         ws_ptr, ws_bytes = ws.data_ptr(), ws.numel()
     cur = torch.cuda.current_device()
     if cur != dev.index:
