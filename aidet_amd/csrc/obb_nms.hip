@@ -782,7 +782,7 @@ constexpr int kGridCap = 32;             // entries per cell
 constexpr int kGridMaxCells = 64;        // cells one box may touch
 constexpr int kGridMaxLog2 = 8;          // at most 256 x 256 cells
 constexpr int kGridSkipCalls = 256;
-constexpr int64_t kGridAutoMax = 150000;
+constexpr int64_t kGridAutoMax = 131072;
 
 template <int KIND>
 __global__ __launch_bounds__(256) void nms_ginsert_kernel(const NmsSource src, int64_t n, QuadRec *__restrict__ rec,
@@ -2579,7 +2579,7 @@ static int nms_layout(int64_t n, int64_t edge_capacity, NmsLayout &L) {
   L.gtab = off;
   if (n >= 256 && n < (1 << 18)) {
     int g = 6;
-    while (g < kGridMaxLog2 && (1ll << (2 * g)) * 2 < n) ++g;
+    while (g < kGridMaxLog2 && (1ll << (2 * g)) * 2 < n) ++g;      // (x 8 instead of x 2 -- a quarter of the probe's waves -- measured no faster: the cell size follows the extents, not this bound)
     L.grid_log2 = g;
     L.gtab = take(((size_t)1 << (2 * g)) * kGridCap * sizeof(uint4));
   }
@@ -2880,7 +2880,8 @@ int nms_enqueue_source(const char *who, NmsSource src, int64_t n, int kind, floa
   {
     const int64_t gknob = tuning(OBB_TUNE_NMS_GRID, -1);          // -1 auto, 0 never, 1 wherever it applies
     // (auto: up to kGridAutoMax boxes -- with at most 256 x 256 cells a larger scene crowds them: 200k boxes measured 131 us
-    // on the grid against 125 us sorted; 100k: 71 vs 95, 50k: 65 vs 78, 20k: 52 vs 71, 12k: 51 vs 69)
+    // on the grid against 125 us sorted and 150k boxes at the headline's density overflow a cell; 100k: 71 vs 95, 50k: 65 vs 78,
+    // 20k: 52 vs 71, 12k: 51 vs 69)
     const bool grid = !direct && L.grid_log2 > 0 && n > direct_max && !group_dev && src.mode == 0 && !f64 && src.allow_grid != 0 &&
                       gknob != 0 && (gknob == 1 || (n <= kGridAutoMax && !grid_skip_take(n, kind)));
     q.grid = grid;
