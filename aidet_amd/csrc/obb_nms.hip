@@ -767,12 +767,12 @@ __global__ __launch_bounds__(256) void nms_prepq_kernel(const NmsSource src, int
 // canvas).  The sorted route pays four launches (frame, prepq, sort-scatter, cull-box) before its first pair test to
 // be distribution-proof; a uniform grid needs none of that when no cell is crowded:
 //   insert   per box: the 64-byte record (as nms_prep_kernel), the packed 15-bit interval, and one 16-byte entry
-//            (interval, box id) into every cell its interval touches -- cells = the quantisation coarsened by a power of
+//            (interval, box id, area) into every cell its interval touches -- cells = the quantisation coarsened by a power of
 //            two, about one mean + sigma extent wide (nms_frame_kernel), fixed capacity kGridCap per cell;
-//   probe    thread = box a: the entries b > a of every cell it touches, four at a time; a pair whose intervals meet is
-//            a candidate IN ONE CELL ONLY -- the one that holds the lower corner of the intersection of the two intervals
-//            (both boxes touch it: the cell function is monotone) -- and goes through the same per-wave queue, pruning
-//            and clip as the direct route (DirectSink::flush); the edges are what every route produces;
+//   probe    a wave per chunk of 2-8 cells, a lane per pair of entries of one cell (nms_gprobe_kernel); a pair whose
+//            intervals meet is a candidate IN ONE CELL ONLY -- the one that holds the lower corner of the intersection of
+//            the two intervals (both boxes touch it: the cell function is monotone) -- and goes through the same per-wave
+//            queue, pruning and clip as the direct route (DirectSink::flush); the edges are what every route produces;
 //   resolve  nms_resolve_kernel<false> with its fused compaction.
 // A crowded cell (more than kGridCap entries) or a box that touches more than kGridMaxCells cells raises `grid_fail`:
 // the call's record says route 3, the synchronous entry points repeat the call on the sorted route and the calling
@@ -832,7 +832,7 @@ __global__ __launch_bounds__(256) void nms_ginsert_kernel(const NmsSource src, i
           for (uint32_t cx = cx0; cx <= cx1; ++cx) {
             const uint32_t cell = cy * (uint32_t)fr.ggx + cx;
             const uint32_t slot = atomicAdd(&gcnt[cell], 1u);
-            if (slot < (uint32_t)kGridCap) gtab[(size_t)cell * kGridCap + slot] = make_uint4(o.x, o.y, (uint32_t)b, 0u);
+            if (slot < (uint32_t)kGridCap) gtab[(size_t)cell * kGridCap + slot] = make_uint4(o.x, o.y, (uint32_t)b, __float_as_uint(r.area));
             else ctr->grid_fail = 1u;
           }
       }
@@ -1601,6 +1601,16 @@ __device__ __forceinline__ bool prune_aabb_f(const Prune &pr, float4 a, float ra
   return I * (1.0f + pr.thr) >= (pr.thr * (ra + ca)) * 0.999999f;
 }
 
+// Instrumented build only (-DOBB_GPROBE_STAMPS, tools/exp_gprobe_stamps.py): shader-clock stamps of every wave of the
+// grid route's probe kernel, read back with obb_debug_gprobe_stamps (not part of the ABI).
+#ifdef OBB_GPROBE_STAMPS
+__device__ unsigned long long g_gprobe_stamps[32768 * 10];
+#define GP_STAMP(i) do { const uint32_t gw_ = blockIdx.x * kNmsWaves + (threadIdx.x >> 6); if ((threadIdx.x & 63) == 0 && gw_ < 32768u) { \
+  g_gprobe_stamps[gw_ * 10 + (i)] = ((i) >= 8) ? wall_clock64() : __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define GP_STAMP(i) do { } while (0)
+#endif
+
 struct DirectSink {
   Prune pr;
   bool per_box_thr;                         // thresholds come from the records (pr.thr unused)
@@ -1642,12 +1652,15 @@ struct DirectSink {
       if (keep && p.thr > 0.0f) keep = prune_area(p, A.area, B.area) && prune_aabb_f(p, a, A.area, b, B.area);
     }
     const uint64_t mk = __ballot(keep);
+    GP_STAMP(4);
     if (mk == 0) return;
     if (lane == 0) atomicAdd(ccnt, (unsigned long long)__popcll(mk));
     bool hit = false;
     uint32_t src = 0, dst = 0;
     if (keep) hit = clip_loaded(A, B, ka, kb, ga, gb, ta, tb, e, flags, src, dst, klo);
+    GP_STAMP(5);
     push_edges(hit, src, dst, eseg, segcap, ecnt, cnt, lane);
+    GP_STAMP(6);
   }
 };
 
@@ -1738,13 +1751,27 @@ __global__ __launch_bounds__(64 * kNmsWaves) void nms_scan_direct_kernel(const f
   }
 }
 
-// ---- 7: clip kernel -----------------------------------------------------------------------
-// One candidate pair per lane.  The edge points from the box that PRECEDES in the
-// grid route, probe + clip: see nms_ginsert_kernel.  A HALF-WAVE owns one cell (32 lanes = the cell's kGridCap entry
-// slots, one coalesced 512-byte read); every entry u of the cell is broadcast to its half-wave in turn and lane s tests
-// the pair (s, u) for u > s: each pair of a cell once.  Two dependent round trips per wave (the cell's count, its
-// entries) -- the first version walked a box's cells and their entries from the box's own thread: up to 27 dependent
-// round trips per wave, 42 us at 100k boxes.
+// ---- 6b: grid route, probe + clip -----------------------------------------------------------
+// See nms_ginsert_kernel.  A wave owns a CHUNK of 2, 4 or 8 consecutive cells (by the number of cells the frame kernel laid
+// out: about 2 048 chunks or more whenever there are that many cells): it stages the chunk's entries in LDS (one
+// coalesced 512-byte read per cell), numbers the pairs (s < u) of every cell of the chunk consecutively and gives ONE
+// PAIR TO A LANE -- 64 pair tests per step whatever the cells hold.  (The second version gave a cell to a half-wave and
+// broadcast entry u to lanes s < u: m - 1 steps for a cell of m entries with m / 64 of the lanes on a pair, 46 % of a
+// 30 us kernel at 100k boxes by the stamps of tools/exp_gprobe_stamps.py; the first walked a box's cells from the box's
+// own thread: 27 dependent round trips, 42 us.)  A pair is tested where the table entries allow it -- packed intervals
+// meet, this cell owns the pair, and for a call with ONE threshold the two bounds of the sorted route's scan (area ratio,
+// overlap of the quantised intervals; the entry carries the box's area) -- so that the queue holds pairs that are nearly
+// all clipped: DirectSink::flush loads two 64-byte records per pair and runs the clip for a full wave or not at all.
+#ifndef OBB_GPROBE_C8
+#define OBB_GPROBE_C8 8192
+#endif
+constexpr int kGridCpwMax = 8;                    // cells per chunk at most
+constexpr uint32_t kGridCpw8 = OBB_GPROBE_C8;     // cells laid out from which a chunk is 8 cells
+constexpr uint32_t kGridCpw4 = 2048;              // ... 4 cells
+constexpr int kGridProbeWaves = 4096;             // most waves of the probe launch (a wave strides over the chunks)
+
+__host__ __device__ inline uint32_t grid_chunk_log2(uint32_t cells) { return cells >= kGridCpw8 ? 3u : (cells >= kGridCpw4 ? 2u : 1u); }
+
 __global__ __launch_bounds__(64 * kNmsWaves) void nms_gprobe_kernel(const QuadRec *__restrict__ rec,
                                                            const NmsFrame *__restrict__ frame,
                                                            const uint32_t *__restrict__ gcnt, const uint4 *__restrict__ gtab,
@@ -1752,24 +1779,26 @@ __global__ __launch_bounds__(64 * kNmsWaves) void nms_gprobe_kernel(const QuadRe
                                                            uint2 *__restrict__ edges, unsigned long long segcap,
                                                            unsigned long long *__restrict__ ccnts, int *__restrict__ cnt,
                                                            const NmsCounters *__restrict__ ctr) {
-  static_assert(kGridCap == 32, "a half-wave per cell");
+  static_assert(kGridCap == 32, "two cells per 64-lane load");
   __shared__ uint2 queue[kNmsWaves][kNmsQueue];
+  __shared__ uint4 ent[kNmsWaves][kGridCpwMax * kGridCap];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const uint32_t gw = blockIdx.x * kNmsWaves + wave;
-  const uint32_t cell = gw * 2u + (uint32_t)(lane >> 5);
-  const int s = lane & 31;
-  const uint32_t c = cell < ncells ? gcnt[cell] : 0u;
-  const int m = (int)(c < (uint32_t)kGridCap ? c : (uint32_t)kGridCap);
-  const int m0 = __builtin_amdgcn_readlane(m, 0), m1 = __builtin_amdgcn_readlane(m, 32);
-  const int mmax = m0 > m1 ? m0 : m1;
-  if (mmax < 2) return;                                        // (wave-uniform) no pair in either cell
-  if (__hip_atomic_load(&ctr->grid_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;   // the call is repeated on the sorted route
+  const uint32_t gw = blockIdx.x * kNmsWaves + wave, nw = gridDim.x * kNmsWaves;
+  GP_STAMP(8);
+  GP_STAMP(0);
   const NmsFrame fr = *frame;
-  const uint4 e = s < m ? gtab[(size_t)cell * kGridCap + s] : make_uint4(kSentLo, kSentHi, 0u, 0u);
-  const uint32_t ccy = cell / (uint32_t)fr.ggx, ccx = cell - ccy * (uint32_t)fr.ggx;
-  const uint32_t axl = e.x & 0x7FFFu, ayl = (e.x >> 16) & 0x7FFFu;
+  // the cells the frame kernel laid out are [0, ggx * ggy), ggx = 2^(15 - gshx): the launch is sized for the largest
+  // grid, the chunks for the one that exists (the headline: 128 x 128 of at most 256 x 256 cells)
+  const uint32_t used = (uint32_t)fr.ggx * (uint32_t)fr.ggy;
+  const uint32_t cells = used < ncells ? used : ncells;
+  const uint32_t cl = grid_chunk_log2(cells);
+  const uint32_t chunks = (cells + (1u << cl) - 1u) >> cl;
+  if (gw >= chunks) return;
+  if (__hip_atomic_load(&ctr->grid_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;   // the call is repeated on the sorted route
+  GP_STAMP(1);
   uint2 *q = queue[wave];
+  uint4 *ew = ent[wave];
   int qn = 0;
   const int shard = (int)(gw & (kShards - 1));
   DirectSink sink;
@@ -1782,36 +1811,101 @@ __global__ __launch_bounds__(64 * kNmsWaves) void nms_gprobe_kernel(const QuadRe
   sink.ccnt = ccnts + (size_t)shard * kCandStride;
   sink.ecnt = ccnts + (size_t)(kShards + shard) * kCandStride;
   sink.cnt = cnt;
+  Prune tp;                                       // bounds applied to the table entries (off for per-box thresholds: the records hold those)
+  tp.thr = per_box_thr ? 0.0f : thr; tp.cpx = fr.cpx; tp.cpy = fr.cpy;
   const uint64_t lt_mask = (1ull << lane) - 1ull;
-  const int half = lane & 32;
-  for (int u = 1; u < mmax; ++u) {
-    // entry u of this lane's cell, broadcast inside the half-wave
-    // (u is wave-uniform: two v_readlane per word and a select, not three LDS-crossbar permutes per step)
-    const uint32_t bx = half ? (uint32_t)__builtin_amdgcn_readlane((int)e.x, 32 + u) : (uint32_t)__builtin_amdgcn_readlane((int)e.x, u);
-    const uint32_t by = half ? (uint32_t)__builtin_amdgcn_readlane((int)e.y, 32 + u) : (uint32_t)__builtin_amdgcn_readlane((int)e.y, u);
-    const uint32_t bz = half ? (uint32_t)__builtin_amdgcn_readlane((int)e.z, 32 + u) : (uint32_t)__builtin_amdgcn_readlane((int)e.z, u);
-    // a candidate of THIS cell: the intervals meet and the cell holds the lower corner of their intersection (the one cell
-    // of all that both boxes touch where the pair is reported)
-    const uint32_t bxl = bx & 0x7FFFu, byl = (bx >> 16) & 0x7FFFu;
-    const uint32_t ox = (axl > bxl ? axl : bxl) >> fr.gshx, oy = (ayl > byl ? ayl : byl) >> fr.gshy;
-    const bool cnd = s < u && u < m && qdisjoint(e.x, e.y, bx, by) == 0u && ox == ccx && oy == ccy;
-    const uint64_t mc = __ballot(cnd);
-    if (mc) {
-      if (cnd) q[qn + __popcll(mc & lt_mask)] = make_uint2(e.z, bz);
-      qn += __popcll(mc);
-      if (qn >= 64) {
-        qn -= 64;
-        __builtin_amdgcn_wave_barrier();
-        sink.flush(q + qn, 64, lane);
+  const int s32 = lane & 31, hi = lane >> 5;
+  const uint32_t xmask = (uint32_t)fr.ggx - 1u;
+  const int xbits = 15 - fr.gshx;
+  for (uint32_t chunk = gw; chunk < chunks; chunk += nw) {
+    const uint32_t cell0 = chunk << cl;
+    uint32_t mc = 0;
+    if (lane < (1 << cl) && cell0 + (uint32_t)lane < cells) {
+      const uint32_t c = gcnt[cell0 + lane];
+      mc = c < (uint32_t)kGridCap ? c : (uint32_t)kGridCap;
+    }
+    int m[kGridCpwMax], O[kGridCpwMax + 1];
+    O[0] = 0;
+#pragma unroll
+    for (int k = 0; k < kGridCpwMax; ++k) {
+      m[k] = __builtin_amdgcn_readlane((int)mc, k);
+      O[k + 1] = O[k] + ((m[k] * (m[k] - 1)) >> 1);
+    }
+    const int total = O[kGridCpwMax];
+    if (total == 0) continue;                      // (wave-uniform) no pair in the chunk
+    uint4 e[kGridCpwMax / 2];
+#pragma unroll
+    for (int r = 0; r < kGridCpwMax / 2; ++r) {
+      const int mm = m[2 * r] + hi * (m[2 * r + 1] - m[2 * r]);   // (a select of two array elements becomes an indexed read of a scratch copy)
+      e[r] = make_uint4(0u, 0u, 0u, 0u);
+      if (s32 < mm) e[r] = gtab[(size_t)(cell0 + 2 * r + hi) * kGridCap + s32];
+    }
+#pragma unroll
+    for (int r = 0; r < kGridCpwMax / 2; ++r) ew[r * 64 + lane] = e[r];
+    __builtin_amdgcn_wave_barrier();
+    GP_STAMP(2);
+    for (int p0 = 0; p0 < total; p0 += 64) {
+      const int p = p0 + lane;
+      const bool valid = p < total;
+      int c = 0, oc = 0;
+#pragma unroll
+      for (int k = 1; k < kGridCpwMax; ++k) {
+        const bool ge = p >= O[k];
+        c += ge ? 1 : 0;
+        oc = ge ? O[k] : oc;
+      }
+      // pair number t of a cell -> (s, u), s < u: t = u (u - 1) / 2 + s
+      const int t = valid ? p - oc : 0;
+      int u = (int)((1.0f + __builtin_sqrtf(1.0f + 8.0f * (float)t)) * 0.5f);
+      int tu = (u * (u - 1)) >> 1;
+      if (tu > t) { --u; tu -= u; }
+      else if (tu + u <= t) { tu += u; ++u; }
+      const int sidx = t - tu;
+      const uint4 ea = ew[c * kGridCap + sidx], eb = ew[c * kGridCap + u];
+      // a candidate of THIS cell: the intervals meet and the cell holds the lower corner of their intersection (the one
+      // cell of all that both boxes touch where the pair is reported)
+      const uint32_t cell = cell0 + (uint32_t)c;
+      const uint32_t ccx = cell & xmask, ccy = cell >> xbits;
+      const uint32_t axl = ea.x & 0x7FFFu, ayl = (ea.x >> 16) & 0x7FFFu;
+      const uint32_t bxl = eb.x & 0x7FFFu, byl = (eb.x >> 16) & 0x7FFFu;
+      const uint32_t ox = (axl > bxl ? axl : bxl) >> fr.gshx, oy = (ayl > byl ? ayl : byl) >> fr.gshy;
+      bool cnd = valid && qdisjoint(ea.x, ea.y, eb.x, eb.y) == 0u && ox == ccx && oy == ccy;
+      if (tp.thr > 0.0f) {
+        const float aa = __uint_as_float(ea.w), ab = __uint_as_float(eb.w);
+        cnd = cnd && prune_area(tp, aa, ab) && prune_aabb(tp, ea.x, ea.y, aa, eb.x, eb.y, ab);
+      }
+      const uint64_t mcnd = __ballot(cnd);
+      if (mcnd) {
+        if (cnd) q[qn + __popcll(mcnd & lt_mask)] = make_uint2(ea.z, eb.z);
+        qn += __popcll(mcnd);
+        if (qn >= 64) {
+          qn -= 64;
+          __builtin_amdgcn_wave_barrier();
+          sink.flush(q + qn, 64, lane);
+        }
       }
     }
+    __builtin_amdgcn_wave_barrier();               // (the next chunk's entries overwrite `ew`)
   }
+  GP_STAMP(3);
   if (qn > 0) {
     __builtin_amdgcn_wave_barrier();
     sink.flush(q, qn, lane);
   }
+  GP_STAMP(7);
+  GP_STAMP(9);
 }
 
+#ifdef OBB_GPROBE_STAMPS
+}  // namespace obb
+extern "C" __attribute__((visibility("default"))) int obb_debug_gprobe_stamps(unsigned long long *host, int words) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(obb::g_gprobe_stamps), sizeof(unsigned long long) * (size_t)words);
+}
+namespace obb {
+#endif
+
+// ---- 7: clip kernel -----------------------------------------------------------------------
+// One candidate pair per lane.  The edge points from the box that PRECEDES in the
 // greedy order (smaller score key, then smaller index) to the other one; the clip
 // always takes the preceding box as the subject A, exactly like the i-before-j
 // loop of nms_cpu.cpp:35-58.  grid = (blocks per shard, shards).
@@ -2905,7 +2999,14 @@ int nms_enqueue_source(const char *who, NmsSource src, int64_t n, int kind, floa
       OBB_LAUNCH_CHECK();
       OBB_PHASE(1); OBB_PHASE(2);
       OBB_PHASE(3);
-      hipLaunchKernelGGL(nms_gprobe_kernel, dim3((unsigned)((gcells / 2 + kNmsWaves - 1) / kNmsWaves)), dim3(64 * kNmsWaves), 0, st,
+      // (waves beyond the chunks of the grid that exists leave on the frame record; a wave strides over the chunks when
+      // the launch is capped)
+      size_t gp_waves = gcells >> 1;                                    // the most chunks any number of cells <= gcells makes
+      if (gcells >= kGridCpw4) { gp_waves = gcells >> 2; if (gp_waves < (kGridCpw4 >> 1)) gp_waves = kGridCpw4 >> 1; }
+      if (gcells >= kGridCpw8) { gp_waves = gcells >> 3; if (gp_waves < (kGridCpw8 >> 2)) gp_waves = kGridCpw8 >> 2; }
+      if (gp_waves > (size_t)kGridProbeWaves) gp_waves = kGridProbeWaves;
+      const size_t gp_blocks = (gp_waves + kNmsWaves - 1) / kNmsWaves;
+      hipLaunchKernelGGL(nms_gprobe_kernel, dim3((unsigned)gp_blocks), dim3(64 * kNmsWaves), 0, st,
                          rec, frame, hist, gtab, (uint32_t)gcells, prune_thr, thr_dev ? 1 : 0, flags, edges, segcap, ccnts, cnt, ctr);
       OBB_LAUNCH_CHECK();
       OBB_PHASE(4);

@@ -17,6 +17,7 @@ CUDA kernel uses ``>`` (nms_kernel.cu:61); pass ``strict=True`` to get that comp
 (the two only differ for pairs whose IoU equals the threshold exactly).
 """
 import ctypes
+import os
 import threading
 
 import numpy as np
@@ -106,6 +107,11 @@ def _fast_ext():
     lookup, argument marshalling (12 us of a 110 us call at 100k boxes)."""
     global _ext
     if _ext is False:
+        if os.environ.get('OBBOPS_LIB'):
+            # an alternative build of the library was asked for (A/B measurements): the extension is linked against
+            # the product library and would silently run THAT one
+            _ext = None
+            return _ext
         try:
             from . import torch_ext
             _ext = torch_ext.ext() if hasattr(torch_ext.ext(), 'nms_ex') else None

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Instrumented builds of the library for tools/exp_rroi_ablate.py / exp_rroi_stamps.py (OBB_RROI_ABLATE = 1..5 in
-# aidet_amd/csrc/obb_rroi.hip): aidet_amd/lib/libobbops_abl<n>.so.  Built in scratch copies of csrc/ (the objects of
+# aidet_amd/csrc/obb_rroi.hip): aidet_amd/lib/libobbops_abl<n>.so, and for tools/exp_gprobe_stamps.py
+# (OBB_GPROBE_STAMPS in obb_nms.hip): libobbops_gpst.so.  Built in scratch copies of csrc/ (the objects of
 # the product build are left alone).  The libraries are git-ignored like every *.so and travel with gpurun snapshots.
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
@@ -11,4 +12,10 @@ for a in ${1:-1 3 4 5 6}; do
   make -s -C $d -j8 EXTRA=-DOBB_RROI_ABLATE=$a OUT=$ROOT/aidet_amd/lib/libobbops_abl$a.so
   rm -rf $d
 done
-ls -la $ROOT/aidet_amd/lib/libobbops_abl*.so
+# stamps of the grid route's probe kernel (tools/exp_gprobe_stamps.py)
+d=$(mktemp -d /tmp/obb_gpst_XXXX)
+cp $ROOT/aidet_amd/csrc/*.hip $ROOT/aidet_amd/csrc/*.h $ROOT/aidet_amd/csrc/Makefile $d/
+sed -i "s#\.\./\.\./include#$ROOT/include#g" $d/Makefile $d/obb_common.h
+make -s -C $d -j8 EXTRA=-DOBB_GPROBE_STAMPS OUT=$ROOT/aidet_amd/lib/libobbops_gpst.so
+rm -rf $d
+ls -la $ROOT/aidet_amd/lib/libobbops_abl*.so $ROOT/aidet_amd/lib/libobbops_gpst.so
