@@ -19,6 +19,7 @@ LIB_PATH = os.environ.get('OBBOPS_LIB') or os.path.join(_HERE, 'lib', 'libobbops
 OBB_OK = 0
 OBB_EINVAL = -1
 OBB_EWORKSPACE = -2
+OBB_ERETRY = -4
 OBB_EHIP = -3
 
 KIND_RBOX = 0

@@ -4,6 +4,7 @@
 #include <atomic>
 
 #include "obb_common.h"
+#include "obb_nms_internal.h"
 
 namespace obb {
 
@@ -31,6 +32,7 @@ int64_t tuning(int knob, int64_t def) {
 extern "C" int obb_set_tuning(int knob, int64_t value) {
   if (knob < 0 || knob >= OBB_TUNE_COUNT) return obb::set_err(OBB_EINVAL, "obb_set_tuning: unknown knob %d", knob);
   obb::g_tune[knob].store(value < 0 ? -1 : value, std::memory_order_relaxed);
+  if (knob == OBB_TUNE_NMS_GRID) obb::nms_grid_hints_clear();      // (the calling thread starts afresh: its "skip the grid" notes go)
   return OBB_OK;
 }
 

@@ -333,8 +333,10 @@ struct TiledCaps { unsigned long long cap, segcap; unsigned int ucap; };   // wh
 // K of the phase's NMS as the exchange publishes it: the kept count, or -(a pair capacity that suffices) when the
 // call overflowed its pair lists (every rank sees every rank's word after the all-gather of the counts and repeats
 // the exchange together)
+constexpr int64_t kTiledRepeat = -(1ll << 62);     // (OBB_TILED_REPEAT)
 __device__ __forceinline__ int64_t tiled_k_word(const void *record, const TiledCaps &c) {
   const NmsHostInfo h = *reinterpret_cast<const NmsHostInfo *>(record);
+  if ((h.route & 0xFFu) == 3u) return kTiledRepeat;          // the NMS's grid route gave up: the phase is repeated as it is
   const unsigned long long need = nms_need_capacity(h, c.cap, c.segcap, c.ucap, nullptr);
   return need ? -(int64_t)need : (int64_t)h.kept;
 }
@@ -725,6 +727,7 @@ extern "C" int obb_tiled_local_f32(const float *dets_dev, const int64_t *labels_
   NmsSource src = {};
   src.dets = dets_dev; src.pitch = 6; src.mode = 1;
   src.a64 = labels_dev; src.b64 = patch_index_dev; src.mult = num_classes;
+  src.allow_grid = 1;          // (a phase whose NMS gives up on the grid is repeated by the caller: kTiledRepeat / OBB_ERETRY)
   NmsEnqueued q;
   int rc = nms_enqueue_source(who, src, n, OBB_KIND_RBOX, iou_thr, 0, keep, record, ws + L.nms, workspace_bytes - L.nms, st, q);
   if (rc != OBB_OK) return rc;
@@ -789,6 +792,7 @@ extern "C" int obb_tiled_merge_f32(const float *recv_dev, int64_t m, int cols, i
   }
   NmsSource src = {};
   src.dets = rows; src.pitch = ld; src.mode = 2; src.mult = num_classes; src.thr_table = class_thrs_dev;
+  src.allow_grid = 1;          // (obb_tiled_result says OBB_ERETRY when the grid gave up: the caller repeats the phase)
   NmsEnqueued q;
   int rc = nms_enqueue_source(who, src, total_rows, kind, iou_thr, flags, keep_dev, result_dev, ws + L.nms, workspace_bytes - L.nms, st, q);
   if (rc != OBB_OK) return rc;

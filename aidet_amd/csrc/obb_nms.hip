@@ -102,8 +102,9 @@ struct NmsCounters {
   long long rounds;                        // resolve sweeps (most of any shard)
   unsigned int done;                       // resolve workgroups finished
   unsigned int state;                      // fused resolve + compaction: 0 wait, 1 all shards resolved (go), 2 a waiter gave up
-  unsigned int grid_fail;                  // grid route: a crowded cell / a box over too many cells -- repeat on the sorted route
-  unsigned long long cand_total;           // candidate pairs over all shards
+  unsigned int grid_fail;                  // grid route: too many crowded cells / a box over too many cells -- repeat on the sorted route
+  alignas(256) unsigned int grid_over;     // grid route: entries on the overflow list (may exceed kGridOverCap)
+  alignas(256) unsigned long long cand_total;           // candidate pairs over all shards
   unsigned long long cand_worst;           // fullest shard
 };
 
@@ -780,18 +781,55 @@ __global__ __launch_bounds__(256) void nms_prepq_kernel(const NmsSource src, int
 // =====================================================================================================================
 constexpr int kGridCap = 32;             // entries per cell
 constexpr int kGridMaxCells = 64;        // cells one box may touch
-constexpr int kGridMaxLog2 = 8;          // at most 256 x 256 cells
+constexpr int kGridMaxLog2 = 9;          // at most 512 x 512 cells per group
+constexpr int kGridMaxBits = 20;         // at most 2^20 cells in the table (512 MiB)
+constexpr int kGridOverCap = 4096;       // entries that found their cell full (the overflow list); more: the route gives up
 constexpr int kGridSkipCalls = 256;
-constexpr int64_t kGridAutoMax = 131072;
+constexpr int64_t kGridAutoMax = 1500000;   // (about 10 entries per cell of the largest table: a 33rd entry in one of 2^18 cells is a 1e-3 event)
 
+// GROUPED calls share the table: a group's cells are the spatial grid shifted by a pseudo-random offset that depends on a
+// 16-bit tag of the group id, modulo the table size (a power of two >= the spatial grid: one group's cells never alias
+// each other).  The entry carries the tag: entries of different tags are never paired; two groups of one tag (or that
+// meet in a cell) are told apart by the records, as everywhere (DirectSink::flush).  Ungrouped: tag 0, offset 0.
+__device__ __forceinline__ uint32_t grid_tag(int32_t group) { return group_hash(group) >> 16; }
+__device__ __forceinline__ uint32_t grid_tag_offset(uint32_t tag, uint32_t mask) { return (tag * 0x9E3779B1u >> 8) & mask; }
+// the entry's last word: the upper half of the area's float bits (a lower bound of the area, within 2^-7 of it) | tag
+__device__ __forceinline__ uint32_t grid_entry_word(float area, uint32_t tag) { return (__float_as_uint(area) & 0xFFFF0000u) | tag; }
+
+// (ablation builds for tools/exp: OBB_GINS_ABL 1 = no table stores, 2 = no atomics, 3 = neither)
+#ifndef OBB_GINS_ABL
+#define OBB_GINS_ABL 0
+#endif
+#if OBB_GINS_ABL & 2
+#define GINS_ATOMIC(cnt_, b_, cell_) ((uint32_t)(b_) & 31u)
+#else
+#define GINS_ATOMIC(cnt_, b_, cell_) atomicAdd(&(cnt_)[cell_], 1u)
+#endif
+#if OBB_GINS_ABL & 1
+#define GINS_STORE(tab_, cell_, slot_, e_) do { if ((cell_) == 0xFFFFFFFFu) (tab_)[0] = (e_); } while (0)
+#else
+#define GINS_STORE(tab_, cell_, slot_, e_) (tab_)[(size_t)(cell_) * kGridCap + (slot_)] = (e_)
+#endif
 template <int KIND>
 __global__ __launch_bounds__(256) void nms_ginsert_kernel(const NmsSource src, int64_t n, QuadRec *__restrict__ rec,
                                                           float *__restrict__ ar,
                                                           const NmsFrame *__restrict__ frame, float thr,
                                                           uint32_t *__restrict__ gcnt, uint4 *__restrict__ gtab,
-                                                          NmsCounters *__restrict__ ctr) {
+                                                          NmsCounters *__restrict__ ctr, uint32_t mask,
+                                                          uint4 *__restrict__ gover) {
   constexpr int S = KIND == 0 ? 6 : (KIND == 1 ? 9 : 5);
   const NmsFrame fr = *frame;
+  uint32_t *__restrict__ gover_cell = reinterpret_cast<uint32_t *>(gover + kGridOverCap);
+  // an entry whose cell is full goes on the overflow list (nms_gprobe_kernel pairs it with the cell's entries and with the
+  // list's other entries of the cell); a full list gives the route up
+  auto spill = [&](uint32_t cell, const uint4 &e, uint32_t failword) {
+    const uint32_t o = atomicAdd(&ctr->grid_over, 1u);
+    if (o < (uint32_t)kGridOverCap) { gover[o] = e; gover_cell[o] = cell; }
+    else ctr->grid_fail = failword;
+  };
+  const bool grouped = src_grouped(src);
+  const uint32_t fail = 1u + (uint32_t)KIND + (grouped ? 4u : 0u);   // (non-zero; names the size class's skip hint: kind, grouped)
+  const int xbits = 15 - fr.gshx;                  // ggx = 2^xbits
   auto qz = [](float x, float b, float s2) {
     float u = floorf((x - b) * s2);
     u = u < 0.0f ? 0.0f : (u > (float)kQMax ? (float)kQMax : u);
@@ -806,12 +844,14 @@ __global__ __launch_bounds__(256) void nms_ginsert_kernel(const NmsSource src, i
 #pragma unroll
     for (int k = 0; k < 4; ++k) { r.rx[k] = q.rx[k]; r.ry[k] = q.ry[k]; }
     r.area = q.area; r.skey = score_key(row[S - 1]);
-    r.group = 0;
+    r.group = grouped ? src_group<S>(src, b, row) : 0;
     r.thr = src_thr<S>(src, b, row, thr);
     bool wellformed = true;
     if (KIND == 2) hbb_record(row, r, wellformed);
     rec[b] = r;
     ar[b] = q.area;
+    const uint32_t tag = grouped ? grid_tag(r.group) : 0u;
+    const uint32_t goff = grid_tag_offset(tag, mask);
     float4 v;
     nms_interval(q.ox, q.ex, v.x, v.y);
     nms_interval(q.oy, q.ey, v.z, v.w);
@@ -825,15 +865,31 @@ __global__ __launch_bounds__(256) void nms_ginsert_kernel(const NmsSource src, i
       o.y = (xh | (yh << 16)) | kGuard;
       const uint32_t cx0 = xl >> fr.gshx, cx1 = xh >> fr.gshx, cy0 = yl >> fr.gshy, cy1 = yh >> fr.gshy;
       const uint32_t ncell = (cx1 - cx0 + 1u) * (cy1 - cy0 + 1u);
+      const uint4 ent = make_uint4(o.x, o.y, (uint32_t)b, grid_entry_word(r.area, tag));
       if (ncell > (uint32_t)kGridMaxCells) {
-        ctr->grid_fail = 1u;
+        ctr->grid_fail = fail;
+      } else if (cx1 - cx0 <= 1u && cy1 - cy0 <= 1u) {
+        // the usual box (a cell is about mean + sigma extent wide): 1-4 cells, their slots requested TOGETHER -- a
+        // returning device-scope atomic is a round trip of ~2 us and four of them in a row were most of this kernel
+        const bool two_x = cx1 > cx0, two_y = cy1 > cy0;
+        const uint32_t s00c = ((cy0 << xbits) | cx0) + goff;
+        const uint32_t c00 = s00c & mask, c10 = (s00c + 1u) & mask, c01 = (s00c + (uint32_t)fr.ggx) & mask, c11 = (s00c + (uint32_t)fr.ggx + 1u) & mask;
+        uint32_t s00 = 0, s10 = 0, s01 = 0, s11 = 0;
+        s00 = GINS_ATOMIC(gcnt, b, c00);
+        if (two_x) s10 = GINS_ATOMIC(gcnt, b, c10);
+        if (two_y) s01 = GINS_ATOMIC(gcnt, b, c01);
+        if (two_x && two_y) s11 = GINS_ATOMIC(gcnt, b, c11);
+        if (s00 < (uint32_t)kGridCap) GINS_STORE(gtab, c00, s00, ent); else spill(c00, ent, fail);
+        if (two_x) { if (s10 < (uint32_t)kGridCap) GINS_STORE(gtab, c10, s10, ent); else spill(c10, ent, fail); }
+        if (two_y) { if (s01 < (uint32_t)kGridCap) GINS_STORE(gtab, c01, s01, ent); else spill(c01, ent, fail); }
+        if (two_x && two_y) { if (s11 < (uint32_t)kGridCap) GINS_STORE(gtab, c11, s11, ent); else spill(c11, ent, fail); }
       } else {
         for (uint32_t cy = cy0; cy <= cy1; ++cy)
           for (uint32_t cx = cx0; cx <= cx1; ++cx) {
-            const uint32_t cell = cy * (uint32_t)fr.ggx + cx;
-            const uint32_t slot = atomicAdd(&gcnt[cell], 1u);
-            if (slot < (uint32_t)kGridCap) gtab[(size_t)cell * kGridCap + slot] = make_uint4(o.x, o.y, (uint32_t)b, __float_as_uint(r.area));
-            else ctr->grid_fail = 1u;
+            const uint32_t cell = (((cy << xbits) | cx) + goff) & mask;
+            const uint32_t slot = GINS_ATOMIC(gcnt, b, cell);
+            if (slot < (uint32_t)kGridCap) GINS_STORE(gtab, cell, slot, ent);
+            else spill(cell, ent, fail);
           }
       }
     }
@@ -1778,7 +1834,9 @@ __global__ __launch_bounds__(64 * kNmsWaves) void nms_gprobe_kernel(const QuadRe
                                                            uint32_t ncells, float thr, int per_box_thr, int flags,
                                                            uint2 *__restrict__ edges, unsigned long long segcap,
                                                            unsigned long long *__restrict__ ccnts, int *__restrict__ cnt,
-                                                           const NmsCounters *__restrict__ ctr) {
+                                                           const NmsCounters *__restrict__ ctr, int grouped,
+                                                           const uint4 *__restrict__ gover,
+                                                           const float *__restrict__ thr_table, int thr_count) {
   static_assert(kGridCap == 32, "two cells per 64-lane load");
   __shared__ uint2 queue[kNmsWaves][kNmsQueue];
   __shared__ uint4 ent[kNmsWaves][kGridCpwMax * kGridCap];
@@ -1789,12 +1847,16 @@ __global__ __launch_bounds__(64 * kNmsWaves) void nms_gprobe_kernel(const QuadRe
   GP_STAMP(0);
   const NmsFrame fr = *frame;
   // the cells the frame kernel laid out are [0, ggx * ggy), ggx = 2^(15 - gshx): the launch is sized for the largest
-  // grid, the chunks for the one that exists (the headline: 128 x 128 of at most 256 x 256 cells)
+  // grid, the chunks for the one that exists (the headline: 128 x 128 of at most 512 x 512 cells); the groups of a
+  // grouped call are spread over the whole table
   const uint32_t used = (uint32_t)fr.ggx * (uint32_t)fr.ggy;
-  const uint32_t cells = used < ncells ? used : ncells;
+  const uint32_t cells = (grouped || used >= ncells) ? ncells : used;
+  const uint32_t mask = ncells - 1u;
   const uint32_t cl = grid_chunk_log2(cells);
   const uint32_t chunks = (cells + (1u << cl) - 1u) >> cl;
-  if (gw >= chunks) return;
+  const uint32_t nover_all = ctr->grid_over;                      // (written by the insert launch)
+  const uint32_t nover = nover_all < (uint32_t)kGridOverCap ? nover_all : (uint32_t)kGridOverCap;
+  if (gw >= chunks && gw >= nover) return;
   if (__hip_atomic_load(&ctr->grid_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;   // the call is repeated on the sorted route
   GP_STAMP(1);
   uint2 *q = queue[wave];
@@ -1813,10 +1875,46 @@ __global__ __launch_bounds__(64 * kNmsWaves) void nms_gprobe_kernel(const QuadRe
   sink.cnt = cnt;
   Prune tp;                                       // bounds applied to the table entries (off for per-box thresholds: the records hold those)
   tp.thr = per_box_thr ? 0.0f : thr; tp.cpx = fr.cpx; tp.cpy = fr.cpy;
+  if (thr_table) {
+    // thresholds from a per-class table (NmsSource mode 2): every pair's threshold is one of the table's or the call's
+    // (src_thr) -- the SMALLEST of them bounds the entries (the records decide with the pair's own)
+    float m = thr;
+    bool ok = thr > 0.0f;
+    for (int k = lane; k < thr_count; k += 64) { const float v = thr_table[k]; ok = ok && v > 0.0f; m = v < m ? v : m; }
+    for (int o = 32; o > 0; o >>= 1) { const float v = __shfl_xor(m, o); m = v < m ? v : m; }
+    tp.thr = __ballot(!ok) == 0ull ? m : 0.0f;     // (a threshold <= 0 or NaN: no bound)
+  }
   const uint64_t lt_mask = (1ull << lane) - 1ull;
   const int s32 = lane & 31, hi = lane >> 5;
-  const uint32_t xmask = (uint32_t)fr.ggx - 1u;
   const int xbits = 15 - fr.gshx;
+  // a candidate of THIS cell: one tag, the intervals meet and the cell holds the lower corner of their intersection (the
+  // one cell of all that both boxes touch where the pair is reported); with ONE threshold, the two bounds on the entries
+  auto pair_here = [&](const uint4 &ea, const uint4 &eb, uint32_t cell) {
+    const uint32_t axl = ea.x & 0x7FFFu, ayl = (ea.x >> 16) & 0x7FFFu;
+    const uint32_t bxl = eb.x & 0x7FFFu, byl = (eb.x >> 16) & 0x7FFFu;
+    const uint32_t ox = (axl > bxl ? axl : bxl) >> fr.gshx, oy = (ayl > byl ? ayl : byl) >> fr.gshy;
+    const uint32_t owner = (((oy << xbits) | ox) + grid_tag_offset(ea.w & 0xFFFFu, mask)) & mask;
+    bool cnd = ((ea.w ^ eb.w) & 0xFFFFu) == 0u && qdisjoint(ea.x, ea.y, eb.x, eb.y) == 0u && owner == cell;
+    if (tp.thr > 0.0f) {
+      // the entries hold lower bounds of the areas (the upper 16 bits of the float): the smaller area is at most
+      // 1.0079 x its bound, the sum at least the sum of the bounds -- both bounds stay on the safe side
+      const float aa = __uint_as_float(ea.w & 0xFFFF0000u), ab = __uint_as_float(eb.w & 0xFFFF0000u);
+      cnd = cnd && !(min_sel(aa, ab) * 1.0079f < (tp.thr * max_sel(aa, ab)) * 0.999999f) && prune_aabb(tp, ea.x, ea.y, aa, eb.x, eb.y, ab);   // (prune_area on the bounds)
+    }
+    return cnd;
+  };
+  auto push = [&](bool cnd, uint32_t ia, uint32_t ib) {
+    const uint64_t mcnd = __ballot(cnd);
+    if (mcnd) {
+      if (cnd) q[qn + __popcll(mcnd & lt_mask)] = make_uint2(ia, ib);
+      qn += __popcll(mcnd);
+      if (qn >= 64) {
+        qn -= 64;
+        __builtin_amdgcn_wave_barrier();
+        sink.flush(q + qn, 64, lane);
+      }
+    }
+  };
   for (uint32_t chunk = gw; chunk < chunks; chunk += nw) {
     const uint32_t cell0 = chunk << cl;
     uint32_t mc = 0;
@@ -1862,30 +1960,32 @@ __global__ __launch_bounds__(64 * kNmsWaves) void nms_gprobe_kernel(const QuadRe
       else if (tu + u <= t) { tu += u; ++u; }
       const int sidx = t - tu;
       const uint4 ea = ew[c * kGridCap + sidx], eb = ew[c * kGridCap + u];
-      // a candidate of THIS cell: the intervals meet and the cell holds the lower corner of their intersection (the one
-      // cell of all that both boxes touch where the pair is reported)
-      const uint32_t cell = cell0 + (uint32_t)c;
-      const uint32_t ccx = cell & xmask, ccy = cell >> xbits;
-      const uint32_t axl = ea.x & 0x7FFFu, ayl = (ea.x >> 16) & 0x7FFFu;
-      const uint32_t bxl = eb.x & 0x7FFFu, byl = (eb.x >> 16) & 0x7FFFu;
-      const uint32_t ox = (axl > bxl ? axl : bxl) >> fr.gshx, oy = (ayl > byl ? ayl : byl) >> fr.gshy;
-      bool cnd = valid && qdisjoint(ea.x, ea.y, eb.x, eb.y) == 0u && ox == ccx && oy == ccy;
-      if (tp.thr > 0.0f) {
-        const float aa = __uint_as_float(ea.w), ab = __uint_as_float(eb.w);
-        cnd = cnd && prune_area(tp, aa, ab) && prune_aabb(tp, ea.x, ea.y, aa, eb.x, eb.y, ab);
-      }
-      const uint64_t mcnd = __ballot(cnd);
-      if (mcnd) {
-        if (cnd) q[qn + __popcll(mcnd & lt_mask)] = make_uint2(ea.z, eb.z);
-        qn += __popcll(mcnd);
-        if (qn >= 64) {
-          qn -= 64;
-          __builtin_amdgcn_wave_barrier();
-          sink.flush(q + qn, 64, lane);
-        }
-      }
+      const bool cnd = valid && pair_here(ea, eb, cell0 + (uint32_t)c);
+      push(cnd, ea.z, eb.z);
     }
     __builtin_amdgcn_wave_barrier();               // (the next chunk's entries overwrite `ew`)
+  }
+  // ---- the overflow list: a wave per entry that found its cell full -- against the 32 entries the cell holds, and
+  // against the later entries of the list that belong to the same cell (every pair of a crowded cell once)
+  if (nover > 0u) {
+    const uint32_t *__restrict__ gover_cell = reinterpret_cast<const uint32_t *>(gover + kGridOverCap);
+    for (uint32_t o = gw; o < nover; o += nw) {
+      const uint4 eo = gover[o];
+      const uint32_t cell = gover_cell[o];
+      {
+        uint4 et = make_uint4(kSentLo, kSentHi, 0u, 0u);
+        if (lane < kGridCap) et = gtab[(size_t)cell * kGridCap + lane];
+        push(lane < kGridCap && pair_here(eo, et, cell), eo.z, et.z);
+      }
+      for (uint32_t j0 = o + 1u; j0 < nover; j0 += 64u) {
+        const uint32_t j = j0 + (uint32_t)lane;
+        const bool same = j < nover && gover_cell[j] == cell;
+        if (__ballot(same) == 0ull) continue;
+        uint4 ej = make_uint4(kSentLo, kSentHi, 0u, 0u);
+        if (same) ej = gover[j];
+        push(same && pair_here(eo, ej, cell), eo.z, ej.z);
+      }
+    }
   }
   GP_STAMP(3);
   if (qn > 0) {
@@ -2194,7 +2294,8 @@ __global__ __launch_bounds__(COMPACT ? kResolveThreadsCompact : kResolveThreads)
         hinfo->rounds = (long long)__hip_atomic_load(reinterpret_cast<unsigned long long *>(&ctr->rounds), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         hinfo->cand_total = v; hinfo->cand_worst = mx;
         hinfo->heavy_units = uh; hinfo->light_units = ul;
-        hinfo->route = __hip_atomic_load(&ctr->grid_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 3u : 2u;   // 3: repeat without the grid
+        const unsigned int gf = __hip_atomic_load(&ctr->grid_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        hinfo->route = gf ? (3u | (gf << 8)) : 2u;   // 3: repeat without the grid (bits 8..: which skip hint, nms_ginsert_kernel)
         hinfo->unit_worst = uw;
       }
     }
@@ -2355,7 +2456,7 @@ __global__ __launch_bounds__(1024) void nms_compact_kernel(const int *__restrict
       hinfo->kept = sbase + tot; hinfo->edges = ctr->edges; hinfo->rounds = ctr->rounds;
       hinfo->cand_total = v; hinfo->cand_worst = mx;
       hinfo->heavy_units = uh; hinfo->light_units = ul;
-      hinfo->route = 2u; hinfo->unit_worst = uw;
+      hinfo->route = ctr->grid_fail ? (3u | (ctr->grid_fail << 8)) : 2u; hinfo->unit_worst = uw;   // 3: the grid route gave up -- repeat without it
     }
   }
 }
@@ -2647,6 +2748,8 @@ struct NmsLayout {
   unsigned long long unit_worst;  // kShards x the most units one shard of the unit list can get
   int64_t ntiles;
   int grid_log2;                  // grid route: cells per axis = 2^grid_log2 at most (0: no grid table in this layout)
+  size_t gover;                   // grid route: the overflow list (entries that found their cell full)
+  int grid_bits;                  // ... and 2^grid_bits cells in the table (>= 2 * grid_log2: the groups of a grouped call share it)
 };
 
 static int nms_layout(int64_t n, int64_t edge_capacity, NmsLayout &L) {
@@ -2669,13 +2772,20 @@ static int nms_layout(int64_t n, int64_t edge_capacity, NmsLayout &L) {
   L.gsrc = take(nn * 4);       // per-box group / threshold derived by the prep kernel (NmsSource modes 1, 2)
   L.tsrc = take(nn * 4);
   // grid route: (2^g x 2^g cells) x kGridCap entries of 16 bytes; g from n (about half a cell per box), sizes where the route applies
-  L.grid_log2 = 0;
+  L.grid_log2 = 0; L.grid_bits = 0;
   L.gtab = off;
-  if (n >= 256 && n < (1 << 18)) {
+  if (n >= 256 && n <= (1 << 21)) {
     int g = 6;
     while (g < kGridMaxLog2 && (1ll << (2 * g)) * 2 < n) ++g;      // (x 8 instead of x 2 -- a quarter of the probe's waves -- measured no faster: the cell size follows the extents, not this bound)
-    L.grid_log2 = g;
-    L.gtab = take(((size_t)1 << (2 * g)) * kGridCap * sizeof(uint4));
+    // table: the spatial grid, or -- grouped calls: the groups' grids share the table -- about 2.5 boxes per cell: with
+    // ~1.8 entries per box that is 4.5 entries per cell on average and a 33rd entry (the route gives up) a 6-sigma
+    // event of the compound-Poisson count (2^18 cells for 1.25 M boxes in 24 000 groups: 9.7 on average, dozens of
+    // overflowing cells in every call)
+    int bits = 2 * g;
+    while (bits < kGridMaxBits && ((int64_t)5 << bits) < 2 * n) ++bits;
+    L.grid_log2 = g; L.grid_bits = bits;
+    L.gtab = take(((size_t)1 << bits) * kGridCap * sizeof(uint4));
+    L.gover = take((size_t)kGridOverCap * (sizeof(uint4) + sizeof(uint32_t)));     // overflow entries, then their cells
   }
   L.qs = take((nt * kTile + kRowChunk) * sizeof(uint2));
   L.pf = take((nt * kTile) * sizeof(uint4));
@@ -2700,7 +2810,8 @@ static int nms_layout(int64_t n, int64_t edge_capacity, NmsLayout &L) {
   L.ticket = take(4);                                // nms_cullbox_kernel: tile tickets
   L.tbox = take(nt * sizeof(uint2));                 // (zero = "not published yet" for nms_cullbox_kernel)
   L.tgr = take(nt * sizeof(uint32_t));
-  L.hist = take(kCells * 4);   // (LAST of the zeroed range: only the cells a call uses are cleared)
+  L.hist = take(((size_t)1 << (L.grid_bits > 18 ? L.grid_bits : 18)) * 4);   // (kCells, or the grid route's cell counters; LAST of the zeroed range: only the cells a call uses are cleared)
+  static_assert(kCells == (1 << 18), "hist");
   L.zero_end = off;
   // variable part, all 8-byte entries: [cands | edges | units]; candidates and edges
   // share one capacity, the unit list gets 1/8 of it (never more than unit_worst).
@@ -2771,6 +2882,7 @@ static bool grid_skip_take(int64_t n, int kind) {
     if (h.left > 0 && h.kind == kind && h.bits == bits) { --h.left; return true; }
   return false;
 }
+void nms_grid_hints_clear() { for (GridSkip &h : g_grid_skip) h.left = 0; }
 static void grid_skip_put(int64_t n, int kind) {
   const int bits = size_class(n);
   GridSkip *slot = &g_grid_skip[(unsigned)(bits + 3 * kind) % 8];
@@ -2976,26 +3088,29 @@ int nms_enqueue_source(const char *who, NmsSource src, int64_t n, int kind, floa
     // (auto: up to kGridAutoMax boxes -- with at most 256 x 256 cells a larger scene crowds them: 200k boxes measured 131 us
     // on the grid against 125 us sorted and 150k boxes at the headline's density overflow a cell; 100k: 71 vs 95, 50k: 65 vs 78,
     // 20k: 52 vs 71, 12k: 51 vs 69)
-    const bool grid = !direct && L.grid_log2 > 0 && n > direct_max && !group_dev && src.mode == 0 && !f64 && src.allow_grid != 0 &&
-                      gknob != 0 && (gknob == 1 || (n <= kGridAutoMax && !grid_skip_take(n, kind)));
+    const bool grouped_call = src.mode != 0 || group_dev != nullptr;
+    const bool grid = !direct && L.grid_log2 > 0 && n > direct_max && !f64 && src.allow_grid != 0 &&
+                      gknob != 0 && (gknob == 1 || n <= kGridAutoMax) && !grid_skip_take(n, kind + (grouped_call ? 4 : 0));
     q.grid = grid;
     if (grid) {
-      const size_t gcells = (size_t)1 << (2 * L.grid_log2);
+      const size_t gcells = (size_t)1 << L.grid_bits;
       const size_t zbytes = (L.hist + gcells * sizeof(uint32_t)) - L.zero_begin;      // (the cell counters live in the histogram's memory)
       uint4 *zero = reinterpret_cast<uint4 *>(ws + L.zero_begin);
       const size_t zero_vecs = zbytes / sizeof(uint4);
       unsigned zb = (unsigned)((zero_vecs + 1023) / 1024) + 1u;
       zb = zb > 256u ? 256u : zb;
       uint4 *gtab = reinterpret_cast<uint4 *>(ws + L.gtab);
+      uint4 *gover = reinterpret_cast<uint4 *>(ws + L.gover);
       const int hbits = 7, grid_log2 = L.grid_log2;
       OBB_PHASE(0);
       if (kind == OBB_KIND_RBOX) hipLaunchKernelGGL(nms_frame_kernel<0>, dim3(zb), dim3(256), 0, st, src, n, hbits, frame, zero, zero_vecs, grid_log2);
       else if (kind == OBB_KIND_POLY) hipLaunchKernelGGL(nms_frame_kernel<1>, dim3(zb), dim3(256), 0, st, src, n, hbits, frame, zero, zero_vecs, grid_log2);
       else hipLaunchKernelGGL(nms_frame_kernel<2>, dim3(zb), dim3(256), 0, st, src, n, hbits, frame, zero, zero_vecs, grid_log2);
       OBB_LAUNCH_CHECK();
-      if (kind == OBB_KIND_RBOX) hipLaunchKernelGGL(nms_ginsert_kernel<0>, dim3(pblocks), dim3(256), 0, st, src, n, rec, ar, frame, iou_thr, hist, gtab, ctr);
-      else if (kind == OBB_KIND_POLY) hipLaunchKernelGGL(nms_ginsert_kernel<1>, dim3(pblocks), dim3(256), 0, st, src, n, rec, ar, frame, iou_thr, hist, gtab, ctr);
-      else hipLaunchKernelGGL(nms_ginsert_kernel<2>, dim3(pblocks), dim3(256), 0, st, src, n, rec, ar, frame, iou_thr, hist, gtab, ctr);
+      const uint32_t gmask = (uint32_t)gcells - 1u;
+      if (kind == OBB_KIND_RBOX) hipLaunchKernelGGL(nms_ginsert_kernel<0>, dim3(pblocks), dim3(256), 0, st, src, n, rec, ar, frame, iou_thr, hist, gtab, ctr, gmask, gover);
+      else if (kind == OBB_KIND_POLY) hipLaunchKernelGGL(nms_ginsert_kernel<1>, dim3(pblocks), dim3(256), 0, st, src, n, rec, ar, frame, iou_thr, hist, gtab, ctr, gmask, gover);
+      else hipLaunchKernelGGL(nms_ginsert_kernel<2>, dim3(pblocks), dim3(256), 0, st, src, n, rec, ar, frame, iou_thr, hist, gtab, ctr, gmask, gover);
       OBB_LAUNCH_CHECK();
       OBB_PHASE(1); OBB_PHASE(2);
       OBB_PHASE(3);
@@ -3007,13 +3122,21 @@ int nms_enqueue_source(const char *who, NmsSource src, int64_t n, int kind, floa
       if (gp_waves > (size_t)kGridProbeWaves) gp_waves = kGridProbeWaves;
       const size_t gp_blocks = (gp_waves + kNmsWaves - 1) / kNmsWaves;
       hipLaunchKernelGGL(nms_gprobe_kernel, dim3((unsigned)gp_blocks), dim3(64 * kNmsWaves), 0, st,
-                         rec, frame, hist, gtab, (uint32_t)gcells, prune_thr, thr_dev ? 1 : 0, flags, edges, segcap, ccnts, cnt, ctr);
+                         rec, frame, hist, gtab, (uint32_t)gcells, prune_thr, thr_dev ? 1 : 0, flags, edges, segcap, ccnts, cnt, ctr, grouped_call ? 1 : 0, gover,
+                         src.mode == 2 ? src.thr_table : nullptr, (int)(src.mult < (1 << 20) ? src.mult : (1 << 20)));
       OBB_LAUNCH_CHECK();
       OBB_PHASE(4);
       OBB_PHASE(5);
-      hipLaunchKernelGGL(nms_resolve_kernel<false>, dim3(kShards), dim3(kResolveThreads), 0, st, edges, segcap, cnt, ctr, ccnts, n, keep_dev, result, 1, blockcnt, ucnts);
+      // (the tail of the sorted route: compaction inside the resolve launch below 2^18 boxes, its own launch from there)
+      const int gcoop = n < (1 << 18) ? 1 : 0;
+      hipLaunchKernelGGL(nms_resolve_kernel<false>, dim3(kShards), dim3(kResolveThreads), 0, st, edges, segcap, cnt, ctr, ccnts, n, keep_dev, result, gcoop, blockcnt, ucnts);
       OBB_LAUNCH_CHECK();
       OBB_PHASE(6);
+      if (!gcoop) {
+        const unsigned cblocks = (unsigned)((n + 4095) / 4096);
+        hipLaunchKernelGGL(nms_compact_kernel<4>, dim3(cblocks), dim3(1024), 0, st, cnt, n, blockcnt, keep_dev, ctr, ccnts, ucnts, result);
+        OBB_LAUNCH_CHECK();
+      }
       OBB_PHASE(7);
       return OBB_OK;
     }
@@ -3217,11 +3340,11 @@ extern "C" int obb_nms_ex_f32(const float *dets_dev, int64_t n, int kind, float 
   if (rc != OBB_OK) return rc;
   OBB_HIP_TRY(hipStreamSynchronize(st));
   g_last_route = q.grid ? 4 : (q.fused ? 0 : (q.direct ? 1 : 2));
-  if (q.grid && hinfo->route == 3u) {
+  if (q.grid && (hinfo->route & 0xFFu) == 3u) {
     g_last_route = 5;
     // the grid route gave up (a crowded cell, a box over too many cells): the same call on the sorted route, and this
     // thread's next calls of the size class go there directly
-    grid_skip_put(n, kind);
+    grid_skip_put(n, kind + ((group_dev != nullptr) ? 4 : 0));
     q = NmsEnqueued();
     rc = nms_enqueue("obb_nms_f32", dets_dev, n, kind, iou_thr, group_dev, thr_dev, flags, keep_dev, hinfo_dev,
                      workspace_dev, workspace_bytes, st, q, false);
@@ -3298,6 +3421,12 @@ extern "C" int obb_nms_async_result(const void *result_host, int64_t n, size_t w
   if (n == 0) return OBB_OK;
   NmsHostInfo h;
   memcpy(&h, result_host, sizeof(h));
+  if ((h.route & 0xFFu) == 3u) {
+    // the grid route gave up on this scene: the caller repeats the call (or the tiled phase) as it is, and this thread's
+    // next calls of the size class take the sorted route from the start
+    grid_skip_put(n, (int)(h.route >> 8) - 1);
+    return set_err(OBB_ERETRY, "the grid route gave up on this scene (a crowded cell): repeat the call as it is");
+  }
   NmsLayout L;
   NmsEnqueued q;
   int rc = nms_capacities(n, workspace_bytes, L, q);

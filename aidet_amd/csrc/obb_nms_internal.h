@@ -97,6 +97,9 @@ int nms_enqueue_source(const char *who, NmsSource src, int64_t n, int kind, floa
                        int64_t *keep_dev, void *result, void *workspace_dev, size_t workspace_bytes,
                        hipStream_t st, NmsEnqueued &q);
 
+// forgets the calling thread's "skip the grid route for this size class" notes (obb_set_tuning(OBB_TUNE_NMS_GRID, ..))
+void nms_grid_hints_clear();
+
 // the keep count of a finished call inside its result record (first 8 bytes: long long kept)
 static __device__ __forceinline__ long long nms_record_kept(const void *record) {
   return *reinterpret_cast<const long long *>(record);

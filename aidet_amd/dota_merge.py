@@ -36,6 +36,8 @@ Row layouts (fp32), chosen by the number of columns:
 """
 import ctypes
 
+import numpy as np
+
 import torch
 import torch.distributed as dist
 
@@ -547,6 +549,7 @@ def patch_rows_to_image(dets, labels, patch_index, patch_xy, patch_image, rate=1
 # per kernel.  The step-by-step functions above stay: they are the CPU path of the gloo tests, the specification the
 # GPU tests compare the fused path with, and the route of the ``sharded`` layout.
 # ---------------------------------------------------------------------------------------------------------------
+TILED_REPEAT = -(1 << 62)    # K word of a phase whose NMS must be repeated as it is (the grid route gave up)
 FUSED = True                 # module switch (tests force the step-by-step path with it)
 _phase_ws = {}               # (device index, stream) -> uint8 workspace shared by the phases (stream-ordered)
 _phase_capacity = {}         # (phase, bit length of n) -> pair capacity the last overflowing call needed
@@ -638,6 +641,8 @@ def tiled_merge_phase(recv, seg_starts, key_max, total, num_classes, iou_thr, cl
         with _lib.on_device(dev):
             rec = record.cpu().numpy()                                   # the phase's one host read
         rc = L.obb_tiled_result(rec.ctypes.data, 1, int(total), cols, world, kmax, nbytes, info)
+        if rc == _lib.OBB_ERETRY:             # the NMS's grid route gave up on this scene: once more, as it is
+            continue
         if rc != _lib.OBB_EWORKSPACE:
             _lib.check(rc)
             break
@@ -678,9 +683,17 @@ def _tiled_fused(dets, labels, patch_index, patch_xy, patch_image, num_classes, 
         kwords = [row[route_world + 1] for row in mat]
         if all(k >= 0 for k in kwords):
             break
+        if kwords[rank] == TILED_REPEAT:
+            # this rank's NMS gave up on its grid route (a crowded cell): the library notes it for the thread through
+            # the record (OBB_ERETRY) and the phase is repeated as it is
+            rec = np.asarray(mat[rank][route_world + 2:], dtype=np.int64)
+            info = (ctypes.c_int64 * 4)()
+            nb = int(_lib.lib().obb_tiled_local_workspace_bytes(n, route_world, capacity or 0))
+            assert _lib.lib().obb_tiled_result(rec.ctypes.data, 0, n, 6, route_world, -1, nb, info) == _lib.OBB_ERETRY
+            continue
         # a rank's per-patch NMS overflowed its pair lists (every rank sees it): that rank repeats its phase with the
         # capacity its kernels asked for, everybody repeats the exchange of the counts
-        if kwords[rank] < 0:
+        if TILED_REPEAT < kwords[rank] < 0:
             capacity = max(-kwords[rank], 2 * (capacity or 0))
             _note_capacity(0, n, capacity)
             nbytes = int(_lib.lib().obb_tiled_local_workspace_bytes(n, route_world, capacity))

@@ -59,6 +59,10 @@ extern "C" {
 #define OBB_EINVAL (-1)     /* bad argument                                   */
 #define OBB_EWORKSPACE (-2) /* workspace too small; see obb_nms_f32           */
 #define OBB_EHIP (-3)       /* a HIP runtime call failed                      */
+#define OBB_ERETRY (-4)     /* obb_nms_async_result / obb_tiled_result: the call's fast route gave up on this scene
+                               (the uniform grid of the NMS: a crowded cell) -- repeat the call, or the tiled phase, as it
+                               is: the library has noted it for the calling thread and takes the general route.  The
+                               synchronous entry points repeat by themselves and never return this.                    */
 
 #define OBB_KIND_RBOX 0
 #define OBB_KIND_POLY 1

@@ -365,15 +365,102 @@ def test_grid_route_is_exact_and_gives_up_on_crowded_scenes(nms_route):
     assert np.array_equal(poly_nms(t(p), 0.4)[1].cpu().numpy(), oracle.poly_nms(p, 0.4)) and L.obb_nms_last_route() == 4
     assert np.array_equal(nms(t(h), 0.5)[1].cpu().numpy(), oracle.hbb_nms(h, 0.5)) and L.obb_nms_last_route() == 4
     assert np.array_equal(rnms(t(d), 0.5, thrs=thrs, strict=True)[1].cpu().numpy(), oracle.rnms(d, 0.5, thrs=thrs, strict=True))
-    # grouped calls never take the grid
+    # grouped calls take it too (test_grid_route_serves_grouped_calls)
     g = rng.integers(0, 5, len(d)).astype(np.int32)
-    assert np.array_equal(rnms(t(d), 0.5, groups=g)[1].cpu().numpy(), oracle.rnms(d, 0.5, groups=g)) and L.obb_nms_last_route() == 2
+    assert np.array_equal(rnms(t(d), 0.5, groups=g)[1].cpu().numpy(), oracle.rnms(d, 0.5, groups=g)) and L.obb_nms_last_route() == 4
     # a crowded scene: 20 000 boxes on a 600 px canvas
     dense = oracle.synth_boxes(20000, 600, 5)
     nms_route('grid')
     got = rnms(t(dense), 0.5)[1].cpu().numpy()
     assert L.obb_nms_last_route() == 5
     assert np.array_equal(got, oracle.rnms(dense, 0.5))
+    _run_nms(t(dense), _lib.KIND_RBOX, 0.5)
+    assert L.obb_nms_last_route() == 2            # (the thread remembers: straight to the sorted route ...
     nms_route('auto')
     _run_nms(t(dense), _lib.KIND_RBOX, 0.5)
-    assert L.obb_nms_last_route() == 2            # (the thread remembers: straight to the sorted route)
+    assert L.obb_nms_last_route() == 5            #  ... until the knob is touched: that clears the thread's notes)
+    nms_route('auto')
+
+
+def test_grid_route_serves_grouped_calls(nms_route):
+    """Grouped calls share the grid's table (a group's cells = the spatial grid shifted by an offset derived from a
+    16-bit tag of the group id; entries of different tags are never paired, groups that share a tag are told apart by
+    the records): a few groups on one canvas, thousands of groups on a small canvas each (the per-patch NMS of a tiled
+    pass), negative and huge group ids, per-box thresholds, 150k boxes (auto routing, compaction in its own launch from
+    2^18 boxes) -- all index-exact with the sorted route and, where it finishes in seconds, the oracle."""
+    from aidet_amd import _lib, rnms
+    L = _lib.lib()
+    rng = np.random.default_rng(5)
+    for n, canvas, ngroups in ((6000, 8000, 5), (40000, 1024, 3000), (150000, 4000, 240), (300000, 30000, 7)):
+        d = oracle.synth_boxes(n, canvas, 11 + ngroups)
+        g = rng.integers(0, ngroups, n).astype(np.int32)
+        if ngroups == 5:
+            g = (g.astype(np.int64) * 715827883 - 2 ** 31 + 17).astype(np.int32)      # ids all over int32, negative ones too
+        thrs = rng.choice([0.3, 0.5], n).astype(np.float32) if ngroups != 240 else None
+        nms_route('grid' if n < 150000 else 'auto')
+        got = rnms(t(d), 0.5, groups=g, thrs=thrs)[1].cpu().numpy()
+        route = L.obb_nms_last_route()
+        nms_route('sorted')
+        want = rnms(t(d), 0.5, groups=g, thrs=thrs)[1].cpu().numpy()
+        assert L.obb_nms_last_route() == 2
+        assert route == 4, (n, route)
+        assert np.array_equal(got, want), n
+        if n <= 40000:
+            assert np.array_equal(got, oracle.rnms(d, 0.5, groups=g, thrs=thrs)), n
+    # groups whose 16-bit tags collide (ids 65536 apart hash to the same tag only by accident: force it with equal ids
+    # modulo the hash's period -- here simply two groups inside every tag by using 200 000 distinct ids)
+    d = oracle.synth_boxes(30000, 3000, 2)
+    g = rng.integers(0, 200000, len(d)).astype(np.int32)
+    nms_route('grid')
+    got = rnms(t(d), 0.4, groups=g)[1].cpu().numpy()
+    assert L.obb_nms_last_route() == 4 and np.array_equal(got, oracle.rnms(d, 0.4, groups=g))
+    # a crowded grouped scene gives the route up: repeated on the sorted route, and remembered for GROUPED calls of the
+    # size class only
+    dense = oracle.synth_boxes(20000, 500, 8)
+    g = rng.integers(0, 2, len(dense)).astype(np.int32)
+    got = rnms(t(dense), 0.5, groups=g)[1].cpu().numpy()
+    assert L.obb_nms_last_route() == 5 and np.array_equal(got, oracle.rnms(dense, 0.5, groups=g))
+    nms_route('auto')
+
+
+def test_fused_tiled_phases_on_the_grid_route_and_its_repeat(nms_route):
+    """A tiled pass whose two NMS calls are large enough for the grid route (forced here: the scene is a small one) ==
+    the same pass with the grid off == the step-by-step pass; a pass whose per-patch NMS gives the grid up (every
+    detection of a patch in one spot: a crowded cell) is repeated by the driver (K word OBB_TILED_REPEAT / OBB_ERETRY)
+    and ends with the sorted route's result."""
+    from aidet_amd import _lib, dota_merge
+    L = _lib.lib()
+    args, scene = _tiled_args(images=2, image_size=4096, objects=6000, classes=5, seed=7)
+    thrs = [0.3, 0.5, 0.1, 0.4, 0.2]
+    nms_route('grid')
+    gk, gkeep, grows = dota_merge.tiled_inference_merge(*args, 5, 0.5, 0.3, thrs)
+    nms_route('sorted')
+    sk, skeep, srows = dota_merge.tiled_inference_merge(*args, 5, 0.5, 0.3, thrs)
+    try:
+        dota_merge.FUSED = False
+        pk, pkeep, prows = dota_merge.tiled_inference_merge(*args, 5, 0.5, 0.3, thrs)
+    finally:
+        dota_merge.FUSED = True
+    assert torch.equal(grows, srows) and torch.equal(gkeep, skeep) and torch.equal(gk, sk)
+    assert torch.equal(grows, prows) and torch.equal(gkeep, pkeep) and torch.equal(gk, pk)
+    assert 0 < gk.size(0) < grows.size(0) < args[0].size(0)
+    # crowded: 400 detections of one class within a few pixels in every patch -- more than a cell holds
+    rng = np.random.default_rng(3)
+    n, P = 20000, 50
+    d = np.zeros((n, 6), np.float32)
+    d[:, 0:2] = 300.0 + rng.random((n, 2)).astype(np.float32) * 8.0
+    d[:, 2:4] = 20.0 + rng.random((n, 2)).astype(np.float32) * 4.0
+    d[:, 4] = -rng.random(n).astype(np.float32)
+    d[:, 5] = (rng.permutation(n) + 0.5) / n
+    patch = np.repeat(np.arange(P, dtype=np.int64), n // P)
+    base = [t(d), t(np.zeros(n, np.int64)), t(patch), t(np.arange(n, dtype=np.int64)),
+            t((rng.integers(0, 8, (P, 2)) * 512).astype(np.float32)), t(np.zeros(P, np.int64))]
+    dota_merge._phase_capacity.clear()
+    nms_route('sorted')
+    want = dota_merge.tiled_inference_merge(*base, 3, 0.5, 0.3, None)
+    nms_route('grid')
+    got = dota_merge.tiled_inference_merge(*base, 3, 0.5, 0.3, None)
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+    nms_route('auto')
+    dota_merge._phase_capacity.clear()
