@@ -449,7 +449,10 @@ __global__ __launch_bounds__(256) void nms_frame_kernel(const NmsSource src, int
   constexpr int T = 256, PER = kFrameSamples / T, NW = T / 64;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int ns = (int)(n < kFrameSamples ? n : kFrameSamples);
-  const int64_t stride = n / ns;                        // (>= 1; the samples cover [0, ns * stride))
+  // sample i sits at box i n / ns: the samples cover [0, n) evenly (a fixed stride n / ns covered [0, ns * stride) only --
+  // the first 1024 of 2000 boxes: a scene ordered along x had its second half outside the frame, clamped into the last cells)
+  static_assert(kFrameSamples == 1024, "the shift below");
+  auto sample_pos = [&](int i) { return ns == kFrameSamples ? (int64_t)(((uint64_t)i * (uint64_t)n) >> 10) : (int64_t)i; };
   {  // all of a thread's rows are requested before the first is used (a loop of dependent round trips took 30 us)
     float4 b[PER];
 #pragma unroll
@@ -457,10 +460,10 @@ __global__ __launch_bounds__(256) void nms_frame_kernel(const NmsSource src, int
       const int i = tid + u * T;
       if constexpr (F64) {
         float rowf[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-        if (i < ns) { const double *r64 = src.dets64 + ((int64_t)i * stride) * src.pitch; for (int k = 0; k < 4; ++k) rowf[k] = (float)r64[k]; }
+        if (i < ns) { const double *r64 = src.dets64 + sample_pos(i) * src.pitch; for (int k = 0; k < 4; ++k) rowf[k] = (float)r64[k]; }
         b[u] = i < ns ? sample_box<KIND>(rowf) : make_float4(1.0f, -1.0f, 1.0f, -1.0f);
       } else {
-        b[u] = i < ns ? sample_box<KIND>(src.dets + ((int64_t)i * stride) * src.pitch) : make_float4(1.0f, -1.0f, 1.0f, -1.0f);
+        b[u] = i < ns ? sample_box<KIND>(src.dets + sample_pos(i) * src.pitch) : make_float4(1.0f, -1.0f, 1.0f, -1.0f);
       }
     }
 #pragma unroll
@@ -1899,7 +1902,11 @@ __global__ __launch_bounds__(64 * kNmsWaves) void nms_gprobe_kernel(const QuadRe
       // the entries hold lower bounds of the areas (the upper 16 bits of the float): the smaller area is at most
       // 1.0079 x its bound, the sum at least the sum of the bounds -- both bounds stay on the safe side
       const float aa = __uint_as_float(ea.w & 0xFFFF0000u), ab = __uint_as_float(eb.w & 0xFFFF0000u);
-      cnd = cnd && !(min_sel(aa, ab) * 1.0079f < (tp.thr * max_sel(aa, ab)) * 0.999999f) && prune_aabb(tp, ea.x, ea.y, aa, eb.x, eb.y, ab);   // (prune_area on the bounds)
+      // (an interval that touches the first or last cell of the quantisation may have been CLAMPED into the frame: its
+      // cells then say nothing about its extent -- as in the sorted route's scan)
+      const bool edge = qedge(ea.x, ea.y) || qedge(eb.x, eb.y);
+      cnd = cnd && !(min_sel(aa, ab) * 1.0079f < (tp.thr * max_sel(aa, ab)) * 0.999999f) &&           // (prune_area on the bounds)
+            (edge || prune_aabb(tp, ea.x, ea.y, aa, eb.x, eb.y, ab));
     }
     return cnd;
   };

@@ -421,8 +421,8 @@ def nms_roofline(n, canvas, kept, scan_ms, step_ms, rk=None, route=2):
         # SURVEY 8(d)'s model of the REFERENCE algorithm (n x n/64 bit mask written, kept rows
         # read back): what this pipeline avoids moving -- not an achieved rate
         'reference_algorithm_bytes': 24 * n + 4 * n * words + 4 * kept * words + 8 * kept,
-        'note': ('grid route (frame, insert, probe + clip, resolve + compaction): pair tests of a half-wave per cell and the clip of the '
-                 'candidates; a latency-bound call; HBM fracs beside it') if route == 4 else
+        'note': ('grid route (frame, insert, probe + clip, resolve + compaction): a lane per pair of entries of a chunk of cells, bounds '
+                 'on the entries, the clip of what is left; a latency-bound call of four launches; HBM fracs beside it') if route == 4 else
                 'VALU-issue bound kernel in a latency-bound call; HBM fracs beside it',
         'counters': c['_file'] if (c and k) else None,
     }

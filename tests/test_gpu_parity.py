@@ -137,19 +137,24 @@ def test_overlaps_cpu_tensor_roundtrip():
 # --------------------------------------------------------------------------
 # rotated NMS: keep indices bit-exact
 # --------------------------------------------------------------------------
-@pytest.fixture(params=['auto', 'sorted', 'listed'])
+@pytest.fixture(params=['auto', 'sorted', 'listed', 'grid'])
 def nms_path(request, monkeypatch):
     """The library routes n <= 128 to the fused kernel, n <= 10240 to the direct
     (unsorted) scan and the rest to the spatially sorted pipeline, whose scan clips its
     candidates in line up to 65 536 boxes and lists them for a clip launch above; 'sorted' /
     'listed' force the pipeline with one or the other for every n above the fused limit."""
     from aidet_amd import _lib
-    if request.param != 'auto':
+    if request.param == 'grid':                        # the uniform grid wherever it applies (n >= 256; it may give a scene up)
+        _lib.set_tuning(_lib.TUNE_NMS_DIRECT_MAX, 0)
+        _lib.set_tuning(_lib.TUNE_NMS_GRID, 1)
+    elif request.param != 'auto':
         _lib.set_tuning(_lib.TUNE_NMS_DIRECT_MAX, 0)
         _lib.set_tuning(_lib.TUNE_NMS_INLINE_MAX, (1 << 40) if request.param == 'sorted' else 0)
+        _lib.set_tuning(_lib.TUNE_NMS_GRID, 0)        # (the uniform-grid route has its own fixture value below)
     yield request.param
     _lib.set_tuning(_lib.TUNE_NMS_DIRECT_MAX, -1)
     _lib.set_tuning(_lib.TUNE_NMS_INLINE_MAX, -1)
+    _lib.set_tuning(_lib.TUNE_NMS_GRID, -1)
 
 
 @pytest.mark.parametrize('n,canvas', [(1, 10), (2, 10), (63, 64), (64, 64), (65, 64), (257, 128),

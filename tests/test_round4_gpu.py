@@ -464,3 +464,33 @@ def test_fused_tiled_phases_on_the_grid_route_and_its_repeat(nms_route):
         assert torch.equal(a, b)
     nms_route('auto')
     dota_merge._phase_capacity.clear()
+
+
+def test_grid_route_boxes_clamped_into_the_frame(nms_route):
+    """The quantisation frame comes from a sample (and trims far outliers): boxes outside it are CLAMPED into its first /
+    last cells, where their cells say nothing about their extent -- the bound on the quantised overlap must not be applied
+    to them (a chain of 2000 boxes along x of which the frame kernel once sampled the first 1024 only; a cluster of
+    mutually overlapping boxes far outside the scene).  Crowded edge cells also exercise the overflow list."""
+    from aidet_amd import _lib, rnms
+    L = _lib.lib()
+    for n, step in ((2000, 4.0), (4000, 4.0), (2000, 3.0), (3000, 2.5)):
+        d = np.zeros((n, 6), np.float32)
+        d[:, 0] = np.arange(n) * step; d[:, 1] = 5; d[:, 2] = 10; d[:, 3] = 10
+        d[:, 5] = 1.0 - np.arange(n) / n
+        nms_route('grid')
+        got = rnms(t(d), 0.4)[1].cpu().numpy()
+        assert L.obb_nms_last_route() in (4, 5)
+        assert np.array_equal(got, oracle.rnms(d, 0.4)), (n, step)
+    rng = np.random.default_rng(12)
+    d = oracle.synth_boxes(5000, 6000, 21)
+    far = np.zeros((60, 6), np.float32)
+    far[:, 0:2] = 3.0e5 + rng.random((60, 2)).astype(np.float32) * 30.0
+    far[:, 2:4] = 40.0 + rng.random((60, 2)).astype(np.float32) * 20.0
+    far[:, 4] = -rng.random(60).astype(np.float32)
+    far[:, 5] = rng.random(60).astype(np.float32)
+    d = np.concatenate([d, far])[rng.permutation(5060)]
+    nms_route('grid')
+    got = rnms(t(d), 0.3)[1].cpu().numpy()
+    assert L.obb_nms_last_route() == 4
+    assert np.array_equal(got, oracle.rnms(d, 0.3))
+    nms_route('auto')
