@@ -1285,6 +1285,15 @@ __device__ __forceinline__ bool qedge(uint32_t lo, uint32_t hiG) {
   return (lo & 0x7FFFu) == 0u || (lo & 0x7FFF0000u) == 0u || (hiG & 0x7FFFu) == kQMax || ((hiG >> 16) & 0x7FFFu) == kQMax;
 }
 
+// qedge(a) || qedge(b) in nine operations: a 15-bit field that is 0 borrows into its guard position when 1 is taken from
+// it (bits 15 / 31 of `lo` are clear), one that is kQMax = 0x7FFE carries out of it when 2 are added (they are set in `hiG`); a
+// borrow / carry that runs on into the upper field can only turn it into an edge when the lower field already is one
+__device__ __forceinline__ bool qedge2(uint32_t alo, uint32_t ahiG, uint32_t blo, uint32_t bhiG) {
+  static_assert(kQMax == 0x7FFEu, "the carry below");
+  const uint32_t k = 0x00010001u, k2 = 0x00020002u;
+  return ((((alo - k) | (blo - k)) | ~((ahiG + k2) & (bhiG + k2))) & 0x80008000u) != 0u;
+}
+
 // first (cheap) bound: iou <= min(area)/max(area)
 __device__ __forceinline__ bool prune_area(const Prune &pr, float ra, float ca) {
   const float mn = min_sel(ra, ca), mx = max_sel(ra, ca);
@@ -1831,13 +1840,14 @@ constexpr int kGridProbeWaves = 4096;             // most waves of the probe lau
 
 __host__ __device__ inline uint32_t grid_chunk_log2(uint32_t cells) { return cells >= kGridCpw8 ? 3u : (cells >= kGridCpw4 ? 2u : 1u); }
 
+template <bool GROUPED>
 __global__ __launch_bounds__(64 * kNmsWaves) void nms_gprobe_kernel(const QuadRec *__restrict__ rec,
                                                            const NmsFrame *__restrict__ frame,
                                                            const uint32_t *__restrict__ gcnt, const uint4 *__restrict__ gtab,
                                                            uint32_t ncells, float thr, int per_box_thr, int flags,
                                                            uint2 *__restrict__ edges, unsigned long long segcap,
                                                            unsigned long long *__restrict__ ccnts, int *__restrict__ cnt,
-                                                           const NmsCounters *__restrict__ ctr, int grouped,
+                                                           const NmsCounters *__restrict__ ctr,
                                                            const uint4 *__restrict__ gover,
                                                            const float *__restrict__ thr_table, int thr_count) {
   static_assert(kGridCap == 32, "two cells per 64-lane load");
@@ -1853,7 +1863,7 @@ __global__ __launch_bounds__(64 * kNmsWaves) void nms_gprobe_kernel(const QuadRe
   // grid, the chunks for the one that exists (the headline: 128 x 128 of at most 512 x 512 cells); the groups of a
   // grouped call are spread over the whole table
   const uint32_t used = (uint32_t)fr.ggx * (uint32_t)fr.ggy;
-  const uint32_t cells = (grouped || used >= ncells) ? ncells : used;
+  const uint32_t cells = (GROUPED || used >= ncells) ? ncells : used;
   const uint32_t mask = ncells - 1u;
   const uint32_t cl = grid_chunk_log2(cells);
   const uint32_t chunks = (cells + (1u << cl) - 1u) >> cl;
@@ -1896,15 +1906,20 @@ __global__ __launch_bounds__(64 * kNmsWaves) void nms_gprobe_kernel(const QuadRe
     const uint32_t axl = ea.x & 0x7FFFu, ayl = (ea.x >> 16) & 0x7FFFu;
     const uint32_t bxl = eb.x & 0x7FFFu, byl = (eb.x >> 16) & 0x7FFFu;
     const uint32_t ox = (axl > bxl ? axl : bxl) >> fr.gshx, oy = (ayl > byl ? ayl : byl) >> fr.gshy;
-    const uint32_t owner = (((oy << xbits) | ox) + grid_tag_offset(ea.w & 0xFFFFu, mask)) & mask;
-    bool cnd = ((ea.w ^ eb.w) & 0xFFFFu) == 0u && qdisjoint(ea.x, ea.y, eb.x, eb.y) == 0u && owner == cell;
+    uint32_t owner = (oy << xbits) | ox;
+    bool cnd = qdisjoint(ea.x, ea.y, eb.x, eb.y) == 0u;
+    if (GROUPED) {
+      owner = (owner + grid_tag_offset(ea.w & 0xFFFFu, mask)) & mask;
+      cnd = cnd && ((ea.w ^ eb.w) & 0xFFFFu) == 0u;
+    }
+    cnd = cnd && owner == cell;
     if (tp.thr > 0.0f) {
       // the entries hold lower bounds of the areas (the upper 16 bits of the float): the smaller area is at most
       // 1.0079 x its bound, the sum at least the sum of the bounds -- both bounds stay on the safe side
       const float aa = __uint_as_float(ea.w & 0xFFFF0000u), ab = __uint_as_float(eb.w & 0xFFFF0000u);
       // (an interval that touches the first or last cell of the quantisation may have been CLAMPED into the frame: its
       // cells then say nothing about its extent -- as in the sorted route's scan)
-      const bool edge = qedge(ea.x, ea.y) || qedge(eb.x, eb.y);
+      const bool edge = qedge2(ea.x, ea.y, eb.x, eb.y);
       cnd = cnd && !(min_sel(aa, ab) * 1.0079f < (tp.thr * max_sel(aa, ab)) * 0.999999f) &&           // (prune_area on the bounds)
             (edge || prune_aabb(tp, ea.x, ea.y, aa, eb.x, eb.y, ab));
     }
@@ -3128,9 +3143,14 @@ int nms_enqueue_source(const char *who, NmsSource src, int64_t n, int kind, floa
       if (gcells >= kGridCpw8) { gp_waves = gcells >> 3; if (gp_waves < (kGridCpw8 >> 2)) gp_waves = kGridCpw8 >> 2; }
       if (gp_waves > (size_t)kGridProbeWaves) gp_waves = kGridProbeWaves;
       const size_t gp_blocks = (gp_waves + kNmsWaves - 1) / kNmsWaves;
-      hipLaunchKernelGGL(nms_gprobe_kernel, dim3((unsigned)gp_blocks), dim3(64 * kNmsWaves), 0, st,
-                         rec, frame, hist, gtab, (uint32_t)gcells, prune_thr, thr_dev ? 1 : 0, flags, edges, segcap, ccnts, cnt, ctr, grouped_call ? 1 : 0, gover,
-                         src.mode == 2 ? src.thr_table : nullptr, (int)(src.mult < (1 << 20) ? src.mult : (1 << 20)));
+      const float *gthr = src.mode == 2 ? src.thr_table : nullptr;
+      const int gthr_n = (int)(src.mult < (1 << 20) ? src.mult : (1 << 20));
+      if (grouped_call)
+        hipLaunchKernelGGL(nms_gprobe_kernel<true>, dim3((unsigned)gp_blocks), dim3(64 * kNmsWaves), 0, st,
+                           rec, frame, hist, gtab, (uint32_t)gcells, prune_thr, thr_dev ? 1 : 0, flags, edges, segcap, ccnts, cnt, ctr, gover, gthr, gthr_n);
+      else
+        hipLaunchKernelGGL(nms_gprobe_kernel<false>, dim3((unsigned)gp_blocks), dim3(64 * kNmsWaves), 0, st,
+                           rec, frame, hist, gtab, (uint32_t)gcells, prune_thr, thr_dev ? 1 : 0, flags, edges, segcap, ccnts, cnt, ctr, gover, gthr, gthr_n);
       OBB_LAUNCH_CHECK();
       OBB_PHASE(4);
       OBB_PHASE(5);

@@ -5,7 +5,7 @@
 # the product build are left alone).  The libraries are git-ignored like every *.so and travel with gpurun snapshots.
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-for a in ${1:-1 3 4 5 6}; do
+for a in ${ABL-1 3 4 5 6}; do     # (ABL= bash tools/build_ablations.sh: the probe-stamp library only)
   d=$(mktemp -d /tmp/obb_abl${a}_XXXX)
   cp $ROOT/aidet_amd/csrc/*.hip $ROOT/aidet_amd/csrc/*.h $ROOT/aidet_amd/csrc/Makefile $d/
   sed -i "s#\.\./\.\./include#$ROOT/include#g" $d/Makefile $d/obb_common.h

@@ -1,5 +1,5 @@
 """One-off soak beyond the oracle's reach: random scenes of 7e4 .. 1.2e6 boxes (sparse to dense, no / few /
-very many groups, per-box thresholds, strict), the two sorted routes (and the direct one below 65 536) must
+very many groups, per-box thresholds, strict), the two sorted routes, the grid route (and the direct one below 65 536) must
 return the same keep list.  usage: python tools/soak_routes.py FIRST LAST"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,10 +9,12 @@ from aidet_amd import _lib, rnms, poly_nms
 
 
 def force(route):
-    direct = {'direct': 65536, 'sorted': 0, 'listed': 0, 'auto': -1}[route]
-    inline = {'direct': -1, 'sorted': 1 << 40, 'listed': 0, 'auto': -1}[route]
+    direct = {'direct': 65536, 'sorted': 0, 'listed': 0, 'grid': 0, 'auto': -1}[route]
+    inline = {'direct': -1, 'sorted': 1 << 40, 'listed': 0, 'grid': -1, 'auto': -1}[route]
+    grid = {'direct': 0, 'sorted': 0, 'listed': 0, 'grid': 1, 'auto': -1}[route]      # ('grid': wherever it applies; a scene it gives up is repeated on the sorted route)
     _lib.set_tuning(_lib.TUNE_NMS_DIRECT_MAX, direct)
     _lib.set_tuning(_lib.TUNE_NMS_INLINE_MAX, inline)
+    _lib.set_tuning(_lib.TUNE_NMS_GRID, grid)
 
 
 a, b = int(sys.argv[1]), int(sys.argv[2])
@@ -36,7 +38,8 @@ for it in range(a, b):
         thrs = torch.from_numpy(rng.choice([0.1, 0.3, 0.5, 0.7], n).astype(np.float32)).cuda()
     thr, strict = float(rng.choice([0.3, 0.5, 0.7])), it % 6 == 0
     ref = None
-    for route in ('listed', 'sorted', 'direct', 'auto'):
+    routes_taken = []
+    for route in ('listed', 'sorted', 'direct', 'grid', 'auto'):
         if route == 'direct' and n > 65536:
             continue
         force(route)
@@ -44,7 +47,8 @@ for it in range(a, b):
         if ref is None:
             ref = keep
         assert torch.equal(keep, ref), (it, route, n)
+        routes_taken.append(_lib.lib().obb_nms_last_route())
     if it % 10 == 0:
-        print('scene', it, 'n', n, 'kept', ref.numel(), 'ok  %.0f s' % (time.time() - t0), flush=True)
+        print('scene', it, 'n', n, 'kept', ref.numel(), 'routes', routes_taken, 'ok  %.0f s' % (time.time() - t0), flush=True)
 force('auto')
 print('soak ok: scenes %d..%d' % (a, b - 1))
