@@ -30,7 +30,8 @@ NMS_STRICT = 1          # OBB_NMS_STRICT: suppress on `>` (nms_kernel.cu:61) ins
 NMS_RESULT_BYTES = 64   # OBB_NMS_RESULT_BYTES
 # obb_set_tuning knobs (test / experiment hooks, include/obbops.h)
 (TUNE_NMS_FUSED_MAX, TUNE_NMS_DIRECT_MAX, TUNE_NMS_SCAN_BLOCKS, TUNE_RROI_GROUPS, TUNE_OVERLAPS_ROWS, TUNE_NMS_INLINE_MAX,
- TUNE_RROI_ORDER_MIN, TUNE_RROI_GATHER_CHAN, TUNE_RPN_BARRIER_TICKS, TUNE_SOFT_NMS_REG, TUNE_NMS_FUSED_COMPACT, TUNE_RROI_PLAN, TUNE_NMS_GRID) = range(13)
+ TUNE_RROI_ORDER_MIN, TUNE_RROI_GATHER_CHAN, TUNE_RPN_BARRIER_TICKS, TUNE_SOFT_NMS_REG, TUNE_NMS_FUSED_COMPACT, TUNE_RROI_PLAN, TUNE_NMS_GRID,
+ TUNE_SOFT_NMS_SHAPE) = range(14)
 
 _lib = None
 
@@ -104,6 +105,8 @@ def lib():
                                                  f32, i32, i32, f32, vp, vp]
         L.obb_head_gather_decode_f32.restype = i32
         L.obb_nms_last_route.restype = i32
+        L.obb_soft_nms_last_path.restype = i32
+        L.obb_soft_nms_last_path.argtypes = []
         L.obb_set_tuning.argtypes = [i32, i64]
         L.obb_set_tuning.restype = i32
         rroi = [vp, i32, i32, i32, i32, vp, i64, i32, i32, f32, i32, f32, vp, vp]

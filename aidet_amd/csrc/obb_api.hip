@@ -20,7 +20,8 @@ int set_err(int code, const char *fmt, ...) {
   return code;
 }
 
-static std::atomic<int64_t> g_tune[OBB_TUNE_COUNT] = {{-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}};
+static std::atomic<int64_t> g_tune[OBB_TUNE_COUNT] = {{-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}};
+static_assert(OBB_TUNE_COUNT == 14, "one initialiser per knob");
 
 int64_t tuning(int knob, int64_t def) {
   const int64_t v = g_tune[knob].load(std::memory_order_relaxed);

@@ -502,6 +502,206 @@ __global__ __launch_bounds__(THREADS) void soft_nms_reg_kernel(const T *__restri
   if (tid == 0) result[0] = nd;
 }
 
+// =====================================================================================================================
+// Round 4, second attempt at one array: the reference's array permutation is observable only where two REMAINING boxes
+// hold the same score at the moment one of them is the maximum (the strict `<` of the arg-max then prefers the lower
+// POSITION, nms_cpu.cpp:114-121) -- or where a score is NaN.  Everywhere else the pick of a round is the unique maximum,
+// whoever sits where, every remaining box is examined exactly once per round (a box pulled into a hole is examined
+// there, :184-198), and the output is the picks in order.  So this kernel drops the positions altogether: a box stays
+// in its register slot with a `live` bit, a round is
+//     barrier -> the waves' candidates (score image, box number, "my maximum is not unique") -> the pick's corners
+//     from a read-only LDS copy -> decay of the live boxes (a slot no lane of the wave overlaps the pick with is skipped
+//     by a wave-uniform branch; the drop test runs on every live box, as in the reference) -> the wave's next candidate
+//     by DPP moves into the other half of a double buffer
+// -- ONE barrier per round.  Measured (tools/bench_soft_nms.py, n = 2000 boxes of 8-200 px on a 900 px canvas): 2.2 ms
+// against 3.3 ms of the array kernel and 3.2 ms of the host loop; 4096 boxes: 6.5 against 11.4 and 14.4 ms.  A round is
+// ~200 instructions of fixed work per wave (candidate reduction, DPP moves and their wait states, the uniqueness test)
+// plus ~50 per box whose columns meet the pick's: with 16 waves on the 4 SIMDs of ONE compute unit that is ~1.1 us per
+// round whatever the scene -- the floor of a one-workgroup kernel (two workgroups would need a grid barrier per round,
+// ~2 us).  The x-extent test below skips a slot only when none of its 64 lanes meets the pick's columns: rare unless the
+// boxes were placed in x order.  A
+// NaN score, or a maximum that two remaining boxes share, ends the kernel with result -2 and the call is repeated on the
+// array kernel, which replays the permutation exactly.
+// =====================================================================================================================
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_max_u32(uint32_t v) {
+  const uint32_t o = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xf, 0xf, true);
+  return o > v ? o : v;
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+  v = dpp_max_u32<0xB1>(v);
+  v = dpp_max_u32<0x4E>(v);
+  v = dpp_max_u32<0x141>(v);
+  v = dpp_max_u32<0x140>(v);
+  uint32_t m = 0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)v, r * 16);
+    m = o > m ? o : m;
+  }
+  return m;
+}
+// order-preserving image of a score (-0 folded into +0): > 0 for every score
+// (a NaN -- a decayed score can become one through NaN corners -- maps to the top value: it surfaces as the next maximum
+// and the kernel gives up there)
+__device__ __forceinline__ uint32_t score_image32(float s) {
+  const uint32_t u = __float_as_uint(s + 0.0f);
+  return s != s ? 0xFFFFFFFFu : ((u & 0x80000000u) ? ~u : (u | 0x80000000u));
+}
+
+constexpr long long kSoftFastGiveUp = -2;
+
+template <int T, int NB>
+__global__ __launch_bounds__(T) void soft_nms_fast_kernel(const float *__restrict__ dets, int n, float thr, int method,
+                                                            float sigma, float min_score, float *__restrict__ out_dets,
+                                                            int64_t *__restrict__ out_inds, long long *__restrict__ result) {
+  constexpr int kW = T / 64;
+  static_assert(kW <= 16, "one row of 16 lanes reduces the waves' candidates");
+  __shared__ float4 cbox[T * NB];
+  __shared__ float carea[T * NB];
+  __shared__ uint2 pub[2][kW];              // { image of the wave's best score (0: none), its box number | not unique << 31 }
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float x1[NB], y1[NB], x2[NB], y2[NB], sc[NB], ar[NB];
+  int rank[NB];
+  uint32_t live = 0u, yfin = 0u;            // yfin: both y corners finite (then h of any intersection is finite or 0)
+  bool bad = false;
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int p = b * T + tid;
+    const bool in = p < n;
+    const float *d = dets + (size_t)(in ? p : 0) * 5;
+    x1[b] = d[0]; y1[b] = d[1]; x2[b] = d[2]; y2[b] = d[3]; sc[b] = d[4];
+    ar[b] = ((x2[b] - x1[b]) + 1.0f) * ((y2[b] - y1[b]) + 1.0f);
+    rank[b] = -1;
+    if (in) {
+      live |= 1u << b;
+      const float big = 3.0e38f;
+      if (fabsf(y1[b]) < big && fabsf(y2[b]) < big) yfin |= 1u << b;
+      bad = bad || (sc[b] != sc[b]);
+      cbox[p] = make_float4(x1[b], y1[b], x2[b], y2[b]);
+      carea[p] = ar[b];
+    }
+  }
+  if (__syncthreads_or(bad ? 1 : 0)) {       // (also publishes the LDS copy)
+    if (tid == 0) result[0] = kSoftFastGiveUp;
+    return;
+  }
+  auto publish = [&](int par) {
+    uint32_t img[NB], best = 0u;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      img[b] = (live >> b & 1u) ? score_image32(sc[b]) : 0u;
+      best = img[b] > best ? img[b] : best;
+    }
+    const uint32_t wmax = wave_max_u32(best);
+    uint32_t eq = 0u;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) eq |= (img[b] == wmax && wmax != 0u) ? (1u << b) : 0u;
+    const uint64_t owners = __ballot(eq != 0u);
+    const bool tie = __ballot(__popc(eq) > 1) != 0ull || __popcll(owners) > 1 || wmax == 0xFFFFFFFFu;
+    int idx = 0;
+    if (owners) {
+      const int ol = __builtin_ctzll(owners);
+      const uint32_t oeq = (uint32_t)__builtin_amdgcn_readlane((int)eq, ol);
+      idx = __builtin_ctz(oeq) * T + wave * 64 + ol;
+    }
+    if (lane == 0) pub[par][wave] = make_uint2(wmax, (uint32_t)idx | (tie ? 0x80000000u : 0u));
+  };
+  int par = 0, picks = 0;
+  publish(par);
+  for (;;) {
+    __syncthreads();
+    // every wave reduces the kW candidates itself: lane k reads wave k's, the maximum of a row of 16 lanes by DPP moves
+    uint2 cand = make_uint2(0u, 0u);
+    if (lane < kW) cand = pub[par][lane];
+    uint32_t gmax = cand.x;
+    gmax = dpp_max_u32<0xB1>(gmax);
+    gmax = dpp_max_u32<0x4E>(gmax);
+    gmax = dpp_max_u32<0x141>(gmax);
+    gmax = dpp_max_u32<0x140>(gmax);
+    gmax = (uint32_t)__builtin_amdgcn_readlane((int)gmax, 0);
+    if (gmax == 0u) break;                                       // nothing left
+    const uint64_t who = __ballot(lane < kW && cand.x == gmax);
+    const uint32_t gy = (uint32_t)__builtin_amdgcn_readlane((int)cand.y, __builtin_ctzll(who));
+    if (__popcll(who) > 1 || (gy >> 31) != 0u) {                 // (block-uniform) the maximum is not unique
+      if (tid == 0) result[0] = kSoftFastGiveUp;
+      return;
+    }
+    const int gi = (int)(gy & 0x7FFFFFFFu);
+    const float4 a = cbox[gi];
+    const float iarea = carea[gi];
+    const bool mine = (gi & (T - 1)) == tid;
+    const bool pick_yfin = fabsf(a.y) < 3.0e38f && fabsf(a.w) < 3.0e38f;
+    const int gslot = gi / T;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const uint32_t bit = 1u << b;
+      if (mine && b == gslot) { live &= ~bit; rank[b] = picks; }
+      const bool on = (live & bit) != 0u;
+      // nms_cpu.cpp:155-163 (= hbb_overlap) with the pick as box i.  The x extent first: a slot none of whose live boxes
+      // meets the pick's columns is done after five operations (wave-uniform) -- an empty intersection over a positive
+      // denominator is ovr = +0, every method's weight exactly 1 (hard / linear: `0 > thr` must be false) and the score
+      // unchanged bit for bit.  (A denominator that is not positive, a NaN corner: the full expression decides.)
+      const float xx1 = a.x < x1[b] ? x1[b] : a.x, xx2 = x2[b] < a.z ? x2[b] : a.z;
+      const float ww = (xx2 - xx1) + 1.0f;
+      const bool plain = method == 2 || !(0.0f > thr);
+      const bool xmiss = !(ww > 0.0f) && ww == ww && plain && (iarea + ar[b]) > 0.0f && pick_yfin && (yfin & bit) != 0u;   // w = 0 and h finite: inter = +0
+      if (__ballot(on && !xmiss) != 0ull) {
+        const float yy1 = a.y < y1[b] ? y1[b] : a.y, yy2 = y2[b] < a.w ? y2[b] : a.w;
+        const float hh = (yy2 - yy1) + 1.0f;
+        const float w = 0.0f < ww ? ww : 0.0f, h = 0.0f < hh ? hh : 0.0f;
+        const float inter = w * h;
+        const float den = (iarea + ar[b]) - inter;
+        const bool skip = inter == 0.0f && den > 0.0f && plain;
+        if (on && !skip) {
+          const float ovr = inter / den;
+          float weight = 1.0f;
+          if (method == 1) { if (ovr > thr) weight = 1.0f - ovr; }
+          else if (method == 2) weight = soft_exp(-(ovr * ovr) / sigma);
+          else weight = (ovr > thr) ? 0.0f : 1.0f;
+          sc[b] = weight * sc[b];
+        }
+      }
+      if (on && sc[b] < min_score) live &= ~bit;                 // (every examined box, decayed or not: nms_cpu.cpp:184)
+    }
+    ++picks;
+    par ^= 1;
+    publish(par);
+  }
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    if (rank[b] >= 0) {
+      float *o = out_dets + (size_t)rank[b] * 5;
+      o[0] = x1[b]; o[1] = y1[b]; o[2] = x2[b]; o[3] = y2[b]; o[4] = sc[b];
+      out_inds[rank[b]] = b * T + tid;
+    }
+  }
+  if (tid == 0) result[0] = picks;
+}
+
+static thread_local int g_soft_path = -1;      // obb_soft_nms_last_path
+constexpr int kSoftFastMax = 4096;
+static bool soft_launch_fast(const float *dets, int64_t n, float thr, int method, float sigma, float min_score,
+                             float *out_dets, int64_t *out_inds, long long *result, hipStream_t st) {
+#define OBB_SOFT_FAST(T, NB) hipLaunchKernelGGL((soft_nms_fast_kernel<T, NB>), dim3(1), dim3(T), 0, st, dets, (int)n, thr, method, sigma, min_score, out_dets, out_inds, result)
+  // (four waves per SIMD hide the latency of the dependent chain -- division, the exponential -- that one wave per SIMD
+  // waits out: 2048 boxes as 256 x 8 took 2.1 us per round in a dense scene)
+  const int64_t shape = tuning(OBB_TUNE_SOFT_NMS_SHAPE, 0);     // (0 default; 1: 256 threads x more boxes, for measurements)
+  if (shape == 1 && n <= 2048) {
+    if (n <= 256) OBB_SOFT_FAST(256, 1); else if (n <= 512) OBB_SOFT_FAST(256, 2); else if (n <= 1024) OBB_SOFT_FAST(256, 4); else OBB_SOFT_FAST(256, 8);
+  } else if (shape == 2) {
+    if (n <= 512) OBB_SOFT_FAST(512, 1); else if (n <= 1024) OBB_SOFT_FAST(512, 2); else if (n <= 2048) OBB_SOFT_FAST(512, 4); else OBB_SOFT_FAST(512, 8);
+  }
+  else if (n <= 256) OBB_SOFT_FAST(256, 1);
+  else if (n <= 512) OBB_SOFT_FAST(512, 1);
+  else if (n <= 1024) OBB_SOFT_FAST(1024, 1);
+  else if (n <= 2048) OBB_SOFT_FAST(1024, 2);
+  else if (n <= kSoftFastMax) OBB_SOFT_FAST(1024, 4);
+  else return false;
+#undef OBB_SOFT_FAST
+  return true;
+}
+
 constexpr int kSoftRegMaxF32 = 8192, kSoftRegMaxF64 = 4096;
 // the register kernel sized by the (largest) array; false = too large for it (float: the global-memory kernel serves it)
 template <class T>
@@ -555,7 +755,16 @@ extern "C" int obb_soft_nms_f32(const float *dets_dev, int64_t n, float iou_thr,
   // 6.3 vs 3.3 ms at n = 2000, 21 vs ~12 ms at n = 5000: with 8 boxes per lane a round is ~600 dependent VALU
   // instructions on one wave per SIMD, DESIGN.md 3.4 -- so float keeps the array kernel; OBB_TUNE_SOFT_NMS_REG = 1 forces
   // the register kernel for tests)
-  if (tuning(OBB_TUNE_SOFT_NMS_REG, 0) == 1 && soft_launch_reg<float>(dets_dev, n, 1, iou_thr, method, sigma, min_score, out_dets_dev, out_inds_dev, pinned_dev, nullptr, st)) {
+  const int64_t knob = tuning(OBB_TUNE_SOFT_NMS_REG, 0);      // 0 default, 1 the position-tracking register kernel, 2 the array kernel only
+  // up to 4096 boxes: the kernel without positions first (unique maxima, no NaN: nearly every call); it gives up with
+  // result -2 where the reference's array permutation matters, and the call runs again on the array kernel
+  if (knob == 0 && soft_launch_fast(dets_dev, n, iou_thr, method, sigma, min_score, out_dets_dev, out_inds_dev, pinned_dev, st)) {
+    OBB_LAUNCH_CHECK();
+    OBB_HIP_TRY(hipStreamSynchronize(st));
+    if (*pinned != kSoftFastGiveUp) { *count_host = *pinned; g_soft_path = 2; return OBB_OK; }
+    g_soft_path = 3;
+  } else g_soft_path = knob == 1 ? 1 : 0;
+  if (knob == 1 && soft_launch_reg<float>(dets_dev, n, 1, iou_thr, method, sigma, min_score, out_dets_dev, out_inds_dev, pinned_dev, nullptr, st)) {
   } else if (n <= 768)          // measured (tools/bench_soft_nms.py): 1.15 us per round with 4 waves, 1.6 with 16 at n = 500
     hipLaunchKernelGGL((soft_nms_kernel<true, 256>), dim3(1), dim3(256), 0, st, dets_dev, (int)n, iou_thr, method, sigma, min_score, ws, out_dets_dev, out_inds_dev, pinned_dev, nullptr);
   else if (n <= kSoftLds)   // 2.0 us per round with 16 waves, 2.3 with 4 at n = 2000
@@ -567,6 +776,8 @@ extern "C" int obb_soft_nms_f32(const float *dets_dev, int64_t n, float iou_thr,
   *count_host = *pinned;
   return OBB_OK;
 }
+
+extern "C" int obb_soft_nms_last_path(void) { return obb::g_soft_path; }
 
 extern "C" int obb_soft_nms_f64(const double *dets_dev, int64_t n, float iou_thr, int method, float sigma,
                                 float min_score, double *out_dets_dev, int64_t *out_inds_dev,

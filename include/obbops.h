@@ -571,15 +571,20 @@ OBB_API int obb_head_gather_decode_f32(const float *rois_dev, const float *cls_s
 #define OBB_TUNE_RROI_ORDER_MIN 6     /* fewest RoIs the workspace forward puts into Morton order      */
 #define OBB_TUNE_RROI_GATHER_CHAN 7   /* channels per block of the gather backward (16 or 32)          */
 #define OBB_TUNE_RPN_BARRIER_TICKS 8  /* bound (100 MHz ticks) of the level barrier of the RPN selection; 0 forces the fallback */
-#define OBB_TUNE_SOFT_NMS_REG 9       /* 1: float Soft-NMS through the register-resident kernel (the float64 one), n <= 8192 */
+#define OBB_TUNE_SOFT_NMS_REG 9       /* float Soft-NMS of one array: 1 the position-tracking register kernel (the float64 one), n <= 8192; 2 the array kernel only (no position-free first try) */
 #define OBB_TUNE_NMS_FUSED_COMPACT 10  /* 0: the sorted route's compaction as a launch of its own (as from 2^18 boxes on); 2: the waiting shards give up at once */
 #define OBB_TUNE_RROI_PLAN 11          /* fewest RoIs the workspace forward of RoI-Align plans per RoI (default 1024; 0 = always) */
 #define OBB_TUNE_NMS_GRID 12           /* grid route of the NMS: 0 never, 1 wherever it applies (ignoring the thread's skip hints); default auto */
-#define OBB_TUNE_COUNT 13
+#define OBB_TUNE_SOFT_NMS_SHAPE 13     /* 1: the position-free Soft-NMS kernel as 256 threads x up to 8 boxes (default: up to 1024 threads x 1-4 boxes) */
+#define OBB_TUNE_COUNT 14
 OBB_API int obb_set_tuning(int knob, int64_t value);
 /* which route the calling thread's last synchronous obb_nms_*_f32 call took: 0 fused (one workgroup), 1 direct, 2 sorted,
  * 4 grid, 5 grid gave up (crowded cell) and the call was repeated on the sorted route; -1 none yet */
 OBB_API int obb_nms_last_route(void);
+/* which kernel served the calling thread's last obb_soft_nms_f32 call: 2 the position-free kernel (n <= 4096, unique
+ * maxima, no NaN), 3 that kernel gave up and the array kernel replayed the reference's permutation, 0 the array kernel
+ * alone, 1 the register kernel (knob); -1 none yet */
+OBB_API int obb_soft_nms_last_path(void);
 
 #ifdef __cplusplus
 }

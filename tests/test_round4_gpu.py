@@ -494,3 +494,58 @@ def test_grid_route_boxes_clamped_into_the_frame(nms_route):
     assert L.obb_nms_last_route() == 4
     assert np.array_equal(got, oracle.rnms(d, 0.3))
     nms_route('auto')
+
+
+def test_position_free_soft_nms_and_its_fallback():
+    """`soft_nms` on one float array up to 4096 boxes: the kernel without positions serves every call whose maxima are
+    unique (index-exact with the oracle's array loop, scores bit-exact for the linear method), gives up on a shared
+    maximum / a NaN / a score that decays into a NaN, and the array kernel then replays the permutation -- same result as
+    with the first try switched off (knob 2).  All launch shapes (1 .. 16 boxes per thread), heavy drops, -0 scores."""
+    from aidet_amd import _lib, soft_nms
+    L = _lib.lib()
+    rng = np.random.default_rng(23)
+    for n, canvas, min_score in ((1, 50, 0.01), (2, 10, 0.3), (200, 100, 0.3), (257, 120, 0.05), (700, 200, 0.2), (1024, 200, 0.05),
+                                 (2000, 300, 0.05), (2048, 260, 0.3), (3000, 400, 0.1), (4096, 500, 0.05)):
+        x1, y1 = rng.uniform(0, canvas, n), rng.uniform(0, canvas, n)
+        d = np.stack([x1, y1, x1 + rng.uniform(4, 60, n), y1 + rng.uniform(4, 60, n), rng.permutation(n) / n + 1e-3], 1).astype(np.float32)
+        if n > 10:
+            d[7, 4] = -0.0
+        for method, thr in (('linear', 0.3), ('gaussian', 0.3), ('linear', 0.0)):
+            nd, inds = soft_nms(t(d), thr, method=method, sigma=0.5, min_score=min_score)
+            path = L.obb_soft_nms_last_path()
+            rd, ri = oracle.soft_nms(d, thr, method, 0.5, min_score)
+            assert np.array_equal(inds.cpu().numpy(), ri), (n, method, thr)
+            if method != 'gaussian':
+                assert np.array_equal(nd.cpu().numpy(), rd), (n, method)
+            else:
+                assert np.allclose(nd.cpu().numpy(), rd, rtol=0, atol=1e-6), (n, method)
+            assert path in (2, 3)
+            if n >= 200 and method == 'linear' and thr == 0.3:
+                assert path == 2, (n, path)       # distinct scores, distinct decays: no shared maximum
+        # shared maxima, NaN scores, a NaN corner (its overlaps, hence the decayed scores of its neighbours' gaussian weights, are NaN)
+        e = d.copy()
+        e[::5, 4] = np.float32(0.5)
+        if n > 10:
+            e[3, 4] = np.nan
+        f = d.copy()
+        if n > 10:
+            f[5, 0] = np.nan
+        for arr in (e, f):
+            for method in ('linear', 'gaussian'):
+                nd, inds = soft_nms(t(arr), 0.3, method=method, sigma=0.5, min_score=min_score)
+                path = L.obb_soft_nms_last_path()
+                if method == 'linear':        # (gaussian: expf of the GPU and of the host's libm may differ in the last bit, and
+                    #  among scores tied at 0.5 that can turn a pick around -- the array kernel below is the comparison)
+                    rd, ri = oracle.soft_nms(arr, 0.3, method, 0.5, min_score)
+                    assert np.array_equal(inds.cpu().numpy(), ri), (n, method, path)
+                    assert np.allclose(nd.cpu().numpy(), rd, rtol=0, atol=1e-6, equal_nan=True), (n, method)
+                try:
+                    _lib.set_tuning(_lib.TUNE_SOFT_NMS_REG, 2)
+                    nd2, inds2 = soft_nms(t(arr), 0.3, method=method, sigma=0.5, min_score=min_score)
+                    assert L.obb_soft_nms_last_path() == 0
+                finally:
+                    _lib.set_tuning(_lib.TUNE_SOFT_NMS_REG, -1)
+                assert torch.equal(inds, inds2) and torch.equal(nd.nan_to_num(-7.0), nd2.nan_to_num(-7.0))
+        if n >= 200:
+            nd, inds = soft_nms(t(e), 0.3, method='linear', sigma=0.5, min_score=min_score)
+            assert L.obb_soft_nms_last_path() == 3
