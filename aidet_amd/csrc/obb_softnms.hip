@@ -517,9 +517,8 @@ __global__ __launch_bounds__(THREADS) void soft_nms_reg_kernel(const T *__restri
 // against 3.3 ms of the array kernel and 3.2 ms of the host loop; 4096 boxes: 6.5 against 11.4 and 14.4 ms.  A round is
 // ~200 instructions of fixed work per wave (candidate reduction, DPP moves and their wait states, the uniqueness test)
 // plus ~50 per box whose columns meet the pick's: with 16 waves on the 4 SIMDs of ONE compute unit that is ~1.1 us per
-// round whatever the scene -- the floor of a one-workgroup kernel (two workgroups would need a grid barrier per round,
-// ~2 us).  The x-extent test below skips a slot only when none of its 64 lanes meets the pick's columns: rare unless the
-// boxes were placed in x order.  A
+// round whatever the scene (stamps: tools/exp_soft_stamps.py) -- the floor of a one-workgroup kernel of this shape (two
+// workgroups would need a grid barrier per round, ~2 us).  A
 // NaN score, or a maximum that two remaining boxes share, ends the kernel with result -2 and the call is repeated on the
 // array kernel, which replays the permutation exactly.
 // =====================================================================================================================
@@ -550,6 +549,12 @@ __device__ __forceinline__ uint32_t score_image32(float s) {
 }
 
 constexpr long long kSoftFastGiveUp = -2;
+#ifdef OBB_SOFT_STAMPS
+__device__ unsigned long long g_soft_stamps[16 * 256 * 8];
+#define SF_STAMP(i) do { if (lane == 0 && picks >= 256 && picks < 512) g_soft_stamps[(wave * 256 + (picks - 256)) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SF_STAMP(i) do { } while (0)
+#endif
 
 template <int T, int NB>
 __global__ __launch_bounds__(T) void soft_nms_fast_kernel(const float *__restrict__ dets, int n, float thr, int method,
@@ -563,7 +568,7 @@ __global__ __launch_bounds__(T) void soft_nms_fast_kernel(const float *__restric
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float x1[NB], y1[NB], x2[NB], y2[NB], sc[NB], ar[NB];
   int rank[NB];
-  uint32_t live = 0u, yfin = 0u;            // yfin: both y corners finite (then h of any intersection is finite or 0)
+  uint32_t live = 0u;
   bool bad = false;
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
@@ -575,8 +580,6 @@ __global__ __launch_bounds__(T) void soft_nms_fast_kernel(const float *__restric
     rank[b] = -1;
     if (in) {
       live |= 1u << b;
-      const float big = 3.0e38f;
-      if (fabsf(y1[b]) < big && fabsf(y2[b]) < big) yfin |= 1u << b;
       bad = bad || (sc[b] != sc[b]);
       cbox[p] = make_float4(x1[b], y1[b], x2[b], y2[b]);
       carea[p] = ar[b];
@@ -610,7 +613,9 @@ __global__ __launch_bounds__(T) void soft_nms_fast_kernel(const float *__restric
   int par = 0, picks = 0;
   publish(par);
   for (;;) {
+    SF_STAMP(0);
     __syncthreads();
+    SF_STAMP(1);
     // every wave reduces the kW candidates itself: lane k reads wave k's, the maximum of a row of 16 lanes by DPP moves
     uint2 cand = make_uint2(0u, 0u);
     if (lane < kW) cand = pub[par][lane];
@@ -628,31 +633,30 @@ __global__ __launch_bounds__(T) void soft_nms_fast_kernel(const float *__restric
       return;
     }
     const int gi = (int)(gy & 0x7FFFFFFFu);
+    SF_STAMP(2);
     const float4 a = cbox[gi];
     const float iarea = carea[gi];
     const bool mine = (gi & (T - 1)) == tid;
-    const bool pick_yfin = fabsf(a.y) < 3.0e38f && fabsf(a.w) < 3.0e38f;
+    SF_STAMP(3);
     const int gslot = gi / T;
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       const uint32_t bit = 1u << b;
       if (mine && b == gslot) { live &= ~bit; rank[b] = picks; }
       const bool on = (live & bit) != 0u;
-      // nms_cpu.cpp:155-163 (= hbb_overlap) with the pick as box i.  The x extent first: a slot none of whose live boxes
-      // meets the pick's columns is done after five operations (wave-uniform) -- an empty intersection over a positive
-      // denominator is ovr = +0, every method's weight exactly 1 (hard / linear: `0 > thr` must be false) and the score
-      // unchanged bit for bit.  (A denominator that is not positive, a NaN corner: the full expression decides.)
-      const float xx1 = a.x < x1[b] ? x1[b] : a.x, xx2 = x2[b] < a.z ? x2[b] : a.z;
-      const float ww = (xx2 - xx1) + 1.0f;
-      const bool plain = method == 2 || !(0.0f > thr);
-      const bool xmiss = !(ww > 0.0f) && ww == ww && plain && (iarea + ar[b]) > 0.0f && pick_yfin && (yfin & bit) != 0u;   // w = 0 and h finite: inter = +0
-      if (__ballot(on && !xmiss) != 0ull) {
-        const float yy1 = a.y < y1[b] ? y1[b] : a.y, yy2 = y2[b] < a.w ? y2[b] : a.w;
-        const float hh = (yy2 - yy1) + 1.0f;
-        const float w = 0.0f < ww ? ww : 0.0f, h = 0.0f < hh ? hh : 0.0f;
-        const float inter = w * h;
-        const float den = (iarea + ar[b]) - inter;
-        const bool skip = inter == 0.0f && den > 0.0f && plain;
+      // nms_cpu.cpp:155-163 (= hbb_overlap) with the pick as box i
+      const float xx1 = a.x < x1[b] ? x1[b] : a.x, yy1 = a.y < y1[b] ? y1[b] : a.y;
+      const float xx2 = x2[b] < a.z ? x2[b] : a.z, yy2 = y2[b] < a.w ? y2[b] : a.w;
+      const float ww = (xx2 - xx1) + 1.0f, hh = (yy2 - yy1) + 1.0f;
+      const float w = 0.0f < ww ? ww : 0.0f, h = 0.0f < hh ? hh : 0.0f;
+      const float inter = w * h;
+      const float den = (iarea + ar[b]) - inter;
+      // empty intersection over a positive denominator: ovr = +0, every method's weight is exactly 1 (hard / linear:
+      // `0 > thr` must be false), the score is unchanged bit for bit -- no division, no exp.  (Wave-uniform: a slot none
+      // of whose 64 boxes meets the pick skips them; a test of the x extents alone in front of this one skipped nothing
+      // more in random order -- 64 lanes rarely all miss the pick's columns -- and cost ten operations per slot.)
+      const bool skip = inter == 0.0f && den > 0.0f && (method == 2 || !(0.0f > thr));
+      if (__ballot(on && !skip) != 0ull) {
         if (on && !skip) {
           const float ovr = inter / den;
           float weight = 1.0f;
@@ -664,9 +668,11 @@ __global__ __launch_bounds__(T) void soft_nms_fast_kernel(const float *__restric
       }
       if (on && sc[b] < min_score) live &= ~bit;                 // (every examined box, decayed or not: nms_cpu.cpp:184)
     }
+    SF_STAMP(4);
     ++picks;
     par ^= 1;
     publish(par);
+    --picks; SF_STAMP(5); ++picks;
   }
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
@@ -778,6 +784,11 @@ extern "C" int obb_soft_nms_f32(const float *dets_dev, int64_t n, float iou_thr,
 }
 
 extern "C" int obb_soft_nms_last_path(void) { return obb::g_soft_path; }
+#ifdef OBB_SOFT_STAMPS
+extern "C" __attribute__((visibility("default"))) int obb_debug_soft_stamps(unsigned long long *host, int words) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(obb::g_soft_stamps), sizeof(unsigned long long) * (size_t)words);
+}
+#endif
 
 extern "C" int obb_soft_nms_f64(const double *dets_dev, int64_t n, float iou_thr, int method, float sigma,
                                 float min_score, double *out_dets_dev, int64_t *out_inds_dev,

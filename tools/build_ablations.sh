@@ -18,4 +18,10 @@ cp $ROOT/aidet_amd/csrc/*.hip $ROOT/aidet_amd/csrc/*.h $ROOT/aidet_amd/csrc/Make
 sed -i "s#\.\./\.\./include#$ROOT/include#g" $d/Makefile $d/obb_common.h
 make -s -C $d -j8 EXTRA=-DOBB_GPROBE_STAMPS OUT=$ROOT/aidet_amd/lib/libobbops_gpst.so
 rm -rf $d
-ls -la $ROOT/aidet_amd/lib/libobbops_abl*.so $ROOT/aidet_amd/lib/libobbops_gpst.so
+# stamps of the position-free Soft-NMS kernel (tools/exp_soft_stamps.py)
+d=$(mktemp -d /tmp/obb_sst_XXXX)
+cp $ROOT/aidet_amd/csrc/*.hip $ROOT/aidet_amd/csrc/*.h $ROOT/aidet_amd/csrc/Makefile $d/
+sed -i "s#\.\./\.\./include#$ROOT/include#g" $d/Makefile $d/obb_common.h
+make -s -C $d -j8 EXTRA=-DOBB_SOFT_STAMPS OUT=$ROOT/aidet_amd/lib/libobbops_sst.so
+rm -rf $d
+ls -la $ROOT/aidet_amd/lib/libobbops_abl*.so $ROOT/aidet_amd/lib/libobbops_gpst.so $ROOT/aidet_amd/lib/libobbops_sst.so
