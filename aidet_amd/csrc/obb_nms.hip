@@ -664,7 +664,14 @@ __global__ __launch_bounds__(256) void nms_frame_kernel(const NmsSource src, int
     // grid route (nms_ginsert_kernel / nms_gprobe_kernel): cells = the 15-bit quantisation coarsened by a power of two,
     // about (mean + one sigma of the sampled extents) wide -- most boxes touch 1-4 cells -- and at most 2^grid_log2 per axis
     {
-      const float ctarget = ext_mean + ext_sd;
+#ifndef OBB_GRID_MANY_SCALE
+#define OBB_GRID_MANY_SCALE 2.0f
+#endif
+      // (very many groups -- the per-patch NMS of a tiled pass: ~50 boxes per group -- leave a (group, cell) key nearly
+      // empty: cells twice as wide mean 1.5 instead of 1.9 entries per box and fewer pairs per table cell -- the
+      // per-patch phase of config 5 277 -> 234 us; three times as wide: a (group, cell) key overflows, the route gives up)
+      const bool many_groups = grouped && s_distinct * 10 >= (int)gs * 7;
+      const float ctarget = (ext_mean + ext_sd) * (many_groups ? OBB_GRID_MANY_SCALE : 1.0f);
       auto shift_for = [&](float scale) {
         const float q = ctarget * scale;                      // cell size in quanta
         int sh = 15 - grid_log2;
@@ -831,7 +838,7 @@ __global__ __launch_bounds__(256) void nms_ginsert_kernel(const NmsSource src, i
     else ctr->grid_fail = failword;
   };
   const bool grouped = src_grouped(src);
-  const uint32_t fail = 1u + (uint32_t)KIND + (grouped ? 4u : 0u);   // (non-zero; names the size class's skip hint: kind, grouped)
+  const uint32_t fail = 1u + (uint32_t)KIND + (grouped ? 4u : 0u) + 8u * (uint32_t)src.mode;   // (non-zero; names the size class's skip hint: kind, grouped, source mode)
   const int xbits = 15 - fr.gshx;                  // ggx = 2^xbits
   auto qz = [](float x, float b, float s2) {
     float u = floorf((x - b) * s2);
@@ -3112,7 +3119,7 @@ int nms_enqueue_source(const char *who, NmsSource src, int64_t n, int kind, floa
     // 20k: 52 vs 71, 12k: 51 vs 69)
     const bool grouped_call = src.mode != 0 || group_dev != nullptr;
     const bool grid = !direct && L.grid_log2 > 0 && n > direct_max && !f64 && src.allow_grid != 0 &&
-                      gknob != 0 && (gknob == 1 || n <= kGridAutoMax) && !grid_skip_take(n, kind + (grouped_call ? 4 : 0));
+                      gknob != 0 && (gknob == 1 || n <= kGridAutoMax) && !grid_skip_take(n, kind + (grouped_call ? 4 : 0) + 8 * src.mode);
     q.grid = grid;
     if (grid) {
       const size_t gcells = (size_t)1 << L.grid_bits;
