@@ -103,7 +103,7 @@ struct NmsCounters {
   unsigned int done;                       // resolve workgroups finished
   unsigned int state;                      // fused resolve + compaction: 0 wait, 1 all shards resolved (go), 2 a waiter gave up
   unsigned int grid_fail;                  // grid route: too many crowded cells / a box over too many cells -- repeat on the sorted route
-  alignas(256) unsigned int grid_over;     // grid route: entries on the overflow list (may exceed kGridOverCap)
+  alignas(256) unsigned int grid_over;     // grid route: entries on the overflow list (may exceed grid_over_cap(n))
   alignas(256) unsigned long long cand_total;           // candidate pairs over all shards
   unsigned long long cand_worst;           // fullest shard
 };
@@ -791,11 +791,17 @@ __global__ __launch_bounds__(256) void nms_prepq_kernel(const NmsSource src, int
 // =====================================================================================================================
 constexpr int kGridCap = 32;             // entries per cell
 constexpr int kGridMaxCells = 64;        // cells one box may touch
-constexpr int kGridMaxLog2 = 9;          // at most 512 x 512 cells per group
-constexpr int kGridMaxBits = 20;         // at most 2^20 cells in the table (512 MiB)
-constexpr int kGridOverCap = 4096;       // entries that found their cell full (the overflow list); more: the route gives up
+constexpr int kGridMaxLog2 = 11;         // at most 2048 x 2048 cells per group
+constexpr int kGridMaxBits = 22;         // at most 2^22 cells in the table (2 GiB: calls of ~10^7 boxes)
+constexpr int kGridOverMax = 32768;      // the overflow list's memory (entries that found their cell full) ...
+// ... of which a call uses max(4096, n / 256): more entries and the route gives up (every entry costs a wave a pass over the
+// list: 4096 entries ~10 us, 32 768 ~0.5 ms -- in proportion only for the calls of millions of boxes that may have them)
+__host__ __device__ inline uint32_t grid_over_cap(int64_t n) {
+  const int64_t c = n / 256;
+  return (uint32_t)(c < 4096 ? 4096 : (c > kGridOverMax ? kGridOverMax : c));
+}
 constexpr int kGridSkipCalls = 256;
-constexpr int64_t kGridAutoMax = 1500000;   // (about 10 entries per cell of the largest table: a 33rd entry in one of 2^18 cells is a 1e-3 event)
+constexpr int64_t kGridAutoMax = 12000000;   // (the layout holds a table up to 2^24 boxes)
 
 // GROUPED calls share the table: a group's cells are the spatial grid shifted by a pseudo-random offset that depends on a
 // 16-bit tag of the group id, modulo the table size (a power of two >= the spatial grid: one group's cells never alias
@@ -829,12 +835,13 @@ __global__ __launch_bounds__(256) void nms_ginsert_kernel(const NmsSource src, i
                                                           uint4 *__restrict__ gover) {
   constexpr int S = KIND == 0 ? 6 : (KIND == 1 ? 9 : 5);
   const NmsFrame fr = *frame;
-  uint32_t *__restrict__ gover_cell = reinterpret_cast<uint32_t *>(gover + kGridOverCap);
+  uint32_t *__restrict__ gover_cell = reinterpret_cast<uint32_t *>(gover + kGridOverMax);
+  const uint32_t over_cap = grid_over_cap(n);
   // an entry whose cell is full goes on the overflow list (nms_gprobe_kernel pairs it with the cell's entries and with the
   // list's other entries of the cell); a full list gives the route up
   auto spill = [&](uint32_t cell, const uint4 &e, uint32_t failword) {
     const uint32_t o = atomicAdd(&ctr->grid_over, 1u);
-    if (o < (uint32_t)kGridOverCap) { gover[o] = e; gover_cell[o] = cell; }
+    if (o < over_cap) { gover[o] = e; gover_cell[o] = cell; }
     else ctr->grid_fail = failword;
   };
   const bool grouped = src_grouped(src);
@@ -1855,7 +1862,7 @@ __global__ __launch_bounds__(64 * kNmsWaves) void nms_gprobe_kernel(const QuadRe
                                                            uint2 *__restrict__ edges, unsigned long long segcap,
                                                            unsigned long long *__restrict__ ccnts, int *__restrict__ cnt,
                                                            const NmsCounters *__restrict__ ctr,
-                                                           const uint4 *__restrict__ gover,
+                                                           const uint4 *__restrict__ gover, uint32_t over_cap,
                                                            const float *__restrict__ thr_table, int thr_count) {
   static_assert(kGridCap == 32, "two cells per 64-lane load");
   __shared__ uint2 queue[kNmsWaves][kNmsQueue];
@@ -1875,7 +1882,7 @@ __global__ __launch_bounds__(64 * kNmsWaves) void nms_gprobe_kernel(const QuadRe
   const uint32_t cl = grid_chunk_log2(cells);
   const uint32_t chunks = (cells + (1u << cl) - 1u) >> cl;
   const uint32_t nover_all = ctr->grid_over;                      // (written by the insert launch)
-  const uint32_t nover = nover_all < (uint32_t)kGridOverCap ? nover_all : (uint32_t)kGridOverCap;
+  const uint32_t nover = nover_all < over_cap ? nover_all : over_cap;
   if (gw >= chunks && gw >= nover) return;
   if (__hip_atomic_load(&ctr->grid_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;   // the call is repeated on the sorted route
   GP_STAMP(1);
@@ -1997,7 +2004,7 @@ __global__ __launch_bounds__(64 * kNmsWaves) void nms_gprobe_kernel(const QuadRe
   // ---- the overflow list: a wave per entry that found its cell full -- against the 32 entries the cell holds, and
   // against the later entries of the list that belong to the same cell (every pair of a crowded cell once)
   if (nover > 0u) {
-    const uint32_t *__restrict__ gover_cell = reinterpret_cast<const uint32_t *>(gover + kGridOverCap);
+    const uint32_t *__restrict__ gover_cell = reinterpret_cast<const uint32_t *>(gover + kGridOverMax);
     for (uint32_t o = gw; o < nover; o += nw) {
       const uint4 eo = gover[o];
       const uint32_t cell = gover_cell[o];
@@ -2803,7 +2810,7 @@ static int nms_layout(int64_t n, int64_t edge_capacity, NmsLayout &L) {
   // grid route: (2^g x 2^g cells) x kGridCap entries of 16 bytes; g from n (about half a cell per box), sizes where the route applies
   L.grid_log2 = 0; L.grid_bits = 0;
   L.gtab = off;
-  if (n >= 256 && n <= (1 << 21)) {
+  if (n >= 256 && n <= (1 << 24)) {
     int g = 6;
     while (g < kGridMaxLog2 && (1ll << (2 * g)) * 2 < n) ++g;      // (x 8 instead of x 2 -- a quarter of the probe's waves -- measured no faster: the cell size follows the extents, not this bound)
     // table: the spatial grid, or -- grouped calls: the groups' grids share the table -- about 2.5 boxes per cell: with
@@ -2814,7 +2821,7 @@ static int nms_layout(int64_t n, int64_t edge_capacity, NmsLayout &L) {
     while (bits < kGridMaxBits && ((int64_t)5 << bits) < 2 * n) ++bits;
     L.grid_log2 = g; L.grid_bits = bits;
     L.gtab = take(((size_t)1 << bits) * kGridCap * sizeof(uint4));
-    L.gover = take((size_t)kGridOverCap * (sizeof(uint4) + sizeof(uint32_t)));     // overflow entries, then their cells
+    L.gover = take((size_t)kGridOverMax * (sizeof(uint4) + sizeof(uint32_t)));     // overflow entries, then their cells
   }
   L.qs = take((nt * kTile + kRowChunk) * sizeof(uint2));
   L.pf = take((nt * kTile) * sizeof(uint4));
@@ -3110,13 +3117,12 @@ int nms_enqueue_source(const char *who, NmsSource src, int64_t n, int kind, floa
   }
   // threshold-aware pruning: the call's threshold, or per pair the smaller of the two boxes'
   const float prune_thr = thr_dev ? 0.0f : iou_thr;
-  // ---- grid route (see nms_ginsert_kernel): ungrouped float calls between the direct route's range and 2^18 boxes,
-  // from the entry points that can repeat a call (src.allow_grid), unless this thread's last try of the size class failed
+  // ---- grid route (see nms_ginsert_kernel): float calls above the direct route's range, from the entry points that can
+  // repeat a call (src.allow_grid), unless this thread's last try of the size class failed
   {
     const int64_t gknob = tuning(OBB_TUNE_NMS_GRID, -1);          // -1 auto, 0 never, 1 wherever it applies
-    // (auto: up to kGridAutoMax boxes -- with at most 256 x 256 cells a larger scene crowds them: 200k boxes measured 131 us
-    // on the grid against 125 us sorted and 150k boxes at the headline's density overflow a cell; 100k: 71 vs 95, 50k: 65 vs 78,
-    // 20k: 52 vs 71, 12k: 51 vs 69)
+    // (auto: up to kGridAutoMax boxes; profiles/r04_grid_vs_sorted.txt: 1.2 - 1.7 x the sorted route from 12 000 to 1.4 M
+    // boxes, ungrouped and grouped)
     const bool grouped_call = src.mode != 0 || group_dev != nullptr;
     const bool grid = !direct && L.grid_log2 > 0 && n > direct_max && !f64 && src.allow_grid != 0 &&
                       gknob != 0 && (gknob == 1 || n <= kGridAutoMax) && !grid_skip_take(n, kind + (grouped_call ? 4 : 0) + 8 * src.mode);
@@ -3154,10 +3160,10 @@ int nms_enqueue_source(const char *who, NmsSource src, int64_t n, int kind, floa
       const int gthr_n = (int)(src.mult < (1 << 20) ? src.mult : (1 << 20));
       if (grouped_call)
         hipLaunchKernelGGL(nms_gprobe_kernel<true>, dim3((unsigned)gp_blocks), dim3(64 * kNmsWaves), 0, st,
-                           rec, frame, hist, gtab, (uint32_t)gcells, prune_thr, thr_dev ? 1 : 0, flags, edges, segcap, ccnts, cnt, ctr, gover, gthr, gthr_n);
+                           rec, frame, hist, gtab, (uint32_t)gcells, prune_thr, thr_dev ? 1 : 0, flags, edges, segcap, ccnts, cnt, ctr, gover, grid_over_cap(n), gthr, gthr_n);
       else
         hipLaunchKernelGGL(nms_gprobe_kernel<false>, dim3((unsigned)gp_blocks), dim3(64 * kNmsWaves), 0, st,
-                           rec, frame, hist, gtab, (uint32_t)gcells, prune_thr, thr_dev ? 1 : 0, flags, edges, segcap, ccnts, cnt, ctr, gover, gthr, gthr_n);
+                           rec, frame, hist, gtab, (uint32_t)gcells, prune_thr, thr_dev ? 1 : 0, flags, edges, segcap, ccnts, cnt, ctr, gover, grid_over_cap(n), gthr, gthr_n);
       OBB_LAUNCH_CHECK();
       OBB_PHASE(4);
       OBB_PHASE(5);

@@ -549,3 +549,27 @@ def test_position_free_soft_nms_and_its_fallback():
         if n >= 200:
             nd, inds = soft_nms(t(e), 0.3, method='linear', sigma=0.5, min_score=min_score)
             assert L.obb_soft_nms_last_path() == 3
+
+
+def test_grid_route_on_millions_of_boxes(nms_route):
+    """3 M boxes -- ungrouped on a canvas of the headline's density, and in 5000 groups overlaid on a smaller one: the
+    grid route (a table of 2^21 / 2^22 cells, compaction in its own launch) returns the sorted route's keep list."""
+    import workloads
+    from aidet_amd import _lib
+    from aidet_amd.nms_wrapper import _run_nms
+    L = _lib.lib()
+    n = 3000000
+    rng = np.random.default_rng(4)
+    for ng, canvas in ((0, 110000.0), (5000, 12000.0)):
+        d = t(workloads.boxes(n, canvas, 5))
+        g = None if ng == 0 else t(rng.integers(0, ng, n).astype(np.int32))
+        nms_route('auto')
+        keep, _ = _run_nms(d, _lib.KIND_RBOX, 0.5, g)
+        assert L.obb_nms_last_route() == 4
+        nms_route('listed')
+        want, _ = _run_nms(d, _lib.KIND_RBOX, 0.5, g)
+        assert L.obb_nms_last_route() == 2
+        assert torch.equal(keep, want) and 0 < keep.numel() < n
+        del d, g, keep, want
+        torch.cuda.empty_cache()
+    nms_route('auto')
