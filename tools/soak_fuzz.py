@@ -8,12 +8,14 @@ from aidet_amd import _lib
 
 
 def force(route):
-    fused = {'fused': 1024, 'direct': 0, 'sorted': 0, 'listed': 0, 'auto': -1}[route]
-    direct = {'fused': -1, 'direct': 65536, 'sorted': 0, 'listed': 0, 'auto': -1}[route]
-    inline = {'fused': -1, 'direct': -1, 'sorted': 1 << 40, 'listed': 0, 'auto': -1}[route]
+    fused = {'fused': 1024, 'direct': 0, 'sorted': 0, 'listed': 0, 'grid': 0, 'auto': -1}[route]
+    direct = {'fused': -1, 'direct': 65536, 'sorted': 0, 'listed': 0, 'grid': 0, 'auto': -1}[route]
+    inline = {'fused': -1, 'direct': -1, 'sorted': 1 << 40, 'listed': 0, 'grid': 0, 'auto': -1}[route]
+    grid = {'fused': -1, 'direct': -1, 'sorted': 0, 'listed': 0, 'grid': 1, 'auto': -1}[route]
     _lib.set_tuning(_lib.TUNE_NMS_FUSED_MAX, fused)
     _lib.set_tuning(_lib.TUNE_NMS_DIRECT_MAX, direct)
     _lib.set_tuning(_lib.TUNE_NMS_INLINE_MAX, inline)
+    _lib.set_tuning(_lib.TUNE_NMS_GRID, grid)
 
 
 a, b = int(sys.argv[1]), int(sys.argv[2])
