@@ -508,17 +508,20 @@ __global__ __launch_bounds__(THREADS) void soft_nms_reg_kernel(const T *__restri
 // POSITION, nms_cpu.cpp:114-121) -- or where a score is NaN.  Everywhere else the pick of a round is the unique maximum,
 // whoever sits where, every remaining box is examined exactly once per round (a box pulled into a hole is examined
 // there, :184-198), and the output is the picks in order.  So this kernel drops the positions altogether: a box stays
-// in its register slot with a `live` bit, a round is
-//     barrier -> the waves' candidates (score image, box number, "my maximum is not unique") -> the pick's corners
-//     from a read-only LDS copy -> decay of the live boxes (a slot no lane of the wave overlaps the pick with is skipped
-//     by a wave-uniform branch; the drop test runs on every live box, as in the reference) -> the wave's next candidate
-//     by DPP moves into the other half of a double buffer
-// -- ONE barrier per round.  Measured (tools/bench_soft_nms.py, n = 2000 boxes of 8-200 px on a 900 px canvas): 2.2 ms
-// against 3.3 ms of the array kernel and 3.2 ms of the host loop; 4096 boxes: 6.5 against 11.4 and 14.4 ms.  A round is
-// ~200 instructions of fixed work per wave (candidate reduction, DPP moves and their wait states, the uniqueness test)
-// plus ~50 per box whose columns meet the pick's: with 16 waves on the 4 SIMDs of ONE compute unit that is ~1.1 us per
-// round whatever the scene (stamps: tools/exp_soft_stamps.py) -- the floor of a one-workgroup kernel of this shape (two
-// workgroups would need a grid barrier per round, ~2 us).  A
+// in its register slot with a `live` bit, and a round is
+//     barrier -> the block's pick from two LDS words (the best score with its lowest and with its highest box number:
+//     they differ when the maximum is not unique) -> the pick's corners from a read-only LDS copy -> decay of the live
+//     boxes -- skipped by a whole wave when all its boxes lie left or right of the pick: the boxes are placed in x order,
+//     64 NB consecutive ranks per wave -- and the drop test on every live box, as in the reference -> a wave whose
+//     candidate was picked, decayed or dropped finds its next one by DPP moves; every wave feeds its candidate to the
+//     next round's two LDS maxima.
+// ONE barrier per round.  Measured (tools/bench_soft_nms.py, boxes of 8-200 px on a 900 px canvas): n = 2000 2.0 ms
+// against 3.3 ms of the array kernel and 3.2 ms of the host loop; 4096 boxes: 6.0 against 11.4 and 14.4 ms -- the same on
+// sparse scenes: a round is ~1 us whatever the boxes do.  What a round waits for is ONE wave's dependent chain (stamps:
+// tools/exp_soft_stamps.py): barrier -> LDS -> LDS -> (division) -> score image, four DPP steps, read-lanes, ballots of
+// the wave that owned the pick -> LDS atomics -> barrier; trimming the other waves' instructions (the candidate reduction
+// by every wave: -30 instructions; no republishing unless touched: -50; no decay away from the pick: -100) moved it
+// from 1.1 to 1.0 us.  Fewer rounds (several non-interacting picks per barrier) would be the next step; not built.  A
 // NaN score, or a maximum that two remaining boxes share, ends the kernel with result -2 and the call is repeated on the
 // array kernel, which replays the permutation exactly.
 // =====================================================================================================================
@@ -562,34 +565,91 @@ __global__ __launch_bounds__(T) void soft_nms_fast_kernel(const float *__restric
                                                             int64_t *__restrict__ out_inds, long long *__restrict__ result) {
   constexpr int kW = T / 64;
   static_assert(kW <= 16, "one row of 16 lanes reduces the waves' candidates");
+  static_assert((NB & (NB - 1)) == 0, "slot = (box number >> 6) & (NB - 1)");
   __shared__ float4 cbox[T * NB];
   __shared__ float carea[T * NB];
-  __shared__ uint2 pub[2][kW];              // { image of the wave's best score (0: none), its box number | not unique << 31 }
+  __shared__ uint32_t ckey[T * NB];         // order-preserving images of x1 while the boxes are ranked, then the scores
+  __shared__ int cid[T * NB];
+  // the block's pick of a round = two LDS maxima the waves feed before the barrier (three sets in rotation):
+  //   [0] (score image << 32) | ~box number  -- the best score, its LOWEST box number
+  //   [1] (score image << 32) |  box number  -- the best score, its HIGHEST box number; the two differ: not unique
+  __shared__ unsigned long long gbest[3][2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float x1[NB], y1[NB], x2[NB], y2[NB], sc[NB], ar[NB];
-  int rank[NB];
+  int rank[NB], oid[NB];
   uint32_t live = 0u;
   bool bad = false;
+  // ---- the boxes are placed in x ORDER: wave w holds the boxes of ranks [w 64 NB, (w + 1) 64 NB) by (x1, row) -- a pick
+  // then meets the columns of a few waves only and the others skip the decay on a wave-uniform test (below).  Nothing
+  // observable depends on the placement: this kernel has no positions.
+  {
+    uint32_t key[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int p = b * T + tid;
+      const bool in = p < n;
+      const float *d = dets + (size_t)(in ? p : 0) * 5;
+      x1[b] = d[0]; y1[b] = d[1]; x2[b] = d[2]; y2[b] = d[3]; sc[b] = d[4];
+      key[b] = in ? score_image32(x1[b]) : 0xFFFFFFFFu;           // (NaN: the top value, like the absent rows)
+      if (in) bad = bad || (sc[b] != sc[b]);
+      ckey[p] = key[b];
+    }
+    if (__syncthreads_or(bad ? 1 : 0)) {       // (also publishes the keys)
+      if (tid == 0) result[0] = kSoftFastGiveUp;
+      return;
+    }
+    int r[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) r[b] = 0;
+    const uint4 *k4 = reinterpret_cast<const uint4 *>(ckey);
+    for (int q = 0; q < T * NB; q += 4) {        // (uniform addresses: LDS broadcast reads)
+      const uint4 k = k4[q >> 2];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {           // (key, row) as one 64-bit number: a strict total order
+        const unsigned long long me = ((unsigned long long)key[b] << 32) | (uint32_t)(b * T + tid);
+        r[b] += ((((unsigned long long)k.x << 32) | (uint32_t)q) < me) ? 1 : 0;
+        r[b] += ((((unsigned long long)k.y << 32) | (uint32_t)(q + 1)) < me) ? 1 : 0;
+        r[b] += ((((unsigned long long)k.z << 32) | (uint32_t)(q + 2)) < me) ? 1 : 0;
+        r[b] += ((((unsigned long long)k.w << 32) | (uint32_t)(q + 3)) < me) ? 1 : 0;
+      }
+    }
+    __syncthreads();                             // every thread is done with the keys
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int p = b * T + tid;
+      cbox[r[b]] = make_float4(x1[b], y1[b], x2[b], y2[b]);
+      ckey[r[b]] = __float_as_uint(sc[b]);
+      cid[r[b]] = p < n ? p : -1;
+    }
+    __syncthreads();
+  }
+  float wxlo = 3.0e38f, wxhi = -3.0e38f, war_min = 3.0e38f;
+  bool irregular = false;
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
-    const int p = b * T + tid;
-    const bool in = p < n;
-    const float *d = dets + (size_t)(in ? p : 0) * 5;
-    x1[b] = d[0]; y1[b] = d[1]; x2[b] = d[2]; y2[b] = d[3]; sc[b] = d[4];
+    const int spos = wave * (64 * NB) + b * 64 + lane;            // the box number used from here on
+    const float4 c = cbox[spos];
+    x1[b] = c.x; y1[b] = c.y; x2[b] = c.z; y2[b] = c.w; sc[b] = __uint_as_float(ckey[spos]);
+    oid[b] = cid[spos];
     ar[b] = ((x2[b] - x1[b]) + 1.0f) * ((y2[b] - y1[b]) + 1.0f);
+    carea[spos] = ar[b];
     rank[b] = -1;
-    if (in) {
+    if (oid[b] >= 0) {
       live |= 1u << b;
-      bad = bad || (sc[b] != sc[b]);
-      cbox[p] = make_float4(x1[b], y1[b], x2[b], y2[b]);
-      carea[p] = ar[b];
+      const float big = 3.0e38f;
+      irregular = irregular || !(fabsf(x1[b]) < big && fabsf(y1[b]) < big && fabsf(x2[b]) < big && fabsf(y2[b]) < big && fabsf(ar[b]) < big);
+      wxlo = x1[b] < wxlo ? x1[b] : wxlo; wxhi = x2[b] > wxhi ? x2[b] : wxhi;
+      war_min = ar[b] < war_min ? ar[b] : war_min;
     }
   }
-  if (__syncthreads_or(bad ? 1 : 0)) {       // (also publishes the LDS copy)
-    if (tid == 0) result[0] = kSoftFastGiveUp;
-    return;
+  for (int o = 32; o > 0; o >>= 1) {
+    const float l = __shfl_xor(wxlo, o), h = __shfl_xor(wxhi, o), m = __shfl_xor(war_min, o);
+    wxlo = l < wxlo ? l : wxlo; wxhi = h > wxhi ? h : wxhi; war_min = m < war_min ? m : war_min;
   }
-  auto publish = [&](int par) {
+  const bool wave_regular = __ballot(irregular) == 0ull;          // every corner and area of the wave's boxes finite
+  __syncthreads();                               // (carea)
+  // the wave's candidate: {score image (0: none), box number of its first owner, of its last owner}; wave-uniform
+  auto candidate = [&]() {
     uint32_t img[NB], best = 0u;
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
@@ -601,77 +661,110 @@ __global__ __launch_bounds__(T) void soft_nms_fast_kernel(const float *__restric
 #pragma unroll
     for (int b = 0; b < NB; ++b) eq |= (img[b] == wmax && wmax != 0u) ? (1u << b) : 0u;
     const uint64_t owners = __ballot(eq != 0u);
-    const bool tie = __ballot(__popc(eq) > 1) != 0ull || __popcll(owners) > 1 || wmax == 0xFFFFFFFFu;
-    int idx = 0;
+    uint32_t lo = 0u, hi = 0u;
     if (owners) {
-      const int ol = __builtin_ctzll(owners);
-      const uint32_t oeq = (uint32_t)__builtin_amdgcn_readlane((int)eq, ol);
-      idx = __builtin_ctz(oeq) * T + wave * 64 + ol;
+      const int fl = __builtin_ctzll(owners), ll = 63 - __builtin_clzll(owners);
+      const uint32_t feq = (uint32_t)__builtin_amdgcn_readlane((int)eq, fl), leq = (uint32_t)__builtin_amdgcn_readlane((int)eq, ll);
+      lo = (uint32_t)(wave * (64 * NB) + __builtin_ctz(feq) * 64 + fl);
+      hi = (uint32_t)(wave * (64 * NB) + (31 - __builtin_clz(leq)) * 64 + ll);
     }
-    if (lane == 0) pub[par][wave] = make_uint2(wmax, (uint32_t)idx | (tie ? 0x80000000u : 0u));
+    return make_uint3(wmax, lo, hi);
   };
-  int par = 0, picks = 0;
-  publish(par);
+  auto feed = [&](int set, const uint3 &c) {
+    if (lane == 0 && c.x != 0u) {
+      atomicMax(&gbest[set][0], ((unsigned long long)c.x << 32) | (uint32_t)~c.y);
+      atomicMax(&gbest[set][1], ((unsigned long long)c.x << 32) | c.z);
+    }
+  };
+  if (tid < 6) (&gbest[0][0])[tid] = 0ull;
+  __syncthreads();
+  int par = 0, picks = 0;                    // par: the set of this round (0, 1, 2, 0, ...)
+  uint3 wc = candidate();
+  feed(par, wc);
   for (;;) {
     SF_STAMP(0);
     __syncthreads();
     SF_STAMP(1);
-    // every wave reduces the kW candidates itself: lane k reads wave k's, the maximum of a row of 16 lanes by DPP moves
-    uint2 cand = make_uint2(0u, 0u);
-    if (lane < kW) cand = pub[par][lane];
-    uint32_t gmax = cand.x;
-    gmax = dpp_max_u32<0xB1>(gmax);
-    gmax = dpp_max_u32<0x4E>(gmax);
-    gmax = dpp_max_u32<0x141>(gmax);
-    gmax = dpp_max_u32<0x140>(gmax);
-    gmax = (uint32_t)__builtin_amdgcn_readlane((int)gmax, 0);
+    const unsigned long long ga = gbest[par][0], gb = gbest[par][1];      // (uniform addresses)
+    const int nxt = par == 2 ? 0 : par + 1, nn = nxt == 2 ? 0 : nxt + 1;
+    if (tid == 0) { gbest[nn][0] = 0ull; gbest[nn][1] = 0ull; }          // the set after the next one: last read two barriers ago
+    const uint32_t gmax = (uint32_t)(ga >> 32);
     if (gmax == 0u) break;                                       // nothing left
-    const uint64_t who = __ballot(lane < kW && cand.x == gmax);
-    const uint32_t gy = (uint32_t)__builtin_amdgcn_readlane((int)cand.y, __builtin_ctzll(who));
-    if (__popcll(who) > 1 || (gy >> 31) != 0u) {                 // (block-uniform) the maximum is not unique
+    const int gi = (int)(~(uint32_t)ga);
+    if (gi != (int)(uint32_t)gb || gmax == 0xFFFFFFFFu) {        // (block-uniform) the maximum is not unique, or a NaN
       if (tid == 0) result[0] = kSoftFastGiveUp;
       return;
     }
-    const int gi = (int)(gy & 0x7FFFFFFFu);
     SF_STAMP(2);
     const float4 a = cbox[gi];
     const float iarea = carea[gi];
-    const bool mine = (gi & (T - 1)) == tid;
+    const bool mine = (gi & 63) == lane && gi / (64 * NB) == wave;
     SF_STAMP(3);
-    const int gslot = gi / T;
+    const int gslot = (gi >> 6) & (NB - 1);
+    // the wave's candidate stays what it is unless its box is picked, decayed or dropped in this round: every other box
+    // of the wave was below it and only goes down (a "not unique" mark may outlive the tie: the kernel then gives up
+    // without need, never the other way round)
+    const int wbest = (int)wc.y;
+    const bool own_best = wc.x != 0u && (wbest & 63) == lane;
+    const int wslot = (wbest >> 6) & (NB - 1);
+    bool touched = false;
+    if (mine) {
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      const uint32_t bit = 1u << b;
-      if (mine && b == gslot) { live &= ~bit; rank[b] = picks; }
-      const bool on = (live & bit) != 0u;
-      // nms_cpu.cpp:155-163 (= hbb_overlap) with the pick as box i
-      const float xx1 = a.x < x1[b] ? x1[b] : a.x, yy1 = a.y < y1[b] ? y1[b] : a.y;
-      const float xx2 = x2[b] < a.z ? x2[b] : a.z, yy2 = y2[b] < a.w ? y2[b] : a.w;
-      const float ww = (xx2 - xx1) + 1.0f, hh = (yy2 - yy1) + 1.0f;
-      const float w = 0.0f < ww ? ww : 0.0f, h = 0.0f < hh ? hh : 0.0f;
-      const float inter = w * h;
-      const float den = (iarea + ar[b]) - inter;
-      // empty intersection over a positive denominator: ovr = +0, every method's weight is exactly 1 (hard / linear:
-      // `0 > thr` must be false), the score is unchanged bit for bit -- no division, no exp.  (Wave-uniform: a slot none
-      // of whose 64 boxes meets the pick skips them; a test of the x extents alone in front of this one skipped nothing
-      // more in random order -- 64 lanes rarely all miss the pick's columns -- and cost ten operations per slot.)
-      const bool skip = inter == 0.0f && den > 0.0f && (method == 2 || !(0.0f > thr));
-      if (__ballot(on && !skip) != 0ull) {
-        if (on && !skip) {
-          const float ovr = inter / den;
+      for (int b = 0; b < NB; ++b) if (b == gslot) { live &= ~(1u << b); rank[b] = picks; touched = true; }
+    }
+    // a wave all of whose boxes lie left or right of the pick (x order) skips the decay: for each of them w = 0, h is
+    // finite, the intersection +0, the denominator iarea + area > 0 -- the case the per-box test below calls `skip`
+    const float big = 3.0e38f;
+    const bool plain = method == 2 || !(0.0f > thr);
+    const bool far = wave_regular && plain && fabsf(a.y) < big && fabsf(a.w) < big && (iarea + war_min) > 0.0f &&
+                     (a.z + 2.0f < wxlo || a.x - 2.0f > wxhi);
+    if (!far) {
+      // nms_cpu.cpp:155-163 (= hbb_overlap) with the pick as box i, for all the lane's boxes first ...
+      float inter[NB], den[NB];
+      bool act[NB];
+      bool any = false;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const uint32_t bit = 1u << b;
+        const float xx1 = a.x < x1[b] ? x1[b] : a.x, yy1 = a.y < y1[b] ? y1[b] : a.y;
+        const float xx2 = x2[b] < a.z ? x2[b] : a.z, yy2 = y2[b] < a.w ? y2[b] : a.w;
+        const float ww = (xx2 - xx1) + 1.0f, hh = (yy2 - yy1) + 1.0f;
+        const float w = 0.0f < ww ? ww : 0.0f, h = 0.0f < hh ? hh : 0.0f;
+        inter[b] = w * h;
+        den[b] = (iarea + ar[b]) - inter[b];
+        // empty intersection over a positive denominator: ovr = +0, every method's weight is exactly 1 (hard / linear:
+        // `0 > thr` must be false), the score is unchanged bit for bit -- no division, no exp
+        const bool skip = inter[b] == 0.0f && den[b] > 0.0f && (method == 2 || !(0.0f > thr));
+        act[b] = (live & bit) != 0u && !skip;
+        any = any || act[b];
+      }
+      // ... then ONE region with the divisions of all of them (a branch per box kept their dependent chains -- IEEE
+      // division, the exponential -- one behind the other: the decay was the longest leg of a round by the stamps)
+      if (__ballot(any) != 0ull) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          const float ovr = inter[b] / den[b];
           float weight = 1.0f;
           if (method == 1) { if (ovr > thr) weight = 1.0f - ovr; }
           else if (method == 2) weight = soft_exp(-(ovr * ovr) / sigma);
           else weight = (ovr > thr) ? 0.0f : 1.0f;
-          sc[b] = weight * sc[b];
+          if (act[b]) {
+            sc[b] = weight * sc[b];
+            touched = touched || (own_best && b == wslot);
+          }
         }
       }
-      if (on && sc[b] < min_score) live &= ~bit;                 // (every examined box, decayed or not: nms_cpu.cpp:184)
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const uint32_t bit = 1u << b;
+      if ((live & bit) != 0u && sc[b] < min_score) { live &= ~bit; touched = touched || (own_best && b == wslot); }   // (every examined box, decayed or not: nms_cpu.cpp:184)
     }
     SF_STAMP(4);
     ++picks;
-    par ^= 1;
-    publish(par);
+    par = nxt;
+    if (__ballot(touched) != 0ull) wc = candidate();             // (wave-uniform)
+    feed(par, wc);
     --picks; SF_STAMP(5); ++picks;
   }
 #pragma unroll
@@ -679,7 +772,7 @@ __global__ __launch_bounds__(T) void soft_nms_fast_kernel(const float *__restric
     if (rank[b] >= 0) {
       float *o = out_dets + (size_t)rank[b] * 5;
       o[0] = x1[b]; o[1] = y1[b]; o[2] = x2[b]; o[3] = y2[b]; o[4] = sc[b];
-      out_inds[rank[b]] = b * T + tid;
+      out_inds[rank[b]] = oid[b];
     }
   }
   if (tid == 0) result[0] = picks;

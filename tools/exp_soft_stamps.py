@@ -21,7 +21,7 @@ buf = np.zeros(16 * 256 * 8, dtype=np.uint64)
 L.obb_debug_soft_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
 assert L.obb_debug_soft_stamps(buf.ctypes.data, buf.size) == 0
 s = buf.reshape(16, 256, 8).astype(np.int64)
-names = ['publish done -> barrier passed', '-> candidates reduced (LDS read, DPP, readlane)', '-> pick corners read (LDS)', '-> decay', '-> next candidate published']
+names = ['publish done -> barrier passed', '-> the block\'s pick read (two LDS words)', '-> pick corners read (LDS)', '-> decay', '-> next candidate published']
 for w in (0, 7, 15):
     r = s[w]
     ok = (r[:, 5] > r[:, 0]) & (r[:, 0] > 0)
