@@ -1939,6 +1939,14 @@ __global__ __launch_bounds__(64 * kNmsWaves) void nms_gprobe_kernel(const QuadRe
     }
     return cnd;
   };
+#ifdef OBB_GPROBE_STAMPS
+  unsigned long long acc_flush = 0ull, acc_over = 0ull, n_flush = 0ull;      // (clocks inside the in-loop flushes / the overflow pass)
+#define GP_ACC_BEGIN() const unsigned long long t0_ = __builtin_amdgcn_s_memtime()
+#define GP_ACC_END(acc_) (acc_) += __builtin_amdgcn_s_memtime() - t0_
+#else
+#define GP_ACC_BEGIN() do { } while (0)
+#define GP_ACC_END(acc_) do { } while (0)
+#endif
   auto push = [&](bool cnd, uint32_t ia, uint32_t ib) {
     const uint64_t mcnd = __ballot(cnd);
     if (mcnd) {
@@ -1947,7 +1955,12 @@ __global__ __launch_bounds__(64 * kNmsWaves) void nms_gprobe_kernel(const QuadRe
       if (qn >= 64) {
         qn -= 64;
         __builtin_amdgcn_wave_barrier();
+        GP_ACC_BEGIN();
         sink.flush(q + qn, 64, lane);
+        GP_ACC_END(acc_flush);
+#ifdef OBB_GPROBE_STAMPS
+        ++n_flush;
+#endif
       }
     }
   };
@@ -2004,6 +2017,7 @@ __global__ __launch_bounds__(64 * kNmsWaves) void nms_gprobe_kernel(const QuadRe
   // ---- the overflow list: a wave per entry that found its cell full -- against the 32 entries the cell holds, and
   // against the later entries of the list that belong to the same cell (every pair of a crowded cell once)
   if (nover > 0u) {
+    GP_ACC_BEGIN();
     const uint32_t *__restrict__ gover_cell = reinterpret_cast<const uint32_t *>(gover + kGridOverMax);
     for (uint32_t o = gw; o < nover; o += nw) {
       const uint4 eo = gover[o];
@@ -2022,6 +2036,7 @@ __global__ __launch_bounds__(64 * kNmsWaves) void nms_gprobe_kernel(const QuadRe
         push(same && pair_here(eo, ej, cell), eo.z, ej.z);
       }
     }
+    GP_ACC_END(acc_over);
   }
   GP_STAMP(3);
   if (qn > 0) {
@@ -2030,6 +2045,11 @@ __global__ __launch_bounds__(64 * kNmsWaves) void nms_gprobe_kernel(const QuadRe
   }
   GP_STAMP(7);
   GP_STAMP(9);
+#ifdef OBB_GPROBE_STAMPS
+  if (lane == 0 && gw < 32768u) {      // (slots 4 .. 6 of a multi-chunk wave: totals instead of the last flush's stamps)
+    g_gprobe_stamps[gw * 10 + 4] = acc_flush; g_gprobe_stamps[gw * 10 + 5] = acc_over; g_gprobe_stamps[gw * 10 + 6] = n_flush;
+  }
+#endif
 }
 
 #ifdef OBB_GPROBE_STAMPS
@@ -2817,7 +2837,7 @@ static int nms_layout(int64_t n, int64_t edge_capacity, NmsLayout &L) {
     // ~1.8 entries per box that is 4.5 entries per cell on average and a 33rd entry (the route gives up) a 6-sigma
     // event of the compound-Poisson count (2^18 cells for 1.25 M boxes in 24 000 groups: 9.7 on average, dozens of
     // overflowing cells in every call)
-    int bits = 2 * g;
+    int bits = 2 * g;                                               // (half that table for 1.25 M grouped boxes: the same times)
     while (bits < kGridMaxBits && ((int64_t)5 << bits) < 2 * n) ++bits;
     L.grid_log2 = g; L.grid_bits = bits;
     L.gtab = take(((size_t)1 << bits) * kGridCap * sizeof(uint4));
