@@ -550,6 +550,7 @@ def patch_rows_to_image(dets, labels, patch_index, patch_xy, patch_image, rate=1
 # GPU tests compare the fused path with, and the route of the ``sharded`` layout.
 # ---------------------------------------------------------------------------------------------------------------
 TILED_REPEAT = -(1 << 62)    # K word of a phase whose NMS must be repeated as it is (the grid route gave up)
+phase_repeats = 0            # phases this process repeated for that reason (tests read it)
 FUSED = True                 # module switch (tests force the step-by-step path with it)
 _phase_ws = {}               # (device index, stream) -> uint8 workspace shared by the phases (stream-ordered)
 _phase_capacity = {}         # (phase, bit length of n) -> pair capacity the last overflowing call needed
@@ -642,6 +643,8 @@ def tiled_merge_phase(recv, seg_starts, key_max, total, num_classes, iou_thr, cl
             rec = record.cpu().numpy()                                   # the phase's one host read
         rc = L.obb_tiled_result(rec.ctypes.data, 1, int(total), cols, world, kmax, nbytes, info)
         if rc == _lib.OBB_ERETRY:             # the NMS's grid route gave up on this scene: once more, as it is
+            global phase_repeats
+            phase_repeats += 1
             continue
         if rc != _lib.OBB_EWORKSPACE:
             _lib.check(rc)
@@ -690,6 +693,8 @@ def _tiled_fused(dets, labels, patch_index, patch_xy, patch_image, num_classes, 
             info = (ctypes.c_int64 * 4)()
             nb = int(_lib.lib().obb_tiled_local_workspace_bytes(n, route_world, capacity or 0))
             assert _lib.lib().obb_tiled_result(rec.ctypes.data, 0, n, 6, route_world, -1, nb, info) == _lib.OBB_ERETRY
+            global phase_repeats
+            phase_repeats += 1
             continue
         # a rank's per-patch NMS overflowed its pair lists (every rank sees it): that rank repeats its phase with the
         # capacity its kernels asked for, everybody repeats the exchange of the counts

@@ -54,6 +54,32 @@ def tiled_inputs(rank, world, images=2, image_size=2048, objects=1500):
             f(scene['patch_xy']), f(scene['patch_image']))
 
 
+def crowd_inputs(rank, world):
+    """The scene 'two' with the detections of its FIRST patch replaced by 600 boxes of one class within a few pixels:
+    more than a cell of the NMS's grid route holds (they go on its overflow list), one of them huge (it touches more cells
+    than a box may: with the route forced, the rank that owns patch 0 gives it up in its per-patch phase and every rank
+    repeats the exchange)."""
+    scene = workloads.tiled_scene(images=2, image_size=2048, objects_per_image=1500, num_classes=NUM_CLASSES, seed=5)
+    rng = np.random.default_rng(9)
+    first = np.nonzero(scene['patch'] == 0)[0]
+    m = 600
+    d = np.zeros((m, 6), np.float32)
+    d[:, 0:2] = 300.0 + rng.random((m, 2)).astype(np.float32) * 6.0
+    d[:, 2:4] = 24.0 + rng.random((m, 2)).astype(np.float32) * 4.0
+    d[:, 4] = -rng.random(m).astype(np.float32)
+    d[:, 5] = (rng.permutation(m) + 0.5) / m
+    d[0, 2:5] = [3000.0, 2800.0, -0.3]           # and one box over more cells than an entry list may name: the route gives up
+    keep = np.ones(len(scene['dets']), bool)
+    keep[first] = False
+    dets = np.concatenate([d, scene['dets'][keep]])
+    label = np.concatenate([np.zeros(m, np.int64), scene['label'][keep]])
+    patch = np.concatenate([np.zeros(m, np.int64), scene['patch'][keep]])
+    P = len(scene['patch_name'])
+    idx = np.nonzero(np.isin(patch, np.asarray(dota_merge.shard_patches(P, rank, world))))[0]
+    f = torch.from_numpy
+    return (f(dets[idx]), f(label[idx]), f(patch[idx]), f(idx.astype(np.int64)), f(scene['patch_xy']), f(scene['patch_image']))
+
+
 def iou_inputs():
     return (torch.from_numpy(workloads.boxes(301, 512, 1)[:, :5].copy()),
             torch.from_numpy(workloads.boxes(257, 512, 2)[:, :5].copy()))

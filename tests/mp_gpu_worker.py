@@ -26,6 +26,11 @@ def main():
     dev = torch.device('cuda', 0)
     torch.cuda.set_device(dev)
     res = {}
+    force_grid = os.environ.get('OBB_TEST_GRID') == '1'
+    if force_grid:       # every NMS call of 256 boxes or more on the uniform-grid route (the scenes here are small)
+        from aidet_amd import _lib
+        _lib.set_tuning(_lib.TUNE_NMS_DIRECT_MAX, 0)
+        _lib.set_tuning(_lib.TUNE_NMS_GRID, 1)
     try:
         # (a) rows with score ties through distributed_merge, every layout
         for ties in (False, True):
@@ -45,6 +50,14 @@ def main():
                                                                     layout=layout, gather_result=gather)
                 tag = 'tiled_%s_%s_%d' % (name, layout, gather)
                 res[tag + '_kept'], res[tag + '_keep'], res[tag + '_rows'] = (x.cpu().numpy() for x in (kept, keep, rows))
+        if force_grid:   # (b') a rank whose per-patch NMS gives the grid up: the repeat word travels with the count exchange
+            args = [a.to(dev) for a in cases.crowd_inputs(rank, world)]
+            for layout, gather in cases.LAYOUTS:
+                kept, keep, rows = dota_merge.tiled_inference_merge(*args, cases.NUM_CLASSES, 0.5, 0.3, cases.CLASS_THRS,
+                                                                    layout=layout, gather_result=gather)
+                tag = 'tiled_crowd_%s_%d' % (layout, gather)
+                res[tag + '_kept'], res[tag + '_keep'], res[tag + '_rows'] = (x.cpu().numpy() for x in (kept, keep, rows))
+            res['phase_repeats'] = np.asarray(dota_merge.phase_repeats)
         # (c) row blocks of rbbox_overlaps: no communication, the blocks tile the matrix
         from aidet_amd import rbbox_overlaps
         a, b = cases.iou_inputs()

@@ -32,13 +32,14 @@ def _free_port():
     return port
 
 
-def run_ranks(world, outdir):
+def run_ranks(world, outdir, grid=False):
     """start `world` child processes (each initialises the GPU itself) and wait for all of them"""
     port = _free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1',
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'),
+                   OBB_TEST_GRID='1' if grid else '0')
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'mp_gpu_worker.py'), str(outdir)],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
@@ -58,9 +59,11 @@ def _owner(rows, world):
     return rows[:, 7].astype(np.int64) % world
 
 
-@pytest.mark.parametrize('world', [2, 3])
-def test_hip_tiled_merge_on_several_ranks_equals_one_rank_and_the_oracle(world, tmp_path):
-    got = run_ranks(world, tmp_path)
+@pytest.mark.parametrize('world,grid', [(2, False), (3, False), (2, True)])
+def test_hip_tiled_merge_on_several_ranks_equals_one_rank_and_the_oracle(world, grid, tmp_path):
+    """grid: every NMS call of the ranks on the uniform-grid route, plus a scene in which one rank's per-patch NMS gives
+    that route up and all ranks repeat the exchange (K word OBB_TILED_REPEAT)."""
+    got = run_ranks(world, tmp_path, grid)
     dev = torch.device('cuda', 0)
 
     def check(tag, ref_kept, ref_keep, ref_rows, ora_kept):
@@ -99,6 +102,15 @@ def test_hip_tiled_merge_on_several_ranks_equals_one_rank_and_the_oracle(world, 
                                                         nms_fn=cases.oracle_nms)
         assert np.array_equal(hrows.cpu().numpy(), orows.numpy())
         check('tiled_' + name, hk.cpu().numpy(), hkeep.cpu().numpy(), hrows.cpu().numpy(), ok.numpy())
+    if grid:
+        args = cases.crowd_inputs(0, 1)
+        hk, hkeep, hrows = dota_merge.tiled_inference_merge(*[a.to(dev) for a in args], cases.NUM_CLASSES, 0.5, 0.3,
+                                                            cases.CLASS_THRS)
+        ok, _, orows = dota_merge.tiled_inference_merge(*args, cases.NUM_CLASSES, 0.5, 0.3, cases.CLASS_THRS,
+                                                        nms_fn=cases.oracle_nms)
+        assert np.array_equal(hrows.cpu().numpy(), orows.numpy())
+        check('tiled_crowd', hk.cpu().numpy(), hkeep.cpu().numpy(), hrows.cpu().numpy(), ok.numpy())
+        assert int(got[0]['phase_repeats']) >= 1          # rank 0 owns patch 0: its per-patch phase was repeated
     # (c) the row blocks of rbbox_overlaps tile the matrix
     import oracle
     a, b = cases.iou_inputs()
