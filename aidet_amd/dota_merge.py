@@ -576,7 +576,9 @@ def tiled_local_phase(dets, labels, patch_index, patch_xy, patch_image, num_clas
     ``image % world``.  Nothing is synchronised.
 
     Returns (rows (n, 9) buffer of which the first K rows are valid, counts int64[world + 2 + 8] on the device:
-    rows per destination | order violations | K, or -(pair capacity needed) after an overflow | the NMS record).
+    rows per destination | order violations | K, or -(pair capacity needed) after an overflow, or TILED_REPEAT when the
+    NMS's grid route gave the scene up (pass the record to ``obb_tiled_result`` -- it answers OBB_ERETRY and notes the size
+    class for this thread -- and call again as it is) | the NMS record).
     """
     L = _lib.lib()
     dev, n = dets.device, dets.size(0)
