@@ -71,6 +71,15 @@ def test_argument_validation_without_gpu():
     assert L.obb_nms_async_result(rec, 1000, ws, info) == _lib.OBB_OK and info[0] == 7
     rec[1] = 1 << 40                                       # more edges than the workspace holds
     assert L.obb_nms_async_result(rec, 1000, ws, info) == _lib.OBB_EWORKSPACE and info[3] > (1 << 39)
+    # a record whose route word says "the grid route gave this scene up" (3 | skip key << 8, at byte 48): the caller repeats
+    # the call as it is -- OBB_ERETRY from obb_nms_async_result and, for a tiled phase's record, from obb_tiled_result
+    rec2 = (ctypes.c_uint32 * 16)()
+    rec2[12] = 3 | ((1 + _lib.KIND_RBOX + 4 + 8) << 8)
+    assert L.obb_nms_async_result(rec2, 20000, L.obb_nms_workspace_bytes(20000, 0, 0), info) == _lib.OBB_ERETRY
+    assert b'repeat' in L.obb_last_error()
+    nb = L.obb_tiled_local_workspace_bytes(20000, 1, 0)
+    assert L.obb_tiled_result(rec2, 0, 20000, 6, 1, -1, nb, info) == _lib.OBB_ERETRY
+    assert L.obb_set_tuning(_lib.TUNE_NMS_GRID, -1) == _lib.OBB_OK          # (forgets the note the two calls above left)
     cnt = ctypes.c_int64(5)
     assert L.obb_soft_nms_f32(null, -1, 0.5, 1, 0.5, 0.001, null, null, ctypes.byref(cnt), null, 0, null) == _lib.OBB_EINVAL
     assert L.obb_soft_nms_f32(null, 3, 0.5, 7, 0.5, 0.001, null, null, ctypes.byref(cnt), null, 0, null) == _lib.OBB_EINVAL
