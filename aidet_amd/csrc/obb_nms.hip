@@ -892,10 +892,24 @@ __global__ __launch_bounds__(256) void nms_ginsert_kernel(const NmsSource src, i
         const uint32_t s00c = ((cy0 << xbits) | cx0) + goff;
         const uint32_t c00 = s00c & mask, c10 = (s00c + 1u) & mask, c01 = (s00c + (uint32_t)fr.ggx) & mask, c11 = (s00c + (uint32_t)fr.ggx + 1u) & mask;
         uint32_t s00 = 0, s10 = 0, s01 = 0, s11 = 0;
-        s00 = GINS_ATOMIC(gcnt, b, c00);
-        if (two_x) s10 = GINS_ATOMIC(gcnt, b, c10);
-        if (two_y) s01 = GINS_ATOMIC(gcnt, b, c01);
-        if (two_x && two_y) s11 = GINS_ATOMIC(gcnt, b, c11);
+#if OBB_GINS_ABL == 0
+        if (two_x && (c00 & 1u) == 0u) {
+          // x neighbours whose counters share an aligned 8-byte word: ONE 64-bit add serves both (the low counter never
+          // carries into the high one) -- a request less at the memory-side atomic units for every second such box
+          const unsigned long long r0 = atomicAdd(reinterpret_cast<unsigned long long *>(gcnt + c00), 0x100000001ull);
+          s00 = (uint32_t)r0; s10 = (uint32_t)(r0 >> 32);
+          if (two_y) {       // (c01 = c00 + ggx has c00's parity: ggx is a power of two >= 2 here)
+            const unsigned long long r1 = atomicAdd(reinterpret_cast<unsigned long long *>(gcnt + c01), 0x100000001ull);
+            s01 = (uint32_t)r1; s11 = (uint32_t)(r1 >> 32);
+          }
+        } else
+#endif
+        {
+          s00 = GINS_ATOMIC(gcnt, b, c00);
+          if (two_x) s10 = GINS_ATOMIC(gcnt, b, c10);
+          if (two_y) s01 = GINS_ATOMIC(gcnt, b, c01);
+          if (two_x && two_y) s11 = GINS_ATOMIC(gcnt, b, c11);
+        }
         if (s00 < (uint32_t)kGridCap) GINS_STORE(gtab, c00, s00, ent); else spill(c00, ent, fail);
         if (two_x) { if (s10 < (uint32_t)kGridCap) GINS_STORE(gtab, c10, s10, ent); else spill(c10, ent, fail); }
         if (two_y) { if (s01 < (uint32_t)kGridCap) GINS_STORE(gtab, c01, s01, ent); else spill(c01, ent, fail); }
