@@ -23,8 +23,8 @@ points; ``box_points``: ``RotatedRect::points``), in the angle / size convention
 reference was written against (theta in [-90, 0) degrees, the `width` is the side along (cos theta, sin theta);
 an axis-aligned box therefore comes back as theta = -90 with width and height swapped).  cv2 is not part of
 this image, so these four are pinned by round trips and analytic cases only (tests/test_rbbox_transforms.py),
-not by vectors of the reference.  Still not here: ``maskobb2thetaobb`` (:166-189; RLE decoding by pycocotools
-and ``cv2.findContours`` -- a mask pipeline, not a box codec).
+not by vectors of the reference.  ``maskobb2thetaobb`` (:166-189; RLE decoding by pycocotools, ``cv2.findContours``,
+``cv2.minAreaRect``) is restated the same way: ``rle_decode``, blobs by ``scipy.ndimage``, ``min_area_rect_points``.
 """
 import math
 
@@ -322,6 +322,118 @@ def min_area_rect(quads):
         new = np.stack([ctr[:, 0], ctr[:, 1], w, h, theta], axis=1)
         out = np.where(take[:, None], new, out)
     return out
+
+
+def min_area_rect_points(points):
+    """(m, 2) points -> (cx, cy, w, h, theta [DEGREES]) of the smallest enclosing rectangle of the set, in the convention
+    of ``min_area_rect``: the directions of the convex hull's edges are tried in hull order (counter-clockwise from the
+    lowest-leftmost point), the smallest area wins, ties go to the earlier edge.  Fewer than two distinct points:
+    w = h = 0, theta = -90; collinear points: a degenerate rectangle along them."""
+    pts = np.unique(np.asarray(points, dtype=np.float64).reshape(-1, 2), axis=0)        # (sorted by x, then y)
+    if len(pts) == 0:
+        return 0.0, 0.0, 0.0, 0.0, -90.0
+    if len(pts) == 1:
+        return float(pts[0, 0]), float(pts[0, 1]), 0.0, 0.0, -90.0
+
+    def half(seq):
+        out = []
+        for q in seq:
+            while len(out) >= 2 and ((out[-1][0] - out[-2][0]) * (q[1] - out[-2][1]) - (out[-1][1] - out[-2][1]) * (q[0] - out[-2][0])) <= 0:
+                out.pop()
+            out.append(q)
+        return out
+    lower, upper = half(pts), half(pts[::-1])
+    hull = np.asarray(lower[:-1] + upper[:-1], dtype=np.float64)
+    best = None
+    for i in range(len(hull)):
+        d = hull[(i + 1) % len(hull)] - hull[i]
+        ln = math.hypot(d[0], d[1])
+        if ln == 0.0:
+            continue
+        u = d / ln
+        v = np.array([-u[1], u[0]])
+        a, b = hull @ u, hull @ v
+        a0, a1, b0, b1 = a.min(), a.max(), b.min(), b.max()
+        lu, lv = a1 - a0, b1 - b0
+        if best is not None and not (lu * lv < best[0]):
+            continue
+        ctr = u * ((a0 + a1) * 0.5) + v * ((b0 + b1) * 0.5)
+        phi = math.degrees(math.atan2(u[1], u[0]))
+        k = math.floor(phi / 90.0) + 1.0
+        theta = phi - 90.0 * k
+        if theta >= 0.0:                                    # (rounding at a multiple of 90)
+            theta -= 90.0
+            k += 1.0
+        w, h = (lv, lu) if int(k) % 2 != 0 else (lu, lv)
+        best = (lu * lv, float(ctr[0]), float(ctr[1]), float(w), float(h), float(theta))
+    return best[1:]
+
+
+def rle_decode(rle):
+    """COCO run-length encoding -> (h, w) uint8 mask, without pycocotools: ``{'size': [h, w], 'counts': ...}`` with the
+    counts as a list (uncompressed) or as the compressed string / bytes of ``maskUtils.encode`` (5 bits per character
+    from '0' on, bit 5 = more follows, sign-extended, every count from the third on stored as the difference to the one
+    two before); runs alternate 0 / 1 from 0, column-major."""
+    h, w = int(rle['size'][0]), int(rle['size'][1])
+    counts = rle['counts']
+    if isinstance(counts, (bytes, str)):
+        data = counts.encode('ascii') if isinstance(counts, str) else counts
+        runs, p = [], 0
+        while p < len(data):
+            x, k, more = 0, 0, True
+            while more:
+                c = data[p] - 48
+                x |= (c & 0x1F) << (5 * k)
+                more = bool(c & 0x20)
+                p += 1
+                k += 1
+                if not more and (c & 0x10):
+                    x |= -1 << (5 * k)
+            if len(runs) > 2:
+                x += runs[-2]
+            runs.append(x)
+        counts = runs
+    flat = np.zeros(h * w, dtype=np.uint8)
+    pos, val = 0, 0
+    for c in counts:
+        if val:
+            flat[pos:pos + c] = 1
+        pos += int(c)
+        val ^= 1
+    return flat.reshape((w, h)).T                             # (column-major runs)
+
+
+def maskobb2thetaobb(maskobb):
+    """Mask (COCO RLE dict, or a 2-D 0 / 1 array) -> [cx, cy, w, h, theta (rad)] of the smallest rectangle around its
+    largest blob (:166-189: ``maskUtils.decode`` -> ``cv2.findContours(RETR_EXTERNAL)`` -> the contour of the largest
+    ``cv2.contourArea`` -> ``cv2.minAreaRect``), without pycocotools and cv2 (neither is part of this image: like the other
+    OpenCV-built codecs above this one is pinned by analytic cases, not by vectors of the reference):
+
+    * blobs = 8-connected components, holes filled (an external contour ignores them);
+    * a blob's contour = its pixels with a background 4-neighbour; ``contourArea`` of the polygon through those pixel
+      centres by Pick's theorem, pixels - boundary pixels / 2 - 1 (exact for a contour that does not touch itself; a
+      one-pixel-wide blob has area 0, as in OpenCV); the first blob in scan order wins among equal areas;
+    * the rectangle = ``min_area_rect_points`` of the contour pixels (x = column, y = row).
+    No foreground: [0, 0, 0, 0, 0]."""
+    from scipy import ndimage
+    mask = rle_decode(maskobb) if isinstance(maskobb, dict) else np.asarray(maskobb)
+    mask = mask.astype(bool)
+    lab, num = ndimage.label(mask, structure=np.ones((3, 3), dtype=bool))
+    if num == 0:
+        return [0, 0, 0, 0, 0]
+    best_area, best_pts = -1.0, None
+    four = np.array([[0, 1, 0], [1, 1, 1], [0, 1, 0]], dtype=bool)
+    for sl_idx, sl in enumerate(ndimage.find_objects(lab), start=1):
+        blob = ndimage.binary_fill_holes(lab[sl] == sl_idx)
+        pad = np.pad(blob, 1)
+        edge = pad & ~ndimage.binary_erosion(pad, structure=four)
+        ys, xs = np.nonzero(edge[1:-1, 1:-1])
+        area = max(float(blob.sum()) - len(ys) / 2.0 - 1.0, 0.0)
+        if best_area < area:
+            best_area = area
+            best_pts = np.stack([xs + sl[1].start, ys + sl[0].start], axis=1)
+    x, y, w, h, theta = min_area_rect_points(best_pts)
+    return [x, y, w, h, theta * np.pi / 180.0]
 
 
 def pointobb2thetaobb(pointobb, truncate=True):

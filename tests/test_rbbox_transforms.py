@@ -172,6 +172,74 @@ def test_min_area_rect_codecs_without_opencv():
     assert np.abs(twice - h0).max() < 3.0
 
 
+def _raster(cx, cy, w, h, th, H=220, W=260):
+    ys, xs = np.mgrid[0:H, 0:W]
+    dx, dy = xs - cx, ys - cy
+    u, v = dx * np.cos(th) + dy * np.sin(th), -dx * np.sin(th) + dy * np.cos(th)
+    return ((np.abs(u) <= w / 2) & (np.abs(v) <= h / 2)).astype(np.uint8)
+
+
+def _rle(mask, compressed):
+    """the encoder side of COCO's RLE, for the test only: column-major runs from 0; the compressed form of maskUtils"""
+    flat = mask.T.reshape(-1)
+    runs, val, c = [], 0, 0
+    for b in flat:
+        if b != val:
+            runs.append(c); c = 0; val = b
+        c += 1
+    runs.append(c)
+    if not compressed:
+        return {'size': list(mask.shape), 'counts': runs}
+    out = bytearray()
+    for i, x in enumerate(runs):
+        if i > 2:
+            x -= runs[i - 2]
+        more = True
+        while more:
+            c = x & 0x1F
+            x >>= 5
+            more = not ((x == -1 and (c & 0x10)) or (x == 0 and not (c & 0x10)))
+            out.append((c | 0x20 if more else c) + 48)
+    return {'size': list(mask.shape), 'counts': bytes(out)}
+
+
+def test_maskobb2thetaobb_without_opencv_and_pycocotools():
+    """maskobb2thetaobb (transforms.py:166-189: maskUtils.decode -> cv2.findContours -> largest contourArea ->
+    cv2.minAreaRect) restated on numpy / scipy.ndimage: rasterised rotated rectangles come back to within a pixel in the
+    minAreaRect convention, the largest blob wins, holes do not matter, both RLE forms decode, an empty mask gives zeros."""
+    for cx, cy, w, h, deg in ((120, 90, 80, 30, -30.0), (100, 110, 40, 90, -62.0), (130, 100, 60, 24, -8.0)):
+        m = _raster(cx, cy, w, h, np.radians(deg))
+        m[5:9, 5:12] = 1                                            # a second, smaller blob
+        m[int(cy) - 1:int(cy) + 2, int(cx) - 1:int(cx) + 2] = 0     # a hole in the large one
+        for form in (m, _rle(m, False), _rle(m, True)):
+            x, y, ww, hh, th = T.maskobb2thetaobb(form)
+            assert -np.pi / 2 <= th < 0.0
+            assert abs(x - cx) < 1.0 and abs(y - cy) < 1.0 and abs(ww - w) < 1.5 and abs(hh - h) < 1.5
+            assert abs(np.degrees(th) - deg) < 1.5
+    # both RLE forms decode to the mask they came from (odd sizes, runs longer than 31 and 1023: multi-character counts)
+    rng = np.random.default_rng(1)
+    m = (rng.random((37, 53)) < 0.3).astype(np.uint8)
+    m[:, 20:45] = 0
+    for compressed in (False, True):
+        assert np.array_equal(T.rle_decode(_rle(m, compressed)), m)
+    big = np.zeros((300, 70), np.uint8)
+    big[10:290, 3:60] = 1
+    assert np.array_equal(T.rle_decode(_rle(big, True)), big)
+    # axis-aligned blob: the minAreaRect quirk (theta = -90 degrees, sizes swapped); pixel centres span 9 x 3
+    ax = np.zeros((20, 30), np.uint8)
+    ax[5:9, 10:20] = 1
+    assert T.maskobb2thetaobb(ax) == [14.5, 6.5, 3.0, 9.0, -np.pi / 2]
+    assert T.maskobb2thetaobb(np.zeros((10, 10), np.uint8)) == [0, 0, 0, 0, 0]
+    one = np.zeros((10, 10), np.uint8)
+    one[4, 7] = 1
+    assert T.maskobb2thetaobb(one) == [7.0, 4.0, 0.0, 0.0, -np.pi / 2]
+    # the point-set form agrees with the four-point form on the corners of a rectangle
+    t = np.array([[50., 40., 30., 12., -0.4]])
+    a = T.min_area_rect(T.box_points(t))[0]
+    b = T.min_area_rect_points(T.box_points(t).reshape(-1, 2))
+    assert np.allclose(a, b, atol=1e-9)
+
+
 @pytest.mark.parametrize('enc,dim', [('thetaobb', 5), ('pointobb', 8), ('hobb', 5)])
 def test_rbbox_target_reproduces_reference(golden, enc, dim):
     """core/rbbox/rbbox_target.py on three images (one without positives, one without negatives)."""
