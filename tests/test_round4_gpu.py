@@ -549,6 +549,18 @@ def test_position_free_soft_nms_and_its_fallback():
         if n >= 200:
             nd, inds = soft_nms(t(e), 0.3, method='linear', sigma=0.5, min_score=min_score)
             assert L.obb_soft_nms_last_path() == 3
+    # the other launch shapes of the kernel (OBB_TUNE_SOFT_NMS_SHAPE: 256 / 512 threads x more boxes; measurements only)
+    for shape in (1, 2):
+        try:
+            _lib.set_tuning(_lib.TUNE_SOFT_NMS_SHAPE, shape)
+            for n in (300, 900, 2048, 3500):
+                x1, y1 = rng.uniform(0, 400, n), rng.uniform(0, 400, n)
+                d = np.stack([x1, y1, x1 + rng.uniform(4, 60, n), y1 + rng.uniform(4, 60, n), rng.permutation(n) / n + 1e-3], 1).astype(np.float32)
+                nd, inds = soft_nms(t(d), 0.3, method='linear', sigma=0.5, min_score=0.05)
+                rd, ri = oracle.soft_nms(d, 0.3, 'linear', 0.5, 0.05)
+                assert np.array_equal(inds.cpu().numpy(), ri) and np.array_equal(nd.cpu().numpy(), rd), (shape, n)
+        finally:
+            _lib.set_tuning(_lib.TUNE_SOFT_NMS_SHAPE, -1)
 
 
 def test_grid_route_on_millions_of_boxes(nms_route):
