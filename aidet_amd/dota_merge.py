@@ -630,6 +630,7 @@ def tiled_merge_phase(recv, seg_starts, key_max, total, num_classes, iou_thr, cl
     seg = (ctypes.c_int64 * world)(*[int(v) for v in seg_starts])
     info = (ctypes.c_int64 * 4)()
     capacity = _phase_capacity.get((1, int(total).bit_length()), 0)
+    retries = 0
     while True:
         nbytes = int(L.obb_tiled_merge_workspace_bytes(total, cols, world, kmax, capacity))
         if nbytes == 0:
@@ -647,6 +648,9 @@ def tiled_merge_phase(recv, seg_starts, key_max, total, num_classes, iou_thr, cl
         if rc == _lib.OBB_ERETRY:             # the NMS's grid route gave up on this scene: once more, as it is
             global phase_repeats
             phase_repeats += 1
+            retries += 1
+            if retries > 3:
+                raise _lib.ObbOpsError('the merge phase asks to be repeated again and again: ' + L.obb_last_error().decode())
             continue
         if rc != _lib.OBB_EWORKSPACE:
             _lib.check(rc)
@@ -673,6 +677,7 @@ def _tiled_fused(dets, labels, patch_index, patch_xy, patch_image, num_classes, 
     if route_world > ROUTE_MAX_WORLD or (world > 1 and (P + 1) * world > RESTORE_MAX_SLOTS):
         return None
     capacity = None
+    repeats = 0
     while True:
         rows, counts = tiled_local_phase(dets, labels, patch_index, patch_xy, patch_image, num_classes, local_thr,
                                          route_world, capacity=capacity)
@@ -694,9 +699,13 @@ def _tiled_fused(dets, labels, patch_index, patch_xy, patch_image, num_classes, 
             rec = np.asarray(mat[rank][route_world + 2:], dtype=np.int64)
             info = (ctypes.c_int64 * 4)()
             nb = int(_lib.lib().obb_tiled_local_workspace_bytes(n, route_world, capacity or 0))
-            assert _lib.lib().obb_tiled_result(rec.ctypes.data, 0, n, 6, route_world, -1, nb, info) == _lib.OBB_ERETRY
+            rc = _lib.lib().obb_tiled_result(rec.ctypes.data, 0, n, 6, route_world, -1, nb, info)
             global phase_repeats
             phase_repeats += 1
+            repeats += 1
+            if rc != _lib.OBB_ERETRY or repeats > 3:      # (the library's note sends the next try down the general route)
+                raise _lib.ObbOpsError('the per-patch phase asks to be repeated again and again (rc %d): %s'
+                                       % (rc, _lib.lib().obb_last_error().decode()))
             continue
         # a rank's per-patch NMS overflowed its pair lists (every rank sees it): that rank repeats its phase with the
         # capacity its kernels asked for, everybody repeats the exchange of the counts
