@@ -37,10 +37,10 @@ extern "C" int obb_set_tuning(int knob, int64_t value) {
   return OBB_OK;
 }
 
-extern "C" int obb_version(void) { return 101; }
+extern "C" int obb_version(void) { return 102; }
 
 extern "C" const char *obb_build_info(void) {
-  return "libobbops 1.1 | OBB-GEOM v1 | gfx950 | -ffp-contract=off | HIP " __VERSION__;
+  return "libobbops 1.2 | OBB-GEOM v1 | gfx950 | -ffp-contract=off | HIP " __VERSION__;
 }
 
 extern "C" const char *obb_last_error(void) { return obb::err_buf(); }
