@@ -104,6 +104,7 @@ struct NmsCounters {
   unsigned int state;                      // fused resolve + compaction: 0 wait, 1 all shards resolved (go), 2 a waiter gave up
   unsigned int grid_fail;                  // grid route: too many crowded cells / a box over too many cells -- repeat on the sorted route
   alignas(256) unsigned int grid_over;     // grid route: entries on the overflow list (may exceed grid_over_cap(n))
+  unsigned int grid_big;                   // grid route: boxes over more than kGridMaxCells cells (may exceed grid_big_cap(n)); (the line of grid_over: both move in rare scenes only)
   alignas(256) unsigned long long cand_total;           // candidate pairs over all shards
   unsigned long long cand_worst;           // fullest shard
 };
@@ -796,9 +797,17 @@ constexpr int kGridMaxBits = 22;         // at most 2^22 cells in the table (2 G
 constexpr int kGridOverMax = 32768;      // the overflow list's memory (entries that found their cell full) ...
 // ... of which a call uses max(4096, n / 256): more entries and the route gives up (every entry costs a wave a pass over the
 // list: 4096 entries ~10 us, 32 768 ~0.5 ms -- in proportion only for the calls of millions of boxes that may have them)
+// boxes that touch more than kGridMaxCells cells (an airport among vehicles) are not inserted: they go on the BIG list and
+// the probe tests each of them against every box of the call (20 bytes per box: its record's intervals, its area); the list holds
+// 1024 boxes and at most 2^28 / n (1.25 M boxes: 214), more and the route gives up
+constexpr int kGridBigMax = 1024;
+__host__ __device__ inline uint32_t grid_big_cap(int64_t n) {
+  const int64_t c = ((int64_t)1 << 28) / (n > 0 ? n : 1);
+  return (uint32_t)(c > kGridBigMax ? kGridBigMax : (c < 1 ? 1 : c));
+}
 __host__ __device__ inline uint32_t grid_over_cap(int64_t n) {
   const int64_t c = n / 256;
-  return (uint32_t)(c < 4096 ? 4096 : (c > kGridOverMax ? kGridOverMax : c));
+  return (uint32_t)(c < 4096 ? 4096 : (c > kGridOverMax - kGridBigMax ? kGridOverMax - kGridBigMax : c));   // (the last kGridBigMax cell words hold the big list)
 }
 constexpr int kGridSkipCalls = 256;
 constexpr int64_t kGridAutoMax = 12000000;   // (the layout holds a table up to 2^24 boxes)
@@ -826,13 +835,39 @@ __device__ __forceinline__ uint32_t grid_entry_word(float area, uint32_t tag) { 
 #else
 #define GINS_STORE(tab_, cell_, slot_, e_) (tab_)[(size_t)(cell_) * kGridCap + (slot_)] = (e_)
 #endif
+// a box's packed 15-bit interval in the call's frame and the cells it touches (shared by the insert kernel and the big
+// boxes' pass of the probe, which rebuilds it from the record: the same expressions, the same bits).  false: isolated.
+__device__ __forceinline__ bool grid_interval(float ox, float ex, float oy, float ey, bool wellformed, const NmsFrame &fr,
+                                              uint2 &o, uint32_t &cx0, uint32_t &cx1, uint32_t &cy0, uint32_t &cy1) {
+  float4 v;
+  nms_interval(ox, ex, v.x, v.y);
+  nms_interval(oy, ey, v.z, v.w);
+  const float big = 3.0e38f;
+  const bool fin = wellformed && (fabs_sel(v.x) < big) && (fabs_sel(v.y) < big) && (fabs_sel(v.z) < big) && (fabs_sel(v.w) < big);
+  o = make_uint2(kSentLo, kSentHi);             // an isolated box: in no cell, meets nothing
+  cx0 = cx1 = cy0 = cy1 = 0u;
+  if (!fin) return false;
+  auto qz = [](float x, float b, float s2) {
+    float u = floorf((x - b) * s2);
+    u = u < 0.0f ? 0.0f : (u > (float)kQMax ? (float)kQMax : u);
+    return (uint32_t)u;
+  };
+  const uint32_t xl = qz(v.x, fr.bx, fr.sx), xh = qz(v.y, fr.bx, fr.sx);
+  const uint32_t yl = qz(v.z, fr.by, fr.sy), yh = qz(v.w, fr.by, fr.sy);
+  o.x = xl | (yl << 16);
+  o.y = (xh | (yh << 16)) | kGuard;
+  cx0 = xl >> fr.gshx; cx1 = xh >> fr.gshx; cy0 = yl >> fr.gshy; cy1 = yh >> fr.gshy;
+  return true;
+}
+
 template <int KIND>
 __global__ __launch_bounds__(256) void nms_ginsert_kernel(const NmsSource src, int64_t n, QuadRec *__restrict__ rec,
                                                           float *__restrict__ ar,
                                                           const NmsFrame *__restrict__ frame, float thr,
                                                           uint32_t *__restrict__ gcnt, uint4 *__restrict__ gtab,
                                                           NmsCounters *__restrict__ ctr, uint32_t mask,
-                                                          uint4 *__restrict__ gover) {
+                                                          uint4 *__restrict__ gover, uint32_t *__restrict__ gbig,
+                                                          uint32_t big_cap, int give_up) {    // (big_cap = grid_big_cap(n), a 64-bit division: the host's)
   constexpr int S = KIND == 0 ? 6 : (KIND == 1 ? 9 : 5);
   const NmsFrame fr = *frame;
   uint32_t *__restrict__ gover_cell = reinterpret_cast<uint32_t *>(gover + kGridOverMax);
@@ -846,12 +881,8 @@ __global__ __launch_bounds__(256) void nms_ginsert_kernel(const NmsSource src, i
   };
   const bool grouped = src_grouped(src);
   const uint32_t fail = 1u + (uint32_t)KIND + (grouped ? 4u : 0u) + 8u * (uint32_t)src.mode;   // (non-zero; names the size class's skip hint: kind, grouped, source mode)
+  if (give_up && blockIdx.x == 0 && threadIdx.x == 0) ctr->grid_fail = fail;      // (test hook, OBB_TUNE_NMS_GRID = 2: the repeat paths without a crowded scene)
   const int xbits = 15 - fr.gshx;                  // ggx = 2^xbits
-  auto qz = [](float x, float b, float s2) {
-    float u = floorf((x - b) * s2);
-    u = u < 0.0f ? 0.0f : (u > (float)kQMax ? (float)kQMax : u);
-    return (uint32_t)u;
-  };
   for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n; b += (int64_t)gridDim.x * blockDim.x) {
     const float *row = src.dets + b * src.pitch;
     Quad q;
@@ -869,22 +900,15 @@ __global__ __launch_bounds__(256) void nms_ginsert_kernel(const NmsSource src, i
     ar[b] = q.area;
     const uint32_t tag = grouped ? grid_tag(r.group) : 0u;
     const uint32_t goff = grid_tag_offset(tag, mask);
-    float4 v;
-    nms_interval(q.ox, q.ex, v.x, v.y);
-    nms_interval(q.oy, q.ey, v.z, v.w);
-    const float big = 3.0e38f;
-    const bool fin = wellformed && (fabs_sel(v.x) < big) && (fabs_sel(v.y) < big) && (fabs_sel(v.z) < big) && (fabs_sel(v.w) < big);
-    uint2 o = make_uint2(kSentLo, kSentHi);     // an isolated box: in no cell, meets nothing
-    if (fin) {
-      const uint32_t xl = qz(v.x, fr.bx, fr.sx), xh = qz(v.y, fr.bx, fr.sx);
-      const uint32_t yl = qz(v.z, fr.by, fr.sy), yh = qz(v.w, fr.by, fr.sy);
-      o.x = xl | (yl << 16);
-      o.y = (xh | (yh << 16)) | kGuard;
-      const uint32_t cx0 = xl >> fr.gshx, cx1 = xh >> fr.gshx, cy0 = yl >> fr.gshy, cy1 = yh >> fr.gshy;
+    uint2 o;
+    uint32_t cx0, cx1, cy0, cy1;
+    if (grid_interval(q.ox, q.ex, q.oy, q.ey, wellformed, fr, o, cx0, cx1, cy0, cy1)) {
       const uint32_t ncell = (cx1 - cx0 + 1u) * (cy1 - cy0 + 1u);
       const uint4 ent = make_uint4(o.x, o.y, (uint32_t)b, grid_entry_word(r.area, tag));
       if (ncell > (uint32_t)kGridMaxCells) {
-        ctr->grid_fail = fail;
+        const uint32_t k = atomicAdd(&ctr->grid_big, 1u);
+        if (k < big_cap) gbig[k] = (uint32_t)b;
+        else ctr->grid_fail = fail;
       } else if (cx1 - cx0 <= 1u && cy1 - cy0 <= 1u) {
         // the usual box (a cell is about mean + sigma extent wide): 1-4 cells, their slots requested TOGETHER -- a
         // returning device-scope atomic is a round trip of ~2 us and four of them in a row were most of this kernel
@@ -1877,7 +1901,9 @@ __global__ __launch_bounds__(64 * kNmsWaves) void nms_gprobe_kernel(const QuadRe
                                                            unsigned long long *__restrict__ ccnts, int *__restrict__ cnt,
                                                            const NmsCounters *__restrict__ ctr,
                                                            const uint4 *__restrict__ gover, uint32_t over_cap,
-                                                           const float *__restrict__ thr_table, int thr_count) {
+                                                           const float *__restrict__ thr_table, int thr_count,
+                                                           const float *__restrict__ ar,
+                                                           const uint32_t *__restrict__ gbig, uint32_t big_cap, uint32_t n) {
   static_assert(kGridCap == 32, "two cells per 64-lane load");
   __shared__ uint2 queue[kNmsWaves][kNmsQueue];
   __shared__ uint4 ent[kNmsWaves][kGridCpwMax * kGridCap];
@@ -1897,7 +1923,9 @@ __global__ __launch_bounds__(64 * kNmsWaves) void nms_gprobe_kernel(const QuadRe
   const uint32_t chunks = (cells + (1u << cl) - 1u) >> cl;
   const uint32_t nover_all = ctr->grid_over;                      // (written by the insert launch)
   const uint32_t nover = nover_all < over_cap ? nover_all : over_cap;
-  if (gw >= chunks && gw >= nover) return;
+  const uint32_t nbig_all = ctr->grid_big;
+  const uint32_t nbig = nbig_all < big_cap ? nbig_all : big_cap;
+  if (gw >= chunks && gw >= nover && nbig == 0u) return;
   if (__hip_atomic_load(&ctr->grid_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;   // the call is repeated on the sorted route
   GP_STAMP(1);
   uint2 *q = queue[wave];
@@ -2051,6 +2079,44 @@ __global__ __launch_bounds__(64 * kNmsWaves) void nms_gprobe_kernel(const QuadRe
       }
     }
     GP_ACC_END(acc_over);
+  }
+  // ---- the big list: every box that touches more cells than an entry list may name, against EVERY box of the call, 64
+  // per step -- their packed intervals are rebuilt from the records (grid_interval: the insert kernel's expressions), so
+  // the common call stores nothing for this pass; two big boxes meet once, in the step of the one with the lower number
+  if (nbig > 0u) {
+    const uint32_t nblk = (n + 63u) >> 6;
+    const unsigned long long items = (unsigned long long)nbig * nblk;
+    auto packed = [&](uint32_t x, uint2 &o, bool &is_big) {
+      const float4 *r4 = reinterpret_cast<const float4 *>(rec + x);
+      const float4 f = r4[0];                     // ox, oy, ex, ey
+      bool wellformed = true;
+      if (flags & kFlagHbb) { const float4 c = r4[1]; wellformed = ((c.z - c.x) + 1.0f > 0.0f) && ((c.w - c.y) + 1.0f > 0.0f); }   // (hbb_record)
+      uint32_t cx0, cx1, cy0, cy1;
+      const bool in = grid_interval(f.x, f.z, f.y, f.w, wellformed, fr, o, cx0, cx1, cy0, cy1);
+      is_big = in && (cx1 - cx0 + 1u) * (cy1 - cy0 + 1u) > (uint32_t)kGridMaxCells;
+    };
+    for (unsigned long long it = gw; it < items; it += nw) {
+      const uint32_t bi = (uint32_t)(it / nblk), blk = (uint32_t)(it - (unsigned long long)bi * nblk);
+      const uint32_t B = gbig[bi];
+      uint2 qB;
+      bool bigB;
+      packed(B, qB, bigB);
+      const float aB = ar[B];
+      const uint32_t x = blk * 64u + (uint32_t)lane;
+      bool cnd = false;
+      if (x < n && x != B) {
+        uint2 qx;
+        bool bigx;
+        packed(x, qx, bigx);
+        cnd = qdisjoint(qB.x, qB.y, qx.x, qx.y) == 0u && (!bigx || B < x);
+        if (cnd && tp.thr > 0.0f) {
+          const float ax = ar[x];
+          cnd = !(min_sel(aB, ax) < (tp.thr * max_sel(aB, ax)) * 0.999999f) &&
+                (qedge2(qB.x, qB.y, qx.x, qx.y) || prune_aabb(tp, qB.x, qB.y, aB, qx.x, qx.y, ax));
+        }
+      }
+      push(cnd, B, x);
+    }
   }
   GP_STAMP(3);
   if (qn > 0) {
@@ -2819,6 +2885,7 @@ struct NmsLayout {
   int64_t ntiles;
   int grid_log2;                  // grid route: cells per axis = 2^grid_log2 at most (0: no grid table in this layout)
   size_t gover;                   // grid route: the overflow list (entries that found their cell full)
+  size_t gbig;                    // grid route: the boxes over too many cells
   int grid_bits;                  // ... and 2^grid_bits cells in the table (>= 2 * grid_log2: the groups of a grouped call share it)
 };
 
@@ -2856,6 +2923,7 @@ static int nms_layout(int64_t n, int64_t edge_capacity, NmsLayout &L) {
     L.grid_log2 = g; L.grid_bits = bits;
     L.gtab = take(((size_t)1 << bits) * kGridCap * sizeof(uint4));
     L.gover = take((size_t)kGridOverMax * (sizeof(uint4) + sizeof(uint32_t)));     // overflow entries, then their cells
+    L.gbig = L.gover + (size_t)kGridOverMax * sizeof(uint4) + (size_t)(kGridOverMax - kGridBigMax) * sizeof(uint32_t);   // (the tail of the overflow cells' array: grid_over_cap)
   }
   L.qs = take((nt * kTile + kRowChunk) * sizeof(uint2));
   L.pf = take((nt * kTile) * sizeof(uint4));
@@ -3154,12 +3222,12 @@ int nms_enqueue_source(const char *who, NmsSource src, int64_t n, int kind, floa
   // ---- grid route (see nms_ginsert_kernel): float calls above the direct route's range, from the entry points that can
   // repeat a call (src.allow_grid), unless this thread's last try of the size class failed
   {
-    const int64_t gknob = tuning(OBB_TUNE_NMS_GRID, -1);          // -1 auto, 0 never, 1 wherever it applies
+    const int64_t gknob = tuning(OBB_TUNE_NMS_GRID, -1);          // -1 auto, 0 never, 1 wherever it applies, 2 the same and give up at once (test hook)
     // (auto: up to kGridAutoMax boxes; profiles/r04_grid_vs_sorted.txt: 1.2 - 1.7 x the sorted route from 12 000 to 1.4 M
     // boxes, ungrouped and grouped)
     const bool grouped_call = src.mode != 0 || group_dev != nullptr;
     const bool grid = !direct && L.grid_log2 > 0 && n > direct_max && !f64 && src.allow_grid != 0 &&
-                      gknob != 0 && (gknob == 1 || n <= kGridAutoMax) && !grid_skip_take(n, kind + (grouped_call ? 4 : 0) + 8 * src.mode);
+                      gknob != 0 && (gknob >= 1 || n <= kGridAutoMax) && !grid_skip_take(n, kind + (grouped_call ? 4 : 0) + 8 * src.mode);
     q.grid = grid;
     if (grid) {
       const size_t gcells = (size_t)1 << L.grid_bits;
@@ -3170,6 +3238,7 @@ int nms_enqueue_source(const char *who, NmsSource src, int64_t n, int kind, floa
       zb = zb > 256u ? 256u : zb;
       uint4 *gtab = reinterpret_cast<uint4 *>(ws + L.gtab);
       uint4 *gover = reinterpret_cast<uint4 *>(ws + L.gover);
+      uint32_t *gbig = reinterpret_cast<uint32_t *>(ws + L.gbig);
       const int hbits = 7, grid_log2 = L.grid_log2;
       OBB_PHASE(0);
       if (kind == OBB_KIND_RBOX) hipLaunchKernelGGL(nms_frame_kernel<0>, dim3(zb), dim3(256), 0, st, src, n, hbits, frame, zero, zero_vecs, grid_log2);
@@ -3177,9 +3246,9 @@ int nms_enqueue_source(const char *who, NmsSource src, int64_t n, int kind, floa
       else hipLaunchKernelGGL(nms_frame_kernel<2>, dim3(zb), dim3(256), 0, st, src, n, hbits, frame, zero, zero_vecs, grid_log2);
       OBB_LAUNCH_CHECK();
       const uint32_t gmask = (uint32_t)gcells - 1u;
-      if (kind == OBB_KIND_RBOX) hipLaunchKernelGGL(nms_ginsert_kernel<0>, dim3(pblocks), dim3(256), 0, st, src, n, rec, ar, frame, iou_thr, hist, gtab, ctr, gmask, gover);
-      else if (kind == OBB_KIND_POLY) hipLaunchKernelGGL(nms_ginsert_kernel<1>, dim3(pblocks), dim3(256), 0, st, src, n, rec, ar, frame, iou_thr, hist, gtab, ctr, gmask, gover);
-      else hipLaunchKernelGGL(nms_ginsert_kernel<2>, dim3(pblocks), dim3(256), 0, st, src, n, rec, ar, frame, iou_thr, hist, gtab, ctr, gmask, gover);
+      if (kind == OBB_KIND_RBOX) hipLaunchKernelGGL(nms_ginsert_kernel<0>, dim3(pblocks), dim3(256), 0, st, src, n, rec, ar, frame, iou_thr, hist, gtab, ctr, gmask, gover, gbig, grid_big_cap(n), gknob == 2 ? 1 : 0);
+      else if (kind == OBB_KIND_POLY) hipLaunchKernelGGL(nms_ginsert_kernel<1>, dim3(pblocks), dim3(256), 0, st, src, n, rec, ar, frame, iou_thr, hist, gtab, ctr, gmask, gover, gbig, grid_big_cap(n), gknob == 2 ? 1 : 0);
+      else hipLaunchKernelGGL(nms_ginsert_kernel<2>, dim3(pblocks), dim3(256), 0, st, src, n, rec, ar, frame, iou_thr, hist, gtab, ctr, gmask, gover, gbig, grid_big_cap(n), gknob == 2 ? 1 : 0);
       OBB_LAUNCH_CHECK();
       OBB_PHASE(1); OBB_PHASE(2);
       OBB_PHASE(3);
@@ -3194,10 +3263,10 @@ int nms_enqueue_source(const char *who, NmsSource src, int64_t n, int kind, floa
       const int gthr_n = (int)(src.mult < (1 << 20) ? src.mult : (1 << 20));
       if (grouped_call)
         hipLaunchKernelGGL(nms_gprobe_kernel<true>, dim3((unsigned)gp_blocks), dim3(64 * kNmsWaves), 0, st,
-                           rec, frame, hist, gtab, (uint32_t)gcells, prune_thr, thr_dev ? 1 : 0, flags, edges, segcap, ccnts, cnt, ctr, gover, grid_over_cap(n), gthr, gthr_n);
+                           rec, frame, hist, gtab, (uint32_t)gcells, prune_thr, thr_dev ? 1 : 0, flags, edges, segcap, ccnts, cnt, ctr, gover, grid_over_cap(n), gthr, gthr_n, ar, gbig, grid_big_cap(n), (uint32_t)n);
       else
         hipLaunchKernelGGL(nms_gprobe_kernel<false>, dim3((unsigned)gp_blocks), dim3(64 * kNmsWaves), 0, st,
-                           rec, frame, hist, gtab, (uint32_t)gcells, prune_thr, thr_dev ? 1 : 0, flags, edges, segcap, ccnts, cnt, ctr, gover, grid_over_cap(n), gthr, gthr_n);
+                           rec, frame, hist, gtab, (uint32_t)gcells, prune_thr, thr_dev ? 1 : 0, flags, edges, segcap, ccnts, cnt, ctr, gover, grid_over_cap(n), gthr, gthr_n, ar, gbig, grid_big_cap(n), (uint32_t)n);
       OBB_LAUNCH_CHECK();
       OBB_PHASE(4);
       OBB_PHASE(5);

@@ -578,7 +578,7 @@ OBB_API int obb_head_gather_decode_f32(const float *rois_dev, const float *cls_s
 #define OBB_TUNE_SOFT_NMS_REG 9       /* float Soft-NMS of one array: 1 the position-tracking register kernel (the float64 one), n <= 8192; 2 the array kernel only (no position-free first try) */
 #define OBB_TUNE_NMS_FUSED_COMPACT 10  /* 0: the sorted route's compaction as a launch of its own (as from 2^18 boxes on); 2: the waiting shards give up at once */
 #define OBB_TUNE_RROI_PLAN 11          /* fewest RoIs the workspace forward of RoI-Align plans per RoI (default 1024; 0 = always) */
-#define OBB_TUNE_NMS_GRID 12           /* grid route of the NMS: 0 never, 1 wherever it applies (ignoring the thread's skip hints); default auto */
+#define OBB_TUNE_NMS_GRID 12           /* grid route of the NMS: 0 never, 1 wherever it applies, 2 the same but it gives up at once (test hook for the repeat paths); default auto.  Setting it clears the calling thread's "skip the grid" notes */
 #define OBB_TUNE_SOFT_NMS_SHAPE 13     /* 1: the position-free Soft-NMS kernel as 256 threads x up to 8 boxes (default: up to 1024 threads x 1-4 boxes) */
 #define OBB_TUNE_COUNT 14
 OBB_API int obb_set_tuning(int knob, int64_t value);

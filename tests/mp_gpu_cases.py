@@ -56,9 +56,9 @@ def tiled_inputs(rank, world, images=2, image_size=2048, objects=1500):
 
 def crowd_inputs(rank, world):
     """The scene 'two' with the detections of its FIRST patch replaced by 600 boxes of one class within a few pixels:
-    more than a cell of the NMS's grid route holds (they go on its overflow list), one of them huge (it touches more cells
-    than a box may: with the route forced, the rank that owns patch 0 gives it up in its per-patch phase and every rank
-    repeats the exchange)."""
+    more than a cell of the NMS's grid route holds (they go on its overflow list), one of them huge (it goes on the big
+    list).  The worker runs it a second time with the give-up hook on rank 0 only: that rank's per-patch phase is repeated
+    and every rank repeats the exchange."""
     scene = workloads.tiled_scene(images=2, image_size=2048, objects_per_image=1500, num_classes=NUM_CLASSES, seed=5)
     rng = np.random.default_rng(9)
     first = np.nonzero(scene['patch'] == 0)[0]
@@ -68,7 +68,7 @@ def crowd_inputs(rank, world):
     d[:, 2:4] = 24.0 + rng.random((m, 2)).astype(np.float32) * 4.0
     d[:, 4] = -rng.random(m).astype(np.float32)
     d[:, 5] = (rng.permutation(m) + 0.5) / m
-    d[0, 2:5] = [3000.0, 2800.0, -0.3]           # and one box over more cells than an entry list may name: the route gives up
+    d[0, 2:5] = [3000.0, 2800.0, -0.3]           # and one box over more cells than an entry list may name: the big list
     keep = np.ones(len(scene['dets']), bool)
     keep[first] = False
     dets = np.concatenate([d, scene['dets'][keep]])

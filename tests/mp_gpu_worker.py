@@ -52,6 +52,8 @@ def main():
                 res[tag + '_kept'], res[tag + '_keep'], res[tag + '_rows'] = (x.cpu().numpy() for x in (kept, keep, rows))
         if force_grid:   # (b') a rank whose per-patch NMS gives the grid up: the repeat word travels with the count exchange
             args = [a.to(dev) for a in cases.crowd_inputs(rank, world)]
+            if rank == 0:    # (OBB_TUNE_NMS_GRID = 2: the route gives up at once -- here on one rank only)
+                _lib.set_tuning(_lib.TUNE_NMS_GRID, 2)
             for layout, gather in cases.LAYOUTS:
                 kept, keep, rows = dota_merge.tiled_inference_merge(*args, cases.NUM_CLASSES, 0.5, 0.3, cases.CLASS_THRS,
                                                                     layout=layout, gather_result=gather)

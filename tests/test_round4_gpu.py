@@ -349,10 +349,28 @@ def test_grid_route_is_exact_and_gives_up_on_crowded_scenes(nms_route):
         assert route == 4, (n, route)
         if n <= 20000:
             assert np.array_equal(got, oracle.rnms(d, 0.5)), n
-    # a box that touches more cells than an entry list may hold gives the route up: same result through the sorted route
+    # boxes that touch more cells than an entry list may name go on the BIG list and are tested against every box: a few
+    # huge boxes among the small ones (two of them on top of each other), per-box thresholds, groups
     d = oracle.synth_boxes(5000, 6000, 9)
     d[11, 2:5] = [3000.0, 2500.0, -0.7]
+    d[12, :5] = d[11, :5] + np.float32([20.0, -15.0, 0.0, 0.0, 0.02])
+    d[13, :5] = [1500.0, 4000.0, 2800.0, 300.0, -0.1]
+    d[14, 2:4] = [1200.0, 1400.0]
     nms_route('grid')
+    got = rnms(t(d), 0.5)[1].cpu().numpy()
+    assert L.obb_nms_last_route() == 4 and np.array_equal(got, oracle.rnms(d, 0.5))
+    gg = rng.integers(0, 3, len(d)).astype(np.int32)
+    tt = rng.choice([0.2, 0.5], len(d)).astype(np.float32)
+    got = rnms(t(d), 0.5, groups=gg, thrs=tt)[1].cpu().numpy()
+    assert L.obb_nms_last_route() == 4 and np.array_equal(got, oracle.rnms(d, 0.5, groups=gg, thrs=tt))
+    # more big boxes than the big list holds (1024): the route gives up, the call is repeated on the sorted route
+    d2 = oracle.synth_boxes(6000, 6000, 10)
+    d2[:1100, 2] = 2000.0 + rng.random(1100).astype(np.float32) * 1500.0
+    d2[:1100, 3] = 1800.0 + rng.random(1100).astype(np.float32) * 1500.0
+    got = rnms(t(d2), 0.5)[1].cpu().numpy()
+    assert L.obb_nms_last_route() == 5 and np.array_equal(got, oracle.rnms(d2, 0.5))
+    # the test hook: the route gives up at once, the call is repeated on the sorted route
+    _lib.set_tuning(_lib.TUNE_NMS_GRID, 2)
     got = rnms(t(d), 0.5)[1].cpu().numpy()
     assert L.obb_nms_last_route() == 5 and np.array_equal(got, oracle.rnms(d, 0.5))
     # other kinds, per-box thresholds, strict
@@ -462,6 +480,13 @@ def test_fused_tiled_phases_on_the_grid_route_and_its_repeat(nms_route):
     got = dota_merge.tiled_inference_merge(*base, 3, 0.5, 0.3, None)
     for a, b in zip(got, want):
         assert torch.equal(a, b)
+    # the repeat paths of both phases through the hook (OBB_TUNE_NMS_GRID = 2: the route gives up at once)
+    before = dota_merge.phase_repeats
+    _lib.set_tuning(_lib.TUNE_NMS_DIRECT_MAX, 0)
+    _lib.set_tuning(_lib.TUNE_NMS_GRID, 2)
+    hk, hkeep, hrows = dota_merge.tiled_inference_merge(*args, 5, 0.5, 0.3, thrs)
+    assert dota_merge.phase_repeats == before + 2               # the per-patch phase and the merge phase, once each
+    assert torch.equal(hrows, srows) and torch.equal(hkeep, skeep) and torch.equal(hk, sk)
     nms_route('auto')
     dota_merge._phase_capacity.clear()
 
