@@ -2921,6 +2921,9 @@ static int nms_layout(int64_t n, int64_t edge_capacity, NmsLayout &L) {
     int bits = 2 * g;                                               // (half that table for 1.25 M grouped boxes: the same times)
     while (bits < kGridMaxBits && ((int64_t)5 << bits) < 2 * n) ++bits;
     L.grid_log2 = g; L.grid_bits = bits;
+    // (table and cell counters on 64-KiB boundaries: the insert kernel -- scattered atomics and 16-B stores -- is 2.5 us
+    // slower at 100 000 - 131 072 boxes with either of them at certain other offsets, whatever the code; DESIGN_LOG)
+    off = align_up(off, 65536);
     L.gtab = take(((size_t)1 << bits) * kGridCap * sizeof(uint4));
     L.gover = take((size_t)kGridOverMax * (sizeof(uint4) + sizeof(uint32_t)));     // overflow entries, then their cells
     L.gbig = L.gover + (size_t)kGridOverMax * sizeof(uint4) + (size_t)(kGridOverMax - kGridBigMax) * sizeof(uint32_t);   // (the tail of the overflow cells' array: grid_over_cap)
@@ -2948,6 +2951,7 @@ static int nms_layout(int64_t n, int64_t edge_capacity, NmsLayout &L) {
   L.ticket = take(4);                                // nms_cullbox_kernel: tile tickets
   L.tbox = take(nt * sizeof(uint2));                 // (zero = "not published yet" for nms_cullbox_kernel)
   L.tgr = take(nt * sizeof(uint32_t));
+  if (L.grid_log2 > 0) off = align_up(off, 65536);
   L.hist = take(((size_t)1 << (L.grid_bits > 18 ? L.grid_bits : 18)) * 4);   // (kCells, or the grid route's cell counters; LAST of the zeroed range: only the cells a call uses are cleared)
   static_assert(kCells == (1 << 18), "hist");
   L.zero_end = off;
