@@ -435,14 +435,51 @@ __device__ __forceinline__ float4 sample_box(const float *__restrict__ row) {
   return fin ? make_float4(lox, hix, loy, hiy) : make_float4(1.0f, -1.0f, 1.0f, -1.0f);
 }
 
+// Wave-wide maximum / sum in every lane by DPP moves inside the rows of 16 and four read-lanes (a `__shfl_xor` is a
+// ds_bpermute, an LDS-crossbar round trip: the 90 of them in the frame kernel's statistics were 2 us of a one-block chain).
+// All 64 lanes must be active.  The sum's order is fixed: the same bits every run.
+template <int CTRL> __device__ __forceinline__ uint32_t dpp_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xf, 0xf, true); }
+template <int CTRL> __device__ __forceinline__ float dpp_f32(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, true)); }
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+  v = max(v, dpp_u32<0xB1>(v));     // quad_perm [1,0,3,2]: lane ^ 1
+  v = max(v, dpp_u32<0x4E>(v));     // quad_perm [2,3,0,1]: lane ^ 2
+  v = max(v, dpp_u32<0x141>(v));    // row_half_mirror
+  v = max(v, dpp_u32<0x140>(v));    // row_mirror: every lane holds its row's maximum
+  const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+  const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), d = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+  return max(max(a, b), max(c, d));
+}
+__device__ __forceinline__ float wave_sum_f32(float v) {
+  v += dpp_f32<0xB1>(v);
+  v += dpp_f32<0x4E>(v);
+  v += dpp_f32<0x141>(v);
+  v += dpp_f32<0x140>(v);
+  const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)), b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+  const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)), d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+  return (a + b) + (c + d);
+}
+
+// Instrumented build only (-DOBB_FRAME_STAMPS, tools/exp_frame_stamps.py): shader-clock stamps of block 0 of the frame
+// kernel (slots 0 .. 7) and wall-clock begin / end of every block of the frame and insert kernels (not part of the ABI).
+#ifdef OBB_FRAME_STAMPS
+__device__ unsigned long long g_frame_stamps[16 + 2 * 2 * 4096];
+#define FR_STAMP(i) do { if (threadIdx.x == 0) g_frame_stamps[(i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define FR_WALL(k, e) do { if (threadIdx.x == 0 && blockIdx.x < 4096u) g_frame_stamps[16 + ((k) * 4096 + blockIdx.x) * 2 + (e)] = wall_clock64(); } while (0)
+#else
+#define FR_STAMP(i) do { } while (0)
+#define FR_WALL(k, e) do { } while (0)
+#endif
 template <int KIND, bool F64 = false>
 __global__ __launch_bounds__(256) void nms_frame_kernel(const NmsSource src, int64_t n, int cell_hbits,
                                                         NmsFrame *__restrict__ frame,
                                                         uint4 *__restrict__ zero, size_t zero_vecs, int grid_log2) {
   constexpr int S = KIND == 0 ? 6 : (KIND == 1 ? 9 : 5);
+  FR_WALL(0, 0);
+  if (blockIdx.x == 0) FR_STAMP(0);
   for (size_t z = (size_t)blockIdx.x * blockDim.x + threadIdx.x; z < zero_vecs; z += (size_t)gridDim.x * blockDim.x)
     zero[z] = make_uint4(0u, 0u, 0u, 0u);
-  if (blockIdx.x != 0) return;
+  if (blockIdx.x != 0) { FR_WALL(0, 1); return; }
+  FR_STAMP(1);
   __shared__ float4 sm[kFrameSamples];       // lo x, hi x, lo y, hi y of every sample (lo > hi: not finite)
   __shared__ float red[4][8];
   __shared__ float tot[8];
@@ -493,11 +530,15 @@ __global__ __launch_bounds__(256) void nms_frame_kernel(const NmsSource src, int
   }
   if (tid < 128) gbm[tid] = 0u;
   __syncthreads();
+  FR_STAMP(2);
   // block-wide sums of up to 8 floats -> tot[], valid after the call
-  auto block_sum = [&](float (&v)[8], int m) {
-    for (int k = 0; k < m; ++k)
-      for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o);
-    if (lane == 0) for (int k = 0; k < m; ++k) red[wv][k] = v[k];
+  auto block_sum = [&](float (&v)[8], int m) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = wave_sum_f32(v[k]);
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) red[wv][k] = v[k];
+    }
     __syncthreads();
     if (tid < m) {
       float a = 0.0f;
@@ -530,12 +571,8 @@ __global__ __launch_bounds__(256) void nms_frame_kernel(const NmsSource src, int
       axh = max(axh, fkey(b.y)); axl = max(axl, ~fkey(b.x)); ayh = max(ayh, fkey(b.w)); ayl = max(ayl, ~fkey(b.z));
       cxh = max(cxh, fkey(cx)); cxl = max(cxl, ~fkey(cx)); cyh = max(cyh, fkey(cy)); cyl = max(cyl, ~fkey(cy));
     }
-    for (int o = 32; o > 0; o >>= 1) {
-      axh = max(axh, shfl_xor_u(axh, o)); axl = max(axl, shfl_xor_u(axl, o));
-      ayh = max(ayh, shfl_xor_u(ayh, o)); ayl = max(ayl, shfl_xor_u(ayl, o));
-      cxh = max(cxh, shfl_xor_u(cxh, o)); cxl = max(cxl, shfl_xor_u(cxl, o));
-      cyh = max(cyh, shfl_xor_u(cyh, o)); cyl = max(cyl, shfl_xor_u(cyl, o));
-    }
+    axh = wave_max_u32(axh); axl = wave_max_u32(axl); ayh = wave_max_u32(ayh); ayl = wave_max_u32(ayl);
+    cxh = wave_max_u32(cxh); cxl = wave_max_u32(cxl); cyh = wave_max_u32(cyh); cyl = wave_max_u32(cyl);
     __shared__ uint4 cred[NW];
     if (lane == 0) { wred[wv] = make_uint4(axh, axl, ayh, ayl); cred[wv] = make_uint4(cxh, cxl, cyh, cyl); }
     block_sum(v, 7);   // (its barriers also publish wred / cred)
@@ -560,6 +597,7 @@ __global__ __launch_bounds__(256) void nms_frame_kernel(const NmsSource src, int
     }
     __syncthreads();
   }
+  FR_STAMP(3);
   // ---- outliers: three rounds of 3-sigma trimming about the previous mean (round 0: the plain mean, in case the
   // first sample itself was the outlier), then a generous last window (8 sigma: intervals beyond it just clamp)
   if (robust) {
@@ -588,6 +626,7 @@ __global__ __launch_bounds__(256) void nms_frame_kernel(const NmsSource src, int
       __syncthreads();
     }
   }
+  FR_STAMP(4);
   // frame = bounding box of the samples whose centre lies inside the last window (all finite samples when there was
   // no outlier, or when the window leaves too few: a multi-modal scene keeps its bounding box)
   const bool trim = robust && cnt_in * 8.0f >= (float)ns;
@@ -602,10 +641,7 @@ __global__ __launch_bounds__(256) void nms_frame_kernel(const NmsSource src, int
         ayh = max(ayh, fkey(b.w)); ayl = max(ayl, ~fkey(b.z));
       }
     }
-    for (int o = 32; o > 0; o >>= 1) {
-      axh = max(axh, shfl_xor_u(axh, o)); axl = max(axl, shfl_xor_u(axl, o));
-      ayh = max(ayh, shfl_xor_u(ayh, o)); ayl = max(ayl, shfl_xor_u(ayl, o));
-    }
+    axh = wave_max_u32(axh); axl = wave_max_u32(axl); ayh = wave_max_u32(ayh); ayl = wave_max_u32(ayl);
     if (lane == 0) wred[wv] = make_uint4(axh, axl, ayh, ayl);
   }
   // bucket bits of a grouped call: distinct 12-bit group hashes among <= 1024 strided samples
@@ -628,6 +664,7 @@ __global__ __launch_bounds__(256) void nms_frame_kernel(const NmsSource src, int
     }
     __syncthreads();
   }
+  FR_STAMP(5);
   if (tid == 0) {
     uint4 m = bbox_all;
     if (trim) {
@@ -684,7 +721,17 @@ __global__ __launch_bounds__(256) void nms_frame_kernel(const NmsSource src, int
     }
     *frame = f;
   }
+  FR_STAMP(6);
+  FR_WALL(0, 1);
 }
+
+#ifdef OBB_FRAME_STAMPS
+}  // namespace obb
+extern "C" __attribute__((visibility("default"))) int obb_debug_frame_stamps(unsigned long long *host, int words) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(obb::g_frame_stamps), sizeof(unsigned long long) * (size_t)words);
+}
+namespace obb {
+#endif
 
 template <int KIND, bool F64 = false>
 __global__ __launch_bounds__(256) void nms_prepq_kernel(const NmsSource src, int64_t n,
@@ -869,6 +916,7 @@ __global__ __launch_bounds__(256) void nms_ginsert_kernel(const NmsSource src, i
                                                           uint4 *__restrict__ gover, uint32_t *__restrict__ gbig,
                                                           uint32_t big_cap, int give_up) {    // (big_cap = grid_big_cap(n), a 64-bit division: the host's)
   constexpr int S = KIND == 0 ? 6 : (KIND == 1 ? 9 : 5);
+  FR_WALL(1, 0);
   const NmsFrame fr = *frame;
   uint32_t *__restrict__ gover_cell = reinterpret_cast<uint32_t *>(gover + kGridOverMax);
   const uint32_t over_cap = grid_over_cap(n);
@@ -949,6 +997,7 @@ __global__ __launch_bounds__(256) void nms_ginsert_kernel(const NmsSource src, i
       }
     }
   }
+  FR_WALL(1, 1);
 }
 
 // CELLS > 0: the block scans hist[0 .. CELLS) into LDS itself; CELLS == 0: `hist` already holds the offsets

@@ -24,4 +24,10 @@ cp $ROOT/aidet_amd/csrc/*.hip $ROOT/aidet_amd/csrc/*.h $ROOT/aidet_amd/csrc/Make
 sed -i "s#\.\./\.\./include#$ROOT/include#g" $d/Makefile $d/obb_common.h
 make -s -C $d -j8 EXTRA=-DOBB_SOFT_STAMPS OUT=$ROOT/aidet_amd/lib/libobbops_sst.so
 rm -rf $d
+# stamps of the grid route's frame and insert kernels (tools/exp_frame_stamps.py)
+d=$(mktemp -d /tmp/obb_frst_XXXX)
+cp $ROOT/aidet_amd/csrc/*.hip $ROOT/aidet_amd/csrc/*.h $ROOT/aidet_amd/csrc/Makefile $d/
+sed -i "s#\.\./\.\./include#$ROOT/include#g" $d/Makefile $d/obb_common.h
+make -s -C $d -j8 EXTRA=-DOBB_FRAME_STAMPS OUT=$ROOT/aidet_amd/lib/libobbops_frst.so
+rm -rf $d
 ls -la $ROOT/aidet_amd/lib/libobbops_abl*.so $ROOT/aidet_amd/lib/libobbops_gpst.so $ROOT/aidet_amd/lib/libobbops_sst.so

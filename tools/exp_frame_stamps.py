@@ -1,0 +1,42 @@
+"""Stamps of the first two launches of the NMS's grid route at the headline workload (instrumented build
+-DOBB_FRAME_STAMPS -> aidet_amd/lib/libobbops_frst.so, tools/build_ablations.sh): the phases of block 0 of
+nms_frame_kernel (shader clock) and begin / end of every block of nms_frame_kernel and nms_ginsert_kernel (wall clock,
+100 MHz)."""
+import ctypes, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ['OBBOPS_LIB'] = os.path.join(ROOT, 'aidet_amd', 'lib', 'libobbops_frst.so')
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import numpy as np
+import torch
+import workloads
+from aidet_amd import _lib, nms_wrapper
+dev = torch.device('cuda', 0)
+L = _lib.lib()
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
+d = torch.from_numpy(workloads.boxes(n, 20000.0 * (n / 100000.0) ** 0.5, 3)).to(dev)
+L.obb_debug_frame_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
+names = ['entry -> own share zeroed', '-> samples in LDS (global round trip)', '-> one-pass statistics', '-> trimming rounds (outliers only)',
+         '-> trimmed box, group hashes', '-> frame written (thread 0)']
+acc = []
+for rep in range(12):
+    keep = nms_wrapper.rnms(d, 0.5)[1]
+    torch.cuda.synchronize()
+    buf = np.zeros(16 + 4 * 4096, dtype=np.uint64)
+    assert L.obb_debug_frame_stamps(buf.ctypes.data, buf.size) == 0
+    s = buf.astype(np.int64)
+    w = s[16:].reshape(2, 4096, 2)
+    fr, ins = w[0][w[0][:, 0] > 0], w[1][w[1][:, 0] > 0]
+    t0 = fr[:, 0].min()
+    row = [s[i + 1] - s[i] for i in range(6)] + [
+        (fr[0, 1] - fr[0, 0]) / 100.0, (fr[:, 1].max() - t0) / 100.0, (ins[:, 0].min() - t0) / 100.0, (ins[:, 0].max() - t0) / 100.0,
+        (np.median(ins[:, 1] - ins[:, 0])) / 100.0, (ins[:, 1].max() - t0) / 100.0, len(fr), len(ins)]
+    if rep >= 2:
+        acc.append(row)
+a = np.median(np.array(acc, dtype=np.float64), axis=0)
+print('route', L.obb_nms_last_route(), 'kept', len(keep), 'n', n)
+print('nms_frame_kernel, block 0, thread 0 (shader clocks, median of 10 calls):')
+for i, nm in enumerate(names):
+    print('  %-44s %7d' % (nm, a[i]))
+print('block 0 of the frame kernel alive %.1f us; last frame block ends at %.1f us after the first began (%d blocks)' % (a[6], a[7], a[12]))
+print('insert kernel: first block begins at %.1f us, last begins at %.1f, median block life %.1f us, last ends at %.1f us (%d blocks)' % (a[8], a[9], a[10], a[11], a[13]))
