@@ -29,6 +29,14 @@ for it in range(a, b):
         d[:m, :2] = d[:m, :2] * 0.05 + d[0, :2]
     if it % 4 == 1:
         d[:, 5] = np.round(d[:, 5], 3)       # tied scores
+    nbig = 0
+    if it % 4 == 2:      # a few boxes that touch more cells than an entry list names (the grid route's big list; more of them than it holds: the route gives up)
+        k = int(rng.choice([1, 3, 40, 400]))
+        rows = rng.choice(n, k, replace=False)
+        side = (n ** 0.5) * per_box
+        d[rows, 2] = side * rng.uniform(0.02, 0.4, k).astype(np.float32)
+        d[rows, 3] = side * rng.uniform(0.02, 0.4, k).astype(np.float32)
+        nbig = k
     dt = torch.from_numpy(d).cuda()
     groups = thrs = None
     if it % 3 == 0:
@@ -48,7 +56,7 @@ for it in range(a, b):
             ref = keep
         assert torch.equal(keep, ref), (it, route, n)
         routes_taken.append(_lib.lib().obb_nms_last_route())
-    if it % 10 == 0:
-        print('scene', it, 'n', n, 'kept', ref.numel(), 'routes', routes_taken, 'ok  %.0f s' % (time.time() - t0), flush=True)
+    if it % 10 == 0 or it % 4 == 2:
+        print('scene', it, 'n', n, 'huge boxes', nbig, 'kept', ref.numel(), 'routes', routes_taken, 'ok  %.0f s' % (time.time() - t0), flush=True)
 force('auto')
 print('soak ok: scenes %d..%d' % (a, b - 1))
