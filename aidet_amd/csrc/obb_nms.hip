@@ -709,7 +709,7 @@ __global__ __launch_bounds__(256) void nms_frame_kernel(const NmsSource src, int
       // empty: cells twice as wide mean 1.5 instead of 1.9 entries per box and fewer pairs per table cell -- the
       // per-patch phase of config 5 277 -> 234 us; three times as wide: a (group, cell) key overflows, the route gives up)
       const bool many_groups = grouped && s_distinct * 10 >= (int)gs * 7;
-      const float ctarget = (ext_mean + ext_sd) * (many_groups ? OBB_GRID_MANY_SCALE : 1.0f);
+      const float ctarget = (ext_mean + ext_sd) * (many_groups ? OBB_GRID_MANY_SCALE : 1.0f);    // (half that: probe 17 -> 25 us at the headline, merged NMS of config 5 440 -> 585 us; LOG)
       auto shift_for = [&](float scale) {
         const float q = ctarget * scale;                      // cell size in quanta
         int sh = 15 - grid_log2;
@@ -2175,7 +2175,7 @@ __global__ __launch_bounds__(64 * kNmsWaves) void nms_gprobe_kernel(const QuadRe
   GP_STAMP(7);
   GP_STAMP(9);
 #ifdef OBB_GPROBE_STAMPS
-  if (lane == 0 && gw < 32768u) {      // (slots 4 .. 6 of a multi-chunk wave: totals instead of the last flush's stamps)
+  if (lane == 0 && gw < 32768u && chunks > nw) {      // (slots 4 .. 6 of a multi-chunk wave: totals instead of the last flush's stamps)
     g_gprobe_stamps[gw * 10 + 4] = acc_flush; g_gprobe_stamps[gw * 10 + 5] = acc_over; g_gprobe_stamps[gw * 10 + 6] = n_flush;
   }
 #endif

@@ -33,6 +33,7 @@ timeout 200 python tools/bench_soft_nms.py > $O/soft_nms.txt 2>> $O/bench.err
 timeout 200 python tools/exp_rroi_ablate.py > $O/rroi_ablate.txt 2>> $O/bench.err
 timeout 200 python tools/exp_rroi_stamps.py > $O/rroi_stamps.txt 2>> $O/bench.err
 timeout 200 python tools/exp_gprobe_stamps.py > $O/gprobe_stamps.txt 2>> $O/bench.err
+timeout 200 python tools/exp_frame_stamps.py > $O/frame_stamps.txt 2>> $O/bench.err
 timeout 300 python tools/exp_tiled_grid.py 16 0,1 > $O/tiled_grid.txt 2>> $O/bench.err
 timeout 300 python tools/exp_grid_vs_sorted.py > $O/grid_vs_sorted.txt 2>> $O/bench.err
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_cfg4 -o t -- python3 tools/prof_cfg4.py > /dev/null 2> $O/trace_cfg4.err
