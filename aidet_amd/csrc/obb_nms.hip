@@ -841,9 +841,10 @@ constexpr int kGridCap = 32;             // entries per cell
 constexpr int kGridMaxCells = 64;        // cells one box may touch
 constexpr int kGridMaxLog2 = 11;         // at most 2048 x 2048 cells per group
 constexpr int kGridMaxBits = 22;         // at most 2^22 cells in the table (2 GiB: calls of ~10^7 boxes)
-constexpr int kGridOverMax = 32768;      // the overflow list's memory (entries that found their cell full) ...
+constexpr int kGridOverMax = 49152;      // the overflow list's memory (entries that found their cell full) ...
 // ... of which a call uses max(4096, n / 256): more entries and the route gives up (every entry costs a wave a pass over the
-// list: 4096 entries ~10 us, 32 768 ~0.5 ms -- in proportion only for the calls of millions of boxes that may have them)
+// list: 4096 entries ~10 us, 32 768 ~0.5 ms -- in proportion only for the calls of millions of boxes that may have them;
+// the merged NMS of 10^7 tiled detections puts ~32 000 there)
 // boxes that touch more than kGridMaxCells cells (an airport among vehicles) are not inserted: they go on the BIG list and
 // the probe tests each of them against every box of the call (20 bytes per box: its record's intervals, its area); the list holds
 // 1024 boxes and at most 2^28 / n (1.25 M boxes: 214), more and the route gives up
@@ -854,7 +855,7 @@ __host__ __device__ inline uint32_t grid_big_cap(int64_t n) {
 }
 __host__ __device__ inline uint32_t grid_over_cap(int64_t n) {
   const int64_t c = n / 256;
-  return (uint32_t)(c < 4096 ? 4096 : (c > kGridOverMax - kGridBigMax ? kGridOverMax - kGridBigMax : c));   // (the last kGridBigMax cell words hold the big list)
+  return (uint32_t)(c < 4096 ? 4096 : (c > kGridOverMax ? kGridOverMax : c));
 }
 constexpr int kGridSkipCalls = 256;
 constexpr int64_t kGridAutoMax = 12000000;   // (the layout holds a table up to 2^24 boxes)
@@ -2974,8 +2975,8 @@ static int nms_layout(int64_t n, int64_t edge_capacity, NmsLayout &L) {
     // slower at 100 000 - 131 072 boxes with either of them at certain other offsets, whatever the code; DESIGN_LOG)
     off = align_up(off, 65536);
     L.gtab = take(((size_t)1 << bits) * kGridCap * sizeof(uint4));
-    L.gover = take((size_t)kGridOverMax * (sizeof(uint4) + sizeof(uint32_t)));     // overflow entries, then their cells
-    L.gbig = L.gover + (size_t)kGridOverMax * sizeof(uint4) + (size_t)(kGridOverMax - kGridBigMax) * sizeof(uint32_t);   // (the tail of the overflow cells' array: grid_over_cap)
+    L.gover = take((size_t)kGridOverMax * (sizeof(uint4) + sizeof(uint32_t)) + (size_t)kGridBigMax * sizeof(uint32_t));     // overflow entries, then their cells, then the big list
+    L.gbig = L.gover + (size_t)kGridOverMax * (sizeof(uint4) + sizeof(uint32_t));
   }
   L.qs = take((nt * kTile + kRowChunk) * sizeof(uint2));
   L.pf = take((nt * kTile) * sizeof(uint4));

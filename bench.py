@@ -326,7 +326,8 @@ def cfg5_leg(args, dev, rank, world, dist):
                     'cfg5_boxes_per_s': round(total * st / elapsed, 1),
                     'cfg5_kept_after_merge': summary['kept_after_merge'],
                     'cfg5_local_nms_us': summary['local_nms_us'], 'cfg5_exchange_us': summary['gather_us'],
-                    'cfg5_merge_us': summary['merge_us'], 'cfg5_keep_ok': bool(good)}
+                    'cfg5_merge_us': summary['merge_us'], 'cfg5_keep_ok': bool(good),
+                    'cfg5_phases_repeated_without_the_grid': summary['phases_repeated_without_the_grid']}
             if single is not None:
                 flat['cfg5_single_rank_ms_per_step'] = single['ms_per_step']
                 flat['cfg5_speedup_vs_single_rank'] = round(single['ms_per_step'] / ms, 3)
@@ -358,7 +359,8 @@ def cfg5_leg(args, dev, rank, world, dist):
         flat.update({'cfg5_large_workload': 'tiled merge, %d images 8192^2, %d patches, %d detections (%s)'
                                             % (summary['images'], summary['patches'], summary['detections'], layout),
                      'cfg5_large_ms_per_step': round(ms, 4), 'cfg5_large_boxes_per_s': round(summary['detections'] * st / elapsed, 1),
-                     'cfg5_large_keep_ok': bool(good)})
+                     'cfg5_large_keep_ok': bool(good),
+                     'cfg5_large_phases_repeated_without_the_grid': summary['phases_repeated_without_the_grid']})
         if big_single is not None:
             flat['cfg5_large_single_rank_ms_per_step'] = big_single['ms_per_step']
             flat['cfg5_large_speedup_vs_single_rank'] = round(big_single['ms_per_step'] / ms, 3)
@@ -885,6 +887,7 @@ def tiled_on_this_rank(dev, rank, world, steps, warmup, layout, group=None, barr
         return dota_merge.tiled_inference_merge(dets, labels, patch, seq, patch_xy, patch_image, C, 0.5, 0.3, thrs,
                                                 group=group, layout=layout, mark=mark if timed else None,
                                                 gather_result=gather_result or layout != 'routed')
+    repeats0 = dota_merge.phase_repeats       # (a phase whose NMS gave the grid route up is repeated on the sorted route -- once: the thread then skips the grid)
     for _ in range(warmup + 1):
         kept, keep, allrows = step()
     if barrier:
@@ -908,7 +911,8 @@ def tiled_on_this_rank(dev, rank, world, steps, warmup, layout, group=None, barr
     summary = {'ms_per_step': round(elapsed * 1e3 / steps, 4), 'boxes_per_s': round(total * steps / elapsed, 1),
                'detections': total, 'patches': P, 'images': int(scene['patch_image'].max()) + 1,
                'local_detections': int(len(idx)), 'rows_merged_on_this_rank': int(allrows.size(0)),
-               'kept_on_this_rank': kept_here, 'kept_after_merge': int(kept.size(0)), 'layout': layout, **ph}
+               'kept_on_this_rank': kept_here, 'kept_after_merge': int(kept.size(0)), 'layout': layout,
+               'phases_repeated_without_the_grid': int(dota_merge.phase_repeats - repeats0), **ph}
     return summary, elapsed, kept[:, :6].contiguous()
 
 
