@@ -1957,11 +1957,24 @@ __global__ __launch_bounds__(64 * kNmsWaves) void nms_gprobe_kernel(const QuadRe
   static_assert(kGridCap == 32, "two cells per 64-lane load");
   __shared__ uint2 queue[kNmsWaves][kNmsQueue];
   __shared__ uint4 ent[kNmsWaves][kGridCpwMax * kGridCap];
+  // pair number t of a cell -> (s, u), s < u, t = u (u - 1) / 2 + s: looked up (the square root and its two corrections were
+  // ~15 of a pair step's ~180 instructions), and the chunk's pair offsets for the lanes' cell -> first pair lookup
+  constexpr int kPairs = kGridCap * (kGridCap - 1) / 2;
+  __shared__ uint16_t pair_su[kPairs];
+  __shared__ int pair_first[kNmsWaves][kGridCpwMax];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t gw = blockIdx.x * kNmsWaves + wave, nw = gridDim.x * kNmsWaves;
   GP_STAMP(8);
   GP_STAMP(0);
+  for (int t = threadIdx.x; t < kPairs; t += 64 * kNmsWaves) {
+    int u = (int)((1.0f + __builtin_sqrtf(1.0f + 8.0f * (float)t)) * 0.5f);
+    int tu = (u * (u - 1)) >> 1;
+    if (tu > t) { --u; tu -= u; }
+    else if (tu + u <= t) { tu += u; ++u; }
+    pair_su[t] = (uint16_t)((t - tu) | (u << 8));
+  }
+  __syncthreads();                                   // (before any wave leaves)
   const NmsFrame fr = *frame;
   // the cells the frame kernel laid out are [0, ggx * ggy), ggx = 2^(15 - gshx): the launch is sized for the largest
   // grid, the chunks for the one that exists (the headline: 128 x 128 of at most 512 x 512 cells); the groups of a
@@ -2072,6 +2085,12 @@ __global__ __launch_bounds__(64 * kNmsWaves) void nms_gprobe_kernel(const QuadRe
     }
     const int total = O[kGridCpwMax];
     if (total == 0) continue;                      // (wave-uniform) no pair in the chunk
+    if (lane < kGridCpwMax) {
+      int of = 0;
+#pragma unroll
+      for (int k = 1; k < kGridCpwMax; ++k) of = lane >= k ? O[k] : of;
+      pair_first[wave][lane] = of;
+    }
     uint4 e[kGridCpwMax / 2];
 #pragma unroll
     for (int r = 0; r < kGridCpwMax / 2; ++r) {
@@ -2086,20 +2105,13 @@ __global__ __launch_bounds__(64 * kNmsWaves) void nms_gprobe_kernel(const QuadRe
     for (int p0 = 0; p0 < total; p0 += 64) {
       const int p = p0 + lane;
       const bool valid = p < total;
-      int c = 0, oc = 0;
+      int c = 0;
 #pragma unroll
-      for (int k = 1; k < kGridCpwMax; ++k) {
-        const bool ge = p >= O[k];
-        c += ge ? 1 : 0;
-        oc = ge ? O[k] : oc;
-      }
-      // pair number t of a cell -> (s, u), s < u: t = u (u - 1) / 2 + s
-      const int t = valid ? p - oc : 0;
-      int u = (int)((1.0f + __builtin_sqrtf(1.0f + 8.0f * (float)t)) * 0.5f);
-      int tu = (u * (u - 1)) >> 1;
-      if (tu > t) { --u; tu -= u; }
-      else if (tu + u <= t) { tu += u; ++u; }
-      const int sidx = t - tu;
+      for (int k = 1; k < kGridCpwMax; ++k) c += (p >= O[k]) ? 1 : 0;
+      const int tf = p - pair_first[wave][c];         // (c <= 7 whatever p: read by every lane, no branch)
+      const int t = valid ? tf : 0;
+      const int su = (int)pair_su[t];
+      const int sidx = su & 255, u = su >> 8;
       const uint4 ea = ew[c * kGridCap + sidx], eb = ew[c * kGridCap + u];
       const bool cnd = valid && pair_here(ea, eb, cell0 + (uint32_t)c);
       push(cnd, ea.z, eb.z);
