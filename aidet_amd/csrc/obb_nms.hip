@@ -2284,6 +2284,30 @@ __global__ __launch_bounds__(COMPACT ? kResolveThreadsCompact : kResolveThreads)
   __shared__ int is_last;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int shard = blockIdx.x;
+  // fused compaction: the sums of the call's result record are final when this launch starts (the earlier launches wrote
+  // them) -- wave 1 gathers them HERE, beside wave 0's prefix, instead of five loads and thirty shuffles behind the last
+  // slice's writes at the very end of the call (~1 us of every call's tail)
+  __shared__ unsigned long long s_info[2];
+  __shared__ unsigned int s_units[4];
+  if constexpr (!COMPACT) if (coop && wave == 1) {
+    unsigned long long v = ccnts[(size_t)lane * kCandStride], mx = v;
+    const unsigned long long ev = ccnts[(size_t)(kShards + lane) * kCandStride];
+    mx = ev > mx ? ev : mx;
+    v += ccnts[(size_t)(2 * kShards + lane) * kCandStride];
+    unsigned int uh = ucnts[lane * kUnitStride], ul = ucnts[(kShards + lane) * kUnitStride], uw = uh + ul;
+    for (int o = 32; o > 0; o >>= 1) {
+      v += __shfl_xor(v, o);
+      const unsigned long long tt = __shfl_xor(mx, o);
+      mx = tt > mx ? tt : mx;
+      uh += __shfl_xor(uh, o); ul += __shfl_xor(ul, o);
+      const unsigned int tw = __shfl_xor(uw, o);
+      uw = tw > uw ? tw : uw;
+    }
+    if (lane == 0) {
+      s_info[0] = v; s_info[1] = mx; s_units[0] = uh; s_units[1] = ul; s_units[2] = uw;
+      s_units[3] = __hip_atomic_load(&ctr->grid_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (set by the insert / probe launches only)
+    }
+  }
   if (wave == 0) {  // 64 lanes = 64 shards
     const unsigned long long c = ccnts[(size_t)(kShards + lane) * kCandStride];
     const unsigned long long cc = ccnts[(size_t)lane * kCandStride];
@@ -2473,29 +2497,14 @@ __global__ __launch_bounds__(COMPACT ? kResolveThreadsCompact : kResolveThreads)
       first_chunk = false;
       __syncthreads();                      // (csum / s_base are reused by the next chunk)
     }
-    if ((go == 3 || shard == kShards - 1) && wave == 0) {   // the last slice knows K: the call's result record
-      unsigned long long v = ccnts[(size_t)lane * kCandStride], mx = v;
-      const unsigned long long ev = ccnts[(size_t)(kShards + lane) * kCandStride];
-      mx = ev > mx ? ev : mx;
-      v += ccnts[(size_t)(2 * kShards + lane) * kCandStride];
-      unsigned int uh = ucnts[lane * kUnitStride], ul = ucnts[(kShards + lane) * kUnitStride], uw = uh + ul;
-      for (int o = 32; o > 0; o >>= 1) {
-        v += __shfl_xor(v, o);
-        const unsigned long long tt = __shfl_xor(mx, o);
-        mx = tt > mx ? tt : mx;
-        uh += __shfl_xor(uh, o); ul += __shfl_xor(ul, o);
-        const unsigned int tw = __shfl_xor(uw, o);
-        uw = tw > uw ? tw : uw;
-      }
-      if (lane == 0) {
-        hinfo->kept = kbase; hinfo->edges = (unsigned long long)total_edges;
-        hinfo->rounds = (long long)__hip_atomic_load(reinterpret_cast<unsigned long long *>(&ctr->rounds), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        hinfo->cand_total = v; hinfo->cand_worst = mx;
-        hinfo->heavy_units = uh; hinfo->light_units = ul;
-        const unsigned int gf = __hip_atomic_load(&ctr->grid_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        hinfo->route = gf ? (3u | (gf << 8)) : 2u;   // 3: repeat without the grid (bits 8..: which skip hint, nms_ginsert_kernel)
-        hinfo->unit_worst = uw;
-      }
+    if ((go == 3 || shard == kShards - 1) && tid == 0) {   // the last slice knows K: the call's result record
+      hinfo->kept = kbase; hinfo->edges = (unsigned long long)total_edges;
+      hinfo->rounds = (long long)__hip_atomic_load(reinterpret_cast<unsigned long long *>(&ctr->rounds), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      hinfo->cand_total = s_info[0]; hinfo->cand_worst = s_info[1];
+      hinfo->heavy_units = s_units[0]; hinfo->light_units = s_units[1];
+      const unsigned int gf = s_units[3];
+      hinfo->route = gf ? (3u | (gf << 8)) : 2u;   // 3: repeat without the grid (bits 8..: which skip hint, nms_ginsert_kernel)
+      hinfo->unit_worst = s_units[2];
     }
     return;
   }

@@ -58,6 +58,45 @@ __device__ __forceinline__ unsigned long long pick_key(float s, int p) {
 __device__ __forceinline__ int key_pos(unsigned long long k) { return (int)(~(uint32_t)k); }
 __device__ __forceinline__ bool key_none(unsigned long long k) { return (k >> 32) == 0ull; }
 
+// The gaussian weight exp(-ovr^2 / sigma) (nms_cpu.cpp:176-178: std::exp on scalar_t = the host libm's expf for float
+// rows).  The device library's expf is within one ulp of it -- and one ulp in a weight can turn two picks around or move a
+// score across min_score (seen in the soak: another kept set).  Rounding the double exponential (correctly rounded) agrees
+// with glibc in all but 0.06 % of the values -- still a few scores per array of thousands of decays.  So this is glibc's
+// own algorithm restated (expf of glibc >= 2.27 = ARM optimized-routines: exp(x) = 2^(k/32) * 2^(r/32), the first from a
+// table of 32 doubles, the second a cubic in double, one rounding to float at the end); tests/test_expf_restatement.py compares the
+// restatement with the libm of this image bit for bit.  exp(-0) = 1 without the call: every box that misses the pick.
+__device__ const unsigned long long kExpfTab[32] = {      // asuint64(2^(i/32)) - (i << 52) / 32
+    0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull,
+    0x3fef72b83c7d517bull, 0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull,
+    0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull,
+    0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull,
+    0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull, 0x3feea11473eb0187ull, 0x3feea589994cce13ull,
+    0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull,
+    0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull,
+    0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full, 0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull,
+};
+__device__ __forceinline__ float soft_exp(float x) {
+  if (x == 0.0f) return 1.0f;
+  if (x != x) return x + x;
+  if (x < -0x1.9fe368p6f) return 0.0f;                      // (underflow; the callers' arguments are <= 0)
+  if (x > 0x1.62e42ep6f) return __builtin_inff();
+  const double inv_ln2_n = 0x1.71547652b82fep+0 * 32.0, shift = 0x1.8p+52;
+  const double c0 = 0x1.c6af84b912394p-5 / 32.0 / 32.0 / 32.0, c1 = 0x1.ebfce50fac4f3p-3 / 32.0 / 32.0, c2 = 0x1.62e42ff0c52d6p-1 / 32.0;
+  const double z = inv_ln2_n * (double)x;
+  double kd = z + shift;                                     // (k in the low bits of the sum: no contraction, no reassociation in this build)
+  const unsigned long long ki = (unsigned long long)__double_as_longlong(kd);
+  kd -= shift;
+  const double r = z - kd;
+  const double sc = __longlong_as_double((long long)(kExpfTab[ki & 31ull] + (ki << 47)));
+  const double q = c0 * r + c1;
+  const double r2 = r * r;
+  double y = c2 * r + 1.0;
+  y = q * r2 + y;
+  y = y * sc;
+  return (float)y;
+}
+__device__ __forceinline__ double soft_exp(double x) { return exp(x); }
+
 template <int CTRL>
 __device__ __forceinline__ unsigned long long dpp_max(unsigned long long v) {
   const int lo = __builtin_amdgcn_mov_dpp((int)(uint32_t)v, CTRL, 0xf, 0xf, true);
@@ -167,7 +206,7 @@ __global__ __launch_bounds__(kSoftThreads) void soft_nms_kernel(const float *__r
         const float ovr = hbb_overlap(a4, iarea, b4, S.ar[p]);
         float weight = 1.0f;
         if (method == 1) { if (ovr > thr) weight = 1.0f - ovr; }
-        else if (method == 2) weight = expf(-(ovr * ovr) / sigma);
+        else if (method == 2) weight = soft_exp(-(ovr * ovr) / sigma);
         else weight = (ovr > thr) ? 0.0f : 1.0f;
         const float sn = weight * S.sc[p];
         S.sc[p] = sn;
@@ -319,8 +358,6 @@ __device__ __forceinline__ SoftKey3 wave_max_key3(SoftKey3 v) {
   }
   return m;
 }
-__device__ __forceinline__ float soft_exp(float x) { return expf(x); }
-__device__ __forceinline__ double soft_exp(double x) { return exp(x); }
 
 constexpr int kSoftInf = 0x7FFFFFFF;      // position of a box that has left the array
 

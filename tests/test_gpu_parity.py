@@ -926,8 +926,8 @@ def test_soft_nms_matches_reference(golden):
         assert np.array_equal(inds.cpu().numpy(), g['rand_%s_inds' % tag]), tag
         want = g['rand_%s_new_dets' % tag]
         assert np.array_equal(nd.cpu().numpy()[:, :4], want[:, :4]), tag
-        tol = 0.0 if method == 'linear' else 1e-6          # gaussian: device expf vs glibc expf
-        assert np.abs(nd.cpu().numpy()[:, 4] - want[:, 4]).max() <= tol, tag
+        # (gaussian too: the kernels restate glibc's expf -- obb_softnms.hip soft_exp -- so the scores are the reference's bits)
+        assert np.array_equal(nd.cpu().numpy()[:, 4], want[:, 4]), tag
     d64 = g['doc6_dets'].astype(np.float64)
     nd, inds = soft_nms(d64, 0.7, sigma=0.5)
     assert nd.dtype == np.float64 and inds.tolist() == g['doc6_inds'].tolist()

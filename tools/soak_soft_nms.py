@@ -1,7 +1,7 @@
 """Soak of `soft_nms` on one float array against the oracle's loop: random sizes 1 .. 4500 (the position-free kernel up to
 4096, the array kernel above and wherever the first one gives up), densities, min_score, both methods, tied scores on
-every third array (linear only), gaussian arrays index-exact against the GPU's array kernel and set / score-exact
-against the oracle (the gaussian weights of GPU and host may differ in the last bit and turn two picks around),
+every third array (linear only), gaussian arrays index- and bit-exact against the oracle's loop as well (the device
+restates glibc's expf) and against the GPU's array kernel,
 NaN / -0 scores now and then.  usage: python tools/soak_soft_nms.py FIRST LAST"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,6 +14,7 @@ L = _lib.lib()
 a, b = int(sys.argv[1]), int(sys.argv[2])
 t0 = time.time()
 paths = {}
+gauss = [0, 0, 0]      # gaussian arrays | index- and bit-exact against the host loop | kept set differs
 for it in range(a, b):
     rng = np.random.default_rng(7000 + it)
     n = int(np.exp(rng.uniform(0, np.log(4500))))
@@ -45,8 +46,10 @@ for it in range(a, b):
             nd2, inds2 = soft_nms(torch.from_numpy(d).cuda(), thr, method=method, sigma=0.5, min_score=min_score)
             _lib.set_tuning(_lib.TUNE_SOFT_NMS_REG, -1)
             assert torch.equal(inds, inds2) and torch.equal(nd.nan_to_num(-7.0), nd2.nan_to_num(-7.0)), (it, n, method, p)
-            assert len(ri) == inds.numel() and np.array_equal(np.sort(inds.cpu().numpy()), np.sort(ri)), (it, n, method, p)
-            assert np.allclose(np.sort(nd.cpu().numpy()[:, 4]), np.sort(rd[:, 4]), rtol=0, atol=1e-6, equal_nan=True), (it, n, method, p)
+            gauss[0] += 1
+            # the host loop's expf is glibc's, restated bit for bit on the device (soft_exp): identical arrays
+            assert np.array_equal(inds.cpu().numpy(), ri) and np.array_equal(nd.cpu().numpy(), rd, equal_nan=True), (it, n, method, p)
+            gauss[1] += 1
     if it % 50 == 0:
         print('array', it, 'n', n, 'paths so far', paths, 'ok  %.0f s' % (time.time() - t0), flush=True)
-print('soak ok: arrays %d..%d, paths %s' % (a, b - 1, paths))
+print('soak ok: arrays %d..%d, paths %s; gaussian arrays %d, identical to the host loop %d, other kept set %d' % (a, b - 1, paths, gauss[0], gauss[1], gauss[2]))
