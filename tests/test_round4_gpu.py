@@ -208,10 +208,7 @@ def _register_soft_nms_cases(soft_nms, rng):
             nd, inds = soft_nms(d, thr, method=method, sigma=0.5, min_score=min_score)
             rd, ri = oracle.soft_nms(d, thr, method, 0.5, min_score)
             assert np.array_equal(inds, ri), (n, method, thr)
-            if method == 'linear':
-                assert np.array_equal(nd, rd, equal_nan=True), (n, method)
-            else:
-                assert np.allclose(nd, rd, rtol=0, atol=1e-6, equal_nan=True), (n, method)
+            assert np.array_equal(nd, rd, equal_nan=True), (n, method)      # (gaussian too: glibc's expf restated on the device)
 
 
 def test_fused_compaction_of_the_sorted_route_and_its_fallbacks(nms_route):
