@@ -170,8 +170,16 @@ def test_float64_bbox_overlaps_and_soft_nms_follow_the_input_dtype(golden):
         cfg, m = g['soft_%s_cfg' % t], str(g['soft_%s_method' % t])
         nd, inds = soft_nms(g['soft_%s_dets' % t], cfg[0], method=m, sigma=cfg[1], min_score=cfg[2])
         assert nd.dtype == np.float64 and np.array_equal(inds, g['soft_%s_inds' % t]), t
-        tol = 0.0 if m == 'linear' else 1e-12          # (device exp)
-        assert np.abs(nd - g['soft_%s_new_dets' % t]).max() <= tol, t
+        assert np.array_equal(nd, g['soft_%s_new_dets' % t]), t      # (gaussian too: glibc's double exp restated on the device, soft_exp)
+    # fresh double arrays against the oracle's double loop (libm exp): gaussian weights bit for bit
+    rng = np.random.default_rng(31)
+    for n, canvas in ((300, 80), (1500, 200), (4000, 400)):
+        x1, y1 = rng.uniform(0, canvas, n), rng.uniform(0, canvas, n)
+        d = np.stack([x1, y1, x1 + rng.uniform(4, 60, n), y1 + rng.uniform(4, 60, n), rng.uniform(0, 1, n)], 1)
+        for sigma in (0.5, 0.2):
+            nd, inds = soft_nms(d, 0.3, method='gaussian', sigma=sigma, min_score=0.05)
+            rd, ri = oracle.soft_nms_f64(d, 0.3, 'gaussian', sigma, 0.05)
+            assert nd.dtype == np.float64 and np.array_equal(inds, ri) and np.array_equal(nd, rd), (n, sigma)
 
 
 def test_float64_rotated_input_says_that_it_is_down_cast():
