@@ -210,9 +210,14 @@ def bench_all(args):
         del a, b
 
     # ---- leg 2: cfg5 (strong scaling) -------------------------------------------------------------
-    cfg5 = None
+    cfg5, cfg5_error = None, None
     if not args.no_cfg5:
-        cfg5 = cfg5_leg(args, dev, rank, world, dist)
+        try:
+            cfg5 = cfg5_leg(args, dev, rank, world, dist)
+        except Exception as e:      # (the replica leg above is measured: its line is still printed, with the failure on it)
+            import traceback
+            cfg5_error = '%s: %s' % (type(e).__name__, str(e)[:300])
+            sys.stderr.write('bench.py: the cfg5 leg failed on rank %d\n%s\n' % (rank, traceback.format_exc()))
 
     rk = None
     if rank == 0 and world == 1 and not args.no_extras:
@@ -252,6 +257,8 @@ def bench_all(args):
         out['config'].update(cfg5['flat'])
         out['cfg5'] = cfg5['detail']
         ok = cfg5['ok']
+    if cfg5_error is not None:
+        out['config']['cfg5_error'] = cfg5_error
     if rank == 0 and world == 1:
         if rk is not None:
             out['roofline_kernels'] = rk
@@ -264,7 +271,7 @@ def bench_all(args):
         if not ok:
             out['error'] = 'distributed merge differs from the single-rank result'
         print(json.dumps(out))
-    if dist is not None:
+    if dist is not None and cfg5_error is None:      # (after a failed leg the ranks may not be in step any more: no further collective)
         dist.barrier()
         dist.destroy_process_group()
     if not ok:
