@@ -227,6 +227,7 @@ __global__ __launch_bounds__(kSoftThreads) void soft_nms_kernel(const float *__r
                                                                 long long *__restrict__ result,
                                                                 const int64_t *__restrict__ seg) {
   if (seg) {
+    const bool only_given_up = n < 0;      // (n = -1: only the groups the position-free kernel gave up on, kSoftFastGiveUp in their count)
     const int64_t off = seg[blockIdx.x];
     n = (int)(seg[blockIdx.x + 1] - off);
     dets += off * 5;
@@ -234,6 +235,7 @@ __global__ __launch_bounds__(kSoftThreads) void soft_nms_kernel(const float *__r
     out_inds += off;
     ws += off * 8;
     result += blockIdx.x;
+    if (only_given_up && result[0] != -2) return;                  // (block-uniform; kSoftFastGiveUp)
     if (n <= 0) { if (threadIdx.x == 0) result[0] = 0; return; }   // (block-uniform)
     if (LDS && n > kSoftLds) { if (threadIdx.x == 0) result[0] = -1; return; }   // (the host routes such calls to the workspace variant)
   }
@@ -691,9 +693,21 @@ __device__ unsigned long long g_soft_stamps[16 * 256 * 8];
 template <int T, int NB>
 __global__ __launch_bounds__(T) void soft_nms_fast_kernel(const float *__restrict__ dets, int n, float thr, int method,
                                                             float sigma, float min_score, float *__restrict__ out_dets,
-                                                            int64_t *__restrict__ out_inds, long long *__restrict__ result) {
+                                                            int64_t *__restrict__ out_inds, long long *__restrict__ result,
+                                                            const int64_t *__restrict__ seg) {
   constexpr int kW = T / 64;
   static_assert(kW <= 16, "one row of 16 lanes reduces the waves' candidates");
+  if (seg) {      // GROUPED (as soft_nms_kernel): workgroup g on the rows [seg[g], seg[g + 1]) as an array of its own
+    const int64_t off = seg[blockIdx.x];
+    const int64_t m = seg[blockIdx.x + 1] - off;
+    dets += off * 5;
+    out_dets += off * 5;
+    out_inds += off;
+    result += blockIdx.x;
+    if (m <= 0) { if (threadIdx.x == 0) result[0] = 0; return; }                        // (block-uniform)
+    if (m > T * NB) { if (threadIdx.x == 0) result[0] = kSoftFastGiveUp; return; }      // (beyond the caller's bound: the array kernel's case)
+    n = (int)m;
+  }
   static_assert((NB & (NB - 1)) == 0, "slot = (box number >> 6) & (NB - 1)");
   __shared__ float4 cbox[T * NB];
   __shared__ float carea[T * NB];
@@ -909,9 +923,11 @@ __global__ __launch_bounds__(T) void soft_nms_fast_kernel(const float *__restric
 
 static thread_local int g_soft_path = -1;      // obb_soft_nms_last_path
 constexpr int kSoftFastMax = 4096;
+// (n = the array's rows, or -- grouped, seg != nullptr -- the caller's bound on the rows of one group)
 static bool soft_launch_fast(const float *dets, int64_t n, float thr, int method, float sigma, float min_score,
-                             float *out_dets, int64_t *out_inds, long long *result, hipStream_t st) {
-#define OBB_SOFT_FAST(T, NB) hipLaunchKernelGGL((soft_nms_fast_kernel<T, NB>), dim3(1), dim3(T), 0, st, dets, (int)n, thr, method, sigma, min_score, out_dets, out_inds, result)
+                             float *out_dets, int64_t *out_inds, long long *result, hipStream_t st,
+                             const int64_t *seg = nullptr, unsigned groups = 1) {
+#define OBB_SOFT_FAST(T, NB) hipLaunchKernelGGL((soft_nms_fast_kernel<T, NB>), dim3(groups), dim3(T), 0, st, dets, (int)n, thr, method, sigma, min_score, out_dets, out_inds, result, seg)
   // (four waves per SIMD hide the latency of the dependent chain -- division, the exponential -- that one wave per SIMD
   // waits out: 2048 boxes as 256 x 8 took 2.1 us per round in a dense scene)
   const int64_t shape = tuning(OBB_TUNE_SOFT_NMS_SHAPE, 0);     // (0 default; 1: 256 threads x more boxes, for measurements)
@@ -1068,12 +1084,21 @@ extern "C" int obb_soft_nms_grouped_max_f32(const float *dets_dev, int64_t n, co
   // `max_group`: the caller's bound on the rows of one group (the segment offsets live on the device): every group's state
   // in LDS while it is <= kSoftLds -- with the total as the only bound, 15 classes of 400 boxes ran on the global-memory
   // state (2.4 us per round instead of 1.2).  A group that exceeds the bound reports -1 in its count.
+  // the position-free kernel first, a workgroup per group (a round of 0.7 us instead of 1.2); the groups it gives up on -- two
+  // remaining boxes sharing the maximum, a NaN score -- say so in their count and the array kernel's launch behind it runs
+  // those only (the others leave at once): no host in between
+  int first = 0;
+  if (tuning(OBB_TUNE_SOFT_NMS_REG, 0) == 0 && max_group >= 1 &&
+      soft_launch_fast(dets_dev, max_group, iou_thr, method, sigma, min_score, out_dets_dev, out_inds_dev, res, st, seg_dev, g)) {
+    OBB_LAUNCH_CHECK();
+    first = -1;
+  }
   if (max_group <= 768)
-    hipLaunchKernelGGL((soft_nms_kernel<true, 256>), dim3(g), dim3(256), 0, st, dets_dev, 0, iou_thr, method, sigma, min_score, ws, out_dets_dev, out_inds_dev, res, seg_dev);
+    hipLaunchKernelGGL((soft_nms_kernel<true, 256>), dim3(g), dim3(256), 0, st, dets_dev, first, iou_thr, method, sigma, min_score, ws, out_dets_dev, out_inds_dev, res, seg_dev);
   else if (max_group <= kSoftLds)
-    hipLaunchKernelGGL((soft_nms_kernel<true, 1024>), dim3(g), dim3(1024), 0, st, dets_dev, 0, iou_thr, method, sigma, min_score, ws, out_dets_dev, out_inds_dev, res, seg_dev);
+    hipLaunchKernelGGL((soft_nms_kernel<true, 1024>), dim3(g), dim3(1024), 0, st, dets_dev, first, iou_thr, method, sigma, min_score, ws, out_dets_dev, out_inds_dev, res, seg_dev);
   else
-    hipLaunchKernelGGL((soft_nms_kernel<false, 1024>), dim3(g), dim3(1024), 0, st, dets_dev, 0, iou_thr, method, sigma, min_score, ws, out_dets_dev, out_inds_dev, res, seg_dev);
+    hipLaunchKernelGGL((soft_nms_kernel<false, 1024>), dim3(g), dim3(1024), 0, st, dets_dev, first, iou_thr, method, sigma, min_score, ws, out_dets_dev, out_inds_dev, res, seg_dev);
   OBB_LAUNCH_CHECK();
   return OBB_OK;
 }

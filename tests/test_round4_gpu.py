@@ -219,6 +219,39 @@ def _register_soft_nms_cases(soft_nms, rng):
             assert np.array_equal(nd, rd, equal_nan=True), (n, method)      # (gaussian too: glibc's expf restated on the device)
 
 
+def test_grouped_soft_nms_runs_the_position_free_kernel_first():
+    """`soft_nms_grouped`: a workgroup per group on the kernel without positions, the groups it gives up on (shared maxima, NaN
+    scores) replayed by the array kernel's launch behind it -- the same rows as the array kernel alone (OBB_TUNE_SOFT_NMS_REG =
+    2) and as the oracle's loop per group, gaussian weights bit for bit; sizes around the launch shapes, empty groups, a
+    group of one, groups beyond the LDS state."""
+    from aidet_amd import _lib, nms_wrapper
+    rng = np.random.default_rng(41)
+    for sizes in ([400] * 15, [0, 1, 2, 257, 0, 1024, 63], [2049, 300, 4096, 5], [4500, 100, 2000], [30] * 200):
+        groups = []
+        for gi, m in enumerate(sizes):
+            x1, y1 = rng.uniform(0, 500, m), rng.uniform(0, 500, m)
+            g = np.stack([x1, y1, x1 + rng.uniform(6, 90, m), y1 + rng.uniform(6, 90, m), rng.random(m)], 1).astype(np.float32)
+            if gi % 3 == 1 and m > 4:
+                g[::4, 4] = np.float32(0.5)              # shared maxima: the position-free kernel gives this group up
+            if gi % 5 == 2 and m > 4:
+                g[2, 4] = np.nan
+            groups.append(g)
+        rows = t(np.concatenate(groups, 0))
+        for method, kw in (('linear', dict(min_score=0.05)), ('gaussian', dict(sigma=0.4, min_score=0.02))):
+            got = nms_wrapper.soft_nms_grouped(rows, sizes, 0.3, method=method, **kw)
+            try:
+                _lib.set_tuning(_lib.TUNE_SOFT_NMS_REG, 2)
+                alone = nms_wrapper.soft_nms_grouped(rows, sizes, 0.3, method=method, **kw)
+            finally:
+                _lib.set_tuning(_lib.TUNE_SOFT_NMS_REG, -1)
+            assert len(got) == len(sizes)
+            for g, (d, k), (d2, k2) in zip(groups, got, alone):
+                rd, ri = oracle.soft_nms(g, 0.3, method, kw.get('sigma', 0.5), kw['min_score'])
+                assert np.array_equal(k.cpu().numpy(), ri), (sizes[:4], method, len(g))
+                assert np.array_equal(d.cpu().numpy(), rd, equal_nan=True), (sizes[:4], method, len(g))
+                assert torch.equal(k, k2) and torch.equal(d.nan_to_num(-7.0), d2.nan_to_num(-7.0))
+
+
 def test_fused_compaction_of_the_sorted_route_and_its_fallbacks(nms_route):
     """Sorted route below 2^18 boxes: the keep list is written by the tail of the resolve launch (64 workgroups, n / 64
     words each).  Same list as the separate compaction launch (knob 0) and as the path where every waiting shard gives
