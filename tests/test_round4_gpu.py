@@ -421,6 +421,18 @@ def test_grid_route_is_exact_and_gives_up_on_crowded_scenes(nms_route):
     assert np.array_equal(poly_nms(t(p), 0.4)[1].cpu().numpy(), oracle.poly_nms(p, 0.4)) and L.obb_nms_last_route() == 4
     assert np.array_equal(nms(t(h), 0.5)[1].cpu().numpy(), oracle.hbb_nms(h, 0.5)) and L.obb_nms_last_route() == 4
     assert np.array_equal(rnms(t(d), 0.5, thrs=thrs, strict=True)[1].cpu().numpy(), oracle.rnms(d, 0.5, thrs=thrs, strict=True))
+    # ... and the other kinds with boxes for the big list (polygons, horizontal boxes incl. a malformed one and two huge twins)
+    d2 = d.copy()
+    d2[20, 2:5] = [3500.0, 2600.0, -0.4]
+    d2[21, :5] = d2[20, :5] + np.float32([10.0, 5.0, 0.0, 0.0, 0.01])
+    d2[22, 2:4] = [900.0, 5000.0]
+    p2 = np.concatenate([oracle.rbox_to_poly(d2).astype(np.float32), d2[:, 5:6]], 1)
+    h2 = h.copy()
+    h2[30, :4] = [100.0, 200.0, 4100.0, 3000.0]
+    h2[31, :4] = [120.0, 210.0, 4105.0, 3010.0]
+    h2[32, :4] = [5000.0, 5000.0, 4000.0, 7000.0]                # x2 < x1: malformed, isolated
+    assert np.array_equal(poly_nms(t(p2), 0.4)[1].cpu().numpy(), oracle.poly_nms(p2, 0.4)) and L.obb_nms_last_route() == 4
+    assert np.array_equal(nms(t(h2), 0.5)[1].cpu().numpy(), oracle.hbb_nms(h2, 0.5)) and L.obb_nms_last_route() == 4
     # grouped calls take it too (test_grid_route_serves_grouped_calls)
     g = rng.integers(0, 5, len(d)).astype(np.int32)
     assert np.array_equal(rnms(t(d), 0.5, groups=g)[1].cpu().numpy(), oracle.rnms(d, 0.5, groups=g)) and L.obb_nms_last_route() == 4
