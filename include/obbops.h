@@ -217,8 +217,9 @@ OBB_API int obb_soft_nms_f64(const double *dets_dev, int64_t n, float iou_thr, i
                              float min_score, double *out_dets_dev, int64_t *out_inds_dev,
                              int64_t *count_host, void *stream);
 
-/* Soft-NMS of several INDEPENDENT groups in one launch: workgroup g replays the reference's loop on the rows
- * [seg_dev[g], seg_dev[g + 1]) as an array of its own.
+/* Soft-NMS of several INDEPENDENT groups without the host in between: workgroup g replays the reference's loop on the rows
+ * [seg_dev[g], seg_dev[g + 1]) as an array of its own (two launches: a kernel that needs no array positions serves the groups
+ * whose maxima are unique -- nearly all -- and the array kernel behind it the groups the first one marked; same rows either way).
  * Replaces: the per-class loop of multiclass_nms_with_index, mmdet/core/post_processing/rbbox_nms.py:29-49
  *           (one `soft_nms` call = one host round trip per class; a detection head has 15 classes).
  *   dets_dev      (n, 5), the rows of a group contiguous (class-major), seg_dev int64[num_groups + 1] ascending
@@ -575,7 +576,7 @@ OBB_API int obb_head_gather_decode_f32(const float *rois_dev, const float *cls_s
 #define OBB_TUNE_RROI_ORDER_MIN 6     /* fewest RoIs the workspace forward puts into Morton order      */
 #define OBB_TUNE_RROI_GATHER_CHAN 7   /* channels per block of the gather backward (16 or 32)          */
 #define OBB_TUNE_RPN_BARRIER_TICKS 8  /* bound (100 MHz ticks) of the level barrier of the RPN selection; 0 forces the fallback */
-#define OBB_TUNE_SOFT_NMS_REG 9       /* float Soft-NMS of one array: 1 the position-tracking register kernel (the float64 one), n <= 8192; 2 the array kernel only (no position-free first try) */
+#define OBB_TUNE_SOFT_NMS_REG 9       /* float Soft-NMS: 1 the position-tracking register kernel (the float64 one; one array, n <= 8192); 2 the array kernel only (no position-free first try; one array and grouped calls) */
 #define OBB_TUNE_NMS_FUSED_COMPACT 10  /* 0: the sorted route's compaction as a launch of its own (as from 2^18 boxes on); 2: the waiting shards give up at once */
 #define OBB_TUNE_RROI_PLAN 11          /* fewest RoIs the workspace forward of RoI-Align plans per RoI (default 1024; 0 = always) */
 #define OBB_TUNE_NMS_GRID 12           /* grid route of the NMS: 0 never, 1 wherever it applies, 2 the same but it gives up at once (test hook for the repeat paths); default auto.  Setting it clears the calling thread's "skip the grid" notes */
