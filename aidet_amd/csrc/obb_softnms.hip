@@ -921,6 +921,223 @@ __global__ __launch_bounds__(T) void soft_nms_fast_kernel(const float *__restric
   if (tid == 0) result[0] = picks;
 }
 
+// ---- the position-free kernel for float64 rows (soft_nms_cpu_kernel<double>): the same rounds, but a double's order image is
+// 64 bits wide and does not share a word with a box number -- the block's pick takes TWO LDS steps (the maximum image, then
+// the lowest / highest box number among the waves that hold it) and two barriers per round.  Up to 2048 rows (56 bytes of
+// LDS per box); shared maxima / NaN scores give up like the float kernel and the register kernel replays the call.
+__device__ __forceinline__ unsigned long long score_image64(double s) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(s + 0.0);
+  return s != s ? ~0ull : ((u >> 63) ? ~u : (u | (1ull << 63)));
+}
+
+template <int T, int NB>
+__global__ __launch_bounds__(T) void soft_nms_fast64_kernel(const double *__restrict__ dets, int n, float thr_f, int method,
+                                                              float sigma_f, float min_score_f, double *__restrict__ out_dets,
+                                                              int64_t *__restrict__ out_inds, long long *__restrict__ result) {
+  static_assert((NB & (NB - 1)) == 0, "slot = (box number >> 6) & (NB - 1)");
+  __shared__ double4 cbox[T * NB];
+  __shared__ double carea[T * NB], cscore[T * NB];
+  __shared__ uint32_t ckey[T * NB];         // order-preserving images of (float)x1: the placement only
+  __shared__ int cid[T * NB];
+  __shared__ unsigned long long gmax[2];     // the best score image of a round (two sets in turn)
+  __shared__ uint32_t glo[2], ghi[2];        // ... the lowest / highest box number that holds it
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const double thr = (double)thr_f, sigma = (double)sigma_f, min_score = (double)min_score_f;     // (promoted as in the double instantiation, nms_cpu.cpp:170,184)
+  double x1[NB], y1[NB], x2[NB], y2[NB], sc[NB], ar[NB];
+  int rank[NB], oid[NB];
+  uint32_t live = 0u;
+  bool bad = false;
+  {
+    uint32_t key[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int p = b * T + tid;
+      const bool in = p < n;
+      const double *d = dets + (size_t)(in ? p : 0) * 5;
+      x1[b] = d[0]; y1[b] = d[1]; x2[b] = d[2]; y2[b] = d[3]; sc[b] = d[4];
+      key[b] = in ? score_image32((float)x1[b]) : 0xFFFFFFFFu;
+      if (in) bad = bad || (sc[b] != sc[b]);
+      ckey[p] = key[b];
+    }
+    if (__syncthreads_or(bad ? 1 : 0)) {
+      if (tid == 0) result[0] = kSoftFastGiveUp;
+      return;
+    }
+    int r[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) r[b] = 0;
+    const uint4 *k4 = reinterpret_cast<const uint4 *>(ckey);
+    for (int q = 0; q < T * NB; q += 4) {
+      const uint4 k = k4[q >> 2];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const unsigned long long me = ((unsigned long long)key[b] << 32) | (uint32_t)(b * T + tid);
+        r[b] += ((((unsigned long long)k.x << 32) | (uint32_t)q) < me) ? 1 : 0;
+        r[b] += ((((unsigned long long)k.y << 32) | (uint32_t)(q + 1)) < me) ? 1 : 0;
+        r[b] += ((((unsigned long long)k.z << 32) | (uint32_t)(q + 2)) < me) ? 1 : 0;
+        r[b] += ((((unsigned long long)k.w << 32) | (uint32_t)(q + 3)) < me) ? 1 : 0;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int p = b * T + tid;
+      cbox[r[b]] = make_double4(x1[b], y1[b], x2[b], y2[b]);
+      cscore[r[b]] = sc[b];
+      cid[r[b]] = p < n ? p : -1;
+    }
+    __syncthreads();
+  }
+  const double big = 1.0e308;
+  double wxlo = big, wxhi = -big, war_min = big;
+  bool irregular = false;
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int spos = wave * (64 * NB) + b * 64 + lane;
+    const double4 c = cbox[spos];
+    x1[b] = c.x; y1[b] = c.y; x2[b] = c.z; y2[b] = c.w; sc[b] = cscore[spos];
+    oid[b] = cid[spos];
+    ar[b] = ((x2[b] - x1[b]) + 1.0) * ((y2[b] - y1[b]) + 1.0);
+    carea[spos] = ar[b];
+    rank[b] = -1;
+    if (oid[b] >= 0) {
+      live |= 1u << b;
+      irregular = irregular || !(fabs(x1[b]) < big && fabs(y1[b]) < big && fabs(x2[b]) < big && fabs(y2[b]) < big && fabs(ar[b]) < big);
+      wxlo = x1[b] < wxlo ? x1[b] : wxlo; wxhi = x2[b] > wxhi ? x2[b] : wxhi;
+      war_min = ar[b] < war_min ? ar[b] : war_min;
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const double l = __shfl_xor(wxlo, o), h = __shfl_xor(wxhi, o), m = __shfl_xor(war_min, o);
+    wxlo = l < wxlo ? l : wxlo; wxhi = h > wxhi ? h : wxhi; war_min = m < war_min ? m : war_min;
+  }
+  const bool wave_regular = __ballot(irregular) == 0ull;
+  unsigned long long cw = 0ull;              // the wave's candidate: score image (0: none), first / last owner's box number
+  uint32_t clo = 0u, chi = 0u;
+  auto candidate = [&]() __attribute__((always_inline)) {
+    unsigned long long img[NB], best = 0ull;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      img[b] = (live >> b & 1u) ? score_image64(sc[b]) : 0ull;
+      best = img[b] > best ? img[b] : best;
+    }
+    const unsigned long long wmax = wave_max_key(best);
+    uint32_t eq = 0u;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) eq |= (img[b] == wmax && wmax != 0ull) ? (1u << b) : 0u;
+    const uint64_t owners = __ballot(eq != 0u);
+    clo = 0u; chi = 0u;
+    if (owners) {
+      const int fl = __builtin_ctzll(owners), ll = 63 - __builtin_clzll(owners);
+      const uint32_t feq = (uint32_t)__builtin_amdgcn_readlane((int)eq, fl), leq = (uint32_t)__builtin_amdgcn_readlane((int)eq, ll);
+      clo = (uint32_t)(wave * (64 * NB) + __builtin_ctz(feq) * 64 + fl);
+      chi = (uint32_t)(wave * (64 * NB) + (31 - __builtin_clz(leq)) * 64 + ll);
+    }
+    cw = wmax;
+  };
+  if (tid < 2) { gmax[tid] = 0ull; glo[tid] = 0xFFFFFFFFu; ghi[tid] = 0u; }
+  __syncthreads();
+  int par = 0, picks = 0;
+  candidate();
+  if (lane == 0 && cw != 0ull) atomicMax(&gmax[par], cw);
+  for (;;) {
+    __syncthreads();                                             // the round's maximum image is complete
+    const unsigned long long gm = gmax[par];
+    const int nxt = par ^ 1;
+    if (tid == 0) { gmax[nxt] = 0ull; glo[nxt] = 0xFFFFFFFFu; ghi[nxt] = 0u; }     // (last read before this barrier, fed after the next one)
+    if (gm == 0ull) break;                                       // nothing left
+    if (gm == ~0ull) {                                           // (block-uniform) a NaN score
+      if (tid == 0) result[0] = kSoftFastGiveUp;
+      return;
+    }
+    if (lane == 0 && cw == gm) { atomicMin(&glo[par], clo); atomicMax(&ghi[par], chi); }
+    __syncthreads();                                             // ... and who holds it
+    const int gi = (int)glo[par];
+    if (glo[par] != ghi[par]) {                                  // (block-uniform) the maximum is not unique
+      if (tid == 0) result[0] = kSoftFastGiveUp;
+      return;
+    }
+    const double4 a = cbox[gi];
+    const double iarea = carea[gi];
+    const bool mine = (gi & 63) == lane && gi / (64 * NB) == wave;
+    const int gslot = (gi >> 6) & (NB - 1);
+    const int wbest = (int)clo;
+    const bool own_best = cw != 0ull && (wbest & 63) == lane;
+    const int wslot = (wbest >> 6) & (NB - 1);
+    bool touched = false;
+    if (mine) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) if (b == gslot) { live &= ~(1u << b); rank[b] = picks; touched = true; }
+    }
+    const bool plain = method == 2 || !(0.0 > thr);
+    const bool far = wave_regular && plain && fabs(a.y) < big && fabs(a.w) < big && (iarea + war_min) > 0.0 &&
+                     (a.z + 2.0 < wxlo || a.x - 2.0 > wxhi);
+    if (!far) {
+      double inter[NB], den[NB];
+      bool act[NB];
+      bool any = false;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const uint32_t bit = 1u << b;
+        const double xx1 = a.x < x1[b] ? x1[b] : a.x, yy1 = a.y < y1[b] ? y1[b] : a.y;
+        const double xx2 = x2[b] < a.z ? x2[b] : a.z, yy2 = y2[b] < a.w ? y2[b] : a.w;
+        const double ww = (xx2 - xx1) + 1.0, hh = (yy2 - yy1) + 1.0;
+        const double w = 0.0 < ww ? ww : 0.0, h = 0.0 < hh ? hh : 0.0;
+        inter[b] = w * h;
+        den[b] = (iarea + ar[b]) - inter[b];
+        const bool skip = inter[b] == 0.0 && den[b] > 0.0 && plain;
+        act[b] = (live & bit) != 0u && !skip;
+        any = any || act[b];
+      }
+      if (__ballot(any) != 0ull) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          const double ovr = inter[b] / den[b];
+          double weight = 1.0;
+          if (method == 1) { if (ovr > thr) weight = 1.0 - ovr; }
+          else if (method == 2) weight = soft_exp(-(ovr * ovr) / sigma);
+          else weight = (ovr > thr) ? 0.0 : 1.0;
+          if (act[b]) {
+            sc[b] = weight * sc[b];
+            touched = touched || (own_best && b == wslot);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const uint32_t bit = 1u << b;
+      if ((live & bit) != 0u && sc[b] < min_score) { live &= ~bit; touched = touched || (own_best && b == wslot); }
+    }
+    ++picks;
+    par = nxt;
+    if (__ballot(touched) != 0ull) candidate();                  // (wave-uniform)
+    if (lane == 0 && cw != 0ull) atomicMax(&gmax[par], cw);
+  }
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    if (rank[b] >= 0) {
+      double *o = out_dets + (size_t)rank[b] * 5;
+      o[0] = x1[b]; o[1] = y1[b]; o[2] = x2[b]; o[3] = y2[b]; o[4] = sc[b];
+      out_inds[rank[b]] = oid[b];
+    }
+  }
+  if (tid == 0) result[0] = picks;
+}
+
+constexpr int kSoftFast64Max = 2048;
+static bool soft_launch_fast64(const double *dets, int64_t n, float thr, int method, float sigma, float min_score,
+                               double *out_dets, int64_t *out_inds, long long *result, hipStream_t st) {
+#define OBB_SOFT_FAST64(T, NB) hipLaunchKernelGGL((soft_nms_fast64_kernel<T, NB>), dim3(1), dim3(T), 0, st, dets, (int)n, thr, method, sigma, min_score, out_dets, out_inds, result)
+  if (n <= 256) OBB_SOFT_FAST64(256, 1);
+  else if (n <= 512) OBB_SOFT_FAST64(512, 1);
+  else if (n <= 1024) OBB_SOFT_FAST64(1024, 1);
+  else if (n <= kSoftFast64Max) OBB_SOFT_FAST64(1024, 2);
+  else return false;
+#undef OBB_SOFT_FAST64
+  return true;
+}
+
 static thread_local int g_soft_path = -1;      // obb_soft_nms_last_path
 constexpr int kSoftFastMax = 4096;
 // (n = the array's rows, or -- grouped, seg != nullptr -- the caller's bound on the rows of one group)
@@ -1047,6 +1264,14 @@ extern "C" int obb_soft_nms_f64(const double *dets_dev, int64_t n, float iou_thr
   long long *pinned_dev = nullptr;
   OBB_HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&pinned_dev), pinned, 0));
   hipStream_t st = (hipStream_t)stream;
+  // up to 2048 rows: the kernel without positions first (as for float rows); it gives up where the array permutation matters
+  if (tuning(OBB_TUNE_SOFT_NMS_REG, 0) == 0 &&
+      soft_launch_fast64(dets_dev, n, iou_thr, method, sigma, min_score, out_dets_dev, out_inds_dev, pinned_dev, st)) {
+    OBB_LAUNCH_CHECK();
+    OBB_HIP_TRY(hipStreamSynchronize(st));
+    if (*pinned != kSoftFastGiveUp) { *count_host = *pinned; g_soft_path = 2; return OBB_OK; }
+    g_soft_path = 3;
+  } else g_soft_path = 1;
   soft_launch_reg<double>(dets_dev, n, 1, iou_thr, method, sigma, min_score, out_dets_dev, out_inds_dev, pinned_dev, nullptr, st);
   OBB_LAUNCH_CHECK();
   OBB_HIP_TRY(hipStreamSynchronize(st));

@@ -212,7 +212,8 @@ OBB_API int obb_soft_nms_f32(const float *dets_dev, int64_t n, float iou_thr, in
 
 /* float64 rows (n, 5): soft_nms_cpu_kernel<double> (AT_DISPATCH_FLOATING_TYPES, nms_cpu.cpp:212-215): overlaps, decayed scores
  * and the `< min_score` / `> iou_thr` comparisons in double (the float arguments promoted, :170,:184); out_dets_dev
- * (n, 5) doubles.  The state lives in registers: n <= 4096.  Synchronises `stream` (returns the count). */
+ * (n, 5) doubles.  n <= 4096 (up to 2048 rows a kernel that needs no array positions, else -- or where two remaining boxes share
+ * the maximum -- the state in registers with positions).  Synchronises `stream` (returns the count). */
 OBB_API int obb_soft_nms_f64(const double *dets_dev, int64_t n, float iou_thr, int method, float sigma,
                              float min_score, double *out_dets_dev, int64_t *out_inds_dev,
                              int64_t *count_host, void *stream);

@@ -158,7 +158,7 @@ def test_float64_nms_is_decided_in_double_like_the_reference(golden, nms_route):
 
 
 def test_float64_bbox_overlaps_and_soft_nms_follow_the_input_dtype(golden):
-    from aidet_amd import bbox_overlaps, soft_nms
+    from aidet_amd import _lib, bbox_overlaps, soft_nms
     g = golden('hbb_f64.npz')
     b1, b2 = torch.from_numpy(g['iou_b1']), torch.from_numpy(g['iou_b2'])
     for where in (lambda x: x, lambda x: x.to(dev())):
@@ -180,6 +180,22 @@ def test_float64_bbox_overlaps_and_soft_nms_follow_the_input_dtype(golden):
             nd, inds = soft_nms(d, 0.3, method='gaussian', sigma=sigma, min_score=0.05)
             rd, ri = oracle.soft_nms_f64(d, 0.3, 'gaussian', sigma, 0.05)
             assert nd.dtype == np.float64 and np.array_equal(inds, ri) and np.array_equal(nd, rd), (n, sigma)
+            # (up to 2048 rows the position-free double kernel serves the call -- distinct scores here --, the register kernel above)
+            assert _lib.lib().obb_soft_nms_last_path() == (2 if n <= 2048 else 1), n
+        # scores that differ beyond float precision only, shared maxima, a NaN, -0: the double order, the array's permutation
+        e = d.copy()
+        e[:, 4] = 0.5 + np.arange(n) * 1e-12
+        f = d.copy()
+        f[::6, 4] = 0.5
+        if n > 10:
+            f[3, 4] = np.nan
+            f[7, 4] = -0.0
+        for arr, want_path in ((e, 2 if n <= 2048 else 1), (f, 3 if n <= 2048 else 1)):
+            for method in ('linear', 'gaussian'):
+                nd, inds = soft_nms(arr, 0.3, method=method, sigma=0.5, min_score=0.05)
+                rd, ri = oracle.soft_nms_f64(arr, 0.3, method, 0.5, 0.05)
+                assert np.array_equal(inds, ri) and np.array_equal(nd, rd, equal_nan=True), (n, method)
+                assert _lib.lib().obb_soft_nms_last_path() == want_path, (n, method)
 
 
 def test_float64_rotated_input_says_that_it_is_down_cast():

@@ -12,6 +12,7 @@ from aidet_amd.nms_wrapper import soft_nms
 
 L = _lib.lib()
 a, b = int(sys.argv[1]), int(sys.argv[2])
+F64 = len(sys.argv) > 3 and sys.argv[3] == 'f64'      # float64 rows against the oracle's double loop (1 .. 4096 rows)
 t0 = time.time()
 paths = {}
 gauss = [0, 0, 0]      # gaussian arrays | index- and bit-exact against the host loop | kept set differs
@@ -30,6 +31,21 @@ for it in range(a, b):
         d[rng.integers(0, n), 4] = -0.0
     min_score = float(rng.choice([1e-3, 0.05, 0.3]))
     thr = float(rng.choice([0.0, 0.3, 0.5]))
+    if F64:
+        d64 = d.astype(np.float64)
+        if n > 4096:
+            continue
+        if not tied:
+            d64[:, 4] += rng.random(n) * 1e-9          # (differences float cannot hold)
+        for method in ('linear', 'gaussian'):
+            nd, inds = soft_nms(d64, thr, method=method, sigma=0.5, min_score=min_score)
+            p = L.obb_soft_nms_last_path()
+            paths[p] = paths.get(p, 0) + 1
+            rd, ri = oracle.soft_nms_f64(d64, thr, method, 0.5, min_score)
+            assert np.array_equal(inds, ri) and np.array_equal(nd, rd, equal_nan=True), (it, n, method, p)
+        if it % 50 == 0:
+            print('array', it, 'n', n, 'float64, paths so far', paths, 'ok  %.0f s' % (time.time() - t0), flush=True)
+        continue
     for method in (('linear',) if tied else ('linear', 'gaussian')):
         nd, inds = soft_nms(torch.from_numpy(d).cuda(), thr, method=method, sigma=0.5, min_score=min_score)
         p = L.obb_soft_nms_last_path()
