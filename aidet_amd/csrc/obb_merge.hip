@@ -146,39 +146,41 @@ __global__ __launch_bounds__(256) void route_count_kernel(const float *__restric
 constexpr int kScanLds = 16384;         // counts that are scanned in LDS (64 KiB): coalesced loads and stores
 __device__ __forceinline__ int block_scan_inplace(int *__restrict__ a, int64_t m, int *part /* LDS, kScanThreads / 64 + 1 */) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t chunk = (m + kScanThreads - 1) / kScanThreads;
-  const int64_t lo = tid * chunk, hi = lo + chunk < m ? lo + chunk : m;
-  if (m <= kScanLds) {
-    // (the 12 808 (patch, source) counts of an 8-rank pass took 11 us with every thread walking its 13 words in global
-    // memory twice -- dependent round trips; staged: one coalesced load and one coalesced store per word)
-    __shared__ int buf[kScanLds];
-    for (int64_t j = tid; j < m; j += kScanThreads) buf[j] = a[j];
+  // tiles of kScanLds counts staged in LDS with a running carry: one coalesced load and one coalesced store per word.
+  // (Every thread walking its words in global memory twice -- dependent round trips at a stride of the chunk -- took 11 us
+  // for the 12 808 (patch, source) counts of an 8-rank pass and 157 us for the 102 400 of the 128-image scene: 17 % of what
+  // one rank of eight computes there.)
+  __shared__ int buf[kScanLds];
+  int carry = 0;                                           // (block-uniform)
+  for (int64_t base = 0; base < m; base += kScanLds) {
+    const int mm = (int)(m - base < (int64_t)kScanLds ? m - base : (int64_t)kScanLds);
+    const int chunk = (mm + kScanThreads - 1) / kScanThreads;
+    const int lo = tid * chunk < mm ? tid * chunk : mm, hi = lo + chunk < mm ? lo + chunk : mm;
+    {  // all of a thread's words requested before the first is used (a load, a wait and an LDS store per turn of a loop were
+       // sixteen dependent round trips per tile)
+      constexpr int kPer = kScanLds / kScanThreads;
+      int v[kPer];
+#pragma unroll
+      for (int u = 0; u < kPer; ++u) { const int j = tid + u * kScanThreads; v[u] = j < mm ? a[base + j] : 0; }
+#pragma unroll
+      for (int u = 0; u < kPer; ++u) { const int j = tid + u * kScanThreads; if (j < mm) buf[j] = v[u]; }
+    }
     __syncthreads();
     int sum = 0;
-    for (int64_t j = lo; j < hi; ++j) sum += buf[j];
+    for (int j = lo; j < hi; ++j) sum += buf[j];
     int inc = sum;
     for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o); if (lane >= o) inc += v; }
     if (lane == 63) part[wave] = inc;
     __syncthreads();
-    int pre = inc - sum, total = 0;
+    int pre = carry + inc - sum, total = 0;
     for (int w = 0; w < kScanThreads / 64; ++w) { const int v = part[w]; pre += (w < wave) ? v : 0; total += v; }
-    for (int64_t j = lo; j < hi; ++j) { const int v = buf[j]; buf[j] = pre; pre += v; }
+    for (int j = lo; j < hi; ++j) { const int v = buf[j]; buf[j] = pre; pre += v; }
     __syncthreads();
-    for (int64_t j = tid; j < m; j += kScanThreads) a[j] = buf[j];
-    __syncthreads();
-    return total;
+    for (int j = tid; j < mm; j += kScanThreads) a[base + j] = buf[j];
+    carry += total;
+    __syncthreads();                                       // (buf and part are reused by the next tile)
   }
-  int sum = 0;
-  for (int64_t j = lo; j < hi; ++j) sum += a[j];
-  int inc = sum;
-  for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o); if (lane >= o) inc += v; }
-  if (lane == 63) part[wave] = inc;
-  __syncthreads();
-  int pre = inc - sum, total = 0;
-  for (int w = 0; w < kScanThreads / 64; ++w) { const int v = part[w]; pre += (w < wave) ? v : 0; total += v; }
-  for (int64_t j = lo; j < hi; ++j) { const int v = a[j]; a[j] = pre; pre += v; }
-  __syncthreads();
-  return total;
+  return carry;
 }
 
 __global__ __launch_bounds__(kScanThreads) void route_scan_kernel(int *__restrict__ blockcnt, int world, int nblocks,
@@ -291,25 +293,37 @@ __global__ __launch_bounds__(256) void restore_mark_kernel(const float *__restri
   if (head) atomicAdd(&cnt[idx], stop ? __builtin_ctzll(stop) + 1 : 64 - lane);
 }
 
-__global__ __launch_bounds__(kScanThreads) void restore_scan_kernel(int *__restrict__ cnt, int64_t m,
+__global__ __launch_bounds__(kScanThreads) void restore_scan_kernel(int *__restrict__ cnt, int64_t m, const int *__restrict__ bad_word,
                                                                     int *__restrict__ status) {
   __shared__ int part[kScanThreads / 64 + 1];
-  const int bad = cnt[m];
+  const int bad = bad_word[0];
   block_scan_inplace(cnt, m, part);
   if (threadIdx.x == 0 && status && bad) *status = bad;
+}
+
+// more than kScanLds counts (the 102 400 (patch, source) counts of one rank of eight at 128 images: one workgroup took 82 us
+// over them, tile after tile): a workgroup per tile scans its own kScanLds counts and hands its total on; restore_scan_kernel
+// then scans the totals and the scatter adds a tile's offset to the local start
+__global__ __launch_bounds__(kScanThreads) void restore_scan_tiles_kernel(int *__restrict__ cnt, int64_t m, int *__restrict__ tile_sum) {
+  __shared__ int part[kScanThreads / 64 + 1];
+  const int64_t base = (int64_t)blockIdx.x * kScanLds;
+  const int64_t mm = m - base < (int64_t)kScanLds ? m - base : (int64_t)kScanLds;
+  const int total = block_scan_inplace(cnt + base, mm, part);
+  if (threadIdx.x == 0) tile_sum[blockIdx.x] = total;
 }
 
 __global__ __launch_bounds__(256) void restore_scatter_kernel(const float *__restrict__ rows, int cols, int key_col,
                                                               int64_t n, SegStarts sg, int world, int key_max,
                                                               const int *__restrict__ start,
                                                               const int64_t *__restrict__ first, int out_cols,
-                                                              int64_t total, float *__restrict__ out) {
+                                                              int64_t total, float *__restrict__ out,
+                                                              const int *__restrict__ tile_off) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const float kf = rows[i * cols + key_col];
   if (!(kf >= 0.0f && kf <= (float)key_max)) return;      // padding
   const int64_t idx = (int64_t)(int)kf * world + seg_of(sg, world, i);
-  const int64_t pos = (int64_t)start[idx] + (i - first[idx]);
+  const int64_t pos = (int64_t)start[idx] + (tile_off ? (int64_t)tile_off[idx / kScanLds] : 0) + (i - first[idx]);
   if (pos < 0 || pos >= total) return;                     // (only when the promise is broken: reported in `status`)
   const float *src = rows + i * cols;
   float *dst = out + pos * out_cols;
@@ -653,7 +667,7 @@ extern "C" size_t obb_rows_restore_workspace_bytes(int world, int64_t key_max) {
   if (world < 1 || world > obb::kRouteMaxWorld || key_max < 0) return 0;
   const int64_t m = (key_max + 1) * world;
   if (m > OBB_RESTORE_MAX_SLOTS) return 0;
-  return (size_t)((m + 2) * sizeof(int) + 8 + m * sizeof(int64_t));
+  return (size_t)((m + 2) * sizeof(int) + 8 + m * sizeof(int64_t) + (size_t)(m / obb::kScanLds + 2) * sizeof(int));      // counts | first rows | tile totals
 }
 
 extern "C" int obb_rows_restore_f32(const float *rows_dev, int64_t n, int cols, int key_col, const int64_t *seg_start_host,
@@ -682,10 +696,19 @@ extern "C" int obb_rows_restore_f32(const float *rows_dev, int64_t n, int cols, 
   const unsigned blocks = (unsigned)((n + 255) / 256);
   hipLaunchKernelGGL(obb::restore_mark_kernel, dim3(blocks), dim3(256), 0, st, rows_dev, cols, key_col, n, sg, world, (int)key_max, m, cnt, first);
   OBB_LAUNCH_CHECK();
-  hipLaunchKernelGGL(obb::restore_scan_kernel, dim3(1), dim3(obb::kScanThreads), 0, st, cnt, m, status_dev);
+  int *tile_off = nullptr;
+  if (m <= obb::kScanLds) {
+    hipLaunchKernelGGL(obb::restore_scan_kernel, dim3(1), dim3(obb::kScanThreads), 0, st, cnt, m, cnt + m, status_dev);
+  } else {
+    const int64_t tiles = (m + obb::kScanLds - 1) / obb::kScanLds;           // (<= OBB_RESTORE_MAX_SLOTS / kScanLds: one tile of totals)
+    tile_off = reinterpret_cast<int *>(first + m);
+    hipLaunchKernelGGL(obb::restore_scan_tiles_kernel, dim3((unsigned)tiles), dim3(obb::kScanThreads), 0, st, cnt, m, tile_off);
+    OBB_LAUNCH_CHECK();
+    hipLaunchKernelGGL(obb::restore_scan_kernel, dim3(1), dim3(obb::kScanThreads), 0, st, tile_off, tiles, cnt + m, status_dev);
+  }
   OBB_LAUNCH_CHECK();
   hipLaunchKernelGGL(obb::restore_scatter_kernel, dim3(blocks), dim3(256), 0, st, rows_dev, cols, key_col, n, sg, world, (int)key_max,
-                     cnt, first, out_cols, total, out_dev);
+                     cnt, first, out_cols, total, out_dev, tile_off);
   OBB_LAUNCH_CHECK();
   return OBB_OK;
 }
