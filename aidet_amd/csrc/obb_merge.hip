@@ -146,39 +146,51 @@ __global__ __launch_bounds__(256) void route_count_kernel(const float *__restric
 constexpr int kScanLds = 16384;         // counts that are scanned in LDS (64 KiB): coalesced loads and stores
 __device__ __forceinline__ int block_scan_inplace(int *__restrict__ a, int64_t m, int *part /* LDS, kScanThreads / 64 + 1 */) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // tiles of kScanLds counts staged in LDS with a running carry: one coalesced load and one coalesced store per word.
-  // (Every thread walking its words in global memory twice -- dependent round trips at a stride of the chunk -- took 11 us
-  // for the 12 808 (patch, source) counts of an 8-rank pass and 157 us for the 102 400 of the 128-image scene: 17 % of what
-  // one rank of eight computes there.)
-  __shared__ int buf[kScanLds];
+  // tiles of kScanLds counts with a running carry.  (Every thread walking a chunk of the WHOLE array in global memory twice --
+  // dependent round trips at a stride of the chunk -- took 11 us for the 12 808 (patch, source) counts of an 8-rank pass and
+  // 157 us for the 102 400 of the 128-image scene: 17 % of what one rank of eight computes there.)
+  // (thread t owns the kPer consecutive counts [t kPer, (t + 1) kPer) of a tile: four 16-byte loads, the sums and the prefix in
+  // registers, four 16-byte stores -- the version that staged the tile in LDS and walked it there at a stride of kPer words
+  // took 6 us for 12 808 counts and 15 us for a full tile)
+  constexpr int kPer = kScanLds / kScanThreads;
+  static_assert(kPer % 4 == 0, "16-byte loads");
   int carry = 0;                                           // (block-uniform)
   for (int64_t base = 0; base < m; base += kScanLds) {
     const int mm = (int)(m - base < (int64_t)kScanLds ? m - base : (int64_t)kScanLds);
-    const int chunk = (mm + kScanThreads - 1) / kScanThreads;
-    const int lo = tid * chunk < mm ? tid * chunk : mm, hi = lo + chunk < mm ? lo + chunk : mm;
-    {  // all of a thread's words requested before the first is used (a load, a wait and an LDS store per turn of a loop were
-       // sixteen dependent round trips per tile)
-      constexpr int kPer = kScanLds / kScanThreads;
-      int v[kPer];
+    int *t = a + base;
+    const int lo = tid * kPer;
+    const bool wide = ((reinterpret_cast<uintptr_t>(t) & 15u) == 0u) && lo + kPer <= mm;      // (a whole, aligned run of this thread)
+    int v[kPer];
+    if (wide) {
 #pragma unroll
-      for (int u = 0; u < kPer; ++u) { const int j = tid + u * kScanThreads; v[u] = j < mm ? a[base + j] : 0; }
+      for (int u = 0; u < kPer / 4; ++u) {
+        const int4 q = reinterpret_cast<const int4 *>(t + lo)[u];
+        v[4 * u] = q.x; v[4 * u + 1] = q.y; v[4 * u + 2] = q.z; v[4 * u + 3] = q.w;
+      }
+    } else {
 #pragma unroll
-      for (int u = 0; u < kPer; ++u) { const int j = tid + u * kScanThreads; if (j < mm) buf[j] = v[u]; }
+      for (int u = 0; u < kPer; ++u) v[u] = lo + u < mm ? t[lo + u] : 0;
     }
-    __syncthreads();
     int sum = 0;
-    for (int j = lo; j < hi; ++j) sum += buf[j];
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) sum += v[u];
     int inc = sum;
-    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o); if (lane >= o) inc += v; }
+    for (int o = 1; o < 64; o <<= 1) { const int x = __shfl_up(inc, o); if (lane >= o) inc += x; }
     if (lane == 63) part[wave] = inc;
     __syncthreads();
     int pre = carry + inc - sum, total = 0;
-    for (int w = 0; w < kScanThreads / 64; ++w) { const int v = part[w]; pre += (w < wave) ? v : 0; total += v; }
-    for (int j = lo; j < hi; ++j) { const int v = buf[j]; buf[j] = pre; pre += v; }
-    __syncthreads();
-    for (int j = tid; j < mm; j += kScanThreads) a[base + j] = buf[j];
+    for (int w = 0; w < kScanThreads / 64; ++w) { const int x = part[w]; pre += (w < wave) ? x : 0; total += x; }
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) { const int x = v[u]; v[u] = pre; pre += x; }
+    if (wide) {
+#pragma unroll
+      for (int u = 0; u < kPer / 4; ++u) reinterpret_cast<int4 *>(t + lo)[u] = make_int4(v[4 * u], v[4 * u + 1], v[4 * u + 2], v[4 * u + 3]);
+    } else {
+#pragma unroll
+      for (int u = 0; u < kPer; ++u) if (lo + u < mm) t[lo + u] = v[u];
+    }
     carry += total;
-    __syncthreads();                                       // (buf and part are reused by the next tile)
+    __syncthreads();                                       // (part is reused by the next tile)
   }
   return carry;
 }
