@@ -13,14 +13,27 @@ import workloads
 from aidet_amd import _lib, nms_wrapper
 dev = torch.device('cuda', 0)
 L = _lib.lib()
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
-d = torch.from_numpy(workloads.boxes(n, 20000.0 * (n / 100000.0) ** 0.5, 3)).to(dev)
+grouped = len(sys.argv) > 1 and sys.argv[1] == 'merge'      # the merged NMS of a config-5 pass (group = image x class, per-class thresholds)
+if grouped:
+    from aidet_amd import dota_io, dota_merge
+    sc = workloads.tiled_scene(images=16)
+    args = [torch.from_numpy(sc[k]).to(dev) for k in ('dets', 'label', 'patch')]
+    rows, counts = dota_merge.tiled_local_phase(*args, torch.from_numpy(sc['patch_xy']).to(dev), torch.from_numpy(sc['patch_image']).to(dev), 15, 0.5, 1)
+    K = counts.tolist()[2]
+    r = rows[:K].contiguous()
+    d = r[:, :6].contiguous()
+    g = (r[:, 7].long() * 15 + r[:, 6].long()).int()
+    t = dota_merge._class_thr_tensor(dota_io.class_thresholds(), dev)[r[:, 6].long()].contiguous()
+    n = K
+else:
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
+    d = torch.from_numpy(workloads.boxes(n, 20000.0 * (n / 100000.0) ** 0.5, 3)).to(dev)
 L.obb_debug_frame_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
 names = ['entry -> own share zeroed', '-> samples in LDS (global round trip)', '-> one-pass statistics', '-> trimming rounds (outliers only)',
          '-> trimmed box, group hashes', '-> frame written (thread 0)']
 acc = []
 for rep in range(12):
-    keep = nms_wrapper.rnms(d, 0.5)[1]
+    keep = nms_wrapper.rnms(d, 0.3, groups=g, thrs=t)[1] if grouped else nms_wrapper.rnms(d, 0.5)[1]
     torch.cuda.synchronize()
     buf = np.zeros(16 + 4 * 4096, dtype=np.uint64)
     assert L.obb_debug_frame_stamps(buf.ctypes.data, buf.size) == 0
