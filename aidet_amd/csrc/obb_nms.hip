@@ -101,7 +101,7 @@ struct NmsCounters {
   alignas(256) long long kept;             // K
   long long rounds;                        // resolve sweeps (most of any shard)
   unsigned int done;                       // resolve workgroups finished
-  unsigned int state;                      // fused resolve + compaction: 0 wait, 1 all shards resolved (go), 2 a waiter gave up
+  unsigned int state;                      // fused resolve + compaction, after a waiter gave up (flag in `done`): shards that have registered to leave
   unsigned int grid_fail;                  // grid route: too many crowded cells / a box over too many cells -- repeat on the sorted route
   alignas(256) unsigned int grid_over;     // grid route: entries on the overflow list (may exceed grid_over_cap(n))
   unsigned int grid_big;                   // grid route: boxes over more than kGridMaxCells cells (may exceed grid_big_cap(n)); (the line of grid_over: both move in rare scenes only)
@@ -2412,30 +2412,38 @@ __global__ __launch_bounds__(COMPACT ? kResolveThreadsCompact : kResolveThreads)
     // ---- fused compaction (round 4: the sorted route's nms_compact_kernel launch and its boundary, n < 2^18).  The 64
     // workgroups of this launch are co-resident by size (64 x 256 threads), so the shards that are done WAIT for the last
     // one -- on one word, with a bound -- and then compact n / 64 words each (counts handed on through flagged words, as in
-    // nms_compact_kernel).  No deadlock whatever the scheduler does: the last shard to finish moves `state` 0 -> 1 (go); a
-    // waiter whose bound expires moves it 0 -> 2 and leaves; only one of the two transitions can happen, and after a 2
-    // the last shard -- which by then sees every final word -- writes the whole keep list alone.
+    // nms_compact_kernel).  No deadlock whatever the scheduler does: a waiter whose bound expires raises a flag in the
+    // arrival word -- possible only while arrivals are missing -- and from then on every shard leaves after its resolve
+    // except the last one to do so, which by then sees every final word and writes the whole keep list alone (below).
     __shared__ int s_go;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (this wave's atomics are acknowledged before the ticket is taken)
     __syncthreads();
     if (tid == 0) {
+      // `done`: arrivals in the low bits, kGave = a waiter's bound expired.  An arrival is a fire-and-forget add and every
+      // shard -- the last one too -- then READS the word until it shows all arrivals (go) or the flag: one load round trip
+      // behind the last add where a returning ticket and a compare-and-swap of a second word (two returning atomics in a
+      // row on the last shard's path, ~2 us each) used to be.  The flag can only be set while arrivals are missing (a
+      // compare-and-swap against the word just read), so "all arrived, no flag" is final for everybody who sees it; with
+      // the flag up every shard registers in `state` (a returning add: the rare path) and the LAST to register -- all the
+      // others have resolved and left by then -- writes the whole keep list alone.
+      constexpr unsigned int kGave = 0x80000000u;
       unsigned int st = 0u;
-      const unsigned int tk = __hip_atomic_fetch_add(&ctr->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (tk == gridDim.x - 1) {
-        unsigned int expect = 0u;
-        const bool ok = __hip_atomic_compare_exchange_strong(&ctr->state, &expect, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        st = ok ? 1u : 3u;                  // 3: somebody gave up -- this workgroup compacts everything
-      } else {
-        const uint64_t t0 = wall_clock64();
-        while ((st = __hip_atomic_load(&ctr->state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) {
-          __builtin_amdgcn_s_sleep(1);
-          if (wall_clock64() - t0 >= (coop == 2 ? 0ull : 25000000ull)) {     // 0.25 s of the 100 MHz wall clock (coop 2: a test hook, at once)
-            unsigned int expect = 0u;
-            __hip_atomic_compare_exchange_strong(&ctr->state, &expect, 2u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            st = __hip_atomic_load(&ctr->state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            break;
-          }
+      (void)__hip_atomic_fetch_add(&ctr->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint64_t t0 = wall_clock64();
+      for (;;) {
+        const unsigned int w = __hip_atomic_load(&ctr->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (w & kGave) { st = 2u; break; }
+        if (w == gridDim.x) { st = 1u; break; }
+        if (wall_clock64() - t0 >= (coop == 2 ? 0ull : 25000000ull)) {     // 0.25 s of the 100 MHz wall clock (coop 2: a test hook, at once)
+          unsigned int expect = w;
+          if (__hip_atomic_compare_exchange_strong(&ctr->done, &expect, w | kGave, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { st = 2u; break; }
+          continue;                                                          // (the word moved: look again)
         }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (st == 2u) {
+        const unsigned int reg = __hip_atomic_fetch_add(&ctr->state, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (reg == gridDim.x - 1) st = 3u;         // everybody else has resolved, registered and left: this workgroup compacts everything
       }
       s_go = (int)st;
     }
