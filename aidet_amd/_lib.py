@@ -31,7 +31,7 @@ NMS_RESULT_BYTES = 64   # OBB_NMS_RESULT_BYTES
 # obb_set_tuning knobs (test / experiment hooks, include/obbops.h)
 (TUNE_NMS_FUSED_MAX, TUNE_NMS_DIRECT_MAX, TUNE_NMS_SCAN_BLOCKS, TUNE_RROI_GROUPS, TUNE_OVERLAPS_ROWS, TUNE_NMS_INLINE_MAX,
  TUNE_RROI_ORDER_MIN, TUNE_RROI_GATHER_CHAN, TUNE_RPN_BARRIER_TICKS, TUNE_SOFT_NMS_REG, TUNE_NMS_FUSED_COMPACT, TUNE_RROI_PLAN, TUNE_NMS_GRID,
- TUNE_SOFT_NMS_SHAPE) = range(14)
+ TUNE_SOFT_NMS_SHAPE, TUNE_RROI_NHWC_NQ, TUNE_RROI_NHWC_XCD, TUNE_RROI_NHWC_WAVES) = range(17)
 
 _lib = None
 
@@ -131,6 +131,10 @@ def lib():
                                                    ctypes.POINTER(f32), i32, i32, i32, vp, vp, i64, i32, i32,
                                                    i32, i32, f32, vp, vp, ctypes.c_size_t, vp]
         L.obb_roi_align_forward_ws_f32.restype = i32
+        L.obb_roi_align_forward_nhwc_f32.argtypes = L.obb_roi_align_forward_ws_f32.argtypes
+        L.obb_roi_align_forward_nhwc_f32.restype = i32
+        L.obb_rroi_align_forward_nhwc_f32.argtypes = rroi
+        L.obb_rroi_align_forward_nhwc_f32.restype = i32
         L.obb_nms_profile_enable.argtypes = [i32]
         L.obb_nms_profile_enable.restype = i32
         L.obb_nms_profile_last.argtypes = [ctypes.POINTER(f32)]

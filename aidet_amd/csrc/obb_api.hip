@@ -20,8 +20,9 @@ int set_err(int code, const char *fmt, ...) {
   return code;
 }
 
-static std::atomic<int64_t> g_tune[OBB_TUNE_COUNT] = {{-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}};
-static_assert(OBB_TUNE_COUNT == 14, "one initialiser per knob");
+// (-1 = unset; the loader runs this before any caller can reach the library)
+static std::atomic<int64_t> g_tune[OBB_TUNE_COUNT];
+static const bool g_tune_init = [] { for (auto &t : g_tune) t.store(-1, std::memory_order_relaxed); return true; }();
 
 int64_t tuning(int knob, int64_t def) {
   const int64_t v = g_tune[knob].load(std::memory_order_relaxed);

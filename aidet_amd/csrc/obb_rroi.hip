@@ -34,132 +34,12 @@
 
 #include "obb_common.h"
 #include "obb_geom.h"
+#include "obb_rroi_internal.h"
 
 namespace obb {
 
 constexpr int kChanPerThread = 8;   // channel grouping of the direct (unstaged) paths
 
-struct RoiFrame {
-  int b, gh, gw, kind;
-  float cnt;                      // divisor of a bin's sum
-  float cx, cy, c, s, x0, y0;     // kind 0: centre, rotation, start in the RoI's own frame
-  float xs, ys;                   // kinds 1, 2: start on the map
-  float rw, rh, bin_w, bin_h;
-};
-
-// RoI row layouts.  kind 0: [b, cx, cy, w, h, theta].  Horizontal RoIs [b, x1, y1, x2, y2]
-// (roi_align.py:136) are evaluated with the reference's own expressions:
-//   kind 1 (legacy V1, roi_align_kernel.cu:79-86): start = x1*s, end = (x2+1)*s, size =
-//          fmaxf(end - start, 0); the sum is divided by gh*gw (0/0 = NaN for an empty grid)
-//   kind 2 (V2 aligned=True, roi_align_kernel_v2.cu:79-92): start = x1*s - 0.5, size = end -
-//          start unclamped; divided by max(gh*gw, 1)
-__device__ __forceinline__ int roi_stride(int kind) { return kind == 0 ? 6 : 5; }
-
-__device__ __forceinline__ int grid_of(float bin, int sample_num) {
-  if (sample_num > 0) return sample_num;
-  const float g = ceilf(bin);
-  return g > 65536.0f ? 65536 : (g > 0.0f ? (int)g : 0);   // (an empty or negative grid samples nothing)
-}
-
-__device__ __forceinline__ void make_frame(const float *__restrict__ roi, int kind, float scale, int ph,
-                                           int pw, int sample_num, float min_size, RoiFrame &f) {
-  f.b = (int)roi[0];
-  f.kind = kind;
-  f.cx = f.cy = f.x0 = f.y0 = f.xs = f.ys = 0.0f;
-  f.c = 1.0f; f.s = 0.0f;
-  if (kind == 0) {
-    f.cx = roi[1] * scale;
-    f.cy = roi[2] * scale;
-    f.rw = max_sel(roi[3] * scale, min_size);
-    f.rh = max_sel(roi[4] * scale, min_size);
-    sincos_det(roi[5], f.s, f.c);
-    f.x0 = -0.5f * f.rw;
-    f.y0 = -0.5f * f.rh;
-  } else if (kind == 1) {
-    f.xs = roi[1] * scale;
-    f.ys = roi[2] * scale;
-    const float xe = (roi[3] + 1.0f) * scale, ye = (roi[4] + 1.0f) * scale;
-    f.rw = fmaxf(xe - f.xs, 0.0f);
-    f.rh = fmaxf(ye - f.ys, 0.0f);
-  } else {
-    f.xs = roi[1] * scale - 0.5f;
-    f.ys = roi[2] * scale - 0.5f;
-    const float xe = roi[3] * scale - 0.5f, ye = roi[4] * scale - 0.5f;
-    f.rw = xe - f.xs;
-    f.rh = ye - f.ys;
-  }
-  f.bin_h = f.rh / (float)ph;
-  f.bin_w = f.rw / (float)pw;
-  f.gh = grid_of(f.bin_h, sample_num);
-  f.gw = grid_of(f.bin_w, sample_num);
-  const long long ci = (long long)f.gh * f.gw;
-  f.cnt = (kind == 1) ? (float)ci : (float)(ci < 1 ? 1 : ci);
-}
-
-__device__ __forceinline__ void sample_xy(const RoiFrame &f, int ph_i, int pw_i, int iy, int ix,
-                                          float &x, float &y) {
-  if (f.kind == 0) {
-    float ly = f.y0 + (float)ph_i * f.bin_h;
-    float t1 = ((float)iy + 0.5f) * f.bin_h;
-    ly = ly + t1 / (float)f.gh;
-    float lx = f.x0 + (float)pw_i * f.bin_w;
-    float t2 = ((float)ix + 0.5f) * f.bin_w;
-    lx = lx + t2 / (float)f.gw;
-    float xc = lx * f.c, ys = ly * f.s;
-    float xs = lx * f.s, yc = ly * f.c;
-    float rx = xc - ys, ry = xs + yc;
-    x = f.cx + rx;
-    y = f.cy + ry;
-  } else {   // roi_start + p * bin + (i + .5) * bin / grid, left to right (roi_align_kernel.cu:100-107)
-    float ty = f.ys + (float)ph_i * f.bin_h;
-    float t1 = ((float)iy + 0.5f) * f.bin_h;
-    y = ty + t1 / (float)f.gh;
-    float tx = f.xs + (float)pw_i * f.bin_w;
-    float t2 = ((float)ix + 0.5f) * f.bin_w;
-    x = tx + t2 / (float)f.gw;
-  }
-}
-
-// tap offsets + weights; all-zero weights for a sample outside the map
-__device__ __forceinline__ void bilinear_taps(int height, int width, float y, float x, int (&o)[4],
-                                              float (&w)[4]) {
-  const bool outside = (y < -1.0f) || (y > (float)height) || (x < -1.0f) || (x > (float)width);
-  if (y <= 0.0f) y = 0.0f;
-  if (x <= 0.0f) x = 0.0f;
-  int y_low = (int)y, x_low = (int)x, y_high, x_high;
-  if (y_low >= height - 1) { y_high = y_low = height - 1; y = (float)y_low; }
-  else y_high = y_low + 1;
-  if (x_low >= width - 1) { x_high = x_low = width - 1; x = (float)x_low; }
-  else x_high = x_low + 1;
-  float ly = y - (float)y_low, lx = x - (float)x_low;
-  float hy = 1.0f - ly, hx = 1.0f - lx;
-  o[0] = y_low * width + x_low;  o[1] = y_low * width + x_high;
-  o[2] = y_high * width + x_low; o[3] = y_high * width + x_high;
-  w[0] = hy * hx; w[1] = hy * lx; w[2] = ly * hx; w[3] = ly * lx;
-  if (outside) {
-    o[0] = o[1] = o[2] = o[3] = 0;
-    w[0] = w[1] = w[2] = w[3] = 0.0f;
-  }
-}
-
-// same rules, but returning the tap coordinates (no division to recover them)
-__device__ __forceinline__ bool bilinear_taps_xy(int height, int width, float y, float x, int &yl,
-                                                 int &xl, int &yh, int &xh, float (&w)[4]) {
-  const bool outside = (y < -1.0f) || (y > (float)height) || (x < -1.0f) || (x > (float)width);
-  if (y <= 0.0f) y = 0.0f;
-  if (x <= 0.0f) x = 0.0f;
-  int y_low = (int)y, x_low = (int)x, y_high, x_high;
-  if (y_low >= height - 1) { y_high = y_low = height - 1; y = (float)y_low; }
-  else y_high = y_low + 1;
-  if (x_low >= width - 1) { x_high = x_low = width - 1; x = (float)x_low; }
-  else x_high = x_low + 1;
-  float ly = y - (float)y_low, lx = x - (float)x_low;
-  float hy = 1.0f - ly, hx = 1.0f - lx;
-  yl = y_low; xl = x_low; yh = y_high; xh = x_high;
-  w[0] = hy * hx; w[1] = hy * lx; w[2] = ly * hx; w[3] = ly * lx;
-  if (outside) { w[0] = w[1] = w[2] = w[3] = 0.0f; }
-  return !outside;
-}
 
 // ---- forward, direct gathers (any footprint size) ---------------------------------------
 // item = (channel group, bin); used for RoIs whose footprint does not fit the LDS tile
@@ -211,47 +91,6 @@ constexpr int kMaxBins = 64;          // bins of a staged RoI
 constexpr int kMaxPassChan = 16;      // channels per staging pass (gradient tile 16 x 65 floats)
 constexpr int kBinPitchMax = 65;
 
-struct Footprint { int x0, y0, w, h; };
-
-// feature pyramid of the multi-level forward (obb_roi_align_levels_forward_f32): passed by value
-struct LevelTable {
-  const float *feat[OBB_MAX_LEVELS];
-  int H[OBB_MAX_LEVELS], W[OBB_MAX_LEVELS];
-  float scale[OBB_MAX_LEVELS];
-};
-
-// The axis-aligned pixel box that holds every bilinear tap of every sample.  The samples
-// are an affine lattice, so their extreme coordinates are those of the four CORNER samples,
-// evaluated by the very expressions the sample table uses; interior samples repeat those
-// expressions with other small integers, i.e. they may exceed a corner by a few ulps of the
-// coordinate: margin 1e-3 px + 1e-6 |coordinate| (>= 8 ulps).  (The rectangle's own corners
-// plus a pixel of slack -- the first version -- cost ~3 more rows and columns per RoI: a
-// third of the bytes staged at configs[2].)
-__device__ __forceinline__ Footprint roi_footprint(const RoiFrame &f, int H, int W, int ph, int pw) {
-  float lox, hix, loy, hiy;
-  {
-    float x, y;
-    sample_xy(f, 0, 0, 0, 0, x, y);
-    lox = hix = x; loy = hiy = y;
-    sample_xy(f, 0, pw - 1, 0, f.gw - 1, x, y);
-    lox = min_sel(lox, x); hix = max_sel(hix, x); loy = min_sel(loy, y); hiy = max_sel(hiy, y);
-    sample_xy(f, ph - 1, 0, f.gh - 1, 0, x, y);
-    lox = min_sel(lox, x); hix = max_sel(hix, x); loy = min_sel(loy, y); hiy = max_sel(hiy, y);
-    sample_xy(f, ph - 1, pw - 1, f.gh - 1, f.gw - 1, x, y);
-    lox = min_sel(lox, x); hix = max_sel(hix, x); loy = min_sel(loy, y); hiy = max_sel(hiy, y);
-  }
-  const float mx = 1.0e-3f + 1.0e-6f * max_sel(fabs_sel(lox), fabs_sel(hix));
-  const float my = 1.0e-3f + 1.0e-6f * max_sel(fabs_sel(loy), fabs_sel(hiy));
-  // low tap of the smallest coordinate .. high tap (+ 1) of the largest
-  float fx0 = floorf(lox - mx), fx1 = floorf(hix + mx) + 1.0f;
-  float fy0 = floorf(loy - my), fy1 = floorf(hiy + my) + 1.0f;
-  fx0 = min_sel(max_sel(fx0, 0.0f), (float)(W - 1)); fx1 = min_sel(max_sel(fx1, 0.0f), (float)(W - 1));
-  fy0 = min_sel(max_sel(fy0, 0.0f), (float)(H - 1)); fy1 = min_sel(max_sel(fy1, 0.0f), (float)(H - 1));
-  Footprint p;
-  p.x0 = (int)fx0; p.y0 = (int)fy0;
-  p.w = (int)fx1 - p.x0 + 1; p.h = (int)fy1 - p.y0 + 1;
-  return p;
-}
 
 // XCD-aware block -> (RoI, channel chunk): consecutive ids take the SAME RoI and 8 DIFFERENT
 // chunks (one per XCD under round-robin dispatch); chunks 8r .. 8r+7 ("round" r) are swept
@@ -1425,7 +1264,6 @@ __global__ __launch_bounds__(256) void rroi_gather_kernel(
 // shape 220 us in the given order, 177 Morton only, 169 with the size classes).  The order inside a cell follows the
 // LDS atomics' arrival -- it decides which block works on which RoI, never a result.
 constexpr int kOrderBins = 32768;    // 4 size classes x 8 levels x 1024 cells
-constexpr int kOrderMaxK = 65536;    // above: identity order (the caller passes no order)
 // below: not worth its launch (measured: 512 RoIs covering a 256^2 map 1.8x: the ordered kernel is 3 us faster, the order
 // kernel and its launch boundary cost 8; 2000 RoIs covering it 22x: 220 -> 175 us all in)
 constexpr int kOrderMinK = 1024;
@@ -1492,7 +1330,16 @@ __global__ __launch_bounds__(1024) void rroi_order_kernel(const LevelTable lv, c
   for (int k = tid + 4096; k < K; k += 1024) order[hist[P(key_of(k))] + (uint32_t)tmp[k]] = k;
 }
 
-static int rroi_check(const char *who, int B, int C, int H, int W, int64_t K, int ph, int pw) {
+// (declared in obb_rroi_internal.h: the channels-last translation unit uses the same order launch)
+int rroi_order_launch(const LevelTable &lv, const int *roi_level_dev, int num_levels, const float *rois_dev, int64_t K,
+                      int roi_kind, int *order_ws, void *stream) {
+  hipLaunchKernelGGL(rroi_order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, lv, roi_level_dev, num_levels, rois_dev,
+                     (int)K, roi_kind, order_ws, order_ws + K);
+  OBB_LAUNCH_CHECK();
+  return OBB_OK;
+}
+
+int rroi_check(const char *who, int B, int C, int H, int W, int64_t K, int ph, int pw) {
   if (B < 0 || C < 0 || H < 0 || W < 0 || K < 0)
     return set_err(OBB_EINVAL, "%s: negative dimension", who);
   if (ph <= 0 || pw <= 0) return set_err(OBB_EINVAL, "%s: out size must be positive (%d x %d)", who, ph, pw);
@@ -1554,9 +1401,8 @@ static int rroi_forward_launch_levels(const char *who, const LevelTable &lv, int
   // hundred RoIs on: the footprints of RoIs that run together then share lines in an XCD's L2)
   const int *order = nullptr;
   if (order_ws && K >= tuning(OBB_TUNE_RROI_ORDER_MIN, kOrderMinK) && K <= kOrderMaxK) {
-    hipLaunchKernelGGL(rroi_order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, lv, roi_level_dev, num_levels, rois_dev,
-                       (int)K, roi_kind, order_ws, order_ws + K);
-    OBB_LAUNCH_CHECK();
+    rc = rroi_order_launch(lv, roi_level_dev, num_levels, rois_dev, K, roi_kind, order_ws, stream);
+    if (rc != OBB_OK) return rc;
     order = order_ws;
   }
   // with a workspace and enough channels: the per-RoI plan (one wave per RoI), read by all C / 32 blocks of the RoI

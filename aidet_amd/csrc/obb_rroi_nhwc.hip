@@ -1,0 +1,326 @@
+// obb_rroi_nhwc.hip -- rotated / horizontal RoI-Align on CHANNELS-LAST feature maps (B, H, W, C) for gfx950.
+//
+// Same operators, values and operation order as obb_rroi.hip (the counterparts of ROIAlignForwardV1 /
+// RoIAlignForwardV2, mmdet/ops/roi_align/src/roi_align_kernel.cu:64-117, roi_align_kernel_v2.cu:62-128, and of
+// RoIAlignBackwardFeatureV2, roi_align_kernel_v2.cu:179-263); what differs is the map's memory layout.  The reference
+// only knows NCHW (roi_align_cuda.cpp:37-42 checks contiguity) -- a PyTorch trunk run in torch.channels_last hands the
+// op a (B, C, H, W) tensor whose memory is (B, H, W, C), and until round 5 the wrapper copied it back to NCHW first.
+//
+// Why the layout matters here.  In NCHW a bilinear tap of one channel is 4 bytes at an arbitrary address: the NCHW
+// kernel stages a RoI's footprint rows (~60 B at arbitrary alignment) of every channel plane into LDS and ends at
+// 2.4 x the algorithmic bytes in 64-byte sector requests.  In channels-last a tap of ALL channels is one
+// contiguous run of 4 C bytes (1 KiB at C = 256):
+//   * lane = four consecutive channels (one 16-byte load), a group of NQ lanes = one tap of a slab of 4 NQ channels;
+//     a wave-instruction fetches 64 / NQ taps as whole 128-byte lines -- nothing is staged, no footprint is computed;
+//   * the sample table (4 tap offsets + 4 weights per sample: the same for every channel) is built once per block in
+//     LDS and read back as a broadcast;
+//   * the sums are transposed through an LDS tile [channel][bin] -- the block's part of the reference's (K, C, ph, pw)
+//     output is one contiguous range -- and leave as 16-byte stores.
+// Per output value: w1*v1 + w2*v2 + w3*v3 + w4*v4 summed over the samples in (iy, ix) order, then / count, exactly
+// the expressions of rroi_forward_kernel (bit-equal results on the permuted map: tests/test_round5_gpu.py).
+#include <cstdlib>
+
+#include "obb_common.h"
+#include "obb_geom.h"
+#include "obb_rroi_internal.h"
+
+namespace obb {
+
+// OBB_NHWC_STAMPS (tools/build_ablations.sh -> libobbops_nhst.so, tools/exp_nhwc_stamps.py): shader-clock stamps of every
+// block's thread 0 -- entry | frame read back | table built | this wave's gathers done | tile complete (barrier) | copy-out
+// issued -- and the 100 MHz real-time counter at entry and exit (comparable across CUs: when do the blocks run?).
+#ifdef OBB_NHWC_STAMPS
+__device__ unsigned long long g_nhwc_stamps[8 * 8192];
+#define OBB_NSTAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) { g_nhwc_stamps[blockIdx.x * 8 + (i)] = (i) >= 6 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define OBB_NSTAMP(i) do { } while (0)
+#endif
+
+constexpr int kNhwcTab = 256;              // samples of one table round (8 KiB)
+constexpr int kNhwcTileBins = 49;          // bins of one output tile when the slab is full (7 x 7: the whole RoI)
+
+// One block = (RoI, slab of CS = 4 NQ channels), NW waves.  lane -> (slot = lane / NQ, quad = lane % NQ): the NW x 64 / NQ
+// slots of a block each take a bin at a time; the NQ lanes of a slot hold the slab's channels, four each.
+//   rounds   the sample table holds <= 256 samples: bins_per_round = 256 / samples_per_bin bins at a time (7 x 7 bins of
+//            2 x 2 samples: one round); a bin of more than 256 samples (adaptive grids of huge RoIs) is summed over
+//            several rounds by its one slot
+//   tiles    the LDS tile holds CS x TB sums: TB = all bins when they fit (then the copy-out is linear)
+// mode 0: block id -> (position id / slabs, slab id % slabs).  mode 1 (with an order; slabs divides 8): the XCD of a block
+// (id & 7 under round-robin dispatch; a speed assumption only) takes slab xcd % slabs and a CONTIGUOUS range of the
+// Morton-ordered RoIs, so that RoIs that run together on an XCD share map lines in its L2.
+template <int NQ, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void roi_forward_nhwc_kernel(
+    const LevelTable lv, const int *__restrict__ roi_level, int num_levels, int B, int C,
+    const float *__restrict__ rois, int ph, int pw, int sample_num, float min_size, int K, int slabs, int mode,
+    int roi_kind, const int *__restrict__ roi_order, float *__restrict__ out, int out_vec4) {
+  constexpr int CS = 4 * NQ;                 // channels of a slab
+  constexpr int SL = 64 / NQ;                // slots per wave
+  constexpr int kSlots = NW * SL;            // ... per block
+  constexpr int kThreads = 64 * NW;
+  constexpr int kTileFloats = CS * kNhwcTileBins;
+  __shared__ __attribute__((aligned(16))) float otile[kTileFloats];
+  __shared__ uint4 s_off[kNhwcTab];          // per sample: byte offsets of the 4 taps' pixels inside the image
+  __shared__ float4 s_wgt[kNhwcTab];         // per sample: the 4 bilinear weights (all zero: the sample is outside)
+  __shared__ RoiFrame s_frame;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int slot = lane / NQ, quad = lane - slot * NQ, sid = wave * SL + slot;
+  int64_t pos;
+  int slab;
+  OBB_NSTAMP(6);
+  OBB_NSTAMP(0);
+  if (mode == 1) {
+    const int xcd = (int)(blockIdx.x & 7u), groups = 8 / slabs;
+    const int per = (K + groups - 1) / groups, j = (int)(blockIdx.x >> 3);
+    slab = xcd % slabs;
+    pos = (int64_t)(xcd / slabs) * per + j;
+    if (j >= per || pos >= K) return;
+  } else {
+    pos = blockIdx.x / (unsigned)slabs;
+    slab = (int)(blockIdx.x - (unsigned)pos * (unsigned)slabs);
+  }
+  int64_t k = pos;
+  if (roi_order) {
+    const int kk = roi_order[pos];
+    if (kk >= 0 && kk < K) k = kk;
+  }
+  const int lvl_raw = roi_level ? roi_level[k] : 0;
+  const bool lvl_ok = lvl_raw >= 0 && lvl_raw < num_levels;
+  const int lvl = lvl_ok ? lvl_raw : 0;
+  const float *__restrict__ feat = lv.feat[lvl];
+  const int H = lv.H[lvl], W = lv.W[lvl];
+  // the RoI's frame (trigonometry, bin sizes): ONE wave computes it, the block reads it back (obb_rroi.hip: the other
+  // waves leave their issue slots to the gathers of the CU's other blocks)
+  if (tid < 64) {
+    RoiFrame f0;
+    make_frame(rois + k * roi_stride(roi_kind), roi_kind, lv.scale[lvl], ph, pw, sample_num, min_size, f0);
+    if (tid == 0) s_frame = f0;
+  }
+  __syncthreads();
+  const RoiFrame f = s_frame;
+  OBB_NSTAMP(1);
+  const int nb = ph * pw;
+  const int c0 = slab * CS, cs = min(CS, C - c0);
+  float *__restrict__ obase = out + ((int64_t)k * C + c0) * nb;         // [cs][nb], contiguous
+  const long long spb64 = (long long)f.gh * f.gw;
+  if (!lvl_ok || f.b < 0 || f.b >= B || spb64 <= 0) {
+    // invalid batch / level index: zeros.  Empty sampling grid: the sum of nothing over the count -- 0 (V2, rotated)
+    // or 0 / 0 = NaN (V1 divides by gh * gw, roi_align_kernel.cu:113)
+    const float v = (!lvl_ok || f.b < 0 || f.b >= B) ? 0.0f : 0.0f / f.cnt;
+    for (int it = tid; it < cs * nb; it += kThreads) obase[it] = v;
+    return;
+  }
+  const bool active = 4 * quad < cs;
+  const char *__restrict__ img = reinterpret_cast<const char *>(feat + (int64_t)f.b * H * W * C + c0 + 4 * (active ? quad : 0));
+  const uint32_t pixb = (uint32_t)C * 4u;      // bytes of a pixel
+  const int spb = (int)(spb64 > (1 << 30) ? (1 << 30) : spb64);
+  const int qn_max = spb < kNhwcTab ? spb : kNhwcTab;              // samples of a bin per round
+  const int bpr = spb <= kNhwcTab ? kNhwcTab / spb : 1;             // bins per round
+  const int tb = min(nb, kTileFloats / CS);                          // bins per tile (>= kNhwcTileBins)
+  // mean over the samples: a division, or -- a power-of-two count (2 x 2 samples), the usual case -- the exact same
+  // value from a multiplication (scaling by a power of two rounds identically)
+  const uint32_t cbits = __float_as_uint(f.cnt);
+  const bool cnt_pow2 = (cbits & 0x007FFFFFu) == 0u && f.cnt >= 1.0f;
+  const float cnt_inv = cnt_pow2 ? 1.0f / f.cnt : 0.0f;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto add_sample = [&](const float4 &w, const float4 &p0, const float4 &p1, const float4 &p2, const float4 &p3) {
+    float4 v;
+    v.x = w.x * p0.x; v.y = w.x * p0.y; v.z = w.x * p0.z; v.w = w.x * p0.w;
+    v.x = v.x + w.y * p1.x; v.y = v.y + w.y * p1.y; v.z = v.z + w.y * p1.z; v.w = v.w + w.y * p1.w;
+    v.x = v.x + w.z * p2.x; v.y = v.y + w.z * p2.y; v.z = v.z + w.z * p2.z; v.w = v.w + w.z * p2.w;
+    v.x = v.x + w.w * p3.x; v.y = v.y + w.w * p3.y; v.z = v.z + w.w * p3.z; v.w = v.w + w.w * p3.w;
+    acc.x = acc.x + v.x; acc.y = acc.y + v.y; acc.z = acc.z + v.z; acc.w = acc.w + v.w;
+  };
+  auto tap = [&](uint32_t off) { return *reinterpret_cast<const float4 *>(img + off); };
+  for (int t0 = 0; t0 < nb; t0 += tb) {
+    const int t1 = min(nb, t0 + tb), tp = t1 - t0;
+    for (int b0 = t0; b0 < t1; b0 += bpr) {
+      const int nbr = min(bpr, t1 - b0);
+      for (int q0 = 0; q0 < spb; q0 += qn_max) {
+        const int qn = min(qn_max, spb - q0);
+        // ---- sample table of this round: coordinates, taps and weights ONCE per block (the reference recomputes
+        // them for every output element, roi_align_kernel.cu:70-113)
+        for (int sidx = tid; sidx < nbr * qn; sidx += kThreads) {
+          const int bl = sidx / qn, qq = sidx - bl * qn;
+          const int bin = b0 + bl, q = q0 + qq;
+          const int bi = bin / pw, bj = bin - bi * pw;
+          const int iy = q / f.gw, ix = q - iy * f.gw;
+          float x, y, w[4];
+          int yl, xl, yh, xh;
+          sample_xy(f, bi, bj, iy, ix, x, y);
+          const bool live = bilinear_taps_xy(H, W, y, x, yl, xl, yh, xh, w);
+          const uint32_t r0 = (uint32_t)yl * (uint32_t)W, r1 = (uint32_t)yh * (uint32_t)W;
+          s_off[sidx] = live ? make_uint4((r0 + (uint32_t)xl) * pixb, (r0 + (uint32_t)xh) * pixb, (r1 + (uint32_t)xl) * pixb, (r1 + (uint32_t)xh) * pixb)
+                             : make_uint4(0u, 0u, 0u, 0u);
+          s_wgt[sidx] = live ? make_float4(w[0], w[1], w[2], w[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __syncthreads();
+        OBB_NSTAMP(2);
+        // ---- gathers: a slot takes a bin at a time, 4 samples = 16 loads of 16 bytes in flight per lane
+        for (int bl = sid; bl < nbr; bl += kSlots) {
+          if (q0 == 0) acc = make_float4(0.f, 0.f, 0.f, 0.f);
+          const int e0 = bl * qn;
+          int qq = 0;
+          if (active) {
+            for (; qq + 4 <= qn; qq += 4) {
+              uint4 o[4];
+              float4 w[4];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) { o[u] = s_off[e0 + qq + u]; w[u] = s_wgt[e0 + qq + u]; }
+              float4 p[4][4];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) { p[u][0] = tap(o[u].x); p[u][1] = tap(o[u].y); p[u][2] = tap(o[u].z); p[u][3] = tap(o[u].w); }
+#pragma unroll
+              for (int u = 0; u < 4; ++u)
+                if (w[u].x != 0.0f) add_sample(w[u], p[u][0], p[u][1], p[u][2], p[u][3]);   // (w1 = 0 <=> the sample is outside the map: it adds nothing)
+            }
+            for (; qq < qn; ++qq) {
+              const uint4 o = s_off[e0 + qq];
+              const float4 w = s_wgt[e0 + qq];
+              if (w.x != 0.0f) add_sample(w, tap(o.x), tap(o.y), tap(o.z), tap(o.w));
+            }
+          }
+          if (q0 + qn >= spb && active) {
+            float4 r;
+            if (cnt_pow2) { r.x = acc.x * cnt_inv; r.y = acc.y * cnt_inv; r.z = acc.z * cnt_inv; r.w = acc.w * cnt_inv; }
+            else { r.x = acc.x / f.cnt; r.y = acc.y / f.cnt; r.z = acc.z / f.cnt; r.w = acc.w / f.cnt; }
+            float *d = otile + (4 * quad) * tp + (b0 + bl - t0);
+            d[0] = r.x; d[tp] = r.y; d[2 * tp] = r.z; d[3 * tp] = r.w;
+          }
+        }
+        OBB_NSTAMP(3);
+        __syncthreads();      // (the next round rewrites the table; the last one: the tile is complete)
+        OBB_NSTAMP(4);
+      }
+    }
+    // ---- copy-out: [channel][bin of the tile] -> out[k][c0 + channel][t0 + bin]
+    if (tp == nb) {
+      const int n = cs * nb;
+      if (out_vec4 && (n & 3) == 0) {
+        const float4 *s4 = reinterpret_cast<const float4 *>(otile);
+        float4 *d4 = reinterpret_cast<float4 *>(obase);
+        for (int i = tid; i < (n >> 2); i += kThreads) d4[i] = s4[i];
+      } else {
+        for (int i = tid; i < n; i += kThreads) obase[i] = otile[i];
+      }
+    } else {
+      for (int i = tid; i < cs * tp; i += kThreads) {
+        const int c = i / tp, j = i - c * tp;
+        obase[(int64_t)c * nb + t0 + j] = otile[i];
+      }
+    }
+    OBB_NSTAMP(5);
+    OBB_NSTAMP(7);
+    __syncthreads();          // (the next tile rewrites otile)
+  }
+}
+
+// lanes per tap: the slab of a block is 4 NQ channels.  Fewer, wider slabs = longer contiguous runs per tap (1 KiB at
+// NQ = 64) and one table per RoI; narrower slabs = a smaller LDS tile (more blocks per CU) and several taps per
+// wave-instruction.  OBB_TUNE_RROI_NHWC_NQ overrides (8, 16, 32, 64).
+static int nhwc_pick_nq(int C) {
+  int nq = 64;
+  while (nq > 8 && 4 * (nq >> 1) >= C) nq >>= 1;      // no slab wider than the map has channels
+  const int64_t t = tuning(OBB_TUNE_RROI_NHWC_NQ, -1);
+  if (t == 8 || t == 16 || t == 32 || t == 64) nq = (int)t;
+  return nq;
+}
+
+static int roi_forward_nhwc_launch(const char *who, const LevelTable &lv, int num_levels, const int *roi_level_dev,
+                                   int B, int C, const float *rois_dev, int64_t K, int ph, int pw, int sample_num,
+                                   float min_size, int roi_kind, float *out_dev, void *stream, int *order_ws) {
+  for (int l = 0; l < num_levels; ++l) {
+    int rc = rroi_check(who, B, C, lv.H[l], lv.W[l], K, ph, pw);
+    if (rc != OBB_OK) return rc;
+    if (K > 0 && C > 0) {
+      if (!lv.feat[l]) return set_err(OBB_EINVAL, "%s: null feature map (level %d)", who, l);
+      if (lv.H[l] == 0 || lv.W[l] == 0 || B == 0) return set_err(OBB_EINVAL, "%s: empty feature map with %lld RoIs", who, (long long)K);
+      if ((reinterpret_cast<uintptr_t>(lv.feat[l]) & 15u) != 0) return set_err(OBB_EINVAL, "%s: feature map (level %d) must be 16-byte aligned", who, l);
+      if ((int64_t)lv.H[l] * lv.W[l] * C >= (1ll << 30))
+        return set_err(OBB_EINVAL, "%s: one image of level %d holds %lld floats (the channels-last path addresses < 2^30)", who, l,
+                       (long long)((int64_t)lv.H[l] * lv.W[l] * C));
+    }
+  }
+  if (K == 0 || C == 0) return OBB_OK;
+  if (C % 4 != 0) return set_err(OBB_EINVAL, "%s: C = %d is not a multiple of 4 (16-byte channel groups)", who, C);
+  if (!rois_dev || !out_dev) return set_err(OBB_EINVAL, "%s: null pointer", who);
+  const int nq = nhwc_pick_nq(C);
+  const int slabs = (C + 4 * nq - 1) / (4 * nq);
+  const int *order = nullptr;
+  if (order_ws && K >= tuning(OBB_TUNE_RROI_ORDER_MIN, 1024) && K <= kOrderMaxK) {
+    int rc = rroi_order_launch(lv, roi_level_dev, num_levels, rois_dev, K, roi_kind, order_ws, stream);
+    if (rc != OBB_OK) return rc;
+    order = order_ws;
+  }
+  int mode = 0;
+  unsigned long long nblk = (unsigned long long)K * (unsigned)slabs;
+  if (order && slabs <= 8 && 8 % slabs == 0 && tuning(OBB_TUNE_RROI_NHWC_XCD, 1) != 0) {
+    const int groups = 8 / slabs;
+    mode = 1;
+    nblk = 8ull * (unsigned long long)((K + groups - 1) / groups);
+  }
+  if (nblk > 2147483647ull) return set_err(OBB_EINVAL, "%s: too many blocks (K=%lld, C=%d)", who, (long long)K, C);
+  const int vec4 = (reinterpret_cast<uintptr_t>(out_dev) & 15u) == 0 ? 1 : 0;
+  const int nw = tuning(OBB_TUNE_RROI_NHWC_WAVES, 4) == 8 ? 8 : 4;
+#define OBB_NHWC_FWD(NQ, NW)                                                                                               \
+  hipLaunchKernelGGL((roi_forward_nhwc_kernel<NQ, NW>), dim3((unsigned)nblk), dim3(64 * NW), 0, (hipStream_t)stream, lv, roi_level_dev, \
+                     num_levels, B, C, rois_dev, ph, pw, sample_num, min_size, (int)K, slabs, mode, roi_kind, order, out_dev, vec4)
+  switch (nq + nw) {
+    case 64 + 4: OBB_NHWC_FWD(64, 4); break;
+    case 64 + 8: OBB_NHWC_FWD(64, 8); break;
+    case 32 + 4: OBB_NHWC_FWD(32, 4); break;
+    case 32 + 8: OBB_NHWC_FWD(32, 8); break;
+    case 16 + 4: OBB_NHWC_FWD(16, 4); break;
+    case 16 + 8: OBB_NHWC_FWD(16, 8); break;
+    case 8 + 8: OBB_NHWC_FWD(8, 8); break;
+    default: OBB_NHWC_FWD(8, 4); break;
+  }
+#undef OBB_NHWC_FWD
+  OBB_LAUNCH_CHECK();
+  return OBB_OK;
+}
+
+}  // namespace obb
+
+#ifdef OBB_NHWC_STAMPS
+extern "C" __attribute__((visibility("default"))) int obb_debug_nhwc_stamps(unsigned long long *host, int words) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(obb::g_nhwc_stamps), (size_t)words * 8);
+}
+#endif
+
+extern "C" int obb_roi_align_forward_nhwc_f32(const float *const *feat_devs_host, const int *H_host,
+                                              const int *W_host, const float *scale_host, int num_levels,
+                                              int B, int C, const float *rois_dev,
+                                              const int32_t *roi_level_dev, int64_t K, int ph, int pw,
+                                              int sample_num, int roi_kind, float min_size,
+                                              float *out_dev, void *workspace_dev, size_t workspace_bytes,
+                                              void *stream) {
+  using namespace obb;
+  const char *who = "obb_roi_align_forward_nhwc_f32";
+  if (num_levels < 1 || num_levels > OBB_MAX_LEVELS) return set_err(OBB_EINVAL, "%s: num_levels = %d (1..%d)", who, num_levels, OBB_MAX_LEVELS);
+  if (roi_kind < 0 || roi_kind > 2) return set_err(OBB_EINVAL, "%s: bad RoI kind %d", who, roi_kind);
+  if (!feat_devs_host || !H_host || !W_host || !scale_host) return set_err(OBB_EINVAL, "%s: null level table", who);
+  if (K > 0 && num_levels > 1 && !roi_level_dev) return set_err(OBB_EINVAL, "%s: null level indices", who);
+  if (workspace_dev) {
+    if (workspace_bytes < obb_roi_forward_workspace_bytes(K))
+      return set_err(OBB_EWORKSPACE, "%s: workspace %zu bytes < obb_roi_forward_workspace_bytes(%lld) = %zu", who, workspace_bytes,
+                     (long long)K, obb_roi_forward_workspace_bytes(K));
+    if (reinterpret_cast<uintptr_t>(workspace_dev) & 15u) return set_err(OBB_EINVAL, "%s: workspace must be 16-byte aligned", who);
+  }
+  LevelTable lv = {};
+  for (int l = 0; l < num_levels; ++l) {
+    lv.feat[l] = feat_devs_host[l]; lv.H[l] = H_host[l]; lv.W[l] = W_host[l]; lv.scale[l] = scale_host[l];
+  }
+  return roi_forward_nhwc_launch(who, lv, num_levels, roi_level_dev, B, C, rois_dev, K, ph, pw, sample_num,
+                                 roi_kind == 0 ? min_size : 0.0f, roi_kind, out_dev, stream, static_cast<int *>(workspace_dev));
+}
+
+extern "C" int obb_rroi_align_forward_nhwc_f32(const float *feat_dev, int B, int C, int H, int W,
+                                               const float *rois_dev, int64_t K, int ph, int pw,
+                                               float spatial_scale, int sample_num, float min_size,
+                                               float *out_dev, void *stream) {
+  using namespace obb;
+  LevelTable lv = {};
+  lv.feat[0] = feat_dev; lv.H[0] = H; lv.W[0] = W; lv.scale[0] = spatial_scale;
+  return roi_forward_nhwc_launch("obb_rroi_align_forward_nhwc_f32", lv, 1, nullptr, B, C, rois_dev, K, ph, pw, sample_num,
+                                 min_size, 0, out_dev, stream, nullptr);
+}

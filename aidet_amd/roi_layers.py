@@ -30,10 +30,10 @@ _warned_layout = set()
 
 
 def nchw_f32(features):
-    """The (B, C, H, W) fp32 contiguous view the kernels read.  A map that is not already that -- a channels-last trunk
-    output, a half-precision map, a strided slice -- is COPIED (67 MB at configs[2]); the reference's kernels read
-    `features.contiguous()` the same way (roi_align_cuda.cpp:44, CHECK_CONTIGUOUS), but silently costs are easy to
-    miss: say so once per cause."""
+    """The (B, C, H, W) fp32 contiguous view the NCHW kernels read.  A map that is not already that -- a half-precision
+    map, a strided slice, a channels-last map the channels-last kernels cannot take -- is COPIED (67 MB at configs[2]);
+    the reference's kernels read `features.contiguous()` the same way (roi_align_cuda.cpp:44, CHECK_CONTIGUOUS), but
+    silent costs are easy to miss: say so once per cause."""
     f = features.detach()
     why = None
     if f.dtype != torch.float32:
@@ -46,6 +46,28 @@ def nchw_f32(features):
         warnings.warn('RoI-Align: the feature map (%s) is copied to contiguous NCHW fp32 before pooling (%.1f MB per call)'
                       % (why, f.numel() * 4 / 1e6), UserWarning, stacklevel=3)
     return f.to(torch.float32).contiguous()
+
+
+# Channels-last maps are pooled IN PLACE by the channels-last kernels (obb_roi_align_forward_nhwc_f32, round 5): a tap
+# of all channels is one contiguous run there.  False: every map is brought to NCHW first (rounds 1-4).
+NHWC_NATIVE = True
+
+
+def is_nhwc(f):
+    """a (B, C, H, W) fp32 HIP tensor whose MEMORY is (B, H, W, C) and which obb_roi_align_forward_nhwc_f32 accepts"""
+    return (NHWC_NATIVE and f.dim() == 4 and f.dtype == torch.float32 and f.is_cuda and f.size(1) % 4 == 0
+            and f.size(1) > 1 and f.size(2) * f.size(3) > 1           # (C == 1 or one pixel: both layouts are the same memory)
+            and not f.is_contiguous() and f.is_contiguous(memory_format=torch.channels_last)
+            and f.size(1) * f.size(2) * f.size(3) < (1 << 30) and f.data_ptr() % 16 == 0)
+
+
+def map_layout(feats):
+    """('nhwc', maps as they are) when EVERY level is channels-last memory the kernels take, else ('nchw', contiguous
+    NCHW fp32 maps; whatever is not that already is copied, with a warning)."""
+    feats = [f.detach() for f in feats]
+    if all(is_nhwc(f) for f in feats):
+        return 'nhwc', feats
+    return 'nchw', [nchw_f32(f) for f in feats]
 
 
 from . import _lib
@@ -97,12 +119,13 @@ def roi_backward(grad_out, rois, feature_size, roi_kind, out_h, out_w, spatial_s
 ORDER_MIN_ROIS = 1024    # = kOrderMinK of obb_rroi.hip: fewer RoIs are not worth the ordering launch
 
 
-def roi_forward(feats, rois, levels, out_h, out_w, scales, sample_num, roi_kind, min_size):
-    """The forward of every RoI-Align flavour: ``obb_roi_align_forward_ws_f32`` -- one launch over the level(s) after
+def roi_forward(feats, rois, levels, out_h, out_w, scales, sample_num, roi_kind, min_size, layout='nchw'):
+    """The forward of every RoI-Align flavour: ``obb_roi_align_forward_ws_f32`` (``layout`` 'nchw') or
+    ``obb_roi_align_forward_nhwc_f32`` ('nhwc': the maps' memory is (B, H, W, C)) -- one launch over the level(s) after
     one small launch that orders the RoIs along a Morton curve (L2 locality; workspace from torch's caching allocator).
 
-    feats: list of contiguous fp32 (B, C, H_l, W_l) HIP tensors; rois: contiguous fp32 (K, 5 | 6) on the same device;
-    levels: int32 (K,) or None for a single map.  Returns (K, C, out_h, out_w) fp32."""
+    feats: list of fp32 (B, C, H_l, W_l) HIP tensors, contiguous in ``layout``; rois: contiguous fp32 (K, 5 | 6) on the
+    same device; levels: int32 (K,) or None for a single map.  Returns (K, C, out_h, out_w) fp32, contiguous."""
     dev = feats[0].device
     B, C = feats[0].shape[:2]
     K, n = rois.size(0), len(feats)
@@ -124,10 +147,11 @@ def roi_forward(feats, rois, levels, out_h, out_w, scales, sample_num, roi_kind,
     if cur != dev.index:
         torch.cuda.set_device(dev)
     try:
-        rc = L.obb_roi_align_forward_ws_f32(ptrs, hs, wd, sc, n, B, C, rois.data_ptr(),
-                                            None if levels is None else levels.data_ptr(), K, out_h, out_w,
-                                            int(sample_num), int(roi_kind), float(min_size), out.data_ptr(),
-                                            ws_ptr, ws_bytes, _lib.current_stream_handle(dev))
+        fn = L.obb_roi_align_forward_nhwc_f32 if layout == 'nhwc' else L.obb_roi_align_forward_ws_f32
+        rc = fn(ptrs, hs, wd, sc, n, B, C, rois.data_ptr(),
+                None if levels is None else levels.data_ptr(), K, out_h, out_w,
+                int(sample_num), int(roi_kind), float(min_size), out.data_ptr(),
+                ws_ptr, ws_bytes, _lib.current_stream_handle(dev))
     finally:
         if cur != dev.index:
             torch.cuda.set_device(cur)
@@ -148,10 +172,11 @@ class RoIAlignFunction(Function):
         ctx.args = (out_h, out_w, float(spatial_scale), int(sample_num), 1 if aligned else 0)
         ctx.feature_size = features.size()
         ctx.in_dtype = features.dtype
-        feat = nchw_f32(features)
+        layout, (feat,) = map_layout([features])
+        ctx.layout = layout
         r = rois.detach().to(device=feat.device, dtype=torch.float32).contiguous()
         ctx.save_for_backward(r)
-        out = roi_forward([feat], r, None, out_h, out_w, [ctx.args[2]], ctx.args[3], 2 if aligned else 1, 0.0)
+        out = roi_forward([feat], r, None, out_h, out_w, [ctx.args[2]], ctx.args[3], 2 if aligned else 1, 0.0, layout)
         return out.to(features.dtype)
 
     @staticmethod
@@ -210,12 +235,12 @@ def pyramid_roi_align(feats, rois, levels, out_size, scales, sample_num, roi_kin
 
     feats: list of (B, C, H_l, W_l) fp32 HIP tensors; rois (K, 5 | 6); levels (K,) int;
     roi_kind 0 rotated (K, 6), 1 horizontal V1, 2 horizontal V2 aligned."""
-    feats = [nchw_f32(f) for f in feats]
+    layout, feats = map_layout(feats)
     dev = feats[0].device
     r = rois.detach().to(device=dev, dtype=torch.float32).contiguous()
     lv = levels.detach().to(device=dev, dtype=torch.int32).contiguous()
     out_h, out_w = _pair(out_size)
-    return roi_forward(feats, r, lv, out_h, out_w, scales, sample_num, roi_kind, min_size)
+    return roi_forward(feats, r, lv, out_h, out_w, scales, sample_num, roi_kind, min_size, layout)
 
 
 def _fusable(layers, feats, rois):

@@ -14,7 +14,6 @@ from torch.autograd.function import once_differentiable
 from torch.nn.modules.utils import _pair
 
 from . import _lib
-from .roi_layers import nchw_f32
 
 
 class RRoIAlignFunction(Function):
@@ -34,11 +33,12 @@ class RRoIAlignFunction(Function):
         ctx.feature_size = features.size()
         ctx.in_dtype = features.dtype
 
-        feat = nchw_f32(features)
+        from .roi_layers import map_layout, roi_forward
+        layout, (feat,) = map_layout([features])
+        ctx.layout = layout
         r = rois.detach().to(device=feat.device, dtype=torch.float32).contiguous()
         ctx.save_for_backward(r)
-        from .roi_layers import roi_forward
-        out = roi_forward([feat], r, None, out_h, out_w, [ctx.spatial_scale], ctx.sample_num, 0, ctx.min_size)
+        out = roi_forward([feat], r, None, out_h, out_w, [ctx.spatial_scale], ctx.sample_num, 0, ctx.min_size, layout)
         return out.to(features.dtype)
 
     @staticmethod

@@ -74,7 +74,8 @@ def parse_args():
                          'share GPUs (rank r uses cuda:(r mod #GPUs)) and every collective is staged through host memory '
                          '(aidet_amd/_collectives.py), so that the N > 1 code path can be smoke-run on a one-GPU box')
     ap.add_argument('--profile-target', default=None,
-                    choices=['nms', 'iou_sparse', 'iou_dense', 'iou_allclip', 'rroi_fwd', 'rroi_bwd', 'rroi_bwd_scatter', 'roi_fwd', 'cfg5'],
+                    choices=['nms', 'iou_sparse', 'iou_dense', 'iou_allclip', 'rroi_fwd', 'rroi_bwd', 'rroi_bwd_scatter', 'roi_fwd', 'cfg5',
+                             'rroi_fwd_nhwc', 'rroi_bwd_nhwc', 'roi_fwd_nhwc'],
                     help='run ONLY this op (for rocprofv3 passes: one workload per kernel name)')
     return ap.parse_args()
 
@@ -943,10 +944,12 @@ def profile_target(args):
     elif t == 'iou_allclip':
         a, b = make_iou_allclip(dev, 4096)
         fn = lambda: rbbox_overlaps(a, b)
-    elif t in ('rroi_fwd', 'rroi_bwd', 'rroi_bwd_scatter'):
+    elif t in ('rroi_fwd', 'rroi_bwd', 'rroi_bwd_scatter', 'rroi_fwd_nhwc', 'rroi_bwd_nhwc'):
         feat, rois = make_rroi(dev)
         layer = RRoIAlign(7, 0.25, sample_num=2)
-        if t == 'rroi_fwd':
+        if t.endswith('_nhwc'):      # the same map as channels-last memory: pooled in place by the channels-last kernels
+            feat = feat.contiguous(memory_format=torch.channels_last)
+        if t in ('rroi_fwd', 'rroi_fwd_nhwc'):
             fn = lambda: layer(feat, rois)
         elif t == 'rroi_bwd_scatter':   # the scatter formulation alone (incl. the zero fill it needs), through the C ABI
             g = torch.randn(512, 256, 7, 7, device=dev)
@@ -965,9 +968,11 @@ def profile_target(args):
             def fn():
                 feat.grad = None
                 layer(feat, rois).backward(g)
-    elif t == 'roi_fwd':
+    elif t in ('roi_fwd', 'roi_fwd_nhwc'):
         import numpy as np
         feat, _ = make_rroi(dev)
+        if t == 'roi_fwd_nhwc':
+            feat = feat.contiguous(memory_format=torch.channels_last)
         rng = np.random.default_rng(2)
         x1, y1 = rng.uniform(0, 900, 2000), rng.uniform(0, 900, 2000)
         r = np.stack([np.zeros(2000), x1, y1, x1 + rng.uniform(8, 200, 2000), y1 + rng.uniform(8, 200, 2000)], 1)

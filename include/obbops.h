@@ -346,6 +346,29 @@ OBB_API int obb_roi_align_forward_ws_f32(const float *const *feat_devs_host, con
                                          void *stream);
 
 /* ---------------------------------------------------------------------------
+ * RoI-Align forward on CHANNELS-LAST maps: feat_devs_host[l] points at a (B, H_l, W_l, C) fp32 array -- the memory of
+ * a PyTorch (B, C, H, W) tensor in torch.channels_last -- everything else (RoI kinds, levels, sampling and tap rules,
+ * the optional workspace of obb_roi_forward_workspace_bytes(K) bytes for the Morton order, the (K, C, ph, pw) output
+ * in the reference's layout) is obb_roi_align_forward_ws_f32.  Values are bit-equal to that entry point on the
+ * permuted map.  C % 4 == 0, 16-byte aligned maps, H * W * C < 2^30 per image; OBB_EINVAL otherwise (the Python wrapper
+ * then copies the map to NCHW, as the reference's `features.contiguous()` would).
+ * Replaces: RoIAlign V1 / V2 forward (roi_align_kernel.cu:64-141, roi_align_kernel_v2.cu:62-128), which read NCHW
+ *           only (roi_align_cuda.cpp:37-42: CHECK_CONTIGUOUS) -- a channels-last trunk pays a 4 B H W C-byte copy there.
+ * obb_rroi_align_forward_nhwc_f32: one map, rotated (K, 6) RoIs = obb_rroi_align_forward_f32 on a channels-last map.
+ * ------------------------------------------------------------------------- */
+OBB_API int obb_roi_align_forward_nhwc_f32(const float *const *feat_devs_host, const int *H_host,
+                                           const int *W_host, const float *scale_host, int num_levels,
+                                           int B, int C, const float *rois_dev,
+                                           const int32_t *roi_level_dev, int64_t K, int ph, int pw,
+                                           int sample_num, int roi_kind, float min_size,
+                                           float *out_dev, void *workspace_dev, size_t workspace_bytes,
+                                           void *stream);
+OBB_API int obb_rroi_align_forward_nhwc_f32(const float *feat_dev, int B, int C, int H, int W,
+                                            const float *rois_dev, int64_t K, int ph, int pw,
+                                            float spatial_scale, int sample_num, float min_size,
+                                            float *out_dev, void *stream);
+
+/* ---------------------------------------------------------------------------
  * RoI-Align backward as a GATHER (any roi_kind: 0 rotated (K,6) rows, 1 RoIAlign V1, 2 V2-aligned
  * (K,5) rows), with a caller-provided workspace of obb_roi_backward_workspace_bytes(K) bytes.
  * Replaces: the same reference kernels as obb_rroi_align_backward_f32 / obb_roi_align_backward_f32
@@ -582,7 +605,10 @@ OBB_API int obb_head_gather_decode_f32(const float *rois_dev, const float *cls_s
 #define OBB_TUNE_RROI_PLAN 11          /* fewest RoIs the workspace forward of RoI-Align plans per RoI (default 1024; 0 = always) */
 #define OBB_TUNE_NMS_GRID 12           /* grid route of the NMS: 0 never, 1 wherever it applies, 2 the same but it gives up at once (test hook for the repeat paths); default auto.  Setting it clears the calling thread's "skip the grid" notes */
 #define OBB_TUNE_SOFT_NMS_SHAPE 13     /* 1: the position-free Soft-NMS kernel as 256 threads x up to 8 boxes (default: up to 1024 threads x 1-4 boxes) */
-#define OBB_TUNE_COUNT 14
+#define OBB_TUNE_RROI_NHWC_NQ 14       /* channels-last RoI-Align forward: lanes per tap = slab of 4 x NQ channels per block (8, 16, 32, 64) */
+#define OBB_TUNE_RROI_NHWC_XCD 15      /* channels-last RoI-Align forward with an order: 0 = plain block -> RoI map instead of one contiguous range of the order per XCD */
+#define OBB_TUNE_RROI_NHWC_WAVES 16   /* channels-last RoI-Align forward: waves per block (4 or 8) */
+#define OBB_TUNE_COUNT 17
 OBB_API int obb_set_tuning(int knob, int64_t value);
 /* which route the calling thread's last synchronous obb_nms_*_f32 call took: 0 fused (one workgroup), 1 direct, 2 sorted,
  * 4 grid, 5 grid gave up (crowded cell) and the call was repeated on the sorted route; -1 none yet */

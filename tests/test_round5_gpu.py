@@ -1,0 +1,161 @@
+"""GPU tests of the round-5 additions (run on the MI355X box: `pytest -m gpu`)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4          # north_star: RoI-Align floats within 1e-4 of the CPU restatement
+
+
+def dev():
+    assert torch.cuda.is_available(), 'GPU tests need a HIP device (no CPU path exists)'
+    return torch.device('cuda:0')
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev())
+
+
+def _rois(k, canvas, seed, batch=1):
+    r = oracle.synth_boxes(k, canvas, seed)[:, :5]
+    b = (np.arange(k) % batch).astype(np.float32)[:, None]
+    return np.concatenate([b, r], 1).astype(np.float32)
+
+
+def _hrois(k, canvas, seed, batch=1):
+    rng = np.random.default_rng(seed)
+    x1 = rng.uniform(0, canvas * 0.9, k); y1 = rng.uniform(0, canvas * 0.9, k)
+    w = np.exp(rng.uniform(np.log(4), np.log(canvas / 3), k)); h = np.exp(rng.uniform(np.log(4), np.log(canvas / 3), k))
+    b = (np.arange(k) % batch)
+    return np.stack([b, x1, y1, x1 + w, y1 + h], 1).astype(np.float32)
+
+
+@pytest.fixture
+def nhwc_nq():
+    """forces the slab width of the channels-last forward (lanes per tap); default restored afterwards"""
+    from aidet_amd import _lib
+
+    def force(nq):
+        _lib.set_tuning(_lib.TUNE_RROI_NHWC_NQ, nq)
+    yield force
+    _lib.set_tuning(_lib.TUNE_RROI_NHWC_NQ, -1)
+    _lib.set_tuning(_lib.TUNE_RROI_ORDER_MIN, -1)
+    _lib.set_tuning(_lib.TUNE_RROI_NHWC_XCD, -1)
+
+
+# ---- channels-last RoI-Align forward ---------------------------------------------------------------
+@pytest.mark.parametrize('nq', [-1, 8, 16, 32, 64])
+@pytest.mark.parametrize('C,H,W,K,out,sn', [(16, 64, 64, 40, 7, 2), (40, 32, 32, 10, 14, 1), (256, 64, 64, 64, 7, 2),
+                                            (12, 33, 47, 25, (5, 9), 0), (260, 40, 24, 30, 7, 2), (64, 50, 50, 20, (8, 8), 3)])
+def test_nhwc_forward_is_bit_equal_to_the_nchw_kernel_and_meets_the_oracle(C, H, W, K, out, sn, nq, nhwc_nq):
+    """A channels-last map is pooled in place (obb_roi_align_forward_nhwc_f32): bit-equal to the NCHW kernel on the
+    same values (same expressions, same order of the sums), <= 1e-4 from the oracle; every slab width; C that is not
+    a multiple of the slab (260 = 256 + 4), several tiles (14 x 14 bins), adaptive grids (sample_num 0: several table
+    rounds), an even bin count."""
+    from aidet_amd import RRoIAlign, roi_layers
+    rng = np.random.default_rng(C + K)
+    feat = rng.standard_normal((2, C, H, W)).astype(np.float32)
+    rois = _rois(K, 4 * W, 5, batch=2)
+    rois[0, 0] = 7            # a batch index outside the map: zeros
+    rois[1, 3:5] = 0.0        # a degenerate RoI (min_size clamps it)
+    layer = RRoIAlign(out, 0.25, sample_num=sn)
+    ft = t(feat)
+    nchw = layer(ft, t(rois))
+    nhwc_nq(nq)
+    fl = ft.contiguous(memory_format=torch.channels_last)
+    assert roi_layers.is_nhwc(fl)
+    got = layer(fl, t(rois))
+    assert got.is_contiguous() and got.shape == nchw.shape
+    assert torch.equal(got, nchw)
+    ref = oracle.rroi_align_forward(feat, rois, out, 0.25, sn)
+    assert np.abs(got.cpu().numpy() - ref).max() <= TOL
+
+
+@pytest.mark.parametrize('aligned', [False, True])
+def test_nhwc_forward_horizontal_kinds(aligned, nhwc_nq):
+    """RoIAlign V1 / V2-aligned rows (roi_align_kernel.cu:64-117, roi_align_kernel_v2.cu:62-128) on a channels-last map:
+    bit-equal to the NCHW kernel, which is bit-equal to the reference's expressions (test_gpu_parity)."""
+    from aidet_amd import RoIAlign
+    rng = np.random.default_rng(11)
+    feat = rng.standard_normal((2, 32, 48, 56)).astype(np.float32)
+    rois = _hrois(60, 200, 3, batch=2)
+    rois[5, 3] = rois[5, 1] - 3.0      # x2 < x1: V1 clamps the size at 0 -> 0 / 0, V2 samples backwards
+    for sn in (2, 0):
+        layer = RoIAlign(7, 0.25, sample_num=sn, aligned=aligned)
+        a = layer(t(feat), t(rois))
+        b = layer(t(feat).contiguous(memory_format=torch.channels_last), t(rois))
+        assert torch.equal(torch.nan_to_num(a, nan=123.0), torch.nan_to_num(b, nan=123.0))
+        ref = oracle.roi_align_forward(feat, rois, 7, 0.25, sn, version=2 if aligned else 1, aligned=aligned)
+        ok = np.isfinite(ref)
+        assert np.array_equal(np.isnan(ref), np.isnan(b.cpu().numpy()))
+        assert np.abs(b.cpu().numpy()[ok] - ref[ok]).max() <= TOL
+
+
+def test_nhwc_forward_cfg3_and_the_ordered_launch(nhwc_nq):
+    """BASELINE.json configs[2] (512 rotated RoIs, 256 x 256 x 256 map, 7 x 7) on a channels-last map: <= 1e-4 from the
+    oracle, bit-equal to the NCHW kernel; and the same call with the Morton order forced (one contiguous range of the
+    order per XCD, and the plain block map) -- which block computes a RoI never changes a value."""
+    from aidet_amd import RRoIAlign, _lib
+    rng = np.random.default_rng(5)
+    feat = rng.standard_normal((1, 256, 256, 256)).astype(np.float32)
+    rois = _rois(512, 1024, 5)
+    layer = RRoIAlign(7, 0.25, sample_num=2)
+    ref = oracle.rroi_align_forward(feat, rois, 7, 0.25, 2)
+    fl = t(feat).contiguous(memory_format=torch.channels_last)
+    got = layer(fl, t(rois))
+    assert np.abs(got.cpu().numpy() - ref).max() <= TOL
+    assert torch.equal(got, layer(t(feat), t(rois)))
+    from aidet_amd import roi_layers
+    old = roi_layers.ORDER_MIN_ROIS
+    try:
+        roi_layers.ORDER_MIN_ROIS = 1
+        _lib.set_tuning(_lib.TUNE_RROI_ORDER_MIN, 1)
+        for nq in (64, 32, 16):
+            nhwc_nq(nq)
+            for xcd in (1, 0):
+                _lib.set_tuning(_lib.TUNE_RROI_NHWC_XCD, xcd)
+                assert torch.equal(layer(fl, t(rois)), got)
+    finally:
+        roi_layers.ORDER_MIN_ROIS = old
+
+
+def test_nhwc_pyramid_extractor_and_fallbacks(nhwc_nq):
+    """SingleRoIExtractor (single_level.py:11-107) over a channels-last pyramid = the NCHW pyramid, in one launch; a
+    pyramid with one NCHW level, a half-precision map and C % 4 != 0 go through the NCHW copy as before."""
+    from aidet_amd import SingleRoIExtractor, RotatedSingleRoIExtractor, RRoIAlign, roi_layers
+    rng = np.random.default_rng(3)
+    feats = [t(rng.standard_normal((2, 64, 128 >> i, 160 >> i)).astype(np.float32)) for i in range(4)]
+    cl = [f.contiguous(memory_format=torch.channels_last) for f in feats]
+    hro = t(_hrois(300, 600, 4, batch=2))
+    ex = SingleRoIExtractor(dict(type='RoIAlign', out_size=7, sample_num=2), 64, [4, 8, 16, 32])
+    with torch.no_grad():
+        a = ex(feats, hro)
+        assert torch.equal(ex(cl, hro), a)
+        assert torch.equal(ex([cl[0], feats[1], cl[2], cl[3]], hro), a)            # mixed: copied to NCHW
+    rro = t(_rois(300, 600, 6, batch=2))
+    rex = RotatedSingleRoIExtractor(dict(type='RRoIAlign', out_size=7, sample_num=2), 64, [4, 8, 16, 32])
+    with torch.no_grad():
+        assert torch.equal(rex(cl, rro), rex(feats, rro))
+    layer = RRoIAlign(7, 0.25, sample_num=2)
+    odd = t(rng.standard_normal((1, 6, 20, 20)).astype(np.float32))
+    assert not roi_layers.is_nhwc(odd.contiguous(memory_format=torch.channels_last))
+    r = t(_rois(9, 80, 2))
+    assert torch.equal(layer(odd.contiguous(memory_format=torch.channels_last), r), layer(odd, r))
+
+
+def test_nhwc_forward_c_abi_rejects_what_it_cannot_take():
+    from aidet_amd import _lib
+    L = _lib.lib()
+    f = torch.zeros((1, 8, 8, 6), device=dev())
+    r = torch.zeros((1, 6), device=dev())
+    o = torch.zeros((1, 6, 7, 7), device=dev())
+    rc = L.obb_rroi_align_forward_nhwc_f32(f.data_ptr(), 1, 6, 8, 8, r.data_ptr(), 1, 7, 7, 1.0, 2, 1.0, o.data_ptr(), None)
+    assert rc == _lib.OBB_EINVAL and b'multiple of 4' in L.obb_last_error()
+    rc = L.obb_rroi_align_forward_nhwc_f32(f.data_ptr() + 4, 1, 8, 8, 6, r.data_ptr(), 1, 7, 7, 1.0, 2, 1.0, o.data_ptr(), None)
+    assert rc == _lib.OBB_EINVAL and b'aligned' in L.obb_last_error()
+    assert L.obb_rroi_align_forward_nhwc_f32(None, 1, 8, 8, 8, None, 0, 7, 7, 1.0, 2, 1.0, None, None) == _lib.OBB_OK   # K = 0
