@@ -146,6 +146,10 @@ def lib():
         L.obb_roi_backward_gather_f32.argtypes = [vp, i32, i32, i32, i32, vp, i64, i32, i32, i32, f32, i32, f32, vp, vp,
                                                   ctypes.c_size_t, vp]
         L.obb_roi_backward_gather_f32.restype = i32
+        L.obb_roi_backward_nhwc_workspace_bytes.argtypes = [i64, i32, i32, i32]
+        L.obb_roi_backward_nhwc_workspace_bytes.restype = ctypes.c_size_t
+        L.obb_roi_backward_gather_nhwc_f32.argtypes = L.obb_roi_backward_gather_f32.argtypes
+        L.obb_roi_backward_gather_nhwc_f32.restype = i32
         L.obb_patch_groups_i32.argtypes = [vp, vp, i64, i64, vp, vp]
         L.obb_patch_groups_i32.restype = i32
         L.obb_patch_rows_to_image_f32.argtypes = [vp, vp, vp, i64, vp, i64, vp, vp, i64, f32, vp, vp]

@@ -86,7 +86,6 @@ __device__ __forceinline__ void rroi_forward_direct(const float *__restrict__ fe
 
 // ---- staged kernels: shared pieces ---------------------------------------------------------
 constexpr int kStageFloats = 5120;    // backward: most floats of one staging pass ([channel][odd pitch]; see kBwdStageFloats)
-constexpr int kMaxTabSamples = 256;   // sample table (8 KiB); 7x7 bins x 2x2 samples = 196
 constexpr int kMaxBins = 64;          // bins of a staged RoI
 constexpr int kMaxPassChan = 16;      // channels per staging pass (gradient tile 16 x 65 floats)
 constexpr int kBinPitchMax = 65;
@@ -639,9 +638,7 @@ __device__ __forceinline__ void rroi_backward_direct(const float *__restrict__ g
 // The order in which a pixel's contributions are summed follows the slot order (atomic
 // tickets): results are reproducible to rounding only, like the reference's atomicAdd
 // backward (roi_align_kernel_v2.cu:179-263); tolerance 1e-4 * max|g|.
-constexpr int kBwdMaxPix = 2047;                       // footprint pixels of the staged backward (2 channels per pass there)
 constexpr int kBwdStageFloats = 4096;                  // sums tile (16 KiB): 16 channels x 255 pixels, 8 x 511, 4 x 1023
-constexpr int kBwdMaxEntries = 4 * kMaxTabSamples;     // taps of a RoI (4 per sample)
 
 // The taps of one bin that land on the SAME pixel become one entry: the first tap of such a group is its leader and
 // carries the sum of the group's weights (ascending tap number: a fixed order).  A bin's taps are `tpb` consecutive tap
@@ -678,7 +675,6 @@ __device__ __forceinline__ void merge_bin_taps(int pix, float w, int lane, int t
 }
 
 // plan record of the gather formulation (rroi_plan_kernel); state 1: planned, 2: left to the atomics kernel, 0: nothing sampled
-struct alignas(16) RoiPlan { int b, x0, y0, w, h, state, nb, pad; };
 
 __global__ __launch_bounds__(256) void rroi_backward_kernel(
     const float *__restrict__ gout, int B, int C, int H, int W, const float *__restrict__ rois,
@@ -855,8 +851,6 @@ __global__ __launch_bounds__(256) void rroi_backward_kernel(
 constexpr int kGTile = 16;                          // map tile: 16 x 16 pixels = one pixel per thread
 constexpr int kGChanDefault = 16;                   // channels per gather block (sums in registers); OBB_TUNE_RROI_GATHER_CHAN
 constexpr int kGList = 2048;                        // RoIs of one tile held in LDS at a time
-constexpr int kPlanPix = kBwdMaxPix + 2;            // CSR offsets per RoI (16 bit)
-constexpr int kLptMax = 4096;                       // map tiles (all images) whose order is worked out: tile counts | ticket | order
 
 template <bool UNUSED = false>
 __device__ __forceinline__ bool plan_holds(int fsz, int nb, int nsamp) {
@@ -1499,9 +1493,7 @@ extern "C" int obb_roi_align_backward_f32(const float *grad_out_dev, int B, int 
 
 namespace obb {
 
-struct GatherLayout { size_t plan, rstart, rentry, lpt, total; };
-
-static GatherLayout gather_layout(int64_t K) {
+GatherLayout gather_layout(int64_t K) {
   GatherLayout L;
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
@@ -1512,6 +1504,16 @@ static GatherLayout gather_layout(int64_t K) {
   L.lpt = take((size_t)(2 * kLptMax + 16) * sizeof(int));
   L.total = off;
   return L;
+}
+
+// the plan pass of the gather formulations (this file's NCHW gather, obb_rroi_nhwc.hip's channels-last one)
+int rroi_plan_launch(int B, int H, int W, const float *rois_dev, int64_t K, int ph, int pw, float spatial_scale, int sample_num,
+                     float min_size, int roi_kind, RoiPlan *plan, unsigned short *rstart, int2 *rentry, int *lpt, int tiles_x,
+                     int tiles, void *stream) {
+  hipLaunchKernelGGL(rroi_plan_kernel, dim3((unsigned)K), dim3(256), 0, (hipStream_t)stream, B, H, W, rois_dev, ph, pw, spatial_scale,
+                     sample_num, min_size, roi_kind, plan, rstart, rentry, lpt, tiles_x, tiles);
+  OBB_LAUNCH_CHECK();
+  return OBB_OK;
 }
 
 }  // namespace obb
@@ -1561,9 +1563,9 @@ extern "C" int obb_roi_backward_gather_f32(const float *grad_out_dev, int B, int
     lpt = reinterpret_cast<int *>(ws + L.lpt);
     OBB_HIP_TRY(hipMemsetAsync(lpt, 0, (size_t)(kLptMax + 16) * sizeof(int), st));
   }
-  hipLaunchKernelGGL(rroi_plan_kernel, dim3((unsigned)K), dim3(256), 0, st, B, H, W, rois_dev, ph, pw, spatial_scale,
-                     sample_num, min_size, roi_kind, plan, rstart, rentry, lpt, tiles_x, (int)tiles);
-  OBB_LAUNCH_CHECK();
+  rc = rroi_plan_launch(B, H, W, rois_dev, K, ph, pw, spatial_scale, sample_num, min_size, roi_kind, plan, rstart, rentry, lpt,
+                        tiles_x, (int)tiles, stream);
+  if (rc != OBB_OK) return rc;
   const int *tile_order = lpt ? lpt + kLptMax + 16 : nullptr;
   // (16 channels per block up to ~1500 RoIs -- configs[2]: 0.068 ms against 0.070 with 32 --, 32 above: a block's list of
   //  the RoIs that meet its tile, built by testing all K plans, is then shared by twice the channels: config-4 shape

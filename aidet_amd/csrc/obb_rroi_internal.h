@@ -171,6 +171,21 @@ __device__ __forceinline__ Footprint roi_footprint(const RoiFrame &f, int H, int
   return p;
 }
 
+// ---- the per-RoI plan of the gather backward (rroi_plan_kernel, obb_rroi.hip) ------------------------------------------
+constexpr int kMaxTabSamples = 256;   // sample table (8 KiB); 7x7 bins x 2x2 samples = 196
+constexpr int kBwdMaxPix = 2047;                       // footprint pixels of a planned RoI
+constexpr int kBwdMaxEntries = 4 * kMaxTabSamples;     // taps of a RoI (4 per sample)
+constexpr int kPlanPix = kBwdMaxPix + 2;               // CSR offsets per RoI (16 bit)
+constexpr int kLptMax = 4096;                          // map tiles (all images) whose order is worked out: tile counts | ticket | order
+// plan record; state 1: planned (rstart / rentry hold "footprint pixel -> (bin, weight / count) of every tap on it", the
+// taps of a pixel in tap order), 2: left to an atomics kernel, 0: nothing sampled
+struct alignas(16) RoiPlan { int b, x0, y0, w, h, state, nb, pad; };
+struct GatherLayout { size_t plan, rstart, rentry, lpt, total; };
+GatherLayout gather_layout(int64_t K);
+int rroi_plan_launch(int B, int H, int W, const float *rois_dev, int64_t K, int ph, int pw, float spatial_scale, int sample_num,
+                     float min_size, int roi_kind, RoiPlan *plan, unsigned short *rstart, int2 *rentry, int *lpt, int tiles_x,
+                     int tiles, void *stream);
+
 // host helpers of obb_rroi.hip used by obb_rroi_nhwc.hip
 constexpr int kOrderMaxK = 65536;    // above: identity order (the caller passes no order)
 int rroi_check(const char *who, int B, int C, int H, int W, int64_t K, int ph, int pw);

@@ -279,6 +279,234 @@ static int roi_forward_nhwc_launch(const char *who, const LevelTable &lv, int nu
   return OBB_OK;
 }
 
+
+// ==== backward on channels-last maps =========================================================================================
+// grad_out (K, C, ph, pw) in the reference's layout -> grad_feat (B, H, W, C).  The gather formulation of obb_rroi.hip with
+// the roles of lane and loop exchanged: there a thread owns a PIXEL and walks its tap lists for 16 channels (lanes of a wave
+// have lists of different lengths, pixels outside every footprint idle); here a LANE owns four CHANNELS, the (pixel, RoI,
+// tap) triple is wave-uniform, and every entry costs the same: one 16-byte load per lane (a contiguous 4 C-byte row of the
+// transposed gradient) and four fused multiply-adds.
+//   plan       rroi_plan_kernel as it is (per RoI: footprint pixel -> (bin, weight / count) of every tap on it, tap order)
+//   transpose  grad_out (K, C, nb) -> gT (K, nb, C) in the workspace: a tap then reads one contiguous row
+//   gather     one block per 8 x 8 map tile: the RoIs whose footprint meets the tile (all K plans tested, RoI order);
+//              a wave takes a row of 8 pixels: lanes = (pixel, RoI of a chunk of 8) fetch the list bounds, the entries of
+//              the 64 (pixel, RoI) pairs are compacted pixel-major into lanes (one entry record per lane, one round trip),
+//              then pixel by pixel the entries' rows are summed into 4 registers per lane; ONE plain 4 C-byte store per
+//              pixel, written whether a RoI touched it or not (no zero fill)
+//   direct     RoIs the plan cannot hold are added by float atomics (4 C contiguous bytes per tap)
+// Summation order per map element: RoI index, then tap number, fused multiply-adds -- the order of rroi_gather_kernel:
+// bit-equal to the NCHW gather on the permuted map, reproducible run to run (no atomics for planned RoIs).
+constexpr int kNT = 8;                                   // map tile of the gather: 8 x 8 pixels
+constexpr int kNList = 2048;                             // RoIs of one tile held in LDS at a time
+
+__global__ __launch_bounds__(256) void nhwc_transpose_kernel(const float *__restrict__ g, int C, int nb, float *__restrict__ gT) {
+  // block = (RoI, 64 channels): [64][nb] contiguous in -> [nb][64 of C] out, through LDS (pitch nb | 1: conflict-free columns)
+  __shared__ float t[64 * 65];
+  const int k = blockIdx.y, c0 = blockIdx.x * 64, cc = min(64, C - c0);
+  const float *src = g + ((int64_t)k * C + c0) * nb;
+  float *dst = gT + (int64_t)k * nb * C + c0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int b0 = 0; b0 < nb; b0 += 64) {                  // (tiles of 64 bins: 7 x 7 = one tile)
+    const int bn = min(64, nb - b0);
+    for (int i = threadIdx.x; i < cc * bn; i += 256) {
+      const int c = i / bn, b = i - c * bn;
+      t[c * 65 + b] = src[(int64_t)c * nb + b0 + b];
+    }
+    __syncthreads();
+    for (int b = wave; b < bn; b += 4)
+      if (lane < cc) dst[(int64_t)(b0 + b) * C + lane] = t[lane * 65 + b];
+    __syncthreads();
+  }
+}
+
+template <int NB>
+__global__ __launch_bounds__(256) void roi_gather_nhwc_kernel(
+    const float *__restrict__ gT, int C, int H, int W, int K, int nb_rt, const RoiPlan *__restrict__ plan,
+    const unsigned short *__restrict__ rstart, const int2 *__restrict__ rentry, float *__restrict__ gfeat) {
+  __shared__ int list[kNList];
+  __shared__ int wcnt[4];
+  __shared__ int2 slots[4][64];                            // per wave: (owner lane, entry number) of the compacted entries
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nb = NB ? NB : nb_rt;
+  const int tiles_x = (W + kNT - 1) / kNT;
+  const int b = (int)blockIdx.y;
+  const int tl = (int)blockIdx.x;
+  const int tx0 = (tl % tiles_x) * kNT, ty0 = (tl / tiles_x) * kNT;
+  const int nq = C >> 2;                                   // 16-byte channel groups of a pixel
+  for (int q0 = 0; q0 < nq; q0 += 64) {                    // (C > 256: slabs of 256 channels, the lists walked again)
+    const bool act = q0 + lane < nq;
+    const int cq = 4 * (q0 + (act ? lane : 0));
+    for (int base = 0; base < K; base += kNList) {
+      // ---- the RoIs whose footprint meets this tile, in RoI order (rroi_gather_kernel's list)
+      int n = 0;
+      const int lim = min(K, base + kNList);
+      for (int r0 = base; r0 < lim; r0 += 256) {
+        const int r = r0 + tid;
+        const RoiPlan p = plan[min(r, lim - 1)];
+        const bool hit = r < lim && p.state == 1 && p.b == b && p.x0 < tx0 + kNT && p.x0 + p.w > tx0 && p.y0 < ty0 + kNT && p.y0 + p.h > ty0;
+        const uint64_t mk = __ballot(hit);
+        if (lane == 0) wcnt[wave] = __popcll(mk);
+        __syncthreads();
+        int off = 0, tot = 0;
+#pragma unroll
+        for (int w2 = 0; w2 < 4; ++w2) { const int v = wcnt[w2]; off += (w2 < wave) ? v : 0; tot += v; }
+        if (hit) list[n + off + __popcll(mk & ((1ull << lane) - 1ull))] = r;
+        n += tot;
+        __syncthreads();
+      }
+      // ---- a wave takes rows wave, wave + 4 of the tile: 8 pixels at a time
+      for (int row = wave; row < kNT; row += 4) {
+        const int y = ty0 + row;
+        if (y >= H) break;                                  // (wave-uniform)
+        float4 acc[kNT];
+        if (base == 0) {
+#pragma unroll
+          for (int pi = 0; pi < kNT; ++pi) acc[pi] = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {                                            // (more than kNList RoIs: the sums of the batches before)
+#pragma unroll
+          for (int pi = 0; pi < kNT; ++pi) {
+            const int x = tx0 + pi;
+            acc[pi] = (x < W && act) ? *reinterpret_cast<const float4 *>(gfeat + (((int64_t)b * H + y) * W + x) * C + cq)
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+        }
+        const int pi_l = lane >> 3, ri_l = lane & 7;        // this lane's (pixel, RoI of the chunk): pixel-major
+        for (int c0 = 0; c0 < n; c0 += 8) {
+          // (a) bounds of the 64 (pixel, RoI) lists
+          const int x = tx0 + pi_l;
+          int r = -1, e0 = 0, m = 0;
+          if (c0 + ri_l < n && x < W) {
+            r = list[c0 + ri_l];
+            const RoiPlan p = plan[r];
+            const int px = x - p.x0, py = y - p.y0;
+            if (px >= 0 && px < p.w && py >= 0 && py < p.h) {
+              const unsigned short *rs = rstart + (int64_t)r * kPlanPix + (py * p.w + px);
+              e0 = rs[0];
+              m = (int)rs[1] - e0;
+            }
+          }
+          // (b) exclusive prefix of the counts over the lanes (pixel-major = summation order)
+          int inc = m;
+#pragma unroll
+          for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o); if (lane >= o) inc += v; }
+          const int pre = inc - m;
+          const int total = __shfl(inc, 63);
+          if (total == 0) continue;                          // (wave-uniform)
+          // first entry number of every pixel's run (lane 8 pi holds the prefix in front of pixel pi)
+          int pstart[kNT + 1];
+#pragma unroll
+          for (int pi = 0; pi < kNT; ++pi) pstart[pi] = __shfl(pre, 8 * pi);
+          pstart[kNT] = total;
+          for (int rb = 0; rb < total; rb += 64) {            // rounds of 64 entries
+            // (c) owners publish their entries of this round; lane j takes entry rb + j and loads its record
+            __builtin_amdgcn_wave_barrier();
+            {
+              const int lo = max(pre, rb), hi = min(pre + m, rb + 64);
+              for (int i = lo; i < hi; ++i) slots[wave][i - rb] = make_int2(lane, i - pre);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int cnt = min(64, total - rb);
+            int2 mine = make_int2(0, 0);
+            if (lane < cnt) mine = slots[wave][lane];
+            const int r_o = __shfl(r, mine.x), e_o = __shfl(e0, mine.x) + mine.y;
+            int2 en = make_int2(0, 0);
+            if (lane < cnt) en = rentry[(int64_t)r_o * kBwdMaxEntries + e_o];
+            // row of the transposed gradient this entry reads: (RoI, bin)
+            const int rowi = lane < cnt ? r_o * nb + en.x : 0;
+            // (d) pixel by pixel: the entries of the pixel that fall into this round, four rows in flight
+#pragma unroll
+            for (int pi = 0; pi < kNT; ++pi) {
+              const int j0 = max(pstart[pi], rb) - rb, j1 = min(pstart[pi + 1], rb + 64) - rb;
+              int j = j0;
+              for (; j + 4 <= j1; j += 4) {
+                float4 v[4];
+                float w[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                  const int row_u = __builtin_amdgcn_readlane(rowi, j + u);
+                  w[u] = __int_as_float(__builtin_amdgcn_readlane(en.y, j + u));
+                  v[u] = *reinterpret_cast<const float4 *>(gT + (int64_t)row_u * C + cq);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                  acc[pi].x = fmaf(v[u].x, w[u], acc[pi].x); acc[pi].y = fmaf(v[u].y, w[u], acc[pi].y);
+                  acc[pi].z = fmaf(v[u].z, w[u], acc[pi].z); acc[pi].w = fmaf(v[u].w, w[u], acc[pi].w);
+                }
+              }
+              for (; j < j1; ++j) {
+                const int row_u = __builtin_amdgcn_readlane(rowi, j);
+                const float w = __int_as_float(__builtin_amdgcn_readlane(en.y, j));
+                const float4 v = *reinterpret_cast<const float4 *>(gT + (int64_t)row_u * C + cq);
+                acc[pi].x = fmaf(v.x, w, acc[pi].x); acc[pi].y = fmaf(v.y, w, acc[pi].y);
+                acc[pi].z = fmaf(v.z, w, acc[pi].z); acc[pi].w = fmaf(v.w, w, acc[pi].w);
+              }
+            }
+          }
+        }
+        if (act) {
+#pragma unroll
+          for (int pi = 0; pi < kNT; ++pi) {
+            const int x = tx0 + pi;
+            if (x < W) *reinterpret_cast<float4 *>(gfeat + (((int64_t)b * H + y) * W + x) * C + cq) = acc[pi];
+          }
+        }
+      }
+      __syncthreads();      // (the next batch of plans rewrites the list)
+    }
+  }
+}
+
+// RoIs the plan does not hold (state 2: footprint > 2047 pixels, > 256 samples, > 64 bins): every tap adds g * w / count to
+// its pixel's 4 C contiguous bytes with float atomics (rroi_backward_direct's expressions).  One block per RoI; blocks of
+// planned RoIs leave at the first word.
+__global__ __launch_bounds__(256) void roi_backward_nhwc_direct_kernel(
+    const float *__restrict__ gT, int B, int C, int H, int W, const float *__restrict__ rois, int ph, int pw, float scale,
+    int sample_num, float min_size, int roi_kind, const RoiPlan *__restrict__ plan, float *__restrict__ gfeat) {
+  const int64_t k = blockIdx.x;
+  if (plan[k].state != 2) return;
+  RoiFrame f;
+  make_frame(rois + k * roi_stride(roi_kind), roi_kind, scale, ph, pw, sample_num, min_size, f);
+  if (f.b < 0 || f.b >= B || (long long)f.gh * f.gw <= 0) return;
+  const int nb = ph * pw, nq = C >> 2;
+  float *img = gfeat + (int64_t)f.b * H * W * C;
+  // item = (bin, channel group); the samples of the bin in order
+  for (int64_t it = threadIdx.x; it < (int64_t)nb * nq; it += 256) {
+    const int bin = (int)(it / nq), q = (int)(it - (int64_t)bin * nq);
+    const int bi = bin / pw, bj = bin - bi * pw;
+    const float4 g = *reinterpret_cast<const float4 *>(gT + ((int64_t)k * nb + bin) * C + 4 * q);
+    for (int iy = 0; iy < f.gh; ++iy) {
+      for (int ix = 0; ix < f.gw; ++ix) {
+        float x, y;
+        sample_xy(f, bi, bj, iy, ix, x, y);
+        int o[4];
+        float w[4];
+        bilinear_taps(H, W, y, x, o, w);
+        if (w[0] == 0.0f && w[1] == 0.0f && w[2] == 0.0f && w[3] == 0.0f) continue;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          float *p = img + (int64_t)o[t] * C + 4 * q;
+          float d;
+          d = g.x * w[t]; d = d / f.cnt; atomicAdd(p + 0, d);
+          d = g.y * w[t]; d = d / f.cnt; atomicAdd(p + 1, d);
+          d = g.z * w[t]; d = d / f.cnt; atomicAdd(p + 2, d);
+          d = g.w * w[t]; d = d / f.cnt; atomicAdd(p + 3, d);
+        }
+      }
+    }
+  }
+}
+
+struct NhwcBwdLayout { GatherLayout g; size_t gT, total; };
+static NhwcBwdLayout nhwc_bwd_layout(int64_t K, int C, int nb) {
+  NhwcBwdLayout L;
+  L.g = gather_layout(K);
+  L.gT = L.g.total;
+  L.total = align_up(L.gT + (size_t)(K > 0 ? K : 1) * (size_t)(nb > 0 ? nb : 1) * (size_t)(C > 0 ? C : 1) * sizeof(float), 256);
+  return L;
+}
+
 }  // namespace obb
 
 #ifdef OBB_NHWC_STAMPS
@@ -323,4 +551,61 @@ extern "C" int obb_rroi_align_forward_nhwc_f32(const float *feat_dev, int B, int
   lv.feat[0] = feat_dev; lv.H[0] = H; lv.W[0] = W; lv.scale[0] = spatial_scale;
   return roi_forward_nhwc_launch("obb_rroi_align_forward_nhwc_f32", lv, 1, nullptr, B, C, rois_dev, K, ph, pw, sample_num,
                                  min_size, 0, out_dev, stream, nullptr);
+}
+
+extern "C" size_t obb_roi_backward_nhwc_workspace_bytes(int64_t K, int C, int ph, int pw) {
+  if (K < 0 || C < 0 || ph <= 0 || pw <= 0) return 0;
+  return obb::nhwc_bwd_layout(K, C, ph * pw).total;
+}
+
+extern "C" int obb_roi_backward_gather_nhwc_f32(const float *grad_out_dev, int B, int C, int H, int W,
+                                                const float *rois_dev, int64_t K, int roi_kind, int ph, int pw,
+                                                float spatial_scale, int sample_num, float min_size,
+                                                float *grad_feat_dev, void *workspace_dev, size_t workspace_bytes,
+                                                void *stream) {
+  using namespace obb;
+  const char *who = "obb_roi_backward_gather_nhwc_f32";
+  if (roi_kind < 0 || roi_kind > 2) return set_err(OBB_EINVAL, "%s: roi_kind %d (0 rotated, 1 RoIAlign V1, 2 V2-aligned)", who, roi_kind);
+  int rc = rroi_check(who, B, C, H, W, K, ph, pw);
+  if (rc != OBB_OK) return rc;
+  if (C == 0 || H == 0 || W == 0 || B == 0) return OBB_OK;
+  if (!grad_feat_dev) return set_err(OBB_EINVAL, "%s: null pointer", who);
+  if (C % 4 != 0) return set_err(OBB_EINVAL, "%s: C = %d is not a multiple of 4 (16-byte channel groups)", who, C);
+  if ((reinterpret_cast<uintptr_t>(grad_feat_dev) & 15u) != 0) return set_err(OBB_EINVAL, "%s: the gradient map must be 16-byte aligned", who);
+  hipStream_t st = (hipStream_t)stream;
+  const size_t map_elems = (size_t)B * C * H * W;
+  if (K == 0) {   // the gradient map is OVERWRITTEN by this entry point: nothing contributes
+    OBB_HIP_TRY(hipMemsetAsync(grad_feat_dev, 0, map_elems * sizeof(float), st));
+    return OBB_OK;
+  }
+  if (!grad_out_dev || !rois_dev || !workspace_dev) return set_err(OBB_EINVAL, "%s: null pointer", who);
+  const int nb = ph * pw;
+  const NhwcBwdLayout L = nhwc_bwd_layout(K, C, nb);
+  if (workspace_bytes < L.total)
+    return set_err(OBB_EWORKSPACE, "%s: workspace %zu bytes < obb_roi_backward_nhwc_workspace_bytes(%lld, %d, %d, %d) = %zu", who,
+                   workspace_bytes, (long long)K, C, ph, pw, L.total);
+  if ((reinterpret_cast<uintptr_t>(workspace_dev) & 15u) != 0) return set_err(OBB_EINVAL, "%s: workspace must be 16-byte aligned", who);
+  if (K > 65535)
+    return set_err(OBB_EINVAL, "%s: K = %lld RoIs (the channels-last gather takes <= 65535)", who, (long long)K);
+  const int tiles_x = (W + kNT - 1) / kNT, tiles_y = (H + kNT - 1) / kNT;
+  if ((long long)tiles_x * tiles_y > 2147483647LL || B > 65535) return set_err(OBB_EINVAL, "%s: too many map tiles / images", who);
+  char *ws = static_cast<char *>(workspace_dev);
+  RoiPlan *plan = reinterpret_cast<RoiPlan *>(ws + L.g.plan);
+  unsigned short *rstart = reinterpret_cast<unsigned short *>(ws + L.g.rstart);
+  int2 *rentry = reinterpret_cast<int2 *>(ws + L.g.rentry);
+  float *gT = reinterpret_cast<float *>(ws + L.gT);
+  rc = rroi_plan_launch(B, H, W, rois_dev, K, ph, pw, spatial_scale, sample_num, min_size, roi_kind, plan, rstart, rentry, nullptr, 0, 0, stream);
+  if (rc != OBB_OK) return rc;
+  hipLaunchKernelGGL(nhwc_transpose_kernel, dim3((unsigned)((C + 63) / 64), (unsigned)K), dim3(256), 0, st, grad_out_dev, C, nb, gT);
+  OBB_LAUNCH_CHECK();
+  const dim3 ggrid((unsigned)(tiles_x * tiles_y), (unsigned)B);
+  if (nb == 49)
+    hipLaunchKernelGGL(roi_gather_nhwc_kernel<49>, ggrid, dim3(256), 0, st, gT, C, H, W, (int)K, nb, plan, rstart, rentry, grad_feat_dev);
+  else
+    hipLaunchKernelGGL(roi_gather_nhwc_kernel<0>, ggrid, dim3(256), 0, st, gT, C, H, W, (int)K, nb, plan, rstart, rentry, grad_feat_dev);
+  OBB_LAUNCH_CHECK();
+  hipLaunchKernelGGL(roi_backward_nhwc_direct_kernel, dim3((unsigned)K), dim3(256), 0, st, gT, B, C, H, W, rois_dev, ph, pw, spatial_scale,
+                     sample_num, min_size, roi_kind, plan, grad_feat_dev);
+  OBB_LAUNCH_CHECK();
+  return OBB_OK;
 }

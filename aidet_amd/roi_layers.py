@@ -85,11 +85,13 @@ BACKWARD = 'auto'
 GATHER_MIN_ROIS = 16
 
 
-def roi_backward(grad_out, rois, feature_size, roi_kind, out_h, out_w, spatial_scale, sample_num, min_size):
+def roi_backward(grad_out, rois, feature_size, roi_kind, out_h, out_w, spatial_scale, sample_num, min_size, layout='nchw'):
     """Gradient of any RoI-Align flavour w.r.t. the feature map: (K, C, ph, pw) -> (B, C, H, W), fp32.
 
     ``roi_kind`` 0: rotated (K, 6) rows, 1: RoIAlign V1, 2: V2-aligned (K, 5) rows.  ``roi_layers.BACKWARD``
-    selects the formulation (see there)."""
+    selects the formulation (see there).  ``layout`` 'nhwc' (the forward pooled a channels-last map): the gradient comes
+    back as a channels-last tensor too, written in place by ``obb_roi_backward_gather_nhwc_f32`` (C % 4 == 0, <= 65535 RoIs;
+    anything else takes the NCHW route and the caller's layout conversion)."""
     B, C, H, W = feature_size
     g = grad_out.detach().to(torch.float32).contiguous()
     K = rois.size(0)
@@ -97,6 +99,13 @@ def roi_backward(grad_out, rois, feature_size, roi_kind, out_h, out_w, spatial_s
     L = _lib.lib()
     with _lib.on_device(dev):
         st = _lib.current_stream_handle(dev)
+        if layout == 'nhwc' and C % 4 == 0 and K <= 65535 and BACKWARD != 'atomics':
+            grad = torch.empty((B, C, H, W), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
+            ws = torch.empty(max(int(L.obb_roi_backward_nhwc_workspace_bytes(K, C, out_h, out_w)), 16), dtype=torch.uint8, device=dev)
+            _lib.check(L.obb_roi_backward_gather_nhwc_f32(g.data_ptr(), B, C, H, W, rois.data_ptr(), K, roi_kind, out_h, out_w,
+                                                          spatial_scale, sample_num, min_size, grad.data_ptr(), ws.data_ptr(),
+                                                          ws.numel(), st))
+            return grad
         if BACKWARD == 'gather' or (BACKWARD == 'auto' and K >= GATHER_MIN_ROIS):
             grad = torch.empty((B, C, H, W), dtype=torch.float32, device=dev)
             ws = torch.empty(max(int(L.obb_roi_backward_workspace_bytes(K)), 16), dtype=torch.uint8, device=dev)
@@ -188,7 +197,7 @@ class RoIAlignFunction(Function):
         grad_input = None
         if ctx.needs_input_grad[0]:
             grad_input = roi_backward(grad_output, r, (B, C, H, W), 2 if aligned else 1, out_h, out_w, scale,
-                                      sample_num, 0.0).to(ctx.in_dtype)
+                                      sample_num, 0.0, ctx.layout).to(ctx.in_dtype)
         return grad_input, None, None, None, None, None
 
 

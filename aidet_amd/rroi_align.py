@@ -52,7 +52,7 @@ class RRoIAlignFunction(Function):
         if ctx.needs_input_grad[0]:
             from .roi_layers import roi_backward
             grad_input = roi_backward(grad_output, r, (B, C, H, W), 0, out_h, out_w, ctx.spatial_scale,
-                                      ctx.sample_num, ctx.min_size).to(ctx.in_dtype)
+                                      ctx.sample_num, ctx.min_size, ctx.layout).to(ctx.in_dtype)
         # gradient w.r.t. features only, like roi_align.py:46-73
         return grad_input, None, None, None, None, None
 

@@ -586,6 +586,23 @@ OBB_API int obb_head_gather_decode_f32(const float *rois_dev, const float *cls_s
                                        int max_h, int max_w, float scale_factor, float *dets_dev, void *stream);
 
 /* ---------------------------------------------------------------------------
+ * RoI-Align backward as a gather on CHANNELS-LAST maps: grad_out_dev is (K, C, ph, pw) in the reference's layout,
+ * grad_feat_dev a (B, H, W, C) fp32 array (the memory of a torch.channels_last (B, C, H, W) tensor), OVERWRITTEN like
+ * obb_roi_backward_gather_f32's: every element stored exactly once, no atomics for planned RoIs, summation order (RoI
+ * index, tap number) -- bit-equal to obb_roi_backward_gather_f32 on the permuted map, reproducible run to run.
+ * Workspace: obb_roi_backward_nhwc_workspace_bytes(K, C, ph, pw) (the plan + the transposed gradient, 4 K C ph pw bytes).
+ * C % 4 == 0, K <= 65535, 16-byte aligned pointers.
+ * Replaces: ROIAlignBackwardV1 (roi_align_kernel.cu:188-280) / RoIAlignBackwardFeatureV2 (roi_align_kernel_v2.cu:179-263),
+ *           which scatter with atomicAdd into an NCHW map only.
+ * ------------------------------------------------------------------------- */
+OBB_API size_t obb_roi_backward_nhwc_workspace_bytes(int64_t K, int C, int ph, int pw);
+OBB_API int obb_roi_backward_gather_nhwc_f32(const float *grad_out_dev, int B, int C, int H, int W,
+                                             const float *rois_dev, int64_t K, int roi_kind, int ph, int pw,
+                                             float spatial_scale, int sample_num, float min_size,
+                                             float *grad_feat_dev, void *workspace_dev, size_t workspace_bytes,
+                                             void *stream);
+
+/* ---------------------------------------------------------------------------
  * Test / tuning hooks.  NOT part of the drop-in surface (no reference counterpart): the
  * parity tests use them to force every size through every code path, and the experiment
  * scripts under tools/ to sweep launch geometry.  Process-wide; value < 0 restores the

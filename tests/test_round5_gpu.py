@@ -159,3 +159,94 @@ def test_nhwc_forward_c_abi_rejects_what_it_cannot_take():
     rc = L.obb_rroi_align_forward_nhwc_f32(f.data_ptr() + 4, 1, 8, 8, 6, r.data_ptr(), 1, 7, 7, 1.0, 2, 1.0, o.data_ptr(), None)
     assert rc == _lib.OBB_EINVAL and b'aligned' in L.obb_last_error()
     assert L.obb_rroi_align_forward_nhwc_f32(None, 1, 8, 8, 8, None, 0, 7, 7, 1.0, 2, 1.0, None, None) == _lib.OBB_OK   # K = 0
+
+
+# ---- channels-last RoI-Align backward ------------------------------------------------------------------------------
+@pytest.mark.parametrize('C,H,W,K,out,sn,batch', [(24, 40, 40, 50, 7, 2, 2), (256, 64, 64, 64, 7, 2, 1), (8, 33, 47, 25, (5, 9), 0, 2),
+                                                  (260, 24, 40, 30, 7, 2, 1), (64, 20, 20, 300, 7, 2, 1), (16, 70, 70, 12, 14, 2, 1)])
+def test_nhwc_backward_is_bit_equal_to_the_nchw_gather_and_meets_the_oracle(C, H, W, K, out, sn, batch):
+    """obb_roi_backward_gather_nhwc_f32 writes the gradient of a channels-last map in place: bit-equal to the NCHW gather
+    (same summation order, fused multiply-adds) where every RoI is planned, <= 1e-4 max|g| from the oracle; small RoIs
+    (long tap lists per pixel: several rounds of 64 entries), many RoIs on one tile (several chunks of 8), C = 260
+    (two channel slabs), a RoI outside the batch, a tile overhanging the map (33 x 47), 14 x 14 bins (196 > 64: those
+    RoIs go through the atomics kernel)."""
+    from aidet_amd import RRoIAlign, roi_layers
+    rng = np.random.default_rng(C + K)
+    feat = rng.standard_normal((batch, C, H, W)).astype(np.float32)
+    rois = _rois(K, 4 * W, 9, batch=batch)
+    rois[0, 0] = batch + 3
+    if K >= 300:
+        rois[:, 3:5] = np.minimum(rois[:, 3:5], 14.0)          # tiny RoIs: ~50-90 taps per pixel
+    layer = RRoIAlign(out, 0.25, sample_num=sn)
+    g = rng.standard_normal((K, C) + ((out, out) if isinstance(out, int) else out)).astype(np.float32)
+    fa = t(feat).requires_grad_(True)
+    layer(fa, t(rois)).backward(t(g))
+    fb = t(feat).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    assert roi_layers.is_nhwc(fb)
+    layer(fb, t(rois)).backward(t(g))
+    assert fb.grad.is_contiguous(memory_format=torch.channels_last) and fb.grad.shape == fa.grad.shape
+    ref = oracle.rroi_align_backward(g, rois, feat.shape, 0.25, sn)
+    tol = 1e-4 * max(1.0, np.abs(ref).max())
+    assert np.abs(fb.grad.cpu().numpy() - ref).max() <= tol
+    nb = out * out if isinstance(out, int) else out[0] * out[1]
+    if nb <= 64 and sn > 0:          # every RoI planned on both sides: the same sums in the same order
+        assert torch.equal(fb.grad.contiguous(), fa.grad)
+    again = t(feat).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    layer(again, t(rois)).backward(t(g))
+    if nb <= 64 and sn > 0:
+        assert torch.equal(again.grad, fb.grad)                  # reproducible run to run
+
+
+@pytest.mark.parametrize('aligned', [False, True])
+def test_nhwc_backward_horizontal_kinds(aligned):
+    from aidet_amd import RoIAlign
+    rng = np.random.default_rng(17)
+    feat = rng.standard_normal((2, 32, 48, 56)).astype(np.float32)
+    rois = _hrois(60, 200, 3, batch=2)
+    layer = RoIAlign(7, 0.25, sample_num=2, aligned=aligned)
+    g = rng.standard_normal((60, 32, 7, 7)).astype(np.float32)
+    fa = t(feat).requires_grad_(True)
+    layer(fa, t(rois)).backward(t(g))
+    fb = t(feat).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    layer(fb, t(rois)).backward(t(g))
+    assert torch.equal(fb.grad.contiguous(), fa.grad)
+    # the op is linear in the map: <grad_feat, feat> == <g, forward(feat)> (the forward is pinned against the oracle's
+    # restatement of roi_align_kernel.cu / roi_align_kernel_v2.cu above)
+    out = layer(fb.detach(), t(rois)).double()
+    lhs = float((fb.grad.double() * fb.detach().double()).sum()); rhs = float((t(g).double() * out).sum())
+    assert abs(lhs - rhs) <= 1e-5 * max(1.0, abs(rhs))
+
+
+def test_nhwc_backward_cfg3_and_large_rois():
+    """configs[2] shape; and RoIs larger than the plan holds (> 2047 footprint pixels): the atomics tail."""
+    from aidet_amd import RRoIAlign
+    rng = np.random.default_rng(5)
+    feat = rng.standard_normal((1, 256, 256, 256)).astype(np.float32)
+    rois = _rois(512, 1024, 5)
+    rois[:6, 3:5] = 400.0              # 100 x 100 map pixels each
+    layer = RRoIAlign(7, 0.25, sample_num=2)
+    g = rng.standard_normal((512, 256, 7, 7)).astype(np.float32)
+    fb = t(feat).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    layer(fb, t(rois)).backward(t(g))
+    ref = oracle.rroi_align_backward(g, rois, feat.shape, 0.25, 2)
+    assert np.abs(fb.grad.cpu().numpy() - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
+    fa = t(feat).requires_grad_(True)
+    layer(fa, t(rois)).backward(t(g))
+    assert np.abs(fb.grad.cpu().numpy() - fa.grad.cpu().numpy()).max() <= 1e-4 * max(1.0, np.abs(ref).max())
+
+
+def test_nhwc_backward_c_abi_edges():
+    from aidet_amd import _lib
+    L = _lib.lib()
+    assert L.obb_roi_backward_nhwc_workspace_bytes(512, 256, 7, 7) >= 512 * 256 * 49 * 4
+    gm = torch.full((1, 8, 8, 8), 7.0, device=dev())
+    rc = L.obb_roi_backward_gather_nhwc_f32(None, 1, 8, 8, 8, None, 0, 0, 7, 7, 1.0, 2, 1.0, gm.data_ptr(), None, 0, None)
+    torch.cuda.synchronize()
+    assert rc == _lib.OBB_OK and float(gm.abs().max()) == 0.0           # K = 0: the map is overwritten with zeros
+    g = torch.zeros((1, 6, 7, 7), device=dev()); r = torch.zeros((1, 6), device=dev())
+    ws = torch.zeros(1 << 20, dtype=torch.uint8, device=dev())
+    rc = L.obb_roi_backward_gather_nhwc_f32(g.data_ptr(), 1, 6, 8, 8, r.data_ptr(), 1, 0, 7, 7, 1.0, 2, 1.0, gm.data_ptr(), ws.data_ptr(), ws.numel(), None)
+    assert rc == _lib.OBB_EINVAL and b'multiple of 4' in L.obb_last_error()
+    g = torch.zeros((1, 8, 7, 7), device=dev())
+    rc = L.obb_roi_backward_gather_nhwc_f32(g.data_ptr(), 1, 8, 8, 8, r.data_ptr(), 1, 0, 7, 7, 1.0, 2, 1.0, gm.data_ptr(), ws.data_ptr(), 16, None)
+    assert rc == _lib.OBB_EWORKSPACE
