@@ -21,7 +21,7 @@ There is no CPU fallback: every op raises if the HIP library or a GPU is missing
 from .merge_augs import merge_aug_bboxes, merge_aug_proposals, merge_aug_scores
 from .nms_wrapper import nms, poly_nms, rnms, soft_nms, thetaobb_nms
 from .post_processing import (get_det_rbboxes, multiclass_nms, multiclass_nms_with_index, multiclass_rnms,
-                              thetaobb_nms_by_bbox_nms)
+                              multiclass_thetaobb_nms, thetaobb_nms_by_bbox_nms)
 from .rbbox_geometry import bbox_overlaps, rbbox_overlaps, thetaobb2pointobb
 from .roi_layers import RoIAlign, RotatedSingleRoIExtractor, SingleRoIExtractor, roi_align
 from .rroi_align import RRoIAlign, rroi_align
@@ -29,7 +29,7 @@ from .rroi_align import RRoIAlign, rroi_align
 __all__ = [
     'rnms', 'poly_nms', 'thetaobb_nms', 'nms', 'soft_nms', 'rbbox_overlaps', 'bbox_overlaps', 'thetaobb2pointobb',
     'RRoIAlign', 'rroi_align', 'RoIAlign', 'roi_align', 'SingleRoIExtractor', 'RotatedSingleRoIExtractor',
-    'multiclass_nms', 'multiclass_rnms', 'multiclass_nms_with_index', 'thetaobb_nms_by_bbox_nms', 'get_det_rbboxes',
+    'multiclass_nms', 'multiclass_rnms', 'multiclass_thetaobb_nms', 'multiclass_nms_with_index', 'thetaobb_nms_by_bbox_nms', 'get_det_rbboxes',
     'merge_aug_proposals', 'merge_aug_bboxes', 'merge_aug_scores'
 ]
 __version__ = '1.2.0'   # = libobbops 1.2 (obb_version() == 102: round 4 -- tiled phases, float64 entry points, OBB_ERETRY)

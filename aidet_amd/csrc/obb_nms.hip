@@ -2943,6 +2943,117 @@ __global__ __launch_bounds__(1024) void nms_small_kernel(const NmsSource src, in
   }
 }
 
+// ---- horizontal boxes, `>=` rule, threshold <= 0 (or NaN) ------------------------------------------------------------
+// nms_cpu.cpp:35-58 as it stands: for i in score order, not suppressed: every later j with ovr(i, j) >= thr is suppressed
+// -- with thr <= 0 that is EVERY later box of the group whose ovr is not negative or NaN (inverted boxes), overlapping or
+// not, so the broad phase of the chain above (which pairs only boxes whose intervals meet) does not apply.  One
+// workgroup; a thread owns the boxes t, t + 1024, ...; a round = the best live box i (64-bit key of the score, then the
+// index: the order of every other route) is kept, then every owner tests its live boxes against i and names its best
+// survivor for the next round.  Rounds = kept boxes (one per group for well-formed boxes).  A NaN threshold suppresses
+// nothing (`ovr >= NaN` is false): every box is kept.
+template <bool F64>
+__global__ __launch_bounds__(1024) void nms_hbb_allpairs_kernel(const NmsSource src, int64_t n, float thr, uint32_t *__restrict__ state,
+                                                                int64_t *__restrict__ keep, NmsHostInfo *__restrict__ hinfo) {
+  __shared__ unsigned long long wkey[16];
+  __shared__ long long widx[16];
+  __shared__ long long s_win;
+  __shared__ int wsum[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool all = thr != thr;
+  for (int64_t j = tid; j < n; j += 1024) state[j] = all ? 2u : 0u;     // 0 live, 1 suppressed, 2 kept (owner-private words)
+  auto key_of = [&](int64_t j) -> unsigned long long {
+    if constexpr (F64) return score_key64(src.dets64[j * src.pitch + 4]);
+    else return (unsigned long long)score_key(src.dets[j * src.pitch + 4]) << 32;
+  };
+  auto group_of = [&](int64_t j) -> int32_t {
+    if constexpr (F64) return src.group ? src.group[j] : 0;
+    else return src_group<5>(src, j, src.dets + j * src.pitch);
+  };
+  long long rounds = 0;
+  long long win = -1;
+  while (!all) {
+    // the winner's row (block-uniform)
+    double wd[4] = {0, 0, 0, 0};
+    float wf[4] = {0, 0, 0, 0}, warea = 0.0f;
+    int32_t wg = 0;
+    if (win >= 0) {
+      if constexpr (F64) { for (int k = 0; k < 4; ++k) wd[k] = src.dets64[win * src.pitch + k]; }
+      else { for (int k = 0; k < 4; ++k) wf[k] = src.dets[win * src.pitch + k]; warea = hbb_area(wf[0], wf[1], wf[2], wf[3]); }
+      wg = group_of(win);
+    }
+    unsigned long long bk = ~0ull;
+    long long bi = -1;
+    for (int64_t j = tid; j < n; j += 1024) {
+      if (state[j] != 0u) continue;
+      if (win >= 0 && group_of(j) == wg) {
+        bool hit;
+        if constexpr (F64) {
+          const double *r = src.dets64 + j * src.pitch;
+          const double aarea = ((wd[2] - wd[0]) + 1.0) * ((wd[3] - wd[1]) + 1.0), barea = ((r[2] - r[0]) + 1.0) * ((r[3] - r[1]) + 1.0);
+          const double xx1 = dmax_sel(wd[0], r[0]), yy1 = dmax_sel(wd[1], r[1]);
+          const double xx2 = dmin_sel(wd[2], r[2]), yy2 = dmin_sel(wd[3], r[3]);
+          const double w = dmax_sel(0.0, (xx2 - xx1) + 1.0), h = dmax_sel(0.0, (yy2 - yy1) + 1.0);
+          const double inter = w * h;
+          hit = inter / ((aarea + barea) - inter) >= (double)thr;
+        } else {
+          const float *r = src.dets + j * src.pitch;
+          const float b[4] = {r[0], r[1], r[2], r[3]};
+          hit = hbb_overlap(wf, warea, b, hbb_area(b[0], b[1], b[2], b[3])) >= thr;
+        }
+        if (hit) { state[j] = 1u; continue; }
+      }
+      const unsigned long long kj = key_of(j);
+      if (bi < 0 || kj < bk) { bk = kj; bi = j; }          // (ascending j per thread: the first of equal keys stays)
+    }
+    // block-wide minimum of (key, index)
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned long long ok = __shfl_xor(bk, o);
+      const long long oi = __shfl_xor(bi, o);
+      if (oi >= 0 && (bi < 0 || ok < bk || (ok == bk && oi < bi))) { bk = ok; bi = oi; }
+    }
+    if (lane == 0) { wkey[wave] = bk; widx[wave] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+      unsigned long long k0 = wkey[0];
+      long long i0 = widx[0];
+      for (int w2 = 1; w2 < 16; ++w2) {
+        const unsigned long long ok = wkey[w2];
+        const long long oi = widx[w2];
+        if (oi >= 0 && (i0 < 0 || ok < k0 || (ok == k0 && oi < i0))) { k0 = ok; i0 = oi; }
+      }
+      s_win = i0;
+    }
+    __syncthreads();
+    win = s_win;
+    __syncthreads();
+    if (win < 0) break;
+    if ((win & 1023) == tid) state[win] = 2u;             // (its owner)
+    ++rounds;
+  }
+  __syncthreads();
+  // ascending keep indices
+  long long total = 0;
+  for (int64_t base = 0; base < n; base += 1024) {
+    const int64_t j = base + tid;
+    const bool f = j < n && state[j] == 2u;
+    const uint64_t mk = __ballot(f);
+    if (lane == 0) wsum[wave] = __popcll(mk);
+    __syncthreads();
+    int off = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { const int v = wsum[k]; off += (k < wave) ? v : 0; tot += v; }
+    if (f) keep[total + off + __popcll(mk & ((1ull << lane) - 1ull))] = j;
+    total += tot;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    hinfo->edges = 0ull; hinfo->kept = total; hinfo->rounds = rounds;
+    hinfo->cand_total = 0ull; hinfo->cand_worst = 0ull;
+    hinfo->heavy_units = 0u; hinfo->light_units = 0u;
+    hinfo->route = 0u; hinfo->unit_worst = 0u;
+  }
+}
+
 // ---- optional per-phase timing (HIP events on the caller's stream) ----------------
 constexpr int kPhases = OBB_NMS_PHASES;
 struct NmsProfile {
@@ -3025,7 +3136,10 @@ static int nms_layout(int64_t n, int64_t edge_capacity, NmsLayout &L) {
   L.ccnts = take((size_t)3 * kShards * kCandStride * sizeof(unsigned long long));  // candidates | edges | candidates clipped in line
   L.ucnts = take((size_t)2 * kShards * kUnitStride * sizeof(unsigned int));        // heavy | light scan units
   L.super = take(((nt + kSuper - 1) / kSuper) * 8 * 4);   // supertile boxes / bucket ranges (maxima: zero = empty)
-  L.blockcnt = take(((nn + 1023) / 1024 + 1) * 4);   // ticket + one flagged count per 1024 boxes
+  // ticket + one flagged count per 1024 boxes (nms_compact_kernel) -- or per SHARD (the compaction fused into
+  // nms_resolve_kernel publishes blockcnt[1 + shard], shard < kShards, whatever n is): sized for both users
+  // (with 64 words, shard 63 wrote the first word of `scanflags` for 10 240 < n <= 64 512)
+  L.blockcnt = take((((nn + 1023) / 1024 > (size_t)kShards ? (nn + 1023) / 1024 : (size_t)kShards) + 1) * 4);
   L.scanflags = take((kCells / kScanBlockCells + 1) * 4);   // multi-block cell scan: ticket + one flagged total per block
   L.ticket = take(4);                                // nms_cullbox_kernel: tile tickets
   L.tbox = take(nt * sizeof(uint2));                 // (zero = "not published yet" for nms_cullbox_kernel)
@@ -3179,13 +3293,9 @@ static int nms_validate(const char *who, const float *dets_dev, int64_t n, int k
   if (n < 0) return set_err(OBB_EINVAL, "%s: negative n", who);
   if (kind != OBB_KIND_RBOX && kind != OBB_KIND_POLY && kind != OBB_KIND_HBB) return set_err(OBB_EINVAL, "%s: bad kind %d", who, kind);
   if (flags_in & ~OBB_NMS_STRICT) return set_err(OBB_EINVAL, "%s: unknown flags 0x%x", who, flags_in);
-  // Horizontal boxes follow nms_cpu.cpp to the letter, and there a threshold <= 0 makes EVERY
-  // later box of a group a victim of the first one (ovr >= thr holds for disjoint boxes too).
-  // That is a different algorithm (arg-max per group), not an NMS: refused rather than served
-  // with different results.  (Rotated kinds: the spec's AABB prefilter is part of the
-  // operator, disjoint boxes never interact, any threshold is well defined.)
-  if (kind == OBB_KIND_HBB && !(flags_in & OBB_NMS_STRICT) && !thr_dev && !(iou_thr > 0.0f))
-    return set_err(OBB_EINVAL, "%s: iou_thr = %g with horizontal boxes and the `>=` rule would suppress every box but the best of each group (nms_cpu.cpp:56); use a positive threshold or OBB_NMS_STRICT", who, (double)iou_thr);
+  // (Horizontal boxes with a threshold <= 0 under the `>=` rule: nms_cpu.cpp:56 then holds for DISJOINT boxes too -- every
+  // later box of a group falls to the first one unless its ovr is negative or NaN.  Served exactly, by
+  // nms_hbb_allpairs_kernel: nms_enqueue_source.)
   if (n == 0) return OBB_OK;   // nothing is read or written
   if (n > (int64_t)kTile * 65535) return set_err(OBB_EINVAL, "%s: n = %lld exceeds %lld", who, (long long)n, (long long)kTile * 65535);
   if (!dets_dev || !keep_dev || !workspace_dev) return set_err(OBB_EINVAL, "%s: null pointer", who);
@@ -3213,6 +3323,17 @@ int nms_enqueue_source(const char *who, NmsSource src, int64_t n, int kind, floa
   const bool f64 = src.dets64 != nullptr;
   if (f64 && (kind != OBB_KIND_HBB || src.mode != 0)) return set_err(OBB_EINVAL, "%s: float64 rows are horizontal boxes with plain group / threshold arrays", who);
   const int flags = (flags_in & OBB_NMS_STRICT ? kFlagStrict : 0) | (kind == OBB_KIND_HBB ? kFlagHbb : 0) | (f64 ? kFlagF64 : 0);
+  if (kind == OBB_KIND_HBB && !(flags_in & OBB_NMS_STRICT) && !has_thr && !(iou_thr > 0.0f)) {
+    // nms_cpu.cpp:56 with a threshold <= 0 (or NaN): every pair of a group counts, not only the overlapping ones
+    if (workspace_bytes < (size_t)n * sizeof(uint32_t)) return set_err(OBB_EWORKSPACE, "%s: workspace %zu bytes < %lld", who, workspace_bytes, (long long)n * 4);
+    q = NmsEnqueued();
+    q.fused = true;
+    q.cap = 1;
+    if (f64) hipLaunchKernelGGL(nms_hbb_allpairs_kernel<true>, dim3(1), dim3(1024), 0, st, src, n, iou_thr, static_cast<uint32_t *>(workspace_dev), keep_dev, result);
+    else hipLaunchKernelGGL(nms_hbb_allpairs_kernel<false>, dim3(1), dim3(1024), 0, st, src, n, iou_thr, static_cast<uint32_t *>(workspace_dev), keep_dev, result);
+    OBB_LAUNCH_CHECK();
+    return OBB_OK;
+  }
 
   // pair capacity = whatever the caller's workspace holds beyond the fixed part,
   // split evenly between the candidate lists and the edge list

@@ -1150,7 +1150,7 @@ static bool soft_launch_fast(const float *dets, int64_t n, float thr, int method
   const int64_t shape = tuning(OBB_TUNE_SOFT_NMS_SHAPE, 0);     // (0 default; 1: 256 threads x more boxes, for measurements)
   if (shape == 1 && n <= 2048) {
     if (n <= 256) OBB_SOFT_FAST(256, 1); else if (n <= 512) OBB_SOFT_FAST(256, 2); else if (n <= 1024) OBB_SOFT_FAST(256, 4); else OBB_SOFT_FAST(256, 8);
-  } else if (shape == 2) {
+  } else if (shape == 2 && n <= kSoftFastMax) {      // (512 x 8 holds kSoftFastMax boxes: larger arrays fall through to `return false`)
     if (n <= 512) OBB_SOFT_FAST(512, 1); else if (n <= 1024) OBB_SOFT_FAST(512, 2); else if (n <= 2048) OBB_SOFT_FAST(512, 4); else OBB_SOFT_FAST(512, 8);
   }
   else if (n <= 256) OBB_SOFT_FAST(256, 1);

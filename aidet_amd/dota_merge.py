@@ -550,6 +550,7 @@ def patch_rows_to_image(dets, labels, patch_index, patch_xy, patch_image, rate=1
 # GPU tests compare the fused path with, and the route of the ``sharded`` layout.
 # ---------------------------------------------------------------------------------------------------------------
 TILED_REPEAT = -(1 << 62)    # K word of a phase whose NMS must be repeated as it is (the grid route gave up)
+TILED_ABORT = -(1 << 62) - 1  # K word a rank publishes INSTEAD of running its phase: it cannot go on, every rank raises together
 phase_repeats = 0            # phases this process repeated for that reason (tests read it)
 FUSED = True                 # module switch (tests force the step-by-step path with it)
 _phase_ws = {}               # (device index, stream) -> uint8 workspace shared by the phases (stream-ordered)
@@ -596,6 +597,7 @@ def tiled_local_phase(dets, labels, patch_index, patch_xy, patch_image, num_clas
     _call(dev, L.obb_tiled_local_f32, d.data_ptr(), lab.data_ptr(), pid.data_ptr(), n, pxy.data_ptr(), pim.data_ptr(),
           pim.numel(), int(num_classes), float(rate), float(iou_thr), int(world), rows.data_ptr(), counts.data_ptr(),
           ws.data_ptr(), nbytes)
+    counts.phase_nbytes = nbytes           # (the workspace size this phase RAN with: obb_tiled_result checks the record against it)
     return rows, counts
 
 
@@ -678,11 +680,22 @@ def _tiled_fused(dets, labels, patch_index, patch_xy, patch_image, num_classes, 
         return None
     capacity = None
     repeats = 0
+    fatal = None
+    width = route_world + 2 + _lib.NMS_RESULT_BYTES // 8
     while True:
-        rows, counts = tiled_local_phase(dets, labels, patch_index, patch_xy, patch_image, num_classes, local_thr,
-                                         route_world, capacity=capacity)
+        # A rank that cannot go on (workspace cap, a phase that keeps asking for a repeat) must not leave the others
+        # waiting in the next exchange of the counts: it publishes TILED_ABORT as its K word instead of running its
+        # phase, every rank sees it in the gathered matrix, and all of them raise together.
+        rows = counts = None
+        if fatal is None:
+            try:
+                rows, counts = tiled_local_phase(dets, labels, patch_index, patch_xy, patch_image, num_classes, local_thr,
+                                                 route_world, capacity=capacity)
+            except _lib.ObbOpsError as e:
+                fatal = e
+        if fatal is not None:
+            counts = torch.full((width,), TILED_ABORT, dtype=torch.int64, device=dev)
         mark('local')
-        width = counts.numel()
         if world > 1:
             mat = torch.empty(world * width, dtype=torch.int64, device=dev)
             coll.all_gather_into_tensor(mat, counts, group=group)
@@ -691,21 +704,27 @@ def _tiled_fused(dets, labels, patch_index, patch_xy, patch_image, num_classes, 
             with _lib.on_device(dev):
                 mat = [counts.tolist()]
         kwords = [row[route_world + 1] for row in mat]
+        if any(k == TILED_ABORT for k in kwords):
+            if fatal is not None:
+                raise fatal
+            raise _lib.ObbOpsError('rank(s) %s aborted the per-patch phase of the tiled pass'
+                                   % [r for r, k in enumerate(kwords) if k == TILED_ABORT])
         if all(k >= 0 for k in kwords):
             break
+        repeats += 1                          # (counted from the gathered matrix: the same number on every rank)
+        if repeats > 4:
+            raise _lib.ObbOpsError('the per-patch phase of the tiled pass was repeated %d times (K words %s)' % (repeats - 1, kwords))
         if kwords[rank] == TILED_REPEAT:
             # this rank's NMS gave up on its grid route (a crowded cell): the library notes it for the thread through
             # the record (OBB_ERETRY) and the phase is repeated as it is
             rec = np.asarray(mat[rank][route_world + 2:], dtype=np.int64)
             info = (ctypes.c_int64 * 4)()
-            nb = int(_lib.lib().obb_tiled_local_workspace_bytes(n, route_world, capacity or 0))
-            rc = _lib.lib().obb_tiled_result(rec.ctypes.data, 0, n, 6, route_world, -1, nb, info)
+            rc = _lib.lib().obb_tiled_result(rec.ctypes.data, 0, n, 6, route_world, -1, int(counts.phase_nbytes), info)
             global phase_repeats
             phase_repeats += 1
-            repeats += 1
-            if rc != _lib.OBB_ERETRY or repeats > 3:      # (the library's note sends the next try down the general route)
-                raise _lib.ObbOpsError('the per-patch phase asks to be repeated again and again (rc %d): %s'
-                                       % (rc, _lib.lib().obb_last_error().decode()))
+            if rc != _lib.OBB_ERETRY:             # (the library's note sends the next try down the general route)
+                fatal = _lib.ObbOpsError('the per-patch phase asks to be repeated but its record says rc %d: %s'
+                                         % (rc, _lib.lib().obb_last_error().decode()))
             continue
         # a rank's per-patch NMS overflowed its pair lists (every rank sees it): that rank repeats its phase with the
         # capacity its kernels asked for, everybody repeats the exchange of the counts
@@ -714,7 +733,7 @@ def _tiled_fused(dets, labels, patch_index, patch_xy, patch_image, num_classes, 
             _note_capacity(0, n, capacity)
             nbytes = int(_lib.lib().obb_tiled_local_workspace_bytes(n, route_world, capacity))
             if nbytes > nms_wrapper.MAX_WORKSPACE_BYTES:
-                raise _capacity_error('the per-patch NMS', n, nbytes, capacity)
+                fatal = _capacity_error('the per-patch NMS', n, nbytes, capacity)
     K = kwords[rank]
     if layout == 'routed' and world > 1:
         if any(row[world] for row in mat):

@@ -337,8 +337,13 @@ def nms(dets, iou_thr, device_id=None, groups=None, thrs=None, strict=False):
     ``(x2-x1+1)*(y2-y1+1)``, intersection widths ``min(x2)-max(x1)+1``,
     ``inter / (a_i + a_j - inter) >= iou_thr`` (nms_cpu.cpp:19,47-56) -- in a dedicated
     narrow phase of the HIP kernels (OBB_KIND_HBB), not with the rotated clip.
-    ``iou_thr <= 0`` raises: under ``>=`` the reference then suppresses every box but the
-    best one (disjoint boxes included), which no NMS kernel should silently imitate.
+    ``iou_thr <= 0`` is served like the reference serves it: ``ovr >= iou_thr`` (nms_cpu.cpp:56) then holds for
+    DISJOINT boxes too, so every later box of the array (of its group) falls to the first one unless its ``ovr`` is NaN
+    (two zero-area boxes) -- a dedicated all-pairs kernel, pinned by tests/golden/hbb_nms_nonpos.npz.  Per-box
+    thresholds (``thrs``, an extension without a reference counterpart) must be positive under ``>=``: host arrays are
+    checked, a HIP tensor is its owner's responsibility (checking it would cost a kernel and a device-to-host
+    synchronisation before the NMS is even queued); with a non-positive entry the result is the broad phase's -- only
+    overlapping pairs count -- not nms_cpu.cpp's.
 
     Example (nms_wrapper.py:24-34):
         >>> dets = np.array([[49.1, 32.4, 51.0, 35.9, 0.9],
@@ -351,9 +356,6 @@ def nms(dets, iou_thr, device_id=None, groups=None, thrs=None, strict=False):
         >>> suppressed, inds = nms(dets, 0.7)
         >>> assert len(inds) == len(suppressed) == 3
     """
-    if not strict and thrs is None and not float(iou_thr) > 0.0:
-        raise ValueError('nms: iou_thr must be positive (got {}); with the reference\'s `>=` rule a '
-                         'non-positive threshold keeps only the best box'.format(iou_thr))
     if not strict and thrs is not None:
         # the same rule box by box: a per-box threshold <= 0 would have to suppress every later box of its group,
         # disjoint ones included (nms_cpu.cpp:56), which the kernels' broad phase never even tests
@@ -504,8 +506,6 @@ def nms_enqueue(dets, iou_thr, op='nms', groups=None, thrs=None, strict=False):
         raise TypeError('nms_enqueue takes a HIP tensor')
     if dets.dim() != 2 or dets.size(1) != cols:
         raise ValueError('{} expects dets of shape (n, {}), got {}'.format(op, cols, tuple(dets.shape)))
-    if op == 'nms' and not strict and thrs is None and not float(iou_thr) > 0.0:
-        raise ValueError('nms: iou_thr must be positive (got {})'.format(iou_thr))
     d = dets.detach().to(dtype=torch.float32).contiguous()
     n, dev = d.size(0), d.device
     t = NmsTicket()

@@ -123,6 +123,14 @@ def multiclass_rnms(multi_rbboxes, multi_scores, score_thr, nms_cfg, max_num=-1,
                        out_dim_reg, 'rnms', offset_trick=False, report=report)
 
 
+def multiclass_thetaobb_nms(thetaobbs, scores, score_thr, polygon_nms_iou_thr, max_per_img=-1):
+    """The call the reference left commented out in ``RBBoxHead.get_det_rbboxes_parallel``
+    (mmdet/models/bbox_heads/rbbox_head.py:294-295), with ITS positional signature:
+    ``multiclass_thetaobb_nms(thetaobbs, scores, cfg.score_thr, cfg.polygon_nms_iou_thr, cfg.max_per_img)`` ->
+    ``(det_thetaobbs (k, 6), det_labels (k,))`` = ``multiclass_rnms`` with ``dict(type='rnms', iou_thr=...)``."""
+    return multiclass_rnms(thetaobbs, scores, score_thr, dict(type='rnms', iou_thr=polygon_nms_iou_thr), max_per_img)
+
+
 def _class_major(masks):
     """masks (C, n) bool -> (class, row) of every set entry, class-major; counts per class."""
     cls, rows = masks.nonzero(as_tuple=True)

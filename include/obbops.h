@@ -151,8 +151,11 @@ OBB_API int obb_nms_grouped_f32(const float *dets_dev, int64_t n, int kind, floa
  *                   two only differ for pairs whose IoU EQUALS the threshold (integer boxes).
  * OBB_KIND_HBB rows are decided with the reference's own arithmetic (nms_cpu.cpp:19,47-56:
  * +1 widths, inter / (a_i + a_j - inter)), not with the polygon clip.  With that kind and
- * the >= rule, iou_thr <= 0 is refused (OBB_EINVAL): in the reference it suppresses every box
- * but the best one of a group, which is not an NMS.                                          */
+ * the >= rule, iou_thr <= 0 (or NaN) is served as nms_cpu.cpp:56 serves it: `ovr >= thr` then
+ * holds for DISJOINT boxes too, every later box of a group falls to the first one unless its ovr
+ * is NaN (two zero-area boxes) -- one all-pairs workgroup instead of the chain (round 5; refused
+ * with OBB_EINVAL until round 4).  Per-box thresholds (thr_dev) must be positive under >=: the
+ * library does not read them on the host.                                                    */
 #define OBB_NMS_STRICT 1
 OBB_API int obb_nms_ex_f32(const float *dets_dev, int64_t n, int kind, float iou_thr,
                            const int32_t *group_dev, const float *thr_dev, int flags,

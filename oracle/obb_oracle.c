@@ -969,6 +969,7 @@ static int line_cross_d(pt_d a, pt_d b, pt_d c, pt_d d, pt_d *p) {
   p->y = (c.y * s2 - d.y * s1) / (s2 - s1);
   return 1;
 }
+static int pt_eq_d(pt_d a, pt_d b) { return sig_d(a.x - b.x) == 0 && sig_d(a.y - b.y) == 0; }
 /* keep the part of polygon p (n vertices) on the left of a->b */
 static void polygon_cut_d(pt_d *p, int *n, pt_d a, pt_d b) {
   pt_d pp[16];
@@ -979,10 +980,12 @@ static void polygon_cut_d(pt_d *p, int *n, pt_d a, pt_d b) {
     if (sig_d(cross3_d(a, b, p[i])) != sig_d(cross3_d(a, b, p[i + 1])))
       line_cross_d(a, b, p[i], p[i + 1], &pp[m++]);
   }
+  /* vertex equality as published: Point::operator== compares through sig() (|dx| <= eps and |dy| <= eps), not
+   * exactly -- crossing points that differ by rounding only are one vertex (an exact `==` stood here) */
   *n = 0;
   for (i = 0; i < m; ++i)
-    if (!i || !(pp[i].x == pp[i - 1].x && pp[i].y == pp[i - 1].y)) p[(*n)++] = pp[i];
-  while (*n > 1 && p[*n - 1].x == p[0].x && p[*n - 1].y == p[0].y) (*n)--;
+    if (!i || !pt_eq_d(pp[i], pp[i - 1])) p[(*n)++] = pp[i];
+  while (*n > 1 && pt_eq_d(p[*n - 1], p[0])) (*n)--;
 }
 static double tri_inter_d(pt_d a, pt_d b, pt_d c, pt_d d) {
   pt_d o = {0.0, 0.0};

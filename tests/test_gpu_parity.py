@@ -172,15 +172,32 @@ def test_rnms_bit_exact(n, canvas, thr, nms_path):
     assert np.array_equal(kept.cpu().numpy(), d[ref])
 
 
-def test_rnms_cfg2_100k_sparse_and_dense():
-    """BASELINE.json configs[1]: 100k synthetic OBBs, thr 0.5, keep bit-exact."""
-    from aidet_amd import rnms
-    for canvas, seed in ((20000, 3), (4096, 4)):
+_CFG2_REF = {}
+
+
+def _cfg2_reference(canvas, seed):
+    """the oracle's keep list of a configs[1] scene (14 s of one host core each): computed once per session"""
+    if (canvas, seed) not in _CFG2_REF:
         d = oracle.synth_boxes(100000, canvas, seed)
+        _CFG2_REF[(canvas, seed)] = (d, oracle.rnms(d, 0.5))
+    return _CFG2_REF[(canvas, seed)]
+
+
+def test_rnms_cfg2_100k_sparse_and_dense(nms_path):
+    """BASELINE.json configs[1]: 100k synthetic OBBs, thr 0.5, keep bit-exact against the oracle -- on the route the
+    library picks AND on every forced one (sorted / listed / grid; VERDICT r4 "weak" 9: above 20 000 boxes the forced
+    routes had only met each other)."""
+    from aidet_amd import _lib, rnms
+    for canvas, seed in ((20000, 3), (4096, 4)):
+        d, ref = _cfg2_reference(canvas, seed)
         _, inds = rnms(t(d), 0.5)
         got = inds.cpu().numpy()
-        ref = oracle.rnms(d, 0.5)
-        assert np.array_equal(got, ref), 'canvas %d' % canvas
+        route = int(_lib.lib().obb_nms_last_route())
+        assert np.array_equal(got, ref), 'canvas %d, route %s (%d)' % (canvas, nms_path, route)
+        if nms_path in ('sorted', 'listed'):
+            assert route == 2
+        if nms_path == 'grid':
+            assert route in (4, 5)                       # (the dense scene crowds cells: the grid gives up, the call is repeated)
         # idempotence: NMS of the survivors keeps them all
         _, again = rnms(t(d[got]), 0.5)
         assert again.numel() == len(got)
@@ -415,6 +432,10 @@ def test_multiclass_rnms_equals_per_class_loop(golden):
     # top-k by score
     det2, lab2 = multiclass_rnms(t(mr), t(ms), 0.05, dict(type='rnms', iou_thr=0.3), max_num=50)
     assert len(det2) == 50 and np.all(np.diff(det2[:, -1].cpu().numpy()) <= 0)
+    # the reference's disabled call site, positional (rbbox_head.py:294-295)
+    from aidet_amd import multiclass_thetaobb_nms
+    det3, lab3 = multiclass_thetaobb_nms(t(mr), t(ms), 0.05, 0.3, 50)
+    assert torch.equal(det3, det2) and torch.equal(lab3, lab2)
 
 
 def test_distributed_merge_on_gpu_single_process():
@@ -884,10 +905,9 @@ def test_hbb_nms_malformed_and_nonpositive_threshold():
                   [2, 2, 9, 9, np.nan], [np.nan, 0, 5, 5, 0.6], [0, 0, 10, 10, 0.5],
                   [4, 4, 3, 3, 0.4]], np.float32)                                    # w = h = 0: inert
     assert np.array_equal(nms(t(d), 0.5)[1].cpu().numpy(), oracle.hbb_nms(d, 0.5))
-    with pytest.raises(ValueError):
-        nms(t(d), 0.0)
-    with pytest.raises(ValueError):
-        nms(t(d), -1.0)
+    # thr <= 0 under `>=`: what nms_cpu.cpp:56 returns (round 5; pinned by hbb_nms_nonpos.npz in test_round5_gpu.py)
+    for thr in (0.0, -1.0):
+        assert np.array_equal(nms(t(d), thr)[1].cpu().numpy(), oracle.hbb_nms(d, thr))
     nms(t(d), 0.0, strict=True)            # `>` with thr 0 is an ordinary NMS
     # rotated kinds: the AABB prefilter is part of the operator, every threshold is defined
     r = oracle.synth_boxes(600, 200, 77)

@@ -101,6 +101,10 @@ def test_multiclass_edge_cases(oracle_ops):
     assert d.shape == (0, 5) and l.dtype == torch.long
     d, l = multiclass_rnms(torch.rand(2, 15), ms, 0.05, dict(type='rnms', iou_thr=0.5), 100)
     assert d.shape == (0, 6)
+    # the positional signature of the reference's disabled call (rbbox_head.py:294-295)
+    from aidet_amd import multiclass_thetaobb_nms
+    d, l = multiclass_thetaobb_nms(torch.rand(2, 15), ms, 0.05, 0.5, 100)
+    assert d.shape == (0, 6) and l.dtype == torch.long
     # one class empty, shared (n, 4) boxes, max_num = -1 quirk of the reference (inds[:-1])
     ms = torch.tensor([[0.1, 0.6, 0.0], [0.1, 0.7, 0.0], [0.1, 0.8, 0.0]])
     mb4 = torch.tensor([[0., 0, 10, 10], [100, 100, 120, 120], [200, 200, 230, 230]])

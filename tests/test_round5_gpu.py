@@ -250,3 +250,43 @@ def test_nhwc_backward_c_abi_edges():
     g = torch.zeros((1, 8, 7, 7), device=dev())
     rc = L.obb_roi_backward_gather_nhwc_f32(g.data_ptr(), 1, 8, 8, 8, r.data_ptr(), 1, 0, 7, 7, 1.0, 2, 1.0, gm.data_ptr(), ws.data_ptr(), 16, None)
     assert rc == _lib.OBB_EWORKSPACE
+
+
+# ---- nms with a non-positive threshold (VERDICT r4 "weak" 2) ------------------------------------------------------------
+def test_hbb_nms_nonpositive_threshold_matches_reference(golden):
+    """`nms(dets, iou_thr <= 0)` returns what nms_cpu.cpp:56 returns (fixtures produced by running the reference): float32
+    and float64 rows, numpy and HIP containers, the queued form, groups (= the oracle's loop per group), a NaN threshold
+    (nothing is suppressed)."""
+    from aidet_amd import nms, nms_wrapper
+    g = golden('hbb_nms_nonpos.npz')
+    for tag in ('a', 'b', 'inv', 'zero', 'zerotop'):
+        for ti, thr in enumerate(g['thrs'].tolist()):
+            for dn in ('f32', 'f64'):
+                d, keep = g['%s_%s_dets' % (tag, dn)], g['%s_%s_keep%d' % (tag, dn, ti)]
+                kd, ki = nms(d, thr)
+                assert isinstance(ki, np.ndarray) and ki.dtype == np.int64 and np.array_equal(ki, keep), (tag, dn, thr)
+                assert np.array_equal(kd, d[keep])
+                assert np.array_equal(nms(t(d), thr)[1].cpu().numpy(), keep), (tag, dn, thr)
+            d32 = g['%s_f32_dets' % tag]
+            got = nms_wrapper.nms_collect([nms_wrapper.nms_enqueue(t(d32), thr)])[0]
+            assert np.array_equal(got.cpu().numpy(), g['%s_f32_keep%d' % (tag, ti)])
+    d = g['inv_f32_dets']
+    grp = (np.arange(len(d)) % 7).astype(np.int32)
+    for thr in (0.0, -0.5):
+        assert np.array_equal(nms(t(d), thr, groups=grp)[1].cpu().numpy(), oracle.hbb_nms(d, thr, groups=grp))
+    assert np.array_equal(nms(t(d), float('nan'))[1].cpu().numpy(), np.arange(len(d)))
+    assert np.array_equal(oracle.hbb_nms(d, float('nan')), np.arange(len(d)))
+
+
+def test_hbb_nms_nonpositive_threshold_c_abi():
+    """the same through the bare C ABI: obb_nms_f32 no longer refuses the call"""
+    from aidet_amd import _lib
+    L = _lib.lib()
+    d = np.array([[0, 0, 10, 10, 0.9], [100, 100, 110, 110, 0.8], [50, 50, 49, 60, 0.95], [7, 7, 6, 9, 0.1]], np.float32)
+    dd = t(d)
+    keep = torch.empty(4, dtype=torch.int64, device=dev())
+    ws = torch.empty(L.obb_nms_workspace_bytes(4, _lib.KIND_HBB, 0), dtype=torch.uint8, device=dev())
+    info = (ctypes.c_int64 * 4)()
+    rc = L.obb_nms_f32(dd.data_ptr(), 4, _lib.KIND_HBB, 0.0, keep.data_ptr(), info, ws.data_ptr(), ws.numel(), None)
+    assert rc == _lib.OBB_OK, L.obb_last_error()
+    assert keep[:info[0]].cpu().tolist() == oracle.hbb_nms(d, 0.0).tolist()
