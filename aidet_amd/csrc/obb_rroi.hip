@@ -640,40 +640,6 @@ __device__ __forceinline__ void rroi_backward_direct(const float *__restrict__ g
 // backward (roi_align_kernel_v2.cu:179-263); tolerance 1e-4 * max|g|.
 constexpr int kBwdStageFloats = 4096;                  // sums tile (16 KiB): 16 channels x 255 pixels, 8 x 511, 4 x 1023
 
-// The taps of one bin that land on the SAME pixel become one entry: the first tap of such a group is its leader and
-// carries the sum of the group's weights (ascending tap number: a fixed order).  A bin's taps are `tpb` consecutive tap
-// numbers = consecutive lanes (tpb a power of two <= 64, the lane groups aligned).  pix < 0: no tap in this lane.
-__device__ __forceinline__ void merge_bin_taps(int pix, float w, int lane, int tpb, bool &lead, float &sum_out) {
-  const int g0 = lane & ~(tpb - 1), me = lane - g0;
-  float sum = 0.0f;
-  bool first = true;
-  if (tpb == 16) {
-    // 2 x 2 samples per bin, the usual case: a bin's taps are one DPP row.  Rotating the row by 16 - d brings lane
-    // me + d (mod 16): d = 1 .. 15 visits me + 1 .. 15 (summed, ascending: the order of the loop below), then
-    // 0 .. me - 1 (the leader test).  VALU moves only -- the same exchanges through ds_bpermute (128 per thread)
-    // kept the LDS pipe of the CU busy for 4.8 us of a 12.6 us plan block.
-    sum = pix >= 0 ? w : 0.0f;
-#define OBB_ROW_STEP(D)                                                                                       \
-    {                                                                                                         \
-      const int pj = __builtin_amdgcn_update_dpp(0, pix, 0x120 + (16 - (D)), 0xF, 0xF, false);                \
-      const float wj = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(w), 0x120 + (16 - (D)), 0xF, 0xF, false)); \
-      if (pix >= 0 && pj == pix) { if (me + (D) >= 16) first = false; else sum += wj; }                        \
-    }
-    OBB_ROW_STEP(1) OBB_ROW_STEP(2) OBB_ROW_STEP(3) OBB_ROW_STEP(4) OBB_ROW_STEP(5) OBB_ROW_STEP(6) OBB_ROW_STEP(7)
-    OBB_ROW_STEP(8) OBB_ROW_STEP(9) OBB_ROW_STEP(10) OBB_ROW_STEP(11) OBB_ROW_STEP(12) OBB_ROW_STEP(13)
-    OBB_ROW_STEP(14) OBB_ROW_STEP(15)
-#undef OBB_ROW_STEP
-  } else {
-    for (int j = 0; j < tpb; ++j) {                      // ascending tap number: a fixed order
-      const int pj = __shfl(pix, g0 + j);
-      const float wj = __shfl(w, g0 + j);
-      if (pix >= 0 && pj == pix) { if (j < me) first = false; else sum += wj; }
-    }
-  }
-  lead = pix >= 0 && first;
-  sum_out = sum;
-}
-
 // plan record of the gather formulation (rroi_plan_kernel); state 1: planned, 2: left to the atomics kernel, 0: nothing sampled
 
 __global__ __launch_bounds__(256) void rroi_backward_kernel(
@@ -860,8 +826,32 @@ __device__ __forceinline__ bool plan_holds(int fsz, int nb, int nsamp) {
 __global__ __launch_bounds__(256) void rroi_plan_kernel(
     int B, int H, int W, const float *__restrict__ rois, int ph, int pw, float scale, int sample_num,
     float min_size, int roi_kind, RoiPlan *__restrict__ plan, unsigned short *__restrict__ rstart,
-    int2 *__restrict__ rentry, int *__restrict__ lpt, int tiles_x, int tiles_per_image) {
+    int2 *__restrict__ rentry, int *__restrict__ lpt, int tiles_x, int tiles_per_image,
+    int nplan, const float *__restrict__ tg, float *__restrict__ tgT, int tC) {
   __shared__ __attribute__((aligned(16))) float tile[kBwdStageFloats];   // sample table | per-pixel counts
+  if ((int)blockIdx.x >= nplan) {
+    // (channels-last gather, obb_rroi_nhwc.hip) blocks behind the plan's transpose grad_out (K, C, nb) -> tgT (K, nb, C),
+    // one (RoI, 64 channels) each, through `tile` ([64][<= 63 bins], odd pitch): independent of the plan blocks, whose
+    // dependent chains leave the memory pipes idle beside them
+    const int nb = ph * pw, chunks = (tC + 63) / 64;
+    const int id = (int)blockIdx.x - nplan, k = id / chunks, c0 = (id - k * chunks) * 64, cc = min(64, tC - c0);
+    const float *src = tg + ((int64_t)k * tC + c0) * nb;
+    float *dst = tgT + (int64_t)k * nb * tC + c0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int kTB = 63;                                   // bins per pass: 64 x 63 floats fit the tile
+    for (int b0 = 0; b0 < nb; b0 += kTB) {
+      const int bn = min(kTB, nb - b0);
+      for (int i = threadIdx.x; i < cc * bn; i += 256) {
+        const int c = i / bn, bb = i - c * bn;
+        tile[c * kTB + bb] = src[(int64_t)c * nb + b0 + bb];
+      }
+      __syncthreads();
+      for (int bb = wave; bb < bn; bb += 4)
+        if (lane < cc) dst[(int64_t)(b0 + bb) * tC + lane] = tile[lane * kTB + bb];
+      __syncthreads();
+    }
+    return;
+  }
   __shared__ int s_last;
   __shared__ int2 entry[kBwdMaxEntries];               // (bin | tap << 8, weight bits), grouped by pixel
   __shared__ int pstart[kBwdMaxPix + 1];
@@ -887,7 +877,7 @@ __global__ __launch_bounds__(256) void rroi_plan_kernel(
     if (!lpt) return;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (this wave's counts are acknowledged before the ticket is taken)
     __syncthreads();
-    if (tid == 0) s_last = __hip_atomic_fetch_add(lpt + kLptMax, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+    if (tid == 0) s_last = __hip_atomic_fetch_add(lpt + kLptMax, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nplan - 1;
     __syncthreads();
     if (!s_last) return;
     int *bucket = pstart;                    // [256] tiles per count (255 = "255 or more"), then their first rank
@@ -1509,9 +1499,12 @@ GatherLayout gather_layout(int64_t K) {
 // the plan pass of the gather formulations (this file's NCHW gather, obb_rroi_nhwc.hip's channels-last one)
 int rroi_plan_launch(int B, int H, int W, const float *rois_dev, int64_t K, int ph, int pw, float spatial_scale, int sample_num,
                      float min_size, int roi_kind, RoiPlan *plan, unsigned short *rstart, int2 *rentry, int *lpt, int tiles_x,
-                     int tiles, void *stream) {
-  hipLaunchKernelGGL(rroi_plan_kernel, dim3((unsigned)K), dim3(256), 0, (hipStream_t)stream, B, H, W, rois_dev, ph, pw, spatial_scale,
-                     sample_num, min_size, roi_kind, plan, rstart, rentry, lpt, tiles_x, tiles);
+                     int tiles, void *stream, const float *tg, float *tgT, int tC) {
+  unsigned long long blocks = (unsigned long long)K;
+  if (tgT) blocks += (unsigned long long)K * (unsigned)((tC + 63) / 64);
+  if (blocks > 2147483647ull) return set_err(OBB_EINVAL, "rroi_plan_launch: too many blocks (K=%lld, C=%d)", (long long)K, tC);
+  hipLaunchKernelGGL(rroi_plan_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, B, H, W, rois_dev, ph, pw, spatial_scale,
+                     sample_num, min_size, roi_kind, plan, rstart, rentry, lpt, tiles_x, tiles, (int)K, tg, tgT, tC);
   OBB_LAUNCH_CHECK();
   return OBB_OK;
 }

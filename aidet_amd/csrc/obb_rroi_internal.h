@@ -171,6 +171,40 @@ __device__ __forceinline__ Footprint roi_footprint(const RoiFrame &f, int H, int
   return p;
 }
 
+// The taps of one bin that land on the SAME pixel become one entry: the first tap of such a group is its leader and
+// carries the sum of the group's weights (ascending tap number: a fixed order).  A bin's taps are `tpb` consecutive tap
+// numbers = consecutive lanes (tpb a power of two <= 64, the lane groups aligned).  pix < 0: no tap in this lane.
+__device__ __forceinline__ void merge_bin_taps(int pix, float w, int lane, int tpb, bool &lead, float &sum_out) {
+  const int g0 = lane & ~(tpb - 1), me = lane - g0;
+  float sum = 0.0f;
+  bool first = true;
+  if (tpb == 16) {
+    // 2 x 2 samples per bin, the usual case: a bin's taps are one DPP row.  Rotating the row by 16 - d brings lane
+    // me + d (mod 16): d = 1 .. 15 visits me + 1 .. 15 (summed, ascending: the order of the loop below), then
+    // 0 .. me - 1 (the leader test).  VALU moves only -- the same exchanges through ds_bpermute (128 per thread)
+    // kept the LDS pipe of the CU busy for 4.8 us of a 12.6 us plan block.
+    sum = pix >= 0 ? w : 0.0f;
+#define OBB_ROW_STEP(D)                                                                                       \
+    {                                                                                                         \
+      const int pj = __builtin_amdgcn_update_dpp(0, pix, 0x120 + (16 - (D)), 0xF, 0xF, false);                \
+      const float wj = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(w), 0x120 + (16 - (D)), 0xF, 0xF, false)); \
+      if (pix >= 0 && pj == pix) { if (me + (D) >= 16) first = false; else sum += wj; }                        \
+    }
+    OBB_ROW_STEP(1) OBB_ROW_STEP(2) OBB_ROW_STEP(3) OBB_ROW_STEP(4) OBB_ROW_STEP(5) OBB_ROW_STEP(6) OBB_ROW_STEP(7)
+    OBB_ROW_STEP(8) OBB_ROW_STEP(9) OBB_ROW_STEP(10) OBB_ROW_STEP(11) OBB_ROW_STEP(12) OBB_ROW_STEP(13)
+    OBB_ROW_STEP(14) OBB_ROW_STEP(15)
+#undef OBB_ROW_STEP
+  } else {
+    for (int j = 0; j < tpb; ++j) {                      // ascending tap number: a fixed order
+      const int pj = __shfl(pix, g0 + j);
+      const float wj = __shfl(w, g0 + j);
+      if (pix >= 0 && pj == pix) { if (j < me) first = false; else sum += wj; }
+    }
+  }
+  lead = pix >= 0 && first;
+  sum_out = sum;
+}
+
 // ---- the per-RoI plan of the gather backward (rroi_plan_kernel, obb_rroi.hip) ------------------------------------------
 constexpr int kMaxTabSamples = 256;   // sample table (8 KiB); 7x7 bins x 2x2 samples = 196
 constexpr int kBwdMaxPix = 2047;                       // footprint pixels of a planned RoI
@@ -184,7 +218,7 @@ struct GatherLayout { size_t plan, rstart, rentry, lpt, total; };
 GatherLayout gather_layout(int64_t K);
 int rroi_plan_launch(int B, int H, int W, const float *rois_dev, int64_t K, int ph, int pw, float spatial_scale, int sample_num,
                      float min_size, int roi_kind, RoiPlan *plan, unsigned short *rstart, int2 *rentry, int *lpt, int tiles_x,
-                     int tiles, void *stream);
+                     int tiles, void *stream, const float *tg = nullptr, float *tgT = nullptr, int tC = 0);
 
 // host helpers of obb_rroi.hip used by obb_rroi_nhwc.hip
 constexpr int kOrderMaxK = 65536;    // above: identity order (the caller passes no order)

@@ -32,9 +32,10 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..anchors import AnchorGenerator
-from ..bbox_transforms import bbox2result, bbox2roi, delta2bbox
+from ..bbox_transforms import bbox2result, bbox2roi, bbox_mapping, delta2bbox
+from ..merge_augs import merge_aug_bboxes, merge_aug_proposals
 from ..post_processing import (detect_horizontal_fused, detect_rotated_fused, get_det_rbboxes, head_fusable,
-                               multiclass_nms_with_index)
+                               multiclass_nms, multiclass_nms_with_index)
 from ..rbbox_transforms import rbbox2result
 from ..roi_layers import SingleRoIExtractor
 from ..rpn import rpn_proposals
@@ -298,6 +299,55 @@ class ThetaOBBRCNN(nn.Module):
         rbbox_results = rbbox2result(det_rbboxes, det_rlabels, self.rbbox_head.num_classes)
         self._tick('results_to_host')
         return bbox_results, rbbox_results
+
+    @torch.no_grad()
+    def aug_test(self, imgs, img_metas, rescale=False, with_rotated=False):
+        """Test with augmentations (``RBBoxRCNN.aug_test``, rbbox_cnn.py:255-282): ``imgs`` / ``img_metas`` hold one
+        entry per augmentation (scale, flip) of ONE image, ``img_metas[i][0]`` its meta.
+
+        RPN leg = ``aug_test_rpn`` (test_mixins.py:37-59): the proposals of every view are mapped back and merged by one
+        NMS (``merge_aug_proposals``).  Box leg = ``aug_test_bboxes`` (:122-157): the merged proposals are mapped INTO
+        every view, pooled and decoded there with ``cfg=None`` (all classes, no NMS), mapped back, averaged
+        (``merge_aug_bboxes``) and only then class-wise NMS'd.  Returns ``bbox_results`` at the scale of ``imgs[0]``
+        (``rescale=False``) or of the original image -- what the reference returns: its rotated leg reads
+        ``self.with_thetaobb`` / ``merge_aug_thetaobbs`` (rbbox_cnn.py:276-279, test_mixins.py:400), neither of which
+        exists.  ``with_rotated=True`` (an extension, no reference counterpart) also returns ``rbbox_results``: the
+        rotated head on the merged proposals in the FIRST view, decoded + rotated NMS like ``simple_test``."""
+        cfg = self.test_cfg
+        feats = [self.extract_feat(img) for img in imgs]           # (the reference recomputes them per leg to save memory)
+        # ---- aug_test_rpn
+        aug_proposals = []
+        for x, meta in zip(feats, img_metas):
+            cls_scores, bbox_preds = self.rpn_head(x)
+            aug_proposals.append(self.rpn_head.get_bboxes(cls_scores, bbox_preds, meta, cfg['rpn'], fused=self.fused)[0])
+        merged = merge_aug_proposals(aug_proposals, [m[0] for m in img_metas], cfg['rpn'])
+        # ---- aug_test_bboxes
+        aug_bboxes, aug_scores = [], []
+        nlv = len(self.bbox_roi_extractor.featmap_strides)
+        for x, meta in zip(feats, img_metas):
+            m0 = meta[0]
+            proposals = bbox_mapping(merged[:, :4], m0['img_shape'], m0['scale_factor'], m0['flip'])
+            rois = bbox2roi([proposals])
+            cls_score, bbox_pred = self.bbox_head(self.bbox_roi_extractor(x[:nlv], rois))
+            scores = F.softmax(cls_score, dim=1)
+            bboxes = delta2bbox(rois[:, 1:], bbox_pred, (0., 0., 0., 0.), self.bbox_target_stds, m0['img_shape'])
+            aug_bboxes.append(bboxes)
+            aug_scores.append(scores)
+        merged_bboxes, merged_scores = merge_aug_bboxes(aug_bboxes, aug_scores, img_metas, cfg['rcnn'])
+        rcnn = cfg['rcnn']
+        det_bboxes, det_labels = multiclass_nms(merged_bboxes, merged_scores, rcnn['score_thr'], rcnn['nms'], rcnn['max_per_img'])
+        if not rescale:                                              # (results fit the scale of imgs[0])
+            det_bboxes = det_bboxes.clone()
+            det_bboxes[:, :4] *= img_metas[0][0]['scale_factor']
+        bbox_results = bbox2result(det_bboxes, det_labels, self.bbox_head.num_classes)
+        if not with_rotated:
+            return bbox_results
+        m0 = img_metas[0][0]
+        rois = bbox2roi([bbox_mapping(merged[:, :4], m0['img_shape'], m0['scale_factor'], m0['flip'])])
+        cls_score, rbbox_pred = self.rbbox_head(self.rbbox_roi_extractor(feats[0][:nlv], rois))
+        det_rbboxes, det_rlabels = get_det_rbboxes(rois, cls_score, rbbox_pred, m0['img_shape'], m0['scale_factor'], rescale=rescale,
+                                                   cfg=cfg['rbbox'], target_stds=self.rbbox_target_stds, rotated_nms=True)
+        return bbox_results, rbbox2result(det_rbboxes, det_rlabels, self.rbbox_head.num_classes)
 
 
 def build_detector(device, rotated_nms=False, seed=0, fused=True):

@@ -330,10 +330,13 @@ def test_library_side_capacity_hint_serves_c_abi_callers():
 
 
 def test_channels_last_feature_map_is_copied_with_a_warning_once():
-    """VERDICT r3 weak #8: a channels-last map is converted to NCHW before pooling -- same values, and it says so."""
+    """a channels-last map the kernels cannot pool in place is converted to NCHW before pooling --
+    same values, and it says so.  (Since round 5 channels-last maps with C % 4 == 0 ARE pooled in place, silently:
+    tests/test_round5_gpu.py; the copy and its warning remain for the rest -- here C = 30 -- and for
+    roi_layers.NHWC_NATIVE = False.)"""
     from aidet_amd import RRoIAlign, roi_layers
     rng = np.random.default_rng(4)
-    feat = t(rng.standard_normal((1, 32, 48, 40)).astype(np.float32))
+    feat = t(rng.standard_normal((1, 30, 48, 40)).astype(np.float32))
     rois = t(np.concatenate([np.zeros((40, 1), np.float32), oracle.synth_boxes(40, 160, 5)[:, :5]], 1))
     layer = RRoIAlign(7, 0.25, sample_num=2)
     want = layer(feat, rois)
@@ -346,6 +349,17 @@ def test_channels_last_feature_map_is_copied_with_a_warning_once():
         warnings.simplefilter('error')
         layer(feat.contiguous(memory_format=torch.channels_last), rois)      # (once per cause)
         layer(feat, rois)
+        feat32 = t(rng.standard_normal((1, 32, 48, 40)).astype(np.float32))
+        layer(feat32.contiguous(memory_format=torch.channels_last), rois)    # (pooled in place: nothing to warn about)
+    old = roi_layers.NHWC_NATIVE
+    try:
+        roi_layers.NHWC_NATIVE = False
+        roi_layers._warned_layout.clear()
+        with pytest.warns(UserWarning, match='channels-last layout'):
+            got = layer(feat32.contiguous(memory_format=torch.channels_last), rois)
+        assert torch.equal(got, layer(feat32, rois))
+    finally:
+        roi_layers.NHWC_NATIVE = old
 
 
 def test_planned_roi_forward_is_bit_equal_to_the_unplanned_one():
