@@ -366,11 +366,17 @@ def demo_inputs(device, size=1024, seed=0):
 
 
 def bench_cfg4(device, iters=5):
-    """Per-stage wall time of one 1024 x 1024 tile (config 4), both post-processing modes."""
+    """Per-stage wall time of one 1024 x 1024 tile (config 4): both post-processing modes on the NCHW trunk, and the
+    rotated-NMS mode on a CHANNELS-LAST trunk (``model.to(memory_format=torch.channels_last)``: MIOpen's NHWC
+    convolutions hand the RoI extractor channels-last pyramid levels, pooled in place since round 5)."""
     out = {}
-    for rotated in (False, True):
+    for tag, rotated, channels_last in (('reference_keep_reuse', False, False), ('rotated_nms', True, False),
+                                        ('rotated_nms_channels_last', True, True)):
         model = build_detector(device, rotated_nms=rotated)
         img, meta = demo_inputs(device)
+        if channels_last:
+            model = model.to(memory_format=torch.channels_last)
+            img = img.contiguous(memory_format=torch.channels_last)
         for _ in range(2):
             res = model.simple_test(img, meta)
         model.timers = {}
@@ -380,10 +386,14 @@ def bench_cfg4(device, iters=5):
             res = model.simple_test(img, meta)
         torch.cuda.synchronize()
         total = (time.perf_counter() - t0) / iters
-        tag = 'rotated_nms' if rotated else 'reference_keep_reuse'
         out[tag] = {'tile_ms': round(total * 1e3, 3),
                     'stages_ms': {k: round(v / iters * 1e3, 3) for k, v in model.timers.items()},
                     'detections_hbb': int(sum(len(r) for r in res[0])), 'detections_obb': int(sum(len(r) for r in res[1]))}
+        if channels_last:
+            from .. import roi_layers
+            with torch.no_grad():
+                x = model.extract_feat(img)
+            out[tag]['pyramid_pooled_in_place'] = bool(all(roi_layers.is_nhwc(f) for f in x[:4]))
         del model
     out['model'] = 'Faster-RCNN-OBB R50-FPN (theta-OBB head), random init (seed 0), fp32, one 1024x1024 tile'
     return out

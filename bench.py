@@ -49,7 +49,8 @@ HBM_PEAK_GBS = 8000.0                 # MI355X HBM3E spec (MI355X_MICROARCH.md)
 # VALU issue: 256 CUs x 4 SIMD-32; a wave64 VALU op occupies its SIMD for 2 cycles
 # (MI355X_MICROARCH.md, cycle constants: v_fma_f32 wave64 = 2 cyc throughput)
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0  # G wave-instructions / s at 2.4 GHz
-COUNTER_FILES = [os.path.join(ROOT, 'profiles', 'r04_counters.json'), os.path.join(ROOT, 'profiles', 'r03_counters.json')]
+COUNTER_FILES = [os.path.join(ROOT, 'profiles', 'r05_counters.json'), os.path.join(ROOT, 'profiles', 'r04_counters.json'),
+                 os.path.join(ROOT, 'profiles', 'r03_counters.json')]
 IOU_M = 16384                         # rbbox_overlaps leg: 16k x 16k (SURVEY 8d scale-up of configs[0])
 IOU_CANVAS = 1024                     # ... at configs[0]'s density (boxes on a 1024 canvas; 1.2 % of the pairs clipped)
 IOU_SPARSE_CANVAS = 8192              # the write-bound extreme beside it (0.02 % clipped): `iou_sparse_*`
@@ -73,6 +74,9 @@ def parse_args():
                     help='rccl (default; backend "nccl" IS RCCL on ROCm, one rank per GPU) | gloo: DEBUG ONLY -- the ranks may '
                          'share GPUs (rank r uses cuda:(r mod #GPUs)) and every collective is staged through host memory '
                          '(aidet_amd/_collectives.py), so that the N > 1 code path can be smoke-run on a one-GPU box')
+    ap.add_argument('--collective-timeout', type=float, default=180.0,
+                    help='seconds a collective (and the whole cfg5 leg per layout) may take at N > 1 before the process '
+                         'prints what it has and exits non-zero')
     ap.add_argument('--profile-target', default=None,
                     choices=['nms', 'iou_sparse', 'iou_dense', 'iou_allclip', 'rroi_fwd', 'rroi_bwd', 'rroi_bwd_scatter', 'roi_fwd', 'cfg5',
                              'rroi_fwd_nhwc', 'rroi_bwd_nhwc', 'roi_fwd_nhwc'],
@@ -129,7 +133,11 @@ def bench_all(args):
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if dist is not None:
-        dist.init_process_group('nccl' if args.transport == 'rccl' else 'gloo', rank=rank, world_size=world)
+        import datetime
+        # every collective under a timeout: a rank that waits for one that will never come ends non-zero (a FRESH launch
+        # restarts the job -- never a re-exec of a process that has touched the GPU) instead of hanging the node
+        dist.init_process_group('nccl' if args.transport == 'rccl' else 'gloo', rank=rank, world_size=world,
+                                timeout=datetime.timedelta(seconds=args.collective_timeout))
         assert dist.get_world_size() == world
     from aidet_amd import _collectives as coll
 
@@ -212,9 +220,20 @@ def bench_all(args):
 
     # ---- leg 2: cfg5 (strong scaling) -------------------------------------------------------------
     cfg5, cfg5_error = None, None
+    partial = {'metric': 'rotated-NMS boxes/sec', 'value': round(value, 1), 'unit': 'boxes/s', 'n_gpus': world, 'steps': args.steps,
+               'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak',
+               'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+               'config': {'workload': 'rnms: %d theta-OBBs per GPU, canvas %g (BASELINE configs[1])' % (n, args.canvas),
+                          'iou_pairs_per_s': round(iou_pairs['cfg'], 1), 'cfg5_progress': {}},
+               'rccl_ranks': world if dist is not None else None}
     if not args.no_cfg5:
+        # the one leg with collectives in its data path.  Pre-flight for a node nobody has run this on: a
+        # watchdog per layout -- when a layout neither finishes nor fails within the limit (a rank stuck in a collective
+        # whose peer raised), rank 0 prints the line it has (replica leg + the layouts done so far + which one hung) and
+        # every rank exits non-zero; a layout that RAISES on every rank (e.g. uneven all_to_all splits refused by the
+        # transport) is recorded and the next layout still runs.
         try:
-            cfg5 = cfg5_leg(args, dev, rank, world, dist)
+            cfg5 = cfg5_leg(args, dev, rank, world, dist, partial)
         except Exception as e:      # (the replica leg above is measured: its line is still printed, with the failure on it)
             import traceback
             cfg5_error = '%s: %s' % (type(e).__name__, str(e)[:300])
@@ -270,7 +289,9 @@ def bench_all(args):
             out['cpu_baseline'] = cpu_baseline(boxes, keep)
     if rank == 0:
         if not ok:
-            out['error'] = 'distributed merge differs from the single-rank result'
+            failed = sorted(k for k in out['config'] if k.startswith('cfg5_') and k.endswith('_error'))
+            out['error'] = ('cfg5: ' + ', '.join('%s = %s' % (k, out['config'][k]) for k in failed)) if failed else \
+                'distributed merge differs from the single-rank result'
         print(json.dumps(out))
     if dist is not None and cfg5_error is None:      # (after a failed leg the ranks may not be in step any more: no further collective)
         dist.barrier()
@@ -279,7 +300,37 @@ def bench_all(args):
         sys.exit(1)
 
 
-def cfg5_leg(args, dev, rank, world, dist):
+class _Watchdog(object):
+    """`with _Watchdog(seconds, what, partial, rank)`: when the body takes longer, rank 0 prints the partial JSON line with
+    `cfg5_error` naming what hung, and the process exits with code 3 (os._exit: the main thread may sit in a collective)."""
+
+    def __init__(self, seconds, what, partial, rank):
+        import threading
+        self.t = threading.Timer(seconds, self.fire)
+        self.t.daemon = True
+        self.what, self.partial, self.rank, self.seconds = what, partial, rank, seconds
+
+    def fire(self):
+        if self.rank == 0 and self.partial is not None:
+            line = dict(self.partial)
+            line['config'] = dict(line['config'], cfg5_error='%s did not finish within %.0f s (a rank stuck in a collective?)' % (self.what, self.seconds))
+            line['error'] = 'timeout in ' + self.what
+            sys.stdout.write(json.dumps(line) + '\n')
+            sys.stdout.flush()
+        sys.stderr.write('bench.py: rank %d: %s timed out after %.0f s; exiting\n' % (self.rank, self.what, self.seconds))
+        sys.stderr.flush()
+        os._exit(3)
+
+    def __enter__(self):
+        self.t.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.t.cancel()
+        return False
+
+
+def cfg5_leg(args, dev, rank, world, dist, partial=None):
     """BASELINE configs[4] on `world` ranks: every layout timed (the chosen one with the full step count), each
     keep set compared with a single-rank run of all patches.  -> {'flat': scalars for `config`, 'detail', 'ok'}"""
     import hashlib
@@ -296,11 +347,31 @@ def cfg5_leg(args, dev, rank, world, dist):
                                                group=dota_merge.LOCAL)
         single = s1
     detail, ok_all, flat = {}, True, {}
+    limit = args.collective_timeout if world > 1 else 3600.0
     for li, layout in enumerate(layouts):
         st = steps if li == 0 else max(3, steps // 2)
         barrier = dist.barrier if dist is not None else None
         group = None if dist is not None else dota_merge.LOCAL
-        summary, elapsed, kept_rows = tiled_on_this_rank(dev, rank, world, st, args.warmup, layout, group=group, barrier=barrier)
+        try:
+            with _Watchdog(limit, 'cfg5 layout %r' % layout, partial if world > 1 else None, rank):
+                if world > 1 and rank == world - 1 and os.environ.get('OBB_BENCH_TEST_HANG') == layout:
+                    time.sleep(1e6)      # (test hook of tests/test_multiproc_gpu.py: a rank that never reaches the collective)
+                if world > 1 and os.environ.get('OBB_BENCH_TEST_RAISE') == layout:
+                    raise RuntimeError('test hook: layout %s refused on every rank' % layout)
+                summary, elapsed, kept_rows = tiled_on_this_rank(dev, rank, world, st, args.warmup, layout, group=group, barrier=barrier)
+        except Exception as e:
+            # raised on this rank.  If every rank raised (the transport refuses the call) the next layout is in step again;
+            # if only this one did, the others wait in a collective and their watchdogs end the job -- either way the line
+            # carries the layout's failure
+            import traceback
+            sys.stderr.write('bench.py: cfg5 layout %r failed on rank %d\n%s\n' % (layout, rank, traceback.format_exc()))
+            flat['cfg5_%s_error' % layout] = '%s: %s' % (type(e).__name__, str(e)[:200])
+            if li == 0:
+                flat['cfg5_layout'] = layout
+            ok_all = False
+            if partial is not None:
+                partial['config']['cfg5_progress'][layout] = 'failed: ' + type(e).__name__
+            continue
         same = True
         if dist is not None:
             tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -343,6 +414,9 @@ def cfg5_leg(args, dev, rank, world, dist):
             flat['cfg5_%s_ms_per_step' % layout] = round(ms, 4)
             if single is not None:
                 flat['cfg5_%s_speedup_vs_single_rank' % layout] = round(single['ms_per_step'] / ms, 3)
+        if partial is not None:
+            partial['config']['cfg5_progress'][layout] = {'ms_per_step': round(ms, 4), 'keep_ok': bool(good)}
+            partial['config'].update({k: v for k, v in flat.items() if not isinstance(v, (dict, list))})
     # ---- the size where strong scaling has room: 128 images, 1.0e7 detections (routed at N > 1: every phase divides)
     if not args.no_cfg5_large:
         layout = args.merge_layout if world == 1 else 'routed'
@@ -352,7 +426,8 @@ def cfg5_leg(args, dev, rank, world, dist):
             big_single, _e, big_ref = tiled_on_this_rank(dev, 0, 1, steps=st, warmup=1, layout='replicated', group=dota_merge.LOCAL, images=128)
         barrier = dist.barrier if dist is not None else None
         group = None if dist is not None else dota_merge.LOCAL
-        summary, elapsed, kept_rows = tiled_on_this_rank(dev, rank, world, st, 1, layout, group=group, barrier=barrier, images=128)
+        with _Watchdog(limit, 'cfg5_large (%s)' % layout, partial if world > 1 else None, rank):
+            summary, elapsed, kept_rows = tiled_on_this_rank(dev, rank, world, st, 1, layout, group=group, barrier=barrier, images=128)
         good = 1
         if dist is not None:
             tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -647,6 +722,38 @@ def roofline_kernels(dev):
                     'achieved': round(alg_b / (ms * 1e-3) / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                     'frac': round(alg_b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), 'traffic': pc.get('traffic'),
                     'rocprof_us': pc.get('rocprof_us')})
+    # ---- the same two ops on the same map held channels-last (B, H, W, C): pooled in place by the channels-last kernels
+    # (round 5; obb_rroi_nhwc.hip), same algorithmic bytes, results bit-equal to the NCHW kernels'
+    featl = feat.contiguous(memory_format=torch.channels_last)
+    out_l = torch.empty((512, 256, 7, 7), device=dev)
+
+    def fwd_nhwc():
+        _lib.check(L.obb_rroi_align_forward_nhwc_f32(featl.data_ptr(), 1, 256, 256, 256, rois.data_ptr(), 512, 7, 7, 0.25, 2, 1.0,
+                                                     out_l.data_ptr(), st))
+    ms = _time_gpu(fwd_nhwc, 50)
+    assert torch.equal(out_l, out_f)
+    pc = sum_counters(['roi_forward_nhwc_kernel'], 'rroi_fwd_nhwc') or {}
+    res.append({'tag': 'rroi_fwd_nhwc', 'kernel': 'roi_forward_nhwc_kernel', 'workload': 'the same RRoIAlign forward on a channels-last map (bit-equal output)',
+                'bound': 'hbm', 'algorithmic_bytes': alg, 'kernel_ms': round(ms, 4), 'rois_per_s': round(512 / (ms * 1e-3), 1),
+                'achieved': round(alg / (ms * 1e-3) / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), 'traffic': pc.get('traffic'),
+                'lds_conflict_share': pc.get('lds_conflict_share'), 'rocprof_us': pc.get('rocprof_us')})
+    gfl = torch.empty((1, 256, 256, 256), device=dev, memory_format=torch.channels_last)
+    wsl = torch.empty(L.obb_roi_backward_nhwc_workspace_bytes(512, 256, 7, 7), dtype=torch.uint8, device=dev)
+
+    def bwd_nhwc():
+        _lib.check(L.obb_roi_backward_gather_nhwc_f32(gout.data_ptr(), 1, 256, 256, 256, rois.data_ptr(), 512, 0, 7, 7, 0.25, 2, 1.0,
+                                                      gfl.data_ptr(), wsl.data_ptr(), wsl.numel(), st))
+    ms = _time_gpu(bwd_nhwc, 20)
+    bwd_gather()
+    assert torch.equal(gfl.contiguous(), gfeat)
+    names = ['rroi_plan_kernel', 'roi_gather_nhwc_kernel', 'roi_backward_nhwc_direct_kernel']
+    pc = sum_counters(names, 'rroi_bwd_nhwc') or {}
+    res.append({'tag': 'rroi_bwd_nhwc', 'kernel': '+'.join(names), 'workload': 'the same backward into a channels-last gradient map (plan + transposition in one launch, gather, atomics tail; bit-equal)',
+                'bound': 'hbm', 'algorithmic_bytes': alg_b, 'kernel_ms': round(ms, 4),
+                'achieved': round(alg_b / (ms * 1e-3) / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': round(alg_b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), 'traffic': pc.get('traffic'),
+                'rocprof_us': pc.get('rocprof_us')})
     return {'measured_peak': peaks, 'kernels': res}
 
 

@@ -133,3 +133,26 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     for layout in ('replicated', 'sharded', 'routed'):
         d = j['cfg5'][layout]
         assert d['keep_equals_single_rank_run'] is True and d['same_keep_on_all_ranks'] is True, layout
+
+
+def test_bench_preflight_a_layout_that_raises_and_a_rank_that_hangs():
+    """the first real multi-GPU run must fail informatively.  (a) a layout that raises on every rank is
+    recorded on the line and the other layouts still run; (b) a rank that never reaches a collective: the other rank's
+    watchdog prints the partial line (replica leg, the layouts done so far, what hung) and the job ends non-zero."""
+    import json
+    base = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--transport', 'gloo',
+           '--no-cpu', '--no-extras', '--no-cfg5-large']
+    r = subprocess.run(cmd, env=dict(base, OBB_BENCH_TEST_RAISE='sharded'), capture_output=True, text=True, timeout=900)
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    c = j['config']
+    assert r.returncode != 0 and 'test hook' in c['cfg5_sharded_error']
+    assert j['rccl_ranks'] == 2 and c['cfg5_layout'] == 'replicated' and c['cfg5_speedup_vs_single_rank'] > 0
+    assert c['cfg5_routed_ms_per_step'] > 0 and j['cfg5']['routed']['keep_equals_single_rank_run'] is True
+    r = subprocess.run(cmd + ['--collective-timeout', '25'], env=dict(base, OBB_BENCH_TEST_HANG='routed'), capture_output=True,
+                       text=True, timeout=900)
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert r.returncode != 0 and lines, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
+    j = json.loads(lines[-1])
+    assert 'did not finish' in j['config']['cfg5_error'] and j['value'] > 0 and j['rccl_ranks'] == 2
+    assert 'replicated' in j['config']['cfg5_progress']
