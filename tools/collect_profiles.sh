@@ -9,7 +9,7 @@
 export TMPDIR=/tmp
 O=gpurun_out/collect
 rm -rf $O; mkdir -p $O
-TARGETS=${TARGETS:-"nms iou_sparse iou_dense iou_allclip rroi_fwd rroi_bwd rroi_bwd_scatter roi_fwd"}
+TARGETS=${TARGETS:-"nms iou_sparse iou_dense iou_allclip rroi_fwd rroi_bwd rroi_bwd_scatter roi_fwd rroi_fwd_nhwc rroi_bwd_nhwc roi_fwd_nhwc"}
 timeout 600 python bench.py > $O/bench.json 2> $O/bench.err
 timeout 200 python bench.py --canvas 4096 --no-cpu --no-extras --no-cfg5-large > $O/bench_dense.json 2>> $O/bench.err
 # the bench command itself under the profiler (MIXED: the NMS leg, both IoU legs, cfg5 -- per-kernel averages of one
@@ -32,6 +32,10 @@ timeout 200 python tools/bench_roi_backward.py > $O/roi_backward.txt 2>> $O/benc
 timeout 200 python tools/bench_soft_nms.py > $O/soft_nms.txt 2>> $O/bench.err
 timeout 200 python tools/exp_rroi_ablate.py > $O/rroi_ablate.txt 2>> $O/bench.err
 timeout 200 python tools/exp_rroi_stamps.py > $O/rroi_stamps.txt 2>> $O/bench.err
+timeout 200 python tools/exp_nhwc_stamps.py 64 4 > $O/nhwc_stamps.txt 2>> $O/bench.err
+timeout 200 python tools/exp_nhwc_fwd.py > $O/nhwc_fwd.txt 2>> $O/bench.err
+timeout 200 python tools/exp_nhwc_bwd.py > $O/nhwc_bwd.txt 2>> $O/bench.err
+timeout 200 python tools/exp_overlaps_density.py > $O/overlaps_density.txt 2>> $O/bench.err
 timeout 200 python tools/exp_gprobe_stamps.py > $O/gprobe_stamps.txt 2>> $O/bench.err
 timeout 200 python tools/exp_frame_stamps.py > $O/frame_stamps.txt 2>> $O/bench.err
 timeout 300 python tools/exp_tiled_grid.py 16 0,1 > $O/tiled_grid.txt 2>> $O/bench.err

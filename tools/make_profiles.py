@@ -7,12 +7,13 @@ import json
 import os
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r04'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r05'
 src = 'gpurun_out/collect'
 dst = 'profiles'
 WORKLOAD = {'nms': 'nms_100000_20000', 'iou_sparse': 'iou_sparse', 'iou_dense': 'iou_dense', 'iou_allclip': 'iou_allclip',
-            'rroi_fwd': 'rroi_fwd', 'rroi_bwd': 'rroi_bwd', 'rroi_bwd_scatter': 'rroi_bwd_scatter', 'roi_fwd': 'roi_fwd'}
-OURS = ('nms_', 'overlaps_', 'rroi_', 'soft_nms', 'rbox_to_poly')
+            'rroi_fwd': 'rroi_fwd', 'rroi_bwd': 'rroi_bwd', 'rroi_bwd_scatter': 'rroi_bwd_scatter', 'roi_fwd': 'roi_fwd',
+            'rroi_fwd_nhwc': 'rroi_fwd_nhwc', 'rroi_bwd_nhwc': 'rroi_bwd_nhwc', 'roi_fwd_nhwc': 'roi_fwd_nhwc'}
+OURS = ('nms_', 'overlaps_', 'rroi_', 'roi_', 'soft_nms', 'rbox_to_poly')
 
 
 def jline(path):
@@ -114,7 +115,8 @@ for name, alg in (('iou_sparse', 20 * 2 * 16384 + 4 * 16384 ** 2), ('iou_dense',
     if ks:
         print('%s: algorithmic %.1f MB / %.1f us = %.0f GB/s = %.3f of 8 TB/s' % (
             name, alg / 1e6, ks[0]['avg_us'], alg / ks[0]['avg_us'] / 1e3, alg / ks[0]['avg_us'] / 1e3 / 8000))
-for name in ('multi_rank_sim.txt', 'multi_rank_sim_large.txt', 'roi_backward.txt', 'detect.json', 'soft_nms.txt', 'rroi_ablate.txt', 'rroi_stamps.txt', 'gprobe_stamps.txt', 'frame_stamps.txt', 'tiled_grid.txt', 'grid_vs_sorted.txt'):
+for name in ('multi_rank_sim.txt', 'multi_rank_sim_large.txt', 'roi_backward.txt', 'detect.json', 'soft_nms.txt', 'rroi_ablate.txt', 'rroi_stamps.txt', 'gprobe_stamps.txt', 'frame_stamps.txt', 'tiled_grid.txt', 'grid_vs_sorted.txt',
+             'nhwc_stamps.txt', 'nhwc_fwd.txt', 'nhwc_bwd.txt', 'overlaps_density.txt'):
     if os.path.exists(os.path.join(src, name)):
         with open(os.path.join(src, name)) as f, open('%s/%s_%s' % (dst, tag, name), 'w') as g:
             g.write(''.join(l for l in f if 'amdgpu.ids' not in l))
@@ -124,7 +126,7 @@ if os.path.isdir(src + '/trace_sim8') and find(src + '/trace_sim8', 'kernel_stat
     copy_stats(src + '/trace_sim8', '%s/%s_kernel_stats_cfg5_rank0_of_8.csv' % (dst, tag))
 rk = bench.get('roofline_kernels', {}).get('kernels', [])
 for r in rk:
-    if r['kernel'].startswith('rroi_'):
+    if r['kernel'].startswith(('rroi_', 'roi_')):
         names = r['kernel'].split('+')
         ks = [v for v in kern.values() if v['kernel'] in names and v['workload'] == r.get('tag')]
         if ks:
