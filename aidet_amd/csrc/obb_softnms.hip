@@ -921,6 +921,126 @@ __global__ __launch_bounds__(T) void soft_nms_fast_kernel(const float *__restric
   if (tid == 0) result[0] = picks;
 }
 
+// ---- the position-free kernel on ONE wave (round 5): arrays of up to 512 boxes -- the per-class arrays of a detection head,
+// the RPN's levels -- need no block: NB <= 8 boxes per lane, the round's pick is a wave reduction (four DPP steps, four
+// read-lanes) instead of two LDS maxima behind a barrier, the pick's corners come from a read-only LDS copy by a
+// broadcast read; no barrier, no atomics.  The rounds, the decay arithmetic and the give-up rule (a maximum shared by two
+// remaining boxes, a NaN score: result -2, the array kernel replays the call) are soft_nms_fast_kernel's -- same picks,
+// same bits.  A grouped call gives every group a wave of its own (one block of 64 threads per group).
+template <int NB>
+__global__ __launch_bounds__(64) void soft_nms_wave_kernel(const float *__restrict__ dets, int n, float thr, int method,
+                                                           float sigma, float min_score, float *__restrict__ out_dets,
+                                                           int64_t *__restrict__ out_inds, long long *__restrict__ result,
+                                                           const int64_t *__restrict__ seg) {
+  if (seg) {
+    const int64_t off = seg[blockIdx.x];
+    const int64_t m = seg[blockIdx.x + 1] - off;
+    dets += off * 5;
+    out_dets += off * 5;
+    out_inds += off;
+    result += blockIdx.x;
+    if (m <= 0) { if (threadIdx.x == 0) result[0] = 0; return; }
+    if (m > 64 * NB) { if (threadIdx.x == 0) result[0] = kSoftFastGiveUp; return; }     // (beyond the caller's bound)
+    n = (int)m;
+  }
+  __shared__ float4 cbox[64 * NB];
+  __shared__ float carea[64 * NB];
+  const int lane = threadIdx.x;
+  float x1[NB], y1[NB], x2[NB], y2[NB], sc[NB], ar[NB];
+  int rank[NB];
+  uint32_t live = 0u;
+  bool bad = false;
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int p = b * 64 + lane;                 // the box number: slot b of lane `lane`
+    const bool in = p < n;
+    const float *d = dets + (size_t)(in ? p : 0) * 5;
+    x1[b] = d[0]; y1[b] = d[1]; x2[b] = d[2]; y2[b] = d[3]; sc[b] = d[4];
+    ar[b] = ((x2[b] - x1[b]) + 1.0f) * ((y2[b] - y1[b]) + 1.0f);
+    rank[b] = -1;
+    if (in) { live |= 1u << b; bad = bad || (sc[b] != sc[b]); }
+    cbox[p] = make_float4(x1[b], y1[b], x2[b], y2[b]);
+    carea[p] = ar[b];
+  }
+  if (__ballot(bad) != 0ull) { if (lane == 0) result[0] = kSoftFastGiveUp; return; }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  int picks = 0;
+  for (;;) {
+    // the round's pick: the unique maximum of the live scores
+    uint32_t img[NB], best = 0u;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      img[b] = (live >> b & 1u) ? score_image32(sc[b]) : 0u;
+      best = img[b] > best ? img[b] : best;
+    }
+    const uint32_t wmax = wave_max_u32(best);
+    if (wmax == 0u) break;                                       // nothing left
+    uint32_t eq = 0u;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) eq |= (img[b] == wmax) ? (1u << b) : 0u;
+    const uint64_t owners = __ballot(eq != 0u);
+    const int fl = __builtin_ctzll(owners);
+    const uint32_t feq = (uint32_t)__builtin_amdgcn_readlane((int)eq, fl);
+    if (wmax == 0xFFFFFFFFu || (owners & (owners - 1ull)) != 0ull || (feq & (feq - 1u)) != 0u) {   // a NaN, or the maximum is not unique
+      if (lane == 0) result[0] = kSoftFastGiveUp;
+      return;
+    }
+    const int fs = __builtin_ctz(feq), gi = fs * 64 + fl;
+    const float4 a = cbox[gi];
+    const float iarea = carea[gi];
+    if (lane == fl) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) if (b == fs) { live &= ~(1u << b); rank[b] = picks; }
+    }
+    // nms_cpu.cpp:155-163 (= hbb_overlap) with the pick as box i, for all the lane's boxes first ...
+    float inter[NB], den[NB];
+    bool act[NB];
+    bool any = false;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const uint32_t bit = 1u << b;
+      const float xx1 = a.x < x1[b] ? x1[b] : a.x, yy1 = a.y < y1[b] ? y1[b] : a.y;
+      const float xx2 = x2[b] < a.z ? x2[b] : a.z, yy2 = y2[b] < a.w ? y2[b] : a.w;
+      const float ww = (xx2 - xx1) + 1.0f, hh = (yy2 - yy1) + 1.0f;
+      const float w = 0.0f < ww ? ww : 0.0f, h = 0.0f < hh ? hh : 0.0f;
+      inter[b] = w * h;
+      den[b] = (iarea + ar[b]) - inter[b];
+      // empty intersection over a positive denominator: ovr = +0, every method's weight is exactly 1: unchanged bit for bit
+      const bool skip = inter[b] == 0.0f && den[b] > 0.0f && (method == 2 || !(0.0f > thr));
+      act[b] = (live & bit) != 0u && !skip;
+      any = any || act[b];
+    }
+    // ... then ONE region with the divisions of all of them
+    if (__ballot(any) != 0ull) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const float ovr = inter[b] / den[b];
+        float weight = 1.0f;
+        if (method == 1) { if (ovr > thr) weight = 1.0f - ovr; }
+        else if (method == 2) weight = soft_exp(-(ovr * ovr) / sigma);
+        else weight = (ovr > thr) ? 0.0f : 1.0f;
+        if (act[b]) sc[b] = weight * sc[b];
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const uint32_t bit = 1u << b;
+      if ((live & bit) != 0u && sc[b] < min_score) live &= ~bit;      // (every examined box, decayed or not: nms_cpu.cpp:184)
+    }
+    ++picks;
+  }
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    if (rank[b] >= 0) {
+      float *o = out_dets + (size_t)rank[b] * 5;
+      o[0] = x1[b]; o[1] = y1[b]; o[2] = x2[b]; o[3] = y2[b]; o[4] = sc[b];
+      out_inds[rank[b]] = b * 64 + lane;
+    }
+  }
+  if (lane == 0) result[0] = picks;
+}
+
 // ---- the position-free kernel for float64 rows (soft_nms_cpu_kernel<double>): the same rounds, but a double's order image is
 // 64 bits wide and does not share a word with a box number -- the block's pick takes TWO LDS steps (the maximum image, then
 // the lowest / highest box number among the waves that hold it) and two barriers per round.  Up to 2048 rows (56 bytes of
@@ -1140,6 +1260,7 @@ static bool soft_launch_fast64(const double *dets, int64_t n, float thr, int met
 
 static thread_local int g_soft_path = -1;      // obb_soft_nms_last_path
 constexpr int kSoftFastMax = 4096;
+constexpr int kSoftWaveMax = 512;               // soft_nms_wave_kernel: 8 boxes per lane
 // (n = the array's rows, or -- grouped, seg != nullptr -- the caller's bound on the rows of one group)
 static bool soft_launch_fast(const float *dets, int64_t n, float thr, int method, float sigma, float min_score,
                              float *out_dets, int64_t *out_inds, long long *result, hipStream_t st,
@@ -1147,7 +1268,13 @@ static bool soft_launch_fast(const float *dets, int64_t n, float thr, int method
 #define OBB_SOFT_FAST(T, NB) hipLaunchKernelGGL((soft_nms_fast_kernel<T, NB>), dim3(groups), dim3(T), 0, st, dets, (int)n, thr, method, sigma, min_score, out_dets, out_inds, result, seg)
   // (four waves per SIMD hide the latency of the dependent chain -- division, the exponential -- that one wave per SIMD
   // waits out: 2048 boxes as 256 x 8 took 2.1 us per round in a dense scene)
-  const int64_t shape = tuning(OBB_TUNE_SOFT_NMS_SHAPE, 0);     // (0 default; 1: 256 threads x more boxes, for measurements)
+  const int64_t shape = tuning(OBB_TUNE_SOFT_NMS_SHAPE, 0);     // (0 default; 1: 256 threads x more boxes, for measurements; 3: never the one-wave kernel)
+#define OBB_SOFT_WAVE(NB) hipLaunchKernelGGL((soft_nms_wave_kernel<NB>), dim3(groups), dim3(64), 0, st, dets, (int)n, thr, method, sigma, min_score, out_dets, out_inds, result, seg)
+  if (shape == 0 && n <= kSoftWaveMax) {          // one wave: no barrier per round (the arrays a detection head hands over)
+    if (n <= 64) OBB_SOFT_WAVE(1); else if (n <= 128) OBB_SOFT_WAVE(2); else if (n <= 256) OBB_SOFT_WAVE(4); else OBB_SOFT_WAVE(8);
+    return true;
+  }
+#undef OBB_SOFT_WAVE
   if (shape == 1 && n <= 2048) {
     if (n <= 256) OBB_SOFT_FAST(256, 1); else if (n <= 512) OBB_SOFT_FAST(256, 2); else if (n <= 1024) OBB_SOFT_FAST(256, 4); else OBB_SOFT_FAST(256, 8);
   } else if (shape == 2 && n <= kSoftFastMax) {      // (512 x 8 holds kSoftFastMax boxes: larger arrays fall through to `return false`)

@@ -1,18 +1,35 @@
-import time, numpy as np, torch, sys
-sys.path.insert(0,'.')
+"""Soft-NMS on one array: the GPU kernels against the host loop (the oracle's restatement of nms_cpu.cpp:71-210) --
+python3 tools/bench_soft_nms.py.  Arrays of up to 512 boxes run on the one-wave kernel (round 5); `shape=3` forces the
+workgroup kernel they ran on until round 4.  Boxes of 8-200 px on a 900 px canvas; medians of 30 calls, host: best of 5."""
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, '.')
 import oracle
+from aidet_amd import _lib
 from aidet_amd.nms_wrapper import soft_nms
-rng=np.random.default_rng(2)
-for n in (500, 2000, 2048, 5000):
-    x1,y1=rng.uniform(0,900,n),rng.uniform(0,900,n)
-    hb=np.stack([x1,y1,x1+rng.uniform(8,200,n),y1+rng.uniform(8,200,n),(rng.permutation(n)+.5)/n],1).astype(np.float32)
-    hd=torch.from_numpy(hb).cuda()
+
+rng = np.random.default_rng(2)
+for n in (64, 100, 200, 300, 500, 700, 1000, 2000, 4096):
+    x1, y1 = rng.uniform(0, 900, n), rng.uniform(0, 900, n)
+    hb = np.stack([x1, y1, x1 + rng.uniform(8, 200, n), y1 + rng.uniform(8, 200, n), (rng.permutation(n) + .5) / n], 1).astype(np.float32)
+    hd = torch.from_numpy(hb).cuda()
     for method in ('linear', 'gaussian'):
-        ts=[]
-        for _ in range(8):
-            t0=time.perf_counter(); sd,si=soft_nms(hd,0.5,method=method,min_score=0.05); ts.append(time.perf_counter()-t0)
-        tcs=[]
-        for _ in range(3):
-            t0=time.perf_counter(); rd,ri=oracle.soft_nms(hb,0.5,method,0.5,0.05); tcs.append(time.perf_counter()-t0)
-        print(n, method, 'gpu ms %.3f'%(np.median(ts[2:])*1e3), 'cpu ms %.3f'%(min(tcs)*1e3), 'kept', len(ri),
-              np.array_equal(si.cpu().numpy(),ri) and np.array_equal(sd.cpu().numpy(),rd))
+        row = {}
+        for shape in (0, 3):
+            _lib.set_tuning(_lib.TUNE_SOFT_NMS_SHAPE, shape)
+            ts = []
+            for _ in range(34):
+                t0 = time.perf_counter(); sd, si = soft_nms(hd, 0.5, method=method, min_score=0.05); ts.append(time.perf_counter() - t0)
+            row[shape] = float(np.median(ts[4:])) * 1e3
+        _lib.set_tuning(_lib.TUNE_SOFT_NMS_SHAPE, -1)
+        tcs = []
+        for _ in range(5):
+            t0 = time.perf_counter(); rd, ri = oracle.soft_nms(hb, 0.5, method, 0.5, 0.05); tcs.append(time.perf_counter() - t0)
+        cpu = min(tcs) * 1e3
+        same = np.array_equal(si.cpu().numpy(), ri) and np.array_equal(sd.cpu().numpy(), rd)
+        print('n %5d %-8s gpu %.3f ms (workgroup kernel %.3f) | host loop %.3f ms | x%.2f | kept %d, bit- and index-equal: %s'
+              % (n, method, row[0], row[3], cpu, cpu / row[0], len(ri), same), flush=True)
