@@ -3638,6 +3638,32 @@ static int nms_enqueue(const char *who, const float *dets_dev, int64_t n, int ki
   return nms_enqueue_source(who, src, n, kind, iou_thr, flags_in, keep_dev, result, workspace_dev, workspace_bytes, st, q);
 }
 
+// Waiting for a synchronous call.  Its last kernel's last act is the 64-byte result record, written straight into pinned
+// host memory: the host fills the record with ones before it queues the call and then WATCHES it -- every word different
+// from the fill = the record is here (no field of a record is all ones; the words may arrive in any order) -- instead of
+// sleeping in hipStreamSynchronize, whose wake-up costs several microseconds of a 60 us call.  The stream may still be
+// retiring that kernel when the entry point returns: whatever is queued behind it is ordered as usual.  A record that has
+// not come after ~1 ms (a long call, a fault) is waited for the old way, which also surfaces the stream's error.
+static void nms_record_arm(NmsHostInfo *host) {
+  volatile unsigned long long *w = reinterpret_cast<volatile unsigned long long *>(host);
+  for (size_t i = 0; i < sizeof(NmsHostInfo) / 8; ++i) w[i] = ~0ull;
+  __atomic_thread_fence(__ATOMIC_SEQ_CST);
+}
+static int nms_record_wait(NmsHostInfo *host, hipStream_t st, bool must_sync) {
+  if (!must_sync) {
+    volatile unsigned long long *w = reinterpret_cast<volatile unsigned long long *>(host);
+    for (int spin = 0; spin < 200000; ++spin) {
+      bool all = true;
+      for (size_t i = 0; i < sizeof(NmsHostInfo) / 8; ++i) all = all && (w[i] != ~0ull);
+      if (all) { __atomic_thread_fence(__ATOMIC_ACQUIRE); return OBB_OK; }
+      __builtin_ia32_pause();
+    }
+  }
+  OBB_HIP_TRY(hipStreamSynchronize(st));
+  return OBB_OK;
+}
+static_assert(sizeof(NmsHostInfo) % 8 == 0 && sizeof(NmsHostInfo) <= 64, "the record is watched word by word");
+
 // one pinned, device-mapped result record per calling thread (synchronous entry points)
 static int nms_pinned_record(NmsHostInfo *&host, NmsHostInfo *&dev) {
   static thread_local NmsHostInfo *hinfo = nullptr;
@@ -3682,10 +3708,13 @@ extern "C" int obb_nms_ex_f32(const float *dets_dev, int64_t n, int kind, float 
   if (rc != OBB_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
   NmsEnqueued q;
+  const bool watch = tuning(OBB_TUNE_NMS_WATCH_RECORD, 1) != 0;
+  nms_record_arm(hinfo);
   rc = nms_enqueue("obb_nms_f32", dets_dev, n, kind, iou_thr, group_dev, thr_dev, flags, keep_dev, hinfo_dev,
                    workspace_dev, workspace_bytes, st, q, true);
   if (rc != OBB_OK) return rc;
-  OBB_HIP_TRY(hipStreamSynchronize(st));
+  rc = nms_record_wait(hinfo, st, q.timed || !watch);
+  if (rc != OBB_OK) return rc;
   g_last_route = q.grid ? 4 : (q.fused ? 0 : (q.direct ? 1 : 2));
   if (q.grid && (hinfo->route & 0xFFu) == 3u) {
     g_last_route = 5;
@@ -3693,10 +3722,13 @@ extern "C" int obb_nms_ex_f32(const float *dets_dev, int64_t n, int kind, float 
     // thread's next calls of the size class go there directly
     grid_skip_put(n, kind + ((group_dev != nullptr) ? 4 : 0));
     q = NmsEnqueued();
+    OBB_HIP_TRY(hipStreamSynchronize(st));       // (the call that gave up has retired before the record is armed again)
+    nms_record_arm(hinfo);
     rc = nms_enqueue("obb_nms_f32", dets_dev, n, kind, iou_thr, group_dev, thr_dev, flags, keep_dev, hinfo_dev,
                      workspace_dev, workspace_bytes, st, q, false);
     if (rc != OBB_OK) return rc;
-    OBB_HIP_TRY(hipStreamSynchronize(st));
+    rc = nms_record_wait(hinfo, st, q.timed || !watch);
+    if (rc != OBB_OK) return rc;
   }
   const NmsHostInfo h = *hinfo;
   NmsProfile &prof = g_prof;

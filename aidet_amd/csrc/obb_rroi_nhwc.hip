@@ -45,14 +45,14 @@ constexpr int kNhwcTileBins = 49;          // bins of one output tile when the s
 //            2 x 2 samples: one round); a bin of more than 256 samples (adaptive grids of huge RoIs) is summed over
 //            several rounds by its one slot
 //   tiles    the LDS tile holds CS x TB sums: TB = all bins when they fit (then the copy-out is linear)
-// mode 0: block id -> (position id / slabs, slab id % slabs).  mode 1 (with an order; slabs divides 8): the XCD of a block
-// (id & 7 under round-robin dispatch; a speed assumption only) takes slab xcd % slabs and a CONTIGUOUS range of the
-// Morton-ordered RoIs, so that RoIs that run together on an XCD share map lines in its L2.
+// block id -> (RoI id / slabs, slab id % slabs).  (Measured and dropped, LOG round 5: the RoIs in Morton order with one
+// contiguous range of the order per XCD -- the order launch costs more than the locality gives here, the XCDs' L2s absorb
+// the overlap of the footprints as it is: counter traffic 1.03 x the algorithmic bytes.)
 template <int NQ, int NW>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void roi_forward_nhwc_kernel(
     const LevelTable lv, const int *__restrict__ roi_level, int num_levels, int B, int C,
-    const float *__restrict__ rois, int ph, int pw, int sample_num, float min_size, int K, int slabs, int mode,
-    int roi_kind, const int *__restrict__ roi_order, float *__restrict__ out, int out_vec4) {
+    const float *__restrict__ rois, int ph, int pw, int sample_num, float min_size, int K, int slabs,
+    int roi_kind, float *__restrict__ out, int out_vec4) {
   constexpr int CS = 4 * NQ;                 // channels of a slab
   constexpr int SL = 64 / NQ;                // slots per wave
   constexpr int kSlots = NW * SL;            // ... per block
@@ -64,25 +64,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void roi_forward_nhwc_ker
   __shared__ RoiFrame s_frame;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int slot = lane / NQ, quad = lane - slot * NQ, sid = wave * SL + slot;
-  int64_t pos;
-  int slab;
   OBB_NSTAMP(6);
   OBB_NSTAMP(0);
-  if (mode == 1) {
-    const int xcd = (int)(blockIdx.x & 7u), groups = 8 / slabs;
-    const int per = (K + groups - 1) / groups, j = (int)(blockIdx.x >> 3);
-    slab = xcd % slabs;
-    pos = (int64_t)(xcd / slabs) * per + j;
-    if (j >= per || pos >= K) return;
-  } else {
-    pos = blockIdx.x / (unsigned)slabs;
-    slab = (int)(blockIdx.x - (unsigned)pos * (unsigned)slabs);
-  }
-  int64_t k = pos;
-  if (roi_order) {
-    const int kk = roi_order[pos];
-    if (kk >= 0 && kk < K) k = kk;
-  }
+  const int64_t k = blockIdx.x / (unsigned)slabs;
+  const int slab = (int)(blockIdx.x - (unsigned)k * (unsigned)slabs);
   const int lvl_raw = roi_level ? roi_level[k] : 0;
   const bool lvl_ok = lvl_raw >= 0 && lvl_raw < num_levels;
   const int lvl = lvl_ok ? lvl_raw : 0;
@@ -245,25 +230,15 @@ static int roi_forward_nhwc_launch(const char *who, const LevelTable &lv, int nu
   if (!rois_dev || !out_dev) return set_err(OBB_EINVAL, "%s: null pointer", who);
   const int nq = nhwc_pick_nq(C);
   const int slabs = (C + 4 * nq - 1) / (4 * nq);
-  const int *order = nullptr;
-  if (order_ws && K >= tuning(OBB_TUNE_RROI_ORDER_MIN, 1024) && K <= kOrderMaxK) {
-    int rc = rroi_order_launch(lv, roi_level_dev, num_levels, rois_dev, K, roi_kind, order_ws, stream);
-    if (rc != OBB_OK) return rc;
-    order = order_ws;
-  }
-  int mode = 0;
-  unsigned long long nblk = (unsigned long long)K * (unsigned)slabs;
-  if (order && slabs <= 8 && 8 % slabs == 0 && tuning(OBB_TUNE_RROI_NHWC_XCD, 1) != 0) {
-    const int groups = 8 / slabs;
-    mode = 1;
-    nblk = 8ull * (unsigned long long)((K + groups - 1) / groups);
-  }
+  (void)order_ws;      // (a workspace is accepted for the signature of obb_roi_align_forward_ws_f32; nothing is ordered here)
+  const unsigned long long nblk = (unsigned long long)K * (unsigned)slabs;
   if (nblk > 2147483647ull) return set_err(OBB_EINVAL, "%s: too many blocks (K=%lld, C=%d)", who, (long long)K, C);
   const int vec4 = (reinterpret_cast<uintptr_t>(out_dev) & 15u) == 0 ? 1 : 0;
-  const int nw = tuning(OBB_TUNE_RROI_NHWC_WAVES, 4) == 8 ? 8 : 4;
+  // (more than two RoIs per CU: 8 waves per block -- 2000 RoIs 73.5 us against 80; at 512 RoIs both take 24 us)
+  const int nw = tuning(OBB_TUNE_RROI_NHWC_WAVES, K >= 1024 ? 8 : 4) == 8 ? 8 : 4;
 #define OBB_NHWC_FWD(NQ, NW)                                                                                               \
   hipLaunchKernelGGL((roi_forward_nhwc_kernel<NQ, NW>), dim3((unsigned)nblk), dim3(64 * NW), 0, (hipStream_t)stream, lv, roi_level_dev, \
-                     num_levels, B, C, rois_dev, ph, pw, sample_num, min_size, (int)K, slabs, mode, roi_kind, order, out_dev, vec4)
+                     num_levels, B, C, rois_dev, ph, pw, sample_num, min_size, (int)K, slabs, roi_kind, out_dev, vec4)
   switch (nq + nw) {
     case 64 + 4: OBB_NHWC_FWD(64, 4); break;
     case 64 + 8: OBB_NHWC_FWD(64, 8); break;

@@ -921,8 +921,8 @@ __global__ __launch_bounds__(T) void soft_nms_fast_kernel(const float *__restric
   if (tid == 0) result[0] = picks;
 }
 
-// ---- the position-free kernel on ONE wave (round 5): arrays of up to 512 boxes -- the per-class arrays of a detection head,
-// the RPN's levels -- need no block: NB <= 8 boxes per lane, the round's pick is a wave reduction (four DPP steps, four
+// ---- the position-free kernel on ONE wave (round 5): small arrays -- the per-class arrays of a detection head -- need no
+// block: NB <= 8 boxes per lane, the round's pick is a wave reduction (four DPP steps, four
 // read-lanes) instead of two LDS maxima behind a barrier, the pick's corners come from a read-only LDS copy by a
 // broadcast read; no barrier, no atomics.  The rounds, the decay arithmetic and the give-up rule (a maximum shared by two
 // remaining boxes, a NaN score: result -2, the array kernel replays the call) are soft_nms_fast_kernel's -- same picks,
@@ -1260,7 +1260,7 @@ static bool soft_launch_fast64(const double *dets, int64_t n, float thr, int met
 
 static thread_local int g_soft_path = -1;      // obb_soft_nms_last_path
 constexpr int kSoftFastMax = 4096;
-constexpr int kSoftWaveMax = 512;               // soft_nms_wave_kernel: 8 boxes per lane
+constexpr int kSoftWaveMax = 64;                // soft_nms_wave_kernel by default: one box per lane (see soft_launch_fast)
 // (n = the array's rows, or -- grouped, seg != nullptr -- the caller's bound on the rows of one group)
 static bool soft_launch_fast(const float *dets, int64_t n, float thr, int method, float sigma, float min_score,
                              float *out_dets, int64_t *out_inds, long long *result, hipStream_t st,
@@ -1270,7 +1270,11 @@ static bool soft_launch_fast(const float *dets, int64_t n, float thr, int method
   // waits out: 2048 boxes as 256 x 8 took 2.1 us per round in a dense scene)
   const int64_t shape = tuning(OBB_TUNE_SOFT_NMS_SHAPE, 0);     // (0 default; 1: 256 threads x more boxes, for measurements; 3: never the one-wave kernel)
 #define OBB_SOFT_WAVE(NB) hipLaunchKernelGGL((soft_nms_wave_kernel<NB>), dim3(groups), dim3(64), 0, st, dets, (int)n, thr, method, sigma, min_score, out_dets, out_inds, result, seg)
-  if (shape == 0 && n <= kSoftWaveMax) {          // one wave: no barrier per round (the arrays a detection head hands over)
+  // One wave serves the arrays of up to 64 boxes (one per lane): 45 us per call against the workgroup kernel's 68.  Beyond
+  // that a single wave ISSUES too slowly -- measured (tools/bench_soft_nms.py, linear): 100 boxes 80 vs 89 us, 200: 220 vs
+  // 154, 500 boxes (8 per lane): 915 vs 350 us: ~2 us per round, every instruction of the round's eight decays waits its
+  // turn on one SIMD, where the workgroup kernel spreads them over sixteen waves.  shape 4 forces it up to 512 boxes (tests).
+  if ((shape == 0 && n <= kSoftWaveMax) || (shape == 4 && n <= 512)) {
     if (n <= 64) OBB_SOFT_WAVE(1); else if (n <= 128) OBB_SOFT_WAVE(2); else if (n <= 256) OBB_SOFT_WAVE(4); else OBB_SOFT_WAVE(8);
     return true;
   }

@@ -124,7 +124,8 @@ OBB_API int obb_hbb_overlaps_f64(const double *a_dev, int64_t m, const double *b
  *              sorted route's arrays) plus, for 256 <= n <= 2^24, the cell table of the uniform-grid route: 512 bytes
  *              per cell, about n / 2.5 cells (a power of two, at most 2^22 = 2 GiB) -- 150 MB at n = 1e5, 2 GB at
  *              1.25e6, 13.8 GB at 1e7.
- * Synchronises `stream` before returning.
+ * Returns when the call's result record has arrived in host memory (the last act of its last kernel: keep_dev and K are
+ * final; `stream` may still be retiring that kernel -- work queued behind it is ordered as usual).
  * ------------------------------------------------------------------------- */
 OBB_API size_t obb_nms_workspace_bytes(int64_t n, int kind, int64_t pair_capacity);
 OBB_API int obb_nms_f32(const float *dets_dev, int64_t n, int kind, float iou_thr,
@@ -351,8 +352,8 @@ OBB_API int obb_roi_align_forward_ws_f32(const float *const *feat_devs_host, con
 /* ---------------------------------------------------------------------------
  * RoI-Align forward on CHANNELS-LAST maps: feat_devs_host[l] points at a (B, H_l, W_l, C) fp32 array -- the memory of
  * a PyTorch (B, C, H, W) tensor in torch.channels_last -- everything else (RoI kinds, levels, sampling and tap rules,
- * the optional workspace of obb_roi_forward_workspace_bytes(K) bytes for the Morton order, the (K, C, ph, pw) output
- * in the reference's layout) is obb_roi_align_forward_ws_f32.  Values are bit-equal to that entry point on the
+ * the (K, C, ph, pw) output in the reference's layout) is obb_roi_align_forward_ws_f32; the workspace arguments are
+ * accepted for that signature and not used (ordering the RoIs does not pay on this layout).  Values are bit-equal to that entry point on the
  * permuted map.  C % 4 == 0, 16-byte aligned maps, H * W * C < 2^30 per image; OBB_EINVAL otherwise (the Python wrapper
  * then copies the map to NCHW, as the reference's `features.contiguous()` would).
  * Replaces: RoIAlign V1 / V2 forward (roi_align_kernel.cu:64-141, roi_align_kernel_v2.cu:62-128), which read NCHW
@@ -624,11 +625,12 @@ OBB_API int obb_roi_backward_gather_nhwc_f32(const float *grad_out_dev, int B, i
 #define OBB_TUNE_NMS_FUSED_COMPACT 10  /* 0: the sorted route's compaction as a launch of its own (as from 2^18 boxes on); 2: the waiting shards give up at once */
 #define OBB_TUNE_RROI_PLAN 11          /* fewest RoIs the workspace forward of RoI-Align plans per RoI (default 1024; 0 = always) */
 #define OBB_TUNE_NMS_GRID 12           /* grid route of the NMS: 0 never, 1 wherever it applies, 2 the same but it gives up at once (test hook for the repeat paths); default auto.  Setting it clears the calling thread's "skip the grid" notes */
-#define OBB_TUNE_SOFT_NMS_SHAPE 13     /* 1: the position-free Soft-NMS kernel as 256 threads x up to 8 boxes (default: up to 1024 threads x 1-4 boxes) */
+#define OBB_TUNE_SOFT_NMS_SHAPE 13     /* 1: the position-free Soft-NMS kernel as 256 threads x up to 8 boxes (default: up to 1024 threads x 1-4 boxes; <= 64 boxes: one wave); 3: never the one-wave kernel; 4: the one-wave kernel up to 512 boxes */
 #define OBB_TUNE_RROI_NHWC_NQ 14       /* channels-last RoI-Align forward: lanes per tap = slab of 4 x NQ channels per block (8, 16, 32, 64) */
-#define OBB_TUNE_RROI_NHWC_XCD 15      /* channels-last RoI-Align forward with an order: 0 = plain block -> RoI map instead of one contiguous range of the order per XCD */
+#define OBB_TUNE_RROI_NHWC_XCD 15      /* (unused since the channels-last forward stopped ordering its RoIs; kept so that the knob numbers stay put) */
 #define OBB_TUNE_RROI_NHWC_WAVES 16   /* channels-last RoI-Align forward: waves per block (4 or 8) */
-#define OBB_TUNE_COUNT 17
+#define OBB_TUNE_NMS_WATCH_RECORD 17   /* 0: the synchronous NMS entry point sleeps in hipStreamSynchronize instead of watching its pinned result record */
+#define OBB_TUNE_COUNT 18
 OBB_API int obb_set_tuning(int knob, int64_t value);
 /* which route the calling thread's last synchronous obb_nms_*_f32 call took: 0 fused (one workgroup), 1 direct, 2 sorted,
  * 4 grid, 5 grid gave up (crowded cell) and the call was repeated on the sorted route; -1 none yet */

@@ -44,8 +44,6 @@ def nhwc_nq():
         _lib.set_tuning(_lib.TUNE_RROI_NHWC_NQ, nq)
     yield force
     _lib.set_tuning(_lib.TUNE_RROI_NHWC_NQ, -1)
-    _lib.set_tuning(_lib.TUNE_RROI_ORDER_MIN, -1)
-    _lib.set_tuning(_lib.TUNE_RROI_NHWC_XCD, -1)
 
 
 # ---- channels-last RoI-Align forward ---------------------------------------------------------------
@@ -96,10 +94,9 @@ def test_nhwc_forward_horizontal_kinds(aligned, nhwc_nq):
         assert np.abs(b.cpu().numpy()[ok] - ref[ok]).max() <= TOL
 
 
-def test_nhwc_forward_cfg3_and_the_ordered_launch(nhwc_nq):
+def test_nhwc_forward_cfg3_and_many_rois(nhwc_nq):
     """BASELINE.json configs[2] (512 rotated RoIs, 256 x 256 x 256 map, 7 x 7) on a channels-last map: <= 1e-4 from the
-    oracle, bit-equal to the NCHW kernel; and the same call with the Morton order forced (one contiguous range of the
-    order per XCD, and the plain block map) -- which block computes a RoI never changes a value."""
+    oracle, bit-equal to the NCHW kernel; 2000 RoIs (the workspace route of the Python layer, 8 waves per block): the same."""
     from aidet_amd import RRoIAlign, _lib
     rng = np.random.default_rng(5)
     feat = rng.standard_normal((1, 256, 256, 256)).astype(np.float32)
@@ -110,18 +107,14 @@ def test_nhwc_forward_cfg3_and_the_ordered_launch(nhwc_nq):
     got = layer(fl, t(rois))
     assert np.abs(got.cpu().numpy() - ref).max() <= TOL
     assert torch.equal(got, layer(t(feat), t(rois)))
-    from aidet_amd import roi_layers
-    old = roi_layers.ORDER_MIN_ROIS
-    try:
-        roi_layers.ORDER_MIN_ROIS = 1
-        _lib.set_tuning(_lib.TUNE_RROI_ORDER_MIN, 1)
-        for nq in (64, 32, 16):
-            nhwc_nq(nq)
-            for xcd in (1, 0):
-                _lib.set_tuning(_lib.TUNE_RROI_NHWC_XCD, xcd)
-                assert torch.equal(layer(fl, t(rois)), got)
-    finally:
-        roi_layers.ORDER_MIN_ROIS = old
+    many = t(_rois(2000, 1024, 8))
+    want = layer(t(feat), many)
+    for nw in (-1, 4, 8):
+        _lib.set_tuning(_lib.TUNE_RROI_NHWC_WAVES, nw)
+        try:
+            assert torch.equal(layer(fl, many), want)
+        finally:
+            _lib.set_tuning(_lib.TUNE_RROI_NHWC_WAVES, -1)
 
 
 def test_nhwc_pyramid_extractor_and_fallbacks(nhwc_nq):
@@ -360,10 +353,10 @@ def test_aug_test_of_the_detector():
 # ---- Soft-NMS on one wave (VERDICT r4 "next" 4) --------------------------------------------------------------------------
 @pytest.mark.parametrize('method', ['linear', 'gaussian'])
 def test_soft_nms_one_wave_kernel_equals_the_host_loop_and_the_workgroup_kernel(method):
-    """Arrays of up to 512 boxes run on soft_nms_wave_kernel (NB = 1, 2, 4, 8 boxes per lane): index- and bit-equal to the
-    oracle's loop (nms_cpu.cpp:71-210) and to the workgroup kernel (OBB_TUNE_SOFT_NMS_SHAPE = 3) at every size class, on
-    dense and sparse scenes, with score ties (the kernel gives up, the array kernel replays the permutation), drops in
-    the last rounds, and as the per-class arrays of a grouped call."""
+    """soft_nms_wave_kernel (arrays of up to 64 boxes by default; OBB_TUNE_SOFT_NMS_SHAPE = 4 forces it up to 512: NB = 1, 2,
+    4, 8 boxes per lane): index- and bit-equal to the oracle's loop (nms_cpu.cpp:71-210) and to the workgroup kernel
+    (shape 3) at every size class, on dense and sparse scenes, with score ties (the kernel gives up, the array kernel
+    replays the permutation) and drops in the last rounds."""
     from aidet_amd import _lib
     from aidet_amd.nms_wrapper import soft_nms
     rng = np.random.default_rng(11)
@@ -375,7 +368,7 @@ def test_soft_nms_one_wave_kernel_equals_the_host_loop_and_the_workgroup_kernel(
                 sc = np.round(sc * 8) / 8
             hb = np.stack([x1, y1, x1 + rng.uniform(8, 120, n), y1 + rng.uniform(8, 120, n), sc], 1).astype(np.float32)
             want_d, want_i = oracle.soft_nms(hb, 0.3, method, 0.5, 0.05)
-            for shape in (0, 3):
+            for shape in (0, 3, 4):
                 try:
                     _lib.set_tuning(_lib.TUNE_SOFT_NMS_SHAPE, shape)
                     d, i = soft_nms(t(hb), 0.3, method=method, sigma=0.5, min_score=0.05)

@@ -45,22 +45,6 @@ def main():
             variants['nhwc nq=%d waves=%d (C ABI)' % (nq, nw)] = f
     run('configs[2] 512 RoIs', variants)
     _lib.set_tuning(_lib.TUNE_RROI_NHWC_WAVES, -1)
-    # with the Morton order (workspace) forced at 512 RoIs
-    old = roi_layers.ORDER_MIN_ROIS
-    roi_layers.ORDER_MIN_ROIS = 1
-    _lib.set_tuning(_lib.TUNE_RROI_ORDER_MIN, 1)
-    variants = {}
-    for nq in (64, 32, 16):
-        for xcd in (1, 0):
-            def f(nq=nq, xcd=xcd):
-                _lib.set_tuning(_lib.TUNE_RROI_NHWC_NQ, nq)
-                _lib.set_tuning(_lib.TUNE_RROI_NHWC_XCD, xcd)
-                return layer(fl, rois)
-            variants['nhwc ordered nq=%d xcd=%d' % (nq, xcd)] = f
-    run('configs[2] 512 RoIs', variants)
-    roi_layers.ORDER_MIN_ROIS = old
-    _lib.set_tuning(_lib.TUNE_RROI_ORDER_MIN, -1)
-    _lib.set_tuning(_lib.TUNE_RROI_NHWC_XCD, -1)
     # 2000 RoIs on one 256^2 map (the config-4 shape's first level, covered 22x)
     feat2, rois2 = bench.make_rroi(dev, K=2000)
     fl2 = feat2.contiguous(memory_format=torch.channels_last)
@@ -70,21 +54,9 @@ def main():
         for nw in (4, 8):
             def f(nq=nq, nw=nw):
                 _lib.set_tuning(_lib.TUNE_RROI_NHWC_NQ, nq)
-                _lib.set_tuning(_lib.TUNE_RROI_NHWC_XCD, 0)
                 _lib.set_tuning(_lib.TUNE_RROI_NHWC_WAVES, nw)
                 return layer(fl2, rois2)
             variants['nhwc nq=%d waves=%d' % (nq, nw)] = f
-    old = roi_layers.ORDER_MIN_ROIS
-    roi_layers.ORDER_MIN_ROIS = 1 << 30
-
-    def unordered():
-        _lib.set_tuning(_lib.TUNE_RROI_NHWC_NQ, 64)
-        _lib.set_tuning(_lib.TUNE_RROI_NHWC_WAVES, 8)
-        roi_layers.ORDER_MIN_ROIS = 1 << 30
-        r = layer(fl2, rois2)
-        roi_layers.ORDER_MIN_ROIS = old
-        return r
-    variants['nhwc nq=64 waves=8 unordered'] = unordered
     run('2000 RoIs, 256^2 map', variants)
 
 
