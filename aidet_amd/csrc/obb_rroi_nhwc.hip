@@ -288,8 +288,8 @@ static_assert(kNEnt >= kBwdMaxEntries, "one RoI's entries fit the batch buffer")
 // all pairs at once, one round trip; (2) a scan per pixel over the RoIs lays the pixels' runs out pixel-major, RoI order
 // inside (= the summation order); (3) the pairs copy their entries into the runs as (row of gT, weight); (4) a wave
 // streams the runs of its 16 pixels.  Every step's global loads are independent of each other.
-template <int NB>
-__global__ __launch_bounds__(256) void roi_gather_nhwc_kernel(
+template <int NB, int NWV>
+__global__ __launch_bounds__(64 * NWV) void roi_gather_nhwc_kernel(
     const float *__restrict__ gT, int C, int H, int W, int K, int nb_rt, const RoiPlan *__restrict__ plan,
     const unsigned short *__restrict__ rstart, const int2 *__restrict__ rentry, float *__restrict__ gfeat) {
   __shared__ int list[kNList];
@@ -298,7 +298,8 @@ __global__ __launch_bounds__(256) void roi_gather_nhwc_kernel(
   __shared__ unsigned short e0s[kNBatch][kNPix];           // ... first entry in the RoI's own list
   __shared__ int pbase[kNPix + 1];                         // first entry of every pixel's run
   __shared__ __attribute__((aligned(16))) int2 ent[kNEnt]; // (row of gT, weight bits)
-  __shared__ int wcnt[4];
+  __shared__ int wcnt[NWV];
+  constexpr int kT = 64 * NWV;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nb = NB ? NB : nb_rt;
   const int tiles_x = (W + kNT - 1) / kNT;
@@ -314,13 +315,13 @@ __global__ __launch_bounds__(256) void roi_gather_nhwc_kernel(
     // about a quarter of the batch's ENTRIES -- and sums their runs back to back: kNDepth rows in flight whatever pixel they
     // belong to (groups cut at pixel boundaries -- a pixel has ~3 entries -- are a round trip per pixel: 53 us instead of 42)
     auto stream = [&](bool have) {
-      int p0 = 16 * wave, p1 = 16 * wave + 16;
+      int p0 = (kNPix / NWV) * wave, p1 = p0 + kNPix / NWV;
       if (have) {
         const int total = pbase[kNPix];
         const int mine = pbase[lane];                        // (lane = pixel)
-        const uint64_t lo = __ballot(mine * 4 >= total * wave), hi = __ballot(mine * 4 >= total * (wave + 1));
+        const uint64_t lo = __ballot(mine * NWV >= total * wave), hi = __ballot(mine * NWV >= total * (wave + 1));
         p0 = wave == 0 ? 0 : (lo ? __ffsll((long long)lo) - 1 : kNPix);
-        p1 = wave == 3 ? kNPix : (hi ? __ffsll((long long)hi) - 1 : kNPix);
+        p1 = wave == NWV - 1 ? kNPix : (hi ? __ffsll((long long)hi) - 1 : kNPix);
       }
       if (p0 >= p1) return;
       int e = have ? __builtin_amdgcn_readfirstlane(pbase[p0]) : 0;
@@ -368,7 +369,7 @@ __global__ __launch_bounds__(256) void roi_gather_nhwc_kernel(
       // ---- the RoIs whose footprint meets this tile, in RoI order (rroi_gather_kernel's list), with their footprints
       int n = 0;
       const int lim = min(K, base + kNList);
-      for (int r0 = base; r0 < lim; r0 += 256) {
+      for (int r0 = base; r0 < lim; r0 += kT) {
         const int r = r0 + tid;
         const RoiPlan p = plan[min(r, lim - 1)];
         const bool hit = r < lim && p.state == 1 && p.b == b && p.x0 < tx0 + kNT && p.x0 + p.w > tx0 && p.y0 < ty0 + kNT && p.y0 + p.h > ty0;
@@ -377,7 +378,7 @@ __global__ __launch_bounds__(256) void roi_gather_nhwc_kernel(
         __syncthreads();
         int off = 0, tot = 0;
 #pragma unroll
-        for (int w2 = 0; w2 < 4; ++w2) { const int v = wcnt[w2]; off += (w2 < wave) ? v : 0; tot += v; }
+        for (int w2 = 0; w2 < NWV; ++w2) { const int v = wcnt[w2]; off += (w2 < wave) ? v : 0; tot += v; }
         if (hit) {
           const int pos = n + off + __popcll(mk & ((1ull << lane) - 1ull));
           list[pos] = r;
@@ -392,7 +393,7 @@ __global__ __launch_bounds__(256) void roi_gather_nhwc_kernel(
         while (true) {
           cur = min(nbr, n - rb0);
           // (1) bounds of every (RoI of the batch, pixel) list
-          for (int idx = tid; idx < cur * kNPix; idx += 256) {
+          for (int idx = tid; idx < cur * kNPix; idx += kT) {
             const int rl = idx >> 6, pp = idx & 63;
             const int4 f = foot[rb0 + rl];
             const int px = tx0 + (pp & 7) - f.x, py = ty0 + (pp >> 3) - f.y;
@@ -423,7 +424,7 @@ __global__ __launch_bounds__(256) void roi_gather_nhwc_kernel(
           __syncthreads();
         }
         // (3) the pairs copy their entries into the pixels' runs
-        for (int idx = tid; idx < cur * kNPix; idx += 256) {
+        for (int idx = tid; idx < cur * kNPix; idx += kT) {
           const int rl = idx >> 6, pp = idx & 63;
           const unsigned int v = mo[rl][pp];
           const int m = (int)(v & 0xFFFFu), off = (int)(v >> 16);
@@ -589,10 +590,15 @@ extern "C" int obb_roi_backward_gather_nhwc_f32(const float *grad_out_dev, int B
                         stream, grad_out_dev, gT, C);
   if (rc != OBB_OK) return rc;
   const dim3 ggrid((unsigned)(tiles_x * tiles_y), (unsigned)B);
-  if (nb == 49)
-    hipLaunchKernelGGL(roi_gather_nhwc_kernel<49>, ggrid, dim3(256), 0, st, gT, C, H, W, (int)K, nb, plan, rstart, rentry, grad_feat_dev);
-  else
-    hipLaunchKernelGGL(roi_gather_nhwc_kernel<0>, ggrid, dim3(256), 0, st, gT, C, H, W, (int)K, nb, plan, rstart, rentry, grad_feat_dev);
+  // waves per tile (OBB_TUNE_RROI_NHWC_GATHER_WAVES: 4, 8, 16).  The launch ends with its heaviest tile (a few small RoIs
+  // put ~900 entries on one: ~19 round trips of 12 rows for each of four waves), but more waves per tile do not help:
+  // measured whole call at configs[2] 60.1 / 63.1 / 82.5 us with 4 / 8 / 16 (2000 RoIs: 229 / 261 / 329) -- the bigger
+  // blocks halve the resident tiles and lengthen every barrier of the list / bounds / scan / fill chain.
+  const int gw = (int)tuning(OBB_TUNE_RROI_NHWC_GATHER_WAVES, 4);
+#define OBB_NHWC_GATHER(NBV, WV) hipLaunchKernelGGL((roi_gather_nhwc_kernel<NBV, WV>), ggrid, dim3(64 * WV), 0, st, gT, C, H, W, (int)K, nb, plan, rstart, rentry, grad_feat_dev)
+  if (nb == 49) { if (gw == 4) OBB_NHWC_GATHER(49, 4); else if (gw == 8) OBB_NHWC_GATHER(49, 8); else OBB_NHWC_GATHER(49, 16); }
+  else { if (gw == 4) OBB_NHWC_GATHER(0, 4); else if (gw == 8) OBB_NHWC_GATHER(0, 8); else OBB_NHWC_GATHER(0, 16); }
+#undef OBB_NHWC_GATHER
   OBB_LAUNCH_CHECK();
   hipLaunchKernelGGL(roi_backward_nhwc_direct_kernel, dim3((unsigned)K), dim3(256), 0, st, gT, B, C, H, W, rois_dev, ph, pw, spatial_scale,
                      sample_num, min_size, roi_kind, plan, grad_feat_dev);

@@ -26,9 +26,12 @@ for K in (512, 2000):
                                                       gl.data_ptr(), wl.data_ptr(), wl.numel(), st))
     nchw(); nhwc()
     print('K=%d  bit-equal to the NCHW gather: %s' % (K, bool(torch.equal(gl.contiguous(), gm))))
-    res = {'nchw gather': [], 'nhwc gather': []}
+    res = {'nchw gather': [], 'nhwc gather, 4 waves per tile': [], 'nhwc gather, 8 waves per tile': [], 'nhwc gather, 16 waves per tile': []}
     for _ in range(7):
         res['nchw gather'].append(bench._time_gpu(nchw, 20))
-        res['nhwc gather'].append(bench._time_gpu(nhwc, 20))
+        for gw in (4, 8, 16):
+            _lib.set_tuning(_lib.TUNE_RROI_NHWC_GATHER_WAVES, gw)
+            res['nhwc gather, %d waves per tile' % gw].append(bench._time_gpu(nhwc, 20))
+        _lib.set_tuning(_lib.TUNE_RROI_NHWC_GATHER_WAVES, -1)
     for k, v in res.items():
-        print('K=%-5d %-12s median %.4f ms  min %.4f ms' % (K, k, float(np.median(v)), min(v)), flush=True)
+        print('K=%-5d %-32s median %.4f ms  min %.4f ms' % (K, k, float(np.median(v)), min(v)), flush=True)
