@@ -132,3 +132,78 @@ def test_fuzz_overlaps_and_rroi_align(block):
         if np.abs(ft.grad.cpu().numpy() - rb).max() > 1e-4 * max(1.0, np.abs(rb).max()):
             bad.append(('rroi bwd', it, float(np.abs(ft.grad.cpu().numpy() - rb).max())))
     assert not bad, bad
+
+
+@pytest.mark.parametrize('block', range(4))
+def test_fuzz_channels_last_roi_align(block):
+    """Round 5: random shapes through the channels-last kernels -- forward bit-equal to the NCHW kernel and <= 1e-4 from
+    the oracle; backward <= 1e-4 max|g| from the oracle and (every RoI planned, fixed sampling grid) bit-equal to the NCHW
+    gather; rotated and horizontal kinds, C any multiple of 4, tiles overhanging the map, several images."""
+    from aidet_amd import RRoIAlign, RoIAlign, roi_layers
+    bad = []
+    for it in range(block * 40, block * 40 + 40):
+        rng = np.random.default_rng(9000 + it)
+        B = int(rng.integers(1, 4)); C = 4 * int(rng.integers(1, 80))
+        H = int(rng.integers(3, 70)); W = int(rng.integers(3, 70))
+        K = int(rng.integers(1, 60)); ph = int(rng.integers(1, 9)); pw = int(rng.integers(1, 9))
+        sn = int(rng.choice([0, 1, 2, 2, 3]))
+        scale = float(rng.choice([1.0, 0.5, 0.25]))
+        feat = rng.standard_normal((B, C, H, W)).astype(np.float32)
+        r = oracle.synth_boxes(K, max(W, H) / scale, 10 * it + 3)[:, :5]
+        r[:, 2:4] *= rng.choice([0.1, 1.0, 2.5])
+        rois = np.concatenate([rng.integers(0, B, (K, 1)).astype(np.float32), r], 1).astype(np.float32)
+        layer = RRoIAlign((ph, pw), scale, sample_num=sn)
+        fa = t(feat).requires_grad_(True)
+        fb = t(feat).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        if not roi_layers.is_nhwc(fb):        # (one pixel or one channel: both layouts are the same memory)
+            continue
+        oa, ob = layer(fa, t(rois)), layer(fb, t(rois))
+        if not torch.equal(oa, ob):
+            bad.append(('fwd vs nchw', it, C, H, W, K, ph, pw, sn))
+        ref = oracle.rroi_align_forward(feat, rois, (ph, pw), scale, sn)
+        if np.abs(ob.detach().cpu().numpy() - ref).max() > 1e-4 * max(1.0, np.abs(ref).max()):
+            bad.append(('fwd vs oracle', it))
+        g = rng.standard_normal(ob.shape).astype(np.float32)
+        oa.backward(t(g)); ob.backward(t(g))
+        rb = oracle.rroi_align_backward(g, rois, feat.shape, scale, sn)
+        if np.abs(fb.grad.cpu().numpy() - rb).max() > 1e-4 * max(1.0, np.abs(rb).max()):
+            bad.append(('bwd vs oracle', it, float(np.abs(fb.grad.cpu().numpy() - rb).max())))
+        if sn > 0 and ph * pw <= 64 and ph * pw * sn * sn <= 256 and K >= roi_layers.GATHER_MIN_ROIS and not torch.equal(fb.grad.contiguous(), fa.grad):
+            small = (r[:, 2] * scale * 1.5 + 3) * (r[:, 3] * scale * 1.5 + 3) < 2000     # (RoIs the plan holds on both sides)
+            if small.all():
+                bad.append(('bwd vs nchw gather', it, C, H, W, K))
+        if it % 4 == 0:      # horizontal kinds on the same map
+            x1 = rng.uniform(0, W / scale, K); y1 = rng.uniform(0, H / scale, K)
+            hr = np.stack([rois[:, 0], x1, y1, x1 + rng.uniform(1, W / scale, K), y1 + rng.uniform(1, H / scale, K)], 1).astype(np.float32)
+            for aligned in (False, True):
+                hl = RoIAlign((ph, pw), scale, sample_num=sn, aligned=aligned)
+                a, b = hl(t(feat), t(hr)), hl(fb.detach(), t(hr))
+                if not torch.equal(torch.nan_to_num(a, nan=7.0), torch.nan_to_num(b, nan=7.0)):
+                    bad.append(('horizontal fwd', it, aligned))
+    assert not bad, bad
+
+
+def test_fuzz_nms_nonpositive_thresholds():
+    """`nms(dets, thr <= 0)` against the oracle's restatement of nms_cpu.cpp:5-68 on random horizontal scenes: float and
+    double rows, inverted and zero-area boxes, groups, thresholds 0, -0.5, NaN."""
+    from aidet_amd import nms
+    bad = []
+    for it in range(60):
+        rng = np.random.default_rng(7000 + it)
+        n = int(np.exp(rng.uniform(0, np.log(3000))))
+        x1, y1 = rng.uniform(0, 300, n), rng.uniform(0, 300, n)
+        h = np.stack([x1, y1, x1 + rng.uniform(-5, 60, n), y1 + rng.uniform(-5, 60, n), (rng.permutation(n) + 0.5) / n], 1)
+        if it % 3 == 0:
+            h[:, :4] = np.round(h[:, :4])
+            h[rng.integers(0, n, max(n // 10, 1)), 2] = h[rng.integers(0, n, max(n // 10, 1)), 0] - 1      # zero-area boxes
+        thr = float(rng.choice([0.0, -0.5, -1e-3]))
+        h32 = h.astype(np.float32)
+        if not np.array_equal(nms(t(h32), thr)[1].cpu().numpy(), oracle.hbb_nms(h32, thr)):
+            bad.append(('f32', it, n, thr))
+        if it % 2 == 0 and not np.array_equal(nms(h, thr)[1], oracle.hbb_nms_f64(h, thr)):
+            bad.append(('f64', it, n, thr))
+        if it % 5 == 0:
+            grp = rng.integers(0, 6, n).astype(np.int32)
+            if not np.array_equal(nms(t(h32), thr, groups=grp)[1].cpu().numpy(), oracle.hbb_nms(h32, thr, groups=grp)):
+                bad.append(('groups', it, n, thr))
+    assert not bad, bad
