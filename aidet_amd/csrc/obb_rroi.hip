@@ -124,9 +124,10 @@ __device__ __forceinline__ int pass_channels(int cpitch, int owned) {
 }
 
 // sample table: footprint-local tap offsets and weights, once per block
+template <int THREADS = 256>
 __device__ __forceinline__ void build_table(const RoiFrame &f, const Footprint &fp, int H, int W, int pw,
                                             int spb, int nsamp, int4 *s_off, float4 *s_wgt) {
-  for (int sidx = threadIdx.x; sidx < nsamp; sidx += 256) {
+  for (int sidx = threadIdx.x; sidx < nsamp; sidx += THREADS) {
     const int bin = sidx / spb, q = sidx - bin * spb;
     const int bi = bin / pw, bj = bin - bi * pw;
     const int iy = q / f.gw, ix = q - iy * f.gw;
@@ -818,12 +819,24 @@ constexpr int kGTile = 16;                          // map tile: 16 x 16 pixels 
 constexpr int kGChanDefault = 16;                   // channels per gather block (sums in registers); OBB_TUNE_RROI_GATHER_CHAN
 constexpr int kGList = 2048;                        // RoIs of one tile held in LDS at a time
 
+// OBB_PLAN_STAMPS (tools/build_ablations.sh -> libobbops_plst.so, tools/exp_plan_stamps.py): shader-clock stamps of the
+// plan kernel's phases, one row of 12 per block (10 / 11: the 100 MHz real-time counter at entry / exit)
+#ifdef OBB_PLAN_STAMPS
+__device__ unsigned long long g_plan_stamps[4096 * 12];
+#define OBB_PSTAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 4096) { g_plan_stamps[blockIdx.x * 12 + (i)] = (i) >= 10 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define OBB_PSTAMP(i) do { } while (0)
+#endif
+
+// plan blocks: 4 waves.  (8 waves measured in round 5, tools/exp_plan_stamps.py: the tap phase 7250 -> 4450 cycles, but frame /
+// table / finish each ~500 slower with two waves per SIMD: block life 20.6k -> 18.0k cycles, whole backward 56.7 -> 57.5 us.)
+constexpr int kPlanThreads = 256, kPlanWaves = kPlanThreads / 64;
 template <bool UNUSED = false>
 __device__ __forceinline__ bool plan_holds(int fsz, int nb, int nsamp) {
   return fsz <= kBwdMaxPix && (fsz | 1) <= kBwdStageFloats && nb <= kMaxBins && nsamp <= kMaxTabSamples;
 }
 
-__global__ __launch_bounds__(256) void rroi_plan_kernel(
+__global__ __launch_bounds__(kPlanThreads) void rroi_plan_kernel(
     int B, int H, int W, const float *__restrict__ rois, int ph, int pw, float scale, int sample_num,
     float min_size, int roi_kind, RoiPlan *__restrict__ plan, unsigned short *__restrict__ rstart,
     int2 *__restrict__ rentry, int *__restrict__ lpt, int tiles_x, int tiles_per_image,
@@ -839,14 +852,50 @@ __global__ __launch_bounds__(256) void rroi_plan_kernel(
     float *dst = tgT + (int64_t)k * nb * tC + c0;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int kTB = 63;                                   // bins per pass: 64 x 63 floats fit the tile
+    if (nb <= kTB && !(tC & 3) && !(reinterpret_cast<uintptr_t>(tg) & 15u)) {
+      // the block's (channel, bin) slab is ONE contiguous, 16-byte aligned run of cc * nb floats: every request issued
+      // before the first is waited for (the loop below waits for each load before its LDS store -- 13 round trips in
+      // a row made these blocks, not the plan's, the end of the launch: 19.0 us)
+      const int n4 = (cc * nb) >> 2;                          // <= 1008 float4
+      const float4 *src4 = reinterpret_cast<const float4 *>(src);
+      constexpr int kV = 1024 / kPlanThreads;
+      float4 v[kV];
+#pragma unroll
+      for (int u = 0; u < kV; ++u) {
+        const int i4 = (int)threadIdx.x + u * kPlanThreads;
+        v[u] = i4 < n4 ? src4[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < kV; ++u) {
+        const int i4 = (int)threadIdx.x + u * kPlanThreads;
+        if (i4 < n4) {
+          int c = (i4 * 4) / nb, bb = i4 * 4 - c * nb;
+          const float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            tile[c * kTB + bb] = e[q];
+            if (++bb == nb) { bb = 0; ++c; }
+          }
+        }
+      }
+      __syncthreads();
+      // a quarter wave per bin row: lane -> 4 channels (cc is a multiple of 4), one 16-byte store each
+      const int l16 = lane & 15, sub = lane >> 4;
+      for (int bb = wave * 4 + sub; bb < nb; bb += 4 * kPlanWaves)
+        if (l16 * 4 < cc) {
+          const float *t = tile + (l16 * 4) * kTB + bb;
+          *reinterpret_cast<float4 *>(dst + (int64_t)bb * tC + l16 * 4) = make_float4(t[0], t[kTB], t[2 * kTB], t[3 * kTB]);
+        }
+      return;
+    }
     for (int b0 = 0; b0 < nb; b0 += kTB) {
       const int bn = min(kTB, nb - b0);
-      for (int i = threadIdx.x; i < cc * bn; i += 256) {
+      for (int i = threadIdx.x; i < cc * bn; i += kPlanThreads) {
         const int c = i / bn, bb = i - c * bn;
         tile[c * kTB + bb] = src[(int64_t)c * nb + b0 + bb];
       }
       __syncthreads();
-      for (int bb = wave; bb < bn; bb += 4)
+      for (int bb = wave; bb < bn; bb += kPlanWaves)
         if (lane < cc) dst[(int64_t)(b0 + bb) * tC + lane] = tile[lane * kTB + bb];
       __syncthreads();
     }
@@ -855,10 +904,12 @@ __global__ __launch_bounds__(256) void rroi_plan_kernel(
   __shared__ int s_last;
   __shared__ int2 entry[kBwdMaxEntries];               // (bin | tap << 8, weight bits), grouped by pixel
   __shared__ int pstart[kBwdMaxPix + 1];
-  __shared__ int wsum[4];
+  __shared__ int wsum[kPlanWaves];
   int *pfill = reinterpret_cast<int *>(tile) + kMaxTabSamples * 8;
   const int64_t k = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  OBB_PSTAMP(10);
+  OBB_PSTAMP(0);
   RoiFrame f;
   make_frame(rois + k * roi_stride(roi_kind), roi_kind, scale, ph, pw, sample_num, min_size, f);
   const long long spb64 = (long long)f.gh * f.gw;
@@ -884,26 +935,26 @@ __global__ __launch_bounds__(256) void rroi_plan_kernel(
     int *perm = lpt + kLptMax + 16;
     for (int img = 0; img < B; ++img) {
       __syncthreads();
-      bucket[tid] = 0;
+      if (tid < 256) bucket[tid] = 0;
       __syncthreads();
       const int *cnt = lpt + img * tiles_per_image;
-      for (int t = tid; t < tiles_per_image; t += 256) {
+      for (int t = tid; t < tiles_per_image; t += kPlanThreads) {
         const int c = __hip_atomic_load(cnt + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         atomicAdd(&bucket[c > 255 ? 255 : c], 1);
       }
       __syncthreads();
       {  // first rank of every count, heaviest first: exclusive scan over the buckets in descending order
-        const int mine = bucket[255 - tid];
+        const int mine = tid < 256 ? bucket[255 - tid] : 0;   // (256 buckets: the first four waves)
         int inc = mine;
         for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o); if (lane >= o) inc += v; }
         if (lane == 63) wsum[wave] = inc;
         __syncthreads();
         int base = inc - mine;
         for (int w2 = 0; w2 < wave; ++w2) base += wsum[w2];
-        bucket[255 - tid] = base;
+        if (tid < 256) bucket[255 - tid] = base;
       }
       __syncthreads();
-      for (int t = tid; t < tiles_per_image; t += 256) {
+      for (int t = tid; t < tiles_per_image; t += kPlanThreads) {
         const int c = __hip_atomic_load(cnt + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         perm[img * tiles_per_image + atomicAdd(&bucket[c > 255 ? 255 : c], 1)] = t;
       }
@@ -918,13 +969,15 @@ __global__ __launch_bounds__(256) void rroi_plan_kernel(
   if (lpt) {
     const int tx0 = fp.x0 / kGTile, tx1 = (fp.x0 + fp.w - 1) / kGTile, ty0 = fp.y0 / kGTile, ty1 = (fp.y0 + fp.h - 1) / kGTile;
     const int nx = tx1 - tx0 + 1, nt = nx * (ty1 - ty0 + 1);
-    for (int i = tid; i < nt; i += 256) atomicAdd(&lpt[f.b * tiles_per_image + (ty0 + i / nx) * tiles_x + tx0 + i % nx], 1);
+    for (int i = tid; i < nt; i += kPlanThreads) atomicAdd(&lpt[f.b * tiles_per_image + (ty0 + i / nx) * tiles_x + tx0 + i % nx], 1);
   }
   int4 *s_off = reinterpret_cast<int4 *>(tile);
   float4 *s_wgt = reinterpret_cast<float4 *>(tile) + kMaxTabSamples;
-  for (int i = tid; i < fsz; i += 256) { pstart[i] = 0; pfill[i] = 0; }
-  build_table(f, fp, H, W, pw, spb, nsamp, s_off, s_wgt);
+  OBB_PSTAMP(1);
+  for (int i = tid; i < fsz; i += kPlanThreads) { pstart[i] = 0; pfill[i] = 0; }
+  build_table<kPlanThreads>(f, fp, H, W, pw, spb, nsamp, s_off, s_wgt);
   __syncthreads();
+  OBB_PSTAMP(2);
   const int ntap = nsamp * 4;
   auto tap_of = [&](int t, int &pix, float &w) {
     const int sidx = t >> 2, j = t & 3;
@@ -940,12 +993,12 @@ __global__ __launch_bounds__(256) void rroi_plan_kernel(
   // <= 64: groups of that many lanes); the first tap of a (bin, pixel) group is its leader and carries the sum.
   const int tpb = 4 * spb;                                   // taps per bin
   const bool merge = tpb <= 64 && (tpb & (tpb - 1)) == 0;
-  constexpr int kTapIters = kBwdMaxEntries / 256;            // <= 4 taps per thread
+  constexpr int kTapIters = kBwdMaxEntries / kPlanThreads;   // <= 4 taps per thread
   bool lead[kTapIters];
   float wsumq[kTapIters];
 #pragma unroll
   for (int it = 0; it < kTapIters; ++it) {
-    const int t = tid + it * 256;
+    const int t = tid + it * kPlanThreads;
     int pix = -1;
     float w = 0.0f;
     if (t < ntap) { tap_of(t, pix, w); w = w != 0.0f ? w / f.cnt : 0.0f; }
@@ -956,10 +1009,12 @@ __global__ __launch_bounds__(256) void rroi_plan_kernel(
     if (lead[it]) atomicAdd(&pstart[pix], 1);
   }
   __syncthreads();
+  OBB_PSTAMP(3);
   {  // exclusive scan of the counts (<= 2048 pixels: 8 per thread)
-    int c8[8], sum = 0;
+    constexpr int kPer = 2048 / kPlanThreads;
+    int c8[kPer], sum = 0;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) { const int i = tid * 8 + u; c8[u] = i < fsz ? pstart[i] : 0; sum += c8[u]; }
+    for (int u = 0; u < kPer; ++u) { const int i = tid * kPer + u; c8[u] = i < fsz ? pstart[i] : 0; sum += c8[u]; }
     int inc = sum;
     for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o); if (lane >= o) inc += v; }
     if (lane == 63) wsum[wave] = inc;
@@ -967,13 +1022,14 @@ __global__ __launch_bounds__(256) void rroi_plan_kernel(
     int base = inc - sum;
     for (int w2 = 0; w2 < wave; ++w2) base += wsum[w2];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) { const int i = tid * 8 + u; if (i < fsz) pstart[i] = base; base += c8[u]; }
-    if (tid == 255) pstart[fsz] = base;
+    for (int u = 0; u < kPer; ++u) { const int i = tid * kPer + u; if (i < fsz) pstart[i] = base; base += c8[u]; }
+    if (tid == kPlanThreads - 1) pstart[fsz] = base;
     __syncthreads();
   }
+  OBB_PSTAMP(4);
 #pragma unroll
   for (int it = 0; it < kTapIters; ++it) {
-    const int t = tid + it * 256;
+    const int t = tid + it * kPlanThreads;
     if (lead[it]) {
       int pix;
       float w;
@@ -983,13 +1039,14 @@ __global__ __launch_bounds__(256) void rroi_plan_kernel(
     }
   }
   __syncthreads();
+  OBB_PSTAMP(5);
   // the slots of a pixel were handed out in arrival order; the plan stores every pixel's taps in TAP order
   // so that the sums of the gather kernel do not depend on it.  A wave takes a pixel at a time, a lane one
   // of its entries and counts the entries with a smaller tap number (the lists are short: ~4 entries on
   // average; an insertion sort per thread took 0.25 ms on a 2 x 2 pixel RoI with ~90 taps per pixel)
   unsigned short *rs = rstart + k * (int64_t)kPlanPix;
   int2 *re = rentry + k * (int64_t)kBwdMaxEntries;
-  for (int i = tid; i <= fsz; i += 256) rs[i] = (unsigned short)pstart[i];
+  for (int i = tid; i <= fsz; i += kPlanThreads) rs[i] = (unsigned short)pstart[i];
   // (a) a thread per pixel for the usual short lists (<= 8 taps: ranks by compares in registers) -- a wave per
   //     pixel walked the 2047 pixels of a large footprint one LDS round trip at a time: 0.1 ms for one RoI;
   // (b) the few longer lists (small RoIs: many taps per pixel) are queued and taken by whole waves.
@@ -997,7 +1054,7 @@ __global__ __launch_bounds__(256) void rroi_plan_kernel(
   __shared__ int nlong;
   if (tid == 0) nlong = 0;
   __syncthreads();
-  for (int pix = tid; pix < fsz; pix += 256) {
+  for (int pix = tid; pix < fsz; pix += kPlanThreads) {
     const int e0 = pstart[pix], m = pstart[pix + 1] - e0;
     if (m > 8) { longq[atomicAdd(&nlong, 1)] = pix; continue; }
     int2 en[8];
@@ -1014,9 +1071,10 @@ __global__ __launch_bounds__(256) void rroi_plan_kernel(
     }
   }
   __syncthreads();
+  OBB_PSTAMP(6);
   unsigned int *bm = reinterpret_cast<unsigned int *>(tile) + wave * 64;   // (the sample table is dead: 32 bitmap words + 32 prefixes per wave)
   const int nq = nlong;
-  for (int qi = __builtin_amdgcn_readfirstlane(wave); qi < nq; qi += 4) {
+  for (int qi = __builtin_amdgcn_readfirstlane(wave); qi < nq; qi += kPlanWaves) {
     const int pix = __builtin_amdgcn_readfirstlane(longq[qi]);
     const int e0 = __builtin_amdgcn_readfirstlane(pstart[pix]);   // (wave-uniform: tell the compiler, or the
     const int m = __builtin_amdgcn_readfirstlane(pstart[pix + 1]) - e0;   //  v_readlane below becomes a waterfall loop)
@@ -1059,8 +1117,11 @@ __global__ __launch_bounds__(256) void rroi_plan_kernel(
       __builtin_amdgcn_wave_barrier();
     }
   }
+  OBB_PSTAMP(7);
   if (tid == 0) { pl.x0 = fp.x0; pl.y0 = fp.y0; pl.w = fp.w; pl.h = fp.h; pl.state = 1; plan[k] = pl; }
   finish();
+  OBB_PSTAMP(8);
+  OBB_PSTAMP(11);
 }
 
 // Every global request of a RoI is issued one RoI ahead: while RoI i is summed, the plan record of RoI i+2, the
@@ -1503,7 +1564,7 @@ int rroi_plan_launch(int B, int H, int W, const float *rois_dev, int64_t K, int 
   unsigned long long blocks = (unsigned long long)K;
   if (tgT) blocks += (unsigned long long)K * (unsigned)((tC + 63) / 64);
   if (blocks > 2147483647ull) return set_err(OBB_EINVAL, "rroi_plan_launch: too many blocks (K=%lld, C=%d)", (long long)K, tC);
-  hipLaunchKernelGGL(rroi_plan_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, B, H, W, rois_dev, ph, pw, spatial_scale,
+  hipLaunchKernelGGL(rroi_plan_kernel, dim3((unsigned)blocks), dim3(kPlanThreads), 0, (hipStream_t)stream, B, H, W, rois_dev, ph, pw, spatial_scale,
                      sample_num, min_size, roi_kind, plan, rstart, rentry, lpt, tiles_x, tiles, (int)K, tg, tgT, tC);
   OBB_LAUNCH_CHECK();
   return OBB_OK;
@@ -1677,3 +1738,10 @@ extern "C" int obb_roi_align_forward_ws_f32(const float *const *feat_devs_host, 
                                     static_cast<int *>(workspace_dev),
                                     (workspace_dev && K <= kPlanMaxK) ? static_cast<unsigned char *>(workspace_dev) + roi_forward_order_bytes(K) : nullptr);
 }
+
+#ifdef OBB_PLAN_STAMPS
+extern "C" __attribute__((visibility("default"))) int obb_debug_plan_stamps(unsigned long long *host, int words) {
+  if (words > 4096 * 12) words = 4096 * 12;
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(obb::g_plan_stamps), (size_t)words * 8) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -32,8 +32,15 @@ namespace obb {
 #ifdef OBB_NHWC_STAMPS
 __device__ unsigned long long g_nhwc_stamps[8 * 8192];
 #define OBB_NSTAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) { g_nhwc_stamps[blockIdx.x * 8 + (i)] = (i) >= 6 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); } } while (0)
+// (the gather backward: 12 words per tile block -- 0..5 shader clock at entry / list / first batch's scan / fill / stream /
+// exit, 6 / 7 the real-time counter at entry / exit, 8 the tile's RoIs, 9 its entries, 10 its batches)
+__device__ unsigned long long g_nhwc_gstamps[4096 * 12];
+#define OBB_GSTAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 4096 && blockIdx.y == 0) { g_nhwc_gstamps[blockIdx.x * 12 + (i)] = ((i) == 6 || (i) == 7) ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); } } while (0)
+#define OBB_GNOTE(i, v) do { if (threadIdx.x == 0 && blockIdx.x < 4096 && blockIdx.y == 0) { g_nhwc_gstamps[blockIdx.x * 12 + (i)] = (unsigned long long)(v); } } while (0)
 #else
 #define OBB_NSTAMP(i) do { } while (0)
+#define OBB_GSTAMP(i) do { } while (0)
+#define OBB_GNOTE(i, v) do { } while (0)
 #endif
 
 constexpr int kNhwcTab = 256;              // samples of one table round (8 KiB)
@@ -276,6 +283,7 @@ static int roi_forward_nhwc_launch(const char *who, const LevelTable &lv, int nu
 // (Round 5 also built the gather WITHOUT the inversion -- per-RoI tap tables filtered by the tile, the hits summed in (RoI,
 // tap) order from an LDS stage: tools/attic/obb_rroi_nhwc_taptable_variant.hip.txt.  Its table pass is 10 us cheaper than
 // the plan, its gather 35 us slower: a block's filter chain takes 7 us and a staged row 650 cycles of a wave's life.)
+typedef float fvec4 __attribute__((ext_vector_type(4)));
 constexpr int kNT = 8;                                   // map tile of the gather: 8 x 8 pixels
 constexpr int kNPix = kNT * kNT;
 constexpr int kNList = 512;                              // RoIs of one tile held in LDS at a time
@@ -292,14 +300,15 @@ template <int NB, int NWV>
 __global__ __launch_bounds__(64 * NWV) void roi_gather_nhwc_kernel(
     const float *__restrict__ gT, int C, int H, int W, int K, int nb_rt, const RoiPlan *__restrict__ plan,
     const unsigned short *__restrict__ rstart, const int2 *__restrict__ rentry, float *__restrict__ gfeat) {
-  __shared__ int list[kNList];
-  __shared__ int4 foot[kNList];                            // footprints of the listed RoIs
+  constexpr int kT = 64 * NWV;
+  constexpr int kL = kT > kNList ? kT : kNList;            // (a round of kT tested RoIs always fits)
+  __shared__ int list[kL];
+  __shared__ int4 foot[kL];                                // footprints of the listed RoIs
   __shared__ unsigned int mo[kNBatch][kNPix];              // (RoI of the batch, pixel): entries | offset inside the pixel's run << 16
   __shared__ unsigned short e0s[kNBatch][kNPix];           // ... first entry in the RoI's own list
   __shared__ int pbase[kNPix + 1];                         // first entry of every pixel's run
   __shared__ __attribute__((aligned(16))) int2 ent[kNEnt]; // (row of gT, weight bits)
   __shared__ int wcnt[NWV];
-  constexpr int kT = 64 * NWV;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nb = NB ? NB : nb_rt;
   const int tiles_x = (W + kNT - 1) / kNT;
@@ -307,6 +316,9 @@ __global__ __launch_bounds__(64 * NWV) void roi_gather_nhwc_kernel(
   const int tl = (int)blockIdx.x;
   const int tx0 = (tl % tiles_x) * kNT, ty0 = (tl / tiles_x) * kNT;
   const int nq = C >> 2;                                   // 16-byte channel groups of a pixel
+  OBB_GSTAMP(6);
+  OBB_GSTAMP(0);
+  [[maybe_unused]] int st_ent = 0, st_roi = 0, st_bat = 0;
   for (int q0 = 0; q0 < nq; q0 += 64) {                    // (C > 256: slabs of 256 channels, the lists walked again)
     const bool act = q0 + lane < nq;
     const int cq = 4 * (q0 + (act ? lane : 0));
@@ -314,7 +326,7 @@ __global__ __launch_bounds__(64 * NWV) void roi_gather_nhwc_kernel(
     // the stream of one batch: wave w owns a contiguous range of the tile's pixels -- the ranges cut so that every wave gets
     // about a quarter of the batch's ENTRIES -- and sums their runs back to back: kNDepth rows in flight whatever pixel they
     // belong to (groups cut at pixel boundaries -- a pixel has ~3 entries -- are a round trip per pixel: 53 us instead of 42)
-    auto stream = [&](bool have) {
+    auto stream = [&](bool have, bool last) {
       int p0 = (kNPix / NWV) * wave, p1 = p0 + kNPix / NWV;
       if (have) {
         const int total = pbase[kNPix];
@@ -335,7 +347,10 @@ __global__ __launch_bounds__(64 * NWV) void roi_gather_nhwc_kernel(
       };
       float4 acc = init(p);
       auto advance = [&]() {                               // the current pixel's run is done: store it, next pixel
-        if (act && inmap(p)) *reinterpret_cast<float4 *>(pix_ptr(p)) = acc;
+        if (act && inmap(p)) {                             // (the final sums stream past the L2: the rows of gT stay in it)
+          if (last) __builtin_nontemporal_store(fvec4{acc.x, acc.y, acc.z, acc.w}, reinterpret_cast<fvec4 *>(pix_ptr(p)));
+          else *reinterpret_cast<float4 *>(pix_ptr(p)) = acc;
+        }
         ++p;
         if (p < p1) {
           acc = init(p);
@@ -365,14 +380,15 @@ __global__ __launch_bounds__(64 * NWV) void roi_gather_nhwc_kernel(
       }
       while (p < p1) advance();
     };
-    for (int base = 0; base < K; base += kNList) {
-      // ---- the RoIs whose footprint meets this tile, in RoI order (rroi_gather_kernel's list), with their footprints
+    for (int r0 = 0; r0 < K;) {
+      // ---- the RoIs whose footprint meets this tile, in RoI order (rroi_gather_kernel's list), with their footprints: all K
+      // plans are tested, kT at a time, and the list is summed when the next kT might not fit it (a tile of configs[2]
+      // lists 4 RoIs, of 2000 RoIs 15: one pass; a pass per 512 TESTED RoIs re-read and re-wrote the tile four times)
       int n = 0;
-      const int lim = min(K, base + kNList);
-      for (int r0 = base; r0 < lim; r0 += kT) {
+      for (; r0 < K && n + kT <= kL; r0 += kT) {
         const int r = r0 + tid;
-        const RoiPlan p = plan[min(r, lim - 1)];
-        const bool hit = r < lim && p.state == 1 && p.b == b && p.x0 < tx0 + kNT && p.x0 + p.w > tx0 && p.y0 < ty0 + kNT && p.y0 + p.h > ty0;
+        const RoiPlan p = plan[min(r, K - 1)];
+        const bool hit = r < K && p.state == 1 && p.b == b && p.x0 < tx0 + kNT && p.x0 + p.w > tx0 && p.y0 < ty0 + kNT && p.y0 + p.h > ty0;
         const uint64_t mk = __ballot(hit);
         if (lane == 0) wcnt[wave] = __popcll(mk);
         __syncthreads();
@@ -387,6 +403,8 @@ __global__ __launch_bounds__(64 * NWV) void roi_gather_nhwc_kernel(
         n += tot;
         __syncthreads();
       }
+      if (r0 <= kL) OBB_GSTAMP(1);
+      st_roi += n;
       int nbr = kNBatch;
       for (int rb0 = 0; rb0 < n;) {
         int cur, total;
@@ -423,6 +441,8 @@ __global__ __launch_bounds__(64 * NWV) void roi_gather_nhwc_kernel(
           nbr = max(1, cur >> 1);                           // too many entries for the buffer: half the batch
           __syncthreads();
         }
+        if (st_bat == 0) OBB_GSTAMP(2);
+        st_ent += total;
         // (3) the pairs copy their entries into the pixels' runs
         for (int idx = tid; idx < cur * kNPix; idx += kT) {
           const int rl = idx >> 6, pp = idx & 63;
@@ -437,16 +457,24 @@ __global__ __launch_bounds__(64 * NWV) void roi_gather_nhwc_kernel(
           }
         }
         __syncthreads();
+        if (st_bat == 0) OBB_GSTAMP(3);
         // (4) the runs are summed
-        stream(true);
+        stream(true, r0 >= K && rb0 + cur >= n);
+        if (st_bat == 0) OBB_GSTAMP(4);
+        ++st_bat;
         stored = true;
         rb0 += cur;
         nbr = kNBatch;
         __syncthreads();      // (the next batch rewrites the buffers)
       }
     }
-    if (!stored) stream(false);                            // no RoI meets the tile: zeros
+    if (!stored) stream(false, true);                            // no RoI meets the tile: zeros
   }
+  OBB_GSTAMP(5);
+  OBB_GSTAMP(7);
+  OBB_GNOTE(8, st_roi);
+  OBB_GNOTE(9, st_ent);
+  OBB_GNOTE(10, st_bat);
 }
 
 // RoIs the plan does not hold (state 2: footprint > 2047 pixels, > 256 samples, > 64 bins): every tap adds g * w / count to
@@ -501,6 +529,10 @@ static NhwcBwdLayout nhwc_bwd_layout(int64_t K, int C, int nb) {
 }  // namespace obb
 
 #ifdef OBB_NHWC_STAMPS
+extern "C" __attribute__((visibility("default"))) int obb_debug_nhwc_gather_stamps(unsigned long long *host, int words) {
+  if (words > 4096 * 12) words = 4096 * 12;
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(obb::g_nhwc_gstamps), (size_t)words * 8) == hipSuccess ? 0 : -1;
+}
 extern "C" __attribute__((visibility("default"))) int obb_debug_nhwc_stamps(unsigned long long *host, int words) {
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(obb::g_nhwc_stamps), (size_t)words * 8);
 }
@@ -578,8 +610,8 @@ extern "C" int obb_roi_backward_gather_nhwc_f32(const float *grad_out_dev, int B
   if ((reinterpret_cast<uintptr_t>(workspace_dev) & 15u) != 0) return set_err(OBB_EINVAL, "%s: workspace must be 16-byte aligned", who);
   if (K > 65535)
     return set_err(OBB_EINVAL, "%s: K = %lld RoIs (the channels-last gather takes <= 65535)", who, (long long)K);
-  const int tiles_x = (W + kNT - 1) / kNT, tiles_y = (H + kNT - 1) / kNT;
-  if ((long long)tiles_x * tiles_y > 2147483647LL || B > 65535) return set_err(OBB_EINVAL, "%s: too many map tiles / images", who);
+  const long long tiles_x = (W + kNT - 1) / kNT, tiles_y = (H + kNT - 1) / kNT;
+  if (tiles_x * tiles_y > 2147483647LL || B > 65535) return set_err(OBB_EINVAL, "%s: too many map tiles / images", who);
   char *ws = static_cast<char *>(workspace_dev);
   RoiPlan *plan = reinterpret_cast<RoiPlan *>(ws + L.g.plan);
   unsigned short *rstart = reinterpret_cast<unsigned short *>(ws + L.g.rstart);

@@ -156,11 +156,13 @@ def test_nhwc_forward_c_abi_rejects_what_it_cannot_take():
 
 # ---- channels-last RoI-Align backward ------------------------------------------------------------------------------
 @pytest.mark.parametrize('C,H,W,K,out,sn,batch', [(24, 40, 40, 50, 7, 2, 2), (256, 64, 64, 64, 7, 2, 1), (8, 33, 47, 25, (5, 9), 0, 2),
-                                                  (260, 24, 40, 30, 7, 2, 1), (64, 20, 20, 300, 7, 2, 1), (16, 70, 70, 12, 14, 2, 1)])
+                                                  (260, 24, 40, 30, 7, 2, 1), (64, 20, 20, 300, 7, 2, 1), (16, 70, 70, 12, 14, 2, 1),
+                                                  (16, 24, 24, 700, 7, 2, 1)])
 def test_nhwc_backward_is_bit_equal_to_the_nchw_gather_and_meets_the_oracle(C, H, W, K, out, sn, batch):
     """obb_roi_backward_gather_nhwc_f32 writes the gradient of a channels-last map in place: bit-equal to the NCHW gather
     (same summation order, fused multiply-adds) where every RoI is planned, <= 1e-4 max|g| from the oracle; small RoIs
-    (long tap lists per pixel: several rounds of 64 entries), many RoIs on one tile (several chunks of 8), C = 260
+    (long tap lists per pixel: several rounds of 64 entries), many RoIs on one tile (several batches; 700 RoIs: the tile's list
+    is summed in two passes, the first stored and read back), C = 260
     (two channel slabs), a RoI outside the batch, a tile overhanging the map (33 x 47), 14 x 14 bins (196 > 64: those
     RoIs go through the atomics kernel)."""
     from aidet_amd import RRoIAlign, roi_layers
@@ -168,7 +170,9 @@ def test_nhwc_backward_is_bit_equal_to_the_nchw_gather_and_meets_the_oracle(C, H
     feat = rng.standard_normal((batch, C, H, W)).astype(np.float32)
     rois = _rois(K, 4 * W, 9, batch=batch)
     rois[0, 0] = batch + 3
-    if K >= 300:
+    if K >= 600:
+        rois[:, 3:5] = np.clip(rois[:, 3:5], 40.0, 90.0)       # 700 RoIs of 10 .. 22 map pixels on a 24 x 24 map: a tile lists > 512
+    elif K >= 300:
         rois[:, 3:5] = np.minimum(rois[:, 3:5], 14.0)          # tiny RoIs: ~50-90 taps per pixel
     layer = RRoIAlign(out, 0.25, sample_num=sn)
     g = rng.standard_normal((K, C) + ((out, out) if isinstance(out, int) else out)).astype(np.float32)

@@ -36,4 +36,10 @@ cp $ROOT/aidet_amd/csrc/*.hip $ROOT/aidet_amd/csrc/*.h $ROOT/aidet_amd/csrc/Make
 sed -i "s#\.\./\.\./include#$ROOT/include#g" $d/Makefile $d/obb_common.h
 make -s -C $d -j8 EXTRA=-DOBB_NHWC_STAMPS OUT=$ROOT/aidet_amd/lib/libobbops_nhst.so
 rm -rf $d
-ls -la $ROOT/aidet_amd/lib/libobbops_nhst.so $ROOT/aidet_amd/lib/libobbops_abl*.so $ROOT/aidet_amd/lib/libobbops_gpst.so $ROOT/aidet_amd/lib/libobbops_sst.so
+# stamps of the backward's plan kernel (tools/exp_plan_stamps.py)
+d=$(mktemp -d /tmp/obb_plst_XXXX)
+cp $ROOT/aidet_amd/csrc/*.hip $ROOT/aidet_amd/csrc/*.h $ROOT/aidet_amd/csrc/Makefile $d/
+sed -i "s#\.\./\.\./include#$ROOT/include#g" $d/Makefile $d/obb_common.h
+make -s -C $d -j8 EXTRA=-DOBB_PLAN_STAMPS OUT=$ROOT/aidet_amd/lib/libobbops_plst.so
+rm -rf $d
+ls -la $ROOT/aidet_amd/lib/libobbops_plst.so $ROOT/aidet_amd/lib/libobbops_nhst.so $ROOT/aidet_amd/lib/libobbops_abl*.so $ROOT/aidet_amd/lib/libobbops_gpst.so $ROOT/aidet_amd/lib/libobbops_sst.so
