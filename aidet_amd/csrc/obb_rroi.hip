@@ -1297,7 +1297,7 @@ __global__ __launch_bounds__(256) void rroi_gather_kernel(
     float *dst = gfeat + (((int64_t)b * C + c0) * H + y) * (int64_t)W + x;
 #pragma unroll
     for (int c = 0; c < CH; ++c)
-      if (c < cc) dst[(int64_t)c * H * W] = acc[c];
+      if (c < cc) __builtin_nontemporal_store(acc[c], dst + (int64_t)c * H * W);   // (streams past the L2: the gradients and the plan stay in it)
   }
 }
 
