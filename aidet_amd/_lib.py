@@ -31,7 +31,8 @@ NMS_RESULT_BYTES = 64   # OBB_NMS_RESULT_BYTES
 # obb_set_tuning knobs (test / experiment hooks, include/obbops.h)
 (TUNE_NMS_FUSED_MAX, TUNE_NMS_DIRECT_MAX, TUNE_NMS_SCAN_BLOCKS, TUNE_RROI_GROUPS, TUNE_OVERLAPS_ROWS, TUNE_NMS_INLINE_MAX,
  TUNE_RROI_ORDER_MIN, TUNE_RROI_GATHER_CHAN, TUNE_RPN_BARRIER_TICKS, TUNE_SOFT_NMS_REG, TUNE_NMS_FUSED_COMPACT, TUNE_RROI_PLAN, TUNE_NMS_GRID,
- TUNE_SOFT_NMS_SHAPE, TUNE_RROI_NHWC_NQ, TUNE_RROI_NHWC_XCD, TUNE_RROI_NHWC_WAVES, TUNE_NMS_WATCH_RECORD, TUNE_RROI_NHWC_GATHER_WAVES) = range(19)
+ TUNE_SOFT_NMS_SHAPE, TUNE_RROI_NHWC_NQ, TUNE_RROI_NHWC_XCD, TUNE_RROI_NHWC_WAVES, TUNE_NMS_WATCH_RECORD, TUNE_RROI_NHWC_GATHER_WAVES,
+ TUNE_NMS_RESOLVE_TAIL, TUNE_NMS_RESOLVE_PARTS) = range(21)
 
 _lib = None
 

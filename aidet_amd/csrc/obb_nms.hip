@@ -2255,15 +2255,35 @@ __global__ __launch_bounds__(256) void nms_clip_kernel(const uint2 *__restrict__
 // One workgroup = one CU sustains about one scattered memory request per clock -- the
 // single-workgroup version of this kernel needed 170 us for 3*10^4 edges.
 constexpr int kSuppressedBit = 1 << 30;
+// Instrumented build only (-DOBB_RESOLVE_STAMPS -> libobbops_rsst.so, tools/exp_resolve_stamps.py): per shard and sweep the
+// live edges at its start and the 100 MHz wall clock; row 0 of a shard: entry clock, exit clock, sweeps
+#ifdef OBB_RESOLVE_STAMPS
+__device__ unsigned long long g_resolve_stamps[64 * 64 * 2];
+#define RS_NOTE(sweep, a, b) do { if (threadIdx.x == 0 && (sweep) < 64) { g_resolve_stamps[(blockIdx.x * 64 + (sweep)) * 2] = (unsigned long long)(a); g_resolve_stamps[(blockIdx.x * 64 + (sweep)) * 2 + 1] = (unsigned long long)(b); } } while (0)
+#else
+#define RS_NOTE(sweep, a, b) do { } while (0)
+#endif
 constexpr unsigned int kCountValid = 0x80000000u;   // flag of a handed-on count (nms_compact_kernel, the fused compaction)
-constexpr int kResolveThreads = 256;          // sorted route: 64 workgroups share the edges
+constexpr int kResolveThreads = 1024;         // sorted / grid route: 64 workgroups share the edges
 constexpr int kResolveThreadsCompact = 1024;  // direct route: usually ONE workgroup does it all
-constexpr long long kSoloEdges = 2048;   // up to here one workgroup resolves alone (direct route)
+constexpr int kResolveParts = 4;              // workgroups per shard in calls without the fused compaction (n >= 2^18)
+constexpr long long kSoloEdges = 2048;
+static inline int resolve_parts() {           // (OBB_TUNE_NMS_RESOLVE_PARTS)
+  const int v = (int)tuning(OBB_TUNE_NMS_RESOLVE_PARTS, kResolveParts);
+  return v < 1 ? 1 : (v > 16 ? 16 : v);
+}   // up to here one workgroup resolves alone (direct route)
 
 __device__ __forceinline__ int ld_word(const int *p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ bool word_kept(int w) { return w == 0; }
+// "source kept -> target suppressed" as an atomic STORE, not a read-modify-write: the flag with all the count bits below
+// it set.  The count of a suppressed word is never read again, a decrement that races with the store (at most one per
+// incoming edge, < 2^24) cannot borrow its way up to bit 30, and a store is a cheaper fabric request than a memory-side
+// read-modify-write (config-5 merge, 480 000 suppressions: resolve 39 -> 28 us).
+__device__ __forceinline__ void mark_suppressed(int *p) {
+  __hip_atomic_store(p, 0x7FFFFFFF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // COMPACT: the workgroup that finishes LAST also writes the ascending keep indices and the
 // host info (medium n: two more launches would cost more than the serial compaction).
@@ -2276,14 +2296,16 @@ __global__ __launch_bounds__(COMPACT ? kResolveThreadsCompact : kResolveThreads)
                                                            int64_t n, int64_t *__restrict__ keep_out,
                                                            NmsHostInfo *__restrict__ hinfo, int coop,
                                                            unsigned int *__restrict__ blockcnt,
-                                                           const unsigned int *__restrict__ ucnts) {
+                                                           const unsigned int *__restrict__ ucnts, int tuning_tail) {
   constexpr int kThreads = COMPACT ? kResolveThreadsCompact : kResolveThreads;
   constexpr int kW = kThreads / 64;
   __shared__ int overflow;
   __shared__ long long pre[kShards + 1];   // virtual start of every edge segment
   __shared__ int is_last;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int shard = blockIdx.x;
+  // large calls (no fused compaction): gridDim.x = kShards * P workgroups, P of them share a shard's segment -- one CU
+  // issues about a third of a scattered request per clock, and a segment of 13 000 edges was 58 us of first sweep
+  const int parts = (int)gridDim.x / kShards, shard = (int)blockIdx.x / parts, part = (int)blockIdx.x - shard * parts;
   // fused compaction: the sums of the call's result record are final when this launch starts (the earlier launches wrote
   // them) -- wave 1 gathers them HERE, beside wave 0's prefix, instead of five loads and thirty shuffles behind the last
   // slice's writes at the very end of the call (~1 us of every call's tail)
@@ -2321,7 +2343,7 @@ __global__ __launch_bounds__(COMPACT ? kResolveThreadsCompact : kResolveThreads)
     if (lane == 63) {
       pre[kShards] = inc;
       overflow = ovm != 0;
-      if (shard == 0) ctr->edges = (unsigned long long)inc;
+      if (blockIdx.x == 0) ctr->edges = (unsigned long long)inc;
     }
   }
   __syncthreads();
@@ -2334,11 +2356,80 @@ __global__ __launch_bounds__(COMPACT ? kResolveThreadsCompact : kResolveThreads)
   // not stored): nothing to resolve, the host reports OBB_EWORKSPACE
   uint2 *seg = solo ? edges : edges + (size_t)shard * segcap;
   long long live = overflow ? 0 : (solo ? total_edges : pre[shard + 1] - pre[shard]);
+  if (parts > 1) {                           // this workgroup's part of the segment (compacted inside its own range)
+    const long long per = (live + parts - 1) / parts, lo = per * part < live ? per * part : live;
+    seg += lo;
+    live = live - lo < per ? live - lo : per;
+  }
   bool segmented = solo;   // sweep 1 of SOLO reads the 64 segments, later ones the compacted front
   long long rounds = 0;
   constexpr int kPer = 4;  // edges per thread and chunk: their dependent loads overlap
+  // (a segment goes to the register tail when it fits it AFTER a sweep, or at once when it is tiny: the first sweep's
+  //  cached loads are cheaper than the tail's polling, which every polling workgroup pays for at the fabric)
+  constexpr int kTailFirst = 512;
+  const bool kTail = tuning_tail & 1, first_mode = !(tuning_tail & 2);
   __shared__ int wsum4[kPer][kW];
+  __shared__ int s_tail_rounds;
+  RS_NOTE(0, wall_clock64(), live);
   while (live > 0) {
+    RS_NOTE(1 + (int)rounds, live, wall_clock64());
+    if (kTail && live <= (rounds == 0 ? (long long)kTailFirst : (long long)kThreads * kPer)) {
+      // ---- the TAIL: what is left fits the threads' registers (<= kPer edges each).  No write-back of the survivors: a
+      // thread re-reads the two words of ITS undecided edges until the workgroup has retired them all -- a sweep is one
+      // load round trip and a barrier instead of edge reload + words + two barriers + compaction (the last sweeps of a call
+      // walk suppression chains a few edges at a time).  Progress is the other threads' and shards' atomics, as before; a
+      // stale read still only postpones the decision.  (The barrier per sweep is not optional: with every wave polling on
+      // its own, a 2000-box chain in ONE workgroup stopped advancing after its first two waves -- 4 M polls, wrong keeps.)
+      uint2 ed[kPer];
+      bool pend[kPer];
+#pragma unroll
+      for (int k = 0; k < kPer; ++k) {
+        const long long e = (long long)k * kThreads + tid;
+        pend[k] = e < live;
+        ed[k] = make_uint2(0u, 0u);
+        if (pend[k]) {
+          long long phys = e;
+          if (segmented) {
+            int lo = 0, hi = kShards - 1;
+            while (lo < hi) {
+              const int mid = (lo + hi + 1) >> 1;
+              if (pre[mid] <= e) lo = mid; else hi = mid - 1;
+            }
+            phys = (long long)lo * (long long)segcap + (e - pre[lo]);
+          }
+          ed[k] = seg[phys];
+        }
+      }
+      if (tid == 0) s_tail_rounds = 0;
+      __syncthreads();
+      int it = 0;
+      bool any = pend[0] | pend[1] | pend[2] | pend[3];
+      static_assert(kPer == 4, "the tail's pending flags");
+      while (__syncthreads_or(any ? 1 : 0) && it < (1 << 22)) {
+        int ws[kPer], wd[kPer];
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {       // (unconditional, clamped: the loads of a sweep travel together)
+          wd[k] = ld_word(cnt + ed[k].y);
+          ws[k] = ld_word(cnt + ed[k].x);
+        }
+        any = false;
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+          if (pend[k]) {
+            if (wd[k] & kSuppressedBit) pend[k] = false;
+            else if (ws[k] & kSuppressedBit) { atomicSub(&cnt[ed[k].y], 1); pend[k] = false; }
+            else if (word_kept(ws[k])) { mark_suppressed(cnt + ed[k].y); pend[k] = false; }
+            else any = true;
+          }
+        }
+        ++it;
+      }
+      if (lane == 0 || it > 0) atomicMax(&s_tail_rounds, it);
+      __syncthreads();
+      rounds += s_tail_rounds;
+      live = 0;
+      break;
+    }
     long long w = 0;
     for (long long base = 0; base < live; base += kThreads * kPer) {
       uint2 ed[kPer];
@@ -2367,13 +2458,21 @@ __global__ __launch_bounds__(COMPACT ? kResolveThreadsCompact : kResolveThreads)
 #pragma unroll
       for (int k = 0; k < kPer; ++k) {
         ws[k] = 0; wd[k] = kSuppressedBit;
-        if (have[k]) { wd[k] = ld_word(cnt + ed[k].y); ws[k] = ld_word(cnt + ed[k].x); }
+        if (have[k]) {
+          if (first_mode && rounds == 0) {
+            // the FIRST sweep reads the words as the launch found them: a cached load of the source (a zero is final:
+            // counts only fall and a zero word has no edge left to suppress it; anything else waits for sweep 2) and no
+            // look at the target (nothing is suppressed yet; a store to a target another shard got first is repeated).
+            // Agent-scope loads go past the L2 to the fabric, and the fabric -- not the 64 CUs -- bounds a large call.
+            wd[k] = 0; ws[k] = cnt[ed[k].x];
+          } else { wd[k] = ld_word(cnt + ed[k].y); ws[k] = ld_word(cnt + ed[k].x); }
+        }
       }
 #pragma unroll
       for (int k = 0; k < kPer; ++k) {
         if (have[k] && !(wd[k] & kSuppressedBit)) {   // (a suppressed target: the edge is moot)
           if (ws[k] & kSuppressedBit) atomicSub(&cnt[ed[k].y], 1);
-          else if (word_kept(ws[k])) atomicOr(&cnt[ed[k].y], kSuppressedBit);
+          else if (word_kept(ws[k])) mark_suppressed(cnt + ed[k].y);
           else keep[k] = true;
         }
       }
@@ -2407,6 +2506,7 @@ __global__ __launch_bounds__(COMPACT ? kResolveThreadsCompact : kResolveThreads)
     ++rounds;
     if (rounds > (1ll << 22)) break;   // corrupted state: stop instead of spinning forever
   }
+  RS_NOTE(63, wall_clock64(), rounds);
   if (tid == 0) atomicMax(reinterpret_cast<unsigned long long *>(&ctr->rounds), (unsigned long long)rounds);
   if constexpr (!COMPACT) if (coop) {
     // ---- fused compaction (round 4: the sorted route's nms_compact_kernel launch and its boundary, n < 2^18).  The 64
@@ -2452,7 +2552,7 @@ __global__ __launch_bounds__(COMPACT ? kResolveThreadsCompact : kResolveThreads)
     if (go == 2) return;
     // one pass: a thread requests its (up to) 16 words of the slice together -- they are agent-scope loads, a fabric
     // round trip each -- keeps the verdicts in registers, the 16 x 4 (row, wave) counts are scanned by one wave
-    constexpr int kR = 16, kSlice = kR * kThreads;          // 4096 words: a slice of n < 2^18 boxes over 64 shards
+    constexpr int kR = 64 / kW, kSlice = kR * kThreads;     // 4096 words: a slice of n < 2^18 boxes over 64 shards
     static_assert(kR * kW == 64, "one wave scans the (row, wave) counts");
     __shared__ int csum[kR][kW];
     __shared__ long long s_base;
@@ -3476,7 +3576,7 @@ int nms_enqueue_source(const char *who, NmsSource src, int64_t n, int kind, floa
       OBB_PHASE(5);
       // (the tail of the sorted route: compaction inside the resolve launch below 2^18 boxes, its own launch from there)
       const int gcoop = n < (1 << 18) ? 1 : 0;
-      hipLaunchKernelGGL(nms_resolve_kernel<false>, dim3(kShards), dim3(kResolveThreads), 0, st, edges, segcap, cnt, ctr, ccnts, n, keep_dev, result, gcoop, blockcnt, ucnts);
+      hipLaunchKernelGGL(nms_resolve_kernel<false>, dim3(kShards * (gcoop ? 1 : resolve_parts())), dim3(kResolveThreads), 0, st, edges, segcap, cnt, ctr, ccnts, n, keep_dev, result, gcoop, blockcnt, ucnts, (int)tuning(OBB_TUNE_NMS_RESOLVE_TAIL, 1));
       OBB_LAUNCH_CHECK();
       OBB_PHASE(6);
       if (!gcoop) {
@@ -3546,7 +3646,7 @@ int nms_enqueue_source(const char *who, NmsSource src, int64_t n, int kind, floa
     OBB_LAUNCH_CHECK();
     OBB_PHASE(4);
     OBB_PHASE(5);
-    hipLaunchKernelGGL(nms_resolve_kernel<true>, dim3(kShards), dim3(kResolveThreadsCompact), 0, st, edges, segcap, cnt, ctr, ccnts, n, keep_dev, result, 0, blockcnt, ucnts);
+    hipLaunchKernelGGL(nms_resolve_kernel<true>, dim3(kShards), dim3(kResolveThreadsCompact), 0, st, edges, segcap, cnt, ctr, ccnts, n, keep_dev, result, 0, blockcnt, ucnts, (int)tuning(OBB_TUNE_NMS_RESOLVE_TAIL, 1));
     OBB_LAUNCH_CHECK();
     OBB_PHASE(6);
     OBB_PHASE(7);
@@ -3605,7 +3705,7 @@ int nms_enqueue_source(const char *who, NmsSource src, int64_t n, int kind, floa
     OBB_PHASE(5);
     // (below 2^18 boxes the compaction is the tail of the resolve launch: its 64 workgroups take n / 64 words each)
     const int coop = n < (1 << 18) ? (int)tuning(OBB_TUNE_NMS_FUSED_COMPACT, 1) : 0;   // (2: waiters give up at once -- the fallback under test)
-    hipLaunchKernelGGL(nms_resolve_kernel<false>, dim3(kShards), dim3(kResolveThreads), 0, st, edges, segcap, cnt, ctr, ccnts, n, keep_dev, result, coop, blockcnt, ucnts);
+    hipLaunchKernelGGL(nms_resolve_kernel<false>, dim3(kShards * (coop ? 1 : resolve_parts())), dim3(kResolveThreads), 0, st, edges, segcap, cnt, ctr, ccnts, n, keep_dev, result, coop, blockcnt, ucnts, (int)tuning(OBB_TUNE_NMS_RESOLVE_TAIL, 1));
     OBB_LAUNCH_CHECK();
     // phase 6: compaction (one pass: every block publishes its count and sums its predecessors')
     OBB_PHASE(6);
@@ -3834,3 +3934,10 @@ extern "C" int obb_nms_profile_last(float *phase_ms_host) {
   for (int k = 0; k < kPhases; ++k) phase_ms_host[k] = g_prof.ms[k];
   return OBB_OK;
 }
+
+#ifdef OBB_RESOLVE_STAMPS
+extern "C" __attribute__((visibility("default"))) int obb_debug_resolve_stamps(unsigned long long *host, int words) {
+  if (words > 64 * 64 * 2) words = 64 * 64 * 2;
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(obb::g_resolve_stamps), (size_t)words * 8) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -631,7 +631,9 @@ OBB_API int obb_roi_backward_gather_nhwc_f32(const float *grad_out_dev, int B, i
 #define OBB_TUNE_RROI_NHWC_WAVES 16   /* channels-last RoI-Align forward: waves per block (4 or 8) */
 #define OBB_TUNE_NMS_WATCH_RECORD 17   /* 0: the synchronous NMS entry point sleeps in hipStreamSynchronize instead of watching its pinned result record */
 #define OBB_TUNE_RROI_NHWC_GATHER_WAVES 18   /* channels-last gather backward: waves per map tile (4, 8, 16) */
-#define OBB_TUNE_COUNT 19
+#define OBB_TUNE_NMS_RESOLVE_TAIL 19   /* resolve: 1 = the last <= 4 edges per thread of a shard are retired from registers (no sweeps through memory), 0 = swept */
+#define OBB_TUNE_NMS_RESOLVE_PARTS 20   /* resolve of calls of >= 2^18 boxes: workgroups per edge shard (1 .. 16) */
+#define OBB_TUNE_COUNT 21
 OBB_API int obb_set_tuning(int knob, int64_t value);
 /* which route the calling thread's last synchronous obb_nms_*_f32 call took: 0 fused (one workgroup), 1 direct, 2 sorted,
  * 4 grid, 5 grid gave up (crowded cell) and the call was repeated on the sorted route; -1 none yet */

@@ -42,4 +42,10 @@ cp $ROOT/aidet_amd/csrc/*.hip $ROOT/aidet_amd/csrc/*.h $ROOT/aidet_amd/csrc/Make
 sed -i "s#\.\./\.\./include#$ROOT/include#g" $d/Makefile $d/obb_common.h
 make -s -C $d -j8 EXTRA=-DOBB_PLAN_STAMPS OUT=$ROOT/aidet_amd/lib/libobbops_plst.so
 rm -rf $d
-ls -la $ROOT/aidet_amd/lib/libobbops_plst.so $ROOT/aidet_amd/lib/libobbops_nhst.so $ROOT/aidet_amd/lib/libobbops_abl*.so $ROOT/aidet_amd/lib/libobbops_gpst.so $ROOT/aidet_amd/lib/libobbops_sst.so
+# per-sweep stamps of the resolve kernel (tools/exp_resolve_stamps.py)
+d=$(mktemp -d /tmp/obb_rsst_XXXX)
+cp $ROOT/aidet_amd/csrc/*.hip $ROOT/aidet_amd/csrc/*.h $ROOT/aidet_amd/csrc/Makefile $d/
+sed -i "s#\.\./\.\./include#$ROOT/include#g" $d/Makefile $d/obb_common.h
+make -s -C $d -j8 EXTRA=-DOBB_RESOLVE_STAMPS OUT=$ROOT/aidet_amd/lib/libobbops_rsst.so
+rm -rf $d
+ls -la $ROOT/aidet_amd/lib/libobbops_rsst.so $ROOT/aidet_amd/lib/libobbops_plst.so $ROOT/aidet_amd/lib/libobbops_nhst.so $ROOT/aidet_amd/lib/libobbops_abl*.so $ROOT/aidet_amd/lib/libobbops_gpst.so $ROOT/aidet_amd/lib/libobbops_sst.so
