@@ -177,10 +177,12 @@ def bench_all(args):
         L.obb_nms_profile_last(pbuf)
         phase_tab += np.frombuffer(pbuf, dtype=np.float32)
     phase_tab /= 5
+    L.obb_nms_profile_enable(0)
 
     # ---- timed region: exactly K steps, barrier + sync on both sides, max over ranks -----------
-    # (the dominant kernel is bracketed by two HIP events on its own stream inside the timed steps -- on every 4th step:
-    # an event between two kernels of a four-launch chain is a ~5 us bubble each, 10 us of a 72 us call)
+    # (the dominant kernel is bracketed by two HIP events on its own stream inside the timed steps -- on every 10th step,
+    # steps 5, 15, ...: an event between two kernels of a four-launch chain is a ~5 us bubble each and reading the pair
+    # back a synchronisation, ~25 us of a 58 us call; `roofline.samples_in_timed_region` says how many there were)
     phases = np.zeros(7, dtype=np.float64)
     buf = (ctypes.c_float * 7)()
     sampled = 0
@@ -188,7 +190,7 @@ def bench_all(args):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        probe = i % 4 == 0
+        probe = i % 10 == 5 or (args.steps <= 5 and i == 0)
         if probe:
             L.obb_nms_profile_enable(1)
         keep, info = step()
@@ -244,6 +246,7 @@ def bench_all(args):
         rk = roofline_kernels(dev)
     roof = nms_roofline(n, args.canvas, kept, scan_ms, ms_per_step, rk, route)
     iou_bytes = 20 * (IOU_M // world + IOU_M) * world + 4 * IOU_M * IOU_M
+    roof['samples_in_timed_region'] = int(sampled)
     roof['iou_rowblock_pairs_per_s'] = round(iou_pairs['cfg'], 1)
     roof['iou_rowblock_hbm_frac'] = round(iou_bytes / (iou_ms['cfg'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
     roof['iou_sparse_rowblock_pairs_per_s'] = round(iou_pairs['sparse'], 1)
