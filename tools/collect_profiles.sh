@@ -36,6 +36,11 @@ timeout 200 python tools/exp_nhwc_stamps.py 64 4 > $O/nhwc_stamps.txt 2>> $O/ben
 timeout 200 python tools/exp_nhwc_fwd.py > $O/nhwc_fwd.txt 2>> $O/bench.err
 timeout 200 python tools/exp_nhwc_bwd.py > $O/nhwc_bwd.txt 2>> $O/bench.err
 timeout 200 python tools/exp_overlaps_density.py > $O/overlaps_density.txt 2>> $O/bench.err
+(timeout 100 python tools/exp_plan_stamps.py; timeout 100 python tools/exp_plan_stamps.py nhwc) > $O/plan_stamps.txt 2>> $O/bench.err
+(timeout 100 python tools/exp_nhwc_gather_stamps.py; timeout 100 python tools/exp_nhwc_gather_stamps.py 2000) > $O/nhwc_gather_stamps.txt 2>> $O/bench.err
+timeout 200 python tools/exp_resolve_stamps.py 16 > $O/resolve_stamps.txt 2>> $O/bench.err
+timeout 200 python tools/exp_resolve_parts.py 16 > $O/resolve_parts.txt 2>> $O/bench.err
+timeout 200 python tools/exp_resolve_tail.py > $O/resolve_tail.txt 2>> $O/bench.err
 timeout 200 python tools/exp_gprobe_stamps.py > $O/gprobe_stamps.txt 2>> $O/bench.err
 timeout 200 python tools/exp_frame_stamps.py > $O/frame_stamps.txt 2>> $O/bench.err
 timeout 300 python tools/exp_tiled_grid.py 16 0,1 > $O/tiled_grid.txt 2>> $O/bench.err

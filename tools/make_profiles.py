@@ -116,7 +116,8 @@ for name, alg in (('iou_sparse', 20 * 2 * 16384 + 4 * 16384 ** 2), ('iou_dense',
         print('%s: algorithmic %.1f MB / %.1f us = %.0f GB/s = %.3f of 8 TB/s' % (
             name, alg / 1e6, ks[0]['avg_us'], alg / ks[0]['avg_us'] / 1e3, alg / ks[0]['avg_us'] / 1e3 / 8000))
 for name in ('multi_rank_sim.txt', 'multi_rank_sim_large.txt', 'roi_backward.txt', 'detect.json', 'soft_nms.txt', 'rroi_ablate.txt', 'rroi_stamps.txt', 'gprobe_stamps.txt', 'frame_stamps.txt', 'tiled_grid.txt', 'grid_vs_sorted.txt',
-             'nhwc_stamps.txt', 'nhwc_fwd.txt', 'nhwc_bwd.txt', 'overlaps_density.txt'):
+             'nhwc_stamps.txt', 'nhwc_fwd.txt', 'nhwc_bwd.txt', 'overlaps_density.txt', 'plan_stamps.txt', 'nhwc_gather_stamps.txt',
+             'resolve_stamps.txt', 'resolve_parts.txt', 'resolve_tail.txt'):
     if os.path.exists(os.path.join(src, name)):
         with open(os.path.join(src, name)) as f, open('%s/%s_%s' % (dst, tag, name), 'w') as g:
             g.write(''.join(l for l in f if 'amdgpu.ids' not in l))
