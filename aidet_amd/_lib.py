@@ -20,6 +20,7 @@ OBB_OK = 0
 OBB_EINVAL = -1
 OBB_EWORKSPACE = -2
 OBB_ERETRY = -4
+OBB_ESTALLED = -5
 OBB_EHIP = -3
 
 KIND_RBOX = 0

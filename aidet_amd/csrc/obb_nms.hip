@@ -2259,24 +2259,26 @@ constexpr int kSuppressedBit = 1 << 30;
 // live edges at its start and the 100 MHz wall clock; row 0 of a shard: entry clock, exit clock, sweeps
 #ifdef OBB_RESOLVE_STAMPS
 __device__ unsigned long long g_resolve_stamps[64 * 64 * 2];
-#define RS_NOTE(sweep, a, b) do { if (threadIdx.x == 0 && (sweep) < 64) { g_resolve_stamps[(blockIdx.x * 64 + (sweep)) * 2] = (unsigned long long)(a); g_resolve_stamps[(blockIdx.x * 64 + (sweep)) * 2 + 1] = (unsigned long long)(b); } } while (0)
+#define RS_NOTE(sweep, a, b) do { if (threadIdx.x == 0 && (sweep) < 64 && part == 0) { g_resolve_stamps[(shard * 64 + (sweep)) * 2] = (unsigned long long)(a); g_resolve_stamps[(shard * 64 + (sweep)) * 2 + 1] = (unsigned long long)(b); } } while (0)   /* (part 0 of every shard) */
 #else
 #define RS_NOTE(sweep, a, b) do { } while (0)
 #endif
 constexpr unsigned int kCountValid = 0x80000000u;   // flag of a handed-on count (nms_compact_kernel, the fused compaction)
-constexpr int kResolveThreads = 1024;         // sorted / grid route: 64 workgroups share the edges
+constexpr int kResolveThreads = 512;          // sorted / grid route: 64 (x parts) workgroups share the edges; three of them fit a CU
 constexpr int kResolveThreadsCompact = 1024;  // direct route: usually ONE workgroup does it all
-constexpr int kResolveParts = 4;              // workgroups per shard in calls without the fused compaction (n >= 2^18)
-constexpr long long kSoloEdges = 2048;
-static inline int resolve_parts() {           // (OBB_TUNE_NMS_RESOLVE_PARTS)
-  const int v = (int)tuning(OBB_TUNE_NMS_RESOLVE_PARTS, kResolveParts);
-  return v < 1 ? 1 : (v > 16 ? 16 : v);
-}   // up to here one workgroup resolves alone (direct route)
+constexpr int kResolveParts = 8;              // workgroups per shard in calls without the fused compaction (n >= 2^18)
+constexpr long long kSoloEdges = 2048;      // up to here one workgroup resolves alone (direct route)
+constexpr long long kStalled = -1;           // `rounds` of a call whose resolve stopped at its bound (nms_verdict: OBB_ESTALLED)
+static int resolve_parts();                   // (OBB_TUNE_NMS_RESOLVE_PARTS, bounded by what the device keeps resident: below the kernel)
 
 __device__ __forceinline__ int ld_word(const int *p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ bool word_kept(int w) { return w == 0; }
+// word of box i (i < 2^24: a 32-bit byte offset beside the scalar base -- no 64-bit address registers per request in flight)
+__device__ __forceinline__ int *word_at(int *cnt, uint32_t i) {
+  return reinterpret_cast<int *>(reinterpret_cast<char *>(cnt) + (size_t)(uint32_t)(i << 2));
+}
 // "source kept -> target suppressed" as an atomic STORE, not a read-modify-write: the flag with all the count bits below
 // it set.  The count of a suppressed word is never read again, a decrement that races with the store (at most one per
 // incoming edge, < 2^24) cannot borrow its way up to bit 30, and a store is a cheaper fabric request than a memory-side
@@ -2363,6 +2365,7 @@ __global__ __launch_bounds__(COMPACT ? kResolveThreadsCompact : kResolveThreads)
   }
   bool segmented = solo;   // sweep 1 of SOLO reads the 64 segments, later ones the compacted front
   long long rounds = 0;
+  bool stalled = false;
   constexpr int kPer = 4;  // edges per thread and chunk: their dependent loads overlap
   // (a segment goes to the register tail when it fits it AFTER a sweep, or at once when it is tiny: the first sweep's
   //  cached loads are cheaper than the tail's polling, which every polling workgroup pays for at the fabric)
@@ -2409,16 +2412,16 @@ __global__ __launch_bounds__(COMPACT ? kResolveThreadsCompact : kResolveThreads)
         int ws[kPer], wd[kPer];
 #pragma unroll
         for (int k = 0; k < kPer; ++k) {       // (unconditional, clamped: the loads of a sweep travel together)
-          wd[k] = ld_word(cnt + ed[k].y);
-          ws[k] = ld_word(cnt + ed[k].x);
+          wd[k] = ld_word(word_at(cnt, ed[k].y));
+          ws[k] = ld_word(word_at(cnt, ed[k].x));
         }
         any = false;
 #pragma unroll
         for (int k = 0; k < kPer; ++k) {
           if (pend[k]) {
             if (wd[k] & kSuppressedBit) pend[k] = false;
-            else if (ws[k] & kSuppressedBit) { atomicSub(&cnt[ed[k].y], 1); pend[k] = false; }
-            else if (word_kept(ws[k])) { mark_suppressed(cnt + ed[k].y); pend[k] = false; }
+            else if (ws[k] & kSuppressedBit) { atomicSub(word_at(cnt, ed[k].y), 1); pend[k] = false; }
+            else if (word_kept(ws[k])) { mark_suppressed(word_at(cnt, ed[k].y)); pend[k] = false; }
             else any = true;
           }
         }
@@ -2427,6 +2430,7 @@ __global__ __launch_bounds__(COMPACT ? kResolveThreadsCompact : kResolveThreads)
       if (lane == 0 || it > 0) atomicMax(&s_tail_rounds, it);
       __syncthreads();
       rounds += s_tail_rounds;
+      if (s_tail_rounds >= (1 << 22)) stalled = true;
       live = 0;
       break;
     }
@@ -2464,15 +2468,15 @@ __global__ __launch_bounds__(COMPACT ? kResolveThreadsCompact : kResolveThreads)
             // counts only fall and a zero word has no edge left to suppress it; anything else waits for sweep 2) and no
             // look at the target (nothing is suppressed yet; a store to a target another shard got first is repeated).
             // Agent-scope loads go past the L2 to the fabric, and the fabric -- not the 64 CUs -- bounds a large call.
-            wd[k] = 0; ws[k] = cnt[ed[k].x];
-          } else { wd[k] = ld_word(cnt + ed[k].y); ws[k] = ld_word(cnt + ed[k].x); }
+            wd[k] = 0; ws[k] = *word_at(cnt, ed[k].x);
+          } else { wd[k] = ld_word(word_at(cnt, ed[k].y)); ws[k] = ld_word(word_at(cnt, ed[k].x)); }
         }
       }
 #pragma unroll
       for (int k = 0; k < kPer; ++k) {
         if (have[k] && !(wd[k] & kSuppressedBit)) {   // (a suppressed target: the edge is moot)
-          if (ws[k] & kSuppressedBit) atomicSub(&cnt[ed[k].y], 1);
-          else if (word_kept(ws[k])) mark_suppressed(cnt + ed[k].y);
+          if (ws[k] & kSuppressedBit) atomicSub(word_at(cnt, ed[k].y), 1);
+          else if (word_kept(ws[k])) mark_suppressed(word_at(cnt, ed[k].y));
           else keep[k] = true;
         }
       }
@@ -2504,10 +2508,11 @@ __global__ __launch_bounds__(COMPACT ? kResolveThreadsCompact : kResolveThreads)
     live = w;
     segmented = false;
     ++rounds;
-    if (rounds > (1ll << 22)) break;   // corrupted state: stop instead of spinning forever
+    if (rounds > (1ll << 22)) { stalled = true; break; }   // corrupted state, or workgroups this one waits for never ran: stop instead of spinning forever
   }
   RS_NOTE(63, wall_clock64(), rounds);
-  if (tid == 0) atomicMax(reinterpret_cast<unsigned long long *>(&ctr->rounds), (unsigned long long)rounds);
+  // (a stalled resolve publishes all ones = kStalled: the maximum of every shard's word, so it survives)
+  if (tid == 0) atomicMax(reinterpret_cast<unsigned long long *>(&ctr->rounds), stalled ? ~0ull : (unsigned long long)rounds);
   if constexpr (!COMPACT) if (coop) {
     // ---- fused compaction (round 4: the sorted route's nms_compact_kernel launch and its boundary, n < 2^18).  The 64
     // workgroups of this launch are co-resident by size (64 x 256 threads), so the shards that are done WAIT for the last
@@ -2682,6 +2687,25 @@ __global__ __launch_bounds__(COMPACT ? kResolveThreadsCompact : kResolveThreads)
       }
     }
   }
+}
+
+// Workgroups per edge shard of a large call.  The resolve's workgroups wait for each other's atomics: ALL of them must be
+// resident together, or the resident ones poll for ever on edges whose owners never start.  So the grid is bounded by half
+// of what the device keeps resident of this kernel (occupancy x CUs; half: a second call on another stream still fits) --
+// 4 on an MI355X (256 CUs x 2 workgroups of 1024 threads), 1 on a device with 64 CUs.
+static int resolve_parts() {
+  static int cap[16] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 1;
+  if (cap[dev] == 0) {
+    int cus = 0, nb = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, nms_resolve_kernel<false>, kResolveThreads, 0) != hipSuccess) nb = 0;
+    const long long fit = (long long)cus * nb / (2 * kShards);
+    cap[dev] = (int)(fit < 1 ? 1 : (fit > 16 ? 16 : fit));
+  }
+  const int v = (int)tuning(OBB_TUNE_NMS_RESOLVE_PARTS, kResolveParts);
+  return v < 1 ? 1 : (v > cap[dev] ? cap[dev] : v);
 }
 
 // ---- 9: compaction --------------------------------------------------------------
@@ -3370,6 +3394,11 @@ static int nms_verdict(const NmsHostInfo &h, const NmsEnqueued &q, int64_t *info
     info_host[1] = (int64_t)h.edges;
     info_host[2] = h.rounds;
     info_host[3] = (int64_t)h.cand_total;
+  }
+  if (h.rounds == kStalled) {
+    if (info_host) info_host[0] = 0;
+    return set_err(OBB_ESTALLED, "obb_nms_f32: the resolve kernel stopped without converging (its workgroups must be resident together: "
+                   "another persistent kernel on the device?); the keep list is not valid -- repeat the call");
   }
   int why = 0;
   const unsigned long long need = nms_need_capacity(h, q.cap, q.segcap, q.ucap, &why);

@@ -403,7 +403,7 @@ __global__ __launch_bounds__(64 * NWV) void roi_gather_nhwc_kernel(
         n += tot;
         __syncthreads();
       }
-      if (r0 <= kL) OBB_GSTAMP(1);
+      if (st_bat == 0 && st_roi == 0) OBB_GSTAMP(1);
       st_roi += n;
       int nbr = kNBatch;
       for (int rb0 = 0; rb0 < n;) {

@@ -63,6 +63,9 @@ extern "C" {
                                (the uniform grid of the NMS: a crowded cell) -- repeat the call, or the tiled phase, as it
                                is: the library has noted it for the calling thread and takes the general route.  The
                                synchronous entry points repeat by themselves and never return this.                    */
+#define OBB_ESTALLED (-5)   /* an NMS call's resolve kernel stopped at its bound without converging: its workgroups wait
+                               for each other and must be resident together -- possible only when another persistent
+                               kernel holds the device's slots.  The keep list is NOT valid; repeat the call.           */
 
 #define OBB_KIND_RBOX 0
 #define OBB_KIND_POLY 1
@@ -632,7 +635,7 @@ OBB_API int obb_roi_backward_gather_nhwc_f32(const float *grad_out_dev, int B, i
 #define OBB_TUNE_NMS_WATCH_RECORD 17   /* 0: the synchronous NMS entry point sleeps in hipStreamSynchronize instead of watching its pinned result record */
 #define OBB_TUNE_RROI_NHWC_GATHER_WAVES 18   /* channels-last gather backward: waves per map tile (4, 8, 16) */
 #define OBB_TUNE_NMS_RESOLVE_TAIL 19   /* resolve: 1 = the last <= 4 edges per thread of a shard are retired from registers (no sweeps through memory), 0 = swept */
-#define OBB_TUNE_NMS_RESOLVE_PARTS 20   /* resolve of calls of >= 2^18 boxes: workgroups per edge shard (1 .. 16) */
+#define OBB_TUNE_NMS_RESOLVE_PARTS 20   /* resolve of calls of >= 2^18 boxes: workgroups per edge shard (1 .. 16; never more than half of what the device keeps resident) */
 #define OBB_TUNE_COUNT 21
 OBB_API int obb_set_tuning(int knob, int64_t value);
 /* which route the calling thread's last synchronous obb_nms_*_f32 call took: 0 fused (one workgroup), 1 direct, 2 sorted,

@@ -80,6 +80,12 @@ def test_argument_validation_without_gpu():
     nb = L.obb_tiled_local_workspace_bytes(20000, 1, 0)
     assert L.obb_tiled_result(rec2, 0, 20000, 6, 1, -1, nb, info) == _lib.OBB_ERETRY
     assert L.obb_set_tuning(_lib.TUNE_NMS_GRID, -1) == _lib.OBB_OK          # (forgets the note the two calls above left)
+    # a record whose `rounds` word (byte 16) is all ones: the resolve kernel stopped at its bound (its workgroups were not resident
+    # together) -- the keep list is not valid and the entry points say so instead of returning it
+    rec3 = (ctypes.c_int64 * 8)()
+    rec3[0] = 7; rec3[2] = -1
+    assert L.obb_nms_async_result(rec3, 1000, ws, info) == _lib.OBB_ESTALLED and info[0] == 0
+    assert b'converg' in L.obb_last_error()
     cnt = ctypes.c_int64(5)
     assert L.obb_soft_nms_f32(null, -1, 0.5, 1, 0.5, 0.001, null, null, ctypes.byref(cnt), null, 0, null) == _lib.OBB_EINVAL
     assert L.obb_soft_nms_f32(null, 3, 0.5, 7, 0.5, 0.001, null, null, ctypes.byref(cnt), null, 0, null) == _lib.OBB_EINVAL

@@ -19,7 +19,7 @@ grp = (r[:, 7].to(torch.int64) * C + r[:, 6].to(torch.int64)).to(torch.int32)
 thr = torch.tensor(dota_io.class_thresholds(), device=dev, dtype=torch.float32)[r[:, 6].to(torch.int64)]
 L = _lib.lib()
 ref = None
-for parts, mode in ((1, 1), (2, 1), (4, 1), (8, 1), (4, 0), (4, 3), (4, 2), (1, 2), (4, 1)):
+for parts, mode in ((1, 1), (2, 1), (4, 1), (6, 1), (8, 1), (16, 1), (4, 0), (4, 3), (4, 2), (1, 2), (-1, -1)):     # (parts above what the device keeps resident / 2 are clamped by the library)
     _lib.set_tuning(_lib.TUNE_NMS_RESOLVE_PARTS, parts)
     _lib.set_tuning(_lib.TUNE_NMS_RESOLVE_TAIL, mode)     # bit 0: register tail, bit 1: first sweep with agent-scope loads like the others
     for _ in range(3):
