@@ -2243,16 +2243,18 @@ __global__ __launch_bounds__(256) void nms_clip_kernel(const uint2 *__restrict__
 // ---- 8: resolve ---------------------------------------------------------------
 // One word per box: the number of LIVE incoming edges (bits 0..29; set by the clip's
 // atomicAdd) and a SUPPRESSED flag (bit 30).  A box is KEPT iff its word is zero: no kept
-// predecessor can reach it any more.  Both transitions are fire-and-forget atomics:
-//   source kept       ->  atomicOr (word[target], SUPPRESSED)
+// predecessor can reach it any more.  Both transitions are fire-and-forget:
+//   source kept       ->  word[target] = SUPPRESSED | all count bits   (an atomic store, mark_suppressed)
 //   source suppressed ->  atomicSub(word[target], 1)
 // and each word only ever moves towards its final value, so the iteration may run
-// ASYNCHRONOUSLY: 64 workgroups, one per edge shard, each walking its own segment (compacted
-// in place) until it is empty, reading the others' progress through agent-scope loads.  A
-// stale read only postpones a decision to the next sweep.  No grid barrier: a workgroup
+// ASYNCHRONOUSLY: 64 x P workgroups, P per edge shard, each walking its own part of the segment
+// (compacted in place) until it is empty, reading the others' progress through agent-scope loads.
+// A stale read only postpones a decision to the next sweep.  No grid barrier: a workgroup
 // whose edges wait for other shards just sweeps again (every sweep retires at least the
-// edge with the globally earliest undecided source once that shard has run).
-// One workgroup = one CU sustains about one scattered memory request per clock -- the
+// edge with the globally earliest undecided source once that shard has run) -- which is why ALL the
+// workgroups must be resident together (resolve_parts() below bounds the grid by the device's occupancy;
+// a workgroup that reaches its bound of sweeps publishes kStalled and the host returns OBB_ESTALLED).
+// One workgroup = one CU sustains about a third of a scattered memory request per clock -- the
 // single-workgroup version of this kernel needed 170 us for 3*10^4 edges.
 constexpr int kSuppressedBit = 1 << 30;
 // Instrumented build only (-DOBB_RESOLVE_STAMPS -> libobbops_rsst.so, tools/exp_resolve_stamps.py): per shard and sweep the
