@@ -413,6 +413,7 @@ __global__ __launch_bounds__(256) void nms_cellscan_big_kernel(uint32_t *__restr
 // before publishing: no deadlock; the hand-over pattern of nms_compact_kernel).
 // =====================================================================================================
 constexpr int kFrameSamples = 1024;     // (4 per thread of ONE 256-thread workgroup: 4096 samples on 16 waves took 14 us, mostly barriers)
+constexpr int64_t kFrameManyBoxes = 2000000;   // from here the frame kernel takes all kFrameSamples samples, below half of them
 struct alignas(16) NmsFrame { float bx, by, sx, sy; float cpx, cpy; int gbits; int any;
                               int gshx, gshy, ggx, ggy; };   // grid route: cell = quantised coordinate >> gsh, ggx x ggy cells
 
@@ -486,11 +487,15 @@ __global__ __launch_bounds__(256) void nms_frame_kernel(const NmsSource src, int
   __shared__ uint32_t gbm[128];
   constexpr int T = 256, PER = kFrameSamples / T, NW = T / 64;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int ns = (int)(n < kFrameSamples ? n : kFrameSamples);
+  // 512 samples below 2 M boxes (round 5: the block's scattered sample reads and its statistics are a 6 us chain in front of
+  // every call -- 12 000 .. 200 000 boxes: 4 - 6 us per call less than with 1024), 1024 above (10 M boxes in 240 groups:
+  // 1.31 ms against 1.77 -- the cell size of a very large scene wants the better estimate)
+  const int full = n >= kFrameManyBoxes ? kFrameSamples : kFrameSamples / 2;
+  const int ns = (int)(n < full ? n : full);
   // sample i sits at box i n / ns: the samples cover [0, n) evenly (a fixed stride n / ns covered [0, ns * stride) only --
   // the first 1024 of 2000 boxes: a scene ordered along x had its second half outside the frame, clamped into the last cells)
-  static_assert(kFrameSamples == 1024, "the shift below");
-  auto sample_pos = [&](int i) { return ns == kFrameSamples ? (int64_t)(((uint64_t)i * (uint64_t)n) >> 10) : (int64_t)i; };
+  static_assert(kFrameSamples == 1024, "the shifts below");
+  auto sample_pos = [&](int i) { return ns == full ? (int64_t)(((uint64_t)i * (uint64_t)n) >> (full == kFrameSamples ? 10 : 9)) : (int64_t)i; };
   {  // all of a thread's rows are requested before the first is used (a loop of dependent round trips took 30 us)
     float4 b[PER];
 #pragma unroll
@@ -679,7 +684,7 @@ __global__ __launch_bounds__(256) void nms_frame_kernel(const NmsSource src, int
     float x0 = 0.0f, x1 = 0.0f, y0 = 0.0f, y1 = 0.0f;
     if (f.any) { x0 = fkey_inv(~m.y); x1 = fkey_inv(m.x); y0 = fkey_inv(~m.w); y1 = fkey_inv(m.z); }
     // the sample misses the outermost boxes by ~range / samples: a margin of 8 such steps (cells are 1 / 32767)
-    const float gx = (x1 - x0) * (8.0f / (float)kFrameSamples), gy = (y1 - y0) * (8.0f / (float)kFrameSamples);
+    const float gx = (x1 - x0) * (8.0f / (float)full), gy = (y1 - y0) * (8.0f / (float)full);
     x0 -= gx; x1 += gx; y0 -= gy; y1 += gy;
     const float rx = f.any ? x1 - x0 : 0.0f, ry = f.any ? y1 - y0 : 0.0f;
     const bool okx = rx > 0.0f && rx < 3.0e38f, oky = ry > 0.0f && ry < 3.0e38f;
