@@ -413,6 +413,10 @@ __global__ __launch_bounds__(256) void nms_cellscan_big_kernel(uint32_t *__restr
 // before publishing: no deadlock; the hand-over pattern of nms_compact_kernel).
 // =====================================================================================================
 constexpr int kFrameSamples = 1024;     // (4 per thread of ONE 256-thread workgroup: 4096 samples on 16 waves took 14 us, mostly barriers)
+#ifndef OBB_FRAME_FEW_LOG2
+#define OBB_FRAME_FEW_LOG2 9
+#endif
+constexpr int kFrameFewLog2 = OBB_FRAME_FEW_LOG2, kFrameFew = 1 << kFrameFewLog2;   // samples of a call below kFrameManyBoxes boxes
 constexpr int64_t kFrameManyBoxes = 2000000;   // from here the frame kernel takes all kFrameSamples samples, below half of them
 struct alignas(16) NmsFrame { float bx, by, sx, sy; float cpx, cpy; int gbits; int any;
                               int gshx, gshy, ggx, ggy; };   // grid route: cell = quantised coordinate >> gsh, ggx x ggy cells
@@ -490,12 +494,12 @@ __global__ __launch_bounds__(256) void nms_frame_kernel(const NmsSource src, int
   // 512 samples below 2 M boxes (round 5: the block's scattered sample reads and its statistics are a 6 us chain in front of
   // every call -- 12 000 .. 200 000 boxes: 4 - 6 us per call less than with 1024), 1024 above (10 M boxes in 240 groups:
   // 1.31 ms against 1.77 -- the cell size of a very large scene wants the better estimate)
-  const int full = n >= kFrameManyBoxes ? kFrameSamples : kFrameSamples / 2;
+  const int full = n >= kFrameManyBoxes ? kFrameSamples : kFrameFew;
   const int ns = (int)(n < full ? n : full);
   // sample i sits at box i n / ns: the samples cover [0, n) evenly (a fixed stride n / ns covered [0, ns * stride) only --
   // the first 1024 of 2000 boxes: a scene ordered along x had its second half outside the frame, clamped into the last cells)
   static_assert(kFrameSamples == 1024, "the shifts below");
-  auto sample_pos = [&](int i) { return ns == full ? (int64_t)(((uint64_t)i * (uint64_t)n) >> (full == kFrameSamples ? 10 : 9)) : (int64_t)i; };
+  auto sample_pos = [&](int i) { return ns == full ? (int64_t)(((uint64_t)i * (uint64_t)n) >> (full == kFrameSamples ? 10 : kFrameFewLog2)) : (int64_t)i; };
   {  // all of a thread's rows are requested before the first is used (a loop of dependent round trips took 30 us)
     float4 b[PER];
 #pragma unroll

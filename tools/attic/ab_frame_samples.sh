@@ -1,10 +1,11 @@
 #!/bin/bash
-# A/B of the frame kernel's sample count in one box: product library (512) against libobbops_fs1024.so
+# A/B of the frame kernel's sample count in one box: product library against a variant (aidet_amd/lib/libobbops_fs256.so, built
+# with -DOBB_FRAME_FEW_LOG2=8)
 for rep in 1 2; do
-for lib in "" /root/repo/aidet_amd/lib/libobbops_fs1024.so; do
+for lib in "" /root/repo/aidet_amd/lib/libobbops_fs256.so; do
   echo "== lib ${lib:-product}"
   OBBOPS_LIB=$lib python tools/exp_grid_vs_sorted.py 2>&1 | grep -v amdgpu | tail -10 | cut -d'|' -f1,2,4
   OBBOPS_LIB=$lib python tools/exp_tiled_grid.py 16 1 2>&1 | tail -1
-  OBBOPS_LIB=$lib python tools/exp_tiled_grid.py 128 1 2>&1 | tail -1
+  OBBOPS_LIB=$lib python tools/attic/bench_loop_dbg.py 2>&1 | grep "watch 1" | head -1
 done
 done
