@@ -2526,7 +2526,7 @@ __global__ __launch_bounds__(COMPACT ? kResolveThreadsCompact : kResolveThreads)
   if (tid == 0) atomicMax(reinterpret_cast<unsigned long long *>(&ctr->rounds), stalled ? ~0ull : (unsigned long long)rounds);
   if constexpr (!COMPACT) if (coop) {
     // ---- fused compaction (round 4: the sorted route's nms_compact_kernel launch and its boundary, n < 2^18).  The 64
-    // workgroups of this launch are co-resident by size (64 x 256 threads), so the shards that are done WAIT for the last
+    // workgroups of this launch are co-resident by size (64 x 512 threads), so the shards that are done WAIT for the last
     // one -- on one word, with a bound -- and then compact n / 64 words each (counts handed on through flagged words, as in
     // nms_compact_kernel).  No deadlock whatever the scheduler does: a waiter whose bound expires raises a flag in the
     // arrival word -- possible only while arrivals are missing -- and from then on every shard leaves after its resolve
