@@ -996,6 +996,7 @@ __global__ __launch_bounds__(kPlanThreads) void rroi_plan_kernel(
   constexpr int kTapIters = kBwdMaxEntries / kPlanThreads;   // <= 4 taps per thread
   bool lead[kTapIters];
   float wsumq[kTapIters];
+  int pixq[kTapIters];
 #pragma unroll
   for (int it = 0; it < kTapIters; ++it) {
     const int t = tid + it * kPlanThreads;
@@ -1003,11 +1004,24 @@ __global__ __launch_bounds__(kPlanThreads) void rroi_plan_kernel(
     float w = 0.0f;
     if (t < ntap) { tap_of(t, pix, w); w = w != 0.0f ? w / f.cnt : 0.0f; }
     if (w == 0.0f) pix = -1;                                 // (a zero weight adds nothing, also in the direct kernel)
+    pixq[it] = pix;
     lead[it] = pix >= 0;
     wsumq[it] = w;
-    if (merge && tpb > 1 && __ballot(t < ntap)) merge_bin_taps(pix, w, lane, tpb, lead[it], wsumq[it]);   // (wave-uniform)
-    if (lead[it]) atomicAdd(&pstart[pix], 1);
   }
+  if (merge && tpb == 16) {
+    // the usual 2 x 2 samples: the four rounds' merges back to back with no branch between them -- four independent chains
+    // of 15 DPP steps that the scheduler interleaves (with a ballot and a branch per round they ran one after the other:
+    // 7.3 k of the block's 20 k cycles); a round without taps holds pix = -1 everywhere and merges nothing
+#pragma unroll
+    for (int it = 0; it < kTapIters; ++it) merge_bin_taps(pixq[it], wsumq[it], lane, 16, lead[it], wsumq[it]);
+  } else if (merge && tpb > 1) {
+#pragma unroll
+    for (int it = 0; it < kTapIters; ++it)
+      if (__ballot(tid + it * kPlanThreads < ntap)) merge_bin_taps(pixq[it], wsumq[it], lane, tpb, lead[it], wsumq[it]);   // (wave-uniform)
+  }
+#pragma unroll
+  for (int it = 0; it < kTapIters; ++it)
+    if (lead[it]) atomicAdd(&pstart[pixq[it]], 1);
   __syncthreads();
   OBB_PSTAMP(3);
   {  // exclusive scan of the counts (<= 2048 pixels: 8 per thread)
