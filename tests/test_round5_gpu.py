@@ -437,3 +437,4 @@ def test_resolve_paths_of_a_large_call_agree():
     finally:
         _lib.set_tuning(_lib.TUNE_NMS_RESOLVE_TAIL, -1)
         _lib.set_tuning(_lib.TUNE_NMS_RESOLVE_PARTS, -1)
+
