@@ -32,7 +32,7 @@ __all__ = [
     'multiclass_nms', 'multiclass_rnms', 'multiclass_thetaobb_nms', 'multiclass_nms_with_index', 'thetaobb_nms_by_bbox_nms', 'get_det_rbboxes',
     'merge_aug_proposals', 'merge_aug_bboxes', 'merge_aug_scores'
 ]
-__version__ = '1.2.0'   # = libobbops 1.2 (obb_version() == 102: round 4 -- tiled phases, float64 entry points, OBB_ERETRY)
+__version__ = '1.3.0'   # = libobbops 1.3 (obb_version() == 103: round 5 -- channels-last RoI-Align entry points, nms with iou_thr <= 0, OBB_ESTALLED)
 
 
 def get_compiler_version():

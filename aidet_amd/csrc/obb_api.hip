@@ -38,7 +38,7 @@ extern "C" int obb_set_tuning(int knob, int64_t value) {
   return OBB_OK;
 }
 
-extern "C" int obb_version(void) { return 102; }
+extern "C" int obb_version(void) { return 103; }
 
 extern "C" const char *obb_build_info(void) {
   return "libobbops 1.2 | OBB-GEOM v1 | gfx950 | -ffp-contract=off | HIP " __VERSION__;
