@@ -2673,7 +2673,10 @@ __global__ __launch_bounds__(COMPACT ? kResolveThreadsCompact : kResolveThreads)
 #pragma unroll
       for (int k = 0; k < kC; ++k) {
         const int64_t i = c0 + (int64_t)k * kThreads + tid;
-        f[k] = (i < n) && word_kept(ld_word(cnt + i));
+        // (a cached load first: a zero is final whenever it is read -- nearly every word; the rest again at agent scope)
+        int w = i < n ? cnt[i] : 1;
+        if (__ballot(i < n && w != 0)) { const int w2 = ld_word(cnt + (i < n ? i : n - 1)); w = w != 0 ? w2 : 0; }
+        f[k] = (i < n) && word_kept(w);
       }
 #pragma unroll
       for (int k = 0; k < kC; ++k) {
