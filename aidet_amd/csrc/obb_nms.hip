@@ -1997,8 +1997,11 @@ __global__ __launch_bounds__(64 * kNmsWaves) void nms_gprobe_kernel(const QuadRe
   const uint32_t nover = nover_all < over_cap ? nover_all : over_cap;
   const uint32_t nbig_all = ctr->grid_big;
   const uint32_t nbig = nbig_all < big_cap ? nbig_all : big_cap;
+  // (the insert launch's verdict, requested WITH the words above: an agent-scope load behind them was a second round trip at
+  //  the head of every wave; what THIS launch adds to the word nobody here needs to see -- the host reads it in the record)
+  const uint32_t gave_up = ctr->grid_fail;
   if (gw >= chunks && gw >= nover && nbig == 0u) return;
-  if (__hip_atomic_load(&ctr->grid_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;   // the call is repeated on the sorted route
+  if (gave_up != 0u) return;                                      // the call is repeated on the sorted route
   GP_STAMP(1);
   uint2 *q = queue[wave];
   uint4 *ew = ent[wave];
