@@ -2387,21 +2387,6 @@ __global__ __launch_bounds__(COMPACT ? kResolveThreadsCompact : kResolveThreads)
   const bool kTail = tuning_tail & 1, first_mode = !(tuning_tail & 2);
   __shared__ int wsum4[kPer][kW];
   __shared__ int s_tail_rounds;
-  // fused compaction: this shard's slice of the words is requested NOW, with cached loads, beside the sweeps.  A word that is
-  // zero is final whenever it is read (counts only fall, and a word without a live edge cannot be suppressed) -- 99.7 % of the
-  // headline's words; only the others are read again, at agent scope, once every shard has arrived (100 000 agent-scope loads
-  // behind the arrival were ~2 us of every call's tail)
-  constexpr int kRc = 64 / kW;
-  unsigned int pre_zero = 0u;
-  if constexpr (!COMPACT) if (coop) {
-    const int64_t per0 = (n + kShards - 1) / kShards, lo0 = (int64_t)shard * per0, hi0 = (lo0 + per0 < n) ? lo0 + per0 : n;
-#pragma unroll
-    for (int r = 0; r < kRc; ++r) {
-      const int64_t i = lo0 + (int64_t)r * kThreads + tid;
-      const int w0 = cnt[i < hi0 ? i : (n > 0 ? n - 1 : 0)];
-      if (i < hi0 && w0 == 0) pre_zero |= 1u << r;
-    }
-  }
   RS_NOTE(0, wall_clock64(), live);
   while (live > 0) {
     RS_NOTE(1 + (int)rounds, live, wall_clock64());
@@ -2586,7 +2571,7 @@ __global__ __launch_bounds__(COMPACT ? kResolveThreadsCompact : kResolveThreads)
     if (go == 2) return;
     // one pass: a thread requests its (up to) 16 words of the slice together -- they are agent-scope loads, a fabric
     // round trip each -- keeps the verdicts in registers, the 16 x 4 (row, wave) counts are scanned by one wave
-    constexpr int kR = kRc, kSlice = kR * kThreads;         // 4096 words: a slice of n < 2^18 boxes over 64 shards
+    constexpr int kR = 64 / kW, kSlice = kR * kThreads;     // 4096 words: a slice of n < 2^18 boxes over 64 shards
     static_assert(kR * kW == 64, "one wave scans the (row, wave) counts");
     __shared__ int csum[kR][kW];
     __shared__ long long s_base;
@@ -2601,10 +2586,8 @@ __global__ __launch_bounds__(COMPACT ? kResolveThreadsCompact : kResolveThreads)
 #pragma unroll
       for (int r = 0; r < kR; ++r) {
         const int64_t i = c0 + (int64_t)r * kThreads + tid;
-        const bool known = go == 1 && first_chunk && ((pre_zero >> r) & 1u);     // (read as zero at the start: final)
-        int wv = 0;
-        if (__ballot(i < hi && !known)) wv = ld_word(cnt + (i < hi ? i : (n > 0 ? n - 1 : 0)));    // (wave-uniform; the rows' loads in flight together)
-        f[r] = (i < hi) && (known || word_kept(wv));
+        const int wv = ld_word(cnt + (i < hi ? i : (n > 0 ? n - 1 : 0)));    // (unconditional: all rows in flight together)
+        f[r] = (i < hi) && word_kept(wv);
       }
 #pragma unroll
       for (int r = 0; r < kR; ++r) {
@@ -2676,10 +2659,7 @@ __global__ __launch_bounds__(COMPACT ? kResolveThreadsCompact : kResolveThreads)
 #pragma unroll
       for (int k = 0; k < kC; ++k) {
         const int64_t i = c0 + (int64_t)k * kThreads + tid;
-        // (a cached load first: a zero is final whenever it is read -- nearly every word; the rest again at agent scope)
-        int w = i < n ? cnt[i] : 1;
-        if (__ballot(i < n && w != 0)) { const int w2 = ld_word(cnt + (i < n ? i : n - 1)); w = w != 0 ? w2 : 0; }
-        f[k] = (i < n) && word_kept(w);
+        f[k] = (i < n) && word_kept(ld_word(cnt + i));
       }
 #pragma unroll
       for (int k = 0; k < kC; ++k) {
