@@ -491,9 +491,9 @@ __global__ __launch_bounds__(256) void nms_frame_kernel(const NmsSource src, int
   __shared__ uint32_t gbm[128];
   constexpr int T = 256, PER = kFrameSamples / T, NW = T / 64;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  // 512 samples below 2 M boxes (round 5: the block's scattered sample reads and its statistics are a 6 us chain in front of
-  // every call -- 12 000 .. 200 000 boxes: 4 - 6 us per call less than with 1024), 1024 above (10 M boxes in 240 groups:
-  // 1.31 ms against 1.77 -- the cell size of a very large scene wants the better estimate)
+  // 512 samples below 2 M boxes (round 5: the block's scattered sample reads and its statistics are a chain in front of every
+  // call -- 6.1 -> 4.9 us, the kernel 7.2 -> 6.3 us by rocprof), 1024 above (10 M boxes in 240 groups: 1.31 ms against 1.77 --
+  // the cell size of a very large scene wants the better estimate)
   const int full = n >= kFrameManyBoxes ? kFrameSamples : kFrameFew;
   const int ns = (int)(n < full ? n : full);
   // sample i sits at box i n / ns: the samples cover [0, n) evenly (a fixed stride n / ns covered [0, ns * stride) only --
