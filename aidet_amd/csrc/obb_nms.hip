@@ -2385,6 +2385,7 @@ __global__ __launch_bounds__(COMPACT ? kResolveThreadsCompact : kResolveThreads)
   //  cached loads are cheaper than the tail's polling, which every polling workgroup pays for at the fabric)
   constexpr int kTailFirst = 512;
   const bool kTail = tuning_tail & 1, first_mode = !(tuning_tail & 2);
+  if (tuning_tail & 4) stalled = true;      // (test hook: the host's OBB_ESTALLED path without a starved device)
   __shared__ int wsum4[kPer][kW];
   __shared__ int s_tail_rounds;
   RS_NOTE(0, wall_clock64(), live);

@@ -634,7 +634,7 @@ OBB_API int obb_roi_backward_gather_nhwc_f32(const float *grad_out_dev, int B, i
 #define OBB_TUNE_RROI_NHWC_WAVES 16   /* channels-last RoI-Align forward: waves per block (4 or 8) */
 #define OBB_TUNE_NMS_WATCH_RECORD 17   /* 0: the synchronous NMS entry point sleeps in hipStreamSynchronize instead of watching its pinned result record */
 #define OBB_TUNE_RROI_NHWC_GATHER_WAVES 18   /* channels-last gather backward: waves per map tile (4, 8, 16) */
-#define OBB_TUNE_NMS_RESOLVE_TAIL 19   /* resolve, bit 0: the last <= 4 edges per thread of a shard are retired from registers (1, default) or swept through memory (0); bit 1: the first sweep uses agent-scope loads like the others (measurement only) */
+#define OBB_TUNE_NMS_RESOLVE_TAIL 19   /* resolve, bit 0: the last <= 4 edges per thread of a shard are retired from registers (1, default) or swept through memory (0); bit 1: the first sweep uses agent-scope loads like the others (measurement only); bit 2: the resolve reports itself stalled (test hook for OBB_ESTALLED) */
 #define OBB_TUNE_NMS_RESOLVE_PARTS 20   /* resolve of calls of >= 2^18 boxes: workgroups per edge shard (1 .. 16; never more than half of what the device keeps resident) */
 #define OBB_TUNE_COUNT 21
 OBB_API int obb_set_tuning(int knob, int64_t value);

@@ -438,3 +438,20 @@ def test_resolve_paths_of_a_large_call_agree():
         _lib.set_tuning(_lib.TUNE_NMS_RESOLVE_TAIL, -1)
         _lib.set_tuning(_lib.TUNE_NMS_RESOLVE_PARTS, -1)
 
+
+
+def test_a_stalled_resolve_is_an_error_not_a_short_keep_list():
+    """OBB_ESTALLED end to end (the resolve's workgroups wait for each other and must be resident together; one that reaches
+    its bound publishes rounds = -1): with the test hook (OBB_TUNE_NMS_RESOLVE_TAIL bit 2) every route that resolves with
+    nms_resolve_kernel raises instead of returning a keep list, and the next call without the hook is served as usual."""
+    from aidet_amd import _lib, rnms
+    for n, canvas in ((5000, 2500), (50000, 12000), (300000, 40000)):
+        d = t(oracle.synth_boxes(n, canvas, 3))
+        want = rnms(d, 0.5)[1]
+        try:
+            _lib.set_tuning(_lib.TUNE_NMS_RESOLVE_TAIL, 1 | 4)
+            with pytest.raises(_lib.ObbOpsError, match='converg'):
+                rnms(d, 0.5)
+        finally:
+            _lib.set_tuning(_lib.TUNE_NMS_RESOLVE_TAIL, -1)
+        assert torch.equal(rnms(d, 0.5)[1], want)
