@@ -32,7 +32,7 @@ __all__ = [
     'multiclass_nms', 'multiclass_rnms', 'multiclass_thetaobb_nms', 'multiclass_nms_with_index', 'thetaobb_nms_by_bbox_nms', 'get_det_rbboxes',
     'merge_aug_proposals', 'merge_aug_bboxes', 'merge_aug_scores'
 ]
-__version__ = '1.3.0'   # = libobbops 1.3 (obb_version() == 103: round 5 -- channels-last RoI-Align entry points, nms with iou_thr <= 0, OBB_ESTALLED)
+__version__ = '1.4.0'   # = libobbops 1.4 (obb_version() == 104: round 6 -- OBB_NMS_RETAIN, the three-launch NMS on a retained workspace)
 
 
 def get_compiler_version():

@@ -28,12 +28,13 @@ KIND_POLY = 1
 KIND_HBB = 2   # NMS only: x1, y1, x2, y2 (+ score) with the reference's +1 convention
 MODE = {'iou': 0, 'iof': 1}
 NMS_STRICT = 1          # OBB_NMS_STRICT: suppress on `>` (nms_kernel.cu:61) instead of `>=` (nms_cpu.cpp:56)
+NMS_RETAIN = 2          # OBB_NMS_RETAIN: the workspace is the caller's alone from call to call -- three launches instead of four (obbops.h)
 NMS_RESULT_BYTES = 64   # OBB_NMS_RESULT_BYTES
 # obb_set_tuning knobs (test / experiment hooks, include/obbops.h)
 (TUNE_NMS_FUSED_MAX, TUNE_NMS_DIRECT_MAX, TUNE_NMS_SCAN_BLOCKS, TUNE_RROI_GROUPS, TUNE_OVERLAPS_ROWS, TUNE_NMS_INLINE_MAX,
  TUNE_RROI_ORDER_MIN, TUNE_RROI_GATHER_CHAN, TUNE_RPN_BARRIER_TICKS, TUNE_SOFT_NMS_REG, TUNE_NMS_FUSED_COMPACT, TUNE_RROI_PLAN, TUNE_NMS_GRID,
  TUNE_SOFT_NMS_SHAPE, TUNE_RROI_NHWC_NQ, TUNE_RROI_NHWC_XCD, TUNE_RROI_NHWC_WAVES, TUNE_NMS_WATCH_RECORD, TUNE_RROI_NHWC_GATHER_WAVES,
- TUNE_NMS_RESOLVE_TAIL, TUNE_NMS_RESOLVE_PARTS) = range(21)
+ TUNE_NMS_RESOLVE_TAIL, TUNE_NMS_RESOLVE_PARTS, TUNE_NMS_RETAIN) = range(22)
 
 _lib = None
 
@@ -107,6 +108,7 @@ def lib():
                                                  f32, i32, i32, f32, vp, vp]
         L.obb_head_gather_decode_f32.restype = i32
         L.obb_nms_last_route.restype = i32
+        L.obb_nms_last_retained.restype = i32
         L.obb_soft_nms_last_path.restype = i32
         L.obb_soft_nms_last_path.argtypes = []
         L.obb_set_tuning.argtypes = [i32, i64]

@@ -38,10 +38,10 @@ extern "C" int obb_set_tuning(int knob, int64_t value) {
   return OBB_OK;
 }
 
-extern "C" int obb_version(void) { return 103; }
+extern "C" int obb_version(void) { return 104; }
 
 extern "C" const char *obb_build_info(void) {
-  return "libobbops 1.2 | OBB-GEOM v1 | gfx950 | -ffp-contract=off | HIP " __VERSION__;
+  return "libobbops 1.4 | OBB-GEOM v1 | gfx950 | -ffp-contract=off | HIP " __VERSION__;
 }
 
 extern "C" const char *obb_last_error(void) { return obb::err_buf(); }

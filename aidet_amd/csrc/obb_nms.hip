@@ -102,12 +102,19 @@ struct NmsCounters {
   long long rounds;                        // resolve sweeps (most of any shard)
   unsigned int done;                       // resolve workgroups finished
   unsigned int state;                      // fused resolve + compaction, after a waiter gave up (flag in `done`): shards that have registered to leave
-  unsigned int grid_fail;                  // grid route: too many crowded cells / a box over too many cells -- repeat on the sorted route
-  alignas(256) unsigned int grid_over;     // grid route: entries on the overflow list (may exceed grid_over_cap(n))
-  unsigned int grid_big;                   // grid route: boxes over more than kGridMaxCells cells (may exceed grid_big_cap(n)); (the line of grid_over: both move in rare scenes only)
   alignas(256) unsigned long long cand_total;           // candidate pairs over all shards
   unsigned long long cand_worst;           // fullest shard
 };
+// What the grid route's INSERT launch counts in.  Apart from NmsCounters since round 6: at a fixed offset of the workspace
+// (just below the cell counters), because on a retained workspace (NmsRetain) these three words are cleared by the
+// PREVIOUS call's tail -- a call of another n, whose NmsCounters lie elsewhere.
+struct NmsGridCtr {
+  alignas(256) unsigned int grid_over;     // entries on the overflow list (may exceed grid_over_cap(n))
+  unsigned int grid_big;                   // boxes over more than kGridMaxCells cells (may exceed grid_big_cap(n)); (the line of grid_over: both move in rare scenes only)
+  alignas(256) unsigned int grid_fail;     // too many crowded cells / a box over too many cells -- repeat on the sorted route
+};
+constexpr size_t kGridCtrBytes = 1024;     // the slot below the cell counters (cleared with them by the frame kernel)
+static_assert(sizeof(NmsGridCtr) <= kGridCtrBytes, "grid counters' slot");
 
 // (NmsHostInfo -- what the host needs after a call, written by the LAST kernel straight into pinned host memory or
 // the caller's device record -- lives in obb_nms_internal.h)
@@ -474,17 +481,13 @@ __device__ unsigned long long g_frame_stamps[16 + 2 * 2 * 4096];
 #define FR_STAMP(i) do { } while (0)
 #define FR_WALL(k, e) do { } while (0)
 #endif
-template <int KIND, bool F64 = false>
-__global__ __launch_bounds__(256) void nms_frame_kernel(const NmsSource src, int64_t n, int cell_hbits,
-                                                        NmsFrame *__restrict__ frame,
-                                                        uint4 *__restrict__ zero, size_t zero_vecs, int grid_log2) {
+// The frame of a call from a strided sample of its boxes: ONE workgroup of 256 threads (block 0 of nms_frame_kernel; round 6:
+// also the extra block of a retained call's insert launch, which takes the frame of THIS call's boxes for the NEXT call).
+// `frame2` (may be null) receives a second copy.
+template <int KIND, bool F64>
+__device__ __forceinline__ void nms_frame_block(const NmsSource &src, int64_t n, int cell_hbits, NmsFrame *__restrict__ frame,
+                                                NmsFrame *__restrict__ frame2, int grid_log2) {
   constexpr int S = KIND == 0 ? 6 : (KIND == 1 ? 9 : 5);
-  FR_WALL(0, 0);
-  if (blockIdx.x == 0) FR_STAMP(0);
-  for (size_t z = (size_t)blockIdx.x * blockDim.x + threadIdx.x; z < zero_vecs; z += (size_t)gridDim.x * blockDim.x)
-    zero[z] = make_uint4(0u, 0u, 0u, 0u);
-  if (blockIdx.x != 0) { FR_WALL(0, 1); return; }
-  FR_STAMP(1);
   __shared__ float4 sm[kFrameSamples];       // lo x, hi x, lo y, hi y of every sample (lo > hi: not finite)
   __shared__ float red[4][8];
   __shared__ float tot[8];
@@ -729,8 +732,26 @@ __global__ __launch_bounds__(256) void nms_frame_kernel(const NmsSource src, int
       f.ggx = (int)(kQMax >> f.gshx) + 1; f.ggy = (int)(kQMax >> f.gshy) + 1;
     }
     *frame = f;
+    if (frame2) *frame2 = f;
   }
   FR_STAMP(6);
+}
+
+template <int KIND, bool F64 = false>
+__global__ __launch_bounds__(256) void nms_frame_kernel(const NmsSource src, int64_t n, int cell_hbits,
+                                                        NmsFrame *__restrict__ frame, NmsFrame *__restrict__ frame2,
+                                                        uint4 *__restrict__ zero, size_t zero_vecs,
+                                                        uint4 *__restrict__ zero2, size_t zero2_vecs, int grid_log2) {
+  FR_WALL(0, 0);
+  if (blockIdx.x == 0) FR_STAMP(0);
+  for (size_t z = (size_t)blockIdx.x * blockDim.x + threadIdx.x; z < zero_vecs; z += (size_t)gridDim.x * blockDim.x)
+    zero[z] = make_uint4(0u, 0u, 0u, 0u);
+  // (grid route: the cell counters, a range of their own since round 6 -- at a fixed offset of the workspace)
+  for (size_t z = (size_t)blockIdx.x * blockDim.x + threadIdx.x; z < zero2_vecs; z += (size_t)gridDim.x * blockDim.x)
+    zero2[z] = make_uint4(0u, 0u, 0u, 0u);
+  if (blockIdx.x != 0) { FR_WALL(0, 1); return; }
+  FR_STAMP(1);
+  nms_frame_block<KIND, F64>(src, n, cell_hbits, frame, frame2, grid_log2);
   FR_WALL(0, 1);
 }
 
@@ -869,6 +890,53 @@ __host__ __device__ inline uint32_t grid_over_cap(int64_t n) {
 constexpr int kGridSkipCalls = 256;
 constexpr int64_t kGridAutoMax = 12000000;   // (the layout holds a table up to 2^24 boxes)
 
+// ---- RETAINED workspace (round 6; OBB_NMS_RETAIN): three launches instead of four ------------------------------------
+// The frame kernel has two jobs in front of every call -- clearing what the call's atomics count in, and the frame -- and
+// neither needs THIS call's boxes: any frame gives the same keep set (coordinates clamp into it monotonically, pairs are
+// only ever added), and the cell counters are zero again as soon as somebody clears them.  A caller that hands the SAME
+// workspace to call after call and promises not to write it in between lets the library keep both in it:
+//   * the tail of a call (the resolve launch, after the probe has read them) clears the cell counters and the three
+//     words the insert launch counts in (grid_over, grid_big, grid_fail); everything the LATER launches of a call count in
+//     (in-degree words, candidate / edge counters, the compaction's hand-over words) is cleared by the insert launch itself;
+//   * an extra workgroup of the insert launch takes the frame of THIS call's boxes (nms_frame_block: the frame kernel's
+//     block 0) and leaves it for the NEXT call, which reads the frame its predecessor left: a stream of scenes of one
+//     kind (the tiles of an image, the frames of a video, the bench's pool) gets frames as good as its own, a scene unlike
+//     its predecessor at worst a crowded grid -- the call is then repeated with the frame kernel in front (seeding).
+// The header at offset 0 of the workspace names the call the state is ready for (magic = f(sequence number, layout
+// signature)); the host keeps the expected value per workspace pointer (thread-local) and every launch of a retained call
+// checks it first: a workspace that somebody else wrote (or another thread used) makes the call leave without touching
+// anything and the host seeds it again.  Applies to the grid route below 2^18 boxes (the fused compaction is the tail).
+struct alignas(64) NmsRetain {
+  unsigned long long magic;
+  unsigned long long pad;
+  NmsFrame frames[2];          // call number q reads frames[q & 1] and leaves the frame of its own boxes in frames[(q + 1) & 1]
+};
+static_assert(sizeof(NmsRetain) <= 256, "the header's slot of the layout");
+constexpr unsigned long long kRetainMagic = 0x6F62626E6D733036ull;
+__host__ __device__ inline unsigned long long retain_magic(unsigned long long seq, unsigned int sig) {
+  return kRetainMagic ^ (seq * 0x9E3779B97F4A7C15ull) ^ ((unsigned long long)sig << 20);
+}
+// the layout signature the header's magic carries: table geometry (what the tail clears, what a frame's grid shifts assume)
+static inline unsigned int retain_sig(int grid_log2, int grid_bits, bool grouped) {
+  return (unsigned int)grid_log2 | ((unsigned int)grid_bits << 8) | (grouped ? 1u << 16 : 0u);
+}
+// what a retained call's launches need beyond the plain grid route's arguments (by value; all zero: a plain call)
+struct RetainArgs {
+  const unsigned long long *hdr_magic;   // header word to check against `expect` (null: no check -- a seeding call)
+  unsigned long long expect;
+  NmsFrame *frame_next;                  // insert launch: where the extra workgroup leaves the frame of this call's boxes
+  int *cnt;                              // insert launch: in-degree words, cleared per box
+  unsigned long long *ccnts;             // ... the candidate / edge counters
+  unsigned int *ucnts, *blockcnt;        // ... scan-unit counters (read by the record), hand-over words of the fused compaction
+};
+struct RetainTail {
+  unsigned long long *hdr_magic;         // null: no tail (a plain call)
+  unsigned long long expect, next;       // expect != 0: check first; next: the header's value once the state is ready again
+  uint4 *gcnt;                           // cell counters, cleared at the start of the resolve launch (the probe has read them)
+  size_t gcnt_vecs;
+};
+constexpr unsigned int kRouteUnseeded = 6u;   // record of a retained call that found the header changed: nothing was computed
+
 // GROUPED calls share the table: a group's cells are the spatial grid shifted by a pseudo-random offset that depends on a
 // 16-bit tag of the group id, modulo the table size (a power of two >= the spatial grid: one group's cells never alias
 // each other).  The entry carries the tag: entries of different tags are never paired; two groups of one tag (or that
@@ -922,26 +990,44 @@ __global__ __launch_bounds__(256) void nms_ginsert_kernel(const NmsSource src, i
                                                           float *__restrict__ ar,
                                                           const NmsFrame *__restrict__ frame, float thr,
                                                           uint32_t *__restrict__ gcnt, uint4 *__restrict__ gtab,
-                                                          NmsCounters *__restrict__ ctr, uint32_t mask,
+                                                          NmsCounters *__restrict__ ctr, NmsGridCtr *__restrict__ gctr, uint32_t mask,
                                                           uint4 *__restrict__ gover, uint32_t *__restrict__ gbig,
-                                                          uint32_t big_cap, int give_up) {    // (big_cap = grid_big_cap(n), a 64-bit division: the host's)
+                                                          uint32_t big_cap, int give_up,    // (big_cap = grid_big_cap(n), a 64-bit division: the host's)
+                                                          const RetainArgs ra, int cell_hbits, int grid_log2) {
   constexpr int S = KIND == 0 ? 6 : (KIND == 1 ? 9 : 5);
   FR_WALL(1, 0);
+  // ---- retained call (no frame launch in front; see NmsRetain): the header must name THIS call, the last workgroup takes
+  // the frame of this call's boxes for the next one, and what the later launches count in is cleared here
+  unsigned int nblk = gridDim.x;
+  if (ra.frame_next) {
+    if (ra.hdr_magic && *ra.hdr_magic != ra.expect) return;      // (uniform over the launch: nothing is touched)
+    nblk = gridDim.x - 1u;
+    if (blockIdx.x == nblk) { nms_frame_block<KIND, false>(src, n, cell_hbits, ra.frame_next, nullptr, grid_log2); return; }
+    if (blockIdx.x == 0) {
+      const unsigned int t = threadIdx.x;
+      if (t < 3u * kShards) ra.ccnts[(size_t)t * kCandStride] = 0ull;
+      if (t < 2u * kShards) ra.ucnts[(size_t)t * kUnitStride] = 0u;
+      if (t < (unsigned)kShards + 1u) ra.blockcnt[t] = 0u;
+      if (t == 255u) {       // (grid_over, grid_big, grid_fail are this launch's own: the previous call's tail cleared them)
+        ctr->edges = 0ull; ctr->kept = 0; ctr->rounds = 0; ctr->done = 0u; ctr->state = 0u; ctr->cand_total = 0ull; ctr->cand_worst = 0ull;
+      }
+    }
+  }
   const NmsFrame fr = *frame;
   uint32_t *__restrict__ gover_cell = reinterpret_cast<uint32_t *>(gover + kGridOverMax);
   const uint32_t over_cap = grid_over_cap(n);
   // an entry whose cell is full goes on the overflow list (nms_gprobe_kernel pairs it with the cell's entries and with the
   // list's other entries of the cell); a full list gives the route up
   auto spill = [&](uint32_t cell, const uint4 &e, uint32_t failword) {
-    const uint32_t o = atomicAdd(&ctr->grid_over, 1u);
+    const uint32_t o = atomicAdd(&gctr->grid_over, 1u);
     if (o < over_cap) { gover[o] = e; gover_cell[o] = cell; }
-    else ctr->grid_fail = failword;
+    else gctr->grid_fail = failword;
   };
   const bool grouped = src_grouped(src);
   const uint32_t fail = 1u + (uint32_t)KIND + (grouped ? 4u : 0u) + 8u * (uint32_t)src.mode;   // (non-zero; names the size class's skip hint: kind, grouped, source mode)
-  if (give_up && blockIdx.x == 0 && threadIdx.x == 0) ctr->grid_fail = fail;      // (test hook, OBB_TUNE_NMS_GRID = 2: the repeat paths without a crowded scene)
+  if (give_up && blockIdx.x == 0 && threadIdx.x == 0) gctr->grid_fail = fail;      // (test hook, OBB_TUNE_NMS_GRID = 2: the repeat paths without a crowded scene)
   const int xbits = 15 - fr.gshx;                  // ggx = 2^xbits
-  for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n; b += (int64_t)gridDim.x * blockDim.x) {
+  for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n; b += (int64_t)nblk * blockDim.x) {
     const float *row = src.dets + b * src.pitch;
     Quad q;
     load_quad<KIND>(row, q);
@@ -956,6 +1042,7 @@ __global__ __launch_bounds__(256) void nms_ginsert_kernel(const NmsSource src, i
     if (KIND == 2) hbb_record(row, r, wellformed);
     rec[b] = r;
     ar[b] = q.area;
+    if (ra.frame_next) ra.cnt[b] = 0;
     const uint32_t tag = grouped ? grid_tag(r.group) : 0u;
     const uint32_t goff = grid_tag_offset(tag, mask);
     uint2 o;
@@ -964,9 +1051,9 @@ __global__ __launch_bounds__(256) void nms_ginsert_kernel(const NmsSource src, i
       const uint32_t ncell = (cx1 - cx0 + 1u) * (cy1 - cy0 + 1u);
       const uint4 ent = make_uint4(o.x, o.y, (uint32_t)b, grid_entry_word(r.area, tag));
       if (ncell > (uint32_t)kGridMaxCells) {
-        const uint32_t k = atomicAdd(&ctr->grid_big, 1u);
+        const uint32_t k = atomicAdd(&gctr->grid_big, 1u);
         if (k < big_cap) gbig[k] = (uint32_t)b;
-        else ctr->grid_fail = fail;
+        else gctr->grid_fail = fail;
       } else if (cx1 - cx0 <= 1u && cy1 - cy0 <= 1u) {
         // the usual box (a cell is about mean + sigma extent wide): 1-4 cells, their slots requested TOGETHER -- a
         // returning device-scope atomic is a round trip of ~2 us and four of them in a row were most of this kernel
@@ -1958,12 +2045,14 @@ __global__ __launch_bounds__(64 * kNmsWaves) void nms_gprobe_kernel(const QuadRe
                                                            uint32_t ncells, float thr, int per_box_thr, int flags,
                                                            uint2 *__restrict__ edges, unsigned long long segcap,
                                                            unsigned long long *__restrict__ ccnts, int *__restrict__ cnt,
-                                                           const NmsCounters *__restrict__ ctr,
+                                                           const NmsGridCtr *__restrict__ ctr,
                                                            const uint4 *__restrict__ gover, uint32_t over_cap,
                                                            const float *__restrict__ thr_table, int thr_count,
                                                            const float *__restrict__ ar,
-                                                           const uint32_t *__restrict__ gbig, uint32_t big_cap, uint32_t n) {
+                                                           const uint32_t *__restrict__ gbig, uint32_t big_cap, uint32_t n,
+                                                           const unsigned long long *__restrict__ hdr_magic, unsigned long long hdr_expect) {
   static_assert(kGridCap == 32, "two cells per 64-lane load");
+  if (hdr_magic && *hdr_magic != hdr_expect) return;      // (a retained call whose workspace somebody else wrote: NmsRetain)
   __shared__ uint2 queue[kNmsWaves][kNmsQueue];
   __shared__ uint4 ent[kNmsWaves][kGridCpwMax * kGridCap];
   // pair number t of a cell -> (s, u), s < u, t = u (u - 1) / 2 + s: looked up (the square root and its two corrections were
@@ -2312,13 +2401,29 @@ __global__ __launch_bounds__(COMPACT ? kResolveThreadsCompact : kResolveThreads)
                                                            int64_t n, int64_t *__restrict__ keep_out,
                                                            NmsHostInfo *__restrict__ hinfo, int coop,
                                                            unsigned int *__restrict__ blockcnt,
-                                                           const unsigned int *__restrict__ ucnts, int tuning_tail) {
+                                                           const unsigned int *__restrict__ ucnts, int tuning_tail,
+                                                           NmsGridCtr *__restrict__ gctr, const RetainTail rt) {
   constexpr int kThreads = COMPACT ? kResolveThreadsCompact : kResolveThreads;
   constexpr int kW = kThreads / 64;
   __shared__ int overflow;
   __shared__ long long pre[kShards + 1];   // virtual start of every edge segment
   __shared__ int is_last;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // a retained call whose workspace somebody else wrote since its predecessor (NmsRetain): the insert and probe launches have
+  // left without touching anything, this one only says so -- the host seeds the workspace again
+  if constexpr (!COMPACT) if (rt.hdr_magic && rt.expect && *rt.hdr_magic != rt.expect) {
+    if (blockIdx.x == 0 && tid == 0) {
+      hinfo->kept = 0; hinfo->edges = 0ull; hinfo->rounds = 0; hinfo->cand_total = 0ull; hinfo->cand_worst = 0ull;
+      hinfo->heavy_units = 0u; hinfo->light_units = 0u; hinfo->route = kRouteUnseeded; hinfo->unit_worst = 0u;
+    }
+    return;
+  }
+  // tail of a call on a retained workspace: this workgroup's share of the cell counters is cleared as the LAST thing it does
+  // (the probe launch has read them; behind the keep list and the record, so that nothing of the call waits for these stores)
+  auto retain_clear = [&]() __attribute__((always_inline)) {
+    if constexpr (!COMPACT) if (rt.gcnt)
+      for (size_t z = (size_t)blockIdx.x * kThreads + tid; z < rt.gcnt_vecs; z += (size_t)gridDim.x * kThreads) rt.gcnt[z] = make_uint4(0u, 0u, 0u, 0u);
+  };
   // large calls (no fused compaction): gridDim.x = kShards * P workgroups, P of them share a shard's segment -- one CU
   // issues about a third of a scattered request per clock, and a segment of 13 000 edges was 58 us of first sweep
   const int parts = (int)gridDim.x / kShards, shard = (int)blockIdx.x / parts, part = (int)blockIdx.x - shard * parts;
@@ -2343,7 +2448,7 @@ __global__ __launch_bounds__(COMPACT ? kResolveThreadsCompact : kResolveThreads)
     }
     if (lane == 0) {
       s_info[0] = v; s_info[1] = mx; s_units[0] = uh; s_units[1] = ul; s_units[2] = uw;
-      s_units[3] = __hip_atomic_load(&ctr->grid_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (set by the insert / probe launches only)
+      s_units[3] = gctr ? __hip_atomic_load(&gctr->grid_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;   // (set by the insert launch only; null: not the grid route)
     }
   }
   if (wave == 0) {  // 64 lanes = 64 shards
@@ -2569,7 +2674,7 @@ __global__ __launch_bounds__(COMPACT ? kResolveThreadsCompact : kResolveThreads)
     }
     __syncthreads();
     const int go = s_go;
-    if (go == 2) return;
+    if (go == 2) { retain_clear(); return; }
     // one pass: a thread requests its (up to) 16 words of the slice together -- they are agent-scope loads, a fabric
     // round trip each -- keeps the verdicts in registers, the 16 x 4 (row, wave) counts are scanned by one wave
     constexpr int kR = 64 / kW, kSlice = kR * kThreads;     // 4096 words: a slice of n < 2^18 boxes over 64 shards
@@ -2633,7 +2738,14 @@ __global__ __launch_bounds__(COMPACT ? kResolveThreadsCompact : kResolveThreads)
       const unsigned int gf = s_units[3];
       hinfo->route = gf ? (3u | (gf << 8)) : 2u;   // 3: repeat without the grid (bits 8..: which skip hint, nms_ginsert_kernel)
       hinfo->unit_worst = s_units[2];
+      if (rt.hdr_magic) {
+        // retained workspace: the three words the NEXT call's insert launch counts in (every workgroup of this launch has
+        // read grid_fail: they have all arrived, or left), and the header now names that call
+        gctr->grid_over = 0u; gctr->grid_big = 0u; gctr->grid_fail = 0u;
+        *rt.hdr_magic = rt.next;
+      }
     }
+    retain_clear();
     return;
   }
   if (COMPACT) {
@@ -2743,7 +2855,8 @@ __global__ __launch_bounds__(1024) void nms_compact_kernel(const int *__restrict
                                                            NmsCounters *__restrict__ ctr,
                                                            const unsigned long long *__restrict__ ccnts,
                                                            const unsigned int *__restrict__ ucnts,
-                                                           NmsHostInfo *__restrict__ hinfo) {
+                                                           NmsHostInfo *__restrict__ hinfo,
+                                                           const NmsGridCtr *__restrict__ gctr) {
   __shared__ int wsum[PER][16];
   __shared__ long long red[16];
   __shared__ unsigned int s_ticket;
@@ -2810,7 +2923,8 @@ __global__ __launch_bounds__(1024) void nms_compact_kernel(const int *__restrict
       hinfo->kept = sbase + tot; hinfo->edges = ctr->edges; hinfo->rounds = ctr->rounds;
       hinfo->cand_total = v; hinfo->cand_worst = mx;
       hinfo->heavy_units = uh; hinfo->light_units = ul;
-      hinfo->route = ctr->grid_fail ? (3u | (ctr->grid_fail << 8)) : 2u; hinfo->unit_worst = uw;   // 3: the grid route gave up -- repeat without it
+      const unsigned int gf = gctr ? gctr->grid_fail : 0u;
+      hinfo->route = gf ? (3u | (gf << 8)) : 2u; hinfo->unit_worst = uw;   // 3: the grid route gave up -- repeat without it
     }
   }
 }
@@ -3216,7 +3330,24 @@ struct NmsLayout {
   size_t gover;                   // grid route: the overflow list (entries that found their cell full)
   size_t gbig;                    // grid route: the boxes over too many cells
   int grid_bits;                  // ... and 2^grid_bits cells in the table (>= 2 * grid_log2: the groups of a grouped call share it)
+  size_t retain, gcnt;            // round 6: the retained-state header (offset 0) and the grid route's cell counters, at offsets that
+                                  // depend on grid_bits only -- what a call leaves there for the next one survives a change of n
 };
+
+// grid route: cells per axis at most (2^g) and cells of the table (2^bits) for a call of n boxes; false: no grid for this n
+static bool grid_geometry(int64_t n, int &g, int &bits) {
+  g = 0; bits = 0;
+  if (!(n >= 256 && n <= (1 << 24))) return false;
+  g = 6;
+  while (g < kGridMaxLog2 && (1ll << (2 * g)) * 2 < n) ++g;      // (x 8 instead of x 2 -- a quarter of the probe's waves -- measured no faster: the cell size follows the extents, not this bound)
+  // table: the spatial grid, or -- grouped calls: the groups' grids share the table -- about 2.5 boxes per cell: with
+  // ~1.8 entries per box that is 4.5 entries per cell on average and a 33rd entry (the route gives up) a 6-sigma
+  // event of the compound-Poisson count (2^18 cells for 1.25 M boxes in 24 000 groups: 9.7 on average, dozens of
+  // overflowing cells in every call)
+  bits = 2 * g;                                               // (half that table for 1.25 M grouped boxes: the same times)
+  while (bits < kGridMaxBits && ((int64_t)5 << bits) < 2 * n) ++bits;
+  return true;
+}
 
 static int nms_layout(int64_t n, int64_t edge_capacity, NmsLayout &L) {
   if (edge_capacity <= 0) {
@@ -3229,6 +3360,20 @@ static int nms_layout(int64_t n, int64_t edge_capacity, NmsLayout &L) {
   L.ntiles = (int64_t)nt;
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+  L.grid_log2 = 0; L.grid_bits = 0;
+  L.retain = take(sizeof(NmsRetain));
+  L.gcnt = off;
+  {
+    int g = 0, bits = 0;
+    if (grid_geometry(n, g, bits)) {
+      L.grid_log2 = g; L.grid_bits = bits;
+      // (table and cell counters on 64-KiB boundaries: the insert kernel -- scattered atomics and 16-B stores -- is 2.5 us
+      // slower at 100 000 - 131 072 boxes with either of them at certain other offsets, whatever the code; DESIGN_LOG)
+      off = align_up(off, 65536);
+      L.gcnt = take(((size_t)1 << bits) * sizeof(uint32_t));
+      off = align_up(off, 65536);
+    }
+  }
   L.rec = take(nn * sizeof(QuadRec));
   L.iv = take(nn * sizeof(float4));       // (direct route only)
   L.ar = take(nn * sizeof(float));
@@ -3238,22 +3383,10 @@ static int nms_layout(int64_t n, int64_t edge_capacity, NmsLayout &L) {
   L.gsrc = take(nn * 4);       // per-box group / threshold derived by the prep kernel (NmsSource modes 1, 2)
   L.tsrc = take(nn * 4);
   // grid route: (2^g x 2^g cells) x kGridCap entries of 16 bytes; g from n (about half a cell per box), sizes where the route applies
-  L.grid_log2 = 0; L.grid_bits = 0;
   L.gtab = off;
-  if (n >= 256 && n <= (1 << 24)) {
-    int g = 6;
-    while (g < kGridMaxLog2 && (1ll << (2 * g)) * 2 < n) ++g;      // (x 8 instead of x 2 -- a quarter of the probe's waves -- measured no faster: the cell size follows the extents, not this bound)
-    // table: the spatial grid, or -- grouped calls: the groups' grids share the table -- about 2.5 boxes per cell: with
-    // ~1.8 entries per box that is 4.5 entries per cell on average and a 33rd entry (the route gives up) a 6-sigma
-    // event of the compound-Poisson count (2^18 cells for 1.25 M boxes in 24 000 groups: 9.7 on average, dozens of
-    // overflowing cells in every call)
-    int bits = 2 * g;                                               // (half that table for 1.25 M grouped boxes: the same times)
-    while (bits < kGridMaxBits && ((int64_t)5 << bits) < 2 * n) ++bits;
-    L.grid_log2 = g; L.grid_bits = bits;
-    // (table and cell counters on 64-KiB boundaries: the insert kernel -- scattered atomics and 16-B stores -- is 2.5 us
-    // slower at 100 000 - 131 072 boxes with either of them at certain other offsets, whatever the code; DESIGN_LOG)
+  if (L.grid_log2 > 0) {
     off = align_up(off, 65536);
-    L.gtab = take(((size_t)1 << bits) * kGridCap * sizeof(uint4));
+    L.gtab = take(((size_t)1 << L.grid_bits) * kGridCap * sizeof(uint4));
     L.gover = take((size_t)kGridOverMax * (sizeof(uint4) + sizeof(uint32_t)) + (size_t)kGridBigMax * sizeof(uint32_t));     // overflow entries, then their cells, then the big list
     L.gbig = L.gover + (size_t)kGridOverMax * (sizeof(uint4) + sizeof(uint32_t));
   }
@@ -3283,8 +3416,7 @@ static int nms_layout(int64_t n, int64_t edge_capacity, NmsLayout &L) {
   L.ticket = take(4);                                // nms_cullbox_kernel: tile tickets
   L.tbox = take(nt * sizeof(uint2));                 // (zero = "not published yet" for nms_cullbox_kernel)
   L.tgr = take(nt * sizeof(uint32_t));
-  if (L.grid_log2 > 0) off = align_up(off, 65536);
-  L.hist = take(((size_t)1 << (L.grid_bits > 18 ? L.grid_bits : 18)) * 4);   // (kCells, or the grid route's cell counters; LAST of the zeroed range: only the cells a call uses are cleared)
+  L.hist = take(((size_t)1 << 18) * 4);   // (kCells; LAST of the zeroed range: only the cells a call uses are cleared.  The grid route's cell counters lived here until round 6: L.gcnt)
   static_assert(kCells == (1 << 18), "hist");
   L.zero_end = off;
   // variable part, all 8-byte entries: [cands | edges | units]; candidates and edges
@@ -3436,7 +3568,7 @@ static int nms_validate(const char *who, const float *dets_dev, int64_t n, int k
                         const void *workspace_dev) {
   if (n < 0) return set_err(OBB_EINVAL, "%s: negative n", who);
   if (kind != OBB_KIND_RBOX && kind != OBB_KIND_POLY && kind != OBB_KIND_HBB) return set_err(OBB_EINVAL, "%s: bad kind %d", who, kind);
-  if (flags_in & ~OBB_NMS_STRICT) return set_err(OBB_EINVAL, "%s: unknown flags 0x%x", who, flags_in);
+  if (flags_in & ~(OBB_NMS_STRICT | OBB_NMS_RETAIN)) return set_err(OBB_EINVAL, "%s: unknown flags 0x%x", who, flags_in);
   // (Horizontal boxes with a threshold <= 0 under the `>=` rule: nms_cpu.cpp:56 then holds for DISJOINT boxes too -- every
   // later box of a group falls to the first one unless its ovr is negative or NaN.  Served exactly, by
   // nms_hbb_allpairs_kernel: nms_enqueue_source.)
@@ -3579,24 +3711,44 @@ int nms_enqueue_source(const char *who, NmsSource src, int64_t n, int kind, floa
     q.grid = grid;
     if (grid) {
       const size_t gcells = (size_t)1 << L.grid_bits;
-      const size_t zbytes = (L.hist + gcells * sizeof(uint32_t)) - L.zero_begin;      // (the cell counters live in the histogram's memory)
-      uint4 *zero = reinterpret_cast<uint4 *>(ws + L.zero_begin);
-      const size_t zero_vecs = zbytes / sizeof(uint4);
-      unsigned zb = (unsigned)((zero_vecs + 1023) / 1024) + 1u;
-      zb = zb > 256u ? 256u : zb;
+      const int gcoop = n < (1 << 18) ? 1 : 0;          // (the tail of the sorted route: compaction inside the resolve launch below 2^18 boxes, its own launch from there)
+      // retained state (NmsRetain): only where the fused compaction is the call's tail; 2 = three launches
+      const int retain = (src.retain != 0 && gcoop && tuning(OBB_TUNE_NMS_RETAIN, 1) != 0) ? src.retain : 0;
+      q.retained = retain;
+      NmsRetain *hdr = reinterpret_cast<NmsRetain *>(ws + L.retain);
+      const unsigned long long seq = src.retain_seq;
+      const unsigned int sig = retain_sig(L.grid_log2, L.grid_bits, grouped_call);
+      NmsFrame *fr_cur = retain ? &hdr->frames[seq & 1ull] : frame, *fr_next = retain ? &hdr->frames[(seq + 1ull) & 1ull] : nullptr;
+      uint32_t *gcnt = reinterpret_cast<uint32_t *>(ws + L.gcnt);
+      NmsGridCtr *gctr = reinterpret_cast<NmsGridCtr *>(ws + L.gcnt - kGridCtrBytes);      // (the slot just below the cell counters)
       uint4 *gtab = reinterpret_cast<uint4 *>(ws + L.gtab);
       uint4 *gover = reinterpret_cast<uint4 *>(ws + L.gover);
       uint32_t *gbig = reinterpret_cast<uint32_t *>(ws + L.gbig);
       const int hbits = 7, grid_log2 = L.grid_log2;
       OBB_PHASE(0);
-      if (kind == OBB_KIND_RBOX) hipLaunchKernelGGL(nms_frame_kernel<0>, dim3(zb), dim3(256), 0, st, src, n, hbits, frame, zero, zero_vecs, grid_log2);
-      else if (kind == OBB_KIND_POLY) hipLaunchKernelGGL(nms_frame_kernel<1>, dim3(zb), dim3(256), 0, st, src, n, hbits, frame, zero, zero_vecs, grid_log2);
-      else hipLaunchKernelGGL(nms_frame_kernel<2>, dim3(zb), dim3(256), 0, st, src, n, hbits, frame, zero, zero_vecs, grid_log2);
-      OBB_LAUNCH_CHECK();
+      if (retain != 2) {
+        const size_t zbytes = L.hist - L.zero_begin;          // the call's counters ...
+        uint4 *zero = reinterpret_cast<uint4 *>(ws + L.zero_begin);
+        const size_t zero_vecs = zbytes / sizeof(uint4);
+        uint4 *zero2 = reinterpret_cast<uint4 *>(gctr);        // ... the insert launch's three words and the cell counters behind them
+        const size_t zero2_vecs = (kGridCtrBytes + gcells * sizeof(uint32_t)) / sizeof(uint4);
+        unsigned zb = (unsigned)((zero_vecs + zero2_vecs + 1023) / 1024) + 1u;
+        zb = zb > 256u ? 256u : zb;
+        if (kind == OBB_KIND_RBOX) hipLaunchKernelGGL(nms_frame_kernel<0>, dim3(zb), dim3(256), 0, st, src, n, hbits, fr_cur, fr_next, zero, zero_vecs, zero2, zero2_vecs, grid_log2);
+        else if (kind == OBB_KIND_POLY) hipLaunchKernelGGL(nms_frame_kernel<1>, dim3(zb), dim3(256), 0, st, src, n, hbits, fr_cur, fr_next, zero, zero_vecs, zero2, zero2_vecs, grid_log2);
+        else hipLaunchKernelGGL(nms_frame_kernel<2>, dim3(zb), dim3(256), 0, st, src, n, hbits, fr_cur, fr_next, zero, zero_vecs, zero2, zero2_vecs, grid_log2);
+        OBB_LAUNCH_CHECK();
+      }
       const uint32_t gmask = (uint32_t)gcells - 1u;
-      if (kind == OBB_KIND_RBOX) hipLaunchKernelGGL(nms_ginsert_kernel<0>, dim3(pblocks), dim3(256), 0, st, src, n, rec, ar, frame, iou_thr, hist, gtab, ctr, gmask, gover, gbig, grid_big_cap(n), gknob == 2 ? 1 : 0);
-      else if (kind == OBB_KIND_POLY) hipLaunchKernelGGL(nms_ginsert_kernel<1>, dim3(pblocks), dim3(256), 0, st, src, n, rec, ar, frame, iou_thr, hist, gtab, ctr, gmask, gover, gbig, grid_big_cap(n), gknob == 2 ? 1 : 0);
-      else hipLaunchKernelGGL(nms_ginsert_kernel<2>, dim3(pblocks), dim3(256), 0, st, src, n, rec, ar, frame, iou_thr, hist, gtab, ctr, gmask, gover, gbig, grid_big_cap(n), gknob == 2 ? 1 : 0);
+      RetainArgs ra = {};
+      if (retain == 2) {
+        ra.hdr_magic = &hdr->magic; ra.expect = retain_magic(seq, sig);
+        ra.frame_next = fr_next; ra.cnt = cnt; ra.ccnts = ccnts; ra.ucnts = ucnts; ra.blockcnt = blockcnt;
+      }
+      const unsigned iblocks = pblocks + (retain == 2 ? 1u : 0u);      // (+ the workgroup that takes the next call's frame)
+      if (kind == OBB_KIND_RBOX) hipLaunchKernelGGL(nms_ginsert_kernel<0>, dim3(iblocks), dim3(256), 0, st, src, n, rec, ar, fr_cur, iou_thr, gcnt, gtab, ctr, gctr, gmask, gover, gbig, grid_big_cap(n), gknob == 2 ? 1 : 0, ra, hbits, grid_log2);
+      else if (kind == OBB_KIND_POLY) hipLaunchKernelGGL(nms_ginsert_kernel<1>, dim3(iblocks), dim3(256), 0, st, src, n, rec, ar, fr_cur, iou_thr, gcnt, gtab, ctr, gctr, gmask, gover, gbig, grid_big_cap(n), gknob == 2 ? 1 : 0, ra, hbits, grid_log2);
+      else hipLaunchKernelGGL(nms_ginsert_kernel<2>, dim3(iblocks), dim3(256), 0, st, src, n, rec, ar, fr_cur, iou_thr, gcnt, gtab, ctr, gctr, gmask, gover, gbig, grid_big_cap(n), gknob == 2 ? 1 : 0, ra, hbits, grid_log2);
       OBB_LAUNCH_CHECK();
       OBB_PHASE(1); OBB_PHASE(2);
       OBB_PHASE(3);
@@ -3609,23 +3761,27 @@ int nms_enqueue_source(const char *who, NmsSource src, int64_t n, int kind, floa
       const size_t gp_blocks = (gp_waves + kNmsWaves - 1) / kNmsWaves;
       const float *gthr = src.mode == 2 ? src.thr_table : nullptr;
       const int gthr_n = (int)(src.mult < (1 << 20) ? src.mult : (1 << 20));
+      const unsigned long long *pmagic = retain == 2 ? &hdr->magic : nullptr;
       if (grouped_call)
         hipLaunchKernelGGL(nms_gprobe_kernel<true>, dim3((unsigned)gp_blocks), dim3(64 * kNmsWaves), 0, st,
-                           rec, frame, hist, gtab, (uint32_t)gcells, prune_thr, thr_dev ? 1 : 0, flags, edges, segcap, ccnts, cnt, ctr, gover, grid_over_cap(n), gthr, gthr_n, ar, gbig, grid_big_cap(n), (uint32_t)n);
+                           rec, fr_cur, gcnt, gtab, (uint32_t)gcells, prune_thr, thr_dev ? 1 : 0, flags, edges, segcap, ccnts, cnt, gctr, gover, grid_over_cap(n), gthr, gthr_n, ar, gbig, grid_big_cap(n), (uint32_t)n, pmagic, ra.expect);
       else
         hipLaunchKernelGGL(nms_gprobe_kernel<false>, dim3((unsigned)gp_blocks), dim3(64 * kNmsWaves), 0, st,
-                           rec, frame, hist, gtab, (uint32_t)gcells, prune_thr, thr_dev ? 1 : 0, flags, edges, segcap, ccnts, cnt, ctr, gover, grid_over_cap(n), gthr, gthr_n, ar, gbig, grid_big_cap(n), (uint32_t)n);
+                           rec, fr_cur, gcnt, gtab, (uint32_t)gcells, prune_thr, thr_dev ? 1 : 0, flags, edges, segcap, ccnts, cnt, gctr, gover, grid_over_cap(n), gthr, gthr_n, ar, gbig, grid_big_cap(n), (uint32_t)n, pmagic, ra.expect);
       OBB_LAUNCH_CHECK();
       OBB_PHASE(4);
       OBB_PHASE(5);
-      // (the tail of the sorted route: compaction inside the resolve launch below 2^18 boxes, its own launch from there)
-      const int gcoop = n < (1 << 18) ? 1 : 0;
-      hipLaunchKernelGGL(nms_resolve_kernel<false>, dim3(kShards * (gcoop ? 1 : resolve_parts())), dim3(kResolveThreads), 0, st, edges, segcap, cnt, ctr, ccnts, n, keep_dev, result, gcoop, blockcnt, ucnts, (int)tuning(OBB_TUNE_NMS_RESOLVE_TAIL, 1));
+      RetainTail rt = {};
+      if (retain) {
+        rt.hdr_magic = &hdr->magic; rt.expect = retain == 2 ? ra.expect : 0ull; rt.next = retain_magic(seq + 1ull, sig);
+        rt.gcnt = reinterpret_cast<uint4 *>(gcnt); rt.gcnt_vecs = gcells * sizeof(uint32_t) / sizeof(uint4);
+      }
+      hipLaunchKernelGGL(nms_resolve_kernel<false>, dim3(kShards * (gcoop ? 1 : resolve_parts())), dim3(kResolveThreads), 0, st, edges, segcap, cnt, ctr, ccnts, n, keep_dev, result, gcoop, blockcnt, ucnts, (int)tuning(OBB_TUNE_NMS_RESOLVE_TAIL, 1), gctr, rt);
       OBB_LAUNCH_CHECK();
       OBB_PHASE(6);
       if (!gcoop) {
         const unsigned cblocks = (unsigned)((n + 4095) / 4096);
-        hipLaunchKernelGGL(nms_compact_kernel<4>, dim3(cblocks), dim3(1024), 0, st, cnt, n, blockcnt, keep_dev, ctr, ccnts, ucnts, result);
+        hipLaunchKernelGGL(nms_compact_kernel<4>, dim3(cblocks), dim3(1024), 0, st, cnt, n, blockcnt, keep_dev, ctr, ccnts, ucnts, result, gctr);
         OBB_LAUNCH_CHECK();
       }
       OBB_PHASE(7);
@@ -3660,13 +3816,13 @@ int nms_enqueue_source(const char *who, NmsSource src, int64_t n, int kind, floa
     unsigned zb = (unsigned)((zero_vecs + 1023) / 1024) + 1u;     // (block 0 also takes the frame)
     zb = zb > 256u ? 256u : zb;
     if (kind == OBB_KIND_RBOX)
-      hipLaunchKernelGGL(nms_frame_kernel<0>, dim3(zb), dim3(256), 0, st, src, n, hbits, frame, zero, zero_vecs, grid_log2);
+      hipLaunchKernelGGL(nms_frame_kernel<0>, dim3(zb), dim3(256), 0, st, src, n, hbits, frame, (NmsFrame *)nullptr, zero, zero_vecs, (uint4 *)nullptr, (size_t)0, grid_log2);
     else if (kind == OBB_KIND_POLY)
-      hipLaunchKernelGGL(nms_frame_kernel<1>, dim3(zb), dim3(256), 0, st, src, n, hbits, frame, zero, zero_vecs, grid_log2);
+      hipLaunchKernelGGL(nms_frame_kernel<1>, dim3(zb), dim3(256), 0, st, src, n, hbits, frame, (NmsFrame *)nullptr, zero, zero_vecs, (uint4 *)nullptr, (size_t)0, grid_log2);
     else if (f64)
-      hipLaunchKernelGGL((nms_frame_kernel<2, true>), dim3(zb), dim3(256), 0, st, src, n, hbits, frame, zero, zero_vecs, grid_log2);
+      hipLaunchKernelGGL((nms_frame_kernel<2, true>), dim3(zb), dim3(256), 0, st, src, n, hbits, frame, (NmsFrame *)nullptr, zero, zero_vecs, (uint4 *)nullptr, (size_t)0, grid_log2);
     else
-      hipLaunchKernelGGL(nms_frame_kernel<2>, dim3(zb), dim3(256), 0, st, src, n, hbits, frame, zero, zero_vecs, grid_log2);
+      hipLaunchKernelGGL(nms_frame_kernel<2>, dim3(zb), dim3(256), 0, st, src, n, hbits, frame, (NmsFrame *)nullptr, zero, zero_vecs, (uint4 *)nullptr, (size_t)0, grid_log2);
     OBB_LAUNCH_CHECK();
     if (kind == OBB_KIND_RBOX)
       hipLaunchKernelGGL(nms_prepq_kernel<0>, dim3(pblocks), dim3(256), 0, st, src, n, rec, qb, ar, ckey, crank, hist, hbits, frame, iou_thr);
@@ -3690,7 +3846,7 @@ int nms_enqueue_source(const char *who, NmsSource src, int64_t n, int kind, floa
     OBB_LAUNCH_CHECK();
     OBB_PHASE(4);
     OBB_PHASE(5);
-    hipLaunchKernelGGL(nms_resolve_kernel<true>, dim3(kShards), dim3(kResolveThreadsCompact), 0, st, edges, segcap, cnt, ctr, ccnts, n, keep_dev, result, 0, blockcnt, ucnts, (int)tuning(OBB_TUNE_NMS_RESOLVE_TAIL, 1));
+    hipLaunchKernelGGL(nms_resolve_kernel<true>, dim3(kShards), dim3(kResolveThreadsCompact), 0, st, edges, segcap, cnt, ctr, ccnts, n, keep_dev, result, 0, blockcnt, ucnts, (int)tuning(OBB_TUNE_NMS_RESOLVE_TAIL, 1), (NmsGridCtr *)nullptr, RetainTail{});
     OBB_LAUNCH_CHECK();
     OBB_PHASE(6);
     OBB_PHASE(7);
@@ -3749,17 +3905,17 @@ int nms_enqueue_source(const char *who, NmsSource src, int64_t n, int kind, floa
     OBB_PHASE(5);
     // (below 2^18 boxes the compaction is the tail of the resolve launch: its 64 workgroups take n / 64 words each)
     const int coop = n < (1 << 18) ? (int)tuning(OBB_TUNE_NMS_FUSED_COMPACT, 1) : 0;   // (2: waiters give up at once -- the fallback under test)
-    hipLaunchKernelGGL(nms_resolve_kernel<false>, dim3(kShards * (coop ? 1 : resolve_parts())), dim3(kResolveThreads), 0, st, edges, segcap, cnt, ctr, ccnts, n, keep_dev, result, coop, blockcnt, ucnts, (int)tuning(OBB_TUNE_NMS_RESOLVE_TAIL, 1));
+    hipLaunchKernelGGL(nms_resolve_kernel<false>, dim3(kShards * (coop ? 1 : resolve_parts())), dim3(kResolveThreads), 0, st, edges, segcap, cnt, ctr, ccnts, n, keep_dev, result, coop, blockcnt, ucnts, (int)tuning(OBB_TUNE_NMS_RESOLVE_TAIL, 1), (NmsGridCtr *)nullptr, RetainTail{});
     OBB_LAUNCH_CHECK();
     // phase 6: compaction (one pass: every block publishes its count and sums its predecessors')
     OBB_PHASE(6);
     if (coop) {
     } else if (n >= (1 << 18)) {
       const unsigned cblocks = (unsigned)((n + 4095) / 4096);
-      hipLaunchKernelGGL(nms_compact_kernel<4>, dim3(cblocks), dim3(1024), 0, st, cnt, n, blockcnt, keep_dev, ctr, ccnts, ucnts, result);
+      hipLaunchKernelGGL(nms_compact_kernel<4>, dim3(cblocks), dim3(1024), 0, st, cnt, n, blockcnt, keep_dev, ctr, ccnts, ucnts, result, (const NmsGridCtr *)nullptr);
     } else {
       const unsigned cblocks = (unsigned)((n + 1023) / 1024);
-      hipLaunchKernelGGL(nms_compact_kernel<1>, dim3(cblocks), dim3(1024), 0, st, cnt, n, blockcnt, keep_dev, ctr, ccnts, ucnts, result);
+      hipLaunchKernelGGL(nms_compact_kernel<1>, dim3(cblocks), dim3(1024), 0, st, cnt, n, blockcnt, keep_dev, ctr, ccnts, ucnts, result, (const NmsGridCtr *)nullptr);
     }
     OBB_LAUNCH_CHECK();
     OBB_PHASE(7);
@@ -3772,13 +3928,15 @@ int nms_enqueue_source(const char *who, NmsSource src, int64_t n, int kind, floa
 static int nms_enqueue(const char *who, const float *dets_dev, int64_t n, int kind, float iou_thr,
                        const int32_t *group_dev, const float *thr_dev, int flags_in,
                        int64_t *keep_dev, NmsHostInfo *result, void *workspace_dev,
-                       size_t workspace_bytes, hipStream_t st, NmsEnqueued &q, bool allow_grid = false) {
+                       size_t workspace_bytes, hipStream_t st, NmsEnqueued &q, bool allow_grid = false,
+                       int retain = 0, unsigned long long retain_seq = 0ull) {
   NmsSource src = {};
   src.dets = dets_dev;
   src.pitch = kind == OBB_KIND_RBOX ? 6 : (kind == OBB_KIND_POLY ? 9 : 5);
   src.group = group_dev;
   src.thrs = thr_dev;
   src.allow_grid = allow_grid ? 1 : 0;
+  src.retain = retain; src.retain_seq = retain_seq;
   return nms_enqueue_source(who, src, n, kind, iou_thr, flags_in, keep_dev, result, workspace_dev, workspace_bytes, st, q);
 }
 
@@ -3807,6 +3965,33 @@ static int nms_record_wait(NmsHostInfo *host, hipStream_t st, bool must_sync) {
   return OBB_OK;
 }
 static_assert(sizeof(NmsHostInfo) % 8 == 0 && sizeof(NmsHostInfo) <= 64, "the record is watched word by word");
+
+// ---- retained workspaces (OBB_NMS_RETAIN; NmsRetain): the host's note of what a workspace's header says.  Per calling
+// thread, by workspace pointer; the device checks the header too, so a note that is wrong (another thread used the
+// workspace, the memory was handed out again) costs a repeated call, not a result.
+struct RetainSlot { const void *ws; unsigned int sig; unsigned long long seq; bool valid; unsigned long long used; };
+constexpr int kRetainSlots = 8;
+static thread_local RetainSlot g_retain[kRetainSlots] = {};
+static thread_local unsigned long long g_retain_clock = 0ull;
+static thread_local int g_last_retained = 0;
+static RetainSlot *retain_find(const void *ws) {
+  for (RetainSlot &r : g_retain) if (r.ws == ws) return &r;
+  return nullptr;
+}
+static RetainSlot *retain_slot(const void *ws) {
+  RetainSlot *r = retain_find(ws);
+  if (!r) {
+    r = &g_retain[0];
+    for (RetainSlot &c : g_retain) if (c.used < r->used) r = &c;     // least recently used (an empty slot: 0)
+    // (a sequence number nobody has used on this memory: the clock in the upper bits -- a stale header of an earlier
+    //  owner of the address does not match)
+    *r = RetainSlot{ws, 0u, (++g_retain_clock) << 32, false, 0ull};
+  }
+  r->used = ++g_retain_clock;
+  return r;
+}
+// any call that writes a workspace outside the retained protocol ends what the thread believes about it
+void nms_retain_forget(const void *ws) { if (RetainSlot *r = retain_find(ws)) r->valid = false; }
 
 // one pinned, device-mapped result record per calling thread (synchronous entry points)
 static int nms_pinned_record(NmsHostInfo *&host, NmsHostInfo *&dev) {
@@ -3853,12 +4038,42 @@ extern "C" int obb_nms_ex_f32(const float *dets_dev, int64_t n, int kind, float 
   hipStream_t st = (hipStream_t)stream;
   NmsEnqueued q;
   const bool watch = tuning(OBB_TUNE_NMS_WATCH_RECORD, 1) != 0;
+  // retained workspace (OBB_NMS_RETAIN): 2 = the three-launch call on the state the previous call left, 1 = seed it
+  const bool want_retain = (flags & OBB_NMS_RETAIN) != 0 && tuning(OBB_TUNE_NMS_RETAIN, 1) != 0;
+  RetainSlot *slot = want_retain ? retain_slot(workspace_dev) : nullptr;
+  unsigned int sig = 0u;
+  if (slot) { int g = 0, bits = 0; grid_geometry(n, g, bits); sig = retain_sig(g, bits, group_dev != nullptr); }
+  if (!slot) nms_retain_forget(workspace_dev);
+  int mode = slot ? ((slot->valid && slot->sig == sig) ? 2 : 1) : 0;
+  g_last_retained = 0;
+  // (every launch sequence that ran to its end on a retained workspace -- whatever the verdict -- has left the header
+  //  naming the next call: the note follows)
+  auto retain_done = [&]() {
+    if (!slot) return;
+    if (q.retained && (hinfo->route & 0xFFu) != kRouteUnseeded) { slot->valid = true; slot->sig = sig; slot->seq += 1ull; g_last_retained = q.retained; }
+    else slot->valid = false;      // another route wrote the workspace (or nothing ran): seed again next time
+  };
   nms_record_arm(hinfo);
   rc = nms_enqueue("obb_nms_f32", dets_dev, n, kind, iou_thr, group_dev, thr_dev, flags, keep_dev, hinfo_dev,
-                   workspace_dev, workspace_bytes, st, q, true);
-  if (rc != OBB_OK) return rc;
+                   workspace_dev, workspace_bytes, st, q, true, mode, slot ? slot->seq : 0ull);
+  if (rc != OBB_OK) { if (slot) slot->valid = false; return rc; }
   rc = nms_record_wait(hinfo, st, q.timed || !watch);
-  if (rc != OBB_OK) return rc;
+  if (rc != OBB_OK) { if (slot) slot->valid = false; return rc; }
+  bool reseed = q.retained == 2 && (hinfo->route & 0xFFu) == kRouteUnseeded;    // somebody else wrote the workspace: nothing was computed
+  retain_done();
+  // a retained call on a crowded grid: the frame its predecessor left may be the reason -- once more with a frame of its own
+  if (!reseed && q.retained == 2 && q.grid && (hinfo->route & 0xFFu) == 3u) reseed = true;
+  if (reseed) {
+    q = NmsEnqueued();
+    OBB_HIP_TRY(hipStreamSynchronize(st));
+    nms_record_arm(hinfo);
+    rc = nms_enqueue("obb_nms_f32", dets_dev, n, kind, iou_thr, group_dev, thr_dev, flags, keep_dev, hinfo_dev,
+                     workspace_dev, workspace_bytes, st, q, true, 1, slot->seq);
+    if (rc != OBB_OK) { slot->valid = false; return rc; }
+    rc = nms_record_wait(hinfo, st, q.timed || !watch);
+    if (rc != OBB_OK) { slot->valid = false; return rc; }
+    retain_done();
+  }
   g_last_route = q.grid ? 4 : (q.fused ? 0 : (q.direct ? 1 : 2));
   if (q.grid && (hinfo->route & 0xFFu) == 3u) {
     g_last_route = 5;
@@ -3873,6 +4088,7 @@ extern "C" int obb_nms_ex_f32(const float *dets_dev, int64_t n, int kind, float 
     if (rc != OBB_OK) return rc;
     rc = nms_record_wait(hinfo, st, q.timed || !watch);
     if (rc != OBB_OK) return rc;
+    g_last_retained = 0;
   }
   const NmsHostInfo h = *hinfo;
   NmsProfile &prof = g_prof;
@@ -3906,6 +4122,8 @@ extern "C" int obb_nms_hbb_f64(const double *dets_dev, int64_t n, float iou_thr,
   hipStream_t st = (hipStream_t)stream;
   NmsSource src = {};
   src.dets64 = dets_dev; src.pitch = 5; src.group = group_dev; src.thrs = thr_dev;
+  if (flags & OBB_NMS_RETAIN) return set_err(OBB_EINVAL, "obb_nms_hbb_f64: OBB_NMS_RETAIN applies to obb_nms_ex_f32");
+  nms_retain_forget(workspace_dev);
   NmsEnqueued q;
   rc = nms_enqueue_source("obb_nms_hbb_f64", src, n, OBB_KIND_HBB, iou_thr, flags, keep_dev, hinfo_dev, workspace_dev, workspace_bytes, st, q);
   if (rc != OBB_OK) return rc;
@@ -3931,6 +4149,8 @@ extern "C" int obb_nms_async_f32(const float *dets_dev, int64_t n, int kind, flo
     OBB_HIP_TRY(hipMemsetAsync(result_dev, 0, OBB_NMS_RESULT_BYTES, st));
     return OBB_OK;
   }
+  if (flags & OBB_NMS_RETAIN) return set_err(OBB_EINVAL, "obb_nms_async_f32: OBB_NMS_RETAIN needs the synchronous entry point (the host reads the record)");
+  nms_retain_forget(workspace_dev);
   NmsEnqueued q;
   return nms_enqueue("obb_nms_async_f32", dets_dev, n, kind, iou_thr, group_dev, thr_dev, flags, keep_dev,
                      static_cast<NmsHostInfo *>(result_dev), workspace_dev, workspace_bytes, st, q);
@@ -3963,6 +4183,7 @@ extern "C" int obb_nms_async_result(const void *result_host, int64_t n, size_t w
 }
 
 extern "C" int obb_nms_last_route(void) { return obb::g_last_route; }
+extern "C" int obb_nms_last_retained(void) { return obb::g_last_retained; }
 
 extern "C" int obb_nms_profile_enable(int on) {
   obb::g_prof.on = on != 0;

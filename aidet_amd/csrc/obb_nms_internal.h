@@ -29,6 +29,9 @@ struct NmsSource {
   int64_t mult;                // modes 1, 2: number of classes
   const float *thr_table;      // mode 2 (may be null: one threshold)
   int allow_grid;              // 1: the caller can repeat the call when the grid route gives up (the synchronous entry points)
+  int retain;                  // round 6 (OBB_NMS_RETAIN; obb_nms.hip, NmsRetain): 0 a plain call; 1 SEED the workspace's retained state
+                               // (the usual four launches, the tail leaves the state ready); 2 the three-launch call on a seeded workspace
+  unsigned long long retain_seq;   // ... the sequence number the workspace's header carries (the host's note of it)
   int32_t *gout;               // modes 1, 2: workspace (n)
   float *tout;                 // mode 2 with a table: workspace (n)
 };
@@ -37,6 +40,7 @@ struct NmsEnqueued {
   unsigned long long cap = 0, segcap = 0;
   unsigned int ucap = 0;
   bool timed = false, direct = false, fused = false, grid = false;
+  int retained = 0;            // what the call did with its workspace's retained state: 0 nothing, 1 seeded it, 2 ran on it (three launches)
 };
 
 constexpr int kNmsShards = 64;

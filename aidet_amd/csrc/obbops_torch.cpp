@@ -13,7 +13,9 @@
 #include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 
+#include <map>
 #include <tuple>
+#include <utility>
 
 #include "obbops.h"
 
@@ -73,6 +75,20 @@ at::Tensor nms_impl(const at::Tensor &dets_in, int kind, double thr, const c10::
   return keep.narrow(0, 0, info[0]);
 }
 
+// The synchronous NMS keeps ONE workspace per (calling thread, device, stream) alive between calls instead of asking the
+// caching allocator for one per call: a call returns when its result is on the host, so the next call on that stream may
+// reuse the buffer -- and a buffer nobody else writes is what OBB_NMS_RETAIN asks for (obbops.h: the library keeps the
+// next call's frame and cleared counters in it, three launches instead of four).  release_workspaces() drops them.
+std::map<std::pair<int, void *>, at::Tensor> &nms_workspaces() {
+  static thread_local std::map<std::pair<int, void *>, at::Tensor> cache;
+  return cache;
+}
+at::Tensor &nms_workspace(const at::Tensor &like, void *stream, size_t bytes) {
+  at::Tensor &ws = nms_workspaces()[std::make_pair((int)like.device().index(), stream)];
+  if (!ws.defined() || (size_t)ws.numel() < bytes) ws = at::empty({(int64_t)bytes}, like.options().dtype(at::kByte));
+  return ws;
+}
+
 // The wrapper's hot path (aidet_amd.nms_wrapper._run_nms): ONE attempt of obb_nms_ex_f32 on tensors that already are
 // what the C ABI takes (fp32 contiguous dets, int32 groups, fp32 per-box thresholds), everything else -- allocation of
 // the keep list and of the workspace, device guard, stream lookup -- on this side of the interpreter.  Returns
@@ -99,9 +115,10 @@ std::tuple<at::Tensor, int64_t, std::vector<int64_t>> nms_ex(const at::Tensor &d
   std::vector<int64_t> info(4, 0);
   const size_t bytes = obb_nms_workspace_bytes(n, (int)kind, capacity);
   TORCH_CHECK(bytes > 0, "obb_nms_workspace_bytes: ", obb_last_error());
-  at::Tensor ws = at::empty({(int64_t)bytes}, dets.options().dtype(at::kByte));
-  const int rc = obb_nms_ex_f32(dets.data_ptr<float>(), n, (int)kind, (float)thr, gp, tp, (int)flags, keep.data_ptr<int64_t>(),
-                                info.data(), ws.data_ptr(), bytes, current_stream(dets));
+  void *stream = current_stream(dets);
+  at::Tensor &ws = nms_workspace(dets, stream, bytes);
+  const int rc = obb_nms_ex_f32(dets.data_ptr<float>(), n, (int)kind, (float)thr, gp, tp, (int)flags | OBB_NMS_RETAIN, keep.data_ptr<int64_t>(),
+                                info.data(), ws.data_ptr(), (size_t)ws.numel(), stream);
   if (rc != OBB_OK && rc != OBB_EWORKSPACE) check_rc(rc, "obb_nms_ex_f32");
   return std::make_tuple(keep.narrow(0, 0, rc == OBB_OK ? info[0] : 0), (int64_t)rc, info);
 }
@@ -223,6 +240,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("build_info", []() { return std::string(obb_build_info()); });
   m.def("nms_ex", &nms_ex, "one attempt of obb_nms_ex_f32: (keep, rc, info)", py::arg("dets"), py::arg("kind"), py::arg("threshold"),
         py::arg("groups") = py::none(), py::arg("thrs") = py::none(), py::arg("flags") = 0, py::arg("capacity") = 0);
+  m.def("release_workspaces", []() { nms_workspaces().clear(); }, "drops the calling thread's cached NMS workspaces");
   m.def("rnms", &rnms, "rotated NMS: keep indices (int64, ascending)", py::arg("dets"), py::arg("threshold"));
   m.def("poly_nms", &poly_nms, "polygon NMS: keep indices", py::arg("dets"), py::arg("threshold"));
   m.def("nms", &hbb_nms, "horizontal-box NMS (the reference's +1 convention): keep indices", py::arg("dets"), py::arg("threshold"));

@@ -132,7 +132,7 @@ def _run_nms(dets_dev, kind, iou_thr, groups=None, thrs=None, strict=False):
     if ext is not None and n > 0:
         if groups is not None or thrs is not None:
             groups, _g, thrs, _t = _side_inputs(dev, n, groups, thrs)
-        flags = _lib.NMS_STRICT if strict else 0
+        flags = _lib.NMS_STRICT if strict else 0     # (the binding adds OBB_NMS_RETAIN: it owns the workspace it passes)
         # A call whose pair lists overflow is repeated with the capacity the library asks for -- twice the time.  A
         # caller that does this every time (the RPN of a dense scene: 8768 boxes, 5.7e5 overlapping pairs, 0.32 instead
         # of 0.19 ms per call) gets that capacity from the start next time: the LIBRARY keeps the hint (per calling
@@ -162,7 +162,9 @@ def _run_nms(dets_dev, kind, iou_thr, groups=None, thrs=None, strict=False):
     gptr = tptr = None
     if groups is not None or thrs is not None:
         groups, gptr, thrs, tptr = _side_inputs(dev, n, groups, thrs)
-    flags = _lib.NMS_STRICT if strict else 0
+    # OBB_NMS_RETAIN: the workspace is this thread's own per (device, stream) and nothing else writes it between calls
+    # (_workspace; the asynchronous tickets of nms_enqueue use it too -- the library forgets a workspace's state then)
+    flags = (_lib.NMS_STRICT if strict else 0) | _lib.NMS_RETAIN
     # (this function is the per-call overhead of every NMS: no context-manager object unless the
     # device has to be switched)
     cur = torch.cuda.current_device()

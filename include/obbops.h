@@ -161,6 +161,23 @@ OBB_API int obb_nms_grouped_f32(const float *dets_dev, int64_t n, int kind, floa
  * with OBB_EINVAL until round 4).  Per-box thresholds (thr_dev) must be positive under >=: the
  * library does not read them on the host.                                                    */
 #define OBB_NMS_STRICT 1
+/*   OBB_NMS_RETAIN  (round 6) the caller hands the SAME workspace to call after call and promises that nothing else writes
+ *                   it in between (no other library call, no other thread, no other tensor in its memory).  The library
+ *                   then keeps state in it: the tail of a call clears what the next call's first atomics count in and
+ *                   leaves the frame of its own boxes, so the next call of the same size class (the table geometry: a
+ *                   step function of n) does without the frame launch -- THREE launches instead of four on the grid
+ *                   route below 2^18 boxes, ~7 us of a 56 us call at 100 000 boxes.  Results are the same bit for bit:
+ *                   any frame gives the same keep list (coordinates clamp into it, pairs are only ever added); a scene
+ *                   unlike its predecessor at worst finds a crowded grid and is repeated with a frame of its own.
+ *                   The first call on a workspace, a call of another size class and a call after anything else wrote
+ *                   the workspace SEED the state (the usual four launches).  The calling thread notes per workspace
+ *                   pointer what its header should say, and every launch of a three-launch call checks the header
+ *                   first: a workspace that another thread used or whose memory was handed out again in between makes
+ *                   the call leave untouched and run again seeded -- but a caller that lets something else write the
+ *                   COUNTERS and not the header breaks the promise, and the result with it.  Other routes (n <= 10 240,
+ *                   n >= 2^18, a crowded scene) ignore the flag.  Synchronous entry point only (OBB_EINVAL elsewhere).
+ *                   obb_nms_last_retained(): 0 the last call did nothing of the kind, 1 it seeded, 2 three launches. */
+#define OBB_NMS_RETAIN 2
 OBB_API int obb_nms_ex_f32(const float *dets_dev, int64_t n, int kind, float iou_thr,
                            const int32_t *group_dev, const float *thr_dev, int flags,
                            int64_t *keep_dev, int64_t *info_host, void *workspace_dev,
@@ -636,11 +653,15 @@ OBB_API int obb_roi_backward_gather_nhwc_f32(const float *grad_out_dev, int B, i
 #define OBB_TUNE_RROI_NHWC_GATHER_WAVES 18   /* channels-last gather backward: waves per map tile (4, 8, 16) */
 #define OBB_TUNE_NMS_RESOLVE_TAIL 19   /* resolve, bit 0: the last <= 4 edges per thread of a shard are retired from registers (1, default) or swept through memory (0); bit 1: the first sweep uses agent-scope loads like the others (measurement only); bit 2: the resolve reports itself stalled (test hook for OBB_ESTALLED) */
 #define OBB_TUNE_NMS_RESOLVE_PARTS 20   /* resolve of calls of >= 2^18 boxes: workgroups per edge shard (1 .. 16; never more than half of what the device keeps resident) */
-#define OBB_TUNE_COUNT 21
+#define OBB_TUNE_NMS_RETAIN 21          /* 0: OBB_NMS_RETAIN is ignored (every call runs the frame launch): A/B measurements */
+#define OBB_TUNE_COUNT 22
 OBB_API int obb_set_tuning(int knob, int64_t value);
 /* which route the calling thread's last synchronous obb_nms_*_f32 call took: 0 fused (one workgroup), 1 direct, 2 sorted,
  * 4 grid, 5 grid gave up (crowded cell) and the call was repeated on the sorted route; -1 none yet */
 OBB_API int obb_nms_last_route(void);
+/* what the calling thread's last obb_nms_ex_f32 call did with its workspace's retained state (OBB_NMS_RETAIN): 0 nothing,
+ * 1 seeded it (four launches), 2 ran on it (three launches) */
+OBB_API int obb_nms_last_retained(void);
 /* which kernel served the calling thread's last obb_soft_nms_f32 call: 2 the position-free kernel (n <= 4096, unique
  * maxima, no NaN), 3 that kernel gave up and the array kernel replayed the reference's permutation, 0 the array kernel
  * alone, 1 the register kernel (knob); -1 none yet */

@@ -137,16 +137,20 @@ def test_overlaps_cpu_tensor_roundtrip():
 # --------------------------------------------------------------------------
 # rotated NMS: keep indices bit-exact
 # --------------------------------------------------------------------------
-@pytest.fixture(params=['auto', 'sorted', 'listed', 'grid'])
+@pytest.fixture(params=['auto', 'sorted', 'listed', 'grid', 'grid4'])
 def nms_path(request, monkeypatch):
     """The library routes n <= 128 to the fused kernel, n <= 10240 to the direct
     (unsorted) scan and the rest to the spatially sorted pipeline, whose scan clips its
     candidates in line up to 65 536 boxes and lists them for a clip launch above; 'sorted' /
     'listed' force the pipeline with one or the other for every n above the fused limit."""
     from aidet_amd import _lib
-    if request.param == 'grid':                        # the uniform grid wherever it applies (n >= 256; it may give a scene up)
+    if request.param in ('grid', 'grid4'):             # the uniform grid wherever it applies (n >= 256; it may give a scene up)
+        # 'grid': as the wrapper runs it since round 6 -- on a retained workspace (OBB_NMS_RETAIN): a call of the size class of its
+        # predecessor is a three-launch one on the frame THAT scene left (the tests' scenes differ wildly: the repeat paths
+        # run); 'grid4': the flag ignored, every call with its own frame launch
         _lib.set_tuning(_lib.TUNE_NMS_DIRECT_MAX, 0)
         _lib.set_tuning(_lib.TUNE_NMS_GRID, 1)
+        _lib.set_tuning(_lib.TUNE_NMS_RETAIN, 0 if request.param == 'grid4' else 1)
     elif request.param != 'auto':
         _lib.set_tuning(_lib.TUNE_NMS_DIRECT_MAX, 0)
         _lib.set_tuning(_lib.TUNE_NMS_INLINE_MAX, (1 << 40) if request.param == 'sorted' else 0)
@@ -155,6 +159,7 @@ def nms_path(request, monkeypatch):
     _lib.set_tuning(_lib.TUNE_NMS_DIRECT_MAX, -1)
     _lib.set_tuning(_lib.TUNE_NMS_INLINE_MAX, -1)
     _lib.set_tuning(_lib.TUNE_NMS_GRID, -1)
+    _lib.set_tuning(_lib.TUNE_NMS_RETAIN, -1)
 
 
 @pytest.mark.parametrize('n,canvas', [(1, 10), (2, 10), (63, 64), (64, 64), (65, 64), (257, 128),
@@ -196,7 +201,7 @@ def test_rnms_cfg2_100k_sparse_and_dense(nms_path):
         assert np.array_equal(got, ref), 'canvas %d, route %s (%d)' % (canvas, nms_path, route)
         if nms_path in ('sorted', 'listed'):
             assert route == 2
-        if nms_path == 'grid':
+        if nms_path in ('grid', 'grid4'):
             assert route in (4, 5)                       # (the dense scene crowds cells: the grid gives up, the call is repeated)
         # idempotence: NMS of the survivors keeps them all
         _, again = rnms(t(d[got]), 0.5)
