@@ -28,7 +28,8 @@ class Caller(object):
         self._lib = _lib
         self.L = _lib.lib()
         self.kind = _lib.KIND_RBOX if kind is None else kind
-        nbytes = self.L.obb_nms_workspace_bytes(nmax, self.kind, capacity)
+        # (an explicit pair capacity: the default follows the calling thread's capacity hints, which other tests leave behind)
+        nbytes = self.L.obb_nms_workspace_bytes(nmax, self.kind, capacity or max(1 << 18, 64 * nmax))
         assert nbytes > 0
         self.ws = torch.empty(nbytes, dtype=torch.uint8, device=dev())
         self.ws.random_(0, 255)            # a fresh workspace holds anything
@@ -47,8 +48,7 @@ class Caller(object):
             thrs = torch.as_tensor(thrs, dtype=torch.float32).to(dev())
             tp = thrs.data_ptr()
         flags = (_lib.NMS_RETAIN if retain else 0) | (_lib.NMS_STRICT if strict else 0)
-        nbytes = L.obb_nms_workspace_bytes(n, self.kind, 0)
-        assert nbytes <= self.ws.numel()
+        assert L.obb_nms_workspace_bytes(n, self.kind, max(1 << 18, 64 * n)) <= self.ws.numel()
         rc = L.obb_nms_ex_f32(dt.data_ptr(), n, self.kind, float(thr), gp, tp, flags, keep.data_ptr(), self.info,
                               self.ws.data_ptr(), self.ws.numel(), _lib.current_stream_handle(dev()))
         _lib.check(rc)
