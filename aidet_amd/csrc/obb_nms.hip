@@ -4115,6 +4115,7 @@ extern "C" int obb_nms_hbb_f64(const double *dets_dev, int64_t n, float iou_thr,
   int rc = nms_validate("obb_nms_hbb_f64", reinterpret_cast<const float *>(dets_dev), n, OBB_KIND_HBB, iou_thr, thr_dev != nullptr, flags,
                         keep_dev, workspace_dev);
   if (rc != OBB_OK) return rc;
+  if (flags & OBB_NMS_RETAIN) return set_err(OBB_EINVAL, "obb_nms_hbb_f64: OBB_NMS_RETAIN applies to obb_nms_ex_f32");
   if (n == 0) return OBB_OK;
   NmsHostInfo *hinfo = nullptr, *hinfo_dev = nullptr;
   rc = nms_pinned_record(hinfo, hinfo_dev);
@@ -4122,7 +4123,6 @@ extern "C" int obb_nms_hbb_f64(const double *dets_dev, int64_t n, float iou_thr,
   hipStream_t st = (hipStream_t)stream;
   NmsSource src = {};
   src.dets64 = dets_dev; src.pitch = 5; src.group = group_dev; src.thrs = thr_dev;
-  if (flags & OBB_NMS_RETAIN) return set_err(OBB_EINVAL, "obb_nms_hbb_f64: OBB_NMS_RETAIN applies to obb_nms_ex_f32");
   nms_retain_forget(workspace_dev);
   NmsEnqueued q;
   rc = nms_enqueue_source("obb_nms_hbb_f64", src, n, OBB_KIND_HBB, iou_thr, flags, keep_dev, hinfo_dev, workspace_dev, workspace_bytes, st, q);

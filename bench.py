@@ -49,7 +49,7 @@ HBM_PEAK_GBS = 8000.0                 # MI355X HBM3E spec (MI355X_MICROARCH.md)
 # VALU issue: 256 CUs x 4 SIMD-32; a wave64 VALU op occupies its SIMD for 2 cycles
 # (MI355X_MICROARCH.md, cycle constants: v_fma_f32 wave64 = 2 cyc throughput)
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0  # G wave-instructions / s at 2.4 GHz
-COUNTER_FILES = [os.path.join(ROOT, 'profiles', 'r05_counters.json'), os.path.join(ROOT, 'profiles', 'r04_counters.json'),
+COUNTER_FILES = [os.path.join(ROOT, 'profiles', 'r06_counters.json'), os.path.join(ROOT, 'profiles', 'r05_counters.json'), os.path.join(ROOT, 'profiles', 'r04_counters.json'),
                  os.path.join(ROOT, 'profiles', 'r03_counters.json')]
 IOU_M = 16384                         # rbbox_overlaps leg: 16k x 16k (SURVEY 8d scale-up of configs[0])
 IOU_CANVAS = 1024                     # ... at configs[0]'s density (boxes on a 1024 canvas; 1.2 % of the pairs clipped)
@@ -154,18 +154,46 @@ def bench_all(args):
 
     # ---- leg 1: replica -- configs[1] on every rank ------------------------------------------
     n = args.boxes
-    boxes = workloads.boxes(n, args.canvas, 3)      # (the same scene on every rank: independent replicas)
+    boxes = workloads.boxes(n, args.canvas, 3)      # (the same scenes on every rank: independent replicas)
     d = torch.from_numpy(boxes).to(dev)
+    # The timed steps walk a POOL of scenes of the configuration (seeds 3, 13, 23, 33; step i takes scene i mod 4): since
+    # round 6 a call on the wrapper's workspace finds the frame its PREDECESSOR left (OBB_NMS_RETAIN, obbops.h) -- with one
+    # scene for every step that would be the frame of the very same boxes.  Scene 0 is the one the keep list, the CPU
+    # baseline and the counters refer to.
+    pool = [d] + [torch.from_numpy(workloads.boxes(n, args.canvas, 3 + 10 * k)).to(dev) for k in (1, 2, 3)]
     L = _lib.lib()
+    state = {'i': 0}
 
     def step():
-        return _run_nms(d, _lib.KIND_RBOX, 0.5)
+        r = _run_nms(pool[state['i'] & 3], _lib.KIND_RBOX, 0.5)
+        state['i'] += 1
+        return r
 
-    keep, info = step()          # (untimed; also sizes the workspace)
-    for _ in range(args.warmup):
-        keep, info = step()
+    keep, info = step()          # (untimed; also sizes the workspace and seeds its retained state)
+    for _ in range(max(args.warmup, 1) * 4 - 1):
+        step()
+    state['i'] = 0
+    keep, info = step()          # scene 0 again, now as a call of the steady state
     kept = int(keep.numel())
-    route = int(L.obb_nms_last_route())      # 4: the four-launch grid route (sparse scenes); 2: the sorted route
+    route = int(L.obb_nms_last_route())      # 4: the grid route (sparse scenes); 2: the sorted route
+    retained = int(L.obb_nms_last_retained())   # 2: three launches on the state the previous call left in the workspace
+
+    # the same steps with the flag ignored (every call with its own frame launch: four launches) -- outside the timed region
+    stateless_ms = None
+    if route == 4 and retained == 2:
+        _lib.set_tuning(_lib.TUNE_NMS_RETAIN, 0)
+        for _ in range(4):
+            step()
+        torch.cuda.synchronize()
+        t0s = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        stateless_ms = (time.perf_counter() - t0s) * 1e3 / args.steps
+        _lib.set_tuning(_lib.TUNE_NMS_RETAIN, -1)
+        for _ in range(4):       # (the first of these seeds the workspace again)
+            step()
+    state['i'] = 0
 
     # per-phase table from a separate, untimed pass (an event between two kernels
     # costs a ~5 us bubble; the timed region only brackets the dominant kernel)
@@ -203,6 +231,9 @@ def bench_all(args):
     barrier()
     elapsed = max_over_ranks(time.perf_counter() - t0)
     phases /= max(sampled, 1)
+    retained_last = int(L.obb_nms_last_retained())     # what the LAST timed call did (2: three launches)
+    state['i'] = 0
+    keep, info = step()          # (scene 0: the keep list the CPU baseline is compared with)
 
     ms_per_step = elapsed * 1e3 / args.steps
     value = world * n * args.steps / elapsed
@@ -259,6 +290,10 @@ def bench_all(args):
         'config': {'workload': 'rnms: %d theta-OBBs per GPU, canvas %g, w,h~logU(8,128), '
                                'theta~U(-pi/2,0), IoU thr 0.5 (BASELINE configs[1])' % (n, args.canvas),
                    'boxes_per_gpu': n, 'kept': kept, 'nms_route': {0: 'fused', 1: 'direct', 2: 'sorted', 4: 'grid', 5: 'grid->sorted'}.get(route, str(route)),
+                   'nms_launches': (3 if retained_last == 2 else 4) if route == 4 else None,
+                   'nms_workspace': ('retained between calls (OBB_NMS_RETAIN): the previous call cleared the cell counters and left the frame of ITS '
+                                     'boxes; every timed step is a different scene of a pool of 4') if retained_last == 2 else 'stateless',
+                   'nms_stateless_ms_per_step': None if stateless_ms is None else round(stateless_ms, 4),
                    'overlap_edges': info[0],
                    'resolve_rounds': info[1], 'candidate_pairs': info[2],
                    'parallelism': 'single GPU' if world == 1 else 'replica x%d (no data-path collective)' % world,
@@ -268,7 +303,7 @@ def bench_all(args):
                    'iou_sparse_workload': 'the same on canvas %d (0.02 %% of the pairs clipped: write bound)' % IOU_SPARSE_CANVAS},
         'roofline': roof,
         'phase_ms': {k: round(float(v), 4) for k, v in zip(
-            ['prep_quant' if route != 4 else 'frame_insert', 'cell_sort', 'permute_cull', 'scan' if route != 4 else 'probe_clip', 'clip',
+            ['prep_quant' if route != 4 else ('insert' if retained == 2 else 'frame_insert'), 'cell_sort', 'permute_cull', 'scan' if route != 4 else 'probe_clip', 'clip',
              'resolve' if route != 4 else 'resolve_compact', 'compact'], phase_tab)},
     }
     if dist is not None:
@@ -287,7 +322,8 @@ def bench_all(args):
             out['roofline_kernels'] = rk
             out['also'] = extras(dev, args)
             # the headline workload without the Python wrapper: one obb_nms_f32 call through the bare C ABI
-            out['config']['nms_c_abi_us_per_call'] = out['also']['rnms_100k_c_abi']['us_per_call']
+            out['config']['nms_c_abi_us_per_call'] = out['also']['rnms_100k_c_abi_retained']['us_per_call']
+            out['config']['nms_c_abi_stateless_us_per_call'] = out['also']['rnms_100k_c_abi']['us_per_call']
         if not args.no_cpu:
             out['cpu_baseline'] = cpu_baseline(boxes, keep)
     if rank == 0:
@@ -509,8 +545,9 @@ def nms_roofline(n, canvas, kept, scan_ms, step_ms, rk=None, route=2):
         # SURVEY 8(d)'s model of the REFERENCE algorithm (n x n/64 bit mask written, kept rows
         # read back): what this pipeline avoids moving -- not an achieved rate
         'reference_algorithm_bytes': 24 * n + 4 * n * words + 4 * kept * words + 8 * kept,
-        'note': ('grid route (frame, insert, probe + clip, resolve + compaction): a lane per pair of entries of a chunk of cells, bounds '
-                 'on the entries, the clip of what is left; a latency-bound call of four launches; HBM fracs beside it') if route == 4 else
+        'note': ('grid route on a retained workspace (insert, probe + clip, resolve + compaction; the frame launch only when the workspace '
+                 'is seeded): a lane per pair of entries of a chunk of cells, bounds on the entries, the clip of what is left; a '
+                 'latency-bound call of three launches; HBM fracs beside it') if route == 4 else
                 'VALU-issue bound kernel in a latency-bound call; HBM fracs beside it',
         'counters': c['_file'] if (c and k) else None,
     }
@@ -845,7 +882,20 @@ def extras(dev, args):
         assert rc == 0
     us = float(np.median(ts[10:])) * 1e6
     res['rnms_100k_c_abi'] = {'us_per_call': round(us, 1), 'boxes_per_s': round(nn / us * 1e6, 1), 'kept': int(infob[0]),
-                              'stat': 'median of 50 calls of obb_nms_f32'}
+                              'stat': 'median of 50 calls of obb_nms_f32 (stateless: four launches)'}
+    # ... and with OBB_NMS_RETAIN on the same caller-owned workspace (three launches from the second call on), over a pool of scenes
+    poolb = [dd] + [torch.from_numpy(workloads.boxes(nn, 20000.0, 3 + 10 * k)).to(dev) for k in (1, 2, 3)]
+    ts = []
+    for i in range(64):
+        t0 = time.perf_counter()
+        rc = L.obb_nms_ex_f32(poolb[i & 3].data_ptr(), nn, 0, 0.5, None, None, _lib.NMS_RETAIN, keepb.data_ptr(), infob, wsb.data_ptr(),
+                              wsb.numel(), stp)
+        ts.append(time.perf_counter() - t0)
+        assert rc == 0
+    us = float(np.median(ts[12:])) * 1e6
+    res['rnms_100k_c_abi_retained'] = {'us_per_call': round(us, 1), 'boxes_per_s': round(nn / us * 1e6, 1), 'kept': int(infob[0]),
+                                       'last_retained': int(L.obb_nms_last_retained()),
+                                       'stat': 'median of 52 calls of obb_nms_ex_f32 with OBB_NMS_RETAIN, four scenes in turn'}
     # RRoIAlign configs[2]: value check against the oracle on ALL 512 RoIs, 1 thread and all cores
     feat, rois = make_rroi(dev)
     layer = RRoIAlign(7, 0.25, sample_num=2)
@@ -1046,8 +1096,13 @@ def profile_target(args):
     dev = torch.device('cuda', 0)
     t = args.profile_target
     if t == 'nms':
-        d = torch.from_numpy(workloads.boxes(args.boxes, args.canvas, 3)).to(dev)
-        fn = lambda: _run_nms(d, _lib.KIND_RBOX, 0.5)
+        # (the pool of scenes of the timed region: a call finds the frame of ANOTHER scene in the retained workspace)
+        pool = [torch.from_numpy(workloads.boxes(args.boxes, args.canvas, 3 + 10 * k)).to(dev) for k in range(4)]
+        cnt = [0]
+
+        def fn():
+            cnt[0] += 1
+            return _run_nms(pool[cnt[0] & 3], _lib.KIND_RBOX, 0.5)
     elif t in ('iou_sparse', 'iou_dense'):
         a, b = make_iou(dev, 16384, 8192 if t == 'iou_sparse' else 1024)
         fn = lambda: rbbox_overlaps(a, b)

@@ -37,6 +37,10 @@ int main(void) {
     if (info[0] != NMS_K) { printf("nms kept %lld, oracle %d\n", (long long)info[0], NMS_K); return 2; }
     HIP_TRY(hipMemcpy(host, keep, sizeof(int64_t) * NMS_K, hipMemcpyDeviceToHost));
     for (i = 0; i < NMS_K; ++i) if (host[i] != nms_keep[i]) { printf("nms keep[%d] = %lld, oracle %lld\n", i, (long long)host[i], (long long)nms_keep[i]); return 3; }
+    /* the same call with OBB_NMS_RETAIN (obbops.h): 300 boxes run on a route that keeps no state in the workspace -- the flag is
+     * accepted, the result is the same, obb_nms_last_retained() says 0 */
+    if (obb_nms_ex_f32(dets, NMS_N, OBB_KIND_RBOX, 0.5f, NULL, NULL, OBB_NMS_RETAIN, keep, info, ws, wsb, st) != OBB_OK ||
+        info[0] != NMS_K || obb_nms_last_retained() != 0) { printf("nms with OBB_NMS_RETAIN: %s\n", obb_last_error()); return 8; }
     HIP_TRY(hipFree(dets)); HIP_TRY(hipFree(keep)); HIP_TRY(hipFree(ws));
   }
   /* ---- rotated IoU */

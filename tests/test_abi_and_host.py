@@ -64,6 +64,13 @@ def test_argument_validation_without_gpu():
     assert L.obb_nms_ex_f32(null, 0, _lib.KIND_HBB, 0.5, null, null, 0, null, info, null, 0, null) == _lib.OBB_OK
     assert L.obb_nms_async_f32(one, 5, 0, 0.5, null, null, 0, one, null, one, 1 << 20, null) == _lib.OBB_EINVAL
     assert L.obb_nms_async_result(null, 5, 1 << 20, info) == _lib.OBB_EINVAL
+    # round 6: OBB_NMS_RETAIN is a flag of the synchronous obb_nms_ex_f32 only (the host reads the call's record)
+    assert L.obb_nms_async_f32(one, 5, 0, 0.5, null, null, _lib.NMS_RETAIN, one, one, one, 1 << 20, null) == _lib.OBB_EINVAL
+    assert b'OBB_NMS_RETAIN' in L.obb_last_error()
+    assert L.obb_nms_hbb_f64(one, 5, 0.5, null, null, _lib.NMS_RETAIN, one, info, one, 1 << 20, null) == _lib.OBB_EINVAL
+    assert b'OBB_NMS_RETAIN' in L.obb_last_error()
+    assert L.obb_nms_ex_f32(one, 5, 0, 0.5, null, null, _lib.NMS_RETAIN | 4, one, info, one, 1 << 20, null) == _lib.OBB_EINVAL
+    assert L.obb_nms_last_retained() in (0, 1, 2)
     rec = (ctypes.c_int64 * 8)()                           # all-zero record = empty result
     assert L.obb_nms_async_result(rec, 0, 0, info) == _lib.OBB_OK and info[0] == 0
     ws = L.obb_nms_workspace_bytes(1000, 0, 0)
