@@ -109,6 +109,8 @@ def lib():
         L.obb_head_gather_decode_f32.restype = i32
         L.obb_nms_last_route.restype = i32
         L.obb_nms_last_retained.restype = i32
+        L.obb_nms_retain_forget.argtypes = [vp]
+        L.obb_nms_retain_forget.restype = i32
         L.obb_soft_nms_last_path.restype = i32
         L.obb_soft_nms_last_path.argtypes = []
         L.obb_set_tuning.argtypes = [i32, i64]

@@ -1002,7 +1002,12 @@ __global__ __launch_bounds__(256) void nms_ginsert_kernel(const NmsSource src, i
   if (ra.frame_next) {
     if (ra.hdr_magic && *ra.hdr_magic != ra.expect) return;      // (uniform over the launch: nothing is touched)
     nblk = gridDim.x - 1u;
-    if (blockIdx.x == nblk) { nms_frame_block<KIND, false>(src, n, cell_hbits, ra.frame_next, nullptr, grid_log2); return; }
+    if (blockIdx.x == nblk) {
+#ifndef OBB_INSERT_NOFRAME      // (timing experiment: the launch without the frame block's 17 KB of LDS; the frame of the seeding call stays)
+      nms_frame_block<KIND, false>(src, n, cell_hbits, ra.frame_next, nullptr, grid_log2);
+#endif
+      return;
+    }
     if (blockIdx.x == 0) {
       const unsigned int t = threadIdx.x;
       if (t < 3u * kShards) ra.ccnts[(size_t)t * kCandStride] = 0ull;
@@ -4184,6 +4189,11 @@ extern "C" int obb_nms_async_result(const void *result_host, int64_t n, size_t w
 
 extern "C" int obb_nms_last_route(void) { return obb::g_last_route; }
 extern "C" int obb_nms_last_retained(void) { return obb::g_last_retained; }
+extern "C" int obb_nms_retain_forget(const void *workspace_dev) {
+  if (workspace_dev) obb::nms_retain_forget(workspace_dev);
+  else for (obb::RetainSlot &r : obb::g_retain) r.valid = false;
+  return OBB_OK;
+}
 
 extern "C" int obb_nms_profile_enable(int on) {
   obb::g_prof.on = on != 0;

@@ -85,8 +85,15 @@ std::map<std::pair<int, void *>, at::Tensor> &nms_workspaces() {
 }
 at::Tensor &nms_workspace(const at::Tensor &like, void *stream, size_t bytes) {
   at::Tensor &ws = nms_workspaces()[std::make_pair((int)like.device().index(), stream)];
-  if (!ws.defined() || (size_t)ws.numel() < bytes) ws = at::empty({(int64_t)bytes}, like.options().dtype(at::kByte));
+  if (!ws.defined() || (size_t)ws.numel() < bytes) {
+    if (ws.defined()) obb_nms_retain_forget(ws.data_ptr());      // (its memory goes back to the allocator)
+    ws = at::empty({(int64_t)bytes}, like.options().dtype(at::kByte));
+  }
   return ws;
+}
+void release_nms_workspaces() {
+  for (auto &kv : nms_workspaces()) if (kv.second.defined()) obb_nms_retain_forget(kv.second.data_ptr());
+  nms_workspaces().clear();
 }
 
 // The wrapper's hot path (aidet_amd.nms_wrapper._run_nms): ONE attempt of obb_nms_ex_f32 on tensors that already are
@@ -240,7 +247,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("build_info", []() { return std::string(obb_build_info()); });
   m.def("nms_ex", &nms_ex, "one attempt of obb_nms_ex_f32: (keep, rc, info)", py::arg("dets"), py::arg("kind"), py::arg("threshold"),
         py::arg("groups") = py::none(), py::arg("thrs") = py::none(), py::arg("flags") = 0, py::arg("capacity") = 0);
-  m.def("release_workspaces", []() { nms_workspaces().clear(); }, "drops the calling thread's cached NMS workspaces");
+  m.def("release_workspaces", &release_nms_workspaces, "drops the calling thread's cached NMS workspaces");
   m.def("rnms", &rnms, "rotated NMS: keep indices (int64, ascending)", py::arg("dets"), py::arg("threshold"));
   m.def("poly_nms", &poly_nms, "polygon NMS: keep indices", py::arg("dets"), py::arg("threshold"));
   m.def("nms", &hbb_nms, "horizontal-box NMS (the reference's +1 convention): keep indices", py::arg("dets"), py::arg("threshold"));

@@ -275,7 +275,7 @@ def bench_all(args):
     rk = None
     if rank == 0 and world == 1 and not args.no_extras:
         rk = roofline_kernels(dev)
-    roof = nms_roofline(n, args.canvas, kept, scan_ms, ms_per_step, rk, route)
+    roof = nms_roofline(n, args.canvas, kept, scan_ms, ms_per_step, rk, route, retained_last)
     iou_bytes = 20 * (IOU_M // world + IOU_M) * world + 4 * IOU_M * IOU_M
     roof['samples_in_timed_region'] = int(sampled)
     roof['iou_rowblock_pairs_per_s'] = round(iou_pairs['cfg'], 1)
@@ -526,7 +526,7 @@ def hbm_bytes(k):
     return int(2 * k['FETCH_SIZE_KB'] * 1024 + k['WRITE_SIZE_KB'] * 1024)
 
 
-def nms_roofline(n, canvas, kept, scan_ms, step_ms, rk=None, route=2):
+def nms_roofline(n, canvas, kept, scan_ms, step_ms, rk=None, route=2, retained=0):
     """nms_scan_kernel is bound by VALU ISSUE (3 full-rate ops per tested pair plus the
     candidate path), not by HBM: its counter traffic is a few MB per launch.  The rest of the
     call is launch/latency bound (dependent launches of 4-20 us).  Everything is a SCALAR (the
@@ -563,6 +563,8 @@ def nms_roofline(n, canvas, kept, scan_ms, step_ms, rk=None, route=2):
             r['hbm_frac'] = round(tb / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         tot = 0
         for name, kk in c['kernels'].items():
+            if retained == 2 and kk.get('kernel') == 'nms_frame_kernel':
+                continue      # (a three-launch call has no frame launch: the counters' one instance is the seeding call's)
             if kk.get('workload') == wl and hbm_bytes(kk):
                 tot += hbm_bytes(kk)
         if tot:

@@ -178,6 +178,10 @@ OBB_API int obb_nms_grouped_f32(const float *dets_dev, int64_t n, int kind, floa
  *                   n >= 2^18, a crowded scene) ignore the flag.  Synchronous entry point only (OBB_EINVAL elsewhere).
  *                   obb_nms_last_retained(): 0 the last call did nothing of the kind, 1 it seeded, 2 three launches. */
 #define OBB_NMS_RETAIN 2
+/* Ends what the calling thread notes about a workspace it used with OBB_NMS_RETAIN: call it before the workspace's memory is
+ * freed or used for anything else (an allocator may hand the same address out again with the header intact and the counters
+ * not).  NULL: all of the thread's notes.  Always OBB_OK. */
+OBB_API int obb_nms_retain_forget(const void *workspace_dev);
 OBB_API int obb_nms_ex_f32(const float *dets_dev, int64_t n, int kind, float iou_thr,
                            const int32_t *group_dev, const float *thr_dev, int flags,
                            int64_t *keep_dev, int64_t *info_host, void *workspace_dev,

@@ -316,3 +316,19 @@ def test_headline_scene_on_a_retained_workspace():
     assert call(warm, 0.5)[1] == 1
     got, mode, route = call(d, 0.5)
     assert mode == 2 and route == 4 and np.array_equal(got, ref)
+
+
+def test_release_workspaces_starts_over():
+    from aidet_amd import _lib, nms_wrapper, rnms
+    L = _lib.lib()
+    d = oracle.synth_boxes(21000, 6500, 17)
+    ref = oracle.rnms(d, 0.5)
+    dt = torch.from_numpy(d).to(dev())
+    for _ in range(2):
+        assert np.array_equal(rnms(dt, 0.5)[1].cpu().numpy(), ref)
+    assert int(L.obb_nms_last_retained()) == 2
+    nms_wrapper.release_workspaces()
+    assert np.array_equal(rnms(dt, 0.5)[1].cpu().numpy(), ref)
+    assert int(L.obb_nms_last_retained()) == 1
+    assert np.array_equal(rnms(dt, 0.5)[1].cpu().numpy(), ref)
+    assert int(L.obb_nms_last_retained()) == 2

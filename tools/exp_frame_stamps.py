@@ -4,7 +4,7 @@ nms_frame_kernel (shader clock) and begin / end of every block of nms_frame_kern
 100 MHz)."""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ['OBBOPS_LIB'] = os.path.join(ROOT, 'aidet_amd', 'lib', 'libobbops_frst.so')
+os.environ['OBBOPS_LIB'] = os.environ.get('OBB_FRST_LIB') or os.path.join(ROOT, 'aidet_amd', 'lib', 'libobbops_frst.so')      # (OBB_FRST_LIB: another instrumented build)
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np
@@ -13,6 +13,9 @@ import workloads
 from aidet_amd import _lib, nms_wrapper
 dev = torch.device('cuda', 0)
 L = _lib.lib()
+stateless = 'stateless' in sys.argv[1:]                      # the four-launch call (OBB_NMS_RETAIN ignored): the frame kernel's phases
+if stateless:
+    sys.argv.remove('stateless')
 grouped = len(sys.argv) > 1 and sys.argv[1] == 'merge'      # the merged NMS of a config-5 pass (group = image x class, per-class thresholds)
 if grouped:
     from aidet_amd import dota_io, dota_merge
@@ -28,6 +31,7 @@ if grouped:
 else:
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
     d = torch.from_numpy(workloads.boxes(n, 20000.0 * (n / 100000.0) ** 0.5, 3)).to(dev)
+_lib.set_tuning(_lib.TUNE_NMS_RETAIN, 0 if stateless else 1)
 L.obb_debug_frame_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
 names = ['entry -> own share zeroed', '-> samples in LDS (global round trip)', '-> one-pass statistics', '-> trimming rounds (outliers only)',
          '-> trimmed box, group hashes', '-> frame written (thread 0)']
@@ -47,7 +51,12 @@ for rep in range(12):
     if rep >= 2:
         acc.append(row)
 a = np.median(np.array(acc, dtype=np.float64), axis=0)
-print('route', L.obb_nms_last_route(), 'kept', len(keep), 'n', n)
+print('route', L.obb_nms_last_route(), 'kept', len(keep), 'n', n, 'retained', L.obb_nms_last_retained())
+if L.obb_nms_last_retained() == 2:
+    # a three-launch call: no frame kernel (its stamps are the seeding call's); the insert launch is the call's first
+    print('insert kernel of a three-launch call (the first launch): blocks begin within %.1f us, median block life %.1f us, last ends %.1f us after the first began (%d blocks incl. the frame block)'
+          % (a[9] - a[8], a[10], a[11] - a[8], a[13]))
+    sys.exit(0)
 print('nms_frame_kernel, block 0, thread 0 (shader clocks, median of 10 calls):')
 for i, nm in enumerate(names):
     print('  %-44s %7d' % (nm, a[i]))

@@ -107,6 +107,9 @@ for k, v in sorted(kern.items()):
         line += ' %10.4f' % (v['SQ_INSTS_VALU'] / t / VALU_PEAK)
     print(line)
 call = [v for v in kern.values() if v['workload'] == WORKLOAD['nms']]
+if call and bench['config'].get('nms_launches') == 3:
+    # a call on a retained workspace (round 6): the frame kernel ran once, for the seeding call -- not part of a timed call
+    call = [v for v in call if v['kernel'] != 'nms_frame_kernel']
 if call:
     print('rnms 100k: %d kernels, sum of avg_us %.1f, HBM bytes per call %.1f MB; bench ms_per_step %.4f'
           % (len(call), sum(v['avg_us'] for v in call), sum(hbm(v) for v in call) / 1e6, bench['ms_per_step']))
