@@ -10,6 +10,23 @@ import workloads
 from aidet_amd import _lib, dota_io, dota_merge
 from aidet_amd.nms_wrapper import _run_nms
 dev = torch.device('cuda', 0)
+if len(sys.argv) > 1 and sys.argv[1] == 'headline':      # the headline call (100 000 boxes, ~270 edges): entry and end-of-sweeps of the 64 shards
+    d = torch.from_numpy(workloads.boxes(100000, 20000.0, 3)).to(dev)
+    L = _lib.lib()
+    for _ in range(6):
+        keep, info = _run_nms(d, _lib.KIND_RBOX, 0.5)
+    torch.cuda.synchronize()
+    buf = np.zeros(64 * 64 * 2, dtype=np.uint64)
+    L.obb_debug_resolve_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    assert L.obb_debug_resolve_stamps(buf.ctypes.data, buf.size) == 0
+    s = buf.reshape(64, 64, 2).astype(np.int64)
+    t_in, t_out = s[:, 0, 0], s[:, 63, 0]
+    base = t_in.min()
+    print('headline: kept %d edges %d rounds %d retained %d' % (keep.numel(), info[0], info[1], L.obb_nms_last_retained()))
+    print('shards enter within %.2f us; the sweeps of a shard end %.2f .. %.2f us after the first entry (median %.2f): what follows in the launch is the '
+          'arrival, the slices\' compaction and the record' % ((t_in.max() - base) / 100.0, (t_out.min() - base) / 100.0, (t_out.max() - base) / 100.0,
+                                                             float(np.median(t_out - base)) / 100.0))
+    sys.exit(0)
 images = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 if len(sys.argv) > 2:
     _lib.set_tuning(_lib.TUNE_NMS_RESOLVE_TAIL, int(sys.argv[2]))
