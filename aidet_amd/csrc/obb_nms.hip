@@ -932,7 +932,7 @@ struct RetainArgs {
 struct RetainTail {
   unsigned long long *hdr_magic;         // null: no tail (a plain call)
   unsigned long long expect, next;       // expect != 0: check first; next: the header's value once the state is ready again
-  uint4 *gcnt;                           // cell counters, cleared at the start of the resolve launch (the probe has read them)
+  uint4 *gcnt;                           // cell counters: every workgroup of the resolve launch clears its share as the last thing it does
   size_t gcnt_vecs;
 };
 constexpr unsigned int kRouteUnseeded = 6u;   // record of a retained call that found the header changed: nothing was computed
@@ -3587,10 +3587,15 @@ static int nms_validate(const char *who, const float *dets_dev, int64_t n, int k
 // Validates, lays out the workspace and enqueues every kernel of one call on `stream`; the
 // last kernel writes the NmsHostInfo record to `result` (device-visible memory: the pinned
 // buffer of the synchronous entry points, or the caller's device record of the async one).
+void nms_retain_forget(const void *ws);      // (below: the calling thread's notes of retained workspaces)
+
 int nms_enqueue_source(const char *who, NmsSource src, int64_t n, int kind, float iou_thr, int flags_in,
                        int64_t *keep_dev, void *result_v, void *workspace_dev,
                        size_t workspace_bytes, hipStream_t st, NmsEnqueued &q) {
   NmsHostInfo *result = static_cast<NmsHostInfo *>(result_v);
+  // any call outside the retained protocol (another entry point, a tiled phase, a plain or repeated call) may write where a
+  // retained workspace keeps its state: the thread's note of it ends here, whatever the entry point
+  if (src.retain == 0 && workspace_dev) nms_retain_forget(workspace_dev);
   const bool has_thr = src.mode == 2 ? src.thr_table != nullptr : src.thrs != nullptr;
   int rc = nms_validate(who, src.dets64 ? reinterpret_cast<const float *>(src.dets64) : src.dets, n, kind, iou_thr, has_thr, flags_in, keep_dev, workspace_dev);
   if (rc != OBB_OK) return rc;
