@@ -123,8 +123,13 @@ std::tuple<at::Tensor, int64_t, std::vector<int64_t>> nms_ex(const at::Tensor &d
   const size_t bytes = obb_nms_workspace_bytes(n, (int)kind, capacity);
   TORCH_CHECK(bytes > 0, "obb_nms_workspace_bytes: ", obb_last_error());
   void *stream = current_stream(dets);
-  at::Tensor &ws = nms_workspace(dets, stream, bytes);
-  const int rc = obb_nms_ex_f32(dets.data_ptr<float>(), n, (int)kind, (float)thr, gp, tp, (int)flags | OBB_NMS_RETAIN, keep.data_ptr<int64_t>(),
+  // (the kept workspace where OBB_NMS_RETAIN applies -- below 2^18 boxes, <= ~400 MB; a larger call's workspace, gigabytes of
+  //  table, goes back to the caching allocator with the call as before)
+  const bool retain = n < (1 << 18);
+  at::Tensor once;
+  if (!retain) once = at::empty({(int64_t)bytes}, dets.options().dtype(at::kByte));
+  at::Tensor &ws = retain ? nms_workspace(dets, stream, bytes) : once;
+  const int rc = obb_nms_ex_f32(dets.data_ptr<float>(), n, (int)kind, (float)thr, gp, tp, (int)flags | (retain ? OBB_NMS_RETAIN : 0), keep.data_ptr<int64_t>(),
                                 info.data(), ws.data_ptr(), (size_t)ws.numel(), stream);
   if (rc != OBB_OK && rc != OBB_EWORKSPACE) check_rc(rc, "obb_nms_ex_f32");
   return std::make_tuple(keep.narrow(0, 0, rc == OBB_OK ? info[0] : 0), (int64_t)rc, info);
