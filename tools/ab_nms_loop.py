@@ -8,6 +8,10 @@ import workloads
 from aidet_amd import _lib
 from aidet_amd.nms_wrapper import _run_nms
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
+if len(sys.argv) > 2:      # knob=value pairs, e.g. 22=0 (OBB_TUNE_NMS_PROBE_PAIR off)
+    for kv in sys.argv[2:]:
+        k, v = kv.split('=')
+        _lib.set_tuning(int(k), int(v))
 dev = torch.device('cuda', 0)
 pool = [torch.from_numpy(workloads.boxes(n, 20000.0 * (n / 100000.0) ** 0.5, 3 + 10 * k)).to(dev) for k in range(4)]
 for i in range(20):
@@ -20,5 +24,5 @@ for rep in range(7):
         _run_nms(pool[i & 3], _lib.KIND_RBOX, 0.5)
     torch.cuda.synchronize()
     res.append((time.perf_counter() - t0) / 200 * 1e6)
-print('%-44s n %d: us per call (7 x 200 calls) %s  median %.2f  retained %d' % (os.path.basename(os.environ.get('OBBOPS_LIB', 'product')), n,
+print('%-30s %s n %d: us per call (7 x 200 calls) %s  median %.2f  retained %d' % (os.path.basename(os.environ.get('OBBOPS_LIB', 'product')), ' '.join(sys.argv[2:]), n,
       ' '.join('%.1f' % x for x in res), float(np.median(res)), _lib.lib().obb_nms_last_retained()))
