@@ -324,6 +324,8 @@ def bench_all(args):
             # the headline workload without the Python wrapper: one obb_nms_f32 call through the bare C ABI
             out['config']['nms_c_abi_us_per_call'] = out['also']['rnms_100k_c_abi_retained']['us_per_call']
             out['config']['nms_c_abi_stateless_us_per_call'] = out['also']['rnms_100k_c_abi']['us_per_call']
+            if 'rnms_100k_4_threads_4_streams' in out['also']:      # four host threads, a stream and a workspace each: a throughput, not `value`
+                out['config']['nms_4_threads_boxes_per_s'] = out['also']['rnms_100k_4_threads_4_streams']['boxes_per_s']
         if not args.no_cpu:
             out['cpu_baseline'] = cpu_baseline(boxes, keep)
     if rank == 0:
@@ -898,6 +900,50 @@ def extras(dev, args):
     res['rnms_100k_c_abi_retained'] = {'us_per_call': round(us, 1), 'boxes_per_s': round(nn / us * 1e6, 1), 'kept': int(infob[0]),
                                        'last_retained': int(L.obb_nms_last_retained()),
                                        'stat': 'median of 52 calls of obb_nms_ex_f32 with OBB_NMS_RETAIN, four scenes in turn'}
+    # ... and FOUR host threads at once, each with a stream, a keep list and a retained workspace of its own (the library's
+    # state is per thread and per workspace; ctypes releases the GIL for the call): what the chip does when it is handed
+    # more than one latency-bound call at a time -- a throughput beside the headline's per-call time, not part of `value`
+    import threading
+    nthreads, per_thread = 4, 60
+    bar = threading.Barrier(nthreads + 1)
+    errs = []
+
+    def worker(t):
+        try:
+            torch.cuda.set_device(dev)
+            with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+                k2 = torch.empty(nn, dtype=torch.int64, device=dev)
+                w2 = torch.empty(wsb.numel(), dtype=torch.uint8, device=dev)
+                i2 = (ctypes.c_int64 * 4)()
+                s2 = _lib.current_stream_handle(dev)
+                for i in range(6):
+                    L.obb_nms_ex_f32(poolb[(i + t) & 3].data_ptr(), nn, 0, 0.5, None, None, _lib.NMS_RETAIN, k2.data_ptr(), i2, w2.data_ptr(), w2.numel(), s2)
+                torch.cuda.synchronize()
+                bar.wait()
+                for i in range(per_thread):
+                    if L.obb_nms_ex_f32(poolb[(i + t) & 3].data_ptr(), nn, 0, 0.5, None, None, _lib.NMS_RETAIN, k2.data_ptr(), i2, w2.data_ptr(),
+                                        w2.numel(), s2) != 0:
+                        errs.append(t)
+                bar.wait()
+        except Exception as e:
+            errs.append(repr(e))
+            bar.abort()
+
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(nthreads)]
+    for th in ths:
+        th.start()
+    try:
+        bar.wait()
+        t0 = time.perf_counter()
+        bar.wait()
+        dt = time.perf_counter() - t0
+    except threading.BrokenBarrierError:
+        dt = None
+    for th in ths:
+        th.join()
+    if dt and not errs:
+        res['rnms_100k_4_threads_4_streams'] = {'boxes_per_s': round(nthreads * per_thread * nn / dt, 1), 'us_per_call_per_thread': round(dt / per_thread * 1e6, 1),
+                                                'stat': '%d threads x %d synchronous calls of obb_nms_ex_f32 (OBB_NMS_RETAIN), a stream and a workspace each' % (nthreads, per_thread)}
     # RRoIAlign configs[2]: value check against the oracle on ALL 512 RoIs, 1 thread and all cores
     feat, rois = make_rroi(dev)
     layer = RRoIAlign(7, 0.25, sample_num=2)

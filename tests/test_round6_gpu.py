@@ -332,3 +332,42 @@ def test_release_workspaces_starts_over():
     assert int(L.obb_nms_last_retained()) == 1
     assert np.array_equal(rnms(dt, 0.5)[1].cpu().numpy(), ref)
     assert int(L.obb_nms_last_retained()) == 2
+
+
+def test_four_threads_four_streams_at_once():
+    """the library keeps its state per thread and per workspace: four threads, each with a stream and a workspace of its own,
+    run retained calls AT THE SAME TIME (ctypes releases the GIL for the call) -- every list is the oracle's"""
+    n = 18000
+    scenes = [oracle.synth_boxes(n, 6500, 300 + k) for k in range(8)]
+    refs = [oracle.rnms(d, 0.5) for d in scenes]
+    errors, modes = [], {}
+    start = threading.Barrier(4)
+
+    def worker(t):
+        try:
+            torch.cuda.set_device(0)
+            st = torch.cuda.Stream(device=dev())
+            with torch.cuda.stream(st):
+                call = Caller(n)
+                ds = [torch.from_numpy(d).to(dev()) for d in scenes]
+                torch.cuda.synchronize()
+                start.wait()
+                seen = []
+                for rep in range(40):
+                    k = (rep * 3 + t) % 8
+                    got, mode, _route = call(ds[k], 0.5)
+                    seen.append(mode)
+                    if not np.array_equal(got, refs[k]):
+                        errors.append((t, rep, k, mode))
+                modes[t] = seen
+        except Exception as e:      # (an assertion in a thread would vanish)
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors[:5]
+    for t in range(4):
+        assert modes[t][0] == 1 and all(m == 2 for m in modes[t][1:]), (t, modes[t])
